@@ -1,0 +1,240 @@
+/*
+ * ptcore.h -- C-ABI of libptcore.so, the MI355X (gfx950) engine behind Pointcept's
+ * SparseUNet voxel-convolution and PTv3 serialized-attention hot paths.
+ *
+ * Boundary contract (level B4):
+ *   - extern "C", plain pointers + sizes, no torch / C++ types.
+ *   - OWNERSHIP: the caller allocates every input, output and workspace buffer (device
+ *     memory unless a parameter is documented as HOST) and passes raw pointers.  The
+ *     library never allocates or frees device memory and keeps no mutable global state.
+ *   - ERRORS: every entry point returns PTC_OK (0) or a negative PTC_E* code; it never
+ *     throws across the ABI and never calls exit().  ptc_last_error() returns a
+ *     thread-local message for the last failing call on this thread.
+ *   - STREAMS: all work is enqueued on the hipStream_t passed as `stream` (the Python
+ *     host passes torch.cuda.current_stream().cuda_stream).  No implicit synchronisation,
+ *     no use of the legacy default stream (contrast the reference's in-repo ops:
+ *     libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:111 launches on stream 0).
+ *   - DTYPES: feature tensors carry a ptc_dtype tag; accumulation is always fp32.
+ *     Index tensors are int64 where the reference's Python API exposes int64
+ *     (serialized_order / inverse / pad / unpad / cluster), int32 for rulebook tables.
+ *
+ * Each entry point cites the reference interface it replaces (file:line under
+ * /root/reference).  Third-party operators that the reference calls but does not vendor
+ * (spconv, flash_attn, torch_scatter) are cited by their call sites.
+ */
+#ifndef PTCORE_H
+#define PTCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ptc_stream_t; /* hipStream_t */
+
+enum ptc_status {
+  PTC_OK = 0,
+  PTC_EINVAL = -1,       /* bad argument (null pointer, negative size, bad enum) */
+  PTC_EUNSUPPORTED = -2, /* shape / dtype combination not implemented */
+  PTC_EHIP = -3,         /* a HIP runtime call failed (see ptc_last_error) */
+  PTC_EWORKSPACE = -4    /* workspace too small */
+};
+
+enum ptc_dtype { PTC_F32 = 0, PTC_F16 = 1, PTC_BF16 = 2 };
+
+/* serialization orders, pointcept/models/utils/serialization/default.py:8-24 */
+enum ptc_order { PTC_ORDER_Z = 0, PTC_ORDER_Z_TRANS = 1, PTC_ORDER_HILBERT = 2, PTC_ORDER_HILBERT_TRANS = 3 };
+
+/* segment reductions, torch_scatter.segment_csr as called at
+ * pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:416-421 */
+enum ptc_reduce { PTC_REDUCE_SUM = 0, PTC_REDUCE_MEAN = 1, PTC_REDUCE_MAX = 2, PTC_REDUCE_MIN = 3 };
+
+const char* ptc_version(void);
+const char* ptc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * A. Serialization keys.
+ * Replaces serialization.encode() for all requested orders in ONE pass:
+ *   pointcept/models/utils/serialization/default.py:8-24 (dispatch, x/y swap, batch prefix)
+ *   pointcept/models/utils/serialization/z_order.py:66-101 (Morton LUT interleave)
+ *   pointcept/models/utils/serialization/hilbert.py:91-192 (Skilling transform + Gray decode)
+ * as called from Point.serialization, pointcept/models/utils/structure.py:89-92.
+ *   grid_coord : [n,3] int64 (coord_is_i64=1) or int32 (0), non-negative, < 2^depth
+ *   batch      : [n] int64 or NULL (no batch prefix)
+ *   orders     : HOST array of k ptc_order values
+ *   code_out   : [k,n] int64,  code = batch << 3*depth | key
+ * depth in [1,16]  (structure.py:82 asserts depth <= 16).
+ * ------------------------------------------------------------------------------------------ */
+int ptc_serialize_encode(const void* grid_coord, int coord_is_i64, const int64_t* batch, int64_t n,
+                         int depth, const int* orders, int k, int64_t* code_out, ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * B. Key sort -> order / inverse.
+ * Replaces torch.argsort(code) + the inverse-permutation scatter of
+ *   pointcept/models/utils/structure.py:93-100 and
+ *   pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:399-406.
+ * Stable LSD radix sort (8-bit digits) of k independent rows of n int64 keys, restricted
+ * to bits [begin_bit, end_bit).  Canonical tie order = ascending original index
+ * (SURVEY Appendix A.3).  inverse may be NULL.  keys are not modified.
+ *   order   : [k,n] int64, keys[r][order[r][i]] ascending in i
+ *   inverse : [k,n] int64, inverse[r][order[r][i]] = i
+ * ------------------------------------------------------------------------------------------ */
+size_t ptc_sort_keys_workspace_bytes(int64_t n, int k);
+int ptc_sort_keys(const int64_t* keys, int64_t n, int k, int begin_bit, int end_bit, int64_t* order,
+                  int64_t* inverse, void* workspace, size_t workspace_bytes, ptc_stream_t stream);
+
+/* Exclusive prefix sum of n int32 values into int64 (building block, exported for tests). */
+size_t ptc_exclusive_scan_workspace_bytes(int64_t n);
+int ptc_exclusive_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace,
+                           size_t workspace_bytes, ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * C. Patch padding maps.
+ * Replaces SerializedAttention.get_padding_and_inverse,
+ *   pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:114-170
+ * (python loop with host syncs) by one launch.
+ *   offset      : [B] int64 device, cumulative scene sizes
+ *   patch       : K
+ *   n_pad       : total padded length N' (host computes it from a host copy of offset)
+ *   n           : offset[B-1]
+ *   n_seq       : number of sequences (host computed)
+ *   pad         : [n_pad] int64   padded slot -> sorted rank
+ *   unpad       : [n]     int64   sorted rank -> padded slot
+ *   cu_seqlens  : [n_seq+1] int32 sequence starts + n_pad
+ *   dup         : [n] int64 or NULL: second padded slot holding sorted rank r, or -1
+ *                 (engine-side extra: makes the backward of the padded gather a pure gather)
+ * ------------------------------------------------------------------------------------------ */
+int ptc_patch_pad_maps(const int64_t* offset, int B, int patch, int64_t n, int64_t n_pad,
+                       int64_t n_seq, int64_t* pad, int64_t* unpad, int32_t* cu_seqlens,
+                       int64_t* dup, ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * D. Serialized pooling maps.
+ * Replaces the index arithmetic of SerializedPooling.forward,
+ *   pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:383-396
+ * (torch.unique(sorted, inverse, counts) + torch.sort(cluster) + cumsum) using the already
+ * sorted row 0 of the parent codes.
+ *   code0   : [n] int64  parent serialized_code[0]
+ *   order0  : [n] int64  parent serialized_order[0]
+ *   shift   : 3 * pooling_depth
+ * Phase 1 (ptc_pool_maps_count): writes cluster[n] (= pooling_inverse, ascending
+ * code0>>shift numbering) and *n_cluster_out (device int64).  Host reads n_cluster.
+ * Phase 2 (ptc_pool_maps_fill): idx_ptr[n_cluster+1] int64, head[n_cluster] int64.
+ * `indices` of the reference (points sorted by cluster) IS order0 (same cluster order;
+ * member order inside a cluster is immaterial for max/mean/sum/min).
+ * ------------------------------------------------------------------------------------------ */
+size_t ptc_pool_maps_workspace_bytes(int64_t n);
+int ptc_pool_maps_count(const int64_t* code0, const int64_t* order0, int64_t n, int shift,
+                        int64_t* cluster, int64_t* n_cluster_out, void* workspace,
+                        size_t workspace_bytes, ptc_stream_t stream);
+int ptc_pool_maps_fill(const int64_t* order0, const int64_t* cluster, int64_t n, int64_t n_cluster,
+                       int64_t* idx_ptr, int64_t* head, ptc_stream_t stream);
+/* code_out[r][c] = code_in[r][head[c]] >> shift, r < k   (ptv3m1:383,398) */
+int ptc_pool_child_codes(const int64_t* code_in, int64_t n, int k, const int64_t* head,
+                         int64_t n_cluster, int shift, int64_t* code_out, ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * E. Row gathers / segmented reductions (feature traffic around the attention and pooling).
+ *   ptc_gather_rows      : out[i,:] = src[idx[i],:] (+ src[idx2[i],:] if idx2 && idx2[i]>=0);
+ *                          idx[i] < 0 writes zeros.  Replaces feat[order] / feat[inverse] /
+ *                          feat[pooling_inverse] (ptv3m1:188,216,478) and their backward.
+ *   ptc_segment_csr_fwd  : out[s,:] = reduce_{r in [indptr[s],indptr[s+1])} src[perm ? perm[r] : r,:]
+ *                          arg_out (int32 [n_seg,c], may be NULL; only for MAX/MIN) = winning SOURCE
+ *                          row (first arg-max in segment order); -1 for an empty segment.
+ *                          Replaces torch_scatter.segment_csr(src[indices], idx_ptr, reduce)
+ *                          (ptv3m1:416-421) with the gather fused.
+ *   ptc_segment_csr_bwd  : grad_src[perm[r],:] from grad_out (SUM/MEAN: broadcast (/count);
+ *                          MAX/MIN: grad on the arg row, zero on the other member rows).  Every
+ *                          member row of every segment is written; rows outside all segments are
+ *                          left untouched (caller zero-fills if perm is not a full cover).
+ * ------------------------------------------------------------------------------------------ */
+int ptc_gather_rows(const void* src, int64_t n_src, const int64_t* idx, const int64_t* idx2,
+                    int64_t n_out, int c, int dtype, void* out, ptc_stream_t stream);
+int ptc_segment_csr_fwd(const void* src, const int64_t* perm, const int64_t* indptr, int64_t n_seg,
+                        int c, int dtype, int reduce, void* out, int32_t* arg_out,
+                        ptc_stream_t stream);
+int ptc_segment_csr_bwd(const void* grad_out, const int64_t* perm, const int64_t* indptr,
+                        const int32_t* arg, int64_t n_seg, int64_t n_src, int c, int dtype,
+                        int reduce, void* grad_src, ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * F. Rulebook (kernel maps) for sparse convolution.  Replaces what spconv builds inside
+ * SubMConv3d / SparseConv3d / SparseInverseConv3d on the first use of an indice_key
+ * (call sites: ptv3m1:278-284,499-506; spconv_unet_v1m1_base.py:43-68,114-121,137-144,173-179).
+ * Canonical form: gather tables nbr[kv][n_out] int32, -1 = no input.
+ *   indices : [n,4] int32 (batch,x,y,z)  (SparseConvTensor.indices, structure.py:139-143)
+ * Hash table: open addressing, 64-bit packed key, value = LOWEST row index with that
+ * coordinate (duplicate voxels after Mix3D: lowest index wins).
+ *   table_size must be a power of two >= 2*n.  keys buffer: table_size*8 B, vals: table_size*4 B.
+ * ------------------------------------------------------------------------------------------ */
+int64_t ptc_hash_table_size(int64_t n);
+int ptc_hash_build(const int32_t* indices, int64_t n, uint64_t* table_keys, int32_t* table_vals,
+                   int64_t table_size, ptc_stream_t stream);
+/* SubM: nbr[k][i] = row at coord_i + delta_k, k = ((d0+r)*ks + (d1+r))*ks + (d2+r), r = ks/2,
+ * (d0,d1,d2) applied to (x,y,z) = indices columns 1..3 (cross-correlation convention). */
+int ptc_rulebook_subm(const int32_t* indices, int64_t n, int ksize, const uint64_t* table_keys,
+                      const int32_t* table_vals, int64_t table_size, int32_t* nbr,
+                      ptc_stream_t stream);
+/* Strided k=2,s=2 (SparseConv3d at spconv_unet_v1m1_base.py:137-144).
+ * Phase 1: out_of_in[n_in] int32 = coarse row of each fine row, numbering = ascending
+ *          (batch, x>>1, y>>1, z>>1) linear key; *n_out_dev (device int64) = number of coarse rows.
+ *          coord_bits: every (coord>>1) < 2^coord_bits; batch_bits: every batch < 2^batch_bits
+ *          (host derives both from spatial_shape / batch_size; they only bound the sort passes).
+ * Phase 2: out_indices[n_out,4] int32, nbr_down[8][n_out] int32 (gather table of the down conv,
+ *          k = (x&1)*4 + (y&1)*2 + (z&1)), nbr_up[8][n_in] int32 (gather table of the inverse conv). */
+size_t ptc_rulebook_down_workspace_bytes(int64_t n_in);
+int ptc_rulebook_down_count(const int32_t* indices, int64_t n_in, int coord_bits, int batch_bits,
+                            int32_t* out_of_in, int64_t* n_out_dev, void* workspace,
+                            size_t workspace_bytes, ptc_stream_t stream);
+int ptc_rulebook_down_fill(const int32_t* indices, int64_t n_in, const int32_t* out_of_in,
+                           int64_t n_out, int32_t* out_indices, int32_t* nbr_down, int32_t* nbr_up,
+                           ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * G. Sparse convolution compute: out[o,:] = bias + sum_k W_k . in[nbr[k][o],:]
+ * One implicit-GEMM kernel (MFMA, gathered operand, W_k slices staged through LDS) serves
+ * forward, dgrad and the inverse convolution -- they differ only in the table and in how the
+ * host lays out the (tiny) weight tensor:
+ *   weight : [c_out][kv][c_in] row-major = the spconv-2.x parameter layout
+ *            [C_out,k0,k1,k2,C_in] flattened.
+ *   forward : table nbr, weight as stored.
+ *   dgrad   : SubM: the SAME table with weight' = W.permute(ci,k,co).flip(k) (mirror, A.6);
+ *             down conv: table nbr_up, weight' = W.permute(ci,k,co); inverse conv: nbr_down.
+ *   bias    : fp32 [c_out] or NULL.   in/out: [n, c] of `dtype`.
+ *   c_in % 8 == 0 and c_out % 16 == 0 (the host zero-pads the 6-channel stem input).
+ *   PTC_F32 uses the exact-f32 MFMA (16x16x4), PTC_F16/PTC_BF16 the 16x16x32 MFMA; fp32 accumulate.
+ * wgrad: dw[c_out][kv][c_in] (fp32) = sum_o dout[o,:]^T (x) in[nbr[k][o],:]
+ * ------------------------------------------------------------------------------------------ */
+int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float* bias,
+                   const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out, int dtype,
+                   void* out, ptc_stream_t stream);
+size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out);
+int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32_t* nbr,
+                     int64_t n_out, int kv, int c_in, int c_out, int dtype, float* dw,
+                     void* workspace, size_t workspace_bytes, ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * H. Serialized (variable-length, fixed-window) attention, head_dim 16.
+ * Replaces flash_attn.flash_attn_varlen_qkvpacked_func as called at ptv3m1:208-214:
+ *   qkv        : [total, 3, H, 16] bf16 (or f16), packed
+ *   cu_seqlens : [n_seq+1] int32
+ *   out        : [total, H, 16] same dtype ; lse : [H, total] fp32 (natural-log sum-exp)
+ * non-causal, no dropout, softmax_scale given.  max_seqlen <= 1024.
+ * Backward recomputes P from (q,k,lse):  dqkv [total,3,H,16].
+ * ------------------------------------------------------------------------------------------ */
+int ptc_attn_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, int64_t n_seq, int64_t total,
+                        int H, int max_seqlen, float softmax_scale, int dtype, void* out,
+                        float* lse, ptc_stream_t stream);
+/* workspace of the backward: delta[H,total] fp32 */
+size_t ptc_attn_varlen_bwd_workspace_bytes(int64_t total, int H);
+int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                        const int32_t* cu_seqlens, int64_t n_seq, int64_t total, int H,
+                        int max_seqlen, float softmax_scale, int dtype, void* dqkv,
+                        void* workspace, size_t workspace_bytes, ptc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTCORE_H */

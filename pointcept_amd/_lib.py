@@ -1,0 +1,145 @@
+"""ctypes binding of libptcore.so (the C-ABI declared in include/ptcore.h).
+
+`import torch` happens BEFORE the library is loaded so that libptcore.so's DT_NEEDED
+libamdhip64.so.7 resolves to the HIP runtime bundled with PyTorch-ROCm (one runtime, shared device
+pointers and streams).  There is no CPU fallback: `lib()` raises if the library cannot be loaded,
+and every op wrapper in this package raises on non-CUDA tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: provides the HIP runtime)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libptcore.so")
+PROBE_PATH = os.path.join(HERE, "libptcore_hostprobe.so")
+
+c_i64, c_int, c_f32, c_size, c_ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/ptcore.h one to one
+_SIGNATURES = {
+    "ptc_version": (ctypes.c_char_p, []),
+    "ptc_last_error": (ctypes.c_char_p, []),
+    "ptc_serialize_encode": (c_int, [c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr]),
+    "ptc_sort_keys_workspace_bytes": (c_size, [c_i64, c_int]),
+    "ptc_sort_keys": (c_int, [c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "ptc_exclusive_scan_workspace_bytes": (c_size, [c_i64]),
+    "ptc_exclusive_scan_i32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
+    "ptc_patch_pad_maps": (c_int, [c_ptr, c_int, c_int, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "ptc_pool_maps_workspace_bytes": (c_size, [c_i64]),
+    "ptc_pool_maps_count": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "ptc_pool_maps_fill": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    "ptc_pool_child_codes": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    "ptc_gather_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    "ptc_segment_csr_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "ptc_segment_csr_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "ptc_hash_table_size": (c_i64, [c_i64]),
+    "ptc_hash_build": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr]),
+    "ptc_rulebook_subm": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    "ptc_rulebook_down_workspace_bytes": (c_size, [c_i64]),
+    "ptc_rulebook_down_count": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "ptc_rulebook_down_fill": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "ptc_spconv_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "ptc_spconv_wgrad_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
+    "ptc_spconv_wgrad": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_size, c_ptr]),
+    "ptc_attn_varlen_fwd": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_f32, c_int, c_ptr, c_ptr, c_ptr]),
+    "ptc_attn_varlen_bwd_workspace_bytes": (c_size, [c_i64, c_int]),
+    "ptc_attn_varlen_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_f32, c_int, c_ptr,
+                                    c_ptr, c_size, c_ptr]),
+}
+
+PTC_F32, PTC_F16, PTC_BF16 = 0, 1, 2
+REDUCE_CODES = {"sum": 0, "mean": 1, "max": 2, "min": 3}
+ORDER_CODES = {"z": 0, "z-trans": 1, "hilbert": 2, "hilbert-trans": 3}
+
+_lib = None
+
+
+class PtcoreError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libptcore.so (building it first when hipcc is available and the .so is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+
+        _build.build()
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # fail loudly: no fallback path exists
+        raise PtcoreError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ptc_last_error().decode("utf-8", "replace")
+        raise PtcoreError(f"{what} failed with code {rc}: {msg}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return PTC_F32
+    if t.dtype == torch.float16:
+        return PTC_F16
+    if t.dtype == torch.bfloat16:
+        return PTC_BF16
+    raise PtcoreError(f"unsupported feature dtype {t.dtype}")
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PtcoreError(
+                "pointcept_amd ops run only on the GPU through libptcore.so (no CPU fallback); "
+                f"got a tensor on {t.device}")
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+_probe = None
+
+
+def host_probe():
+    """g++-built copy of the kernels' pure helper functions (CPU unit checks of product code)."""
+    global _probe
+    if _probe is None:
+        if not os.path.exists(PROBE_PATH):
+            from . import build as _build
+
+            _build.build_host_probe()
+        _probe = ctypes.CDLL(PROBE_PATH)
+        _probe.probe_serialize_encode.argtypes = [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr]
+        _probe.probe_serialize_encode.restype = None
+        _probe.probe_patch_pad_maps.argtypes = [c_ptr, c_int, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]
+        _probe.probe_patch_pad_maps.restype = None
+        _probe.probe_padded_len.argtypes = [c_i64, c_i64]
+        _probe.probe_padded_len.restype = c_i64
+        _probe.probe_num_seq.argtypes = [c_i64, c_i64]
+        _probe.probe_num_seq.restype = c_i64
+        _probe.probe_vox_pack.argtypes = [c_int, c_int, c_int, c_int]
+        _probe.probe_vox_pack.restype = ctypes.c_uint64
+        _probe.probe_vox_hash.argtypes = [ctypes.c_uint64]
+        _probe.probe_vox_hash.restype = ctypes.c_uint64
+    return _probe

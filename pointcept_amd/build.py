@@ -1,0 +1,118 @@
+"""Build libptcore.so (HIP, gfx950) and libptcore_hostprobe.so (g++, CPU probes of the pure
+host/device helper functions) IN-TREE next to this file.
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting .so files travel to the GPU box with
+the repo snapshot.  Each .hip file is compiled to an object (parallel, cached by mtime), then
+linked into one shared library whose only HIP dependency is libamdhip64.so.7 -- the SONAME of the
+runtime bundled with PyTorch-ROCm, so that `import torch` followed by ctypes.CDLL shares ONE HIP
+runtime (device pointers and streams are interchangeable).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(HERE, "csrc", "build")
+LIB = os.path.join(HERE, "libptcore.so")
+PROBE_LIB = os.path.join(HERE, "libptcore_hostprobe.so")
+
+HIP_SOURCES = [
+    "serialize.hip",
+    "scan_sort.hip",
+    "maps.hip",
+    "rows.hip",
+    "rulebook.hip",
+    "spconv.hip",
+    "attention.hip",
+]
+CXX_SOURCES = ["core.cpp"]
+PROBE_SOURCES = ["host_probe.cpp"]
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+HIP_FLAGS = [
+    "-O3",
+    "-std=c++17",
+    f"--offload-arch={ARCH}",
+    "-mcode-object-version=5",
+    "-fPIC",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def _newer(src: str, dst: str, extra: list[str]) -> bool:
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in [src] + extra if os.path.exists(p))
+
+
+def _headers() -> list[str]:
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "include", "ptcore.h"))
+    return hs
+
+
+def _run(cmd: list[str]) -> None:
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError(f"build step failed: {cmd[0]} {cmd[-1]}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 and link libptcore.so.  Returns the library path."""
+    if not os.path.exists(HIPCC):
+        if os.path.exists(LIB):
+            return LIB  # GPU box without a compiler: use the prebuilt in-tree library
+        raise RuntimeError(f"hipcc not found at {HIPCC} and no prebuilt {LIB}")
+    os.makedirs(BUILD, exist_ok=True)
+    hdrs = _headers()
+    jobs = []
+    objs = []
+    for src in HIP_SOURCES + CXX_SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            raise RuntimeError(f"missing source {sp}")
+        op = os.path.join(BUILD, src + ".o")
+        objs.append(op)
+        if force or _newer(sp, op, hdrs):
+            if src.endswith(".hip"):
+                cmd = [HIPCC] + HIP_FLAGS + ["-c", sp, "-o", op]
+            else:
+                cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-x", "c++", "-c", sp, "-o", op]
+            jobs.append(cmd)
+    if jobs:
+        if verbose:
+            print(f"[ptcore.build] compiling {len(jobs)} file(s) for {ARCH}")
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if force or jobs or not os.path.exists(LIB):
+        _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
+    return LIB
+
+
+def build_host_probe(force: bool = False) -> str:
+    """g++ build of the pure helper functions shared with the kernels (CPU unit checks)."""
+    gxx = shutil.which("g++")
+    if gxx is None:
+        if os.path.exists(PROBE_LIB):
+            return PROBE_LIB
+        raise RuntimeError("g++ not found")
+    srcs = [os.path.join(CSRC, s) for s in PROBE_SOURCES]
+    if force or any(_newer(s, PROBE_LIB, _headers()) for s in srcs):
+        _run([gxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-o", PROBE_LIB] + srcs)
+    return PROBE_LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host_probe(force="--force" in sys.argv))

@@ -1,0 +1,16 @@
+// core.cpp -- version string and thread-local error message of libptcore.so.
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/ptcore.h"
+
+static thread_local char g_err[512] = "";
+
+void ptc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* ptc_last_error(void) { return g_err; }
+extern "C" const char* ptc_version(void) { return "ptcore 0.1 (gfx950)"; }

@@ -1,0 +1,77 @@
+// ptc_common.h -- shared helpers for the gfx950 kernels of libptcore.so.
+// Wave = 64 lanes everywhere (CDNA4); no warp-32 idioms, no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/ptcore.h"
+
+#define PTC_WAVE 64
+
+// ---- error plumbing -------------------------------------------------------------------------
+void ptc_set_error(const char* fmt, ...);
+
+#define PTC_REQUIRE(cond, code, ...)      \
+  do {                                    \
+    if (!(cond)) {                        \
+      ptc_set_error(__VA_ARGS__);         \
+      return (code);                      \
+    }                                     \
+  } while (0)
+
+#define PTC_CHECK_LAUNCH(name)                                                        \
+  do {                                                                                \
+    hipError_t e__ = hipGetLastError();                                               \
+    if (e__ != hipSuccess) {                                                          \
+      ptc_set_error("%s: launch failed: %s", (name), hipGetErrorString(e__));         \
+      return PTC_EHIP;                                                                \
+    }                                                                                 \
+  } while (0)
+
+#define PTC_HIP(call)                                                                 \
+  do {                                                                                \
+    hipError_t e__ = (call);                                                          \
+    if (e__ != hipSuccess) {                                                          \
+      ptc_set_error("%s failed: %s", #call, hipGetErrorString(e__));                  \
+      return PTC_EHIP;                                                                \
+    }                                                                                 \
+  } while (0)
+
+static inline int64_t ptc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t ptc_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- storage types --------------------------------------------------------------------------
+// bf16 / f16 are carried as raw 16-bit patterns; arithmetic is always fp32.
+struct bf16_t { uint16_t x; };
+struct f16_t { _Float16 x; };
+
+__device__ __forceinline__ float ptc_to_float(float v) { return v; }
+__device__ __forceinline__ float ptc_to_float(bf16_t v) { return __uint_as_float(((uint32_t)v.x) << 16); }
+__device__ __forceinline__ float ptc_to_float(f16_t v) { return (float)v.x; }
+
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet), same rounding as torch's .to(bfloat16)
+__device__ __forceinline__ uint16_t ptc_f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+template <typename T> __device__ __forceinline__ T ptc_from_float(float v);
+template <> __device__ __forceinline__ float ptc_from_float<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t ptc_from_float<bf16_t>(float v) { bf16_t r; r.x = ptc_f32_to_bf16_bits(v); return r; }
+template <> __device__ __forceinline__ f16_t ptc_from_float<f16_t>(float v) { f16_t r; r.x = (_Float16)v; return r; }
+
+// dispatch a templated launcher on the ptc_dtype tag
+#define PTC_DISPATCH_DTYPE(dtype, T, ...)                 \
+  switch (dtype) {                                        \
+    case PTC_F32: { using T = float; __VA_ARGS__; } break; \
+    case PTC_F16: { using T = f16_t; __VA_ARGS__; } break; \
+    case PTC_BF16: { using T = bf16_t; __VA_ARGS__; } break; \
+    default: ptc_set_error("bad dtype %d", (int)(dtype)); return PTC_EINVAL; \
+  }
+
+static inline size_t ptc_dtype_size(int dtype) { return dtype == PTC_F32 ? 4 : 2; }
+
+// ---- wave helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ int ptc_lane() { return threadIdx.x & 63; }

@@ -1,0 +1,264 @@
+// rows.hip -- HBM-bound feature-row movers of the PTv3 path:
+//   * row gather (feat[order], feat[inverse], feat[pooling_inverse]; ptv3m1:188,216,478) with an
+//     optional second source row (gather-form backward of the padded gather: no atomics),
+//   * CSR segmented reduce with the gather fused (torch_scatter.segment_csr(src[indices], idx_ptr)
+//     at ptv3m1:416-421) and its backward.
+// Roofline: (rows_in + rows_out) * C * e bytes + 8 B index per row.
+// Every thread moves one 16-byte chunk (8 x 16-bit or 4 x fp32 channels); consecutive threads
+// cover consecutive chunks of a row, so reads inside a gathered row and all writes are coalesced.
+#include "ptc_common.h"
+
+template <typename T> struct Vec16;  // 16-byte chunk of T
+template <> struct Vec16<float> { static constexpr int N = 4; float v[4]; };
+template <> struct Vec16<bf16_t> { static constexpr int N = 8; bf16_t v[8]; };
+template <> struct Vec16<f16_t> { static constexpr int N = 8; f16_t v[8]; };
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> load16(const T* p) {
+  Vec16<T> r;
+  *reinterpret_cast<uint4*>(&r) = *reinterpret_cast<const uint4*>(p);
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store16(T* p, const Vec16<T>& r) {
+  *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(&r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather rows
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ idx, const int64_t* __restrict__ idx2,
+                   int64_t n_out, int c, T* __restrict__ out) {
+  constexpr int W = VEC ? Vec16<T>::N : 1;
+  const int cpr = c / W;  // chunks per row
+  const int64_t total = n_out * cpr;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t row = t / cpr;
+    const int ch = (int)(t - row * cpr) * W;
+    const int64_t s1 = idx[row];
+    const int64_t s2 = idx2 ? idx2[row] : -1;
+    if (VEC) {
+      Vec16<T> a;
+      if (s1 >= 0) a = load16(src + s1 * c + ch);
+      else { for (int j = 0; j < W; ++j) a.v[j] = ptc_from_float<T>(0.f); }
+      if (s2 >= 0) {
+        Vec16<T> b = load16(src + s2 * c + ch);
+#pragma unroll
+        for (int j = 0; j < W; ++j) a.v[j] = ptc_from_float<T>(ptc_to_float(a.v[j]) + ptc_to_float(b.v[j]));
+      }
+      store16(out + row * c + ch, a);
+    } else {
+      float a = s1 >= 0 ? ptc_to_float(src[s1 * c + ch]) : 0.f;
+      if (s2 >= 0) a += ptc_to_float(src[s2 * c + ch]);
+      out[row * c + ch] = ptc_from_float<T>(a);
+    }
+  }
+}
+
+template <typename T>
+static int launch_gather_rows(const void* src, const int64_t* idx, const int64_t* idx2, int64_t n_out, int c,
+                              void* out, hipStream_t s) {
+  const bool vec = (c % Vec16<T>::N) == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  const int W = vec ? Vec16<T>::N : 1;
+  const int64_t total = n_out * (c / W);
+  int64_t grid = ptc_cdiv(total, 256);
+  if (grid > 256 * 32) grid = 256 * 32;
+  if (vec)
+    hipLaunchKernelGGL((gather_rows_kernel<T, true>), dim3((unsigned)grid), dim3(256), 0, s, (const T*)src, idx, idx2, n_out, c, (T*)out);
+  else
+    hipLaunchKernelGGL((gather_rows_kernel<T, false>), dim3((unsigned)grid), dim3(256), 0, s, (const T*)src, idx, idx2, n_out, c, (T*)out);
+  PTC_CHECK_LAUNCH("gather_rows_kernel");
+  return PTC_OK;
+}
+
+extern "C" int ptc_gather_rows(const void* src, int64_t n_src, const int64_t* idx, const int64_t* idx2,
+                               int64_t n_out, int c, int dtype, void* out, ptc_stream_t stream) {
+  PTC_REQUIRE(n_src >= 0 && n_out >= 0 && c >= 1, PTC_EINVAL, "ptc_gather_rows: bad sizes");
+  if (n_out == 0) return PTC_OK;
+  PTC_REQUIRE(src && idx && out, PTC_EINVAL, "ptc_gather_rows: null buffer");
+  PTC_DISPATCH_DTYPE(dtype, T, return launch_gather_rows<T>(src, idx, idx2, n_out, c, out, (hipStream_t)stream));
+  return PTC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// segment_csr forward / backward
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool VEC, int REDUCE>
+__global__ void __launch_bounds__(256)
+segment_csr_fwd_kernel(const T* __restrict__ src, const int64_t* __restrict__ perm, const int64_t* __restrict__ indptr,
+                       int64_t n_seg, int c, T* __restrict__ out, int32_t* __restrict__ arg_out) {
+  constexpr int W = VEC ? Vec16<T>::N : 1;
+  const int cpr = c / W;
+  const int64_t total = n_seg * cpr;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t seg = t / cpr;
+    const int ch = (int)(t - seg * cpr) * W;
+    const int64_t r0 = indptr[seg], r1 = indptr[seg + 1];
+    float acc[W];
+    int32_t arg[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      acc[j] = (REDUCE == PTC_REDUCE_MAX) ? -INFINITY : (REDUCE == PTC_REDUCE_MIN ? INFINITY : 0.f);
+      arg[j] = -1;
+    }
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t p = perm ? perm[r] : r;
+      float v[W];
+      if (VEC) {
+        Vec16<T> a = load16(src + p * c + ch);
+#pragma unroll
+        for (int j = 0; j < W; ++j) v[j] = ptc_to_float(a.v[j]);
+      } else {
+        v[0] = ptc_to_float(src[p * c + ch]);
+      }
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        if (REDUCE == PTC_REDUCE_MAX) { if (v[j] > acc[j] || arg[j] < 0) { acc[j] = v[j]; arg[j] = (int32_t)p; } }
+        else if (REDUCE == PTC_REDUCE_MIN) { if (v[j] < acc[j] || arg[j] < 0) { acc[j] = v[j]; arg[j] = (int32_t)p; } }
+        else acc[j] += v[j];
+      }
+    }
+    const float cnt = (float)(r1 - r0);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if (REDUCE == PTC_REDUCE_MEAN) acc[j] = (r1 > r0) ? acc[j] / cnt : 0.f;
+      if ((REDUCE == PTC_REDUCE_MAX || REDUCE == PTC_REDUCE_MIN) && r1 <= r0) acc[j] = 0.f;  // empty segment -> 0
+    }
+    if (VEC) {
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < W; ++j) o.v[j] = ptc_from_float<T>(acc[j]);
+      store16(out + seg * c + ch, o);
+    } else {
+      out[seg * c + ch] = ptc_from_float<T>(acc[0]);
+    }
+    if (arg_out && (REDUCE == PTC_REDUCE_MAX || REDUCE == PTC_REDUCE_MIN)) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) arg_out[seg * c + ch + j] = arg[j];
+    }
+  }
+}
+
+template <typename T, int REDUCE>
+static int launch_segment_fwd(const void* src, const int64_t* perm, const int64_t* indptr, int64_t n_seg, int c,
+                              void* out, int32_t* arg_out, hipStream_t s) {
+  const bool vec = (c % Vec16<T>::N) == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  const int W = vec ? Vec16<T>::N : 1;
+  int64_t grid = ptc_cdiv(n_seg * (c / W), 256);
+  if (grid > 256 * 32) grid = 256 * 32;
+  if (vec)
+    hipLaunchKernelGGL((segment_csr_fwd_kernel<T, true, REDUCE>), dim3((unsigned)grid), dim3(256), 0, s, (const T*)src, perm, indptr, n_seg, c, (T*)out, arg_out);
+  else
+    hipLaunchKernelGGL((segment_csr_fwd_kernel<T, false, REDUCE>), dim3((unsigned)grid), dim3(256), 0, s, (const T*)src, perm, indptr, n_seg, c, (T*)out, arg_out);
+  PTC_CHECK_LAUNCH("segment_csr_fwd_kernel");
+  return PTC_OK;
+}
+
+extern "C" int ptc_segment_csr_fwd(const void* src, const int64_t* perm, const int64_t* indptr, int64_t n_seg,
+                                   int c, int dtype, int reduce, void* out, int32_t* arg_out, ptc_stream_t stream) {
+  PTC_REQUIRE(n_seg >= 0 && c >= 1, PTC_EINVAL, "ptc_segment_csr_fwd: bad sizes");
+  PTC_REQUIRE(reduce >= 0 && reduce <= 3, PTC_EINVAL, "ptc_segment_csr_fwd: bad reduce %d", reduce);
+  if (n_seg == 0) return PTC_OK;
+  PTC_REQUIRE(src && indptr && out, PTC_EINVAL, "ptc_segment_csr_fwd: null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  PTC_DISPATCH_DTYPE(dtype, T, {
+    switch (reduce) {
+      case PTC_REDUCE_SUM: return launch_segment_fwd<T, PTC_REDUCE_SUM>(src, perm, indptr, n_seg, c, out, arg_out, s);
+      case PTC_REDUCE_MEAN: return launch_segment_fwd<T, PTC_REDUCE_MEAN>(src, perm, indptr, n_seg, c, out, arg_out, s);
+      case PTC_REDUCE_MAX: return launch_segment_fwd<T, PTC_REDUCE_MAX>(src, perm, indptr, n_seg, c, out, arg_out, s);
+      default: return launch_segment_fwd<T, PTC_REDUCE_MIN>(src, perm, indptr, n_seg, c, out, arg_out, s);
+    }
+  });
+  return PTC_OK;
+}
+
+// backward: one thread per (segment, chunk) walks the segment's rows and writes EVERY member row
+// (value or zero), so no pre-zeroing and no atomics are needed when perm covers all source rows.
+template <typename T, bool VEC, int REDUCE>
+__global__ void __launch_bounds__(256)
+segment_csr_bwd_kernel(const T* __restrict__ gout, const int64_t* __restrict__ perm, const int64_t* __restrict__ indptr,
+                       const int32_t* __restrict__ arg, int64_t n_seg, int c, T* __restrict__ gsrc) {
+  constexpr int W = VEC ? Vec16<T>::N : 1;
+  const int cpr = c / W;
+  const int64_t total = n_seg * cpr;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t seg = t / cpr;
+    const int ch = (int)(t - seg * cpr) * W;
+    const int64_t r0 = indptr[seg], r1 = indptr[seg + 1];
+    float g[W];
+    int32_t a[W];
+    if (VEC) {
+      Vec16<T> gv = load16(gout + seg * c + ch);
+#pragma unroll
+      for (int j = 0; j < W; ++j) g[j] = ptc_to_float(gv.v[j]);
+    } else {
+      g[0] = ptc_to_float(gout[seg * c + ch]);
+    }
+    if (REDUCE == PTC_REDUCE_MEAN) {
+      const float inv = (r1 > r0) ? 1.f / (float)(r1 - r0) : 0.f;
+#pragma unroll
+      for (int j = 0; j < W; ++j) g[j] *= inv;
+    }
+    if (REDUCE == PTC_REDUCE_MAX || REDUCE == PTC_REDUCE_MIN) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) a[j] = arg[seg * c + ch + j];
+    }
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t p = perm ? perm[r] : r;
+      if (VEC) {
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          float v = g[j];
+          if (REDUCE == PTC_REDUCE_MAX || REDUCE == PTC_REDUCE_MIN) v = (a[j] == (int32_t)p) ? g[j] : 0.f;
+          o.v[j] = ptc_from_float<T>(v);
+        }
+        store16(gsrc + p * c + ch, o);
+      } else {
+        float v = g[0];
+        if (REDUCE == PTC_REDUCE_MAX || REDUCE == PTC_REDUCE_MIN) v = (a[0] == (int32_t)p) ? g[0] : 0.f;
+        gsrc[p * c + ch] = ptc_from_float<T>(v);
+      }
+    }
+  }
+}
+
+template <typename T, int REDUCE>
+static int launch_segment_bwd(const void* gout, const int64_t* perm, const int64_t* indptr, const int32_t* arg,
+                              int64_t n_seg, int c, void* gsrc, hipStream_t s) {
+  const bool vec = (c % Vec16<T>::N) == 0 && ((uintptr_t)gout % 16 == 0) && ((uintptr_t)gsrc % 16 == 0);
+  const int W = vec ? Vec16<T>::N : 1;
+  int64_t grid = ptc_cdiv(n_seg * (c / W), 256);
+  if (grid > 256 * 32) grid = 256 * 32;
+  if (vec)
+    hipLaunchKernelGGL((segment_csr_bwd_kernel<T, true, REDUCE>), dim3((unsigned)grid), dim3(256), 0, s, (const T*)gout, perm, indptr, arg, n_seg, c, (T*)gsrc);
+  else
+    hipLaunchKernelGGL((segment_csr_bwd_kernel<T, false, REDUCE>), dim3((unsigned)grid), dim3(256), 0, s, (const T*)gout, perm, indptr, arg, n_seg, c, (T*)gsrc);
+  PTC_CHECK_LAUNCH("segment_csr_bwd_kernel");
+  return PTC_OK;
+}
+
+extern "C" int ptc_segment_csr_bwd(const void* grad_out, const int64_t* perm, const int64_t* indptr,
+                                   const int32_t* arg, int64_t n_seg, int64_t n_src, int c, int dtype, int reduce,
+                                   void* grad_src, ptc_stream_t stream) {
+  PTC_REQUIRE(n_seg >= 0 && n_src >= 0 && c >= 1, PTC_EINVAL, "ptc_segment_csr_bwd: bad sizes");
+  PTC_REQUIRE(reduce >= 0 && reduce <= 3, PTC_EINVAL, "ptc_segment_csr_bwd: bad reduce %d", reduce);
+  if (n_seg == 0) return PTC_OK;
+  PTC_REQUIRE(grad_out && indptr && grad_src, PTC_EINVAL, "ptc_segment_csr_bwd: null buffer");
+  PTC_REQUIRE(!(reduce == PTC_REDUCE_MAX || reduce == PTC_REDUCE_MIN) || arg, PTC_EINVAL, "ptc_segment_csr_bwd: max/min needs arg");
+  hipStream_t s = (hipStream_t)stream;
+  PTC_DISPATCH_DTYPE(dtype, T, {
+    switch (reduce) {
+      case PTC_REDUCE_SUM: return launch_segment_bwd<T, PTC_REDUCE_SUM>(grad_out, perm, indptr, arg, n_seg, c, grad_src, s);
+      case PTC_REDUCE_MEAN: return launch_segment_bwd<T, PTC_REDUCE_MEAN>(grad_out, perm, indptr, arg, n_seg, c, grad_src, s);
+      case PTC_REDUCE_MAX: return launch_segment_bwd<T, PTC_REDUCE_MAX>(grad_out, perm, indptr, arg, n_seg, c, grad_src, s);
+      default: return launch_segment_bwd<T, PTC_REDUCE_MIN>(grad_out, perm, indptr, arg, n_seg, c, grad_src, s);
+    }
+  });
+  return PTC_OK;
+}

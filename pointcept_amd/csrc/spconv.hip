@@ -1,0 +1,352 @@
+// spconv.hip -- sparse convolution compute on MFMA: out[o,:] = bias + sum_k W_k . in[nbr[k][o],:]
+//
+// Replaces the feature path of spconv's SubMConv3d / SparseConv3d / SparseInverseConv3d (third
+// party, un-vendored; call sites ptv3m1:278-284,499-506 and spconv_unet_v1m1_base.py:43-68,
+// 114-121,137-144,173-179) with ONE output-stationary implicit-GEMM kernel over the gather table
+// built by rulebook.hip.  No atomics: every output row is produced by exactly one wave in a
+// fixed k order, so results are bit-reproducible run to run.
+//
+// gfx950 mapping
+//   * wave64 MFMA 16x16x32 (bf16/f16) or 16x16x4 (exact f32); roles are SWAPPED -- A = W_k tile
+//     (rows = output channels), B = gathered input rows -- so that a lane ends up holding 4
+//     CONSECUTIVE output channels of one output row (one 8/16-byte store instead of four 2-byte).
+//   * B fragments are gathered straight from HBM/L2 into registers: lane (row r, k-group g) loads
+//     16 contiguous bytes of input row nbr[k][r]; the 4 k-groups of a row cover 64 contiguous
+//     bytes.  The contraction index inside one MFMA may be permuted freely as long as A and B
+//     agree, which is what makes "16 contiguous bytes per lane" legal for both dtypes.
+//   * W_k slices ([NT x KC] elements, <= 34 KB) are staged through LDS once per (k, channel chunk)
+//     per 128-row workgroup; row pitch KC+16 B makes the ds_read_b128 fragment reads conflict-free.
+//   * a workgroup skips offset k entirely when none of its 128 rows has that neighbour.
+// Roofline: bytes = N_in*C_in*e + N_out*C_out*e + 4*kv*N_out (table) + kv*C_in*C_out*e,
+// flops = 2*P*C_in*C_out; HBM-bound for C <= 64, MFMA-bound above.
+#include "ptc_common.h"
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int KS = 32;   // channels per super-step
+  static constexpr int EPL = 8;   // elements per lane per super-step (16 bytes)
+  using frag = s16x8;
+  static __device__ __forceinline__ frag zero() { frag z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<f16_t> {
+  static constexpr int KS = 32;
+  static constexpr int EPL = 8;
+  using frag = h16x8;
+  static __device__ __forceinline__ frag zero() { frag z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KS = 16;
+  static constexpr int EPL = 4;
+  using frag = f32x4;
+  static __device__ __forceinline__ frag zero() { frag z = {0.f, 0.f, 0.f, 0.f}; return z; }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::frag ld_frag(const T* p) {
+  return *reinterpret_cast<const typename Mma<T>::frag*>(p);
+}
+
+#define SC_ROWS 128          // output rows per workgroup (4 waves x 2 sub-tiles x 16)
+#define SC_LDS_BYTES 34816   // NT<=128 rows x (KC + 16 B) : (128+8)*2*128 = (64+4)*4*128
+
+// ------------------------------------------------------------------------------------------------
+// forward / dgrad / inverse conv
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NTILES>
+__global__ void __launch_bounds__(256)
+spconv_fwd_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+                  const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, T* __restrict__ out) {
+  using M = Mma<T>;
+  constexpr int EPL = M::EPL, KS = M::KS;
+  constexpr int KC = 16 * EPL;          // channel chunk staged in LDS (128 for 16-bit, 64 for f32)
+  constexpr int PITCH = KC + EPL;       // +16 B pad: conflict-free ds_read_b128
+  constexpr int NT = NTILES * 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SC_LDS_BYTES];
+  T* wl = reinterpret_cast<T*>(smem);
+
+  const int lane = ptc_lane(), wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * SC_ROWS + wave * 32;
+  const int n0 = blockIdx.y * NT;
+  const int64_t rowA = row0 + r, rowB = row0 + 16 + r;
+
+  f32x4 acc[2][NTILES];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k = 0; k < kv; ++k) {
+    const int32_t ia = rowA < n_out ? nbr[(int64_t)k * n_out + rowA] : -1;
+    const int32_t ib = rowB < n_out ? nbr[(int64_t)k * n_out + rowB] : -1;
+    // barrier (protects the LDS tile of the previous k) + workgroup-wide "any neighbour at k"
+    if (!__syncthreads_or((ia >= 0) | (ib >= 0))) continue;
+    for (int c0 = 0; c0 < c_in; c0 += KC) {
+      const int kc = (c_in - c0) < KC ? (c_in - c0) : KC;
+      if (c0 > 0) __syncthreads();
+      // stage W[n0 .. n0+NT)[k][c0 .. c0+kc) -> LDS [NT][PITCH]
+      const int vpr = kc / EPL;  // 16-byte vectors per row
+      for (int q = threadIdx.x; q < NT * vpr; q += 256) {
+        const int n = q / vpr, cc = q - n * vpr;
+        *reinterpret_cast<uint4*>(wl + n * PITCH + cc * EPL) =
+            *reinterpret_cast<const uint4*>(w + ((int64_t)(n0 + n) * kv + k) * c_in + c0 + cc * EPL);
+      }
+      __syncthreads();
+      const int nks = (kc + KS - 1) / KS;
+      for (int ks = 0; ks < nks; ++ks) {
+        const int kk = ks * KS + g * EPL;
+        const bool kval = kk < kc;
+        typename M::frag fa = M::zero(), fb = M::zero();
+        if (kval && ia >= 0) fa = ld_frag<T>(in + (int64_t)ia * c_in + c0 + kk);
+        if (kval && ib >= 0) fb = ld_frag<T>(in + (int64_t)ib * c_in + c0 + kk);
+#pragma unroll
+        for (int t = 0; t < NTILES; ++t) {
+          typename M::frag fw = M::zero();
+          if (kval) fw = ld_frag<T>(wl + (t * 16 + r) * PITCH + kk);
+          acc[0][t] = M::mma(fw, fa, acc[0][t]);
+          acc[1][t] = M::mma(fw, fb, acc[1][t]);
+        }
+      }
+    }
+  }
+  // epilogue: lane (row r, group g) holds channels n0 + t*16 + g*4 + {0..3} of rows rowA / rowB
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int64_t row = s ? rowB : rowA;
+    if (row >= n_out) continue;
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) {
+      const int ch = n0 + t * 16 + g * 4;
+      f32x4 v = acc[s][t];
+      if (bias) { v[0] += bias[ch]; v[1] += bias[ch + 1]; v[2] += bias[ch + 2]; v[3] += bias[ch + 3]; }
+      T o4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = ptc_from_float<T>(v[e]);
+      if (sizeof(T) == 2) *reinterpret_cast<uint2*>(out + row * c_out + ch) = *reinterpret_cast<uint2*>(o4);
+      else *reinterpret_cast<uint4*>(out + row * c_out + ch) = *reinterpret_cast<uint4*>(o4);
+    }
+  }
+}
+
+template <typename T, int NTILES>
+static int launch_fwd(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
+                      int c_in, int c_out, void* out, hipStream_t s) {
+  dim3 grid((unsigned)ptc_cdiv(n_out, SC_ROWS), (unsigned)(c_out / (NTILES * 16)));
+  hipLaunchKernelGGL((spconv_fwd_kernel<T, NTILES>), grid, dim3(256), 0, s, (const T*)in, (const T*)w, bias, nbr, n_out,
+                     kv, c_in, c_out, (T*)out);
+  PTC_CHECK_LAUNCH("spconv_fwd_kernel");
+  return PTC_OK;
+}
+
+template <typename T>
+static int dispatch_fwd(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
+                        int c_in, int c_out, void* out, hipStream_t s) {
+  // output-channel tile = largest of {128, 96, 64, 48, 32, 16} dividing c_out
+  if (c_out % 128 == 0) return launch_fwd<T, 8>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  if (c_out % 96 == 0) return launch_fwd<T, 6>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  if (c_out % 64 == 0) return launch_fwd<T, 4>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  if (c_out % 48 == 0) return launch_fwd<T, 3>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  if (c_out % 32 == 0) return launch_fwd<T, 2>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  return launch_fwd<T, 1>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+}
+
+extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr,
+                              int64_t n_out, int kv, int c_in, int c_out, int dtype, void* out, ptc_stream_t stream) {
+  PTC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1, PTC_EINVAL, "ptc_spconv_fwd: bad sizes");
+  PTC_REQUIRE(c_in >= 8 && c_in % 8 == 0, PTC_EUNSUPPORTED, "ptc_spconv_fwd: c_in=%d must be a multiple of 8", c_in);
+  PTC_REQUIRE(c_out >= 16 && c_out % 16 == 0, PTC_EUNSUPPORTED, "ptc_spconv_fwd: c_out=%d must be a multiple of 16", c_out);
+  if (n_out == 0) return PTC_OK;
+  PTC_REQUIRE(weight && nbr && out && (n_in == 0 || in), PTC_EINVAL, "ptc_spconv_fwd: null buffer");
+  PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)out % 16 == 0), PTC_EINVAL,
+              "ptc_spconv_fwd: buffers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  PTC_DISPATCH_DTYPE(dtype, T, return dispatch_fwd<T>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s));
+  return PTC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: dw[co][k][ci] = sum_o dout[o][co] * in[nbr[k][o]][ci]
+// grid = (splits, kv, channel tiles of 64x64).  The contraction runs over ROWS, so both operands
+// are transposed on their way into LDS ([channel][row], rows contiguous) and read back as
+// k-contiguous ds_read_b128 fragments.  Partials per split -> deterministic reduction kernel.
+// ------------------------------------------------------------------------------------------------
+#define WG_RO 64  // rows per staged chunk
+#define WG_CT 64  // channel tile (both co and ci)
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+spconv_wgrad_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_t* __restrict__ nbr,
+                    int64_t n_out, int kv, int c_in, int c_out, int64_t rows_per_split, int ci_tiles,
+                    float* __restrict__ partial) {
+  using M = Mma<T>;
+  constexpr int EPL = M::EPL, KS = M::KS;
+  constexpr int PITCH = WG_RO + EPL;  // elements; rows of 16-byte multiples
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WG_CT * (WG_RO + 8) * 4];
+  T* dT = reinterpret_cast<T*>(smem);                 // [WG_CT][PITCH]  dout^T
+  T* iT = dT + WG_CT * PITCH;                         // [WG_CT][PITCH]  gathered in^T
+
+  const int lane = ptc_lane(), wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int k = blockIdx.y;
+  const int co0 = (blockIdx.z / ci_tiles) * WG_CT, ci0 = (blockIdx.z % ci_tiles) * WG_CT;
+  const int64_t begin = (int64_t)blockIdx.x * rows_per_split;
+  int64_t end = begin + rows_per_split;
+  if (end > n_out) end = n_out;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t chunk = begin; chunk < end; chunk += WG_RO) {
+    __syncthreads();  // previous chunk fully consumed
+    if (sizeof(T) == 2) {
+      // thread -> (row pair p, channel vector cv): two rows packed into one 32-bit LDS store
+      const int p = threadIdx.x & 31, cv = threadIdx.x >> 5;  // cv in [0,8): 8 x 8 = 64 channels
+      const int64_t ra = chunk + 2 * p, rb = ra + 1;
+      uint4 da = {0, 0, 0, 0}, db = {0, 0, 0, 0}, xa = {0, 0, 0, 0}, xb = {0, 0, 0, 0};
+      const bool cov = (co0 + cv * 8) < c_out, civ = (ci0 + cv * 8) < c_in;
+      if (ra < end) {
+        if (cov) da = *reinterpret_cast<const uint4*>(dout + ra * c_out + co0 + cv * 8);
+        const int32_t j = nbr[(int64_t)k * n_out + ra];
+        if (civ && j >= 0) xa = *reinterpret_cast<const uint4*>(in + (int64_t)j * c_in + ci0 + cv * 8);
+      }
+      if (rb < end) {
+        if (cov) db = *reinterpret_cast<const uint4*>(dout + rb * c_out + co0 + cv * 8);
+        const int32_t j = nbr[(int64_t)k * n_out + rb];
+        if (civ && j >= 0) xb = *reinterpret_cast<const uint4*>(in + (int64_t)j * c_in + ci0 + cv * 8);
+      }
+      const uint16_t* pa = reinterpret_cast<const uint16_t*>(&da);
+      const uint16_t* pb = reinterpret_cast<const uint16_t*>(&db);
+      const uint16_t* qa = reinterpret_cast<const uint16_t*>(&xa);
+      const uint16_t* qb = reinterpret_cast<const uint16_t*>(&xb);
+      uint32_t* d32 = reinterpret_cast<uint32_t*>(dT);
+      uint32_t* i32 = reinterpret_cast<uint32_t*>(iT);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        d32[((cv * 8 + e) * PITCH) / 2 + p] = (uint32_t)pa[e] | ((uint32_t)pb[e] << 16);
+        i32[((cv * 8 + e) * PITCH) / 2 + p] = (uint32_t)qa[e] | ((uint32_t)qb[e] << 16);
+      }
+    } else {
+      // fp32: thread -> (row rr, channel vector cv), 4 passes cover 16 vectors x 4 floats
+      const int rr = threadIdx.x & 63;
+      const int64_t row = chunk + rr;
+      const int32_t j = row < end ? nbr[(int64_t)k * n_out + row] : -1;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int cv = (threadIdx.x >> 6) + pass * 4;  // [0,16)
+        float4 d = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
+        if (row < end && (co0 + cv * 4) < c_out)
+          d = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dout) + row * c_out + co0 + cv * 4);
+        if (j >= 0 && (ci0 + cv * 4) < c_in)
+          x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + (int64_t)j * c_in + ci0 + cv * 4);
+        float* df = reinterpret_cast<float*>(dT);
+        float* xf = reinterpret_cast<float*>(iT);
+        df[(cv * 4 + 0) * PITCH + rr] = d.x; df[(cv * 4 + 1) * PITCH + rr] = d.y;
+        df[(cv * 4 + 2) * PITCH + rr] = d.z; df[(cv * 4 + 3) * PITCH + rr] = d.w;
+        xf[(cv * 4 + 0) * PITCH + rr] = x.x; xf[(cv * 4 + 1) * PITCH + rr] = x.y;
+        xf[(cv * 4 + 2) * PITCH + rr] = x.z; xf[(cv * 4 + 3) * PITCH + rr] = x.w;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < WG_RO / KS; ++ks) {
+      const int kk = ks * KS + g * EPL;
+      const typename M::frag fa = ld_frag<T>(dT + (wave * 16 + r) * PITCH + kk);  // A: i = co, k = rows
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const typename M::frag fb = ld_frag<T>(iT + (t * 16 + r) * PITCH + kk);    // B: j = ci
+        acc[t] = M::mma(fa, fb, acc[t]);
+      }
+    }
+  }
+  // D[i = co][j = ci]: lane (j = r) holds co = wave*16 + g*4 + e
+  float* pout = partial + (int64_t)blockIdx.x * c_out * kv * c_in;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ci = ci0 + t * 16 + r;
+    if (ci >= c_in) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = co0 + wave * 16 + g * 4 + e;
+      if (co < c_out) pout[((int64_t)co * kv + k) * c_in + ci] = acc[t][e];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int64_t count, float* __restrict__ dw) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    float s = 0.f;
+    for (int p = 0; p < splits; ++p) s += partial[(int64_t)p * count + i];
+    dw[i] = s;
+  }
+}
+
+static int wgrad_splits(int64_t n_out, int kv, int c_in, int c_out) {
+  const int64_t tiles = ptc_cdiv(c_out, WG_CT) * ptc_cdiv(c_in, WG_CT);
+  int64_t s = 2048 / (kv * tiles);
+  const int64_t max_s = ptc_cdiv(n_out, 4 * WG_RO);  // at least 4 chunks per split
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return (int)s;
+}
+
+extern "C" size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out) {
+  return ptc_align_up((size_t)wgrad_splits(n_out, kv, c_in, c_out) * (size_t)c_out * kv * c_in * sizeof(float), 256);
+}
+
+template <typename T>
+static int launch_wgrad(const void* in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in,
+                        int c_out, float* dw, void* ws, hipStream_t s) {
+  const int splits = wgrad_splits(n_out, kv, c_in, c_out);
+  const int ci_tiles = (int)ptc_cdiv(c_in, WG_CT), co_tiles = (int)ptc_cdiv(c_out, WG_CT);
+  int64_t rps = ptc_cdiv(ptc_cdiv(n_out, splits), WG_RO) * WG_RO;
+  dim3 grid((unsigned)splits, (unsigned)kv, (unsigned)(ci_tiles * co_tiles));
+  hipLaunchKernelGGL((spconv_wgrad_kernel<T>), grid, dim3(256), 0, s, (const T*)in, (const T*)dout, nbr, n_out, kv,
+                     c_in, c_out, rps, ci_tiles, (float*)ws);
+  PTC_CHECK_LAUNCH("spconv_wgrad_kernel");
+  const int64_t count = (int64_t)c_out * kv * c_in;
+  int64_t rgrid = ptc_cdiv(count, 256);
+  if (rgrid > 4096) rgrid = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, (const float*)ws, splits, count, dw);
+  PTC_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return PTC_OK;
+}
+
+extern "C" int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out,
+                                int kv, int c_in, int c_out, int dtype, float* dw, void* workspace,
+                                size_t workspace_bytes, ptc_stream_t stream) {
+  PTC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1, PTC_EINVAL, "ptc_spconv_wgrad: bad sizes");
+  PTC_REQUIRE(c_in >= 8 && c_in % 8 == 0 && c_out >= 8 && c_out % 8 == 0, PTC_EUNSUPPORTED,
+              "ptc_spconv_wgrad: c_in=%d c_out=%d must be multiples of 8", c_in, c_out);
+  PTC_REQUIRE(dw && workspace, PTC_EINVAL, "ptc_spconv_wgrad: null buffer");
+  PTC_REQUIRE(workspace_bytes >= ptc_spconv_wgrad_workspace_bytes(n_out, kv, c_in, c_out), PTC_EWORKSPACE,
+              "ptc_spconv_wgrad: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (n_out == 0) {
+    PTC_HIP(hipMemsetAsync(dw, 0, (size_t)c_out * kv * c_in * sizeof(float), s));
+    return PTC_OK;
+  }
+  PTC_REQUIRE(in && dout && nbr, PTC_EINVAL, "ptc_spconv_wgrad: null buffer");
+  PTC_DISPATCH_DTYPE(dtype, T, return launch_wgrad<T>(in, dout, nbr, n_out, kv, c_in, c_out, dw, workspace, s));
+  return PTC_OK;
+}

@@ -1,0 +1,320 @@
+"""Raw (non-differentiable) Python wrappers over the C-ABI of libptcore.so.
+
+Every function takes CUDA tensors, allocates outputs / workspaces as torch tensors, and enqueues
+the kernels on torch's current stream.  CPU tensors raise PtcoreError -- there is no fallback.
+Differentiable versions live in pointcept_amd/functional.py.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import PtcoreError, check, dtype_code, lib, ptr, require_cuda, stream_ptr
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# serialization
+# ------------------------------------------------------------------------------------------------
+def serialize_encode(grid_coord: torch.Tensor, batch: Optional[torch.Tensor], depth: int,
+                     orders: Sequence[str]) -> torch.Tensor:
+    """serialization.encode for all `orders` at once -> code [k,N] int64
+    (pointcept/models/utils/serialization/default.py:8-24)."""
+    require_cuda(grid_coord, batch)
+    if grid_coord.dtype not in (torch.int64, torch.int32):
+        raise PtcoreError(f"grid_coord must be int32/int64, got {grid_coord.dtype}")
+    gc = grid_coord.contiguous()
+    n = gc.shape[0]
+    b = None if batch is None else batch.to(torch.int64).contiguous()
+    k = len(orders)
+    oc = (ctypes.c_int * k)(*[_lib.ORDER_CODES[o] for o in orders])
+    out = torch.empty((k, n), dtype=torch.int64, device=gc.device)
+    check(lib().ptc_serialize_encode(ptr(gc), 1 if gc.dtype == torch.int64 else 0, ptr(b), n, int(depth),
+                                     ctypes.cast(oc, ctypes.c_void_p), k, ptr(out), stream_ptr()),
+          "ptc_serialize_encode")
+    return out
+
+
+def sort_keys(keys: torch.Tensor, begin_bit: int, end_bit: int, want_inverse: bool = True):
+    """Stable argsort of every row of keys [k,N] int64 over bits [begin_bit,end_bit) ->
+    (order [k,N] int64, inverse [k,N] int64 | None)   (structure.py:93-100)."""
+    require_cuda(keys)
+    if keys.dtype != torch.int64:
+        raise PtcoreError("keys must be int64")
+    squeeze = keys.dim() == 1
+    k2 = keys.reshape(1, -1) if squeeze else keys
+    k2 = k2.contiguous()
+    k, n = k2.shape
+    order = torch.empty_like(k2)
+    inverse = torch.empty_like(k2) if want_inverse else None
+    nbytes = lib().ptc_sort_keys_workspace_bytes(n, k)
+    ws = _ws(nbytes, k2.device)
+    check(lib().ptc_sort_keys(ptr(k2), n, k, int(begin_bit), int(end_bit), ptr(order), ptr(inverse), ptr(ws), nbytes,
+                              stream_ptr()), "ptc_sort_keys")
+    if squeeze:
+        return order[0], (inverse[0] if want_inverse else None)
+    return order, inverse
+
+
+def exclusive_scan_i32(x: torch.Tensor) -> torch.Tensor:
+    require_cuda(x)
+    x = x.to(torch.int32).contiguous()
+    n = x.numel()
+    out = torch.empty(n, dtype=torch.int64, device=x.device)
+    nbytes = lib().ptc_exclusive_scan_workspace_bytes(n)
+    ws = _ws(nbytes, x.device)
+    check(lib().ptc_exclusive_scan_i32(ptr(x), n, ptr(out), ptr(ws), nbytes, stream_ptr()), "ptc_exclusive_scan_i32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# patch padding maps
+# ------------------------------------------------------------------------------------------------
+def pad_sizes(offset_host: Sequence[int], patch: int):
+    """(n, n_pad, n_seq) from a host copy of `offset` (ptv3m1:123-138,156-164)."""
+    prev, n_pad, n_seq = 0, 0, 0
+    for o in offset_host:
+        ni = int(o) - prev
+        prev = int(o)
+        p = ((ni + patch - 1) // patch) * patch if ni > patch else ni
+        n_pad += p
+        n_seq += (p + patch - 1) // patch
+    return prev, n_pad, n_seq
+
+
+def patch_pad_maps(offset: torch.Tensor, offset_host: Sequence[int], patch: int):
+    """SerializedAttention.get_padding_and_inverse (ptv3m1:114-170) in one launch.
+    Returns pad [N'] i64, unpad [N] i64, cu_seqlens [n_seq+1] i32, dup [N] i64."""
+    require_cuda(offset)
+    off = offset.to(torch.int64).contiguous()
+    n, n_pad, n_seq = pad_sizes(offset_host, patch)
+    dev = off.device
+    pad = torch.empty(n_pad, dtype=torch.int64, device=dev)
+    unpad = torch.empty(n, dtype=torch.int64, device=dev)
+    cu = torch.empty(n_seq + 1, dtype=torch.int32, device=dev)
+    dup = torch.empty(n, dtype=torch.int64, device=dev)
+    check(lib().ptc_patch_pad_maps(ptr(off), off.numel(), int(patch), n, n_pad, n_seq, ptr(pad), ptr(unpad), ptr(cu),
+                                   ptr(dup), stream_ptr()), "ptc_patch_pad_maps")
+    return pad, unpad, cu, dup
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling maps
+# ------------------------------------------------------------------------------------------------
+def pool_maps(code0: torch.Tensor, order0: torch.Tensor, shift: int):
+    """cluster (= pooling_inverse), idx_ptr, head for SerializedPooling (ptv3m1:383-396).
+    One host sync (the number of clusters sizes the outputs, as torch.unique does in the reference)."""
+    require_cuda(code0, order0)
+    code0 = code0.contiguous()
+    order0 = order0.contiguous()
+    n = code0.numel()
+    dev = code0.device
+    cluster = torch.empty(n, dtype=torch.int64, device=dev)
+    ncl = torch.empty(1, dtype=torch.int64, device=dev)
+    nbytes = lib().ptc_pool_maps_workspace_bytes(n)
+    ws = _ws(nbytes, dev)
+    check(lib().ptc_pool_maps_count(ptr(code0), ptr(order0), n, int(shift), ptr(cluster), ptr(ncl), ptr(ws), nbytes,
+                                    stream_ptr()), "ptc_pool_maps_count")
+    n_cluster = int(ncl.item())
+    idx_ptr = torch.empty(n_cluster + 1, dtype=torch.int64, device=dev)
+    head = torch.empty(n_cluster, dtype=torch.int64, device=dev)
+    check(lib().ptc_pool_maps_fill(ptr(order0), ptr(cluster), n, n_cluster, ptr(idx_ptr), ptr(head), stream_ptr()),
+          "ptc_pool_maps_fill")
+    return cluster, idx_ptr, head
+
+
+def pool_child_codes(code: torch.Tensor, head: torch.Tensor, shift: int) -> torch.Tensor:
+    require_cuda(code, head)
+    code = code.contiguous()
+    head = head.contiguous()
+    k, n = code.shape
+    nc = head.numel()
+    out = torch.empty((k, nc), dtype=torch.int64, device=code.device)
+    check(lib().ptc_pool_child_codes(ptr(code), n, k, ptr(head), nc, int(shift), ptr(out), stream_ptr()),
+          "ptc_pool_child_codes")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# rows
+# ------------------------------------------------------------------------------------------------
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, idx2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = src[idx[i]] (+ src[idx2[i]] where idx2[i] >= 0); idx[i] < 0 -> zeros."""
+    require_cuda(src, idx, idx2)
+    if src.dim() != 2:
+        raise PtcoreError("gather_rows expects [N,C] features")
+    src = src.contiguous()
+    idx = idx.to(torch.int64).contiguous()
+    if idx2 is not None:
+        idx2 = idx2.to(torch.int64).contiguous()
+    n_out, c = idx.numel(), src.shape[1]
+    out = torch.empty((n_out, c), dtype=src.dtype, device=src.device)
+    check(lib().ptc_gather_rows(ptr(src), src.shape[0], ptr(idx), ptr(idx2), n_out, c, dtype_code(src), ptr(out),
+                                stream_ptr()), "ptc_gather_rows")
+    return out
+
+
+def segment_csr_fwd(src: torch.Tensor, perm: Optional[torch.Tensor], indptr: torch.Tensor, reduce: str):
+    """out[s] = reduce_{r in [indptr[s], indptr[s+1])} src[perm[r]]; returns (out, arg|None)."""
+    require_cuda(src, perm, indptr)
+    src = src.contiguous()
+    indptr = indptr.to(torch.int64).contiguous()
+    if perm is not None:
+        perm = perm.to(torch.int64).contiguous()
+    n_seg, c = indptr.numel() - 1, src.shape[1]
+    out = torch.empty((n_seg, c), dtype=src.dtype, device=src.device)
+    arg = torch.empty((n_seg, c), dtype=torch.int32, device=src.device) if reduce in ("max", "min") else None
+    check(lib().ptc_segment_csr_fwd(ptr(src), ptr(perm), ptr(indptr), n_seg, c, dtype_code(src),
+                                    _lib.REDUCE_CODES[reduce], ptr(out), ptr(arg), stream_ptr()), "ptc_segment_csr_fwd")
+    return out, arg
+
+
+def segment_csr_bwd(grad_out: torch.Tensor, perm: Optional[torch.Tensor], indptr: torch.Tensor,
+                    arg: Optional[torch.Tensor], n_src: int, reduce: str) -> torch.Tensor:
+    require_cuda(grad_out, perm, indptr, arg)
+    grad_out = grad_out.contiguous()
+    n_seg, c = indptr.numel() - 1, grad_out.shape[1]
+    # rows outside every segment (none when perm is a full permutation) must read as zero
+    covered = int(n_src)
+    gsrc = torch.zeros((covered, c), dtype=grad_out.dtype, device=grad_out.device)
+    check(lib().ptc_segment_csr_bwd(ptr(grad_out), ptr(perm), ptr(indptr), ptr(arg), n_seg, covered, c,
+                                    dtype_code(grad_out), _lib.REDUCE_CODES[reduce], ptr(gsrc), stream_ptr()),
+          "ptc_segment_csr_bwd")
+    return gsrc
+
+
+# ------------------------------------------------------------------------------------------------
+# rulebooks
+# ------------------------------------------------------------------------------------------------
+VOX_MAX = 1 << 18
+BATCH_MAX = 1023
+
+
+class HashTable:
+    def __init__(self, indices: torch.Tensor):
+        require_cuda(indices)
+        if indices.dtype != torch.int32 or indices.dim() != 2 or indices.shape[1] != 4:
+            raise PtcoreError("indices must be int32 [N,4] (batch,x,y,z)")
+        self.indices = indices.contiguous()
+        n = self.indices.shape[0]
+        self.size = int(lib().ptc_hash_table_size(n))
+        dev = indices.device
+        self.keys = torch.empty(self.size, dtype=torch.int64, device=dev)
+        self.vals = torch.empty(self.size, dtype=torch.int32, device=dev)
+        check(lib().ptc_hash_build(ptr(self.indices), n, ptr(self.keys), ptr(self.vals), self.size, stream_ptr()),
+              "ptc_hash_build")
+
+
+def rulebook_subm(indices: torch.Tensor, ksize: int, table: Optional[HashTable] = None) -> torch.Tensor:
+    """Gather table nbr [ksize^3, N] int32 of a submanifold convolution."""
+    if table is None:
+        table = HashTable(indices)
+    ind = table.indices
+    n = ind.shape[0]
+    nbr = torch.empty((ksize ** 3, n), dtype=torch.int32, device=ind.device)
+    check(lib().ptc_rulebook_subm(ptr(ind), n, int(ksize), ptr(table.keys), ptr(table.vals), table.size, ptr(nbr),
+                                  stream_ptr()), "ptc_rulebook_subm")
+    return nbr
+
+
+def rulebook_down(indices: torch.Tensor, coord_bits: int, batch_bits: int):
+    """k=2,s=2 strided conv maps: out_indices [M,4] i32, nbr_down [8,M] i32, nbr_up [8,N] i32."""
+    require_cuda(indices)
+    ind = indices.contiguous()
+    n = ind.shape[0]
+    dev = ind.device
+    out_of_in = torch.empty(n, dtype=torch.int32, device=dev)
+    n_out_dev = torch.empty(1, dtype=torch.int64, device=dev)
+    nbytes = lib().ptc_rulebook_down_workspace_bytes(n)
+    ws = _ws(nbytes, dev)
+    check(lib().ptc_rulebook_down_count(ptr(ind), n, int(coord_bits), int(batch_bits), ptr(out_of_in), ptr(n_out_dev),
+                                        ptr(ws), nbytes, stream_ptr()), "ptc_rulebook_down_count")
+    n_out = int(n_out_dev.item())
+    out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
+    nbr_down = torch.empty((8, n_out), dtype=torch.int32, device=dev)
+    nbr_up = torch.empty((8, n), dtype=torch.int32, device=dev)
+    check(lib().ptc_rulebook_down_fill(ptr(ind), n, ptr(out_of_in), n_out, ptr(out_indices), ptr(nbr_down), ptr(nbr_up),
+                                       stream_ptr()), "ptc_rulebook_down_fill")
+    return out_indices, nbr_down, nbr_up
+
+
+# ------------------------------------------------------------------------------------------------
+# sparse conv compute
+# ------------------------------------------------------------------------------------------------
+def spconv_fwd(feat: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], nbr: torch.Tensor) -> torch.Tensor:
+    """out[o] = bias + sum_k W[:,k,:] . feat[nbr[k][o]].  weight [C_out, kv, C_in] in feat.dtype,
+    bias fp32.  C_in % 8 == 0 and C_out % 16 == 0 (callers pad)."""
+    require_cuda(feat, weight, bias, nbr)
+    feat = feat.contiguous()
+    weight = weight.contiguous()
+    nbr = nbr.contiguous()
+    if weight.dtype != feat.dtype:
+        raise PtcoreError("weight dtype must match feature dtype")
+    c_out, kv, c_in = weight.shape
+    if feat.shape[1] != c_in or nbr.shape[0] != kv or nbr.dtype != torch.int32:
+        raise PtcoreError(f"shape mismatch: feat {tuple(feat.shape)} weight {tuple(weight.shape)} nbr {tuple(nbr.shape)}")
+    if bias is not None:
+        bias = bias.to(torch.float32).contiguous()
+    n_out = nbr.shape[1]
+    out = torch.empty((n_out, c_out), dtype=feat.dtype, device=feat.device)
+    check(lib().ptc_spconv_fwd(ptr(feat), feat.shape[0], ptr(weight), ptr(bias), ptr(nbr), n_out, kv, c_in, c_out,
+                               dtype_code(feat), ptr(out), stream_ptr()), "ptc_spconv_fwd")
+    return out
+
+
+def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: torch.Tensor) -> torch.Tensor:
+    """dw [C_out, kv, C_in] fp32 = sum_o dout[o]^T (x) feat[nbr[k][o]]."""
+    require_cuda(feat, dout, nbr)
+    feat = feat.contiguous()
+    dout = dout.contiguous()
+    nbr = nbr.contiguous()
+    if feat.dtype != dout.dtype:
+        raise PtcoreError("feat / dout dtype mismatch")
+    kv, n_out = nbr.shape
+    c_in, c_out = feat.shape[1], dout.shape[1]
+    dw = torch.empty((c_out, kv, c_in), dtype=torch.float32, device=feat.device)
+    nbytes = lib().ptc_spconv_wgrad_workspace_bytes(n_out, kv, c_in, c_out)
+    ws = _ws(nbytes, feat.device)
+    check(lib().ptc_spconv_wgrad(ptr(feat), feat.shape[0], ptr(dout), ptr(nbr), n_out, kv, c_in, c_out,
+                                 dtype_code(feat), ptr(dw), ptr(ws), nbytes, stream_ptr()), "ptc_spconv_wgrad")
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, softmax_scale: float):
+    """qkv [T,3,H,16] bf16 -> (out [T,H,16] bf16, lse [H,T] fp32)."""
+    require_cuda(qkv, cu_seqlens)
+    if qkv.dtype != torch.bfloat16 or qkv.dim() != 4 or qkv.shape[1] != 3 or qkv.shape[3] != 16:
+        raise PtcoreError(f"qkv must be bf16 [T,3,H,16], got {qkv.dtype} {tuple(qkv.shape)}")
+    qkv = qkv.contiguous()
+    cu = cu_seqlens.to(torch.int32).contiguous()
+    T, _, H, _ = qkv.shape
+    out = torch.empty((T, H, 16), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((H, T), dtype=torch.float32, device=qkv.device)
+    check(lib().ptc_attn_varlen_fwd(ptr(qkv), ptr(cu), cu.numel() - 1, T, H, int(max_seqlen), float(softmax_scale),
+                                    _lib.PTC_BF16, ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_fwd")
+    return out, lse
+
+
+def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_scale: float) -> torch.Tensor:
+    require_cuda(qkv, out, dout, lse, cu_seqlens)
+    qkv = qkv.contiguous()
+    out = out.contiguous()
+    dout = dout.to(torch.bfloat16).contiguous()
+    cu = cu_seqlens.to(torch.int32).contiguous()
+    T, _, H, _ = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    nbytes = lib().ptc_attn_varlen_bwd_workspace_bytes(T, H)
+    ws = _ws(nbytes, qkv.device)
+    check(lib().ptc_attn_varlen_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), cu.numel() - 1, T, H,
+                                    int(max_seqlen), float(softmax_scale), _lib.PTC_BF16, ptr(dqkv), ptr(ws), nbytes,
+                                    stream_ptr()), "ptc_attn_varlen_bwd")
+    return dqkv

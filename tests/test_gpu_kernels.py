@@ -1,0 +1,375 @@
+"""-m gpu parity tests proper: every libptcore.so kernel, called through the C-ABI (via
+pointcept_amd.ops), against the CPU oracle on the same seeded inputs.
+
+Bars: integer / index outputs bit-exact; fp32 features rtol 2e-5 (summation-order differences only);
+bf16 / f16 features compared with an fp32 oracle fed the SAME rounded inputs, tolerance one output
+rounding step (2^-8 relative for bf16, 2^-10 for f16) plus fp32 accumulation slack.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import maps as omaps
+from oracle import ops as oops
+from oracle import sfc as osfc
+
+pytestmark = pytest.mark.gpu
+
+ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
+
+
+def _t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def _close(name, got, ref, rtol, atol):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{name}: non-finite values in kernel output"
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        i = int(torch.argmax(err - tol))
+        raise AssertionError(
+            f"{name}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; worst at flat {i}: "
+            f"got {got.flatten()[i].item():.6g} ref {ref.flatten()[i].item():.6g} "
+            f"(max abs err {err.max().item():.3g}, ref absmax {ref.abs().max().item():.3g})")
+
+
+# ------------------------------------------------------------------------------------------------
+# A. serialization
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("depth", [1, 3, 7, 8, 9, 12, 16])
+@pytest.mark.parametrize("i64", [True, False])
+def test_serialize_encode_bit_exact(cuda, depth, i64):
+    from pointcept_amd import ops
+
+    rng = np.random.default_rng(depth)
+    n = 20000 + depth
+    gc = rng.integers(0, 1 << depth, size=(n, 3), dtype=np.int64)
+    b = rng.integers(0, 16, size=n, dtype=np.int64)
+    ref = osfc.encode_c(gc, b, depth, ORDERS)
+    got = ops.serialize_encode(_t(gc if i64 else gc.astype(np.int32), cuda), _t(b, cuda), depth, ORDERS)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    got_nb = ops.serialize_encode(_t(gc, cuda), None, depth, ("hilbert", "z"))
+    assert np.array_equal(got_nb.cpu().numpy(), osfc.encode_c(gc, None, depth, ("hilbert", "z")))
+
+
+def test_serialize_and_sort_full_size(cuda):
+    """BASELINE config 3 size: 8 x 102400 points, 4 orders: codes bit-exact, orders bit-exact (unique keys)."""
+    from pointcept_amd import ops, synthetic
+
+    batch = synthetic.indoor_batch(8, 102400)
+    gc, off = batch["grid_coord"], batch["offset"]
+    b = omaps.offset2batch(off)
+    depth, code, order, inverse = osfc.serialization(gc, b, ORDERS)
+    got = ops.serialize_encode(_t(gc, cuda), _t(b, cuda), depth, ORDERS)
+    assert np.array_equal(got.cpu().numpy(), code)
+    bits = 3 * depth + int(len(off)).bit_length()
+    go, gi = ops.sort_keys(got, 0, bits)
+    assert np.array_equal(go.cpu().numpy(), order)
+    assert np.array_equal(gi.cpu().numpy(), inverse)
+    # size-independent properties
+    srt = torch.gather(got, 1, go)
+    assert bool((srt[:, 1:] >= srt[:, :-1]).all())
+    ar = torch.arange(got.shape[1], device=cuda).expand_as(go)
+    assert bool((torch.gather(gi, 1, go) == ar).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# B. sort / scan
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 4095, 4096, 4097, 50000])
+def test_sort_keys_stable(cuda, n):
+    from pointcept_amd import ops
+
+    rng = np.random.default_rng(n)
+    for k, bits, hi in [(1, 64, 1 << 62), (4, 27, 1 << 27), (3, 10, 1 << 10), (2, 39, 1 << 39)]:
+        keys = rng.integers(0, hi, size=(k, n), dtype=np.int64)
+        if n > 10:
+            keys[:, n // 2:] = keys[:, : n - n // 2]  # force duplicates: stability must hold
+        order, inv = ops.sort_keys(_t(keys, cuda), 0, bits if bits < 64 else 63)
+        ref = np.argsort(keys, axis=1, kind="stable")
+        assert np.array_equal(order.cpu().numpy(), ref), f"n={n} k={k} bits={bits}"
+        ar = np.arange(n)
+        for r in range(k):
+            assert np.array_equal(inv.cpu().numpy()[r][ref[r]], ar)
+
+
+def test_sort_keys_bit_window(cuda):
+    from pointcept_amd import ops
+
+    rng = np.random.default_rng(7)
+    keys = rng.integers(0, 1 << 40, size=(2, 30000), dtype=np.int64)
+    order, _ = ops.sort_keys(_t(keys, cuda), 8, 29)
+    ref = np.argsort((keys >> 8) & ((1 << 21) - 1), axis=1, kind="stable")
+    assert np.array_equal(order.cpu().numpy(), ref)
+    order0, inv0 = ops.sort_keys(_t(keys, cuda), 5, 5)  # empty window -> identity
+    assert np.array_equal(order0.cpu().numpy(), np.tile(np.arange(30000), (2, 1)))
+
+
+@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 300001])
+def test_exclusive_scan(cuda, n):
+    from pointcept_amd import ops
+
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 1000, size=n).astype(np.int32)
+    got = ops.exclusive_scan_i32(_t(x, cuda)).cpu().numpy()
+    ref = np.concatenate([[0], np.cumsum(x.astype(np.int64))[:-1]])
+    assert np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# C / D. index maps
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("counts,K", [([10, 3, 7], 4), ([1024, 1025, 5000, 1], 1024), ([48, 49, 100, 7], 48),
+                                      ([330, 1425, 2048], 1024), ([102400] * 8, 1024), ([5], 1024),
+                                      ([2047, 2049, 1023, 1024, 1], 1024)])
+def test_patch_pad_maps(cuda, counts, K):
+    from pointcept_amd import ops
+
+    off = np.cumsum(counts).astype(np.int64)
+    pad, unpad, cu = omaps.pad_maps(off, K)
+    dup = omaps.dup_map(pad, unpad)
+    gp, gu, gc_, gd = ops.patch_pad_maps(_t(off, cuda), off.tolist(), K)
+    assert np.array_equal(gp.cpu().numpy(), pad)
+    assert np.array_equal(gu.cpu().numpy(), unpad)
+    assert np.array_equal(gc_.cpu().numpy(), cu)
+    assert np.array_equal(gd.cpu().numpy(), dup)
+
+
+@pytest.mark.parametrize("n_pts", [2000, 60000])
+def test_pool_maps(cuda, n_pts):
+    from pointcept_amd import ops, synthetic
+
+    batch = synthetic.indoor_batch(2, n_pts)
+    gc, off = batch["grid_coord"], batch["offset"]
+    b = omaps.offset2batch(off)
+    depth, code, order, inverse = osfc.serialization(gc, b, ORDERS)
+    ref = omaps.pooling_maps(code, 2, depth)
+    dcode, dorder = _t(code, cuda), _t(order, cuda)
+    cluster, idx_ptr, head = ops.pool_maps(dcode[0], dorder[0], 3)
+    assert np.array_equal(cluster.cpu().numpy(), ref["cluster"])
+    assert np.array_equal(idx_ptr.cpu().numpy(), ref["idx_ptr"])
+    child = ops.pool_child_codes(dcode, head, 3)
+    assert np.array_equal(child.cpu().numpy(), ref["code"])  # head choice is immaterial for the child codes
+    # members listed under idx_ptr (via order0) are exactly the cluster's members
+    o0 = order[0]
+    assert np.array_equal(ref["cluster"][o0], np.repeat(np.arange(len(ref["counts"])), ref["counts"]))
+    assert np.array_equal(ref["cluster"][head.cpu().numpy()], np.arange(len(ref["counts"])))
+    bits = 3 * (depth - 1) + int(len(off)).bit_length()
+    corder, cinv = ops.sort_keys(child, 0, bits)
+    assert np.array_equal(corder.cpu().numpy(), ref["order"])
+    assert np.array_equal(cinv.cpu().numpy(), ref["inverse"])
+
+
+# ------------------------------------------------------------------------------------------------
+# E. rows
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("c", [3, 16, 96, 512])
+def test_gather_rows(cuda, dtype, c):
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(c)
+    src = torch.randn(5000, c, generator=g).to(dtype)
+    idx = torch.randint(0, 5000, (7777,), generator=g)
+    idx[::17] = -1
+    idx2 = torch.randint(0, 5000, (7777,), generator=g)
+    idx2[::3] = -1
+    got = ops.gather_rows(src.to(cuda), idx.to(cuda))
+    ref = torch.where((idx >= 0)[:, None], src[idx.clamp(min=0)], torch.zeros((), dtype=dtype))
+    assert torch.equal(got.cpu(), ref)  # pure data movement: bit-exact
+    got2 = ops.gather_rows(src.to(cuda), idx.to(cuda), idx2.to(cuda))
+    ref2 = ref.float() + torch.where((idx2 >= 0)[:, None], src[idx2.clamp(min=0)].float(), torch.zeros(()))
+    assert torch.equal(got2.cpu(), ref2.to(dtype))  # one fp32 add, one rounding
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("reduce", ["max", "mean", "sum", "min"])
+@pytest.mark.parametrize("c", [3, 64])
+def test_segment_csr(cuda, dtype, reduce, c):
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    counts = torch.randint(1, 9, (3000,), generator=g)
+    counts[5] = 0  # an empty segment
+    indptr = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])
+    n = int(indptr[-1])
+    perm = torch.randperm(n, generator=g)
+    src = torch.randn(n, c, generator=g).to(dtype)
+    out, arg = ops.segment_csr_fwd(src.to(cuda), perm.to(cuda), indptr.to(cuda), reduce)
+    ref = oops.segment_csr(src[perm].float(), indptr, reduce)
+    if reduce in ("max", "min"):
+        assert torch.equal(out.cpu().float(), ref)  # selection: exact
+    else:
+        _close(f"segment_{reduce}", out, ref, 1e-2 if dtype != torch.float32 else 1e-6, 1e-2 if dtype != torch.float32 else 1e-6)
+    # backward against autograd through the oracle
+    gout = torch.randn(indptr.numel() - 1, c, generator=g).to(dtype)
+    src_ref = src[perm].float().requires_grad_(True)
+    oops.segment_csr(src_ref, indptr, reduce).backward(gout.float())
+    gref = torch.zeros(n, c)
+    gref[perm] = src_ref.grad
+    gsrc = ops.segment_csr_bwd(gout.to(cuda), perm.to(cuda), indptr.to(cuda), arg, n, reduce)
+    _close(f"segment_{reduce}_bwd", gsrc, gref.to(dtype).float(), 1e-2 if dtype != torch.float32 else 1e-6, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# F. rulebooks
+# ------------------------------------------------------------------------------------------------
+def _scene_indices(n_pts, batch=2, dup=False):
+    from pointcept_amd import synthetic
+
+    b = synthetic.indoor_batch(batch, n_pts)
+    ind = np.concatenate([omaps.offset2batch(b["offset"])[:, None], b["grid_coord"]], axis=1).astype(np.int32)
+    if dup:  # Mix3D-style duplicate voxels
+        ind = np.concatenate([ind, ind[::7]], axis=0)
+    return ind
+
+
+@pytest.mark.parametrize("ksize", [3, 5])
+@pytest.mark.parametrize("dup", [False, True])
+def test_rulebook_subm(cuda, ksize, dup):
+    from pointcept_amd import ops
+
+    ind = _scene_indices(6000, dup=dup)
+    ref = oops.subm_rulebook(ind, ksize)
+    got = ops.rulebook_subm(_t(ind, cuda), ksize)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    # symmetry property used by dgrad: nbr[k][i] = j  <=>  nbr[kv-1-k][j] = i  (unique voxels only)
+    if not dup:
+        kv = ksize ** 3
+        g = got.cpu().numpy()
+        k, i = np.nonzero(g >= 0)
+        assert np.array_equal(g[kv - 1 - k, g[k, i]], i)
+
+
+def test_rulebook_down(cuda):
+    from pointcept_amd import ops
+
+    ind = _scene_indices(9000)
+    oi, ooi, nd, nu = oops.down_rulebook(ind)
+    cb = int(ind[:, 1:].max() >> 1).bit_length()
+    goi, gnd, gnu = ops.rulebook_down(_t(ind, cuda), max(cb, 1), 2)
+    assert np.array_equal(goi.cpu().numpy(), oi)
+    assert np.array_equal(gnd.cpu().numpy(), nd)
+    assert np.array_equal(gnu.cpu().numpy(), nu)
+
+
+# ------------------------------------------------------------------------------------------------
+# G. sparse conv compute
+# ------------------------------------------------------------------------------------------------
+def _tols(dtype):
+    if dtype == torch.float32:
+        return 2e-5, 2e-5
+    if dtype == torch.bfloat16:
+        return 1.0 / 128, 2e-3
+    return 1.0 / 512, 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout,ksize", [(8, 32, 5), (32, 32, 3), (64, 64, 3), (96, 96, 3), (128, 48, 3),
+                                            (192, 128, 3), (256, 256, 3), (16, 16, 3)])
+def test_spconv_fwd_and_wgrad(cuda, dtype, cin, cout, ksize):
+    from pointcept_amd import ops
+
+    ind = _scene_indices(1500 if cin * cout > 20000 else 4000)
+    n = ind.shape[0]
+    nbr = oops.subm_rulebook(ind, ksize)
+    kv = ksize ** 3
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    feat = (torch.randn(n, cin, generator=g) * 0.5).to(dtype)
+    w = (torch.randn(cout, kv, cin, generator=g) / (kv * cin) ** 0.5 * 2).to(dtype)
+    bias = torch.randn(cout, generator=g)
+    rtol, atol = _tols(dtype)
+    ref = oops.gather_conv(feat.float(), w.float(), bias, nbr)
+    got = ops.spconv_fwd(feat.to(cuda), w.to(cuda), bias.to(cuda), _t(nbr, cuda))
+    _close("spconv_fwd", got, ref, rtol, atol)
+    got_nb = ops.spconv_fwd(feat.to(cuda), w.to(cuda), None, _t(nbr, cuda))
+    _close("spconv_fwd_nobias", got_nb, ref - bias, rtol, atol)
+    # wgrad (fp32 output, fp32 accumulation over rows)
+    dout = (torch.randn(n, cout, generator=g) * 0.5).to(dtype)
+    fr = feat.float()
+    wr = w.float().requires_grad_(True)
+    oops.gather_conv(fr, wr, None, nbr).backward(dout.float())
+    dw = ops.spconv_wgrad(feat.to(cuda), dout.to(cuda), _t(nbr, cuda))
+    _close("spconv_wgrad", dw, wr.grad, 1e-4, 1e-3 * float(wr.grad.abs().max()))
+
+
+def test_spconv_dgrad_via_mirrored_table(cuda):
+    """dgrad = the same kernel with W' = W.permute(ci,k,co).flip(k) on the SAME table (Appendix A.6)."""
+    from pointcept_amd import ops
+
+    ind = _scene_indices(3000)
+    n = ind.shape[0]
+    nbr = oops.subm_rulebook(ind, 3)
+    g = torch.Generator().manual_seed(5)
+    cin, cout = 32, 64
+    feat = torch.randn(n, cin, generator=g).requires_grad_(True)
+    w = torch.randn(cout, 27, cin, generator=g) * 0.1
+    dout = torch.randn(n, cout, generator=g)
+    oops.gather_conv(feat, w, None, nbr).backward(dout)
+    wt = w.permute(2, 1, 0).flip(1).contiguous()
+    got = ops.spconv_fwd(dout.to(cuda), wt.to(cuda), None, _t(nbr, cuda))
+    _close("spconv_dgrad", got, feat.grad, 2e-5, 2e-5)
+
+
+def test_spconv_down_up_tables(cuda):
+    from pointcept_amd import ops
+
+    ind = _scene_indices(5000)
+    oi, ooi, nd, nu = oops.down_rulebook(ind)
+    g = torch.Generator().manual_seed(9)
+    feat = torch.randn(ind.shape[0], 32, generator=g)
+    w = torch.randn(64, 8, 32, generator=g) * 0.2
+    ref = oops.gather_conv(feat, w, None, nd)
+    got = ops.spconv_fwd(feat.to(cuda), w.to(cuda), None, _t(nd, cuda))
+    _close("down_conv", got, ref, 2e-5, 2e-5)
+    wi = torch.randn(32, 8, 64, generator=g) * 0.2
+    ref_up = oops.gather_conv(ref, wi, None, nu)
+    got_up = ops.spconv_fwd(got, wi.to(cuda), None, _t(nu, cuda))
+    _close("inverse_conv", got_up, ref_up, 1e-4, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# H. attention
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lens,H", [([1024], 2), ([1024, 1024, 330], 4), ([48, 48, 17], 2), ([1, 2, 31, 32, 33, 65], 3),
+                                    ([128] * 5, 8), ([1000, 24], 32)])
+def test_attention_fwd_bwd(cuda, lens, H):
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(sum(lens) + H)
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    qkv = (torch.randn(T, 3, H, 16, generator=g) * 1.5).to(torch.bfloat16)
+    scale = 16 ** -0.5
+    out, lse = ops.attn_varlen_fwd(qkv.to(cuda), cu.to(cuda), max(lens), scale)
+    q32 = qkv.float().requires_grad_(True)
+    ref, ref_lse = oops.attention_varlen(q32, cu, scale, return_lse=True)
+    _close("attn_fwd", out, ref, 1.0 / 64, 4e-3)        # bf16 P and bf16 output rounding
+    _close("attn_lse", lse, ref_lse, 1e-3, 2e-2)         # denominator summed from bf16-rounded P
+    dout = torch.randn(T, H, 16, generator=g).to(torch.bfloat16)
+    ref.backward(dout.float())
+    dqkv = ops.attn_varlen_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale)
+    gmax = float(q32.grad.abs().max())
+    _close("attn_bwd", dqkv, q32.grad, 1.0 / 32, 1e-2 * gmax)
+
+
+def test_attention_large_logits(cuda):
+    """Peaked softmax (online-max path): one key dominates each query."""
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    L, H = 512, 2
+    qkv = torch.randn(L, 3, H, 16, generator=g)
+    qkv[:, 0] *= 6.0
+    qkv[:, 1] *= 6.0
+    qkv = qkv.to(torch.bfloat16)
+    cu = torch.tensor([0, L], dtype=torch.int32)
+    out, lse = ops.attn_varlen_fwd(qkv.to(cuda), cu.to(cuda), L, 0.25)
+    ref, ref_lse = oops.attention_varlen(qkv.float(), cu, 0.25, return_lse=True)
+    _close("attn_fwd_peaked", out, ref, 1.0 / 64, 1e-2)
+    _close("attn_lse_peaked", lse, ref_lse, 1e-3, 3e-2)
