@@ -240,6 +240,15 @@ def scatter(src, index, dim=0, dim_size=None, reduce="sum"):
     return out
 
 
+def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
+                                     **unused):
+    """CPU stand-in for flash_attn (ptv3m1:208-214): bf16 in, fp32 math, bf16 out.  Lets the
+    reference run its FLASH branch (enable_flash=True) unmodified on CPU."""
+    assert qkv.dtype == torch.bfloat16 and dropout_p == 0 and not causal
+    scale = qkv.shape[-1] ** -0.5 if softmax_scale is None else softmax_scale
+    return ops.attention_varlen(qkv.float(), cu_seqlens.tolist(), scale).to(torch.bfloat16)
+
+
 def install_third_party(mods=None):
     """Seed sys.modules with the stand-ins (idempotent)."""
     m = sys.modules if mods is None else mods
@@ -254,6 +263,7 @@ def install_third_party(mods=None):
     timm = mod("timm")
     timm.layers = mod("timm.layers", DropPath=DropPath, trunc_normal_=trunc_normal_)
     mod("torch_scatter", segment_csr=segment_csr)
+    mod("flash_attn", flash_attn_varlen_qkvpacked_func=flash_attn_varlen_qkvpacked_func)
     sp_modules = mod("spconv.pytorch.modules", is_spconv_module=is_spconv_module, SparseModule=SparseModule)
     sp = mod("spconv")
     sp.pytorch = mod(

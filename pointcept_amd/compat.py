@@ -1,0 +1,34 @@
+"""Operator-level drop-in (SURVEY 8(b) level B3): make `import spconv.pytorch`, `import flash_attn`
+and `import torch_scatter` resolve to the engine, so the reference's model files
+(point_transformer_v3m1_base.py, spconv_unet_v1m1_base.py, structure.py, modules.py) run UNMODIFIED
+on libptcore.so.  Call once before importing pointcept.models:
+
+    import pointcept_amd.compat; pointcept_amd.compat.install()
+
+Only names the hot-path files use are provided; real packages already imported are left alone
+unless force=True.
+"""
+from __future__ import annotations
+
+import sys
+import types
+
+
+def install(force: bool = False) -> None:
+    from . import flash_attn_api, spconv_api, torch_scatter_api
+
+    def put(name, module):
+        if force or name not in sys.modules:
+            sys.modules[name] = module
+
+    sp = types.ModuleType("spconv")
+    sp.pytorch = spconv_api
+    put("spconv", sp)
+    put("spconv.pytorch", spconv_api)
+    put("spconv.pytorch.modules", spconv_api.modules)
+    fa = types.ModuleType("flash_attn")
+    fa.flash_attn_varlen_qkvpacked_func = flash_attn_api.flash_attn_varlen_qkvpacked_func
+    put("flash_attn", fa)
+    ts = types.ModuleType("torch_scatter")
+    ts.segment_csr = torch_scatter_api.segment_csr
+    put("torch_scatter", ts)

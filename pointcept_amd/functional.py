@@ -1,0 +1,182 @@
+"""Differentiable operators of the engine (torch.autograd.Function wrappers over pointcept_amd.ops).
+
+Design rule: every backward is written in GATHER form over precomputed index maps, so no kernel
+uses floating-point atomics and every result is bit-reproducible run to run:
+  * backward of a row gather through a permutation-with-padding = a row gather through the inverse
+    map (+ the duplicate slot),
+  * backward of the unpooling gather = a segmented sum over the cluster CSR,
+  * sparse-conv dgrad = the forward kernel on the transposed table / mirrored weights,
+  * sparse-conv wgrad = per-split partial sums + a deterministic reduction.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+from ._lib import PtcoreError
+
+
+def _autocast_dtype(t: torch.Tensor) -> torch.dtype:
+    if torch.is_autocast_enabled():
+        return torch.get_autocast_gpu_dtype()
+    return t.dtype
+
+
+# ------------------------------------------------------------------------------------------------
+# row gathers
+# ------------------------------------------------------------------------------------------------
+class _GatherRows(Function):
+    @staticmethod
+    def forward(ctx, src, idx, bwd_idx, bwd_idx2):
+        ctx.save_for_backward(bwd_idx, bwd_idx2)
+        return ops.gather_rows(src, idx)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        bwd_idx, bwd_idx2 = ctx.saved_tensors
+        return ops.gather_rows(grad.contiguous(), bwd_idx, bwd_idx2), None, None, None
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, bwd_idx: torch.Tensor,
+                bwd_idx2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = src[idx[i]].  `bwd_idx` [n_src] (and optional `bwd_idx2`) list, for every source row,
+    the output row(s) it was copied to (-1 = none): grad_src[p] = g[bwd_idx[p]] + g[bwd_idx2[p]]."""
+    return _GatherRows.apply(src, idx, bwd_idx, bwd_idx2)
+
+
+class _GatherByCluster(Function):
+    @staticmethod
+    def forward(ctx, src, cluster, perm, indptr):
+        ctx.save_for_backward(perm, indptr)
+        return ops.gather_rows(src, cluster)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        perm, indptr = ctx.saved_tensors
+        gsrc, _ = ops.segment_csr_fwd(grad.contiguous(), perm, indptr, "sum")
+        return gsrc, None, None, None
+
+
+def gather_by_cluster(src: torch.Tensor, cluster: torch.Tensor, perm: torch.Tensor, indptr: torch.Tensor):
+    """out[p] = src[cluster[p]] (SerializedUnpooling, ptv3m1:478).  Backward = segmented sum over
+    the cluster CSR (perm = points sorted by cluster, indptr = idx_ptr)."""
+    return _GatherByCluster.apply(src, cluster, perm, indptr)
+
+
+# ------------------------------------------------------------------------------------------------
+# segment_csr
+# ------------------------------------------------------------------------------------------------
+class _SegmentCSR(Function):
+    @staticmethod
+    def forward(ctx, src, perm, indptr, reduce):
+        out, arg = ops.segment_csr_fwd(src, perm, indptr, reduce)
+        ctx.reduce = reduce
+        ctx.n_src = src.shape[0]
+        ctx.save_for_backward(perm, indptr, arg)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        perm, indptr, arg = ctx.saved_tensors
+        g = ops.segment_csr_bwd(grad.contiguous(), perm, indptr, arg, ctx.n_src, ctx.reduce)
+        return g, None, None, None
+
+
+def segment_csr(src: torch.Tensor, indptr: torch.Tensor, reduce: str = "sum", perm: Optional[torch.Tensor] = None):
+    """torch_scatter.segment_csr(src[perm], indptr, reduce) with the gather fused (ptv3m1:416-421)."""
+    if src.dim() == 1:
+        return _SegmentCSR.apply(src[:, None], perm, indptr, reduce)[:, 0]
+    return _SegmentCSR.apply(src, perm, indptr, reduce)
+
+
+# ------------------------------------------------------------------------------------------------
+# sparse convolution
+# ------------------------------------------------------------------------------------------------
+def _pad_to(x: torch.Tensor, dim: int, mult: int) -> torch.Tensor:
+    c = x.shape[dim]
+    r = (-c) % mult
+    if r == 0:
+        return x
+    pad = [0, 0] * (x.dim() - 1 - dim) + [0, r]
+    return F.pad(x, pad)
+
+
+class _SparseConv(Function):
+    """out = conv(feat; weight [C_out, kv, C_in], bias) over gather table `nbr`;
+    `nbr_t` is the table of the transposed map (SubM: the same table, with mirrored weights)."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, nbr, nbr_t, mirror):
+        dt = _autocast_dtype(feat)
+        c_out, kv, c_in = weight.shape
+        f = _pad_to(feat.to(dt), 1, 16).contiguous()
+        w = _pad_to(_pad_to(weight.to(dt), 2, 16), 0, 16).contiguous()
+        b = None if bias is None else _pad_to(bias.float(), 0, 16)
+        out = ops.spconv_fwd(f, w, b, nbr)
+        ctx.save_for_backward(f, w, nbr, nbr_t)
+        ctx.mirror = mirror
+        ctx.shape = (c_out, kv, c_in)
+        ctx.in_dtype, ctx.w_dtype = feat.dtype, weight.dtype
+        ctx.has_bias = bias is not None
+        return out[:, :c_out] if out.shape[1] != c_out else out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        f, w, nbr, nbr_t = ctx.saved_tensors
+        c_out, kv, c_in = ctx.shape
+        g = _pad_to(grad.to(f.dtype), 1, 16).contiguous()
+        dfeat = dw = dbias = None
+        if ctx.needs_input_grad[0]:
+            wt = w.permute(2, 1, 0)
+            if ctx.mirror:
+                wt = wt.flip(1)
+            dfeat = ops.spconv_fwd(g, wt.contiguous(), None, nbr_t)[:, :c_in].to(ctx.in_dtype)
+        if ctx.needs_input_grad[1]:
+            dw = ops.spconv_wgrad(f, g, nbr)[:c_out, :, :c_in].to(ctx.w_dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbias = grad.float().sum(0)
+        return dfeat, dw, dbias, None, None, None
+
+
+def sparse_conv(feat, weight, bias, nbr, nbr_t, mirror: bool):
+    """weight: [C_out, kv, C_in] (a view of the spconv-layout parameter [C_out,k0,k1,k2,C_in])."""
+    return _SparseConv.apply(feat, weight, bias, nbr, nbr_t, mirror)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+class _AttnVarlen(Function):
+    @staticmethod
+    def forward(ctx, qkv, cu_seqlens, max_seqlen, softmax_scale):
+        out, lse = ops.attn_varlen_fwd(qkv, cu_seqlens, max_seqlen, softmax_scale)
+        ctx.save_for_backward(qkv, out, lse, cu_seqlens)
+        ctx.max_seqlen, ctx.scale = max_seqlen, softmax_scale
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        qkv, out, lse, cu = ctx.saved_tensors
+        dqkv = ops.attn_varlen_bwd(qkv, out, dout.contiguous(), lse, cu, ctx.max_seqlen, ctx.scale)
+        return dqkv, None, None, None
+
+
+def attn_varlen_qkvpacked(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
+                          softmax_scale: Optional[float] = None) -> torch.Tensor:
+    """flash_attn.flash_attn_varlen_qkvpacked_func semantics (ptv3m1:208-214), dropout 0,
+    non-causal, qkv [T,3,H,16] bf16 -> [T,H,16] bf16."""
+    if qkv.dtype != torch.bfloat16:
+        raise PtcoreError("attn_varlen_qkvpacked expects bf16 (the reference casts with .to(torch.bfloat16), ptv3m1:209)")
+    if softmax_scale is None:
+        softmax_scale = qkv.shape[-1] ** -0.5
+    return _AttnVarlen.apply(qkv, cu_seqlens, int(max_seqlen), float(softmax_scale))

@@ -1,0 +1,406 @@
+"""PT-v3m1 on the engine: drop-in for
+pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py (registry name "PT-v3m1",
+same constructor kwargs (:520-552), same state-dict keys/shapes, same Point
+protocol in and out), with the hot path on libptcore.so:
+
+  Point.serialization / sparsify      -> fused key kernel + batched radix sort         (structure.py)
+  SerializedAttention                 -> device pad maps, gather kernel, MFMA window attention
+                                         (replaces the python loop :142-164 and flash_attn :208-214)
+  SerializedPooling / Unpooling       -> scan-based cluster maps, fused gather+segment reduce,
+                                         gather-form backward (replaces torch.unique/sort + torch_scatter)
+  CPE / stem SubMConv3d               -> hash rulebook + MFMA implicit GEMM             (spconv_api.py)
+Dense Linear / LayerNorm / BatchNorm / GELU stay on PyTorch-ROCm (hipBLASLt / ATen).
+
+Behaviours of the reference that change numerics are reproduced on purpose:
+stale sparse_conv_feat in the first decoder block's CPE (D.1), per-point DropPath (D.2), CPU-RNG
+order shuffling (D.3), bf16 attention regardless of the AMP dtype (D.4).
+Not implemented (raise): enable_rpe=True, PDNorm (pdnorm_bn / pdnorm_ln), head_dim != 16.
+`enable_flash=False` runs the same attention kernel (fixed patch size, bf16) -- the reference's
+data-dependent K of the dense branch (:173-176) is not reproduced.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import functional as PF
+from . import ops
+from . import spconv_api as spconv
+from ._lib import PtcoreError
+from .structure import AttrDict, Point
+
+
+class PointModule(nn.Module):
+    """modules taking / returning a Point (pointcept/models/modules.py:27-34)"""
+
+
+class PointSequential(PointModule):
+    """type-dispatching container, pointcept/models/modules.py:36-111"""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for module in self._modules.values():
+            if isinstance(module, PointModule):
+                input = module(input)
+            elif spconv.is_spconv_module(module):
+                if isinstance(input, Point):
+                    input.sparse_conv_feat = module(input.sparse_conv_feat)
+                    input.feat = input.sparse_conv_feat.features
+                else:
+                    input = module(input)
+            else:
+                if isinstance(input, Point):
+                    input.feat = module(input.feat)
+                    if "sparse_conv_feat" in input.keys():
+                        input.sparse_conv_feat = input.sparse_conv_feat.replace_feature(input.feat)
+                elif isinstance(input, spconv.SparseConvTensor):
+                    if input.indices.shape[0] != 0:
+                        input = input.replace_feature(module(input.features))
+                else:
+                    input = module(input)
+        return input
+
+
+class DropPath(nn.Module):
+    """timm.layers.DropPath: drops rows of dim 0, i.e. individual points for [N,C] features."""
+
+    def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return x * mask
+
+
+class SerializedAttention(PointModule):
+    def __init__(self, channels, num_heads, patch_size, qkv_bias=True, qk_scale=None, attn_drop=0.0, proj_drop=0.0,
+                 order_index=0, enable_rpe=False, enable_flash=True, upcast_attention=True, upcast_softmax=True):
+        super().__init__()
+        assert channels % num_heads == 0
+        if enable_rpe:
+            raise PtcoreError("enable_rpe=True is not implemented by the engine")
+        if channels // num_heads != 16:
+            raise PtcoreError(f"engine attention needs head_dim 16, got {channels // num_heads}")
+        if attn_drop != 0.0:
+            raise PtcoreError("attention dropout is not implemented (every reference config uses attn_drop=0.0)")
+        self.channels, self.num_heads = channels, num_heads
+        self.scale = qk_scale or (channels // num_heads) ** -0.5
+        self.order_index = order_index
+        self.patch_size = patch_size
+        self.enable_flash = enable_flash
+        self.qkv = nn.Linear(channels, channels * 3, bias=qkv_bias)
+        self.proj = nn.Linear(channels, channels)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    @torch.no_grad()
+    def get_padding_and_inverse(self, point):
+        """ptv3m1:114-170, one kernel launch; cached on the Point under the reference's keys."""
+        if "pad" not in point.keys() or "unpad" not in point.keys() or "cu_seqlens_key" not in point.keys():
+            _, offset_host = point._host_facts()
+            pad, unpad, cu, dup = ops.patch_pad_maps(point.offset, offset_host, self.patch_size)
+            point["pad"], point["unpad"], point["cu_seqlens_key"], point["_ptc_dup"] = pad, unpad, cu, dup
+        return point["pad"], point["unpad"], point["cu_seqlens_key"]
+
+    @torch.no_grad()
+    def _index_maps(self, point):
+        """per serialization order: gather index (padded slot -> point), its inverse (point -> slot),
+        and the two maps that make both backward passes pure gathers."""
+        key = f"_ptc_attn_maps_{self.order_index}"
+        if key not in point.keys():
+            pad, unpad, _ = self.get_padding_and_inverse(point)
+            order = point.serialized_order[self.order_index]
+            inverse = point.serialized_inverse[self.order_index]
+            gidx = order[pad]                      # ptv3m1:184
+            inv = unpad[inverse]                   # ptv3m1:185
+            dup_of_point = point["_ptc_dup"][inverse]   # second slot holding each point, or -1
+            slots = torch.arange(gidx.numel(), device=gidx.device)
+            gidx_primary = torch.where(inv[gidx] == slots, gidx, torch.full_like(gidx, -1))
+            point[key] = (gidx, inv, dup_of_point, gidx_primary)
+        return point[key]
+
+    def forward(self, point):
+        H, K, C = self.num_heads, self.patch_size, self.channels
+        _, _, cu_seqlens = self.get_padding_and_inverse(point)
+        gidx, inv, dup_of_point, gidx_primary = self._index_maps(point)
+        qkv = self.qkv(point.feat)
+        # padded, serialized qkv in bf16 (ptv3m1:188,209); backward = gather through (inv, dup)
+        qkv_s = PF.gather_rows(qkv.to(torch.bfloat16), gidx, inv, dup_of_point)
+        out = PF.attn_varlen_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale)
+        feat = PF.gather_rows(out.reshape(-1, C), inv, gidx_primary)      # ptv3m1:216
+        feat = feat.to(qkv.dtype)                                          # ptv3m1:215
+        feat = self.proj(feat)
+        feat = self.proj_drop(feat)
+        point.feat = feat
+        return point
+
+
+class MLP(nn.Module):
+    def __init__(self, in_channels, hidden_channels=None, out_channels=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_channels = out_channels or in_channels
+        hidden_channels = hidden_channels or in_channels
+        self.fc1 = nn.Linear(in_channels, hidden_channels)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_channels, out_channels)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+class Block(PointModule):
+    def __init__(self, channels, num_heads, patch_size=48, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, attn_drop=0.0,
+                 proj_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm, act_layer=nn.GELU, pre_norm=True,
+                 order_index=0, cpe_indice_key=None, enable_rpe=False, enable_flash=True, upcast_attention=True,
+                 upcast_softmax=True):
+        super().__init__()
+        self.channels, self.pre_norm = channels, pre_norm
+        self.cpe = PointSequential(
+            spconv.SubMConv3d(channels, channels, kernel_size=3, bias=True, indice_key=cpe_indice_key),
+            nn.Linear(channels, channels),
+            norm_layer(channels),
+        )
+        self.norm1 = PointSequential(norm_layer(channels))
+        self.attn = SerializedAttention(
+            channels=channels, patch_size=patch_size, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+            attn_drop=attn_drop, proj_drop=proj_drop, order_index=order_index, enable_rpe=enable_rpe,
+            enable_flash=enable_flash, upcast_attention=upcast_attention, upcast_softmax=upcast_softmax)
+        self.norm2 = PointSequential(norm_layer(channels))
+        self.mlp = PointSequential(MLP(in_channels=channels, hidden_channels=int(channels * mlp_ratio),
+                                       out_channels=channels, act_layer=act_layer, drop=proj_drop))
+        self.drop_path = PointSequential(DropPath(drop_path) if drop_path > 0.0 else nn.Identity())
+
+    def forward(self, point: Point):
+        shortcut = point.feat
+        point = self.cpe(point)  # consumes point.sparse_conv_feat.features (stale after unpooling: Appendix D.1)
+        point.feat = shortcut + point.feat
+        shortcut = point.feat
+        if self.pre_norm:
+            point = self.norm1(point)
+        point = self.drop_path(self.attn(point))
+        point.feat = shortcut + point.feat
+        if not self.pre_norm:
+            point = self.norm1(point)
+        shortcut = point.feat
+        if self.pre_norm:
+            point = self.norm2(point)
+        point = self.drop_path(self.mlp(point))
+        point.feat = shortcut + point.feat
+        if not self.pre_norm:
+            point = self.norm2(point)
+        point.sparse_conv_feat = point.sparse_conv_feat.replace_feature(point.feat)
+        return point
+
+
+class SerializedPooling(PointModule):
+    def __init__(self, in_channels, out_channels, stride=2, norm_layer=None, act_layer=None, reduce="max",
+                 shuffle_orders=True, traceable=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        assert stride == 2 ** (math.ceil(stride) - 1).bit_length()
+        self.stride = stride
+        assert reduce in ["sum", "mean", "min", "max"]
+        self.reduce, self.shuffle_orders, self.traceable = reduce, shuffle_orders, traceable
+        self.proj = nn.Linear(in_channels, out_channels)
+        if norm_layer is not None:
+            self.norm = PointSequential(norm_layer(out_channels))
+        if act_layer is not None:
+            self.act = PointSequential(act_layer())
+
+    def forward(self, point: Point):
+        pooling_depth = (math.ceil(self.stride) - 1).bit_length()
+        if pooling_depth > point.serialized_depth:
+            pooling_depth = 0
+        assert {"serialized_code", "serialized_order", "serialized_inverse", "serialized_depth"}.issubset(point.keys()), \
+            "Run point.serialization() point cloud before SerializedPooling"
+        shift = pooling_depth * 3
+        coord_max, offset_host = point._host_facts()
+        with torch.no_grad():
+            code, order0 = point.serialized_code, point.serialized_order[0]
+            # ptv3m1:383-396 without torch.unique / torch.sort: row 0 is already sorted
+            cluster, idx_ptr, head = ops.pool_maps(code[0], order0, shift)
+            child_code = ops.pool_child_codes(code, head, shift)                    # ptv3m1:398
+            depth = point.serialized_depth - pooling_depth
+            order, inverse = ops.sort_keys(child_code, 0, depth * 3 + len(offset_host).bit_length())  # :399-406
+            if self.shuffle_orders:
+                perm = torch.randperm(child_code.shape[0])                          # ptv3m1:409 (CPU RNG)
+                child_code, order, inverse = child_code[perm], order[perm], inverse[perm]
+            grid_coord = point.grid_coord[head] >> pooling_depth
+            batch = point.batch[head]
+        point_dict = AttrDict(
+            feat=PF.segment_csr(self.proj(point.feat), idx_ptr, self.reduce, perm=order0),   # ptv3m1:416-418
+            coord=PF.segment_csr(point.coord, idx_ptr, "mean", perm=order0),                   # ptv3m1:419-421
+            grid_coord=grid_coord,
+            serialized_code=child_code,
+            serialized_order=order,
+            serialized_inverse=inverse,
+            serialized_depth=depth,
+            batch=batch,
+        )
+        if "condition" in point.keys():
+            point_dict["condition"] = point.condition
+        if "context" in point.keys():
+            point_dict["context"] = point.context
+        if self.traceable:
+            point_dict["pooling_inverse"] = cluster
+            point_dict["pooling_parent"] = point
+        child = Point(point_dict)
+        # engine-side caches: CSR of the clusters (gather-form backward of unpooling) and host facts
+        child["_ptc_pool_csr"] = (order0, idx_ptr)
+        child["_ptc_coord_max"] = [int(m) >> pooling_depth for m in coord_max]
+        child["_ptc_offset_host"] = child.offset.tolist()
+        if getattr(self, "norm", None) is not None:
+            child = self.norm(child)
+        if getattr(self, "act", None) is not None:
+            child = self.act(child)
+        child.sparsify()
+        return child
+
+
+class SerializedUnpooling(PointModule):
+    def __init__(self, in_channels, skip_channels, out_channels, norm_layer=None, act_layer=None, traceable=False):
+        super().__init__()
+        self.proj = PointSequential(nn.Linear(in_channels, out_channels))
+        self.proj_skip = PointSequential(nn.Linear(skip_channels, out_channels))
+        if norm_layer is not None:
+            self.proj.add(norm_layer(out_channels))
+            self.proj_skip.add(norm_layer(out_channels))
+        if act_layer is not None:
+            self.proj.add(act_layer())
+            self.proj_skip.add(act_layer())
+        self.traceable = traceable
+
+    def forward(self, point):
+        assert "pooling_parent" in point.keys() and "pooling_inverse" in point.keys()
+        parent = point.pop("pooling_parent")
+        inverse = point.pop("pooling_inverse")
+        perm, idx_ptr = point["_ptc_pool_csr"]
+        point = self.proj(point)
+        parent = self.proj_skip(parent)
+        # ptv3m1:478 -- note: parent.sparse_conv_feat is NOT refreshed here (Appendix D.1)
+        parent.feat = parent.feat + PF.gather_by_cluster(point.feat, inverse, perm, idx_ptr)
+        if self.traceable:
+            parent["unpooling_parent"] = point
+        return parent
+
+
+class Embedding(PointModule):
+    def __init__(self, in_channels, embed_channels, norm_layer=None, act_layer=None):
+        super().__init__()
+        self.in_channels, self.embed_channels = in_channels, embed_channels
+        self.stem = PointSequential(conv=spconv.SubMConv3d(in_channels, embed_channels, kernel_size=5, padding=1,
+                                                           bias=False, indice_key="stem"))
+        if norm_layer is not None:
+            self.stem.add(norm_layer(embed_channels), name="norm")
+        if act_layer is not None:
+            self.stem.add(act_layer(), name="act")
+
+    def forward(self, point: Point):
+        return self.stem(point)
+
+
+class PointTransformerV3(PointModule):
+    """registry name "PT-v3m1" (ptv3m1:518); kwargs exactly as ptv3m1:520-552."""
+
+    def __init__(self, in_channels=6, order=("z", "z-trans"), stride=(2, 2, 2, 2), enc_depths=(2, 2, 2, 6, 2),
+                 enc_channels=(32, 64, 128, 256, 512), enc_num_head=(2, 4, 8, 16, 32),
+                 enc_patch_size=(48, 48, 48, 48, 48), dec_depths=(2, 2, 2, 2), dec_channels=(64, 64, 128, 256),
+                 dec_num_head=(4, 4, 8, 16), dec_patch_size=(48, 48, 48, 48), mlp_ratio=4, qkv_bias=True, qk_scale=None,
+                 attn_drop=0.0, proj_drop=0.0, drop_path=0.3, pre_norm=True, shuffle_orders=True, enable_rpe=False,
+                 enable_flash=True, upcast_attention=False, upcast_softmax=False, enc_mode=False, pdnorm_bn=False,
+                 pdnorm_ln=False, pdnorm_decouple=True, pdnorm_adaptive=False, pdnorm_affine=True,
+                 pdnorm_conditions=("ScanNet", "S3DIS", "Structured3D")):
+        super().__init__()
+        if pdnorm_bn or pdnorm_ln:
+            raise PtcoreError("PDNorm (pdnorm_bn / pdnorm_ln) is not implemented by the engine (off in all BASELINE configs)")
+        self.num_stages = len(enc_depths)
+        self.order = [order] if isinstance(order, str) else order
+        self.enc_mode = enc_mode
+        self.shuffle_orders = shuffle_orders
+        assert self.num_stages == len(stride) + 1 == len(enc_channels) == len(enc_num_head) == len(enc_patch_size)
+        assert self.enc_mode or self.num_stages == len(dec_depths) + 1 == len(dec_channels) + 1
+        assert self.enc_mode or self.num_stages == len(dec_num_head) + 1 == len(dec_patch_size) + 1
+
+        bn_layer = lambda c: nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)  # noqa: E731  (ptv3m1:581)
+        ln_layer = nn.LayerNorm
+        act_layer = nn.GELU
+        blk = dict(mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop,
+                   norm_layer=ln_layer, act_layer=act_layer, pre_norm=pre_norm, enable_rpe=enable_rpe,
+                   enable_flash=enable_flash, upcast_attention=upcast_attention, upcast_softmax=upcast_softmax)
+
+        self.embedding = Embedding(in_channels=in_channels, embed_channels=enc_channels[0], norm_layer=bn_layer,
+                                   act_layer=act_layer)
+        enc_dp = [x.item() for x in torch.linspace(0, drop_path, sum(enc_depths))]
+        self.enc = PointSequential()
+        for s in range(self.num_stages):
+            dp = enc_dp[sum(enc_depths[:s]):sum(enc_depths[:s + 1])]
+            enc = PointSequential()
+            if s > 0:
+                enc.add(SerializedPooling(in_channels=enc_channels[s - 1], out_channels=enc_channels[s],
+                                          stride=stride[s - 1], norm_layer=bn_layer, act_layer=act_layer), name="down")
+            for i in range(enc_depths[s]):
+                enc.add(Block(channels=enc_channels[s], num_heads=enc_num_head[s], patch_size=enc_patch_size[s],
+                              drop_path=dp[i], order_index=i % len(self.order), cpe_indice_key=f"stage{s}", **blk),
+                        name=f"block{i}")
+            if len(enc) != 0:
+                self.enc.add(module=enc, name=f"enc{s}")
+        if not self.enc_mode:
+            dec_dp = [x.item() for x in torch.linspace(0, drop_path, sum(dec_depths))]
+            self.dec = PointSequential()
+            dec_channels = list(dec_channels) + [enc_channels[-1]]
+            for s in reversed(range(self.num_stages - 1)):
+                dp = dec_dp[sum(dec_depths[:s]):sum(dec_depths[:s + 1])]
+                dp.reverse()
+                dec = PointSequential()
+                dec.add(SerializedUnpooling(in_channels=dec_channels[s + 1], skip_channels=enc_channels[s],
+                                            out_channels=dec_channels[s], norm_layer=bn_layer, act_layer=act_layer),
+                        name="up")
+                for i in range(dec_depths[s]):
+                    dec.add(Block(channels=dec_channels[s], num_heads=dec_num_head[s], patch_size=dec_patch_size[s],
+                                  drop_path=dp[i], order_index=i % len(self.order), cpe_indice_key=f"stage{s}", **blk),
+                            name=f"block{i}")
+                self.dec.add(module=dec, name=f"dec{s}")
+
+    def forward(self, data_dict):
+        point = Point(data_dict)
+        point.serialization(order=self.order, shuffle_orders=self.shuffle_orders)
+        point.sparsify()
+        point = self.embedding(point)
+        point = self.enc(point)
+        if not self.enc_mode:
+            point = self.dec(point)
+        return point

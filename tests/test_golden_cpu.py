@@ -1,0 +1,153 @@
+"""-m "not gpu": the oracle (and the g++-compiled copy of the kernels' pure helper functions)
+against the golden vectors produced by the REFERENCE's own code (tests/golden/make_golden.py),
+plus the C-ABI surface checks that need no GPU.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maps as omaps
+from oracle import sfc as osfc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
+DEPTHS = (1, 2, 5, 8, 9, 13, 16)
+
+
+def test_oracle_serialization_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, "serialization.npz"))
+    for d in DEPTHS:
+        gc, b, code = g[f"gc_{d}"], g[f"batch_{d}"], g[f"code_{d}"]
+        assert np.array_equal(osfc.encode_c(gc, b, d, ORDERS), code), f"C oracle, depth {d}"
+        assert np.array_equal(osfc.encode_py(gc[:64], b[:64], d, ORDERS), code[:, :64]), f"py oracle, depth {d}"
+
+
+def test_product_key_functions_match_reference_golden():
+    """sfc_keys.h (the functions inside serialize_encode_kernel) compiled for the host."""
+    from pointcept_amd import _lib
+
+    P = _lib.host_probe()
+    g = np.load(os.path.join(GOLD, "serialization.npz"))
+    oc = np.asarray([0, 1, 2, 3], dtype=np.int32)
+    for d in DEPTHS:
+        gc, b, code = np.ascontiguousarray(g[f"gc_{d}"]), np.ascontiguousarray(g[f"batch_{d}"]), g[f"code_{d}"]
+        out = np.empty_like(code)
+        P.probe_serialize_encode(gc.ctypes.data, b.ctypes.data, gc.shape[0], d, oc.ctypes.data, 4, out.ctypes.data)
+        assert np.array_equal(out, code), f"depth {d}"
+
+
+def test_hilbert_prefix_property():
+    """dropping 3 bits of a key gives the parent cell's key (what SerializedPooling relies on, ptv3m1:383,398)."""
+    rng = np.random.default_rng(0)
+    for d in (4, 9, 16):
+        gc = rng.integers(0, 1 << d, size=(500, 3), dtype=np.int64)
+        for o in ("z", "hilbert", "hilbert-trans", "z-trans"):
+            a = osfc.encode_c(gc, None, d, (o,))[0] >> 3
+            b = osfc.encode_c(gc >> 1, None, d - 1, (o,))[0]
+            assert np.array_equal(a, b), (d, o)
+
+
+def test_oracle_and_product_pad_maps_match_reference_golden():
+    from pointcept_amd import _lib
+
+    P = _lib.host_probe()
+    g = np.load(os.path.join(GOLD, "padmaps.npz"))
+    for ci in range(int(g["n_cases"])):
+        counts, K = g[f"counts_{ci}"], int(g[f"K_{ci}"])
+        off = np.cumsum(counts).astype(np.int64)
+        pad, unpad, cu = omaps.pad_maps(off, K)
+        assert np.array_equal(pad, g[f"pad_{ci}"]) and np.array_equal(unpad, g[f"unpad_{ci}"])
+        assert np.array_equal(cu, g[f"cu_{ci}"]) and cu.dtype == np.int32
+        n, n_pad, n_seq = int(off[-1]), len(pad), len(cu) - 1
+        from pointcept_amd.ops import pad_sizes
+
+        assert pad_sizes(off.tolist(), K) == (n, n_pad, n_seq)
+        p2, u2 = np.empty(n_pad, np.int64), np.empty(n, np.int64)
+        c2, d2 = np.empty(n_seq + 1, np.int32), np.empty(n, np.int64)
+        P.probe_patch_pad_maps(off.ctypes.data, len(off), K, n, n_pad, n_seq, p2.ctypes.data, u2.ctypes.data,
+                               c2.ctypes.data, d2.ctypes.data)
+        assert np.array_equal(p2, pad) and np.array_equal(u2, unpad) and np.array_equal(c2, cu)
+        assert np.array_equal(d2, omaps.dup_map(pad, unpad))
+
+
+def test_pad_maps_worked_example():
+    """bincount [10,3,7], K=4."""
+    pad, unpad, cu = omaps.pad_maps(np.array([10, 13, 20]), 4)
+    assert pad.tolist() == list(range(10)) + [6, 7] + [10, 11, 12] + list(range(13, 20)) + [16]
+    assert unpad.tolist() == list(range(10)) + [12, 13, 14] + list(range(15, 22))
+    assert cu.tolist() == [0, 4, 8, 12, 15, 19, 23]
+
+
+def test_oracle_pooling_maps_match_reference_golden():
+    g = np.load(os.path.join(GOLD, "pooling.npz"))
+    m = omaps.pooling_maps(g["parent_code"], 2, int(g["parent_depth"]))
+    assert np.array_equal(m["cluster"], g["cluster"])
+    assert np.array_equal(m["code"], g["child_code"])
+    assert np.array_equal(m["order"], g["child_order"]) and np.array_equal(m["inverse"], g["child_inverse"])
+    assert np.array_equal(g["grid_coord"][m["head"]] >> 1, g["child_grid_coord"])
+    assert np.array_equal(omaps.offset2batch(g["offset"])[m["head"]], g["child_batch"])
+    assert int(g["child_depth"]) == int(g["parent_depth"]) - 1
+
+
+def test_oracle_ptv3_tiny_matches_reference_golden():
+    """BASELINE config 1: the standalone oracle model reproduces the reference's output."""
+    from oracle import ptv3_model as om
+    from pointcept_amd import synthetic
+
+    g = np.load(os.path.join(GOLD, "ptv3_tiny.npz"))
+    cfg = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), dec_depths=(1, 1, 1, 1),
+               enc_patch_size=(1024,) * 5, dec_patch_size=(1024,) * 4, drop_path=0.0, shuffle_orders=False)
+    torch.manual_seed(0)
+    net = om.PointTransformerV3(**cfg)
+    sd = om.deterministic_state_dict(net, 0)
+    assert abs(sum(float(v.double().abs().sum()) for v in sd.values()) - float(g["weight_checksum"])) < 1e-3
+    net.load_state_dict(sd)
+    net.eval()
+    scene = synthetic.collate([synthetic.indoor_scene(int(g["scene_seed"]), int(g["n_points"]))])
+    assert scene["grid_coord"].sum() == g["input_checksum"][0]
+    torch.manual_seed(5)
+    with torch.no_grad():
+        out = net({k: torch.from_numpy(v) for k, v in scene.items()}).feat.numpy()
+    assert np.abs(out[::16] - g["feat_rows"]).max() <= 1e-4 * float(g["feat_absmax"])
+    assert np.allclose(np.linalg.norm(out.astype(np.float64), axis=1), g["feat_row_norm"], rtol=1e-4, atol=1e-4)
+
+
+# ---- C-ABI surface (no compute) -----------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    from pointcept_amd import _lib
+
+    header = open(os.path.join(os.path.dirname(GOLD), "..", "include", "ptcore.h")).read()
+    declared = set(re.findall(r"\b(ptc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ptc_stream_t"}
+    L = _lib.lib()  # raises if the library is missing / does not load
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/ptcore.h but not exported by libptcore.so"
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    assert b"gfx950" in L.ptc_version()
+
+
+def test_argument_validation_returns_error_codes():
+    from pointcept_amd import _lib
+
+    L = _lib.lib()
+    oc = (ctypes.c_int * 1)(0)
+    rc = L.ptc_serialize_encode(None, 1, None, 10, 17, ctypes.cast(oc, ctypes.c_void_p), 1, None, None)
+    assert rc == -1 and b"depth" in L.ptc_last_error()
+    rc = L.ptc_attn_varlen_fwd(None, None, 1, 10, 2, 4096, 0.25, 2, None, None, None)
+    assert rc == -2 and b"max_seqlen" in L.ptc_last_error()
+    rc = L.ptc_spconv_fwd(None, 10, None, None, None, 10, 27, 6, 32, 2, None, None)
+    assert rc == -2 and b"c_in" in L.ptc_last_error()
+
+
+def test_ops_refuse_cpu_tensors():
+    from pointcept_amd import ops
+    from pointcept_amd._lib import PtcoreError
+
+    with pytest.raises(PtcoreError, match="no CPU fallback"):
+        ops.gather_rows(torch.zeros(4, 8), torch.zeros(4, dtype=torch.long))
+    with pytest.raises(PtcoreError, match="no CPU fallback"):
+        ops.serialize_encode(torch.zeros(4, 3, dtype=torch.long), None, 4, ("z",))
