@@ -170,7 +170,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    last_loss = float(loss)
+    last_loss = float(loss.detach())
 
     if rank == 0:
         scenes_total = args.batch * world * args.steps

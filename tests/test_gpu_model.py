@@ -93,20 +93,30 @@ def test_ptv3_two_scenes_forward_backward_vs_oracle(cuda):
     torch.manual_seed(9)
     le = eng(synthetic.to_torch(batch, cuda))["loss"]
     le.backward()
-    assert abs(float(le) - float(lo)) < 2e-2 * abs(float(lo)), (float(le), float(lo))
+    assert abs(le.item() - lo.item()) < 2e-2 * abs(lo.item()), (le.item(), lo.item())
     go = dict(orc.named_parameters())
-    bad = []
+    rows = []
     for name, p in eng.named_parameters():
         assert p.grad is not None, f"no gradient for {name}"
         assert torch.isfinite(p.grad).all(), name
         r = go[name].grad
-        scale = float(r.abs().max())
-        if scale < 1e-12:
-            continue
-        rel = float((p.grad.cpu() - r).abs().max()) / scale
-        if rel > 0.1:
-            bad.append((name, rel))
-    assert not bad, f"gradient mismatch (rel max err > 0.1): {bad[:8]}"
+        rows.append((name, float((p.grad.cpu() - r).norm()), float(r.norm()), float(r.abs().max())))
+    gmax = max(r[3] for r in rows)
+    # Parameters whose true gradient is zero (biases feeding a batch-statistics BatchNorm) only carry
+    # rounding noise on both sides: compare those absolutely, the rest relatively (Frobenius norm).
+    report, bad = [], []
+    for name, dn, rn, rmax in rows:
+        rel = dn / max(rn, 1e-30)
+        report.append(f"{rel:10.3e} {rn:10.3e} {name}")
+        if rmax < 1e-5 * gmax:
+            if dn > 1e-4 * gmax * max(1.0, float(go[name].numel()) ** 0.5):
+                bad.append((name, rel, rn))
+        elif rel > 0.1:
+            bad.append((name, rel, rn))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/grad_report.txt", "w") as f:
+        f.write("rel_fro_err   ref_norm   parameter\n" + "\n".join(report) + "\n")
+    assert not bad, f"gradient mismatch: {bad[:8]}"
     # running statistics of the BatchNorm layers follow the same batch statistics
     for (k, a), (_, b) in zip(eng.backbone.state_dict().items(), orc.backbone.state_dict().items()):
         if k.endswith("running_mean") or k.endswith("running_var"):
