@@ -206,14 +206,37 @@ int ptc_rulebook_down_fill(const int32_t* indices, int64_t n_in, const int32_t* 
  *   c_in % 8 == 0 and c_out % 16 == 0 (the host zero-pads the 6-channel stem input).
  *   PTC_F32 uses the exact-f32 MFMA (16x16x4), PTC_F16/PTC_BF16 the 16x16x32 MFMA; fp32 accumulate.
  * wgrad: dw[c_out][kv][c_in] (fp32) = sum_o dout[o,:]^T (x) in[nbr[k][o],:]
+ *        dbias[c_out] (fp32, may be NULL) = sum_o dout[o,:]  (fused: one extra MFMA against ones)
+ * nbr == NULL (only with kv == 1) is the IDENTITY table: the same kernels then are the dense
+ * row-wise GEMMs of the nn.Linear layers on the path (ptv3m1:97-98,240-244,286,366,463-464;
+ * pointcept/models/default.py:52): out = in W^T + b, dX = dY W, dW = dY^T X, db = colsum(dY),
+ * tall-skinny shapes (N ~ 8e5 rows, 32..512 channels) that are HBM-bound.
  * ------------------------------------------------------------------------------------------ */
 int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float* bias,
                    const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out, int dtype,
                    void* out, ptc_stream_t stream);
 size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out);
 int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32_t* nbr,
-                     int64_t n_out, int kv, int c_in, int c_out, int dtype, float* dw,
+                     int64_t n_out, int kv, int c_in, int c_out, int dtype, float* dw, float* dbias,
                      void* workspace, size_t workspace_bytes, ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * G2. LayerNorm over channels of [n, c] features (nn.LayerNorm inside every PTv3 Block:
+ * ptv3m1:286 cpe.2, :289 norm1, :305 norm2).  c in {32,64,128,256,512} (ptc_layer_norm_supported).
+ *   fwd: y = (x-mean)*rstd*gamma + beta, statistics in fp32; y dtype may differ from x
+ *        (fp32 out under autocast, or bf16 out when the consumer is a bf16 GEMM);
+ *        mean[n], rstd[n] fp32 are saved for the backward.
+ *   bwd: dx (x's dtype), dgamma[c], dbeta[c] fp32 (either may be NULL).
+ * ------------------------------------------------------------------------------------------ */
+int ptc_layer_norm_supported(int c);
+int ptc_layer_norm_fwd(const void* x, int64_t n, int c, int in_dtype, const float* gamma,
+                       const float* beta, float eps, void* y, int out_dtype, float* mean, float* rstd,
+                       ptc_stream_t stream);
+size_t ptc_layer_norm_bwd_workspace_bytes(int64_t n, int c);
+int ptc_layer_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
+                       const float* rstd, const float* gamma, int64_t n, int c, void* dx,
+                       float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                       ptc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * H. Serialized (variable-length, fixed-window) attention, head_dim 16.

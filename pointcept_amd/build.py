@@ -28,6 +28,7 @@ HIP_SOURCES = [
     "rows.hip",
     "rulebook.hip",
     "spconv.hip",
+    "norm.hip",
     "attention.hip",
 ]
 CXX_SOURCES = ["core.cpp"]

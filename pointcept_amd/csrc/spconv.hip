@@ -20,6 +20,7 @@
 // Roofline: bytes = N_in*C_in*e + N_out*C_out*e + 4*kv*N_out (table) + kv*C_in*C_out*e,
 // flops = 2*P*C_in*C_out; HBM-bound for C <= 64, MFMA-bound above.
 #include "ptc_common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
@@ -69,6 +70,28 @@ __device__ __forceinline__ typename Mma<T>::frag ld_frag(const T* p) {
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad / inverse conv
 // ------------------------------------------------------------------------------------------------
+// Output-channel tiles are processed in groups of G in {4,2,1} tiles.  Inside a group the weight
+// rows are PERMUTED across the G MFMA tiles -- tile tt, A-row r  <->  channel 4G*(r>>2) + 4*tt + (r&3)
+// -- so that after the MFMAs lane (row, g) holds 4G CONSECUTIVE output channels (8G / 16G bytes):
+// one or two 16-byte stores per lane and 128 contiguous bytes per output row, instead of four
+// scattered 8-byte pieces.  The permutation is applied while W is staged into LDS (row p(n)).
+template <int NTILES> struct TileGroups {
+  // group start / size of tile t
+  static __host__ __device__ constexpr int gsize(int t) { return (NTILES - (t & ~3)) >= 4 ? 4 : (((NTILES & 3) - ((t & 3) & ~1)) >= 2 ? 2 : 1); }
+  static __host__ __device__ constexpr int gstart(int t) { return (NTILES - (t & ~3)) >= 4 ? (t & ~3) : (((NTILES & 3) - ((t & 3) & ~1)) >= 2 ? ((t & ~3) + ((t & 3) & ~1)) : t); }
+};
+
+// LDS row that holds natural weight row n (0 <= n < NTILES*16)
+template <int NTILES>
+__device__ __forceinline__ int lds_row_of_channel(int n) {
+  const int t0 = n >> 4;                       // tile the channel would naturally live in
+  const int gs = TileGroups<NTILES>::gstart(t0), G = TileGroups<NTILES>::gsize(t0);
+  const int local = n - 16 * gs;               // channel inside the group, [0, 16G)
+  const int gq = local / (4 * G), rem = local - gq * 4 * G;
+  const int tt = rem >> 2, e = rem & 3;
+  return 16 * (gs + tt) + 4 * gq + e;
+}
+
 template <typename T, int NTILES>
 __global__ void __launch_bounds__(256)
 spconv_fwd_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
@@ -94,18 +117,25 @@ spconv_fwd_kernel(const T* __restrict__ in, const T* __restrict__ w, const float
     for (int t = 0; t < NTILES; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int k = 0; k < kv; ++k) {
-    const int32_t ia = rowA < n_out ? nbr[(int64_t)k * n_out + rowA] : -1;
-    const int32_t ib = rowB < n_out ? nbr[(int64_t)k * n_out + rowB] : -1;
+    // nbr == nullptr: identity table (dense row-wise GEMM: Linear layers, 1x1x1 convs)
+    int32_t ia, ib;
+    if (nbr) {
+      ia = rowA < n_out ? nbr[(int64_t)k * n_out + rowA] : -1;
+      ib = rowB < n_out ? nbr[(int64_t)k * n_out + rowB] : -1;
+    } else {
+      ia = rowA < n_out ? (int32_t)rowA : -1;
+      ib = rowB < n_out ? (int32_t)rowB : -1;
+    }
     // barrier (protects the LDS tile of the previous k) + workgroup-wide "any neighbour at k"
     if (!__syncthreads_or((ia >= 0) | (ib >= 0))) continue;
     for (int c0 = 0; c0 < c_in; c0 += KC) {
       const int kc = (c_in - c0) < KC ? (c_in - c0) : KC;
       if (c0 > 0) __syncthreads();
-      // stage W[n0 .. n0+NT)[k][c0 .. c0+kc) -> LDS [NT][PITCH]
+      // stage W[n0 .. n0+NT)[k][c0 .. c0+kc) -> LDS row p(n), [NT][PITCH]
       const int vpr = kc / EPL;  // 16-byte vectors per row
       for (int q = threadIdx.x; q < NT * vpr; q += 256) {
         const int n = q / vpr, cc = q - n * vpr;
-        *reinterpret_cast<uint4*>(wl + n * PITCH + cc * EPL) =
+        *reinterpret_cast<uint4*>(wl + lds_row_of_channel<NTILES>(n) * PITCH + cc * EPL) =
             *reinterpret_cast<const uint4*>(w + ((int64_t)(n0 + n) * kv + k) * c_in + c0 + cc * EPL);
       }
       __syncthreads();
@@ -126,21 +156,43 @@ spconv_fwd_kernel(const T* __restrict__ in, const T* __restrict__ w, const float
       }
     }
   }
-  // epilogue: lane (row r, group g) holds channels n0 + t*16 + g*4 + {0..3} of rows rowA / rowB
+  // epilogue: for a group of G tiles starting at gs, lane (row r, group g) holds channels
+  // n0 + 16*gs + 4G*g + 4*tt + e  (tt < G, e < 4): 4G consecutive channels.
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int64_t row = s ? rowB : rowA;
     if (row >= n_out) continue;
 #pragma unroll
     for (int t = 0; t < NTILES; ++t) {
-      const int ch = n0 + t * 16 + g * 4;
-      f32x4 v = acc[s][t];
-      if (bias) { v[0] += bias[ch]; v[1] += bias[ch + 1]; v[2] += bias[ch + 2]; v[3] += bias[ch + 3]; }
-      T o4[4];
+      constexpr int dummy = 0; (void)dummy;
+      const int gs = TileGroups<NTILES>::gstart(t), G = TileGroups<NTILES>::gsize(t);
+      if (t != gs) continue;                      // one store sequence per group
+      const int ch0 = n0 + 16 * gs + 4 * G * g;
+      T o[16];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o4[e] = ptc_from_float<T>(v[e]);
-      if (sizeof(T) == 2) *reinterpret_cast<uint2*>(out + row * c_out + ch) = *reinterpret_cast<uint2*>(o4);
-      else *reinterpret_cast<uint4*>(out + row * c_out + ch) = *reinterpret_cast<uint4*>(o4);
+      for (int tt = 0; tt < 4; ++tt) {
+        if (tt < G) {
+          f32x4 v = acc[s][(gs + tt) < NTILES ? (gs + tt) : t];
+          if (bias) {
+            v[0] += bias[ch0 + 4 * tt]; v[1] += bias[ch0 + 4 * tt + 1];
+            v[2] += bias[ch0 + 4 * tt + 2]; v[3] += bias[ch0 + 4 * tt + 3];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[4 * tt + e] = ptc_from_float<T>(v[e]);
+        }
+      }
+      T* dst = out + row * c_out + ch0;
+      constexpr int BYTES4 = 4 * (int)sizeof(T);   // bytes of 4 channels
+      if (G == 4) {
+        if (BYTES4 == 8) { reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0]; reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<uint4*>(o)[1]; }
+        else { for (int q4 = 0; q4 < 4; ++q4) reinterpret_cast<uint4*>(dst)[q4] = reinterpret_cast<uint4*>(o)[q4]; }
+      } else if (G == 2) {
+        if (BYTES4 == 8) reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0];
+        else { reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0]; reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<uint4*>(o)[1]; }
+      } else {
+        if (BYTES4 == 8) reinterpret_cast<uint2*>(dst)[0] = reinterpret_cast<uint2*>(o)[0];
+        else reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0];
+      }
     }
   }
 }
@@ -173,7 +225,8 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
   PTC_REQUIRE(c_in >= 8 && c_in % 8 == 0, PTC_EUNSUPPORTED, "ptc_spconv_fwd: c_in=%d must be a multiple of 8", c_in);
   PTC_REQUIRE(c_out >= 16 && c_out % 16 == 0, PTC_EUNSUPPORTED, "ptc_spconv_fwd: c_out=%d must be a multiple of 16", c_out);
   if (n_out == 0) return PTC_OK;
-  PTC_REQUIRE(weight && nbr && out && (n_in == 0 || in), PTC_EINVAL, "ptc_spconv_fwd: null buffer");
+  PTC_REQUIRE(weight && out && (n_in == 0 || in), PTC_EINVAL, "ptc_spconv_fwd: null buffer");
+  PTC_REQUIRE(nbr || (kv == 1 && n_in >= n_out), PTC_EINVAL, "ptc_spconv_fwd: nbr may be NULL only for kv == 1 (identity table)");
   PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)out % 16 == 0), PTC_EINVAL,
               "ptc_spconv_fwd: buffers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
@@ -194,7 +247,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 spconv_wgrad_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_t* __restrict__ nbr,
                     int64_t n_out, int kv, int c_in, int c_out, int64_t rows_per_split, int ci_tiles,
-                    float* __restrict__ partial) {
+                    float* __restrict__ partial, float* __restrict__ bias_partial) {
   using M = Mma<T>;
   constexpr int EPL = M::EPL, KS = M::KS;
   constexpr int PITCH = WG_RO + EPL;  // elements; rows of 16-byte multiples
@@ -213,6 +266,17 @@ spconv_wgrad_kernel(const T* __restrict__ in, const T* __restrict__ dout, const 
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of dout: one extra MFMA per k-step against an all-ones B operand,
+  // done by the workgroups of table row 0 / input-channel tile 0 only
+  const bool do_bias = bias_partial != nullptr && k == 0 && (blockIdx.z % ci_tiles) == 0;
+  f32x4 acc_b = (f32x4){0.f, 0.f, 0.f, 0.f};
+  typename M::frag ones;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    if (sizeof(T) == 4) reinterpret_cast<float*>(&ones)[e] = 1.0f;
+    else if (std::is_same<T, bf16_t>::value) reinterpret_cast<uint16_t*>(&ones)[e] = 0x3F80;
+    else reinterpret_cast<uint16_t*>(&ones)[e] = 0x3C00;
+  }
 
   for (int64_t chunk = begin; chunk < end; chunk += WG_RO) {
     __syncthreads();  // previous chunk fully consumed
@@ -224,12 +288,12 @@ spconv_wgrad_kernel(const T* __restrict__ in, const T* __restrict__ dout, const 
       const bool cov = (co0 + cv * 8) < c_out, civ = (ci0 + cv * 8) < c_in;
       if (ra < end) {
         if (cov) da = *reinterpret_cast<const uint4*>(dout + ra * c_out + co0 + cv * 8);
-        const int32_t j = nbr[(int64_t)k * n_out + ra];
+        const int32_t j = nbr ? nbr[(int64_t)k * n_out + ra] : (int32_t)ra;
         if (civ && j >= 0) xa = *reinterpret_cast<const uint4*>(in + (int64_t)j * c_in + ci0 + cv * 8);
       }
       if (rb < end) {
         if (cov) db = *reinterpret_cast<const uint4*>(dout + rb * c_out + co0 + cv * 8);
-        const int32_t j = nbr[(int64_t)k * n_out + rb];
+        const int32_t j = nbr ? nbr[(int64_t)k * n_out + rb] : (int32_t)rb;
         if (civ && j >= 0) xb = *reinterpret_cast<const uint4*>(in + (int64_t)j * c_in + ci0 + cv * 8);
       }
       const uint16_t* pa = reinterpret_cast<const uint16_t*>(&da);
@@ -247,7 +311,7 @@ spconv_wgrad_kernel(const T* __restrict__ in, const T* __restrict__ dout, const 
       // fp32: thread -> (row rr, channel vector cv), 4 passes cover 16 vectors x 4 floats
       const int rr = threadIdx.x & 63;
       const int64_t row = chunk + rr;
-      const int32_t j = row < end ? nbr[(int64_t)k * n_out + row] : -1;
+      const int32_t j = row < end ? (nbr ? nbr[(int64_t)k * n_out + row] : (int32_t)row) : -1;
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int cv = (threadIdx.x >> 6) + pass * 4;  // [0,16)
@@ -269,11 +333,19 @@ spconv_wgrad_kernel(const T* __restrict__ in, const T* __restrict__ dout, const 
     for (int ks = 0; ks < WG_RO / KS; ++ks) {
       const int kk = ks * KS + g * EPL;
       const typename M::frag fa = ld_frag<T>(dT + (wave * 16 + r) * PITCH + kk);  // A: i = co, k = rows
+      if (do_bias) acc_b = M::mma(fa, ones, acc_b);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const typename M::frag fb = ld_frag<T>(iT + (t * 16 + r) * PITCH + kk);    // B: j = ci
         acc[t] = M::mma(fa, fb, acc[t]);
       }
+    }
+  }
+  if (do_bias && r == 0) {  // every column j of acc_b holds the same column sum
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = co0 + wave * 16 + g * 4 + e;
+      if (co < c_out) bias_partial[(int64_t)blockIdx.x * c_out + co] = acc_b[e];
     }
   }
   // D[i = co][j = ci]: lane (j = r) holds co = wave*16 + g*4 + e
@@ -311,29 +383,36 @@ static int wgrad_splits(int64_t n_out, int kv, int c_in, int c_out) {
 }
 
 extern "C" size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out) {
-  return ptc_align_up((size_t)wgrad_splits(n_out, kv, c_in, c_out) * (size_t)c_out * kv * c_in * sizeof(float), 256);
+  const size_t splits = (size_t)wgrad_splits(n_out, kv, c_in, c_out);
+  return ptc_align_up(splits * (size_t)c_out * kv * c_in * sizeof(float), 256) + ptc_align_up(splits * (size_t)c_out * sizeof(float), 256);
 }
 
 template <typename T>
 static int launch_wgrad(const void* in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in,
-                        int c_out, float* dw, void* ws, hipStream_t s) {
+                        int c_out, float* dw, float* dbias, void* ws, hipStream_t s) {
   const int splits = wgrad_splits(n_out, kv, c_in, c_out);
+  float* bias_partial = dbias ? (float*)((char*)ws + ptc_align_up((size_t)splits * (size_t)c_out * kv * c_in * sizeof(float), 256)) : nullptr;
   const int ci_tiles = (int)ptc_cdiv(c_in, WG_CT), co_tiles = (int)ptc_cdiv(c_out, WG_CT);
   int64_t rps = ptc_cdiv(ptc_cdiv(n_out, splits), WG_RO) * WG_RO;
   dim3 grid((unsigned)splits, (unsigned)kv, (unsigned)(ci_tiles * co_tiles));
   hipLaunchKernelGGL((spconv_wgrad_kernel<T>), grid, dim3(256), 0, s, (const T*)in, (const T*)dout, nbr, n_out, kv,
-                     c_in, c_out, rps, ci_tiles, (float*)ws);
+                     c_in, c_out, rps, ci_tiles, (float*)ws, bias_partial);
   PTC_CHECK_LAUNCH("spconv_wgrad_kernel");
   const int64_t count = (int64_t)c_out * kv * c_in;
   int64_t rgrid = ptc_cdiv(count, 256);
   if (rgrid > 4096) rgrid = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, (const float*)ws, splits, count, dw);
   PTC_CHECK_LAUNCH("wgrad_reduce_kernel");
+  if (dbias) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ptc_cdiv(c_out, 256)), dim3(256), 0, s, (const float*)bias_partial,
+                       splits, (int64_t)c_out, dbias);
+    PTC_CHECK_LAUNCH("wgrad_reduce_kernel(bias)");
+  }
   return PTC_OK;
 }
 
 extern "C" int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out,
-                                int kv, int c_in, int c_out, int dtype, float* dw, void* workspace,
+                                int kv, int c_in, int c_out, int dtype, float* dw, float* dbias, void* workspace,
                                 size_t workspace_bytes, ptc_stream_t stream) {
   PTC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1, PTC_EINVAL, "ptc_spconv_wgrad: bad sizes");
   PTC_REQUIRE(c_in >= 8 && c_in % 8 == 0 && c_out >= 8 && c_out % 8 == 0, PTC_EUNSUPPORTED,
@@ -344,9 +423,11 @@ extern "C" int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, 
   hipStream_t s = (hipStream_t)stream;
   if (n_out == 0) {
     PTC_HIP(hipMemsetAsync(dw, 0, (size_t)c_out * kv * c_in * sizeof(float), s));
+    if (dbias) PTC_HIP(hipMemsetAsync(dbias, 0, (size_t)c_out * sizeof(float), s));
     return PTC_OK;
   }
-  PTC_REQUIRE(in && dout && nbr, PTC_EINVAL, "ptc_spconv_wgrad: null buffer");
-  PTC_DISPATCH_DTYPE(dtype, T, return launch_wgrad<T>(in, dout, nbr, n_out, kv, c_in, c_out, dw, workspace, s));
+  PTC_REQUIRE(in && dout, PTC_EINVAL, "ptc_spconv_wgrad: null buffer");
+  PTC_REQUIRE(nbr || (kv == 1 && n_in >= n_out), PTC_EINVAL, "ptc_spconv_wgrad: nbr may be NULL only for kv == 1 (identity table)");
+  PTC_DISPATCH_DTYPE(dtype, T, return launch_wgrad<T>(in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s));
   return PTC_OK;
 }

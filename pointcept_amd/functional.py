@@ -21,9 +21,13 @@ from . import ops
 from ._lib import PtcoreError
 
 
+def _autocast_on() -> bool:
+    return torch.is_autocast_enabled("cuda")
+
+
 def _autocast_dtype(t: torch.Tensor) -> torch.dtype:
-    if torch.is_autocast_enabled():
-        return torch.get_autocast_gpu_dtype()
+    if _autocast_on():
+        return torch.get_autocast_dtype("cuda")
     return t.dtype
 
 
@@ -150,6 +154,95 @@ class _SparseConv(Function):
 def sparse_conv(feat, weight, bias, nbr, nbr_t, mirror: bool):
     """weight: [C_out, kv, C_in] (a view of the spconv-layout parameter [C_out,k0,k1,k2,C_in])."""
     return _SparseConv.apply(feat, weight, bias, nbr, nbr_t, mirror)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense row-wise GEMM (nn.Linear on [N,C] point features) on the sparse-conv MFMA kernels
+# ------------------------------------------------------------------------------------------------
+class _Linear(Function):
+    """out[o] = W x[tab[o]] + b.  tab_fwd [1, n_out] int32 (None = identity) folds a row gather into
+    the GEMM; tab_bwd [k, n_in] int32 lists, for every input row, the output rows that read it
+    (-1 = none), which makes the input gradient a gather too: dx[p] = sum_k dout[tab_bwd[k][p]] W."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, tab_fwd, tab_bwd):
+        dt = _autocast_dtype(x)
+        c_out, c_in = weight.shape
+        xp = _pad_to(x.to(dt), 1, 16).contiguous()
+        wp = _pad_to(_pad_to(weight.to(dt), 1, 16), 0, 16).contiguous()
+        bp = None if bias is None else _pad_to(bias.float(), 0, 16)
+        out = ops.spconv_fwd(xp, wp[:, None, :], bp, tab_fwd)
+        ctx.save_for_backward(xp, wp, tab_fwd, tab_bwd)
+        ctx.shape = (c_out, c_in)
+        ctx.in_dtype, ctx.w_dtype = x.dtype, weight.dtype
+        ctx.b_dtype = None if bias is None else bias.dtype
+        return out[:, :c_out] if out.shape[1] != c_out else out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        xp, wp, tab_fwd, tab_bwd = ctx.saved_tensors
+        c_out, c_in = ctx.shape
+        g = _pad_to(grad.to(xp.dtype), 1, 16).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = wp.t().contiguous()[:, None, :]                       # [c_in, 1, c_out]
+            if tab_bwd is not None and tab_bwd.shape[0] > 1:
+                wt = wt.expand(-1, tab_bwd.shape[0], -1).contiguous()   # same W for every slot
+            dx = ops.spconv_fwd(g, wt, None, tab_bwd)[:, :c_in].to(ctx.in_dtype)
+        if ctx.needs_input_grad[1] or (ctx.b_dtype is not None and ctx.needs_input_grad[2]):
+            want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
+            res = ops.spconv_wgrad(xp, g, tab_fwd, want_bias=want_b)
+            dwp, dbp = res if want_b else (res, None)
+            dw = dwp[:c_out, 0, :c_in].to(ctx.w_dtype)
+            if want_b:
+                db = dbp[:c_out].to(ctx.b_dtype)
+        return dx, dw, db, None, None
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           tab_fwd: Optional[torch.Tensor] = None, tab_bwd: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.linear for [N, C_in] point features: out = x W^T + b, autocast-aware (bf16 operands, fp32
+    accumulate), forward / dgrad / wgrad (+ fused bias gradient) on the identity-table MFMA kernels.
+    With (tab_fwd, tab_bwd) the GEMM also applies a row permutation-with-padding:
+    out[o] = W x[tab_fwd[0][o]] + b  (= F.linear(x)[tab] = F.linear(x[tab]): a row-wise map commutes
+    with a row gather), which removes the separate gather pass around serialized attention."""
+    if x.dim() != 2:
+        raise PtcoreError("linear expects [N, C] features")
+    if (tab_fwd is None) != (tab_bwd is None):
+        raise PtcoreError("linear: tab_fwd and tab_bwd go together")
+    return _Linear.apply(x, weight, bias, tab_fwd, tab_bwd)
+
+
+# ------------------------------------------------------------------------------------------------
+# layer norm
+# ------------------------------------------------------------------------------------------------
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        y, mean, rstd = ops.layer_norm_fwd(x, weight, bias, eps, out_dtype)
+        ctx.save_for_backward(x, mean, rstd, weight)
+        ctx.has_affine = weight is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, mean, rstd, weight = ctx.saved_tensors
+        dx, dg, db = ops.layer_norm_bwd(dy, x, mean, rstd, weight, want_affine=ctx.has_affine)
+        if ctx.has_affine:
+            dg, db = dg.to(weight.dtype), db.to(weight.dtype)
+        return dx, dg, db, None, None
+
+
+def layer_norm(x: torch.Tensor, weight, bias, eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None):
+    """nn.LayerNorm over the last dim of [N,C].  Default output dtype follows PyTorch: fp32 under
+    autocast (layer_norm is an fp32 autocast op) else x.dtype; `out_dtype=torch.bfloat16` lets the
+    caller take the value already rounded for a following bf16 GEMM (same number the autocast
+    cast would produce, one HBM pass less)."""
+    if out_dtype is None:
+        out_dtype = torch.float32 if (_autocast_on() or x.dtype == torch.float32) else x.dtype
+    return _LayerNorm.apply(x, weight, bias, float(eps), out_dtype)
 
 
 # ------------------------------------------------------------------------------------------------

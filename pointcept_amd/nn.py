@@ -1,0 +1,55 @@
+"""Parameter-compatible replacements for the dense per-point layers of the PTv3 path.
+
+`Linear` / `LayerNorm` subclass torch's modules (same parameters, same state-dict keys, same
+initialisation: pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:97-98,240-244,
+286-305,366,463-464) and only change WHERE forward runs: [N, C] CUDA features go to libptcore.so
+(tall-skinny MFMA GEMMs with split-K weight gradients, one-pass LayerNorm), anything else -- CPU
+construction-time calls, 3-D inputs -- stays on torch.  No numerics are silently traded: the
+kernels accumulate in fp32 and round operands exactly where autocast would.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import config
+from . import functional as PF
+from . import ops
+
+# hipBLASLt is well tuned for square-ish GEMMs; the engine kernels win on the tall-skinny shapes of
+# point features (N ~ 1e4..1e6 rows, C <= 512) and on every weight gradient (contraction over N).
+_OWN_MAX_CIN = 512
+_OWN_MAX_COUT = 2048
+
+
+def _own_linear_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    if not (config.OWN_LINEAR and x.is_cuda and x.dim() == 2 and x.shape[0] > 0):
+        return False
+    if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        return False
+    return weight.shape[1] <= _OWN_MAX_CIN and weight.shape[0] <= _OWN_MAX_COUT
+
+
+class Linear(nn.Linear):
+    def forward(self, x: torch.Tensor, tab_fwd: Optional[torch.Tensor] = None,
+                tab_bwd: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if tab_fwd is not None or _own_linear_ok(x, self.weight):
+            return PF.linear(x, self.weight, self.bias, tab_fwd, tab_bwd)
+        return F.linear(x, self.weight, self.bias)
+
+
+class LayerNorm(nn.LayerNorm):
+    gemm_consumer = False  # set by Block when the only reader of the output is a GEMM
+
+    def forward(self, x: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        if out_dtype is None and self.gemm_consumer and x.is_cuda and torch.is_autocast_enabled("cuda"):
+            out_dtype = torch.get_autocast_dtype("cuda")  # the value autocast's cast would produce anyway
+        if (config.OWN_NORM and x.is_cuda and x.dim() == 2 and len(self.normalized_shape) == 1
+                and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+                and ops.layer_norm_supported(x.shape[1]) and x.shape[0] > 0):
+            return PF.layer_norm(x, self.weight, self.bias, self.eps, out_dtype)
+        y = F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+        return y if out_dtype is None else y.to(out_dtype)

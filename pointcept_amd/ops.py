@@ -247,43 +247,97 @@ def rulebook_down(indices: torch.Tensor, coord_bits: int, batch_bits: int):
 # ------------------------------------------------------------------------------------------------
 # sparse conv compute
 # ------------------------------------------------------------------------------------------------
-def spconv_fwd(feat: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], nbr: torch.Tensor) -> torch.Tensor:
+def spconv_fwd(feat: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+               nbr: Optional[torch.Tensor]) -> torch.Tensor:
     """out[o] = bias + sum_k W[:,k,:] . feat[nbr[k][o]].  weight [C_out, kv, C_in] in feat.dtype,
-    bias fp32.  C_in % 8 == 0 and C_out % 16 == 0 (callers pad)."""
+    bias fp32.  C_in % 8 == 0 and C_out % 16 == 0 (callers pad).  nbr=None (kv == 1): identity
+    table, i.e. the dense row-wise GEMM out = feat @ W[:,0,:]^T + bias."""
     require_cuda(feat, weight, bias, nbr)
     feat = feat.contiguous()
     weight = weight.contiguous()
-    nbr = nbr.contiguous()
     if weight.dtype != feat.dtype:
         raise PtcoreError("weight dtype must match feature dtype")
     c_out, kv, c_in = weight.shape
-    if feat.shape[1] != c_in or nbr.shape[0] != kv or nbr.dtype != torch.int32:
-        raise PtcoreError(f"shape mismatch: feat {tuple(feat.shape)} weight {tuple(weight.shape)} nbr {tuple(nbr.shape)}")
+    if nbr is not None:
+        nbr = nbr.contiguous()
+        if nbr.shape[0] != kv or nbr.dtype != torch.int32:
+            raise PtcoreError(f"table mismatch: weight {tuple(weight.shape)} nbr {tuple(nbr.shape)} {nbr.dtype}")
+    elif kv != 1:
+        raise PtcoreError("nbr=None needs kv == 1")
+    if feat.shape[1] != c_in:
+        raise PtcoreError(f"shape mismatch: feat {tuple(feat.shape)} weight {tuple(weight.shape)}")
     if bias is not None:
         bias = bias.to(torch.float32).contiguous()
-    n_out = nbr.shape[1]
+    n_out = nbr.shape[1] if nbr is not None else feat.shape[0]
     out = torch.empty((n_out, c_out), dtype=feat.dtype, device=feat.device)
     check(lib().ptc_spconv_fwd(ptr(feat), feat.shape[0], ptr(weight), ptr(bias), ptr(nbr), n_out, kv, c_in, c_out,
                                dtype_code(feat), ptr(out), stream_ptr()), "ptc_spconv_fwd")
     return out
 
 
-def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: torch.Tensor) -> torch.Tensor:
-    """dw [C_out, kv, C_in] fp32 = sum_o dout[o]^T (x) feat[nbr[k][o]]."""
+def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: Optional[torch.Tensor], want_bias: bool = False):
+    """dw [C_out, kv, C_in] fp32 = sum_o dout[o]^T (x) feat[nbr[k][o]]  (nbr=None: identity, kv=1);
+    with want_bias also dbias [C_out] fp32 = column sums of dout (fused).  Returns dw or (dw, dbias)."""
     require_cuda(feat, dout, nbr)
     feat = feat.contiguous()
     dout = dout.contiguous()
-    nbr = nbr.contiguous()
     if feat.dtype != dout.dtype:
         raise PtcoreError("feat / dout dtype mismatch")
-    kv, n_out = nbr.shape
+    if nbr is not None:
+        nbr = nbr.contiguous()
+        kv, n_out = nbr.shape
+    else:
+        kv, n_out = 1, dout.shape[0]
     c_in, c_out = feat.shape[1], dout.shape[1]
     dw = torch.empty((c_out, kv, c_in), dtype=torch.float32, device=feat.device)
+    db = torch.empty(c_out, dtype=torch.float32, device=feat.device) if want_bias else None
     nbytes = lib().ptc_spconv_wgrad_workspace_bytes(n_out, kv, c_in, c_out)
     ws = _ws(nbytes, feat.device)
     check(lib().ptc_spconv_wgrad(ptr(feat), feat.shape[0], ptr(dout), ptr(nbr), n_out, kv, c_in, c_out,
-                                 dtype_code(feat), ptr(dw), ptr(ws), nbytes, stream_ptr()), "ptc_spconv_wgrad")
-    return dw
+                                 dtype_code(feat), ptr(dw), ptr(db), ptr(ws), nbytes, stream_ptr()), "ptc_spconv_wgrad")
+    return (dw, db) if want_bias else dw
+
+
+# ------------------------------------------------------------------------------------------------
+# layer norm
+# ------------------------------------------------------------------------------------------------
+_DT = {torch.float32: _lib.PTC_F32, torch.float16: _lib.PTC_F16, torch.bfloat16: _lib.PTC_BF16}
+
+
+def layer_norm_supported(c: int) -> bool:
+    return bool(lib().ptc_layer_norm_supported(int(c)))
+
+
+def layer_norm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype: torch.dtype):
+    """y [N,C] (out_dtype), mean [N], rstd [N] (fp32).  gamma / beta fp32 or None."""
+    require_cuda(x, gamma, beta)
+    x = x.contiguous()
+    n, c = x.shape
+    g = None if gamma is None else gamma.to(torch.float32).contiguous()
+    b = None if beta is None else beta.to(torch.float32).contiguous()
+    y = torch.empty((n, c), dtype=out_dtype, device=x.device)
+    mean = torch.empty(n, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n, dtype=torch.float32, device=x.device)
+    check(lib().ptc_layer_norm_fwd(ptr(x), n, c, dtype_code(x), ptr(g), ptr(b), float(eps), ptr(y), _DT[out_dtype],
+                                   ptr(mean), ptr(rstd), stream_ptr()), "ptc_layer_norm_fwd")
+    return y, mean, rstd
+
+
+def layer_norm_bwd(dy: torch.Tensor, x: torch.Tensor, mean, rstd, gamma, want_affine: bool = True):
+    """dx (x.dtype), dgamma, dbeta (fp32 or None)."""
+    require_cuda(dy, x, mean, rstd, gamma)
+    dy = dy.contiguous()
+    x = x.contiguous()
+    n, c = x.shape
+    g = None if gamma is None else gamma.to(torch.float32).contiguous()
+    dx = torch.empty_like(x)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine else None
+    db = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine else None
+    nbytes = lib().ptc_layer_norm_bwd_workspace_bytes(n, c)
+    ws = _ws(nbytes, x.device)
+    check(lib().ptc_layer_norm_bwd(ptr(dy), dtype_code(dy), ptr(x), dtype_code(x), ptr(mean), ptr(rstd), ptr(g), n, c,
+                                   ptr(dx), ptr(dg), ptr(db), ptr(ws), nbytes, stream_ptr()), "ptc_layer_norm_bwd")
+    return dx, dg, db
 
 
 # ------------------------------------------------------------------------------------------------

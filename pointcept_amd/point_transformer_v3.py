@@ -9,7 +9,10 @@ protocol in and out), with the hot path on libptcore.so:
   SerializedPooling / Unpooling       -> scan-based cluster maps, fused gather+segment reduce,
                                          gather-form backward (replaces torch.unique/sort + torch_scatter)
   CPE / stem SubMConv3d               -> hash rulebook + MFMA implicit GEMM             (spconv_api.py)
-Dense Linear / LayerNorm / BatchNorm / GELU stay on PyTorch-ROCm (hipBLASLt / ATen).
+  nn.Linear / nn.LayerNorm            -> tall-skinny MFMA GEMMs with split-K weight gradients, the
+                                         serialization gather folded into the qkv / proj GEMMs;
+                                         one-pass LayerNorm                             (nn.py)
+BatchNorm / GELU / residual adds stay on PyTorch-ROCm (ATen).
 
 Behaviours of the reference that change numerics are reproduced on purpose:
 stale sparse_conv_feat in the first decoder block's CPE (D.1), per-point DropPath (D.2), CPU-RNG
@@ -26,7 +29,9 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from . import config
 from . import functional as PF
+from . import nn as PNN
 from . import ops
 from . import spconv_api as spconv
 from ._lib import PtcoreError
@@ -122,8 +127,8 @@ class SerializedAttention(PointModule):
         self.order_index = order_index
         self.patch_size = patch_size
         self.enable_flash = enable_flash
-        self.qkv = nn.Linear(channels, channels * 3, bias=qkv_bias)
-        self.proj = nn.Linear(channels, channels)
+        self.qkv = PNN.Linear(channels, channels * 3, bias=qkv_bias)
+        self.proj = PNN.Linear(channels, channels)
         self.proj_drop = nn.Dropout(proj_drop)
 
     @torch.no_grad()
@@ -138,7 +143,8 @@ class SerializedAttention(PointModule):
     @torch.no_grad()
     def _index_maps(self, point):
         """per serialization order: gather index (padded slot -> point), its inverse (point -> slot),
-        and the two maps that make both backward passes pure gathers."""
+        and the two maps that make both backward passes pure gathers; plus the same four maps as the
+        int32 kv = 1 / kv = 2 gather tables that fold the permutation into the qkv / proj GEMMs."""
         key = f"_ptc_attn_maps_{self.order_index}"
         if key not in point.keys():
             pad, unpad, _ = self.get_padding_and_inverse(point)
@@ -149,20 +155,34 @@ class SerializedAttention(PointModule):
             dup_of_point = point["_ptc_dup"][inverse]   # second slot holding each point, or -1
             slots = torch.arange(gidx.numel(), device=gidx.device)
             gidx_primary = torch.where(inv[gidx] == slots, gidx, torch.full_like(gidx, -1))
-            point[key] = (gidx, inv, dup_of_point, gidx_primary)
+            tabs = None
+            if config.FUSE_GATHER:
+                tabs = (gidx.to(torch.int32)[None].contiguous(),                       # qkv forward  [1, N']
+                        torch.stack([inv, dup_of_point]).to(torch.int32).contiguous(),  # qkv backward [2, N]
+                        inv.to(torch.int32)[None].contiguous(),                        # proj forward [1, N]
+                        gidx_primary.to(torch.int32)[None].contiguous())               # proj backward [1, N']
+            point[key] = (gidx, inv, dup_of_point, gidx_primary, tabs)
         return point[key]
 
     def forward(self, point):
         H, K, C = self.num_heads, self.patch_size, self.channels
         _, _, cu_seqlens = self.get_padding_and_inverse(point)
-        gidx, inv, dup_of_point, gidx_primary = self._index_maps(point)
-        qkv = self.qkv(point.feat)
-        # padded, serialized qkv in bf16 (ptv3m1:188,209); backward = gather through (inv, dup)
-        qkv_s = PF.gather_rows(qkv.to(torch.bfloat16), gidx, inv, dup_of_point)
-        out = PF.attn_varlen_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale)
-        feat = PF.gather_rows(out.reshape(-1, C), inv, gidx_primary)      # ptv3m1:216
-        feat = feat.to(qkv.dtype)                                          # ptv3m1:215
-        feat = self.proj(feat)
+        gidx, inv, dup_of_point, gidx_primary, tabs = self._index_maps(point)
+        if tabs is not None:
+            # qkv[order] == Linear(feat[order]): the GEMM reads its rows through the gather table and
+            # writes the padded, serialized qkv directly (ptv3m1:188); proj reads the attention output
+            # through the inverse table (ptv3m1:216,219).  Two full gather passes less per block.
+            qkv_s = self.qkv(point.feat, tabs[0], tabs[1])
+            out = PF.attn_varlen_qkvpacked(qkv_s.to(torch.bfloat16).reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale)
+            feat = self.proj(out.reshape(-1, C).to(qkv_s.dtype), tabs[2], tabs[3])   # ptv3m1:215
+        else:
+            qkv = self.qkv(point.feat)
+            # padded, serialized qkv in bf16 (ptv3m1:188,209); backward = gather through (inv, dup)
+            qkv_s = PF.gather_rows(qkv.to(torch.bfloat16), gidx, inv, dup_of_point)
+            out = PF.attn_varlen_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale)
+            feat = PF.gather_rows(out.reshape(-1, C), inv, gidx_primary)      # ptv3m1:216
+            feat = feat.to(qkv.dtype)                                          # ptv3m1:215
+            feat = self.proj(feat)
         feat = self.proj_drop(feat)
         point.feat = feat
         return point
@@ -173,9 +193,9 @@ class MLP(nn.Module):
         super().__init__()
         out_channels = out_channels or in_channels
         hidden_channels = hidden_channels or in_channels
-        self.fc1 = nn.Linear(in_channels, hidden_channels)
+        self.fc1 = PNN.Linear(in_channels, hidden_channels)
         self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_channels, out_channels)
+        self.fc2 = PNN.Linear(hidden_channels, out_channels)
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
@@ -191,7 +211,7 @@ class Block(PointModule):
         self.channels, self.pre_norm = channels, pre_norm
         self.cpe = PointSequential(
             spconv.SubMConv3d(channels, channels, kernel_size=3, bias=True, indice_key=cpe_indice_key),
-            nn.Linear(channels, channels),
+            PNN.Linear(channels, channels),
             norm_layer(channels),
         )
         self.norm1 = PointSequential(norm_layer(channels))
@@ -203,6 +223,10 @@ class Block(PointModule):
         self.mlp = PointSequential(MLP(in_channels=channels, hidden_channels=int(channels * mlp_ratio),
                                        out_channels=channels, act_layer=act_layer, drop=proj_drop))
         self.drop_path = PointSequential(DropPath(drop_path) if drop_path > 0.0 else nn.Identity())
+        if pre_norm:  # norm1 / norm2 feed only a GEMM: under autocast they emit its operand dtype directly
+            for m in (self.norm1[0], self.norm2[0]):
+                if isinstance(m, PNN.LayerNorm):
+                    m.gemm_consumer = True
 
     def forward(self, point: Point):
         shortcut = point.feat
@@ -235,7 +259,7 @@ class SerializedPooling(PointModule):
         self.stride = stride
         assert reduce in ["sum", "mean", "min", "max"]
         self.reduce, self.shuffle_orders, self.traceable = reduce, shuffle_orders, traceable
-        self.proj = nn.Linear(in_channels, out_channels)
+        self.proj = PNN.Linear(in_channels, out_channels)
         if norm_layer is not None:
             self.norm = PointSequential(norm_layer(out_channels))
         if act_layer is not None:
@@ -294,8 +318,8 @@ class SerializedPooling(PointModule):
 class SerializedUnpooling(PointModule):
     def __init__(self, in_channels, skip_channels, out_channels, norm_layer=None, act_layer=None, traceable=False):
         super().__init__()
-        self.proj = PointSequential(nn.Linear(in_channels, out_channels))
-        self.proj_skip = PointSequential(nn.Linear(skip_channels, out_channels))
+        self.proj = PointSequential(PNN.Linear(in_channels, out_channels))
+        self.proj_skip = PointSequential(PNN.Linear(skip_channels, out_channels))
         if norm_layer is not None:
             self.proj.add(norm_layer(out_channels))
             self.proj_skip.add(norm_layer(out_channels))
@@ -356,7 +380,7 @@ class PointTransformerV3(PointModule):
         assert self.enc_mode or self.num_stages == len(dec_num_head) + 1 == len(dec_patch_size) + 1
 
         bn_layer = lambda c: nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)  # noqa: E731  (ptv3m1:581)
-        ln_layer = nn.LayerNorm
+        ln_layer = PNN.LayerNorm
         act_layer = nn.GELU
         blk = dict(mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop,
                    norm_layer=ln_layer, act_layer=act_layer, pre_norm=pre_norm, enable_rpe=enable_rpe,

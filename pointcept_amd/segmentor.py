@@ -12,13 +12,14 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import nn as PNN
 from .structure import Point
 
 
 class DefaultSegmentorV2(nn.Module):
     def __init__(self, num_classes, backbone_out_channels, backbone, ignore_index=-1):
         super().__init__()
-        self.seg_head = nn.Linear(backbone_out_channels, num_classes) if num_classes > 0 else nn.Identity()
+        self.seg_head = PNN.Linear(backbone_out_channels, num_classes) if num_classes > 0 else nn.Identity()
         self.backbone = backbone
         self.ignore_index = ignore_index
 

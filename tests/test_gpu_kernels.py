@@ -334,6 +334,116 @@ def test_spconv_down_up_tables(cuda):
 
 
 # ------------------------------------------------------------------------------------------------
+# G'. identity / gather-table GEMM (nn.Linear on point features) and LayerNorm
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,cin,cout", [(1, 32, 96), (5000, 32, 96), (3001, 64, 192), (777, 128, 512), (300, 512, 2048),
+                                        (900, 2048, 512), (2500, 64, 20), (4100, 6, 32)])
+def test_linear_identity_table(cuda, dtype, n, cin, cout):
+    """PF.linear == F.linear (forward, input / weight / bias gradients) incl. channel padding."""
+    from pointcept_amd import functional as PF
+
+    g = torch.Generator().manual_seed(n + cin + cout)
+    x = torch.randn(n, cin, generator=g).to(dtype)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dtype)
+    b = torch.randn(cout, generator=g)
+    dout = torch.randn(n, cout, generator=g).to(dtype)
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.linear(xr, wr, br)
+    ref.backward(dout.float())
+    xe, we, be = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    got = PF.linear(xe, we, be)
+    got.backward(dout.to(cuda))
+    rtol, atol = _tols(dtype)
+    _close("linear_fwd", got, ref, rtol, atol * 4)
+    _close("linear_dx", xe.grad, xr.grad, rtol, atol * 4)
+    _close("linear_dw", we.grad, wr.grad, 2 * rtol, 2e-3 * float(wr.grad.abs().max()))
+    _close("linear_db", be.grad, br.grad, 1e-4, 2e-3 * float(br.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_gather_tables(cuda, dtype):
+    """out = F.linear(x)[gidx] with a padded permutation (duplicated tail rows), gather-form backward."""
+    from pointcept_amd import functional as PF
+
+    n, n_pad, cin, cout = 3000, 3072, 32, 96
+    g = torch.Generator().manual_seed(17)
+    perm = torch.randperm(n, generator=g)
+    gidx = torch.cat([perm, perm[n - 72 - 100:n - 100]])            # 72 padded slots repeat earlier points
+    inv = torch.empty(n, dtype=torch.int64)
+    inv[perm] = torch.arange(n)
+    dup = torch.full((n,), -1, dtype=torch.int64)
+    dup[gidx[n:]] = torch.arange(n, n_pad)
+    x = torch.randn(n, cin, generator=g).to(dtype)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dtype)
+    b = torch.randn(cout, generator=g)
+    dout = torch.randn(n_pad, cout, generator=g).to(dtype)
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.linear(xr, wr, br)[gidx]
+    ref.backward(dout.float())
+    xe, we, be = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    tf = gidx.to(torch.int32)[None].contiguous().to(cuda)
+    tb = torch.stack([inv, dup]).to(torch.int32).contiguous().to(cuda)
+    got = PF.linear(xe, we, be, tf, tb)
+    got.backward(dout.to(cuda))
+    rtol, atol = _tols(dtype)
+    _close("glinear_fwd", got, ref, rtol, atol * 4)
+    _close("glinear_dx", xe.grad, xr.grad, rtol, atol * 8)
+    _close("glinear_dw", we.grad, wr.grad, 2 * rtol, 2e-3 * float(wr.grad.abs().max()))
+    _close("glinear_db", be.grad, br.grad, 1e-4, 2e-3 * float(br.grad.abs().max()))
+    # un-gather with dropped (non-primary) slots: out[p] = W a[inv[p]], backward table has -1 rows
+    a = torch.randn(n_pad, cin, generator=g).to(dtype)
+    prim = torch.where(inv[gidx] == torch.arange(n_pad), gidx, torch.full_like(gidx, -1))
+    ar = a.float().requires_grad_(True)
+    ref2 = torch.nn.functional.linear(ar, w.float(), b)[inv]
+    d2 = torch.randn(n, cout, generator=g).to(dtype)
+    ref2.backward(d2.float())
+    ae = a.to(cuda).requires_grad_(True)
+    got2 = PF.linear(ae, w.to(cuda), b.to(cuda), inv.to(torch.int32)[None].contiguous().to(cuda),
+                     prim.to(torch.int32)[None].contiguous().to(cuda))
+    got2.backward(d2.to(cuda))
+    _close("glinear2_fwd", got2, ref2, rtol, atol * 4)
+    _close("glinear2_dx", ae.grad, ar.grad, rtol, atol * 8)
+
+
+@pytest.mark.parametrize("c", [32, 64, 128, 256, 512])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
+def test_layer_norm_fwd_bwd(cuda, c, xdt, ydt):
+    from pointcept_amd import ops
+
+    n = 70001 if c <= 64 else 5003
+    g = torch.Generator().manual_seed(c)
+    x = (torch.randn(n, c, generator=g) * 2 + 0.5).to(xdt)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    dy = torch.randn(n, c, generator=g).to(ydt)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (c,), gr, br, 1e-5)
+    ref.backward(dy.float())
+    y, mean, rstd = ops.layer_norm_fwd(x.to(cuda), gamma.to(cuda), beta.to(cuda), 1e-5, ydt)
+    rtol, atol = _tols(ydt)
+    _close("ln_fwd", y, ref, rtol, atol * 4)
+    _close("ln_mean", mean, x.float().mean(1), 1e-5, 1e-5)
+    dx, dg, db = ops.layer_norm_bwd(dy.to(cuda), x.to(cuda), mean, rstd, gamma.to(cuda))
+    rt2, at2 = _tols(xdt)
+    _close("ln_dx", dx, xr.grad, rt2, at2 * 4)
+    _close("ln_dgamma", dg, gr.grad, 1e-4, 1e-4 * float(gr.grad.abs().max()) + 1e-3)
+    _close("ln_dbeta", db, br.grad, 1e-4, 1e-4 * float(br.grad.abs().max()) + 1e-3)
+
+
+def test_layer_norm_empty_and_unsupported(cuda):
+    from pointcept_amd import ops
+    from pointcept_amd._lib import PtcoreError
+
+    assert not ops.layer_norm_supported(48)
+    with pytest.raises(PtcoreError):
+        ops.layer_norm_fwd(torch.zeros(4, 48, device=cuda), None, None, 1e-5, torch.float32)
+    y, m, r = ops.layer_norm_fwd(torch.zeros(0, 64, device=cuda), None, None, 1e-5, torch.float32)
+    assert y.shape == (0, 64)
+
+
+# ------------------------------------------------------------------------------------------------
 # H. attention
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("lens,H", [([1024], 2), ([1024, 1024, 330], 4), ([48, 48, 17], 2), ([1, 2, 31, 32, 33, 65], 3),

@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Per-operator timings of the hot path at the PTv3-base / ScanNet shapes (8 scenes x 102400 voxels),
+engine kernel vs the PyTorch-ROCm library op for the same math.  HIP-event timing on torch's current
+stream (the stream the engine launches on).  Writes gpurun_out/bench_ops.json and prints a table.
+
+    python tools/bench_ops.py [--quick]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from pointcept_amd import ops  # noqa: E402
+
+DEV = torch.device("cuda:0")
+HBM_PEAK = 8.0e12
+MFMA_PEAK = 2.5e15
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3  # seconds
+
+
+def roof(bytes_, flops, t):
+    t_roof = max(bytes_ / HBM_PEAK, flops / MFMA_PEAK)
+    return {"us": round(t * 1e6, 1), "GBps": round(bytes_ / t / 1e9, 1), "TFLOPs": round(flops / t / 1e12, 1),
+            "roof_frac": round(t_roof / t, 3)}
+
+
+def bench_linear(rows, n, cin, cout, results):
+    dt = torch.bfloat16
+    x = torch.randn(n, cin, device=DEV).to(dt)
+    w = (torch.randn(cout, cin, device=DEV) / cin ** 0.5).to(dt)
+    b = torch.randn(cout, device=DEV)
+    g = torch.randn(n, cout, device=DEV).to(dt)
+    wt = w.t().contiguous()[:, None, :]
+    e = 2
+    by_f = n * (cin + cout) * e + cin * cout * e
+    fl = 2.0 * n * cin * cout
+    r = {"shape": [n, cin, cout]}
+    r["own_fwd"] = roof(by_f, fl, timeit(lambda: ops.spconv_fwd(x, w[:, None, :], b, None)))
+    r["lib_fwd"] = roof(by_f, fl, timeit(lambda: F.linear(x, w, b.to(dt))))
+    r["own_dgrad"] = roof(by_f, fl, timeit(lambda: ops.spconv_fwd(g, wt, None, None)))
+    r["lib_dgrad"] = roof(by_f, fl, timeit(lambda: g @ w))
+    by_w = n * (cin + cout) * e + cin * cout * 4
+    r["own_wgrad"] = roof(by_w, fl, timeit(lambda: ops.spconv_wgrad(x, g, None, want_bias=True)))
+    r["lib_wgrad"] = roof(by_w, fl, timeit(lambda: (g.t() @ x, g.sum(0))))
+    results.append(r)
+    rows.append(f"linear n={n:7d} {cin:4d}->{cout:4d} | fwd own {r['own_fwd']['us']:8.1f} lib {r['lib_fwd']['us']:8.1f} | "
+                f"dgrad own {r['own_dgrad']['us']:8.1f} lib {r['lib_dgrad']['us']:8.1f} | "
+                f"wgrad own {r['own_wgrad']['us']:8.1f} lib {r['lib_wgrad']['us']:8.1f} | own fwd roof {r['own_fwd']['roof_frac']}")
+
+
+def bench_ln(rows, n, c, results):
+    x = torch.randn(n, c, device=DEV)
+    gm, bt = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV)
+    dy = torch.randn(n, c, device=DEV)
+    dyb = dy.to(torch.bfloat16)
+    y, mean, rstd = ops.layer_norm_fwd(x, gm, bt, 1e-5, torch.float32)
+    r = {"shape": [n, c]}
+    r["own_fwd_f32"] = roof(n * c * 8, 0, timeit(lambda: ops.layer_norm_fwd(x, gm, bt, 1e-5, torch.float32)))
+    r["own_fwd_bf16out"] = roof(n * c * 6, 0, timeit(lambda: ops.layer_norm_fwd(x, gm, bt, 1e-5, torch.bfloat16)))
+    r["lib_fwd_f32"] = roof(n * c * 8, 0, timeit(lambda: F.layer_norm(x, (c,), gm, bt, 1e-5)))
+    r["own_bwd_f32"] = roof(n * c * 12, 0, timeit(lambda: ops.layer_norm_bwd(dy, x, mean, rstd, gm)))
+    r["own_bwd_bf16dy"] = roof(n * c * 10, 0, timeit(lambda: ops.layer_norm_bwd(dyb, x, mean, rstd, gm)))
+    xr = x.clone().requires_grad_(True)
+    gr, br = gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (c,), gr, br, 1e-5)
+    r["lib_bwd_f32"] = roof(n * c * 12, 0, timeit(lambda: torch.autograd.grad(yr, (xr, gr, br), dy, retain_graph=True)))
+    results.append(r)
+    rows.append(f"layernorm n={n:7d} c={c:4d} | fwd own {r['own_fwd_f32']['us']:7.1f} ({r['own_fwd_f32']['GBps']:.0f} GB/s) "
+                f"bf16out {r['own_fwd_bf16out']['us']:7.1f} lib {r['lib_fwd_f32']['us']:7.1f} | bwd own {r['own_bwd_f32']['us']:7.1f} "
+                f"({r['own_bwd_f32']['GBps']:.0f} GB/s) bf16dy {r['own_bwd_bf16dy']['us']:7.1f} lib {r['lib_bwd_f32']['us']:7.1f}")
+
+
+def bench_attention(rows, n_seq, H, results, L=1024):
+    T = n_seq * L
+    qkv = torch.randn(T, 3, H, 16, device=DEV).to(torch.bfloat16)
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=DEV)
+    sc = 0.25
+    out, lse = ops.attn_varlen_fwd(qkv, cu, L, sc)
+    do = torch.randn_like(out)
+    fl_f = 4.0 * L * L * 16 * n_seq * H
+    by_f = T * H * 16 * 2 * 4
+    r = {"shape": [n_seq, L, H]}
+    r["fwd"] = roof(by_f, fl_f, timeit(lambda: ops.attn_varlen_fwd(qkv, cu, L, sc), iters=10))
+    r["bwd"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
+                    timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
+    results.append(r)
+    rows.append(f"attention n_seq={n_seq:4d} L={L} H={H:2d} | fwd {r['fwd']['us']:8.1f} us {r['fwd']['TFLOPs']:7.1f} TF/s | "
+                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s (10 L^2 D)")
+
+
+def bench_spconv(rows, results, scenes=8, points=102400):
+    from pointcept_amd import synthetic
+
+    b = synthetic.to_torch(synthetic.indoor_batch(scenes, points), DEV)
+    n = b["grid_coord"].shape[0]
+    batch = torch.repeat_interleave(torch.arange(scenes, device=DEV), torch.diff(b["offset"], prepend=b["offset"].new_zeros(1)))
+    ind = torch.cat([batch[:, None].int(), b["grid_coord"].int()], 1).contiguous()
+    r = {"n": n}
+    t_hash = timeit(lambda: ops.HashTable(ind), iters=5)
+    table = ops.HashTable(ind)
+    for ks in (3, 5):
+        r[f"rulebook_k{ks}_us"] = round(timeit(lambda: ops.rulebook_subm(ind, ks, table), iters=5) * 1e6, 1)
+    r["hash_us"] = round(t_hash * 1e6, 1)
+    nbr = ops.rulebook_subm(ind, 3, table)
+    pairs = int((nbr >= 0).sum())
+    r["pairs_k3"] = pairs
+    for c in (32, 64):
+        x = torch.randn(n, c, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(c, 27, c, device=DEV) * 0.05).to(torch.bfloat16)
+        bias = torch.randn(c, device=DEV)
+        g = torch.randn(n, c, device=DEV).to(torch.bfloat16)
+        by = n * c * 2 * 2 + 4 * 27 * n + 27 * c * c * 2
+        fl = 2.0 * pairs * c * c
+        r[f"fwd_c{c}"] = roof(by, fl, timeit(lambda: ops.spconv_fwd(x, w, bias, nbr), iters=10))
+        r[f"wgrad_c{c}"] = roof(by, fl, timeit(lambda: ops.spconv_wgrad(x, g, nbr), iters=10))
+        rows.append(f"spconv k3 n={n} c={c} pairs={pairs} | fwd {r[f'fwd_c{c}']['us']:8.1f} us ({r[f'fwd_c{c}']['GBps']:.0f} GB/s alg, "
+                    f"{r[f'fwd_c{c}']['TFLOPs']:.1f} TF/s) | wgrad {r[f'wgrad_c{c}']['us']:8.1f} us")
+    rows.append(f"rulebook n={n}: hash {r['hash_us']} us, k3 {r['rulebook_k3_us']} us, k5 {r['rulebook_k5_us']} us")
+    # serialization + sort
+    code_t = timeit(lambda: ops.serialize_encode(b["grid_coord"], batch, 8, ("z", "z-trans", "hilbert", "hilbert-trans")), iters=10)
+    code = ops.serialize_encode(b["grid_coord"], batch, 8, ("z", "z-trans", "hilbert", "hilbert-trans"))
+    sort_t = timeit(lambda: ops.sort_keys(code, 0, 28), iters=10)
+    r["encode"] = roof(n * 48, 0, code_t)
+    r["sort4"] = roof(4 * n * (16 * 4 + 16), 0, sort_t)
+    rows.append(f"serialize n={n}: encode(4 orders) {r['encode']['us']} us ({r['encode']['GBps']} GB/s), sort 4x28bit {r['sort4']['us']} us")
+    idx = torch.randperm(n, device=DEV)
+    for c in (96, 192):
+        src = torch.randn(n, c, device=DEV).to(torch.bfloat16)
+        t = timeit(lambda: ops.gather_rows(src, idx), iters=10)
+        r[f"gather_c{c}"] = roof(n * c * 4 + n * 8, 0, t)
+        rows.append(f"gather_rows n={n} c={c} bf16: {r[f'gather_c{c}']['us']} us ({r[f'gather_c{c}']['GBps']} GB/s)")
+    results.append(r)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    rows, res = [], {"linear": [], "ln": [], "attn": [], "spconv": []}
+    stages = [(819200, 32), (202560, 64), (49256, 128), (11400, 256), (2640, 512)]
+    if args.quick:
+        stages = stages[:2]
+    for n, c in stages:
+        for cin, cout in ((c, 3 * c), (c, c), (c, 4 * c), (4 * c, c)):
+            bench_linear(rows, n, cin, cout, res["linear"])
+    bench_linear(rows, 819200, 64, 192, res["linear"])
+    bench_linear(rows, 819200, 64, 256, res["linear"])
+    bench_linear(rows, 819200, 256, 64, res["linear"])
+    bench_linear(rows, 819200, 64, 32, res["linear"])   # seg head (20 padded to 32)
+    for n, c in stages:
+        bench_ln(rows, n, c, res["ln"])
+    bench_ln(rows, 819200, 64, res["ln"])
+    for n_seq, H in ((800, 2), (800, 4), (200, 4), (48, 8), (16, 16)):
+        bench_attention(rows, n_seq, H, res["attn"])
+    bench_spconv(rows, res["spconv"])
+    print("\n".join(rows))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_ops.txt"), "w") as f:
+        f.write("\n".join(rows) + "\n")
+
+
+if __name__ == "__main__":
+    main()
