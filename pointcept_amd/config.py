@@ -10,6 +10,8 @@ settings), and so a regression can be bisected without a rebuild.
   PTC_OWN_NORM=0     nn.LayerNorm runs on ATen instead of csrc/norm.hip
   PTC_FUSE_GATHER=0  serialized attention gathers / un-gathers rows with ptc_gather_rows instead of
                      folding the permutation into the qkv / proj GEMMs (kv = 1 gather tables)
+  PTC_SORT_POINTS=0  PT-v3m1 keeps the caller's (dataloader) row order at stage 0 instead of physically
+                     sorting the points along the first serialization curve for L2 locality
 """
 from __future__ import annotations
 
@@ -26,3 +28,4 @@ def _flag(name: str, default: bool) -> bool:
 OWN_LINEAR = _flag("PTC_OWN_LINEAR", True)
 OWN_NORM = _flag("PTC_OWN_NORM", True)
 FUSE_GATHER = _flag("PTC_FUSE_GATHER", True)
+SORT_POINTS = _flag("PTC_SORT_POINTS", True)

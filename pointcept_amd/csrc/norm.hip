@@ -128,16 +128,27 @@ layer_norm_bwd_kernel(const TG* __restrict__ dy, const TX* __restrict__ x, const
   }
 }
 
-__global__ void __launch_bounds__(256)
+// dgamma / dbeta = column sums of the per-block partials [blocks][2][c].  One workgroup per 32
+// channels, 32 slices of the block axis summed in parallel (coalesced 128-byte reads), LDS tree.
+__global__ void __launch_bounds__(1024)
 ln_partial_reduce_kernel(const float* __restrict__ partial, int blocks, int c, float* __restrict__ dgamma,
                          float* __restrict__ dbeta) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 2 * c) return;
+  __shared__ float red[32][33];
+  const int cx = threadIdx.x & 31, sy = threadIdx.x >> 5;
+  const int t = blockIdx.x * 32 + cx;  // flat index into [2][c]; c % 32 == 0 so a block never straddles
   const int which = t / c, ch = t - which * c;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[((int64_t)b * 2 + which) * c + ch];
-  float* dst = which ? dbeta : dgamma;
-  if (dst) dst[ch] = s;
+  if (t < 2 * c)
+    for (int b = sy; b < blocks; b += 32) s += partial[((int64_t)b * 2 + which) * c + ch];
+  red[sy][cx] = s;
+  __syncthreads();
+  if (sy == 0 && t < 2 * c) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a += red[i][cx];
+    float* dst = which ? dbeta : dgamma;
+    if (dst) dst[ch] = a;
+  }
 }
 
 static int ln_grid(int64_t n, int lpr) {
@@ -208,7 +219,7 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* mean, const
 #undef LN_BWD_CASE
   PTC_CHECK_LAUNCH("layer_norm_bwd_kernel");
   if (dgamma || dbeta) {
-    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)ptc_cdiv(2 * c, 256)), dim3(256), 0, s, (const float*)ws,
+    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)ptc_cdiv(2 * c, 32)), dim3(1024), 0, s, (const float*)ws,
                        grid, c, dgamma, dbeta);
     PTC_CHECK_LAUNCH("ln_partial_reduce_kernel");
   }

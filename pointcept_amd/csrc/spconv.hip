@@ -362,13 +362,27 @@ spconv_wgrad_kernel(const T* __restrict__ in, const T* __restrict__ dout, const 
   }
 }
 
+// dw[i] = sum_p partial[p][i].  Threads (32 elements x 8 slices of the split axis): coalesced
+// 128-byte reads, 8 partial sums in flight per element, LDS finish.  Fixed summation order ->
+// bit-reproducible.
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int64_t count, float* __restrict__ dw) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+  __shared__ float red[8][33];
+  const int ex = threadIdx.x & 31, sy = threadIdx.x >> 5;
+  for (int64_t base = (int64_t)blockIdx.x * 32; base < count; base += (int64_t)gridDim.x * 32) {
+    const int64_t i = base + ex;
     float s = 0.f;
-    for (int p = 0; p < splits; ++p) s += partial[(int64_t)p * count + i];
-    dw[i] = s;
+    if (i < count)
+      for (int p = sy; p < splits; p += 8) s += partial[(int64_t)p * count + i];
+    red[sy][ex] = s;
+    __syncthreads();
+    if (sy == 0 && i < count) {
+      float a = red[0][ex];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) a += red[q][ex];
+      dw[i] = a;
+    }
+    __syncthreads();
   }
 }
 
@@ -396,15 +410,17 @@ static int launch_wgrad(const void* in, const void* dout, const int32_t* nbr, in
   int64_t rps = ptc_cdiv(ptc_cdiv(n_out, splits), WG_RO) * WG_RO;
   dim3 grid((unsigned)splits, (unsigned)kv, (unsigned)(ci_tiles * co_tiles));
   hipLaunchKernelGGL((spconv_wgrad_kernel<T>), grid, dim3(256), 0, s, (const T*)in, (const T*)dout, nbr, n_out, kv,
-                     c_in, c_out, rps, ci_tiles, (float*)ws, bias_partial);
+                     c_in, c_out, rps, ci_tiles, splits > 1 ? (float*)ws : dw, bias_partial);
   PTC_CHECK_LAUNCH("spconv_wgrad_kernel");
   const int64_t count = (int64_t)c_out * kv * c_in;
-  int64_t rgrid = ptc_cdiv(count, 256);
-  if (rgrid > 4096) rgrid = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, (const float*)ws, splits, count, dw);
-  PTC_CHECK_LAUNCH("wgrad_reduce_kernel");
+  if (splits > 1) {
+    int64_t rgrid = ptc_cdiv(count, 32);
+    if (rgrid > 16384) rgrid = 16384;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, (const float*)ws, splits, count, dw);
+    PTC_CHECK_LAUNCH("wgrad_reduce_kernel");
+  }
   if (dbias) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ptc_cdiv(c_out, 256)), dim3(256), 0, s, (const float*)bias_partial,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ptc_cdiv(c_out, 32)), dim3(256), 0, s, (const float*)bias_partial,
                        splits, (int64_t)c_out, dbias);
     PTC_CHECK_LAUNCH("wgrad_reduce_kernel(bias)");
   }

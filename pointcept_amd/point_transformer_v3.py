@@ -422,9 +422,29 @@ class PointTransformerV3(PointModule):
     def forward(self, data_dict):
         point = Point(data_dict)
         point.serialization(order=self.order, shuffle_orders=self.shuffle_orders)
+        caller = None
+        if config.SORT_POINTS and point.feat.is_cuda:
+            caller, point = point, point.physically_sorted()
         point.sparsify()
         point = self.embedding(point)
         point = self.enc(point)
         if not self.enc_mode:
             point = self.dec(point)
+        if caller is not None:
+            point = self._restore_order(point, caller)
+        return point
+
+    @staticmethod
+    def _restore_order(point, caller):
+        """undo Point.physically_sorted on the stage-0 point (the returned point itself, or -- in
+        enc_mode -- the last `pooling_parent` of the returned chain, consumed at default.py:69-74)"""
+        if "pooling_parent" not in point.keys():
+            return point.restore_order(caller)
+        child = point
+        while "pooling_parent" in child["pooling_parent"].keys():
+            child = child["pooling_parent"]
+        stage0 = child["pooling_parent"]
+        _, inv0 = stage0["_ptc_unsort"]
+        child["pooling_parent"] = stage0.restore_order(caller)
+        child["pooling_inverse"] = child["pooling_inverse"][inv0]
         return point

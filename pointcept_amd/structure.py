@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import torch
 
+from . import functional as PF
 from . import ops
 from . import spconv_api as spconv
 
@@ -124,6 +125,49 @@ class Point(_RefPoint if _RefPoint is not None else AttrDict):
         self["serialized_code"] = code
         self["serialized_order"] = sorted_order
         self["serialized_inverse"] = inverse
+
+    # -- physical row order ------------------------------------------------------------------------
+    _NOT_PER_POINT = ("offset", "serialized_code", "serialized_order", "serialized_inverse")
+
+    def physically_sorted(self):
+        """Engine-internal working copy whose ROWS are stored in the order of the first serialization
+        curve (row r holds original point serialized_order[0][r]).  Dataloader order is spatially
+        random, so every neighbour gather of the stage-0 convolutions and the serialization gathers
+        of attention would otherwise miss L2 (4 MiB per XCD); pooled stages are born curve-sorted
+        (clusters are numbered by ascending code, ptv3m1:385-390).  All index maps are re-expressed
+        in the new row numbering, so every operator of the model is unchanged; `restore_order`
+        undoes the permutation on the way out.  Requires serialization() to have run."""
+        pi, inv0 = self.serialized_order[0], self.serialized_inverse[0]
+        n = pi.numel()
+        d = {}
+        for key, val in self.items():
+            if key in self._NOT_PER_POINT or key.startswith("_ptc_unsort"):
+                continue
+            if isinstance(val, torch.Tensor) and val.dim() >= 1 and val.shape[0] == n and key != "feat":
+                d[key] = val[pi]
+            else:
+                d[key] = val
+        d["offset"] = self.offset  # codes carry the batch index in their top bits: scenes stay contiguous
+        d["feat"] = PF.gather_rows(self.feat, pi, inv0) if self.feat.is_floating_point() and self.feat.dim() == 2 \
+            else self.feat[pi]
+        d["serialized_code"] = self.serialized_code[:, pi]
+        d["serialized_order"] = inv0[self.serialized_order]      # sorted rank -> new row
+        d["serialized_inverse"] = self.serialized_inverse[:, pi]  # new row -> sorted rank
+        w = Point(d)
+        w["_ptc_unsort"] = (pi, inv0)
+        return w
+
+    def restore_order(self, template):
+        """Inverse of physically_sorted: `template` (the caller-order Point the working copy was made
+        from) with this point's features brought back to caller order; order-independent caches
+        (pad / unpad / cu_seqlens_key) are carried over."""
+        pi, inv0 = self["_ptc_unsort"]
+        out = Point(template)
+        out["feat"] = PF.gather_rows(self.feat, inv0, pi)
+        for key in ("pad", "unpad", "cu_seqlens_key", "sparse_shape"):
+            if key in self.keys():
+                out[key] = self[key]
+        return out
 
     def sparsify(self, pad=96):
         """structure.py:112-148"""

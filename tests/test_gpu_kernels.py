@@ -348,7 +348,7 @@ def test_linear_identity_table(cuda, dtype, n, cin, cout):
     w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dtype)
     b = torch.randn(cout, generator=g)
     dout = torch.randn(n, cout, generator=g).to(dtype)
-    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.clone().requires_grad_(True)
+    xr, wr, br = x.float().clone().requires_grad_(True), w.float().clone().requires_grad_(True), b.clone().requires_grad_(True)
     ref = torch.nn.functional.linear(xr, wr, br)
     ref.backward(dout.float())
     xe, we, be = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
@@ -378,7 +378,7 @@ def test_linear_gather_tables(cuda, dtype):
     w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dtype)
     b = torch.randn(cout, generator=g)
     dout = torch.randn(n_pad, cout, generator=g).to(dtype)
-    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.clone().requires_grad_(True)
+    xr, wr, br = x.float().clone().requires_grad_(True), w.float().clone().requires_grad_(True), b.clone().requires_grad_(True)
     ref = torch.nn.functional.linear(xr, wr, br)[gidx]
     ref.backward(dout.float())
     xe, we, be = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
@@ -394,7 +394,7 @@ def test_linear_gather_tables(cuda, dtype):
     # un-gather with dropped (non-primary) slots: out[p] = W a[inv[p]], backward table has -1 rows
     a = torch.randn(n_pad, cin, generator=g).to(dtype)
     prim = torch.where(inv[gidx] == torch.arange(n_pad), gidx, torch.full_like(gidx, -1))
-    ar = a.float().requires_grad_(True)
+    ar = a.float().clone().requires_grad_(True)
     ref2 = torch.nn.functional.linear(ar, w.float(), b)[inv]
     d2 = torch.randn(n, cout, generator=g).to(dtype)
     ref2.backward(d2.float())
@@ -417,7 +417,7 @@ def test_layer_norm_fwd_bwd(cuda, c, xdt, ydt):
     x = (torch.randn(n, c, generator=g) * 2 + 0.5).to(xdt)
     gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
     dy = torch.randn(n, c, generator=g).to(ydt)
-    xr = x.float().requires_grad_(True)
+    xr = x.float().clone().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     ref = torch.nn.functional.layer_norm(xr, (c,), gr, br, 1e-5)
     ref.backward(dy.float())

@@ -14,6 +14,7 @@ import csv
 import glob
 import json
 import os
+import sqlite3
 from collections import defaultdict
 
 
@@ -40,7 +41,19 @@ def main():
                 return w
         return name[:80]
 
+    # rocprofv3 >= 7.x writes a rocpd SQLite database by default (views `top_kernels`, `kernels`,
+    # `pmc_events`); CSV (--output-format csv) is read too.
     if a.stats:
+        for f in find(a.stats, "*_results.db"):
+            db = sqlite3.connect(f)
+            for name, in db.execute("select distinct name from kernels"):
+                if keep(name):
+                    d = [r[0] for r in db.execute("select duration from kernels where name = ?", (name,))]
+                    k = res["kernels"].setdefault(short(name), {})
+                    k["calls"] = len(d)
+                    k["avg_us"] = round(sum(d) / len(d) / 1e3, 2)
+                    k["min_us"] = round(min(d) / 1e3, 2)
+                    k["max_us"] = round(max(d) / 1e3, 2)
         for f in find(a.stats, "*kernel_stats.csv"):
             for r in csv.DictReader(open(f)):
                 if keep(r["Name"]):
@@ -56,6 +69,11 @@ def main():
                 name = r.get("Kernel_Name", "")
                 if keep(name):
                     acc[short(name)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for f in find(d, "*_results.db"):
+            db = sqlite3.connect(f)
+            for name, cn, val in db.execute("select name, counter_name, counter_value from pmc_events"):
+                if keep(name):
+                    acc[short(name)][cn].append(float(val))
         for kn, cs in acc.items():
             k = res["kernels"].setdefault(kn, {})
             for cn, vals in cs.items():
