@@ -20,49 +20,9 @@
 // Roofline: bytes = N_in*C_in*e + N_out*C_out*e + 4*kv*N_out (table) + kv*C_in*C_out*e,
 // flops = 2*P*C_in*C_out; HBM-bound for C <= 64, MFMA-bound above.
 #include "ptc_common.h"
-#include <type_traits>
 
-typedef __attribute__((ext_vector_type(8))) short s16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  static constexpr int KS = 32;   // channels per super-step
-  static constexpr int EPL = 8;   // elements per lane per super-step (16 bytes)
-  using frag = s16x8;
-  static __device__ __forceinline__ frag zero() { frag z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
-  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<f16_t> {
-  static constexpr int KS = 32;
-  static constexpr int EPL = 8;
-  using frag = h16x8;
-  static __device__ __forceinline__ frag zero() { frag z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
-  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  static constexpr int KS = 16;
-  static constexpr int EPL = 4;
-  using frag = f32x4;
-  static __device__ __forceinline__ frag zero() { frag z = {0.f, 0.f, 0.f, 0.f}; return z; }
-  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
-    return c;
-  }
-};
-
-template <typename T>
-__device__ __forceinline__ typename Mma<T>::frag ld_frag(const T* p) {
-  return *reinterpret_cast<const typename Mma<T>::frag*>(p);
-}
+#include "mma.h"
+#include "wgrad2.h"
 
 #define SC_ROWS 128          // output rows per workgroup (4 waves x 2 sub-tiles x 16)
 #define SC_LDS_BYTES 34816   // NT<=128 rows x (KC + 16 B) : (128+8)*2*128 = (64+4)*4*128
@@ -397,7 +357,10 @@ static int wgrad_splits(int64_t n_out, int kv, int c_in, int c_out) {
 }
 
 extern "C" size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out) {
-  const size_t splits = (size_t)wgrad_splits(n_out, kv, c_in, c_out);
+  // max over the fp32 path (v1, `splits` partials) and the 16-bit path (v2, one partial per workgroup)
+  size_t splits = (size_t)wgrad_splits(n_out, kv, c_in, c_out);
+  const size_t gx = (size_t)w2_plan(n_out, kv, c_in, c_out).gx;
+  if (gx > splits) splits = gx;
   return ptc_align_up(splits * (size_t)c_out * kv * c_in * sizeof(float), 256) + ptc_align_up(splits * (size_t)c_out * sizeof(float), 256);
 }
 
@@ -427,6 +390,54 @@ static int launch_wgrad(const void* in, const void* dout, const int32_t* nbr, in
   return PTC_OK;
 }
 
+// ---- v2 (16-bit features): wave-private staging + transposing LDS reads, see wgrad2.h -----------
+template <typename T, int COT, int CIT, int KG>
+static int launch_wgrad2_inst(const W2Plan& p, const void* in, const void* dout, const int32_t* nbr, int64_t n_out, int kv,
+                              int c_in, int c_out, float* partial, float* bias_partial, hipStream_t s) {
+  auto kern = wgrad2_kernel<T, COT, CIT, KG>;
+  if (p.lds > 48 * 1024)
+    PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+  dim3 grid((unsigned)p.gx, (unsigned)p.groups, (unsigned)(p.co_blocks * p.ci_blocks));
+  hipLaunchKernelGGL(kern, grid, dim3(256), p.lds, s, (const T*)in, (const T*)dout, nbr, n_out, kv, c_in, c_out,
+                     ptc_cdiv(n_out, W2_ROWS), p.ci_blocks, partial, bias_partial);
+  PTC_CHECK_LAUNCH("wgrad2_kernel");
+  return PTC_OK;
+}
+
+template <typename T>
+static int launch_wgrad2(const void* in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
+                         float* dw, float* dbias, void* ws, hipStream_t s) {
+  const W2Plan p = w2_plan(n_out, kv, c_in, c_out);
+  const int64_t count = (int64_t)c_out * kv * c_in;
+  float* partial = p.gx > 1 ? (float*)ws : dw;
+  float* bias_partial = nullptr;
+  if (dbias) bias_partial = p.gx > 1 ? (float*)((char*)ws + ptc_align_up((size_t)p.gx * (size_t)count * sizeof(float), 256)) : dbias;
+  int rc = PTC_EUNSUPPORTED;
+#define W2_CASE(COT, CIT, KG)                                                                                         \
+  if (p.cot == COT && p.cit == CIT && p.kg == KG)                                                                     \
+    rc = launch_wgrad2_inst<T, COT, CIT, KG>(p, in, dout, nbr, n_out, kv, c_in, c_out, partial, bias_partial, s);
+  W2_CASE(2, 1, 1) W2_CASE(2, 2, 1) W2_CASE(2, 4, 1) W2_CASE(4, 1, 1) W2_CASE(4, 2, 1) W2_CASE(4, 4, 1)
+  W2_CASE(6, 1, 1) W2_CASE(6, 2, 1) W2_CASE(6, 4, 1) W2_CASE(8, 1, 1) W2_CASE(8, 2, 1) W2_CASE(8, 4, 1)
+  W2_CASE(2, 1, 16) W2_CASE(2, 2, 9) W2_CASE(4, 2, 4) W2_CASE(2, 4, 4) W2_CASE(4, 4, 2)
+#undef W2_CASE
+  if (rc != PTC_OK) {
+    if (rc == PTC_EUNSUPPORTED) ptc_set_error("ptc_spconv_wgrad: no wgrad2 instance for tiles (%d,%d,%d)", p.cot, p.cit, p.kg);
+    return rc;
+  }
+  if (p.gx > 1) {
+    int64_t rgrid = ptc_cdiv(count, 32);
+    if (rgrid > 16384) rgrid = 16384;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, (const float*)partial, p.gx, count, dw);
+    PTC_CHECK_LAUNCH("wgrad_reduce_kernel");
+    if (dbias) {
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ptc_cdiv(c_out, 32)), dim3(256), 0, s, (const float*)bias_partial,
+                         p.gx, (int64_t)c_out, dbias);
+      PTC_CHECK_LAUNCH("wgrad_reduce_kernel(bias)");
+    }
+  }
+  return PTC_OK;
+}
+
 extern "C" int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out,
                                 int kv, int c_in, int c_out, int dtype, float* dw, float* dbias, void* workspace,
                                 size_t workspace_bytes, ptc_stream_t stream) {
@@ -444,6 +455,8 @@ extern "C" int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, 
   }
   PTC_REQUIRE(in && dout, PTC_EINVAL, "ptc_spconv_wgrad: null buffer");
   PTC_REQUIRE(nbr || (kv == 1 && n_in >= n_out), PTC_EINVAL, "ptc_spconv_wgrad: nbr may be NULL only for kv == 1 (identity table)");
+  if (dtype == PTC_BF16) return launch_wgrad2<bf16_t>(in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s);
+  if (dtype == PTC_F16) return launch_wgrad2<f16_t>(in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s);
   PTC_DISPATCH_DTYPE(dtype, T, return launch_wgrad<T>(in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s));
   return PTC_OK;
 }

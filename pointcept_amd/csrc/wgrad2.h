@@ -1,0 +1,236 @@
+// wgrad2.h -- weight gradient of the gather-table convolution / Linear layers for 16-bit features:
+//     dw[co][k][ci] = sum_o dout[o][co] * in[nbr[k][o]][ci]        (contraction over ROWS)
+// Both MFMA operands are needed "channel-major" (8 consecutive rows of one channel per lane) while
+// memory is row-major.  v1 (spconv.hip) transposed through LDS with 2-byte stores and two workgroup
+// barriers per 64-row chunk per k and ran at ~15 % of the HBM roofline.  v2:
+//   * every WAVE is an independent worker: it owns 32-row steps (interleaved across workers so
+//     neighbouring waves stream neighbouring rows), stages them in a wave-private LDS slice and
+//     never meets a workgroup barrier in the main loop;
+//   * rows are stored row-major in LDS with plain 16-byte stores, as [16-channel plane][32 rows][16]
+//     sub-tiles (pitch 32 B), and read back TRANSPOSED by ds_read_b64_tr_b16 (gfx950): a 16-lane
+//     group addresses a [4 rows][16 channels] block and lane j receives rows 0..3 of channel j
+//     (mapping measured with tools/probe_gfx950.hip) -- two reads make one MFMA fragment, and the
+//     half-wave footprint (8 rows x 32 B) covers all 64 banks exactly once;
+//   * the dout fragments of a step are read once and reused for all KG table rows of the group;
+//     the gathered `in` rows of table row k+1 are in flight (registers) while k is multiplied;
+//   * accumulators for KG table rows stay in registers for the whole row range; the four waves of a
+//     workgroup are summed through LDS once at the end, then per-workgroup partials go to the
+//     deterministic reduction kernel (no atomics, bit-reproducible).
+#pragma once
+#include "mma.h"
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+#define W2_ROWS 32  // rows per wave step
+
+// LDS byte offset of (row, 8-channel piece) inside a wave's [planes][32][16] image
+__device__ __forceinline__ int w2_off(int row, int piece) { return (((piece >> 1) * W2_ROWS + row) << 5) + ((piece & 1) << 4); }
+
+// one MFMA fragment (8 contraction values = rows {4g..4g+3, 16+4g..16+4g+3} of channel `lane&15` of plane t)
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::frag w2_frag(const unsigned char* img, int t, int lane) {
+  const int lp = lane & 15, g = lane >> 4;
+  const int row = 4 * g + (lp >> 2);
+  const unsigned char* p = img + ((t * W2_ROWS + row) << 5) + ((lp & 3) << 3);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * 32));
+  s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  typename Mma<T>::frag out;
+  __builtin_memcpy(&out, &f, sizeof(out));
+  return out;
+}
+
+// orders a wave's own LDS stores before its following (cross-lane) LDS reads
+__device__ __forceinline__ void w2_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T, int COT, int CIT, int KG>
+__global__ void __launch_bounds__(256)
+wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_t* __restrict__ nbr, int64_t n_out, int kv,
+              int c_in, int c_out, int64_t steps_total, int ci_blocks, float* __restrict__ partial,
+              float* __restrict__ bias_partial) {
+  using M = Mma<T>;
+  constexpr int WAVE_BYTES = (COT + 2 * CIT) * 1024;  // dout image + two `in` images
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned char* D = smem + wave * WAVE_BYTES;
+  unsigned char* I[2] = {D + COT * 1024, D + (COT + CIT) * 1024};
+  const int k0 = blockIdx.y * KG;
+  const int nk = (kv - k0) < KG ? (kv - k0) : KG;
+  const int co0 = (blockIdx.z / ci_blocks) * COT * 16, ci0 = (blockIdx.z % ci_blocks) * CIT * 16;
+  const int64_t workers = (int64_t)gridDim.x * 4, worker = (int64_t)blockIdx.x * 4 + wave;
+  const bool do_bias = bias_partial != nullptr && blockIdx.y == 0 && (blockIdx.z % ci_blocks) == 0;
+
+  f32x4 acc[KG][COT][CIT];
+  f32x4 accb[COT];
+#pragma unroll
+  for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+    for (int a = 0; a < COT; ++a)
+#pragma unroll
+      for (int b = 0; b < CIT; ++b) acc[kk][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < COT; ++a) accb[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  typename M::frag ones;
+  {
+    uint16_t one = std::is_same<T, bf16_t>::value ? 0x3F80 : 0x3C00;
+    uint16_t o8[8] = {one, one, one, one, one, one, one, one};
+    __builtin_memcpy(&ones, o8, sizeof(ones));
+  }
+
+  for (int64_t s = worker; s < steps_total; s += workers) {
+    const int64_t r0 = s * W2_ROWS;
+    // table entries of the rows this lane stages, for every table row of the group
+    int32_t idx[KG][CIT];
+#pragma unroll
+    for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+      for (int i = 0; i < CIT; ++i) {
+        const int row = (i * 64 + lane) / (2 * CIT);
+        const int64_t rr = r0 + row;
+        int32_t j = -1;
+        if (kk < nk && rr < n_out) j = nbr ? nbr[(int64_t)(k0 + kk) * n_out + rr] : (int32_t)rr;
+        idx[kk][i] = j;
+      }
+    // dout rows -> LDS (row-major sub-tiles)
+#pragma unroll
+    for (int i = 0; i < COT; ++i) {
+      const int v = i * 64 + lane, row = v / (2 * COT), piece = v % (2 * COT);
+      const int64_t rr = r0 + row;
+      const int ch = co0 + piece * 8;
+      uint4 x = {0, 0, 0, 0};
+      if (rr < n_out && ch < c_out) x = *reinterpret_cast<const uint4*>(dout + rr * c_out + ch);
+      *reinterpret_cast<uint4*>(D + w2_off(row, piece)) = x;
+    }
+    // gathered input rows of the first table row
+    uint4 pre[CIT];
+#pragma unroll
+    for (int i = 0; i < CIT; ++i) {
+      const int piece = (i * 64 + lane) % (2 * CIT);
+      const int ch = ci0 + piece * 8;
+      uint4 x = {0, 0, 0, 0};
+      if (idx[0][i] >= 0 && ch < c_in) x = *reinterpret_cast<const uint4*>(in + (int64_t)idx[0][i] * c_in + ch);
+      pre[i] = x;
+    }
+    w2_wave_sync();
+    typename M::frag A[COT];
+#pragma unroll
+    for (int a = 0; a < COT; ++a) A[a] = w2_frag<T>(D, a, lane);
+    if (do_bias) {
+#pragma unroll
+      for (int a = 0; a < COT; ++a) accb[a] = M::mma(A[a], ones, accb[a]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KG; ++kk) {
+      if (kk < nk) {
+        unsigned char* buf = I[kk & 1];
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) {
+          const int v = i * 64 + lane, row = v / (2 * CIT), piece = v % (2 * CIT);
+          *reinterpret_cast<uint4*>(buf + w2_off(row, piece)) = pre[i];
+        }
+        if (kk + 1 < KG && kk + 1 < nk) {  // next table row's gather goes out before this one is multiplied
+#pragma unroll
+          for (int i = 0; i < CIT; ++i) {
+            const int piece = (i * 64 + lane) % (2 * CIT);
+            const int ch = ci0 + piece * 8;
+            uint4 x = {0, 0, 0, 0};
+            const int32_t j = idx[(kk + 1) < KG ? (kk + 1) : 0][i];
+            if (j >= 0 && ch < c_in) x = *reinterpret_cast<const uint4*>(in + (int64_t)j * c_in + ch);
+            pre[i] = x;
+          }
+        }
+        w2_wave_sync();
+        typename M::frag B[CIT];
+#pragma unroll
+        for (int b = 0; b < CIT; ++b) B[b] = w2_frag<T>(buf, b, lane);
+#pragma unroll
+        for (int a = 0; a < COT; ++a)
+#pragma unroll
+          for (int b = 0; b < CIT; ++b) acc[kk][a][b] = M::mma(A[a], B[b], acc[kk][a][b]);
+      }
+    }
+  }
+
+  // ---- sum the four waves through LDS, write this workgroup's partial ------------------------------
+  // D[i = co][j = ci]: lane (j = lane & 15, g = lane >> 4) holds co = 16 a + 4 g + e, ci = 16 b + j
+  float* red = reinterpret_cast<float*>(smem);  // [4 waves][CIT][4][64] floats <= 16 KB
+  float* pout = partial + (int64_t)blockIdx.x * c_out * kv * c_in;
+#pragma unroll
+  for (int kk = 0; kk < KG; ++kk) {
+#pragma unroll
+    for (int a = 0; a < COT; ++a) {
+      __syncthreads();
+      if (kk < nk) {
+#pragma unroll
+        for (int b = 0; b < CIT; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) red[((wave * CIT + b) * 4 + e) * 64 + lane] = acc[kk][a][b][e];
+      }
+      __syncthreads();
+      if (kk < nk) {
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) {
+          const int q = i * 256 + threadIdx.x;  // (b, e, lane)
+          const int ln = q & 63, e = (q >> 6) & 3, b = q >> 8;
+          const float v = red[q] + red[CIT * 256 + q] + red[2 * CIT * 256 + q] + red[3 * CIT * 256 + q];
+          const int co = co0 + 16 * a + 4 * (ln >> 4) + e, ci = ci0 + 16 * b + (ln & 15);
+          if (co < c_out && ci < c_in) pout[((int64_t)co * kv + (k0 + kk)) * c_in + ci] = v;
+        }
+      }
+    }
+  }
+  if (do_bias) {  // every column j of accb holds the same column sum; take j = 0
+    __syncthreads();
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int a = 0; a < COT; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave * COT * 16 + 16 * a + 4 * (lane >> 4) + e] = accb[a][e];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < COT * 16) {
+      const int co = co0 + threadIdx.x;
+      if (co < c_out)
+        bias_partial[(int64_t)blockIdx.x * c_out + co] = red[threadIdx.x] + red[COT * 16 + threadIdx.x] +
+                                                         red[2 * COT * 16 + threadIdx.x] + red[3 * COT * 16 + threadIdx.x];
+    }
+  }
+}
+
+// ---- host-side plan ----------------------------------------------------------------------------
+struct W2Plan {
+  int cot, cit, kg;          // tiles per workgroup (x16 channels), table rows per group
+  int co_blocks, ci_blocks, groups;
+  int gx;                    // workgroups along the row axis (= number of partials)
+  size_t lds;
+};
+
+static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out) {
+  W2Plan p;
+  p.cit = c_in <= 16 ? 1 : (c_in <= 32 ? 2 : 4);
+  p.cot = c_out <= 32 ? 2 : (c_out <= 64 ? 4 : (c_out <= 96 ? 6 : 8));
+  p.kg = 1;
+  if (kv > 1) {  // instantiated groups (register budget: KG*COT*CIT*4 accumulators)
+    if (p.cot == 2 && p.cit == 1) p.kg = 16;
+    else if (p.cot == 2 && p.cit == 2) p.kg = 9;
+    else if (p.cot == 4 && p.cit == 2) p.kg = 4;
+    else if (p.cot == 2 && p.cit == 4) p.kg = 4;
+    else if (p.cot == 4 && p.cit == 4) p.kg = 2;
+  }
+  p.co_blocks = (int)ptc_cdiv(c_out, p.cot * 16);
+  p.ci_blocks = (int)ptc_cdiv(c_in, p.cit * 16);
+  p.groups = (int)ptc_cdiv(kv, p.kg);
+  const int64_t steps = ptc_cdiv(n_out, W2_ROWS);
+  int64_t gx = 1024 / ((int64_t)p.groups * p.co_blocks * p.ci_blocks);
+  const int64_t max_gx = ptc_cdiv(steps, 16);  // at least ~4 steps per wave
+  if (gx > max_gx) gx = max_gx;
+  if (gx > 512) gx = 512;
+  if (gx < 1) gx = 1;
+  p.gx = (int)gx;
+  p.lds = (size_t)4 * (p.cot + 2 * p.cit) * 1024;  // >= the 4*CIT KB of the final cross-wave sum
+  return p;
+}
