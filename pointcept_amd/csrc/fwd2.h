@@ -1,0 +1,239 @@
+// fwd2.h -- second-generation forward kernels of the gather-table convolution for 16-bit features
+// and c_in <= 256 (the large-N stages of PTv3 / SpUNet).  Included by spconv.hip after the v1
+// kernel, whose weight-row permutation (lds_row_of_channel) and epilogue (sc_epilogue) they share.
+//
+// v1 walked the table one row k at a time: two workgroup barriers, a restaged W_k and an unhidden
+// dependent load chain (table entry -> gathered row) per k, ~10 % of the HBM roofline at C = 32.
+//   conv2_kernel   (kv > 1): W is staged for a GROUP of table rows at once (<= 40 KB), the table
+//                  entries of the group sit in a wave-private LDS block, and every wave streams its
+//                  (k, 32-channel step) units through a PD-deep register ring: the gathers of unit
+//                  u + PD are in flight while unit u is multiplied.  Table rows with no valid entry
+//                  in a wave's 32 output rows cost that wave nothing.  Two barriers per GROUP.
+//   linear2_kernel (kv == 1: nn.Linear, 1x1x1 convs, the gather-fused qkv / proj GEMMs): persistent
+//                  workgroups keep W in LDS for their whole life and walk 128-row tiles; the rows of
+//                  tile i+1 (and the table entries of tile i+2) are loaded before tile i is multiplied.
+#pragma once
+
+#define F2_ROWS 128
+#define F2_MAX_W_BYTES (40 * 1024)
+
+template <typename T, int NTILES, int PD>
+__global__ void __launch_bounds__(256)
+conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+             const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int kg, T* __restrict__ out) {
+  using M = Mma<T>;
+  constexpr int NT = NTILES * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int pitch = c_in + 8;                          // elements; +16 B staggers the fragment reads
+  T* wl = reinterpret_cast<T*>(smem);                  // [kg][NT][pitch]
+  const int w_bytes = (kg * NT * pitch * 2 + 15) & ~15;
+  const int lane = ptc_lane(), wave = threadIdx.x >> 6;
+  int32_t* il = reinterpret_cast<int32_t*>(smem + w_bytes) + wave * kg * 32;  // this wave's [kg][32] entries
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * F2_ROWS + wave * 32;
+  const int n0 = blockIdx.y * NT;
+  const int64_t rowA = row0 + r, rowB = row0 + 16 + r;
+  const int S = (c_in + 31) >> 5;                      // 32-channel steps per table row
+  const int vpr = c_in >> 3;                           // 16-byte vectors per weight row
+
+  f32x4 acc[2][NTILES];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < kv; k0 += kg) {
+    const int gk = (kv - k0) < kg ? (kv - k0) : kg;
+    if (k0 > 0) __syncthreads();  // every wave is done with the previous group's W slices
+    for (int q = lane; q < gk * 32; q += 64) {
+      const int64_t row = row0 + (q & 31);
+      il[q] = row < n_out ? nbr[(int64_t)(k0 + (q >> 5)) * n_out + row] : -1;
+    }
+    for (int q = threadIdx.x; q < gk * NT * vpr; q += 256) {
+      const int kk = q / (NT * vpr), rem = q - kk * NT * vpr;
+      const int n = rem / vpr, cc = rem - n * vpr;
+      *reinterpret_cast<uint4*>(wl + (kk * NT + lds_row_of_channel<NTILES>(n)) * pitch + cc * 8) =
+          *reinterpret_cast<const uint4*>(w + ((int64_t)(n0 + n) * kv + (k0 + kk)) * c_in + cc * 8);
+    }
+    __syncthreads();
+
+    const int U = gk * S;
+    typename M::frag ra[PD], rb[PD];
+    int32_t xa[PD], xb[PD];
+    auto issue = [&](int j, int u) {
+      const int kk = u / S, s = u - kk * S;
+      const int col = s * 32 + g * 8;
+      const int32_t ia = il[kk * 32 + r], ib = il[kk * 32 + 16 + r];
+      typename M::frag fa = M::zero(), fb = M::zero();
+      if (col < c_in) {
+        if (ia >= 0) fa = ld_frag<T>(in + (int64_t)ia * c_in + col);
+        if (ib >= 0) fb = ld_frag<T>(in + (int64_t)ib * c_in + col);
+      }
+      ra[j] = fa; rb[j] = fb; xa[j] = ia; xb[j] = ib;
+    };
+#pragma unroll
+    for (int j = 0; j < PD; ++j)
+      if (j < U) issue(j, j);
+    for (int base = 0; base < U; base += PD) {
+#pragma unroll
+      for (int j = 0; j < PD; ++j) {
+        const int u = base + j;
+        if (u < U) {
+          const typename M::frag fa = ra[j], fb = rb[j];
+          const bool anyA = __builtin_amdgcn_ballot_w64(xa[j] >= 0) != 0;
+          const bool anyB = __builtin_amdgcn_ballot_w64(xb[j] >= 0) != 0;
+          if (u + PD < U) issue(j, u + PD);
+          if (anyA | anyB) {
+            const int kk = u / S, s = u - kk * S;
+            const int col = s * 32 + g * 8;
+            const T* wrow = wl + (kk * NT + r) * pitch + col;
+#pragma unroll
+            for (int t = 0; t < NTILES; ++t) {
+              typename M::frag fw = M::zero();
+              if (col < c_in) fw = ld_frag<T>(wrow + t * 16 * pitch);
+              if (anyA) acc[0][t] = M::mma(fw, fa, acc[0][t]);
+              if (anyB) acc[1][t] = M::mma(fw, fb, acc[1][t]);
+            }
+          }
+        }
+      }
+    }
+  }
+  sc_epilogue<T, NTILES>(acc, bias, out, rowA, rowB, n_out, c_out, n0, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NTILES, int S>
+__global__ void __launch_bounds__(256)
+linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+               const int32_t* __restrict__ nbr, int64_t n_out, int c_in, int c_out, T* __restrict__ out) {
+  using M = Mma<T>;
+  constexpr int NT = NTILES * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int pitch = c_in + 8;
+  T* wl = reinterpret_cast<T*>(smem);  // [NT][pitch]
+  const int lane = ptc_lane(), wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * NT;
+  const int vpr = c_in >> 3;
+  for (int q = threadIdx.x; q < NT * vpr; q += 256) {
+    const int n = q / vpr, cc = q - n * vpr;
+    *reinterpret_cast<uint4*>(wl + lds_row_of_channel<NTILES>(n) * pitch + cc * 8) =
+        *reinterpret_cast<const uint4*>(w + (int64_t)(n0 + n) * c_in + cc * 8);
+  }
+  __syncthreads();
+
+  const int64_t tiles = (n_out + F2_ROWS - 1) / F2_ROWS;
+  auto load_idx = [&](int64_t tile, int32_t& ia, int32_t& ib) {
+    const int64_t rowA = tile * F2_ROWS + wave * 32 + r, rowB = rowA + 16;
+    ia = -1; ib = -1;
+    if (tile < tiles) {
+      if (rowA < n_out) ia = nbr ? nbr[rowA] : (int32_t)rowA;
+      if (rowB < n_out) ib = nbr ? nbr[rowB] : (int32_t)rowB;
+    }
+  };
+  auto load_rows = [&](int32_t ia, int32_t ib, typename M::frag (&fa)[S], typename M::frag (&fb)[S]) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int col = s * 32 + g * 8;
+      fa[s] = M::zero(); fb[s] = M::zero();
+      if (col < c_in) {
+        if (ia >= 0) fa[s] = ld_frag<T>(in + (int64_t)ia * c_in + col);
+        if (ib >= 0) fb[s] = ld_frag<T>(in + (int64_t)ib * c_in + col);
+      }
+    }
+  };
+
+  int64_t tile = blockIdx.x;
+  int32_t ia, ib, na, nb;
+  typename M::frag ca[S], cb[S], pa[S], pb[S];
+  load_idx(tile, ia, ib);
+  load_rows(ia, ib, ca, cb);
+  load_idx(tile + gridDim.x, na, nb);
+  for (; tile < tiles; tile += gridDim.x) {
+    load_rows(na, nb, pa, pb);                       // next tile's rows (entries fetched one round ago)
+    load_idx(tile + 2 * (int64_t)gridDim.x, na, nb);  // entries of the tile after next
+    f32x4 acc[2][NTILES];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int t = 0; t < NTILES; ++t) acc[s2][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int col = s * 32 + g * 8;
+      const T* wrow = wl + r * pitch + col;
+#pragma unroll
+      for (int t = 0; t < NTILES; ++t) {
+        typename M::frag fw = M::zero();
+        if (col < c_in) fw = ld_frag<T>(wrow + t * 16 * pitch);
+        acc[0][t] = M::mma(fw, ca[s], acc[0][t]);
+        acc[1][t] = M::mma(fw, cb[s], acc[1][t]);
+      }
+    }
+    const int64_t rowA = tile * F2_ROWS + wave * 32 + r;
+    sc_epilogue<T, NTILES>(acc, bias, out, rowA, rowA + 16, n_out, c_out, n0, g);
+#pragma unroll
+    for (int s = 0; s < S; ++s) { ca[s] = pa[s]; cb[s] = pb[s]; }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+static inline bool fwd2_supported(int dtype, int kv, int c_in) { return dtype != PTC_F32 && c_in <= (kv == 1 ? 256 : 128); }
+
+static inline int conv2_kg(int kv, int c_in, int nt) {
+  const int per_k = nt * (c_in + 8) * 2 + 4 * 32 * 4;
+  int kgmax = F2_MAX_W_BYTES / per_k;
+  if (kgmax < 1) kgmax = 1;
+  const int groups = (kv + kgmax - 1) / kgmax;
+  return (kv + groups - 1) / groups;
+}
+
+template <typename T, int NTILES>
+static int launch_fwd2(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
+                       int c_out, void* out, hipStream_t s) {
+  constexpr int NT = NTILES * 16;
+  if (kv == 1) {
+    const size_t lds = (size_t)NT * (c_in + 8) * 2;
+    const int64_t tiles = ptc_cdiv(n_out, F2_ROWS);
+    const int64_t per_cu = lds > 40 * 1024 ? 2 : 4;
+    int64_t gx = 256 * per_cu / (c_out / NT);
+    if (gx > tiles) gx = tiles;
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)(c_out / NT));
+    const int S = (c_in + 31) / 32;
+#define L2_CASE(SS)                                                                                                     \
+  case SS: {                                                                                                            \
+    auto kern = linear2_kernel<T, NTILES, SS>;                                                                          \
+    if (lds > 48 * 1024)                                                                                                \
+      PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, c_in, c_out, (T*)out);  \
+  } break;
+    switch (S) {
+      L2_CASE(1) L2_CASE(2) L2_CASE(3) L2_CASE(4) L2_CASE(5) L2_CASE(6) L2_CASE(7) L2_CASE(8)
+      default: ptc_set_error("linear2: c_in=%d unsupported", c_in); return PTC_EUNSUPPORTED;
+    }
+#undef L2_CASE
+    PTC_CHECK_LAUNCH("linear2_kernel");
+    return PTC_OK;
+  }
+  const int kg = conv2_kg(kv, c_in, NT);
+  const size_t lds = (((size_t)kg * NT * (c_in + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * kg * 32 * 4;
+  auto kern = conv2_kernel<T, NTILES, 4>;
+  if (lds > 48 * 1024)
+    PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((unsigned)ptc_cdiv(n_out, F2_ROWS), (unsigned)(c_out / NT));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv, c_in, c_out, kg, (T*)out);
+  PTC_CHECK_LAUNCH("conv2_kernel");
+  return PTC_OK;
+}
+
+template <typename T>
+static int dispatch_fwd2(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
+                         int c_out, void* out, hipStream_t s) {
+  if (c_out % 128 == 0) return launch_fwd2<T, 8>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  if (c_out % 96 == 0) return launch_fwd2<T, 6>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  if (c_out % 64 == 0) return launch_fwd2<T, 4>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  if (c_out % 48 == 0) return launch_fwd2<T, 3>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  if (c_out % 32 == 0) return launch_fwd2<T, 2>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  return launch_fwd2<T, 1>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+}

@@ -52,6 +52,50 @@ __device__ __forceinline__ int lds_row_of_channel(int n) {
   return 16 * (gs + tt) + 4 * gq + e;
 }
 
+// epilogue shared by the forward kernels: for a group of G tiles starting at gs, lane (row r, group g)
+// holds channels n0 + 16*gs + 4G*g + 4*tt + e (tt < G, e < 4) = 4G consecutive channels of its row.
+template <typename T, int NTILES>
+__device__ __forceinline__ void sc_epilogue(f32x4 (&acc)[2][NTILES], const float* __restrict__ bias, T* __restrict__ out,
+                                            int64_t rowA, int64_t rowB, int64_t n_out, int c_out, int n0, int g) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int64_t row = s ? rowB : rowA;
+    if (row >= n_out) continue;
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) {
+      constexpr int dummy = 0; (void)dummy;
+      const int gs = TileGroups<NTILES>::gstart(t), G = TileGroups<NTILES>::gsize(t);
+      if (t != gs) continue;                      // one store sequence per group
+      const int ch0 = n0 + 16 * gs + 4 * G * g;
+      T o[16];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        if (tt < G) {
+          f32x4 v = acc[s][(gs + tt) < NTILES ? (gs + tt) : t];
+          if (bias) {
+            v[0] += bias[ch0 + 4 * tt]; v[1] += bias[ch0 + 4 * tt + 1];
+            v[2] += bias[ch0 + 4 * tt + 2]; v[3] += bias[ch0 + 4 * tt + 3];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[4 * tt + e] = ptc_from_float<T>(v[e]);
+        }
+      }
+      T* dst = out + row * c_out + ch0;
+      constexpr int BYTES4 = 4 * (int)sizeof(T);   // bytes of 4 channels
+      if (G == 4) {
+        if (BYTES4 == 8) { reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0]; reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<uint4*>(o)[1]; }
+        else { for (int q4 = 0; q4 < 4; ++q4) reinterpret_cast<uint4*>(dst)[q4] = reinterpret_cast<uint4*>(o)[q4]; }
+      } else if (G == 2) {
+        if (BYTES4 == 8) reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0];
+        else { reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0]; reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<uint4*>(o)[1]; }
+      } else {
+        if (BYTES4 == 8) reinterpret_cast<uint2*>(dst)[0] = reinterpret_cast<uint2*>(o)[0];
+        else reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0];
+      }
+    }
+  }
+}
+
 template <typename T, int NTILES>
 __global__ void __launch_bounds__(256)
 spconv_fwd_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
@@ -116,45 +160,7 @@ spconv_fwd_kernel(const T* __restrict__ in, const T* __restrict__ w, const float
       }
     }
   }
-  // epilogue: for a group of G tiles starting at gs, lane (row r, group g) holds channels
-  // n0 + 16*gs + 4G*g + 4*tt + e  (tt < G, e < 4): 4G consecutive channels.
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int64_t row = s ? rowB : rowA;
-    if (row >= n_out) continue;
-#pragma unroll
-    for (int t = 0; t < NTILES; ++t) {
-      constexpr int dummy = 0; (void)dummy;
-      const int gs = TileGroups<NTILES>::gstart(t), G = TileGroups<NTILES>::gsize(t);
-      if (t != gs) continue;                      // one store sequence per group
-      const int ch0 = n0 + 16 * gs + 4 * G * g;
-      T o[16];
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        if (tt < G) {
-          f32x4 v = acc[s][(gs + tt) < NTILES ? (gs + tt) : t];
-          if (bias) {
-            v[0] += bias[ch0 + 4 * tt]; v[1] += bias[ch0 + 4 * tt + 1];
-            v[2] += bias[ch0 + 4 * tt + 2]; v[3] += bias[ch0 + 4 * tt + 3];
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[4 * tt + e] = ptc_from_float<T>(v[e]);
-        }
-      }
-      T* dst = out + row * c_out + ch0;
-      constexpr int BYTES4 = 4 * (int)sizeof(T);   // bytes of 4 channels
-      if (G == 4) {
-        if (BYTES4 == 8) { reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0]; reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<uint4*>(o)[1]; }
-        else { for (int q4 = 0; q4 < 4; ++q4) reinterpret_cast<uint4*>(dst)[q4] = reinterpret_cast<uint4*>(o)[q4]; }
-      } else if (G == 2) {
-        if (BYTES4 == 8) reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0];
-        else { reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0]; reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<uint4*>(o)[1]; }
-      } else {
-        if (BYTES4 == 8) reinterpret_cast<uint2*>(dst)[0] = reinterpret_cast<uint2*>(o)[0];
-        else reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0];
-      }
-    }
-  }
+  sc_epilogue<T, NTILES>(acc, bias, out, rowA, rowB, n_out, c_out, n0, g);
 }
 
 template <typename T, int NTILES>
@@ -179,6 +185,8 @@ static int dispatch_fwd(const void* in, const void* w, const float* bias, const 
   return launch_fwd<T, 1>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
 }
 
+#include "fwd2.h"
+
 extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr,
                               int64_t n_out, int kv, int c_in, int c_out, int dtype, void* out, ptc_stream_t stream) {
   PTC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1, PTC_EINVAL, "ptc_spconv_fwd: bad sizes");
@@ -190,6 +198,10 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
   PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)out % 16 == 0), PTC_EINVAL,
               "ptc_spconv_fwd: buffers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  if (fwd2_supported(dtype, kv, c_in) && (nbr || kv == 1)) {
+    if (dtype == PTC_BF16) return dispatch_fwd2<bf16_t>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
+    return dispatch_fwd2<f16_t>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  }
   PTC_DISPATCH_DTYPE(dtype, T, return dispatch_fwd<T>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s));
   return PTC_OK;
 }
