@@ -36,11 +36,10 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   const int S = (c_in + 31) >> 5;                      // 32-channel steps per table row
   const int vpr = c_in >> 3;                           // 16-byte vectors per weight row
 
-  f32x4 acc[2][NTILES];
+  f32x4 acc[2][NTILES], breg[NTILES];
+  sc_bias_regs<NTILES>(bias, n0, g, breg);
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int t = 0; t < NTILES; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTILES; ++t) { acc[0][t] = breg[t]; acc[1][t] = breg[t]; }
 
   for (int k0 = 0; k0 < kv; k0 += kg) {
     const int gk = (kv - k0) < kg ? (kv - k0) : kg;
@@ -99,7 +98,7 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       }
     }
   }
-  sc_epilogue<T, NTILES>(acc, bias, out, rowA, rowB, n_out, c_out, n0, g);
+  sc_epilogue<T, NTILES>(acc, nullptr, out, rowA, rowB, n_out, c_out, n0, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -121,6 +120,8 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
     *reinterpret_cast<uint4*>(wl + lds_row_of_channel<NTILES>(n) * pitch + cc * 8) =
         *reinterpret_cast<const uint4*>(w + (int64_t)(n0 + n) * c_in + cc * 8);
   }
+  f32x4 breg[NTILES];
+  sc_bias_regs<NTILES>(bias, n0, g, breg);
   __syncthreads();
 
   const int64_t tiles = (n_out + F2_ROWS - 1) / F2_ROWS;
@@ -155,9 +156,7 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
     load_idx(tile + 2 * (int64_t)gridDim.x, na, nb);  // entries of the tile after next
     f32x4 acc[2][NTILES];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int t = 0; t < NTILES; ++t) acc[s2][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTILES; ++t) { acc[0][t] = breg[t]; acc[1][t] = breg[t]; }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const int col = s * 32 + g * 8;
@@ -171,7 +170,7 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
       }
     }
     const int64_t rowA = tile * F2_ROWS + wave * 32 + r;
-    sc_epilogue<T, NTILES>(acc, bias, out, rowA, rowA + 16, n_out, c_out, n0, g);
+    sc_epilogue<T, NTILES>(acc, nullptr, out, rowA, rowA + 16, n_out, c_out, n0, g);
 #pragma unroll
     for (int s = 0; s < S; ++s) { ca[s] = pa[s]; cb[s] = pb[s]; }
   }

@@ -50,13 +50,16 @@ __device__ __forceinline__ float ptc_to_float(float v) { return v; }
 __device__ __forceinline__ float ptc_to_float(bf16_t v) { return __uint_as_float(((uint32_t)v.x) << 16); }
 __device__ __forceinline__ float ptc_to_float(f16_t v) { return (float)v.x; }
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet), same rounding as torch's .to(bfloat16)
-__device__ __forceinline__ uint16_t ptc_f32_to_bf16_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet), same rounding as torch's .to(bfloat16):
+// the hardware conversion v_cvt_pk_bf16_f32 of gfx950 (one instruction per two values)
+__device__ __forceinline__ uint32_t ptc_pack_bf16x2(float lo, float hi) {
+  typedef float ptc_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 ptc_bf16x2 __attribute__((ext_vector_type(2)));
+  ptc_f32x2 f = {lo, hi};
+  ptc_bf16x2 h = __builtin_convertvector(f, ptc_bf16x2);
+  return *reinterpret_cast<uint32_t*>(&h);
 }
+__device__ __forceinline__ uint16_t ptc_f32_to_bf16_bits(float f) { return (uint16_t)(ptc_pack_bf16x2(f, 0.f) & 0xffffu); }
 template <typename T> __device__ __forceinline__ T ptc_from_float(float v);
 template <> __device__ __forceinline__ float ptc_from_float<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t ptc_from_float<bf16_t>(float v) { bf16_t r; r.x = ptc_f32_to_bf16_bits(v); return r; }

@@ -52,6 +52,21 @@ __device__ __forceinline__ int lds_row_of_channel(int n) {
   return 16 * (gs + tt) + 4 * gq + e;
 }
 
+// accumulator initialisation = bias of the channel each accumulator element will be stored to (the
+// inverse of the epilogue mapping): the bias add costs nothing and, above all, no global load sits
+// between the last MFMA and the stores (loads return in order: a bias load in the epilogue would
+// queue behind the rows prefetched for the next tile).
+template <int NTILES>
+__device__ __forceinline__ void sc_bias_regs(const float* __restrict__ bias, int n0, int g, f32x4 (&b)[NTILES]) {
+#pragma unroll
+  for (int t = 0; t < NTILES; ++t) {
+    const int gs = TileGroups<NTILES>::gstart(t), G = TileGroups<NTILES>::gsize(t);
+    const int ch = n0 + 16 * gs + 4 * G * g + 4 * (t - gs);
+    b[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (bias) b[t] = *reinterpret_cast<const f32x4*>(bias + ch);
+  }
+}
+
 // epilogue shared by the forward kernels: for a group of G tiles starting at gs, lane (row r, group g)
 // holds channels n0 + 16*gs + 4G*g + 4*tt + e (tt < G, e < 4) = 4G consecutive channels of its row.
 template <typename T, int NTILES>
@@ -67,7 +82,7 @@ __device__ __forceinline__ void sc_epilogue(f32x4 (&acc)[2][NTILES], const float
       const int gs = TileGroups<NTILES>::gstart(t), G = TileGroups<NTILES>::gsize(t);
       if (t != gs) continue;                      // one store sequence per group
       const int ch0 = n0 + 16 * gs + 4 * G * g;
-      T o[16];
+      __attribute__((aligned(16))) T o[16];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         if (tt < G) {
@@ -76,8 +91,14 @@ __device__ __forceinline__ void sc_epilogue(f32x4 (&acc)[2][NTILES], const float
             v[0] += bias[ch0 + 4 * tt]; v[1] += bias[ch0 + 4 * tt + 1];
             v[2] += bias[ch0 + 4 * tt + 2]; v[3] += bias[ch0 + 4 * tt + 3];
           }
+          if (std::is_same<T, bf16_t>::value) {
+            uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+            o32[2 * tt] = ptc_pack_bf16x2(v[0], v[1]);
+            o32[2 * tt + 1] = ptc_pack_bf16x2(v[2], v[3]);
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[4 * tt + e] = ptc_from_float<T>(v[e]);
+            for (int e = 0; e < 4; ++e) o[4 * tt + e] = ptc_from_float<T>(v[e]);
+          }
         }
       }
       T* dst = out + row * c_out + ch0;
