@@ -18,7 +18,7 @@
 #define F2_MAX_W_BYTES (40 * 1024)
 
 template <typename T, int NTILES, int PD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
              const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int kg, T* __restrict__ out) {
   using M = Mma<T>;
@@ -41,6 +41,7 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 #pragma unroll
   for (int t = 0; t < NTILES; ++t) { acc[0][t] = breg[t]; acc[1][t] = breg[t]; }
 
+#pragma unroll 1
   for (int k0 = 0; k0 < kv; k0 += kg) {
     const int gk = (kv - k0) < kg ? (kv - k0) : kg;
     if (k0 > 0) __syncthreads();  // every wave is done with the previous group's W slices
@@ -73,16 +74,16 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 #pragma unroll
     for (int j = 0; j < PD; ++j)
       if (j < U) issue(j, j);
+#pragma unroll 1
     for (int base = 0; base < U; base += PD) {
 #pragma unroll
       for (int j = 0; j < PD; ++j) {
         const int u = base + j;
         if (u < U) {
           const typename M::frag fa = ra[j], fb = rb[j];
-          const bool anyA = __builtin_amdgcn_ballot_w64(xa[j] >= 0) != 0;
-          const bool anyB = __builtin_amdgcn_ballot_w64(xb[j] >= 0) != 0;
+          const bool any = __builtin_amdgcn_ballot_w64((xa[j] >= 0) | (xb[j] >= 0)) != 0;
           if (u + PD < U) issue(j, u + PD);
-          if (anyA | anyB) {
+          if (any) {
             const int kk = u / S, s = u - kk * S;
             const int col = s * 32 + g * 8;
             const T* wrow = wl + (kk * NT + r) * pitch + col;
@@ -90,8 +91,8 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
             for (int t = 0; t < NTILES; ++t) {
               typename M::frag fw = M::zero();
               if (col < c_in) fw = ld_frag<T>(wrow + t * 16 * pitch);
-              if (anyA) acc[0][t] = M::mma(fw, fa, acc[0][t]);
-              if (anyB) acc[1][t] = M::mma(fw, fb, acc[1][t]);
+              acc[0][t] = M::mma(fw, fa, acc[0][t]);
+              acc[1][t] = M::mma(fw, fb, acc[1][t]);
             }
           }
         }
@@ -151,6 +152,7 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
   load_idx(tile, ia, ib);
   load_rows(ia, ib, ca, cb);
   load_idx(tile + gridDim.x, na, nb);
+#pragma unroll 1
   for (; tile < tiles; tile += gridDim.x) {
     load_rows(na, nb, pa, pb);                       // next tile's rows (entries fetched one round ago)
     load_idx(tile + 2 * (int64_t)gridDim.x, na, nb);  // entries of the tile after next

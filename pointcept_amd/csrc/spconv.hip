@@ -69,6 +69,14 @@ __device__ __forceinline__ void sc_bias_regs(const float* __restrict__ bias, int
 
 // epilogue shared by the forward kernels: for a group of G tiles starting at gs, lane (row r, group g)
 // holds channels n0 + 16*gs + 4G*g + 4*tt + e (tt < G, e < 4) = 4G consecutive channels of its row.
+// two fp32 values -> one 32-bit word of two 16-bit features (RNE)
+template <typename T> __device__ __forceinline__ uint32_t sc_pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t sc_pack2<bf16_t>(float lo, float hi) { return ptc_pack_bf16x2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t sc_pack2<f16_t>(float lo, float hi) {
+  const _Float16 a = (_Float16)lo, b = (_Float16)hi;
+  return (uint32_t)(*reinterpret_cast<const uint16_t*>(&a)) | ((uint32_t)(*reinterpret_cast<const uint16_t*>(&b)) << 16);
+}
+
 template <typename T, int NTILES>
 __device__ __forceinline__ void sc_epilogue(f32x4 (&acc)[2][NTILES], const float* __restrict__ bias, T* __restrict__ out,
                                             int64_t rowA, int64_t rowB, int64_t n_out, int c_out, int n0, int g) {
@@ -78,40 +86,38 @@ __device__ __forceinline__ void sc_epilogue(f32x4 (&acc)[2][NTILES], const float
     if (row >= n_out) continue;
 #pragma unroll
     for (int t = 0; t < NTILES; ++t) {
-      constexpr int dummy = 0; (void)dummy;
       const int gs = TileGroups<NTILES>::gstart(t), G = TileGroups<NTILES>::gsize(t);
       if (t != gs) continue;                      // one store sequence per group
       const int ch0 = n0 + 16 * gs + 4 * G * g;
-      __attribute__((aligned(16))) T o[16];
+      f32x4 v[4];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
-        if (tt < G) {
-          f32x4 v = acc[s][(gs + tt) < NTILES ? (gs + tt) : t];
-          if (bias) {
-            v[0] += bias[ch0 + 4 * tt]; v[1] += bias[ch0 + 4 * tt + 1];
-            v[2] += bias[ch0 + 4 * tt + 2]; v[3] += bias[ch0 + 4 * tt + 3];
-          }
-          if (std::is_same<T, bf16_t>::value) {
-            uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
-            o32[2 * tt] = ptc_pack_bf16x2(v[0], v[1]);
-            o32[2 * tt + 1] = ptc_pack_bf16x2(v[2], v[3]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[4 * tt + e] = ptc_from_float<T>(v[e]);
-          }
+        v[tt] = acc[s][(gs + tt) < NTILES ? (gs + tt) : t];
+        if (bias && tt < G) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch0 + 4 * tt);
+          v[tt] += b;
         }
       }
       T* dst = out + row * c_out + ch0;
-      constexpr int BYTES4 = 4 * (int)sizeof(T);   // bytes of 4 channels
-      if (G == 4) {
-        if (BYTES4 == 8) { reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0]; reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<uint4*>(o)[1]; }
-        else { for (int q4 = 0; q4 < 4; ++q4) reinterpret_cast<uint4*>(dst)[q4] = reinterpret_cast<uint4*>(o)[q4]; }
-      } else if (G == 2) {
-        if (BYTES4 == 8) reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0];
-        else { reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0]; reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<uint4*>(o)[1]; }
+      if constexpr (sizeof(T) == 2) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          pk[2 * tt] = sc_pack2<T>(v[tt][0], v[tt][1]);
+          pk[2 * tt + 1] = sc_pack2<T>(v[tt][2], v[tt][3]);
+        }
+        if (G == 4) {
+          reinterpret_cast<uint4*>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+          reinterpret_cast<uint4*>(dst)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        } else if (G == 2) {
+          reinterpret_cast<uint4*>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        } else {
+          reinterpret_cast<uint2*>(dst)[0] = make_uint2(pk[0], pk[1]);
+        }
       } else {
-        if (BYTES4 == 8) reinterpret_cast<uint2*>(dst)[0] = reinterpret_cast<uint2*>(o)[0];
-        else reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<uint4*>(o)[0];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+          if (tt < G) reinterpret_cast<f32x4*>(dst)[tt] = v[tt];
       }
     }
   }
