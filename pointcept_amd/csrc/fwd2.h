@@ -17,8 +17,8 @@
 #define F2_ROWS 128
 #define F2_MAX_W_BYTES (40 * 1024)
 
-template <typename T, int NTILES, int PD>
-__global__ void __launch_bounds__(256, 3)
+template <typename T, int NTILES, int PD, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 3 : 2)
 conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
              const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int kg, T* __restrict__ out) {
   using M = Mma<T>;
@@ -30,7 +30,7 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   int32_t* il = reinterpret_cast<int32_t*>(smem + w_bytes) + wave * kg * 32;  // this wave's [kg][32] entries
   const int r = lane & 15, g = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * F2_ROWS + wave * 32;
+  const int64_t row0 = (int64_t)blockIdx.x * (WAVES * 32) + wave * 32;
   const int n0 = blockIdx.y * NT;
   const int64_t rowA = row0 + r, rowB = row0 + 16 + r;
   const int S = (c_in + 31) >> 5;                      // 32-channel steps per table row
@@ -49,7 +49,7 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       const int64_t row = row0 + (q & 31);
       il[q] = row < n_out ? nbr[(int64_t)(k0 + (q >> 5)) * n_out + row] : -1;
     }
-    for (int q = threadIdx.x; q < gk * NT * vpr; q += 256) {
+    for (int q = threadIdx.x; q < gk * NT * vpr; q += WAVES * 64) {
       const int kk = q / (NT * vpr), rem = q - kk * NT * vpr;
       const int n = rem / vpr, cc = rem - n * vpr;
       *reinterpret_cast<uint4*>(wl + (kk * NT + lds_row_of_channel<NTILES>(n)) * pitch + cc * 8) =
@@ -181,8 +181,8 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
 // ---- host side ---------------------------------------------------------------------------------
 static inline bool fwd2_supported(int dtype, int kv, int c_in) { return dtype != PTC_F32 && c_in <= (kv == 1 ? 256 : 128); }
 
-static inline int conv2_kg(int kv, int c_in, int nt) {
-  const int per_k = nt * (c_in + 8) * 2 + 4 * 32 * 4;
+static inline int conv2_kg(int kv, int c_in, int nt, int waves) {
+  const int per_k = nt * (c_in + 8) * 2 + waves * 32 * 4;
   int kgmax = F2_MAX_W_BYTES / per_k;
   if (kgmax < 1) kgmax = 1;
   const int groups = (kv + kgmax - 1) / kgmax;
@@ -217,13 +217,17 @@ static int launch_fwd2(const void* in, const void* w, const float* bias, const i
     PTC_CHECK_LAUNCH("linear2_kernel");
     return PTC_OK;
   }
-  const int kg = conv2_kg(kv, c_in, NT);
-  const size_t lds = (((size_t)kg * NT * (c_in + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * kg * 32 * 4;
-  auto kern = conv2_kernel<T, NTILES, 4>;
+  // W slices are restaged per workgroup: with >= 64 output channels the restaging traffic (from L2)
+  // rivals the gathered rows, so those shapes use 8-wave workgroups (256 rows share one staged copy)
+  constexpr int WAVES = NTILES >= 4 ? 8 : 4;
+  const int kg = conv2_kg(kv, c_in, NT, WAVES);
+  const size_t lds = (((size_t)kg * NT * (c_in + 8) * 2 + 15) & ~(size_t)15) + (size_t)WAVES * kg * 32 * 4;
+  auto kern = conv2_kernel<T, NTILES, 4, WAVES>;
   if (lds > 48 * 1024)
     PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid((unsigned)ptc_cdiv(n_out, F2_ROWS), (unsigned)(c_out / NT));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv, c_in, c_out, kg, (T*)out);
+  dim3 grid((unsigned)ptc_cdiv(n_out, WAVES * 32), (unsigned)(c_out / NT));
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv, c_in, c_out, kg,
+                     (T*)out);
   PTC_CHECK_LAUNCH("conv2_kernel");
   return PTC_OK;
 }

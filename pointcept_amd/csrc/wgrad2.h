@@ -18,6 +18,7 @@
 //     deterministic reduction kernel (no atomics, bit-reproducible).
 #pragma once
 #include "mma.h"
+#include <stdlib.h>
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
@@ -209,10 +210,18 @@ struct W2Plan {
   size_t lds;
 };
 
+static inline int w2_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out) {
+  static const int cot_max = w2_env_int("PTC_W2_COT_MAX", 8), cit_max = w2_env_int("PTC_W2_CIT_MAX", 4);  // tuning knobs
   W2Plan p;
   p.cit = c_in <= 16 ? 1 : (c_in <= 32 ? 2 : 4);
   p.cot = c_out <= 32 ? 2 : (c_out <= 64 ? 4 : (c_out <= 96 ? 6 : 8));
+  if (p.cot > cot_max) p.cot = cot_max;
+  if (p.cit > cit_max) p.cit = cit_max;
   p.kg = 1;
   if (kv > 1) {  // instantiated groups (register budget: KG*COT*CIT*4 accumulators)
     if (p.cot == 2 && p.cit == 1) p.kg = 16;

@@ -159,6 +159,18 @@ def sparse_conv(feat, weight, bias, nbr, nbr_t, mirror: bool):
 # ------------------------------------------------------------------------------------------------
 # dense row-wise GEMM (nn.Linear on [N,C] point features) on the sparse-conv MFMA kernels
 # ------------------------------------------------------------------------------------------------
+# Shape policy (measured, profiles/r01_c_bench_ops.txt): the engine's streaming kernels win on tall-skinny
+# shapes (many rows, contraction <= 256 channels) and on every weight gradient with >= 4096 rows;
+# hipBLASLt wins on the short, wide GEMMs of the deep stages (N <= ~1e4, C >= 256).
+_OWN_MIN_ROWS = 32768
+_OWN_MAX_K = 256
+_OWN_WGRAD_MIN_ROWS = 4096
+
+
+def _own_gemm(n_rows: int, k: int, dtype: torch.dtype) -> bool:
+    return dtype != torch.float32 and n_rows >= _OWN_MIN_ROWS and k <= _OWN_MAX_K
+
+
 class _Linear(Function):
     """out[o] = W x[tab[o]] + b.  tab_fwd [1, n_out] int32 (None = identity) folds a row gather into
     the GEMM; tab_bwd [k, n_in] int32 lists, for every input row, the output rows that read it
@@ -170,8 +182,11 @@ class _Linear(Function):
         c_out, c_in = weight.shape
         xp = _pad_to(x.to(dt), 1, 16).contiguous()
         wp = _pad_to(_pad_to(weight.to(dt), 1, 16), 0, 16).contiguous()
-        bp = None if bias is None else _pad_to(bias.float(), 0, 16)
-        out = ops.spconv_fwd(xp, wp[:, None, :], bp, tab_fwd)
+        if tab_fwd is not None or dt == torch.float32 or _own_gemm(xp.shape[0], xp.shape[1], dt):
+            bp = None if bias is None else _pad_to(bias.float(), 0, 16)
+            out = ops.spconv_fwd(xp, wp[:, None, :], bp, tab_fwd)
+        else:
+            out = F.linear(xp, wp, None if bias is None else _pad_to(bias.to(dt), 0, 16))
         ctx.save_for_backward(xp, wp, tab_fwd, tab_bwd)
         ctx.shape = (c_out, c_in)
         ctx.in_dtype, ctx.w_dtype = x.dtype, weight.dtype
@@ -186,15 +201,23 @@ class _Linear(Function):
         g = _pad_to(grad.to(xp.dtype), 1, 16).contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = wp.t().contiguous()[:, None, :]                       # [c_in, 1, c_out]
-            if tab_bwd is not None and tab_bwd.shape[0] > 1:
-                wt = wt.expand(-1, tab_bwd.shape[0], -1).contiguous()   # same W for every slot
-            dx = ops.spconv_fwd(g, wt, None, tab_bwd)[:, :c_in].to(ctx.in_dtype)
-        if ctx.needs_input_grad[1] or (ctx.b_dtype is not None and ctx.needs_input_grad[2]):
-            want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
-            res = ops.spconv_wgrad(xp, g, tab_fwd, want_bias=want_b)
-            dwp, dbp = res if want_b else (res, None)
-            dw = dwp[:c_out, 0, :c_in].to(ctx.w_dtype)
+            if tab_bwd is not None or xp.dtype == torch.float32 or _own_gemm(xp.shape[0], g.shape[1], xp.dtype):
+                wt = wp.t().contiguous()[:, None, :]                       # [c_in, 1, c_out]
+                if tab_bwd is not None and tab_bwd.shape[0] > 1:
+                    wt = wt.expand(-1, tab_bwd.shape[0], -1).contiguous()   # same W for every slot
+                dx = ops.spconv_fwd(g, wt, None, tab_bwd)
+            else:
+                dx = g @ wp
+            dx = dx[:, :c_in].to(ctx.in_dtype)
+        want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            if tab_fwd is not None or xp.dtype == torch.float32 or g.shape[0] >= _OWN_WGRAD_MIN_ROWS:
+                res = ops.spconv_wgrad(xp, g, tab_fwd, want_bias=want_b)
+                dwp, dbp = res if want_b else (res, None)
+                dw = dwp[:c_out, 0, :c_in].to(ctx.w_dtype)
+            else:
+                dw = (g.t() @ xp)[:c_out, :c_in].to(ctx.w_dtype)
+                dbp = g.float().sum(0) if want_b else None
             if want_b:
                 db = dbp[:c_out].to(ctx.b_dtype)
         return dx, dw, db, None, None
