@@ -12,6 +12,8 @@ settings), and so a regression can be bisected without a rebuild.
                      folding the permutation into the qkv / proj GEMMs (kv = 1 gather tables)
   PTC_SORT_POINTS=0  PT-v3m1 keeps the caller's (dataloader) row order at stage 0 instead of physically
                      sorting the points along the first serialization curve for L2 locality
+  PTC_FUSE_BLOCK=0   the three residual joints of a PTv3 Block run as separate LayerNorm / add / cast
+                     kernels instead of the fused add_norm passes
 """
 from __future__ import annotations
 
@@ -29,3 +31,4 @@ OWN_LINEAR = _flag("PTC_OWN_LINEAR", True)
 OWN_NORM = _flag("PTC_OWN_NORM", True)
 FUSE_GATHER = _flag("PTC_FUSE_GATHER", True)
 SORT_POINTS = _flag("PTC_SORT_POINTS", True)
+FUSE_BLOCK = _flag("PTC_FUSE_BLOCK", True)

@@ -24,7 +24,12 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   using M = Mma<T>;
   constexpr int NT = NTILES * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int pitch = c_in + 8;                          // elements; +16 B staggers the fragment reads
+  // contraction chunks of <= 128 channels: a "virtual table row" v = k * nch + chunk reads W[.][k][chunk]
+  // and the same table entry nbr[k]; c_in <= 128 is the single-chunk case
+  const int cc_len = c_in < 128 ? c_in : 128;          // c_in % 128 == 0 when c_in > 128 (host-checked)
+  const int nch = c_in / cc_len;
+  const int kvv = kv * nch;
+  const int pitch = cc_len + 8;                        // elements; +16 B staggers the fragment reads
   T* wl = reinterpret_cast<T*>(smem);                  // [kg][NT][pitch]
   const int w_bytes = (kg * NT * pitch * 2 + 15) & ~15;
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
@@ -33,8 +38,8 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   const int64_t row0 = (int64_t)blockIdx.x * (WAVES * 32) + wave * 32;
   const int n0 = blockIdx.y * NT;
   const int64_t rowA = row0 + r, rowB = row0 + 16 + r;
-  const int S = (c_in + 31) >> 5;                      // 32-channel steps per table row
-  const int vpr = c_in >> 3;                           // 16-byte vectors per weight row
+  const int S = (cc_len + 31) >> 5;                    // 32-channel steps per virtual table row
+  const int vpr = cc_len >> 3;                         // 16-byte vectors per staged weight row
 
   f32x4 acc[2][NTILES], breg[NTILES];
   sc_bias_regs<NTILES>(bias, n0, g, breg);
@@ -42,18 +47,19 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   for (int t = 0; t < NTILES; ++t) { acc[0][t] = breg[t]; acc[1][t] = breg[t]; }
 
 #pragma unroll 1
-  for (int k0 = 0; k0 < kv; k0 += kg) {
-    const int gk = (kv - k0) < kg ? (kv - k0) : kg;
+  for (int k0 = 0; k0 < kvv; k0 += kg) {
+    const int gk = (kvv - k0) < kg ? (kvv - k0) : kg;
     if (k0 > 0) __syncthreads();  // every wave is done with the previous group's W slices
     for (int q = lane; q < gk * 32; q += 64) {
       const int64_t row = row0 + (q & 31);
-      il[q] = row < n_out ? nbr[(int64_t)(k0 + (q >> 5)) * n_out + row] : -1;
+      il[q] = row < n_out ? nbr[(int64_t)((k0 + (q >> 5)) / nch) * n_out + row] : -1;
     }
     for (int q = threadIdx.x; q < gk * NT * vpr; q += WAVES * 64) {
       const int kk = q / (NT * vpr), rem = q - kk * NT * vpr;
       const int n = rem / vpr, cc = rem - n * vpr;
+      const int v = k0 + kk, k = v / nch, ch = v - k * nch;
       *reinterpret_cast<uint4*>(wl + (kk * NT + lds_row_of_channel<NTILES>(n)) * pitch + cc * 8) =
-          *reinterpret_cast<const uint4*>(w + ((int64_t)(n0 + n) * kv + (k0 + kk)) * c_in + cc * 8);
+          *reinterpret_cast<const uint4*>(w + ((int64_t)(n0 + n) * kv + k) * c_in + ch * cc_len + cc * 8);
     }
     __syncthreads();
 
@@ -63,11 +69,12 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
     auto issue = [&](int j, int u) {
       const int kk = u / S, s = u - kk * S;
       const int col = s * 32 + g * 8;
+      const int base_c = ((k0 + kk) % nch) * cc_len;
       const int32_t ia = il[kk * 32 + r], ib = il[kk * 32 + 16 + r];
       typename M::frag fa = M::zero(), fb = M::zero();
-      if (col < c_in) {
-        if (ia >= 0) fa = ld_frag<T>(in + (int64_t)ia * c_in + col);
-        if (ib >= 0) fb = ld_frag<T>(in + (int64_t)ib * c_in + col);
+      if (col < cc_len) {
+        if (ia >= 0) fa = ld_frag<T>(in + (int64_t)ia * c_in + base_c + col);
+        if (ib >= 0) fb = ld_frag<T>(in + (int64_t)ib * c_in + base_c + col);
       }
       ra[j] = fa; rb[j] = fb; xa[j] = ia; xb[j] = ib;
     };
@@ -90,7 +97,7 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 #pragma unroll
             for (int t = 0; t < NTILES; ++t) {
               typename M::frag fw = M::zero();
-              if (col < c_in) fw = ld_frag<T>(wrow + t * 16 * pitch);
+              if (col < cc_len) fw = ld_frag<T>(wrow + t * 16 * pitch);
               acc[0][t] = M::mma(fw, fa, acc[0][t]);
               acc[1][t] = M::mma(fw, fb, acc[1][t]);
             }
@@ -179,9 +186,12 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static inline bool fwd2_supported(int dtype, int kv, int c_in) { return dtype != PTC_F32 && c_in <= (kv == 1 ? 256 : 128); }
+static inline bool fwd2_supported(int dtype, int kv, int c_in) {
+  if (dtype == PTC_F32) return false;
+  return kv == 1 ? c_in <= 256 : (c_in <= 128 || c_in % 128 == 0);
+}
 
-static inline int conv2_kg(int kv, int c_in, int nt, int waves) {
+static inline int conv2_kg(int kv, int c_in, int nt, int waves) {  // kv = number of VIRTUAL table rows, c_in = chunk length
   const int per_k = nt * (c_in + 8) * 2 + waves * 32 * 4;
   int kgmax = F2_MAX_W_BYTES / per_k;
   if (kgmax < 1) kgmax = 1;
@@ -217,11 +227,10 @@ static int launch_fwd2(const void* in, const void* w, const float* bias, const i
     PTC_CHECK_LAUNCH("linear2_kernel");
     return PTC_OK;
   }
-  // W slices are restaged per workgroup: with >= 64 output channels the restaging traffic (from L2)
-  // rivals the gathered rows, so those shapes use 8-wave workgroups (256 rows share one staged copy)
-  constexpr int WAVES = NTILES >= 4 ? 8 : 4;
-  const int kg = conv2_kg(kv, c_in, NT, WAVES);
-  const size_t lds = (((size_t)kg * NT * (c_in + 8) * 2 + 15) & ~(size_t)15) + (size_t)WAVES * kg * 32 * 4;
+  constexpr int WAVES = 4;  // 8-wave workgroups (256 rows per staged W copy) measured slower: r01 session s7
+  const int cc_len = c_in < 128 ? c_in : 128;
+  const int kg = conv2_kg(kv * (c_in / cc_len), cc_len, NT, WAVES);
+  const size_t lds = (((size_t)kg * NT * (cc_len + 8) * 2 + 15) & ~(size_t)15) + (size_t)WAVES * kg * 32 * 4;
   auto kern = conv2_kernel<T, NTILES, 4, WAVES>;
   if (lds > 48 * 1024)
     PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

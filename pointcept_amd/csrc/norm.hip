@@ -248,3 +248,286 @@ extern "C" int ptc_layer_norm_bwd(const void* dy, int dy_dtype, const void* x, i
   });
   return PTC_OK;
 }
+
+// ================================================================================================
+// Fused residual + normalisation of the PTv3 Block (ptv3m1:318-338):
+//     z = a + s_row * f(u),   f = LayerNorm_A or identity          (a: fp32 residual stream)
+//     y = LayerNorm_B(z)  or  y = z                                (y: operand of the next GEMM / conv)
+// covers the three residual joints of a block in one pass each:
+//     x1 = x + LN(cpe);  y1 = norm1(x1)      |  x2 = x1 + droppath(attn);  y2 = norm2(x2)
+//     x3 = x2 + droppath(mlp);  y3 = bf16(x3) (next conv input)
+// Unfused this is 3-4 kernels and 20-24 B per element of HBM traffic; fused it is 12 B.
+// Backward (one pass, 18 B per element): dz = dz_in + LN_B'(dy) (or + dy);  da = dz;
+// du = s_row * LN_A'(dz) (or s_row * dz);  affine gradients as per-block partials.
+// ================================================================================================
+template <typename TU, typename TY, int LPR>
+__global__ void __launch_bounds__(LN_THREADS)
+add_norm_fwd_kernel(const TU* __restrict__ u, const float* __restrict__ a, const float* __restrict__ row_scale, int64_t n,
+                    const float* __restrict__ gA, const float* __restrict__ bA, float epsA, int normA,
+                    const float* __restrict__ gB, const float* __restrict__ bB, float epsB, int normB,
+                    float* __restrict__ z, TY* __restrict__ y, float* __restrict__ statA, float* __restrict__ statB) {
+  constexpr int C = LPR * LN_VEC;
+  constexpr int RPB = LN_THREADS / LPR;
+  const int slot = threadIdx.x % LPR, rib = threadIdx.x / LPR;
+  float ga[LN_VEC], ba[LN_VEC], gb[LN_VEC], bb[LN_VEC];
+#pragma unroll
+  for (int i = 0; i < LN_VEC; ++i) {
+    ga[i] = (normA && gA) ? gA[slot * LN_VEC + i] : 1.f; ba[i] = (normA && bA) ? bA[slot * LN_VEC + i] : 0.f;
+    gb[i] = (normB && gB) ? gB[slot * LN_VEC + i] : 1.f; bb[i] = (normB && bB) ? bB[slot * LN_VEC + i] : 0.f;
+  }
+  for (int64_t row = (int64_t)blockIdx.x * RPB + rib; row < n; row += (int64_t)gridDim.x * RPB) {
+    float v[LN_VEC], r[LN_VEC];
+    ln_load8<TU>(u + row * C + slot * LN_VEC, v);
+    ln_load8<float>(a + row * C + slot * LN_VEC, r);
+    if (normA) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_VEC; ++i) s += v[i];
+      const float mean = group_sum<LPR>(s) * (1.f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_VEC; ++i) { const float d = v[i] - mean; q += d * d; }
+      const float rstd = rsqrtf(group_sum<LPR>(q) * (1.f / C) + epsA);
+#pragma unroll
+      for (int i = 0; i < LN_VEC; ++i) v[i] = (v[i] - mean) * rstd * ga[i] + ba[i];
+      if (slot == 0) { statA[row] = mean; statA[n + row] = rstd; }
+    }
+    const float sc = row_scale ? row_scale[row] : 1.f;
+#pragma unroll
+    for (int i = 0; i < LN_VEC; ++i) r[i] += sc * v[i];
+    ln_store8<float>(z + row * C + slot * LN_VEC, r);
+    if (y) {
+      if (normB) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_VEC; ++i) s += r[i];
+        const float mean = group_sum<LPR>(s) * (1.f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_VEC; ++i) { const float d = r[i] - mean; q += d * d; }
+        const float rstd = rsqrtf(group_sum<LPR>(q) * (1.f / C) + epsB);
+#pragma unroll
+        for (int i = 0; i < LN_VEC; ++i) r[i] = (r[i] - mean) * rstd * gb[i] + bb[i];
+        if (slot == 0) { statB[row] = mean; statB[n + row] = rstd; }
+      }
+      ln_store8<TY>(y + row * C + slot * LN_VEC, r);
+    }
+  }
+}
+
+template <typename TU, typename TY, int LPR>
+__global__ void __launch_bounds__(LN_THREADS)
+add_norm_bwd_kernel(const float* __restrict__ dz_in, const TY* __restrict__ dy, const float* __restrict__ z,
+                    const TU* __restrict__ u, const float* __restrict__ row_scale, int64_t n,
+                    const float* __restrict__ gA, const float* __restrict__ statA, int normA,
+                    const float* __restrict__ gB, const float* __restrict__ statB, int normB,
+                    float* __restrict__ da, TU* __restrict__ du, float* __restrict__ partial /*[grid][4][C]*/) {
+  constexpr int C = LPR * LN_VEC;
+  constexpr int RPB = LN_THREADS / LPR;
+  __shared__ float red[4][LN_THREADS][LN_VEC + 1];
+  const int slot = threadIdx.x % LPR, rib = threadIdx.x / LPR;
+  float ga[LN_VEC], gb[LN_VEC], dgA[LN_VEC], dbA[LN_VEC], dgB[LN_VEC], dbB[LN_VEC];
+#pragma unroll
+  for (int i = 0; i < LN_VEC; ++i) {
+    ga[i] = (normA && gA) ? gA[slot * LN_VEC + i] : 1.f;
+    gb[i] = (normB && gB) ? gB[slot * LN_VEC + i] : 1.f;
+    dgA[i] = dbA[i] = dgB[i] = dbB[i] = 0.f;
+  }
+  for (int64_t row = (int64_t)blockIdx.x * RPB + rib; row < n; row += (int64_t)gridDim.x * RPB) {
+    float dz[LN_VEC];
+    if (dz_in) ln_load8<float>(dz_in + row * C + slot * LN_VEC, dz);
+    else {
+#pragma unroll
+      for (int i = 0; i < LN_VEC; ++i) dz[i] = 0.f;
+    }
+    if (dy) {
+      float g[LN_VEC];
+      ln_load8<TY>(dy + row * C + slot * LN_VEC, g);
+      if (normB) {
+        float zv[LN_VEC];
+        ln_load8<float>(z + row * C + slot * LN_VEC, zv);
+        const float m = statB[row], rs = statB[n + row];
+        float s1 = 0.f, s2 = 0.f, xh[LN_VEC], w[LN_VEC];
+#pragma unroll
+        for (int i = 0; i < LN_VEC; ++i) {
+          xh[i] = (zv[i] - m) * rs;
+          w[i] = g[i] * gb[i];
+          s1 += w[i] * xh[i];
+          s2 += w[i];
+          dgB[i] += g[i] * xh[i];
+          dbB[i] += g[i];
+        }
+        const float c1 = group_sum<LPR>(s1) * (1.f / C), c2 = group_sum<LPR>(s2) * (1.f / C);
+#pragma unroll
+        for (int i = 0; i < LN_VEC; ++i) dz[i] += (w[i] - c2 - xh[i] * c1) * rs;
+      } else {
+#pragma unroll
+        for (int i = 0; i < LN_VEC; ++i) dz[i] += g[i];
+      }
+    }
+    ln_store8<float>(da + row * C + slot * LN_VEC, dz);
+    const float sc = row_scale ? row_scale[row] : 1.f;
+    float o[LN_VEC];
+    if (normA) {
+      float uv[LN_VEC];
+      ln_load8<TU>(u + row * C + slot * LN_VEC, uv);
+      const float m = statA[row], rs = statA[n + row];
+      float s1 = 0.f, s2 = 0.f, xh[LN_VEC], w[LN_VEC];
+#pragma unroll
+      for (int i = 0; i < LN_VEC; ++i) {
+        const float gg = dz[i] * sc;
+        xh[i] = (uv[i] - m) * rs;
+        w[i] = gg * ga[i];
+        s1 += w[i] * xh[i];
+        s2 += w[i];
+        dgA[i] += gg * xh[i];
+        dbA[i] += gg;
+      }
+      const float c1 = group_sum<LPR>(s1) * (1.f / C), c2 = group_sum<LPR>(s2) * (1.f / C);
+#pragma unroll
+      for (int i = 0; i < LN_VEC; ++i) o[i] = (w[i] - c2 - xh[i] * c1) * rs;
+    } else {
+#pragma unroll
+      for (int i = 0; i < LN_VEC; ++i) o[i] = dz[i] * sc;
+    }
+    ln_store8<TU>(du + row * C + slot * LN_VEC, o);
+  }
+#pragma unroll
+  for (int i = 0; i < LN_VEC; ++i) {
+    red[0][threadIdx.x][i] = dgA[i]; red[1][threadIdx.x][i] = dbA[i];
+    red[2][threadIdx.x][i] = dgB[i]; red[3][threadIdx.x][i] = dbB[i];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 4 * C; t += LN_THREADS) {
+    const int which = t / C, ch = t - which * C;
+    const int sl = ch / LN_VEC, i = ch - sl * LN_VEC;
+    float s = 0.f;
+    for (int rr = 0; rr < RPB; ++rr) s += red[which][rr * LPR + sl][i];
+    partial[((int64_t)blockIdx.x * 4 + which) * C + ch] = s;
+  }
+}
+
+// column sums of partial [blocks][4][c] -> four vectors (any may be NULL)
+__global__ void __launch_bounds__(1024)
+add_norm_partial_reduce_kernel(const float* __restrict__ partial, int blocks, int c, float* __restrict__ o0,
+                               float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ o3) {
+  __shared__ float red[32][33];
+  const int cx = threadIdx.x & 31, sy = threadIdx.x >> 5;
+  const int t = blockIdx.x * 32 + cx;
+  const int which = t / c, ch = t - which * c;
+  float s = 0.f;
+  if (t < 4 * c)
+    for (int b = sy; b < blocks; b += 32) s += partial[((int64_t)b * 4 + which) * c + ch];
+  red[sy][cx] = s;
+  __syncthreads();
+  if (sy == 0 && t < 4 * c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc += red[i][cx];
+    float* dst = which == 0 ? o0 : (which == 1 ? o1 : (which == 2 ? o2 : o3));
+    if (dst) dst[ch] = acc;
+  }
+}
+
+static int an_grid(int64_t n, int lpr) {
+  const int rpb = LN_THREADS / lpr;
+  int64_t g = ptc_cdiv(n, rpb);
+  if (g > 1024) g = 1024;
+  return (int)(g < 1 ? 1 : g);
+}
+
+template <typename TU, typename TY>
+static int launch_an_fwd(const void* u, const float* a, const float* row_scale, int64_t n, int c, const float* gA,
+                         const float* bA, float epsA, int normA, const float* gB, const float* bB, float epsB, int normB,
+                         float* z, void* y, float* statA, float* statB, hipStream_t s) {
+#define AN_FWD_CASE(LPR)                                                                                                \
+  hipLaunchKernelGGL((add_norm_fwd_kernel<TU, TY, LPR>), dim3(ln_grid(n, LPR)), dim3(LN_THREADS), 0, s, (const TU*)u, a, \
+                     row_scale, n, gA, bA, epsA, normA, gB, bB, epsB, normB, z, (TY*)y, statA, statB)
+  switch (c / LN_VEC) {
+    case 4: AN_FWD_CASE(4); break;
+    case 8: AN_FWD_CASE(8); break;
+    case 16: AN_FWD_CASE(16); break;
+    case 32: AN_FWD_CASE(32); break;
+    default: AN_FWD_CASE(64); break;
+  }
+#undef AN_FWD_CASE
+  PTC_CHECK_LAUNCH("add_norm_fwd_kernel");
+  return PTC_OK;
+}
+
+extern "C" int ptc_add_norm_fwd(const void* u, int u_dtype, const float* a, const float* row_scale, int64_t n, int c,
+                                const float* gA, const float* bA, float epsA, int normA, const float* gB, const float* bB,
+                                float epsB, int normB, float* z, void* y, int y_dtype, float* statA, float* statB,
+                                ptc_stream_t stream) {
+  PTC_REQUIRE(n >= 0, PTC_EINVAL, "ptc_add_norm_fwd: n < 0");
+  PTC_REQUIRE(ln_supported_c(c), PTC_EUNSUPPORTED, "ptc_add_norm_fwd: C=%d not in {32,64,128,256,512}", c);
+  if (n == 0) return PTC_OK;
+  PTC_REQUIRE(u && a && z, PTC_EINVAL, "ptc_add_norm_fwd: null buffer");
+  PTC_REQUIRE((!normA || statA) && (!(normB && y) || statB), PTC_EINVAL, "ptc_add_norm_fwd: missing statistics buffer");
+  PTC_REQUIRE(u_dtype == PTC_BF16 || u_dtype == PTC_F32, PTC_EUNSUPPORTED, "ptc_add_norm_fwd: u must be bf16 or f32");
+  PTC_REQUIRE(!y || y_dtype == PTC_BF16 || y_dtype == PTC_F32, PTC_EUNSUPPORTED, "ptc_add_norm_fwd: y must be bf16 or f32");
+  hipStream_t s = (hipStream_t)stream;
+  if (u_dtype == PTC_BF16) {
+    if (y_dtype == PTC_BF16) return launch_an_fwd<bf16_t, bf16_t>(u, a, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
+    return launch_an_fwd<bf16_t, float>(u, a, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
+  }
+  if (y_dtype == PTC_BF16) return launch_an_fwd<float, bf16_t>(u, a, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
+  return launch_an_fwd<float, float>(u, a, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
+}
+
+extern "C" size_t ptc_add_norm_bwd_workspace_bytes(int64_t n, int c) {
+  if (!ln_supported_c(c)) return 256;
+  return ptc_align_up((size_t)an_grid(n, c / LN_VEC) * 4 * (size_t)c * sizeof(float), 256);
+}
+
+template <typename TU, typename TY>
+static int launch_an_bwd(const float* dz_in, const void* dy, const float* z, const void* u, const float* row_scale, int64_t n,
+                         int c, const float* gA, const float* statA, int normA, const float* gB, const float* statB, int normB,
+                         float* da, void* du, float* dgA, float* dbA, float* dgB, float* dbB, void* ws, hipStream_t s) {
+  const int lpr = c / LN_VEC;
+  const int grid = an_grid(n, lpr);
+#define AN_BWD_CASE(LPR)                                                                                               \
+  hipLaunchKernelGGL((add_norm_bwd_kernel<TU, TY, LPR>), dim3(grid), dim3(LN_THREADS), 0, s, dz_in, (const TY*)dy, z,  \
+                     (const TU*)u, row_scale, n, gA, statA, normA, gB, statB, normB, da, (TU*)du, (float*)ws)
+  switch (lpr) {
+    case 4: AN_BWD_CASE(4); break;
+    case 8: AN_BWD_CASE(8); break;
+    case 16: AN_BWD_CASE(16); break;
+    case 32: AN_BWD_CASE(32); break;
+    default: AN_BWD_CASE(64); break;
+  }
+#undef AN_BWD_CASE
+  PTC_CHECK_LAUNCH("add_norm_bwd_kernel");
+  if (dgA || dbA || dgB || dbB) {
+    hipLaunchKernelGGL(add_norm_partial_reduce_kernel, dim3((unsigned)ptc_cdiv(4 * c, 32)), dim3(1024), 0, s, (const float*)ws,
+                       grid, c, dgA, dbA, dgB, dbB);
+    PTC_CHECK_LAUNCH("add_norm_partial_reduce_kernel");
+  }
+  return PTC_OK;
+}
+
+extern "C" int ptc_add_norm_bwd(const float* dz_in, const void* dy, int dy_dtype, const float* z, const void* u, int u_dtype,
+                                const float* row_scale, int64_t n, int c, const float* gA, const float* statA, int normA,
+                                const float* gB, const float* statB, int normB, float* da, void* du, float* dgA, float* dbA,
+                                float* dgB, float* dbB, void* workspace, size_t workspace_bytes, ptc_stream_t stream) {
+  PTC_REQUIRE(n >= 0, PTC_EINVAL, "ptc_add_norm_bwd: n < 0");
+  PTC_REQUIRE(ln_supported_c(c), PTC_EUNSUPPORTED, "ptc_add_norm_bwd: C=%d not in {32,64,128,256,512}", c);
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    float* outs[4] = {dgA, dbA, dgB, dbB};
+    for (int i = 0; i < 4; ++i)
+      if (outs[i]) PTC_HIP(hipMemsetAsync(outs[i], 0, (size_t)c * 4, s));
+    return PTC_OK;
+  }
+  PTC_REQUIRE(da && du && workspace && (dz_in || dy), PTC_EINVAL, "ptc_add_norm_bwd: null buffer");
+  PTC_REQUIRE((!normA || (u && statA)) && (!(normB && dy) || (z && statB)), PTC_EINVAL, "ptc_add_norm_bwd: missing saved tensors");
+  PTC_REQUIRE(workspace_bytes >= ptc_add_norm_bwd_workspace_bytes(n, c), PTC_EWORKSPACE, "ptc_add_norm_bwd: workspace too small");
+  PTC_REQUIRE(u_dtype == PTC_BF16 || u_dtype == PTC_F32, PTC_EUNSUPPORTED, "ptc_add_norm_bwd: u must be bf16 or f32");
+  PTC_REQUIRE(!dy || dy_dtype == PTC_BF16 || dy_dtype == PTC_F32, PTC_EUNSUPPORTED, "ptc_add_norm_bwd: dy must be bf16 or f32");
+  if (u_dtype == PTC_BF16) {
+    if (dy_dtype == PTC_BF16) return launch_an_bwd<bf16_t, bf16_t>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, du, dgA, dbA, dgB, dbB, workspace, s);
+    return launch_an_bwd<bf16_t, float>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, du, dgA, dbA, dgB, dbB, workspace, s);
+  }
+  if (dy_dtype == PTC_BF16) return launch_an_bwd<float, bf16_t>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, du, dgA, dbA, dgB, dbB, workspace, s);
+  return launch_an_bwd<float, float>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, du, dgA, dbA, dgB, dbB, workspace, s);
+}

@@ -216,7 +216,7 @@ static inline int w2_env_int(const char* name, int dflt) {
 }
 
 static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out) {
-  static const int cot_max = w2_env_int("PTC_W2_COT_MAX", 8), cit_max = w2_env_int("PTC_W2_CIT_MAX", 4);  // tuning knobs
+  static const int cot_max = w2_env_int("PTC_W2_COT_MAX", 4), cit_max = w2_env_int("PTC_W2_CIT_MAX", 4);  // tuning knobs
   W2Plan p;
   p.cit = c_in <= 16 ? 1 : (c_in <= 32 ? 2 : 4);
   p.cot = c_out <= 32 ? 2 : (c_out <= 64 ? 4 : (c_out <= 96 ? 6 : 8));

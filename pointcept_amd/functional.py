@@ -159,10 +159,10 @@ def sparse_conv(feat, weight, bias, nbr, nbr_t, mirror: bool):
 # ------------------------------------------------------------------------------------------------
 # dense row-wise GEMM (nn.Linear on [N,C] point features) on the sparse-conv MFMA kernels
 # ------------------------------------------------------------------------------------------------
-# Shape policy (measured, profiles/r01_c_bench_ops.txt): the engine's streaming kernels win on tall-skinny
-# shapes (many rows, contraction <= 256 channels) and on every weight gradient with >= 4096 rows;
-# hipBLASLt wins on the short, wide GEMMs of the deep stages (N <= ~1e4, C >= 256).
-_OWN_MIN_ROWS = 32768
+# Shape policy (measured on MI355X, profiles/): the engine's streaming kernels cover contractions of
+# <= 256 channels (linear2) and every weight gradient with >= 4096 rows (wgrad2); wider contractions
+# (fc2 / dgrad-of-fc1 of the deep stages: few rows, C >= 128) go to hipBLASLt.
+_OWN_MIN_ROWS = 0
 _OWN_MAX_K = 256
 _OWN_WGRAD_MIN_ROWS = 4096
 
@@ -266,6 +266,52 @@ def layer_norm(x: torch.Tensor, weight, bias, eps: float = 1e-5, out_dtype: Opti
     if out_dtype is None:
         out_dtype = torch.float32 if (_autocast_on() or x.dtype == torch.float32) else x.dtype
     return _LayerNorm.apply(x, weight, bias, float(eps), out_dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused residual joint: z = a + row_scale * LN_A(u),  y = LN_B(z)
+# ------------------------------------------------------------------------------------------------
+class _AddNorm(Function):
+    @staticmethod
+    def forward(ctx, u, a, row_scale, ga, ba, eps_a, gb, bb, eps_b, has_a, has_b, y_dtype):
+        norm_a = (None if ga is None else ga.float(), None if ba is None else ba.float(), eps_a) if has_a else None
+        norm_b = (None if gb is None else gb.float(), None if bb is None else bb.float(), eps_b) if has_b else None
+        z, y, st_a, st_b = ops.add_norm_fwd(u, a, row_scale, norm_a, norm_b, y_dtype)
+        ctx.save_for_backward(u, z, row_scale, st_a, st_b, None if norm_a is None else norm_a[0],
+                              None if norm_b is None else norm_b[0])
+        ctx.has_a, ctx.has_b = has_a, has_b
+        ctx.aff = (ga is not None, gb is not None)
+        ctx.mark_non_differentiable()
+        if y is None:
+            y = z.new_empty(0)
+            ctx.mark_non_differentiable(y)
+        return z, y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, dy):
+        u, z, row_scale, st_a, st_b, ga, gb = ctx.saved_tensors
+        if dy is not None and dy.numel() == 0:
+            dy = None
+        if dz is None and dy is None:
+            return (None,) * 12
+        da, du, dga, dba, dgb, dbb = ops.add_norm_bwd(dz, dy, z, u, row_scale, ga, st_a, gb, st_b,
+                                                      ctx.has_a and ctx.aff[0], ctx.has_b and ctx.aff[1] and dy is not None)
+        return du, da, None, dga, dba, None, dgb, dbb, None, None, None, None
+
+
+def add_norm(u: torch.Tensor, a: torch.Tensor, row_scale: Optional[torch.Tensor] = None, norm_a=None, norm_b=None,
+             y_dtype: Optional[torch.dtype] = None):
+    """One pass over a residual joint of the PTv3 Block: z = a + row_scale[:,None] * f(u) (fp32 residual
+    stream), y = g(z) as `y_dtype`.  f / g are nn.LayerNorm modules (norm_a / norm_b) or identity.
+    Returns (z, y); y is None when y_dtype is None."""
+    if a.dtype != torch.float32:
+        a = a.float()
+    ga, ba, ea = (norm_a.weight, norm_a.bias, norm_a.eps) if norm_a is not None else (None, None, 0.0)
+    gb, bb, eb = (norm_b.weight, norm_b.bias, norm_b.eps) if norm_b is not None else (None, None, 0.0)
+    z, y = _AddNorm.apply(u, a, row_scale, ga, ba, float(ea), gb, bb, float(eb), norm_a is not None, norm_b is not None,
+                          y_dtype)
+    return z, (y if y_dtype is not None else None)
 
 
 # ------------------------------------------------------------------------------------------------

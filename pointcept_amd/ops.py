@@ -340,6 +340,50 @@ def layer_norm_bwd(dy: torch.Tensor, x: torch.Tensor, mean, rstd, gamma, want_af
     return dx, dg, db
 
 
+def add_norm_fwd(u, a, row_scale, norm_a, norm_b, y_dtype):
+    """z = a + row_scale * f(u) (fp32), y = g(z) (y_dtype or None).  norm_a / norm_b: (gamma, beta, eps) or
+    None (identity).  Returns (z, y, statA, statB)."""
+    require_cuda(u, a, row_scale)
+    u = u.contiguous()
+    a = a.contiguous()
+    if a.dtype != torch.float32:
+        raise PtcoreError("add_norm: the residual stream `a` must be fp32")
+    n, c = u.shape
+    dev = u.device
+    z = torch.empty((n, c), dtype=torch.float32, device=dev)
+    y = torch.empty((n, c), dtype=y_dtype, device=dev) if y_dtype is not None else None
+    st_a = torch.empty((2, n), dtype=torch.float32, device=dev) if norm_a is not None else None
+    st_b = torch.empty((2, n), dtype=torch.float32, device=dev) if (norm_b is not None and y is not None) else None
+    ga, ba, ea = norm_a if norm_a is not None else (None, None, 0.0)
+    gb, bb, eb = norm_b if norm_b is not None else (None, None, 0.0)
+    rs = None if row_scale is None else row_scale.to(torch.float32).contiguous()
+    check(lib().ptc_add_norm_fwd(ptr(u), dtype_code(u), ptr(a), ptr(rs), n, c, ptr(ga), ptr(ba), float(ea),
+                                 int(norm_a is not None), ptr(gb), ptr(bb), float(eb), int(norm_b is not None), ptr(z), ptr(y),
+                                 _DT[y_dtype] if y_dtype is not None else 0, ptr(st_a), ptr(st_b), stream_ptr()),
+          "ptc_add_norm_fwd")
+    return z, y, st_a, st_b
+
+
+def add_norm_bwd(dz_in, dy, z, u, row_scale, g_a, st_a, g_b, st_b, want_affine_a: bool, want_affine_b: bool):
+    """-> (da fp32, du (u.dtype), dgA, dbA, dgB, dbB)"""
+    require_cuda(dz_in, dy, z, u, row_scale)
+    n, c = u.shape
+    dev = u.device
+    dz_in = None if dz_in is None else dz_in.to(torch.float32).contiguous()
+    dy = None if dy is None else dy.contiguous()
+    da = torch.empty((n, c), dtype=torch.float32, device=dev)
+    du = torch.empty_like(u)
+    mk = lambda want: torch.empty(c, dtype=torch.float32, device=dev) if want else None  # noqa: E731
+    dga, dba, dgb, dbb = mk(want_affine_a), mk(want_affine_a), mk(want_affine_b), mk(want_affine_b)
+    nbytes = lib().ptc_add_norm_bwd_workspace_bytes(n, c)
+    ws = _ws(nbytes, dev)
+    check(lib().ptc_add_norm_bwd(ptr(dz_in), ptr(dy), dtype_code(dy) if dy is not None else 0, ptr(z), ptr(u), dtype_code(u),
+                                 ptr(row_scale), n, c, ptr(g_a), ptr(st_a), int(st_a is not None), ptr(g_b), ptr(st_b),
+                                 int(st_b is not None), ptr(da), ptr(du), ptr(dga), ptr(dba), ptr(dgb), ptr(dbb), ptr(ws),
+                                 nbytes, stream_ptr()), "ptc_add_norm_bwd")
+    return da, du, dga, dba, dgb, dbb
+
+
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------

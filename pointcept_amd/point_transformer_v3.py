@@ -228,7 +228,55 @@ class Block(PointModule):
                 if isinstance(m, PNN.LayerNorm):
                     m.gemm_consumer = True
 
+    def _row_keep_scale(self, n, device):
+        """per-point DropPath factor (timm DropPath on [N,C] drops rows) or None"""
+        dp = self.drop_path[0]
+        p = getattr(dp, "drop_prob", 0.0)
+        if p == 0.0 or not self.training:
+            return None
+        keep = 1.0 - p
+        mask = torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep)
+        if keep > 0.0 and getattr(dp, "scale_by_keep", True):
+            mask.div_(keep)
+        return mask
+
+    def _fusable(self, point) -> bool:
+        return (config.FUSE_BLOCK and self.pre_norm and point.feat.is_cuda and point.feat.dim() == 2
+                and isinstance(self.cpe[2], PNN.LayerNorm) and isinstance(self.norm1[0], PNN.LayerNorm)
+                and isinstance(self.norm2[0], PNN.LayerNorm) and ops.layer_norm_supported(self.channels)
+                and point.feat.shape[0] > 0 and point.feat.dtype in (torch.float32, torch.bfloat16))
+
+    def _forward_fused(self, point: Point):
+        """Same arithmetic as `forward`, with each residual joint (branch output -> [LayerNorm] -> add ->
+        [LayerNorm | cast]) done in one pass (PF.add_norm) instead of 3-4 elementwise kernels."""
+        auto = torch.is_autocast_enabled("cuda")
+        gemm_dt = torch.get_autocast_dtype("cuda") if auto else torch.float32
+        if gemm_dt not in (torch.bfloat16, torch.float32):
+            return None
+        n, dev = point.feat.shape[0], point.feat.device
+        sc = point.sparse_conv_feat
+        x0 = point.feat                                           # residual stream (fp32 after the first joint)
+        lin = self.cpe[1](self.cpe[0](sc).features)              # CPE conv (stale input in dec block 0: D.1) + Linear
+        if lin.dtype != gemm_dt:
+            lin = lin.to(gemm_dt)
+        x1, y1 = PF.add_norm(lin, x0, None, self.cpe[2], self.norm1[0], gemm_dt)        # x + LN(cpe); norm1
+        point.feat = y1
+        point = self.attn(point)
+        a = point.feat if point.feat.dtype == gemm_dt else point.feat.to(gemm_dt)
+        x2, y2 = PF.add_norm(a, x1, self._row_keep_scale(n, dev), None, self.norm2[0], gemm_dt)  # + droppath(attn); norm2
+        h = self.mlp[0](y2)
+        if h.dtype != gemm_dt:
+            h = h.to(gemm_dt)
+        x3, xb = PF.add_norm(h, x2, self._row_keep_scale(n, dev), None, None, gemm_dt if auto else None)  # + droppath(mlp)
+        point.feat = x3
+        point.sparse_conv_feat = sc.replace_feature(xb if xb is not None else x3)    # next conv's operand, already cast
+        return point
+
     def forward(self, point: Point):
+        if self._fusable(point):
+            out = self._forward_fused(point)
+            if out is not None:
+                return out
         shortcut = point.feat
         point = self.cpe(point)  # consumes point.sparse_conv_feat.features (stale after unpooling: Appendix D.1)
         point.feat = shortcut + point.feat

@@ -432,6 +432,58 @@ def test_layer_norm_fwd_bwd(cuda, c, xdt, ydt):
     _close("ln_dbeta", db, br.grad, 1e-4, 1e-4 * float(br.grad.abs().max()) + 1e-3)
 
 
+@pytest.mark.parametrize("c", [32, 128, 512])
+@pytest.mark.parametrize("mode", ["ln_add_ln", "add_ln_scaled", "add_cast", "fp32"])
+def test_add_norm_fused_joint(cuda, c, mode):
+    """PF.add_norm == a + s * LN_A(u) followed by LN_B / cast, forward and every gradient."""
+    from pointcept_amd import functional as PF
+
+    n = 3001
+    g = torch.Generator().manual_seed(c + len(mode))
+    udt = torch.float32 if mode == "fp32" else torch.bfloat16
+    u = (torch.randn(n, c, generator=g) * 1.5).to(udt)
+    a = torch.randn(n, c, generator=g)
+    scale = (torch.rand(n, generator=g) > 0.3).float() / 0.7 if mode == "add_ln_scaled" else None
+    na = torch.nn.LayerNorm(c) if mode in ("ln_add_ln", "fp32") else None
+    nb = torch.nn.LayerNorm(c) if mode != "add_cast" else None
+    for m in (na, nb):
+        if m is not None:
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(c, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(c, generator=g))
+    dz = torch.randn(n, c, generator=g)
+    dy = torch.randn(n, c, generator=g).to(udt)
+    # reference (fp32 math on the same rounded inputs)
+    ur, ar = u.float().clone().requires_grad_(True), a.clone().requires_grad_(True)
+    fu = na(ur) if na is not None else ur
+    zr = ar + (fu if scale is None else fu * scale[:, None])
+    yr = nb(zr) if nb is not None else zr
+    (zr * dz).sum().backward(retain_graph=True)
+    (yr * dy.float()).sum().backward()
+    ref_grads = {"u": ur.grad, "a": ar.grad}
+    for name, m in (("A", na), ("B", nb)):
+        if m is not None:
+            ref_grads["g" + name], ref_grads["b" + name] = m.weight.grad.clone(), m.bias.grad.clone()
+            m.weight.grad = None
+            m.bias.grad = None
+    # engine
+    import copy
+    na_e = copy.deepcopy(na).to(cuda) if na is not None else None
+    nb_e = copy.deepcopy(nb).to(cuda) if nb is not None else None
+    ue, ae = u.to(cuda).requires_grad_(True), a.to(cuda).requires_grad_(True)
+    z, y = PF.add_norm(ue, ae, None if scale is None else scale.to(cuda), na_e, nb_e, udt)
+    ((z * dz.to(cuda)).sum() + (y.float() * dy.to(cuda).float()).sum()).backward()
+    rtol, atol = _tols(udt)
+    _close("an_z", z, zr, 2e-5 if udt == torch.float32 else 1e-3, 2e-3 if udt != torch.float32 else 2e-5)
+    _close("an_y", y, yr, rtol, atol * 4)
+    _close("an_da", ae.grad, ref_grads["a"], 1e-3, 2e-3 * float(ref_grads["a"].abs().max()))
+    _close("an_du", ue.grad, ref_grads["u"], rtol, atol * 4 + 4e-3 * float(ref_grads["u"].abs().max()) * (udt != torch.float32))
+    for name, m in (("A", na_e), ("B", nb_e)):
+        if m is not None:
+            _close("an_dg" + name, m.weight.grad, ref_grads["g" + name], 1e-3, 2e-3 * float(ref_grads["g" + name].abs().max()))
+            _close("an_db" + name, m.bias.grad, ref_grads["b" + name], 1e-3, 2e-3 * float(ref_grads["b" + name].abs().max()))
+
+
 def test_layer_norm_empty_and_unsupported(cuda):
     from pointcept_amd import ops
     from pointcept_amd._lib import PtcoreError
