@@ -48,6 +48,11 @@ __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __uint_
 __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
 #pragma unroll
@@ -133,9 +138,15 @@ __device__ __forceinline__ s16x8 make_frag(uint32_t a, uint32_t b, uint32_t c, u
 // ================================================================================================
 __global__ void __launch_bounds__(AT_THREADS)
 attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                int lp_max, uint16_t* __restrict__ out, float* __restrict__ lse) {
+                int lp_max, int n_units, uint16_t* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int seq = blockIdx.x / H, head = blockIdx.x % H;
+  // XCD-aware order: workgroup b runs on XCD b % 8, so logical unit = (b % 8) * per + b / 8 gives every
+  // XCD a contiguous run of (sequence, head) units -- the H heads of a sequence read interleaved
+  // 32-byte pieces of the same qkv rows and now share one L2 instead of re-fetching them per XCD.
+  const int per_xcd = (n_units + 7) >> 3;
+  const int unit = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (unit >= n_units) return;
+  const int seq = unit / H, head = unit % H;
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
@@ -164,16 +175,24 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
         for (int r = 0; r < 16; ++r)
           if (kt * 32 + crow(r, h2) >= L) s[r] = -INFINITY;
       }
-      float mt = s[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+      // tile maximum of this lane's 16 keys: 8 three-input maxima (v_max3_f32 costs the same issue
+      // slot as v_max_f32, measured in tools/probe_gfx950.hip), then one exchange with lane ^ 32
+      float mt = max3(max3(s[0], s[1], s[2]), max3(s[3], s[4], s[5]), max3(s[6], s[7], s[8]));
+      mt = max3(mt, max3(s[9], s[10], s[11]), max3(s[12], s[13], s[14]));
+      mt = fmaxf(mt, s[15]);
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m, mt);
-      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
-      const float mc = m_new * c;
-      m = m_new;
+      // deferred rescale: keep the stale running maximum while the tile maximum exceeds it by less than
+      // 2^8 in the exp2 domain for every query of the wave (P <= 256, exact in the fp32 accumulators;
+      // softmax is invariant to the reference point).  On trained / random logits almost every tile
+      // after the first few skips the 9 accumulator multiplies and one exp.
+      if (__builtin_amdgcn_ballot_w64((mt - m) * c > 8.0f) != 0) {
+        const float m_new = fmaxf(m, mt);
+        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
+        m = m_new;
 #pragma unroll
-      for (int r = 0; r < 9; ++r) acc[r] *= alpha;  // rows 0..15 = O^T, row 16 (reg 8, h2=0) = denominator
+        for (int r = 0; r < 9; ++r) acc[r] *= alpha;  // rows 0..15 = O^T, row 16 (reg 8, h2=0) = denominator
+      }
+      const float mc = m * c;
       uint32_t pk[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -205,9 +224,15 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 __global__ void __launch_bounds__(AT_THREADS)
 attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                    const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                   int lp_max, uint16_t* __restrict__ dqkv, float* __restrict__ delta) {
+                   int lp_max, int n_units, uint16_t* __restrict__ dqkv, float* __restrict__ delta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int seq = blockIdx.x / H, head = blockIdx.x % H;
+  // XCD-aware order: workgroup b runs on XCD b % 8, so logical unit = (b % 8) * per + b / 8 gives every
+  // XCD a contiguous run of (sequence, head) units -- the H heads of a sequence read interleaved
+  // 32-byte pieces of the same qkv rows and now share one L2 instead of re-fetching them per XCD.
+  const int per_xcd = (n_units + 7) >> 3;
+  const int unit = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (unit >= n_units) return;
+  const int seq = unit / H, head = unit % H;
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
@@ -277,9 +302,15 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
 __global__ void __launch_bounds__(AT_THREADS)
 attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                     const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                    int lp_max, uint16_t* __restrict__ dqkv) {
+                    int lp_max, int n_units, uint16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int seq = blockIdx.x / H, head = blockIdx.x % H;
+  // XCD-aware order: workgroup b runs on XCD b % 8, so logical unit = (b % 8) * per + b / 8 gives every
+  // XCD a contiguous run of (sequence, head) units -- the H heads of a sequence read interleaved
+  // 32-byte pieces of the same qkv rows and now share one L2 instead of re-fetching them per XCD.
+  const int per_xcd = (n_units + 7) >> 3;
+  const int unit = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (unit >= n_units) return;
+  const int seq = unit / H, head = unit % H;
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
@@ -386,8 +417,9 @@ extern "C" int ptc_attn_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, i
   hipStream_t s = (hipStream_t)stream;
   rc = allow_big_lds(attn_fwd_kernel, lds);
   if (rc != PTC_OK) return rc;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(n_seq * H)), dim3(AT_THREADS), lds, s, (const uint16_t*)qkv,
-                     cu_seqlens, H, softmax_scale, total, lp_max, (uint16_t*)out, lse);
+  const int n_units = (int)(n_seq * H);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(8 * ((n_units + 7) / 8))), dim3(AT_THREADS), lds, s, (const uint16_t*)qkv,
+                     cu_seqlens, H, softmax_scale, total, lp_max, n_units, (uint16_t*)out, lse);
   PTC_CHECK_LAUNCH("attn_fwd_kernel");
   return PTC_OK;
 }
@@ -415,13 +447,15 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   if (rc != PTC_OK) return rc;
   rc = allow_big_lds(attn_bwd_dkv_kernel, dkv_lds_bytes(lp_max));
   if (rc != PTC_OK) return rc;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(n_seq * H)), dim3(AT_THREADS), fwd_lds_bytes(lp_max), s,
+  const int n_units = (int)(n_seq * H);
+  const unsigned grid = (unsigned)(8 * ((n_units + 7) / 8));
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(grid), dim3(AT_THREADS), fwd_lds_bytes(lp_max), s,
                      (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H,
-                     softmax_scale, total, lp_max, (uint16_t*)dqkv, delta);
+                     softmax_scale, total, lp_max, n_units, (uint16_t*)dqkv, delta);
   PTC_CHECK_LAUNCH("attn_bwd_dq_kernel");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(n_seq * H)), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s,
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(grid), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s,
                      (const uint16_t*)qkv, (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H,
-                     softmax_scale, total, lp_max, (uint16_t*)dqkv);
+                     softmax_scale, total, lp_max, n_units, (uint16_t*)dqkv);
   PTC_CHECK_LAUNCH("attn_bwd_dkv_kernel");
   return PTC_OK;
 }

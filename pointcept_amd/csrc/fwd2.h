@@ -18,7 +18,7 @@
 #define F2_MAX_W_BYTES (40 * 1024)
 
 template <typename T, int NTILES, int PD, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 3 : 2)
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 3 : 2)  // both: <= 170 registers per lane
 conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
              const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int kg, T* __restrict__ out) {
   using M = Mma<T>;
@@ -199,6 +199,23 @@ static inline int conv2_kg(int kv, int c_in, int nt, int waves) {  // kv = numbe
   return (kv + groups - 1) / groups;
 }
 
+template <typename T, int NTILES, int WAVES>
+static int launch_conv2_w(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
+                          int c_out, void* out, hipStream_t s) {
+  constexpr int NT = NTILES * 16;
+  const int cc_len = c_in < 128 ? c_in : 128;
+  const int kg = conv2_kg(kv * (c_in / cc_len), cc_len, NT, WAVES);
+  const size_t lds = (((size_t)kg * NT * (cc_len + 8) * 2 + 15) & ~(size_t)15) + (size_t)WAVES * kg * 32 * 4;
+  auto kern = conv2_kernel<T, NTILES, 4, WAVES>;
+  if (lds > 48 * 1024)
+    PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((unsigned)ptc_cdiv(n_out, WAVES * 32), (unsigned)(c_out / NT));
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv, c_in, c_out, kg,
+                     (T*)out);
+  PTC_CHECK_LAUNCH("conv2_kernel");
+  return PTC_OK;
+}
+
 template <typename T, int NTILES>
 static int launch_fwd2(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
                        int c_out, void* out, hipStream_t s) {
@@ -227,18 +244,12 @@ static int launch_fwd2(const void* in, const void* w, const float* bias, const i
     PTC_CHECK_LAUNCH("linear2_kernel");
     return PTC_OK;
   }
-  constexpr int WAVES = 4;  // 8-wave workgroups (256 rows per staged W copy) measured slower: r01 session s7
-  const int cc_len = c_in < 128 ? c_in : 128;
-  const int kg = conv2_kg(kv * (c_in / cc_len), cc_len, NT, WAVES);
-  const size_t lds = (((size_t)kg * NT * (cc_len + 8) * 2 + 15) & ~(size_t)15) + (size_t)WAVES * kg * 32 * 4;
-  auto kern = conv2_kernel<T, NTILES, 4, WAVES>;
-  if (lds > 48 * 1024)
-    PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid((unsigned)ptc_cdiv(n_out, WAVES * 32), (unsigned)(c_out / NT));
-  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv, c_in, c_out, kg,
-                     (T*)out);
-  PTC_CHECK_LAUNCH("conv2_kernel");
-  return PTC_OK;
+  // Deep stages (few rows, wide channels) leave a 128-row grid under-filled (N = 11400, C = 256: 180
+  // workgroups on 256 CUs, one latency-bound chain per CU): there 64-row workgroups double the number
+  // of independent chains.  (8-wave / 256-row workgroups measured slower everywhere: r01 session s7.)
+  const int64_t wg128 = ptc_cdiv(n_out, 128) * (c_out / NT);
+  if (wg128 < 512) return launch_conv2_w<T, NTILES, 2>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  return launch_conv2_w<T, NTILES, 4>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
 }
 
 template <typename T>
