@@ -7,24 +7,41 @@
 //
 // Shape facts that drive the design (SURVEY section 7 "hard parts"): every PTv3 stage has
 // head_dim = 16, windows are <= 1024 keys.  QK^T is ONE k-step of v_mfma_f32_32x32x16_bf16, so
-// there is one exp per 64 MFMA flops: the kernel is VALU/transcendental-bound, not MFMA-bound.
-// Therefore: MFMA work is spent freely to delete VALU work.
-//   * One workgroup = one (sequence, head); all of K (row-major) and V^T for the sequence live in
-//     LDS (<= 65 KB), each wave walks 32-query tiles against every 32-key tile.
+// there is one exp per 64 MFMA flops and the kernel is bound by VALU ISSUE SLOTS (r01_b PMC: 27 VALU
+// instructions per MFMA in the first version, matrix pipe 26 % busy).  The matrix pipe has slack, the
+// vector pipe has none, so every piece of softmax arithmetic that can be phrased as a matrix
+// product is moved into MFMA operands:
+//   * One workgroup = one (sequence, head); the sequence's operands live in LDS (<= 72 KB, two
+//     workgroups per CU), each wave walks 32-row tiles against every 32-row tile of the other side.
 //   * "Swapped" products S^T = K Q^T: a lane owns ONE query column (q = lane&31) and 16 keys in
-//     registers, so row max / exp / scaling are lane-local; the only cross-lane op per tile is one
-//     exchange with lane^32.
-//   * P V is issued as O^T = [V^T ; 1 ; 0] P^T on the 32x32x16 MFMA: the packed P registers ARE
-//     the B operand (no lane shuffles), row 16 of the A operand is all ones so the MFMA also
-//     produces the softmax denominator (no VALU row sums), and O^T lands in the same lane as the
-//     softmax state (rescale is lane-local).  Half of that MFMA's rows are padding; the matrix
-//     pipe has the slack.
-//   * The contraction order inside an MFMA is free as long as A and B agree: key slot (h,j) of
-//     the P V product is key 16m + 4h + (j&3) + 8(j>>2), i.e. two 8-byte LDS reads of V^T.
-// Backward = two kernels with the same skeleton (recompute P from q,k,lse; no atomics, no
-// cross-wave reductions, bit-reproducible): dQ is query-stationary, dK/dV key-stationary.
-// Roofline: fwd 4 L^2 D flops and L^2 exps per (sequence, head); bwd here 14 L^2 D
-// flops (S and dP recomputed in both kernels) and 2 L^2 exps.
+//     registers, so everything per query is lane-local.
+//   * The softmax scale is folded into the stationary operand: q*c (c = scale*log2 e) is split
+//     into bf16 hi + lo parts (error 2^-17) and S' = K qhi^T + K qlo^T costs a second MFMA instead
+//     of 16 multiplies per tile.
+//   * The softmax REFERENCE POINT is the MFMA's C operand: S' = K qc^T - ref comes out of the
+//     matrix pipe ready for v_exp_f32.  Forward: ref = |q| max_k|k| c, a Cauchy-Schwarz bound on
+//     every logit of the row, known before the first key tile -- no running maximum, no rescaling,
+//     no cross-lane traffic in the loop.  Softmax is invariant to the reference point; P <= 1 so
+//     nothing overflows; the bound is only used while it is <= 64 in the exp2 domain, so the
+//     largest P of a row is >= 2^-128 and bf16 / fp32 keep their full relative precision; rows above
+//     that limit take the classic online-softmax loop.  Backward: ref = lse (and dP' = V dO^T -
+//     delta the same way).
+//   * P V is issued as O^T = [V^T ; 1 ; x] P^T: the packed P registers ARE the B operand (no lane
+//     shuffles), row 16 of the A operand is all ones so the MFMA also produces the softmax
+//     denominator, and O^T lands in the same lane as the softmax state.  Rows 17..31 of that
+//     product are never read, so their A lanes may load anything.
+//   * Transposed operands of the backward products come from the SAME row-major LDS images through
+//     ds_read_b64_tr_b16 (a 16-lane group addresses [4 rows][16 channels], lane j receives rows 0..3
+//     of channel j; mapping measured with tools/probe_gfx950.hip): no transposed staging pass.
+//   * In the key-stationary backward kernel the per-QUERY constants (lse, delta) vary along the
+//     register index, so they enter through one extra MFMA each: A = [lse_hi, lse_lo, d_hi, d_lo]
+//     per query (bf16 pairs, staged once per workgroup), B = -1 in the matching contraction slots.
+// Per 32x32 tile: forward 4 MFMA + ~26 VALU (was 3 + 80), dQ 5 + ~42, dK/dV 9 + ~50.
+// No inline assembly touches MFMA results (the hazard recognizer cannot see into asm blocks: an
+// asm v_max3_f32 on fresh accumulators read half-written registers, r01_d).
+// Backward = two kernels (recompute P from q,k,lse; no atomics, no cross-wave reductions,
+// bit-reproducible): dQ is query-stationary, dK/dV key-stationary.
+// Roofline: fwd 4 L^2 D flops and L^2 exps per (sequence, head); bwd 10 L^2 D.
 #include "ptc_common.h"
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -36,7 +53,10 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define AT_WAVES 8
 #define AT_THREADS (AT_WAVES * 64)
 #define AT_MAX_L 1024
+#define AT_MIN_WAVES 4          // waves per SIMD the register budget must allow (two 8-wave workgroups per CU)
 #define AT_LOG2E 1.4426950408889634f
+#define AT_LN2 0.6931471805599453f
+#define AT_FIXED_REF_MAX 64.0f   // largest Cauchy-Schwarz bound (exp2 domain) served by the fixed-reference loop
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   f32x2_t f = {lo, hi};
@@ -48,31 +68,50 @@ __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __uint_
 __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ float max3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-__device__ __forceinline__ f32x16 zero16() {
+__device__ __forceinline__ f32x16 splat16(float v) {
   f32x16 z;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  for (int i = 0; i < 16; ++i) z[i] = v;
   return z;
 }
+__device__ __forceinline__ f32x16 zero16() { return splat16(0.f); }
 // C/D layout of the 32x32 MFMA: column = lane&31, row(reg, lane) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int crow(int reg, int h2) { return (reg & 3) + 8 * (reg >> 2) + 4 * h2; }
 
 // packed row index of element (t, j, head) in qkv [T,3,H,16]
 __device__ __forceinline__ int64_t qkv_off(int64_t t, int j, int H, int head) { return ((t * 3 + j) * H + head) * 16; }
 
+__device__ __forceinline__ s16x8 make_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  uint4 u = {a, b, c, d};
+  return *reinterpret_cast<s16x8*>(&u);
+}
+__device__ __forceinline__ s16x8 ld_global_frag(const uint16_t* p, bool valid) {
+  s16x8 f = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (valid) f = *reinterpret_cast<const s16x8*>(p);
+  return f;
+}
+// x * c -> bf16 hi + bf16 lo (hi + lo = x*c to 2^-17 relative)
+__device__ __forceinline__ void split_scaled(s16x8 x, float c, s16x8& hi, s16x8& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = bf16_bits_to_float((uint16_t)x[2 * j]) * c, b = bf16_bits_to_float((uint16_t)x[2 * j + 1]) * c;
+    h[j] = pack_bf16x2(a, b);
+    l[j] = pack_bf16x2(a - __uint_as_float(h[j] << 16), b - __uint_as_float(h[j] & 0xffff0000u));
+  }
+  hi = make_frag(h[0], h[1], h[2], h[3]);
+  lo = make_frag(l[0], l[1], l[2], l[3]);
+}
+
 // ---- LDS images -------------------------------------------------------------------------------
 // row-major [Lp][16] bf16 (32 B rows); the two 16-byte halves of a row are swapped when bit 3 of
 // the row index is set, which makes the 16-lane ds_read_b128 groups conflict-free.
 __device__ __forceinline__ int rm_off(int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
 
-// stage rows [0,Lp) of component `comp` (0 q, 1 k, 2 v) of (sequence at a, head) row-major
-__device__ __forceinline__ void stage_row_major(const uint16_t* __restrict__ src, int64_t row_stride, int L, int Lp,
-                                                unsigned char* lds) {
+// stage rows [0,Lp) (zeros beyond L) row-major; returns this thread's max over its rows of |row|^2
+__device__ __forceinline__ float stage_row_major(const uint16_t* __restrict__ src, int64_t row_stride, int L, int Lp,
+                                                 unsigned char* lds) {
+  float mx = 0.f;
   for (int row = threadIdx.x; row < Lp; row += AT_THREADS) {
     uint4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
     if (row < L) {
@@ -82,10 +121,28 @@ __device__ __forceinline__ void stage_row_major(const uint16_t* __restrict__ src
     }
     *reinterpret_cast<uint4*>(lds + rm_off(row, 0)) = v0;
     *reinterpret_cast<uint4*>(lds + rm_off(row, 1)) = v1;
+    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = __uint_as_float(w[j] << 16), b = __uint_as_float(w[j] & 0xffff0000u);
+      ss = fmaf(a, a, fmaf(b, b, ss));
+    }
+    mx = fmaxf(mx, ss);
   }
+  return mx;
 }
-// stage transposed [16][pitch] bf16 (pitch = Lp_max + 8 elements): thread handles two rows and
-// writes one 32-bit word per channel
+// stage transposed [16][pitch] bf16 (pitch = Lp_max + 8 elements) with the keys of every 16-key block
+// PERMUTED into the order in which the P V product consumes them: a lane's 8 contraction slots are keys
+// 4*h2 + {0,1,2,3, 8,9,10,11} of the block (the rows a 32x32 MFMA leaves in 8 consecutive registers), so
+// key kappa sits at position 8*((kappa>>2)&1) + (kappa&3) + 4*(kappa>>3) and the whole fragment is ONE
+// 16-byte read.  (Two 8-byte reads get fused into ds_read2_b64, whose 32-bank addressing made rows i and
+// i+8 collide: 1.97 M conflict cycles per launch in profiles/r01_f.)  A thread handles two adjacent rows
+// (they stay adjacent under the permutation) and writes one 32-bit word per channel.
+__device__ __forceinline__ int vt_pos(int key) {
+  const int kk = key & 15;
+  return (key & ~15) + 8 * ((kk >> 2) & 1) + (kk & 3) + 4 * (kk >> 3);
+}
 __device__ __forceinline__ void stage_transposed(const uint16_t* __restrict__ src, int64_t row_stride, int L, int Lp,
                                                  int pitch, unsigned char* lds) {
   uint32_t* t32 = reinterpret_cast<uint32_t*>(lds);
@@ -103,106 +160,214 @@ __device__ __forceinline__ void stage_transposed(const uint16_t* __restrict__ sr
     uint16_t ea[16], eb[16];
     *reinterpret_cast<uint4*>(ea) = a0; *reinterpret_cast<uint4*>(ea + 8) = a1;
     *reinterpret_cast<uint4*>(eb) = b0; *reinterpret_cast<uint4*>(eb + 8) = b1;
+    const int w = vt_pos(ra) >> 1;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) t32[(d * pitch) / 2 + p] = (uint32_t)ea[d] | ((uint32_t)eb[d] << 16);
+    for (int d = 0; d < 16; ++d) t32[(d * pitch) / 2 + w] = (uint32_t)ea[d] | ((uint32_t)eb[d] << 16);
   }
 }
-// A/B operand "[16 channels ; ones/zeros][8 contraction slots]" from a transposed image:
-// lane (i = lane&31, h2) -> channel i, slots j -> column base + (j&3) + 8*(j>>2)
-__device__ __forceinline__ s16x8 ld_transposed_frag(const unsigned char* lds, int pitch, int i, int col, bool ones_row) {
-  s16x8 f = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (i < 16) {
-    const unsigned char* p = lds + ((int64_t)i * pitch + col) * 2;
-    const s16x4 lo = *reinterpret_cast<const s16x4*>(p);
-    const s16x4 hi = *reinterpret_cast<const s16x4*>(p + 16);
-    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-  } else if (ones_row && i == 16) {
-    const short one = (short)0x3F80;  // bf16 1.0
-    f = (s16x8){one, one, one, one, one, one, one, one};
-  }
-  return f;
+
+// Transposed MFMA operand from a ROW-MAJOR image: lane (i = lane&31, h2 = lane>>5) receives, for channel
+// i & 15, the 8 contraction slots rows base + 4*h2 + {0,1,2,3, 8,9,10,11} (the register order in which a
+// 32x32 product leaves its rows).  Lanes 16..31 of each half alias lanes 0..15: they feed operand rows
+// that only reach output rows / columns >= 16, which no kernel reads.
+struct TrAddr { int lo, hi; };   // byte offsets of the two ds_read_b64_tr_b16 for row base 0
+__device__ __forceinline__ TrAddr tr_addr(int lane) {
+  const int lp = lane & 15, h2 = lane >> 5;
+  const int row = 4 * h2 + (lp >> 2), cq = lp & 3;
+  TrAddr a;
+  a.lo = rm_off(row, cq >> 1) + ((cq & 1) << 3);
+  a.hi = rm_off(row + 8, cq >> 1) + ((cq & 1) << 3);
+  return a;
 }
-__device__ __forceinline__ s16x8 ld_global_frag(const uint16_t* p, bool valid) {
-  s16x8 f = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (valid) f = *reinterpret_cast<const s16x8*>(p);
-  return f;
+__device__ __forceinline__ s16x8 ld_tr_frag(const unsigned char* img, TrAddr a, int row_base) {
+  const unsigned char* p = img + row_base * 32;   // row_base is a multiple of 16: the swizzle phase is unchanged
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + a.lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + a.hi));
+  return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-__device__ __forceinline__ s16x8 make_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-  uint4 u = {a, b, c, d};
-  return *reinterpret_cast<s16x8*>(&u);
+
+// XCD-aware order: workgroup b runs on XCD b % 8, so logical unit = (b % 8) * per + b / 8 gives every
+// XCD a contiguous run of (sequence, head) units -- the H heads of a sequence read interleaved
+// 32-byte pieces of the same qkv rows and share one L2 instead of re-fetching them per XCD.
+__device__ __forceinline__ int at_unit(int n_units) {
+  const int per_xcd = (n_units + 7) >> 3;
+  return (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
 }
 
 // ================================================================================================
 // forward
 // ================================================================================================
-__global__ void __launch_bounds__(AT_THREADS)
+// LDS: K row-major [lp_max][16] | V^T [17][pitch] (row 16 = 1.0 for keys < L, else 0) | 8 floats (reduction)
+__global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
                 int lp_max, int n_units, uint16_t* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // XCD-aware order: workgroup b runs on XCD b % 8, so logical unit = (b % 8) * per + b / 8 gives every
-  // XCD a contiguous run of (sequence, head) units -- the H heads of a sequence read interleaved
-  // 32-byte pieces of the same qkv rows and now share one L2 instead of re-fetching them per XCD.
-  const int per_xcd = (n_units + 7) >> 3;
-  const int unit = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  const int unit = at_unit(n_units);
   if (unit >= n_units) return;
   const int seq = unit / H, head = unit % H;
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
   const int pitch = lp_max + 8;
-  unsigned char* Ksm = smem;                          // [lp_max][16] row-major
-  unsigned char* Vt = smem + (size_t)lp_max * 32;     // [16][pitch] transposed
-  const int64_t rs = (int64_t)3 * H * 16;
-  stage_row_major(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
-  stage_transposed(qkv + qkv_off(a, 2, H, head), rs, L, Lp, pitch, Vt);
-  __syncthreads();
-
+  unsigned char* Ksm = smem;                                   // [lp_max][16] row-major
+  unsigned char* Vt = smem + (size_t)lp_max * 32;              // [17][pitch] transposed, keys permuted (vt_pos)
+  float* red = reinterpret_cast<float*>(Vt + (size_t)17 * pitch * 2);  // [AT_WAVES]
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
+  const int64_t rs = (int64_t)3 * H * 16;
+  float kn = stage_row_major(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
+  stage_transposed(qkv + qkv_off(a, 2, H, head), rs, L, Lp, pitch, Vt);
+  // row 16: the denominator row of the P V product.  Zero beyond L, so padding keys (k = 0, finite P)
+  // reach neither the numerator (V^T = 0) nor the denominator: no masking in the key loop.
+  for (int key = threadIdx.x; key < Lp; key += AT_THREADS)
+    reinterpret_cast<uint16_t*>(Vt + (size_t)16 * pitch * 2)[vt_pos(key)] = key < L ? (uint16_t)0x3F80 : (uint16_t)0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) kn = fmaxf(kn, __shfl_xor(kn, o, 64));
+  if (lane == 0) red[wave] = kn;
+  __syncthreads();
+  float kmax2 = red[0];
+#pragma unroll
+  for (int w = 1; w < AT_WAVES; ++w) kmax2 = fmaxf(kmax2, red[w]);
+
   const int col = lane & 31, h2 = lane >> 5;
   const float c = scale * AT_LOG2E;
+  // A operand of the P V product: lane col <= 16 reads image row col (16 = denominator row); lanes
+  // col > 16 feed output rows nobody reads and alias rows 1..15.  One 16-byte read per 16 keys.
+  const unsigned char* vbase = Vt + ((size_t)(col <= 16 ? col : (col & 15)) * pitch + 8 * h2) * 2;
+  const int vstride = 64, voff = 32;                           // bytes per 32-key tile / per 16-key block
+  const unsigned char* kbase = Ksm + rm_off(col, h2);
 
   for (int qt = wave; qt < n_tiles; qt += AT_WAVES) {
     const int q = qt * 32 + col;
     const s16x8 qf = ld_global_frag(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, q < L);
-    float m = -INFINITY;
-    f32x16 acc = zero16();
-    for (int kt = 0; kt < n_tiles; ++kt) {
-      const s16x8 kf = *reinterpret_cast<const s16x8*>(Ksm + rm_off(kt * 32 + col, h2));
-      f32x16 s = mfma32(kf, qf, zero16());  // S^T[key][q]: lane = q, regs = keys crow(r,h2)
-      if (kt == n_tiles - 1 && L < Lp) {
+    float qn = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kt * 32 + crow(r, h2) >= L) s[r] = -INFINITY;
+    for (int j = 0; j < 8; ++j) {
+      const float x = bf16_bits_to_float((uint16_t)qf[j]);
+      qn = fmaf(x, x, qn);
+    }
+    qn += __shfl_xor(qn, 32, 64);
+    // Cauchy-Schwarz: every logit of this row satisfies s*c <= |q| max|k| c =: bnd.  (1 + 2^-10) and
+    // the additive term cover the rounding of the norms and of the MFMA sums.
+    const float bnd = sqrtf(qn * kmax2) * c * 1.0009765625f + 1e-3f;
+    s16x8 qhi, qlo;
+    split_scaled(qf, c, qhi, qlo);
+    f32x16 acc = zero16();
+    float ref2;                                                // softmax reference point, exp2 domain
+    if (__builtin_amdgcn_ballot_w64(bnd > AT_FIXED_REF_MAX) == 0) {
+      // ---- fixed reference: P = exp2(S c - bnd) <= ~1
+      ref2 = bnd;
+      const f32x16 negb = splat16(-bnd);
+      const unsigned char* kp = kbase;
+      const unsigned char* vp = vbase;
+      // software pipeline: the S' product of tile kt+1 is in the matrix pipe while the vector pipe
+      // exponentiates tile kt (a wave is in-order: without this its MFMAs and exps never overlap)
+      // LDS operands are fetched one stage ahead of the MFMA that consumes them
+      auto ldk = [&]() {
+        const s16x8 f = *reinterpret_cast<const s16x8*>(kp);
+        kp += 1024;
+        return f;
+      };
+      s16x8 kfn = ldk();
+      auto s_tile = [&]() {
+        const s16x8 kf = kfn;
+        f32x16 sv = mfma32(kf, qhi, negb);  // S'^T[key][q] = k.(q c) - bnd: lane = q, regs = keys crow(r,h2)
+        sv = mfma32(kf, qlo, sv);
+        kfn = ldk();
+        return sv;
+      };
+      // Three-stage software pipeline over key tiles, two tiles per trip with ping-pong registers:
+      //   matrix pipe : S'(kt+1) and P V (kt-1)      vector pipe : exp / pack of tile kt
+      // so that no MFMA of a trip depends on the trip's own vector work (a wave is in-order: otherwise
+      // its MFMAs and exps never overlap), and sched_group_barrier spreads the 24 vector instructions
+      // over the 4 MFMA shadows.
+      auto expo = [&](const f32x16& sv, uint32_t (&pk)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(sv[2 * i]), __builtin_amdgcn_exp2f(sv[2 * i + 1]));
+      };
+      s16x8 vf0, vf1;
+      auto ldv = [&]() {
+        vf0 = *reinterpret_cast<const s16x8*>(vp);
+        vf1 = *reinterpret_cast<const s16x8*>(vp + voff);
+        vp += vstride;
+      };
+      auto pv = [&](const uint32_t (&pk)[8]) {
+        acc = mfma32(vf0, make_frag(pk[0], pk[1], pk[2], pk[3]), acc);
+        acc = mfma32(vf1, make_frag(pk[4], pk[5], pk[6], pk[7]), acc);
+      };
+      auto interleave = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);     // the trip's three LDS reads first
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA, and in its shadow:
+          __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);   //   four transcendentals (v_exp_f32)
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   //   two plain VALU (v_cvt_pk_bf16_f32)
+        }
+      };
+      // S' of one tile past the end is computed and never used (it reads the V^T image: in-bounds LDS),
+      // which keeps the trip body branch-free.
+      f32x16 s0 = s_tile(), s1 = s_tile();
+      uint32_t pa[8], pb[8];
+      expo(s0, pa);
+      int kt = 1;
+      for (; kt + 1 < n_tiles; kt += 2) {             // at the top: s1 = S'(kt), pa = P(kt-1), P V done for tiles < kt-1
+        ldv();
+        s0 = s_tile();
+        expo(s1, pb);
+        pv(pa);
+        interleave();
+        ldv();
+        s1 = s_tile();
+        expo(s0, pa);
+        pv(pb);
+        interleave();
       }
-      // tile maximum of this lane's 16 keys: 8 three-input maxima (v_max3_f32 costs the same issue
-      // slot as v_max_f32, measured in tools/probe_gfx950.hip), then one exchange with lane ^ 32
-      float mt = max3(max3(s[0], s[1], s[2]), max3(s[3], s[4], s[5]), max3(s[6], s[7], s[8]));
-      mt = max3(mt, max3(s[9], s[10], s[11]), max3(s[12], s[13], s[14]));
-      mt = fmaxf(mt, s[15]);
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      // deferred rescale: keep the stale running maximum while the tile maximum exceeds it by less than
-      // 2^8 in the exp2 domain for every query of the wave (P <= 256, exact in the fp32 accumulators;
-      // softmax is invariant to the reference point).  On trained / random logits almost every tile
-      // after the first few skips the 9 accumulator multiplies and one exp.
-      if (__builtin_amdgcn_ballot_w64((mt - m) * c > 8.0f) != 0) {
+      if (kt < n_tiles) {
+        expo(s1, pb);
+        ldv();
+        pv(pa);
+        ldv();
+        pv(pb);
+      } else {
+        ldv();
+        pv(pa);
+      }
+    } else {
+      // ---- online softmax (rows whose norm bound is too loose to serve as the reference)
+      float m = -INFINITY;                                     // running maximum of S' = s*c
+      const unsigned char* kp = kbase;
+      const unsigned char* vp = vbase;
+      for (int kt = 0; kt < n_tiles; ++kt) {
+        const s16x8 kf = *reinterpret_cast<const s16x8*>(kp);
+        kp += 1024;
+        f32x16 s = mfma32(kf, qhi, zero16());
+        s = mfma32(kf, qlo, s);
+        if (kt == n_tiles - 1 && L < Lp) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kt * 32 + crow(r, h2) >= L) s[r] = -INFINITY;
+        }
+        float mt = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m, mt);
-        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
         m = m_new;
 #pragma unroll
         for (int r = 0; r < 9; ++r) acc[r] *= alpha;  // rows 0..15 = O^T, row 16 (reg 8, h2=0) = denominator
-      }
-      const float mc = m * c;
-      uint32_t pk[8];
+        uint32_t pk[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i] * c - mc), __builtin_amdgcn_exp2f(s[2 * i + 1] * c - mc));
+        for (int i = 0; i < 8; ++i)
+          pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i] - m), __builtin_amdgcn_exp2f(s[2 * i + 1] - m));
 #pragma unroll
-      for (int mm = 0; mm < 2; ++mm) {
-        const s16x8 pf = make_frag(pk[4 * mm], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]);
-        const s16x8 vf = ld_transposed_frag(Vt, pitch, col, kt * 32 + 16 * mm + 4 * h2, true);
-        acc = mfma32(vf, pf, acc);
+        for (int mm = 0; mm < 2; ++mm) {
+          const s16x8 pf = make_frag(pk[4 * mm], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]);
+          const s16x8 vf = *reinterpret_cast<const s16x8*>(vp + mm * voff);
+          acc = mfma32(vf, pf, acc);
+        }
+        vp += vstride;
       }
+      ref2 = m;
     }
     const float l = __shfl(acc[8], col, 64);  // denominator lives in the h2 = 0 lane of column q
     const float inv = 1.f / l;
@@ -213,7 +378,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
       w1.x = pack_bf16x2(acc[4] * inv, acc[5] * inv); w1.y = pack_bf16x2(acc[6] * inv, acc[7] * inv);
       *reinterpret_cast<uint2*>(o + 4 * h2) = w0;       // d = 4*h2 + {0..3}
       *reinterpret_cast<uint2*>(o + 8 + 4 * h2) = w1;   // d = 8 + 4*h2 + {0..3}
-      if (h2 == 0) lse[(int64_t)head * total + a + q] = m * scale + __logf(l);
+      if (h2 == 0) lse[(int64_t)head * total + a + q] = ref2 * AT_LN2 + __logf(l);
     }
   }
 }
@@ -221,32 +386,30 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 // ================================================================================================
 // backward, part 1: dQ (query-stationary) + delta = rowsum(dO * O)
 // ================================================================================================
-__global__ void __launch_bounds__(AT_THREADS)
+// LDS: V row-major [lp_max][16] | K row-major [lp_max][16]
+__global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                    const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
                    int lp_max, int n_units, uint16_t* __restrict__ dqkv, float* __restrict__ delta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // XCD-aware order: workgroup b runs on XCD b % 8, so logical unit = (b % 8) * per + b / 8 gives every
-  // XCD a contiguous run of (sequence, head) units -- the H heads of a sequence read interleaved
-  // 32-byte pieces of the same qkv rows and now share one L2 instead of re-fetching them per XCD.
-  const int per_xcd = (n_units + 7) >> 3;
-  const int unit = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  const int unit = at_unit(n_units);
   if (unit >= n_units) return;
   const int seq = unit / H, head = unit % H;
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
-  const int pitch = lp_max + 8;
-  unsigned char* Vsm = smem;                          // V row-major
-  unsigned char* Kt = smem + (size_t)lp_max * 32;     // K transposed
+  unsigned char* Vsm = smem;
+  unsigned char* Ksm = smem + (size_t)lp_max * 32;
   const int64_t rs = (int64_t)3 * H * 16;
   stage_row_major(qkv + qkv_off(a, 2, H, head), rs, L, Lp, Vsm);
-  stage_transposed(qkv + qkv_off(a, 1, H, head), rs, L, Lp, pitch, Kt);
+  stage_row_major(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
   __syncthreads();
 
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const int col = lane & 31, h2 = lane >> 5;
   const float c = scale * AT_LOG2E;
+  const TrAddr ta = tr_addr(lane);
+  const int rmo = rm_off(col, h2);
 
   for (int qt = wave; qt < n_tiles; qt += AT_WAVES) {
     const int q = qt * 32 + col;
@@ -261,28 +424,26 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
     dl += __shfl_xor(dl, 32, 64);
     const float l2 = qv ? lse[(int64_t)head * total + a + q] * AT_LOG2E : INFINITY;
     if (qv && h2 == 0) delta[(int64_t)head * total + a + q] = dl;
+    s16x8 qhi, qlo;
+    split_scaled(qf, c, qhi, qlo);
+    const f32x16 negl = splat16(-l2), negd = splat16(-dl);
     f32x16 acc = zero16();
     for (int kt = 0; kt < n_tiles; ++kt) {
-      const int key = kt * 32 + col;
-      const s16x8 kf = ld_global_frag(qkv + qkv_off(a + key, 1, H, head) + h2 * 8, key < L);
-      const f32x16 s = mfma32(kf, qf, zero16());                                        // S^T
-      const s16x8 vf = *reinterpret_cast<const s16x8*>(Vsm + rm_off(key, h2));
-      const f32x16 dp = mfma32(vf, dof, zero16());                                      // dP^T
+      const s16x8 kf = *reinterpret_cast<const s16x8*>(Ksm + kt * 1024 + rmo);
+      const s16x8 vf = *reinterpret_cast<const s16x8*>(Vsm + kt * 1024 + rmo);
+      f32x16 s = mfma32(kf, qhi, negl);                 // S'^T = k.(q c) - lse  (exp2 domain)
+      s = mfma32(kf, qlo, s);
+      const f32x16 dp = mfma32(vf, dof, negd);          // dP^T - delta
+      // keys >= L have k = 0, so whatever (finite) dS they get multiplies K^T = 0 below
       uint32_t pk[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float p0 = __builtin_amdgcn_exp2f(s[2 * i] * c - l2), p1 = __builtin_amdgcn_exp2f(s[2 * i + 1] * c - l2);
-        if (kt == n_tiles - 1 && L < Lp) {
-          if (kt * 32 + crow(2 * i, h2) >= L) p0 = 0.f;
-          if (kt * 32 + crow(2 * i + 1, h2) >= L) p1 = 0.f;
-        }
-        pk[i] = pack_bf16x2(p0 * (dp[2 * i] - dl), p1 * (dp[2 * i + 1] - dl));          // dS^T
-      }
+      for (int i = 0; i < 8; ++i)
+        pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i]) * dp[2 * i], __builtin_amdgcn_exp2f(s[2 * i + 1]) * dp[2 * i + 1]);
 #pragma unroll
       for (int mm = 0; mm < 2; ++mm) {
         const s16x8 dsf = make_frag(pk[4 * mm], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]);
-        const s16x8 ktf = ld_transposed_frag(Kt, pitch, col, kt * 32 + 16 * mm + 4 * h2, false);
-        acc = mfma32(ktf, dsf, acc);                                                    // dQ^T[d][q]
+        const s16x8 ktf = ld_tr_frag(Ksm, ta, kt * 32 + 16 * mm);
+        acc = mfma32(ktf, dsf, acc);                    // dQ^T[d][q]
       }
     }
     if (qv) {
@@ -299,70 +460,76 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
 // ================================================================================================
 // backward, part 2: dK, dV (key-stationary).  Needs delta written by part 1 (same stream).
 // ================================================================================================
-__global__ void __launch_bounds__(AT_THREADS)
+// LDS: Q row-major [lp_max][16] | dO row-major [lp_max][16] | aux [lp_max][4] bf16 = (lse_hi, lse_lo, delta_hi, delta_lo)
+#define AT_PAD_LSE 1.0e30f   // lse of padding queries: exp2(s - 1e30) = 0 and, unlike +inf, 1e30 * 0 = 0 in the delta product
+__global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                     const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
                     int lp_max, int n_units, uint16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // XCD-aware order: workgroup b runs on XCD b % 8, so logical unit = (b % 8) * per + b / 8 gives every
-  // XCD a contiguous run of (sequence, head) units -- the H heads of a sequence read interleaved
-  // 32-byte pieces of the same qkv rows and now share one L2 instead of re-fetching them per XCD.
-  const int per_xcd = (n_units + 7) >> 3;
-  const int unit = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  const int unit = at_unit(n_units);
   if (unit >= n_units) return;
   const int seq = unit / H, head = unit % H;
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
-  const int pitch = lp_max + 8;
-  unsigned char* Qt = smem;                                        // Q transposed [16][pitch]
-  unsigned char* dOt = smem + (size_t)16 * pitch * 2;              // dO transposed
-  float* l2s = reinterpret_cast<float*>(smem + (size_t)32 * pitch * 2);  // lse * log2e, +inf beyond L
-  float* dls = l2s + lp_max;                                        // delta
-  stage_transposed(qkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, Lp, pitch, Qt);
-  stage_transposed(dout + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, Lp, pitch, dOt);
+  unsigned char* Qsm = smem;
+  unsigned char* dOsm = smem + (size_t)lp_max * 32;
+  uint2* aux = reinterpret_cast<uint2*>(smem + (size_t)lp_max * 64);
+  stage_row_major(qkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, Lp, Qsm);
+  stage_row_major(dout + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, Lp, dOsm);
   for (int q = threadIdx.x; q < Lp; q += AT_THREADS) {
-    l2s[q] = q < L ? lse[(int64_t)head * total + a + q] * AT_LOG2E : INFINITY;
-    dls[q] = q < L ? delta[(int64_t)head * total + a + q] : 0.f;
+    const float l2 = q < L ? lse[(int64_t)head * total + a + q] * AT_LOG2E : AT_PAD_LSE;
+    const float dl = q < L ? delta[(int64_t)head * total + a + q] : 0.f;
+    const uint32_t hi = pack_bf16x2(l2, dl);                                    // (lse_hi, delta_hi)
+    const uint32_t lo = pack_bf16x2(l2 - __uint_as_float(hi << 16), dl - __uint_as_float(hi & 0xffff0000u));
+    uint2 w;
+    w.x = (hi & 0xffffu) | (lo << 16);                                          // lse_hi, lse_lo
+    w.y = (hi >> 16) | (lo & 0xffff0000u);                                      // delta_hi, delta_lo
+    aux[q] = w;
   }
   __syncthreads();
 
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const int col = lane & 31, h2 = lane >> 5;
   const float c = scale * AT_LOG2E;
+  const TrAddr ta = tr_addr(lane);
+  const int rmo = rm_off(col, h2);
+  // B operands of the two "constant" products: -1 in the contraction slots that hold lse / delta
+  const uint32_t m1 = 0xBF80BF80u;                                              // (-1, -1) bf16
+  const s16x8 bS = make_frag(h2 == 0 ? m1 : 0u, 0u, 0u, 0u);
+  const s16x8 bD = make_frag(0u, h2 == 0 ? m1 : 0u, 0u, 0u);
 
   for (int kt = wave; kt < n_tiles; kt += AT_WAVES) {
     const int key = kt * 32 + col;
     const s16x8 kf = ld_global_frag(qkv + qkv_off(a + key, 1, H, head) + h2 * 8, key < L);
     const s16x8 vf = ld_global_frag(qkv + qkv_off(a + key, 2, H, head) + h2 * 8, key < L);
+    s16x8 khi, klo;
+    split_scaled(kf, c, khi, klo);
     f32x16 dv = zero16(), dk = zero16();
     for (int qt = 0; qt < n_tiles; ++qt) {
-      const int q = qt * 32 + col;
-      const s16x8 qf = ld_global_frag(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, q < L);
-      const s16x8 dof = ld_global_frag(dout + ((int64_t)(a + q) * H + head) * 16 + h2 * 8, q < L);
-      const f32x16 s = mfma32(qf, kf, zero16());     // S[q][key]: lane = key, regs = queries crow(r,h2)
-      const f32x16 dp = mfma32(dof, vf, zero16());   // dP[q][key]
+      const s16x8 qf = *reinterpret_cast<const s16x8*>(Qsm + qt * 1024 + rmo);
+      const s16x8 dof = *reinterpret_cast<const s16x8*>(dOsm + qt * 1024 + rmo);
+      const uint2 ax = aux[qt * 32 + col];                                      // h2 = 1 lanes meet B = 0: any finite value
+      const s16x8 af = make_frag(ax.x, ax.y, 0u, 0u);
+      f32x16 s = mfma32(af, bS, zero16());            // -lse[q]          S'[q][key]: lane = key, regs = queries crow(r,h2)
+      s = mfma32(qf, khi, s);
+      s = mfma32(qf, klo, s);
+      f32x16 dp = mfma32(af, bD, zero16());           // -delta[q]
+      dp = mfma32(dof, vf, dp);                       // dP[q][key] - delta[q]
       uint32_t pp[8], ps[8];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // registers 4g..4g+3 <-> queries qt*32 + 8g + 4*h2 + {0..3}: one 16-byte broadcast read each
-        const float4 l4 = *reinterpret_cast<const float4*>(l2s + qt * 32 + 8 * g + 4 * h2);
-        const float4 d4 = *reinterpret_cast<const float4*>(dls + qt * 32 + 8 * g + 4 * h2);
-        const float p0 = __builtin_amdgcn_exp2f(s[4 * g + 0] * c - l4.x);
-        const float p1 = __builtin_amdgcn_exp2f(s[4 * g + 1] * c - l4.y);
-        const float p2 = __builtin_amdgcn_exp2f(s[4 * g + 2] * c - l4.z);
-        const float p3 = __builtin_amdgcn_exp2f(s[4 * g + 3] * c - l4.w);
-        pp[2 * g] = pack_bf16x2(p0, p1);
-        pp[2 * g + 1] = pack_bf16x2(p2, p3);
-        ps[2 * g] = pack_bf16x2(p0 * (dp[4 * g + 0] - d4.x), p1 * (dp[4 * g + 1] - d4.y));
-        ps[2 * g + 1] = pack_bf16x2(p2 * (dp[4 * g + 2] - d4.z), p3 * (dp[4 * g + 3] - d4.w));
+      for (int i = 0; i < 8; ++i) {
+        const float p0 = __builtin_amdgcn_exp2f(s[2 * i]), p1 = __builtin_amdgcn_exp2f(s[2 * i + 1]);
+        pp[i] = pack_bf16x2(p0, p1);
+        ps[i] = pack_bf16x2(p0 * dp[2 * i], p1 * dp[2 * i + 1]);
       }
 #pragma unroll
       for (int mm = 0; mm < 2; ++mm) {
         const s16x8 pf = make_frag(pp[4 * mm], pp[4 * mm + 1], pp[4 * mm + 2], pp[4 * mm + 3]);     // P^T[key][q slots]
         const s16x8 dsf = make_frag(ps[4 * mm], ps[4 * mm + 1], ps[4 * mm + 2], ps[4 * mm + 3]);    // dS^T
-        const s16x8 dotf = ld_transposed_frag(dOt, pitch, col, qt * 32 + 16 * mm + 4 * h2, false);  // dO[q slots][d]
-        const s16x8 qtf = ld_transposed_frag(Qt, pitch, col, qt * 32 + 16 * mm + 4 * h2, false);    // Q[q slots][d]
+        const s16x8 dotf = ld_tr_frag(dOsm, ta, qt * 32 + 16 * mm);                                 // dO[q slots][d]
+        const s16x8 qtf = ld_tr_frag(Qsm, ta, qt * 32 + 16 * mm);                                   // Q[q slots][d]
         dv = mfma32(pf, dotf, dv);   // dV[key][d]
         dk = mfma32(dsf, qtf, dk);   // dK[key][d]
       }
@@ -391,8 +558,9 @@ static int allow_big_lds(K kernel, size_t bytes) {
   return PTC_OK;
 }
 
-static size_t fwd_lds_bytes(int lp_max) { return (size_t)lp_max * 32 + (size_t)16 * (lp_max + 8) * 2; }
-static size_t dkv_lds_bytes(int lp_max) { return (size_t)32 * (lp_max + 8) * 2 + (size_t)2 * lp_max * 4; }
+static size_t fwd_lds_bytes(int lp_max) { return (size_t)lp_max * 32 + (size_t)17 * (lp_max + 8) * 2 + AT_WAVES * 4; }
+static size_t dq_lds_bytes(int lp_max) { return (size_t)lp_max * 64; }
+static size_t dkv_lds_bytes(int lp_max) { return (size_t)lp_max * 64 + (size_t)lp_max * 8; }
 
 static int check_common(const char* name, const void* qkv, const int32_t* cu, int64_t n_seq, int64_t total, int H,
                         int max_seqlen, int dtype) {
@@ -443,13 +611,13 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   const int lp_max = (max_seqlen + 31) & ~31;
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)workspace;
-  rc = allow_big_lds(attn_bwd_dq_kernel, fwd_lds_bytes(lp_max));
+  rc = allow_big_lds(attn_bwd_dq_kernel, dq_lds_bytes(lp_max));
   if (rc != PTC_OK) return rc;
   rc = allow_big_lds(attn_bwd_dkv_kernel, dkv_lds_bytes(lp_max));
   if (rc != PTC_OK) return rc;
   const int n_units = (int)(n_seq * H);
   const unsigned grid = (unsigned)(8 * ((n_units + 7) / 8));
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(grid), dim3(AT_THREADS), fwd_lds_bytes(lp_max), s,
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(grid), dim3(AT_THREADS), dq_lds_bytes(lp_max), s,
                      (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H,
                      softmax_scale, total, lp_max, n_units, (uint16_t*)dqkv, delta);
   PTC_CHECK_LAUNCH("attn_bwd_dq_kernel");

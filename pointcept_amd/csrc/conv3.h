@@ -1,0 +1,192 @@
+// conv3.h -- third-generation forward / dgrad kernel of the gather-table convolution for 16-bit
+// features with c_in in {32, 64, 128, 256, 512, ...} and c_out % 64 == 0 (every CPE convolution of
+// PTv3 and every 3x3x3 / 2x2x2 convolution of SpUNet beyond the stem).  Included by spconv.hip.
+//
+// What was wrong with conv2 (profiles/r01_d): it restaged W through LDS once per table row, between two
+// workgroup barriers, with an index computation (two integer divisions) per 16-byte vector and with
+// nothing else in flight -- for the deep stages (N <= 50k rows, C >= 128: 27 x 256 x 256 weights per
+// 64-row workgroup) that staging WAS the kernel: 28 launches of ~0.6 ms for ~20 GFLOP each.
+//
+// conv3:
+//   * the contraction is flattened to v = k * c_in + c (the weight row [kv][c_in] of one output
+//     channel is contiguous in the spconv layout) and cut into CHUNKS of 128 v's = four MFMA steps
+//     of 32 channels; a chunk of W is 64 output channels x 256 B = 16 KB;
+//   * W chunks run through a two-deep LDS pipeline: chunk c+1 is fetched into registers (4 x 16 B per
+//     thread, addresses are one multiply-add) while chunk c is multiplied, stored, ONE barrier per chunk;
+//   * the LDS image is in MFMA FRAGMENT ORDER ([tile][step][lane][8 channels], 1 KB per fragment, 64 B
+//     of padding between fragments so the four steps written by a lane quad hit different banks): the
+//     A-operand read is a lane-linear ds_read_b128, conflict-free by construction;
+//   * gathered rows go HBM/L2 -> registers directly as B operands (no LDS), through a ring of four
+//     step slots: the rows of (chunk c+1, step s) are requested right after (chunk c, step s) is
+//     multiplied, i.e. one full chunk (64 MFMAs per wave) ahead; table entries another chunk ahead;
+//   * a wave owns RT row tiles of 16 rows x all 64 output channels of the workgroup (RT = 4: 256 rows
+//     per workgroup, W fragments reused by 4 row tiles; RT = 2 when the grid would not fill the chip);
+//     row tiles with no valid neighbour at a step skip its MFMAs (wave-uniform branch);
+//   * workgroups are numbered XCD-first (b % 8 = XCD): consecutive row blocks -- and the c_out tiles
+//     of one row block -- share an L2, so neighbouring rows are fetched from HBM once per XCD.
+// Output-stationary, no atomics, fixed summation order: bit-reproducible.
+#pragma once
+
+#define C3_FRAG 1024
+#define C3_FPAD 64
+#define C3_BUF (16 * (C3_FRAG + C3_FPAD))   // one W chunk: 4 tiles x 4 steps
+
+template <typename T, int RT, int KPC>
+__global__ void __launch_bounds__(256, 2)
+conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+             const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int n_rowblk, T* __restrict__ out) {
+  using M = Mma<T>;
+  using frag = typename M::frag;
+  constexpr int NTILES = 4, NT = 64, BM = RT * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ny = c_out / NT;
+  const int nblk = n_rowblk * ny;
+  const int per_xcd = (nblk + 7) >> 3;
+  const int lb = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const int rb = lb / ny, n0 = (lb - rb * ny) * NT;
+  const int lane = ptc_lane(), wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t row0 = (int64_t)rb * BM + wave * (RT * 16);
+  const int KV = kv * c_in;
+  const int nchunks = (KV + 127) >> 7;
+
+  // ---- W staging: thread -> (weight row, step); 4 x 16 B per chunk
+  const int wrow = threadIdx.x >> 2, qd = threadIdx.x & 3;
+  const T* wsrc = w + (int64_t)(n0 + wrow) * KV + qd * 32;
+  const int prow = lds_row_of_channel<NTILES>(wrow);
+  const int wdst = ((prow >> 4) * 4 + qd) * (C3_FRAG + C3_FPAD) + (prow & 15) * 16;
+  uint4 wreg[4];
+  auto wload = [&](int c) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      uint4 v = {0, 0, 0, 0};
+      if (c * 128 + qd * 32 + gq * 8 < KV) v = *reinterpret_cast<const uint4*>(wsrc + c * 128 + gq * 8);
+      wreg[gq] = v;
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<uint4*>(smem + buf * C3_BUF + wdst + gq * 256) = wreg[gq];
+  };
+
+  // ---- gather ring
+  frag ga[4][RT];
+  bool anyv[4][RT];
+  int32_t idxN[KPC][RT], idxNN[KPC][RT];
+  auto load_idx = [&](int c, int32_t (&ix)[KPC][RT]) {
+#pragma unroll
+    for (int kk = 0; kk < KPC; ++kk) {
+      const int k = KPC > 1 ? c * KPC + kk : (c * 128) / c_in;
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const int64_t row = row0 + j * 16 + r;
+        ix[kk][j] = (k < kv && row < n_out) ? nbr[(int64_t)k * n_out + row] : -1;
+      }
+    }
+  };
+  auto issue = [&](int c, int s, const int32_t (&ix)[KPC][RT]) {
+    const int kk = (s * KPC) >> 2;
+    const int cbase = (c * 128 + s * 32) % c_in + g * 8;
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      const int32_t i = ix[kk][j];
+      frag f = M::zero();
+      if (i >= 0) f = ld_frag<T>(in + (int64_t)i * c_in + cbase);
+      ga[s][j] = f;
+      anyv[s][j] = __builtin_amdgcn_ballot_w64(i >= 0) != 0;
+    }
+  };
+
+  f32x4 acc[RT][NTILES];
+  {
+    f32x4 breg[NTILES];
+    sc_bias_regs<NTILES>(bias, n0, g, breg);
+#pragma unroll
+    for (int j = 0; j < RT; ++j)
+#pragma unroll
+      for (int t = 0; t < NTILES; ++t) acc[j][t] = breg[t];
+  }
+
+  // ---- prologue: W(0) -> LDS, gathers of chunk 0 in flight, W(1) and idx(1) requested
+  wload(0);
+  load_idx(0, idxN);
+  wstore(0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) issue(0, s, idxN);
+  load_idx(1, idxN);
+  wload(1);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int c = 0; c < nchunks; ++c) {
+    const unsigned char* wb = smem + (c & 1) * C3_BUF + lane * 16;
+    load_idx(c + 2, idxNN);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      frag wf[NTILES];
+#pragma unroll
+      for (int t = 0; t < NTILES; ++t) wf[t] = *reinterpret_cast<const frag*>(wb + (t * 4 + s) * (C3_FRAG + C3_FPAD));
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        if (anyv[s][j]) {
+#pragma unroll
+          for (int t = 0; t < NTILES; ++t) acc[j][t] = M::mma(wf[t], ga[s][j], acc[j][t]);
+        }
+      }
+      issue(c + 1, s, idxN);
+    }
+    wstore((c + 1) & 1);
+    __syncthreads();
+    wload(c + 2);
+#pragma unroll
+    for (int kk = 0; kk < KPC; ++kk)
+#pragma unroll
+      for (int j = 0; j < RT; ++j) idxN[kk][j] = idxNN[kk][j];
+  }
+
+#pragma unroll
+  for (int j = 0; j < RT; j += 2) {
+    const int64_t rowA = row0 + j * 16 + r;
+    sc_epilogue<T, NTILES>(*reinterpret_cast<f32x4(*)[2][NTILES]>(&acc[j]), nullptr, out, rowA, rowA + 16, n_out, c_out, n0, g);
+  }
+}
+
+static inline bool conv3_supported(int dtype, int kv, int c_in, int c_out, const int32_t* nbr) {
+  if (dtype == PTC_F32 || nbr == nullptr || kv < 2) return false;
+  if (c_out % 64 != 0 || c_in % 32 != 0) return false;
+  return c_in == 32 || c_in == 64 || c_in % 128 == 0;
+}
+
+template <typename T, int RT, int KPC>
+static int launch_conv3_i(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
+                          int c_out, void* out, hipStream_t s) {
+  const int n_rowblk = (int)ptc_cdiv(n_out, RT * 64);
+  const int nblk = n_rowblk * (c_out / 64);
+  const size_t lds = 2 * C3_BUF;
+  auto kern = conv3_kernel<T, RT, KPC>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv,
+                     c_in, c_out, n_rowblk, (T*)out);
+  PTC_CHECK_LAUNCH("conv3_kernel");
+  return PTC_OK;
+}
+
+template <typename T>
+static int launch_conv3(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
+                        int c_out, void* out, hipStream_t s) {
+  // 256-row workgroups when they still give every CU two workgroups, else 128-row ones
+  // (PTC_CONV3_RT=2|4 forces the choice: used by the tests to reach both instantiations at small n)
+  bool big = ptc_cdiv(n_out, 256) * (c_out / 64) >= 512;
+  if (const char* e = getenv("PTC_CONV3_RT")) {
+    if (atoi(e) == 4) big = true;
+    if (atoi(e) == 2) big = false;
+  }
+  const int kpc = c_in >= 128 ? 1 : 128 / c_in;
+#define C3_CASE(K)                                                                                          \
+  if (kpc == K) return big ? launch_conv3_i<T, 4, K>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s)      \
+                           : launch_conv3_i<T, 2, K>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  C3_CASE(1) C3_CASE(2) C3_CASE(4)
+#undef C3_CASE
+  ptc_set_error("conv3: c_in=%d unsupported", c_in);
+  return PTC_EUNSUPPORTED;
+}

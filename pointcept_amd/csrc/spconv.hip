@@ -213,6 +213,13 @@ static int dispatch_fwd(const void* in, const void* w, const float* bias, const 
 }
 
 #include "fwd2.h"
+#include "conv3.h"
+
+// experiment switch (read per call, ~50 ns): PTC_CONV3=0 keeps the table convolutions on conv2
+static bool ptc_use_conv3() {
+  const char* e = getenv("PTC_CONV3");
+  return e ? atoi(e) != 0 : true;
+}
 
 extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr,
                               int64_t n_out, int kv, int c_in, int c_out, int dtype, void* out, ptc_stream_t stream) {
@@ -225,6 +232,10 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
   PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)out % 16 == 0), PTC_EINVAL,
               "ptc_spconv_fwd: buffers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  if (ptc_use_conv3() && conv3_supported(dtype, kv, c_in, c_out, nbr)) {
+    if (dtype == PTC_BF16) return launch_conv3<bf16_t>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
+    return launch_conv3<f16_t>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  }
   if (fwd2_supported(dtype, kv, c_in) && (nbr || kv == 1)) {
     if (dtype == PTC_BF16) return dispatch_fwd2<bf16_t>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
     return dispatch_fwd2<f16_t>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);

@@ -152,27 +152,74 @@ def bench_spconv(rows, results, scenes=8, points=102400):
     results.append(r)
 
 
+def bench_spconv_stages(rows, results, scenes=8, points=102400):
+    """CPE convolution (k=3 SubM, C -> C) forward at the five PTv3 stages of the bench batch, rows in
+    Hilbert order as in the model (config.SORT_POINTS), conv2 vs conv3."""
+    from pointcept_amd import synthetic
+
+    b = synthetic.to_torch(synthetic.indoor_batch(scenes, points), DEV)
+    batch = torch.repeat_interleave(torch.arange(scenes, device=DEV), torch.diff(b["offset"], prepend=b["offset"].new_zeros(1)))
+    gc = b["grid_coord"]
+    for s, chans in enumerate(((32, 64), (64,), (128,), (256,), (512,))):
+        key = (batch << 48) | ((gc[:, 0] >> s) << 32) | ((gc[:, 1] >> s) << 16) | (gc[:, 2] >> s)
+        uk = torch.unique(key)
+        bb = uk >> 48
+        cc = torch.stack([(uk >> 32) & 0xffff, (uk >> 16) & 0xffff, uk & 0xffff], 1)
+        code = ops.serialize_encode(cc, bb, 8 - s, ("hilbert",))
+        order, _ = ops.sort_keys(code, 0, 3 * (8 - s) + 3)
+        cc, bb = cc[order[0]], bb[order[0]]
+        ind = torch.cat([bb[:, None].int(), cc.int()], 1).contiguous()
+        n = ind.shape[0]
+        nbr = ops.rulebook_subm(ind, 3, ops.HashTable(ind))
+        pairs = int((nbr >= 0).sum())
+        for c in chans:
+            x = torch.randn(n, c, device=DEV).to(torch.bfloat16)
+            w = (torch.randn(c, 27, c, device=DEV) * 0.05).to(torch.bfloat16)
+            bias = torch.randn(c, device=DEV)
+            by = n * c * 2 * 2 + 4 * 27 * n + 27 * c * c * 2
+            fl = 2.0 * pairs * c * c
+            r = {"stage": s, "n": n, "c": c, "pairs": pairs}
+            for name, flag in (("conv2", "0"), ("conv3", "1")):
+                os.environ["PTC_CONV3"] = flag
+                r[name] = roof(by, fl, timeit(lambda: ops.spconv_fwd(x, w, bias, nbr), iters=10))
+            os.environ.pop("PTC_CONV3", None)
+            g = torch.randn(n, c, device=DEV).to(torch.bfloat16)
+            r["wgrad"] = roof(by, fl, timeit(lambda: ops.spconv_wgrad(x, g, nbr), iters=10))
+            results.append(r)
+            rows.append(f"cpe conv stage {s} n={n:7d} c={c:3d} pairs/pt={pairs / n:5.2f} | conv2 {r['conv2']['us']:8.1f} us | conv3 {r['conv3']['us']:8.1f} us "
+                        f"({r['conv3']['GBps']:.0f} GB/s alg, {r['conv3']['TFLOPs']:.1f} TF/s) | wgrad {r['wgrad']['us']:8.1f} us ({r['wgrad']['TFLOPs']:.1f} TF/s)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="comma list of sections: linear,ln,attn,spconv")
     args = ap.parse_args()
-    rows, res = [], {"linear": [], "ln": [], "attn": [], "spconv": []}
+    only = set(x for x in args.only.split(",") if x)
+    want = lambda name: not only or name in only  # noqa: E731
+    rows, res = [], {"linear": [], "ln": [], "attn": [], "spconv": [], "stages": []}
     stages = [(819200, 32), (202560, 64), (49256, 128), (11400, 256), (2640, 512)]
     if args.quick:
         stages = stages[:2]
-    for n, c in stages:
-        for cin, cout in ((c, 3 * c), (c, c), (c, 4 * c), (4 * c, c)):
-            bench_linear(rows, n, cin, cout, res["linear"])
-    bench_linear(rows, 819200, 64, 192, res["linear"])
-    bench_linear(rows, 819200, 64, 256, res["linear"])
-    bench_linear(rows, 819200, 256, 64, res["linear"])
-    bench_linear(rows, 819200, 64, 32, res["linear"])   # seg head (20 padded to 32)
-    for n, c in stages:
-        bench_ln(rows, n, c, res["ln"])
-    bench_ln(rows, 819200, 64, res["ln"])
-    for n_seq, H in ((800, 2), (800, 4), (200, 4), (48, 8), (16, 16)):
-        bench_attention(rows, n_seq, H, res["attn"])
-    bench_spconv(rows, res["spconv"])
+    if want("linear"):
+        for n, c in stages:
+            for cin, cout in ((c, 3 * c), (c, c), (c, 4 * c), (4 * c, c)):
+                bench_linear(rows, n, cin, cout, res["linear"])
+        bench_linear(rows, 819200, 64, 192, res["linear"])
+        bench_linear(rows, 819200, 64, 256, res["linear"])
+        bench_linear(rows, 819200, 256, 64, res["linear"])
+        bench_linear(rows, 819200, 64, 32, res["linear"])   # seg head (20 padded to 32)
+    if want("ln"):
+        for n, c in stages:
+            bench_ln(rows, n, c, res["ln"])
+        bench_ln(rows, 819200, 64, res["ln"])
+    if want("attn"):
+        for n_seq, H in ((800, 2), (800, 4), (200, 4), (48, 8), (16, 16)):
+            bench_attention(rows, n_seq, H, res["attn"])
+    if want("spconv"):
+        bench_spconv(rows, res["spconv"])
+    if want("stages"):
+        bench_spconv_stages(rows, res["stages"])
     print("\n".join(rows))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:

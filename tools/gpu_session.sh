@@ -16,6 +16,9 @@ for sec in "$@"; do
   case $sec in
     tests) timeout 1500 python -m pytest tests -q -m gpu > $O/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> $O/${TAG}_env.log; tail -4 $O/${TAG}_tests.log;;
     ops) timeout 900 python tools/bench_ops.py > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log;;
+    ops:*) timeout 900 python tools/bench_ops.py --only ${sec#ops:} > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log; cat $O/${TAG}_ops.log | cut -c1-220;;
+    test:*) timeout 1500 python -m pytest tests -q -m gpu -k "${sec#test:}" > $O/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> $O/${TAG}_env.log; tail -15 $O/${TAG}_tests.log;;
+    probe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_gfx950 tools/probe_gfx950.hip > $O/${TAG}_probe.log 2>&1 && timeout 300 /tmp/probe_gfx950 >> $O/${TAG}_probe.log 2>&1; tail -20 $O/${TAG}_probe.log | cut -c1-200;;
     opsq) timeout 900 python tools/bench_ops.py --quick > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log;;
     bench) timeout 900 python bench.py --steps 10 --warmup 3 > $O/${TAG}_bench.log 2>&1; echo "bench rc=$?" >> $O/${TAG}_env.log; tail -1 $O/${TAG}_bench.log | cut -c1-330;;
     ab:*) envs=$(echo "${sec#ab:}" | tr ',' ' '); name=$(echo "${sec#ab:}" | tr -c 'A-Za-z0-9=\n' '_');
@@ -27,9 +30,10 @@ for sec in "$@"; do
           timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_roof_fetch -- python $R/tools/roofline_kernel.py > $O/${TAG}_roof_fetch.log 2>&1
           timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_roof_write -- python $R/tools/roofline_kernel.py > $O/${TAG}_roof_write.log 2>&1
           timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $O/${TAG}_roof_sq -- python $R/tools/roofline_kernel.py > $O/${TAG}_roof_sq.log 2>&1
-          cd $R; python tools/pmc_summary.py --stats $O/${TAG}_roof_stats --pmc $O/${TAG}_roof_fetch $O/${TAG}_roof_write $O/${TAG}_roof_sq \
+          timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU -d $O/${TAG}_roof_sq2 -- python $R/tools/roofline_kernel.py > $O/${TAG}_roof_sq2.log 2>&1
+          cd $R; python tools/pmc_summary.py --stats $O/${TAG}_roof_stats --pmc $O/${TAG}_roof_fetch $O/${TAG}_roof_write $O/${TAG}_roof_sq $O/${TAG}_roof_sq2 \
             --kernels attn_fwd_kernel,attn_bwd_dq_kernel,attn_bwd_dkv_kernel --out $O/${TAG}_roof_pmc.json > $O/${TAG}_roof_pmc.log 2>&1
-          rm -rf $O/${TAG}_roof_stats $O/${TAG}_roof_fetch $O/${TAG}_roof_write $O/${TAG}_roof_sq;;
+          rm -rf $O/${TAG}_roof_stats $O/${TAG}_roof_fetch $O/${TAG}_roof_write $O/${TAG}_roof_sq $O/${TAG}_roof_sq2; tail -3 $O/${TAG}_roof_sq2.log;;
     *) echo "unknown section $sec";;
   esac
 done

@@ -97,6 +97,65 @@ __global__ void __launch_bounds__(1024) tp_probe(float* out, uint64_t* cycles, f
   if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
+
+// ---- instruction-mix probe: the forward attention trip (4 MFMA 32x32x16 on two dependent pairs, NE
+// v_exp_f32, NC v_cvt_pk_bf16_f32), hand-interleaved as in attn_fwd_kernel.  Gives the floor of that mix.
+template <int NE, int NC, int NM>
+__global__ void __launch_bounds__(1024) mix_probe(float* out, uint64_t* cycles, float seed) {
+  float r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r[i] = seed + 0.001f * (threadIdx.x + i);
+  f32x16 a0, a1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+  s16x8 fa = {0x3c00, 0x3c01, 0x3c02, 0x3c03, 0x3c04, 0x3c05, 0x3c06, 0x3c07}, fb = {0x3c08, 0x3c07, 0x3c06, 0x3c05, 0x3c04, 0x3c03, 0x3c02, 0x3c01};
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (m < NM) {
+        if (m < 2) a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, a0, 0, 0, 0);
+        else a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, a1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NE / 4; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(r[(m * (NE / 4) + i) & 15]));
+#pragma unroll
+      for (int i = 0; i < NC / 4; ++i) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(r[(m * 2 + i) & 15]) : "v"(r[(m * 2 + i + 8) & 15]));
+    }
+  }
+  const uint64_t t1 = __builtin_readcyclecounter();
+  float s = a0[0] + a1[0];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += r[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int NE, int NC, int NM>
+static int run_mix(const char* name, float* dout, uint64_t* dcyc) {
+  const int waves_per_simd[3] = {1, 2, 4};
+  printf("%-34s", name);
+  for (int w = 0; w < 3; ++w) {
+    const int threads = 64 * 4 * waves_per_simd[w];
+    const int blocks = 256;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    hipLaunchKernelGGL((mix_probe<NE, NC, NM>), dim3(blocks), dim3(threads), 0, 0, dout, dcyc, 0.5f);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((mix_probe<NE, NC, NM>), dim3(blocks), dim3(threads), 0, 0, dout, dcyc, 0.5f);
+    CK(hipEventRecord(b));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    // ns per trip per SIMD (a "trip" = one 32x32 attention tile of one wave)
+    printf(" | %dw/SIMD: %7.1f ns/trip/SIMD (%6.3f ms)", waves_per_simd[w], ms * 1e6 / (ITERS * (double)waves_per_simd[w]), ms);
+  }
+  printf("\n");
+  return 0;
+}
+
 template <int KIND>
 static int run_tp(const char* name, float* dout, uint64_t* dcyc) {
   const int waves_per_simd[3] = {1, 2, 4};
@@ -165,6 +224,14 @@ int main() {
   run_tp<23>("mfma 32x32x16 bf16 (2 acc)", fo, cyc);
   run_tp<21>("mfma 16x16x32 bf16 (dep)", fo, cyc);
   run_tp<22>("mfma 16x16x32 bf16 (4 acc)", fo, cyc);
+  printf("\ninstruction-mix floors (ns per trip per SIMD; 32 cycles at 2.4 GHz = 13.3 ns)\n");
+  run_mix<0, 0, 4>("4 mfma", fo, cyc);
+  run_mix<16, 0, 0>("16 exp", fo, cyc);
+  run_mix<16, 8, 0>("16 exp + 8 cvt", fo, cyc);
+  run_mix<16, 8, 4>("4 mfma + 16 exp + 8 cvt (fwd)", fo, cyc);
+  run_mix<8, 8, 4>("4 mfma + 8 exp + 8 cvt", fo, cyc);
+  run_mix<16, 8, 3>("3 mfma + 16 exp + 8 cvt", fo, cyc);
+  run_mix<0, 8, 4>("4 mfma + 8 cvt", fo, cyc);
   int clk = 0;
   CK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0));
   printf("device clock rate attribute: %d kHz\n", clk);
