@@ -409,7 +409,9 @@ static int wgrad_splits(int64_t n_out, int kv, int c_in, int c_out) {
 extern "C" size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out) {
   // max over the fp32 path (v1, `splits` partials) and the 16-bit path (v2, one partial per workgroup)
   size_t splits = (size_t)wgrad_splits(n_out, kv, c_in, c_out);
-  const size_t gx = (size_t)w2_plan(n_out, kv, c_in, c_out).gx;
+  size_t gx = (size_t)w2_plan(n_out, kv, c_in, c_out, false).gx;
+  const size_t gxb = (size_t)w2_plan(n_out, kv, c_in, c_out, true).gx;
+  if (gxb > gx) gx = gxb;
   if (gx > splits) splits = gx;
   return ptc_align_up(splits * (size_t)c_out * kv * c_in * sizeof(float), 256) + ptc_align_up(splits * (size_t)c_out * sizeof(float), 256);
 }
@@ -457,7 +459,7 @@ static int launch_wgrad2_inst(const W2Plan& p, const void* in, const void* dout,
 template <typename T>
 static int launch_wgrad2(const void* in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
                          float* dw, float* dbias, void* ws, hipStream_t s) {
-  const W2Plan p = w2_plan(n_out, kv, c_in, c_out);
+  const W2Plan p = w2_plan(n_out, kv, c_in, c_out, dbias != nullptr);
   const int64_t count = (int64_t)c_out * kv * c_in;
   float* partial = p.gx > 1 ? (float*)ws : dw;
   float* bias_partial = nullptr;

@@ -48,22 +48,35 @@ __device__ __forceinline__ void w2_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// PIPE (step-ahead prefetch): while a wave multiplies step s out of its LDS slice, the dout rows and the
+// gathered rows of ALL KG table rows of its next step are in flight in registers (COT + KG*CIT 16-byte
+// loads per lane), and the table entries of the step after that are being fetched.  v2 without it had one
+// table row of gathers in flight and two dependent global latencies (entries -> rows) at every step:
+// 56 TF/s useful at C = 64 (profiles/r01_h).  PIPE needs (COT + KG*CIT) KB of LDS per wave and
+// 4*(COT + KG*CIT) registers; instances whose accumulators leave no room keep the in-step gathers.
+template <int COT, int CIT, int KG>
+struct W2Pipe { static constexpr bool value = KG * COT * CIT * 4 + 4 * (COT + KG * CIT) + 4 * (COT + CIT) <= 208; };
+
 template <typename T, int COT, int CIT, int KG>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)   // two waves per SIMD: <= 256 registers
 wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_t* __restrict__ nbr, int64_t n_out, int kv,
               int c_in, int c_out, int64_t steps_total, int ci_blocks, float* __restrict__ partial,
               float* __restrict__ bias_partial) {
   using M = Mma<T>;
-  constexpr int WAVE_BYTES = (COT + 2 * CIT) * 1024;  // dout image + two `in` images
+  constexpr bool PIPE = W2Pipe<COT, CIT, KG>::value;
+  constexpr int NI = PIPE ? KG : 2;                    // gathered-row images per wave
+  constexpr int WAVE_BYTES = (COT + NI * CIT) * 1024;  // dout image + `in` images
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char* D = smem + wave * WAVE_BYTES;
-  unsigned char* I[2] = {D + COT * 1024, D + (COT + CIT) * 1024};
+  unsigned char* I0 = D + COT * 1024;
   const int k0 = blockIdx.y * KG;
   const int nk = (kv - k0) < KG ? (kv - k0) : KG;
   const int co0 = (blockIdx.z / ci_blocks) * COT * 16, ci0 = (blockIdx.z % ci_blocks) * CIT * 16;
   const int64_t workers = (int64_t)gridDim.x * 4, worker = (int64_t)blockIdx.x * 4 + wave;
-  const bool do_bias = bias_partial != nullptr && blockIdx.y == 0 && (blockIdx.z % ci_blocks) == 0;
+  // the fused bias gradient (one extra MFMA against ones per dout fragment) exists in the KG == 1 instances
+  // only -- the host plans KG = 1 whenever dbias is requested; grouped instances have no registers to spare
+  const bool do_bias = KG == 1 && bias_partial != nullptr && blockIdx.y == 0 && (blockIdx.z % ci_blocks) == 0;
 
   f32x4 acc[KG][COT][CIT];
   f32x4 accb[COT];
@@ -82,10 +95,9 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
     __builtin_memcpy(&ones, o8, sizeof(ones));
   }
 
-  for (int64_t s = worker; s < steps_total; s += workers) {
+  // table entries of the rows this lane stages, for every table row of the group
+  auto load_idx = [&](int64_t s, int32_t (&ix)[KG][CIT]) {
     const int64_t r0 = s * W2_ROWS;
-    // table entries of the rows this lane stages, for every table row of the group
-    int32_t idx[KG][CIT];
 #pragma unroll
     for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
@@ -93,65 +105,126 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
         const int row = (i * 64 + lane) / (2 * CIT);
         const int64_t rr = r0 + row;
         int32_t j = -1;
-        if (kk < nk && rr < n_out) j = nbr ? nbr[(int64_t)(k0 + kk) * n_out + rr] : (int32_t)rr;
-        idx[kk][i] = j;
+        if (kk < nk && rr < n_out && s < steps_total) j = nbr ? nbr[(int64_t)(k0 + kk) * n_out + rr] : (int32_t)rr;
+        ix[kk][i] = j;
       }
-    // dout rows -> LDS (row-major sub-tiles)
+  };
+  auto load_dout = [&](int64_t s, uint4 (&pd)[COT]) {
+    const int64_t r0 = s * W2_ROWS;
 #pragma unroll
     for (int i = 0; i < COT; ++i) {
       const int v = i * 64 + lane, row = v / (2 * COT), piece = v % (2 * COT);
       const int64_t rr = r0 + row;
       const int ch = co0 + piece * 8;
       uint4 x = {0, 0, 0, 0};
-      if (rr < n_out && ch < c_out) x = *reinterpret_cast<const uint4*>(dout + rr * c_out + ch);
-      *reinterpret_cast<uint4*>(D + w2_off(row, piece)) = x;
+      if (rr < n_out && ch < c_out && s < steps_total) x = *reinterpret_cast<const uint4*>(dout + rr * c_out + ch);
+      pd[i] = x;
     }
-    // gathered input rows of the first table row
-    uint4 pre[CIT];
+  };
+  auto store_dout = [&](const uint4 (&pd)[COT]) {
+#pragma unroll
+    for (int i = 0; i < COT; ++i) {
+      const int v = i * 64 + lane, row = v / (2 * COT), piece = v % (2 * COT);
+      *reinterpret_cast<uint4*>(D + w2_off(row, piece)) = pd[i];
+    }
+  };
+  auto gather = [&](const int32_t (&ixk)[CIT], uint4 (&pi)[CIT]) {
 #pragma unroll
     for (int i = 0; i < CIT; ++i) {
       const int piece = (i * 64 + lane) % (2 * CIT);
       const int ch = ci0 + piece * 8;
       uint4 x = {0, 0, 0, 0};
-      if (idx[0][i] >= 0 && ch < c_in) x = *reinterpret_cast<const uint4*>(in + (int64_t)idx[0][i] * c_in + ch);
-      pre[i] = x;
+      if (ixk[i] >= 0 && ch < c_in) x = *reinterpret_cast<const uint4*>(in + (int64_t)ixk[i] * c_in + ch);
+      pi[i] = x;
     }
-    w2_wave_sync();
-    typename M::frag A[COT];
+  };
+  auto store_in = [&](unsigned char* buf, const uint4 (&pi)[CIT]) {
 #pragma unroll
-    for (int a = 0; a < COT; ++a) A[a] = w2_frag<T>(D, a, lane);
-    if (do_bias) {
-#pragma unroll
-      for (int a = 0; a < COT; ++a) accb[a] = M::mma(A[a], ones, accb[a]);
+    for (int i = 0; i < CIT; ++i) {
+      const int v = i * 64 + lane, row = v / (2 * CIT), piece = v % (2 * CIT);
+      *reinterpret_cast<uint4*>(buf + w2_off(row, piece)) = pi[i];
     }
+  };
+
+  if constexpr (PIPE) {
+    int32_t idx[KG][CIT];
+    uint4 pd[COT], pi[KG][CIT];
+    load_idx(worker, idx);
+    load_dout(worker, pd);
 #pragma unroll
-    for (int kk = 0; kk < KG; ++kk) {
-      if (kk < nk) {
-        unsigned char* buf = I[kk & 1];
+    for (int kk = 0; kk < KG; ++kk) gather(idx[kk], pi[kk]);
+    load_idx(worker + workers, idx);
+    for (int64_t s = worker; s < steps_total; s += workers) {
+      // 1. step s lands in the wave's LDS slice
+      store_dout(pd);
 #pragma unroll
-        for (int i = 0; i < CIT; ++i) {
-          const int v = i * 64 + lane, row = v / (2 * CIT), piece = v % (2 * CIT);
-          *reinterpret_cast<uint4*>(buf + w2_off(row, piece)) = pre[i];
+      for (int kk = 0; kk < KG; ++kk)
+        if (kk < nk) store_in(I0 + kk * CIT * 1024, pi[kk]);
+      // 2. step s + workers goes out, entries of the one after it too
+      load_dout(s + workers, pd);
+#pragma unroll
+      for (int kk = 0; kk < KG; ++kk) gather(idx[kk], pi[kk]);
+      load_idx(s + 2 * workers, idx);
+      // 3. multiply step s
+      w2_wave_sync();
+      typename M::frag A[COT];
+#pragma unroll
+      for (int a = 0; a < COT; ++a) A[a] = w2_frag<T>(D, a, lane);
+      if constexpr (KG == 1) {
+        if (do_bias) {
+#pragma unroll
+          for (int a = 0; a < COT; ++a) accb[a] = M::mma(A[a], ones, accb[a]);
         }
-        if (kk + 1 < KG && kk + 1 < nk) {  // next table row's gather goes out before this one is multiplied
+      }
 #pragma unroll
-          for (int i = 0; i < CIT; ++i) {
-            const int piece = (i * 64 + lane) % (2 * CIT);
-            const int ch = ci0 + piece * 8;
-            uint4 x = {0, 0, 0, 0};
-            const int32_t j = idx[(kk + 1) < KG ? (kk + 1) : 0][i];
-            if (j >= 0 && ch < c_in) x = *reinterpret_cast<const uint4*>(in + (int64_t)j * c_in + ch);
-            pre[i] = x;
-          }
+      for (int kk = 0; kk < KG; ++kk) {
+        if (kk < nk) {
+          typename M::frag B[CIT];
+#pragma unroll
+          for (int b = 0; b < CIT; ++b) B[b] = w2_frag<T>(I0 + kk * CIT * 1024, b, lane);
+#pragma unroll
+          for (int a = 0; a < COT; ++a)
+#pragma unroll
+            for (int b = 0; b < CIT; ++b) acc[kk][a][b] = M::mma(A[a], B[b], acc[kk][a][b]);
         }
-        w2_wave_sync();
-        typename M::frag B[CIT];
+      }
+      w2_wave_sync();  // the slice is rewritten at the top of the next trip
+    }
+  } else {
+    unsigned char* I[2] = {I0, I0 + CIT * 1024};
+    for (int64_t s = worker; s < steps_total; s += workers) {
+      int32_t idx[KG][CIT];
+      load_idx(s, idx);
+      uint4 pd[COT];
+      load_dout(s, pd);
+      store_dout(pd);
+      uint4 pre[CIT];
+      gather(idx[0], pre);
+      w2_wave_sync();
+      typename M::frag A[COT];
 #pragma unroll
-        for (int b = 0; b < CIT; ++b) B[b] = w2_frag<T>(buf, b, lane);
+      for (int a = 0; a < COT; ++a) A[a] = w2_frag<T>(D, a, lane);
+      if constexpr (KG == 1) {
+        if (do_bias) {
 #pragma unroll
-        for (int a = 0; a < COT; ++a)
+          for (int a = 0; a < COT; ++a) accb[a] = M::mma(A[a], ones, accb[a]);
+        }
+      }
 #pragma unroll
-          for (int b = 0; b < CIT; ++b) acc[kk][a][b] = M::mma(A[a], B[b], acc[kk][a][b]);
+      for (int kk = 0; kk < KG; ++kk) {
+        if (kk < nk) {
+          unsigned char* buf = I[kk & 1];
+          store_in(buf, pre);
+          if (kk + 1 < KG && kk + 1 < nk) gather(idx[(kk + 1) < KG ? (kk + 1) : 0], pre);  // next table row goes out first
+          w2_wave_sync();
+          typename M::frag B[CIT];
+#pragma unroll
+          for (int b = 0; b < CIT; ++b) B[b] = w2_frag<T>(buf, b, lane);
+#pragma unroll
+          for (int a = 0; a < COT; ++a)
+#pragma unroll
+            for (int b = 0; b < CIT; ++b) acc[kk][a][b] = M::mma(A[a], B[b], acc[kk][a][b]);
+        }
       }
     }
   }
@@ -215,15 +288,16 @@ static inline int w2_env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out) {
+static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out, bool want_bias = false) {
   static const int cot_max = w2_env_int("PTC_W2_COT_MAX", 4), cit_max = w2_env_int("PTC_W2_CIT_MAX", 4);  // tuning knobs
   W2Plan p;
   p.cit = c_in <= 16 ? 1 : (c_in <= 32 ? 2 : 4);
   p.cot = c_out <= 32 ? 2 : (c_out <= 64 ? 4 : (c_out <= 96 ? 6 : 8));
+  if (p.cit == 4 && p.cot > 4) p.cot = 4;   // 64x64 accumulators: the wider tiles spill under the 256-register cap
   if (p.cot > cot_max) p.cot = cot_max;
   if (p.cit > cit_max) p.cit = cit_max;
   p.kg = 1;
-  if (kv > 1) {  // instantiated groups (register budget: KG*COT*CIT*4 accumulators)
+  if (kv > 1 && !want_bias) {  // instantiated groups (register budget: KG*COT*CIT*4 accumulators)
     if (p.cot == 2 && p.cit == 1) p.kg = 16;
     else if (p.cot == 2 && p.cit == 2) p.kg = 9;
     else if (p.cot == 4 && p.cit == 2) p.kg = 4;
@@ -240,6 +314,7 @@ static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out) {
   if (gx > 512) gx = 512;
   if (gx < 1) gx = 1;
   p.gx = (int)gx;
-  p.lds = (size_t)4 * (p.cot + 2 * p.cit) * 1024;  // >= the 4*CIT KB of the final cross-wave sum
+  const bool pipe = p.kg * p.cot * p.cit * 4 + 4 * (p.cot + p.kg * p.cit) + 4 * (p.cot + p.cit) <= 208;   // = W2Pipe<cot,cit,kg>
+  p.lds = (size_t)4 * (p.cot + (pipe ? p.kg : 2) * p.cit) * 1024;  // >= the 4*CIT KB of the final cross-wave sum
   return p;
 }
