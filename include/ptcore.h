@@ -279,6 +279,27 @@ int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void* dout, cons
                         int max_seqlen, float softmax_scale, int dtype, void* dqkv,
                         void* workspace, size_t workspace_bytes, ptc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * I. Ends of the step.
+ * ptc_coord_max: out3[a] = max_i grid_coord[i][a] (0 for n == 0).  Replaces the reductions behind
+ *   `int(self.grid_coord.max() + 1).bit_length()` (pointcept/models/utils/structure.py:74) and
+ *   `torch.max(self.grid_coord, dim=0).values` (:136-138).  grid_coord [n,3] int64 / int32, >= 0.
+ * ptc_cross_entropy_*: nn.CrossEntropyLoss(ignore_index) of pointcept/models/losses/misc.py as called at
+ *   pointcept/models/default.py:78-84 on seg_logits [n, c] (`logits` may be a strided view: row_stride
+ *   in elements; dtype = ptc_dtype of the logits).
+ *   fwd: lse[n] fp32; partial[2*b], partial[2*b+1] = (sum of -log p[target], number of counted rows) of
+ *        workgroup b, b < ptc_cross_entropy_partials(n).  loss = sum(partial[::2]) / sum(partial[1::2]).
+ *   bwd: dlogits[i][j] = scale[0] * (softmax(logits[i])[j] - [j == target[i]]) for counted rows, else 0;
+ *        `scale` is a DEVICE scalar (= grad_loss / count).
+ * ------------------------------------------------------------------------------------------ */
+int ptc_coord_max(const void* grid_coord, int coord_is_i64, int64_t n, int64_t* out3, ptc_stream_t stream);
+int64_t ptc_cross_entropy_partials(int64_t n);
+int ptc_cross_entropy_fwd(const void* logits, int64_t row_stride, const int64_t* target, int64_t n, int c, int dtype,
+                          int64_t ignore_index, float* lse, float* partial, ptc_stream_t stream);
+int ptc_cross_entropy_bwd(const void* logits, int64_t row_stride, const int64_t* target, const float* lse,
+                          const float* scale, int64_t n, int c, int dtype, int64_t ignore_index, void* dlogits,
+                          int64_t drow_stride, ptc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,7 @@ HIP_SOURCES = [
     "spconv.hip",
     "norm.hip",
     "attention.hip",
+    "loss.hip",
 ]
 CXX_SOURCES = ["core.cpp"]
 PROBE_SOURCES = ["host_probe.cpp"]

@@ -193,6 +193,14 @@ __device__ __forceinline__ int at_unit(int n_units) {
   const int per_xcd = (n_units + 7) >> 3;
   return (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
 }
+// Small launches (deep stages: 256..1000 (sequence, head) units for 512 workgroup slots) are split
+// `qs` ways along the stationary side: part p of a unit owns tiles [p*per, (p+1)*per).  The parts of a
+// unit are consecutive workgroups (same XCD); each stages the whole other side again (64 KB, L2-hot).
+__host__ __device__ __forceinline__ int at_split(int n_units, int lp_max) {
+  int qs = 1;
+  while (qs < 4 && (long long)n_units * qs < 1024 && (lp_max >> 5) / (2 * qs) >= AT_WAVES) qs *= 2;
+  return qs;
+}
 
 // ================================================================================================
 // forward
@@ -200,14 +208,17 @@ __device__ __forceinline__ int at_unit(int n_units) {
 // LDS: K row-major [lp_max][16] | V^T [17][pitch] (row 16 = 1.0 for keys < L, else 0) | 8 floats (reduction)
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                int lp_max, int n_units, uint16_t* __restrict__ out, float* __restrict__ lse) {
+                int lp_max, int n_units, int qs, uint16_t* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int unit = at_unit(n_units);
-  if (unit >= n_units) return;
+  const int lunit = at_unit(n_units * qs);
+  if (lunit >= n_units * qs) return;
+  const int unit = lunit / qs, part = lunit - unit * qs;
   const int seq = unit / H, head = unit % H;
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
+  const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
+  if (t_lo >= n_tiles) return;
   const int pitch = lp_max + 8;
   unsigned char* Ksm = smem;                                   // [lp_max][16] row-major
   unsigned char* Vt = smem + (size_t)lp_max * 32;              // [17][pitch] transposed, keys permuted (vt_pos)
@@ -236,7 +247,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
   const int vstride = 64, voff = 32;                           // bytes per 32-key tile / per 16-key block
   const unsigned char* kbase = Ksm + rm_off(col, h2);
 
-  for (int qt = wave; qt < n_tiles; qt += AT_WAVES) {
+  for (int qt = t_lo + wave; qt < t_hi; qt += AT_WAVES) {
     const int q = qt * 32 + col;
     const s16x8 qf = ld_global_frag(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, q < L);
     float qn = 0.f;
@@ -390,14 +401,17 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                    const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                   int lp_max, int n_units, uint16_t* __restrict__ dqkv, float* __restrict__ delta) {
+                   int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, float* __restrict__ delta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int unit = at_unit(n_units);
-  if (unit >= n_units) return;
+  const int lunit = at_unit(n_units * qs);
+  if (lunit >= n_units * qs) return;
+  const int unit = lunit / qs, part = lunit - unit * qs;
   const int seq = unit / H, head = unit % H;
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
+  const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
+  if (t_lo >= n_tiles) return;
   unsigned char* Vsm = smem;
   unsigned char* Ksm = smem + (size_t)lp_max * 32;
   const int64_t rs = (int64_t)3 * H * 16;
@@ -411,7 +425,7 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
   const TrAddr ta = tr_addr(lane);
   const int rmo = rm_off(col, h2);
 
-  for (int qt = wave; qt < n_tiles; qt += AT_WAVES) {
+  for (int qt = t_lo + wave; qt < t_hi; qt += AT_WAVES) {
     const int q = qt * 32 + col;
     const bool qv = q < L;
     const s16x8 qf = ld_global_frag(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, qv);
@@ -465,14 +479,17 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                     const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                    int lp_max, int n_units, uint16_t* __restrict__ dqkv) {
+                    int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int unit = at_unit(n_units);
-  if (unit >= n_units) return;
+  const int lunit = at_unit(n_units * qs);
+  if (lunit >= n_units * qs) return;
+  const int unit = lunit / qs, part = lunit - unit * qs;
   const int seq = unit / H, head = unit % H;
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
+  const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
+  if (t_lo >= n_tiles) return;
   unsigned char* Qsm = smem;
   unsigned char* dOsm = smem + (size_t)lp_max * 32;
   uint2* aux = reinterpret_cast<uint2*>(smem + (size_t)lp_max * 64);
@@ -500,7 +517,7 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
   const s16x8 bS = make_frag(h2 == 0 ? m1 : 0u, 0u, 0u, 0u);
   const s16x8 bD = make_frag(0u, h2 == 0 ? m1 : 0u, 0u, 0u);
 
-  for (int kt = wave; kt < n_tiles; kt += AT_WAVES) {
+  for (int kt = t_lo + wave; kt < t_hi; kt += AT_WAVES) {
     const int key = kt * 32 + col;
     const s16x8 kf = ld_global_frag(qkv + qkv_off(a + key, 1, H, head) + h2 * 8, key < L);
     const s16x8 vf = ld_global_frag(qkv + qkv_off(a + key, 2, H, head) + h2 * 8, key < L);
@@ -567,7 +584,7 @@ static int check_common(const char* name, const void* qkv, const int32_t* cu, in
   PTC_REQUIRE(dtype == PTC_BF16, PTC_EUNSUPPORTED, "%s: only bf16 is implemented (the reference casts qkv to bf16, ptv3m1:209)", name);
   PTC_REQUIRE(n_seq >= 0 && total >= 0 && H >= 1, PTC_EINVAL, "%s: bad sizes", name);
   PTC_REQUIRE(max_seqlen >= 1 && max_seqlen <= AT_MAX_L, PTC_EUNSUPPORTED, "%s: max_seqlen=%d not in [1,%d]", name, max_seqlen, AT_MAX_L);
-  PTC_REQUIRE(n_seq * H < (1ll << 31), PTC_EUNSUPPORTED, "%s: grid too large", name);
+  PTC_REQUIRE(n_seq * H < (1ll << 29), PTC_EUNSUPPORTED, "%s: grid too large", name);
   PTC_REQUIRE(n_seq == 0 || (qkv && cu), PTC_EINVAL, "%s: null buffer", name);
   PTC_REQUIRE((uintptr_t)qkv % 16 == 0, PTC_EINVAL, "%s: qkv must be 16-byte aligned", name);
   return PTC_OK;
@@ -586,8 +603,9 @@ extern "C" int ptc_attn_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, i
   rc = allow_big_lds(attn_fwd_kernel, lds);
   if (rc != PTC_OK) return rc;
   const int n_units = (int)(n_seq * H);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(8 * ((n_units + 7) / 8))), dim3(AT_THREADS), lds, s, (const uint16_t*)qkv,
-                     cu_seqlens, H, softmax_scale, total, lp_max, n_units, (uint16_t*)out, lse);
+  const int qs = at_split(n_units, lp_max);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds, s, (const uint16_t*)qkv,
+                     cu_seqlens, H, softmax_scale, total, lp_max, n_units, qs, (uint16_t*)out, lse);
   PTC_CHECK_LAUNCH("attn_fwd_kernel");
   return PTC_OK;
 }
@@ -616,14 +634,15 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   rc = allow_big_lds(attn_bwd_dkv_kernel, dkv_lds_bytes(lp_max));
   if (rc != PTC_OK) return rc;
   const int n_units = (int)(n_seq * H);
-  const unsigned grid = (unsigned)(8 * ((n_units + 7) / 8));
+  const int qs = at_split(n_units, lp_max);
+  const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(grid), dim3(AT_THREADS), dq_lds_bytes(lp_max), s,
                      (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H,
-                     softmax_scale, total, lp_max, n_units, (uint16_t*)dqkv, delta);
+                     softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv, delta);
   PTC_CHECK_LAUNCH("attn_bwd_dq_kernel");
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(grid), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s,
                      (const uint16_t*)qkv, (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H,
-                     softmax_scale, total, lp_max, n_units, (uint16_t*)dqkv);
+                     softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv);
   PTC_CHECK_LAUNCH("attn_bwd_dkv_kernel");
   return PTC_OK;
 }

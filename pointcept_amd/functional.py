@@ -21,6 +21,43 @@ from . import ops
 from ._lib import PtcoreError
 
 
+# ------------------------------------------------------------------------------------------------
+# weight casts under autocast: ONE multi-tensor kernel per step instead of one cast kernel per layer
+# ------------------------------------------------------------------------------------------------
+# Every Linear / sparse-conv forward needs its fp32 master weight in the autocast dtype.  Casting at the
+# point of use cost ~190 launches of 5 us per step (profiles/r01_k: bfloat16_copy_kernel).  The cache keeps
+# one low-precision shadow per weight storage and, at the first miss after the optimizer step (version
+# counters moved), refreshes ALL shadows with a single torch._foreach_copy_.
+class _CastCache:
+    def __init__(self):
+        self.entries = {}   # (data_ptr, numel, dtype) -> [src alias (flat), shadow (flat), version]
+
+    def get(self, w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+        if w.dtype == dt:
+            return w
+        if not w.is_contiguous() or not w.is_cuda:
+            return w.to(dt)
+        key = (w.data_ptr(), w.numel(), dt)
+        e = self.entries.get(key)
+        if e is not None and e[2] == w._version:
+            return e[1].view(w.shape)
+        if e is None:
+            if len(self.entries) > 4096:
+                self.entries.clear()
+            src = w.detach().reshape(-1)
+            e = [src, torch.empty(w.numel(), dtype=dt, device=w.device), -1]
+            self.entries[key] = e
+        stale = [x for x in self.entries.values() if x[2] != x[0]._version]
+        with torch.no_grad():
+            torch._foreach_copy_([x[1] for x in stale], [x[0] for x in stale])
+        for x in stale:
+            x[2] = x[0]._version
+        return e[1].view(w.shape)
+
+
+_cast_cache = _CastCache()
+
+
 def _autocast_on() -> bool:
     return torch.is_autocast_enabled("cuda")
 
@@ -122,7 +159,7 @@ class _SparseConv(Function):
         dt = _autocast_dtype(feat)
         c_out, kv, c_in = weight.shape
         f = _pad_to(feat.to(dt), 1, 16).contiguous()
-        w = _pad_to(_pad_to(weight.to(dt), 2, 16), 0, 16).contiguous()
+        w = _pad_to(_pad_to(_cast_cache.get(weight, dt), 2, 16), 0, 16).contiguous()
         b = None if bias is None else _pad_to(bias.float(), 0, 16)
         out = ops.spconv_fwd(f, w, b, nbr)
         ctx.save_for_backward(f, w, nbr, nbr_t)
@@ -181,7 +218,7 @@ class _Linear(Function):
         dt = _autocast_dtype(x)
         c_out, c_in = weight.shape
         xp = _pad_to(x.to(dt), 1, 16).contiguous()
-        wp = _pad_to(_pad_to(weight.to(dt), 1, 16), 0, 16).contiguous()
+        wp = _pad_to(_pad_to(_cast_cache.get(weight, dt), 1, 16), 0, 16).contiguous()
         if tab_fwd is not None or dt == torch.float32 or _own_gemm(xp.shape[0], xp.shape[1], dt):
             bp = None if bias is None else _pad_to(bias.float(), 0, 16)
             out = ops.spconv_fwd(xp, wp[:, None, :], bp, tab_fwd)
@@ -342,3 +379,31 @@ def attn_varlen_qkvpacked(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqle
     if softmax_scale is None:
         softmax_scale = qkv.shape[-1] ** -0.5
     return _AttnVarlen.apply(qkv, cu_seqlens, int(max_seqlen), float(softmax_scale))
+
+
+# ------------------------------------------------------------------------------------------------
+# cross entropy
+# ------------------------------------------------------------------------------------------------
+class _CrossEntropy(Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        loss_sum, count, lse = ops.cross_entropy_fwd(logits, target, ignore_index)
+        ctx.save_for_backward(logits, target, lse, count)
+        ctx.ignore_index = ignore_index
+        return loss_sum / count          # nan when nothing is counted, as nn.CrossEntropyLoss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, target, lse, count = ctx.saved_tensors
+        d = ops.cross_entropy_bwd(logits, target, lse, g.float() / count, ctx.ignore_index)
+        return d, None, None
+
+
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = -1) -> torch.Tensor:
+    """nn.CrossEntropyLoss(ignore_index=ignore_index) (mean over counted points) on seg logits [N, C]
+    (pointcept/models/losses/misc.py, pointcept/models/default.py:78-84): one forward and one backward
+    kernel, fp32 log-sum-exp straight from the head's (bf16, possibly strided) output."""
+    if logits.dim() != 2:
+        raise PtcoreError("cross_entropy expects [N, C] logits")
+    return _CrossEntropy.apply(logits, target, int(ignore_index))

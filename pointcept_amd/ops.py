@@ -416,3 +416,55 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_sc
                                     int(max_seqlen), float(softmax_scale), _lib.PTC_BF16, ptr(dqkv), ptr(ws), nbytes,
                                     stream_ptr()), "ptc_attn_varlen_bwd")
     return dqkv
+
+
+# ------------------------------------------------------------------------------------------------
+# ends of the step: coordinate maxima, cross-entropy
+# ------------------------------------------------------------------------------------------------
+def coord_max(grid_coord: torch.Tensor) -> torch.Tensor:
+    """max over points of grid_coord per axis -> int64 [3] on the device (structure.py:74,136-138)."""
+    require_cuda(grid_coord)
+    if grid_coord.dtype not in (torch.int64, torch.int32) or grid_coord.dim() != 2 or grid_coord.shape[1] != 3:
+        raise PtcoreError("grid_coord must be int32/int64 [N,3]")
+    gc = grid_coord.contiguous()
+    out = torch.empty(3, dtype=torch.int64, device=gc.device)
+    check(lib().ptc_coord_max(ptr(gc), int(gc.dtype == torch.int64), gc.shape[0], ptr(out), stream_ptr()), "ptc_coord_max")
+    return out
+
+
+def _rows_view(t: torch.Tensor):
+    """[N, C] tensor whose rows are contiguous (any row stride) -> (tensor, row_stride)"""
+    if t.dim() != 2:
+        raise PtcoreError("expected [N, C]")
+    if t.shape[0] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+
+
+def cross_entropy_fwd(logits: torch.Tensor, target: torch.Tensor, ignore_index: int):
+    """-> (loss_sum [] fp32, count [] fp32, lse [N] fp32); loss = loss_sum / count (CrossEntropyLoss, mean)."""
+    require_cuda(logits, target)
+    if target.dtype != torch.int64:
+        raise PtcoreError("target must be int64")
+    lg, rs = _rows_view(logits)
+    n, c = lg.shape
+    nb = lib().ptc_cross_entropy_partials(n)
+    lse = torch.empty(n, dtype=torch.float32, device=lg.device)
+    partial = torch.empty((nb, 2), dtype=torch.float32, device=lg.device)
+    check(lib().ptc_cross_entropy_fwd(ptr(lg), rs, ptr(target.contiguous()), n, c, dtype_code(lg), int(ignore_index), ptr(lse),
+                                      ptr(partial), stream_ptr()), "ptc_cross_entropy_fwd")
+    tot = partial.sum(0)   # fixed-order tree reduction of <= N/256 partials: deterministic
+    return tot[0], tot[1], lse
+
+
+def cross_entropy_bwd(logits: torch.Tensor, target: torch.Tensor, lse: torch.Tensor, scale: torch.Tensor, ignore_index: int):
+    """dlogits [N, C] (logits' dtype) = scale * (softmax - onehot) on counted rows; `scale` device scalar fp32."""
+    require_cuda(logits, target, lse, scale)
+    lg, rs = _rows_view(logits)
+    n, c = lg.shape
+    out = torch.empty((n, c), dtype=lg.dtype, device=lg.device)
+    check(lib().ptc_cross_entropy_bwd(ptr(lg), rs, ptr(target.contiguous()), ptr(lse), ptr(scale.reshape(1).float().contiguous()),
+                                      n, c, dtype_code(lg), int(ignore_index), ptr(out), c, stream_ptr()), "ptc_cross_entropy_bwd")
+    return out

@@ -10,8 +10,8 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from . import functional as PF
 from . import nn as PNN
 from .structure import Point
 
@@ -24,7 +24,7 @@ class DefaultSegmentorV2(nn.Module):
         self.ignore_index = ignore_index
 
     def criteria(self, seg_logits, segment):
-        return F.cross_entropy(seg_logits.float(), segment, ignore_index=self.ignore_index)
+        return PF.cross_entropy(seg_logits, segment, self.ignore_index)   # GPU only, like every op of the engine
 
     def forward(self, input_dict, return_point=False):
         point = Point(input_dict)

@@ -99,7 +99,8 @@ class Point(_RefPoint if _RefPoint is not None else AttrDict):
                 assert {"grid_size", "coord"}.issubset(self.keys())
                 self["grid_coord"] = torch.div(self.coord - self.coord.min(0)[0], self.grid_size,
                                                rounding_mode="trunc").int()  # structure.py:68-70
-            packed = torch.cat([self.grid_coord.max(0).values.to(torch.int64), self.offset.to(torch.int64)])
+            cmax = ops.coord_max(self.grid_coord)
+            packed = torch.cat([cmax, self.offset.to(torch.int64)])
             host = packed.tolist()  # the single host sync (reference: structure.py:74,138,145 + ptv3m1:142-164)
             self["_ptc_coord_max"] = host[:3]
             self["_ptc_offset_host"] = host[3:]

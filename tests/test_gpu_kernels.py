@@ -571,3 +571,46 @@ def test_attention_large_logits(cuda):
     ref, ref_lse = oops.attention_varlen(qkv.float(), cu, 0.25, return_lse=True)
     _close("attn_fwd_peaked", out, ref, 1.0 / 64, 1e-2)
     _close("attn_lse_peaked", lse, ref_lse, 1e-3, 3e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+# I. ends of the step: coordinate maxima, cross entropy
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 63, 100000])
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+def test_coord_max(cuda, n, dtype):
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(n + 1)
+    gc = torch.randint(0, 60000, (n, 3), generator=g).to(dtype)
+    got = ops.coord_max(gc.to(cuda)).cpu()
+    ref = gc.max(0).values.to(torch.int64) if n else torch.zeros(3, dtype=torch.int64)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,c,strided", [(1, 20, False), (1000, 20, True), (70001, 16, False), (513, 13, True)])
+def test_cross_entropy_fwd_bwd(cuda, dtype, n, c, strided):
+    """CrossEntropyLoss(ignore_index=-1, mean) of pointcept/models/losses/misc.py: loss and gradient vs
+    torch on the same (rounded) logits in fp32; strided = a [:, :c] view of a wider head output."""
+    from pointcept_amd import functional as PF
+
+    g = torch.Generator().manual_seed(n * 31 + c)
+    wide = (torch.randn(n, 32, generator=g) * 3).to(dtype)
+    tgt = torch.randint(0, c, (n,), generator=g)
+    tgt[torch.rand(n, generator=g) < 0.1] = -1
+    if n == 1:
+        tgt[0] = 3
+    base = wide.to(cuda).requires_grad_(True)
+    logits = base[:, :c] if strided else base[:, :c].contiguous()
+    loss = PF.cross_entropy(logits, tgt.to(cuda), -1)
+    loss.backward()
+    ref_in = wide[:, :c].float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in, tgt, ignore_index=-1)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref)))
+    tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8 * float(ref_in.grad.abs().max())
+    _close("ce_grad", base.grad[:, :c], ref_in.grad, 1e-5 if dtype == torch.float32 else 2.0 ** -7, tol)
+    assert float(base.grad[:, c:].abs().max()) == 0.0
+    again = PF.cross_entropy(logits.detach(), tgt.to(cuda), -1)
+    assert float(again) == float(loss), "deterministic reduction"
