@@ -300,6 +300,30 @@ int ptc_cross_entropy_bwd(const void* logits, int64_t row_stride, const int64_t*
                           const float* scale, int64_t n, int c, int dtype, int64_t ignore_index, void* dlogits,
                           int64_t drow_stride, ptc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * J. BatchNorm1d over the rows of [n, c] features with the following activation fused:
+ *    y = act((x - mean) * rstd * gamma + beta),  act in {0 none, 1 GELU (erf), 2 ReLU}.
+ * Replaces `nn.BatchNorm1d(eps=1e-3, momentum=0.01)` + `nn.GELU()` of PTv3's Embedding / SerializedPooling /
+ * SerializedUnpooling (ptv3m1:485-515,371-444,447-482; norm built at :581) and BatchNorm1d + ReLU of
+ * SpUNet (spconv_unet_v1m1_base.py:49-68,110-121,137-146,173-181).  Per-GPU statistics (sync_bn = False).
+ *   training != 0 : batch statistics (biased variance for normalisation), running statistics updated as
+ *                   r = (1 - momentum) * r + momentum * stat (unbiased variance), both may be NULL;
+ *   training == 0 : running statistics are used.
+ *   save_mean / save_rstd [c] fp32 feed the backward, which RECOMPUTES the pre-activation from x:
+ *   dx (x's dtype), dgamma / dbeta [c] fp32 (may be NULL).  c % 8 == 0 (16-bit) or c % 4 == 0 (fp32),
+ *   c <= 2048 / 1024 (ptc_batch_norm_supported).  Reductions run in a fixed order: bit-reproducible.
+ * ------------------------------------------------------------------------------------------ */
+int ptc_batch_norm_supported(int c, int dtype);
+size_t ptc_batch_norm_workspace_bytes(int64_t n, int c);
+int ptc_batch_norm_act_fwd(const void* x, int64_t n, int c, int dtype, const float* gamma, const float* beta, float eps,
+                           float momentum, int training, float* running_mean, float* running_var, int act, void* y,
+                           int y_dtype, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                           ptc_stream_t stream);
+int ptc_batch_norm_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
+                           const float* save_mean, const float* save_rstd, int64_t n, int c, int training, int act,
+                           void* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                           ptc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,12 @@ _SIGNATURES = {
     "ptc_attn_varlen_bwd_workspace_bytes": (c_size, [c_i64, c_int]),
     "ptc_attn_varlen_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_f32, c_int, c_ptr,
                                     c_ptr, c_size, c_ptr]),
+    "ptc_batch_norm_supported": (c_int, [c_int, c_int]),
+    "ptc_batch_norm_workspace_bytes": (c_size, [c_i64, c_int]),
+    "ptc_batch_norm_act_fwd": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_f32, c_f32, c_int, c_ptr, c_ptr, c_int, c_ptr, c_int,
+                                       c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "ptc_batch_norm_act_bwd": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr,
+                                       c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_coord_max": (c_int, [c_ptr, c_int, c_i64, c_ptr, c_ptr]),
     "ptc_cross_entropy_partials": (c_i64, [c_i64]),
     "ptc_cross_entropy_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_i64, c_ptr, c_ptr, c_ptr]),

@@ -1,0 +1,426 @@
+// bn.hip -- BatchNorm1d over the rows of [N, C] point features with the following activation fused.
+//
+// Where the reference has `Linear/conv -> BatchNorm1d(eps=1e-3, momentum=0.01) -> GELU` (PTv3:
+// Embedding ptv3m1:485-515, SerializedPooling :371-444, SerializedUnpooling :447-482, norm built at :581)
+// or `conv -> BatchNorm1d -> ReLU` (SpUNet: spconv_unet_v1m1_base.py:49-68,110-121,137-146,173-181), ATen runs
+// six elementwise / reduction kernels per site and step (statistics, transform, activation; activation
+// backward, reduce, elementwise) and materialises the pre-activation.  Here:
+//   forward  : bn_reduce (one read of x -> per-workgroup (sum, sum of squares) partials) -> bn_finish (fp64
+//              sums in a fixed order, running statistics, per-channel scale / shift) -> bn_apply (y = act(x*a+b))
+//   backward : bn_bwd_reduce (x, dy -> sum dz, sum dz*xhat with dz = dy*act'(z), z RECOMPUTED from x)
+//              -> bn_bwd_finish -> bn_bwd_apply (dx = a*(dz - mean(dz) - xhat*mean(dz*xhat)))
+// 8 instead of 13 passes over [N, C], nothing saved but x, mean and rstd, fixed reduction order
+// (bit-reproducible), statistics in fp32/fp64 whatever the feature dtype.  Per-GPU statistics, as in
+// the reference (sync_bn = False).
+#include "ptc_common.h"
+
+#define BN_THREADS 256
+#define BN_MAX_GROUPS 1024
+enum { BN_ACT_NONE = 0, BN_ACT_GELU = 1, BN_ACT_RELU = 2 };
+
+template <typename T> struct BnVec;
+template <> struct BnVec<float> { static constexpr int V = 4; };
+template <> struct BnVec<bf16_t> { static constexpr int V = 8; };
+template <> struct BnVec<f16_t> { static constexpr int V = 8; };
+
+template <typename T>
+__device__ __forceinline__ void bn_load(const T* p, float (&v)[BnVec<T>::V]) {
+  constexpr int V = BnVec<T>::V;
+  const uint4 raw = *reinterpret_cast<const uint4*>(p);
+  T tmp[V];
+  __builtin_memcpy(tmp, &raw, 16);
+#pragma unroll
+  for (int j = 0; j < V; ++j) v[j] = ptc_to_float(tmp[j]);
+}
+template <typename T>
+__device__ __forceinline__ void bn_store(T* p, const float (&v)[BnVec<T>::V]) {
+  constexpr int V = BnVec<T>::V;
+  T tmp[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) tmp[j] = ptc_from_float<T>(v[j]);
+  uint4 raw;
+  __builtin_memcpy(&raw, tmp, 16);
+  *reinterpret_cast<uint4*>(p) = raw;
+}
+
+__device__ __forceinline__ float bn_act(float z, int act) {
+  if (act == BN_ACT_GELU) return 0.5f * z * (1.f + erff(z * 0.70710678118654752f));   // nn.GELU() (exact erf form)
+  if (act == BN_ACT_RELU) return z > 0.f ? z : 0.f;
+  return z;
+}
+__device__ __forceinline__ float bn_act_grad(float z, int act) {
+  if (act == BN_ACT_GELU)
+    return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+  if (act == BN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+// Row / column-group decomposition shared by all kernels: a thread owns V consecutive channels (16 bytes)
+// of rows r, r + rpi, ... ; cgs = C / V column groups, rpi = 256 / cgs rows per sweep.
+struct BnMap { int cgs, rpi; };
+template <typename T> __host__ __device__ __forceinline__ BnMap bn_map(int c) {
+  BnMap m;
+  m.cgs = c / BnVec<T>::V;
+  m.rpi = BN_THREADS / m.cgs;
+  return m;
+}
+
+// ---- per-channel two-value reduction over rows: workgroup partials --------------------------------
+// MODE 0: (sum x, sum x^2);  MODE 1: (sum dz, sum dz * xhat).  A thread adds <= ~100 values in fp32; the
+// <= 1024 workgroup partials are then summed in fp64 by the finish kernels.
+template <typename T, typename TD, int MODE>
+__global__ void __launch_bounds__(BN_THREADS)
+bn_reduce_kernel(const T* __restrict__ x, const TD* __restrict__ dy, const float* __restrict__ coef, int64_t n, int c,
+                 int act, int64_t rows_per_group, float* __restrict__ partial) {
+  constexpr int V = BnVec<T>::V;
+  __shared__ float red[BN_THREADS][2 * V + 1];
+  const BnMap m = bn_map<T>(c);
+  const int cg = threadIdx.x % m.cgs, r = threadIdx.x / m.cgs;
+  const int64_t row_lo = (int64_t)blockIdx.x * rows_per_group;
+  const int64_t row_hi = (row_lo + rows_per_group) < n ? (row_lo + rows_per_group) : n;
+  float s1[V], s2[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  float a[V], b[V], mu[V], rs[V];
+  if (MODE == 1 && r < m.rpi) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int ch = cg * V + j;
+      a[j] = coef[ch]; b[j] = coef[c + ch]; mu[j] = coef[2 * c + ch]; rs[j] = coef[3 * c + ch];
+    }
+  }
+  if (r < m.rpi) {
+    for (int64_t row = row_lo + r; row < row_hi; row += m.rpi) {
+      float xv[V];
+      bn_load<T>(x + row * c + cg * V, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s1[j] += xv[j]; s2[j] = fmaf(xv[j], xv[j], s2[j]); }
+      } else {
+        float dv[BnVec<T>::V];
+        if constexpr (sizeof(TD) == sizeof(T)) {
+          bn_load<TD>(dy + row * c + cg * V, dv);
+        } else {                                       // 16-bit x with fp32 dy (or the reverse): element loads
+#pragma unroll
+          for (int j = 0; j < V; ++j) dv[j] = ptc_to_float(dy[row * c + cg * V + j]);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float dz = dv[j] * bn_act_grad(fmaf(xv[j], a[j], b[j]), act);
+          s1[j] += dz;
+          s2[j] = fmaf(dz, (xv[j] - mu[j]) * rs[j], s2[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][V + j] = s2[j]; }
+  __syncthreads();
+  // thread t < C sums its channel over the rpi row slots in a fixed order
+  for (int ch = threadIdx.x; ch < c; ch += BN_THREADS) {
+    const int g = ch / V, j = ch % V;
+    float t1 = 0.f, t2 = 0.f;
+    for (int rr = 0; rr < m.rpi; ++rr) {
+      t1 += red[rr * m.cgs + g][j];
+      t2 += red[rr * m.cgs + g][V + j];
+    }
+    float* out = partial + ((int64_t)blockIdx.x * c + ch) * 2;
+    out[0] = t1;
+    out[1] = t2;
+  }
+}
+
+// Sum of the <= 1024 workgroup partials of one channel, in fp64 and in a fixed order.  A workgroup owns 16
+// channels; 16 "parts" of 16 lanes walk the groups with stride 16, 8 independent loads in flight per lane
+// (a single thread per channel walking all groups serially was latency-bound: 117 us per call, r01_p),
+// then the parts are combined through LDS by part 0.
+#define BN_FIN_CH 16
+__device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ partial, int groups, int c, double& s1, double& s2, int& ch) {
+  __shared__ double fin[BN_THREADS / BN_FIN_CH][BN_FIN_CH][2];
+  const int lc = threadIdx.x % BN_FIN_CH, part = threadIdx.x / BN_FIN_CH;
+  constexpr int PARTS = BN_THREADS / BN_FIN_CH;
+  ch = blockIdx.x * BN_FIN_CH + lc;
+  double a1[8], a2[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { a1[u] = 0.0; a2[u] = 0.0; }
+  if (ch < c) {
+    for (int g0 = part; g0 < groups; g0 += PARTS * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int g = g0 + u * PARTS;
+        if (g < groups) {
+          const float2 v = *reinterpret_cast<const float2*>(partial + ((int64_t)g * c + ch) * 2);
+          a1[u] += v.x;
+          a2[u] += v.y;
+        }
+      }
+    }
+  }
+  fin[part][lc][0] = ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
+  fin[part][lc][1] = ((a2[0] + a2[1]) + (a2[2] + a2[3])) + ((a2[4] + a2[5]) + (a2[6] + a2[7]));
+  __syncthreads();
+  if (part != 0 || ch >= c) return false;
+  s1 = 0.0; s2 = 0.0;
+  for (int p = 0; p < PARTS; ++p) { s1 += fin[p][lc][0]; s2 += fin[p][lc][1]; }
+  return true;
+}
+
+// coef layout (fp32, 4*C): [0,C) a = gamma*rstd | [C,2C) b = beta - mean*a | [2C,3C) mean | [3C,4C) rstd
+__global__ void __launch_bounds__(BN_THREADS)
+bn_finish_kernel(const float* __restrict__ partial, int groups, int64_t n, int c,
+                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, int training,
+                 float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ coef,
+                 float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+  double s1 = 0.0, s2 = 0.0;
+  int ch;
+  if (training) {
+    if (!bn_sum_partials(partial, groups, c, s1, s2, ch)) return;
+  } else {
+    ch = blockIdx.x * BN_FIN_CH + threadIdx.x;
+    if (threadIdx.x >= BN_FIN_CH || ch >= c) return;
+  }
+  double mean, var;
+  if (training) {
+    const double cnt = (double)n;
+    mean = s1 / cnt;
+    var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (running_mean) running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+    if (running_var) running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * (n > 1 ? var * cnt / (cnt - 1.0) : var));
+  } else {
+    mean = running_mean[ch];
+    var = running_var[ch];
+  }
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float a = (gamma ? gamma[ch] : 1.f) * rstd;
+  coef[ch] = a;
+  coef[c + ch] = (beta ? beta[ch] : 0.f) - (float)mean * a;
+  coef[2 * c + ch] = (float)mean;
+  coef[3 * c + ch] = rstd;
+  if (save_mean) save_mean[ch] = (float)mean;
+  if (save_rstd) save_rstd[ch] = rstd;
+}
+
+// Elementwise passes: a thread keeps ONE column group (its V channels' coefficients live in registers for the
+// whole kernel) and walks rows r, r + rows_per_sweep, ...  (The first version re-derived the column group per
+// element and re-loaded 6 coefficients per channel per element: 290 us for 819200 x 64, VALU/L1-bound.)
+template <typename T, typename TY>
+__global__ void __launch_bounds__(BN_THREADS)
+bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef, int64_t n, int c, int act, TY* __restrict__ y) {
+  constexpr int V = BnVec<T>::V;
+  const BnMap m = bn_map<T>(c);
+  const int cg = threadIdx.x % m.cgs, r = threadIdx.x / m.cgs;
+  if (r >= m.rpi) return;
+  float a[V], b[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { a[j] = coef[cg * V + j]; b[j] = coef[c + cg * V + j]; }
+  const int64_t sweep = (int64_t)gridDim.x * m.rpi;
+  for (int64_t row = (int64_t)blockIdx.x * m.rpi + r; row < n; row += sweep) {
+    const int64_t e = row * c + cg * V;
+    float xv[V];
+    bn_load<T>(x + e, xv);
+#pragma unroll
+    for (int j = 0; j < V; ++j) xv[j] = bn_act(fmaf(xv[j], a[j], b[j]), act);
+    if constexpr (sizeof(TY) == sizeof(T)) {
+      bn_store<TY>(reinterpret_cast<TY*>(y) + e, reinterpret_cast<const float(&)[BnVec<TY>::V]>(xv));
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) y[e + j] = ptc_from_float<TY>(xv[j]);
+    }
+  }
+}
+
+// bcoef (fp32, 2*C): [0,C) c1 = a*S1/N | [C,2C) c2 = a*S2/N  (both 0 when the statistics were not batch statistics)
+__global__ void __launch_bounds__(BN_THREADS)
+bn_bwd_finish_kernel(const float* __restrict__ partial, int groups, int64_t n, int c, const float* __restrict__ coef, int training,
+                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ bcoef) {
+  double s1, s2;
+  int ch;
+  if (!bn_sum_partials(partial, groups, c, s1, s2, ch)) return;
+  if (dgamma) dgamma[ch] = (float)s2;
+  if (dbeta) dbeta[ch] = (float)s1;
+  const double a = coef[ch];
+  bcoef[ch] = training ? (float)(a * s1 / (double)n) : 0.f;
+  bcoef[c + ch] = training ? (float)(a * s2 / (double)n) : 0.f;
+}
+
+template <typename T, typename TD>
+__global__ void __launch_bounds__(BN_THREADS)
+bn_bwd_apply_kernel(const T* __restrict__ x, const TD* __restrict__ dy, const float* __restrict__ coef, const float* __restrict__ bcoef,
+                    int64_t n, int c, int act, T* __restrict__ dx) {
+  constexpr int V = BnVec<T>::V;
+  const BnMap m = bn_map<T>(c);
+  const int cg = threadIdx.x % m.cgs, r = threadIdx.x / m.cgs;
+  if (r >= m.rpi) return;
+  float a[V], b[V], mu[V], rs[V], c1[V], c2[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int ch = cg * V + j;
+    a[j] = coef[ch]; b[j] = coef[c + ch]; mu[j] = coef[2 * c + ch]; rs[j] = coef[3 * c + ch];
+    c1[j] = bcoef[ch]; c2[j] = bcoef[c + ch];
+  }
+  const int64_t sweep = (int64_t)gridDim.x * m.rpi;
+  for (int64_t row = (int64_t)blockIdx.x * m.rpi + r; row < n; row += sweep) {
+    const int64_t e = row * c + cg * V;
+    float xv[V], dv[V];
+    bn_load<T>(x + e, xv);
+    if constexpr (sizeof(TD) == sizeof(T)) {
+      bn_load<TD>(dy + e, reinterpret_cast<float(&)[BnVec<TD>::V]>(dv));
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) dv[j] = ptc_to_float(dy[e + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float dz = dv[j] * bn_act_grad(fmaf(xv[j], a[j], b[j]), act);
+      const float xhat = (xv[j] - mu[j]) * rs[j];
+      xv[j] = a[j] * dz - c1[j] - xhat * c2[j];
+    }
+    bn_store<T>(dx + e, xv);
+  }
+}
+
+// a = gamma*rstd, b = beta - mean*a from the saved statistics (backward: same coef layout as forward)
+__global__ void __launch_bounds__(BN_THREADS)
+bn_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+               const float* __restrict__ rstd, int c, float* __restrict__ coef) {
+  for (int ch = blockIdx.x * BN_THREADS + threadIdx.x; ch < c; ch += gridDim.x * BN_THREADS) {
+    const float a = (gamma ? gamma[ch] : 1.f) * rstd[ch];
+    coef[ch] = a;
+    coef[c + ch] = (beta ? beta[ch] : 0.f) - mean[ch] * a;
+    coef[2 * c + ch] = mean[ch];
+    coef[3 * c + ch] = rstd[ch];
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+struct BnPlan { int groups; int64_t rows_per_group; };
+static BnPlan bn_plan(int64_t n, int rpi) {
+  BnPlan p;
+  int64_t g = ptc_cdiv(n, (int64_t)rpi * 8);            // >= 8 sweeps per workgroup
+  if (g > BN_MAX_GROUPS) g = BN_MAX_GROUPS;
+  if (g < 1) g = 1;
+  p.rows_per_group = ptc_cdiv(n, g);
+  p.groups = (int)ptc_cdiv(n, p.rows_per_group);
+  if (p.groups < 1) p.groups = 1;
+  return p;
+}
+
+extern "C" int ptc_batch_norm_supported(int c, int dtype) {
+  const int v = dtype == PTC_F32 ? 4 : 8;
+  return c >= v && c % v == 0 && c / v <= BN_THREADS;
+}
+
+// workspace: partial [BN_MAX_GROUPS][C][2] | coef [4C] | bcoef [2C]   (fp32)
+static size_t bn_partial_bytes(int c) { return ptc_align_up((size_t)BN_MAX_GROUPS * c * 2 * sizeof(float), 256); }
+extern "C" size_t ptc_batch_norm_workspace_bytes(int64_t n, int c) {
+  (void)n;
+  return bn_partial_bytes(c) + ptc_align_up((size_t)6 * c * sizeof(float), 256);
+}
+
+template <typename T, typename TY>
+static int bn_fwd_typed(const void* x, int64_t n, int c, const float* gamma, const float* beta, float eps, float momentum,
+                        int training, float* running_mean, float* running_var, int act, void* y, float* save_mean,
+                        float* save_rstd, char* ws, hipStream_t s) {
+  float* partial = (float*)ws;
+  float* coef = (float*)(ws + bn_partial_bytes(c));
+  const BnMap m = bn_map<T>(c);
+  const BnPlan p = bn_plan(n, m.rpi);
+  if (training) {
+    hipLaunchKernelGGL((bn_reduce_kernel<T, T, 0>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const T*)nullptr,
+                       (const float*)nullptr, n, c, act, p.rows_per_group, partial);
+    PTC_CHECK_LAUNCH("bn_reduce_kernel<stats>");
+  }
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)ptc_cdiv(c, BN_FIN_CH)), dim3(BN_THREADS), 0, s, partial, p.groups,
+                     n, c, gamma, beta, eps, momentum, training, running_mean, running_var, coef, save_mean, save_rstd);
+  PTC_CHECK_LAUNCH("bn_finish_kernel");
+  int64_t grid = ptc_cdiv(n, (int64_t)m.rpi * 4);        // >= 4 rows per thread
+  if (grid > 256 * 16) grid = 256 * 16;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, (const T*)x, coef, n, c, act, (TY*)y);
+  PTC_CHECK_LAUNCH("bn_apply_kernel");
+  return PTC_OK;
+}
+
+extern "C" int ptc_batch_norm_act_fwd(const void* x, int64_t n, int c, int dtype, const float* gamma, const float* beta, float eps,
+                                      float momentum, int training, float* running_mean, float* running_var, int act, void* y,
+                                      int y_dtype, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                                      ptc_stream_t stream) {
+  PTC_REQUIRE(n >= 0 && ptc_batch_norm_supported(c, dtype), PTC_EUNSUPPORTED, "ptc_batch_norm_act_fwd: n=%lld c=%d dtype=%d unsupported",
+              (long long)n, c, dtype);
+  PTC_REQUIRE(act >= 0 && act <= 2, PTC_EINVAL, "ptc_batch_norm_act_fwd: bad activation %d", act);
+  PTC_REQUIRE(training || (running_mean && running_var), PTC_EINVAL, "ptc_batch_norm_act_fwd: eval mode needs running statistics");
+  PTC_REQUIRE(y_dtype == dtype || y_dtype == PTC_F32 || dtype == PTC_F32, PTC_EUNSUPPORTED, "ptc_batch_norm_act_fwd: dtype pair");
+  if (n == 0) return PTC_OK;
+  PTC_REQUIRE(x && y && workspace, PTC_EINVAL, "ptc_batch_norm_act_fwd: null buffer");
+  PTC_REQUIRE(workspace_bytes >= ptc_batch_norm_workspace_bytes(n, c), PTC_EWORKSPACE, "ptc_batch_norm_act_fwd: workspace too small");
+  PTC_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), PTC_EINVAL, "ptc_batch_norm_act_fwd: buffers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+#define BN_FWD(T, TY) return bn_fwd_typed<T, TY>(x, n, c, gamma, beta, eps, momentum, training, running_mean, running_var, act, y, save_mean, save_rstd, ws, s)
+  if (dtype == PTC_F32 && y_dtype == PTC_F32) BN_FWD(float, float);
+  if (dtype == PTC_BF16 && y_dtype == PTC_BF16) BN_FWD(bf16_t, bf16_t);
+  if (dtype == PTC_F16 && y_dtype == PTC_F16) BN_FWD(f16_t, f16_t);
+  if (dtype == PTC_BF16 && y_dtype == PTC_F32) BN_FWD(bf16_t, float);
+  if (dtype == PTC_F16 && y_dtype == PTC_F32) BN_FWD(f16_t, float);
+  if (dtype == PTC_F32 && y_dtype == PTC_BF16) BN_FWD(float, bf16_t);
+  if (dtype == PTC_F32 && y_dtype == PTC_F16) BN_FWD(float, f16_t);
+#undef BN_FWD
+  ptc_set_error("ptc_batch_norm_act_fwd: unsupported dtype pair (%d, %d)", dtype, y_dtype);
+  return PTC_EUNSUPPORTED;
+}
+
+template <typename T, typename TD>
+static int bn_bwd_typed(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                        int64_t n, int c, int training, int act, void* dx, float* dgamma, float* dbeta, char* ws, hipStream_t s) {
+  float* partial = (float*)ws;
+  float* coef = (float*)(ws + bn_partial_bytes(c));
+  float* bcoef = coef + 4 * c;
+  const BnMap m = bn_map<T>(c);
+  const BnPlan p = bn_plan(n, m.rpi);
+  // rebuild coef = (a, b, mean, rstd) from the saved statistics
+  hipLaunchKernelGGL(bn_coef_kernel, dim3((unsigned)ptc_cdiv(c, BN_THREADS)), dim3(BN_THREADS), 0, s, gamma, beta, mean, rstd, c, coef);
+  PTC_CHECK_LAUNCH("bn_coef_kernel");
+  hipLaunchKernelGGL((bn_reduce_kernel<T, TD, 1>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, coef, n, c, act,
+                     p.rows_per_group, partial);
+  PTC_CHECK_LAUNCH("bn_reduce_kernel<bwd>");
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)ptc_cdiv(c, BN_FIN_CH)), dim3(BN_THREADS), 0, s, partial, p.groups, n, c, coef,
+                     training, dgamma, dbeta, bcoef);
+  PTC_CHECK_LAUNCH("bn_bwd_finish_kernel");
+  int64_t grid = ptc_cdiv(n, (int64_t)m.rpi * 4);
+  if (grid > 256 * 16) grid = 256 * 16;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TD>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, coef, bcoef, n, c,
+                     act, (T*)dx);
+  PTC_CHECK_LAUNCH("bn_bwd_apply_kernel");
+  return PTC_OK;
+}
+
+extern "C" int ptc_batch_norm_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
+                                      const float* save_mean, const float* save_rstd, int64_t n, int c, int training, int act,
+                                      void* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                      ptc_stream_t stream) {
+  PTC_REQUIRE(n >= 0 && ptc_batch_norm_supported(c, x_dtype), PTC_EUNSUPPORTED, "ptc_batch_norm_act_bwd: n=%lld c=%d dtype=%d unsupported",
+              (long long)n, c, x_dtype);
+  PTC_REQUIRE(act >= 0 && act <= 2, PTC_EINVAL, "ptc_batch_norm_act_bwd: bad activation %d", act);
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    if (dgamma) PTC_HIP(hipMemsetAsync(dgamma, 0, (size_t)c * sizeof(float), s));
+    if (dbeta) PTC_HIP(hipMemsetAsync(dbeta, 0, (size_t)c * sizeof(float), s));
+    return PTC_OK;
+  }
+  PTC_REQUIRE(dy && x && dx && save_mean && save_rstd && workspace, PTC_EINVAL, "ptc_batch_norm_act_bwd: null buffer");
+  PTC_REQUIRE(workspace_bytes >= ptc_batch_norm_workspace_bytes(n, c), PTC_EWORKSPACE, "ptc_batch_norm_act_bwd: workspace too small");
+  char* ws = (char*)workspace;
+#define BN_BWD(T, TD) return bn_bwd_typed<T, TD>(dy, x, gamma, beta, save_mean, save_rstd, n, c, training, act, dx, dgamma, dbeta, ws, s)
+  if (x_dtype == PTC_F32 && dy_dtype == PTC_F32) BN_BWD(float, float);
+  if (x_dtype == PTC_BF16 && dy_dtype == PTC_BF16) BN_BWD(bf16_t, bf16_t);
+  if (x_dtype == PTC_F16 && dy_dtype == PTC_F16) BN_BWD(f16_t, f16_t);
+  if (x_dtype == PTC_BF16 && dy_dtype == PTC_F32) BN_BWD(bf16_t, float);
+  if (x_dtype == PTC_F16 && dy_dtype == PTC_F32) BN_BWD(f16_t, float);
+  if (x_dtype == PTC_F32 && dy_dtype == PTC_BF16) BN_BWD(float, bf16_t);
+  if (x_dtype == PTC_F32 && dy_dtype == PTC_F16) BN_BWD(float, f16_t);
+#undef BN_BWD
+  ptc_set_error("ptc_batch_norm_act_bwd: unsupported dtype pair (%d, %d)", x_dtype, dy_dtype);
+  return PTC_EUNSUPPORTED;
+}

@@ -29,3 +29,9 @@ PTC_HD3 uint64_t ptc_vox_hash(uint64_t h) {
   h ^= h >> 33;
   return h;
 }
+
+// Home slot of a packed voxel key.  (A block-local variant -- hash the 4x4x4 block, add the position
+// inside it -- was tried for cache locality in r01: linear probing degenerates under such clustered homes,
+// E[run length] 3.3 -> 32 on the indoor scenes and the build / lookups got 4-6x SLOWER.  Locality comes
+// from the voxel-major lookup order in rulebook.hip instead.)
+PTC_HD3 uint64_t ptc_vox_home(uint64_t key) { return ptc_vox_hash(key); }

@@ -407,3 +407,32 @@ def cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int 
     if logits.dim() != 2:
         raise PtcoreError("cross_entropy expects [N, C] logits")
     return _CrossEntropy.apply(logits, target, int(ignore_index))
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm1d + activation
+# ------------------------------------------------------------------------------------------------
+class _BatchNormAct(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
+        y, mean, rstd = ops.batch_norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, act)
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        ctx.training, ctx.act = training, act
+        ctx.mark_non_differentiable()
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.batch_norm_act_bwd(dy, x, weight, bias, mean, rstd, ctx.training, ctx.act, want_affine=weight is not None)
+        if weight is not None:
+            dg, db = dg.to(weight.dtype), db.to(weight.dtype)
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, training: bool, momentum: float, eps: float,
+                   act: str = "none") -> torch.Tensor:
+    """act(F.batch_norm(x, ...)) over the rows of [N, C] (act in {"none", "gelu", "relu"}), statistics in
+    fp32/fp64, output in x's dtype; backward recomputes the pre-activation (nothing but x is saved)."""
+    return _BatchNormAct.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps), act)

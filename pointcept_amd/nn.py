@@ -53,3 +53,49 @@ class LayerNorm(nn.LayerNorm):
             return PF.layer_norm(x, self.weight, self.bias, self.eps, out_dtype)
         y = F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
         return y if out_dtype is None else y.to(out_dtype)
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d on [N, C] point features (ptv3m1:581; spconv_unet_v1m1_base.py:110) with the activation
+    that FOLLOWS it in the reference absorbed (`act`): the container marks the pair with `absorb_activations`,
+    the activation module stays in place (state-dict / module indices unchanged) and becomes a no-op."""
+    act = "none"
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        use = (config.OWN_NORM and x.is_cuda and x.dim() == 2 and x.shape[0] > 1 and ops.batch_norm_supported(x.shape[1], x.dtype)
+               and (self.training or self.running_mean is not None))
+        if not use:
+            y = super().forward(x)
+            return y if self.act == "none" else (F.gelu(y) if self.act == "gelu" else F.relu(y))
+        training = self.training or (self.running_mean is None and self.running_var is None)
+        momentum = 0.0 if self.momentum is None else self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            if self.momentum is None:   # cumulative moving average (host value needed: not used by the reference configs)
+                momentum = 1.0 / float(self.num_batches_tracked)
+        rm = self.running_mean if (not self.training or self.track_running_stats) else None
+        rv = self.running_var if (not self.training or self.track_running_stats) else None
+        return PF.batch_norm_act(x, self.weight, self.bias, rm, rv, training, momentum, self.eps, self.act)
+
+
+class GELU(nn.GELU):
+    absorbed = False  # True: the preceding BatchNorm1d applies it
+
+    def forward(self, x):
+        return x if self.absorbed else super().forward(x)
+
+
+class ReLU(nn.ReLU):
+    absorbed = False
+
+    def forward(self, x):
+        return x if self.absorbed else super().forward(x)
+
+
+def absorb_activations(modules) -> None:
+    """modules: the ORDERED children of a sequential container.  Marks every (BatchNorm1d, GELU|ReLU) pair."""
+    mods = list(modules)
+    for a, b in zip(mods[:-1], mods[1:]):
+        if isinstance(a, BatchNorm1d) and a.act == "none" and isinstance(b, (GELU, ReLU)) and not b.absorbed and config.OWN_NORM:
+            a.act = "gelu" if isinstance(b, GELU) else "relu"
+            b.absorbed = True

@@ -468,3 +468,57 @@ def cross_entropy_bwd(logits: torch.Tensor, target: torch.Tensor, lse: torch.Ten
     check(lib().ptc_cross_entropy_bwd(ptr(lg), rs, ptr(target.contiguous()), ptr(lse), ptr(scale.reshape(1).float().contiguous()),
                                       n, c, dtype_code(lg), int(ignore_index), ptr(out), c, stream_ptr()), "ptc_cross_entropy_bwd")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm1d + activation
+# ------------------------------------------------------------------------------------------------
+ACT_CODES = {"none": 0, "gelu": 1, "relu": 2}
+
+
+def batch_norm_supported(c: int, dtype: torch.dtype) -> bool:
+    if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        return False
+    code = {torch.float32: _lib.PTC_F32, torch.float16: _lib.PTC_F16, torch.bfloat16: _lib.PTC_BF16}[dtype]
+    return bool(lib().ptc_batch_norm_supported(int(c), code))
+
+
+def batch_norm_act_fwd(x, gamma, beta, running_mean, running_var, training: bool, momentum: float, eps: float, act: str,
+                       out_dtype: Optional[torch.dtype] = None):
+    """-> (y [N,C] out_dtype, save_mean [C] f32, save_rstd [C] f32); running statistics updated in place."""
+    require_cuda(x, gamma, beta, running_mean, running_var)
+    x = x.contiguous()
+    n, c = x.shape
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty((n, c), dtype=out_dtype, device=x.device)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    nbytes = lib().ptc_batch_norm_workspace_bytes(n, c)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    g = None if gamma is None else gamma.float().contiguous()
+    b = None if beta is None else beta.float().contiguous()
+    for t in (running_mean, running_var):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise PtcoreError("running statistics must be contiguous fp32")
+    check(lib().ptc_batch_norm_act_fwd(ptr(x), n, c, dtype_code(x), ptr(g), ptr(b), float(eps), float(momentum), int(bool(training)),
+                                       ptr(running_mean), ptr(running_var), ACT_CODES[act], ptr(y), dtype_code(y), ptr(mean),
+                                       ptr(rstd), ptr(ws), nbytes, stream_ptr()), "ptc_batch_norm_act_fwd")
+    return y, mean, rstd
+
+
+def batch_norm_act_bwd(dy, x, gamma, beta, mean, rstd, training: bool, act: str, want_affine: bool = True):
+    """-> (dx [N,C] x.dtype, dgamma [C] f32 | None, dbeta [C] f32 | None)"""
+    require_cuda(dy, x, mean, rstd)
+    dy = dy.contiguous()
+    n, c = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine else None
+    db = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine else None
+    nbytes = lib().ptc_batch_norm_workspace_bytes(n, c)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    g = None if gamma is None else gamma.float().contiguous()
+    b = None if beta is None else beta.float().contiguous()
+    check(lib().ptc_batch_norm_act_bwd(ptr(dy), dtype_code(dy), ptr(x), dtype_code(x), ptr(g), ptr(b), ptr(mean), ptr(rstd), n, c,
+                                       int(bool(training)), ACT_CODES[act], ptr(dx), ptr(dg), ptr(db), ptr(ws), nbytes, stream_ptr()),
+          "ptc_batch_norm_act_bwd")
+    return dx, dg, db

@@ -312,6 +312,8 @@ class SerializedPooling(PointModule):
             self.norm = PointSequential(norm_layer(out_channels))
         if act_layer is not None:
             self.act = PointSequential(act_layer())
+        if norm_layer is not None and act_layer is not None:   # norm and act run back to back at the end of forward
+            PNN.absorb_activations([self.norm[0], self.act[0]])
 
     def forward(self, point: Point):
         pooling_depth = (math.ceil(self.stride) - 1).bit_length()
@@ -374,6 +376,8 @@ class SerializedUnpooling(PointModule):
         if act_layer is not None:
             self.proj.add(act_layer())
             self.proj_skip.add(act_layer())
+        PNN.absorb_activations(self.proj._modules.values())
+        PNN.absorb_activations(self.proj_skip._modules.values())
         self.traceable = traceable
 
     def forward(self, point):
@@ -400,6 +404,7 @@ class Embedding(PointModule):
             self.stem.add(norm_layer(embed_channels), name="norm")
         if act_layer is not None:
             self.stem.add(act_layer(), name="act")
+        PNN.absorb_activations(self.stem._modules.values())
 
     def forward(self, point: Point):
         return self.stem(point)
@@ -427,9 +432,9 @@ class PointTransformerV3(PointModule):
         assert self.enc_mode or self.num_stages == len(dec_depths) + 1 == len(dec_channels) + 1
         assert self.enc_mode or self.num_stages == len(dec_num_head) + 1 == len(dec_patch_size) + 1
 
-        bn_layer = lambda c: nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)  # noqa: E731  (ptv3m1:581)
+        bn_layer = lambda c: PNN.BatchNorm1d(c, eps=1e-3, momentum=0.01)  # noqa: E731  (ptv3m1:581)
         ln_layer = PNN.LayerNorm
-        act_layer = nn.GELU
+        act_layer = PNN.GELU
         blk = dict(mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop,
                    norm_layer=ln_layer, act_layer=act_layer, pre_norm=pre_norm, enable_rpe=enable_rpe,
                    enable_flash=enable_flash, upcast_attention=upcast_attention, upcast_softmax=upcast_softmax)

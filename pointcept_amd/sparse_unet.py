@@ -16,6 +16,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from . import nn as PNN
 from . import spconv_api as spconv
 from .structure import offset2batch
 
@@ -40,6 +41,8 @@ class BasicBlock(spconv.SparseModule):
                                        indice_key=indice_key)
         self.bn1 = norm_fn(embed_channels)
         self.relu = nn.ReLU()
+        if isinstance(self.bn1, PNN.BatchNorm1d):
+            self.bn1.act = "relu"   # bn1 is always followed by self.relu (spconv_unet_v1m1_base.py:77): fused
         self.conv2 = spconv.SubMConv3d(embed_channels, embed_channels, kernel_size=3, stride=stride, padding=1,
                                        bias=bias, indice_key=indice_key)
         self.bn2 = norm_fn(embed_channels)
@@ -48,7 +51,8 @@ class BasicBlock(spconv.SparseModule):
     def forward(self, x):
         residual = x
         out = self.conv1(x)
-        out = out.replace_feature(self.relu(self.bn1(out.features)))
+        h = self.bn1(out.features)
+        out = out.replace_feature(h if getattr(self.bn1, "act", "none") == "relu" else self.relu(h))
         out = self.conv2(out)
         out = out.replace_feature(self.bn2(out.features))
         out = out.replace_feature(self.relu(out.features + self.proj(residual).features))
@@ -64,11 +68,12 @@ class SpUNetBase(nn.Module):
         self.channels, self.layers = channels, layers
         self.num_stages = len(layers) // 2
         self.enc_mode = enc_mode
-        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        norm_fn = partial(PNN.BatchNorm1d, eps=1e-3, momentum=0.01)
 
         self.conv_input = spconv.SparseSequential(
             spconv.SubMConv3d(in_channels, base_channels, kernel_size=5, padding=1, bias=False, indice_key="stem"),
-            norm_fn(base_channels), nn.ReLU())
+            norm_fn(base_channels), PNN.ReLU())
+        PNN.absorb_activations(self.conv_input._modules.values())
         enc_channels, dec_channels = base_channels, channels[-1]
         self.down, self.up, self.enc = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
         self.dec = nn.ModuleList() if not self.enc_mode else None
@@ -76,7 +81,8 @@ class SpUNetBase(nn.Module):
             self.down.append(spconv.SparseSequential(
                 spconv.SparseConv3d(enc_channels, channels[s], kernel_size=2, stride=2, bias=False,
                                     indice_key=f"spconv{s + 1}"),
-                norm_fn(channels[s]), nn.ReLU()))
+                norm_fn(channels[s]), PNN.ReLU()))
+            PNN.absorb_activations(self.down[-1]._modules.values())
             self.enc.append(spconv.SparseSequential(OrderedDict(
                 (f"block{i}", BasicBlock(channels[s], channels[s], norm_fn=norm_fn, indice_key=f"subm{s + 1}"))
                 for i in range(layers[s]))))
@@ -84,7 +90,8 @@ class SpUNetBase(nn.Module):
                 self.up.append(spconv.SparseSequential(
                     spconv.SparseInverseConv3d(channels[len(channels) - s - 2], dec_channels, kernel_size=2, bias=False,
                                                indice_key=f"spconv{s + 1}"),
-                    norm_fn(dec_channels), nn.ReLU()))
+                    norm_fn(dec_channels), PNN.ReLU()))
+                PNN.absorb_activations(self.up[-1]._modules.values())
                 self.dec.append(spconv.SparseSequential(OrderedDict(
                     (f"block{i}", BasicBlock(dec_channels + enc_channels if i == 0 else dec_channels, dec_channels,
                                              norm_fn=norm_fn, indice_key=f"subm{s}"))

@@ -614,3 +614,66 @@ def test_cross_entropy_fwd_bwd(cuda, dtype, n, c, strided):
     assert float(base.grad[:, c:].abs().max()) == 0.0
     again = PF.cross_entropy(logits.detach(), tgt.to(cuda), -1)
     assert float(again) == float(loss), "deterministic reduction"
+
+
+# ------------------------------------------------------------------------------------------------
+# J. BatchNorm1d + activation
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,c", [(2, 32), (1000, 32), (70001, 64), (513, 96), (4097, 512)])
+@pytest.mark.parametrize("act", ["none", "gelu", "relu"])
+def test_batch_norm_act_train(cuda, dtype, n, c, act):
+    """training mode: output, running statistics, dx / dgamma / dbeta vs torch (fp32 on the same rounded input)"""
+    from pointcept_amd import functional as PF
+
+    g = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, c, generator=g) * 2 + 0.7).to(dtype)
+    w = torch.rand(c, generator=g) + 0.5
+    b = torch.randn(c, generator=g) * 0.3
+    dy = torch.randn(n, c, generator=g).to(dtype)
+    rm0, rv0 = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    fn = {"none": lambda t: t, "gelu": torch.nn.functional.gelu, "relu": torch.relu}[act]
+    xr, wr, br = x.float().clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    ref = fn(torch.nn.functional.batch_norm(xr, rm, rv, wr, br, True, 0.01, 1e-3))
+    ref.backward(dy.float())
+    xg, wg, bg = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    rmg, rvg = rm0.to(cuda), rv0.to(cuda)
+    got = PF.batch_norm_act(xg, wg, bg, rmg, rvg, True, 0.01, 1e-3, act)
+    got.backward(dy.to(cuda))
+    assert got.dtype == dtype
+    lo = dtype == torch.bfloat16
+    _close("bn_y", got, ref, 2.0 ** -7 if lo else 2e-5, 2e-2 if lo else 2e-5)
+    _close("bn_running_mean", rmg, rm, 1e-5, 1e-5)
+    _close("bn_running_var", rvg, rv, 1e-5, 1e-5)
+    gmax = float(xr.grad.abs().max())
+    _close("bn_dx", xg.grad, xr.grad, 2.0 ** -6 if lo else 1e-4, (2e-2 if lo else 1e-4) * max(gmax, 1e-3))
+    _close("bn_dgamma", wg.grad, wr.grad, 1e-3, 1e-3 * float(wr.grad.abs().max()) + 1e-4)
+    _close("bn_dbeta", bg.grad, br.grad, 1e-3, 1e-3 * float(br.grad.abs().max()) + 1e-4)
+    again = PF.batch_norm_act(x.to(cuda), w.to(cuda), b.to(cuda), rm0.to(cuda), rv0.to(cuda), True, 0.01, 1e-3, act)
+    assert torch.equal(again, got.detach()), "bit-reproducible"
+
+
+def test_batch_norm_act_eval_and_module(cuda):
+    """eval mode uses the running statistics; the nn.Module wrapper keeps nn.BatchNorm1d's state dict."""
+    from pointcept_amd import nn as PNN
+
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.BatchNorm1d(64, eps=1e-3, momentum=0.01), torch.nn.GELU())
+    eng = torch.nn.Sequential(PNN.BatchNorm1d(64, eps=1e-3, momentum=0.01), PNN.GELU())
+    PNN.absorb_activations(eng._modules.values())
+    assert eng[0].act == "gelu" and eng[1].absorbed
+    with torch.no_grad():
+        ref[0].weight.uniform_(0.5, 1.5); ref[0].bias.normal_()
+    assert set(eng.state_dict()) == set(ref.state_dict())
+    eng.load_state_dict(ref.state_dict())
+    eng = eng.to(cuda)
+    x = torch.randn(3000, 64) * 1.5 + 0.2
+    for _ in range(3):   # training steps move the running statistics identically
+        yr, ye = ref(x), eng(x.to(cuda))
+        _close("bn_module_train", ye, yr, 2e-5, 2e-5)
+    assert int(eng[0].num_batches_tracked) == int(ref[0].num_batches_tracked) == 3
+    _close("bn_module_rm", eng[0].running_mean, ref[0].running_mean, 1e-5, 1e-6)
+    _close("bn_module_rv", eng[0].running_var, ref[0].running_var, 1e-5, 1e-6)
+    ref.eval(); eng.eval()
+    _close("bn_module_eval", eng(x.to(cuda)), ref(x), 2e-5, 2e-5)

@@ -170,8 +170,14 @@ def bench_spconv_stages(rows, results, scenes=8, points=102400):
         cc, bb = cc[order[0]], bb[order[0]]
         ind = torch.cat([bb[:, None].int(), cc.int()], 1).contiguous()
         n = ind.shape[0]
-        nbr = ops.rulebook_subm(ind, 3, ops.HashTable(ind))
+        table = ops.HashTable(ind)
+        nbr = ops.rulebook_subm(ind, 3, table)
         pairs = int((nbr >= 0).sum())
+        t_h = timeit(lambda: ops.HashTable(ind), iters=5)
+        t_3 = timeit(lambda: ops.rulebook_subm(ind, 3, table), iters=5)
+        t_5 = timeit(lambda: ops.rulebook_subm(ind, 5, table), iters=5) if s == 0 else 0.0
+        rows.append(f"rulebook stage {s} n={n:7d} (curve order): hash {t_h * 1e6:7.1f} us | k3 {t_3 * 1e6:7.1f} us "
+                    f"({27 * n * 4 / t_3 / 1e9:.0f} GB/s table out) | k5 {t_5 * 1e6:7.1f} us")
         for c in chans:
             x = torch.randn(n, c, device=DEV).to(torch.bfloat16)
             w = (torch.randn(c, 27, c, device=DEV) * 0.05).to(torch.bfloat16)
