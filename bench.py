@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
     ap.add_argument("--points", type=int, default=102400, help="voxels per scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="ptv3", choices=["ptv3", "spunet"],
+                    help="ptv3 = BASELINE.json metric (configs[2]); spunet = configs[1] (SpUNet-v1m1, 100000 voxels/scene), "
+                         "reported with its own metric name")
     ap.add_argument("--cpu-sample-points", type=int, default=20480)
     return ap.parse_args()
 
@@ -111,6 +114,63 @@ def cpu_baseline(sample_points: int, scene_points: int):
                       f"scaled by voxels to {scene_points}-voxel scenes"}
 
 
+def main_spunet(args, rank, local_rank, world, device):
+    """BASELINE configs[1]: SpUNet-v1m1 (configs/scannet/semseg-spunet-v1m1-0-base.py:12-18), batch 8 x 100000 voxels,
+    CE loss, SGD(momentum 0.9, nesterov) as at :36, bf16 autocast (the reference runs fp16 AMP)."""
+    import torch.nn.functional as F
+
+    from pointcept_amd import functional as PF
+    from pointcept_amd import synthetic
+    from pointcept_amd.sparse_unet import SpUNetBase
+
+    points = 100000 if args.points == 102400 else args.points
+    model = SpUNetBase(6, 20, channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2)).to(device).train()
+    n_params = sum(p.numel() for p in model.parameters())
+    step_model = model
+    if world > 1:
+        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    batch = synthetic.to_torch(synthetic.indoor_batch(args.batch, points, rank=rank), device)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = step_model(dict(batch))
+            loss = PF.cross_entropy(logits, batch["segment"], -1)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "scenes/sec (fwd+bwd+optimizer) SpUNet-v1m1 ScanNet-semseg @ 100k voxels", "value": round(args.batch * world * args.steps / dt, 4),
+            "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"SpUNet-v1m1 (39.2M params) + CE, fwd+bwd+SGD, {args.batch} scenes x {points} voxels per GPU",
+                       "global_batch": args.batch * world, "params": n_params, "parallelism": f"dp{world}",
+                       "final_loss": round(float(loss.detach()), 4)}}), flush=True)
+    if world > 1:
+        torch.distributed.barrier(device_ids=[local_rank])
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -134,6 +194,8 @@ def main():
     from pointcept_amd.segmentor import DefaultSegmentorV2
 
     torch.manual_seed(1234)  # identical initial weights on every rank
+    if args.model == "spunet":
+        return main_spunet(args, rank, local_rank, world, device)
     model = DefaultSegmentorV2(20, 64, PointTransformerV3(**PTV3_BASE)).to(device).train()
     n_params = sum(p.numel() for p in model.parameters())
     step_model = model

@@ -1,6 +1,6 @@
 // conv3.h -- third-generation forward / dgrad kernel of the gather-table convolution for 16-bit
-// features with c_in in {32, 64, 128, 256, 512, ...} and c_out % 64 == 0 (every CPE convolution of
-// PTv3 and every 3x3x3 / 2x2x2 convolution of SpUNet beyond the stem).  Included by spconv.hip.
+// features with c_in % 32 == 0 and c_out % 32 == 0 (every CPE convolution of PTv3, the gather-fused
+// qkv backward, and every 3x3x3 / 2x2x2 convolution of SpUNet beyond the stem).  Included by spconv.hip.
 //
 // What was wrong with conv2 (profiles/r01_d): it restaged W through LDS once per table row, between two
 // workgroup barriers, with an index computation (two integer divisions) per 16-byte vector and with
@@ -29,15 +29,15 @@
 
 #define C3_FRAG 1024
 #define C3_FPAD 64
-#define C3_BUF (16 * (C3_FRAG + C3_FPAD))   // one W chunk: 4 tiles x 4 steps
+#define C3_BUF(NTILES) (4 * (NTILES) * (C3_FRAG + C3_FPAD))   // one W chunk: NTILES tiles x 4 steps
 
-template <typename T, int RT, int KPC>
+template <typename T, int RT, int KPC, int NTILES>
 __global__ void __launch_bounds__(256, 2)
 conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
              const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int n_rowblk, T* __restrict__ out) {
   using M = Mma<T>;
   using frag = typename M::frag;
-  constexpr int NTILES = 4, NT = 64, BM = RT * 64;
+  constexpr int NT = NTILES * 16, BM = RT * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ny = c_out / NT;
   const int nblk = n_rowblk * ny;
@@ -53,21 +53,24 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 
   // ---- W staging: thread -> (weight row, step); 4 x 16 B per chunk
   const int wrow = threadIdx.x >> 2, qd = threadIdx.x & 3;
-  const T* wsrc = w + (int64_t)(n0 + wrow) * KV + qd * 32;
-  const int prow = lds_row_of_channel<NTILES>(wrow);
+  const T* wsrc = w + (int64_t)(n0 + (wrow < NT ? wrow : 0)) * KV + qd * 32;
+  const int prow = lds_row_of_channel<NTILES>(wrow < NT ? wrow : 0);
   const int wdst = ((prow >> 4) * 4 + qd) * (C3_FRAG + C3_FPAD) + (prow & 15) * 16;
   uint4 wreg[4];
+  const bool wthread = wrow < NT;   // NT = 32: half of the threads stage W
   auto wload = [&](int c) {
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       uint4 v = {0, 0, 0, 0};
-      if (c * 128 + qd * 32 + gq * 8 < KV) v = *reinterpret_cast<const uint4*>(wsrc + c * 128 + gq * 8);
+      if (wthread && c * 128 + qd * 32 + gq * 8 < KV) v = *reinterpret_cast<const uint4*>(wsrc + c * 128 + gq * 8);
       wreg[gq] = v;
     }
   };
   auto wstore = [&](int buf) {
+    if (wthread) {
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<uint4*>(smem + buf * C3_BUF + wdst + gq * 256) = wreg[gq];
+      for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<uint4*>(smem + buf * C3_BUF(NTILES) + wdst + gq * 256) = wreg[gq];
+    }
   };
 
   // ---- gather ring
@@ -75,9 +78,10 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   bool anyv[4][RT];
   int32_t idxN[KPC][RT], idxNN[KPC][RT];
   auto load_idx = [&](int c, int32_t (&ix)[KPC][RT]) {
+    const int kfirst = (c * 128) / c_in;             // first table row touched by chunk c
 #pragma unroll
     for (int kk = 0; kk < KPC; ++kk) {
-      const int k = KPC > 1 ? c * KPC + kk : (c * 128) / c_in;
+      const int k = kfirst + kk;
 #pragma unroll
       for (int j = 0; j < RT; ++j) {
         const int64_t row = row0 + j * 16 + r;
@@ -86,11 +90,15 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
     }
   };
   auto issue = [&](int c, int s, const int32_t (&ix)[KPC][RT]) {
-    const int kk = (s * KPC) >> 2;
-    const int cbase = (c * 128 + s * 32) % c_in + g * 8;
+    const int v0 = c * 128 + s * 32;                 // flattened contraction index of this step
+    const int k = v0 / c_in;
+    const int kk = KPC > 1 ? k - (c * 128) / c_in : 0;
+    const int cbase = v0 - k * c_in + g * 8;
 #pragma unroll
     for (int j = 0; j < RT; ++j) {
-      const int32_t i = ix[kk][j];
+      int32_t i = ix[0][j];
+#pragma unroll
+      for (int q = 1; q < KPC; ++q) i = kk == q ? ix[q][j] : i;   // static indexing: no scratch
       frag f = M::zero();
       if (i >= 0) f = ld_frag<T>(in + (int64_t)i * c_in + cbase);
       ga[s][j] = f;
@@ -120,7 +128,7 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 
 #pragma unroll 1
   for (int c = 0; c < nchunks; ++c) {
-    const unsigned char* wb = smem + (c & 1) * C3_BUF + lane * 16;
+    const unsigned char* wb = smem + (c & 1) * C3_BUF(NTILES) + lane * 16;
     load_idx(c + 2, idxNN);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -154,17 +162,16 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 
 static inline bool conv3_supported(int dtype, int kv, int c_in, int c_out, const int32_t* nbr) {
   if (dtype == PTC_F32 || nbr == nullptr || kv < 2) return false;
-  if (c_out % 64 != 0 || c_in % 32 != 0) return false;
-  return c_in == 32 || c_in == 64 || c_in % 128 == 0;
+  return c_out % 32 == 0 && c_in % 32 == 0;
 }
 
-template <typename T, int RT, int KPC>
+template <typename T, int RT, int KPC, int NTILES>
 static int launch_conv3_i(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
                           int c_out, void* out, hipStream_t s) {
   const int n_rowblk = (int)ptc_cdiv(n_out, RT * 64);
-  const int nblk = n_rowblk * (c_out / 64);
-  const size_t lds = 2 * C3_BUF;
-  auto kern = conv3_kernel<T, RT, KPC>;
+  const int nblk = n_rowblk * (c_out / (NTILES * 16));
+  const size_t lds = 2 * C3_BUF(NTILES);
+  auto kern = conv3_kernel<T, RT, KPC, NTILES>;
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv,
                      c_in, c_out, n_rowblk, (T*)out);
   PTC_CHECK_LAUNCH("conv3_kernel");
@@ -174,19 +181,22 @@ static int launch_conv3_i(const void* in, const void* w, const float* bias, cons
 template <typename T>
 static int launch_conv3(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
                         int c_out, void* out, hipStream_t s) {
-  // 256-row workgroups when they still give every CU two workgroups, else 128-row ones
+  // 64 output channels per workgroup (32 when c_out is not a multiple of 64); 256-row workgroups when they
+  // still give every CU two workgroups, else 128-row ones
   // (PTC_CONV3_RT=2|4 forces the choice: used by the tests to reach both instantiations at small n)
-  bool big = ptc_cdiv(n_out, 256) * (c_out / 64) >= 512;
+  const int nt = c_out % 64 == 0 ? 4 : 2;
+  bool big = ptc_cdiv(n_out, 256) * (c_out / (nt * 16)) >= 512;
   if (const char* e = getenv("PTC_CONV3_RT")) {
     if (atoi(e) == 4) big = true;
     if (atoi(e) == 2) big = false;
   }
-  const int kpc = c_in >= 128 ? 1 : 128 / c_in;
-#define C3_CASE(K)                                                                                          \
-  if (kpc == K) return big ? launch_conv3_i<T, 4, K>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s)      \
-                           : launch_conv3_i<T, 2, K>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
-  C3_CASE(1) C3_CASE(2) C3_CASE(4)
+  // table rows one 128-wide chunk can touch: 1 (c_in % 128 == 0), 4 (c_in = 32), else 2
+  const int kpc = c_in % 128 == 0 ? 1 : (c_in == 32 ? 4 : 2);
+#define C3_CASE(K, N)                                                                                          \
+  if (kpc == K && nt == N) return big ? launch_conv3_i<T, 4, K, N>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s) \
+                                      : launch_conv3_i<T, 2, K, N>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  C3_CASE(1, 4) C3_CASE(2, 4) C3_CASE(4, 4) C3_CASE(1, 2) C3_CASE(2, 2) C3_CASE(4, 2)
 #undef C3_CASE
-  ptc_set_error("conv3: c_in=%d unsupported", c_in);
+  ptc_set_error("conv3: c_in=%d c_out=%d unsupported", c_in, c_out);
   return PTC_EUNSUPPORTED;
 }

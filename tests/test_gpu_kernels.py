@@ -300,7 +300,8 @@ def test_spconv_fwd_and_wgrad(cuda, dtype, cin, cout, ksize):
 
 @pytest.mark.parametrize("rt", ["2", "4"])
 @pytest.mark.parametrize("cin,cout,ksize", [(32, 64, 3), (64, 64, 3), (64, 128, 3), (128, 128, 3), (256, 64, 3), (512, 128, 3),
-                                            (64, 128, 2), (128, 64, 5)])
+                                            (64, 128, 2), (128, 64, 5), (32, 32, 3), (96, 96, 3), (128, 96, 3), (160, 32, 3),
+                                            (192, 64, 2)])
 def test_spconv_fwd_chunked_pipeline(cuda, cin, cout, ksize, rt, monkeypatch):
     """conv3 (double-buffered W chunks, fragment-order LDS, gather ring): every chunking case
     (4 / 2 / 1 table rows per 128-channel chunk, multi-chunk rows, partial last chunk), both workgroup

@@ -105,26 +105,29 @@ __global__ void __launch_bounds__(1024) mix_probe(float* out, uint64_t* cycles, 
   float r[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) r[i] = seed + 0.001f * (threadIdx.x + i);
-  f32x16 a0, a1;
+  f32x16 a0, a1, a2;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+  for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; a2[i] = 0.f; }
   s16x8 fa = {0x3c00, 0x3c01, 0x3c02, 0x3c03, 0x3c04, 0x3c05, 0x3c06, 0x3c07}, fb = {0x3c08, 0x3c07, 0x3c06, 0x3c05, 0x3c04, 0x3c03, 0x3c02, 0x3c01};
+  constexpr int G = NM > 0 ? NM : 4;          // instruction groups per trip
   const uint64_t t0 = __builtin_readcyclecounter();
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < G; ++m) {
       if (m < NM) {
-        if (m < 2) a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, a0, 0, 0, 0);
-        else a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, a1, 0, 0, 0);
+        if (m % 3 == 0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, a0, 0, 0, 0);
+        else if (m % 3 == 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, a1, 0, 0, 0);
+        else a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, a2, 0, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < NE / 4; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(r[(m * (NE / 4) + i) & 15]));
+      for (int i = (NE * m) / G; i < (NE * (m + 1)) / G; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i & 15]));
 #pragma unroll
-      for (int i = 0; i < NC / 4; ++i) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(r[(m * 2 + i) & 15]) : "v"(r[(m * 2 + i + 8) & 15]));
+      for (int i = (NC * m) / G; i < (NC * (m + 1)) / G; ++i)
+        asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(r[i & 15]) : "v"(r[(i + 8) & 15]));
     }
   }
   const uint64_t t1 = __builtin_readcyclecounter();
-  float s = a0[0] + a1[0];
+  float s = a0[0] + a1[0] + a2[0];
 #pragma unroll
   for (int i = 0; i < 16; ++i) s += r[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -232,6 +235,12 @@ int main() {
   run_mix<8, 8, 4>("4 mfma + 8 exp + 8 cvt", fo, cyc);
   run_mix<16, 8, 3>("3 mfma + 16 exp + 8 cvt", fo, cyc);
   run_mix<0, 8, 4>("4 mfma + 8 cvt", fo, cyc);
+  run_mix<0, 16, 4>("4 mfma + 16 plain", fo, cyc);
+  run_mix<0, 32, 4>("4 mfma + 32 plain", fo, cyc);
+  run_mix<16, 24, 5>("5 mfma + 16 exp + 24 plain (dQ)", fo, cyc);
+  run_mix<16, 48, 9>("9 mfma + 16 exp + 48 plain (dKV)", fo, cyc);
+  run_mix<16, 40, 11>("11 mfma + 16 exp + 40 plain (1pass)", fo, cyc);
+  run_mix<8, 8, 2>("2 mfma + 8 exp + 8 cvt", fo, cyc);
   int clk = 0;
   CK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0));
   printf("device clock rate attribute: %d kHz\n", clk);
