@@ -51,26 +51,39 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   const int KV = kv * c_in;
   const int nchunks = (KV + 127) >> 7;
 
-  // ---- W staging: thread -> (weight row, step); 4 x 16 B per chunk
-  const int wrow = threadIdx.x >> 2, qd = threadIdx.x & 3;
-  const T* wsrc = w + (int64_t)(n0 + (wrow < NT ? wrow : 0)) * KV + qd * 32;
-  const int prow = lds_row_of_channel<NTILES>(wrow < NT ? wrow : 0);
-  const int wdst = ((prow >> 4) * 4 + qd) * (C3_FRAG + C3_FPAD) + (prow & 15) * 16;
-  uint4 wreg[4];
-  const bool wthread = wrow < NT;   // NT = 32: half of the threads stage W
+  // ---- W staging: thread -> (weight row, step); 4 x 16 B per chunk and pass (NT = 96: two passes of 64 rows)
+  constexpr int WP = (NT + 63) / 64;
+  const int qd = threadIdx.x & 3;
+  const T* wsrc[WP];
+  int wdst[WP];
+  bool wthread[WP];
+#pragma unroll
+  for (int ps = 0; ps < WP; ++ps) {
+    const int wrow = ps * 64 + (threadIdx.x >> 2);
+    wthread[ps] = wrow < NT;
+    const int wr = wthread[ps] ? wrow : 0;
+    wsrc[ps] = w + (int64_t)(n0 + wr) * KV + qd * 32;
+    const int prow = lds_row_of_channel<NTILES>(wr);
+    wdst[ps] = ((prow >> 4) * 4 + qd) * (C3_FRAG + C3_FPAD) + (prow & 15) * 16;
+  }
+  uint4 wreg[WP][4];
   auto wload = [&](int c) {
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      uint4 v = {0, 0, 0, 0};
-      if (wthread && c * 128 + qd * 32 + gq * 8 < KV) v = *reinterpret_cast<const uint4*>(wsrc + c * 128 + gq * 8);
-      wreg[gq] = v;
-    }
+    for (int ps = 0; ps < WP; ++ps)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        uint4 v = {0, 0, 0, 0};
+        if (wthread[ps] && c * 128 + qd * 32 + gq * 8 < KV) v = *reinterpret_cast<const uint4*>(wsrc[ps] + c * 128 + gq * 8);
+        wreg[ps][gq] = v;
+      }
   };
   auto wstore = [&](int buf) {
-    if (wthread) {
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<uint4*>(smem + buf * C3_BUF(NTILES) + wdst + gq * 256) = wreg[gq];
-    }
+    for (int ps = 0; ps < WP; ++ps)
+      if (wthread[ps]) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<uint4*>(smem + buf * C3_BUF(NTILES) + wdst[ps] + gq * 256) = wreg[ps][gq];
+      }
   };
 
   // ---- gather ring
@@ -181,10 +194,10 @@ static int launch_conv3_i(const void* in, const void* w, const float* bias, cons
 template <typename T>
 static int launch_conv3(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
                         int c_out, void* out, hipStream_t s) {
-  // 64 output channels per workgroup (32 when c_out is not a multiple of 64); 256-row workgroups when they
-  // still give every CU two workgroups, else 128-row ones
+  // 64 output channels per workgroup (96 when c_out is a multiple of 96 but not of 64 -- SpUNet's decoder --
+  // else 32); 256-row workgroups when they still give every CU two workgroups, else 128-row ones
   // (PTC_CONV3_RT=2|4 forces the choice: used by the tests to reach both instantiations at small n)
-  const int nt = c_out % 64 == 0 ? 4 : 2;
+  const int nt = c_out % 64 == 0 ? 4 : (c_out % 96 == 0 ? 6 : 2);
   bool big = ptc_cdiv(n_out, 256) * (c_out / (nt * 16)) >= 512;
   if (const char* e = getenv("PTC_CONV3_RT")) {
     if (atoi(e) == 4) big = true;
@@ -195,7 +208,7 @@ static int launch_conv3(const void* in, const void* w, const float* bias, const 
 #define C3_CASE(K, N)                                                                                          \
   if (kpc == K && nt == N) return big ? launch_conv3_i<T, 4, K, N>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s) \
                                       : launch_conv3_i<T, 2, K, N>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
-  C3_CASE(1, 4) C3_CASE(2, 4) C3_CASE(4, 4) C3_CASE(1, 2) C3_CASE(2, 2) C3_CASE(4, 2)
+  C3_CASE(1, 4) C3_CASE(2, 4) C3_CASE(4, 4) C3_CASE(1, 2) C3_CASE(2, 2) C3_CASE(4, 2) C3_CASE(1, 6) C3_CASE(2, 6) C3_CASE(4, 6)
 #undef C3_CASE
   ptc_set_error("conv3: c_in=%d c_out=%d unsupported", c_in, c_out);
   return PTC_EUNSUPPORTED;

@@ -514,7 +514,7 @@ static int launch_wgrad2(const void* in, const void* dout, const int32_t* nbr, i
     rc = launch_wgrad2_inst<T, COT, CIT, KG>(p, in, dout, nbr, n_out, kv, c_in, c_out, partial, bias_partial, s);
   W2_CASE(2, 1, 1) W2_CASE(2, 2, 1) W2_CASE(2, 4, 1) W2_CASE(4, 1, 1) W2_CASE(4, 2, 1) W2_CASE(4, 4, 1)
   W2_CASE(6, 1, 1) W2_CASE(6, 2, 1) W2_CASE(6, 4, 1) W2_CASE(8, 1, 1) W2_CASE(8, 2, 1) W2_CASE(8, 4, 1)
-  W2_CASE(2, 1, 16) W2_CASE(2, 2, 9) W2_CASE(4, 2, 4) W2_CASE(2, 4, 4) W2_CASE(4, 4, 2)
+  W2_CASE(2, 1, 16) W2_CASE(2, 2, 9) W2_CASE(4, 2, 4) W2_CASE(2, 4, 4) W2_CASE(4, 4, 2) W2_CASE(6, 2, 2)
 #undef W2_CASE
   if (rc != PTC_OK) {
     if (rc == PTC_EUNSUPPORTED) ptc_set_error("ptc_spconv_wgrad: no wgrad2 instance for tiles (%d,%d,%d)", p.cot, p.cit, p.kg);

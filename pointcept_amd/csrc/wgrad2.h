@@ -289,10 +289,14 @@ static inline int w2_env_int(const char* name, int dflt) {
 }
 
 static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out, bool want_bias = false) {
-  static const int cot_max = w2_env_int("PTC_W2_COT_MAX", 4), cit_max = w2_env_int("PTC_W2_CIT_MAX", 4);  // tuning knobs
+  static const int cot_max = w2_env_int("PTC_W2_COT_MAX", 8), cit_max = w2_env_int("PTC_W2_CIT_MAX", 4);  // tuning knobs
   W2Plan p;
-  p.cit = c_in <= 16 ? 1 : (c_in <= 32 ? 2 : 4);
+  // channel tiles: 64x64 accumulators by default; channel counts that are multiples of 32 but not of 64
+  // (SpUNet's 96-channel decoder) take 32-wide input tiles / a 96-wide output tile so that no MFMA runs on padding
+  p.cit = c_in <= 16 ? 1 : (c_in <= 32 ? 2 : (c_in % 64 == 0 ? 4 : 2));
   p.cot = c_out <= 32 ? 2 : (c_out <= 64 ? 4 : (c_out <= 96 ? 6 : 8));
+  if (c_out > 96 && c_out % 96 == 0 && c_out % 64 != 0) p.cot = 6;
+  if (p.cot == 6) p.cit = p.cit > 2 ? 2 : p.cit;
   if (p.cit == 4 && p.cot > 4) p.cot = 4;   // 64x64 accumulators: the wider tiles spill under the 256-register cap
   if (p.cot > cot_max) p.cot = cot_max;
   if (p.cit > cit_max) p.cit = cit_max;
@@ -303,6 +307,7 @@ static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out, bool wa
     else if (p.cot == 4 && p.cit == 2) p.kg = 4;
     else if (p.cot == 2 && p.cit == 4) p.kg = 4;
     else if (p.cot == 4 && p.cit == 4) p.kg = 2;
+    else if (p.cot == 6 && p.cit == 2) p.kg = 2;
   }
   p.co_blocks = (int)ptc_cdiv(c_out, p.cot * 16);
   p.ci_blocks = (int)ptc_cdiv(c_in, p.cit * 16);

@@ -116,7 +116,9 @@ class SpUNetBase(nn.Module):
     def forward(self, input_dict):
         grid_coord, feat, offset = input_dict["grid_coord"], input_dict["feat"], input_dict["offset"]
         batch = offset2batch(offset)
-        host = torch.cat([grid_coord.max(0).values.to(torch.int64), offset[-1:].to(torch.int64) * 0 + offset.numel()]).tolist()
+        from . import ops
+
+        host = torch.cat([ops.coord_max(grid_coord), offset[-1:].to(torch.int64) * 0 + offset.numel()]).tolist()
         sparse_shape = [int(m) + 96 for m in host[:3]]  # spconv_unet_v1m1_base.py:250 (one host sync)
         x = spconv.SparseConvTensor(
             features=feat, indices=torch.cat([batch.unsqueeze(-1).int(), grid_coord.int()], dim=1).contiguous(),

@@ -159,7 +159,11 @@ class SubMConv3d(_SparseConvolution):
     def forward(self, x: SparseConvTensor):
         k = self.kernel_size[0]
         if k == 1:  # spconv short-circuits 1x1x1 submanifold convs to a GEMM
-            return x.replace_feature(F.linear(x.features, self.weight.reshape(self.out_channels, self.in_channels), self.bias))
+            w2 = self.weight.reshape(self.out_channels, self.in_channels)
+            f = x.features
+            if f.is_cuda and f.dim() == 2 and f.shape[0] > 0:   # the engine's tall-skinny GEMM kernels (fwd / dgrad / split-K wgrad)
+                return x.replace_feature(PF.linear(f, w2, self.bias))
+            return x.replace_feature(F.linear(f, w2, self.bias))
         if x.indices.shape[0] == 0:
             return x.replace_feature(x.features.new_zeros((0, self.out_channels)))
         key = ("subm", self.indice_key, k)

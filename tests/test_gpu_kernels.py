@@ -271,7 +271,7 @@ def _tols(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cin,cout,ksize", [(8, 32, 5), (32, 32, 3), (64, 64, 3), (96, 96, 3), (128, 48, 3),
-                                            (192, 128, 3), (256, 256, 3), (16, 16, 3)])
+                                            (192, 128, 3), (256, 256, 3), (16, 16, 3), (128, 96, 3), (96, 64, 3), (32, 192, 3)])
 def test_spconv_fwd_and_wgrad(cuda, dtype, cin, cout, ksize):
     from pointcept_amd import ops
 
