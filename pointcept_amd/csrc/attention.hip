@@ -43,6 +43,7 @@
 // bit-reproducible): dQ is query-stationary, dK/dV key-stationary.
 // Roofline: fwd 4 L^2 D flops and L^2 exps per (sequence, head); bwd 10 L^2 D.
 #include "ptc_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -566,6 +567,220 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
 }
 
 // ================================================================================================
+// backward, single pass: dQ, dK, dV from ONE recomputation of S / P / dS per (query tile, key tile)
+// ================================================================================================
+// The two-kernel backward recomputes S twice (once per orientation: lane = query for dQ, lane = key for
+// dK/dV): 14 MFMA + 32 exp per tile pair, and transcendentals do not overlap MFMAs on a SIMD
+// (tools/probe_gfx950.hip: instruction-mix floors 116 + 173 ns against 193 ns for the mix below).  Here a
+// workgroup still owns one (sequence, head); wave w is key-stationary on key tiles w, w+8, ... (dK, dV in
+// registers) and walks the query tiles; per (query tile, key tile):
+//   S' = Q (K c)^T - lse and dP' = dO V^T - delta straight out of the matrix pipe (as attn_bwd_dkv_kernel),
+//   P = exp2(S'), dS = P o dP', dV += P^T dO, dK += dS^T Q,
+//   dS is written once to a wave-private 2 KB LDS slice as [key][query] and read back through
+//   ds_read_b64_tr_b16 as the B operand of dQ^T[d][q] += K^T[d][key] dS^T[key][q]  (A = the stationary K tile),
+//   and that 16 x 32 contribution is added to the query tile's fp32 accumulator in LDS.
+// The walk is SKEWED (wave w starts at query tile w * n_tiles / 8), so the eight waves are normally on eight
+// different query tiles; every accumulator tile carries a turn counter in LDS and a wave adds its contribution
+// only when the counter equals its position in the tile's (fixed, schedule-derived) order of contributors --
+// the sum order is deterministic (bit-reproducible like the two-kernel form) without any workgroup barrier in
+// the loop.  (A barrier per step kept the two waves of a SIMD in phase -- both in their MFMA part, then both in
+// their exp part -- and ran 1.35x SLOWER than the two-kernel form; ds_add_f32 serialises per lane: 6.5x slower.)
+// 11 MFMA + 16 exp per tile pair; LDS 152 KB (one workgroup per CU, 256 registers per lane).
+// LDS: Q row-major [lp][16] | dO row-major [lp][16] | aux [lp][4] bf16 | dQ acc [lp/32][16][32] fp32 | 8 x 2 KB slices | turn counters
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_bwd_fused_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
+                      const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
+                      int lp_max, int n_units, uint16_t* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int unit = at_unit(n_units);
+  if (unit >= n_units) return;
+  const int seq = unit / H, head = unit % H;
+  const int a = cu[seq], L = cu[seq + 1] - a;
+  if (L <= 0) return;
+  const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
+  unsigned char* Qsm = smem;
+  unsigned char* dOsm = smem + (size_t)lp_max * 32;
+  uint2* aux = reinterpret_cast<uint2*>(smem + (size_t)lp_max * 64);
+  float* dQacc = reinterpret_cast<float*>(smem + (size_t)lp_max * 72);
+  const int lane = ptc_lane(), wave = threadIdx.x >> 6;
+  unsigned char* slice = smem + (size_t)lp_max * 136 + wave * 2048;
+  volatile int* turn_cnt = reinterpret_cast<volatile int*>(smem + (size_t)lp_max * 136 + AT_WAVES * 2048);
+  const int64_t rs = (int64_t)3 * H * 16;
+
+  // ---- prologue: Q, dO row-major; (lse, delta) pairs; zero dQ accumulators
+  stage_row_major(qkv + qkv_off(a, 0, H, head), rs, L, Lp, Qsm);
+  for (int q = threadIdx.x; q < Lp; q += AT_THREADS) {
+    uint4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+    float l2 = AT_PAD_LSE, dl = 0.f;
+    if (q < L) {
+      const int64_t orow = ((int64_t)(a + q) * H + head) * 16;
+      const uint4* pd = reinterpret_cast<const uint4*>(dout + orow);
+      const uint4* po = reinterpret_cast<const uint4*>(out + orow);
+      d0 = pd[0]; d1 = pd[1];
+      const uint4 o0 = po[0], o1 = po[1];
+      const uint32_t dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      const uint32_t ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        dl = fmaf(__uint_as_float(dw[j] << 16), __uint_as_float(ow[j] << 16), dl);
+        dl = fmaf(__uint_as_float(dw[j] & 0xffff0000u), __uint_as_float(ow[j] & 0xffff0000u), dl);
+      }
+      l2 = lse[(int64_t)head * total + a + q] * AT_LOG2E;
+    }
+    *reinterpret_cast<uint4*>(dOsm + rm_off(q, 0)) = d0;
+    *reinterpret_cast<uint4*>(dOsm + rm_off(q, 1)) = d1;
+    const uint32_t hi = pack_bf16x2(l2, dl);
+    const uint32_t lo = pack_bf16x2(l2 - __uint_as_float(hi << 16), dl - __uint_as_float(hi & 0xffff0000u));
+    uint2 w;
+    w.x = (hi & 0xffffu) | (lo << 16);
+    w.y = (hi >> 16) | (lo & 0xffff0000u);
+    aux[q] = w;
+  }
+  for (int i = threadIdx.x; i < n_tiles * 512; i += AT_THREADS) dQacc[i] = 0.f;
+  if ((int)threadIdx.x < n_tiles) turn_cnt[threadIdx.x] = 0;
+  __syncthreads();
+
+  const int col = lane & 31, h2 = lane >> 5;
+  const float c = scale * AT_LOG2E;
+  const TrAddr ta = tr_addr(lane);
+  const int rmo = rm_off(col, h2);
+  const uint32_t m1 = 0xBF80BF80u;
+  const s16x8 bS = make_frag(h2 == 0 ? m1 : 0u, 0u, 0u, 0u);
+  const s16x8 bD = make_frag(0u, h2 == 0 ? m1 : 0u, 0u, 0u);
+  // transposing read of the [key][query] dS slice (64-byte rows): lane (q = lane & 31, h2) gets keys
+  // 16 mm + 4 h2 + {0..3} (+8) of its query column
+  const int lp16 = lane & 15, qblk = (lane >> 4) & 1;
+  const int ds_rd = (4 * h2 + (lp16 >> 2)) * 64 + (qblk * 16 + (lp16 & 3) * 4) * 2;
+  const int skew = n_tiles >= AT_WAVES ? n_tiles / AT_WAVES : 1;
+  const int off_w = wave * skew;
+  const int n_kb = (n_tiles + AT_WAVES - 1) / AT_WAVES;
+  int turn_base = 0;                                  // contributions every tile has received in earlier kb rounds
+
+  for (int kb = 0; kb < n_kb; ++kb) {
+    const int kt = wave + AT_WAVES * kb;
+    const bool have = kt < n_tiles;
+    const int active = (n_tiles - AT_WAVES * kb) < AT_WAVES ? (n_tiles - AT_WAVES * kb) : AT_WAVES;   // waves with a key tile this round
+    const int key = kt * 32 + col;
+    const bool kvalid = have && key < L;
+    const s16x8 kf = ld_global_frag(qkv + qkv_off(a + key, 1, H, head) + h2 * 8, kvalid);
+    const s16x8 vf = ld_global_frag(qkv + qkv_off(a + key, 2, H, head) + h2 * 8, kvalid);
+    s16x8 khi, klo;
+    split_scaled(kf, c, khi, klo);
+    // K^T fragments of the stationary tile (A operand of the dQ product), via the slice
+    *reinterpret_cast<s16x8*>(slice + rm_off(col, h2)) = kf;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const s16x8 ktf0 = ld_tr_frag(slice, ta, 0), ktf1 = ld_tr_frag(slice, ta, 16);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f32x16 dv = zero16(), dk = zero16();
+    for (int j = 0; j < n_tiles; ++j) {
+      if (have) {
+        int qt = j + off_w;
+        qt = qt >= n_tiles ? qt - n_tiles : qt;
+        const s16x8 qf = *reinterpret_cast<const s16x8*>(Qsm + qt * 1024 + rmo);
+        const s16x8 dof = *reinterpret_cast<const s16x8*>(dOsm + qt * 1024 + rmo);
+        const uint2 ax = aux[qt * 32 + col];
+        const s16x8 af = make_frag(ax.x, ax.y, 0u, 0u);
+        f32x16 sv = mfma32(af, bS, zero16());           // -lse[q]       S'[q][key]: lane = key, regs = queries crow(r,h2)
+        sv = mfma32(qf, khi, sv);
+        sv = mfma32(qf, klo, sv);
+        f32x16 dp = mfma32(af, bD, zero16());           // -delta[q]
+        dp = mfma32(dof, vf, dp);
+        uint32_t pp[8], ps[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float p0 = __builtin_amdgcn_exp2f(sv[2 * i]), p1 = __builtin_amdgcn_exp2f(sv[2 * i + 1]);
+          pp[i] = pack_bf16x2(p0, p1);
+          ps[i] = pack_bf16x2(p0 * dp[2 * i], p1 * dp[2 * i + 1]);
+        }
+        // dS -> slice as [key = col][query]: registers 4g..4g+3 are queries 8g + 4 h2 + {0..3}
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 w;
+          w.x = ps[2 * g]; w.y = ps[2 * g + 1];
+          *reinterpret_cast<uint2*>(slice + col * 64 + (8 * g + 4 * h2) * 2) = w;
+        }
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          const s16x8 pf = make_frag(pp[4 * mm], pp[4 * mm + 1], pp[4 * mm + 2], pp[4 * mm + 3]);
+          const s16x8 dsf = make_frag(ps[4 * mm], ps[4 * mm + 1], ps[4 * mm + 2], ps[4 * mm + 3]);
+          const s16x8 dotf = ld_tr_frag(dOsm, ta, qt * 32 + 16 * mm);
+          const s16x8 qtf = ld_tr_frag(Qsm, ta, qt * 32 + 16 * mm);
+          dv = mfma32(pf, dotf, dv);
+          dk = mfma32(dsf, qtf, dk);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x16 dq = zero16();
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          const unsigned char* pr = slice + 16 * mm * 64 + ds_rd;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pr));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pr + 8 * 64));
+          const s16x8 dst = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          dq = mfma32(mm == 0 ? ktf0 : ktf1, dst, dq);  // dQ^T[d][q] contribution of this key tile
+        }
+        // my position among this round's contributors to tile qt: wave w' reaches qt at step (qt - w' skew) mod n,
+        // I reach it at step j -- earlier are the waves above me that are <= j/skew ahead and the waves below me
+        // whose walk has already wrapped around
+        int rank = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < AT_WAVES; ++w2) {
+          if (w2 < active) {
+            if (w2 > wave && (w2 - wave) * skew <= j) ++rank;
+            if (w2 < wave && j + (wave - w2) * skew >= n_tiles) ++rank;
+          }
+        }
+        const int my_turn = turn_base + rank;
+        while (turn_cnt[qt] != my_turn) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        float* acc = dQacc + qt * 512 + col;            // [d][32 queries]
+        // plain read-modify-write: the turn counter makes this wave the only writer of the tile right now
+        // (ds_add_f32 serialises per lane on gfx950: 13k cycles per step in the first version of this kernel)
+        float cur[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) cur[r] = acc[crow(r, h2) * 32];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[crow(r, h2) * 32] = cur[r] + dq[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) turn_cnt[qt] = my_turn + 1;
+      }
+    }
+    turn_base += active;
+    if (have && col < 16) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = kt * 32 + crow(r, h2);
+        if (kk < L) {
+          dqkv[qkv_off(a + kk, 1, H, head) + col] = (uint16_t)(pack_bf16x2(dk[r] * scale, 0.f) & 0xffffu);
+          dqkv[qkv_off(a + kk, 2, H, head) + col] = (uint16_t)(pack_bf16x2(dv[r], 0.f) & 0xffffu);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- dQ rows out: lane (q, h2) owns d = 4 h2 + {0..3} and 8 + 4 h2 + {0..3}
+  for (int qt = wave; qt < n_tiles; qt += AT_WAVES) {
+    const int q = qt * 32 + col;
+    const float* acc = dQacc + qt * 512 + col;
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = acc[crow(r, h2) * 32] * scale;
+    if (q < L) {
+      uint16_t* o = dqkv + qkv_off(a + q, 0, H, head);
+      uint2 w0, w1;
+      w0.x = pack_bf16x2(v[0], v[1]); w0.y = pack_bf16x2(v[2], v[3]);
+      w1.x = pack_bf16x2(v[4], v[5]); w1.y = pack_bf16x2(v[6], v[7]);
+      *reinterpret_cast<uint2*>(o + 4 * h2) = w0;
+      *reinterpret_cast<uint2*>(o + 8 + 4 * h2) = w1;
+    }
+  }
+}
+
+// ================================================================================================
 // host side
 // ================================================================================================
 // dynamic LDS above 64 KB has to be opted into once per kernel
@@ -578,6 +793,15 @@ static int allow_big_lds(K kernel, size_t bytes) {
 static size_t fwd_lds_bytes(int lp_max) { return (size_t)lp_max * 32 + (size_t)17 * (lp_max + 8) * 2 + AT_WAVES * 4; }
 static size_t dq_lds_bytes(int lp_max) { return (size_t)lp_max * 64; }
 static size_t dkv_lds_bytes(int lp_max) { return (size_t)lp_max * 64 + (size_t)lp_max * 8; }
+static size_t fused_lds_bytes(int lp_max) { return (size_t)lp_max * 136 + (size_t)AT_WAVES * 2048 + 256; }
+// The two-kernel backward (dQ, then dK/dV) is the default.  PTC_ATTN_BWD=1 selects the single-pass kernel, kept as
+// a measured experiment: correct and bit-reproducible, 11 MFMA + 16 exp per tile pair instead of 14 + 32, but its
+// 152 KB of LDS allows two waves per SIMD instead of four and the per-step dependency chain (LDS -> MFMA -> exp ->
+// LDS transpose -> MFMA -> LDS accumulate) is then exposed: 2.1-2.3 ms against 1.56 ms at the bench shape (r01_w/x).
+static bool at_fused_bwd() {
+  const char* e = getenv("PTC_ATTN_BWD");
+  return e && atoi(e) == 1;
+}
 
 static int check_common(const char* name, const void* qkv, const int32_t* cu, int64_t n_seq, int64_t total, int H,
                         int max_seqlen, int dtype) {
@@ -629,6 +853,16 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   const int lp_max = (max_seqlen + 31) & ~31;
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)workspace;
+  if (at_fused_bwd()) {
+    rc = allow_big_lds(attn_bwd_fused_kernel, fused_lds_bytes(lp_max));
+    if (rc != PTC_OK) return rc;
+    const int nu = (int)(n_seq * H);
+    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3((unsigned)(8 * ((nu + 7) / 8))), dim3(AT_THREADS), fused_lds_bytes(lp_max), s,
+                       (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H, softmax_scale, total,
+                       lp_max, nu, (uint16_t*)dqkv);
+    PTC_CHECK_LAUNCH("attn_bwd_fused_kernel");
+    return PTC_OK;
+  }
   rc = allow_big_lds(attn_bwd_dq_kernel, dq_lds_bytes(lp_max));
   if (rc != PTC_OK) return rc;
   rc = allow_big_lds(attn_bwd_dkv_kernel, dkv_lds_bytes(lp_max));

@@ -557,6 +557,32 @@ def test_attention_fwd_bwd(cuda, lens, H):
     _close("attn_bwd", dqkv, q32.grad, 1.0 / 32, 1e-2 * gmax)
 
 
+def test_attention_bwd_two_kernel_form_matches_fused(cuda, monkeypatch):
+    """PTC_ATTN_BWD=1 runs the single-pass backward kernel, the default (=2) is the dQ / dK+dV kernel pair.  Same
+    math, both against the oracle, and each bit-reproducible run to run."""
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    lens, H = [1024, 700, 33], 4
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    qkv = (torch.randn(T, 3, H, 16, generator=g) * 1.5).to(torch.bfloat16)
+    out, lse = ops.attn_varlen_fwd(qkv.to(cuda), cu.to(cuda), max(lens), 0.25)
+    dout = torch.randn(T, H, 16, generator=g).to(torch.bfloat16)
+    q32 = qkv.float().requires_grad_(True)
+    oops.attention_varlen(q32, cu, 0.25).backward(dout.float())
+    gmax = float(q32.grad.abs().max())
+    res = {}
+    for mode in ("1", "2"):
+        monkeypatch.setenv("PTC_ATTN_BWD", mode)
+        d1 = ops.attn_varlen_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), 0.25)
+        d2 = ops.attn_varlen_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), 0.25)
+        assert torch.equal(d1, d2), f"backward form {mode} is not bit-reproducible"
+        _close(f"attn_bwd_form{mode}", d1, q32.grad, 1.0 / 32, 1e-2 * gmax)
+        res[mode] = d1.float()
+    _close("attn_bwd_forms_agree", res["1"], res["2"], 1.0 / 32, 1e-2 * gmax)
+
+
 def test_attention_large_logits(cuda):
     """Peaked softmax (online-max path): one key dominates each query."""
     from pointcept_amd import ops

@@ -103,9 +103,13 @@ def bench_attention(rows, n_seq, H, results, L=1024):
     r["fwd"] = roof(by_f, fl_f, timeit(lambda: ops.attn_varlen_fwd(qkv, cu, L, sc), iters=10))
     r["bwd"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
                     timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
+    os.environ["PTC_ATTN_BWD"] = "1"
+    r["bwd2"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
+                     timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
+    os.environ.pop("PTC_ATTN_BWD", None)
     results.append(r)
     rows.append(f"attention n_seq={n_seq:4d} L={L} H={H:2d} | fwd {r['fwd']['us']:8.1f} us {r['fwd']['TFLOPs']:7.1f} TF/s | "
-                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s (10 L^2 D)")
+                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s | bwd single-pass (experiment) {r['bwd2']['us']:8.1f} us (10 L^2 D)")
 
 
 def bench_spconv(rows, results, scenes=8, points=102400):
