@@ -319,6 +319,10 @@ int ptc_batch_norm_act_fwd(const void* x, int64_t n, int c, int dtype, const flo
                            float momentum, int training, float* running_mean, float* running_var, int act, void* y,
                            int y_dtype, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
                            ptc_stream_t stream);
+/* out[c] (fp32) = sum_i x[i][c]: bias gradients (`grad.sum(0)`), one read of x, fixed summation order.
+ * Same shape limits and workspace size as the BatchNorm entry points. */
+int ptc_column_sum(const void* x, int64_t n, int c, int dtype, float* out, void* workspace, size_t workspace_bytes,
+                   ptc_stream_t stream);
 int ptc_batch_norm_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
                            const float* save_mean, const float* save_rstd, int64_t n, int c, int training, int act,
                            void* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,

@@ -31,7 +31,7 @@
 #define C3_FPAD 64
 #define C3_BUF(NTILES) (4 * (NTILES) * (C3_FRAG + C3_FPAD))   // one W chunk: NTILES tiles x 4 steps
 
-template <typename T, int RT, int KPC, int NTILES>
+template <typename T, int RT, int KPC, int NTILES, bool GEN>
 __global__ void __launch_bounds__(256, 2)
 conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
              const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int n_rowblk, T* __restrict__ out) {
@@ -91,7 +91,9 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   bool anyv[4][RT];
   int32_t idxN[KPC][RT], idxNN[KPC][RT];
   auto load_idx = [&](int c, int32_t (&ix)[KPC][RT]) {
-    const int kfirst = (c * 128) / c_in;             // first table row touched by chunk c
+    // GEN = false: c_in divides 128 or is a multiple of it, a chunk holds exactly KPC whole table rows
+    // (or a slice of one); GEN = true (c_in = 96, 160, 192, ...): rows straddle chunks, everything by division
+    const int kfirst = (GEN || KPC == 1) ? (c * 128) / c_in : c * KPC;
 #pragma unroll
     for (int kk = 0; kk < KPC; ++kk) {
       const int k = kfirst + kk;
@@ -104,14 +106,25 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   };
   auto issue = [&](int c, int s, const int32_t (&ix)[KPC][RT]) {
     const int v0 = c * 128 + s * 32;                 // flattened contraction index of this step
-    const int k = v0 / c_in;
-    const int kk = KPC > 1 ? k - (c * 128) / c_in : 0;
-    const int cbase = v0 - k * c_in + g * 8;
+    int kk, cbase;
+    if constexpr (GEN) {
+      const int k = v0 / c_in;
+      kk = k - (c * 128) / c_in;
+      cbase = v0 - k * c_in + g * 8;
+    } else {
+      kk = (s * KPC) >> 2;
+      cbase = v0 % c_in + g * 8;
+    }
 #pragma unroll
     for (int j = 0; j < RT; ++j) {
-      int32_t i = ix[0][j];
+      int32_t i;
+      if constexpr (GEN) {
+        i = ix[0][j];
 #pragma unroll
-      for (int q = 1; q < KPC; ++q) i = kk == q ? ix[q][j] : i;   // static indexing: no scratch
+        for (int q = 1; q < KPC; ++q) i = kk == q ? ix[q][j] : i;   // run-time kk: select instead of dynamic indexing
+      } else {
+        i = ix[kk][j];                                               // kk is a compile-time constant after unrolling
+      }
       frag f = M::zero();
       if (i >= 0) f = ld_frag<T>(in + (int64_t)i * c_in + cbase);
       ga[s][j] = f;
@@ -175,16 +188,19 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 
 static inline bool conv3_supported(int dtype, int kv, int c_in, int c_out, const int32_t* nbr) {
   if (dtype == PTC_F32 || nbr == nullptr || kv < 2) return false;
-  return c_out % 32 == 0 && c_in % 32 == 0;
+  if (c_out % 32 != 0 || c_in % 32 != 0) return false;
+  // 32 -> 32 convolutions (PTv3 stage 0, SpUNet level 0) stay on conv2: with 2 MFMAs per gathered fragment the
+  // chunk pipeline has nothing to amortise and measured slower (1.17 vs 0.91 ms per step, r01_z)
+  return !(c_in == 32 && c_out % 64 != 0 && c_out % 96 != 0);
 }
 
-template <typename T, int RT, int KPC, int NTILES>
+template <typename T, int RT, int KPC, int NTILES, bool GEN>
 static int launch_conv3_i(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
                           int c_out, void* out, hipStream_t s) {
   const int n_rowblk = (int)ptc_cdiv(n_out, RT * 64);
   const int nblk = n_rowblk * (c_out / (NTILES * 16));
   const size_t lds = 2 * C3_BUF(NTILES);
-  auto kern = conv3_kernel<T, RT, KPC, NTILES>;
+  auto kern = conv3_kernel<T, RT, KPC, NTILES, GEN>;
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv,
                      c_in, c_out, n_rowblk, (T*)out);
   PTC_CHECK_LAUNCH("conv3_kernel");
@@ -205,10 +221,14 @@ static int launch_conv3(const void* in, const void* w, const float* bias, const 
   }
   // table rows one 128-wide chunk can touch: 1 (c_in % 128 == 0), 4 (c_in = 32), else 2
   const int kpc = c_in % 128 == 0 ? 1 : (c_in == 32 ? 4 : 2);
-#define C3_CASE(K, N)                                                                                          \
-  if (kpc == K && nt == N) return big ? launch_conv3_i<T, 4, K, N>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s) \
-                                      : launch_conv3_i<T, 2, K, N>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
-  C3_CASE(1, 4) C3_CASE(2, 4) C3_CASE(4, 4) C3_CASE(1, 2) C3_CASE(2, 2) C3_CASE(4, 2) C3_CASE(1, 6) C3_CASE(2, 6) C3_CASE(4, 6)
+  const bool gen = !(c_in == 32 || c_in == 64 || c_in % 128 == 0);   // table rows straddle chunks (kpc == 2)
+#define C3_CASE(K, N, G)                                                                                                   \
+  if (kpc == K && nt == N && gen == G)                                                                                     \
+    return big ? launch_conv3_i<T, 4, K, N, G>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s)                           \
+               : launch_conv3_i<T, 2, K, N, G>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  C3_CASE(1, 4, false) C3_CASE(2, 4, false) C3_CASE(4, 4, false) C3_CASE(2, 4, true)
+  C3_CASE(1, 2, false) C3_CASE(2, 2, false) C3_CASE(2, 2, true)
+  C3_CASE(1, 6, false) C3_CASE(2, 6, false) C3_CASE(4, 6, false) C3_CASE(2, 6, true)
 #undef C3_CASE
   ptc_set_error("conv3: c_in=%d c_out=%d unsupported", c_in, c_out);
   return PTC_EUNSUPPORTED;

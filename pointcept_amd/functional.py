@@ -187,7 +187,7 @@ class _SparseConv(Function):
         if ctx.needs_input_grad[1]:
             dw = ops.spconv_wgrad(f, g, nbr)[:c_out, :, :c_in].to(ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbias = grad.float().sum(0)
+            dbias = ops.column_sum(grad)
         return dfeat, dw, dbias, None, None, None
 
 
@@ -257,7 +257,7 @@ class _Linear(Function):
                 dw = dwp[:c_out, 0, :c_in].to(ctx.w_dtype)
             else:
                 dw = (g.t() @ xp)[:c_out, :c_in].to(ctx.w_dtype)
-                dbp = g.float().sum(0) if want_b else None
+                dbp = ops.column_sum(g) if want_b else None
             if want_b:
                 db = dbp[:c_out].to(ctx.b_dtype)
         return dx, dw, db, None, None

@@ -522,3 +522,19 @@ def batch_norm_act_bwd(dy, x, gamma, beta, mean, rstd, training: bool, act: str,
                                        int(bool(training)), ACT_CODES[act], ptr(dx), ptr(dg), ptr(db), ptr(ws), nbytes, stream_ptr()),
           "ptc_batch_norm_act_bwd")
     return dx, dg, db
+
+
+def column_sum(x: torch.Tensor) -> torch.Tensor:
+    """x [N, C] (f32 / bf16 / f16) -> fp32 [C] = x.float().sum(0) in one read of x (bias gradients)."""
+    require_cuda(x)
+    if x.dim() != 2:
+        raise PtcoreError("column_sum expects [N, C]")
+    if not batch_norm_supported(x.shape[1], x.dtype):
+        return x.float().sum(0)          # odd channel counts: ATen on the GPU
+    x = x.contiguous()
+    n, c = x.shape
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    nbytes = lib().ptc_batch_norm_workspace_bytes(n, c)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(lib().ptc_column_sum(ptr(x), n, c, dtype_code(x), ptr(out), ptr(ws), nbytes, stream_ptr()), "ptc_column_sum")
+    return out

@@ -704,3 +704,16 @@ def test_batch_norm_act_eval_and_module(cuda):
     _close("bn_module_rv", eng[0].running_var, ref[0].running_var, 1e-5, 1e-6)
     ref.eval(); eng.eval()
     _close("bn_module_eval", eng(x.to(cuda)), ref(x), 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,c", [(1, 32), (4099, 64), (70001, 96), (333, 20)])
+def test_column_sum(cuda, dtype, n, c):
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g).to(dtype)
+    got = ops.column_sum(x.to(cuda))
+    ref = x.double().sum(0)
+    _close("column_sum", got.double(), ref, 1e-5, 1e-4 * max(1.0, float(ref.abs().max())))
+    assert got.dtype == torch.float32
