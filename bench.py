@@ -82,10 +82,24 @@ def attention_roofline(device, scenes: int, points: int):
     ms = start.elapsed_time(stop) / iters
     flops = 4.0 * L * L * D * n_seq * H
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "attn_fwd_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-            "launch_ms": round(ms, 4), "shape": {"n_seq": n_seq, "L": L, "H": H, "D": D},
-            "algorithmic_flops_per_launch": flops}
+    out = {"kernel": "attn_fwd_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+           "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+           "launch_ms": round(ms, 4), "shape": {"n_seq": n_seq, "L": L, "H": H, "D": D},
+           "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": T * H * D * 2 * 4}
+    # HBM bytes per launch of this kernel at this shape, from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on
+    # gfx950 + WRITE_SIZE, separate --pmc runs: tools/gpu_session.sh roof); not re-measured inside bench.py
+    try:
+        import glob
+
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*attn_pmc.json")))[-1]
+        k = json.load(open(pm))["kernels"]["attn_fwd_kernel"]
+        if (n_seq, H) == (800, 4):
+            out["traffic"] = round(k["hbm_bytes"])
+            out["traffic_source"] = os.path.relpath(pm, ROOT)
+            out["mfma_busy_frac"] = round(k["SQ_VALU_MFMA_BUSY_CYCLES_mean"] * 32 / (k["GRBM_GUI_ACTIVE_mean"] * 1024), 3)
+    except Exception:
+        pass
+    return out
 
 
 def cpu_baseline(sample_points: int, scene_points: int):

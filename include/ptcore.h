@@ -215,6 +215,13 @@ int ptc_rulebook_down_fill(const int32_t* indices, int64_t n_in, const int32_t* 
 int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float* bias,
                    const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out, int dtype,
                    void* out, ptc_stream_t stream);
+/* Dense row-wise GEMM out = in W^T + b with an MLP epilogue fused (PTv3 MLP, ptv3m1:225-248: fc1 -> GELU -> fc2):
+ *   epilogue 1 : out = h (the pre-activation, saved for the backward), aux_out = GELU(h)         [fc1 forward]
+ *   epilogue 2 : out = (in W^T) * GELU'(aux_in), aux_in = h [n, c_out]                          [fc2 input gradient]
+ * weight [c_out][c_in] in `dtype` (bf16 / f16), c_in <= 256 (ptc_linear_supported_ex); GELU = erf form, fp32. */
+int ptc_linear_supported_ex(int c_in, int c_out, int dtype);
+int ptc_linear_fwd_ex(const void* in, int64_t n, const void* weight, const float* bias, int c_in, int c_out, int dtype,
+                      int epilogue, const void* aux_in, void* out, void* aux_out, ptc_stream_t stream);
 size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out);
 int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32_t* nbr,
                      int64_t n_out, int kv, int c_in, int c_out, int dtype, float* dw, float* dbias,

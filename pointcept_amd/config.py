@@ -12,6 +12,8 @@ settings), and so a regression can be bisected without a rebuild.
                      folding the permutation into the qkv / proj GEMMs (kv = 1 gather tables)
   PTC_SORT_POINTS=0  PT-v3m1 keeps the caller's (dataloader) row order at stage 0 instead of physically
                      sorting the points along the first serialization curve for L2 locality
+  PTC_FUSE_MLP=0     the MLP runs fc1, GELU, fc2 as three kernels (+2 in the backward) instead of fusing GELU into
+                     fc1's epilogue and GELU' into the epilogue of fc2's input gradient
   PTC_FUSE_BLOCK=0   the three residual joints of a PTv3 Block run as separate LayerNorm / add / cast
                      kernels instead of the fused add_norm passes
 """
@@ -32,3 +34,4 @@ OWN_NORM = _flag("PTC_OWN_NORM", True)
 FUSE_GATHER = _flag("PTC_FUSE_GATHER", True)
 SORT_POINTS = _flag("PTC_SORT_POINTS", True)
 FUSE_BLOCK = _flag("PTC_FUSE_BLOCK", True)
+FUSE_MLP = _flag("PTC_FUSE_MLP", True)

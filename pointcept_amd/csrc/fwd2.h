@@ -110,10 +110,79 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NTILES, int S>
+// Epilogues of the MLP (ptv3m1:225-248: fc1 -> GELU -> fc2), fused into the GEMMs that produce the values:
+//   EPI 1 (fc1 forward)    : out = h (pre-activation, kept for the backward), aux_out = GELU(h)
+//   EPI 2 (fc2 input grad) : out = acc * GELU'(aux_in)   (aux_in = h: the gradient leaves the kernel already
+//                            multiplied through the activation; no dA tensor is ever written)
+// Same lane -> channel mapping as sc_epilogue; GELU is nn.GELU()'s erf form, evaluated in fp32.
+__device__ __forceinline__ float f2_gelu(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float f2_gelu_grad(float z) {
+  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+}
+
+template <typename T, int NTILES, int EPI>
+__device__ __forceinline__ void f2_epilogue_ex(f32x4 (&acc)[2][NTILES], T* __restrict__ out, const T* __restrict__ aux_in,
+                                               T* __restrict__ aux_out, int64_t rowA, int64_t rowB, int64_t n_out, int c_out,
+                                               int n0, int g) {
+  static_assert(sizeof(T) == 2, "16-bit features only");
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int64_t row = s ? rowB : rowA;
+    if (row >= n_out) continue;
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) {
+      const int gs = TileGroups<NTILES>::gstart(t), G = TileGroups<NTILES>::gsize(t);
+      if (t != gs) continue;
+      const int ch0 = n0 + 16 * gs + 4 * G * g;
+      const int64_t off = row * c_out + ch0;
+      float v[16], u[16];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * tt + e] = acc[s][(gs + tt) < NTILES ? (gs + tt) : t][e];
+      const int nv = 4 * G;                                   // valid values: 16, 8 or 4 consecutive channels
+      if (EPI == 2) {
+        T hv[16];
+        if (G == 4) { *reinterpret_cast<uint4*>(hv) = reinterpret_cast<const uint4*>(aux_in + off)[0]; *reinterpret_cast<uint4*>(hv + 8) = reinterpret_cast<const uint4*>(aux_in + off)[1]; }
+        else if (G == 2) { *reinterpret_cast<uint4*>(hv) = reinterpret_cast<const uint4*>(aux_in + off)[0]; }
+        else { *reinterpret_cast<uint2*>(hv) = reinterpret_cast<const uint2*>(aux_in + off)[0]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (i < nv) v[i] *= f2_gelu_grad(ptc_to_float(hv[i]));
+      }
+      if (EPI == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (i < nv) {
+            // the activation sees the value the reference's GELU sees: h rounded to the feature dtype
+            const float hr = ptc_to_float(ptc_from_float<T>(v[i]));
+            u[i] = f2_gelu(hr);
+          }
+      }
+      auto store = [&](T* dst, const float* val) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pk[i] = sc_pack2<T>(val[2 * i], val[2 * i + 1]);
+        if (G == 4) {
+          reinterpret_cast<uint4*>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+          reinterpret_cast<uint4*>(dst)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        } else if (G == 2) {
+          reinterpret_cast<uint4*>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        } else {
+          reinterpret_cast<uint2*>(dst)[0] = make_uint2(pk[0], pk[1]);
+        }
+      };
+      store(out + off, v);
+      if (EPI == 1) store(aux_out + off, u);
+    }
+  }
+}
+
+template <typename T, int NTILES, int S, int EPI = 0>
 __global__ void __launch_bounds__(256)
 linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-               const int32_t* __restrict__ nbr, int64_t n_out, int c_in, int c_out, T* __restrict__ out) {
+               const int32_t* __restrict__ nbr, int64_t n_out, int c_in, int c_out, T* __restrict__ out,
+               const T* __restrict__ aux_in = nullptr, T* __restrict__ aux_out = nullptr) {
   using M = Mma<T>;
   constexpr int NT = NTILES * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -179,7 +248,8 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
       }
     }
     const int64_t rowA = tile * F2_ROWS + wave * 32 + r;
-    sc_epilogue<T, NTILES>(acc, nullptr, out, rowA, rowA + 16, n_out, c_out, n0, g);
+    if constexpr (EPI == 0) sc_epilogue<T, NTILES>(acc, nullptr, out, rowA, rowA + 16, n_out, c_out, n0, g);
+    else f2_epilogue_ex<T, NTILES, EPI>(acc, out, aux_in, aux_out, rowA, rowA + 16, n_out, c_out, n0, g);
 #pragma unroll
     for (int s = 0; s < S; ++s) { ca[s] = pa[s]; cb[s] = pb[s]; }
   }
@@ -218,7 +288,7 @@ static int launch_conv2_w(const void* in, const void* w, const float* bias, cons
 
 template <typename T, int NTILES>
 static int launch_fwd2(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
-                       int c_out, void* out, hipStream_t s) {
+                       int c_out, void* out, hipStream_t s, int epi = 0, const void* aux_in = nullptr, void* aux_out = nullptr) {
   constexpr int NT = NTILES * 16;
   if (kv == 1) {
     const size_t lds = (size_t)NT * (c_in + 8) * 2;
@@ -229,18 +299,24 @@ static int launch_fwd2(const void* in, const void* w, const float* bias, const i
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)(c_out / NT));
     const int S = (c_in + 31) / 32;
-#define L2_CASE(SS)                                                                                                     \
-  case SS: {                                                                                                            \
-    auto kern = linear2_kernel<T, NTILES, SS>;                                                                          \
+#define L2_LAUNCH(SS, EE)                                                                                               \
+  {                                                                                                                     \
+    auto kern = linear2_kernel<T, NTILES, SS, EE>;                                                                      \
     if (lds > 48 * 1024)                                                                                                \
       PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, c_in, c_out, (T*)out);  \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, c_in, c_out, (T*)out,   \
+                       (const T*)aux_in, (T*)aux_out);                                                                  \
+  }
+#define L2_CASE(SS)                                                                                                     \
+  case SS: {                                                                                                            \
+    if (epi == 1) L2_LAUNCH(SS, 1) else if (epi == 2) L2_LAUNCH(SS, 2) else L2_LAUNCH(SS, 0)                              \
   } break;
     switch (S) {
       L2_CASE(1) L2_CASE(2) L2_CASE(3) L2_CASE(4) L2_CASE(5) L2_CASE(6) L2_CASE(7) L2_CASE(8)
       default: ptc_set_error("linear2: c_in=%d unsupported", c_in); return PTC_EUNSUPPORTED;
     }
 #undef L2_CASE
+#undef L2_LAUNCH
     PTC_CHECK_LAUNCH("linear2_kernel");
     return PTC_OK;
   }
@@ -254,11 +330,11 @@ static int launch_fwd2(const void* in, const void* w, const float* bias, const i
 
 template <typename T>
 static int dispatch_fwd2(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
-                         int c_out, void* out, hipStream_t s) {
-  if (c_out % 128 == 0) return launch_fwd2<T, 8>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
-  if (c_out % 96 == 0) return launch_fwd2<T, 6>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
-  if (c_out % 64 == 0) return launch_fwd2<T, 4>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
-  if (c_out % 48 == 0) return launch_fwd2<T, 3>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
-  if (c_out % 32 == 0) return launch_fwd2<T, 2>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
-  return launch_fwd2<T, 1>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+                         int c_out, void* out, hipStream_t s, int epi = 0, const void* aux_in = nullptr, void* aux_out = nullptr) {
+  if (c_out % 128 == 0) return launch_fwd2<T, 8>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  if (c_out % 96 == 0) return launch_fwd2<T, 6>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  if (c_out % 64 == 0) return launch_fwd2<T, 4>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  if (c_out % 48 == 0) return launch_fwd2<T, 3>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  if (c_out % 32 == 0) return launch_fwd2<T, 2>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  return launch_fwd2<T, 1>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
 }

@@ -244,6 +244,23 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
   return PTC_OK;
 }
 
+// Dense row-wise GEMM with an MLP epilogue (see fwd2.h): epilogue 1 = out: h, aux_out: GELU(h);
+// epilogue 2 = out: acc * GELU'(aux_in).  16-bit features, c_in <= 256 (the persistent linear2 kernel).
+extern "C" int ptc_linear_supported_ex(int c_in, int c_out, int dtype) {
+  return dtype != PTC_F32 && c_in % 8 == 0 && c_in <= 256 && c_out % 16 == 0;
+}
+extern "C" int ptc_linear_fwd_ex(const void* in, int64_t n, const void* weight, const float* bias, int c_in, int c_out, int dtype,
+                                 int epilogue, const void* aux_in, void* out, void* aux_out, ptc_stream_t stream) {
+  PTC_REQUIRE(n >= 0 && ptc_linear_supported_ex(c_in, c_out, dtype), PTC_EUNSUPPORTED, "ptc_linear_fwd_ex: c_in=%d c_out=%d dtype=%d",
+              c_in, c_out, dtype);
+  PTC_REQUIRE(epilogue == 1 || epilogue == 2, PTC_EINVAL, "ptc_linear_fwd_ex: epilogue %d", epilogue);
+  if (n == 0) return PTC_OK;
+  PTC_REQUIRE(in && weight && out && (epilogue == 1 ? aux_out != nullptr : aux_in != nullptr), PTC_EINVAL, "ptc_linear_fwd_ex: null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PTC_BF16) return dispatch_fwd2<bf16_t>(in, weight, bias, nullptr, n, 1, c_in, c_out, out, s, epilogue, aux_in, aux_out);
+  return dispatch_fwd2<f16_t>(in, weight, bias, nullptr, n, 1, c_in, c_out, out, s, epilogue, aux_in, aux_out);
+}
+
 // ------------------------------------------------------------------------------------------------
 // wgrad: dw[co][k][ci] = sum_o dout[o][co] * in[nbr[k][o]][ci]
 // grid = (splits, kv, channel tiles of 64x64).  The contraction runs over ROWS, so both operands

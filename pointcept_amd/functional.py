@@ -439,3 +439,73 @@ def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, tra
     """act(F.batch_norm(x, ...)) over the rows of [N, C] (act in {"none", "gelu", "relu"}), statistics in
     fp32/fp64, output in x's dtype; backward recomputes the pre-activation (nothing but x is saved)."""
     return _BatchNormAct.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps), act)
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP (fc1 -> GELU -> fc2) with the activation fused into the GEMM epilogues
+# ------------------------------------------------------------------------------------------------
+class _MLP(Function):
+    """out = GELU(x W1^T + b1) W2^T + b2 (ptv3m1:225-248, dropout p = 0).  GELU rides in fc1's epilogue (h and
+    GELU(h) leave the kernel together) and GELU' in the epilogue of fc2's input gradient (the gradient reaches
+    HBM already multiplied through the activation): the two elementwise kernels of the unfused form, and the
+    dA tensor, disappear.  Weight gradients run on the split-K kernels as in `linear`."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        dt = torch.get_autocast_dtype("cuda") if _autocast_on() else x.dtype
+        xp = x.to(dt).contiguous()
+        w1c, w2c = _cast_cache.get(w1, dt).contiguous(), _cast_cache.get(w2, dt).contiguous()
+        h, a = ops.linear_gelu_fwd(xp, w1c, b1)
+        if _own_gemm(a.shape[0], a.shape[1], dt):
+            out = ops.spconv_fwd(a, w2c[:, None, :], None if b2 is None else b2.float(), None)
+        else:
+            out = F.linear(a, w2c, None if b2 is None else b2.to(dt))
+        ctx.save_for_backward(xp, h, a, w1c, w2c)
+        ctx.dtypes = (x.dtype, w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        xp, h, a, w1c, w2c = ctx.saved_tensors
+        x_dt, w1_dt, b1_dt, w2_dt, b2_dt = ctx.dtypes
+        g = dout.to(xp.dtype).contiguous()
+        n = g.shape[0]
+        # fc2: weight / bias gradients, then the input gradient THROUGH the activation
+        if n >= _OWN_WGRAD_MIN_ROWS:
+            res = ops.spconv_wgrad(a, g, None, want_bias=b2_dt is not None)
+            dw2, db2 = res if b2_dt is not None else (res, None)
+            dw2 = dw2[:, 0, :]
+        else:
+            dw2 = (g.t() @ a).float()
+            db2 = ops.column_sum(g) if b2_dt is not None else None
+        dh = ops.linear_gelu_bwd_input(g, w2c.t().contiguous(), h)
+        # fc1
+        if n >= _OWN_WGRAD_MIN_ROWS:
+            res = ops.spconv_wgrad(xp, dh, None, want_bias=b1_dt is not None)
+            dw1, db1 = res if b1_dt is not None else (res, None)
+            dw1 = dw1[:, 0, :]
+        else:
+            dw1 = (dh.t() @ xp).float()
+            db1 = ops.column_sum(dh) if b1_dt is not None else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if _own_gemm(n, dh.shape[1], xp.dtype):
+                dx = ops.spconv_fwd(dh, w1c.t().contiguous()[:, None, :], None, None)
+            else:
+                dx = dh @ w1c
+            dx = dx.to(x_dt)
+        return (dx, dw1.to(w1_dt), None if db1 is None else db1.to(b1_dt), dw2.to(w2_dt), None if db2 is None else db2.to(b2_dt))
+
+
+def mlp_gelu_supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
+    if not (x.is_cuda and x.dim() == 2 and x.shape[0] > 0):
+        return False
+    dt = torch.get_autocast_dtype("cuda") if _autocast_on() else x.dtype
+    hidden, c = w1.shape
+    return (dt in (torch.bfloat16, torch.float16) and c % 16 == 0 and hidden % 16 == 0 and w2.shape[0] % 16 == 0
+            and ops.linear_supported_ex(c, hidden, dt) and ops.linear_supported_ex(w2.shape[0], hidden, dt))
+
+
+def mlp_gelu(x, w1, b1, w2, b2):
+    return _MLP.apply(x, w1, b1, w2, b2)

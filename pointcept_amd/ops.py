@@ -538,3 +538,36 @@ def column_sum(x: torch.Tensor) -> torch.Tensor:
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     check(lib().ptc_column_sum(ptr(x), n, c, dtype_code(x), ptr(out), ptr(ws), nbytes, stream_ptr()), "ptc_column_sum")
     return out
+
+
+def linear_supported_ex(c_in: int, c_out: int, dtype: torch.dtype) -> bool:
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    code = _lib.PTC_F16 if dtype == torch.float16 else _lib.PTC_BF16
+    return bool(lib().ptc_linear_supported_ex(int(c_in), int(c_out), code))
+
+
+def linear_gelu_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """(h, a) = (x W^T + b, GELU(h)) in one kernel; x [N, C_in], weight [C_out, C_in] (both bf16 / f16)."""
+    require_cuda(x, weight, bias)
+    x, weight = x.contiguous(), weight.contiguous()
+    n, c_in = x.shape
+    c_out = weight.shape[0]
+    h = torch.empty((n, c_out), dtype=x.dtype, device=x.device)
+    a = torch.empty((n, c_out), dtype=x.dtype, device=x.device)
+    b = None if bias is None else bias.to(torch.float32).contiguous()
+    check(lib().ptc_linear_fwd_ex(ptr(x), n, ptr(weight), ptr(b), c_in, c_out, dtype_code(x), 1, 0, ptr(h), ptr(a), stream_ptr()),
+          "ptc_linear_fwd_ex")
+    return h, a
+
+
+def linear_gelu_bwd_input(g: torch.Tensor, weight_t: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    """dh = (g W) * GELU'(h) in one kernel; g [N, C_out2], weight_t [hidden, C_out2] (= W2^T), h [N, hidden]."""
+    require_cuda(g, weight_t, h)
+    g, weight_t, h = g.contiguous(), weight_t.contiguous(), h.contiguous()
+    n, c_in = g.shape
+    c_out = weight_t.shape[0]
+    out = torch.empty((n, c_out), dtype=g.dtype, device=g.device)
+    check(lib().ptc_linear_fwd_ex(ptr(g), n, ptr(weight_t), 0, c_in, c_out, dtype_code(g), 2, ptr(h), ptr(out), 0, stream_ptr()),
+          "ptc_linear_fwd_ex")
+    return out

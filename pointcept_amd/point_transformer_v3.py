@@ -199,6 +199,9 @@ class MLP(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
+        if (config.FUSE_MLP and self.drop.p == 0.0 and type(self.act) in (nn.GELU, PNN.GELU) and getattr(self.act, "approximate", "none") == "none"
+                and isinstance(self.fc1, PNN.Linear) and PF.mlp_gelu_supported(x, self.fc1.weight, self.fc2.weight)):
+            return PF.mlp_gelu(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)   # GELU in the GEMM epilogues
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 

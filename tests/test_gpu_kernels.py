@@ -717,3 +717,35 @@ def test_column_sum(cuda, dtype, n, c):
     ref = x.double().sum(0)
     _close("column_sum", got.double(), ref, 1e-5, 1e-4 * max(1.0, float(ref.abs().max())))
     assert got.dtype == torch.float32
+
+
+@pytest.mark.parametrize("n,c", [(5000, 32), (4097, 64), (1000, 128), (333, 256)])
+def test_mlp_gelu_fused(cuda, n, c):
+    """fc1 -> GELU -> fc2 with GELU / GELU' fused into the GEMM epilogues vs torch fp32 on the same rounded
+    operands (bf16 autocast): output, input gradient, all four parameter gradients."""
+    from pointcept_amd import functional as PF
+
+    g = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, c, generator=g)).to(torch.bfloat16)
+    w1 = torch.randn(4 * c, c, generator=g) / c ** 0.5
+    b1 = torch.randn(4 * c, generator=g) * 0.1
+    w2 = torch.randn(c, 4 * c, generator=g) / (4 * c) ** 0.5
+    b2 = torch.randn(c, generator=g) * 0.1
+    dy = torch.randn(n, c, generator=g).to(torch.bfloat16)
+    ps = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    xr = x.float().clone().requires_grad_(True)
+    rnd = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    h = rnd(xr @ rnd(ps[0]).t() + ps[1])
+    a = rnd(torch.nn.functional.gelu(h))
+    ref = a @ rnd(ps[2]).t() + ps[3]
+    ref.backward(dy.float())
+    pg = [t.to(cuda).requires_grad_(True) for t in (w1, b1, w2, b2)]
+    xg = x.to(cuda).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert PF.mlp_gelu_supported(xg, pg[0], pg[2])
+        out = PF.mlp_gelu(xg, *pg)
+    out.backward(dy.to(cuda))
+    _close("mlp_out", out, ref, 2.0 ** -7, 2e-2)
+    _close("mlp_dx", xg.grad, xr.grad, 2.0 ** -6, 2e-2 * float(xr.grad.abs().max()))
+    for name, a_, b_ in zip(("dw1", "db1", "dw2", "db2"), pg, ps):
+        _close("mlp_" + name, a_.grad, b_.grad, 2.0 ** -6, 2e-2 * float(b_.grad.abs().max()))
