@@ -165,18 +165,17 @@ int ptc_segment_csr_bwd(const void* grad_out, const int64_t* perm, const int64_t
  * (call sites: ptv3m1:278-284,499-506; spconv_unet_v1m1_base.py:43-68,114-121,137-144,173-179).
  * Canonical form: gather tables nbr[kv][n_out] int32, -1 = no input.
  *   indices : [n,4] int32 (batch,x,y,z)  (SparseConvTensor.indices, structure.py:139-143)
- * Hash table: open addressing, 64-bit packed key, value = LOWEST row index with that
+ * Voxel table (opaque, caller-allocated, 64-byte aligned, ptc_hash_table_bytes(n) bytes): open addressing
+ * over 64-byte BUCKETS of 2x2x2 voxels { block key, 8 row indices }; row = LOWEST row index with that
  * coordinate (duplicate voxels after Mix3D: lowest index wins).
- *   table_size must be a power of two >= 2*n.  keys buffer: table_size*8 B, vals: table_size*4 B.
  * ------------------------------------------------------------------------------------------ */
-int64_t ptc_hash_table_size(int64_t n);
-int ptc_hash_build(const int32_t* indices, int64_t n, uint64_t* table_keys, int32_t* table_vals,
-                   int64_t table_size, ptc_stream_t stream);
+int64_t ptc_hash_table_size(int64_t n);   /* number of buckets */
+size_t ptc_hash_table_bytes(int64_t n);
+int ptc_hash_build(const int32_t* indices, int64_t n, void* table, size_t table_bytes, ptc_stream_t stream);
 /* SubM: nbr[k][i] = row at coord_i + delta_k, k = ((d0+r)*ks + (d1+r))*ks + (d2+r), r = ks/2,
  * (d0,d1,d2) applied to (x,y,z) = indices columns 1..3 (cross-correlation convention). */
-int ptc_rulebook_subm(const int32_t* indices, int64_t n, int ksize, const uint64_t* table_keys,
-                      const int32_t* table_vals, int64_t table_size, int32_t* nbr,
-                      ptc_stream_t stream);
+int ptc_rulebook_subm(const int32_t* indices, int64_t n, int ksize, const void* table, size_t table_bytes,
+                      int32_t* nbr, ptc_stream_t stream);
 /* Strided k=2,s=2 (SparseConv3d at spconv_unet_v1m1_base.py:137-144).
  * Phase 1: out_of_in[n_in] int32 = coarse row of each fine row, numbering = ascending
  *          (batch, x>>1, y>>1, z>>1) linear key; *n_out_dev (device int64) = number of coarse rows.

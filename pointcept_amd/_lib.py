@@ -36,8 +36,9 @@ _SIGNATURES = {
     "ptc_segment_csr_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "ptc_segment_csr_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
     "ptc_hash_table_size": (c_i64, [c_i64]),
-    "ptc_hash_build": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr]),
-    "ptc_rulebook_subm": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    "ptc_hash_table_bytes": (c_size, [c_i64]),
+    "ptc_hash_build": (c_int, [c_ptr, c_i64, c_ptr, c_size, c_ptr]),
+    "ptc_rulebook_subm": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_size, c_ptr, c_ptr]),
     "ptc_rulebook_down_workspace_bytes": (c_size, [c_i64]),
     "ptc_rulebook_down_count": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_rulebook_down_fill": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),

@@ -14,24 +14,43 @@ extern "C" size_t ptc_sort_keys_workspace_bytes(int64_t, int);
 extern "C" size_t ptc_exclusive_scan_workspace_bytes(int64_t);
 extern "C" int ptc_exclusive_scan_i32(const int32_t*, int64_t, int64_t*, void*, size_t, ptc_stream_t);
 
-extern "C" int64_t ptc_hash_table_size(int64_t n) {
+// ---- voxel table: open addressing over BUCKETS of 2x2x2 voxels ------------------------------------
+// One 64-byte bucket = { block key (b, x>>1, y>>1, z>>1) | 8 row indices, one per voxel of the block }.
+// A 3^3 window touches at most 8 buckets and a 5^3 window 27 -- one cache line each -- where the
+// voxel-per-slot table of r01 needed 27 / 125 unrelated lines (k = 5: 1.36 ms, 4 % of the HBM roofline).
+// Buckets are placed by the murmur finalizer of the block key (uniform homes: a locality-preserving
+// "block-local" home was tried and made linear probing 4-6x slower); at most one bucket per occupied block,
+// and there are never more occupied blocks than voxels, so n_buckets = pow2 >= n keeps the load <= 1 and
+// typically ~1/3.  Duplicate voxels: lowest row index wins (atomicMin).
+struct __attribute__((aligned(64))) VoxBucket {
+  unsigned long long key;
+  unsigned int pad[2];
+  unsigned int vals[8];
+  unsigned int pad2[4];
+};
+static_assert(sizeof(VoxBucket) == 64, "bucket = one 64-byte line");
+
+extern "C" int64_t ptc_hash_table_size(int64_t n) {   // number of buckets
   int64_t t = 1024;
-  while (t < 2 * n) t <<= 1;
+  while (t < n) t <<= 1;
   return t;
 }
+extern "C" size_t ptc_hash_table_bytes(int64_t n) { return (size_t)ptc_hash_table_size(n) * sizeof(VoxBucket); }
+
+__device__ __forceinline__ unsigned long long vox_block_key(int b, int x, int y, int z) { return ptc_vox_pack(b, x >> 1, y >> 1, z >> 1); }
+__device__ __forceinline__ int vox_local(int x, int y, int z) { return ((x & 1) << 2) | ((y & 1) << 1) | (z & 1); }
 
 __global__ void __launch_bounds__(256)
-hash_insert_kernel(const int32_t* __restrict__ indices, int64_t n, unsigned long long* __restrict__ keys,
-                   unsigned int* __restrict__ vals, uint64_t mask) {
+hash_insert_kernel(const int32_t* __restrict__ indices, int64_t n, VoxBucket* __restrict__ table, uint64_t mask) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int4 c = reinterpret_cast<const int4*>(indices)[i];
-    const unsigned long long key = ptc_vox_pack(c.x, c.y, c.z, c.w);
+    const unsigned long long key = vox_block_key(c.x, c.y, c.z, c.w);
     uint64_t slot = ptc_vox_home(key) & mask;
     for (uint64_t probe = 0; probe <= mask; ++probe) {
-      const unsigned long long prev = atomicCAS(&keys[slot], (unsigned long long)PTC_HASH_EMPTY, key);
+      const unsigned long long prev = atomicCAS(&table[slot].key, (unsigned long long)PTC_HASH_EMPTY, key);
       if (prev == PTC_HASH_EMPTY || prev == key) {
-        atomicMin(&vals[slot], (unsigned int)i);  // duplicate voxels: lowest row index wins
+        atomicMin(&table[slot].vals[vox_local(c.y, c.z, c.w)], (unsigned int)i);  // duplicate voxels: lowest row index wins
         break;
       }
       slot = (slot + 1) & mask;
@@ -39,101 +58,85 @@ hash_insert_kernel(const int32_t* __restrict__ indices, int64_t n, unsigned long
   }
 }
 
-__device__ __forceinline__ int32_t hash_lookup(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
-                                               uint64_t mask, uint64_t key) {
-  uint64_t slot = ptc_vox_home(key) & mask;
-  for (uint64_t probe = 0; probe <= mask; ++probe) {
-    const uint64_t k = keys[slot];
-    if (k == key) return vals[slot];
-    if (k == PTC_HASH_EMPTY) return -1;
-    slot = (slot + 1) & mask;
-  }
-  return -1;
-}
-
-extern "C" int ptc_hash_build(const int32_t* indices, int64_t n, uint64_t* table_keys, int32_t* table_vals,
-                              int64_t table_size, ptc_stream_t stream) {
+extern "C" int ptc_hash_build(const int32_t* indices, int64_t n, void* table, size_t table_bytes, ptc_stream_t stream) {
   PTC_REQUIRE(n >= 0, PTC_EINVAL, "ptc_hash_build: n < 0");
-  PTC_REQUIRE(table_size >= 2 * n && table_size >= 2 && (table_size & (table_size - 1)) == 0, PTC_EINVAL,
-              "ptc_hash_build: table_size %lld must be a power of two >= 2n", (long long)table_size);
   PTC_REQUIRE(n < (1ll << 31), PTC_EUNSUPPORTED, "ptc_hash_build: n >= 2^31");
-  PTC_REQUIRE(table_keys && table_vals && (n == 0 || indices), PTC_EINVAL, "ptc_hash_build: null buffer");
+  PTC_REQUIRE(table && table_bytes >= ptc_hash_table_bytes(n) && (n == 0 || indices), PTC_EINVAL, "ptc_hash_build: null / short buffer");
+  PTC_REQUIRE((uintptr_t)table % 64 == 0, PTC_EINVAL, "ptc_hash_build: table must be 64-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  PTC_HIP(hipMemsetAsync(table_keys, 0xff, (size_t)table_size * 8, s));
-  PTC_HIP(hipMemsetAsync(table_vals, 0xff, (size_t)table_size * 4, s));
+  const int64_t nb = ptc_hash_table_size(n);
+  PTC_HIP(hipMemsetAsync(table, 0xff, (size_t)nb * sizeof(VoxBucket), s));   // keys EMPTY, rows -1
   if (n == 0) return PTC_OK;
   int64_t grid = ptc_cdiv(n, 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(hash_insert_kernel, dim3((unsigned)grid), dim3(256), 0, s, indices, n,
-                     (unsigned long long*)table_keys, (unsigned int*)table_vals, (uint64_t)(table_size - 1));
+  hipLaunchKernelGGL(hash_insert_kernel, dim3((unsigned)grid), dim3(256), 0, s, indices, n, (VoxBucket*)table, (uint64_t)(nb - 1));
   PTC_CHECK_LAUNCH("hash_insert_kernel");
   return PTC_OK;
 }
 
-// One thread per voxel, all ks^3 probes.  Consecutive lanes hold voxels that are neighbours along the
-// serialization curve, and neighbouring voxels share most of their windows (18 of 27 cells for a face
-// neighbour): the cells a wave probes are re-probed by the same wave within microseconds and hit L1/L2,
-// instead of being touched once per offset in 27 / 125 separate sweeps over the 24 MB table (the
-// offset-major mapping of r01: 1.76 ms for k = 5, 3 % of the HBM roofline).  The ks probes along z of one (dx,dy) column are issued together (ks independent loads in
-// flight); nbr[k][i] stores are coalesced across lanes for every k.
+// One thread per voxel.  Its ks^3 window spans NB = ks/2 + 1 blocks per axis; each block is ONE bucket probe
+// (key compare) and, on a hit, one 32-byte read of its 8 row indices, which are then scattered to the window
+// offsets they belong to.  Consecutive lanes hold neighbouring voxels (curve order), so the handful of
+// buckets of a window is shared by the whole wave and served by L1/L2.
 template <int KS>
 __global__ void __launch_bounds__(256)
-rulebook_subm_kernel(const int32_t* __restrict__ indices, int64_t n, const uint64_t* __restrict__ keys,
-                     const int32_t* __restrict__ vals, uint64_t mask, int32_t* __restrict__ nbr) {
-  constexpr int R = KS / 2;
+rulebook_subm_kernel(const int32_t* __restrict__ indices, int64_t n, const VoxBucket* __restrict__ table, uint64_t mask,
+                     int32_t* __restrict__ nbr) {
+  constexpr int R = KS / 2, NB = R + 1;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int4 c = reinterpret_cast<const int4*>(indices)[i];
+    const int bx0 = (c.y - R) >> 1, by0 = (c.z - R) >> 1, bz0 = (c.w - R) >> 1;   // arithmetic shift: floor for negatives
+    const int ex = c.y - 2 * bx0, ey = c.z - 2 * by0, ez = c.w - 2 * bz0;         // R or R + 1
 #pragma unroll 1
-    for (int a = 0; a < KS * KS; ++a) {
-      const int d0 = a / KS - R, d1 = a % KS - R;
-      const int x = c.y + d0, y = c.z + d1;
-      uint64_t key[KS], slot[KS], got[KS];
-      bool ok[KS];
-#pragma unroll
-      for (int b = 0; b < KS; ++b) {
-        const int z = c.w + b - R;
-        ok[b] = ptc_vox_in_range(x, y, z);
-        key[b] = ptc_vox_pack(c.x, x, y, z);
-        slot[b] = ptc_vox_home(key[b]) & mask;
-        got[b] = ok[b] ? keys[slot[b]] : PTC_HASH_EMPTY;
-      }
-#pragma unroll
-      for (int b = 0; b < KS; ++b) {
-        int32_t j = -1;
-        if (got[b] == key[b]) {
-          j = vals[slot[b]];
-        } else if (got[b] != PTC_HASH_EMPTY) {   // collision: continue the linear probe
-          uint64_t sl = (slot[b] + 1) & mask;
-          for (uint64_t probe = 1; probe <= mask; ++probe) {
-            const uint64_t kk = keys[sl];
-            if (kk == key[b]) { j = vals[sl]; break; }
-            if (kk == PTC_HASH_EMPTY) break;
-            sl = (sl + 1) & mask;
+    for (int ob = 0; ob < NB * NB * NB; ++ob) {
+      const int o0 = ob / (NB * NB), o1 = (ob / NB) % NB, o2 = ob % NB;
+      const int bx = bx0 + o0, by = by0 + o1, bz = bz0 + o2;
+      uint4 v0 = make_uint4(~0u, ~0u, ~0u, ~0u), v1 = v0;
+      if (bx >= 0 && by >= 0 && bz >= 0 && bx < (PTC_VOX_MAX >> 1) && by < (PTC_VOX_MAX >> 1) && bz < (PTC_VOX_MAX >> 1)) {
+        const unsigned long long key = ptc_vox_pack(c.x, bx, by, bz);
+        uint64_t slot = ptc_vox_home(key) & mask;
+        for (uint64_t probe = 0; probe <= mask; ++probe) {
+          const unsigned long long kk = table[slot].key;
+          if (kk == key) {
+            const uint4* pv = reinterpret_cast<const uint4*>(table[slot].vals);
+            v0 = pv[0];
+            v1 = pv[1];
+            break;
           }
+          if (kk == PTC_HASH_EMPTY) break;
+          slot = (slot + 1) & mask;
         }
-        nbr[(int64_t)(a * KS + b) * n + i] = j;
+      }
+      const unsigned int vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int cell = 0; cell < 8; ++cell) {
+        const int d0 = 2 * o0 + (cell >> 2) - ex, d1 = 2 * o1 + ((cell >> 1) & 1) - ey, d2 = 2 * o2 + (cell & 1) - ez;
+        if (d0 >= -R && d0 <= R && d1 >= -R && d1 <= R && d2 >= -R && d2 <= R) {
+          const int k = ((d0 + R) * KS + (d1 + R)) * KS + (d2 + R);
+          nbr[(int64_t)k * n + i] = (int32_t)vv[cell];
+        }
       }
     }
   }
 }
 
-extern "C" int ptc_rulebook_subm(const int32_t* indices, int64_t n, int ksize, const uint64_t* table_keys,
-                                 const int32_t* table_vals, int64_t table_size, int32_t* nbr, ptc_stream_t stream) {
+extern "C" int ptc_rulebook_subm(const int32_t* indices, int64_t n, int ksize, const void* table, size_t table_bytes, int32_t* nbr,
+                                 ptc_stream_t stream) {
   PTC_REQUIRE(n >= 0, PTC_EINVAL, "ptc_rulebook_subm: n < 0");
   PTC_REQUIRE(ksize >= 1 && ksize <= 7 && (ksize & 1), PTC_EUNSUPPORTED, "ptc_rulebook_subm: ksize %d (odd, <= 7)", ksize);
-  PTC_REQUIRE(table_size >= 2 && (table_size & (table_size - 1)) == 0, PTC_EINVAL, "ptc_rulebook_subm: bad table_size");
   if (n == 0) return PTC_OK;
-  PTC_REQUIRE(indices && table_keys && table_vals && nbr, PTC_EINVAL, "ptc_rulebook_subm: null buffer");
+  PTC_REQUIRE(indices && table && nbr && table_bytes >= ptc_hash_table_bytes(n), PTC_EINVAL, "ptc_rulebook_subm: null / short buffer");
   int64_t grid = ptc_cdiv(n, 256);
   if (grid > 256 * 64) grid = 256 * 64;
-  const uint64_t mask = (uint64_t)(table_size - 1);
+  const uint64_t mask = (uint64_t)(ptc_hash_table_size(n) - 1);
+  const VoxBucket* tb = (const VoxBucket*)table;
   hipStream_t s = (hipStream_t)stream;
   switch (ksize) {
-    case 1: hipLaunchKernelGGL(rulebook_subm_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, table_keys, table_vals, mask, nbr); break;
-    case 3: hipLaunchKernelGGL(rulebook_subm_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, table_keys, table_vals, mask, nbr); break;
-    case 5: hipLaunchKernelGGL(rulebook_subm_kernel<5>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, table_keys, table_vals, mask, nbr); break;
-    default: hipLaunchKernelGGL(rulebook_subm_kernel<7>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, table_keys, table_vals, mask, nbr); break;
+    case 1: hipLaunchKernelGGL(rulebook_subm_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
+    case 3: hipLaunchKernelGGL(rulebook_subm_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
+    case 5: hipLaunchKernelGGL(rulebook_subm_kernel<5>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
+    default: hipLaunchKernelGGL(rulebook_subm_kernel<7>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
   }
   PTC_CHECK_LAUNCH("rulebook_subm_kernel");
   return PTC_OK;

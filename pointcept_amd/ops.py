@@ -203,12 +203,10 @@ class HashTable:
             raise PtcoreError("indices must be int32 [N,4] (batch,x,y,z)")
         self.indices = indices.contiguous()
         n = self.indices.shape[0]
-        self.size = int(lib().ptc_hash_table_size(n))
-        dev = indices.device
-        self.keys = torch.empty(self.size, dtype=torch.int64, device=dev)
-        self.vals = torch.empty(self.size, dtype=torch.int32, device=dev)
-        check(lib().ptc_hash_build(ptr(self.indices), n, ptr(self.keys), ptr(self.vals), self.size, stream_ptr()),
-              "ptc_hash_build")
+        self.size = int(lib().ptc_hash_table_size(n))            # buckets of 2x2x2 voxels, 64 bytes each
+        self.nbytes = int(lib().ptc_hash_table_bytes(n))
+        self.buf = torch.empty(self.nbytes // 8, dtype=torch.int64, device=indices.device)   # torch allocations are >= 256 B aligned
+        check(lib().ptc_hash_build(ptr(self.indices), n, ptr(self.buf), self.nbytes, stream_ptr()), "ptc_hash_build")
 
 
 def rulebook_subm(indices: torch.Tensor, ksize: int, table: Optional[HashTable] = None) -> torch.Tensor:
@@ -218,8 +216,8 @@ def rulebook_subm(indices: torch.Tensor, ksize: int, table: Optional[HashTable] 
     ind = table.indices
     n = ind.shape[0]
     nbr = torch.empty((ksize ** 3, n), dtype=torch.int32, device=ind.device)
-    check(lib().ptc_rulebook_subm(ptr(ind), n, int(ksize), ptr(table.keys), ptr(table.vals), table.size, ptr(nbr),
-                                  stream_ptr()), "ptc_rulebook_subm")
+    check(lib().ptc_rulebook_subm(ptr(ind), n, int(ksize), ptr(table.buf), table.nbytes, ptr(nbr), stream_ptr()),
+          "ptc_rulebook_subm")
     return nbr
 
 
