@@ -749,3 +749,129 @@ def test_mlp_gelu_fused(cuda, n, c):
     _close("mlp_dx", xg.grad, xr.grad, 2.0 ** -6, 2e-2 * float(xr.grad.abs().max()))
     for name, a_, b_ in zip(("dw1", "db1", "dw2", "db2"), pg, ps):
         _close("mlp_" + name, a_.grad, b_.grad, 2.0 ** -6, 2e-2 * float(b_.grad.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# K. BASELINE full size (8 x 102400 voxels): size-independent properties (the oracle is too slow here)
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_scene(cuda):
+    from pointcept_amd import ops, synthetic
+
+    b = synthetic.indoor_batch(8, 102400)
+    ind = np.concatenate([omaps.offset2batch(b["offset"])[:, None], b["grid_coord"]], axis=1).astype(np.int32)
+    ind_t = _t(ind, cuda)
+    table = ops.HashTable(ind_t)
+    return ind_t, table, ops.rulebook_subm(ind_t, 3, table)
+
+
+def test_full_size_rulebook_properties(cuda, full_scene):
+    """k=3 and k=5 tables of the bench batch: centre column is the identity, entries are in range, the map is
+    symmetric (nbr[k][i] = j <=> nbr[K-1-k][j] = i: the property dgrad relies on), pairs/voxel matches the count of
+    occupied neighbour cells computed independently (sorted-key membership test on the device)."""
+    from pointcept_amd import ops
+
+    ind, table, nbr3 = full_scene
+    n = ind.shape[0]
+    ar = torch.arange(n, device=cuda, dtype=torch.int32)
+    for ks, nbr in ((3, nbr3), (5, ops.rulebook_subm(ind, 5, table))):
+        kv = ks ** 3
+        assert nbr.shape == (kv, n) and bool((nbr[kv // 2] == ar).all())
+        assert int(nbr.max()) < n and int(nbr.min()) >= -1
+        for k in (0, 1, kv // 3, kv // 2 - 1):   # spot-check the symmetry on a few offsets (all rows of those offsets)
+            j = nbr[k].long()
+            valid = j >= 0
+            back = nbr[kv - 1 - k][j[valid]]
+            assert bool((back == ar[valid]).all())
+        # independent pair count for offset (+1, 0, 0): key membership
+        ind64 = ind.long()
+        key = ((ind64[:, 0] << 54) | (ind64[:, 1] << 36) | (ind64[:, 2] << 18) | ind64[:, 3])
+        skey = torch.sort(key).values
+        r = ks // 2
+        q = key + (1 << 36)
+        pos = torch.searchsorted(skey, q).clamp(max=n - 1)
+        cnt = int((skey[pos] == q).sum())
+        k_plus_x = ((1 + r) * ks + r) * ks + r
+        assert int((nbr[k_plus_x] >= 0).sum()) == cnt
+
+
+@pytest.mark.parametrize("c", [64, 96])
+def test_full_size_conv_is_a_gather_for_one_hot_weights(cuda, full_scene, c):
+    """W = identity at ONE offset, zero elsewhere: the convolution must reproduce in[nbr[k]] BIT-EXACTLY (products with
+    1.0 and sums with 0.0 are exact in the MFMA): checks tables, gathers, chunk pipeline and epilogue at full size."""
+    from pointcept_amd import ops
+
+    ind, table, nbr = full_scene
+    n = ind.shape[0]
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(n, c, generator=g).to(torch.bfloat16).to(cuda)
+    for k in (13, 4, 26):
+        w = torch.zeros(c, 27, c, dtype=torch.bfloat16)
+        w[:, k, :] = torch.eye(c, dtype=torch.bfloat16)
+        out = ops.spconv_fwd(x, w.to(cuda), None, nbr)
+        idx = nbr[k].long()
+        ref = torch.where((idx >= 0)[:, None], x[idx.clamp(min=0)], torch.zeros_like(x[:1]))
+        assert torch.equal(out, ref), f"offset {k}"
+
+
+def test_full_size_wgrad_counts_pairs(cuda, full_scene):
+    """in = ones, dout = ones: dw[co][k][ci] = number of (output, input) pairs of offset k, exactly (integers < 2^24)."""
+    from pointcept_amd import ops
+
+    ind, table, nbr = full_scene
+    n = ind.shape[0]
+    ones = torch.ones(n, 64, dtype=torch.bfloat16, device=cuda)
+    dw = ops.spconv_wgrad(ones, ones, nbr)
+    cnt = (nbr >= 0).sum(1).float()
+    assert dw.shape == (64, 27, 64)
+    assert torch.equal(dw, cnt[None, :, None].expand(64, 27, 64))
+
+
+def test_full_size_attention_properties(cuda):
+    """800 sequences x 1024 x 4 heads: (a) V constant per sequence-head -> output equals that constant (softmax rows sum
+    to one), (b) lse is invariant... shifts by log of the key count for zero queries, (c) backward of a constant V field
+    gives dQ = dK = 0 (the gradient through a row-stochastic matrix applied to a constant vanishes)."""
+    from pointcept_amd import ops
+
+    n_seq, L, H = 800, 1024, 4
+    T = n_seq * L
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(T, 3, H, 16, generator=g).to(torch.bfloat16)
+    const = torch.randn(n_seq, 1, H, 16, generator=g).to(torch.bfloat16)
+    qkv[:, 2] = const.expand(n_seq, L, H, 16).reshape(T, H, 16)
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32)
+    out, lse = ops.attn_varlen_fwd(qkv.to(cuda), cu.to(cuda), L, 0.25)
+    ref = const.expand(n_seq, L, H, 16).reshape(T, H, 16).to(cuda)
+    _close("attn_const_v", out, ref.float(), 2.0 ** -7, 1e-3)
+    zq = qkv.clone()
+    zq[:, 0] = 0
+    _, lse0 = ops.attn_varlen_fwd(zq.to(cuda), cu.to(cuda), L, 0.25)
+    _close("attn_lse_zero_q", lse0, torch.full_like(lse0, float(np.log(L))), 1e-4, 1e-3)
+    dout = torch.randn(T, H, 16, generator=g).to(torch.bfloat16).to(cuda)
+    dqkv = ops.attn_varlen_bwd(qkv.to(cuda), out, dout, lse, cu.to(cuda), L, 0.25)
+    scale = float(dout.float().abs().max())
+    assert float(dqkv[:, 0].float().abs().max()) <= 3e-2 * scale   # bf16 P / dP rounding noise only
+    assert float(dqkv[:, 1].float().abs().max()) <= 3e-2 * scale
+
+
+@pytest.mark.parametrize("n", [1, 5, 17, 33, 129])
+def test_conv_tiny_inputs(cuda, n):
+    """row counts below one tile / one workgroup, through the chunked-pipeline kernel and the weight gradient"""
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(n)
+    coords = torch.stack([torch.zeros(n, dtype=torch.int64), torch.arange(n) % 4, (torch.arange(n) // 4) % 4, torch.arange(n) // 16], 1)
+    ind = coords.numpy().astype(np.int32)
+    nbr = oops.subm_rulebook(ind, 3)
+    got_nbr = ops.rulebook_subm(_t(ind, cuda), 3)
+    assert np.array_equal(got_nbr.cpu().numpy(), nbr)
+    feat = torch.randn(n, 64, generator=g).to(torch.bfloat16)
+    w = (torch.randn(64, 27, 64, generator=g) * 0.05).to(torch.bfloat16)
+    ref = oops.gather_conv(feat.float(), w.float(), None, nbr)
+    got = ops.spconv_fwd(feat.to(cuda), w.to(cuda), None, got_nbr)
+    _close("conv_tiny", got, ref, 1.0 / 128, 2e-3)
+    dout = torch.randn(n, 64, generator=g).to(torch.bfloat16)
+    wr = w.float().requires_grad_(True)
+    oops.gather_conv(feat.float(), wr, None, nbr).backward(dout.float())
+    dw = ops.spconv_wgrad(feat.to(cuda), dout.to(cuda), got_nbr)
+    _close("wgrad_tiny", dw, wr.grad, 1e-4, 1e-3 * float(wr.grad.abs().max()) + 1e-6)
