@@ -110,6 +110,15 @@ int ptc_patch_pad_maps(const int64_t* offset, int B, int patch, int64_t n, int64
                        int64_t n_seq, int64_t* pad, int64_t* unpad, int32_t* cu_seqlens,
                        int64_t* dup, ptc_stream_t stream);
 
+/* C2. int32 gather tables of ONE serialization order for the gather-fused qkv / proj GEMMs (the index algebra of
+ * SerializedAttention.forward, ptv3m1:184-188,216, and of its backward) in one launch:
+ *   t_qkv_fwd [n_pad] = order[pad[s]];  t_qkv_bwd [2][n] = (unpad[inverse[p]], dup[inverse[p]]);
+ *   t_proj_fwd [n] = unpad[inverse[p]];  t_proj_bwd [n_pad] = point of slot s if s is its primary slot, else -1.
+ * order / inverse: one row of serialized_order / serialized_inverse; pad / unpad / dup from ptc_patch_pad_maps. */
+int ptc_attn_tables(const int64_t* order, const int64_t* inverse, const int64_t* pad, const int64_t* unpad,
+                    const int64_t* dup, int64_t n, int64_t n_pad, int32_t* t_qkv_fwd, int32_t* t_qkv_bwd,
+                    int32_t* t_proj_fwd, int32_t* t_proj_bwd, ptc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * D. Serialized pooling maps.
  * Replaces the index arithmetic of SerializedPooling.forward,

@@ -28,6 +28,7 @@ _SIGNATURES = {
     "ptc_exclusive_scan_workspace_bytes": (c_size, [c_i64]),
     "ptc_exclusive_scan_i32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_patch_pad_maps": (c_int, [c_ptr, c_int, c_int, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "ptc_attn_tables": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_pool_maps_workspace_bytes": (c_size, [c_i64]),
     "ptc_pool_maps_count": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_pool_maps_fill": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),

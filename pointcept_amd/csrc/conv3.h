@@ -211,10 +211,10 @@ template <typename T>
 static int launch_conv3(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
                         int c_out, void* out, hipStream_t s) {
   // 64 output channels per workgroup (96 when c_out is a multiple of 96 but not of 64 -- SpUNet's decoder --
-  // else 32); 256-row workgroups when they still give every CU two workgroups, else 128-row ones
+  // else 32); 256-row workgroups when they still give every CU a workgroup, else 128-row ones
   // (PTC_CONV3_RT=2|4 forces the choice: used by the tests to reach both instantiations at small n)
   const int nt = c_out % 64 == 0 ? 4 : (c_out % 96 == 0 ? 6 : 2);
-  bool big = ptc_cdiv(n_out, 256) * (c_out / (nt * 16)) >= 512;
+  bool big = ptc_cdiv(n_out, 256) * (c_out / (nt * 16)) >= 256;   // >= one 256-row workgroup per CU (r01_ag: N = 50k, C = 128: 79 vs 88 us)
   if (const char* e = getenv("PTC_CONV3_RT")) {
     if (atoi(e) == 4) big = true;
     if (atoi(e) == 2) big = false;

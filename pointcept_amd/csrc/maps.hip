@@ -80,6 +80,53 @@ extern "C" int ptc_patch_pad_maps(const int64_t* offset, int B, int patch, int64
 }
 
 // ------------------------------------------------------------------------------------------------
+// Gather tables of one serialized-attention order, in ONE launch (the torch form is ~12 indexing / cast
+// kernels per (stage, order): order[pad], unpad[inverse], dup[inverse], inv[gidx] == arange, where, 4 casts):
+//   t_qkv_fwd [n_pad]   = order[pad[s]]                      padded slot -> point        (ptv3m1:184,188)
+//   t_qkv_bwd [2][n]    = (unpad[inverse[p]], dup[inverse[p]])  point -> its slot(s)     (backward of the gather)
+//   t_proj_fwd [n]      = unpad[inverse[p]]                   point -> primary slot       (ptv3m1:185,216)
+//   t_proj_bwd [n_pad]  = point if slot is that point's primary slot else -1              (backward of the un-gather)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+attn_tables_kernel(const int64_t* __restrict__ order, const int64_t* __restrict__ inverse, const int64_t* __restrict__ pad,
+                   const int64_t* __restrict__ unpad, const int64_t* __restrict__ dup, int64_t n, int64_t n_pad,
+                   int32_t* __restrict__ t_qkv_fwd, int32_t* __restrict__ t_qkv_bwd, int32_t* __restrict__ t_proj_fwd,
+                   int32_t* __restrict__ t_proj_bwd) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t work = n_pad > n ? n_pad : n;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += stride) {
+    if (t < n_pad) {
+      const int64_t point = order[pad[t]];
+      t_qkv_fwd[t] = (int32_t)point;
+      t_proj_bwd[t] = unpad[inverse[point]] == t ? (int32_t)point : -1;
+    }
+    if (t < n) {
+      const int64_t rank = inverse[t];
+      const int32_t slot = (int32_t)unpad[rank];
+      t_qkv_bwd[t] = slot;
+      t_qkv_bwd[n + t] = (int32_t)dup[rank];
+      t_proj_fwd[t] = slot;
+    }
+  }
+}
+
+extern "C" int ptc_attn_tables(const int64_t* order, const int64_t* inverse, const int64_t* pad, const int64_t* unpad,
+                               const int64_t* dup, int64_t n, int64_t n_pad, int32_t* t_qkv_fwd, int32_t* t_qkv_bwd,
+                               int32_t* t_proj_fwd, int32_t* t_proj_bwd, ptc_stream_t stream) {
+  PTC_REQUIRE(n >= 0 && n_pad >= n && n_pad < (1ll << 31), PTC_EINVAL, "ptc_attn_tables: bad sizes n=%lld n_pad=%lld", (long long)n,
+              (long long)n_pad);
+  if (n == 0) return PTC_OK;
+  PTC_REQUIRE(order && inverse && pad && unpad && dup && t_qkv_fwd && t_qkv_bwd && t_proj_fwd && t_proj_bwd, PTC_EINVAL,
+              "ptc_attn_tables: null buffer");
+  int64_t grid = ptc_cdiv(n_pad, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(attn_tables_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, order, inverse, pad, unpad, dup, n,
+                     n_pad, t_qkv_fwd, t_qkv_bwd, t_proj_fwd, t_proj_bwd);
+  PTC_CHECK_LAUNCH("attn_tables_kernel");
+  return PTC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // pooling maps
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

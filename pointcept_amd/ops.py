@@ -104,6 +104,21 @@ def patch_pad_maps(offset: torch.Tensor, offset_host: Sequence[int], patch: int)
     return pad, unpad, cu, dup
 
 
+def attn_tables(order: torch.Tensor, inverse: torch.Tensor, pad: torch.Tensor, unpad: torch.Tensor, dup: torch.Tensor):
+    """int32 gather tables of one serialization order (ptv3m1:184-188,216 and their backward) in one launch:
+    (t_qkv_fwd [1,N'], t_qkv_bwd [2,N], t_proj_fwd [1,N], t_proj_bwd [1,N'])."""
+    require_cuda(order, inverse, pad, unpad, dup)
+    n, n_pad = order.numel(), pad.numel()
+    dev = order.device
+    t1 = torch.empty((1, n_pad), dtype=torch.int32, device=dev)
+    t2 = torch.empty((2, n), dtype=torch.int32, device=dev)
+    t3 = torch.empty((1, n), dtype=torch.int32, device=dev)
+    t4 = torch.empty((1, n_pad), dtype=torch.int32, device=dev)
+    check(lib().ptc_attn_tables(ptr(order.contiguous()), ptr(inverse.contiguous()), ptr(pad), ptr(unpad), ptr(dup), n, n_pad,
+                                ptr(t1), ptr(t2), ptr(t3), ptr(t4), stream_ptr()), "ptc_attn_tables")
+    return t1, t2, t3, t4
+
+
 # ------------------------------------------------------------------------------------------------
 # pooling maps
 # ------------------------------------------------------------------------------------------------

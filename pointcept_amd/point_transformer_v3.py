@@ -150,18 +150,15 @@ class SerializedAttention(PointModule):
             pad, unpad, _ = self.get_padding_and_inverse(point)
             order = point.serialized_order[self.order_index]
             inverse = point.serialized_inverse[self.order_index]
-            gidx = order[pad]                      # ptv3m1:184
-            inv = unpad[inverse]                   # ptv3m1:185
-            dup_of_point = point["_ptc_dup"][inverse]   # second slot holding each point, or -1
-            slots = torch.arange(gidx.numel(), device=gidx.device)
-            gidx_primary = torch.where(inv[gidx] == slots, gidx, torch.full_like(gidx, -1))
-            tabs = None
-            if config.FUSE_GATHER:
-                tabs = (gidx.to(torch.int32)[None].contiguous(),                       # qkv forward  [1, N']
-                        torch.stack([inv, dup_of_point]).to(torch.int32).contiguous(),  # qkv backward [2, N]
-                        inv.to(torch.int32)[None].contiguous(),                        # proj forward [1, N]
-                        gidx_primary.to(torch.int32)[None].contiguous())               # proj backward [1, N']
-            point[key] = (gidx, inv, dup_of_point, gidx_primary, tabs)
+            if config.FUSE_GATHER:   # all four int32 tables in one launch; the int64 maps are not needed
+                point[key] = (None, None, None, None, ops.attn_tables(order, inverse, pad, unpad, point["_ptc_dup"]))
+            else:
+                gidx = order[pad]                      # ptv3m1:184
+                inv = unpad[inverse]                   # ptv3m1:185
+                dup_of_point = point["_ptc_dup"][inverse]   # second slot holding each point, or -1
+                slots = torch.arange(gidx.numel(), device=gidx.device)
+                gidx_primary = torch.where(inv[gidx] == slots, gidx, torch.full_like(gidx, -1))
+                point[key] = (gidx, inv, dup_of_point, gidx_primary, None)
         return point[key]
 
     def forward(self, point):

@@ -875,3 +875,28 @@ def test_conv_tiny_inputs(cuda, n):
     oops.gather_conv(feat.float(), wr, None, nbr).backward(dout.float())
     dw = ops.spconv_wgrad(feat.to(cuda), dout.to(cuda), got_nbr)
     _close("wgrad_tiny", dw, wr.grad, 1e-4, 1e-3 * float(wr.grad.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("counts,K", [([10, 3, 7], 4), ([1024, 1025, 5000, 1], 1024), ([48, 49, 100, 7], 48), ([2048], 1024)])
+def test_attn_tables_match_index_algebra(cuda, counts, K):
+    """ptc_attn_tables = the index algebra of SerializedAttention.forward (ptv3m1:184-188,216) and its backward"""
+    from pointcept_amd import ops
+
+    n = sum(counts)
+    off = torch.tensor(np.cumsum(counts), dtype=torch.int64)
+    g = torch.Generator().manual_seed(n + K)
+    # a per-scene permutation as the serialization order
+    order = torch.cat([torch.randperm(c, generator=g) + s for c, s in zip(counts, [0] + list(np.cumsum(counts)[:-1]))])
+    inverse = torch.empty_like(order)
+    inverse[order] = torch.arange(n)
+    pad, unpad, cu, dup = ops.patch_pad_maps(off.to(cuda), off.tolist(), K)
+    t1, t2, t3, t4 = ops.attn_tables(order.to(cuda), inverse.to(cuda), pad, unpad, dup)
+    gidx = order.to(cuda)[pad]
+    inv = unpad[inverse.to(cuda)]
+    dup_of_point = dup[inverse.to(cuda)]
+    slots = torch.arange(gidx.numel(), device=cuda)
+    gidx_primary = torch.where(inv[gidx] == slots, gidx, torch.full_like(gidx, -1))
+    assert torch.equal(t1[0].long(), gidx)
+    assert torch.equal(t2[0].long(), inv) and torch.equal(t2[1].long(), dup_of_point)
+    assert torch.equal(t3[0].long(), inv)
+    assert torch.equal(t4[0].long(), gidx_primary)

@@ -21,6 +21,7 @@ for sec in "$@"; do
     probe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_gfx950 tools/probe_gfx950.hip > $O/${TAG}_probe.log 2>&1 && timeout 300 /tmp/probe_gfx950 >> $O/${TAG}_probe.log 2>&1; tail -20 $O/${TAG}_probe.log | cut -c1-200;;
     opsq) timeout 900 python tools/bench_ops.py --quick > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log;;
     bench) timeout 900 python bench.py --steps 10 --warmup 3 > $O/${TAG}_bench.log 2>&1; echo "bench rc=$?" >> $O/${TAG}_env.log; tail -1 $O/${TAG}_bench.log | cut -c1-330;;
+    smoke) timeout 600 python __graft_entry__.py --smoke > $O/${TAG}_smoke.log 2>&1; echo "smoke rc=$?" >> $O/${TAG}_env.log; tail -2 $O/${TAG}_smoke.log;;
     trace) timeout 600 python tools/trace_step.py > $O/${TAG}_trace_step.txt 2>$O/${TAG}_trace_step.err; echo "trace rc=$?" >> $O/${TAG}_env.log; head -5 $O/${TAG}_trace_step.txt;;
     spunet) timeout 900 python bench.py --model spunet --steps 6 --warmup 2 > $O/${TAG}_spunet.log 2>&1; echo "spunet rc=$?" >> $O/${TAG}_env.log; tail -1 $O/${TAG}_spunet.log | cut -c1-400;;
     profspunet) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profsp -- python $R/bench.py --model spunet --steps 3 --warmup 2 > $O/${TAG}_profsp.log 2>&1
