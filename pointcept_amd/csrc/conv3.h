@@ -34,9 +34,11 @@
 template <typename T, int RT, int KPC, int NTILES, bool GEN>
 __global__ void __launch_bounds__(256, 2)
 conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-             const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int n_rowblk, T* __restrict__ out) {
+             const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int n_rowblk, T* __restrict__ out,
+             uint32_t in_bytes) {
   using M = Mma<T>;
   using frag = typename M::frag;
+  const __amdgpu_buffer_rsrc_t in_buf = ptc_buf(in, in_bytes);
   constexpr int NT = NTILES * 16, BM = RT * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ny = c_out / NT;
@@ -72,8 +74,14 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
     for (int ps = 0; ps < WP; ++ps)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        uint4 v = {0, 0, 0, 0};
-        if (wthread[ps] && c * 128 + qd * 32 + gq * 8 < KV) v = *reinterpret_cast<const uint4*>(wsrc[ps] + c * 128 + gq * 8);
+        // UNCONDITIONAL load from a clamped address, zeroed by a select: a load under an exec-masked branch
+        // makes the compiler's wait-count bookkeeping give up (s_waitcnt vmcnt(0) before every MFMA group: the
+        // whole prefetch pipeline of this kernel was serialised, r01_aj ISA)
+        const int v0 = c * 128 + qd * 32 + gq * 8;
+        const bool ok = wthread[ps] && v0 < KV;
+        const int vc = v0 < KV ? v0 : KV - 8;
+        uint4 v = *reinterpret_cast<const uint4*>(wsrc[ps] - qd * 32 + vc);
+        if (!ok) v = make_uint4(0, 0, 0, 0);
         wreg[ps][gq] = v;
       }
   };
@@ -88,7 +96,7 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 
   // ---- gather ring
   frag ga[4][RT];
-  bool anyv[4][RT];
+  bool anyv[4][RT];                  // wave-level "any neighbour at this step"
   int32_t idxN[KPC][RT], idxNN[KPC][RT];
   auto load_idx = [&](int c, int32_t (&ix)[KPC][RT]) {
     // GEN = false: c_in divides 128 or is a multiple of it, a chunk holds exactly KPC whole table rows
@@ -100,7 +108,9 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 #pragma unroll
       for (int j = 0; j < RT; ++j) {
         const int64_t row = row0 + j * 16 + r;
-        ix[kk][j] = (k < kv && row < n_out) ? nbr[(int64_t)k * n_out + row] : -1;
+        const bool ok = k < kv && row < n_out;
+        const int32_t e = nbr[(int64_t)(k < kv ? k : kv - 1) * n_out + (row < n_out ? row : n_out - 1)];   // always in bounds
+        ix[kk][j] = ok ? e : -1;
       }
     }
   };
@@ -125,9 +135,8 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       } else {
         i = ix[kk][j];                                               // kk is a compile-time constant after unrolling
       }
-      frag f = M::zero();
-      if (i >= 0) f = ld_frag<T>(in + (int64_t)i * c_in + cbase);
-      ga[s][j] = f;
+      // one unconditional buffer load: absent neighbours are out-of-range offsets and come back as zeros
+      ga[s][j] = ld_frag_buf<T>(in_buf, i >= 0 ? ((uint32_t)i * (uint32_t)c_in + (uint32_t)cbase) * 2u : PTC_BUF_OOB);
       anyv[s][j] = __builtin_amdgcn_ballot_w64(i >= 0) != 0;
     }
   };
@@ -195,21 +204,21 @@ static inline bool conv3_supported(int dtype, int kv, int c_in, int c_out, const
 }
 
 template <typename T, int RT, int KPC, int NTILES, bool GEN>
-static int launch_conv3_i(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
-                          int c_out, void* out, hipStream_t s) {
+static int launch_conv3_i(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
+                          int c_in, int c_out, void* out, hipStream_t s) {
   const int n_rowblk = (int)ptc_cdiv(n_out, RT * 64);
   const int nblk = n_rowblk * (c_out / (NTILES * 16));
   const size_t lds = 2 * C3_BUF(NTILES);
   auto kern = conv3_kernel<T, RT, KPC, NTILES, GEN>;
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv,
-                     c_in, c_out, n_rowblk, (T*)out);
+                     c_in, c_out, n_rowblk, (T*)out, (uint32_t)((uint64_t)n_in * c_in * sizeof(T)));
   PTC_CHECK_LAUNCH("conv3_kernel");
   return PTC_OK;
 }
 
 template <typename T>
-static int launch_conv3(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
-                        int c_out, void* out, hipStream_t s) {
+static int launch_conv3(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
+                        int c_in, int c_out, void* out, hipStream_t s) {
   // 64 output channels per workgroup (96 when c_out is a multiple of 96 but not of 64 -- SpUNet's decoder --
   // else 32); 256-row workgroups when they still give every CU a workgroup, else 128-row ones
   // (PTC_CONV3_RT=2|4 forces the choice: used by the tests to reach both instantiations at small n)
@@ -224,8 +233,8 @@ static int launch_conv3(const void* in, const void* w, const float* bias, const 
   const bool gen = !(c_in == 32 || c_in == 64 || c_in % 128 == 0);   // table rows straddle chunks (kpc == 2)
 #define C3_CASE(K, N, G)                                                                                                   \
   if (kpc == K && nt == N && gen == G)                                                                                     \
-    return big ? launch_conv3_i<T, 4, K, N, G>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s)                           \
-               : launch_conv3_i<T, 2, K, N, G>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+    return big ? launch_conv3_i<T, 4, K, N, G>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s)                           \
+               : launch_conv3_i<T, 2, K, N, G>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
   C3_CASE(1, 4, false) C3_CASE(2, 4, false) C3_CASE(4, 4, false) C3_CASE(2, 4, true)
   C3_CASE(1, 2, false) C3_CASE(2, 2, false) C3_CASE(2, 2, true)
   C3_CASE(1, 6, false) C3_CASE(2, 6, false) C3_CASE(4, 6, false) C3_CASE(2, 6, true)

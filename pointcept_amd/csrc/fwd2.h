@@ -20,8 +20,10 @@
 template <typename T, int NTILES, int PD, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 3 : 2)  // both: <= 170 registers per lane
 conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-             const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int kg, T* __restrict__ out) {
+             const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int kg, T* __restrict__ out,
+             uint32_t in_bytes) {
   using M = Mma<T>;
+  const __amdgpu_buffer_rsrc_t in_buf = ptc_buf(in, in_bytes);
   constexpr int NT = NTILES * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // contraction chunks of <= 128 channels: a "virtual table row" v = k * nch + chunk reads W[.][k][chunk]
@@ -71,11 +73,11 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       const int col = s * 32 + g * 8;
       const int base_c = ((k0 + kk) % nch) * cc_len;
       const int32_t ia = il[kk * 32 + r], ib = il[kk * 32 + 16 + r];
-      typename M::frag fa = M::zero(), fb = M::zero();
-      if (col < cc_len) {
-        if (ia >= 0) fa = ld_frag<T>(in + (int64_t)ia * c_in + base_c + col);
-        if (ib >= 0) fb = ld_frag<T>(in + (int64_t)ib * c_in + base_c + col);
-      }
+      // unconditional buffer loads (absent rows = out-of-range offsets = zeros): loads under exec-masked branches
+      // force s_waitcnt vmcnt(0) at every use and serialise the ring against the MFMAs
+      const uint32_t cb = (uint32_t)(base_c + col);
+      typename M::frag fa = ld_frag_buf<T>(in_buf, (col < cc_len && ia >= 0) ? ((uint32_t)ia * (uint32_t)c_in + cb) * 2u : PTC_BUF_OOB);
+      typename M::frag fb = ld_frag_buf<T>(in_buf, (col < cc_len && ib >= 0) ? ((uint32_t)ib * (uint32_t)c_in + cb) * 2u : PTC_BUF_OOB);
       ra[j] = fa; rb[j] = fb; xa[j] = ia; xb[j] = ib;
     };
 #pragma unroll
@@ -182,8 +184,9 @@ template <typename T, int NTILES, int S, int EPI = 0>
 __global__ void __launch_bounds__(256)
 linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                const int32_t* __restrict__ nbr, int64_t n_out, int c_in, int c_out, T* __restrict__ out,
-               const T* __restrict__ aux_in = nullptr, T* __restrict__ aux_out = nullptr) {
+               const T* __restrict__ aux_in, T* __restrict__ aux_out, uint32_t in_bytes) {
   using M = Mma<T>;
+  const __amdgpu_buffer_rsrc_t in_buf = ptc_buf(in, in_bytes);
   constexpr int NT = NTILES * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int pitch = c_in + 8;
@@ -204,21 +207,19 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
   const int64_t tiles = (n_out + F2_ROWS - 1) / F2_ROWS;
   auto load_idx = [&](int64_t tile, int32_t& ia, int32_t& ib) {
     const int64_t rowA = tile * F2_ROWS + wave * 32 + r, rowB = rowA + 16;
-    ia = -1; ib = -1;
-    if (tile < tiles) {
-      if (rowA < n_out) ia = nbr ? nbr[rowA] : (int32_t)rowA;
-      if (rowB < n_out) ib = nbr ? nbr[rowB] : (int32_t)rowB;
-    }
+    // unconditional loads (clamped), validity applied by select: keeps the compiler's vmcnt bookkeeping exact
+    const bool okA = tile < tiles && rowA < n_out, okB = tile < tiles && rowB < n_out;
+    const int64_t ca = okA ? rowA : 0, cb = okB ? rowB : 0;
+    const int32_t ja = nbr ? nbr[ca] : (int32_t)ca, jb = nbr ? nbr[cb] : (int32_t)cb;
+    ia = okA ? ja : -1;
+    ib = okB ? jb : -1;
   };
   auto load_rows = [&](int32_t ia, int32_t ib, typename M::frag (&fa)[S], typename M::frag (&fb)[S]) {
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const int col = s * 32 + g * 8;
-      fa[s] = M::zero(); fb[s] = M::zero();
-      if (col < c_in) {
-        if (ia >= 0) fa[s] = ld_frag<T>(in + (int64_t)ia * c_in + col);
-        if (ib >= 0) fb[s] = ld_frag<T>(in + (int64_t)ib * c_in + col);
-      }
+      fa[s] = ld_frag_buf<T>(in_buf, (col < c_in && ia >= 0) ? ((uint32_t)ia * (uint32_t)c_in + (uint32_t)col) * 2u : PTC_BUF_OOB);
+      fb[s] = ld_frag_buf<T>(in_buf, (col < c_in && ib >= 0) ? ((uint32_t)ib * (uint32_t)c_in + (uint32_t)col) * 2u : PTC_BUF_OOB);
     }
   };
 
@@ -270,8 +271,8 @@ static inline int conv2_kg(int kv, int c_in, int nt, int waves) {  // kv = numbe
 }
 
 template <typename T, int NTILES, int WAVES>
-static int launch_conv2_w(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
-                          int c_out, void* out, hipStream_t s) {
+static int launch_conv2_w(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
+                          int c_in, int c_out, void* out, hipStream_t s) {
   constexpr int NT = NTILES * 16;
   const int cc_len = c_in < 128 ? c_in : 128;
   const int kg = conv2_kg(kv * (c_in / cc_len), cc_len, NT, WAVES);
@@ -281,14 +282,14 @@ static int launch_conv2_w(const void* in, const void* w, const float* bias, cons
     PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((unsigned)ptc_cdiv(n_out, WAVES * 32), (unsigned)(c_out / NT));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv, c_in, c_out, kg,
-                     (T*)out);
+                     (T*)out, (uint32_t)((uint64_t)n_in * c_in * sizeof(T)));
   PTC_CHECK_LAUNCH("conv2_kernel");
   return PTC_OK;
 }
 
 template <typename T, int NTILES>
-static int launch_fwd2(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
-                       int c_out, void* out, hipStream_t s, int epi = 0, const void* aux_in = nullptr, void* aux_out = nullptr) {
+static int launch_fwd2(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
+                       int c_in, int c_out, void* out, hipStream_t s, int epi = 0, const void* aux_in = nullptr, void* aux_out = nullptr) {
   constexpr int NT = NTILES * 16;
   if (kv == 1) {
     const size_t lds = (size_t)NT * (c_in + 8) * 2;
@@ -305,7 +306,7 @@ static int launch_fwd2(const void* in, const void* w, const float* bias, const i
     if (lds > 48 * 1024)                                                                                                \
       PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, c_in, c_out, (T*)out,   \
-                       (const T*)aux_in, (T*)aux_out);                                                                  \
+                       (const T*)aux_in, (T*)aux_out, (uint32_t)((uint64_t)n_in * c_in * sizeof(T)));                   \
   }
 #define L2_CASE(SS)                                                                                                     \
   case SS: {                                                                                                            \
@@ -324,17 +325,17 @@ static int launch_fwd2(const void* in, const void* w, const float* bias, const i
   // workgroups on 256 CUs, one latency-bound chain per CU): there 64-row workgroups double the number
   // of independent chains.  (8-wave / 256-row workgroups measured slower everywhere: r01 session s7.)
   const int64_t wg128 = ptc_cdiv(n_out, 128) * (c_out / NT);
-  if (wg128 < 512) return launch_conv2_w<T, NTILES, 2>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
-  return launch_conv2_w<T, NTILES, 4>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  if (wg128 < 512) return launch_conv2_w<T, NTILES, 2>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  return launch_conv2_w<T, NTILES, 4>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
 }
 
 template <typename T>
-static int dispatch_fwd2(const void* in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv, int c_in,
-                         int c_out, void* out, hipStream_t s, int epi = 0, const void* aux_in = nullptr, void* aux_out = nullptr) {
-  if (c_out % 128 == 0) return launch_fwd2<T, 8>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
-  if (c_out % 96 == 0) return launch_fwd2<T, 6>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
-  if (c_out % 64 == 0) return launch_fwd2<T, 4>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
-  if (c_out % 48 == 0) return launch_fwd2<T, 3>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
-  if (c_out % 32 == 0) return launch_fwd2<T, 2>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
-  return launch_fwd2<T, 1>(in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+static int dispatch_fwd2(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
+                         int c_in, int c_out, void* out, hipStream_t s, int epi = 0, const void* aux_in = nullptr, void* aux_out = nullptr) {
+  if (c_out % 128 == 0) return launch_fwd2<T, 8>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  if (c_out % 96 == 0) return launch_fwd2<T, 6>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  if (c_out % 64 == 0) return launch_fwd2<T, 4>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  if (c_out % 48 == 0) return launch_fwd2<T, 3>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  if (c_out % 32 == 0) return launch_fwd2<T, 2>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  return launch_fwd2<T, 1>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
 }

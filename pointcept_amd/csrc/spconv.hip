@@ -232,13 +232,15 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
   PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)out % 16 == 0), PTC_EINVAL,
               "ptc_spconv_fwd: buffers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (ptc_use_conv3() && conv3_supported(dtype, kv, c_in, c_out, nbr)) {
-    if (dtype == PTC_BF16) return launch_conv3<bf16_t>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
-    return launch_conv3<f16_t>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  // the second- and third-generation kernels gather through raw buffer loads (32-bit offsets, < 2 GiB tensors)
+  const bool buf_ok = (uint64_t)n_in * (uint64_t)c_in * ptc_dtype_size(dtype) <= PTC_BUF_MAX_BYTES;
+  if (buf_ok && ptc_use_conv3() && conv3_supported(dtype, kv, c_in, c_out, nbr)) {
+    if (dtype == PTC_BF16) return launch_conv3<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
+    return launch_conv3<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
   }
-  if (fwd2_supported(dtype, kv, c_in) && (nbr || kv == 1)) {
-    if (dtype == PTC_BF16) return dispatch_fwd2<bf16_t>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
-    return dispatch_fwd2<f16_t>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  if (buf_ok && fwd2_supported(dtype, kv, c_in) && (nbr || kv == 1)) {
+    if (dtype == PTC_BF16) return dispatch_fwd2<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
+    return dispatch_fwd2<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
   }
   PTC_DISPATCH_DTYPE(dtype, T, return dispatch_fwd<T>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s));
   return PTC_OK;
@@ -247,18 +249,19 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
 // Dense row-wise GEMM with an MLP epilogue (see fwd2.h): epilogue 1 = out: h, aux_out: GELU(h);
 // epilogue 2 = out: acc * GELU'(aux_in).  16-bit features, c_in <= 256 (the persistent linear2 kernel).
 extern "C" int ptc_linear_supported_ex(int c_in, int c_out, int dtype) {
-  return dtype != PTC_F32 && c_in % 8 == 0 && c_in <= 256 && c_out % 16 == 0;
+  return dtype != PTC_F32 && c_in % 8 == 0 && c_in <= 256 && c_out % 16 == 0;   // and n * c_in * 2 < 2 GiB (checked per call)
 }
 extern "C" int ptc_linear_fwd_ex(const void* in, int64_t n, const void* weight, const float* bias, int c_in, int c_out, int dtype,
                                  int epilogue, const void* aux_in, void* out, void* aux_out, ptc_stream_t stream) {
   PTC_REQUIRE(n >= 0 && ptc_linear_supported_ex(c_in, c_out, dtype), PTC_EUNSUPPORTED, "ptc_linear_fwd_ex: c_in=%d c_out=%d dtype=%d",
               c_in, c_out, dtype);
   PTC_REQUIRE(epilogue == 1 || epilogue == 2, PTC_EINVAL, "ptc_linear_fwd_ex: epilogue %d", epilogue);
+  PTC_REQUIRE((uint64_t)n * (uint64_t)c_in * 2 <= PTC_BUF_MAX_BYTES, PTC_EUNSUPPORTED, "ptc_linear_fwd_ex: input of 2 GiB or more");
   if (n == 0) return PTC_OK;
   PTC_REQUIRE(in && weight && out && (epilogue == 1 ? aux_out != nullptr : aux_in != nullptr), PTC_EINVAL, "ptc_linear_fwd_ex: null buffer");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == PTC_BF16) return dispatch_fwd2<bf16_t>(in, weight, bias, nullptr, n, 1, c_in, c_out, out, s, epilogue, aux_in, aux_out);
-  return dispatch_fwd2<f16_t>(in, weight, bias, nullptr, n, 1, c_in, c_out, out, s, epilogue, aux_in, aux_out);
+  if (dtype == PTC_BF16) return dispatch_fwd2<bf16_t>(in, n, weight, bias, nullptr, n, 1, c_in, c_out, out, s, epilogue, aux_in, aux_out);
+  return dispatch_fwd2<f16_t>(in, n, weight, bias, nullptr, n, 1, c_in, c_out, out, s, epilogue, aux_in, aux_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -505,20 +508,21 @@ static int launch_wgrad(const void* in, const void* dout, const int32_t* nbr, in
 
 // ---- v2 (16-bit features): wave-private staging + transposing LDS reads, see wgrad2.h -----------
 template <typename T, int COT, int CIT, int KG>
-static int launch_wgrad2_inst(const W2Plan& p, const void* in, const void* dout, const int32_t* nbr, int64_t n_out, int kv,
+static int launch_wgrad2_inst(const W2Plan& p, const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv,
                               int c_in, int c_out, float* partial, float* bias_partial, hipStream_t s) {
   auto kern = wgrad2_kernel<T, COT, CIT, KG>;
   if (p.lds > 48 * 1024)
     PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-  dim3 grid((unsigned)p.gx, (unsigned)p.groups, (unsigned)(p.co_blocks * p.ci_blocks));
-  hipLaunchKernelGGL(kern, grid, dim3(256), p.lds, s, (const T*)in, (const T*)dout, nbr, n_out, kv, c_in, c_out,
-                     ptc_cdiv(n_out, W2_ROWS), p.ci_blocks, partial, bias_partial);
+  const int nblocks = p.co_blocks * p.ci_blocks, total = p.gx * p.groups * nblocks;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(256), p.lds, s, (const T*)in, (const T*)dout, nbr, n_out, kv,
+                     c_in, c_out, ptc_cdiv(n_out, W2_ROWS), p.ci_blocks, partial, bias_partial, p.gx, p.groups, nblocks,
+                     (uint32_t)((uint64_t)n_in * c_in * sizeof(T)), (uint32_t)((uint64_t)n_out * c_out * sizeof(T)));
   PTC_CHECK_LAUNCH("wgrad2_kernel");
   return PTC_OK;
 }
 
 template <typename T>
-static int launch_wgrad2(const void* in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
+static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
                          float* dw, float* dbias, void* ws, hipStream_t s) {
   const W2Plan p = w2_plan(n_out, kv, c_in, c_out, dbias != nullptr);
   const int64_t count = (int64_t)c_out * kv * c_in;
@@ -528,10 +532,10 @@ static int launch_wgrad2(const void* in, const void* dout, const int32_t* nbr, i
   int rc = PTC_EUNSUPPORTED;
 #define W2_CASE(COT, CIT, KG)                                                                                         \
   if (p.cot == COT && p.cit == CIT && p.kg == KG)                                                                     \
-    rc = launch_wgrad2_inst<T, COT, CIT, KG>(p, in, dout, nbr, n_out, kv, c_in, c_out, partial, bias_partial, s);
+    rc = launch_wgrad2_inst<T, COT, CIT, KG>(p, in, n_in, dout, nbr, n_out, kv, c_in, c_out, partial, bias_partial, s);
   W2_CASE(2, 1, 1) W2_CASE(2, 2, 1) W2_CASE(2, 4, 1) W2_CASE(4, 1, 1) W2_CASE(4, 2, 1) W2_CASE(4, 4, 1)
   W2_CASE(6, 1, 1) W2_CASE(6, 2, 1) W2_CASE(6, 4, 1) W2_CASE(8, 1, 1) W2_CASE(8, 2, 1) W2_CASE(8, 4, 1)
-  W2_CASE(2, 1, 16) W2_CASE(2, 2, 9) W2_CASE(4, 2, 4) W2_CASE(2, 4, 4) W2_CASE(4, 4, 2) W2_CASE(6, 2, 2)
+  W2_CASE(2, 1, 16) W2_CASE(2, 2, 4) W2_CASE(4, 2, 4) W2_CASE(2, 4, 4) W2_CASE(4, 4, 2) W2_CASE(6, 2, 2)
 #undef W2_CASE
   if (rc != PTC_OK) {
     if (rc == PTC_EUNSUPPORTED) ptc_set_error("ptc_spconv_wgrad: no wgrad2 instance for tiles (%d,%d,%d)", p.cot, p.cit, p.kg);
@@ -558,8 +562,10 @@ extern "C" int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, 
   }
   PTC_REQUIRE(in && dout, PTC_EINVAL, "ptc_spconv_wgrad: null buffer");
   PTC_REQUIRE(nbr || (kv == 1 && n_in >= n_out), PTC_EINVAL, "ptc_spconv_wgrad: nbr may be NULL only for kv == 1 (identity table)");
-  if (dtype == PTC_BF16) return launch_wgrad2<bf16_t>(in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s);
-  if (dtype == PTC_F16) return launch_wgrad2<f16_t>(in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s);
+  // wgrad2 gathers through raw buffer loads (< 2 GiB operands); larger ones take the v1 kernel
+  const bool buf_ok = (uint64_t)n_in * c_in * 2 <= PTC_BUF_MAX_BYTES && (uint64_t)n_out * c_out * 2 <= PTC_BUF_MAX_BYTES;
+  if (dtype == PTC_BF16 && buf_ok) return launch_wgrad2<bf16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s);
+  if (dtype == PTC_F16 && buf_ok) return launch_wgrad2<f16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s);
   PTC_DISPATCH_DTYPE(dtype, T, return launch_wgrad<T>(in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s));
   return PTC_OK;
 }

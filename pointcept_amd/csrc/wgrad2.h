@@ -61,8 +61,9 @@ template <typename T, int COT, int CIT, int KG>
 __global__ void __launch_bounds__(256, 2)   // two waves per SIMD: <= 256 registers
 wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_t* __restrict__ nbr, int64_t n_out, int kv,
               int c_in, int c_out, int64_t steps_total, int ci_blocks, float* __restrict__ partial,
-              float* __restrict__ bias_partial) {
+              float* __restrict__ bias_partial, int gx, int groups, int nblocks, uint32_t in_bytes, uint32_t dout_bytes) {
   using M = Mma<T>;
+  const __amdgpu_buffer_rsrc_t in_buf = ptc_buf(in, in_bytes), dout_buf = ptc_buf(dout, dout_bytes);
   constexpr bool PIPE = W2Pipe<COT, CIT, KG>::value;
   constexpr int NI = PIPE ? KG : 2;                    // gathered-row images per wave
   constexpr int WAVE_BYTES = (COT + NI * CIT) * 1024;  // dout image + `in` images
@@ -70,13 +71,22 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char* D = smem + wave * WAVE_BYTES;
   unsigned char* I0 = D + COT * 1024;
-  const int k0 = blockIdx.y * KG;
+  // 1-D grid, XCD-first numbering (workgroup b runs on XCD b % 8): logical id l = (row worker * blocks + channel
+  // block) * groups + table-row group, so the `groups` workgroups that stream the SAME dout rows (and gather
+  // overlapping neighbourhoods) run on one XCD at the same time and share its L2 -- dout left HBM once per group
+  // (14x for a 3^3 table) in the (x, y, z)-grid form.
+  const int total = gx * groups * nblocks;
+  const int per_xcd = (total + 7) >> 3;
+  const int lid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (lid >= total) return;
+  const int bgrp = lid % groups, bz = (lid / groups) % nblocks, bx = lid / (groups * nblocks);
+  const int k0 = bgrp * KG;
   const int nk = (kv - k0) < KG ? (kv - k0) : KG;
-  const int co0 = (blockIdx.z / ci_blocks) * COT * 16, ci0 = (blockIdx.z % ci_blocks) * CIT * 16;
-  const int64_t workers = (int64_t)gridDim.x * 4, worker = (int64_t)blockIdx.x * 4 + wave;
+  const int co0 = (bz / ci_blocks) * COT * 16, ci0 = (bz % ci_blocks) * CIT * 16;
+  const int64_t workers = (int64_t)gx * 4, worker = (int64_t)bx * 4 + wave;
   // the fused bias gradient (one extra MFMA against ones per dout fragment) exists in the KG == 1 instances
   // only -- the host plans KG = 1 whenever dbias is requested; grouped instances have no registers to spare
-  const bool do_bias = KG == 1 && bias_partial != nullptr && blockIdx.y == 0 && (blockIdx.z % ci_blocks) == 0;
+  const bool do_bias = KG == 1 && bias_partial != nullptr && bgrp == 0 && (bz % ci_blocks) == 0;
 
   f32x4 acc[KG][COT][CIT];
   f32x4 accb[COT];
@@ -95,6 +105,10 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
     __builtin_memcpy(&ones, o8, sizeof(ones));
   }
 
+  // All prefetch loads are UNCONDITIONAL: feature rows through raw buffer loads (absent rows = out-of-range offsets =
+  // zeros, mma.h), table entries from clamped addresses.  A load under an exec-masked branch makes the compiler fall
+  // back to s_waitcnt vmcnt(0) at every use, which serialised the step-ahead prefetch against the MFMAs it was
+  // meant to overlap (ISA of r01_aj).
   // table entries of the rows this lane stages, for every table row of the group
   auto load_idx = [&](int64_t s, int32_t (&ix)[KG][CIT]) {
     const int64_t r0 = s * W2_ROWS;
@@ -104,9 +118,15 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
       for (int i = 0; i < CIT; ++i) {
         const int row = (i * 64 + lane) / (2 * CIT);
         const int64_t rr = r0 + row;
-        int32_t j = -1;
-        if (kk < nk && rr < n_out && s < steps_total) j = nbr ? nbr[(int64_t)(k0 + kk) * n_out + rr] : (int32_t)rr;
-        ix[kk][i] = j;
+        const bool ok = kk < nk && rr < n_out && s < steps_total;
+        int32_t j;
+        if (nbr) {   // wave-uniform
+          const int kc = kk < nk ? kk : nk - 1;
+          j = nbr[(int64_t)(k0 + kc) * n_out + (rr < n_out ? rr : n_out - 1)];
+        } else {
+          j = (int32_t)rr;
+        }
+        ix[kk][i] = ok ? j : -1;
       }
   };
   auto load_dout = [&](int64_t s, uint4 (&pd)[COT]) {
@@ -116,9 +136,8 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
       const int v = i * 64 + lane, row = v / (2 * COT), piece = v % (2 * COT);
       const int64_t rr = r0 + row;
       const int ch = co0 + piece * 8;
-      uint4 x = {0, 0, 0, 0};
-      if (rr < n_out && ch < c_out && s < steps_total) x = *reinterpret_cast<const uint4*>(dout + rr * c_out + ch);
-      pd[i] = x;
+      const bool ok = rr < n_out && ch < c_out && s < steps_total;
+      pd[i] = ptc_buf_load16(dout_buf, ok ? ((uint32_t)rr * (uint32_t)c_out + (uint32_t)ch) * 2u : PTC_BUF_OOB);
     }
   };
   auto store_dout = [&](const uint4 (&pd)[COT]) {
@@ -133,9 +152,8 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
     for (int i = 0; i < CIT; ++i) {
       const int piece = (i * 64 + lane) % (2 * CIT);
       const int ch = ci0 + piece * 8;
-      uint4 x = {0, 0, 0, 0};
-      if (ixk[i] >= 0 && ch < c_in) x = *reinterpret_cast<const uint4*>(in + (int64_t)ixk[i] * c_in + ch);
-      pi[i] = x;
+      const bool ok = ixk[i] >= 0 && ch < c_in;
+      pi[i] = ptc_buf_load16(in_buf, ok ? ((uint32_t)ixk[i] * (uint32_t)c_in + (uint32_t)ch) * 2u : PTC_BUF_OOB);
     }
   };
   auto store_in = [&](unsigned char* buf, const uint4 (&pi)[CIT]) {
@@ -232,7 +250,7 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
   // ---- sum the four waves through LDS, write this workgroup's partial ------------------------------
   // D[i = co][j = ci]: lane (j = lane & 15, g = lane >> 4) holds co = 16 a + 4 g + e, ci = 16 b + j
   float* red = reinterpret_cast<float*>(smem);  // [4 waves][CIT][4][64] floats <= 16 KB
-  float* pout = partial + (int64_t)blockIdx.x * c_out * kv * c_in;
+  float* pout = partial + (int64_t)bx * c_out * kv * c_in;
 #pragma unroll
   for (int kk = 0; kk < KG; ++kk) {
 #pragma unroll
@@ -269,7 +287,7 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
     if ((int)threadIdx.x < COT * 16) {
       const int co = co0 + threadIdx.x;
       if (co < c_out)
-        bias_partial[(int64_t)blockIdx.x * c_out + co] = red[threadIdx.x] + red[COT * 16 + threadIdx.x] +
+        bias_partial[(int64_t)bx * c_out + co] = red[threadIdx.x] + red[COT * 16 + threadIdx.x] +
                                                          red[2 * COT * 16 + threadIdx.x] + red[3 * COT * 16 + threadIdx.x];
     }
   }
@@ -303,7 +321,7 @@ static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out, bool wa
   p.kg = 1;
   if (kv > 1 && !want_bias) {  // instantiated groups (register budget: KG*COT*CIT*4 accumulators)
     if (p.cot == 2 && p.cit == 1) p.kg = 16;
-    else if (p.cot == 2 && p.cit == 2) p.kg = 9;
+    else if (p.cot == 2 && p.cit == 2) p.kg = 4;   // (2,2,9) cannot hold the step-ahead prefetch in registers
     else if (p.cot == 4 && p.cit == 2) p.kg = 4;
     else if (p.cot == 2 && p.cit == 4) p.kg = 4;
     else if (p.cot == 4 && p.cit == 4) p.kg = 2;
