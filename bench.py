@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
     ap.add_argument("--points", type=int, default=102400, help="voxels per scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lovasz", action="store_true",
+                    help="criteria = CE + Lovasz-Softmax as in scannet/semseg-pt-v3m1-0-base.py:49-52 (default: CE only)")
     ap.add_argument("--model", default="ptv3", choices=["ptv3", "spunet"],
                     help="ptv3 = BASELINE.json metric (configs[2]); spunet = configs[1] (SpUNet-v1m1, 100000 voxels/scene), "
                          "reported with its own metric name")
@@ -210,7 +212,8 @@ def main():
     torch.manual_seed(1234)  # identical initial weights on every rank
     if args.model == "spunet":
         return main_spunet(args, rank, local_rank, world, device)
-    model = DefaultSegmentorV2(20, 64, PointTransformerV3(**PTV3_BASE)).to(device).train()
+    criteria = ("ce", "lovasz") if args.lovasz else ("ce",)
+    model = DefaultSegmentorV2(20, 64, PointTransformerV3(**PTV3_BASE), criteria=criteria).to(device).train()
     n_params = sum(p.numel() for p in model.parameters())
     step_model = model
     if world > 1:
@@ -264,10 +267,10 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": "PT-v3m1 base (46.2M params) + seg head + CE, fwd+bwd+AdamW, "
+            "config": {"workload": "PT-v3m1 base (46.2M params) + seg head + " + ("CE + Lovasz" if args.lovasz else "CE") + ", fwd+bwd+AdamW, "
                                    f"{args.batch} scenes x {args.points} voxels per GPU, patch 1024, 4 orders",
                        "global_batch": args.batch * world, "points_per_gpu": n_points, "parallelism": f"dp{world}",
-                       "params": n_params, "loss": "CrossEntropy(ignore_index=-1)", "final_loss": round(last_loss, 4)},
+                       "params": n_params, "loss": "CrossEntropy(ignore_index=-1)" + (" + LovaszSoftmax" if args.lovasz else ""), "final_loss": round(last_loss, 4)},
         }
         try:
             out["roofline"] = attention_roofline(device, args.batch, args.points)

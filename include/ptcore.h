@@ -315,6 +315,20 @@ int ptc_cross_entropy_bwd(const void* logits, int64_t row_stride, const int64_t*
                           const float* scale, int64_t n, int c, int dtype, int64_t ignore_index, void* dlogits,
                           int64_t drow_stride, ptc_stream_t stream);
 
+/* Lovasz-Softmax loss, multiclass, classes = "present", whole batch (per_image = False), with its gradient.
+ * Replaces LovaszLoss(mode="multiclass", ignore_index, loss_weight) of pointcept/models/losses/lovasz.py:209-260
+ * (_lovasz_softmax_flat :118-146, _lovasz_grad :22-33, _flatten_probas :149-166), the second criterion of
+ * configs/scannet/semseg-pt-v3m1-0-base.py:49-52, called from pointcept/models/default.py:78-84.
+ *   logits [n, c] (row_stride in elements, dtype = ptc_dtype), target [n] int64 (ignore_index / out of range = not
+ *   counted), c <= 64.  loss[0] (fp32, DEVICE) = mean over the classes present in the counted labels of
+ *   <sorted errors, Jaccard steps>; dlogits [n, c] fp32 contiguous = d loss / d logits (0 for uncounted rows).
+ *   One segmented radix sort of the [c, n] error matrix; reductions in a fixed order (bit-reproducible).
+ *   Ties between equal errors are ordered by ascending point index (the loss does not depend on it). */
+size_t ptc_lovasz_softmax_workspace_bytes(int64_t n, int c);
+int ptc_lovasz_softmax(const void* logits, int64_t row_stride, const int64_t* target, int64_t n, int c, int dtype,
+                       int64_t ignore_index, float* loss, float* dlogits, void* workspace, size_t workspace_bytes,
+                       ptc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * J. BatchNorm1d over the rows of [n, c] features with the following activation fused:
  *    y = act((x - mean) * rstd * gamma + beta),  act in {0 none, 1 GELU (erf), 2 ReLU}.

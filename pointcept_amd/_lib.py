@@ -74,6 +74,8 @@ _SIGNATURES = {
     "ptc_cross_entropy_partials": (c_i64, [c_i64]),
     "ptc_cross_entropy_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     "ptc_cross_entropy_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_i64, c_ptr, c_i64, c_ptr]),
+    "ptc_lovasz_softmax_workspace_bytes": (c_size, [c_i64, c_int]),
+    "ptc_lovasz_softmax": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
 }
 
 PTC_F32, PTC_F16, PTC_BF16 = 0, 1, 2

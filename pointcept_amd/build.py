@@ -31,6 +31,7 @@ HIP_SOURCES = [
     "norm.hip",
     "attention.hip",
     "loss.hip",
+    "lovasz.hip",
     "bn.hip",
 ]
 CXX_SOURCES = ["core.cpp"]

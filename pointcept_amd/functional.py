@@ -412,6 +412,30 @@ def cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int 
     return _CrossEntropy.apply(logits, target, int(ignore_index))
 
 
+class _LovaszSoftmax(Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        loss, dlogits = ops.lovasz_softmax(logits, target, ignore_index)
+        ctx.save_for_backward(dlogits)
+        ctx.dtype = logits.dtype
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return (dlogits * g.float()).to(ctx.dtype), None, None
+
+
+def lovasz_softmax(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = -1) -> torch.Tensor:
+    """LovaszLoss(mode="multiclass", ignore_index=ignore_index) on seg logits [N, C]
+    (pointcept/models/losses/lovasz.py:209-260; second criterion of scannet/semseg-pt-v3m1-0-base.py:49-52):
+    softmax, per-class errors, ONE segmented sort, exact Jaccard steps and the gradient, all on device."""
+    if logits.dim() != 2:
+        raise PtcoreError("lovasz_softmax expects [N, C] logits")
+    return _LovaszSoftmax.apply(logits, target, int(ignore_index))
+
+
 # ------------------------------------------------------------------------------------------------
 # BatchNorm1d + activation
 # ------------------------------------------------------------------------------------------------

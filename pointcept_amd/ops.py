@@ -483,6 +483,25 @@ def cross_entropy_bwd(logits: torch.Tensor, target: torch.Tensor, lse: torch.Ten
     return out
 
 
+def lovasz_softmax(logits: torch.Tensor, target: torch.Tensor, ignore_index: int):
+    """Lovasz-Softmax (multiclass, classes present, whole batch: pointcept/models/losses/lovasz.py:118-146) ->
+    (loss [] fp32, dlogits [N, C] fp32): one segmented radix sort of the [C, N] error matrix."""
+    require_cuda(logits, target)
+    if target.dtype != torch.int64:
+        raise PtcoreError("target must be int64")
+    lg, rs = _rows_view(logits)
+    n, c = lg.shape
+    nbytes = lib().ptc_lovasz_softmax_workspace_bytes(n, c)
+    if nbytes == 0:
+        raise PtcoreError(f"lovasz_softmax: unsupported shape [{n}, {c}] (at most 64 classes)")
+    ws = _ws(nbytes, lg.device)
+    loss = torch.empty((), dtype=torch.float32, device=lg.device)
+    dlogits = torch.empty((n, c), dtype=torch.float32, device=lg.device)
+    check(lib().ptc_lovasz_softmax(ptr(lg), rs, ptr(target.contiguous()), n, c, dtype_code(lg), int(ignore_index), ptr(loss),
+                                   ptr(dlogits), ptr(ws), nbytes, stream_ptr()), "ptc_lovasz_softmax")
+    return loss, dlogits
+
+
 # ------------------------------------------------------------------------------------------------
 # BatchNorm1d + activation
 # ------------------------------------------------------------------------------------------------

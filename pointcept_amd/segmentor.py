@@ -3,8 +3,10 @@ the DefaultSegmentorV2 contract of pointcept/models/default.py:40-95 (seg_head L
 point.feat, loss in train mode, loss + seg_logits with labels in eval mode, seg_logits otherwise).
 Inside Pointcept the reference's own DefaultSegmentorV2 wraps the engine backbone unchanged.
 
-criteria: CrossEntropyLoss(ignore_index=-1) (pointcept/models/losses/misc.py) -- the Lovasz term of
-the ScanNet config (scannet/semseg-pt-v3m1-0-base.py:49-52) is a SURVEY 8(f) next-row, not built yet.
+criteria (pointcept/models/losses/builder.py:22-31 sums the configured terms): "ce" = CrossEntropyLoss(
+ignore_index=-1) (losses/misc.py), "lovasz" = LovaszLoss(mode="multiclass", ignore_index=-1) (losses/lovasz.py);
+the ScanNet config uses both with weight 1 (scannet/semseg-pt-v3m1-0-base.py:49-52).  Default ("ce",) -- the
+criterion bench.py states.
 """
 from __future__ import annotations
 
@@ -17,14 +19,23 @@ from .structure import Point
 
 
 class DefaultSegmentorV2(nn.Module):
-    def __init__(self, num_classes, backbone_out_channels, backbone, ignore_index=-1):
+    def __init__(self, num_classes, backbone_out_channels, backbone, ignore_index=-1, criteria=("ce",), loss_weights=None):
         super().__init__()
+        for name in criteria:
+            if name not in ("ce", "lovasz"):
+                raise ValueError(f"unknown criterion {name!r}")
+        self.criteria_names = tuple(criteria)
+        self.loss_weights = tuple(loss_weights) if loss_weights is not None else (1.0,) * len(self.criteria_names)
         self.seg_head = PNN.Linear(backbone_out_channels, num_classes) if num_classes > 0 else nn.Identity()
         self.backbone = backbone
         self.ignore_index = ignore_index
 
-    def criteria(self, seg_logits, segment):
-        return PF.cross_entropy(seg_logits, segment, self.ignore_index)   # GPU only, like every op of the engine
+    def criteria(self, seg_logits, segment):   # GPU only, like every op of the engine
+        loss = 0
+        for name, w in zip(self.criteria_names, self.loss_weights):
+            fn = PF.cross_entropy if name == "ce" else PF.lovasz_softmax
+            loss = loss + fn(seg_logits, segment, self.ignore_index) * w
+        return loss
 
     def forward(self, input_dict, return_point=False):
         point = Point(input_dict)

@@ -26,7 +26,6 @@ from collections import OrderedDict
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import functional as PF
 from . import ops
@@ -161,9 +160,11 @@ class SubMConv3d(_SparseConvolution):
         if k == 1:  # spconv short-circuits 1x1x1 submanifold convs to a GEMM
             w2 = self.weight.reshape(self.out_channels, self.in_channels)
             f = x.features
-            if f.is_cuda and f.dim() == 2 and f.shape[0] > 0:   # the engine's tall-skinny GEMM kernels (fwd / dgrad / split-K wgrad)
-                return x.replace_feature(PF.linear(f, w2, self.bias))
-            return x.replace_feature(F.linear(f, w2, self.bias))
+            if not f.is_cuda:
+                raise PtcoreError("SubMConv3d: features must live on a GPU (there is no CPU fallback)")
+            if f.shape[0] == 0:
+                return x.replace_feature(f.new_zeros((0, self.out_channels)))
+            return x.replace_feature(PF.linear(f, w2, self.bias))   # the engine's tall-skinny GEMM kernels
         if x.indices.shape[0] == 0:
             return x.replace_feature(x.features.new_zeros((0, self.out_channels)))
         key = ("subm", self.indice_key, k)

@@ -78,6 +78,43 @@ def indoor_scene(seed: int, point_max: int = 102400, grid: float = 0.02, density
     return dict(coord=coord, grid_coord=gc.astype(np.int64), feat=feat, segment=segment)
 
 
+def outdoor_scene(seed: int, point_max: int = 0, grid: float = 0.05, azimuth_steps: int = 2200):
+    """LiDAR-like sweep (SURVEY 8(d) outdoor generator, BASELINE configs[4]): 64-96 beams at elevations -30..+10 deg,
+    `azimuth_steps` columns; below-horizon beams hit the ground plane z = -1.8 m (range clipped to 60 m), the others
+    return from U(8, 50) m; 2.5 % Gaussian range noise; voxelised at `grid` (0.05 m -> extent ~2400 voxels, depth 12);
+    feat = coord | strength (in_channels = 4, nuscenes/semseg-pt-v3m1-0-base.py:16); 16 classes."""
+    rng = np.random.default_rng(seed)
+    beams = int(rng.integers(64, 97))
+    elev = np.deg2rad(np.linspace(-30.0, 10.0, beams))[:, None]
+    azim = np.linspace(0.0, 2 * np.pi, azimuth_steps, endpoint=False)[None, :] + rng.uniform(0, 2 * np.pi)
+    down = np.broadcast_to(elev < 0, (beams, azimuth_steps))
+    r_ground = np.minimum(1.8 / np.maximum(np.sin(-elev), 1e-6), 60.0)
+    r = np.where(down, np.broadcast_to(r_ground, (beams, azimuth_steps)), rng.uniform(8.0, 50.0, (beams, azimuth_steps)))
+    r = r * (1.0 + 0.025 * rng.standard_normal(r.shape))
+    keep = rng.random(r.shape) < np.where(down, 1.0, 0.35)     # most above-horizon beams see the sky
+    ce = np.broadcast_to(np.cos(elev), r.shape)
+    p = np.stack([r * ce * np.cos(azim), r * ce * np.sin(azim), r * np.broadcast_to(np.sin(elev), r.shape)], axis=-1)[keep]
+    gc = np.floor(p / grid).astype(np.int64)
+    gc -= gc.min(0)
+    key = (gc[:, 0] * 8192 + gc[:, 1]) * 8192 + gc[:, 2]
+    _, first = np.unique(key, return_index=True)
+    first = first[rng.permutation(first.shape[0])]
+    if point_max and first.shape[0] > point_max:   # half the budget nearest the sensor (dense), half anywhere (keeps the extent)
+        near = np.argsort((p[first] ** 2).sum(1), kind="stable")
+        far = np.ones(first.shape[0], dtype=bool)
+        far[near[: point_max // 2]] = False
+        first = np.concatenate([first[near[: point_max // 2]], first[np.flatnonzero(far)[: point_max - point_max // 2]]])
+        first = first[rng.permutation(first.shape[0])]
+    gc, p = gc[first], p[first]
+    gc = gc - gc.min(0)
+    n = gc.shape[0]
+    coord = p.astype(np.float32)
+    feat = np.concatenate([coord, rng.random((n, 1)).astype(np.float32)], axis=1)
+    segment = rng.integers(0, 16, size=n).astype(np.int64)
+    segment[rng.random(n) < 0.05] = -1
+    return dict(coord=coord, grid_coord=gc.astype(np.int64), feat=feat, segment=segment)
+
+
 def collate(scenes):
     """point_collate_fn equivalent: concatenate and build the cumulative `offset`."""
     out = {k: np.concatenate([s[k] for s in scenes]) for k in scenes[0]}

@@ -13,6 +13,11 @@ Fixtures
                       backbone output of the reference model running its FLASH branch on the CPU
                       stand-ins of oracle/shims.py, deterministic weights (oracle.ptv3_model.
                       deterministic_state_dict), CPU RNG seeded with 5 before the forward.
+  spunet_tiny.npz   : SpUNet-v1m1 (the reference file spconv_unet_v1m1_base.py on oracle/shims.py), channels
+                      (16,32,48,64,64,48,32,32), layers (1,2,1,1,1,1,2,1), two scenes (3000 + 1200 voxels):
+                      eval-mode and train-mode logits (every 4th row), CE loss and the gradient norm of every parameter.
+  lovasz.npz        : logits / labels -> LovaszLoss(mode="multiclass", ignore_index=-1) loss and gradient
+                      (pointcept/models/losses/lovasz.py), five shapes incl. absent classes and a single point.
 """
 import os
 import sys
@@ -31,6 +36,9 @@ from pointcept_amd import synthetic  # noqa: E402
 ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
 TINY_CFG = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), dec_depths=(1, 1, 1, 1),
                 enc_patch_size=(1024,) * 5, dec_patch_size=(1024,) * 4, drop_path=0.0, shuffle_orders=False)
+
+
+SPUNET_CFG = dict(base_channels=16, channels=(16, 32, 48, 64, 64, 48, 32, 32), layers=(1, 2, 1, 1, 1, 1, 2, 1))
 
 
 def main():
@@ -99,6 +107,53 @@ def main():
         weight_checksum=np.asarray(key_sum), feat_rows=out[::16].astype(np.float32),
         feat_row_norm=np.linalg.norm(out.astype(np.float64), axis=1).astype(np.float32),
         feat_absmax=np.asarray(np.abs(out).max()))
+    # ---- SpUNet tiny ---------------------------------------------------------------------------
+    spunet = R["spunet"]
+    torch.manual_seed(0)
+    ref = spunet.SpUNetBase(6, 20, **SPUNET_CFG)
+    sd = om.deterministic_state_dict(ref, 1)
+    ref.load_state_dict(sd)
+    batch = synthetic.collate([synthetic.indoor_scene(31, 3000), synthetic.indoor_scene(32, 1200)])
+    inp = {k: torch.from_numpy(v) for k, v in batch.items()}
+    ref.eval()
+    with torch.no_grad():
+        logits_eval = ref(inp).numpy()
+    ref.train()
+    logits = ref(inp)
+    loss = torch.nn.functional.cross_entropy(logits, inp["segment"], ignore_index=-1)
+    loss.backward()
+    names = [k for k, _ in ref.named_parameters()]
+    np.savez_compressed(
+        os.path.join(OUT, "spunet_tiny.npz"), scene_seeds=np.asarray([31, 32]), n_points=np.asarray([3000, 1200]),
+        input_checksum=np.asarray([batch["grid_coord"].sum(), float(batch["feat"].astype(np.float64).sum())]),
+        logits_eval=logits_eval[::4].astype(np.float32), logits_train=logits.detach().numpy()[::4].astype(np.float32),
+        logits_absmax=np.asarray(float(np.abs(logits_eval).max())),
+        loss=np.asarray(float(loss.detach())), param_names=np.asarray(names),
+        grad_norms=np.asarray([float(p.grad.double().norm()) for _, p in ref.named_parameters()]),
+        grad_conv_input=ref.conv_input[0].weight.grad.numpy().astype(np.float32),
+        grad_final=ref.final.weight.grad.numpy().astype(np.float32),
+        n_state=np.asarray(len(sd)))
+    # ---- Lovasz-Softmax ------------------------------------------------------------------------
+    import importlib
+    import types
+    pkg = types.ModuleType("pointcept.models.losses")
+    pkg.__path__ = [ref_import.REF + "/pointcept/models/losses"]
+    sys.modules["pointcept.models.losses"] = pkg
+    lov = importlib.import_module("pointcept.models.losses.lovasz")
+    crit = lov.LovaszLoss(mode="multiclass", ignore_index=-1, loss_weight=1.0)
+    blobs = {}
+    cases = [(1000, 20, 0.05, 20, 1.0), (2049, 13, 0.3, 9, 4.0), (257, 20, 0.0, 3, 0.5), (64, 5, 0.9, 5, 2.0), (1, 20, 0.0, 20, 1.0)]
+    for ci, (n, c, p_ignore, n_used, spread) in enumerate(cases):
+        x, y = om.lovasz_case(ci, n, c, p_ignore, n_used, spread)   # seeded; regenerated by the tests, checksummed here
+        x.requires_grad_(True)
+        loss = crit(x, y)
+        loss.backward()
+        blobs[f"shape_{ci}"] = np.asarray([n, c, n_used], dtype=np.int64)
+        blobs[f"params_{ci}"] = np.asarray([p_ignore, spread], dtype=np.float64)
+        blobs[f"logits_sum_{ci}"], blobs[f"labels_{ci}"] = np.asarray(float(x.detach().double().sum())), y.numpy().astype(np.int8)
+        blobs[f"loss_{ci}"], blobs[f"grad_{ci}"] = np.asarray(float(loss.detach())), x.grad.numpy()
+    blobs["n_cases"] = np.asarray(len(cases))
+    np.savez_compressed(os.path.join(OUT, "lovasz.npz"), **blobs)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

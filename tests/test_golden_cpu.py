@@ -116,6 +116,60 @@ def test_oracle_ptv3_tiny_matches_reference_golden():
     assert np.allclose(np.linalg.norm(out.astype(np.float64), axis=1), g["feat_row_norm"], rtol=1e-4, atol=1e-4)
 
 
+SPUNET_TINY = dict(base_channels=16, channels=(16, 32, 48, 64, 64, 48, 32, 32), layers=(1, 2, 1, 1, 1, 1, 2, 1))
+
+
+def test_oracle_spunet_tiny_matches_reference_golden():
+    """SpUNet-v1m1: the standalone oracle reproduces the reference file's logits (eval and train mode),
+    loss and every parameter gradient on two ragged scenes."""
+    from oracle import ptv3_model as om
+    from oracle import spunet_model as osp
+    from pointcept_amd import synthetic
+
+    g = np.load(os.path.join(GOLD, "spunet_tiny.npz"))
+    net = osp.SpUNetBase(6, 20, **SPUNET_TINY)
+    assert len(net.state_dict()) == int(g["n_state"])
+    assert [k for k, _ in net.named_parameters()] == list(g["param_names"])
+    net.load_state_dict(om.deterministic_state_dict(net, 1))
+    batch = synthetic.collate([synthetic.indoor_scene(int(s), int(n)) for s, n in zip(g["scene_seeds"], g["n_points"])])
+    assert batch["grid_coord"].sum() == g["input_checksum"][0]
+    inp = {k: torch.from_numpy(v) for k, v in batch.items()}
+    tol = 1e-4 * float(g["logits_absmax"])
+    net.eval()
+    with torch.no_grad():
+        assert np.abs(net(inp).numpy()[::4] - g["logits_eval"]).max() <= tol
+    net.train()
+    out = osp.Segmentor(net)(inp)
+    assert np.abs(out["seg_logits"].detach().numpy()[::4] - g["logits_train"]).max() <= tol
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    out["loss"].backward()
+    norms = np.asarray([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+    assert np.allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-7)
+    assert np.allclose(net.final.weight.grad.numpy(), g["grad_final"], rtol=1e-3, atol=1e-6)
+
+
+def lovasz_cases():
+    from oracle import ptv3_model as om
+
+    g = np.load(os.path.join(GOLD, "lovasz.npz"))
+    for ci in range(int(g["n_cases"])):
+        n, c, n_used = (int(v) for v in g[f"shape_{ci}"])
+        p_ignore, spread = (float(v) for v in g[f"params_{ci}"])
+        x, y = om.lovasz_case(ci, n, c, p_ignore, n_used, spread)
+        assert abs(float(x.double().sum()) - float(g[f"logits_sum_{ci}"])) < 1e-6 and np.array_equal(y.numpy(), g[f"labels_{ci}"])
+        yield ci, x, y, float(g[f"loss_{ci}"]), g[f"grad_{ci}"]
+
+
+def test_oracle_lovasz_matches_reference_golden():
+    """numpy fp64 restatement vs the reference LovaszLoss module (loss and gradient, fp32 reference arithmetic)."""
+    from oracle import losses
+
+    for ci, x, y, loss, grad in lovasz_cases():
+        l, d = losses.lovasz_softmax(x.numpy(), y.numpy(), -1)
+        assert abs(l - loss) <= 2e-5 * max(abs(loss), 1e-3), (ci, l, loss)
+        assert np.abs(d - grad).max() <= 2e-4 * max(np.abs(grad).max(), 1e-12), (ci, np.abs(d - grad).max(), np.abs(grad).max())
+
+
 # ---- C-ABI surface (no compute) -----------------------------------------------------------------
 def test_library_exports_every_declared_symbol():
     from pointcept_amd import _lib

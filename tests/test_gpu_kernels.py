@@ -900,3 +900,100 @@ def test_attn_tables_match_index_algebra(cuda, counts, K):
     assert torch.equal(t2[0].long(), inv) and torch.equal(t2[1].long(), dup_of_point)
     assert torch.equal(t3[0].long(), inv)
     assert torch.equal(t4[0].long(), gidx_primary)
+
+
+# ---- Lovasz-Softmax (the second criterion of the ScanNet config) ------------------------------
+def test_lovasz_softmax_matches_reference_golden_and_oracle(cuda):
+    """fp32 logits: loss vs the REFERENCE module's value (tests/golden/lovasz.npz), gradient vs the fp64 oracle
+    (the reference's own fp32 gradient carries the cancellation noise of lovasz.py:31-32, so it is compared looser)."""
+    from oracle import losses
+    from pointcept_amd import functional as PF
+    from test_golden_cpu import lovasz_cases
+
+    for ci, x, y, loss_ref, grad_ref in lovasz_cases():
+        xe = x.to(cuda).requires_grad_(True)
+        loss = PF.lovasz_softmax(xe, y.to(cuda), -1)
+        (loss * 2.5).backward()
+        lo, do = losses.lovasz_softmax(x.numpy(), y.numpy(), -1)
+        assert abs(loss.item() - loss_ref) <= 1e-4 * max(abs(loss_ref), 1e-3), (ci, loss.item(), loss_ref)
+        assert abs(loss.item() - lo) <= 2e-6 * max(abs(lo), 1e-3), (ci, loss.item(), lo)
+        g = xe.grad.cpu().numpy() / 2.5
+        gmax = max(np.abs(do).max(), 1e-12)
+        assert np.abs(g - do).max() <= 1e-4 * gmax, (ci, np.abs(g - do).max(), gmax)
+        assert np.abs(g - grad_ref).max() <= 1e-3 * gmax, ci
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_lovasz_softmax_16bit_strided_and_edge_cases(cuda, dtype):
+    from oracle import losses
+    from pointcept_amd import functional as PF
+
+    g = torch.Generator().manual_seed(11)
+    n, c = 5000, 20
+    wide = (torch.randn(n, 32, generator=g) * 2).to(dtype)
+    y = torch.randint(0, 17, (n,), generator=g)        # classes 17..19 absent
+    y[torch.rand(n, generator=g) < 0.1] = -1
+    xe = wide.to(cuda).requires_grad_(True)
+    loss = PF.lovasz_softmax(xe[:, :c], y.to(cuda), -1)   # strided view of a wider head output
+    loss.backward()
+    lo, do = losses.lovasz_softmax(wide[:, :c].float().numpy(), y.numpy(), -1)
+    assert abs(loss.item() - lo) <= 1e-5 * abs(lo)
+    got = xe.grad[:, :c].float().cpu().numpy()
+    assert np.abs(got - do).max() <= 2e-2 * np.abs(do).max()      # gradient rounded to the 16-bit input dtype
+    assert float(xe.grad[:, c:].abs().max()) == 0.0
+    # nothing counted -> 0 loss, 0 gradient; empty input -> 0
+    x2 = torch.randn(300, c, generator=g).to(dtype).to(cuda).requires_grad_(True)
+    l2 = PF.lovasz_softmax(x2, torch.full((300,), -1, dtype=torch.int64, device=cuda), -1)
+    l2.backward()
+    assert l2.item() == 0.0 and float(x2.grad.abs().max()) == 0.0
+    assert PF.lovasz_softmax(torch.zeros(0, c, dtype=dtype, device=cuda), torch.zeros(0, dtype=torch.int64, device=cuda), -1).item() == 0.0
+
+
+def test_lovasz_softmax_full_size_properties(cuda):
+    """BASELINE batch (819200 points x 20 classes): bit-reproducible, invariant under a permutation of the points
+    (the loss is a symmetric function of the (error, label) pairs), bounded by [0, 1], zero for a perfect prediction."""
+    from pointcept_amd import functional as PF
+
+    g = torch.Generator().manual_seed(12)
+    n, c = 819200, 20
+    x = torch.randn(n, c, generator=g).to(torch.bfloat16).to(cuda)
+    y = torch.randint(0, c, (n,), generator=g)
+    y[torch.rand(n, generator=g) < 0.05] = -1
+    y = y.to(cuda)
+    xa = x.clone().requires_grad_(True)
+    la = PF.lovasz_softmax(xa, y, -1)
+    la.backward()
+    xb = x.clone().requires_grad_(True)
+    lb = PF.lovasz_softmax(xb, y, -1)
+    lb.backward()
+    assert torch.equal(la, lb) and torch.equal(xa.grad, xb.grad)
+    assert 0.0 < la.item() <= 1.0 and torch.isfinite(xa.grad).all()
+    perm = torch.randperm(n, generator=g).to(cuda)
+    lp = PF.lovasz_softmax(x[perm], y[perm], -1)
+    assert abs(lp.item() - la.item()) <= 1e-6
+    perfect = torch.full((n, c), -30.0, device=cuda)
+    perfect[torch.arange(n, device=cuda), y.clamp(min=0)] = 30.0
+    assert PF.lovasz_softmax(perfect, y, -1).item() <= 1e-6
+
+
+def test_segmentor_ce_plus_lovasz(cuda):
+    """criteria = [CrossEntropyLoss, LovaszLoss] summed (losses/builder.py:22-31), the ScanNet PTv3 configuration."""
+    from oracle import losses
+    from pointcept_amd.segmentor import DefaultSegmentorV2
+
+    class Feat(torch.nn.Module):
+        def forward(self, point):
+            return point["feat"]
+
+    torch.manual_seed(0)
+    seg = DefaultSegmentorV2(20, 64, Feat(), criteria=("ce", "lovasz")).to(cuda).train()
+    g = torch.Generator().manual_seed(13)
+    feat = torch.randn(3000, 64, generator=g)
+    y = torch.randint(-1, 20, (3000,), generator=g)
+    out = seg(dict(feat=feat.to(cuda), segment=y.to(cuda), offset=torch.tensor([3000], device=cuda)))
+    out["loss"].backward()
+    logits = feat @ seg.seg_head.weight.detach().cpu().t() + seg.seg_head.bias.detach().cpu()
+    ce = torch.nn.functional.cross_entropy(logits, y, ignore_index=-1).item()
+    lv, _ = losses.lovasz_softmax(logits.numpy(), y.numpy(), -1)
+    assert abs(out["loss"].item() - (ce + lv)) <= 2e-3 * (ce + lv)
+    assert seg.seg_head.weight.grad is not None and torch.isfinite(seg.seg_head.weight.grad).all()

@@ -158,3 +158,84 @@ def test_ptv3_deterministic(cuda):
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+def test_ptv3_outdoor_depth12_four_channels(cuda):
+    """BASELINE configs[4] in small: LiDAR-like sweeps, in_channels = 4 (coord | strength,
+    nuscenes/semseg-pt-v3m1-0-base.py:16), grid extent ~2500 voxels => serialization depth 12 (39-bit keys, 5 radix
+    passes), very sparse neighbourhoods far from the sensor.  Integer maps bit-exact, features vs the live oracle."""
+    from pointcept_amd import synthetic
+
+    cfg = dict(TINY, in_channels=4, enc_patch_size=(256,) * 5, dec_patch_size=(256,) * 4)
+    orc, eng = _models(cfg, seed=7)
+    eng = eng.to(cuda).eval()
+    orc.eval()
+    batch = synthetic.collate([synthetic.outdoor_scene(81, 5000), synthetic.outdoor_scene(82, 3000)])
+    assert int(batch["grid_coord"].max() + 1).bit_length() == 12
+    torch.manual_seed(5)
+    with torch.no_grad():
+        pe = eng(synthetic.to_torch(batch, cuda))
+    torch.manual_seed(5)
+    with torch.no_grad():
+        po = orc({k: torch.from_numpy(v) for k, v in batch.items()})
+    assert pe.serialized_depth == po.serialized_depth == 12
+    for key in ("serialized_code", "serialized_order", "serialized_inverse"):
+        assert torch.equal(pe[key].cpu(), po[key]), key
+    assert torch.isfinite(pe.feat).all()
+    assert _rel(pe.feat, po.feat) < 2e-2
+
+
+def test_ptv3_mix3d_duplicate_voxels(cuda):
+    """Mix3D (scannet/semseg-pt-v3m1-0-base.py:6 mix_prob) merges two scenes into one batch item WITHOUT re-voxelising:
+    duplicate grid coordinates inside one item are legal input.  Equal keys keep their input order in
+    the sorts (stable, App. A.3), the rulebook lets the lowest row win: engine == oracle, maps bit-exact."""
+    from oracle import ptv3_model as om
+    from pointcept_amd import synthetic
+    from pointcept_amd.segmentor import DefaultSegmentorV2
+
+    cfg = dict(TINY, enc_patch_size=(128,) * 5, dec_patch_size=(128,) * 4)
+    orc_b, eng_b = _models(cfg, seed=8)
+    torch.manual_seed(1)
+    orc = om.SegmentorV2(20, 64, orc_b)
+    eng = DefaultSegmentorV2(20, 64, eng_b)
+    eng.seg_head.load_state_dict(orc.seg_head.state_dict())
+    eng = eng.to(cuda).train()
+    orc.train()
+    a, b = synthetic.indoor_scene(91, 1800), synthetic.indoor_scene(92, 1200)
+    mixed = {k: np.concatenate([a[k], b[k]]) for k in a}
+    assert len(mixed["grid_coord"]) > len(np.unique(mixed["grid_coord"], axis=0))
+    batch = synthetic.collate([mixed, synthetic.indoor_scene(93, 500)])
+    torch.manual_seed(9)
+    oo = orc({k: torch.from_numpy(v) for k, v in batch.items()})
+    oo["loss"].backward()
+    torch.manual_seed(9)
+    oe = eng(synthetic.to_torch(batch, cuda), return_point=True)
+    oe["loss"].backward()
+    assert abs(oe["loss"].item() - oo["loss"].item()) < 2e-2 * abs(oo["loss"].item())
+    worst = 0.0
+    for name, p in eng.named_parameters():
+        r = dict(orc.named_parameters())[name].grad
+        if float(r.norm()) > 1e-3:
+            worst = max(worst, float((p.grad.cpu() - r).norm() / r.norm()))
+    assert worst < 0.1, worst
+
+
+def test_ptv3_fp16_autocast(cuda):
+    """the reference trains under fp16 AMP (train.py:202-208; attention itself still runs in bf16, ptv3m1:209)."""
+    from pointcept_amd import synthetic
+    from pointcept_amd.segmentor import DefaultSegmentorV2
+
+    _, eng_b = _models(dict(TINY, enc_patch_size=(256,) * 5, dec_patch_size=(256,) * 4))
+    eng = DefaultSegmentorV2(20, 64, eng_b).to(cuda).train()
+    batch = synthetic.to_torch(synthetic.collate([synthetic.indoor_scene(5, 3000)]), cuda)
+    torch.manual_seed(2)
+    ref = eng(dict(batch))["loss"]
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    eng.zero_grad(set_to_none=True)
+    torch.manual_seed(2)
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss = eng(dict(batch))["loss"]
+    scaler.scale(loss).backward()
+    assert torch.isfinite(loss) and abs(loss.item() - ref.item()) < 5e-2 * abs(ref.item())
+    for name, p in eng.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name

@@ -200,6 +200,35 @@ def bench_spconv_stages(rows, results, scenes=8, points=102400):
                         f"({r['conv3']['GBps']:.0f} GB/s alg, {r['conv3']['TFLOPs']:.1f} TF/s) | wgrad {r['wgrad']['us']:8.1f} us ({r['wgrad']['TFLOPs']:.1f} TF/s)")
 
 
+def bench_losses(rows, results, n=819200, c=20):
+    """CE and Lovasz-Softmax on the seg-head output of the BASELINE batch (bf16, strided [N, 32] storage)."""
+    from pointcept_amd import functional as PF
+
+    g = torch.Generator().manual_seed(0)
+    wide = torch.randn(n, 32, generator=g).to(torch.bfloat16).to(DEV)
+    y = torch.randint(-1, c, (n,), generator=g).to(DEV)
+    logits = wide[:, :c]
+    t_ce = timeit(lambda: ops.cross_entropy_fwd(logits, y, -1), 10, 2)
+    t_lv = timeit(lambda: ops.lovasz_softmax(logits, y, -1), 10, 2)
+    slot_bytes = 190.0 * n * c   # keys 8w + sort 4 passes x (8r + 8r + 12w) + order 8w+8r + fg 4w+4r + scan 8w+8r + g 4w+4r ...
+
+    def aten():
+        p = logits.float().softmax(1)
+        tot = 0
+        for k in range(c):
+            fg = (y == k).float()
+            e, perm = torch.sort((fg - p[:, k]).abs(), descending=True)
+            tot = tot + e.sum() + fg[perm].cumsum(0)[-1]
+        return tot
+
+    t_at = timeit(aten, 3, 1)
+    r = {"n": n, "c": c, "ce_fwd_us": round(t_ce * 1e6, 1), "lovasz_us": round(t_lv * 1e6, 1),
+         "lovasz_GBps": round(slot_bytes / t_lv / 1e9, 1), "aten_sorts_only_us": round(t_at * 1e6, 1)}
+    results.append(r)
+    rows.append(f"losses [{n} x {c}] bf16: CE fwd {r['ce_fwd_us']:.1f} us | Lovasz fwd+grad {r['lovasz_us']:.1f} us "
+                f"({r['lovasz_GBps']:.0f} GB/s of ~190 B/slot) | ATen softmax + {c} sorts + cumsums alone {r['aten_sorts_only_us']:.1f} us")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -207,7 +236,7 @@ def main():
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     want = lambda name: not only or name in only  # noqa: E731
-    rows, res = [], {"linear": [], "ln": [], "attn": [], "spconv": [], "stages": []}
+    rows, res = [], {"linear": [], "ln": [], "attn": [], "spconv": [], "stages": [], "losses": []}
     stages = [(819200, 32), (202560, 64), (49256, 128), (11400, 256), (2640, 512)]
     if args.quick:
         stages = stages[:2]
@@ -230,6 +259,8 @@ def main():
         bench_spconv(rows, res["spconv"])
     if want("stages"):
         bench_spconv_stages(rows, res["stages"])
+    if want("losses"):
+        bench_losses(rows, res["losses"])
     print("\n".join(rows))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:
