@@ -150,12 +150,37 @@ def _pad_to(x: torch.Tensor, dim: int, mult: int) -> torch.Tensor:
     return F.pad(x, pad)
 
 
+def _merge_duplicate_rows(g: torch.Tensor, rep: torch.Tensor) -> torch.Tensor:
+    """g with, for every voxel listed more than once, the rows of all its copies summed into the representative row
+    rep[i] (the lowest row of the voxel).  Only runs for inputs that carry duplicate coordinates (Mix3D batches);
+    one pass per extra copy, each pass touching every representative at most once: no atomics, fixed order."""
+    n = g.shape[0]
+    rows = (rep != torch.arange(n, device=rep.device, dtype=rep.dtype)).nonzero().squeeze(1)
+    if rows.numel() == 0:
+        return g
+    target, perm = torch.sort(rep[rows], stable=True)
+    rows = rows[perm]
+    _, counts = torch.unique_consecutive(target, return_counts=True)
+    rank = torch.arange(rows.numel(), device=rep.device) - torch.repeat_interleave(torch.cumsum(counts, 0) - counts, counts)
+    out = g.to(torch.float32, copy=True)      # never in place: the weight gradient needs the unmerged rows
+    for k in range(int(counts.max())):
+        sel = rank == k
+        out[target[sel]] += g[rows[sel]].float()
+    return out.to(g.dtype)
+
+
 class _SparseConv(Function):
     """out = conv(feat; weight [C_out, kv, C_in], bias) over gather table `nbr`;
-    `nbr_t` is the table of the transposed map (SubM: the same table, with mirrored weights)."""
+    `nbr_t` is the table of the transposed map (SubM: the same table, with mirrored weights).
+
+    Duplicate voxel coordinates (legal input: Mix3D) make the maps many-to-one -- every copy of a voxel reads
+    the SAME neighbour rows (lowest row wins in the hash) and no row ever reads a non-lowest copy -- so the transposed
+    gather needs two corrections to stay the exact adjoint: `dup_out` = representative row of every OUTPUT row (the
+    incoming gradient of the copies is first summed into their representative), `dup_in` = representative row of every
+    INPUT row (copies that nothing reads get a zero gradient).  Both None for duplicate-free coordinates."""
 
     @staticmethod
-    def forward(ctx, feat, weight, bias, nbr, nbr_t, mirror):
+    def forward(ctx, feat, weight, bias, nbr, nbr_t, mirror, dup_out, dup_in):
         dt = _autocast_dtype(feat)
         c_out, kv, c_in = weight.shape
         f = _pad_to(feat.to(dt), 1, 16).contiguous()
@@ -163,9 +188,8 @@ class _SparseConv(Function):
         b = None if bias is None else _pad_to(bias.float(), 0, 16)
         # (padding the 6 -> 16 channel stem further to 32 so that conv3 takes it was measured SLOWER than conv2:
         #  1.20 ms vs 0.74 ms for the 125-offset table, r01_u)
-        f_fwd, w_fwd = f, w
-        out = ops.spconv_fwd(f_fwd, w_fwd, b, nbr)
-        ctx.save_for_backward(f, w, nbr, nbr_t)
+        out = ops.spconv_fwd(f, w, b, nbr)
+        ctx.save_for_backward(f, w, nbr, nbr_t, dup_out, dup_in)
         ctx.mirror = mirror
         ctx.shape = (c_out, kv, c_in)
         ctx.in_dtype, ctx.w_dtype = feat.dtype, weight.dtype
@@ -175,7 +199,7 @@ class _SparseConv(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad):
-        f, w, nbr, nbr_t = ctx.saved_tensors
+        f, w, nbr, nbr_t, dup_out, dup_in = ctx.saved_tensors
         c_out, kv, c_in = ctx.shape
         g = _pad_to(grad.to(f.dtype), 1, 16).contiguous()
         dfeat = dw = dbias = None
@@ -183,17 +207,21 @@ class _SparseConv(Function):
             wt = w.permute(2, 1, 0)
             if ctx.mirror:
                 wt = wt.flip(1)
-            dfeat = ops.spconv_fwd(g, wt.contiguous(), None, nbr_t)[:, :c_in].to(ctx.in_dtype)
+            gm = g if dup_out is None else _merge_duplicate_rows(g, dup_out)
+            dfeat = ops.spconv_fwd(gm, wt.contiguous(), None, nbr_t)[:, :c_in].to(ctx.in_dtype)
+            if dup_in is not None:
+                own = dup_in == torch.arange(dup_in.numel(), device=dup_in.device, dtype=dup_in.dtype)
+                dfeat = dfeat * own[:, None].to(dfeat.dtype)
         if ctx.needs_input_grad[1]:
             dw = ops.spconv_wgrad(f, g, nbr)[:c_out, :, :c_in].to(ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = ops.column_sum(grad)
-        return dfeat, dw, dbias, None, None, None
+        return dfeat, dw, dbias, None, None, None, None, None
 
 
-def sparse_conv(feat, weight, bias, nbr, nbr_t, mirror: bool):
+def sparse_conv(feat, weight, bias, nbr, nbr_t, mirror: bool, dup_out=None, dup_in=None):
     """weight: [C_out, kv, C_in] (a view of the spconv-layout parameter [C_out,k0,k1,k2,C_in])."""
-    return _SparseConv.apply(feat, weight, bias, nbr, nbr_t, mirror)
+    return _SparseConv.apply(feat, weight, bias, nbr, nbr_t, mirror, dup_out, dup_in)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -17,9 +17,10 @@ BatchNorm / GELU / residual adds stay on PyTorch-ROCm (ATen).
 Behaviours of the reference that change numerics are reproduced on purpose:
 stale sparse_conv_feat in the first decoder block's CPE (D.1), per-point DropPath (D.2), CPU-RNG
 order shuffling (D.3), bf16 attention regardless of the AMP dtype (D.4).
-Not implemented (raise): enable_rpe=True, PDNorm (pdnorm_bn / pdnorm_ln), head_dim != 16.
-`enable_flash=False` runs the same attention kernel (fixed patch size, bf16) -- the reference's
-data-dependent K of the dense branch (:173-176) is not reproduced.
+Not implemented (raise): PDNorm (pdnorm_bn / pdnorm_ln); head_dim != 16 or attention dropout with enable_flash=True.
+`enable_flash=False` follows the reference's patch-size rule (min(smallest scene, patch_size), ptv3m1:173-176) and runs the
+same attention kernel when it can (no RPE / dropout, head_dim 16; bf16 operands), else the dense [P,H,K,K] branch of
+:190-206 (RPE bias, upcasts, dropout) in torch ops on the GPU.
 """
 from __future__ import annotations
 
@@ -111,25 +112,95 @@ class DropPath(nn.Module):
         return x * mask
 
 
+class RPE(nn.Module):
+    """Relative position bias of the dense attention branch (ptv3m1:29-48): one learned [2 bnd + 1, H] table per axis
+    (stored stacked, state-dict key `rpe_table` [3 (2 bnd + 1), H]), looked up by the clamped grid offset between the
+    two points of a pair and summed over x, y, z.  bnd = int((4 K)^(1/3) * 2)."""
+
+    def __init__(self, patch_size, num_heads):
+        super().__init__()
+        self.patch_size, self.num_heads = patch_size, num_heads
+        self.pos_bnd = int((4 * patch_size) ** (1 / 3) * 2)
+        self.rpe_num = 2 * self.pos_bnd + 1
+        self.rpe_table = nn.Parameter(torch.zeros(3 * self.rpe_num, num_heads))
+        nn.init.trunc_normal_(self.rpe_table, std=0.02)
+
+    def forward(self, coord):                      # [P, K, K, 3] integer offsets -> [P, H, K, K]
+        idx = coord.clamp(-self.pos_bnd, self.pos_bnd) + self.pos_bnd
+        bias = self.rpe_table[idx[..., 0]]
+        bias = bias + self.rpe_table[idx[..., 1] + self.rpe_num]
+        bias = bias + self.rpe_table[idx[..., 2] + 2 * self.rpe_num]
+        return bias.permute(0, 3, 1, 2)
+
+
 class SerializedAttention(PointModule):
+    """ptv3m1:51-222.  enable_flash=True: the MFMA window-attention kernels (attention.hip) behind the
+    flash_attn_varlen_qkvpacked_func contract.  enable_flash=False: the reference's second branch -- the patch size
+    shrinks to the smallest scene of the batch (:173-176) so every patch is full; without RPE / attention dropout /
+    head_dim != 16 that is still the same kernel (bf16 operands, fp32 accumulation), otherwise the dense
+    [P, H, K, K] formulation of :190-206 in torch ops on the GPU (RPE bias, upcasts, dropout)."""
+
     def __init__(self, channels, num_heads, patch_size, qkv_bias=True, qk_scale=None, attn_drop=0.0, proj_drop=0.0,
                  order_index=0, enable_rpe=False, enable_flash=True, upcast_attention=True, upcast_softmax=True):
         super().__init__()
         assert channels % num_heads == 0
-        if enable_rpe:
-            raise PtcoreError("enable_rpe=True is not implemented by the engine")
-        if channels // num_heads != 16:
-            raise PtcoreError(f"engine attention needs head_dim 16, got {channels // num_heads}")
-        if attn_drop != 0.0:
-            raise PtcoreError("attention dropout is not implemented (every reference config uses attn_drop=0.0)")
         self.channels, self.num_heads = channels, num_heads
         self.scale = qk_scale or (channels // num_heads) ** -0.5
         self.order_index = order_index
-        self.patch_size = patch_size
-        self.enable_flash = enable_flash
+        self.upcast_attention, self.upcast_softmax = upcast_attention, upcast_softmax
+        self.enable_rpe, self.enable_flash = enable_rpe, enable_flash
+        if enable_flash:
+            assert enable_rpe is False, "Set enable_rpe to False when enable Flash Attention"               # ptv3m1:78-86
+            assert upcast_attention is False, "Set upcast_attention to False when enable Flash Attention"
+            assert upcast_softmax is False, "Set upcast_softmax to False when enable Flash Attention"
+            if channels // num_heads != 16:
+                raise PtcoreError(f"engine flash attention needs head_dim 16, got {channels // num_heads}")
+            if attn_drop != 0.0:
+                raise PtcoreError("attention dropout is not implemented in the flash branch (every reference config uses 0.0)")
+            self.patch_size = patch_size
+            self.attn_drop = attn_drop
+        else:
+            self.patch_size_max = patch_size       # ptv3m1:92-97
+            self.patch_size = 0
+            self.attn_drop = nn.Dropout(attn_drop)
         self.qkv = PNN.Linear(channels, channels * 3, bias=qkv_bias)
         self.proj = PNN.Linear(channels, channels)
         self.proj_drop = nn.Dropout(proj_drop)
+        self.rpe = RPE(patch_size, num_heads) if enable_rpe else None
+
+    def _kernel_ok(self) -> bool:
+        drop = self.attn_drop.p if isinstance(self.attn_drop, nn.Dropout) else self.attn_drop
+        return (self.rpe is None and self.channels // self.num_heads == 16 and self.patch_size <= 1024
+                and (drop == 0.0 or not self.training))
+
+    @torch.no_grad()
+    def get_rel_pos(self, point, order):
+        """ptv3m1:104-112, cached per order under the reference's key."""
+        key = f"rel_pos_{self.order_index}"
+        if key not in point.keys():
+            g = point.grid_coord[order].reshape(-1, self.patch_size, 3)
+            point[key] = g.unsqueeze(2) - g.unsqueeze(1)
+        return point[key]
+
+    def _forward_dense(self, point):
+        H, K, C = self.num_heads, self.patch_size, self.channels
+        pad, unpad, _ = self.get_padding_and_inverse(point)
+        order = point.serialized_order[self.order_index][pad]
+        inverse = unpad[point.serialized_inverse[self.order_index]]
+        qkv = self.qkv(point.feat)[order]
+        q, k, v = qkv.reshape(-1, K, 3, H, C // H).permute(2, 0, 3, 1, 4).unbind(dim=0)   # [P, H, K, D]
+        if self.upcast_attention:
+            q, k = q.float(), k.float()
+        attn = (q * self.scale) @ k.transpose(-2, -1)
+        if self.rpe is not None:
+            attn = attn + self.rpe(self.get_rel_pos(point, order))
+        if self.upcast_softmax:
+            attn = attn.float()
+        attn = torch.softmax(attn, dim=-1)
+        attn = self.attn_drop(attn).to(qkv.dtype)
+        feat = (attn @ v).transpose(1, 2).reshape(-1, C)[inverse]
+        point.feat = self.proj_drop(self.proj(feat))
+        return point
 
     @torch.no_grad()
     def get_padding_and_inverse(self, point):
@@ -162,6 +233,12 @@ class SerializedAttention(PointModule):
         return point[key]
 
     def forward(self, point):
+        if not self.enable_flash:
+            _, offset_host = point._host_facts()
+            smallest = min(b - a for a, b in zip([0] + list(offset_host[:-1]), offset_host))
+            self.patch_size = min(int(smallest), self.patch_size_max)      # ptv3m1:173-176
+            if not self._kernel_ok():
+                return self._forward_dense(point)
         H, K, C = self.num_heads, self.patch_size, self.channels
         _, _, cu_seqlens = self.get_padding_and_inverse(point)
         gidx, inv, dup_of_point, gidx_primary, tabs = self._index_maps(point)
@@ -357,6 +434,7 @@ class SerializedPooling(PointModule):
         child["_ptc_pool_csr"] = (order0, idx_ptr)
         child["_ptc_coord_max"] = [int(m) >> pooling_depth for m in coord_max]
         child["_ptc_offset_host"] = child.offset.tolist()
+        child["_ptc_n_dup"] = 0   # one row per cluster: pooled coordinates are unique
         if getattr(self, "norm", None) is not None:
             child = self.norm(child)
         if getattr(self, "act", None) is not None:

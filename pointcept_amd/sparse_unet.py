@@ -118,11 +118,16 @@ class SpUNetBase(nn.Module):
         batch = offset2batch(offset)
         from . import ops
 
-        host = torch.cat([ops.coord_max(grid_coord), offset[-1:].to(torch.int64) * 0 + offset.numel()]).tolist()
+        indices = torch.cat([batch.unsqueeze(-1).int(), grid_coord.int()], dim=1).contiguous()
+        n = indices.shape[0]
+        table = ops.HashTable(indices)                       # reused by the stem / subm0 rulebooks below
+        rep = ops.rulebook_subm(indices, 1, table)[0]        # lowest row holding each row's voxel
+        n_dup = (rep != torch.arange(n, device=rep.device, dtype=rep.dtype)).sum().reshape(1).to(torch.int64)
+        host = torch.cat([ops.coord_max(grid_coord), n_dup]).tolist()
         sparse_shape = [int(m) + 96 for m in host[:3]]  # spconv_unet_v1m1_base.py:250 (one host sync)
-        x = spconv.SparseConvTensor(
-            features=feat, indices=torch.cat([batch.unsqueeze(-1).int(), grid_coord.int()], dim=1).contiguous(),
-            spatial_shape=sparse_shape, batch_size=int(host[3]))
+        x = spconv.SparseConvTensor(features=feat, indices=indices, spatial_shape=sparse_shape, batch_size=int(offset.numel()))
+        x.indice_dict["__hash__"] = table
+        spconv.mark_duplicates(x, host[3] > 0)   # Mix3D batches: the conv backward needs to know (functional._SparseConv)
         x = self.conv_input(x)
         skips = [x]
         for s in range(self.num_stages):

@@ -54,6 +54,56 @@ class SparseConvTensor:
         return None if key is None else self.indice_dict.get(key)
 
 
+# ---- duplicate voxel coordinates ---------------------------------------------------------------------------------
+# Legal input (Mix3D merges two scenes into one batch item without re-voxelising).  Forward semantics:
+# the lowest row of a voxel wins every lookup.  The backward needs the representative row of every row (see
+# functional._SparseConv); it is kept per coordinate set in indice_dict[("__dup__", id(indices))] = [indices, state],
+# state = None (unknown) | False (no duplicates) | True (has duplicates, representatives not computed yet) | rep [N] int64.
+def _dup_entry(x):
+    key = ("__dup__", id(x.indices))
+    e = x.indice_dict.get(key)
+    if e is None or e[0] is not x.indices:
+        e = x.indice_dict[key] = [x.indices, None]
+    return e
+
+
+def mark_duplicates(x, has_duplicates: bool) -> None:
+    """Tell the engine what the caller already knows about x.indices (the engine's own models learn it in the one
+    host sync of the forward); without it the first convolution on x spends a host sync to find out."""
+    e = _dup_entry(x)
+    if e[1] is None or isinstance(e[1], bool):
+        e[1] = bool(has_duplicates)
+
+
+def _hash_of(x):
+    table = x.indice_dict.get("__hash__")
+    if table is None or table.indices is not x.indices:
+        table = ops.HashTable(x.indices)
+        x.indice_dict["__hash__"] = table
+    return table
+
+
+def _dup_rep(x, center_row=None):
+    """representative (lowest) row of every row of x, or None when x.indices has no duplicates."""
+    e = _dup_entry(x)
+    state = e[1]
+    if state is False:
+        return None
+    if torch.is_tensor(state):
+        return state
+    n = x.indices.shape[0]
+    if n == 0:
+        e[1] = False
+        return None
+    rep = center_row if center_row is not None else ops.rulebook_subm(x.indices, 1, _hash_of(x))[0]
+    if state is None:   # coordinates of unknown provenance: one host sync per coordinate set
+        if not bool((rep != torch.arange(n, device=rep.device, dtype=rep.dtype)).any().item()):
+            e[1] = False
+            return None
+    e[1] = rep.long()
+    return e[1]
+
+
 class SparseModule(nn.Module):
     """marker base class (spconv.pytorch.modules.SparseModule)"""
 
@@ -170,14 +220,11 @@ class SubMConv3d(_SparseConvolution):
         key = ("subm", self.indice_key, k)
         rb = x.indice_dict.get(key) if self.indice_key is not None else None
         if rb is None:
-            table = x.indice_dict.get("__hash__")
-            if table is None or table.indices is not x.indices:
-                table = ops.HashTable(x.indices)
-                x.indice_dict["__hash__"] = table
-            rb = ops.rulebook_subm(x.indices, k, table)
+            rb = ops.rulebook_subm(x.indices, k, _hash_of(x))
             if self.indice_key is not None:
                 x.indice_dict[key] = rb
-        return x.replace_feature(PF.sparse_conv(x.features, self._w(), self.bias, rb, rb, True))
+        rep = _dup_rep(x, rb[rb.shape[0] // 2])   # centre offset = the row that wins the lookup of its own voxel
+        return x.replace_feature(PF.sparse_conv(x.features, self._w(), self.bias, rb, rb, True, rep, rep))
 
 
 class SparseConv3d(_SparseConvolution):
@@ -193,11 +240,14 @@ class SparseConv3d(_SparseConvolution):
                 x.indices, _coord_bits(x.spatial_shape), max(1, int(x.batch_size).bit_length()))
             out_shape = [(s - 2) // 2 + 1 for s in x.spatial_shape]
             rb = dict(out_indices=out_indices, nbr_down=nbr_down, nbr_up=nbr_up, in_indices=x.indices,
-                      in_shape=x.spatial_shape, out_shape=out_shape)
+                      in_shape=x.spatial_shape, out_shape=out_shape, in_rep=_dup_rep(x))
             if self.indice_key is not None:
                 x.indice_dict[key] = rb
-        feat = PF.sparse_conv(x.features, self._w(), self.bias, rb["nbr_down"], rb["nbr_up"], False)
-        return SparseConvTensor(feat, rb["out_indices"], rb["out_shape"], x.batch_size, indice_dict=x.indice_dict)
+        # copies of a voxel other than the lowest row are read by no output row: dup_in zeroes their gradient
+        feat = PF.sparse_conv(x.features, self._w(), self.bias, rb["nbr_down"], rb["nbr_up"], False, None, rb["in_rep"])
+        out = SparseConvTensor(feat, rb["out_indices"], rb["out_shape"], x.batch_size, indice_dict=x.indice_dict)
+        mark_duplicates(out, False)   # coarse sites are unique by construction
+        return out
 
 
 class SparseInverseConv3d(_SparseConvolution):
@@ -207,7 +257,8 @@ class SparseInverseConv3d(_SparseConvolution):
         rb = x.indice_dict.get(("down", self.indice_key))
         if rb is None:
             raise PtcoreError(f"SparseInverseConv3d: no SparseConv3d with indice_key={self.indice_key!r} ran before")
-        feat = PF.sparse_conv(x.features, self._w(), self.bias, rb["nbr_up"], rb["nbr_down"], False)
+        # every copy of a fine voxel receives an output row, the transposed table reads only the lowest: dup_out merges
+        feat = PF.sparse_conv(x.features, self._w(), self.bias, rb["nbr_up"], rb["nbr_down"], False, rb["in_rep"], None)
         return SparseConvTensor(feat, rb["in_indices"], rb["in_shape"], x.batch_size, indice_dict=x.indice_dict)
 
 

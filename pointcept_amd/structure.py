@@ -100,10 +100,20 @@ class Point(_RefPoint if _RefPoint is not None else AttrDict):
                 self["grid_coord"] = torch.div(self.coord - self.coord.min(0)[0], self.grid_size,
                                                rounding_mode="trunc").int()  # structure.py:68-70
             cmax = ops.coord_max(self.grid_coord)
-            packed = torch.cat([cmax, self.offset.to(torch.int64)])
+            # duplicate voxel coordinates (Mix3D batches) change the adjoint of the sparse convolutions
+            # (functional._SparseConv): count them here so that the answer rides in the same host sync
+            n = self.grid_coord.shape[0]
+            if n > 0 and "batch" in self.keys():
+                idx = torch.cat([self.batch.unsqueeze(-1).int(), self.grid_coord.int()], dim=1).contiguous()
+                rep = ops.rulebook_subm(idx, 1, ops.HashTable(idx))[0]
+                n_dup = (rep != torch.arange(n, device=rep.device, dtype=rep.dtype)).sum().reshape(1)
+            else:
+                n_dup = cmax.new_zeros(1)
+            packed = torch.cat([cmax, n_dup.to(torch.int64), self.offset.to(torch.int64)])
             host = packed.tolist()  # the single host sync (reference: structure.py:74,138,145 + ptv3m1:142-164)
             self["_ptc_coord_max"] = host[:3]
-            self["_ptc_offset_host"] = host[3:]
+            self["_ptc_n_dup"] = int(host[3])
+            self["_ptc_offset_host"] = host[4:]
         return self["_ptc_coord_max"], self["_ptc_offset_host"]
 
     def serialization(self, order="z", depth=None, shuffle_orders=False):
@@ -182,3 +192,4 @@ class Point(_RefPoint if _RefPoint is not None else AttrDict):
         self["sparse_shape"] = sparse_shape
         self["sparse_conv_feat"] = spconv.SparseConvTensor(
             features=self.feat, indices=indices, spatial_shape=sparse_shape, batch_size=len(offset_host))
+        spconv.mark_duplicates(self["sparse_conv_feat"], self.get("_ptc_n_dup", 0) > 0)

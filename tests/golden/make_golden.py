@@ -16,6 +16,9 @@ Fixtures
   spunet_tiny.npz   : SpUNet-v1m1 (the reference file spconv_unet_v1m1_base.py on oracle/shims.py), channels
                       (16,32,48,64,64,48,32,32), layers (1,2,1,1,1,1,2,1), two scenes (3000 + 1200 voxels):
                       eval-mode and train-mode logits (every 4th row), CE loss and the gradient norm of every parameter.
+  ptv3_rpe.npz      : the reference's dense attention branch (enable_flash=False, enable_rpe=True, both upcasts), patch
+                      256 on scenes of 900 + 200 voxels (=> K shrinks to the smallest scene at every stage):
+                      eval output, train-mode output rows, loss = mean(feat^2) and all gradient norms.
   lovasz.npz        : logits / labels -> LovaszLoss(mode="multiclass", ignore_index=-1) loss and gradient
                       (pointcept/models/losses/lovasz.py), five shapes incl. absent classes and a single point.
 """
@@ -38,6 +41,8 @@ TINY_CFG = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), dec_dep
                 enc_patch_size=(1024,) * 5, dec_patch_size=(1024,) * 4, drop_path=0.0, shuffle_orders=False)
 
 
+RPE_CFG = dict(TINY_CFG, enc_patch_size=(256,) * 5, dec_patch_size=(256,) * 4, enable_flash=False, enable_rpe=True,
+               upcast_attention=True, upcast_softmax=True)
 SPUNET_CFG = dict(base_channels=16, channels=(16, 32, 48, 64, 64, 48, 32, 32), layers=(1, 2, 1, 1, 1, 1, 2, 1))
 
 
@@ -133,6 +138,31 @@ def main():
         grad_conv_input=ref.conv_input[0].weight.grad.numpy().astype(np.float32),
         grad_final=ref.final.weight.grad.numpy().astype(np.float32),
         n_state=np.asarray(len(sd)))
+    # ---- PTv3 dense attention branch + RPE (ptv3m1:29-48,173-206) -------------------------------
+    torch.manual_seed(0)
+    ref = ptv3.PointTransformerV3(**RPE_CFG)
+    sd = om.deterministic_state_dict(ref, 2)
+    ref.load_state_dict(sd)
+    batch = synthetic.collate([synthetic.indoor_scene(23, 900), synthetic.indoor_scene(24, 200)])
+    inp = {k: torch.from_numpy(v) for k, v in batch.items()}
+    ref.eval()
+    torch.manual_seed(5)     # SerializedPooling shuffles the order rows with the CPU generator even when the model's
+    with torch.no_grad():    # shuffle_orders is False (ptv3m1:624-632 builds it with its default shuffle_orders=True)
+        feat_eval = ref(dict(inp)).feat.numpy()
+    ref.train()
+    torch.manual_seed(6)
+    feat = ref(dict(inp)).feat
+    loss = feat.pow(2).mean()
+    loss.backward()
+    names = [k for k, _ in ref.named_parameters()]
+    np.savez_compressed(
+        os.path.join(OUT, "ptv3_rpe.npz"), scene_seeds=np.asarray([23, 24]), n_points=np.asarray([900, 200]),
+        input_checksum=np.asarray([batch["grid_coord"].sum()]), feat_eval_rows=feat_eval[::4].astype(np.float32), feat_absmax=np.asarray(float(np.abs(feat_eval).max())),
+        feat_train_rows=feat.detach().numpy()[::4].astype(np.float32), loss=np.asarray(float(loss.detach())),
+        param_names=np.asarray(names),
+        grad_norms=np.asarray([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in ref.named_parameters()]),
+        grad_rpe_dec0=ref.dec.dec0.block0.attn.rpe.rpe_table.grad.numpy().astype(np.float32))
+
     # ---- Lovasz-Softmax ------------------------------------------------------------------------
     import importlib
     import types

@@ -116,6 +116,42 @@ def test_oracle_ptv3_tiny_matches_reference_golden():
     assert np.allclose(np.linalg.norm(out.astype(np.float64), axis=1), g["feat_row_norm"], rtol=1e-4, atol=1e-4)
 
 
+RPE_CFG = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), dec_depths=(1, 1, 1, 1), enc_patch_size=(256,) * 5,
+               dec_patch_size=(256,) * 4, drop_path=0.0, shuffle_orders=False, enable_flash=False, enable_rpe=True,
+               upcast_attention=True, upcast_softmax=True)
+
+
+def test_oracle_ptv3_dense_rpe_branch_matches_reference_golden():
+    """ptv3m1:29-48,173-206: dense attention with the patch size shrunk to the smallest scene, RPE bias, upcasts --
+    eval output, train output, loss and every gradient norm (incl. the RPE tables) vs the reference model."""
+    from oracle import ptv3_model as om
+    from pointcept_amd import synthetic
+
+    g = np.load(os.path.join(GOLD, "ptv3_rpe.npz"))
+    torch.manual_seed(0)
+    net = om.PointTransformerV3(**RPE_CFG)
+    assert [k for k, _ in net.named_parameters()] == list(g["param_names"])
+    net.load_state_dict(om.deterministic_state_dict(net, 2))
+    batch = synthetic.collate([synthetic.indoor_scene(int(s), int(n)) for s, n in zip(g["scene_seeds"], g["n_points"])])
+    assert batch["grid_coord"].sum() == g["input_checksum"][0]
+    inp = {k: torch.from_numpy(v) for k, v in batch.items()}
+    tol = 1e-4 * float(g["feat_absmax"])
+    net.eval()
+    torch.manual_seed(5)   # pooling shuffles the order rows with the CPU generator (ptv3m1:408-412), seeds as in make_golden.py
+    with torch.no_grad():
+        assert np.abs(net(dict(inp)).feat.numpy()[::4] - g["feat_eval_rows"]).max() <= tol
+    net.train()
+    torch.manual_seed(6)
+    feat = net(dict(inp)).feat
+    assert np.abs(feat.detach().numpy()[::4] - g["feat_train_rows"]).max() <= tol
+    loss = feat.pow(2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    norms = np.asarray([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in net.named_parameters()])
+    assert np.allclose(norms, g["grad_norms"], rtol=5e-3, atol=1e-7)
+    assert np.allclose(net.dec.dec0.block0.attn.rpe.rpe_table.grad.numpy(), g["grad_rpe_dec0"], rtol=1e-3, atol=1e-7)
+
+
 SPUNET_TINY = dict(base_channels=16, channels=(16, 32, 48, 64, 64, 48, 32, 32), layers=(1, 2, 1, 1, 1, 1, 2, 1))
 
 

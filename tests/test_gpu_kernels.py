@@ -997,3 +997,49 @@ def test_segmentor_ce_plus_lovasz(cuda):
     lv, _ = losses.lovasz_softmax(logits.numpy(), y.numpy(), -1)
     assert abs(out["loss"].item() - (ce + lv)) <= 2e-3 * (ce + lv)
     assert seg.seg_head.weight.grad is not None and torch.isfinite(seg.seg_head.weight.grad).all()
+
+
+def test_spconv_autograd_with_duplicate_voxels(cuda):
+    """Mix3D batches list some voxels twice (or more).  Forward: the lowest row wins every lookup; the backward must be
+    the exact adjoint of THAT map (copies that nothing reads get zero gradient, the gradients of identical output rows
+    add up in the representative).  SubM k=3, strided k=2 s=2 and its inverse, chained, vs the oracle's plain autograd."""
+    from oracle import shims
+    from pointcept_amd import spconv_api as sp
+
+    g = torch.Generator().manual_seed(21)
+    base = torch.unique(torch.randint(0, 12, (400, 3), generator=g), dim=0)
+    extra = base[torch.randperm(base.shape[0], generator=g)[:60]]
+    coords = torch.cat([base, extra, extra[:15]])                       # 60 voxels twice, 15 of them three times
+    coords = coords[torch.randperm(coords.shape[0], generator=g)]
+    n = coords.shape[0]
+    batch = (torch.arange(n) >= n // 2).int()
+    indices = torch.cat([batch[:, None], coords.int()], dim=1).contiguous()
+    feat = torch.randn(n, 16, generator=g)
+    probe = torch.randn(n, 16, generator=g)
+
+    def build(mod):
+        torch.manual_seed(3)
+        return [mod.SubMConv3d(16, 32, 3, bias=True, indice_key="a"), mod.SparseConv3d(32, 32, 2, stride=2, bias=False, indice_key="d"),
+                mod.SubMConv3d(32, 32, 3, bias=False, indice_key="b"), mod.SparseInverseConv3d(32, 16, 2, bias=False, indice_key="d"),
+                mod.SubMConv3d(16, 16, 3, bias=False, indice_key="a")]
+
+    ref_layers, eng_layers = build(shims), build(sp)
+    for a, b in zip(ref_layers, eng_layers):
+        b.load_state_dict(a.state_dict())
+        b.to(cuda)
+    fo = feat.clone().requires_grad_(True)
+    x = shims.SparseConvTensor(fo, indices, [108, 108, 108], 2)
+    for layer in ref_layers:
+        x = layer(x)
+    (x.features * probe).sum().backward()
+    fe = feat.to(cuda).requires_grad_(True)
+    y = sp.SparseConvTensor(fe, indices.to(cuda), [108, 108, 108], 2)
+    for layer in eng_layers:
+        y = layer(y)
+    (y.features * probe.to(cuda)).sum().backward()
+    assert torch.allclose(y.features.detach().cpu(), x.features.detach(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(fe.grad.cpu(), fo.grad, rtol=1e-3, atol=1e-4)
+    assert float((fo.grad.abs().sum(1) == 0).float().mean()) > 0.05            # the unread copies
+    for a, b in zip(ref_layers, eng_layers):
+        assert torch.allclose(b.weight.grad.cpu(), a.weight.grad, rtol=1e-3, atol=1e-3), a.indice_key
+    assert torch.allclose(eng_layers[0].bias.grad.cpu(), ref_layers[0].bias.grad, rtol=1e-3, atol=1e-3)
