@@ -93,7 +93,9 @@ def attention_roofline(device, scenes: int, points: int):
     try:
         import glob
 
-        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*attn_pmc.json")))[-1]
+        # session tags run r01_a .. r01_z, r01_aa ..: order by (length, name) to get the most recent one
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*attn_pmc.json")),
+                    key=lambda q: (len(os.path.basename(q)), os.path.basename(q)))[-1]
         k = json.load(open(pm))["kernels"]["attn_fwd_kernel"]
         if (n_seq, H) == (800, 4):
             out["traffic"] = round(k["hbm_bytes"])

@@ -144,6 +144,14 @@ int ptc_pool_maps_fill(const int64_t* order0, const int64_t* cluster, int64_t n,
 int ptc_pool_child_codes(const int64_t* code_in, int64_t n, int k, const int64_t* head,
                          int64_t n_cluster, int shift, int64_t* code_out, ptc_stream_t stream);
 
+/* Cluster counts of every pooling level from the stage-0 codes, in one pass: counts[l][b] = number of distinct values of
+ * code0 >> shifts[l] among the points of scene b (b = code >> batch_shift), i.e. the child point counts that
+ * `torch.unique(code >> depth*3)` (ptv3m1:384-390) will produce at level l.  Lets the host size every level of the
+ * hierarchy with ONE device->host copy instead of two per SerializedPooling.  code0 [n] = any row of serialized_code,
+ * order0 [n] = its sorting permutation; n_levels <= 8; counts [n_levels][n_batch] int64 (zeroed here). */
+int ptc_pool_level_counts(const int64_t* code0, const int64_t* order0, int64_t n, int batch_shift, int n_batch,
+                          const int* shifts, int n_levels, int64_t* counts, ptc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * E. Row gathers / segmented reductions (feature traffic around the attention and pooling).
  *   ptc_gather_rows      : out[i,:] = src[idx[i],:] (+ src[idx2[i],:] if idx2 && idx2[i]>=0);

@@ -33,6 +33,7 @@ _SIGNATURES = {
     "ptc_pool_maps_count": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_pool_maps_fill": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     "ptc_pool_child_codes": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    "ptc_pool_level_counts": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr]),
     "ptc_gather_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "ptc_segment_csr_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "ptc_segment_csr_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),

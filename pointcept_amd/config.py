@@ -14,6 +14,8 @@ settings), and so a regression can be bisected without a rebuild.
                      sorting the points along the first serialization curve for L2 locality
   PTC_FUSE_MLP=0     the MLP runs fc1, GELU, fc2 as three kernels (+2 in the backward) instead of fusing GELU into
                      fc1's epilogue and GELU' into the epilogue of fc2's input gradient
+  PTC_PREFETCH_LEVELS=0  every SerializedPooling fetches its own sizes (two host syncs per stage) instead of the one
+                     up-front copy of all level sizes (ptc_pool_level_counts)
   PTC_FUSE_BLOCK=0   the three residual joints of a PTv3 Block run as separate LayerNorm / add / cast
                      kernels instead of the fused add_norm passes
 """
@@ -35,3 +37,4 @@ FUSE_GATHER = _flag("PTC_FUSE_GATHER", True)
 SORT_POINTS = _flag("PTC_SORT_POINTS", True)
 FUSE_BLOCK = _flag("PTC_FUSE_BLOCK", True)
 FUSE_MLP = _flag("PTC_FUSE_MLP", True)
+PREFETCH_LEVELS = _flag("PTC_PREFETCH_LEVELS", True)

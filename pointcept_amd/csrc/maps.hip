@@ -238,3 +238,86 @@ extern "C" int ptc_pool_child_codes(const int64_t* code_in, int64_t n, int k, co
   PTC_CHECK_LAUNCH("pool_child_codes_kernel");
   return PTC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Cluster counts of EVERY pooling level in one pass over the stage-0 codes (one host sync instead of two per level).
+// A cluster of level l is a cell of 2^d_l voxels per axis; all serialization curves are hierarchical (Morton bit
+// interleave; Hilbert: tests/test_golden_cpu.py::test_hilbert_prefix_property), so `code >> shift_l` names that cell
+// for whichever curve sits in row 0, and the number of cells per scene equals the number of changes of code >> shift_l
+// along the sorted row.  counts[l][b] = clusters of scene b at level l.  Scenes are contiguous in sorted order, so a
+// wave normally sees one scene: one integer atomic per (wave, level); exact and order independent.
+// ------------------------------------------------------------------------------------------------
+#define PL_MAX_LEVELS 8
+struct PoolLevelShifts { int n; int shift[PL_MAX_LEVELS]; };
+
+#define PL_CHUNK 512    // consecutive sorted positions per wave: scenes are contiguous, so a wave flushes ~once per level
+__global__ void __launch_bounds__(256)
+pool_level_counts_kernel(const int64_t* __restrict__ code0, const int64_t* __restrict__ order0, int64_t n, int batch_shift,
+                         int n_batch, PoolLevelShifts lv, unsigned long long* __restrict__ counts) {
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = ptc_lane();
+  const int64_t begin = wave * PL_CHUNK;
+  if (begin >= n) return;                               // whole wave leaves together
+  const int64_t end = begin + PL_CHUNK < n ? begin + PL_CHUNK : n;
+  int cur_b = -1;                                       // scene the running counters belong to (wave-uniform)
+  unsigned int run[PL_MAX_LEVELS];
+#pragma unroll
+  for (int l = 0; l < PL_MAX_LEVELS; ++l) run[l] = 0;
+  for (int64_t base = begin; base < end; base += 64) {  // trip count is wave-uniform: ballots below are safe
+    const int64_t r = base + lane;
+    const bool valid = r < end;
+    const uint64_t c = valid ? (uint64_t)code0[order0[r]] : 0ull;
+    uint64_t prev = __shfl_up(c, 1, 64);                 // the sorted predecessor sits in the previous lane
+    if (lane == 0) prev = r > 0 ? (uint64_t)code0[order0[r - 1]] : ~0ull;
+    int b = valid ? (int)(c >> batch_shift) : -1;
+    if (b >= n_batch) b = n_batch - 1;
+    const int b0 = __shfl(b, 0, 64);
+    const bool uniform = __all(!valid || b == b0);
+    if (!uniform || b0 != cur_b) {                      // scene boundary: flush the running counters
+      if (lane == 0 && cur_b >= 0) {
+#pragma unroll
+        for (int l = 0; l < PL_MAX_LEVELS; ++l)
+          if (l < lv.n && run[l]) atomicAdd(&counts[(int64_t)l * n_batch + cur_b], (unsigned long long)run[l]);
+      }
+#pragma unroll
+      for (int l = 0; l < PL_MAX_LEVELS; ++l) run[l] = 0;
+      cur_b = uniform ? b0 : -1;
+    }
+#pragma unroll
+    for (int l = 0; l < PL_MAX_LEVELS; ++l) {
+      if (l < lv.n) {                                   // wave-uniform condition
+        const bool head = valid && (r == 0 || (c >> lv.shift[l]) != (prev >> lv.shift[l]));
+        if (uniform) run[l] += (unsigned int)__popcll(__ballot(head));
+        else if (head) atomicAdd(&counts[(int64_t)l * n_batch + b], 1ull);
+      }
+    }
+  }
+  if (lane == 0 && cur_b >= 0) {
+#pragma unroll
+    for (int l = 0; l < PL_MAX_LEVELS; ++l)
+      if (l < lv.n && run[l]) atomicAdd(&counts[(int64_t)l * n_batch + cur_b], (unsigned long long)run[l]);
+  }
+}
+
+extern "C" int ptc_pool_level_counts(const int64_t* code0, const int64_t* order0, int64_t n, int batch_shift, int n_batch,
+                                     const int* shifts, int n_levels, int64_t* counts, ptc_stream_t stream) {
+  PTC_REQUIRE(n >= 0 && n_batch >= 1 && batch_shift >= 0 && batch_shift < 64, PTC_EINVAL, "ptc_pool_level_counts: bad sizes");
+  PTC_REQUIRE(n_levels >= 1 && n_levels <= PL_MAX_LEVELS && shifts, PTC_EINVAL, "ptc_pool_level_counts: n_levels=%d not in [1,%d]",
+              n_levels, PL_MAX_LEVELS);
+  PTC_REQUIRE(counts != nullptr, PTC_EINVAL, "ptc_pool_level_counts: null output");
+  hipStream_t s = (hipStream_t)stream;
+  PTC_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)n_levels * (size_t)n_batch, s));
+  if (n == 0) return PTC_OK;
+  PTC_REQUIRE(code0 && order0, PTC_EINVAL, "ptc_pool_level_counts: null buffer");
+  PoolLevelShifts lv;
+  lv.n = n_levels;
+  for (int l = 0; l < PL_MAX_LEVELS; ++l) {
+    lv.shift[l] = l < n_levels ? shifts[l] : 0;
+    PTC_REQUIRE(lv.shift[l] >= 0 && lv.shift[l] < 64, PTC_EINVAL, "ptc_pool_level_counts: shift %d", lv.shift[l]);
+  }
+  const int64_t grid = ptc_cdiv(ptc_cdiv(n, PL_CHUNK), 4);   // 4 waves per workgroup, PL_CHUNK positions per wave
+  hipLaunchKernelGGL(pool_level_counts_kernel, dim3((unsigned)grid), dim3(256), 0, s, code0, order0, n, batch_shift, n_batch, lv,
+                     (unsigned long long*)counts);
+  PTC_CHECK_LAUNCH("pool_level_counts_kernel");
+  return PTC_OK;
+}

@@ -122,9 +122,24 @@ def attn_tables(order: torch.Tensor, inverse: torch.Tensor, pad: torch.Tensor, u
 # ------------------------------------------------------------------------------------------------
 # pooling maps
 # ------------------------------------------------------------------------------------------------
-def pool_maps(code0: torch.Tensor, order0: torch.Tensor, shift: int):
+def pool_level_counts(code0: torch.Tensor, order0: torch.Tensor, batch_shift: int, n_batch: int, shifts: Sequence[int]):
+    """counts [len(shifts), n_batch] int64 (device): distinct values of code0 >> shifts[l] per scene -- the point counts
+    of every pooled level (ptv3m1:384-390), one launch, no sync (the caller fetches them with its own single copy)."""
+    require_cuda(code0, order0)
+    import ctypes
+
+    counts = torch.empty((len(shifts), n_batch), dtype=torch.int64, device=code0.device)
+    arr = (ctypes.c_int * len(shifts))(*[int(v) for v in shifts])
+    check(lib().ptc_pool_level_counts(ptr(code0.contiguous()), ptr(order0.contiguous()), code0.numel(), int(batch_shift), int(n_batch),
+                                      ctypes.cast(arr, ctypes.c_void_p), len(shifts), ptr(counts), stream_ptr()),
+          "ptc_pool_level_counts")
+    return counts
+
+
+def pool_maps(code0: torch.Tensor, order0: torch.Tensor, shift: int, n_cluster: Optional[int] = None):
     """cluster (= pooling_inverse), idx_ptr, head for SerializedPooling (ptv3m1:383-396).
-    One host sync (the number of clusters sizes the outputs, as torch.unique does in the reference)."""
+    One host sync (the number of clusters sizes the outputs, as torch.unique does in the reference) unless the caller
+    already knows `n_cluster` (pool_level_counts)."""
     require_cuda(code0, order0)
     code0 = code0.contiguous()
     order0 = order0.contiguous()
@@ -136,7 +151,8 @@ def pool_maps(code0: torch.Tensor, order0: torch.Tensor, shift: int):
     ws = _ws(nbytes, dev)
     check(lib().ptc_pool_maps_count(ptr(code0), ptr(order0), n, int(shift), ptr(cluster), ptr(ncl), ptr(ws), nbytes,
                                     stream_ptr()), "ptc_pool_maps_count")
-    n_cluster = int(ncl.item())
+    if n_cluster is None:
+        n_cluster = int(ncl.item())
     idx_ptr = torch.empty(n_cluster + 1, dtype=torch.int64, device=dev)
     head = torch.empty(n_cluster, dtype=torch.int64, device=dev)
     check(lib().ptc_pool_maps_fill(ptr(order0), ptr(cluster), n, n_cluster, ptr(idx_ptr), ptr(head), stream_ptr()),

@@ -403,7 +403,9 @@ class SerializedPooling(PointModule):
         with torch.no_grad():
             code, order0 = point.serialized_code, point.serialized_order[0]
             # ptv3m1:383-396 without torch.unique / torch.sort: row 0 is already sorted
-            cluster, idx_ptr, head = ops.pool_maps(code[0], order0, shift)
+            levels = point.get("_ptc_pool_levels") or []
+            known = levels[0] if levels and levels[0] and levels[0][-1] > 0 else None   # child offsets, prefetched
+            cluster, idx_ptr, head = ops.pool_maps(code[0], order0, shift, None if known is None else known[-1])
             child_code = ops.pool_child_codes(code, head, shift)                    # ptv3m1:398
             depth = point.serialized_depth - pooling_depth
             order, inverse = ops.sort_keys(child_code, 0, depth * 3 + len(offset_host).bit_length())  # :399-406
@@ -433,7 +435,8 @@ class SerializedPooling(PointModule):
         # engine-side caches: CSR of the clusters (gather-form backward of unpooling) and host facts
         child["_ptc_pool_csr"] = (order0, idx_ptr)
         child["_ptc_coord_max"] = [int(m) >> pooling_depth for m in coord_max]
-        child["_ptc_offset_host"] = child.offset.tolist()
+        child["_ptc_offset_host"] = list(known) if known is not None else child.offset.tolist()
+        child["_ptc_pool_levels"] = levels[1:]
         child["_ptc_n_dup"] = 0   # one row per cluster: pooled coordinates are unique
         if getattr(self, "norm", None) is not None:
             child = self.norm(child)
@@ -553,6 +556,7 @@ class PointTransformerV3(PointModule):
     def forward(self, data_dict):
         point = Point(data_dict)
         point.serialization(order=self.order, shuffle_orders=self.shuffle_orders)
+        self._prefetch_pool_levels(point)
         caller = None
         if config.SORT_POINTS and point.feat.is_cuda:
             caller, point = point, point.physically_sorted()
@@ -564,6 +568,34 @@ class PointTransformerV3(PointModule):
         if caller is not None:
             point = self._restore_order(point, caller)
         return point
+
+    def _prefetch_pool_levels(self, point):
+        """Point counts of every pooled stage, fetched with ONE host copy before any feature work is queued (the
+        reference syncs twice per SerializedPooling: torch.unique and the python loop over bincounts).  With the sizes
+        known the host never waits for the GPU again during the forward, so it runs far ahead and the short kernels of
+        the deep stages find their launches already queued."""
+        strides = [m.stride for m in self.modules() if isinstance(m, SerializedPooling)]
+        if not config.PREFETCH_LEVELS or not strides or not point.feat.is_cuda or point.grid_coord.shape[0] == 0 or len(strides) > 8:
+            return
+        depth, shifts, cum = point.serialized_depth, [], 0
+        for st in strides:
+            pd = (math.ceil(st) - 1).bit_length()
+            if pd > depth:
+                pd = 0
+            cum += 3 * pd
+            depth -= pd
+            shifts.append(cum)
+        _, offset_host = point._host_facts()
+        counts = ops.pool_level_counts(point.serialized_code[0], point.serialized_order[0], 3 * point.serialized_depth,
+                                       len(offset_host), shifts).tolist()
+        levels = []
+        for per_scene in counts:
+            acc, offs = 0, []
+            for c in per_scene:
+                acc += int(c)
+                offs.append(acc)
+            levels.append(offs)
+        point["_ptc_pool_levels"] = levels
 
     @staticmethod
     def _restore_order(point, caller):

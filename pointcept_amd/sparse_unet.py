@@ -128,6 +128,7 @@ class SpUNetBase(nn.Module):
         x = spconv.SparseConvTensor(features=feat, indices=indices, spatial_shape=sparse_shape, batch_size=int(offset.numel()))
         x.indice_dict["__hash__"] = table
         spconv.mark_duplicates(x, host[3] > 0)   # Mix3D batches: the conv backward needs to know (functional._SparseConv)
+        spconv.prefetch_down_rulebooks(x, [f"spconv{s + 1}" for s in range(self.num_stages)])   # all host waits up front
         x = self.conv_input(x)
         skips = [x]
         for s in range(self.num_stages):

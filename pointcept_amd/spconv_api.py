@@ -227,22 +227,39 @@ class SubMConv3d(_SparseConvolution):
         return x.replace_feature(PF.sparse_conv(x.features, self._w(), self.bias, rb, rb, True, rep, rep))
 
 
+def _down_rulebook(x: SparseConvTensor, indice_key):
+    """maps of a k=2, s=2 strided convolution on x (and of its inverse), cached under ("down", indice_key)."""
+    key = ("down", indice_key)
+    rb = x.indice_dict.get(key) if indice_key is not None else None
+    if rb is None:
+        out_indices, nbr_down, nbr_up = ops.rulebook_down(
+            x.indices, _coord_bits(x.spatial_shape), max(1, int(x.batch_size).bit_length()))
+        out_shape = [(s - 2) // 2 + 1 for s in x.spatial_shape]
+        rb = dict(out_indices=out_indices, nbr_down=nbr_down, nbr_up=nbr_up, in_indices=x.indices,
+                  in_shape=x.spatial_shape, out_shape=out_shape, in_rep=_dup_rep(x))
+        if indice_key is not None:
+            x.indice_dict[key] = rb
+    return rb
+
+
+def prefetch_down_rulebooks(x: SparseConvTensor, indice_keys) -> None:
+    """Build the maps of a chain of SparseConv3d(k=2, s=2) layers (x -> indice_keys[0] -> indice_keys[1] ...) NOW.
+    Each level sizes its outputs from a device count (one host sync per level, as spconv's own indice generation);
+    doing all of them before any feature work is queued keeps the rest of the forward free of host waits."""
+    t = x
+    for key in indice_keys:
+        rb = _down_rulebook(t, key)
+        t = SparseConvTensor(None, rb["out_indices"], rb["out_shape"], x.batch_size, indice_dict=x.indice_dict)
+        mark_duplicates(t, False)
+
+
 class SparseConv3d(_SparseConvolution):
     _kind = "down"
 
     def forward(self, x: SparseConvTensor):
         if self.kernel_size[0] != 2 or self.stride[0] != 2:
             raise PtcoreError("SparseConv3d: only kernel_size=2, stride=2 is implemented (the SpUNet down conv)")
-        key = ("down", self.indice_key)
-        rb = x.indice_dict.get(key) if self.indice_key is not None else None
-        if rb is None:
-            out_indices, nbr_down, nbr_up = ops.rulebook_down(
-                x.indices, _coord_bits(x.spatial_shape), max(1, int(x.batch_size).bit_length()))
-            out_shape = [(s - 2) // 2 + 1 for s in x.spatial_shape]
-            rb = dict(out_indices=out_indices, nbr_down=nbr_down, nbr_up=nbr_up, in_indices=x.indices,
-                      in_shape=x.spatial_shape, out_shape=out_shape, in_rep=_dup_rep(x))
-            if self.indice_key is not None:
-                x.indice_dict[key] = rb
+        rb = _down_rulebook(x, self.indice_key)
         # copies of a voxel other than the lowest row are read by no output row: dup_in zeroes their gradient
         feat = PF.sparse_conv(x.features, self._w(), self.bias, rb["nbr_down"], rb["nbr_up"], False, None, rb["in_rep"])
         out = SparseConvTensor(feat, rb["out_indices"], rb["out_shape"], x.batch_size, indice_dict=x.indice_dict)

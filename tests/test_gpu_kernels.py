@@ -1043,3 +1043,28 @@ def test_spconv_autograd_with_duplicate_voxels(cuda):
     for a, b in zip(ref_layers, eng_layers):
         assert torch.allclose(b.weight.grad.cpu(), a.weight.grad, rtol=1e-3, atol=1e-3), a.indice_key
     assert torch.allclose(eng_layers[0].bias.grad.cpu(), ref_layers[0].bias.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("row", [0, 2])
+def test_pool_level_counts(cuda, row):
+    """sizes of every pooled level from the stage-0 codes: equal to counting unique (code >> shift) per scene, for the
+    Morton row and a Hilbert row alike (both curves are hierarchical), with duplicate voxels present."""
+    from pointcept_amd import ops, synthetic
+
+    a, b = synthetic.indoor_scene(3, 5000), synthetic.indoor_scene(4, 800)
+    a = {k: np.concatenate([v, v[:100]]) for k, v in a.items()}          # 100 duplicate voxels
+    batch = synthetic.collate([a, b, synthetic.indoor_scene(5, 1)])
+    gc, off = batch["grid_coord"], batch["offset"]
+    depth = int(gc.max() + 1).bit_length()
+    bidx = omaps.offset2batch(off)
+    code = osfc.encode_c(gc, bidx, depth, ("z", "z-trans", "hilbert", "hilbert-trans"))
+    order = np.argsort(code, axis=1, kind="stable")
+    shifts = [3, 6, 9, 15, 3 * depth]
+    got = ops.pool_level_counts(torch.from_numpy(code[row]).to(cuda), torch.from_numpy(order[row]).to(cuda), 3 * depth, len(off),
+                                shifts).cpu().numpy()
+    for l, sh in enumerate(shifts):
+        want = [len(np.unique(code[row][bidx == s] >> sh)) for s in range(len(off))]
+        assert got[l].tolist() == want, (l, sh)
+    z = [len(np.unique(code[0][bidx == s] >> 3)) for s in range(len(off))]
+    h = [len(np.unique(code[2][bidx == s] >> 3)) for s in range(len(off))]
+    assert z == h
