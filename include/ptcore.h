@@ -338,6 +338,17 @@ int ptc_lovasz_softmax(const void* logits, int64_t row_stride, const int64_t* ta
                        ptc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K. Voxelisation front end (GridSample), for point clouds that already live on the device.
+ * Replaces the numpy prologue of GridSample.__call__, pointcept/datasets/transform.py:867-875 with
+ * fnv_hash_vec (:997-1011):  grid = floor(coord / grid_size) (float64 division, as numpy promotes it),
+ * min_coord3 = grid.min(0), grid_coord = grid - min_coord3 (written in place, int64 [n,3]),
+ * key[n] = FNV64 of the three shifted coordinates (bit pattern of the reference's uint64, stored as int64).
+ * argsort / unique / inverse / count of the keys: ptc_sort_keys (bits [0,64)) + ptc_pool_maps_count(shift 0) / _fill.
+ * ------------------------------------------------------------------------------------------ */
+int ptc_voxel_keys(const float* coord, int64_t n, double grid_size, int64_t* grid_coord, int64_t* min_coord3,
+                   int64_t* key, ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * J. BatchNorm1d over the rows of [n, c] features with the following activation fused:
  *    y = act((x - mean) * rstd * gamma + beta),  act in {0 none, 1 GELU (erf), 2 ReLU}.
  * Replaces `nn.BatchNorm1d(eps=1e-3, momentum=0.01)` + `nn.GELU()` of PTv3's Embedding / SerializedPooling /

@@ -57,3 +57,18 @@ def load():
     _loaded["structure"] = importlib.import_module("pointcept.models.utils.structure")
     _loaded["misc"] = importlib.import_module("pointcept.models.utils.misc")
     return _loaded
+
+
+def load_transform():
+    """pointcept/datasets/transform.py (numpy / scipy only, apart from an unused torchvision import that is stubbed)."""
+    load()
+    if "transform" not in _loaded:
+        pkg = types.ModuleType("pointcept.datasets")
+        pkg.__path__ = [REF + "/pointcept/datasets"]
+        sys.modules["pointcept.datasets"] = pkg
+        if "torchvision" not in sys.modules:
+            tv = types.ModuleType("torchvision")
+            tv.transforms = types.ModuleType("torchvision.transforms")
+            sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tv.transforms
+        _loaded["transform"] = importlib.import_module("pointcept.datasets.transform")
+    return _loaded["transform"]

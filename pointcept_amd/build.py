@@ -32,6 +32,7 @@ HIP_SOURCES = [
     "attention.hip",
     "loss.hip",
     "lovasz.hip",
+    "voxelize.hip",
     "bn.hip",
 ]
 CXX_SOURCES = ["core.cpp"]

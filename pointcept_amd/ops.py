@@ -173,6 +173,24 @@ def pool_child_codes(code: torch.Tensor, head: torch.Tensor, shift: int) -> torc
 
 
 # ------------------------------------------------------------------------------------------------
+# voxelisation (GridSample front end)
+# ------------------------------------------------------------------------------------------------
+def voxel_keys(coord: torch.Tensor, grid_size: float):
+    """floor(coord / grid_size) (float64 division), min-shifted, and the FNV-64 key of every point
+    (pointcept/datasets/transform.py:867-875,997-1011) -> (grid_coord [N,3] i64, min_coord [3] i64, key [N] i64)."""
+    require_cuda(coord)
+    if coord.dtype != torch.float32 or coord.dim() != 2 or coord.shape[1] != 3:
+        raise PtcoreError("coord must be float32 [N,3]")
+    c = coord.contiguous()
+    n = c.shape[0]
+    grid = torch.empty((n, 3), dtype=torch.int64, device=c.device)
+    mn = torch.empty(3, dtype=torch.int64, device=c.device)
+    key = torch.empty(n, dtype=torch.int64, device=c.device)
+    check(lib().ptc_voxel_keys(ptr(c), n, float(grid_size), ptr(grid), ptr(mn), ptr(key), stream_ptr()), "ptc_voxel_keys")
+    return grid, mn, key
+
+
+# ------------------------------------------------------------------------------------------------
 # rows
 # ------------------------------------------------------------------------------------------------
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, idx2: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -1,0 +1,120 @@
+"""Device-side GridSample: the voxelisation transform of pointcept/datasets/transform.py:839-1011 for point clouds
+that already live on the GPU (SURVEY 8(f) rank 1 -- the step immediately before the hot path; on the reference it runs
+in numpy inside 24 dataloader workers).  Same constructor arguments, same dict protocol (`index_valid_keys`,
+`inverse`, `grid_coord`, `min_coord`, `displacement`, train / test modes), torch tensors instead of numpy arrays.
+
+    voxel of a point  : floor(coord / grid_size) in float64, min-shifted           ptc_voxel_keys   (voxelize.hip)
+    key               : FNV-64 over the three coordinates (hash_type="fnv")         ptc_voxel_keys
+    argsort(key)      : stable LSD radix sort over 64 bits                          ptc_sort_keys    (scan_sort.hip)
+    unique / inverse / count : flags + scan + fill over the sorted keys             ptc_pool_maps_*  (maps.hip)
+    representative    : idx_sort[start + r % count], r random per voxel             torch indexing
+
+Differences, all documented: numpy's argsort is unstable, so WHICH point of a voxel sits at a given rank is
+implementation-defined there and "ascending index" here (the voxel set, `inverse`, `count` and the key order are
+identical); the random offsets come from torch's generator (`rand=` injects them for tests) and are drawn from
+[0, 2^31) instead of [0, count.max()) so that no host sync is needed; hash_type="ravel" and `frame_pcd_offset` are
+not implemented (raise).  There is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from ._lib import PtcoreError
+
+_DEFAULT_KEYS = ["coord", "color", "normal", "superpoint", "strength", "segment", "instance"]   # transform.py:27-35
+
+
+def index_operator(data_dict, index, duplicate=False):
+    """transform.py:23-52: apply `index` to every key listed in data_dict["index_valid_keys"]."""
+    if "index_valid_keys" not in data_dict:
+        data_dict["index_valid_keys"] = list(_DEFAULT_KEYS)
+    if not duplicate:
+        for key in data_dict["index_valid_keys"]:
+            if key in data_dict:
+                data_dict[key] = data_dict[key][index]
+        return data_dict
+    out = dict()
+    for key in data_dict.keys():
+        if key in data_dict["index_valid_keys"]:
+            out[key] = data_dict[key][index]
+        elif key == "index_valid_keys":
+            out[key] = list(data_dict[key])      # each part extends its own copy
+        else:
+            out[key] = data_dict[key]
+    return out
+
+
+class GridSample:
+    def __init__(self, grid_size=0.05, hash_type="fnv", mode="train", return_inverse=False, return_grid_coord=False,
+                 return_min_coord=False, return_displacement=False, project_displacement=False):
+        if hash_type != "fnv":
+            raise PtcoreError("GridSample: only hash_type='fnv' (the default of every reference config) is implemented")
+        assert mode in ["train", "test"]
+        self.grid_size = grid_size
+        self.mode = mode
+        self.return_inverse = return_inverse
+        self.return_grid_coord = return_grid_coord
+        self.return_min_coord = return_min_coord
+        self.return_displacement = return_displacement
+        self.project_displacement = project_displacement
+
+    @torch.no_grad()
+    def voxels(self, coord: torch.Tensor):
+        """-> dict(grid_coord [N,3] i64, min_coord [3] i64, key [N] i64, idx_sort [N], inverse [N] (voxel id of every
+        point, voxels numbered by ascending key as np.unique does), idx_ptr [V+1] (CSR of the voxels over idx_sort))."""
+        grid_coord, min_coord, key = ops.voxel_keys(coord, self.grid_size)
+        idx_sort, _ = ops.sort_keys(key, 0, 64, want_inverse=False)
+        inverse, idx_ptr, _ = ops.pool_maps(key, idx_sort, 0)     # one host sync: the number of voxels sizes the outputs
+        return dict(grid_coord=grid_coord, min_coord=min_coord, key=key, idx_sort=idx_sort, inverse=inverse, idx_ptr=idx_ptr)
+
+    def _extras(self, out, data_dict, v, index):
+        if self.return_inverse:
+            out["inverse"] = v["inverse"]
+        if self.return_grid_coord:
+            out["grid_coord"] = v["grid_coord"][index]
+            if "grid_coord" not in out["index_valid_keys"]:
+                out["index_valid_keys"] = list(out["index_valid_keys"]) + ["grid_coord"]
+        if self.return_min_coord:
+            out["min_coord"] = (v["min_coord"].double() * self.grid_size).reshape(1, 3)
+        if self.return_displacement:
+            scaled = data_dict["coord"].double() / self.grid_size - v["min_coord"].double()
+            disp = scaled - v["grid_coord"].double() - 0.5           # [0, 1] -> [-0.5, 0.5] from the voxel centre
+            if self.project_displacement:
+                disp = (disp * data_dict["normal"].double()).sum(-1, keepdim=True)
+            out["displacement"] = disp[index]
+            if "displacement" not in out["index_valid_keys"]:
+                out["index_valid_keys"] = list(out["index_valid_keys"]) + ["displacement"]
+        return out
+
+    @torch.no_grad()
+    def __call__(self, data_dict, rand: Optional[torch.Tensor] = None):
+        assert "coord" in data_dict.keys()
+        if "frame_pcd_offset" in data_dict:
+            raise PtcoreError("GridSample: frame_pcd_offset is not implemented")
+        src = dict(data_dict)                      # originals, for the displacement (the reference computes it before indexing)
+        if data_dict["coord"].shape[0] == 0:
+            raise PtcoreError("GridSample: empty point cloud")
+        v = self.voxels(data_dict["coord"])
+        idx_sort, idx_ptr = v["idx_sort"], v["idx_ptr"]
+        start, count = idx_ptr[:-1], idx_ptr[1:] - idx_ptr[:-1]
+        if self.mode == "train":
+            if rand is None:
+                rand = torch.randint(0, 2 ** 31 - 1, (count.numel(),), device=count.device)
+            idx_unique = idx_sort[start + rand.to(count.dtype) % count]           # transform.py:877-882
+            if "sampled_index" in data_dict:                                       # transform.py:883-891
+                idx_unique = torch.unique(torch.cat([idx_unique, data_dict["sampled_index"].to(idx_unique.dtype)]))
+                mask = torch.zeros(data_dict["segment"].shape[0], dtype=torch.bool, device=idx_unique.device)
+                mask[data_dict["sampled_index"]] = True
+                data_dict["sampled_index"] = torch.where(mask[idx_unique])[0]
+            out = index_operator(data_dict, idx_unique)
+            return self._extras(out, src, v, idx_unique)
+        parts = []                                                                  # transform.py:916-949
+        for i in range(int(count.max().item()) if count.numel() else 0):
+            idx_part = idx_sort[start + i % count]
+            part = index_operator(data_dict, idx_part, duplicate=True)
+            part["index"] = idx_part
+            parts.append(self._extras(part, src, v, idx_part))
+        return parts

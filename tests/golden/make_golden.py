@@ -19,6 +19,8 @@ Fixtures
   ptv3_rpe.npz      : the reference's dense attention branch (enable_flash=False, enable_rpe=True, both upcasts), patch
                       256 on scenes of 900 + 200 voxels (=> K shrinks to the smallest scene at every stage):
                       eval output, train-mode output rows, loss = mean(feat^2) and all gradient norms.
+  gridsample.npz    : coord -> GridSample(hash_type="fnv", mode="train") of pointcept/datasets/transform.py: inverse,
+                      the voxel set in np.unique (ascending key) order, min_coord and the picked representatives.
   lovasz.npz        : logits / labels -> LovaszLoss(mode="multiclass", ignore_index=-1) loss and gradient
                       (pointcept/models/losses/lovasz.py), five shapes incl. absent classes and a single point.
 """
@@ -162,6 +164,27 @@ def main():
         param_names=np.asarray(names),
         grad_norms=np.asarray([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in ref.named_parameters()]),
         grad_rpe_dec0=ref.dec.dec0.block0.attn.rpe.rpe_table.grad.numpy().astype(np.float32))
+
+    # ---- GridSample (voxelisation) --------------------------------------------------------------
+    tr = ref_import.load_transform()
+    blobs = {}
+    gcases = [(3000, 0.02, 0.6, 0), (5000, 0.05, 3.0, 1), (64, 0.1, 0.05, 2)]
+    for ci, (n, grid, extent, seed) in enumerate(gcases):
+        coord = om.gridsample_case(seed, n, extent)
+        gs = tr.GridSample(grid_size=grid, hash_type="fnv", mode="train", return_grid_coord=True, return_inverse=True,
+                           return_min_coord=True)
+        np.random.seed(seed)
+        d = gs(dict(coord=coord.copy(), segment=np.arange(n), index_valid_keys=["coord", "segment"]))
+        order = np.lexsort(d["grid_coord"].T[::-1])
+        blobs[f"params_{ci}"] = np.asarray([n, grid, extent, seed], dtype=np.float64)
+        blobs[f"coord_sum_{ci}"] = np.asarray(float(coord.astype(np.float64).sum()))
+        blobs[f"inverse_{ci}"] = d["inverse"].astype(np.int32)
+        blobs[f"voxels_sorted_{ci}"] = d["grid_coord"][order].astype(np.int32)       # the voxel set
+        blobs[f"voxels_keyorder_{ci}"] = d["grid_coord"].astype(np.int32)            # ... in ascending-key (np.unique) order
+        blobs[f"min_coord_{ci}"] = d["min_coord"]
+        blobs[f"picked_{ci}"] = d["segment"].astype(np.int32)                        # the reference's own representatives
+    blobs["n_cases"] = np.asarray(len(gcases))
+    np.savez_compressed(os.path.join(OUT, "gridsample.npz"), **blobs)
 
     # ---- Lovasz-Softmax ------------------------------------------------------------------------
     import importlib

@@ -206,6 +206,34 @@ def test_oracle_lovasz_matches_reference_golden():
         assert np.abs(d - grad).max() <= 2e-4 * max(np.abs(grad).max(), 1e-12), (ci, np.abs(d - grad).max(), np.abs(grad).max())
 
 
+def gridsample_cases():
+    from oracle import ptv3_model as om
+
+    g = np.load(os.path.join(GOLD, "gridsample.npz"))
+    for ci in range(int(g["n_cases"])):
+        n, grid, extent, seed = g[f"params_{ci}"]
+        coord = om.gridsample_case(int(seed), int(n), float(extent))
+        assert abs(float(coord.astype(np.float64).sum()) - float(g[f"coord_sum_{ci}"])) < 1e-6
+        yield ci, coord, float(grid), {k[: -len(f"_{ci}")]: g[k] for k in g.files if k.endswith(f"_{ci}")}
+
+
+def test_oracle_gridsample_matches_reference_golden():
+    """voxel ids (`inverse`), the voxel list in np.unique order, min_coord: exact.  The reference's picked points are
+    valid representatives (right voxel); their identity inside a voxel depends on numpy's unstable argsort."""
+    from oracle import voxelize
+
+    for ci, coord, grid, g in gridsample_cases():
+        v = voxelize.voxels(coord, grid)
+        assert np.array_equal(v["inverse"], g["inverse"]), ci
+        first = v["idx_sort"][np.cumsum(np.insert(v["count"], 0, 0)[:-1])]
+        assert np.array_equal(v["grid_coord"][first], g["voxels_keyorder"]), ci
+        assert np.allclose(v["min_coord"] * grid, g["min_coord"].reshape(3)), ci
+        assert np.array_equal(v["inverse"][g["picked"]], np.arange(len(v["count"]))), ci
+        rand = np.random.default_rng(ci).integers(0, 1 << 30, len(v["count"]))
+        pick = voxelize.select_train(v, rand)
+        assert np.array_equal(v["inverse"][pick], np.arange(len(v["count"])))
+
+
 # ---- C-ABI surface (no compute) -----------------------------------------------------------------
 def test_library_exports_every_declared_symbol():
     from pointcept_amd import _lib

@@ -1068,3 +1068,58 @@ def test_pool_level_counts(cuda, row):
     z = [len(np.unique(code[0][bidx == s] >> 3)) for s in range(len(off))]
     h = [len(np.unique(code[2][bidx == s] >> 3)) for s in range(len(off))]
     assert z == h
+
+
+# ---- device-side GridSample -------------------------------------------------------------------
+def test_gridsample_matches_reference_golden_and_oracle(cuda):
+    """voxel of every point, FNV keys, key order, voxel ids, counts: bit-exact vs the oracle; `inverse`, the voxel list
+    in np.unique order and min_coord: equal to what the REFERENCE transform produced (tests/golden/gridsample.npz);
+    with injected random offsets the picked representatives equal the oracle's (stable tie order)."""
+    from oracle import voxelize
+    from pointcept_amd.transform import GridSample
+    from test_golden_cpu import gridsample_cases
+
+    for ci, coord, grid, g in gridsample_cases():
+        v = voxelize.voxels(coord, grid)
+        gs = GridSample(grid_size=grid, mode="train", return_grid_coord=True, return_inverse=True, return_min_coord=True,
+                        return_displacement=True)
+        dev = gs.voxels(torch.from_numpy(coord).to(cuda))
+        assert np.array_equal(dev["grid_coord"].cpu().numpy(), v["grid_coord"]), ci
+        assert np.array_equal(dev["key"].cpu().numpy().view(np.uint64), v["key"]), ci
+        assert np.array_equal(dev["idx_sort"].cpu().numpy(), v["idx_sort"]), ci
+        assert np.array_equal(dev["inverse"].cpu().numpy(), g["inverse"]), ci
+        assert np.array_equal(np.diff(dev["idx_ptr"].cpu().numpy()), v["count"]), ci
+        rand = np.random.default_rng(ci).integers(0, 1 << 30, len(v["count"]))
+        n = coord.shape[0]
+        out = gs(dict(coord=torch.from_numpy(coord).to(cuda), segment=torch.arange(n, device=cuda),
+                      index_valid_keys=["coord", "segment"]), rand=torch.from_numpy(rand).to(cuda))
+        pick = voxelize.select_train(v, rand)
+        assert np.array_equal(out["segment"].cpu().numpy(), pick), ci
+        assert np.array_equal(out["grid_coord"].cpu().numpy(), g["voxels_keyorder"]), ci
+        assert np.array_equal(out["coord"].cpu().numpy(), coord[pick]), ci
+        assert np.allclose(out["min_coord"].cpu().numpy(), g["min_coord"]), ci
+        assert np.array_equal(out["inverse"].cpu().numpy(), g["inverse"]), ci
+        disp = out["displacement"].cpu().numpy()
+        assert disp.shape == (len(pick), 3) and (disp >= -0.5).all() and (disp <= 0.5).all()
+        assert out["index_valid_keys"] == ["coord", "segment", "grid_coord", "displacement"]
+
+
+def test_gridsample_test_mode_and_full_size_properties(cuda):
+    from pointcept_amd.transform import GridSample
+
+    g = torch.Generator().manual_seed(31)
+    coord = ((torch.rand(2_000_000, 3, generator=g) - 0.5) * torch.tensor([7.0, 5.0, 2.8])).to(cuda)
+    gs = GridSample(grid_size=0.02, mode="train", return_grid_coord=True, return_inverse=True)
+    out = gs(dict(coord=coord, index_valid_keys=["coord"]))
+    gc, inv = out["grid_coord"], out["inverse"]
+    v = gc.shape[0]
+    assert torch.unique(gc, dim=0).shape[0] == v                       # one representative per voxel
+    assert int(inv.max()) == v - 1 and int(inv.min()) == 0
+    assert torch.equal(torch.floor(out["coord"].double() / 0.02).long() - torch.floor(coord.double() / 0.02).long().min(0).values, gc)
+    small = coord[:5000] * 0.05
+    parts = GridSample(grid_size=0.02, mode="test", return_grid_coord=True)(dict(coord=small, index_valid_keys=["coord"]))
+    seen = torch.zeros(5000, dtype=torch.bool, device=cuda)
+    for p in parts:
+        assert torch.unique(p["grid_coord"], dim=0).shape[0] == p["grid_coord"].shape[0]
+        seen[p["index"]] = True
+    assert bool(seen.all())                                             # every point appears in some part (transform.py:916-949)
