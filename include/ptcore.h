@@ -349,6 +349,22 @@ int ptc_voxel_keys(const float* coord, int64_t n, double grid_size, int64_t* gri
                    int64_t* key, ptc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * L. pointops subset (offset-batched point sets; offsets int32 cumulative ends as the reference passes `offset.int()`).
+ * ptc_knn_query: knn_query_cuda of libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:60-108 behind
+ *   libs/pointops/functions/query.py:7-26 -- for each of the m query points (new_xyz, scene given by new_offset) the
+ *   nsample (<= 128) nearest points of the same scene in xyz: idx [m, nsample] int32 (row index into xyz, -1 = scene
+ *   has fewer points), dist [m, nsample] fp32 = sqrt(squared distance) (1e5 for empty slots), ascending; equal
+ *   distances ordered by ascending index.
+ * ptc_farthest_point_sampling: farthest_point_sampling_cuda of src/sampling/sampling_cuda_kernel.cu:15-122 behind
+ *   functions/sampling.py:7-24 -- idx [new_offset[b-1]] int32; scene s contributes new_offset[s]-new_offset[s-1]
+ *   picks, the first one its first point; tmp [n] fp32 scratch (initialised here).  Equal distances: lowest index.
+ * ------------------------------------------------------------------------------------------ */
+int ptc_knn_query(const float* xyz, const int32_t* offset, const float* new_xyz, const int32_t* new_offset, int b,
+                  int64_t n, int64_t m, int nsample, int32_t* idx, float* dist, ptc_stream_t stream);
+int ptc_farthest_point_sampling(const float* xyz, const int32_t* offset, const int32_t* new_offset, int b, int64_t n,
+                                float* tmp, int32_t* idx, ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * J. BatchNorm1d over the rows of [n, c] features with the following activation fused:
  *    y = act((x - mean) * rstd * gamma + beta),  act in {0 none, 1 GELU (erf), 2 ReLU}.
  * Replaces `nn.BatchNorm1d(eps=1e-3, momentum=0.01)` + `nn.GELU()` of PTv3's Embedding / SerializedPooling /

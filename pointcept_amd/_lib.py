@@ -75,6 +75,8 @@ _SIGNATURES = {
     "ptc_cross_entropy_partials": (c_i64, [c_i64]),
     "ptc_cross_entropy_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     "ptc_cross_entropy_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_i64, c_ptr, c_i64, c_ptr]),
+    "ptc_knn_query": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
+    "ptc_farthest_point_sampling": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     "ptc_voxel_keys": (c_int, [c_ptr, c_i64, ctypes.c_double, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_lovasz_softmax_workspace_bytes": (c_size, [c_i64, c_int]),
     "ptc_lovasz_softmax": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),

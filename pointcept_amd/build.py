@@ -33,6 +33,7 @@ HIP_SOURCES = [
     "loss.hip",
     "lovasz.hip",
     "voxelize.hip",
+    "pointops.hip",
     "bn.hip",
 ]
 CXX_SOURCES = ["core.cpp"]

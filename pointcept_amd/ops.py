@@ -191,6 +191,44 @@ def voxel_keys(coord: torch.Tensor, grid_size: float):
 
 
 # ------------------------------------------------------------------------------------------------
+# pointops subset
+# ------------------------------------------------------------------------------------------------
+def _xyz(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != 3:
+        raise PtcoreError(f"{name} must be float32 [N,3]")
+    return t.contiguous()
+
+
+def knn_query(nsample: int, xyz, offset, new_xyz, new_offset):
+    """-> (idx [m, nsample] int32, dist [m, nsample] fp32), libs/pointops/functions/query.py:7-26."""
+    require_cuda(xyz, offset, new_xyz, new_offset)
+    x, q = _xyz(xyz, "xyz"), _xyz(new_xyz, "new_xyz")
+    off, noff = offset.to(torch.int32).contiguous(), new_offset.to(torch.int32).contiguous()
+    if off.numel() != noff.numel() or off.numel() == 0:
+        raise PtcoreError("offset / new_offset must list the same (non-zero) number of scenes")
+    m = q.shape[0]
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=x.device)
+    dist = torch.empty((m, nsample), dtype=torch.float32, device=x.device)
+    check(lib().ptc_knn_query(ptr(x), ptr(off), ptr(q), ptr(noff), off.numel(), x.shape[0], m, int(nsample), ptr(idx), ptr(dist),
+                              stream_ptr()), "ptc_knn_query")
+    return idx, dist
+
+
+def farthest_point_sampling(xyz, offset, new_offset):
+    """-> idx [new_offset[-1]] int32, libs/pointops/functions/sampling.py:7-24 (one host sync for the output size)."""
+    require_cuda(xyz, offset, new_offset)
+    x = _xyz(xyz, "xyz")
+    off, noff = offset.to(torch.int32).contiguous(), new_offset.to(torch.int32).contiguous()
+    if off.numel() != noff.numel() or off.numel() == 0:
+        raise PtcoreError("offset / new_offset must list the same (non-zero) number of scenes")
+    idx = torch.zeros(int(noff[-1].item()), dtype=torch.int32, device=x.device)
+    tmp = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(lib().ptc_farthest_point_sampling(ptr(x), ptr(off), ptr(noff), off.numel(), x.shape[0], ptr(tmp), ptr(idx), stream_ptr()),
+          "ptc_farthest_point_sampling")
+    return idx
+
+
+# ------------------------------------------------------------------------------------------------
 # rows
 # ------------------------------------------------------------------------------------------------
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, idx2: Optional[torch.Tensor] = None) -> torch.Tensor:

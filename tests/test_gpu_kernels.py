@@ -1123,3 +1123,85 @@ def test_gridsample_test_mode_and_full_size_properties(cuda):
         assert torch.unique(p["grid_coord"], dim=0).shape[0] == p["grid_coord"].shape[0]
         seen[p["index"]] = True
     assert bool(seen.all())                                             # every point appears in some part (transform.py:916-949)
+
+
+# ---- pointops subset ---------------------------------------------------------------------------
+@pytest.mark.parametrize("nsample", [1, 3, 16, 20, 70])
+def test_pointops_knn_query(cuda, nsample):
+    """three scenes (one with fewer points than nsample, one whose queries straddle a workgroup boundary), duplicated
+    points (exact distance ties): idx and dist bit-exact vs the oracle (ties: lower index first)."""
+    from oracle import pointops as opo
+    from pointcept_amd import pointops_api as po
+
+    rng = np.random.default_rng(41)
+    sizes, qsizes = [2500, 9, 1300], [700, 40, 300]
+    xyz = rng.random((sum(sizes), 3)).astype(np.float32)
+    xyz[100:150] = xyz[50:100]                                        # ties
+    new_xyz = rng.random((sum(qsizes), 3)).astype(np.float32)
+    new_xyz[:20] = xyz[:20]                                           # zero distances
+    off, noff = np.cumsum(sizes), np.cumsum(qsizes)
+    want_i, want_d = opo.knn_query(nsample, xyz, off, new_xyz, noff)
+    got_i, got_d = po.knn_query(nsample, torch.from_numpy(xyz).to(cuda), torch.from_numpy(off).to(cuda),
+                                torch.from_numpy(new_xyz).to(cuda), torch.from_numpy(noff).to(cuda))
+    assert got_i.dtype == torch.int32 and got_i.shape == (sum(qsizes), nsample)
+    assert np.array_equal(got_i.cpu().numpy(), want_i)
+    assert np.array_equal(got_d.cpu().numpy(), want_d)
+    self_i, self_d = po.knn_query(min(nsample, 8), torch.from_numpy(xyz).to(cuda), torch.from_numpy(off).to(cuda))
+    assert float(self_d[:, 0].max()) == 0.0                           # every point is its own (or its twin's) nearest neighbour
+
+
+def test_pointops_fps_grouping_interpolation(cuda):
+    from oracle import pointops as opo
+    from pointcept_amd import pointops_api as po
+
+    rng = np.random.default_rng(42)
+    sizes, picks = [3000, 1, 777], [200, 1, 64]
+    xyz = rng.random((sum(sizes), 3)).astype(np.float32)
+    off, noff = np.cumsum(sizes), np.cumsum(picks)
+    x, o, no = torch.from_numpy(xyz).to(cuda), torch.from_numpy(off).to(cuda), torch.from_numpy(noff).to(cuda)
+    got = po.farthest_point_sampling(x, o, no)
+    assert np.array_equal(got.cpu().numpy(), opo.farthest_point_sampling(xyz, off, noff))
+    # grouping (-1 slots -> zeros, relative coordinates) and its gradient
+    feat = torch.randn(sum(sizes), 8, device=cuda, requires_grad=True)
+    centres = x[got.long()]
+    idx, _ = po.knn_query(4, x, o, centres, no)
+    grouped = po.grouping(idx, feat, x, centres, with_xyz=True)
+    assert grouped.shape == (noff[-1], 4, 11)
+    slot = idx[0, 1].long()
+    assert torch.equal(grouped[0, 1, 3:], feat[slot].detach()) and torch.allclose(grouped[0, 1, :3], x[slot] - centres[0])
+    assert int((idx[picks[0]] == -1).sum()) == 3 and float(grouped[picks[0], 1:].abs().max()) == 0.0   # the 1-point scene
+    grouped.sum().backward()
+    counts = torch.bincount(idx[idx >= 0].long(), minlength=sum(sizes)).float()
+    assert torch.allclose(feat.grad[:, 0], counts)
+    # interpolation back to all points: exact at the sampled points, convex combination elsewhere
+    vals = torch.randn(noff[-1], 5, device=cuda)
+    up = po.interpolation(centres, x, vals, no, o, k=3)
+    assert up.shape == (sum(sizes), 5)
+    assert torch.allclose(up[got.long()], vals, atol=1e-4)
+    assert float(up.abs().max()) <= float(vals.abs().max()) + 1e-4
+
+
+def test_pointops_through_compat_and_unsupported(cuda):
+    import sys
+
+    import pointcept_amd.compat as compat
+    from pointcept_amd._lib import PtcoreError
+
+    saved = {k: sys.modules.get(k) for k in ("spconv", "spconv.pytorch", "spconv.pytorch.modules", "flash_attn", "torch_scatter", "pointops")}
+    try:
+        compat.install(force=True)
+        import pointops
+
+        x = torch.rand(100, 3, device=cuda)
+        o = torch.tensor([60, 100], device=cuda)
+        idx, dist = pointops.knn_query(2, x, o)
+        assert idx.shape == (100, 2) and bool((idx[:60] < 60).all()) and bool((idx[60:] >= 60).all())
+        assert torch.equal(pointops.offset2batch(o), torch.cat([torch.zeros(60), torch.ones(40)]).long().to(cuda))
+        with pytest.raises(PtcoreError):
+            pointops.ball_query(4, 0.2, 0.0, x, o)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
