@@ -1,11 +1,12 @@
 // host_probe.cpp -- g++ build of the pure helper functions the gfx950 kernels are made of
-// (sfc_keys.h, pad_maps.h, voxel_hash.h), exported for CPU unit checks (-m "not gpu" tests).
+// (sfc_keys.h, pad_maps.h, voxel_hash.h, voxel_keys.h), exported for CPU unit checks (-m "not gpu" tests).
 // This is PRODUCT code exercised on the host, not an oracle: the same headers are compiled into
 // libptcore.so by hipcc.  The oracle they are compared against lives in oracle/.
 #include <stdint.h>
 #include "sfc_keys.h"
 #include "pad_maps.h"
 #include "voxel_hash.h"
+#include "voxel_keys.h"
 
 extern "C" {
 
@@ -78,4 +79,30 @@ int64_t probe_num_seq(int64_t n_i, int64_t K) { return ptc_num_seq(n_i, K); }
 uint64_t probe_vox_pack(int b, int x, int y, int z) { return ptc_vox_pack(b, x, y, z); }
 uint64_t probe_vox_hash(uint64_t h) { return ptc_vox_hash(h); }
 
-}  // extern "C"
+
+// mirrors voxel_floor_kernel + voxel_key_kernel (voxelize.hip)
+void probe_voxel_keys(const float* coord, int64_t n, double grid_size, int64_t* grid, int64_t* min3, int64_t* key) {
+  long long m[3] = {0x7fffffffffffffffll, 0x7fffffffffffffffll, 0x7fffffffffffffffll};
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const long long v = ptc_voxel_floor(coord[3 * i + a], grid_size);
+      grid[3 * i + a] = v;
+      if (v < m[a]) m[a] = v;
+    }
+  for (int a = 0; a < 3; ++a) min3[a] = n ? m[a] : 0;
+  for (int64_t i = 0; i < n; ++i) {
+    for (int a = 0; a < 3; ++a) grid[3 * i + a] -= m[a];
+    key[i] = (int64_t)ptc_fnv3((unsigned long long)grid[3 * i], (unsigned long long)grid[3 * i + 1], (unsigned long long)grid[3 * i + 2]);
+  }
+}
+
+// Lovasz steps of one class row given its sorted foreground flags (mirrors lovasz_step_kernel's arithmetic)
+void probe_lovasz_steps(const int32_t* fg_sorted, int64_t n, double* step) {
+  long long gts = 0, cf = 0;
+  for (int64_t i = 0; i < n; ++i) gts += fg_sorted[i];
+  for (int64_t i = 0; i < n; ++i) {
+    cf += fg_sorted[i];
+    step[i] = gts > 0 ? ptc_lovasz_step(gts, cf, (i + 1) - cf, fg_sorted[i]) : 0.0;
+  }
+}
+}

@@ -22,6 +22,7 @@
 //   6. lovasz_dlogits   : softmax backward per point, dz = p * (g - <g, p>), 0 for ignored points.
 // All of it is HBM-bound streaming work (~190 B per (point, class) slot); bit-reproducible.
 #include "ptc_common.h"
+#include "voxel_keys.h"
 
 #define LV_THREADS 256
 #define LV_MAX_C 64
@@ -91,9 +92,7 @@ lovasz_step_kernel(const int64_t* __restrict__ keys, const int64_t* __restrict__
       const int f = fg[t];
       const int64_t cum_fg = fg_scan[t] - fg_scan[(int64_t)row * n] + f;   // inclusive
       const int64_t cum_bg = (i + 1) - cum_fg;
-      const double U = (double)(gts + cum_bg);          // union after slot i
-      const double I = (double)(gts - cum_fg);          // foreground still to come
-      const double step = f ? 1.0 / U : I / (U * (U - 1.0));
+      const double step = ptc_lovasz_step(gts, cum_fg, cum_bg, f);   // exact Jaccard difference (voxel_keys.h)
       const float e = __uint_as_float(LV_ONE - (uint32_t)keys[(int64_t)row * n + src]);
       contrib = (double)e * step;
       g = (float)(step / (double)n_present_s);

@@ -13,6 +13,7 @@
 // Two streaming passes (12 B in + 24 B out, then 24 B in + 24 B + 8 B out per point); the minimum is an integer
 // atomic (exact, order free).
 #include "ptc_common.h"
+#include "voxel_keys.h"
 
 __global__ void __launch_bounds__(256)
 voxel_floor_kernel(const float* __restrict__ coord, int64_t n, double grid_size, int64_t* __restrict__ grid,
@@ -20,9 +21,9 @@ voxel_floor_kernel(const float* __restrict__ coord, int64_t n, double grid_size,
   long long m0 = LLONG_MAX, m1 = LLONG_MAX, m2 = LLONG_MAX;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const long long x = (long long)floor((double)coord[3 * i] / grid_size);
-    const long long y = (long long)floor((double)coord[3 * i + 1] / grid_size);
-    const long long z = (long long)floor((double)coord[3 * i + 2] / grid_size);
+    const long long x = ptc_voxel_floor(coord[3 * i], grid_size);
+    const long long y = ptc_voxel_floor(coord[3 * i + 1], grid_size);
+    const long long z = ptc_voxel_floor(coord[3 * i + 2], grid_size);
     grid[3 * i] = x;
     grid[3 * i + 1] = y;
     grid[3 * i + 2] = z;
@@ -54,11 +55,7 @@ voxel_key_kernel(int64_t* __restrict__ grid, int64_t n, const long long* __restr
     grid[3 * i] = (int64_t)x;
     grid[3 * i + 1] = (int64_t)y;
     grid[3 * i + 2] = (int64_t)z;
-    unsigned long long h = 14695981039346656037ull;      // FNV offset basis; multiply first, then xor (transform.py:1008-1010)
-    h *= 1099511628211ull; h ^= x;
-    h *= 1099511628211ull; h ^= y;
-    h *= 1099511628211ull; h ^= z;
-    key[i] = (int64_t)h;
+    key[i] = (int64_t)ptc_fnv3(x, y, z);
   }
 }
 

@@ -234,6 +234,33 @@ def test_oracle_gridsample_matches_reference_golden():
         assert np.array_equal(v["inverse"][pick], np.arange(len(v["count"])))
 
 
+def test_product_voxel_keys_and_lovasz_steps_on_the_host():
+    """the per-point / per-slot arithmetic the kernels are made of (csrc/voxel_keys.h), compiled for the host:
+    floor + min shift + FNV key == the reference transform's voxels; exact Jaccard steps == lovasz.py:22-33 in fp64."""
+    from oracle import losses, voxelize
+    from pointcept_amd import _lib
+
+    P = _lib.host_probe()
+    for ci, coord, grid, g in gridsample_cases():
+        n = coord.shape[0]
+        gc, mn, key = np.empty((n, 3), np.int64), np.empty(3, np.int64), np.empty(n, np.int64)
+        c = np.ascontiguousarray(coord)
+        P.probe_voxel_keys.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        P.probe_voxel_keys(c.ctypes.data, n, grid, gc.ctypes.data, mn.ctypes.data, key.ctypes.data)
+        v = voxelize.voxels(coord, grid)
+        assert np.array_equal(gc, v["grid_coord"]) and np.array_equal(mn, v["min_coord"]) and np.array_equal(key.view(np.uint64), v["key"])
+        _, inv = np.unique(key.view(np.uint64), return_inverse=True)
+        assert np.array_equal(inv, g["inverse"])                      # == the reference transform's voxel ids
+    rng = np.random.default_rng(5)
+    for n, p in ((1, 1.0), (7, 0.5), (5000, 0.03), (300, 0.0)):
+        fg = (rng.random(n) < p).astype(np.int32)
+        step = np.empty(n, np.float64)
+        P.probe_lovasz_steps.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        P.probe_lovasz_steps(fg.ctypes.data, n, step.ctypes.data)
+        want = losses.lovasz_grad(fg.astype(np.float64)) if fg.sum() > 0 else np.zeros(n)
+        assert np.allclose(step, want, rtol=1e-9, atol=1e-12), (n, p)
+
+
 # ---- C-ABI surface (no compute) -----------------------------------------------------------------
 def test_library_exports_every_declared_symbol():
     from pointcept_amd import _lib
