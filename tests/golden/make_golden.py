@@ -21,6 +21,8 @@ Fixtures
                       eval output, train-mode output rows, loss = mean(feat^2) and all gradient norms.
   gridsample.npz    : coord -> GridSample(hash_type="fnv", mode="train") of pointcept/datasets/transform.py: inverse,
                       the voxel set in np.unique (ascending key) order, min_coord and the picked representatives.
+  ptv3_enc_mode.npz : reference PT-v3m1 with enc_mode=True followed by the parent-chain concatenation of
+                      DefaultSegmentorV2.forward (default.py:69-74): [N, 32+64+128+256+512] features (every 32nd row, column norms).
   lovasz.npz        : logits / labels -> LovaszLoss(mode="multiclass", ignore_index=-1) loss and gradient
                       (pointcept/models/losses/lovasz.py), five shapes incl. absent classes and a single point.
 """
@@ -45,6 +47,8 @@ TINY_CFG = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), dec_dep
 
 RPE_CFG = dict(TINY_CFG, enc_patch_size=(256,) * 5, dec_patch_size=(256,) * 4, enable_flash=False, enable_rpe=True,
                upcast_attention=True, upcast_softmax=True)
+ENC_CFG = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), enc_channels=(32, 64, 128, 256, 512),
+               enc_num_head=(2, 4, 8, 16, 32), enc_patch_size=(128,) * 5, drop_path=0.0, shuffle_orders=False)
 SPUNET_CFG = dict(base_channels=16, channels=(16, 32, 48, 64, 64, 48, 32, 32), layers=(1, 2, 1, 1, 1, 1, 2, 1))
 
 
@@ -185,6 +189,28 @@ def main():
         blobs[f"picked_{ci}"] = d["segment"].astype(np.int32)                        # the reference's own representatives
     blobs["n_cases"] = np.asarray(len(gcases))
     np.savez_compressed(os.path.join(OUT, "gridsample.npz"), **blobs)
+
+    # ---- PTv3 enc_mode: the pooling_parent / pooling_inverse chain consumed at models/default.py:69-74 ----------
+    torch.manual_seed(0)
+    ref = ptv3.PointTransformerV3(enc_mode=True, **ENC_CFG)
+    ref.load_state_dict(om.deterministic_state_dict(ref, 3))
+    ref.eval()
+    batch = synthetic.collate([synthetic.indoor_scene(27, 1500), synthetic.indoor_scene(28, 400)])
+    torch.manual_seed(5)
+    with torch.no_grad():
+        pt = ref({k: torch.from_numpy(v) for k, v in batch.items()})
+        sizes = [pt.feat.shape[0]]
+        while "pooling_parent" in pt.keys():
+            parent, inverse = pt.pop("pooling_parent"), pt.pop("pooling_inverse")
+            parent.feat = torch.cat([parent.feat, pt.feat[inverse]], dim=-1)
+            pt = parent
+            sizes.append(pt.feat.shape[0])
+    feat = pt.feat.numpy()
+    np.savez_compressed(
+        os.path.join(OUT, "ptv3_enc_mode.npz"), scene_seeds=np.asarray([27, 28]), n_points=np.asarray([1500, 400]),
+        input_checksum=np.asarray([batch["grid_coord"].sum()]), stage_sizes=np.asarray(sizes[::-1]),
+        feat_rows=feat[::32].astype(np.float32), feat_absmax=np.asarray(float(np.abs(feat).max())),
+        feat_col_norm=np.linalg.norm(feat.astype(np.float64), axis=0).astype(np.float32))
 
     # ---- Lovasz-Softmax ------------------------------------------------------------------------
     import importlib

@@ -301,3 +301,65 @@ def test_ptv3_enable_flash_false_uses_the_shrunk_patch(cuda):
     assert eng.enc.enc0.block0.attn.patch_size == 150 and eng.dec.dec0.block0.attn.patch_size == 150
     assert torch.equal(pe.pad.cpu(), po.pad) and torch.equal(pe.unpad.cpu(), po.unpad)
     assert _rel(pe.feat, po.feat) < 2e-2
+
+
+ENC_CFG = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), enc_channels=(32, 64, 128, 256, 512),
+               enc_num_head=(2, 4, 8, 16, 32), enc_patch_size=(128,) * 5, drop_path=0.0, shuffle_orders=False, enc_mode=True)
+
+
+def test_ptv3_enc_mode_chain_matches_reference_golden_and_oracle(cuda):
+    """enc_mode=True: the returned Point carries the pooling_parent / pooling_inverse chain in the CALLER's
+    row order; DefaultSegmentorV2 unrolls it (default.py:69-74) into [N, 992] features.  Golden rows of the reference,
+    then loss and gradients against the live oracle."""
+    from oracle import ptv3_model as om
+    from pointcept_amd import synthetic
+    from pointcept_amd.segmentor import DefaultSegmentorV2
+
+    g = np.load(os.path.join(GOLD, "ptv3_enc_mode.npz"))
+    orc_b, eng_b = _models(ENC_CFG, seed=3)
+    torch.manual_seed(1)
+    orc = om.SegmentorV2(20, 992, orc_b)
+    eng = DefaultSegmentorV2(20, 992, eng_b)
+    eng.seg_head.load_state_dict(orc.seg_head.state_dict())
+    eng = eng.to(cuda)
+    batch = synthetic.collate([synthetic.indoor_scene(int(s), int(n)) for s, n in zip(g["scene_seeds"], g["n_points"])])
+    assert batch["grid_coord"].sum() == g["input_checksum"][0]
+    captured = {}
+    eng.seg_head.register_forward_pre_hook(lambda m, inp: captured.__setitem__("feat", inp[0].detach()))
+    eng.eval()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        out = eng({k: v for k, v in synthetic.to_torch(batch, cuda).items() if k != "segment"}, return_point=True)
+    feat = captured["feat"].float().cpu().numpy()
+    assert feat.shape == (int(g["stage_sizes"][0]), 992) and out["seg_logits"].shape == (feat.shape[0], 20)
+    assert "pooling_parent" not in out["point"].keys()
+    assert np.abs(feat[::32] - g["feat_rows"]).max() <= 2e-2 * float(g["feat_absmax"])
+    assert np.allclose(np.linalg.norm(feat.astype(np.float64), axis=0), g["feat_col_norm"], rtol=2e-2, atol=1e-3)
+    eng.train()
+    orc.train()
+    torch.manual_seed(9)
+    lo = orc({k: torch.from_numpy(v) for k, v in batch.items()})["loss"]
+    lo.backward()
+    torch.manual_seed(9)
+    le = eng(synthetic.to_torch(batch, cuda))["loss"]
+    le.backward()
+    assert abs(le.item() - lo.item()) < 2e-2 * abs(lo.item())
+    go = dict(orc.named_parameters())
+    num = den = 0.0
+    rows = []
+    for name, p in eng.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        r = go[name].grad
+        dn, rn = float((p.grad.cpu() - r).norm()), float(r.norm())
+        num, den = num + dn * dn, den + rn * rn
+        rows.append((dn / max(rn, 1e-30), rn, name))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/grad_report_enc_mode.txt", "w") as f:
+        f.write("\n".join(f"{a:10.3e} {b:10.3e} {c}" for a, b, c in rows) + "\n")
+    # Measured (r01_bc, deterministic kernels): 0.060 for the whole gradient vector, per tensor 0.007 at stage 4 rising to
+    # 0.05-0.09 from stage 3 outwards -- the error enters in the backward of the last pooling, whose train-mode BatchNorm
+    # normalises over 13 rows (a 1e-3 bf16-attention difference in the activations is divided by a tiny batch variance);
+    # seg_head and stage 4 agree to < 1 %.  In decoder mode the skip connections dominate those gradients (1-3 % there).
+    assert (num / den) ** 0.5 < 0.1, (num / den) ** 0.5
+    big = max(r[1] for r in rows)
+    assert all(a < 0.2 for a, b, _ in rows if b > 1e-2 * big), [r for r in rows if r[1] > 1e-2 * big and r[0] >= 0.2][:5]
