@@ -3,9 +3,10 @@
 `Linear` / `LayerNorm` subclass torch's modules (same parameters, same state-dict keys, same
 initialisation: pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:97-98,240-244,
 286-305,366,463-464) and only change WHERE forward runs: [N, C] CUDA features go to libptcore.so
-(tall-skinny MFMA GEMMs with split-K weight gradients, one-pass LayerNorm), anything else -- CPU
-construction-time calls, 3-D inputs -- stays on torch.  No numerics are silently traded: the
-kernels accumulate in fp32 and round operands exactly where autocast would.
+(tall-skinny MFMA GEMMs with split-K weight gradients, one-pass LayerNorm); shapes the kernels do not
+cover (3-D inputs, empty tensors, very wide layers) stay on PyTorch-ROCm's GPU libraries.  CPU tensors are
+refused (`PtcoreError`): like every op of the engine these layers have no CPU path.  No numerics are silently
+traded: the kernels accumulate in fp32 and round operands exactly where autocast would.
 """
 from __future__ import annotations
 
@@ -18,6 +19,13 @@ import torch.nn.functional as F
 from . import config
 from . import functional as PF
 from . import ops
+from ._lib import PtcoreError
+
+
+def _require_gpu(x: torch.Tensor, layer: str) -> None:
+    if not x.is_cuda:
+        raise PtcoreError(f"pointcept_amd.nn.{layer}: input lives on {x.device} -- the engine has no CPU fallback")
+
 
 # hipBLASLt is well tuned for square-ish GEMMs; the engine kernels win on the tall-skinny shapes of
 # point features (N ~ 1e4..1e6 rows, C <= 512) and on every weight gradient (contraction over N).
@@ -36,6 +44,7 @@ def _own_linear_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
 class Linear(nn.Linear):
     def forward(self, x: torch.Tensor, tab_fwd: Optional[torch.Tensor] = None,
                 tab_bwd: Optional[torch.Tensor] = None) -> torch.Tensor:
+        _require_gpu(x, "Linear")
         if tab_fwd is not None or _own_linear_ok(x, self.weight):
             return PF.linear(x, self.weight, self.bias, tab_fwd, tab_bwd)
         return F.linear(x, self.weight, self.bias)
@@ -45,6 +54,7 @@ class LayerNorm(nn.LayerNorm):
     gemm_consumer = False  # set by Block when the only reader of the output is a GEMM
 
     def forward(self, x: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        _require_gpu(x, "LayerNorm")
         if out_dtype is None and self.gemm_consumer and x.is_cuda and torch.is_autocast_enabled("cuda"):
             out_dtype = torch.get_autocast_dtype("cuda")  # the value autocast's cast would produce anyway
         if (config.OWN_NORM and x.is_cuda and x.dim() == 2 and len(self.normalized_shape) == 1
@@ -62,6 +72,7 @@ class BatchNorm1d(nn.BatchNorm1d):
     act = "none"
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _require_gpu(x, "BatchNorm1d")
         use = (config.OWN_NORM and x.is_cuda and x.dim() == 2 and x.shape[0] > 1 and ops.batch_norm_supported(x.shape[1], x.dtype)
                and (self.training or self.running_mean is not None))
         if not use:

@@ -324,3 +324,14 @@ def test_ops_refuse_cpu_tensors():
         ops.gather_rows(torch.zeros(4, 8), torch.zeros(4, dtype=torch.long))
     with pytest.raises(PtcoreError, match="no CPU fallback"):
         ops.serialize_encode(torch.zeros(4, 3, dtype=torch.long), None, 4, ("z",))
+    from pointcept_amd import nn as PNN
+    from pointcept_amd import spconv_api as sp
+
+    for layer in (PNN.Linear(8, 8), PNN.LayerNorm(32), PNN.BatchNorm1d(32)):
+        with pytest.raises(PtcoreError, match="no CPU fallback"):
+            layer(torch.zeros(4, 32 if not isinstance(layer, PNN.Linear) else 8))
+    x = sp.SparseConvTensor(torch.zeros(4, 8), torch.zeros(4, 4, dtype=torch.int32), [8, 8, 8], 1)
+    with pytest.raises(PtcoreError, match="no CPU fallback"):
+        sp.SubMConv3d(8, 16, 1)(x)
+    with pytest.raises(PtcoreError, match="no CPU fallback"):
+        sp.SubMConv3d(8, 16, 3)(x)
