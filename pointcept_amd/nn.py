@@ -57,8 +57,8 @@ class LayerNorm(nn.LayerNorm):
         _require_gpu(x, "LayerNorm")
         if out_dtype is None and self.gemm_consumer and x.is_cuda and torch.is_autocast_enabled("cuda"):
             out_dtype = torch.get_autocast_dtype("cuda")  # the value autocast's cast would produce anyway
-        if (config.OWN_NORM and x.is_cuda and x.dim() == 2 and len(self.normalized_shape) == 1
-                and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+        if (config.OWN_NORM and x.is_cuda and x.dim() == 2 and len(self.normalized_shape) == 1 and self.elementwise_affine
+                and self.bias is not None and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
                 and ops.layer_norm_supported(x.shape[1]) and x.shape[0] > 0):
             return PF.layer_norm(x, self.weight, self.bias, self.eps, out_dtype)
         y = F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
@@ -73,7 +73,7 @@ class BatchNorm1d(nn.BatchNorm1d):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _require_gpu(x, "BatchNorm1d")
-        use = (config.OWN_NORM and x.is_cuda and x.dim() == 2 and x.shape[0] > 1 and ops.batch_norm_supported(x.shape[1], x.dtype)
+        use = (config.OWN_NORM and self.affine and x.is_cuda and x.dim() == 2 and x.shape[0] > 1 and ops.batch_norm_supported(x.shape[1], x.dtype)
                and (self.training or self.running_mean is not None))
         if not use:
             y = super().forward(x)

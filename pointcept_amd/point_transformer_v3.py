@@ -17,7 +17,8 @@ BatchNorm / GELU / residual adds stay on PyTorch-ROCm (ATen).
 Behaviours of the reference that change numerics are reproduced on purpose:
 stale sparse_conv_feat in the first decoder block's CPE (D.1), per-point DropPath (D.2), CPU-RNG
 order shuffling (D.3), bf16 attention regardless of the AMP dtype (D.4).
-Not implemented (raise): PDNorm (pdnorm_bn / pdnorm_ln); head_dim != 16 or attention dropout with enable_flash=True.
+Not implemented (raise): head_dim != 16 or attention dropout with enable_flash=True.  PDNorm (pdnorm_bn / pdnorm_ln, the
+PPT multi-dataset configs) selects among the engine's own per-condition norm layers; those blocks take the unfused path.
 `enable_flash=False` follows the reference's patch-size rule (min(smallest scene, patch_size), ptv3m1:173-176) and runs the
 same attention kernel when it can (no RPE / dropout, head_dim 16; bf16 operands), else the dense [P,H,K,K] branch of
 :190-206 (RPE bias, upcasts, dropout) in torch ops on the GPU.
@@ -26,6 +27,7 @@ from __future__ import annotations
 
 import math
 from collections import OrderedDict
+from functools import partial
 
 import torch
 import torch.nn as nn
@@ -93,6 +95,40 @@ class PointSequential(PointModule):
                 else:
                     input = module(input)
         return input
+
+
+class PDNorm(PointModule):
+    """Prompt-driven normalisation of the multi-dataset (PPT) configs,
+    pointcept/models/point_prompt_training/prompt_driven_normalization.py:8-49: one norm layer per dataset condition
+    (`decouple`), selected by `point.condition`, optionally modulated by `point.context` (`adaptive`:
+    feat * (1 + scale) + shift with (shift, scale) = Linear(SiLU(context))).  Same attribute names, so the state dict
+    (`norm.{i}.*`, `modulation.1.*`) is the reference's."""
+
+    def __init__(self, num_features, norm_layer, context_channels=256, conditions=("ScanNet", "S3DIS", "Structured3D"),
+                 decouple=True, adaptive=False):
+        super().__init__()
+        self.conditions, self.decouple, self.adaptive = conditions, decouple, adaptive
+        if self.decouple:
+            self.norm = nn.ModuleList([norm_layer(num_features) for _ in conditions])
+        else:
+            self.norm = norm_layer     # as the reference: the factory itself (only meaningful with decouple=True)
+        if self.adaptive:
+            self.modulation = nn.Sequential(nn.SiLU(), nn.Linear(context_channels, 2 * num_features, bias=True))
+
+    def forward(self, point):
+        assert {"feat", "condition"}.issubset(point.keys())
+        condition = point.condition if isinstance(point.condition, str) else point.condition[0]
+        if self.decouple:
+            assert condition in self.conditions
+            norm = self.norm[self.conditions.index(condition)]
+        else:
+            norm = self.norm
+        point.feat = norm(point.feat)
+        if self.adaptive:
+            assert "context" in point.keys()
+            shift, scale = self.modulation(point.context).chunk(2, dim=1)
+            point.feat = point.feat * (1.0 + scale) + shift
+        return point
 
 
 class DropPath(nn.Module):
@@ -503,8 +539,6 @@ class PointTransformerV3(PointModule):
                  pdnorm_ln=False, pdnorm_decouple=True, pdnorm_adaptive=False, pdnorm_affine=True,
                  pdnorm_conditions=("ScanNet", "S3DIS", "Structured3D")):
         super().__init__()
-        if pdnorm_bn or pdnorm_ln:
-            raise PtcoreError("PDNorm (pdnorm_bn / pdnorm_ln) is not implemented by the engine (off in all BASELINE configs)")
         self.num_stages = len(enc_depths)
         self.order = [order] if isinstance(order, str) else order
         self.enc_mode = enc_mode
@@ -515,6 +549,11 @@ class PointTransformerV3(PointModule):
 
         bn_layer = lambda c: PNN.BatchNorm1d(c, eps=1e-3, momentum=0.01)  # noqa: E731  (ptv3m1:581)
         ln_layer = PNN.LayerNorm
+        pd = dict(conditions=pdnorm_conditions, decouple=pdnorm_decouple, adaptive=pdnorm_adaptive)
+        if pdnorm_bn:   # ptv3m1:570-580 (PPT multi-dataset training; the per-condition layers are the engine's own)
+            bn_layer = partial(PDNorm, norm_layer=partial(PNN.BatchNorm1d, eps=1e-3, momentum=0.01, affine=pdnorm_affine), **pd)
+        if pdnorm_ln:   # ptv3m1:582-590
+            ln_layer = partial(PDNorm, norm_layer=partial(PNN.LayerNorm, elementwise_affine=pdnorm_affine), **pd)
         act_layer = PNN.GELU
         blk = dict(mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop,
                    norm_layer=ln_layer, act_layer=act_layer, pre_norm=pre_norm, enable_rpe=enable_rpe,

@@ -152,3 +152,36 @@ def test_lovasz_and_gridsample_random_cases(R):
         first = v["idx_sort"][np.cumsum(np.insert(v["count"], 0, 0)[:-1])]
         assert np.array_equal(v["grid_coord"][first], d["grid_coord"])
         assert np.array_equal(v["inverse"][d["segment"]], np.arange(len(v["count"])))
+
+
+def test_pdnorm_state_dict_and_module_semantics(R):
+    """PPT configs (pdnorm_bn / pdnorm_ln): the engine model has the reference's state-dict keys and shapes, and the
+    engine's PDNorm (per-condition norm selection + adaptive modulation) computes what the reference class computes
+    (checked here with torch's CPU norm layers inside both -- the engine's own layers are GPU-only)."""
+    import torch.nn as nn
+    from functools import partial
+
+    from pointcept_amd.point_transformer_v3 import PDNorm, PointTransformerV3
+    from pointcept_amd.structure import AttrDict
+
+    cfg = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), dec_depths=(1, 1, 1, 1), enc_patch_size=(64,) * 5,
+               dec_patch_size=(64,) * 4, pdnorm_bn=True, pdnorm_ln=True, pdnorm_adaptive=True, pdnorm_decouple=True,
+               pdnorm_conditions=("ScanNet", "S3DIS"))
+    torch.manual_seed(0)
+    ref, eng = R["ptv3"].PointTransformerV3(**cfg), PointTransformerV3(**cfg)
+    assert list(ref.state_dict().keys()) == list(eng.state_dict().keys())
+    for (k, a), (_, b) in zip(ref.state_dict().items(), eng.state_dict().items()):
+        assert a.shape == b.shape, k
+    assert any(".norm.1.running_mean" in k for k in eng.state_dict()) and any("modulation.1.weight" in k for k in eng.state_dict())
+
+    RefPD = R["ptv3"].PDNorm
+    for layer in (partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01), partial(nn.LayerNorm, elementwise_affine=False)):
+        torch.manual_seed(1)
+        a = RefPD(32, layer, context_channels=16, conditions=("A", "B", "C"), decouple=True, adaptive=True)
+        b = PDNorm(32, layer, context_channels=16, conditions=("A", "B", "C"), decouple=True, adaptive=True)
+        b.load_state_dict(a.state_dict())
+        x, ctx = torch.randn(50, 32), torch.randn(50, 16)
+        for cond in ("B", ["C"]):
+            pa = a(R["structure"].Point(feat=x.clone(), condition=cond, context=ctx, offset=torch.tensor([50])))
+            pb = b(AttrDict(feat=x.clone(), condition=cond, context=ctx))
+            assert torch.allclose(pa.feat, pb["feat"], atol=1e-6)
