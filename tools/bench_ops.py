@@ -229,14 +229,39 @@ def bench_losses(rows, results, n=819200, c=20):
                 f"({r['lovasz_GBps']:.0f} GB/s of ~190 B/slot) | ATen softmax + {c} sorts + cumsums alone {r['aten_sorts_only_us']:.1f} us")
 
 
+def bench_front_end(rows, results):
+    """the 8(f) rows: device GridSample on a raw 2M-point scan, kNN at the evaluator's shape (predictions of a 100k-voxel
+    scene carried to its 250k raw points, evaluator.py:569), k = 16 self-query, farthest point sampling 100k -> 2048."""
+    from pointcept_amd import pointops_api as po
+    from pointcept_amd.transform import GridSample
+
+    g = torch.Generator().manual_seed(0)
+    raw = ((torch.rand(2_000_000, 3, generator=g) - 0.5) * torch.tensor([7.0, 5.0, 2.8])).to(DEV)
+    gs = GridSample(grid_size=0.02, mode="train", return_grid_coord=True)
+    t_gs = timeit(lambda: gs(dict(coord=raw, index_valid_keys=["coord"])), 5, 1)
+    vox = torch.rand(100_000, 3, generator=g).to(DEV)
+    pts = torch.rand(250_000, 3, generator=g).to(DEV)
+    o1, o2 = torch.tensor([100_000], device=DEV), torch.tensor([250_000], device=DEV)
+    t_k1 = timeit(lambda: po.knn_query(1, vox, o1, pts, o2), 5, 1)
+    t_k16 = timeit(lambda: po.knn_query(16, vox, o1), 3, 1)
+    t_fps = timeit(lambda: po.farthest_point_sampling(vox, o1, torch.tensor([2048], device=DEV)), 3, 1)
+    r = {"gridsample_2M_us": round(t_gs * 1e6, 1), "knn1_100k_x_250k_us": round(t_k1 * 1e6, 1),
+         "knn16_100k_self_us": round(t_k16 * 1e6, 1), "fps_100k_2048_us": round(t_fps * 1e6, 1),
+         "knn1_Gdist_per_s": round(100_000 * 250_000 / t_k1 / 1e9, 1), "knn16_Gdist_per_s": round(100_000 * 100_000 / t_k16 / 1e9, 1)}
+    results.append(r)
+    rows.append(f"front end: GridSample 2M pts {r['gridsample_2M_us']:.0f} us | kNN k=1 100k x 250k {r['knn1_100k_x_250k_us']:.0f} us "
+                f"({r['knn1_Gdist_per_s']:.0f} G dist/s) | kNN k=16 100k self {r['knn16_100k_self_us']:.0f} us "
+                f"({r['knn16_Gdist_per_s']:.0f} G dist/s) | FPS 100k -> 2048 {r['fps_100k_2048_us']:.0f} us")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of sections: linear,ln,attn,spconv")
+    ap.add_argument("--only", default="", help="comma list of sections: linear,ln,attn,spconv,stages,losses,front")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     want = lambda name: not only or name in only  # noqa: E731
-    rows, res = [], {"linear": [], "ln": [], "attn": [], "spconv": [], "stages": [], "losses": []}
+    rows, res = [], {"linear": [], "ln": [], "attn": [], "spconv": [], "stages": [], "losses": [], "front": []}
     stages = [(819200, 32), (202560, 64), (49256, 128), (11400, 256), (2640, 512)]
     if args.quick:
         stages = stages[:2]
@@ -261,6 +286,8 @@ def main():
         bench_spconv_stages(rows, res["stages"])
     if want("losses"):
         bench_losses(rows, res["losses"])
+    if want("front"):
+        bench_front_end(rows, res["front"])
     print("\n".join(rows))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_ops.json"), "w") as f:
