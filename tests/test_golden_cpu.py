@@ -303,6 +303,37 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.ptc_version()
 
 
+def test_ctypes_signatures_match_the_header():
+    """every binding in pointcept_amd/_lib.py has the parameter count, the scalar / pointer kind of each parameter and
+    the return kind that include/ptcore.h declares (an int64 passed where the C side reads an int, or a missing
+    argument, corrupts the call silently on x86-64)."""
+    from pointcept_amd import _lib
+
+    header = open(os.path.join(os.path.dirname(GOLD), "..", "include", "ptcore.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    decls = re.findall(r"\b(const char\*|int64_t|size_t|int)\s+(ptc_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
+    assert len(decls) == len(_lib._SIGNATURES)
+
+    def kind(ctype):
+        if ctype in (ctypes.c_void_p, ctypes.c_char_p):
+            return "ptr"
+        return {ctypes.c_int: "int", ctypes.c_int64: "i64", ctypes.c_size_t: "size", ctypes.c_float: "f32", ctypes.c_double: "f64"}[ctype]
+
+    def ckind(param):
+        param = param.strip()
+        if "*" in param or param.startswith("ptc_stream_t"):
+            return "ptr"
+        base = param.rsplit(" ", 1)[0].replace("const ", "").strip()
+        return {"int": "int", "int64_t": "i64", "size_t": "size", "float": "f32", "double": "f64"}[base]
+
+    for ret, name, params in decls:
+        restype, argtypes = _lib._SIGNATURES[name]
+        plist = [q for q in params.split(",") if q.strip() and q.strip() != "void"]
+        assert len(plist) == len(argtypes), (name, len(plist), len(argtypes))
+        assert [ckind(q) for q in plist] == [kind(a) for a in argtypes], name
+        assert kind(restype) == {"const char*": "ptr", "int64_t": "i64", "size_t": "size", "int": "int"}[ret], name
+
+
 def test_argument_validation_returns_error_codes():
     from pointcept_amd import _lib
 
