@@ -104,6 +104,11 @@ def _dup_rep(x, center_row=None):
     return e[1]
 
 
+def _require_gpu(t, what: str) -> None:
+    if not t.is_cuda:
+        raise PtcoreError(f"{what}: features must live on a GPU (there is no CPU fallback)")
+
+
 class SparseModule(nn.Module):
     """marker base class (spconv.pytorch.modules.SparseModule)"""
 
@@ -210,8 +215,7 @@ class SubMConv3d(_SparseConvolution):
         if k == 1:  # spconv short-circuits 1x1x1 submanifold convs to a GEMM
             w2 = self.weight.reshape(self.out_channels, self.in_channels)
             f = x.features
-            if not f.is_cuda:
-                raise PtcoreError("SubMConv3d: features must live on a GPU (there is no CPU fallback)")
+            _require_gpu(f, "SubMConv3d")
             if f.shape[0] == 0:
                 return x.replace_feature(f.new_zeros((0, self.out_channels)))
             return x.replace_feature(PF.linear(f, w2, self.bias))   # the engine's tall-skinny GEMM kernels

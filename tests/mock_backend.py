@@ -1,0 +1,235 @@
+"""TEST INFRASTRUCTURE.  CPU stand-ins for `pointcept_amd.ops` so that the engine's PYTHON layer -- modules, autograd
+wrappers, index bookkeeping, host-fact prefetching, criteria -- can be exercised in the `-m "not gpu"` tier.
+
+    with mock_backend.cpu_ops():
+        model = PointTransformerV3(...)      # construct INSIDE the context (activation absorption reads the switches)
+        out = model(batch_on_cpu)
+
+Every stand-in restates the documented contract of the op it replaces (pointcept_amd/ops.py docstrings,
+include/ptcore.h) on oracle/ functions or plain torch.  NOTHING here tests a kernel -- that is the `-m gpu` tier, which
+runs the real library.  The product never imports this module; outside the context manager every op still refuses CPU
+tensors.
+"""
+from __future__ import annotations
+
+import contextlib
+
+import numpy as np
+import torch
+
+from oracle import losses as olosses
+from oracle import maps as omaps
+from oracle import ops as oops
+from oracle import sfc as osfc
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def coord_max(grid_coord):
+    return grid_coord.max(0).values.to(torch.int64) if grid_coord.shape[0] else torch.zeros(3, dtype=torch.int64)
+
+
+def serialize_encode(grid_coord, batch, depth, orders):
+    return torch.from_numpy(osfc.encode_c(_np(grid_coord).astype(np.int64), None if batch is None else _np(batch).astype(np.int64),
+                                          int(depth), tuple(orders)))
+
+
+def sort_keys(keys, begin_bit, end_bit, want_inverse=True):
+    squeeze = keys.dim() == 1
+    k2 = keys.reshape(1, -1) if squeeze else keys
+    width = end_bit - begin_bit
+    masked = (_np(k2).astype(np.uint64) >> np.uint64(begin_bit)) & np.uint64((1 << width) - 1 if width < 64 else 0xFFFFFFFFFFFFFFFF)
+    order = np.argsort(masked, axis=1, kind="stable")
+    inverse = np.empty_like(order)
+    for r in range(order.shape[0]):
+        inverse[r, order[r]] = np.arange(order.shape[1])
+    o, i = torch.from_numpy(order), torch.from_numpy(inverse)
+    if squeeze:
+        return o[0], (i[0] if want_inverse else None)
+    return o, (i if want_inverse else None)
+
+
+def patch_pad_maps(offset, offset_host, patch):
+    pad, unpad, cu = omaps.pad_maps(np.asarray(offset_host, dtype=np.int64), int(patch))
+    return tuple(torch.from_numpy(x) for x in (pad, unpad, cu, omaps.dup_map(pad, unpad)))
+
+
+def attn_tables(order, inverse, pad, unpad, dup):
+    point = order[pad]
+    slots = torch.arange(pad.numel())
+    t_qkv_fwd = point.to(torch.int32)[None]
+    t_proj_bwd = torch.where(unpad[inverse[point]] == slots, point, torch.full_like(point, -1)).to(torch.int32)[None]
+    slot = unpad[inverse]
+    t_qkv_bwd = torch.stack([slot, dup[inverse]]).to(torch.int32)
+    return t_qkv_fwd, t_qkv_bwd, slot.to(torch.int32)[None], t_proj_bwd
+
+
+def pool_level_counts(code0, order0, batch_shift, n_batch, shifts):
+    c = _np(code0).astype(np.uint64)
+    b = (c >> np.uint64(batch_shift)).astype(np.int64)
+    return torch.tensor([[len(np.unique(c[b == s] >> np.uint64(sh))) for s in range(n_batch)] for sh in shifts], dtype=torch.int64)
+
+
+def pool_maps(code0, order0, shift, n_cluster=None):
+    c = _np(code0) >> shift
+    uniq, cluster, counts = np.unique(c, return_inverse=True, return_counts=True)
+    assert n_cluster is None or n_cluster == len(uniq), (n_cluster, len(uniq))
+    idx_ptr = np.concatenate([[0], np.cumsum(counts)])
+    head = _np(order0)[idx_ptr[:-1]]
+    return torch.from_numpy(cluster.astype(np.int64)), torch.from_numpy(idx_ptr.astype(np.int64)), torch.from_numpy(head.astype(np.int64))
+
+
+def pool_child_codes(code, head, shift):
+    return code[:, head] >> shift
+
+
+def gather_rows(src, idx, idx2=None):
+    def take(i):
+        i = i.long()
+        return src[i.clamp(min=0)] * (i >= 0)[:, None].to(src.dtype)
+    out = take(idx)
+    return out if idx2 is None else out + take(idx2)
+
+
+def segment_csr_fwd(src, perm, indptr, reduce):
+    rows = src if perm is None else src[perm.long()]
+    indptr = indptr.long()
+    n_seg = indptr.numel() - 1
+    out = oops.segment_csr(rows.detach(), indptr, reduce)
+    arg = None
+    if reduce in ("max", "min"):
+        arg = torch.zeros((n_seg, src.shape[1]), dtype=torch.int32)
+        for s in range(n_seg):                                       # small test inputs only
+            a, b = int(indptr[s]), int(indptr[s + 1])
+            if b > a:
+                seg = rows[a:b]
+                first = (seg == out[s][None]).float().argmax(0) + a   # first arg-max / arg-min row of the segment
+                arg[s] = (first if perm is None else perm.long()[first]).to(torch.int32)
+    return out, arg
+
+
+def segment_csr_bwd(grad_out, perm, indptr, arg, n_src, reduce):
+    indptr = indptr.long()
+    n_seg, c = indptr.numel() - 1, grad_out.shape[1]
+    g = torch.zeros((int(n_src), c), dtype=grad_out.dtype)
+    counts = indptr[1:] - indptr[:-1]
+    if reduce in ("max", "min"):
+        live = (counts > 0)[:, None].expand(-1, c)
+        cols = torch.arange(c)[None].expand(n_seg, -1)
+        g.index_put_((arg.long()[live], cols[live]), grad_out[live], accumulate=True)
+        return g
+    seg = torch.repeat_interleave(torch.arange(n_seg), counts)
+    rows = torch.arange(int(indptr[-1])) if perm is None else perm.long()[: int(indptr[-1])]
+    val = grad_out[seg]
+    if reduce == "mean":
+        val = val / counts[seg][:, None].to(val.dtype)
+    g.index_add_(0, rows, val)
+    return g
+
+
+class HashTable:
+    def __init__(self, indices):
+        assert indices.dtype == torch.int32 and indices.dim() == 2 and indices.shape[1] == 4
+        self.indices = indices.contiguous()
+
+
+def rulebook_subm(indices, ksize, table=None):
+    ind = table.indices if table is not None else indices
+    return torch.from_numpy(oops.subm_rulebook(_np(ind), int(ksize)))
+
+
+def rulebook_down(indices, coord_bits, batch_bits):
+    out_indices, _, nbr_down, nbr_up = oops.down_rulebook(_np(indices))
+    return torch.from_numpy(out_indices), torch.from_numpy(nbr_down), torch.from_numpy(nbr_up)
+
+
+def spconv_fwd(feat, weight, bias, nbr):
+    f, w = feat.float(), weight.float()
+    if nbr is None:
+        out = f @ w[:, 0, :].t()
+        if bias is not None:
+            out = out + bias.float()
+    else:
+        out = oops.gather_conv(f, w, None if bias is None else bias.float(), _np(nbr))
+    return out.to(feat.dtype)
+
+
+def spconv_wgrad(feat, dout, nbr, want_bias=False):
+    f, g = feat.float(), dout.float()
+    if nbr is None:
+        dw = (g.t() @ f)[:, None, :]
+    else:
+        fpad = torch.cat([f, f.new_zeros(1, f.shape[1])])
+        dw = torch.stack([g.t() @ fpad[nbr[k].long()] for k in range(nbr.shape[0])], dim=1)
+    return (dw, g.sum(0)) if want_bias else dw
+
+
+def attn_varlen_fwd(qkv, cu_seqlens, max_seqlen, softmax_scale):
+    out, lse = oops.attention_varlen(qkv.float(), cu_seqlens.tolist(), float(softmax_scale), return_lse=True)
+    return out.to(torch.bfloat16), lse
+
+
+def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen, softmax_scale):
+    q = qkv.detach().float().requires_grad_(True)
+    with torch.enable_grad():
+        o = oops.attention_varlen(q, cu_seqlens.tolist(), float(softmax_scale))
+    o.backward(dout.float())
+    return q.grad.to(torch.bfloat16)
+
+
+def cross_entropy_fwd(logits, target, ignore_index):
+    lg = logits.float()
+    lse = torch.logsumexp(lg, dim=1)
+    valid = (target != ignore_index) & (target >= 0) & (target < lg.shape[1])
+    picked = lg.gather(1, target.clamp(0, lg.shape[1] - 1)[:, None])[:, 0]
+    return ((lse - picked) * valid).sum(), valid.float().sum(), lse
+
+
+def cross_entropy_bwd(logits, target, lse, scale, ignore_index):
+    lg = logits.float()
+    valid = (target != ignore_index) & (target >= 0) & (target < lg.shape[1])
+    p = torch.exp(lg - lse[:, None])
+    p[torch.arange(lg.shape[0])[valid], target[valid]] -= 1.0
+    return (p * valid[:, None] * scale.float()).to(logits.dtype)
+
+
+def lovasz_softmax(logits, target, ignore_index):
+    loss, d = olosses.lovasz_softmax(_np(logits.float()), _np(target), int(ignore_index))
+    return torch.tensor(loss, dtype=torch.float32), torch.from_numpy(d).float()
+
+
+def column_sum(x):
+    return x.float().sum(0)
+
+
+_STANDINS = dict(
+    coord_max=coord_max, serialize_encode=serialize_encode, sort_keys=sort_keys, patch_pad_maps=patch_pad_maps,
+    attn_tables=attn_tables, pool_level_counts=pool_level_counts, pool_maps=pool_maps, pool_child_codes=pool_child_codes,
+    gather_rows=gather_rows, segment_csr_fwd=segment_csr_fwd, segment_csr_bwd=segment_csr_bwd, HashTable=HashTable,
+    rulebook_subm=rulebook_subm, rulebook_down=rulebook_down, spconv_fwd=spconv_fwd, spconv_wgrad=spconv_wgrad,
+    attn_varlen_fwd=attn_varlen_fwd, attn_varlen_bwd=attn_varlen_bwd, cross_entropy_fwd=cross_entropy_fwd,
+    cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum,
+    layer_norm_supported=lambda c: False, batch_norm_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)
+
+
+@contextlib.contextmanager
+def cpu_ops():
+    """pointcept_amd.ops -> the stand-ins above; the layers' "GPU only" guards -> no-ops.  Restored on exit."""
+    from pointcept_amd import nn as PNN
+    from pointcept_amd import ops, spconv_api
+
+    saved = {k: getattr(ops, k) for k in _STANDINS}
+    guards = [(PNN, "_require_gpu", PNN._require_gpu), (spconv_api, "_require_gpu", spconv_api._require_gpu)]
+    try:
+        for k, v in _STANDINS.items():
+            setattr(ops, k, v)
+        for mod, name, _ in guards:
+            setattr(mod, name, lambda *a, **kw: None)
+        yield
+    finally:
+        for k, v in saved.items():
+            setattr(ops, k, v)
+        for mod, name, fn in guards:
+            setattr(mod, name, fn)
