@@ -174,3 +174,68 @@ def test_pdnorm_model_matches_the_reference_model():
         _grad_check(eng, ref, 1e-2)
         unused = [k for k, p in eng.named_parameters() if ".norm.0." in k and "enc0.block0.norm1" in k]
         assert unused and all(dict(eng.named_parameters())[k].grad is None for k in unused)      # "ScanNet" layers were not used
+
+
+@pytest.mark.needs_reference
+def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
+    """SURVEY 8(b) B3 end to end: the REFERENCE's own files (structure.py, modules.py, point_transformer_v3m1_base.py,
+    spconv_unet_v1m1_base.py) are imported a second time with `spconv.pytorch`, `flash_attn` and `torch_scatter` bound to
+    what pointcept_amd.compat.install() provides (ops on the CPU stand-ins), and compared with the same files running
+    on the oracle's third-party stand-ins: same outputs, same gradients.  Nothing of the engine's own model code is
+    involved -- only its operator-level API."""
+    import importlib
+    import sys
+
+    import pointcept_amd.compat as compat
+    from oracle import ptv3_model as om
+    from oracle import ref_import
+
+    R = ref_import.load()                                        # reference files on oracle/shims.py
+    names = ["spconv", "spconv.pytorch", "spconv.pytorch.modules", "flash_attn", "torch_scatter",
+             "pointcept.models.utils", "pointcept.models.utils.structure", "pointcept.models.utils.misc",
+             "pointcept.models.utils.serialization", "pointcept.models.modules", "pointcept.models.builder",
+             "pointcept.models.point_transformer_v3.point_transformer_v3m1_base",
+             "pointcept.models.sparse_unet.spconv_unet_v1m1_base"]
+    names += [k for k in list(sys.modules) if k.startswith("pointcept.models.utils.serialization.")]
+    saved = {k: sys.modules.pop(k, None) for k in names}
+    try:
+        compat.install(force=True)                               # engine operator API under the third-party names
+        E = dict(ptv3=importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m1_base"),
+                 spunet=importlib.import_module("pointcept.models.sparse_unet.spconv_unet_v1m1_base"))
+        assert E["ptv3"] is not R["ptv3"] and E["ptv3"].spconv.__name__ == "pointcept_amd.spconv_api"
+        with mock_backend.cpu_ops():
+            cfg = dict(TINY, enable_flash=True)
+            batch = _batch([500, 220], seed0=500)
+            torch.manual_seed(0)
+            a, b = R["ptv3"].PointTransformerV3(**cfg), E["ptv3"].PointTransformerV3(**cfg)
+            sd = om.deterministic_state_dict(a, 24)
+            a.load_state_dict(sd)
+            b.load_state_dict(sd)
+            feats = []
+            for net in (a, b):
+                net.train()
+                torch.manual_seed(9)
+                f = net({k: v for k, v in batch.items()}).feat
+                (f * torch.linspace(-1, 1, f.shape[1])).pow(2).mean().backward()
+                feats.append(f.detach())
+            assert _rel(feats[1], feats[0]) < 1e-3
+            _grad_check(b, a, 1e-2)
+            scfg = dict(base_channels=16, channels=(16, 32, 32, 48, 48, 32, 32, 16), layers=(1, 1, 1, 1, 1, 1, 1, 1))
+            c, d = R["spunet"].SpUNetBase(6, 20, **scfg), E["spunet"].SpUNetBase(6, 20, **scfg)
+            sd = om.deterministic_state_dict(c, 25)
+            c.load_state_dict(sd)
+            d.load_state_dict(sd)
+            outs = []
+            for net in (c, d):
+                net.train()
+                o = net({k: v for k, v in batch.items()})
+                torch.nn.functional.cross_entropy(o, batch["segment"], ignore_index=-1).backward()
+                outs.append(o.detach())
+            assert _rel(outs[1], outs[0]) < 1e-4
+            _grad_check(d, c, 2e-3)
+    finally:
+        for k in names:
+            sys.modules.pop(k, None)
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
