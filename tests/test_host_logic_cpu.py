@@ -240,3 +240,32 @@ def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
         for k, v in saved.items():
             if v is not None:
                 sys.modules[k] = v
+
+
+def test_physically_sorted_working_copy_and_restore():
+    """Point.physically_sorted re-expresses every per-point tensor and all k serialization maps in the row order of the
+    first curve; restore_order brings features back (and its backward routes gradients to the caller's rows)."""
+    from pointcept_amd.structure import Point
+
+    batch = _batch([400, 150], seed0=600)
+    with mock_backend.cpu_ops():
+        p = Point({k: v for k, v in batch.items()})
+        p["feat"] = p.feat.clone().requires_grad_(True)
+        torch.manual_seed(3)
+        p.serialization(order=ORDERS, shuffle_orders=True)
+        w = p.physically_sorted()
+        pi = p.serialized_order[0]
+        assert torch.equal(w.feat.detach(), p.feat.detach()[pi]) and torch.equal(w.grid_coord, p.grid_coord[pi])
+        assert torch.equal(w.batch, p.batch[pi]) and torch.equal(w.offset, p.offset)
+        assert torch.equal(w.serialized_order[0], torch.arange(pi.numel()))          # rows ARE the first curve now
+        for k in range(len(ORDERS)):
+            codes = w.serialized_code[k][w.serialized_order[k]]
+            assert bool((codes[1:] >= codes[:-1]).all())
+            assert torch.equal(w.serialized_inverse[k][w.serialized_order[k]], torch.arange(pi.numel()))
+            assert torch.equal(w.serialized_code[k], p.serialized_code[k][pi])
+        w["feat"] = w.feat * 2.0
+        back = w.restore_order(p)
+        assert torch.allclose(back.feat, p.feat * 2.0)
+        probe = torch.randn_like(back.feat)
+        (back.feat * probe).sum().backward()
+        assert torch.allclose(p.feat.grad, 2.0 * probe)
