@@ -72,3 +72,66 @@ def test_ddp_gloo_world2():
         assert np.allclose(a, b, atol=1e-7)            # all-reduced gradients are identical on both ranks
         assert np.allclose(a, (la + lb) / 2, atol=1e-6)  # ... and equal the mean of the local gradients
     assert not np.allclose(bn0, bn1)                   # broadcast_buffers=False: BN statistics stay per rank
+
+
+def _engine_worker(rank, world, port, q):
+    """the ENGINE's PT-v3m1 (python layer + autograd wrappers; ops on the CPU stand-ins of tests/mock_backend.py) under
+    DistributedDataParallel over gloo: one process per rank, different scenes per rank, CE + Lovasz loss."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import mock_backend
+    from pointcept_amd import dp, synthetic
+    from pointcept_amd.point_transformer_v3 import PointTransformerV3
+    from pointcept_amd.segmentor import DefaultSegmentorV2
+
+    dev = torch.device("cpu")
+    dp.init_distributed(backend="gloo")
+    cfg = dict(in_channels=6, order=("z", "z-trans", "hilbert", "hilbert-trans"), enc_depths=(1, 1, 1, 1, 1), dec_depths=(1, 1, 1, 1),
+               enc_patch_size=(64,) * 5, dec_patch_size=(64,) * 4, drop_path=0.0, shuffle_orders=False)
+    with mock_backend.cpu_ops():
+        torch.manual_seed(0)                                       # identical initial weights on every rank
+        model = DefaultSegmentorV2(20, 64, PointTransformerV3(**cfg), criteria=("ce", "lovasz")).train()
+        ddp = dp.wrap_ddp(model, dev)
+        seeds = dp.scene_seeds(rank, 2, base_seed=700)
+        batch = synthetic.collate([synthetic.indoor_scene(s, 300 + 60 * rank) for s in seeds])
+        batch = {k: torch.from_numpy(v) for k, v in batch.items()}
+        torch.manual_seed(5)
+        loss = ddp(dict(batch))["loss"]
+        loss.backward()
+        dp.barrier(dev)
+        names = [n for n, _ in model.named_parameters()]
+        grads = [p.grad.numpy().copy() for _, p in model.named_parameters()]
+        # the same loss on a fresh, unwrapped copy: the local (un-averaged) gradient
+        torch.manual_seed(0)
+        ref = DefaultSegmentorV2(20, 64, PointTransformerV3(**cfg), criteria=("ce", "lovasz")).train()
+        torch.manual_seed(5)
+        ref(dict(batch))["loss"].backward()
+        local = [p.grad.numpy().copy() for _, p in ref.named_parameters()]
+    q.put((rank, float(loss.detach()), names, grads, local))
+    torch.distributed.destroy_process_group()
+
+
+def test_engine_model_under_ddp_gloo_world2():
+    """N > 1 path with the engine's own model and autograd Functions: the all-reduced gradients are identical on both
+    ranks and equal the mean of the two local gradients (scenes shard, the only exchange is the gradient all-reduce)."""
+    import numpy as np
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, l0, names, g0, loc0), (_, l1, _, g1, loc1) = res
+    assert l0 != l1                                                   # different scenes per rank
+    gmax = max(float(np.abs(a).max()) for a in g0)
+    for n, a, b, la, lb in zip(names, g0, g1, loc0, loc1):
+        assert np.allclose(a, b, atol=1e-7 * max(gmax, 1.0)), n        # identical after the all-reduce
+        assert np.allclose(a, (la + lb) / 2, rtol=2e-2, atol=2e-3 * gmax), n   # = mean of the local gradients (bf16 attention roundings)
