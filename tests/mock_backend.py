@@ -204,13 +204,21 @@ def column_sum(x):
     return x.float().sum(0)
 
 
+def voxel_keys(coord, grid_size):
+    from oracle import voxelize
+
+    v = voxelize.voxels(_np(coord), float(grid_size))
+    return (torch.from_numpy(v["grid_coord"]), torch.from_numpy(v["min_coord"].astype(np.int64)),
+            torch.from_numpy(v["key"].view(np.int64).copy()))
+
+
 _STANDINS = dict(
     coord_max=coord_max, serialize_encode=serialize_encode, sort_keys=sort_keys, patch_pad_maps=patch_pad_maps,
     attn_tables=attn_tables, pool_level_counts=pool_level_counts, pool_maps=pool_maps, pool_child_codes=pool_child_codes,
     gather_rows=gather_rows, segment_csr_fwd=segment_csr_fwd, segment_csr_bwd=segment_csr_bwd, HashTable=HashTable,
     rulebook_subm=rulebook_subm, rulebook_down=rulebook_down, spconv_fwd=spconv_fwd, spconv_wgrad=spconv_wgrad,
     attn_varlen_fwd=attn_varlen_fwd, attn_varlen_bwd=attn_varlen_bwd, cross_entropy_fwd=cross_entropy_fwd,
-    cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum,
+    cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum, voxel_keys=voxel_keys,
     layer_norm_supported=lambda c: False, batch_norm_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)
 
 

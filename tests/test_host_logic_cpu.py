@@ -269,3 +269,59 @@ def test_physically_sorted_working_copy_and_restore():
         probe = torch.randn_like(back.feat)
         (back.feat * probe).sum().backward()
         assert torch.allclose(p.feat.grad, 2.0 * probe)
+
+
+@pytest.mark.needs_reference
+def test_gridsample_python_layer_against_the_reference_transform():
+    """pointcept_amd.transform.GridSample (dict protocol, index_valid_keys bookkeeping, sampled_index, inverse / grid_coord /
+    min_coord / displacement, test mode) on the CPU stand-ins vs the reference transform (numpy) on the same cloud.  Which
+    point represents a voxel is random on both sides, so pick-dependent outputs are compared through the voxel they belong to."""
+    from oracle import ref_import
+    from pointcept_amd.transform import GridSample
+
+    tr = ref_import.load_transform()
+    rng = np.random.default_rng(31)
+    n = 3000
+    coord = ((rng.random((n, 3)) - 0.4) * 1.5).astype(np.float32)
+    normal = rng.standard_normal((n, 3)).astype(np.float32)
+    segment = rng.integers(0, 20, n)
+    sampled = np.sort(rng.choice(n, 40, replace=False))
+    kw = dict(grid_size=0.05, hash_type="fnv", return_inverse=True, return_grid_coord=True, return_min_coord=True,
+              return_displacement=True)    # (project_displacement with `normal` among the indexed keys raises in the reference itself)
+    keys = ["coord", "normal", "segment"]
+    np.random.seed(0)
+    ref = tr.GridSample(mode="train", **kw)(dict(coord=coord.copy(), normal=normal.copy(), segment=segment.copy(),
+                                                 sampled_index=sampled.copy(), index_valid_keys=list(keys)))
+    with mock_backend.cpu_ops():
+        torch.manual_seed(0)
+        eng = GridSample(mode="train", **kw)(dict(coord=torch.from_numpy(coord), normal=torch.from_numpy(normal),
+                                                  segment=torch.from_numpy(segment), sampled_index=torch.from_numpy(sampled),
+                                                  index_valid_keys=list(keys)))
+        parts = GridSample(mode="test", grid_size=0.05, return_grid_coord=True)(
+            dict(coord=torch.from_numpy(coord), segment=torch.from_numpy(segment), index_valid_keys=["coord", "segment"]))
+    ref_parts = tr.GridSample(mode="test", grid_size=0.05, hash_type="fnv", return_grid_coord=True)(
+        dict(coord=coord.copy(), segment=segment.copy(), index_valid_keys=["coord", "segment"]))
+    assert eng["index_valid_keys"] == ref["index_valid_keys"]
+    assert np.array_equal(eng["inverse"].numpy(), ref["inverse"])
+    assert np.allclose(eng["min_coord"].numpy(), ref["min_coord"])
+    # every voxel is represented; the labelled points (sampled_index) are all kept and re-indexed (transform.py:883-891)
+    n_vox = int(ref["inverse"].max()) + 1
+    for out in (ref, {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in eng.items()}):
+        vox_of_pick = set(map(tuple, out["grid_coord"]))
+        assert len(vox_of_pick) == n_vox
+        assert len(out["sampled_index"]) == len(sampled)
+        assert out["displacement"].shape == (out["coord"].shape[0], 3) and np.abs(out["displacement"]).max() <= 0.5
+    eng_np = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in eng.items()}
+    assert set(map(tuple, eng_np["coord"][eng_np["sampled_index"]])) == set(map(tuple, coord[sampled]))
+    assert set(map(tuple, ref["coord"][ref["sampled_index"]])) == set(map(tuple, coord[sampled]))
+    for out in (eng_np, ref):                                           # one pick per voxel + the labelled points not picked anyway
+        assert n_vox <= out["coord"].shape[0] <= n_vox + len(sampled)
+    # test mode: as many parts as the fullest voxel holds points; part i takes the (i mod count)-th point of every voxel
+    assert len(parts) == len(ref_parts)
+    for pe, pr in zip(parts, ref_parts):
+        assert pe["grid_coord"].shape == pr["grid_coord"].shape
+        assert set(map(tuple, pe["grid_coord"].numpy())) == set(map(tuple, pr["grid_coord"]))
+    seen = np.zeros(n, bool)
+    for pe in parts:
+        seen[pe["index"].numpy()] = True
+    assert seen.all()
