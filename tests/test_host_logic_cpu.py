@@ -192,10 +192,12 @@ def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
     from oracle import ref_import
 
     R = ref_import.load()                                        # reference files on oracle/shims.py
+    R_m2 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m2_sonata")
     names = ["spconv", "spconv.pytorch", "spconv.pytorch.modules", "flash_attn", "torch_scatter",
              "pointcept.models.utils", "pointcept.models.utils.structure", "pointcept.models.utils.misc",
              "pointcept.models.utils.serialization", "pointcept.models.modules", "pointcept.models.builder",
              "pointcept.models.point_transformer_v3.point_transformer_v3m1_base",
+             "pointcept.models.point_transformer_v3.point_transformer_v3m2_sonata",
              "pointcept.models.sparse_unet.spconv_unet_v1m1_base"]
     names += [k for k in list(sys.modules) if k.startswith("pointcept.models.utils.serialization.")]
     saved = {k: sys.modules.pop(k, None) for k in names}
@@ -203,8 +205,31 @@ def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
         compat.install(force=True)                               # engine operator API under the third-party names
         E = dict(ptv3=importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m1_base"),
                  spunet=importlib.import_module("pointcept.models.sparse_unet.spconv_unet_v1m1_base"))
+        E_m2 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m2_sonata")
         assert E["ptv3"] is not R["ptv3"] and E["ptv3"].spconv.__name__ == "pointcept_amd.spconv_api"
+        assert E_m2 is not R_m2 and E_m2.spconv.__name__ == "pointcept_amd.spconv_api"
         with mock_backend.cpu_ops():
+            # PT-v3m2 (Sonata; GridPooling / GridUnpooling, LayerScale): a SURVEY 8(f).2 model family the engine has no
+            # module-level port of -- its reference file runs through the operator-level API as is
+            m2cfg = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), dec_depths=(1, 1, 1, 1),
+                         enc_patch_size=(128,) * 5, dec_patch_size=(128,) * 4, drop_path=0.0, shuffle_orders=False,
+                         layer_scale=0.5)
+            mb = _batch([450, 200], seed0=520)
+            mb["grid_size"] = 0.02
+            torch.manual_seed(0)
+            m_a, m_b = R_m2.PointTransformerV3(**m2cfg), E_m2.PointTransformerV3(**m2cfg)
+            sd = om.deterministic_state_dict(m_a, 26)
+            m_a.load_state_dict(sd)
+            m_b.load_state_dict(sd)
+            fm = []
+            for net in (m_a, m_b):
+                net.train()
+                torch.manual_seed(9)
+                f = net({k: v for k, v in mb.items()}).feat
+                (f * torch.linspace(-1, 1, f.shape[1])).pow(2).mean().backward()
+                fm.append(f.detach())
+            assert _rel(fm[1], fm[0]) < 1e-3
+            _grad_check(m_b, m_a, 3e-2)
             cfg = dict(TINY, enable_flash=True)
             batch = _batch([500, 220], seed0=500)
             torch.manual_seed(0)
