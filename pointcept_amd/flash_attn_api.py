@@ -2,13 +2,41 @@
 (pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:208-214; also m2/m3, LitePT):
     flash_attn.flash_attn_varlen_qkvpacked_func(qkv[T,3,H,D] bf16, cu_seqlens int32[S+1], max_seqlen,
                                                 dropout_p=0.0, softmax_scale=None, causal=False) -> [T,H,D]
-backed by the gfx950 MFMA window-attention kernels (attention.hip).  D must be 16, max_seqlen <= 1024,
-dropout_p must be 0 (all reference PTv3 configs) -- anything else raises.
+head_dim 16 and max_seqlen <= 1024 (every PT-v3m1 / m2 configuration) run on the gfx950 MFMA window-attention kernels
+(attention.hip).  Other head dims (PT-v3m3 / LitePT use multiples of 3 for their 3-D RoPE) are served by
+PyTorch-ROCm's scaled_dot_product_attention on the GPU, one batched call per distinct sequence length -- a library
+path that exists so those model files run through the operator-level API, not a tuned one (it needs the sequence
+lengths on the host: one sync per call).  dropout_p must be 0 (all reference PTv3 configs); causal / alibi / softcap /
+local windows raise.
 """
 from __future__ import annotations
 
+import torch
+import torch.nn.functional as F
+
 from . import functional as PF
 from ._lib import PtcoreError
+
+
+def _require_gpu(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise PtcoreError("flash_attn_varlen_qkvpacked_func: qkv must live on a GPU (there is no CPU fallback)")
+
+
+def _sdpa_varlen(qkv: torch.Tensor, cu_seqlens: torch.Tensor, softmax_scale) -> torch.Tensor:
+    T, _, H, D = qkv.shape
+    cu = cu_seqlens.tolist()
+    out = torch.empty((T, H, D), dtype=qkv.dtype, device=qkv.device)
+    by_len = {}
+    for a, b in zip(cu[:-1], cu[1:]):
+        if b > a:
+            by_len.setdefault(b - a, []).append(a)
+    for length, starts in by_len.items():
+        rows = (torch.tensor(starts, device=qkv.device)[:, None] + torch.arange(length, device=qkv.device)[None]).reshape(-1)
+        blk = qkv[rows].reshape(len(starts), length, 3, H, D).permute(2, 0, 3, 1, 4)     # [3, n, H, L, D]
+        o = F.scaled_dot_product_attention(blk[0], blk[1], blk[2], dropout_p=0.0, is_causal=False, scale=softmax_scale)
+        out[rows] = o.permute(0, 2, 1, 3).reshape(-1, H, D).to(out.dtype)
+    return out
 
 
 def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
@@ -18,4 +46,11 @@ def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
         raise PtcoreError("flash_attn_varlen_qkvpacked_func: dropout_p > 0 is not implemented")
     if causal or alibi_slopes is not None or softcap != 0.0 or tuple(window_size) != (-1, -1) or return_attn_probs:
         raise PtcoreError("flash_attn_varlen_qkvpacked_func: only plain non-causal attention is implemented")
+    if qkv.dim() != 4 or qkv.shape[1] != 3:
+        raise PtcoreError(f"flash_attn_varlen_qkvpacked_func: qkv must be [T,3,H,D], got {tuple(qkv.shape)}")
+    _require_gpu(qkv)
+    if qkv.shape[3] != 16 or int(max_seqlen) > 1024:
+        if softmax_scale is None:
+            softmax_scale = qkv.shape[3] ** -0.5
+        return _sdpa_varlen(qkv, cu_seqlens, float(softmax_scale))
     return PF.attn_varlen_qkvpacked(qkv, cu_seqlens, max_seqlen, softmax_scale)

@@ -226,10 +226,11 @@ _STANDINS = dict(
 def cpu_ops():
     """pointcept_amd.ops -> the stand-ins above; the layers' "GPU only" guards -> no-ops.  Restored on exit."""
     from pointcept_amd import nn as PNN
-    from pointcept_amd import ops, spconv_api
+    from pointcept_amd import flash_attn_api, ops, spconv_api
 
     saved = {k: getattr(ops, k) for k in _STANDINS}
-    guards = [(PNN, "_require_gpu", PNN._require_gpu), (spconv_api, "_require_gpu", spconv_api._require_gpu)]
+    guards = [(PNN, "_require_gpu", PNN._require_gpu), (spconv_api, "_require_gpu", spconv_api._require_gpu),
+              (flash_attn_api, "_require_gpu", flash_attn_api._require_gpu)]
     try:
         for k, v in _STANDINS.items():
             setattr(ops, k, v)

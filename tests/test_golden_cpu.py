@@ -366,3 +366,8 @@ def test_ops_refuse_cpu_tensors():
         sp.SubMConv3d(8, 16, 1)(x)
     with pytest.raises(PtcoreError, match="no CPU fallback"):
         sp.SubMConv3d(8, 16, 3)(x)
+    from pointcept_amd.flash_attn_api import flash_attn_varlen_qkvpacked_func
+
+    for d in (16, 24):     # kernel path and library path alike
+        with pytest.raises(PtcoreError, match="no CPU fallback"):
+            flash_attn_varlen_qkvpacked_func(torch.zeros(8, 3, 2, d, dtype=torch.bfloat16), torch.tensor([0, 8], dtype=torch.int32), 8)

@@ -193,11 +193,13 @@ def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
 
     R = ref_import.load()                                        # reference files on oracle/shims.py
     R_m2 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m2_sonata")
+    R_m3 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m3_utonia")
     names = ["spconv", "spconv.pytorch", "spconv.pytorch.modules", "flash_attn", "torch_scatter",
              "pointcept.models.utils", "pointcept.models.utils.structure", "pointcept.models.utils.misc",
              "pointcept.models.utils.serialization", "pointcept.models.modules", "pointcept.models.builder",
              "pointcept.models.point_transformer_v3.point_transformer_v3m1_base",
              "pointcept.models.point_transformer_v3.point_transformer_v3m2_sonata",
+             "pointcept.models.point_transformer_v3.point_transformer_v3m3_utonia",
              "pointcept.models.sparse_unet.spconv_unet_v1m1_base"]
     names += [k for k in list(sys.modules) if k.startswith("pointcept.models.utils.serialization.")]
     saved = {k: sys.modules.pop(k, None) for k in names}
@@ -206,6 +208,7 @@ def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
         E = dict(ptv3=importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m1_base"),
                  spunet=importlib.import_module("pointcept.models.sparse_unet.spconv_unet_v1m1_base"))
         E_m2 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m2_sonata")
+        E_m3 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m3_utonia")
         assert E["ptv3"] is not R["ptv3"] and E["ptv3"].spconv.__name__ == "pointcept_amd.spconv_api"
         assert E_m2 is not R_m2 and E_m2.spconv.__name__ == "pointcept_amd.spconv_api"
         with mock_backend.cpu_ops():
@@ -230,6 +233,25 @@ def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
                 fm.append(f.detach())
             assert _rel(fm[1], fm[0]) < 1e-3
             _grad_check(m_b, m_a, 3e-2)
+            # PT-v3m3 (Utonia; 3-D RoPE inside attention needs head_dim % 3 == 0): flash_attn_varlen_qkvpacked_func then
+            # takes the library (SDPA) path of pointcept_amd/flash_attn_api.py instead of the head_dim-16 kernels
+            m3cfg = dict(m2cfg, enc_channels=(48, 96, 96, 192, 192), enc_num_head=(2, 4, 4, 8, 8), dec_channels=(48, 96, 96, 192),
+                         dec_num_head=(2, 4, 4, 8))
+            m3cfg.pop("layer_scale")
+            torch.manual_seed(0)
+            u_a, u_b = R_m3.PointTransformerV3(**m3cfg), E_m3.PointTransformerV3(**m3cfg)
+            sd = om.deterministic_state_dict(u_a, 27)
+            u_a.load_state_dict(sd)
+            u_b.load_state_dict(sd)
+            fu = []
+            for net in (u_a, u_b):
+                net.train()
+                torch.manual_seed(9)
+                f = net({k: v for k, v in mb.items()}).feat
+                (f * torch.linspace(-1, 1, f.shape[1])).pow(2).mean().backward()
+                fu.append(f.detach())
+            assert _rel(fu[1], fu[0]) < 2e-2             # bf16 SDPA vs the fp32-math stand-in
+            _grad_check(u_b, u_a, 6e-2)
             cfg = dict(TINY, enable_flash=True)
             batch = _batch([500, 220], seed0=500)
             torch.manual_seed(0)
