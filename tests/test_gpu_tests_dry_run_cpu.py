@@ -1,0 +1,32 @@
+"""-m "not gpu": the BODIES of the model-level GPU tests executed with device = cpu on the CPU stand-ins of the ops
+(tests/mock_backend.py).  Purpose: the python of those tests, their fixtures / goldens and the engine's host logic are
+exercised in every CPU run, so that a GPU session is never spent on a typo or a stale threshold; the kernels
+themselves are only tested when the same functions run with the real library (-m gpu).
+"""
+import pytest
+import torch
+
+import mock_backend
+
+MODEL_TESTS = ["test_ptv3_tiny_forward_matches_reference_golden_and_oracle", "test_ptv3_two_scenes_forward_backward_vs_oracle",
+               "test_ptv3_outdoor_depth12_four_channels", "test_ptv3_mix3d_duplicate_voxels",
+               "test_ptv3_dense_rpe_branch_matches_reference_golden_and_oracle", "test_ptv3_enable_flash_false_uses_the_shrunk_patch",
+               "test_ptv3_enc_mode_chain_matches_reference_golden_and_oracle"]
+SPUNET_TESTS = ["test_spunet_tiny_matches_reference_golden_and_oracle", "test_spunet_base_channels_single_scene_and_duplicates",
+                "test_spunet_enc_mode", "test_reference_style_model_file_runs_on_the_engine_through_compat"]
+
+
+@pytest.mark.parametrize("name", MODEL_TESTS)
+def test_gpu_model_test_bodies_on_cpu_standins(name):
+    import test_gpu_model as T
+
+    with mock_backend.cpu_ops():
+        getattr(T, name)(torch.device("cpu"))
+
+
+@pytest.mark.parametrize("name", SPUNET_TESTS)
+def test_gpu_spunet_test_bodies_on_cpu_standins(name):
+    import test_gpu_spunet as T
+
+    with mock_backend.cpu_ops():
+        getattr(T, name)(torch.device("cpu"))
