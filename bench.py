@@ -2,27 +2,37 @@
 """bench.py -- BASELINE.json metric on MI355X: scenes/sec of one training step (forward + backward
 + optimizer) of DefaultSegmentorV2(PT-v3m1) on ScanNet-shaped synthetic scenes.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: spawns its own N ranks, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[2] / SURVEY 8(d) config 3): PT-v3m1 base (46,166,272 parameters,
 4 serialization orders, patch 1024), batch 8 scenes x 102,400 voxels PER GPU (weak scaling),
-bf16 autocast, CrossEntropy loss (ignore_index -1), AdamW; N > 1: one process per GPU,
-DistributedDataParallel over RCCL (gradient all-reduce overlapped with backward).
+16-bit autocast (`--amp bf16` default; `--amp fp16` = the reference's recipe: fp16 autocast +
+torch.amp.GradScaler, engines/train.py:203-231), criteria CrossEntropy + Lovasz-Softmax as in
+configs/scannet/semseg-pt-v3m1-0-base.py:48-52 (`--ce-only` drops the Lovasz term), AdamW.
+N > 1: one process per GPU, DistributedDataParallel over RCCL through pointcept_amd/dp.py
+(gradient all-reduce overlapped with backward).  Started WITHOUT a torchrun environment and with
+--gpus N > 1, this file launches its own N workers (the role of pointcept/engines/launch.py:106-136)
+and refuses to report anything but n_gpus = N.
 Inputs are generated on the host, copied to HBM BEFORE the timed region and reused every step
 (rulebooks, sort, pad maps are rebuilt every step -- nothing is cached across steps).
 
 Prints ONE JSON line on rank 0 (contract of the driver) carrying
-  roofline     : the dominant kernel (serialized attention forward at the dec0/enc0 shapes),
-                 timed live with HIP events on the launch stream
-  cpu_baseline : the CPU oracle (oracle/ptv3_model.py, port of the reference model) timed on this
-                 box's host cores on a bounded sample (rank 0, N=1 only)
+  roofline        : the dominant kernel (serialized attention forward at the dec0/enc0 shapes),
+                    timed live with HIP events on the launch stream
+  roofline_gather : the gather-table convolution (CPE conv 64->64 at stage 0), HBM-bound by SURVEY 8(d)
+  secondary       : BASELINE configs[1] (SpUNet-v1m1, 8 x 100000 voxels) measured in the same process
+  cpu_baseline    : the CPU oracle (oracle/ptv3_model.py, port of the reference model) timed on this
+                    box's host cores on a bounded sample (rank 0, N=1 only)
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,11 +47,13 @@ PTV3_BASE = dict(  # configs/scannet/semseg-pt-v3m1-0-base.py:15-47
     enc_num_head=(2, 4, 8, 16, 32), enc_patch_size=(1024,) * 5, dec_depths=(2, 2, 2, 2), dec_channels=(64, 64, 128, 256),
     dec_num_head=(4, 4, 8, 16), dec_patch_size=(1024,) * 4, mlp_ratio=4, qkv_bias=True, drop_path=0.3,
     shuffle_orders=True, pre_norm=True, enable_flash=True, upcast_attention=False, upcast_softmax=False)
+SPUNET_BASE = dict(channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2))  # scannet/semseg-spunet-v1m1-0-base.py:16-17
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBPS = 8000.0          # HBM3E spec peak, same table (6.29 TB/s is what a float4 copy reaches)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -49,13 +61,66 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
     ap.add_argument("--points", type=int, default=102400, help="voxels per scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lovasz", action="store_true",
-                    help="criteria = CE + Lovasz-Softmax as in scannet/semseg-pt-v3m1-0-base.py:49-52 (default: CE only)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the SpUNet (configs[1]) measurement and the gather roofline")
+    ap.add_argument("--ce-only", action="store_true", help="criteria = CrossEntropy only (default: CE + Lovasz-Softmax, the config's criteria)")
+    ap.add_argument("--lovasz", action="store_true", help="(kept for old command lines; CE + Lovasz is the default)")
+    ap.add_argument("--amp", default="bf16", choices=["bf16", "fp16"],
+                    help="autocast dtype; fp16 adds torch.amp.GradScaler exactly as engines/train.py:203-231")
     ap.add_argument("--model", default="ptv3", choices=["ptv3", "spunet"],
                     help="ptv3 = BASELINE.json metric (configs[2]); spunet = configs[1] (SpUNet-v1m1, 100000 voxels/scene), "
                          "reported with its own metric name")
-    ap.add_argument("--cpu-sample-points", type=int, default=20480)
-    return ap.parse_args()
+    ap.add_argument("--cpu-sample-points", type=int, default=10240)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher / DP plumbing check without a GPU: gloo backend, CPU tensors, a small torch model "
+                         "(tests/test_dp_gloo.py); never a benchmark result")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# self-launch (pointcept/engines/launch.py:106-136 spawns one worker per GPU; here: re-exec under torch.distributed.run)
+# ----------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 without a torchrun environment: start N ranks of this file on this node, one per GPU."""
+    if not args.stub:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s); refusing to run fewer ranks than asked")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# rooflines of the two dominant kernels, timed live
+# ----------------------------------------------------------------------------------------------------------------
+def _time_launches(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()   # torch's current stream IS the stream ops.* launch on (_lib.stream_ptr)
+    for _ in range(iters):
+        fn()
+    stop.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(stop) / iters
+
+
+def _latest_profile(pattern):
+    # session tags run r01_a .. r01_z, r01_aa .., r02_a ..: order by (round, length, name)
+    fs = glob.glob(os.path.join(ROOT, "profiles", pattern))
+    return sorted(fs, key=lambda q: (os.path.basename(q)[:3], len(os.path.basename(q)), os.path.basename(q)))[-1] if fs else None
 
 
 def attention_roofline(device, scenes: int, points: int):
@@ -71,17 +136,7 @@ def attention_roofline(device, scenes: int, points: int):
     qkv = torch.randn(T, 3, H, D, generator=g).to(torch.bfloat16).to(device)
     cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=device)
     scale = D ** -0.5
-    for _ in range(3):
-        ops.attn_varlen_fwd(qkv, cu, L, scale)
-    iters = 10
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    start.record()
-    for _ in range(iters):
-        ops.attn_varlen_fwd(qkv, cu, L, scale)
-    stop.record()
-    torch.cuda.synchronize()
-    ms = start.elapsed_time(stop) / iters
+    ms = _time_launches(lambda: ops.attn_varlen_fwd(qkv, cu, L, scale))
     flops = 4.0 * L * L * D * n_seq * H
     achieved = flops / (ms * 1e-3) / 1e12
     out = {"kernel": "attn_fwd_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
@@ -91,11 +146,7 @@ def attention_roofline(device, scenes: int, points: int):
     # HBM bytes per launch of this kernel at this shape, from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on
     # gfx950 + WRITE_SIZE, separate --pmc runs: tools/gpu_session.sh roof); not re-measured inside bench.py
     try:
-        import glob
-
-        # session tags run r01_a .. r01_z, r01_aa ..: order by (length, name) to get the most recent one
-        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*attn_pmc.json")),
-                    key=lambda q: (len(os.path.basename(q)), os.path.basename(q)))[-1]
+        pm = _latest_profile("*attn_pmc.json")
         k = json.load(open(pm))["kernels"]["attn_fwd_kernel"]
         if (n_seq, H) == (800, 4):
             out["traffic"] = round(k["hbm_bytes"])
@@ -106,186 +157,273 @@ def attention_roofline(device, scenes: int, points: int):
     return out
 
 
-def cpu_baseline(sample_points: int, scene_points: int):
+def gather_roofline(device, batch):
+    """The gather-table convolution at its largest shape in the model: the CPE convolution of dec0 (SubM k=3,
+    64 -> 64 channels, N = all voxels of the batch, rows in curve order as the model keeps them).  HBM-bound by
+    SURVEY 8(d): algorithmic bytes = N C e (in) + N C e (out) + 4 kv N (dense gather table, the format this engine
+    reads) + kv C C e (weights); achieved = those bytes / launch time."""
+    from pointcept_amd import ops
+
+    gc, off = batch["grid_coord"], batch["offset"]
+    n = gc.shape[0]
+    counts = torch.diff(off, prepend=off.new_zeros(1))
+    b = torch.repeat_interleave(torch.arange(off.shape[0], device=device), counts)
+    depth = int(gc.max().item()).bit_length()
+    code = ops.serialize_encode(gc, b, depth, ("hilbert",))
+    order, _ = ops.sort_keys(code, 0, 3 * depth + max(1, (off.shape[0] - 1).bit_length()))
+    ind = torch.cat([b[:, None].int(), gc.int()], 1)[order[0]].contiguous()
+    nbr = ops.rulebook_subm(ind, 3, ops.HashTable(ind))
+    pairs = int((nbr >= 0).sum())
+    c, kv = 64, 27
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(n, c, generator=g).to(torch.bfloat16).to(device)
+    w = (torch.randn(c, kv, c, generator=g) * 0.05).to(torch.bfloat16).to(device)
+    bias = torch.zeros(c, device=device)
+    ms = _time_launches(lambda: ops.spconv_fwd(x, w, bias, nbr))
+    nbytes = n * c * 2 * 2 + 4 * kv * n + kv * c * c * 2
+    flops = 2.0 * pairs * c * c
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    out = {"kernel": "conv3_kernel (SubM k=3, 64->64, stage 0)", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "launch_ms": round(ms, 4),
+           "shape": {"n": n, "c_in": c, "c_out": c, "kv": kv, "pairs": pairs},
+           "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
+           "useful_tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+    try:
+        pm = _latest_profile("*conv_pmc_s0.json")
+        ks = json.load(open(pm))["kernels"]
+        k = next(v for kn, v in ks.items() if kn.startswith("conv3_kernel<bf16_t, 4, 2, 4, false>") and "hbm_bytes" in v)
+        out["traffic"] = round(k["hbm_bytes"])
+        out["traffic_source"] = os.path.relpath(pm, ROOT)
+    except Exception:
+        pass
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ----------------------------------------------------------------------------------------------------------------
+def cpu_baseline(sample_points: int, scene_points: int, iters: int, lovasz: bool):
     """The oracle port of the reference model (fp32, flash-branch semantics in fp32 math) on the host
-    cores: one forward+backward of the SAME PT-v3m1 base architecture on one scene of
-    `sample_points` voxels, scaled by points to scenes of `scene_points`."""
+    cores: 1 warm-up + `iters` timed forward+backward of the SAME PT-v3m1 base architecture + criteria on one scene
+    of `sample_points` voxels, scaled by voxels to scenes of `scene_points` (attention works on fixed 1024-patches
+    and every other op is per-voxel, so the cost is linear in voxels).  kind = "port": the reference's own model file
+    needs /root/reference and its un-vendored dependencies, neither exists on the GPU box."""
     from oracle import ptv3_model as om
     from pointcept_amd import synthetic
 
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    net = om.SegmentorV2(20, 64, om.PointTransformerV3(**{k: v for k, v in PTV3_BASE.items()
-                                                          if k not in ("enable_flash", "upcast_attention", "upcast_softmax")}))
+    kw = {k: v for k, v in PTV3_BASE.items() if k not in ("enable_flash", "upcast_attention", "upcast_softmax")}
+    net = om.SegmentorV2(20, 64, om.PointTransformerV3(**kw), criteria=("ce", "lovasz") if lovasz else ("ce",))
     net.train()
-    warm = {k: torch.from_numpy(v) for k, v in synthetic.collate([synthetic.indoor_scene(1, 2048)]).items()}
-    net(warm)["loss"].backward()
     batch = {k: torch.from_numpy(v) for k, v in synthetic.collate([synthetic.indoor_scene(0, sample_points)]).items()}
-    t0 = time.perf_counter()
-    net(batch)["loss"].backward()
-    dt = time.perf_counter() - t0
+    net(batch)["loss"].backward()  # warm-up (thread pools, allocator)
+    times = []
+    for _ in range(max(1, iters)):
+        net.zero_grad(set_to_none=True)
+        t0 = time.perf_counter()
+        net(batch)["loss"].backward()
+        times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
     n = int(batch["offset"][-1])
     value = (n / scene_points) / dt
     return {"value": round(value, 5), "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": f"1 scene x {n} voxels, 1 fwd+bwd of PT-v3m1 base fp32 on the CPU oracle in {dt:.2f} s, "
-                      f"scaled by voxels to {scene_points}-voxel scenes"}
+            "sample": f"1 scene x {n} voxels, 1 warm-up + {len(times)} timed fwd+bwd of PT-v3m1 base fp32 on the CPU oracle "
+                      f"(mean {dt:.2f} s, min {min(times):.2f} s), scaled by voxels to {scene_points}-voxel scenes; "
+                      "port of the reference model file (the file itself cannot travel to the GPU box)"}
 
 
-def main_spunet(args, rank, local_rank, world, device):
-    """BASELINE configs[1]: SpUNet-v1m1 (configs/scannet/semseg-spunet-v1m1-0-base.py:12-18), batch 8 x 100000 voxels,
-    CE loss, SGD(momentum 0.9, nesterov) as at :36, bf16 autocast (the reference runs fp16 AMP)."""
-    import torch.nn.functional as F
+# ----------------------------------------------------------------------------------------------------------------
+# the timed loop (shared by both models and the stub)
+# ----------------------------------------------------------------------------------------------------------------
+def timed_steps(step, steps, warmup, device):
+    from pointcept_amd import dp
 
-    from pointcept_amd import functional as PF
-    from pointcept_amd import synthetic
-    from pointcept_amd.sparse_unet import SpUNetBase
+    loss = None
+    for _ in range(warmup):
+        loss = step()
+    dp.barrier(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    dp.barrier(device)
+    dt = time.perf_counter() - t0
+    return dp.max_over_ranks(dt, device), loss
 
-    points = 100000 if args.points == 102400 else args.points
-    model = SpUNetBase(6, 20, channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2)).to(device).train()
-    n_params = sum(p.numel() for p in model.parameters())
-    step_model = model
-    if world > 1:
-        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False)
-    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
-    batch = synthetic.to_torch(synthetic.indoor_batch(args.batch, points, rank=rank), device)
+
+def make_step(step_model, opt, batch, amp: str, loss_of, device):
+    """One optimizer step as engines/train.py:185-246 runs it: zero_grad, autocast forward, (scaled) backward,
+    (unscale + inf check +) optimizer step.  fp16: GradScaler; bf16: no scaler (same exponent range as fp32)."""
+    dtype = torch.float16 if amp == "fp16" else torch.bfloat16
+    scaler = torch.amp.GradScaler(device.type) if amp == "fp16" else None
 
     def step():
         opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            logits = step_model(dict(batch))
-            loss = PF.cross_entropy(logits, batch["segment"], -1)
-        loss.backward()
-        opt.step()
+        with torch.autocast(device.type, dtype=dtype):
+            loss = loss_of(step_model(dict(batch)))
+        if scaler is not None:
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+        else:
+            loss.backward()
+            opt.step()
         return loss
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        loss = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "scenes/sec (fwd+bwd+optimizer) SpUNet-v1m1 ScanNet-semseg @ 100k voxels", "value": round(args.batch * world * args.steps / dt, 4),
-            "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"SpUNet-v1m1 (39.2M params) + CE, fwd+bwd+SGD, {args.batch} scenes x {points} voxels per GPU",
-                       "global_batch": args.batch * world, "params": n_params, "parallelism": f"dp{world}",
-                       "final_loss": round(float(loss.detach()), 4)}}), flush=True)
-    if world > 1:
-        torch.distributed.barrier(device_ids=[local_rank])
-        torch.distributed.destroy_process_group()
+    return step
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
-
+def build_ptv3(args, device, rank):
     from pointcept_amd import synthetic
     from pointcept_amd.point_transformer_v3 import PointTransformerV3
     from pointcept_amd.segmentor import DefaultSegmentorV2
 
-    torch.manual_seed(1234)  # identical initial weights on every rank
-    if args.model == "spunet":
-        return main_spunet(args, rank, local_rank, world, device)
-    criteria = ("ce", "lovasz") if args.lovasz else ("ce",)
+    criteria = ("ce",) if args.ce_only else ("ce", "lovasz")
     model = DefaultSegmentorV2(20, 64, PointTransformerV3(**PTV3_BASE), criteria=criteria).to(device).train()
-    n_params = sum(p.numel() for p in model.parameters())
-    step_model = model
-    if world > 1:
-        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False)
     # AdamW of scannet/semseg-pt-v3m1-0-base.py:56; fused=True = the same update in one multi-tensor kernel per group
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
-
     batch = synthetic.to_torch(synthetic.indoor_batch(args.batch, args.points, rank=rank), device)
-    n_points = int(batch["offset"][-1])
+    return model, opt, batch, (lambda out: out["loss"])
+
+
+def build_spunet(args, device, rank, points):
+    from pointcept_amd import functional as PF
+    from pointcept_amd import synthetic
+    from pointcept_amd.sparse_unet import SpUNetBase
+
+    model = SpUNetBase(6, 20, **SPUNET_BASE).to(device).train()
+    # SGD of scannet/semseg-spunet-v1m1-0-base.py:36
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    batch = synthetic.to_torch(synthetic.indoor_batch(args.batch, points, rank=rank), device)
+    seg = batch["segment"]
+    return model, opt, batch, (lambda logits: PF.cross_entropy(logits, seg, -1))
+
+
+def build_stub(args, device, rank):
+    """CPU stand-in for the launcher test: the DP plumbing is the subject, not the model."""
+    from pointcept_amd import dp
+
+    model = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.BatchNorm1d(32), torch.nn.GELU(), torch.nn.Linear(32, 20)).to(device)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01)
+    g = torch.Generator().manual_seed(dp.scene_seeds(rank, 1)[0])
+    n = 256 * args.batch
+    batch = {"feat": torch.randn(n, 6, generator=g), "segment": torch.randint(0, 20, (n,), generator=g)}
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, d):
+            return self.m(d["feat"])
+
+    seg = batch["segment"]
+    return Wrap(model), opt, batch, (lambda logits: torch.nn.functional.cross_entropy(logits.float(), seg))
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    from pointcept_amd import dp
+
+    rank, local_rank, world = dp.env_rank()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a different GPU count than asked")
+    if args.stub:
+        device = torch.device("cpu")
+        dp.init_distributed(backend="gloo")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        dp.init_distributed(backend="nccl", device=device)
+    ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    if ranks != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the process group has {ranks} rank(s)")
+
+    torch.manual_seed(1234)  # identical initial weights on every rank
+    points = args.points
+    if args.stub:
+        model, opt, batch, loss_of = build_stub(args, device, rank)
+        metric, workload, amp = "stub steps (launcher / DP plumbing check, not a benchmark)", "stub", "bf16"
+    elif args.model == "spunet":
+        points = 100000 if args.points == 102400 else args.points
+        model, opt, batch, loss_of = build_spunet(args, device, rank, points)
+        metric = "scenes/sec (fwd+bwd+optimizer) SpUNet-v1m1 ScanNet-semseg @ 100k voxels"
+        workload = f"SpUNet-v1m1 (39.2M params) + CE, fwd+bwd+SGD, {args.batch} scenes x {points} voxels per GPU"
+        amp = args.amp
+    else:
+        model, opt, batch, loss_of = build_ptv3(args, device, rank)
+        metric = "scenes/sec (fwd+bwd+optimizer) PTv3 ScanNet-semseg @ ~100k pts"
+        workload = ("PT-v3m1 base (46.2M params) + seg head + " + ("CE" if args.ce_only else "CE + Lovasz") + ", fwd+bwd+AdamW, "
+                    f"{args.batch} scenes x {points} voxels per GPU, patch 1024, 4 orders")
+        amp = args.amp
+    n_params = sum(p.numel() for p in model.parameters())
+    step_model = dp.wrap_ddp(model, device)   # identity at world 1
     torch.manual_seed(100 + rank)  # order shuffles / DropPath differ per rank, as in training
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            loss = step_model(dict(batch))["loss"]
-        loss.backward()
-        opt.step()
-        return loss
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        loss = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    step = make_step(step_model, opt, batch, amp, loss_of, device)
+    dt, loss = timed_steps(step, args.steps, args.warmup, device)
     last_loss = float(loss.detach())
 
     if rank == 0:
-        scenes_total = args.batch * world * args.steps
         out = {
-            "metric": "scenes/sec (fwd+bwd+optimizer) PTv3 ScanNet-semseg @ ~100k pts",
-            "value": round(scenes_total / dt, 4),
+            "metric": metric,
+            "value": round(args.batch * world * args.steps / dt, 4),
             "unit": "scenes/s",
             "n_gpus": world,
+            "rccl_ranks": ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": amp,
             "data": "synthetic",
-            "config": {"workload": "PT-v3m1 base (46.2M params) + seg head + " + ("CE + Lovasz" if args.lovasz else "CE") + ", fwd+bwd+AdamW, "
-                                   f"{args.batch} scenes x {args.points} voxels per GPU, patch 1024, 4 orders",
-                       "global_batch": args.batch * world, "points_per_gpu": n_points, "parallelism": f"dp{world}",
-                       "params": n_params, "loss": "CrossEntropy(ignore_index=-1)" + (" + LovaszSoftmax" if args.lovasz else ""), "final_loss": round(last_loss, 4)},
+            "config": {"workload": workload, "global_batch": args.batch * world, "parallelism": f"dp{world}", "params": n_params,
+                       "amp": ("fp16 autocast + GradScaler" if amp == "fp16" else "bf16 autocast"), "final_loss": round(last_loss, 4)},
         }
-        try:
-            out["roofline"] = attention_roofline(device, args.batch, args.points)
-        except Exception as e:  # never lose the headline number to a diagnostics failure
-            out["roofline"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.stub and args.model == "ptv3":
+            out["config"]["points_per_gpu"] = int(batch["offset"][-1])
+            out["config"]["loss"] = "CrossEntropy(ignore_index=-1)" + ("" if args.ce_only else " + LovaszSoftmax")
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_sample_points, args.points)
+                out["roofline"] = attention_roofline(device, args.batch, args.points)
+            except Exception as e:  # never lose the headline number to a diagnostics failure
+                out["roofline"] = {"error": repr(e)}
+            if not args.no_secondary:
+                try:
+                    out["roofline_gather"] = gather_roofline(device, batch)
+                except Exception as e:
+                    out["roofline_gather"] = {"error": repr(e)}
+        if not args.stub and args.model == "ptv3" and world == 1 and not args.no_secondary:
+            try:
+                del step, step_model, model, opt, batch
+                torch.cuda.empty_cache()
+                torch.manual_seed(1234)
+                m2, o2, b2, l2 = build_spunet(args, device, rank, 100000)
+                st2 = make_step(m2, o2, b2, amp, l2, device)
+                k2 = max(3, min(args.steps, 10))
+                dt2, loss2 = timed_steps(st2, k2, 2, device)
+                out["secondary"] = {"metric": "scenes/sec (fwd+bwd+optimizer) SpUNet-v1m1 ScanNet-semseg @ 100k voxels (BASELINE configs[1])",
+                                    "value": round(args.batch * k2 / dt2, 4), "unit": "scenes/s", "ms_per_step": round(dt2 / k2 * 1e3, 3),
+                                    "steps": k2, "warmup": 2, "final_loss": round(float(loss2.detach()), 4),
+                                    "workload": f"SpUNet-v1m1 (39.2M params) + CE, fwd+bwd+SGD, {args.batch} scenes x 100000 voxels"}
+                del st2, m2, o2, b2
+            except Exception as e:
+                out["secondary"] = {"error": repr(e)}
+        if not args.stub and args.model == "ptv3" and world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_sample_points, args.points, args.cpu_iters, not args.ce_only)
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.barrier(device_ids=[local_rank])
+        dp.barrier(device)
         torch.distributed.destroy_process_group()
 
 

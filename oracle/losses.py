@@ -54,3 +54,30 @@ def lovasz_softmax(logits: np.ndarray, labels: np.ndarray, ignore_index: int = -
     dz = p * (gp - (gp * p).sum(axis=1, keepdims=True))
     dlogits[valid] = dz
     return float(np.mean(losses)), dlogits
+
+
+def lovasz_softmax_torch(logits, labels, ignore_index: int = -1):
+    """Same criterion as a differentiable torch expression (fp32/fp64 follows `logits`), for the oracle MODEL's loss
+    (SegmentorV2(criteria=("ce", "lovasz"))): lovasz.py:118-146 / :22-33 / :149-166 line by line, sort permutation
+    constant under autograd as in the reference."""
+    import torch
+
+    valid = labels != ignore_index
+    probas = torch.softmax(logits.float() if logits.dtype in (torch.float16, torch.bfloat16) else logits, dim=1)[valid]
+    lab = labels[valid]
+    if probas.numel() == 0:
+        return (probas * 0.0).sum()
+    losses = []
+    for c in lab.unique():
+        fg = (lab == c).to(probas.dtype)
+        errors = (fg - probas[:, c]).abs()
+        errors_sorted, perm = torch.sort(errors, 0, descending=True)
+        fg_sorted = fg[perm]
+        gts = fg_sorted.sum()
+        inter = gts - fg_sorted.cumsum(0)
+        union = gts + (1.0 - fg_sorted).cumsum(0)
+        jac = 1.0 - inter / union
+        if jac.numel() > 1:
+            jac = torch.cat([jac[:1], jac[1:] - jac[:-1]])
+        losses.append(torch.dot(errors_sorted, jac))
+    return torch.stack(losses).mean()

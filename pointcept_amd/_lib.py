@@ -102,10 +102,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        from . import build as _build
+    # build() is mtime-cached (a no-op when nothing changed) and returns the prebuilt library where there is no
+    # hipcc (the GPU box): a stale .so can never meet newer ctypes signatures silently
+    from . import build as _build
 
-        _build.build()
+    _build.build()
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # fail loudly: no fallback path exists
@@ -114,6 +115,18 @@ def lib():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # ptc_version carries a hash of include/ptcore.h as it was when the library was compiled: compare it with the
+    # header next to this binding (present in the repo; absent in a stripped install -> nothing to compare)
+    ver = L.ptc_version().decode()
+    hdr = os.path.join(HERE, "..", "include", "ptcore.h")
+    if os.path.exists(hdr) and "abi " in ver:
+        import zlib
+
+        want = f"{zlib.crc32(open(hdr, 'rb').read()) & 0xffffffff:08x}"
+        got = ver.split("abi ")[1].split(")")[0].split()[0]
+        if got != want:
+            raise PtcoreError(f"{LIB_PATH} was built against another include/ptcore.h (abi {got}, header {want}): rebuild "
+                              "(python -m pointcept_amd.build --force)")
     _lib = L
     return L
 

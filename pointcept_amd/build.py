@@ -94,7 +94,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if src.endswith(".hip"):
                 cmd = [HIPCC] + HIP_FLAGS + ["-c", sp, "-o", op]
             else:
-                cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-x", "c++", "-c", sp, "-o", op]
+                import zlib
+
+                abi = f"{zlib.crc32(open(os.path.join(HERE, '..', 'include', 'ptcore.h'), 'rb').read()) & 0xffffffff:08x}"
+                cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", f'-DPTC_ABI_HASH="{abi}"', "-x", "c++", "-c", sp, "-o", op]
             jobs.append(cmd)
     if jobs:
         if verbose:

@@ -203,6 +203,20 @@ __host__ __device__ __forceinline__ int at_split(int n_units, int lp_max) {
   return qs;
 }
 
+// A sequence longer than max_seqlen (cu_seqlens built for a larger patch than the caller's max_seqlen, or a caller
+// of the flash_attn API passing inconsistent arguments) would overrun the LDS images, which are sized from
+// max_seqlen.  Such units write NaN to every output row they own (16 bf16 per row, optionally the fp32 side vector) and
+// return: the error is loud in the loss, memory stays intact.
+__device__ __forceinline__ void at_poison_rows(uint16_t* rows, int64_t row_stride, int L, float* side) {
+  const uint4 nan4 = {0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u};
+  for (int q = threadIdx.x; q < L; q += AT_THREADS) {
+    uint4* o = reinterpret_cast<uint4*>(rows + (int64_t)q * row_stride);
+    o[0] = nan4;
+    o[1] = nan4;
+    if (side) side[q] = __uint_as_float(0x7FC00000u);
+  }
+}
+
 // ================================================================================================
 // forward
 // ================================================================================================
@@ -218,6 +232,10 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
+  if (Lp > lp_max) {   // sequence longer than the caller's max_seqlen: LDS is sized from max_seqlen -- poison, never overrun
+    if (part == 0) at_poison_rows(out + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, lse + (int64_t)head * total + a);
+    return;
+  }
   const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
   if (t_lo >= n_tiles) return;
   const int pitch = lp_max + 8;
@@ -411,6 +429,10 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
+  if (Lp > lp_max) {   // see attn_fwd_kernel
+    if (part == 0) at_poison_rows(dqkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, nullptr);
+    return;
+  }
   const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
   if (t_lo >= n_tiles) return;
   unsigned char* Vsm = smem;
@@ -489,6 +511,13 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
+  if (Lp > lp_max) {   // see attn_fwd_kernel
+    if (part == 0) {
+      at_poison_rows(dqkv + qkv_off(a, 1, H, head), (int64_t)3 * H * 16, L, nullptr);
+      at_poison_rows(dqkv + qkv_off(a, 2, H, head), (int64_t)3 * H * 16, L, nullptr);
+    }
+    return;
+  }
   const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
   if (t_lo >= n_tiles) return;
   unsigned char* Qsm = smem;
@@ -598,6 +627,10 @@ attn_bwd_fused_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
+  if (Lp > lp_max) {   // see attn_fwd_kernel
+    for (int j = 0; j < 3; ++j) at_poison_rows(dqkv + qkv_off(a, j, H, head), (int64_t)3 * H * 16, L, nullptr);
+    return;
+  }
   unsigned char* Qsm = smem;
   unsigned char* dOsm = smem + (size_t)lp_max * 32;
   uint2* aux = reinterpret_cast<uint2*>(smem + (size_t)lp_max * 64);

@@ -13,4 +13,8 @@ void ptc_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ptc_last_error(void) { return g_err; }
-extern "C" const char* ptc_version(void) { return "ptcore 0.1 (gfx950)"; }
+#ifndef PTC_ABI_HASH
+#define PTC_ABI_HASH "unknown"
+#endif
+// "abi <crc32 of include/ptcore.h at build time>": pointcept_amd/_lib.py compares it with the header it binds
+extern "C" const char* ptc_version(void) { return "ptcore 0.2 (gfx950, abi " PTC_ABI_HASH ")"; }

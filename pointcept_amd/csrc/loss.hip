@@ -14,25 +14,29 @@
 template <typename CoordT>
 __global__ void __launch_bounds__(256)
 coord_max_kernel(const CoordT* __restrict__ gc, int64_t n, unsigned long long* __restrict__ out3) {
-  long long m0 = 0, m1 = 0, m2 = 0;
+  // the maximum is taken over the UNSIGNED (sign-extended) values: a negative coordinate is larger than every legal
+  // one, so it surfaces as a negative int64 in out3 and the host-side range check (ops.check_coord_range) rejects it
+  // -- the voxel hash packs coordinates into 18-bit fields and would otherwise alias it silently
+  unsigned long long m0 = 0, m1 = 0, m2 = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const long long x = (long long)gc[3 * i], y = (long long)gc[3 * i + 1], z = (long long)gc[3 * i + 2];
+    const unsigned long long x = (unsigned long long)(long long)gc[3 * i], y = (unsigned long long)(long long)gc[3 * i + 1],
+                             z = (unsigned long long)(long long)gc[3 * i + 2];
     m0 = x > m0 ? x : m0;
     m1 = y > m1 ? y : m1;
     m2 = z > m2 ? z : m2;
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
-    const long long a = __shfl_xor(m0, o, 64), b = __shfl_xor(m1, o, 64), c = __shfl_xor(m2, o, 64);
+    const unsigned long long a = __shfl_xor(m0, o, 64), b = __shfl_xor(m1, o, 64), c = __shfl_xor(m2, o, 64);
     m0 = a > m0 ? a : m0;
     m1 = b > m1 ? b : m1;
     m2 = c > m2 ? c : m2;
   }
   if (ptc_lane() == 0) {  // integer max: order-independent, exact
-    atomicMax(out3 + 0, (unsigned long long)m0);
-    atomicMax(out3 + 1, (unsigned long long)m1);
-    atomicMax(out3 + 2, (unsigned long long)m2);
+    atomicMax(out3 + 0, m0);
+    atomicMax(out3 + 1, m1);
+    atomicMax(out3 + 2, m2);
   }
 }
 

@@ -195,7 +195,10 @@ pool_fill_kernel(const int64_t* __restrict__ order0, const int64_t* __restrict__
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
     const int64_t p = order0[r];
     const int64_t c = cluster[p];
-    if (r == 0 || cluster[order0[r - 1]] != c) {
+    // c < n_cluster: n_cluster may come from the host-side prefetch of the level sizes rather than from the count
+    // kernel that numbered `cluster`; a stale value must not become an out-of-bounds write (the maps are then wrong
+    // -- caught by the bit-exact tests -- but memory stays intact)
+    if ((r == 0 || cluster[order0[r - 1]] != c) && c >= 0 && c < n_cluster) {
       idx_ptr[c] = r;   // ptv3m1:394
       head[c] = p;      // ptv3m1:396 (any member: all share code>>shift, grid_coord>>depth, batch)
     }

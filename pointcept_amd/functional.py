@@ -10,6 +10,7 @@ uses floating-point atomics and every result is bit-reproducible run to run:
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -29,33 +30,62 @@ from ._lib import PtcoreError
 # one low-precision shadow per weight storage and, at the first miss after the optimizer step (version
 # counters moved), refreshes ALL shadows with a single torch._foreach_copy_.
 class _CastCache:
-    def __init__(self):
-        self.entries = {}   # (data_ptr, numel, dtype) -> [src alias (flat), shadow (flat), version]
+    """Entries die with the parameter they shadow (weak reference on the owning tensor: nothing here pins a discarded
+    model's storage), are validated by the tensor's version counter, and can be dropped explicitly:
+    `invalidate_weight_casts()` after writes that do not move the counter (`p.data.copy_()`, `p.data.mul_()` -- EMA /
+    weight clipping code written against `.data`; optimizers, `load_state_dict` and `copy_` under `no_grad` do move it).
+    A refresh between the forward and the backward of one live graph raises autograd's saved-tensor version error, as
+    modifying the weight itself does in stock PyTorch."""
+
+    def __init__(self, cuda_only: bool = True):
+        self.entries = {}   # (data_ptr, numel, dtype) -> [weakref(owner), shadow (flat), version]
+        self.cuda_only = cuda_only   # False only in the CPU unit test of this class
+
+    def invalidate(self) -> None:
+        self.entries.clear()
 
     def get(self, w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
         if w.dtype == dt:
             return w
-        if not w.is_contiguous() or not w.is_cuda:
+        owner = w._base if w._base is not None else w     # conv weights arrive as views of the Parameter
+        if not w.is_contiguous() or (self.cuda_only and not w.is_cuda) or owner.numel() != w.numel() or not owner.is_contiguous():
             return w.to(dt)
         key = (w.data_ptr(), w.numel(), dt)
         e = self.entries.get(key)
-        if e is not None and e[2] == w._version:
+        if e is not None and e[0]() is not owner:          # address reused by another tensor
+            e = None
+        if e is not None and e[2] == owner._version:
             return e[1].view(w.shape)
         if e is None:
-            if len(self.entries) > 4096:
-                self.entries.clear()
-            src = w.detach().reshape(-1)
-            e = [src, torch.empty(w.numel(), dtype=dt, device=w.device), -1]
+            entries = self.entries
+
+            def _drop(_ref, key=key, entries=entries):
+                cur = entries.get(key)
+                if cur is not None and cur[0] is _ref:
+                    del entries[key]
+
+            e = [weakref.ref(owner, _drop), torch.empty(w.numel(), dtype=dt, device=w.device), -1]
             self.entries[key] = e
-        stale = [x for x in self.entries.values() if x[2] != x[0]._version]
+        # one multi-tensor copy refreshes every stale shadow (the first miss after an optimizer step)
+        stale, srcs = [], []
+        for x in list(self.entries.values()):
+            o = x[0]()
+            if o is not None and x[2] != o._version:
+                stale.append(x)
+                srcs.append(o.detach().reshape(-1))
         with torch.no_grad():
-            torch._foreach_copy_([x[1] for x in stale], [x[0] for x in stale])
-        for x in stale:
-            x[2] = x[0]._version
+            torch._foreach_copy_([x[1] for x in stale], srcs)
+        for x, o in zip(stale, srcs):
+            x[2] = x[0]()._version
         return e[1].view(w.shape)
 
 
 _cast_cache = _CastCache()
+
+
+def invalidate_weight_casts() -> None:
+    """Drop every low-precision weight shadow (call after `.data` writes to parameters, see _CastCache)."""
+    _cast_cache.invalidate()
 
 
 def _autocast_on() -> bool:

@@ -283,6 +283,22 @@ VOX_MAX = 1 << 18
 BATCH_MAX = 1023
 
 
+def check_coord_range(coord_max_host, batch_size: int, spatial_shape=None) -> None:
+    """The voxel hash packs (batch, x, y, z) into 10 + 3 x 18 bits (csrc/voxel_hash.h): coordinates outside [0, 2^18) --
+    ptc_coord_max reports a negative coordinate as a negative maximum -- or outside the declared spatial_shape, or more
+    than BATCH_MAX batch items, would alias other voxels' keys and give silently wrong neighbour maps.  Host integers
+    only (they ride in the one host sync of the forward): no device work."""
+    for a, m in enumerate(coord_max_host):
+        m = int(m)
+        if m < 0 or m >= VOX_MAX:
+            raise PtcoreError(f"grid_coord axis {a}: coordinates must lie in [0, {VOX_MAX}) (max reported {m}; negative = a negative "
+                              "coordinate in the input)")
+        if spatial_shape is not None and m >= int(spatial_shape[a]):
+            raise PtcoreError(f"grid_coord axis {a}: maximum {m} outside the declared spatial_shape {list(spatial_shape)}")
+    if int(batch_size) > BATCH_MAX:
+        raise PtcoreError(f"batch size {batch_size} exceeds the {BATCH_MAX} batch items the voxel key can hold")
+
+
 class HashTable:
     def __init__(self, indices: torch.Tensor):
         require_cuda(indices)

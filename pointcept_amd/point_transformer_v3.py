@@ -245,6 +245,14 @@ class SerializedAttention(PointModule):
             _, offset_host = point._host_facts()
             pad, unpad, cu, dup = ops.patch_pad_maps(point.offset, offset_host, self.patch_size)
             point["pad"], point["unpad"], point["cu_seqlens_key"], point["_ptc_dup"] = pad, unpad, cu, dup
+            point["_ptc_pad_patch"] = self.patch_size
+        elif point.get("_ptc_pad_patch", self.patch_size) != self.patch_size:
+            # The reference caches the maps under fixed keys whatever the patch size (ptv3m1:119-124) and then hands
+            # flash-attn cu_seqlens of longer windows than max_seqlen = K: rows past K are never written there.  The
+            # engine's kernels size their LDS from max_seqlen, so refuse instead of computing garbage.
+            raise ops.PtcoreError(
+                f"pad / cu_seqlens on this Point were built for patch size {point['_ptc_pad_patch']} but this attention uses "
+                f"{self.patch_size}: enc_patch_size and dec_patch_size of one stage must agree (reference quirk, ptv3m1:119-124)")
         return point["pad"], point["unpad"], point["cu_seqlens_key"]
 
     @torch.no_grad()

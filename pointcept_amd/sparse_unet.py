@@ -124,6 +124,7 @@ class SpUNetBase(nn.Module):
         rep = ops.rulebook_subm(indices, 1, table)[0]        # lowest row holding each row's voxel
         n_dup = (rep != torch.arange(n, device=rep.device, dtype=rep.dtype)).sum().reshape(1).to(torch.int64)
         host = torch.cat([ops.coord_max(grid_coord), n_dup]).tolist()
+        ops.check_coord_range(host[:3], offset.numel())
         sparse_shape = [int(m) + 96 for m in host[:3]]  # spconv_unet_v1m1_base.py:250 (one host sync)
         x = spconv.SparseConvTensor(features=feat, indices=indices, spatial_shape=sparse_shape, batch_size=int(offset.numel()))
         x.indice_dict["__hash__"] = table

@@ -41,6 +41,9 @@ class SparseConvTensor:
         self.indices = indices
         self.spatial_shape = list(spatial_shape)
         self.batch_size = int(batch_size)
+        if max(int(v) for v in self.spatial_shape) > ops.VOX_MAX or self.batch_size > ops.BATCH_MAX:
+            raise PtcoreError(f"spatial_shape {self.spatial_shape} / batch_size {self.batch_size}: the voxel key holds "
+                              f"{ops.VOX_MAX} cells per axis and {ops.BATCH_MAX} batch items")
         self.indice_dict = {} if indice_dict is None else indice_dict
 
     def replace_feature(self, feature):

@@ -111,6 +111,7 @@ class Point(_RefPoint if _RefPoint is not None else AttrDict):
                 n_dup = cmax.new_zeros(1)
             packed = torch.cat([cmax, n_dup.to(torch.int64), self.offset.to(torch.int64)])
             host = packed.tolist()  # the single host sync (reference: structure.py:74,138,145 + ptv3m1:142-164)
+            ops.check_coord_range(host[:3], self.offset.numel())
             self["_ptc_coord_max"] = host[:3]
             self["_ptc_n_dup"] = int(host[3])
             self["_ptc_offset_host"] = host[4:]

@@ -135,3 +135,45 @@ def test_engine_model_under_ddp_gloo_world2():
     for n, a, b, la, lb in zip(names, g0, g1, loc0, loc1):
         assert np.allclose(a, b, atol=1e-7 * max(gmax, 1.0)), n        # identical after the all-reduce
         assert np.allclose(a, (la + lb) / 2, rtol=2e-2, atol=2e-3 * gmax), n   # = mean of the local gradients (bf16 attention roundings)
+
+
+def _run_bench(*argv, env_extra=None, timeout=300):
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_bench_self_launch_gloo_stub():
+    """`python bench.py --gpus 2` WITHOUT a torchrun environment spawns its own two ranks (the role of
+    pointcept/engines/launch.py:106-136); rank 0 prints ONE JSON line with n_gpus = 2 = the size of the process group.
+    --stub: gloo + CPU tensors + a small torch model through the SAME dp.py / timing / JSON code as the GPU run."""
+    import json
+
+    r = _run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--stub")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak"
+    assert out["value"] > 0 and abs(out["value"] - 4 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-2 * out["value"]
+
+
+def test_bench_refuses_fewer_gpus_than_asked():
+    """no GPU in this container: --gpus 2 must fail loudly, never print an n_gpus = 1 line"""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert "refusing" in (r.stderr + r.stdout)
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+    # a torchrun environment whose world size disagrees with --gpus is refused as well
+    r = _run_bench("--gpus", "4", "--steps", "1", "--warmup", "0", "--stub",
+                   env_extra=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29512"))
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

@@ -372,3 +372,32 @@ def test_gridsample_python_layer_against_the_reference_transform():
     for pe in parts:
         seen[pe["index"].numpy()] = True
     assert seen.all()
+
+
+def test_cast_cache_lifetime_and_invalidation():
+    """functional._CastCache: shadows die with their parameter, follow the version counter, survive address
+    reuse, and `.data` writes (which do not move the counter) are covered by invalidate_weight_casts()."""
+    import gc
+
+    from pointcept_amd import functional as PF
+
+    c = PF._CastCache(cuda_only=False)
+    p = torch.nn.Parameter(torch.randn(4, 27, 8))
+    v = p.view(4, 27, 8)
+    a = c.get(v, torch.bfloat16)
+    assert a.dtype == torch.bfloat16 and torch.equal(a, p.detach().to(torch.bfloat16)) and len(c.entries) == 1
+    assert c.get(p.view(4, 27, 8), torch.bfloat16).data_ptr() == a.data_ptr()      # a fresh view object hits the same entry
+    with torch.no_grad():
+        p.mul_(2.0)                                                                  # optimizer-style update: version moves
+    assert torch.equal(c.get(p, torch.bfloat16), p.detach().to(torch.bfloat16))
+    p.data.mul_(0.5)                                                                 # .data write: version does NOT move
+    assert not torch.equal(c.get(p, torch.bfloat16), p.detach().to(torch.bfloat16))  # documented limitation ...
+    c.invalidate()
+    assert torch.equal(c.get(p, torch.bfloat16), p.detach().to(torch.bfloat16))      # ... and its remedy
+    q = torch.nn.Parameter(torch.randn(16, 16))
+    c.get(q, torch.bfloat16)
+    assert len(c.entries) == 2
+    del p, v, a
+    gc.collect()
+    assert len(c.entries) == 1                                                       # the entry died with its parameter
+    assert c.get(q[:8], torch.bfloat16).shape == (8, 16) and len(c.entries) == 1     # partial views are never cached

@@ -39,6 +39,23 @@ for sec in "$@"; do
           cd $R; python tools/pmc_summary.py --stats $O/${TAG}_roof_stats --pmc $O/${TAG}_roof_fetch $O/${TAG}_roof_write $O/${TAG}_roof_sq $O/${TAG}_roof_sq2 \
             --kernels attn_fwd_kernel,attn_bwd_dq_kernel,attn_bwd_dkv_kernel --out $O/${TAG}_roof_pmc.json > $O/${TAG}_roof_pmc.log 2>&1
           rm -rf $O/${TAG}_roof_stats $O/${TAG}_roof_fetch $O/${TAG}_roof_write $O/${TAG}_roof_sq $O/${TAG}_roof_sq2; tail -3 $O/${TAG}_roof_sq2.log;;
+    convpmc) cd /tmp
+          rocprofv3 -L > $O/${TAG}_counters_list.txt 2>&1
+          for cs in s0 s1; do
+            export PTC_CK_CASE=$cs
+            timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_ck_${cs}_stats -- python $R/tools/conv_kernels.py > $O/${TAG}_ck_${cs}_stats.log 2>&1
+            timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_ck_${cs}_fetch -- python $R/tools/conv_kernels.py > $O/${TAG}_ck_${cs}_fetch.log 2>&1
+            timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_ck_${cs}_write -- python $R/tools/conv_kernels.py > $O/${TAG}_ck_${cs}_write.log 2>&1
+            timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/${TAG}_ck_${cs}_tcc -- python $R/tools/conv_kernels.py > $O/${TAG}_ck_${cs}_tcc.log 2>&1
+            timeout 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr -d $O/${TAG}_ck_${cs}_tcp -- python $R/tools/conv_kernels.py > $O/${TAG}_ck_${cs}_tcp.log 2>&1
+            timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE -d $O/${TAG}_ck_${cs}_sq -- python $R/tools/conv_kernels.py > $O/${TAG}_ck_${cs}_sq.log 2>&1
+            timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU -d $O/${TAG}_ck_${cs}_sq2 -- python $R/tools/conv_kernels.py > $O/${TAG}_ck_${cs}_sq2.log 2>&1
+            cd $R; python tools/pmc_summary.py --stats $O/${TAG}_ck_${cs}_stats --pmc $O/${TAG}_ck_${cs}_fetch $O/${TAG}_ck_${cs}_write $O/${TAG}_ck_${cs}_tcc $O/${TAG}_ck_${cs}_tcp $O/${TAG}_ck_${cs}_sq $O/${TAG}_ck_${cs}_sq2 \
+              --kernels conv3_kernel,conv2_kernel,wgrad2_kernel,wgrad_reduce_kernel,linear2_kernel,rulebook_subm_kernel,hash_insert --out $O/${TAG}_conv_pmc_${cs}.json > $O/${TAG}_conv_pmc_${cs}.log 2>&1
+            grep CONVKERNELS $O/${TAG}_ck_${cs}_stats.log > $O/${TAG}_conv_info_${cs}.txt
+            rm -rf $O/${TAG}_ck_${cs}_stats $O/${TAG}_ck_${cs}_fetch $O/${TAG}_ck_${cs}_write $O/${TAG}_ck_${cs}_tcc $O/${TAG}_ck_${cs}_tcp $O/${TAG}_ck_${cs}_sq $O/${TAG}_ck_${cs}_sq2
+            cd /tmp
+          done; unset PTC_CK_CASE; tail -3 $O/${TAG}_ck_s1_tcp.log;;
     *) echo "unknown section $sec";;
   esac
 done

@@ -38,7 +38,9 @@ def main():
     def short(name):
         for w in want:
             if w in name:
-                return w
+                # keep the template arguments (distinct instances = distinct shapes), drop the parameter list
+                head = name.split("(")[0].strip()
+                return head.replace("void ", "") if "<" in head else w
         return name[:80]
 
     # rocprofv3 >= 7.x writes a rocpd SQLite database by default (views `top_kernels`, `kernels`,
