@@ -123,6 +123,57 @@ def segment_csr(src: torch.Tensor, indptr: torch.Tensor, reduce: str = "sum") ->
     return out.reshape((n_seg,) + tuple(c))
 
 
+class _AttnKernelRounding(torch.autograd.Function):
+    """attention_varlen with the 16-bit roundings of the gfx950 kernels (csrc/attention.hip) placed where THEY round,
+    forward and backward -- used to show that the engine-vs-oracle gradient differences are those roundings and nothing
+    else (tests/test_gpu_fullsize.py).  fp32 math otherwise.
+      forward : P = exp(s - max) rounded to bf16 BEFORE the P V product; the denominator is the sum of the same rounded
+                values (it comes out of the same MFMA); output rounded to bf16 (flash-attn returns bf16 too).
+      backward: P recomputed in fp32 from lse; delta = rowsum(dO * O) with the bf16 output; dV = bf16(P)^T dO;
+                dS = P * (dP - delta) rounded to bf16 before dQ = dS K and dK = dS^T Q; dQ / dK / dV rounded to bf16."""
+
+    @staticmethod
+    def forward(ctx, qkv, cu, scale):
+        T, _, H, D = qkv.shape
+        out = qkv.new_zeros(T, H, D)
+        lse = qkv.new_zeros(H, T)
+        for a, b in zip(cu[:-1], cu[1:]):
+            q, k, v = (qkv[a:b, j].transpose(0, 1).float() for j in range(3))
+            s = (q * scale) @ k.transpose(1, 2)
+            m = s.max(dim=-1, keepdim=True).values
+            p16 = torch.exp(s - m).to(torch.bfloat16).float()
+            l = p16.sum(-1, keepdim=True)
+            out[a:b] = ((p16 @ v) / l).transpose(0, 1).to(torch.bfloat16).float()
+            lse[:, a:b] = (m + torch.log(l))[..., 0]
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cu, ctx.scale = cu, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        dqkv = torch.zeros_like(qkv)
+        do16 = dout.to(torch.bfloat16).float()
+        for a, b in zip(ctx.cu[:-1], ctx.cu[1:]):
+            q, k, v = (qkv[a:b, j].transpose(0, 1).float() for j in range(3))
+            do, o = do16[a:b].transpose(0, 1), out[a:b].transpose(0, 1)
+            s = (q * ctx.scale) @ k.transpose(1, 2)
+            p = torch.exp(s - lse[:, a:b, None])
+            delta = (do * o).sum(-1, keepdim=True)
+            dp = do @ v.transpose(1, 2)
+            ds16 = (p * (dp - delta)).to(torch.bfloat16).float()
+            p16 = p.to(torch.bfloat16).float()
+            dqkv[a:b, 0] = ((ds16 @ k) * ctx.scale).transpose(0, 1).to(torch.bfloat16).float()
+            dqkv[a:b, 1] = ((ds16.transpose(1, 2) @ q) * ctx.scale).transpose(0, 1).to(torch.bfloat16).float()
+            dqkv[a:b, 2] = (p16.transpose(1, 2) @ do).transpose(0, 1).to(torch.bfloat16).float()
+        return dqkv, None, None
+
+
+def attention_varlen_kernel_rounding(qkv: torch.Tensor, cu_seqlens, softmax_scale: float) -> torch.Tensor:
+    """see _AttnKernelRounding; qkv holds bf16-representable values (callers round first, ptv3m1:209)"""
+    return _AttnKernelRounding.apply(qkv, [int(v) for v in cu_seqlens], float(softmax_scale))
+
+
 # ------------------------------------------------------------------------------------------------
 # variable-length attention (flash_attn.flash_attn_varlen_qkvpacked_func semantics; ptv3m1:208-214)
 # ------------------------------------------------------------------------------------------------

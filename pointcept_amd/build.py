@@ -27,6 +27,7 @@ HIP_SOURCES = [
     "maps.hip",
     "rows.hip",
     "rulebook.hip",
+    "blocks.hip",
     "spconv.hip",
     "norm.hip",
     "attention.hip",

@@ -214,6 +214,7 @@ static int dispatch_fwd(const void* in, const void* w, const float* bias, const 
 
 #include "fwd2.h"
 #include "conv3.h"
+#include "conv4.h"
 
 // experiment switch (read per call, ~50 ns): PTC_CONV3=0 keeps the table convolutions on conv2
 static bool ptc_use_conv3() {
@@ -244,6 +245,23 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
   }
   PTC_DISPATCH_DTYPE(dtype, T, return dispatch_fwd<T>(in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s));
   return PTC_OK;
+}
+
+extern "C" int ptc_spconv_fwd_blk(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr,
+                                  const int16_t* lnbr, const int32_t* halo, const int32_t* hcnt, int bm, int hmax, int64_t n_out, int kv,
+                                  int c_in, int c_out, int dtype, void* out, ptc_stream_t stream) {
+  const bool buf_ok = (uint64_t)n_in * (uint64_t)c_in * ptc_dtype_size(dtype) <= PTC_BUF_MAX_BYTES;
+  const char* e = getenv("PTC_CONV4");
+  const bool on = e ? atoi(e) != 0 : true;
+  if (!on || !buf_ok || !lnbr || !halo || !hcnt || !nbr || n_out == 0 || !conv4_supported(dtype, kv, c_in, c_out, bm, hmax))
+    return ptc_spconv_fwd(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, dtype, out, stream);
+  PTC_REQUIRE(n_in >= 0 && n_out >= 0, PTC_EINVAL, "ptc_spconv_fwd_blk: bad sizes");
+  PTC_REQUIRE(weight && out && in, PTC_EINVAL, "ptc_spconv_fwd_blk: null buffer");
+  PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)out % 16 == 0), PTC_EINVAL,
+              "ptc_spconv_fwd_blk: buffers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PTC_BF16) return launch_conv4<bf16_t>(in, n_in, weight, bias, nbr, lnbr, halo, hcnt, bm, hmax, n_out, kv, c_in, c_out, out, s);
+  return launch_conv4<f16_t>(in, n_in, weight, bias, nbr, lnbr, halo, hcnt, bm, hmax, n_out, kv, c_in, c_out, out, s);
 }
 
 // Dense row-wise GEMM with an MLP epilogue (see fwd2.h): epilogue 1 = out: h, aux_out: GELU(h);

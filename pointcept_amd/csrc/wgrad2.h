@@ -23,16 +23,23 @@
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
 #define W2_ROWS 32  // rows per wave step
+// Byte stride between the 16-channel planes of an image.  32 rows x 32 B = 1024 B would put every plane on the SAME
+// banks (1024 = 4 x 256 B): the eight lanes that store one row (pieces 0..7 = planes 0..3) then collide 4-way on every
+// ds_write_b128 -- rocprofv3 PMC at the dec0 shape: SQ_LDS_BANK_CONFLICT = 100.8 M cycles, 44 % of the kernel's
+// CU-cycles (profiles/r02_a_conv_pmc_s0.json).  +64 B rotates consecutive planes by 16 banks: the eight stores of a
+// lane group land on distinct 16-byte bank quads for every COT / CIT in use; reads touch one plane per instruction
+// and keep their conflict-free pattern.
+#define W2_PLANE 1088
 
 // LDS byte offset of (row, 8-channel piece) inside a wave's [planes][32][16] image
-__device__ __forceinline__ int w2_off(int row, int piece) { return (((piece >> 1) * W2_ROWS + row) << 5) + ((piece & 1) << 4); }
+__device__ __forceinline__ int w2_off(int row, int piece) { return (piece >> 1) * W2_PLANE + (row << 5) + ((piece & 1) << 4); }
 
 // one MFMA fragment (8 contraction values = rows {4g..4g+3, 16+4g..16+4g+3} of channel `lane&15` of plane t)
 template <typename T>
 __device__ __forceinline__ typename Mma<T>::frag w2_frag(const unsigned char* img, int t, int lane) {
   const int lp = lane & 15, g = lane >> 4;
   const int row = 4 * g + (lp >> 2);
-  const unsigned char* p = img + ((t * W2_ROWS + row) << 5) + ((lp & 3) << 3);
+  const unsigned char* p = img + t * W2_PLANE + (row << 5) + ((lp & 3) << 3);
   const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
   const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * 32));
   s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -66,11 +73,11 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
   const __amdgpu_buffer_rsrc_t in_buf = ptc_buf(in, in_bytes), dout_buf = ptc_buf(dout, dout_bytes);
   constexpr bool PIPE = W2Pipe<COT, CIT, KG>::value;
   constexpr int NI = PIPE ? KG : 2;                    // gathered-row images per wave
-  constexpr int WAVE_BYTES = (COT + NI * CIT) * 1024;  // dout image + `in` images
+  constexpr int WAVE_BYTES = (COT + NI * CIT) * W2_PLANE;  // dout image + `in` images
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char* D = smem + wave * WAVE_BYTES;
-  unsigned char* I0 = D + COT * 1024;
+  unsigned char* I0 = D + COT * W2_PLANE;
   // 1-D grid, XCD-first numbering (workgroup b runs on XCD b % 8): logical id l = (row worker * blocks + channel
   // block) * groups + table-row group, so the `groups` workgroups that stream the SAME dout rows (and gather
   // overlapping neighbourhoods) run on one XCD at the same time and share its L2 -- dout left HBM once per group
@@ -177,7 +184,7 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
       store_dout(pd);
 #pragma unroll
       for (int kk = 0; kk < KG; ++kk)
-        if (kk < nk) store_in(I0 + kk * CIT * 1024, pi[kk]);
+        if (kk < nk) store_in(I0 + kk * CIT * W2_PLANE, pi[kk]);
       // 2. step s + workers goes out, entries of the one after it too
       load_dout(s + workers, pd);
 #pragma unroll
@@ -199,7 +206,7 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
         if (kk < nk) {
           typename M::frag B[CIT];
 #pragma unroll
-          for (int b = 0; b < CIT; ++b) B[b] = w2_frag<T>(I0 + kk * CIT * 1024, b, lane);
+          for (int b = 0; b < CIT; ++b) B[b] = w2_frag<T>(I0 + kk * CIT * W2_PLANE, b, lane);
 #pragma unroll
           for (int a = 0; a < COT; ++a)
 #pragma unroll
@@ -209,7 +216,7 @@ wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_
       w2_wave_sync();  // the slice is rewritten at the top of the next trip
     }
   } else {
-    unsigned char* I[2] = {I0, I0 + CIT * 1024};
+    unsigned char* I[2] = {I0, I0 + CIT * W2_PLANE};
     for (int64_t s = worker; s < steps_total; s += workers) {
       int32_t idx[KG][CIT];
       load_idx(s, idx);
@@ -338,6 +345,6 @@ static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out, bool wa
   if (gx < 1) gx = 1;
   p.gx = (int)gx;
   const bool pipe = p.kg * p.cot * p.cit * 4 + 4 * (p.cot + p.kg * p.cit) + 4 * (p.cot + p.cit) <= 208;   // = W2Pipe<cot,cit,kg>
-  p.lds = (size_t)4 * (p.cot + (pipe ? p.kg : 2) * p.cit) * 1024;  // >= the 4*CIT KB of the final cross-wave sum
+  p.lds = (size_t)4 * (p.cot + (pipe ? p.kg : 2) * p.cit) * W2_PLANE;  // >= the 4*CIT KB of the final cross-wave sum
   return p;
 }

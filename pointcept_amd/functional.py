@@ -210,7 +210,7 @@ class _SparseConv(Function):
     INPUT row (copies that nothing reads get a zero gradient).  Both None for duplicate-free coordinates."""
 
     @staticmethod
-    def forward(ctx, feat, weight, bias, nbr, nbr_t, mirror, dup_out, dup_in):
+    def forward(ctx, feat, weight, bias, nbr, nbr_t, mirror, dup_out, dup_in, blocks):
         dt = _autocast_dtype(feat)
         c_out, kv, c_in = weight.shape
         f = _pad_to(feat.to(dt), 1, 16).contiguous()
@@ -218,8 +218,11 @@ class _SparseConv(Function):
         b = None if bias is None else _pad_to(bias.float(), 0, 16)
         # (padding the 6 -> 16 channel stem further to 32 so that conv3 takes it was measured SLOWER than conv2:
         #  1.20 ms vs 0.74 ms for the 125-offset table, r01_u)
-        out = ops.spconv_fwd(f, w, b, nbr)
+        # blocks = ops.BlockProvider of the (submanifold) table: the LDS-staged kernel where the shape allows it
+        blk = None if blocks is None else blocks.get(f.shape[1], w.shape[0], dt)
+        out = ops.spconv_fwd(f, w, b, nbr, blk)
         ctx.save_for_backward(f, w, nbr, nbr_t, dup_out, dup_in)
+        ctx.blocks = blocks if mirror else None    # SubM: dgrad runs over the same table
         ctx.mirror = mirror
         ctx.shape = (c_out, kv, c_in)
         ctx.in_dtype, ctx.w_dtype = feat.dtype, weight.dtype
@@ -238,7 +241,9 @@ class _SparseConv(Function):
             if ctx.mirror:
                 wt = wt.flip(1)
             gm = g if dup_out is None else _merge_duplicate_rows(g, dup_out)
-            dfeat = ops.spconv_fwd(gm, wt.contiguous(), None, nbr_t)[:, :c_in].to(ctx.in_dtype)
+            wt = wt.contiguous()
+            blk = None if ctx.blocks is None else ctx.blocks.get(gm.shape[1], wt.shape[0], gm.dtype)
+            dfeat = ops.spconv_fwd(gm, wt, None, nbr_t, blk)[:, :c_in].to(ctx.in_dtype)
             if dup_in is not None:
                 own = dup_in == torch.arange(dup_in.numel(), device=dup_in.device, dtype=dup_in.dtype)
                 dfeat = dfeat * own[:, None].to(dfeat.dtype)
@@ -246,12 +251,13 @@ class _SparseConv(Function):
             dw = ops.spconv_wgrad(f, g, nbr)[:c_out, :, :c_in].to(ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = ops.column_sum(grad)
-        return dfeat, dw, dbias, None, None, None, None, None
+        return dfeat, dw, dbias, None, None, None, None, None, None
 
 
-def sparse_conv(feat, weight, bias, nbr, nbr_t, mirror: bool, dup_out=None, dup_in=None):
-    """weight: [C_out, kv, C_in] (a view of the spconv-layout parameter [C_out,k0,k1,k2,C_in])."""
-    return _SparseConv.apply(feat, weight, bias, nbr, nbr_t, mirror, dup_out, dup_in)
+def sparse_conv(feat, weight, bias, nbr, nbr_t, mirror: bool, dup_out=None, dup_in=None, blocks=None):
+    """weight: [C_out, kv, C_in] (a view of the spconv-layout parameter [C_out,k0,k1,k2,C_in]).  blocks: optional
+    ops.BlockProvider of `nbr` (submanifold tables only)."""
+    return _SparseConv.apply(feat, weight, bias, nbr, nbr_t, mirror, dup_out, dup_in, blocks)
 
 
 # ------------------------------------------------------------------------------------------------

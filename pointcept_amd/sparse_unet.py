@@ -116,7 +116,23 @@ class SpUNetBase(nn.Module):
     def forward(self, input_dict):
         grid_coord, feat, offset = input_dict["grid_coord"], input_dict["feat"], input_dict["offset"]
         batch = offset2batch(offset)
-        from . import ops
+        from . import config, ops
+        from . import functional as PF
+
+        # Rows arrive in dataloader order (no spatial order at all): every gathered neighbour row is then a random
+        # 64..256-byte access.  Sort the rows of the batch along a Hilbert curve once (batch-prefixed key, so scenes
+        # stay contiguous and `offset` is unchanged), run the whole network on the sorted rows -- neighbours of
+        # consecutive output rows are consecutive-ish input rows: L1/L2 serve the 27-point gathers -- and hand the
+        # logits back in the caller's order.  Convolutions do not care about row numbering; BatchNorm sums do not either.
+        unsort = None
+        if config.SORT_POINTS and feat.is_cuda and grid_coord.shape[0] > 0 and not self.enc_mode:
+            gc_l = grid_coord if grid_coord.dtype in (torch.int32, torch.int64) else grid_coord.long()
+            depth = 16          # no host fact needed: a deeper curve than the data's is still a curve (keys stay < 2^(3 d_data))
+            code = ops.serialize_encode(gc_l, batch, depth, ("hilbert",))
+            order, inverse = ops.sort_keys(code, 0, 3 * depth + max(1, int(offset.numel() - 1).bit_length()))
+            order, unsort = order[0], inverse[0]
+            grid_coord, batch = gc_l[order], batch[order]
+            feat = PF.gather_rows(feat, order, unsort)
 
         indices = torch.cat([batch.unsqueeze(-1).int(), grid_coord.int()], dim=1).contiguous()
         n = indices.shape[0]
@@ -150,4 +166,6 @@ class SpUNetBase(nn.Module):
             out = f.new_zeros((x.batch_size, f.shape[1])).index_add_(0, idx, f)
             cnt = torch.bincount(idx, minlength=x.batch_size).clamp(min=1).to(f.dtype)
             x = x.replace_feature(out / cnt[:, None])
+        if unsort is not None:
+            return PF.gather_rows(x.features, unsort, order)     # caller's row order; backward = gather through `order`
         return x.features

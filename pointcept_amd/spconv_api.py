@@ -231,7 +231,13 @@ class SubMConv3d(_SparseConvolution):
             if self.indice_key is not None:
                 x.indice_dict[key] = rb
         rep = _dup_rep(x, rb[rb.shape[0] // 2])   # centre offset = the row that wins the lookup of its own voxel
-        return x.replace_feature(PF.sparse_conv(x.features, self._w(), self.bias, rb, rb, True, rep, rep))
+        blocks = None
+        if k == 3 and self.indice_key is not None:   # block-local tables (ops.BlockProvider), cached next to the rulebook
+            bkey = ("blocks", self.indice_key, k)
+            blocks = x.indice_dict.get(bkey)
+            if blocks is None or blocks.nbr is not rb:
+                blocks = x.indice_dict[bkey] = ops.BlockProvider(rb)
+        return x.replace_feature(PF.sparse_conv(x.features, self._w(), self.bias, rb, rb, True, rep, rep, blocks))
 
 
 def _down_rulebook(x: SparseConvTensor, indice_key):

@@ -145,7 +145,7 @@ def rulebook_down(indices, coord_bits, batch_bits):
     return torch.from_numpy(out_indices), torch.from_numpy(nbr_down), torch.from_numpy(nbr_up)
 
 
-def spconv_fwd(feat, weight, bias, nbr):
+def spconv_fwd(feat, weight, bias, nbr, blk=None):
     f, w = feat.float(), weight.float()
     if nbr is None:
         out = f @ w[:, 0, :].t()

@@ -332,6 +332,137 @@ def test_spconv_fwd_chunked_pipeline(cuda, cin, cout, ksize, rt, monkeypatch):
         assert torch.equal(got, again), "conv3 must be bit-reproducible"
 
 
+@pytest.mark.parametrize("cin,cout,ksize", [(32, 64, 3), (64, 64, 3), (128, 128, 3), (96, 96, 3), (128, 96, 3), (64, 128, 2), (32, 32, 3)])
+def test_spconv_fwd_coalesced_bounce_is_bit_identical(cuda, cin, cout, ksize, monkeypatch):
+    """conv3 BNC (quad-coalesced gathers + wave-private LDS bounce into the MFMA layout) feeds the MFMAs the same
+    operands in the same order as the direct-gather form: outputs must be IDENTICAL, for both workgroup shapes."""
+    from pointcept_amd import ops
+
+    monkeypatch.setenv("PTC_CONV3_C32", "1")
+    ind = _scene_indices(2100)
+    nbr = oops.down_rulebook(ind)[2] if ksize == 2 else oops.subm_rulebook(ind, ksize)
+    kv = nbr.shape[0]
+    g = torch.Generator().manual_seed(cin + cout)
+    feat = (torch.randn(ind.shape[0], cin, generator=g) * 0.5).to(torch.bfloat16).to(cuda)
+    w = (torch.randn(cout, kv, cin, generator=g) / (kv * cin) ** 0.5 * 2).to(torch.bfloat16).to(cuda)
+    bias = torch.randn(cout, generator=g).to(cuda)
+    nbr_d = _t(nbr, cuda)
+    for rt in ("2", "4"):
+        monkeypatch.setenv("PTC_CONV3_RT", rt)
+        monkeypatch.setenv("PTC_CONV3_BNC", "0")
+        base = ops.spconv_fwd(feat, w, bias, nbr_d)
+        monkeypatch.setenv("PTC_CONV3_BNC", "1")
+        got = ops.spconv_fwd(feat, w, bias, nbr_d)
+        assert torch.isfinite(got.float()).all()
+        assert torch.equal(got, base), f"rt={rt}: max diff {(got.float() - base.float()).abs().max().item()}"
+    _close("conv3_bnc", got, oops.gather_conv(feat.float().cpu(), w.float().cpu(), bias.cpu(), nbr), 1.0 / 128, 2e-3)
+
+
+def _curve_sorted_indices(n_pts, batch=2):
+    """scene indices with rows in Hilbert order (what PTC_SORT_POINTS / the SpUNet entry sort give the kernels)"""
+    from pointcept_amd import synthetic
+
+    b = synthetic.indoor_batch(batch, n_pts)
+    bt = omaps.offset2batch(b["offset"])
+    gc = b["grid_coord"]
+    depth = int(gc.max() + 1).bit_length()
+    code = osfc.encode_c(gc, bt, depth, ("hilbert",))[0]
+    o = np.argsort(code, kind="stable")
+    return np.concatenate([bt[o, None], gc[o]], axis=1).astype(np.int32)
+
+
+@pytest.mark.parametrize("bm,hmax", [(256, 512), (128, 320)])
+@pytest.mark.parametrize("ordered", [True, False])
+def test_rulebook_blocks(cuda, bm, hmax, ordered):
+    """block-local rulebook (csrc/blocks.hip): halo lists ascending + distinct + exactly the rows the block names,
+    lnbr maps every entry to its position; rows in no spatial order overflow and are flagged, not truncated."""
+    from pointcept_amd import ops
+
+    ind = _curve_sorted_indices(9000) if ordered else _scene_indices(9000)
+    nbr = oops.subm_rulebook(ind, 3)
+    n = nbr.shape[1]
+    bt = ops.BlockTables(_t(nbr, cuda), bm, hmax)
+    lnbr, halo, hcnt = bt.lnbr.cpu().numpy(), bt.halo.cpu().numpy(), bt.hcnt.cpu().numpy()
+    nblk = (n + bm - 1) // bm
+    assert hcnt.shape == (nblk,)
+    n_ovf = 0
+    for b in range(nblk):
+        e = nbr[:, b * bm:(b + 1) * bm]
+        want = np.unique(e[e >= 0])
+        if len(want) > hmax:
+            assert hcnt[b] == hmax + 1
+            n_ovf += 1
+            continue
+        assert hcnt[b] == len(want)
+        assert np.array_equal(halo[b, :len(want)], want)             # ascending, distinct, complete
+        le = lnbr[:, b * bm:(b + 1) * bm]
+        assert np.array_equal(le < 0, e < 0)
+        assert np.array_equal(halo[b][np.where(le >= 0, le, 0)][e >= 0], e[e >= 0])
+    assert int(bt.n_overflow.item()) == n_ovf
+    if ordered:
+        assert n_ovf == 0, "curve-ordered rows must fit their halo budget"
+    else:
+        assert n_ovf > 0, "this case is meant to exercise the overflow flag"
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 32), (64, 96), (64, 128), (96, 96), (128, 96), (128, 128),
+                                      (96, 64), (128, 64)])
+@pytest.mark.parametrize("ordered", [True, False])
+def test_spconv_fwd_block_staged(cuda, cin, cout, ordered):
+    """conv4 (input rows of a block staged once in LDS, csrc/conv4.h): bit-identical to the global-gather kernels on
+    the same table -- same summation order -- and within the 16-bit bar of the fp32 oracle; the un-ordered case runs
+    the kernel's fallback loop for the overflowing blocks (and the LDS loop for the others) in ONE launch."""
+    from pointcept_amd import ops
+
+    ind = _curve_sorted_indices(5000)
+    if not ordered:   # second half of the rows in random order: the first blocks fit their halo budget, the others overflow
+        rng = np.random.default_rng(cin)
+        h = ind.shape[0] // 2
+        ind = np.concatenate([ind[:h], ind[h:][rng.permutation(ind.shape[0] - h)]])
+    nbr = oops.subm_rulebook(ind, 3)
+    n = nbr.shape[1]
+    plan = ops.block_plan(cin, cout, 27, torch.bfloat16)
+    assert plan is not None
+    nbr_d = _t(nbr, cuda)
+    bt = ops.BlockTables(nbr_d, *plan)
+    g = torch.Generator().manual_seed(cin * 131 + cout)
+    for dtype in (torch.bfloat16, torch.float16):
+        feat = (torch.randn(n, cin, generator=g) * 0.5).to(dtype)
+        w = (torch.randn(cout, 27, cin, generator=g) / (27 * cin) ** 0.5 * 2).to(dtype)
+        bias = torch.randn(cout, generator=g)
+        base = ops.spconv_fwd(feat.to(cuda), w.to(cuda), bias.to(cuda), nbr_d)
+        got = ops.spconv_fwd(feat.to(cuda), w.to(cuda), bias.to(cuda), nbr_d, bt)
+        assert torch.isfinite(got.float()).all()
+        assert torch.equal(got, base), f"conv4 differs from the global-gather kernel: max diff {(got.float() - base.float()).abs().max().item()}"
+        rtol, atol = _tols(dtype)
+        _close(f"conv4_{dtype}", got, oops.gather_conv(feat.float(), w.float(), bias, nbr), rtol, atol)
+        nb = ops.spconv_fwd(feat.to(cuda), w.to(cuda), None, nbr_d, bt)
+        assert torch.equal(nb, ops.spconv_fwd(feat.to(cuda), w.to(cuda), None, nbr_d))
+
+
+def test_spconv_block_staged_full_size(cuda):
+    """BASELINE size: 8 x 102400 voxels in curve order, 64 -> 64: conv4 == conv3 bit for bit, no block overflows."""
+    from pointcept_amd import ops, synthetic
+
+    b = synthetic.to_torch(synthetic.indoor_batch(8, 102400), cuda)
+    off = b["offset"]
+    bt_ = torch.repeat_interleave(torch.arange(off.numel(), device=cuda), torch.diff(off, prepend=off.new_zeros(1)))
+    code = ops.serialize_encode(b["grid_coord"], bt_, 8, ("hilbert",))
+    order, _ = ops.sort_keys(code, 0, 3 * 8 + 3)
+    ind = torch.cat([bt_[:, None].int(), b["grid_coord"].int()], 1)[order[0]].contiguous()
+    nbr = ops.rulebook_subm(ind, 3, ops.HashTable(ind))
+    n = ind.shape[0]
+    for cin, cout in ((64, 64), (32, 32)):
+        blk = ops.BlockTables(nbr, *ops.block_plan(cin, cout, 27, torch.bfloat16))
+        assert int(blk.n_overflow.item()) <= 8           # 3200 blocks; a handful exceed the 512-row halo budget and take the fallback loop
+        assert int((blk.hcnt > blk.hmax).sum().item()) == int(blk.n_overflow.item()) and int(blk.hcnt.min().item()) >= 1
+        g = torch.Generator().manual_seed(cin)
+        x = torch.randn(n, cin, generator=g).to(torch.bfloat16).to(cuda)
+        w = (torch.randn(cout, 27, cin, generator=g) * 0.05).to(torch.bfloat16).to(cuda)
+        bias = torch.randn(cout, generator=g).to(cuda)
+        assert torch.equal(ops.spconv_fwd(x, w, bias, nbr, blk), ops.spconv_fwd(x, w, bias, nbr))
+
+
 def test_spconv_dgrad_via_mirrored_table(cuda):
     """dgrad = the same kernel with W' = W.permute(ci,k,co).flip(k) on the SAME table (Appendix A.6)."""
     from pointcept_amd import ops

@@ -30,3 +30,21 @@ def test_gpu_spunet_test_bodies_on_cpu_standins(name):
 
     with mock_backend.cpu_ops():
         getattr(T, name)(torch.device("cpu"))
+
+
+FULLSIZE_TESTS = ["test_ptv3_base_one_full_scene_maps_and_logits", "test_ptv3_base_train_step_gradients_vs_oracle",
+                  "test_spunet_base_one_full_scene_forward", "test_ptv3_outdoor_full_scene_forward"]
+
+
+@pytest.mark.parametrize("name", FULLSIZE_TESTS)
+def test_gpu_fullsize_test_bodies_on_cpu_standins(name, monkeypatch):
+    """the full-size / full-depth parity tests, bodies unchanged, on scenes shrunk 16x (PTC_FULLSIZE_SCALE) so that the
+    base-depth models fit the CPU budget of this tier"""
+    import importlib
+
+    monkeypatch.setenv("PTC_FULLSIZE_SCALE", "0.0625")
+    import test_gpu_fullsize as T
+
+    T = importlib.reload(T)
+    with mock_backend.cpu_ops():
+        getattr(T, name)(torch.device("cpu"))

@@ -164,7 +164,7 @@ def bench_spconv_stages(rows, results, scenes=8, points=102400):
     b = synthetic.to_torch(synthetic.indoor_batch(scenes, points), DEV)
     batch = torch.repeat_interleave(torch.arange(scenes, device=DEV), torch.diff(b["offset"], prepend=b["offset"].new_zeros(1)))
     gc = b["grid_coord"]
-    for s, chans in enumerate(((32, 64), (64,), (128,), (256,), (512,))):
+    for s, chans in enumerate(((32, 64, (128, 96), 96), (64, 32, 128), (128,), (256,), (512,))):
         key = (batch << 48) | ((gc[:, 0] >> s) << 32) | ((gc[:, 1] >> s) << 16) | (gc[:, 2] >> s)
         uk = torch.unique(key)
         bb = uk >> 48
@@ -182,22 +182,41 @@ def bench_spconv_stages(rows, results, scenes=8, points=102400):
         t_5 = timeit(lambda: ops.rulebook_subm(ind, 5, table), iters=5) if s == 0 else 0.0
         rows.append(f"rulebook stage {s} n={n:7d} (curve order): hash {t_h * 1e6:7.1f} us | k3 {t_3 * 1e6:7.1f} us "
                     f"({27 * n * 4 / t_3 / 1e9:.0f} GB/s table out) | k5 {t_5 * 1e6:7.1f} us")
-        for c in chans:
-            x = torch.randn(n, c, device=DEV).to(torch.bfloat16)
-            w = (torch.randn(c, 27, c, device=DEV) * 0.05).to(torch.bfloat16)
+        for cc in chans:
+            ci, c = cc if isinstance(cc, tuple) else (cc, cc)
+            x = torch.randn(n, ci, device=DEV).to(torch.bfloat16)
+            w = (torch.randn(c, 27, ci, device=DEV) * 0.05).to(torch.bfloat16)
             bias = torch.randn(c, device=DEV)
-            by = n * c * 2 * 2 + 4 * 27 * n + 27 * c * c * 2
-            fl = 2.0 * pairs * c * c
-            r = {"stage": s, "n": n, "c": c, "pairs": pairs}
-            for name, flag in (("conv2", "0"), ("conv3", "1")):
+            by = n * (ci + c) * 2 + 4 * 27 * n + 27 * ci * c * 2
+            fl = 2.0 * pairs * ci * c
+            r = {"stage": s, "n": n, "c_in": ci, "c": c, "pairs": pairs}
+            os.environ["PTC_CONV3_C32"] = "1"
+            for name, flag, bnc in (("conv2", "0", "0"), ("conv3d", "1", "0"), ("conv3", "1", "1")):
                 os.environ["PTC_CONV3"] = flag
-                r[name] = roof(by, fl, timeit(lambda: ops.spconv_fwd(x, w, bias, nbr), iters=10))
+                os.environ["PTC_CONV3_BNC"] = bnc
+                try:
+                    r[name] = roof(by, fl, timeit(lambda: ops.spconv_fwd(x, w, bias, nbr), iters=10))
+                except Exception as e:   # an unsupported instantiation must not cost the rest of the table
+                    r[name] = {"us": float("nan"), "GBps": 0.0, "TFLOPs": 0.0, "roof_frac": 0.0, "error": repr(e)}
             os.environ.pop("PTC_CONV3", None)
+            os.environ.pop("PTC_CONV3_BNC", None)
+            os.environ.pop("PTC_CONV3_C32", None)
+            plan = ops.block_plan(ci, c, 27, torch.bfloat16)
+            c4 = ""
+            if plan is not None:
+                t_b = timeit(lambda: ops.BlockTables(nbr, *plan), iters=5)
+                blk = ops.BlockTables(nbr, *plan)
+                r["conv4"] = roof(by, fl, timeit(lambda: ops.spconv_fwd(x, w, bias, nbr, blk), iters=10))
+                r["blocks_us"] = round(t_b * 1e6, 1)
+                r["blocks_overflow"] = int(blk.n_overflow.item())
+                r["halo_mean"] = round(float(blk.hcnt.float().mean()), 1)
+                c4 = (f" | conv4 {r['conv4']['us']:8.1f} us ({r['conv4']['GBps']:.0f} GB/s alg, {r['conv4']['TFLOPs']:.1f} TF/s; tables {r['blocks_us']:.1f} us, "
+                      f"halo {r['halo_mean']:.0f}/{plan[0]}, {r['blocks_overflow']} overflow)")
             g = torch.randn(n, c, device=DEV).to(torch.bfloat16)
             r["wgrad"] = roof(by, fl, timeit(lambda: ops.spconv_wgrad(x, g, nbr), iters=10))
             results.append(r)
-            rows.append(f"cpe conv stage {s} n={n:7d} c={c:3d} pairs/pt={pairs / n:5.2f} | conv2 {r['conv2']['us']:8.1f} us | conv3 {r['conv3']['us']:8.1f} us "
-                        f"({r['conv3']['GBps']:.0f} GB/s alg, {r['conv3']['TFLOPs']:.1f} TF/s) | wgrad {r['wgrad']['us']:8.1f} us ({r['wgrad']['TFLOPs']:.1f} TF/s)")
+            rows.append(f"conv stage {s} n={n:7d} {ci:3d}->{c:3d} pairs/pt={pairs / n:5.2f} | conv2 {r['conv2']['us']:8.1f} us | conv3 direct {r['conv3d']['us']:8.1f} us | conv3 bounce {r['conv3']['us']:8.1f} us "
+                        f"({r['conv3']['GBps']:.0f} GB/s alg, {r['conv3']['TFLOPs']:.1f} TF/s){c4} | wgrad {r['wgrad']['us']:8.1f} us ({r['wgrad']['TFLOPs']:.1f} TF/s)")
 
 
 def bench_losses(rows, results, n=819200, c=20):
