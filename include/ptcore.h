@@ -261,6 +261,17 @@ int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32
                      void* workspace, size_t workspace_bytes, ptc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * G1b. 3-axis rotary embedding on point tokens, IN PLACE (LitePT / PT-v3m3 "PointROPE").
+ * Replaces libs/pointrope/kernels.cu:19-100 behind pointrope.pointrope(tokens, positions, base, F0)
+ * (libs/pointrope/pointrope.cpp:51-67; call sites pointcept/models/litept/litept_v1.py:27-59,240-241).
+ *   tokens [n_tokens, H, D] of `dtype` (fp32 / f16 / bf16), D % 6 == 0, Q = D/6, head = [u_x|v_x|u_y|v_y|u_z|v_z] (Q each);
+ *   positions [n_tokens, 3] int64;  f = pos[a] * (fwd / base^(i/Q));  (u, v) <- (u cos f - v sin f, v cos f + u sin f).
+ *   The backward of the operator is the same call with fwd = -F0.
+ * ------------------------------------------------------------------------------------------ */
+int ptc_rope3d(void* tokens, int dtype, const int64_t* positions, int64_t n_tokens, int H, int D, float base, float fwd,
+               ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * G2. LayerNorm over channels of [n, c] features (nn.LayerNorm inside every PTv3 Block:
  * ptv3m1:286 cpe.2, :289 norm1, :305 norm2).  c in {32,64,128,256,512} (ptc_layer_norm_supported).
  *   fwd: y = (x-mean)*rstd*gamma + beta, statistics in fp32; y dtype may differ from x

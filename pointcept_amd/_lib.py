@@ -53,6 +53,7 @@ _SIGNATURES = {
     "ptc_spconv_wgrad_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "ptc_spconv_wgrad": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size,
                                  c_ptr]),
+    "ptc_rope3d": (c_int, [c_ptr, c_int, c_ptr, c_i64, c_int, c_int, c_f32, c_f32, c_ptr]),
     "ptc_layer_norm_supported": (c_int, [c_int]),
     "ptc_layer_norm_fwd": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
     "ptc_layer_norm_bwd_workspace_bytes": (c_size, [c_i64, c_int]),

@@ -36,6 +36,7 @@ HIP_SOURCES = [
     "voxelize.hip",
     "pointops.hip",
     "bn.hip",
+    "rope.hip",
 ]
 CXX_SOURCES = ["core.cpp"]
 PROBE_SOURCES = ["host_probe.cpp"]

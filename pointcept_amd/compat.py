@@ -1,5 +1,5 @@
 """Operator-level drop-in (SURVEY 8(b) level B3): make `import spconv.pytorch`, `import flash_attn`
-`import torch_scatter` and `import pointops` resolve to the engine, so the reference's model files
+`import torch_scatter`, `import pointops` and `import pointrope` resolve to the engine, so the reference's model files
 (point_transformer_v3m1_base.py, spconv_unet_v1m1_base.py, structure.py, modules.py) run UNMODIFIED
 on libptcore.so.  Call once before importing pointcept.models:
 
@@ -15,7 +15,7 @@ import types
 
 
 def install(force: bool = False) -> None:
-    from . import flash_attn_api, pointops_api, spconv_api, torch_scatter_api
+    from . import flash_attn_api, pointops_api, pointrope_api, spconv_api, torch_scatter_api
 
     def put(name, module):
         if force or name not in sys.modules:
@@ -33,3 +33,4 @@ def install(force: bool = False) -> None:
     ts.segment_csr = torch_scatter_api.segment_csr
     put("torch_scatter", ts)
     put("pointops", pointops_api)
+    put("pointrope", pointrope_api)      # libs/pointrope: `import pointrope as _kernels` (litept_v1.py:26)

@@ -57,6 +57,7 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define AT_MIN_WAVES 4          // waves per SIMD the register budget must allow (two 8-wave workgroups per CU)
 #define AT_LOG2E 1.4426950408889634f
 #define AT_LN2 0.6931471805599453f
+#define AT_FWD_DEFAULT 2         // forward variant bit mask (1 = Q1, 2 = PRIO, 4 = TRUNC), see attn_fwd_kernel
 #define AT_FIXED_REF_MAX 64.0f   // largest Cauchy-Schwarz bound (exp2 domain) served by the fixed-reference loop
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
@@ -221,6 +222,13 @@ __device__ __forceinline__ void at_poison_rows(uint16_t* rows, int64_t row_strid
 // forward
 // ================================================================================================
 // LDS: K row-major [lp_max][16] | V^T [17][pitch] (row 16 = 1.0 for keys < L, else 0) | 8 floats (reduction)
+// Variants measured against each other in one process (PTC_ATTN_FWD bit mask, tools/bench_ops.py attn):
+//   Q1    : the scaled query q*c is rounded to ONE bf16 operand (no hi + lo split): 3 MFMAs per tile instead of 4; the logits
+//           then carry a 2^-9 relative error (flash-attn itself multiplies the fp32 product by the scale: exact)
+//   PRIO  : s_setprio 1 for the second-dispatched half of the workgroup's waves (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+//   TRUNC : P is packed to bf16 by truncation (one v_perm_b32, a full-rate VALU op) instead of v_cvt_pk_bf16_f32 (RNE, ~1.6x
+//           the issue cost); numerator and denominator use the same truncated values, so the bias cancels in the ratio
+template <bool Q1, bool PRIO, bool TRUNC>
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
                 int lp_max, int n_units, int qs, uint16_t* __restrict__ out, float* __restrict__ lse) {
@@ -260,6 +268,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 
   const int col = lane & 31, h2 = lane >> 5;
   const float c = scale * AT_LOG2E;
+  if (PRIO && wave >= AT_WAVES / 2) __builtin_amdgcn_s_setprio(1);
   // A operand of the P V product: lane col <= 16 reads image row col (16 = denominator row); lanes
   // col > 16 feed output rows nobody reads and alias rows 1..15.  One 16-byte read per 16 keys.
   const unsigned char* vbase = Vt + ((size_t)(col <= 16 ? col : (col & 15)) * pitch + 8 * h2) * 2;
@@ -301,7 +310,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
       auto s_tile = [&]() {
         const s16x8 kf = kfn;
         f32x16 sv = mfma32(kf, qhi, negb);  // S'^T[key][q] = k.(q c) - bnd: lane = q, regs = keys crow(r,h2)
-        sv = mfma32(kf, qlo, sv);
+        if (!Q1) sv = mfma32(kf, qlo, sv);
         kfn = ldk();
         return sv;
       };
@@ -312,7 +321,10 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
       // over the 4 MFMA shadows.
       auto expo = [&](const f32x16& sv, uint32_t (&pk)[8]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(sv[2 * i]), __builtin_amdgcn_exp2f(sv[2 * i + 1]));
+        for (int i = 0; i < 8; ++i) {
+          const float e0 = __builtin_amdgcn_exp2f(sv[2 * i]), e1 = __builtin_amdgcn_exp2f(sv[2 * i + 1]);
+          pk[i] = TRUNC ? __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u) : pack_bf16x2(e0, e1);
+        }
       };
       s16x8 vf0, vf1;
       auto ldv = [&]() {
@@ -326,11 +338,23 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
       };
       auto interleave = [&]() {
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);     // the trip's three LDS reads first
+        if constexpr (!Q1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA, and in its shadow:
-          __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);   //   four transcendentals (v_exp_f32)
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   //   two plain VALU (v_cvt_pk_bf16_f32)
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA, and in its shadow:
+            __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);   //   four transcendentals (v_exp_f32)
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   //   two plain VALU (v_cvt_pk_bf16_f32 / v_perm_b32)
+          }
+        } else {                                                 // three MFMAs per tile: 6 + 5 + 5 exps, 3 + 3 + 2 packs
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, 6, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, 5, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, 5, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
       };
       // S' of one tile past the end is computed and never used (it reads the V^T image: in-bounds LDS),
@@ -370,7 +394,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
         const s16x8 kf = *reinterpret_cast<const s16x8*>(kp);
         kp += 1024;
         f32x16 s = mfma32(kf, qhi, zero16());
-        s = mfma32(kf, qlo, s);
+        if (!Q1) s = mfma32(kf, qlo, s);
         if (kt == n_tiles - 1 && L < Lp) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
@@ -420,7 +444,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                    const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                   int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, float* __restrict__ delta) {
+                   int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, float* __restrict__ delta, int prio) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lunit = at_unit(n_units * qs);
   if (lunit >= n_units * qs) return;
@@ -447,6 +471,7 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
   const float c = scale * AT_LOG2E;
   const TrAddr ta = tr_addr(lane);
   const int rmo = rm_off(col, h2);
+  if (prio && wave >= AT_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // as the forward's PRIO variant (bit-identical)
 
   for (int qt = t_lo + wave; qt < t_hi; qt += AT_WAVES) {
     const int q = qt * 32 + col;
@@ -502,7 +527,7 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                     const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                    int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv) {
+                    int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, int prio) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lunit = at_unit(n_units * qs);
   if (lunit >= n_units * qs) return;
@@ -546,6 +571,7 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
   const uint32_t m1 = 0xBF80BF80u;                                              // (-1, -1) bf16
   const s16x8 bS = make_frag(h2 == 0 ? m1 : 0u, 0u, 0u, 0u);
   const s16x8 bD = make_frag(0u, h2 == 0 ? m1 : 0u, 0u, 0u);
+  if (prio && wave >= AT_WAVES / 2) __builtin_amdgcn_s_setprio(1);
 
   for (int kt = t_lo + wave; kt < t_hi; kt += AT_WAVES) {
     const int key = kt * 32 + col;
@@ -857,14 +883,25 @@ extern "C" int ptc_attn_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, i
   const int lp_max = (max_seqlen + 31) & ~31;
   const size_t lds = fwd_lds_bytes(lp_max);
   hipStream_t s = (hipStream_t)stream;
-  rc = allow_big_lds(attn_fwd_kernel, lds);
-  if (rc != PTC_OK) return rc;
   const int n_units = (int)(n_seq * H);
   const int qs = at_split(n_units, lp_max);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds, s, (const uint16_t*)qkv,
-                     cu_seqlens, H, softmax_scale, total, lp_max, n_units, qs, (uint16_t*)out, lse);
-  PTC_CHECK_LAUNCH("attn_fwd_kernel");
-  return PTC_OK;
+  int mode = AT_FWD_DEFAULT;
+  if (const char* e = getenv("PTC_ATTN_FWD")) mode = atoi(e);
+#define AT_FWD_CASE(M, Q1, PRIO, TRUNC)                                                                                        \
+  if (mode == M) {                                                                                                             \
+    rc = allow_big_lds(attn_fwd_kernel<Q1, PRIO, TRUNC>, lds);                                                                 \
+    if (rc != PTC_OK) return rc;                                                                                               \
+    hipLaunchKernelGGL((attn_fwd_kernel<Q1, PRIO, TRUNC>), dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds, s, \
+                       (const uint16_t*)qkv, cu_seqlens, H, softmax_scale, total, lp_max, n_units, qs, (uint16_t*)out, lse);   \
+    PTC_CHECK_LAUNCH("attn_fwd_kernel");                                                                                       \
+    return PTC_OK;                                                                                                             \
+  }
+  AT_FWD_CASE(0, false, false, false) AT_FWD_CASE(1, true, false, false) AT_FWD_CASE(2, false, true, false)
+  AT_FWD_CASE(4, false, false, true) AT_FWD_CASE(6, false, true, true) AT_FWD_CASE(7, true, true, true) AT_FWD_CASE(5, true, false, true)
+  AT_FWD_CASE(3, true, true, false)
+#undef AT_FWD_CASE
+  ptc_set_error("ptc_attn_varlen_fwd: PTC_ATTN_FWD=%d is not a variant", mode);
+  return PTC_EINVAL;
 }
 
 extern "C" size_t ptc_attn_varlen_bwd_workspace_bytes(int64_t total, int H) {
@@ -903,13 +940,18 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   const int n_units = (int)(n_seq * H);
   const int qs = at_split(n_units, lp_max);
   const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
+  // s_setprio 1 on waves 4..7 as in the forward: measured NEUTRAL to harmful here (H = 4: 1440 vs 1423 us, H = 2: 842 vs 776 us,
+  // profiles/r02_h_attn_variants.txt) -- the backward loops are not pinned with sched_group_barrier, so the prioritised
+  // half simply starves the other.  Off; PTC_ATTN_BWD_PRIO=1 is the A/B switch.
+  int prio = 0;
+  if (const char* e = getenv("PTC_ATTN_BWD_PRIO")) prio = atoi(e);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(grid), dim3(AT_THREADS), dq_lds_bytes(lp_max), s,
                      (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H,
-                     softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv, delta);
+                     softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv, delta, prio);
   PTC_CHECK_LAUNCH("attn_bwd_dq_kernel");
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(grid), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s,
                      (const uint16_t*)qkv, (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H,
-                     softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv);
+                     softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv, prio);
   PTC_CHECK_LAUNCH("attn_bwd_dkv_kernel");
   return PTC_OK;
 }

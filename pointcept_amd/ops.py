@@ -467,6 +467,24 @@ def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: Optional[torch.Ten
 
 
 # ------------------------------------------------------------------------------------------------
+# 3-axis rotary embedding (libs/pointrope)
+# ------------------------------------------------------------------------------------------------
+def rope3d_(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> torch.Tensor:
+    """in place on tokens [..., H, D] (contiguous, D % 6 == 0) with positions [..., 3] int64 (libs/pointrope/kernels.cu:19-100)"""
+    require_cuda(tokens, positions)
+    if tokens.dim() < 3 or not tokens.is_contiguous():
+        raise PtcoreError("tokens must be contiguous [..., H, D]")       # kernels.cu:83: "tokens are not contiguous"
+    if positions.dtype != torch.int64 or not positions.is_contiguous() or positions.shape[-1] != 3:
+        raise PtcoreError("positions must be contiguous int64 [..., 3]")
+    H, D = tokens.shape[-2], tokens.shape[-1]
+    n = tokens.numel() // (H * D) if H * D > 0 else 0
+    if positions.numel() != 3 * n:
+        raise PtcoreError(f"positions {tuple(positions.shape)} do not match tokens {tuple(tokens.shape)}")
+    check(lib().ptc_rope3d(ptr(tokens), dtype_code(tokens), ptr(positions), n, H, D, float(base), float(fwd), stream_ptr()), "ptc_rope3d")
+    return tokens
+
+
+# ------------------------------------------------------------------------------------------------
 # layer norm
 # ------------------------------------------------------------------------------------------------
 _DT = {torch.float32: _lib.PTC_F32, torch.float16: _lib.PTC_F16, torch.bfloat16: _lib.PTC_BF16}

@@ -23,6 +23,11 @@ Fixtures
                       the voxel set in np.unique (ascending key) order, min_coord and the picked representatives.
   ptv3_enc_mode.npz : reference PT-v3m1 with enc_mode=True followed by the parent-chain concatenation of
                       DefaultSegmentorV2.forward (default.py:69-74): [N, 32+64+128+256+512] features (every 32nd row, column norms).
+  ptv3m2_tiny.npz   : the reference's point_transformer_v3m2_sonata.py (GridPooling / GridUnpooling / LayerScale / Linear stem) on
+                      oracle/shims.py: depths 1/1/1/2/1 + 1/1/1/1, layer_scale 0.5, two scenes (2500 + 700 voxels): eval features
+                      (every 8th row), train-mode loss and the gradient norm of every parameter, the state-dict key list.
+  pointrope.npz     : tokens / positions -> pointrope_cpu of libs/pointrope/pointrope.cpp:13-49 (compiled from the reference tree by
+                      oracle/build_ref.py), four shapes (D = 18, 24, 48, 6; F0 = +-1).
   lovasz.npz        : logits / labels -> LovaszLoss(mode="multiclass", ignore_index=-1) loss and gradient
                       (pointcept/models/losses/lovasz.py), five shapes incl. absent classes and a single point.
 """
@@ -49,6 +54,9 @@ RPE_CFG = dict(TINY_CFG, enc_patch_size=(256,) * 5, dec_patch_size=(256,) * 4, e
                upcast_attention=True, upcast_softmax=True)
 ENC_CFG = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), enc_channels=(32, 64, 128, 256, 512),
                enc_num_head=(2, 4, 8, 16, 32), enc_patch_size=(128,) * 5, drop_path=0.0, shuffle_orders=False)
+M2_CFG = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 2, 1), enc_channels=(32, 64, 128, 256, 512), enc_num_head=(2, 4, 8, 16, 32),
+              dec_depths=(1, 1, 1, 1), dec_channels=(64, 64, 128, 256), dec_num_head=(4, 4, 8, 16), enc_patch_size=(128,) * 5,
+              dec_patch_size=(128,) * 4, drop_path=0.0, shuffle_orders=False, layer_scale=0.5)
 SPUNET_CFG = dict(base_channels=16, channels=(16, 32, 48, 64, 64, 48, 32, 32), layers=(1, 2, 1, 1, 1, 1, 2, 1))
 
 
@@ -212,8 +220,52 @@ def main():
         feat_rows=feat[::32].astype(np.float32), feat_absmax=np.asarray(float(np.abs(feat).max())),
         feat_col_norm=np.linalg.norm(feat.astype(np.float64), axis=0).astype(np.float32))
 
-    # ---- Lovasz-Softmax ------------------------------------------------------------------------
+    # ---- PT-v3m2 (Sonata backbone) tiny -----------------------------------------------------------
     import importlib
+    m2 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m2_sonata")
+    torch.manual_seed(0)
+    ref = m2.PointTransformerV3(**M2_CFG)
+    sd = om.deterministic_state_dict(ref, 33)
+    ref.load_state_dict(sd)
+    batch = synthetic.collate([synthetic.indoor_scene(61, 2500), synthetic.indoor_scene(62, 700)])
+    inp = {k: torch.from_numpy(v) for k, v in batch.items()}
+    inp["grid_size"] = 0.02
+    ref.eval()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        out_eval = ref(dict(inp)).feat.numpy()
+    ref.train()
+    torch.manual_seed(5)
+    f = ref(dict(inp)).feat
+    loss = (f * torch.linspace(-1, 1, f.shape[1])).pow(2).mean()
+    loss.backward()
+    names = [k for k, _ in ref.named_parameters()]
+    np.savez_compressed(
+        os.path.join(OUT, "ptv3m2_tiny.npz"), scene_seeds=np.asarray([61, 62]), n_points=np.asarray([2500, 700]),
+        input_checksum=np.asarray([batch["grid_coord"].sum(), float(batch["feat"].astype(np.float64).sum())]),
+        weight_checksum=np.asarray(float(sum(float(v.double().abs().sum()) for v in sd.values()))),
+        state_keys=np.asarray(list(sd.keys())), feat_rows=out_eval[::8].astype(np.float32), feat_absmax=np.asarray(np.abs(out_eval).max()),
+        loss=np.asarray(float(loss.detach())), grad_names=np.asarray(names),
+        grad_norms=np.asarray([float(p.grad.norm()) for _, p in ref.named_parameters()], dtype=np.float64))
+
+    # ---- libs/pointrope: the reference's own pointrope_cpu, compiled by oracle/build_ref.py ------------
+    from oracle import build_ref
+    ext = build_ref.build_pointrope()
+    blobs = {}
+    cases = [(2, 37, 2, 18, 100.0, 1.0), (1, 200, 4, 24, 100.0, -1.0), (3, 16, 3, 48, 10.0, 1.0), (1, 5, 1, 6, 100.0, 1.0)]
+    for ci, (B, N, H, D, base, fwd) in enumerate(cases):
+        g = torch.Generator().manual_seed(700 + ci)
+        tok = torch.randn(B, N, H, D, generator=g)
+        pos = torch.randint(0, 300, (B, N, 3), generator=g)
+        out = tok.clone()
+        ext.pointrope(out, pos, base, fwd)
+        blobs[f"shape_{ci}"] = np.asarray([B, N, H, D], dtype=np.int64)
+        blobs[f"params_{ci}"] = np.asarray([base, fwd], dtype=np.float64)
+        blobs[f"tokens_{ci}"], blobs[f"pos_{ci}"], blobs[f"out_{ci}"] = tok.numpy(), pos.numpy(), out.numpy()
+    blobs["n_cases"] = np.asarray(len(cases))
+    np.savez_compressed(os.path.join(OUT, "pointrope.npz"), **blobs)
+
+    # ---- Lovasz-Softmax ------------------------------------------------------------------------
     import types
     pkg = types.ModuleType("pointcept.models.losses")
     pkg.__path__ = [ref_import.REF + "/pointcept/models/losses"]

@@ -371,3 +371,24 @@ def test_ops_refuse_cpu_tensors():
     for d in (16, 24):     # kernel path and library path alike
         with pytest.raises(PtcoreError, match="no CPU fallback"):
             flash_attn_varlen_qkvpacked_func(torch.zeros(8, 3, 2, d, dtype=torch.bfloat16), torch.tensor([0, 8], dtype=torch.int32), 8)
+
+
+def test_oracle_pointrope_matches_reference_golden():
+    """oracle/pointrope.py (the CUDA kernel's formula, numpy fp32) against tests/golden/pointrope.npz = the reference's own
+    pointrope_cpu (libs/pointrope/pointrope.cpp:13-49, compiled by oracle/build_ref.py); and its defining properties:
+    the rotation is orthogonal (norms of every (u, v) pair kept) and F0 -> -F0 undoes it (that IS the backward)."""
+    from oracle import pointrope as orope
+
+    g = np.load(os.path.join(GOLD, "pointrope.npz"))
+    for ci in range(int(g["n_cases"])):
+        tok, pos, ref = g[f"tokens_{ci}"], g[f"pos_{ci}"], g[f"out_{ci}"]
+        base, fwd = (float(v) for v in g[f"params_{ci}"])
+        out = orope.pointrope(tok, pos, base, fwd)
+        assert np.abs(out - ref).max() < 2e-4 * np.abs(ref).max(), ci      # fp32 sin/cos of arguments up to ~300 rad
+        back = orope.pointrope(out, pos, base, -fwd)
+        assert np.abs(back - tok).max() < 5e-4 * np.abs(tok).max(), ci
+        Q = tok.shape[-1] // 6
+        for a in range(3):
+            n_in = tok[..., a * 2 * Q:a * 2 * Q + Q] ** 2 + tok[..., a * 2 * Q + Q:a * 2 * Q + 2 * Q] ** 2
+            n_out = out[..., a * 2 * Q:a * 2 * Q + Q] ** 2 + out[..., a * 2 * Q + Q:a * 2 * Q + 2 * Q] ** 2
+            assert np.allclose(n_in, n_out, rtol=1e-4, atol=1e-5)

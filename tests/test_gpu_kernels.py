@@ -358,6 +358,38 @@ def test_spconv_fwd_coalesced_bounce_is_bit_identical(cuda, cin, cout, ksize, mo
     _close("conv3_bnc", got, oops.gather_conv(feat.float().cpu(), w.float().cpu(), bias.cpu(), nbr), 1.0 / 128, 2e-3)
 
 
+@pytest.mark.parametrize("cin,cout,ksize", [(32, 32, 3), (32, 64, 3), (64, 64, 3), (64, 32, 3), (64, 96, 3), (64, 128, 3), (128, 128, 3), (128, 96, 3),
+                                            (128, 64, 3), (32, 96, 3), (64, 128, 2), (128, 64, 2), (32, 64, 5)])
+def test_spconv_fwd_whole_line_gathers_are_bit_identical(cuda, cin, cout, ksize, monkeypatch):
+    """conv5 (whole-row coalesced gathers + swizzled wave-private tile images, line-coalesced W staging) feeds the MFMAs
+    the same operands in the same order as conv3's direct gathers: outputs must be IDENTICAL, for both workgroup
+    shapes, ragged row counts, bf16 and f16; and within the 16-bit bar of the fp32 oracle."""
+    from pointcept_amd import ops
+
+    monkeypatch.setenv("PTC_CONV3_C32", "1")
+    monkeypatch.setenv("PTC_CONV5_C128", "1")
+    ind = _scene_indices(2100)
+    nbr = oops.down_rulebook(ind)[2] if ksize == 2 else oops.subm_rulebook(ind, ksize)
+    kv = nbr.shape[0]
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    nbr_d = _t(nbr, cuda)
+    for dtype in (torch.bfloat16, torch.float16):
+        feat = (torch.randn(ind.shape[0], cin, generator=g) * 0.5).to(dtype).to(cuda)
+        w = (torch.randn(cout, kv, cin, generator=g) / (kv * cin) ** 0.5 * 2).to(dtype).to(cuda)
+        bias = torch.randn(cout, generator=g).to(cuda)
+        for rt in ("2", "4"):
+            monkeypatch.setenv("PTC_CONV3_RT", rt)
+            monkeypatch.setenv("PTC_CONV3_BNC", "0")
+            monkeypatch.setenv("PTC_CONV5", "0")
+            base = ops.spconv_fwd(feat, w, bias, nbr_d)
+            monkeypatch.setenv("PTC_CONV5", "1")
+            got = ops.spconv_fwd(feat, w, bias, nbr_d)
+            assert torch.isfinite(got.float()).all()
+            assert torch.equal(got, base), f"{dtype} rt={rt}: max diff {(got.float() - base.float()).abs().max().item()}"
+        rtol, atol = _tols(dtype)
+        _close(f"conv5_{dtype}", got, oops.gather_conv(feat.float().cpu(), w.float().cpu(), bias.cpu(), nbr), rtol, atol)
+
+
 def _curve_sorted_indices(n_pts, batch=2):
     """scene indices with rows in Hilbert order (what PTC_SORT_POINTS / the SpUNet entry sort give the kernels)"""
     from pointcept_amd import synthetic
@@ -1336,3 +1368,59 @@ def test_pointops_through_compat_and_unsupported(cuda):
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+# ------------------------------------------------------------------------------------------------
+# libs/pointrope
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_rope3d_matches_reference_golden_and_oracle(cuda, dtype):
+    """ptc_rope3d (csrc/rope.hip) through the pointrope operator API against (a) the golden outputs of the reference's own
+    pointrope_cpu and (b) the numpy oracle on the same inputs; in place, as the extension."""
+    import os
+
+    from oracle import pointrope as orope
+    from pointcept_amd import pointrope_api
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pointrope.npz"))
+    for ci in range(int(g["n_cases"])):
+        tok, pos, ref = g[f"tokens_{ci}"], g[f"pos_{ci}"], g[f"out_{ci}"]
+        base, fwd = (float(v) for v in g[f"params_{ci}"])
+        t = _t(tok, cuda).to(dtype).contiguous()
+        t_in = t.float().cpu().numpy()
+        p = _t(pos, cuda)
+        ret = pointrope_api.pointrope(t, p, base, fwd)
+        assert ret is None                                              # in place
+        got = t.float().cpu().numpy()
+        tol = {torch.float32: 2e-4, torch.bfloat16: 1.0 / 128, torch.float16: 1.0 / 512}[dtype] * np.abs(ref).max()
+        assert np.abs(got - orope.pointrope(t_in, pos, base, fwd)).max() <= tol, ci      # oracle on the SAME rounded inputs
+        if dtype == torch.float32:
+            assert np.abs(got - ref).max() <= tol, ci                   # reference golden
+
+
+def test_rope3d_autograd_is_the_inverse_rotation(cuda):
+    """PointROPE_func (litept_v1.py:27-46): backward = the same kernel with -F0; checked against autograd through the
+    oracle's formula in torch, and as a round trip."""
+    from pointcept_amd import pointrope_api
+
+    g = torch.Generator().manual_seed(5)
+    B, H, N, D = 2, 3, 77, 24
+    x = torch.randn(B, H, N, D, generator=g).to(cuda).requires_grad_(True)
+    pos = torch.randint(0, 200, (B, N, 3), generator=g).to(cuda)
+    rope = pointrope_api.PointROPE(freq=100.0, F0=1.0)
+    y = rope(x, pos)
+    w = torch.randn(y.shape, generator=g).to(cuda)
+    (y * w).sum().backward()
+    # reference formula in torch (differentiable)
+    xr = x.detach().clone().requires_grad_(True)
+    Q = D // 6
+    inv = 1.0 / (100.0 ** (torch.arange(Q, device=cuda, dtype=torch.float32) / Q))
+    parts = []
+    for a in range(3):
+        f = pos[:, None, :, a, None].float() * inv
+        u, v = xr[..., a * 2 * Q:a * 2 * Q + Q], xr[..., a * 2 * Q + Q:a * 2 * Q + 2 * Q]
+        parts += [u * f.cos() - v * f.sin(), v * f.cos() + u * f.sin()]
+    yr = torch.cat(parts, dim=-1)
+    (yr * w).sum().backward()
+    _close("rope_fwd", y, yr, 1e-4, 1e-4)
+    _close("rope_bwd", x.grad, xr.grad, 1e-4, 1e-4)

@@ -365,3 +365,49 @@ def test_ptv3_enc_mode_chain_matches_reference_golden_and_oracle(cuda):
     assert (num / den) ** 0.5 < 0.1, (num / den) ** 0.5
     big = max(r[1] for r in rows)
     assert all(a < 0.2 for a, b, _ in rows if b > 1e-2 * big), [r for r in rows if r[1] > 1e-2 * big and r[0] >= 0.2][:5]
+
+
+M2_CFG = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 2, 1), enc_channels=(32, 64, 128, 256, 512), enc_num_head=(2, 4, 8, 16, 32),
+              dec_depths=(1, 1, 1, 1), dec_channels=(64, 64, 128, 256), dec_num_head=(4, 4, 8, 16), enc_patch_size=(128,) * 5,
+              dec_patch_size=(128,) * 4, drop_path=0.0, shuffle_orders=False, layer_scale=0.5)   # = tests/golden/make_golden.py M2_CFG
+
+
+def test_ptv3m2_matches_reference_golden(cuda):
+    """the engine's module-level PT-v3m2 (GridPooling / GridUnpooling / LayerScale / Linear stem,
+    pointcept_amd/point_transformer_v3m2.py) against tests/golden/ptv3m2_tiny.npz = the REFERENCE's own
+    point_transformer_v3m2_sonata.py: state-dict keys, eval features, train-mode loss and every gradient norm."""
+    from oracle import ptv3_model as om
+    from pointcept_amd import synthetic
+    from pointcept_amd.point_transformer_v3m2 import PointTransformerV3 as M2
+
+    g = np.load(os.path.join(GOLD, "ptv3m2_tiny.npz"))
+    torch.manual_seed(0)
+    eng = M2(**M2_CFG)
+    assert list(eng.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    sd = om.deterministic_state_dict(eng, 33)
+    assert abs(float(sum(float(v.double().abs().sum()) for v in sd.values())) - float(g["weight_checksum"])) < 1e-6 * float(g["weight_checksum"])
+    eng.load_state_dict(sd)
+    eng = eng.to(cuda)
+    batch = synthetic.collate([synthetic.indoor_scene(int(s), int(n)) for s, n in zip(g["scene_seeds"], g["n_points"])])
+    assert batch["grid_coord"].sum() == g["input_checksum"][0]
+    inp = synthetic.to_torch(batch, cuda)
+    inp["grid_size"] = 0.02
+    eng.eval()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        out = eng(dict(inp)).feat.float().cpu().numpy()
+    assert np.isfinite(out).all()
+    err = np.abs(out[::8] - g["feat_rows"]).max() / float(g["feat_absmax"])
+    assert err < 2e-2, f"engine PT-v3m2 vs reference golden: rel err {err:.3e}"
+    eng.train()
+    torch.manual_seed(5)
+    f = eng(dict(inp)).feat
+    loss = (f * torch.linspace(-1, 1, f.shape[1], device=f.device)).pow(2).mean()
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 2e-2 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    ref = dict(zip([str(k) for k in g["grad_names"]], g["grad_norms"]))
+    gmax = max(ref.values())
+    for name, p in eng.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        gn, rn = float(p.grad.norm()), ref[name]
+        assert abs(gn - rn) <= 0.1 * rn + 1e-4 * gmax, (name, gn, rn)

@@ -401,3 +401,46 @@ def test_cast_cache_lifetime_and_invalidation():
     gc.collect()
     assert len(c.entries) == 1                                                       # the entry died with its parameter
     assert c.get(q[:8], torch.bfloat16).shape == (8, 16) and len(c.entries) == 1     # partial views are never cached
+
+
+M2_TINY = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), enc_channels=(32, 64, 128, 256, 512), enc_num_head=(2, 4, 8, 16, 32),
+               dec_depths=(1, 1, 1, 1), dec_channels=(64, 64, 128, 256), dec_num_head=(4, 4, 8, 16), enc_patch_size=(128,) * 5,
+               dec_patch_size=(128,) * 4, drop_path=0.0, shuffle_orders=False)
+
+
+@pytest.mark.needs_reference
+@pytest.mark.parametrize("layer_scale", [None, 0.5])
+def test_ptv3m2_module_port_matches_the_reference_file(layer_scale):
+    """the engine's module-level PT-v3m2 (pointcept_amd/point_transformer_v3m2.py: GridPooling /
+    GridUnpooling / LayerScale / Linear stem) against the REFERENCE's own point_transformer_v3m2_sonata.py on the oracle's
+    third-party stand-ins: same state-dict keys and shapes, same features, same gradients, ragged two-scene batch."""
+    import importlib
+
+    from oracle import ptv3_model as om
+    from oracle import ref_import
+    from pointcept_amd.point_transformer_v3m2 import PointTransformerV3 as EngM2
+
+    ref_import.load()
+    R_m2 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m2_sonata")
+    cfg = dict(M2_TINY, layer_scale=layer_scale)
+    torch.manual_seed(0)
+    ref, eng = R_m2.PointTransformerV3(**cfg), EngM2(**cfg)
+    assert list(ref.state_dict().keys()) == list(eng.state_dict().keys())
+    for (k, a), (_, b) in zip(ref.state_dict().items(), eng.state_dict().items()):
+        assert a.shape == b.shape, k
+    sd = om.deterministic_state_dict(ref, 31)
+    ref.load_state_dict(sd)
+    eng.load_state_dict(sd)
+    mb = _batch([700, 260], seed0=610)
+    mb["grid_size"] = 0.02
+    feats = []
+    with mock_backend.cpu_ops():
+        for net in (ref, eng):
+            net.train()
+            torch.manual_seed(9)
+            f = net({k: v for k, v in mb.items()}).feat
+            (f * torch.linspace(-1, 1, f.shape[1])).pow(2).mean().backward()
+            feats.append(f.detach())
+    assert feats[0].shape == feats[1].shape == (960, 64)
+    assert _rel(feats[1], feats[0]) < 1e-3
+    _grad_check(eng, ref, 3e-2)

@@ -185,3 +185,20 @@ def test_pdnorm_state_dict_and_module_semantics(R):
             pa = a(R["structure"].Point(feat=x.clone(), condition=cond, context=ctx, offset=torch.tensor([50])))
             pb = b(AttrDict(feat=x.clone(), condition=cond, context=ctx))
             assert torch.allclose(pa.feat, pb["feat"], atol=1e-6)
+
+
+def test_pointrope_oracle_vs_reference_build():
+    """oracle/pointrope.py live against the reference's pointrope_cpu (oracle/_ref, built from
+    /root/reference/libs/pointrope/pointrope.cpp by oracle/build_ref.py) on fresh random inputs, several head dims."""
+    from oracle import build_ref
+    from oracle import pointrope as orope
+
+    ext = build_ref.build_pointrope()
+    g = torch.Generator().manual_seed(99)
+    for B, N, H, D, base, fwd in ((2, 50, 2, 18, 100.0, 1.0), (1, 300, 3, 36, 100.0, -1.0), (4, 9, 1, 48, 1000.0, 1.0)):
+        tok = torch.randn(B, N, H, D, generator=g)
+        pos = torch.randint(0, 500, (B, N, 3), generator=g)
+        ref = tok.clone()
+        ext.pointrope(ref, pos, base, fwd)
+        out = orope.pointrope(tok.numpy(), pos.numpy(), base, fwd)
+        assert np.abs(out - ref.numpy()).max() < 3e-4 * float(ref.abs().max())

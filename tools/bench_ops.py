@@ -101,15 +101,31 @@ def bench_attention(rows, n_seq, H, results, L=1024):
     by_f = T * H * 16 * 2 * 4
     r = {"shape": [n_seq, L, H]}
     r["fwd"] = roof(by_f, fl_f, timeit(lambda: ops.attn_varlen_fwd(qkv, cu, L, sc), iters=10))
+    # forward variants (PTC_ATTN_FWD bit mask: 1 = single-bf16 scaled query, 2 = s_setprio on the younger waves, 4 = truncating pack)
+    os.environ["PTC_ATTN_FWD"] = "0"
+    base_out = ops.attn_varlen_fwd(qkv, cu, L, sc)[0].float()
+    var = []
+    for m in range(8):
+        os.environ["PTC_ATTN_FWD"] = str(m)
+        t = timeit(lambda: ops.attn_varlen_fwd(qkv, cu, L, sc), iters=10)
+        o = ops.attn_varlen_fwd(qkv, cu, L, sc)[0].float()
+        var.append((m, t * 1e6, float((o - base_out).abs().max() / base_out.abs().max())))
+    os.environ.pop("PTC_ATTN_FWD", None)
+    r["fwd_variants"] = var
     r["bwd"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
                     timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
+    os.environ["PTC_ATTN_BWD_PRIO"] = "1"
+    r["bwd_noprio"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
+                           timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
+    os.environ.pop("PTC_ATTN_BWD_PRIO", None)
     os.environ["PTC_ATTN_BWD"] = "1"
     r["bwd2"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
                      timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
     os.environ.pop("PTC_ATTN_BWD", None)
     results.append(r)
     rows.append(f"attention n_seq={n_seq:4d} L={L} H={H:2d} | fwd {r['fwd']['us']:8.1f} us {r['fwd']['TFLOPs']:7.1f} TF/s | "
-                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s | bwd single-pass (experiment) {r['bwd2']['us']:8.1f} us (10 L^2 D)")
+                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s (with s_setprio: {r['bwd_noprio']['us']:8.1f}) | bwd single-pass (experiment) {r['bwd2']['us']:8.1f} us (10 L^2 D)")
+    rows.append("    fwd variants (mask: us, max|diff|/max|out| vs mask 0): " + "  ".join(f"{m}: {t:.1f} us {d:.1e}" for m, t, d in r["fwd_variants"]))
 
 
 def bench_spconv(rows, results, scenes=8, points=102400):
@@ -191,16 +207,19 @@ def bench_spconv_stages(rows, results, scenes=8, points=102400):
             fl = 2.0 * pairs * ci * c
             r = {"stage": s, "n": n, "c_in": ci, "c": c, "pairs": pairs}
             os.environ["PTC_CONV3_C32"] = "1"
-            for name, flag, bnc in (("conv2", "0", "0"), ("conv3d", "1", "0"), ("conv3", "1", "1")):
+            for name, flag, bnc, c5 in (("conv2", "0", "0", "0"), ("conv3d", "1", "0", "0"), ("conv3", "1", "1", "0"), ("conv5", "1", "0", "1"),
+                                        ("conv5rt2", "1", "0", "1")):
                 os.environ["PTC_CONV3"] = flag
                 os.environ["PTC_CONV3_BNC"] = bnc
+                os.environ["PTC_CONV5"] = c5
+                if name == "conv5rt2":
+                    os.environ["PTC_CONV3_RT"] = "2"
                 try:
                     r[name] = roof(by, fl, timeit(lambda: ops.spconv_fwd(x, w, bias, nbr), iters=10))
                 except Exception as e:   # an unsupported instantiation must not cost the rest of the table
                     r[name] = {"us": float("nan"), "GBps": 0.0, "TFLOPs": 0.0, "roof_frac": 0.0, "error": repr(e)}
-            os.environ.pop("PTC_CONV3", None)
-            os.environ.pop("PTC_CONV3_BNC", None)
-            os.environ.pop("PTC_CONV3_C32", None)
+            for e in ("PTC_CONV3", "PTC_CONV3_BNC", "PTC_CONV3_C32", "PTC_CONV5", "PTC_CONV3_RT"):
+                os.environ.pop(e, None)
             plan = ops.block_plan(ci, c, 27, torch.bfloat16)
             c4 = ""
             if plan is not None:
@@ -215,8 +234,8 @@ def bench_spconv_stages(rows, results, scenes=8, points=102400):
             g = torch.randn(n, c, device=DEV).to(torch.bfloat16)
             r["wgrad"] = roof(by, fl, timeit(lambda: ops.spconv_wgrad(x, g, nbr), iters=10))
             results.append(r)
-            rows.append(f"conv stage {s} n={n:7d} {ci:3d}->{c:3d} pairs/pt={pairs / n:5.2f} | conv2 {r['conv2']['us']:8.1f} us | conv3 direct {r['conv3d']['us']:8.1f} us | conv3 bounce {r['conv3']['us']:8.1f} us "
-                        f"({r['conv3']['GBps']:.0f} GB/s alg, {r['conv3']['TFLOPs']:.1f} TF/s){c4} | wgrad {r['wgrad']['us']:8.1f} us ({r['wgrad']['TFLOPs']:.1f} TF/s)")
+            rows.append(f"conv stage {s} n={n:7d} {ci:3d}->{c:3d} pairs/pt={pairs / n:5.2f} | conv2 {r['conv2']['us']:8.1f} us | conv3 direct {r['conv3d']['us']:8.1f} us | conv3 bounce {r['conv3']['us']:8.1f} us | conv5 {r['conv5']['us']:8.1f} us (RT=2: {r['conv5rt2']['us']:8.1f}) "
+                        f"({r['conv5']['GBps']:.0f} GB/s alg, {r['conv5']['TFLOPs']:.1f} TF/s){c4} | wgrad {r['wgrad']['us']:8.1f} us ({r['wgrad']['TFLOPs']:.1f} TF/s)")
 
 
 def bench_losses(rows, results, n=819200, c=20):

@@ -19,10 +19,12 @@ for sec in "$@"; do
     ops:*) timeout 900 python tools/bench_ops.py --only ${sec#ops:} > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log; cat $O/${TAG}_ops.log | cut -c1-220;;
     test:*) timeout 1500 python -m pytest tests -q -m gpu -k "${sec#test:}" > $O/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> $O/${TAG}_env.log; tail -15 $O/${TAG}_tests.log;;
     probe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_gfx950 tools/probe_gfx950.hip > $O/${TAG}_probe.log 2>&1 && timeout 300 /tmp/probe_gfx950 >> $O/${TAG}_probe.log 2>&1; tail -20 $O/${TAG}_probe.log | cut -c1-200;;
+    pgather) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_gather tools/probe_gather.hip > $O/${TAG}_probe_gather.log 2>&1 && timeout 300 /tmp/probe_gather >> $O/${TAG}_probe_gather.log 2>&1; cat $O/${TAG}_probe_gather.log | cut -c1-250;;
     opsq) timeout 900 python tools/bench_ops.py --quick > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log;;
     bench) timeout 900 python bench.py --steps 10 --warmup 3 > $O/${TAG}_bench.log 2>&1; echo "bench rc=$?" >> $O/${TAG}_env.log; tail -1 $O/${TAG}_bench.log | cut -c1-330;;
     smoke) timeout 600 python __graft_entry__.py --smoke > $O/${TAG}_smoke.log 2>&1; echo "smoke rc=$?" >> $O/${TAG}_env.log; tail -2 $O/${TAG}_smoke.log;;
     trace) timeout 600 python tools/trace_step.py > $O/${TAG}_trace_step.txt 2>$O/${TAG}_trace_step.err; echo "trace rc=$?" >> $O/${TAG}_env.log; head -5 $O/${TAG}_trace_step.txt;;
+    copies) timeout 600 python tools/trace_copies.py > $O/${TAG}_trace_copies.txt 2>$O/${TAG}_trace_copies.err; echo "copies rc=$?" >> $O/${TAG}_env.log; head -30 $O/${TAG}_trace_copies.txt;;
     spunet) timeout 900 python bench.py --model spunet --steps 6 --warmup 2 > $O/${TAG}_spunet.log 2>&1; echo "spunet rc=$?" >> $O/${TAG}_env.log; tail -1 $O/${TAG}_spunet.log | cut -c1-400;;
     profspunet) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profsp -- python $R/bench.py --model spunet --steps 3 --warmup 2 > $O/${TAG}_profsp.log 2>&1
           cd $R; TOP=30 python tools/prof_top.py $O/${TAG}_profsp 5 $O/${TAG}_spunet_kernel_stats.csv > $O/${TAG}_profsp_top.log 2>&1; rm -rf $O/${TAG}_profsp;;
@@ -51,7 +53,7 @@ for sec in "$@"; do
             timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE -d $O/${TAG}_ck_${cs}_sq -- python $R/tools/conv_kernels.py > $O/${TAG}_ck_${cs}_sq.log 2>&1
             timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU -d $O/${TAG}_ck_${cs}_sq2 -- python $R/tools/conv_kernels.py > $O/${TAG}_ck_${cs}_sq2.log 2>&1
             cd $R; python tools/pmc_summary.py --stats $O/${TAG}_ck_${cs}_stats --pmc $O/${TAG}_ck_${cs}_fetch $O/${TAG}_ck_${cs}_write $O/${TAG}_ck_${cs}_tcc $O/${TAG}_ck_${cs}_tcp $O/${TAG}_ck_${cs}_sq $O/${TAG}_ck_${cs}_sq2 \
-              --kernels conv3_kernel,conv2_kernel,wgrad2_kernel,wgrad_reduce_kernel,linear2_kernel,rulebook_subm_kernel,hash_insert --out $O/${TAG}_conv_pmc_${cs}.json > $O/${TAG}_conv_pmc_${cs}.log 2>&1
+              --kernels conv5_kernel,conv3_kernel,conv2_kernel,wgrad2_kernel,wgrad_reduce_kernel,linear2_kernel,rulebook_subm_kernel,hash_insert --out $O/${TAG}_conv_pmc_${cs}.json > $O/${TAG}_conv_pmc_${cs}.log 2>&1
             grep CONVKERNELS $O/${TAG}_ck_${cs}_stats.log > $O/${TAG}_conv_info_${cs}.txt
             rm -rf $O/${TAG}_ck_${cs}_stats $O/${TAG}_ck_${cs}_fetch $O/${TAG}_ck_${cs}_write $O/${TAG}_ck_${cs}_tcc $O/${TAG}_ck_${cs}_tcp $O/${TAG}_ck_${cs}_sq $O/${TAG}_ck_${cs}_sq2
             cd /tmp

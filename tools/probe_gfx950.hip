@@ -100,8 +100,11 @@ __global__ void __launch_bounds__(1024) tp_probe(float* out, uint64_t* cycles, f
 
 // ---- instruction-mix probe: the forward attention trip (4 MFMA 32x32x16 on two dependent pairs, NE
 // v_exp_f32, NC v_cvt_pk_bf16_f32), hand-interleaved as in attn_fwd_kernel.  Gives the floor of that mix.
-template <int NE, int NC, int NM>
+// PRIO: s_setprio 1 on the second-dispatched half of the workgroup's waves (MI355X_MICROARCH.md "two waves per SIMD" item 4);
+// PERM: the packs are v_perm_b32 (truncating bf16 pack, full-rate VALU) instead of v_cvt_pk_bf16_f32
+template <int NE, int NC, int NM, bool PRIO = false, bool PERM = false>
 __global__ void __launch_bounds__(1024) mix_probe(float* out, uint64_t* cycles, float seed) {
+  if (PRIO && (threadIdx.x >> 6) >= (blockDim.x >> 7)) __builtin_amdgcn_s_setprio(1);
   float r[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) r[i] = seed + 0.001f * (threadIdx.x + i);
@@ -122,8 +125,10 @@ __global__ void __launch_bounds__(1024) mix_probe(float* out, uint64_t* cycles, 
 #pragma unroll
       for (int i = (NE * m) / G; i < (NE * (m + 1)) / G; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i & 15]));
 #pragma unroll
-      for (int i = (NC * m) / G; i < (NC * (m + 1)) / G; ++i)
-        asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(r[i & 15]) : "v"(r[(i + 8) & 15]));
+      for (int i = (NC * m) / G; i < (NC * (m + 1)) / G; ++i) {
+        if (PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r[i & 15]) : "v"(r[(i + 8) & 15]), "s"(0x07060302));
+        else asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(r[i & 15]) : "v"(r[(i + 8) & 15]));
+      }
     }
   }
   const uint64_t t1 = __builtin_readcyclecounter();
@@ -134,7 +139,7 @@ __global__ void __launch_bounds__(1024) mix_probe(float* out, uint64_t* cycles, 
   if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
-template <int NE, int NC, int NM>
+template <int NE, int NC, int NM, bool PRIO = false, bool PERM = false>
 static int run_mix(const char* name, float* dout, uint64_t* dcyc) {
   const int waves_per_simd[3] = {1, 2, 4};
   printf("%-34s", name);
@@ -144,10 +149,10 @@ static int run_mix(const char* name, float* dout, uint64_t* dcyc) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
-    hipLaunchKernelGGL((mix_probe<NE, NC, NM>), dim3(blocks), dim3(threads), 0, 0, dout, dcyc, 0.5f);
+    hipLaunchKernelGGL((mix_probe<NE, NC, NM, PRIO, PERM>), dim3(blocks), dim3(threads), 0, 0, dout, dcyc, 0.5f);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
-    hipLaunchKernelGGL((mix_probe<NE, NC, NM>), dim3(blocks), dim3(threads), 0, 0, dout, dcyc, 0.5f);
+    hipLaunchKernelGGL((mix_probe<NE, NC, NM, PRIO, PERM>), dim3(blocks), dim3(threads), 0, 0, dout, dcyc, 0.5f);
     CK(hipEventRecord(b));
     CK(hipDeviceSynchronize());
     float ms = 0;
@@ -232,6 +237,9 @@ int main() {
   run_mix<16, 0, 0>("16 exp", fo, cyc);
   run_mix<16, 8, 0>("16 exp + 8 cvt", fo, cyc);
   run_mix<16, 8, 4>("4 mfma + 16 exp + 8 cvt (fwd)", fo, cyc);
+  run_mix<16, 8, 4, true, false>("  same, s_setprio 1 on 2nd half", fo, cyc);
+  run_mix<16, 8, 4, false, true>("  same, packs = v_perm_b32", fo, cyc);
+  run_mix<16, 8, 3, true, true>("3 mfma + 16 exp + 8 perm + prio", fo, cyc);
   run_mix<8, 8, 4>("4 mfma + 8 exp + 8 cvt", fo, cyc);
   run_mix<16, 8, 3>("3 mfma + 16 exp + 8 cvt", fo, cyc);
   run_mix<0, 8, 4>("4 mfma + 8 cvt", fo, cyc);
