@@ -261,6 +261,19 @@ int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32
                      void* workspace, size_t workspace_bytes, ptc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * G1a. Evaluation tail of the segmentation step in one pass.
+ * Replaces pred = seg_logits.max(1)[1]; pred = pred[inverse]; intersection_and_union_gpu(pred, segment, K, ignore)
+ * (pointcept/engines/hooks/evaluator.py:139-152, pointcept/utils/misc.py:57-69: three torch.histc).
+ *   logits [n_rows, c] of `dtype`, row pitch `row_stride` elements (or NULL and pred [m] int64 given instead);
+ *   inverse [m] int64 (evaluated point -> logit row) or NULL (identity); target [m] int64;
+ *   hist3k [3][k] int64: intersection, area_output (ignored targets excluded), area_target;  union = [1] + [2] - [0].
+ *   arg-max ties -> lowest class.  k <= 1024.
+ * ------------------------------------------------------------------------------------------ */
+int ptc_seg_eval_hist(const void* logits, int dtype, int64_t row_stride, int c, const int64_t* pred, const int64_t* inverse,
+                      const int64_t* target, int64_t m, int64_t n_rows, int k, int64_t ignore_index, int64_t* hist3k,
+                      ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * G1b. 3-axis rotary embedding on point tokens, IN PLACE (LitePT / PT-v3m3 "PointROPE").
  * Replaces libs/pointrope/kernels.cu:19-100 behind pointrope.pointrope(tokens, positions, base, F0)
  * (libs/pointrope/pointrope.cpp:51-67; call sites pointcept/models/litept/litept_v1.py:27-59,240-241).
@@ -391,6 +404,16 @@ int ptc_knn_query(const float* xyz, const int32_t* offset, const float* new_xyz,
                   int64_t n, int64_t m, int nsample, int32_t* idx, float* dist, ptc_stream_t stream);
 int ptc_farthest_point_sampling(const float* xyz, const int32_t* offset, const int32_t* new_offset, int b, int64_t n,
                                 float* tmp, int32_t* idx, ptc_stream_t stream);
+/* Ball query and random ball query (libs/pointops/src/ball_query/ball_query_cuda_kernel.cu:59-123,
+ * src/random_ball_query/random_ball_query_cuda_kernel.cu:58-108; wrappers libs/pointops/functions/query.py:29-113).
+ * In range: d2 <= 1e-5 or min_radius^2 <= d2 < max_radius^2, inside the query's own scene.
+ *   order == NULL : all in-range points (first 2048 in index order) sorted by (distance, index); <= nsample -> all + padding
+ *                   (idx -1, dist2 1e10), else the nsample ranks int(i * float(count) / nsample).
+ *   order != NULL : int32 [n], a permutation of every scene's point indices: the first nsample in-range points in that order.
+ * Outputs idx [m, nsample] int32, dist2 [m, nsample] fp32 (SQUARED distances; the python wrapper takes the root). */
+int ptc_ball_query(const float* xyz, const int32_t* offset, const float* new_xyz, const int32_t* new_offset, const int32_t* order,
+                   int b, int64_t n, int64_t m, int nsample, float min_radius, float max_radius, int32_t* idx, float* dist2,
+                   ptc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * J. BatchNorm1d over the rows of [n, c] features with the following activation fused:

@@ -43,3 +43,36 @@ def farthest_point_sampling(xyz, offset, new_offset):
                 out[j] = old
         s0, q0 = s1, q1
     return out
+
+
+def ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz, new_offset, order=None):
+    """libs/pointops/src/ball_query/ball_query_cuda_kernel.cu:59-123 (order=None) and
+    src/random_ball_query/random_ball_query_cuda_kernel.cu:58-108 (order = permutation): -> (idx, dist) with dist = sqrt(dist2)
+    as the python wrappers return (functions/query.py:75,113).  Ties: lower index first.  The sub-sampled branch returns the
+    candidate's distance (the CUDA kernel writes the candidate index into dist2 there, :120)."""
+    m = new_xyz.shape[0]
+    idx = np.full((m, nsample), -1, dtype=np.int32)
+    d2o = np.full((m, nsample), np.float32(1e10), dtype=np.float32)
+    mn, mx = np.float32(min_radius) * np.float32(min_radius), np.float32(max_radius) * np.float32(max_radius)
+    s0 = q0 = 0
+    for s1, q1 in zip(offset, new_offset):
+        cand_ids = np.arange(s0, s1) if order is None else np.asarray(order[s0:s1])
+        pts = xyz[cand_ids]
+        for q in range(q0, q1):
+            d = _d2(pts, new_xyz[q][None, :])
+            inr = (d <= np.float32(1e-5)) | ((d >= mn) & (d < mx))
+            ci, cd = cand_ids[inr], d[inr]
+            if order is None:
+                ci, cd = ci[:2048], cd[:2048]                      # the kernel's candidate array bound
+                o = np.lexsort((ci, cd))
+                ci, cd = ci[o], cd[o]
+                if len(ci) > nsample:
+                    sep = np.float32(len(ci)) / np.float32(nsample)
+                    pick = (sep * np.arange(nsample, dtype=np.float32)).astype(np.int32)
+                    ci, cd = ci[pick], cd[pick]
+            else:
+                ci, cd = ci[:nsample], cd[:nsample]
+            idx[q, :len(ci)] = ci
+            d2o[q, :len(ci)] = cd
+        s0, q0 = s1, q1
+    return idx, np.sqrt(d2o)

@@ -72,3 +72,18 @@ def load_transform():
             sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tv.transforms
         _loaded["transform"] = importlib.import_module("pointcept.datasets.transform")
     return _loaded["transform"]
+
+
+def load_dataset_utils():
+    """pointcept/datasets/utils.py (collate_fn / point_collate_fn with Mix3D), on the torch_scatter stand-in."""
+    load()
+    if "dataset_utils" not in _loaded:
+        if "pointcept.datasets" not in sys.modules:
+            pkg = types.ModuleType("pointcept.datasets")
+            pkg.__path__ = [REF + "/pointcept/datasets"]
+            sys.modules["pointcept.datasets"] = pkg
+        mu = sys.modules["pointcept.models.utils"] if "pointcept.models.utils" in sys.modules else importlib.import_module("pointcept.models.utils")
+        if not hasattr(mu, "offset2batch"):
+            mu.offset2batch = _loaded["misc"].offset2batch
+        _loaded["dataset_utils"] = importlib.import_module("pointcept.datasets.utils")
+    return _loaded["dataset_utils"]

@@ -240,6 +240,16 @@ def scatter(src, index, dim=0, dim_size=None, reduce="sum"):
     return out
 
 
+def scatter_min(src, index, dim=0, out=None, dim_size=None):
+    """torch_scatter.scatter_min over dim 0 (pointcept/datasets/utils.py:249): (per-group minimum, unused argmin)."""
+    assert dim == 0
+    n = int(index.max()) + 1 if dim_size is None else dim_size
+    idx = index.reshape((-1,) + (1,) * (src.ndim - 1)).expand_as(src)
+    big = torch.iinfo(src.dtype).max if not src.is_floating_point() else float("inf")
+    res = src.new_full((n,) + tuple(src.shape[1:]), big).scatter_reduce(0, idx, src, "amin", include_self=True)
+    return res, None
+
+
 def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
                                      **unused):
     """CPU stand-in for flash_attn (ptv3m1:208-214): bf16 in, fp32 math, bf16 out.  Lets the
@@ -262,7 +272,7 @@ def install_third_party(mods=None):
     mod("addict", Dict=Dict)
     timm = mod("timm")
     timm.layers = mod("timm.layers", DropPath=DropPath, trunc_normal_=trunc_normal_)
-    mod("torch_scatter", segment_csr=segment_csr)
+    mod("torch_scatter", segment_csr=segment_csr, scatter_min=scatter_min)
     mod("flash_attn", flash_attn_varlen_qkvpacked_func=flash_attn_varlen_qkvpacked_func)
     sp_modules = mod("spconv.pytorch.modules", is_spconv_module=is_spconv_module, SparseModule=SparseModule)
     sp = mod("spconv")

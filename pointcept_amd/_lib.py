@@ -53,6 +53,7 @@ _SIGNATURES = {
     "ptc_spconv_wgrad_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "ptc_spconv_wgrad": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size,
                                  c_ptr]),
+    "ptc_seg_eval_hist": (c_int, [c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_ptr, c_ptr]),
     "ptc_rope3d": (c_int, [c_ptr, c_int, c_ptr, c_i64, c_int, c_int, c_f32, c_f32, c_ptr]),
     "ptc_layer_norm_supported": (c_int, [c_int]),
     "ptc_layer_norm_fwd": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
@@ -80,6 +81,7 @@ _SIGNATURES = {
     "ptc_cross_entropy_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     "ptc_cross_entropy_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_i64, c_ptr, c_i64, c_ptr]),
     "ptc_knn_query": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
+    "ptc_ball_query": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_i64, c_int, c_f32, c_f32, c_ptr, c_ptr, c_ptr]),
     "ptc_farthest_point_sampling": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     "ptc_voxel_keys": (c_int, [c_ptr, c_i64, ctypes.c_double, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_lovasz_softmax_workspace_bytes": (c_size, [c_i64, c_int]),

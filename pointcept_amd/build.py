@@ -37,6 +37,7 @@ HIP_SOURCES = [
     "pointops.hip",
     "bn.hip",
     "rope.hip",
+    "evalhist.hip",
 ]
 CXX_SOURCES = ["core.cpp"]
 PROBE_SOURCES = ["host_probe.cpp"]

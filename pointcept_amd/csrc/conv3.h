@@ -26,7 +26,7 @@
 //     of one row block -- share an L2, so neighbouring rows are fetched from HBM once per XCD.
 // Output-stationary, no atomics, fixed summation order: bit-reproducible.
 //
-// BNC = true (round 2): COALESCED gathers + a wave-private LDS bounce.  rocprofv3 PMC of the form above at the dec0
+// BNC = true (round 2 experiment, kept for the record; superseded by conv5.h): COALESCED gathers + a wave-private LDS bounce.  rocprofv3 PMC of the form above at the dec0
 // shape (profiles/r02_a_conv_pmc_s0.json): HBM traffic 1.03 x algorithmic, L2 hit rate 87 %, matrix pipe 12 % busy,
 // TA_BUSY 72 % -- ~70 address cycles per non-empty 1-KB wave gather.  The MFMA B layout puts row n in lanes n, n+16,
 // n+32, n+48, so the four 16-byte pieces of one gathered row (64 contiguous bytes) sit in four NON-adjacent lanes and
@@ -289,8 +289,11 @@ static inline bool conv3_supported(int dtype, int kv, int c_in, int c_out, const
 }
 
 static inline bool conv3_bounce() {
-  const char* e = getenv("PTC_CONV3_BNC");   // read per launch: the tests A/B both forms in one process
-  return e ? atoi(e) != 0 : true;
+  // OFF by default: measured equal at 64 -> 64 (262 vs 266 us) and 20-55 % SLOWER at 96 / 128 input channels
+  // (profiles/r02_d_conv_stages_ops.txt) -- the rows still leave L2 as half lines, see conv5.h.  Read per launch: the
+  // tests A/B both forms in one process.
+  const char* e = getenv("PTC_CONV3_BNC");
+  return e ? atoi(e) != 0 : false;
 }
 
 template <typename T, int RT, int KPC, int NTILES, bool GEN, bool BNC>

@@ -183,3 +183,158 @@ extern "C" int ptc_farthest_point_sampling(const float* xyz, const int32_t* offs
   PTC_CHECK_LAUNCH("fps_kernel");
   return PTC_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// ball query / random ball query
+// ------------------------------------------------------------------------------------------------
+// ptc_ball_query replaces ball_query_cuda (libs/pointops/src/ball_query/ball_query_cuda_kernel.cu:59-123, wrapper
+// functions/query.py:78-113): for every query, the points p of ITS scene with d2 <= 1e-5 or min_r^2 <= d2 < max_r^2
+// (:98), sorted by ascending distance (:106), all of them when there are <= nsample (padding idx -1 / dist2 1e10,
+// :107-115), else nsample of them at the uniformly spaced ranks int(i * float(count) / nsample) (:117-122).  The
+// reference keeps 2048 candidates per THREAD in local memory and heap-sorts them; here ONE WAVE serves a query: the scene
+// is scanned 64 points at a time (coalesced), in-range candidates are appended to a wave-private LDS list through a
+// ballot / prefix count (the first BQ_CAP = 2048 in index order: the reference's array bound), the list is bitonic-
+// sorted by (distance, index) in LDS, and the selected ranks are written out.  Two deliberate deviations, both in the
+// documentation of pointops_api.ball_query: equal distances come out in ascending index order (heap sort leaves it
+// unspecified), and in the sub-sampled branch dist2 holds the candidate's DISTANCE (the reference stores its INDEX there,
+// :120 `dist2[i] = candi_idx[index]` -- a bug not to copy).
+// ptc_random_ball_query replaces random_ball_query_cuda (src/random_ball_query/...kernel.cu:58-108): the first nsample
+// in-range points in the order of a caller-supplied permutation `order` of every scene's points (wrapper
+// functions/query.py:29-75 draws it with torch.randperm); wave-cooperative scan with early exit.
+#define BQ_CAP 2048
+#define BQ_WAVES 4
+
+__global__ void __launch_bounds__(BQ_WAVES * 64)
+ball_query_kernel(const float* __restrict__ xyz, const int* __restrict__ offset, const float* __restrict__ new_xyz,
+                  const int* __restrict__ new_offset, int b, int64_t m, int nsample, float min_r2, float max_r2,
+                  int32_t* __restrict__ idx, float* __restrict__ dist2) {
+  __shared__ float cd[BQ_WAVES][BQ_CAP];
+  __shared__ int ci[BQ_WAVES][BQ_CAP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * BQ_WAVES + wave;
+  if (q >= m) return;                              // whole wave
+  float* D = cd[wave];
+  int* I = ci[wave];
+  const int sc = po_scene_of(new_offset, b, q);
+  const int start = sc ? offset[sc - 1] : 0, end = offset[sc];
+  const float qx = new_xyz[3 * q], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
+  int cnt = 0;
+  for (int base = start; base < end && cnt < BQ_CAP; base += 64) {
+    const int p = base + lane;
+    float d = 0.f;
+    bool in = false;
+    if (p < end) {
+      d = po_dist2(qx, qy, qz, xyz[3 * (int64_t)p], xyz[3 * (int64_t)p + 1], xyz[3 * (int64_t)p + 2]);
+      in = d <= 1e-5f || (d >= min_r2 && d < max_r2);
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+    const int pos = cnt + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    if (in && pos < BQ_CAP) {
+      D[pos] = d;
+      I[pos] = p;
+    }
+    cnt += __builtin_popcountll(mask);
+  }
+  if (cnt > BQ_CAP) cnt = BQ_CAP;
+  int P = 2;
+  while (P < cnt) P <<= 1;
+  for (int i = cnt + lane; i < P; i += 64) {       // padding sorts last
+    D[i] = 3.0e38f;
+    I[i] = 0x7fffffff;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int k2 = 2; k2 <= P; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = lane; i < P; i += 64) {
+        const int x = i ^ j;
+        if (x > i) {
+          const float da = D[i], db = D[x];
+          const int ia = I[i], ib = I[x];
+          const bool gt = da > db || (da == db && ia > ib);
+          if (gt == ((i & k2) == 0)) {
+            D[i] = db; D[x] = da;
+            I[i] = ib; I[x] = ia;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  int32_t* oi = idx + q * nsample;
+  float* od = dist2 + q * nsample;
+  if (cnt <= nsample) {
+    for (int i = lane; i < nsample; i += 64) {
+      oi[i] = i < cnt ? I[i] : -1;
+      od[i] = i < cnt ? D[i] : 1e10f;
+    }
+  } else {
+    const float sep = (float)cnt / (float)nsample;            // :117, fp32 as the reference
+    for (int i = lane; i < nsample; i += 64) {
+      const int r = (int)(sep * (float)i);
+      oi[i] = I[r];
+      od[i] = D[r];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+random_ball_query_kernel(const float* __restrict__ xyz, const int* __restrict__ offset, const float* __restrict__ new_xyz,
+                         const int* __restrict__ new_offset, const int* __restrict__ order, int b, int64_t m, int nsample,
+                         float min_r2, float max_r2, int32_t* __restrict__ idx, float* __restrict__ dist2) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= m) return;
+  const int sc = po_scene_of(new_offset, b, q);
+  const int start = sc ? offset[sc - 1] : 0, end = offset[sc];
+  const float qx = new_xyz[3 * q], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
+  int32_t* oi = idx + q * nsample;
+  float* od = dist2 + q * nsample;
+  int cnt = 0;
+  for (int base = start; base < end && cnt < nsample; base += 64) {
+    const int i = base + lane;
+    float d = 0.f;
+    int p = -1;
+    bool in = false;
+    if (i < end) {
+      p = order[i];
+      d = po_dist2(qx, qy, qz, xyz[3 * (int64_t)p], xyz[3 * (int64_t)p + 1], xyz[3 * (int64_t)p + 2]);
+      in = d <= 1e-5f || (d >= min_r2 && d < max_r2);
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+    const int pos = cnt + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    if (in && pos < nsample) {
+      oi[pos] = p;
+      od[pos] = d;
+    }
+    cnt += __builtin_popcountll(mask);
+  }
+  if (cnt > nsample) cnt = nsample;
+  for (int i = cnt + lane; i < nsample; i += 64) {
+    oi[i] = -1;
+    od[i] = 1e10f;
+  }
+}
+
+extern "C" int ptc_ball_query(const float* xyz, const int32_t* offset, const float* new_xyz, const int32_t* new_offset, const int32_t* order,
+                              int b, int64_t n, int64_t m, int nsample, float min_radius, float max_radius, int32_t* idx, float* dist2,
+                              ptc_stream_t stream) {
+  PTC_REQUIRE(n >= 0 && m >= 0 && b >= 1 && nsample >= 1, PTC_EINVAL, "ptc_ball_query: bad sizes");
+  PTC_REQUIRE(min_radius < max_radius, PTC_EINVAL, "ptc_ball_query: min_radius must be < max_radius");     // query.py:45,93
+  PTC_REQUIRE(n < (1ll << 31), PTC_EUNSUPPORTED, "ptc_ball_query: n >= 2^31");
+  if (m == 0) return PTC_OK;
+  PTC_REQUIRE(offset && new_xyz && new_offset && idx && dist2 && (n == 0 || xyz), PTC_EINVAL, "ptc_ball_query: null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  const float mn = min_radius * min_radius, mx = max_radius * max_radius;
+  if (order)
+    hipLaunchKernelGGL(random_ball_query_kernel, dim3((unsigned)ptc_cdiv(m, 4)), dim3(256), 0, s, xyz, offset, new_xyz, new_offset, order, b, m,
+                       nsample, mn, mx, idx, dist2);
+  else
+    hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)ptc_cdiv(m, BQ_WAVES)), dim3(BQ_WAVES * 64), 0, s, xyz, offset, new_xyz, new_offset, b, m,
+                       nsample, mn, mx, idx, dist2);
+  PTC_CHECK_LAUNCH("ball_query_kernel");
+  return PTC_OK;
+}

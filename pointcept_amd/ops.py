@@ -214,6 +214,29 @@ def knn_query(nsample: int, xyz, offset, new_xyz, new_offset):
     return idx, dist
 
 
+def ball_query(nsample: int, max_radius: float, min_radius: float, xyz, offset, new_xyz, new_offset, order=None):
+    """-> (idx [m, nsample] int32 (-1 = none), dist [m, nsample] fp32 (1e5 = none)), libs/pointops/functions/query.py:29-113.
+    order = None: ball_query (sorted by distance, uniformly sub-sampled); order = int32 permutation of every scene's points:
+    random_ball_query (first nsample in-range points in that order)."""
+    require_cuda(xyz, offset, new_xyz, new_offset, order)
+    if not float(min_radius) < float(max_radius):
+        raise PtcoreError("min_radius must be smaller than max_radius")      # query.py:45,93
+    x, q = _xyz(xyz, "xyz"), _xyz(new_xyz, "new_xyz")
+    off, noff = offset.to(torch.int32).contiguous(), new_offset.to(torch.int32).contiguous()
+    if off.numel() != noff.numel() or off.numel() == 0:
+        raise PtcoreError("offset / new_offset must list the same (non-zero) number of scenes")
+    if order is not None:
+        order = order.to(torch.int32).contiguous()
+        if order.numel() != x.shape[0]:
+            raise PtcoreError("order must be a permutation of the source points")
+    m = q.shape[0]
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=x.device)
+    d2 = torch.empty((m, nsample), dtype=torch.float32, device=x.device)
+    check(lib().ptc_ball_query(ptr(x), ptr(off), ptr(q), ptr(noff), ptr(order), off.numel(), x.shape[0], m, int(nsample), float(min_radius),
+                               float(max_radius), ptr(idx), ptr(d2), stream_ptr()), "ptc_ball_query")
+    return idx, torch.sqrt(d2)
+
+
 def farthest_point_sampling(xyz, offset, new_offset):
     """-> idx [new_offset[-1]] int32, libs/pointops/functions/sampling.py:7-24 (one host sync for the output size)."""
     require_cuda(xyz, offset, new_offset)
@@ -464,6 +487,39 @@ def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: Optional[torch.Ten
     check(lib().ptc_spconv_wgrad(ptr(feat), feat.shape[0], ptr(dout), ptr(nbr), n_out, kv, c_in, c_out,
                                  dtype_code(feat), ptr(dw), ptr(db), ptr(ws), nbytes, stream_ptr()), "ptc_spconv_wgrad")
     return (dw, db) if want_bias else dw
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation tail: arg-max + inverse gather + three class histograms in one pass
+# ------------------------------------------------------------------------------------------------
+def seg_eval_hist(logits: Optional[torch.Tensor], target: torch.Tensor, k: int, ignore_index: int = -1,
+                  inverse: Optional[torch.Tensor] = None, pred: Optional[torch.Tensor] = None):
+    """(area_intersection, area_union, area_target), each int64 [k]: pointcept/utils/misc.py:57-69 applied to
+    pred = logits.max(1)[1][inverse] (pointcept/engines/hooks/evaluator.py:139-147), or to given predictions."""
+    require_cuda(logits, target, inverse, pred)
+    if (logits is None) == (pred is None):
+        raise PtcoreError("give logits or pred")
+    target = target.reshape(-1).to(torch.int64).contiguous()
+    m = target.numel()
+    hist = torch.empty((3, int(k)), dtype=torch.int64, device=target.device)
+    if pred is not None:
+        pred = pred.reshape(-1).to(torch.int64).contiguous()
+        if pred.numel() != m:
+            raise PtcoreError("pred / target size mismatch")            # misc.py:60
+        check(lib().ptc_seg_eval_hist(0, 0, 0, 0, ptr(pred), 0, ptr(target), m, 0, int(k), int(ignore_index), ptr(hist), stream_ptr()),
+              "ptc_seg_eval_hist")
+    else:
+        if logits.dim() != 2 or logits.stride(1) != 1:
+            raise PtcoreError("logits must be [N, C] with unit column stride")
+        if inverse is not None:
+            inverse = inverse.reshape(-1).to(torch.int64).contiguous()
+            if inverse.numel() != m:
+                raise PtcoreError("inverse / target size mismatch")
+        elif logits.shape[0] != m:
+            raise PtcoreError("logits / target size mismatch")
+        check(lib().ptc_seg_eval_hist(ptr(logits), dtype_code(logits), logits.stride(0), logits.shape[1], 0, ptr(inverse), ptr(target), m,
+                                      logits.shape[0], int(k), int(ignore_index), ptr(hist), stream_ptr()), "ptc_seg_eval_hist")
+    return hist[0], hist[1] + hist[2] - hist[0], hist[2]
 
 
 # ------------------------------------------------------------------------------------------------

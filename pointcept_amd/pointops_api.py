@@ -11,8 +11,11 @@ datasets/modelnet.py:100).  Same names, argument order and return conventions; `
     knn_query_and_group(feat, xyz, offset, new_xyz, new_offset, idx=None, nsample=None, with_xyz=False)
     offset2batch / batch2offset
 
-Tie order (equal distances: lower index first) is fixed here and implementation-defined in the reference.  ball_query /
-random_ball_query / subtraction / aggregation / attention_*_step (PTv1 / PTv2 only) are not implemented and raise.
+    ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None)  -> (idx, dist)   HIP (pointops.hip)
+    random_ball_query(..., order=None)                                                          -> (idx, dist)   HIP
+    subtraction / aggregation / attention_relation_step / attention_fusion_step (PTv1 / PTv2)  differentiable torch / segment ops
+
+Tie order (equal distances: lower index first) is fixed here and implementation-defined in the reference.
 """
 from __future__ import annotations
 
@@ -68,16 +71,73 @@ def knn_query_and_group(feat, xyz, offset=None, new_xyz=None, new_offset=None, i
     return grouping(idx, feat, xyz, new_xyz, with_xyz), idx
 
 
-def _missing(name):
-    def f(*args, **kwargs):
-        raise PtcoreError(f"pointops.{name} is not implemented by the engine")
-    f.__name__ = name
-    return f
+def ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None):
+    """libs/pointops/functions/query.py:78-113.  Differences from the CUDA kernel, on purpose: equal distances are ordered by
+    ascending index (heap sort leaves it unspecified), and in the sub-sampled branch (more than nsample candidates) the
+    returned distance is the candidate's distance -- ball_query_cuda_kernel.cu:120 stores the candidate INDEX there."""
+    if new_xyz is None or new_offset is None:
+        new_xyz, new_offset = xyz, offset
+    return ops.ball_query(int(nsample), max_radius, min_radius, xyz, offset, new_xyz, new_offset)
 
 
-ball_query = _missing("ball_query")
-random_ball_query = _missing("random_ball_query")
-subtraction = _missing("subtraction")
-aggregation = _missing("aggregation")
-attention_relation_step = _missing("attention_relation_step")
-attention_fusion_step = _missing("attention_fusion_step")
+def random_ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None, order=None):
+    """libs/pointops/functions/query.py:29-75: the first nsample in-range points along a random permutation of every scene's
+    points (torch.randperm per scene, :47-53; `order=` injects it for tests)."""
+    if new_xyz is None or new_offset is None:
+        new_xyz, new_offset = xyz, offset
+    if order is None:
+        parts, s0 = [], 0
+        for s1 in offset.tolist():
+            parts.append(torch.randperm(s1 - s0, dtype=torch.int32, device=xyz.device) + s0)
+            s0 = s1
+        order = torch.cat(parts)
+    return ops.ball_query(int(nsample), max_radius, min_radius, xyz, offset, new_xyz, new_offset, order=order)
+
+
+def subtraction(input1, input2, idx):
+    """libs/pointops/functions/subtraction.py / src/subtraction/subtraction_cuda_kernel.cu:5-30:
+    out[n, s, :] = input1[n, :] - input2[idx[n, s], :]   (differentiable; the CUDA backward scatters with atomics, torch's
+    index backward here)."""
+    n, ns = idx.shape
+    return input1.unsqueeze(1) - input2[idx.reshape(-1).long()].view(n, ns, -1)
+
+
+def aggregation(input, position, weight, idx):
+    """libs/pointops/functions/aggregation.py / src/aggregation/aggregation_cuda_kernel.cu:5-39 (PTv1 vector attention):
+    out[n, c] = sum_s (input[idx[n, s], c] + position[n, s, c]) * weight[n, s, c % w_c]."""
+    n, ns, c = position.shape
+    w_c = weight.shape[-1]
+    g = input[idx.reshape(-1).long()].view(n, ns, c) + position
+    w = weight.repeat(1, 1, c // w_c) if c != w_c else weight          # channel c uses weight column c % w_c
+    return (g * w).sum(1)
+
+
+def _csr_by_target(index_target, n):
+    """edges sorted by target row + CSR pointer: the segmented (atomics-free, fixed-order) form of the scatter-adds"""
+    order = torch.sort(index_target.long(), stable=True).indices
+    counts = torch.bincount(index_target.long(), minlength=n)
+    indptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)])
+    return order, indptr
+
+
+def attention_relation_step(query, key, weight, index_target, index_refer):
+    """libs/pointops/functions/attention.py:11-62 / src/attention/attention_cuda_kernel.cu:9-25:
+    relation[m, g] = sum_c query[index_target[m], g, c] * key[index_refer[m], g, c] * weight[c]   (differentiable)"""
+    return (query[index_target.long()] * key[index_refer.long()] * weight).sum(-1)
+
+
+def attention_fusion_step(weight, value, index_target, index_refer):
+    """libs/pointops/functions/attention.py:64-120 / attention_cuda_kernel.cu:46-62:
+    out[index_target[m], g, c] += weight[m, g] * value[index_refer[m], g, c].  The reference accumulates with atomicAdd
+    (run-to-run different sums); here the edges are sorted by target and reduced per target row in a fixed order
+    (PF.segment_csr "sum": csrc/rows.hip), output [n, g, c]."""
+    from . import functional as PF
+
+    n, g, c = value.shape
+    order, indptr = _csr_by_target(index_target, n)
+    contrib = (weight.unsqueeze(-1) * value[index_refer.long()]).reshape(-1, g * c)
+    if contrib.is_cuda:
+        out = PF.segment_csr(contrib, indptr, "sum", perm=order)
+    else:
+        out = torch.zeros((n, g * c), dtype=contrib.dtype).index_add_(0, index_target.long(), contrib)
+    return out.view(n, g, c)

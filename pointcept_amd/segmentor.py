@@ -61,3 +61,16 @@ class DefaultSegmentorV2(nn.Module):
         else:
             return_dict["seg_logits"] = seg_logits
         return return_dict
+
+
+def semseg_eval_counts(seg_logits, input_dict, num_classes: int, ignore_index: int = -1):
+    """The per-batch body of SemSegEvaluator.eval (pointcept/engines/hooks/evaluator.py:139-152) in one kernel launch:
+    pred = seg_logits.max(1)[1]; with `inverse` / `origin_segment` in the batch (GridSample test mode) predictions are
+    carried back to the original points; then intersection_and_union_gpu (pointcept/utils/misc.py:57-69).
+    Returns (intersection, union, target), int64 [num_classes] on the device -- ready for the evaluator's all_reduce."""
+    from . import ops
+
+    if "inverse" in input_dict.keys():
+        assert "origin_segment" in input_dict.keys()
+        return ops.seg_eval_hist(seg_logits, input_dict["origin_segment"], num_classes, ignore_index, inverse=input_dict["inverse"])
+    return ops.seg_eval_hist(seg_logits, input_dict["segment"], num_classes, ignore_index)

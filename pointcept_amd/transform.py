@@ -1,4 +1,7 @@
-"""Device-side GridSample: the voxelisation transform of pointcept/datasets/transform.py:839-1011 for point clouds
+"""Device-side front end of the hot path: GridSample, SphereCrop and the Mix3D collate of the
+reference's dataloader, for point clouds that already live on the GPU.
+
+GridSample: the voxelisation transform of pointcept/datasets/transform.py:839-1011 for point clouds
 that already live on the GPU (SURVEY 8(f) rank 1 -- the step immediately before the hot path; on the reference it runs
 in numpy inside 24 dataloader workers).  Same constructor arguments, same dict protocol (`index_valid_keys`,
 `inverse`, `grid_coord`, `min_coord`, `displacement`, train / test modes), torch tensors instead of numpy arrays.
@@ -118,3 +121,114 @@ class GridSample:
             part["index"] = idx_part
             parts.append(self._extras(part, src, v, idx_part))
         return parts
+
+
+class SphereCrop:
+    """pointcept/datasets/transform.py:1014-1057 on device tensors: keep the `point_max` points nearest a centre.
+    The reference sorts ALL squared distances (np.argsort) and keeps the first point_max -- the output is in ascending
+    distance order; here the fp32 distance bits are radix-sorted (non-negative floats order like their bit patterns), ties
+    in ascending index order (numpy's argsort is unstable there).  mode "random" draws the centre from torch's generator
+    (`center_index=` injects it); "center" takes point N // 2 (:1033); "given" follows :1034-1047.  mode "all" is
+    accepted by the reference's assert but never implemented there (:1048-1049); same here."""
+
+    def __init__(self, point_max=80000, sample_rate=None, mode="random"):
+        self.point_max, self.sample_rate = point_max, sample_rate
+        assert mode in ["random", "center", "all", "given"]
+        self.mode = mode
+
+    @torch.no_grad()
+    def __call__(self, data_dict, center_index: Optional[int] = None):
+        assert "coord" in data_dict.keys()
+        coord = data_dict["coord"]
+        n = coord.shape[0]
+        point_max = int(self.sample_rate * n) if self.sample_rate is not None else self.point_max
+        if n <= point_max:
+            return data_dict
+        if self.mode == "random":
+            ci = int(torch.randint(n, (1,)).item()) if center_index is None else int(center_index)
+            center = coord[ci]
+        elif self.mode == "center":
+            center = coord[n // 2]
+        elif self.mode == "given":
+            corr = data_dict["correspondence"].reshape(data_dict["correspondence"].shape[0], -1)
+            given = (corr != -1).all(dim=1)
+            if int(given.sum()) == 0:
+                ci = int(torch.randint(n, (1,)).item()) if center_index is None else int(center_index)
+                center = coord[ci]
+            else:
+                center = coord[given].mean(dim=0)
+        else:
+            raise NotImplementedError
+        d2 = ((coord - center) ** 2).sum(1)
+        if d2.dtype == torch.float64:
+            keys, bits = d2.view(torch.int64), 63
+        else:
+            keys, bits = d2.float().view(torch.int32).to(torch.int64), 31
+        order, _ = ops.sort_keys(keys[None].contiguous(), 0, bits, want_inverse=False)
+        return index_operator(data_dict, order[0][:point_max])
+
+
+def collate_fn(batch):
+    """pointcept/datasets/utils.py:19-73 for device tensors: concatenate along points; keys containing "offset" become
+    cumulative offsets of the concatenation (:52-60).  (The image / correspondence branches of the multi-modal
+    pre-training datasets, :44-45,61-71, are outside the PTv3 / SpUNet path and raise.)"""
+    from collections.abc import Mapping, Sequence
+
+    if not isinstance(batch, Sequence):
+        raise TypeError(f"{type(batch)} is not supported.")
+    if isinstance(batch[0], torch.Tensor):
+        return torch.cat(list(batch))
+    if isinstance(batch[0], str):
+        return list(batch)
+    if isinstance(batch[0], (int, float)):
+        return torch.tensor(list(batch))
+    if isinstance(batch[0], list):
+        return torch.cat([torch.tensor(d) for d in batch])
+    if isinstance(batch[0], Mapping):
+        if "img_num" in batch[0] or any("correspondence" in k for k in batch[0]):
+            raise PtcoreError("collate_fn: the image / correspondence branches are not part of this engine")
+        out = {}
+        for key in batch[0]:
+            if "offset" in key:
+                parts = [torch.diff(d[key], prepend=d[key].new_zeros(1)) for d in batch]
+                out[key] = torch.cumsum(torch.cat(parts), dim=0)
+            else:
+                out[key] = collate_fn([d[key] for d in batch])
+        return out
+    raise TypeError(f"collate_fn: unsupported element type {type(batch[0])}")
+
+
+def point_collate_fn(batch, mix_prob=0, mix: Optional[bool] = None):
+    """pointcept/datasets/utils.py:208-258: collate, then with probability mix_prob Mix3D -- every second scene boundary
+    is dropped (:231-236), so pairs of scenes become ONE batch item whose grid coordinates overlap (duplicate voxels are
+    legal input of the engine); instance ids of the second scene of a pair are shifted (:222-230); when the
+    sample carries `grid_size`, grid_coord is recomputed from the merged coordinates per batch item (:245-250).
+    `mix=` injects the coin flip for tests (the reference uses python's `random`)."""
+    import random
+
+    assert isinstance(batch[0], dict)
+    batch = collate_fn(batch)
+    do_mix = (random.random() < mix_prob) if mix is None else bool(mix)
+    if not do_mix:
+        return batch
+    if "instance" in batch.keys():
+        offset = batch["offset"].tolist()
+        start, num_instance = 0, 0
+        for i in range(len(offset)):
+            seg = batch["instance"][start:offset[i]]
+            if i % 2 == 0:
+                num_instance = int(seg.max()) if seg.numel() else 0
+            else:
+                seg += num_instance * (seg != -1)
+            start = offset[i]
+    for key in [k for k in batch.keys() if "offset" in k]:
+        batch[key] = torch.cat([batch[key][1:-1:2], batch[key][-1].unsqueeze(0)], dim=0)
+    if "grid_coord" in batch and "grid_size" in batch:
+        off = batch["offset"]
+        counts = torch.diff(off, prepend=off.new_zeros(1))
+        bidx = torch.repeat_interleave(torch.arange(off.numel(), device=off.device), counts)
+        gs = batch["grid_size"][0] if torch.is_tensor(batch["grid_size"]) and batch["grid_size"].dim() > 0 else batch["grid_size"]
+        gc = torch.floor(batch["coord"] / gs).to(torch.int64)
+        mn = gc.new_full((off.numel(), 3), torch.iinfo(torch.int64).max).scatter_reduce(0, bidx[:, None].expand(-1, 3), gc, "amin")
+        batch["grid_coord"] = gc - mn[bidx]
+    return batch

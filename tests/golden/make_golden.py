@@ -26,6 +26,8 @@ Fixtures
   ptv3m2_tiny.npz   : the reference's point_transformer_v3m2_sonata.py (GridPooling / GridUnpooling / LayerScale / Linear stem) on
                       oracle/shims.py: depths 1/1/1/2/1 + 1/1/1/1, layer_scale 0.5, two scenes (2500 + 700 voxels): eval features
                       (every 8th row), train-mode loss and the gradient norm of every parameter, the state-dict key list.
+  spherecrop.npz    : coord / segment -> SphereCrop(point_max, mode) of pointcept/datasets/transform.py:1014-1057, three cases
+                      (mode "center" twice, mode "random" with numpy's generator seeded and the drawn centre recorded).
   pointrope.npz     : tokens / positions -> pointrope_cpu of libs/pointrope/pointrope.cpp:13-49 (compiled from the reference tree by
                       oracle/build_ref.py), four shapes (D = 18, 24, 48, 6; F0 = +-1).
   lovasz.npz        : logits / labels -> LovaszLoss(mode="multiclass", ignore_index=-1) loss and gradient
@@ -264,6 +266,28 @@ def main():
         blobs[f"tokens_{ci}"], blobs[f"pos_{ci}"], blobs[f"out_{ci}"] = tok.numpy(), pos.numpy(), out.numpy()
     blobs["n_cases"] = np.asarray(len(cases))
     np.savez_compressed(os.path.join(OUT, "pointrope.npz"), **blobs)
+
+    # ---- SphereCrop (pointcept/datasets/transform.py:1014-1057) ----------------------------------------
+    TR = ref_import.load_transform()
+    blobs = {}
+    rng = np.random.default_rng(11)
+    cases = [(5000, 1200, "center"), (3000, 2999, "center"), (2000, 500, "random")]
+    for ci, (n, pmax, mode) in enumerate(cases):
+        coord = (rng.random((n, 3)) * np.array([7.0, 5.0, 2.8])).astype(np.float32)
+        seg = rng.integers(0, 20, size=n).astype(np.int64)
+        d = dict(coord=coord.copy(), segment=seg.copy())
+        np.random.seed(123 + ci)
+        ci_center = None
+        if mode == "random":     # the centre the transform is about to draw
+            st = np.random.get_state()
+            ci_center = int(np.random.randint(n))
+            np.random.set_state(st)
+        out = TR.SphereCrop(point_max=pmax, mode=mode)(d)
+        blobs[f"coord_{ci}"], blobs[f"segment_{ci}"], blobs[f"point_max_{ci}"] = coord, seg, np.asarray(pmax)
+        blobs[f"mode_{ci}"], blobs[f"center_index_{ci}"] = np.asarray(mode), np.asarray(-1 if ci_center is None else ci_center)
+        blobs[f"out_coord_{ci}"], blobs[f"out_segment_{ci}"] = out["coord"], out["segment"]
+    blobs["n_cases"] = np.asarray(len(cases))
+    np.savez_compressed(os.path.join(OUT, "spherecrop.npz"), **blobs)
 
     # ---- Lovasz-Softmax ------------------------------------------------------------------------
     import types

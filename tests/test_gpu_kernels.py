@@ -1360,8 +1360,10 @@ def test_pointops_through_compat_and_unsupported(cuda):
         idx, dist = pointops.knn_query(2, x, o)
         assert idx.shape == (100, 2) and bool((idx[:60] < 60).all()) and bool((idx[60:] >= 60).all())
         assert torch.equal(pointops.offset2batch(o), torch.cat([torch.zeros(60), torch.ones(40)]).long().to(cuda))
+        bi, bd = pointops.ball_query(4, 0.2, 0.0, x, o)
+        assert bi.shape == (100, 4) and bool((bi[:, 0] == torch.arange(100, device=cuda)).all())     # nearest in-range point = itself
         with pytest.raises(PtcoreError):
-            pointops.ball_query(4, 0.2, 0.0, x, o)
+            pointops.ball_query(4, 0.1, 0.2, x, o)                                                     # min_radius >= max_radius (query.py:93)
     finally:
         for k, v in saved.items():
             if v is None:
@@ -1424,3 +1426,119 @@ def test_rope3d_autograd_is_the_inverse_rotation(cuda):
     (yr * w).sum().backward()
     _close("rope_fwd", y, yr, 1e-4, 1e-4)
     _close("rope_bwd", x.grad, xr.grad, 1e-4, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# front end: SphereCrop
+# ------------------------------------------------------------------------------------------------
+def test_sphere_crop_matches_reference_golden(cuda):
+    """device SphereCrop (radix sort of the fp32 distance bits) against the reference transform's own output: same points
+    in the same (ascending distance) order -- the random coordinates have no distance ties."""
+    import os
+
+    from pointcept_amd.transform import SphereCrop
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spherecrop.npz"))
+    for ci in range(int(g["n_cases"])):
+        d = dict(coord=_t(g[f"coord_{ci}"], cuda), segment=_t(g[f"segment_{ci}"], cuda))
+        c = int(g[f"center_index_{ci}"])
+        out = SphereCrop(point_max=int(g[f"point_max_{ci}"]), mode=str(g[f"mode_{ci}"]))(d, center_index=None if c < 0 else c)
+        assert np.array_equal(out["coord"].cpu().numpy(), g[f"out_coord_{ci}"]), ci
+        assert np.array_equal(out["segment"].cpu().numpy(), g[f"out_segment_{ci}"]), ci
+    small = dict(coord=torch.rand(100, 3, device=cuda), segment=torch.zeros(100, dtype=torch.long, device=cuda))
+    assert SphereCrop(point_max=200)(small)["coord"].shape[0] == 100          # fewer points than point_max: untouched (:1031)
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation tail (SURVEY 8(f).3): arg-max + inverse + class histograms
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_seg_eval_hist_matches_the_reference_formula(cuda, dtype):
+    """ptc_seg_eval_hist against intersection_and_union (pointcept/utils/misc.py:37-54, the numpy form of the GPU function
+    at :57-69) applied to pred = logits.max(1)[1][inverse] (evaluator.py:139-147): exact integer counts; ignored points,
+    classes absent from the labels, a strided logits view, predictions given directly."""
+    from pointcept_amd import ops
+
+    rng = np.random.default_rng(3)
+    n, m, k = 5000, 23000, 20
+    wide = torch.from_numpy(rng.standard_normal((n, 32)).astype(np.float32)).to(dtype).to(cuda)
+    logits = wide[:, :k]                                                        # row pitch 32, as the padded head output
+    inverse = rng.integers(0, n, size=m)
+    target = rng.integers(-1, k - 3, size=m)                                    # -1 = ignore; the last classes never occur
+    pred = logits.float().cpu().numpy().argmax(1)[inverse]
+
+    def ref(output, tgt):
+        mask = tgt != -1
+        o, t = output[mask], tgt[mask]
+        inter = np.histogram(o[o == t], bins=np.arange(k + 1))[0]
+        ao, at = np.histogram(o, bins=np.arange(k + 1))[0], np.histogram(t, bins=np.arange(k + 1))[0]
+        return inter, ao + at - inter, at
+
+    want = ref(pred, target)
+    got = ops.seg_eval_hist(logits, _t(target, cuda), k, -1, inverse=_t(inverse, cuda))
+    for a, b in zip(got, want):
+        assert np.array_equal(a.cpu().numpy(), b)
+    got2 = ops.seg_eval_hist(None, _t(target, cuda), k, -1, pred=_t(pred, cuda))
+    for a, b in zip(got2, want):
+        assert np.array_equal(a.cpu().numpy(), b)
+    got3 = ops.seg_eval_hist(logits, _t(target[:n], cuda), k, -1)              # no inverse: evaluated points = rows
+    for a, b in zip(got3, ref(logits.float().cpu().numpy().argmax(1), target[:n])):
+        assert np.array_equal(a.cpu().numpy(), b)
+
+
+# ------------------------------------------------------------------------------------------------
+# libs/pointops remainder (SURVEY 8(f).4)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nsample,rmax,rmin", [(16, 0.12, 0.0), (8, 0.3, 0.05), (64, 0.08, 0.0)])
+def test_ball_query_and_random_ball_query(cuda, nsample, rmax, rmin):
+    """ptc_ball_query against the numpy restatement of the CUDA kernels' loops (parity unpinned: CUDA-only in the
+    reference): two scenes, fewer / more candidates than nsample, the uniform sub-sampling ranks in fp32, a caller-supplied
+    permutation for the random variant.  Distances are computed without FMA contraction on both sides: bit-equal."""
+    from oracle import pointops as opo
+    from pointcept_amd import pointops_api as po
+
+    rng = np.random.default_rng(nsample)
+    xyz = rng.random((1500, 3)).astype(np.float32)
+    offset = np.array([900, 1500], dtype=np.int32)
+    new_xyz = np.concatenate([xyz[:900:7], xyz[900::5]]).astype(np.float32)
+    new_offset = np.array([len(xyz[:900:7]), len(new_xyz)], dtype=np.int32)
+    idx, dist = po.ball_query(nsample, rmax, rmin, _t(xyz, cuda), _t(offset, cuda), _t(new_xyz, cuda), _t(new_offset, cuda))
+    ri, rd = opo.ball_query(nsample, rmax, rmin, xyz, offset, new_xyz, new_offset)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert np.array_equal(dist.cpu().numpy(), rd)
+    order = np.concatenate([rng.permutation(900), 900 + rng.permutation(600)]).astype(np.int32)
+    idx, dist = po.random_ball_query(nsample, rmax, rmin, _t(xyz, cuda), _t(offset, cuda), _t(new_xyz, cuda), _t(new_offset, cuda),
+                                     order=_t(order, cuda))
+    ri, rd = opo.ball_query(nsample, rmax, rmin, xyz, offset, new_xyz, new_offset, order=order)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert np.array_equal(dist.cpu().numpy(), rd)
+    idx, _ = po.random_ball_query(nsample, rmax, rmin, _t(xyz, cuda), _t(offset, cuda))       # self query, fresh permutation
+    got = idx.cpu().numpy()
+    assert ((got >= -1) & (got < 1500)).all() and (got[:900][got[:900] >= 0] < 900).all()      # neighbours stay inside the scene
+
+
+def test_ptv1_ptv2_operators_match_their_definitions(cuda):
+    """subtraction / aggregation / attention_relation_step / attention_fusion_step (libs/pointops/src/{subtraction,
+    aggregation,attention}) against the kernels' loops written out in numpy; the fusion step is a segmented sum here."""
+    from pointcept_amd import pointops_api as po
+
+    rng = np.random.default_rng(1)
+    n, ns, c, wc, g, m = 300, 8, 12, 4, 3, 2000
+    f1, f2 = rng.standard_normal((n, c)).astype(np.float32), rng.standard_normal((n, c)).astype(np.float32)
+    idx = rng.integers(0, n, size=(n, ns)).astype(np.int32)
+    sub = po.subtraction(_t(f1, cuda), _t(f2, cuda), _t(idx, cuda)).cpu().numpy()
+    assert np.allclose(sub, f1[:, None, :] - f2[idx], atol=1e-6)
+    pos, w = rng.standard_normal((n, ns, c)).astype(np.float32), rng.standard_normal((n, ns, wc)).astype(np.float32)
+    agg = po.aggregation(_t(f1, cuda), _t(pos, cuda), _t(w, cuda), _t(idx, cuda)).cpu().numpy()
+    ref = ((f1[idx] + pos) * w[:, :, np.arange(c) % wc]).sum(1)
+    assert np.allclose(agg, ref, atol=1e-4)
+    q, k = rng.standard_normal((n, g, c)).astype(np.float32), rng.standard_normal((n, g, c)).astype(np.float32)
+    wt = rng.standard_normal(c).astype(np.float32)
+    it, ir = rng.integers(0, n, size=m).astype(np.int32), rng.integers(0, n, size=m).astype(np.int32)
+    rel = po.attention_relation_step(_t(q, cuda), _t(k, cuda), _t(wt, cuda), _t(it, cuda), _t(ir, cuda)).cpu().numpy()
+    assert np.allclose(rel, (q[it] * k[ir] * wt).sum(-1), atol=1e-4)
+    aw = rng.standard_normal((m, g)).astype(np.float32)
+    fus = po.attention_fusion_step(_t(aw, cuda), _t(k, cuda), _t(it, cuda), _t(ir, cuda)).cpu().numpy()
+    ref = np.zeros((n, g, c), np.float64)
+    np.add.at(ref, it, (aw[:, :, None] * k[ir]).astype(np.float64))
+    assert np.allclose(fus, ref, atol=1e-4)

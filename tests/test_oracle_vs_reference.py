@@ -202,3 +202,33 @@ def test_pointrope_oracle_vs_reference_build():
         ext.pointrope(ref, pos, base, fwd)
         out = orope.pointrope(tok.numpy(), pos.numpy(), base, fwd)
         assert np.abs(out - ref.numpy()).max() < 3e-4 * float(ref.abs().max())
+
+
+def test_collate_and_mix3d_match_the_reference_functions():
+    """pointcept_amd.transform.collate_fn / point_collate_fn (the device-tensor collate with Mix3D) against
+    pointcept/datasets/utils.py:19-73,208-258 on the same samples: offsets, instance shift, the grid_coord recomputation
+    of merged pairs -- five ragged scenes, with and without mixing."""
+    import copy
+
+    from oracle import ref_import
+    from pointcept_amd import synthetic
+    from pointcept_amd import transform as T
+
+    U = ref_import.load_dataset_utils()
+
+    def sample(seed, n):
+        s = synthetic.indoor_scene(seed, n)
+        d = {k: torch.from_numpy(v) for k, v in s.items()}
+        d["offset"] = torch.tensor([d["coord"].shape[0]])
+        d["instance"] = torch.randint(-1, 5, (d["coord"].shape[0],), generator=torch.Generator().manual_seed(seed))
+        d["grid_size"] = torch.tensor([0.02])
+        return d
+
+    items = [sample(s, n) for s, n in ((1, 500), (2, 300), (3, 700), (4, 200), (5, 100))]
+    for mix in (0, 1):
+        a = U.point_collate_fn(copy.deepcopy(items), mix_prob=mix)
+        b = T.point_collate_fn(copy.deepcopy(items), mix_prob=mix, mix=bool(mix))
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k].to(torch.float64), b[k].to(torch.float64)), (mix, k)
+    assert b["offset"].tolist() == [800, 1700, 1800]
