@@ -8,6 +8,7 @@
 // so the convolution is output-stationary: no atomics, bit-reproducible accumulation order.
 #include "ptc_common.h"
 #include "voxel_hash.h"
+#include <stdlib.h>
 
 extern "C" int ptc_sort_keys(const int64_t*, int64_t, int, int, int, int64_t*, int64_t*, void*, size_t, ptc_stream_t);
 extern "C" size_t ptc_sort_keys_workspace_bytes(int64_t, int);
@@ -78,9 +79,84 @@ extern "C" int ptc_hash_build(const int32_t* indices, int64_t n, void* table, si
 // (key compare) and, on a hit, one 32-byte read of its 8 row indices, which are then scattered to the window
 // offsets they belong to.  Consecutive lanes hold neighbouring voxels (curve order), so the handful of
 // buckets of a window is shared by the whole wave and served by L1/L2.
+// Round 2: the probes of a window are INDEPENDENT, the first version walked them one after the other
+// (`#pragma unroll 1`): rocprofv3 PMC at 819200 voxels: 81 % of the wave cycles in s_waitcnt, 9 % issuing
+// (profiles/r02_a_conv_pmc_s0.json) -- a chain of 8 (k = 3) or 27 (k = 5) dependent L2 latencies per voxel.  Now the
+// home-slot keys of a GROUP of blocks (8 / 9) are requested together, collisions (rare at load <= 1/3: linear probing
+// from the home slot) are resolved per block, then the 32-byte value reads of the group go out together.
 template <int KS>
 __global__ void __launch_bounds__(256)
 rulebook_subm_kernel(const int32_t* __restrict__ indices, int64_t n, const VoxBucket* __restrict__ table, uint64_t mask,
+                     int32_t* __restrict__ nbr) {
+  constexpr int R = KS / 2, NB = R + 1, NBLK = NB * NB * NB;
+  constexpr int GB = NBLK <= 9 ? NBLK : 9;                 // blocks per group: 1 | 8 | 9 (k = 5, 7: 3 / 8 groups... NBLK % GB == 0 for 1,8,27,64)
+  constexpr int NG = (NBLK + GB - 1) / GB;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[i];
+    const int bx0 = (c.y - R) >> 1, by0 = (c.z - R) >> 1, bz0 = (c.w - R) >> 1;   // arithmetic shift: floor for negatives
+    const int ex = c.y - 2 * bx0, ey = c.z - 2 * by0, ez = c.w - 2 * bz0;         // R or R + 1
+#pragma unroll 1
+    for (int grp = 0; grp < NG; ++grp) {
+      unsigned long long key[GB], kk[GB];
+      uint64_t slot[GB];
+      bool live[GB];
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        const int ob = grp * GB + q;
+        const int o0 = ob / (NB * NB), o1 = (ob / NB) % NB, o2 = ob % NB;
+        const int bx = bx0 + o0, by = by0 + o1, bz = bz0 + o2;
+        live[q] = ob < NBLK && bx >= 0 && by >= 0 && bz >= 0 && bx < (PTC_VOX_MAX >> 1) && by < (PTC_VOX_MAX >> 1) && bz < (PTC_VOX_MAX >> 1);
+        key[q] = ptc_vox_pack(c.x, bx, by, bz);
+        slot[q] = ptc_vox_home(key[q]) & mask;
+        kk[q] = table[slot[q]].key;                                   // all GB home-slot keys in flight (always in bounds)
+      }
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        bool found = live[q] && kk[q] == key[q];
+        if (live[q] && !found && kk[q] != PTC_HASH_EMPTY) {           // collision at the home slot: walk on
+          uint64_t sl = slot[q];
+          for (uint64_t probe = 1; probe <= mask; ++probe) {
+            sl = (sl + 1) & mask;
+            const unsigned long long k2 = table[sl].key;
+            if (k2 == key[q]) { found = true; slot[q] = sl; break; }
+            if (k2 == PTC_HASH_EMPTY) break;
+          }
+        }
+        live[q] = found;
+      }
+      uint4 v0[GB], v1[GB];
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        const uint4* pv = reinterpret_cast<const uint4*>(table[slot[q]].vals);   // in bounds whether found or not
+        v0[q] = pv[0];
+        v1[q] = pv[1];
+      }
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        const int ob = grp * GB + q;
+        if (ob >= NBLK) continue;
+        const int o0 = ob / (NB * NB), o1 = (ob / NB) % NB, o2 = ob % NB;
+        const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
+        const uint4 a = live[q] ? v0[q] : none, b2 = live[q] ? v1[q] : none;
+        const unsigned int vv[8] = {a.x, a.y, a.z, a.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+        for (int cell = 0; cell < 8; ++cell) {
+          const int d0 = 2 * o0 + (cell >> 2) - ex, d1 = 2 * o1 + ((cell >> 1) & 1) - ey, d2 = 2 * o2 + (cell & 1) - ez;
+          if (d0 >= -R && d0 <= R && d1 >= -R && d1 <= R && d2 >= -R && d2 <= R) {
+            const int k = ((d0 + R) * KS + (d1 + R)) * KS + (d2 + R);
+            nbr[(int64_t)k * n + i] = (int32_t)vv[cell];
+          }
+        }
+      }
+    }
+  }
+}
+
+// first-generation kernel (one dependent probe chain per voxel), kept behind PTC_RULEBOOK_V1=1 for A/B runs
+template <int KS>
+__global__ void __launch_bounds__(256)
+rulebook_subm_kernel_v1(const int32_t* __restrict__ indices, int64_t n, const VoxBucket* __restrict__ table, uint64_t mask,
                      int32_t* __restrict__ nbr) {
   constexpr int R = KS / 2, NB = R + 1;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -132,6 +208,18 @@ extern "C" int ptc_rulebook_subm(const int32_t* indices, int64_t n, int ksize, c
   const uint64_t mask = (uint64_t)(ptc_hash_table_size(n) - 1);
   const VoxBucket* tb = (const VoxBucket*)table;
   hipStream_t s = (hipStream_t)stream;
+  if (const char* e = getenv("PTC_RULEBOOK_V1")) {
+    if (atoi(e) != 0) {
+      switch (ksize) {
+        case 1: hipLaunchKernelGGL(rulebook_subm_kernel_v1<1>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
+        case 3: hipLaunchKernelGGL(rulebook_subm_kernel_v1<3>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
+        case 5: hipLaunchKernelGGL(rulebook_subm_kernel_v1<5>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
+        default: hipLaunchKernelGGL(rulebook_subm_kernel_v1<7>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
+      }
+      PTC_CHECK_LAUNCH("rulebook_subm_kernel_v1");
+      return PTC_OK;
+    }
+  }
   switch (ksize) {
     case 1: hipLaunchKernelGGL(rulebook_subm_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
     case 3: hipLaunchKernelGGL(rulebook_subm_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;

@@ -199,6 +199,17 @@ def _merge_duplicate_rows(g: torch.Tensor, rep: torch.Tensor) -> torch.Tensor:
     return out.to(g.dtype)
 
 
+_rev_index_cache = {}
+
+
+def _reverse_index(n: int, device) -> torch.Tensor:
+    key = (n, device)
+    t = _rev_index_cache.get(key)
+    if t is None:
+        t = _rev_index_cache[key] = torch.arange(n - 1, -1, -1, device=device)
+    return t
+
+
 class _SparseConv(Function):
     """out = conv(feat; weight [C_out, kv, C_in], bias) over gather table `nbr`;
     `nbr_t` is the table of the transposed map (SubM: the same table, with mirrored weights).
@@ -238,10 +249,11 @@ class _SparseConv(Function):
         dfeat = dw = dbias = None
         if ctx.needs_input_grad[0]:
             wt = w.permute(2, 1, 0)
-            if ctx.mirror:
-                wt = wt.flip(1)
+            if ctx.mirror:   # W' = W.permute(ci, k, co).flip(k), contiguous, in ONE launch (flip + contiguous were two)
+                wt = wt.index_select(1, _reverse_index(wt.shape[1], wt.device))
+            else:
+                wt = wt.contiguous()
             gm = g if dup_out is None else _merge_duplicate_rows(g, dup_out)
-            wt = wt.contiguous()
             blk = None if ctx.blocks is None else ctx.blocks.get(gm.shape[1], wt.shape[0], gm.dtype)
             dfeat = ops.spconv_fwd(gm, wt, None, nbr_t, blk)[:, :c_in].to(ctx.in_dtype)
             if dup_in is not None:

@@ -349,17 +349,23 @@ class Block(PointModule):
                 if isinstance(m, PNN.LayerNorm):
                     m.gemm_consumer = True
 
+    _ones = {}   # device -> persistent ones buffer (grown on demand): source operand of the one-launch mask below
+
     def _row_keep_scale(self, n, device):
-        """per-point DropPath factor (timm DropPath on [N,C] drops rows) or None"""
+        """per-point DropPath factor (timm DropPath on [N,C] drops rows) or None.
+        ONE launch: fused dropout of a persistent ones vector yields 0 or 1/keep per row (bernoulli_ + div_ were two
+        launches per mask, 80 per step at the bench config, profiles/r02_g_trace_copies.txt)."""
         dp = self.drop_path[0]
         p = getattr(dp, "drop_prob", 0.0)
         if p == 0.0 or not self.training:
             return None
         keep = 1.0 - p
-        mask = torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep)
-        if keep > 0.0 and getattr(dp, "scale_by_keep", True):
-            mask.div_(keep)
-        return mask
+        if not (keep > 0.0 and getattr(dp, "scale_by_keep", True)):
+            return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep)
+        ones = Block._ones.get(device)
+        if ones is None or ones.numel() < n:
+            ones = Block._ones[device] = torch.ones(max(n, 1 << 20), dtype=torch.float32, device=device)
+        return torch.nn.functional.dropout(ones[:n], p=p, training=True)
 
     def _fusable(self, point) -> bool:
         return (config.FUSE_BLOCK and self.pre_norm and point.feat.is_cuda and point.feat.dim() == 2

@@ -50,21 +50,39 @@ def _golden_batch(g):
     return batch
 
 
-def _compare_grads(eng, orc, tag):
+def _fp64_twin(orc, batch):
+    """the same oracle in float64 after one forward + backward on `batch`.  Why: the tiny configurations normalise over a
+    dozen rows at their deepest level (train-mode BatchNorm) and are ill-conditioned enough that the fp32 CPU oracle ITSELF
+    moves by 1-2 % on the worst BatchNorm parameters when only its thread count (= summation order) changes -- measured:
+    8 threads 1.2e-2, 1 thread 1.8e-2, 4 threads 1.6e-5 away from the fp64 result, which is stable to 1e-13 under row
+    permutation.  Gradients are therefore judged against the fp64 oracle, with a bar of twice the fp32 oracle's own spread."""
+    import copy
+
+    from oracle import spunet_model as osp
+
+    o64 = copy.deepcopy(orc).double().train()
+    o64.zero_grad(set_to_none=True)
+    b = {k: torch.from_numpy(v) for k, v in batch.items()}
+    b = {k: (v.double() if v.is_floating_point() else v) for k, v in b.items()}
+    osp.Segmentor(o64)(b)["loss"].backward()
+    return o64
+
+
+def _compare_grads(eng, orc, tag, bar=0.02):
     go = dict(orc.named_parameters())
     rows, bad = [], []
     for name, p in eng.named_parameters():
         assert p.grad is not None, f"no gradient for {name}"
         assert torch.isfinite(p.grad).all(), name
         r = go[name].grad
-        rows.append((name, float((p.grad.cpu() - r).norm()), float(r.norm()), float(r.abs().max())))
+        rows.append((name, float((p.grad.cpu().to(r.dtype) - r).norm()), float(r.norm()), float(r.abs().max())))
     gmax = max(r[3] for r in rows)
     for name, dn, rn, rmax in rows:
         rel = dn / max(rn, 1e-30)
         if rmax < 1e-5 * gmax:   # true gradient is zero (rounding noise on both sides): absolute comparison
             if dn > 1e-4 * gmax * max(1.0, float(go[name].numel()) ** 0.5):
                 bad.append((name, rel, rn))
-        elif rel > 0.02:
+        elif rel > bar:
             bad.append((name, rel, rn))
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/grad_report_{tag}.txt", "w") as f:
@@ -105,7 +123,7 @@ def test_spunet_tiny_matches_reference_golden_and_oracle(cuda):
     orc.train()
     out_o = osp.Segmentor(orc)({k: torch.from_numpy(v) for k, v in batch.items()})
     out_o["loss"].backward()
-    _compare_grads(eng, orc, "spunet_tiny")
+    _compare_grads(eng, _fp64_twin(orc, batch), "spunet_tiny", bar=0.04)
     for (k, a), (_, b) in zip(eng.state_dict().items(), orc.state_dict().items()):
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert _rel(a, b) < 1e-3, k
