@@ -343,6 +343,21 @@ int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void* dout, cons
                         int max_seqlen, float softmax_scale, int dtype, void* dqkv,
                         void* workspace, size_t workspace_bytes, ptc_stream_t stream);
 
+/* Same operator for head_dim 17..64 (PT-v3m3 / LitePT: head_dim 18, flash_attn_varlen_qkvpacked_func as called at
+ * pointcept/models/point_transformer_v3/point_transformer_v3m3_utonia.py:353-359 and pointcept/models/litept/litept_v1.py:244-256):
+ *   qkv [total, 3, H, head_dim] bf16 packed, out [total, H, head_dim], lse [H, total] fp32, dqkv like qkv.
+ * The window's operands live in LDS, which bounds max_seqlen: head_dim <= 32: 1024, <= 48: 672, <= 64: 512
+ * (ptc_attn_varlen_hd_supported returns 1 / 0; the calls return PTC_EUNSUPPORTED outside that range).
+ * The backward's workspace is ptc_attn_varlen_bwd_workspace_bytes(total, H). */
+int ptc_attn_varlen_hd_supported(int head_dim, int max_seqlen);
+int ptc_attn_varlen_hd_fwd(const void* qkv, const int32_t* cu_seqlens, int64_t n_seq, int64_t total,
+                           int H, int head_dim, int max_seqlen, float softmax_scale, int dtype,
+                           void* out, float* lse, ptc_stream_t stream);
+int ptc_attn_varlen_hd_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                           const int32_t* cu_seqlens, int64_t n_seq, int64_t total, int H,
+                           int head_dim, int max_seqlen, float softmax_scale, int dtype, void* dqkv,
+                           void* workspace, size_t workspace_bytes, ptc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * I. Ends of the step.
  * ptc_coord_max: out3[a] = max_i grid_coord[i][a] (0 for n == 0).  Replaces the reductions behind

@@ -839,6 +839,8 @@ attn_bwd_fused_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
   }
 }
 
+#include "attention_hd.h"
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -954,4 +956,93 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
                      softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv, prio);
   PTC_CHECK_LAUNCH("attn_bwd_dkv_kernel");
   return PTC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// head_dim 17..64 (attention_hd.h)
+// ------------------------------------------------------------------------------------------------
+static size_t hd_fwd_lds(int dk, int D, int lp_max) { return (size_t)dk * lp_max * 32 + (size_t)(D + 1) * (lp_max + 8) * 2 + AT_WAVES * 4; }
+static size_t hd_dq_lds(int dk, int lp_max) { return (size_t)2 * dk * lp_max * 32; }
+static size_t hd_dkv_lds(int dk, int lp_max) { return (size_t)2 * dk * lp_max * 32 + (size_t)lp_max * 8; }
+
+extern "C" int ptc_attn_varlen_hd_supported(int head_dim, int max_seqlen) {
+  if (head_dim < 17 || head_dim > 64 || max_seqlen < 1 || max_seqlen > AT_MAX_L) return 0;
+  const int dk = (head_dim + 15) / 16, lp_max = (max_seqlen + 31) & ~31;
+  return hd_fwd_lds(dk, head_dim, lp_max) <= AH_LDS_LIMIT && hd_dkv_lds(dk, lp_max) <= AH_LDS_LIMIT;
+}
+
+static int hd_check(const char* name, const void* qkv, const int32_t* cu, int64_t n_seq, int64_t total, int H, int D,
+                    int max_seqlen, int dtype) {
+  int rc = check_common(name, qkv, cu, n_seq, total, H, max_seqlen, dtype);
+  if (rc != PTC_OK) return rc;
+  PTC_REQUIRE(ptc_attn_varlen_hd_supported(D, max_seqlen), PTC_EUNSUPPORTED,
+              "%s: head_dim=%d with max_seqlen=%d is outside the LDS-resident range (17..32: 1024 keys, ..48: 672, ..64: 512)", name, D,
+              max_seqlen);
+  return PTC_OK;
+}
+
+extern "C" int ptc_attn_varlen_hd_fwd(const void* qkv, const int32_t* cu_seqlens, int64_t n_seq, int64_t total, int H, int head_dim,
+                                      int max_seqlen, float softmax_scale, int dtype, void* out, float* lse, ptc_stream_t stream) {
+  int rc = hd_check("ptc_attn_varlen_hd_fwd", qkv, cu_seqlens, n_seq, total, H, head_dim, max_seqlen, dtype);
+  if (rc != PTC_OK) return rc;
+  if (n_seq == 0 || total == 0) return PTC_OK;
+  PTC_REQUIRE(out && lse, PTC_EINVAL, "ptc_attn_varlen_hd_fwd: null buffer");
+  const int lp_max = (max_seqlen + 31) & ~31, dk = (head_dim + 15) / 16, mb = head_dim / 32 + 1;
+  const size_t lds = hd_fwd_lds(dk, head_dim, lp_max);
+  const int n_units = (int)(n_seq * H);
+  const int qs = at_split(n_units, lp_max);
+  hipStream_t s = (hipStream_t)stream;
+#define AH_FWD_CASE(DK, MB)                                                                                                    \
+  if (dk == DK && mb == MB) {                                                                                                  \
+    rc = allow_big_lds(attn_hd_fwd_kernel<DK, MB>, lds);                                                                       \
+    if (rc != PTC_OK) return rc;                                                                                               \
+    hipLaunchKernelGGL((attn_hd_fwd_kernel<DK, MB>), dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds, s,  \
+                       (const uint16_t*)qkv, cu_seqlens, H, head_dim, softmax_scale, total, lp_max, n_units, qs, (uint16_t*)out, \
+                       lse);                                                                                                   \
+    PTC_CHECK_LAUNCH("attn_hd_fwd_kernel");                                                                                    \
+    return PTC_OK;                                                                                                             \
+  }
+  AH_FWD_CASE(2, 1) AH_FWD_CASE(2, 2) AH_FWD_CASE(3, 2) AH_FWD_CASE(4, 2) AH_FWD_CASE(4, 3)
+#undef AH_FWD_CASE
+  ptc_set_error("ptc_attn_varlen_hd_fwd: no instance for head_dim=%d", head_dim);
+  return PTC_EUNSUPPORTED;
+}
+
+extern "C" int ptc_attn_varlen_hd_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
+                                      int64_t n_seq, int64_t total, int H, int head_dim, int max_seqlen, float softmax_scale,
+                                      int dtype, void* dqkv, void* workspace, size_t workspace_bytes, ptc_stream_t stream) {
+  int rc = hd_check("ptc_attn_varlen_hd_bwd", qkv, cu_seqlens, n_seq, total, H, head_dim, max_seqlen, dtype);
+  if (rc != PTC_OK) return rc;
+  if (n_seq == 0 || total == 0) return PTC_OK;
+  PTC_REQUIRE(out && dout && lse && dqkv && workspace, PTC_EINVAL, "ptc_attn_varlen_hd_bwd: null buffer");
+  PTC_REQUIRE(workspace_bytes >= ptc_attn_varlen_bwd_workspace_bytes(total, H), PTC_EWORKSPACE,
+              "ptc_attn_varlen_hd_bwd: workspace too small");
+  PTC_REQUIRE(((uintptr_t)out % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0), PTC_EINVAL,
+              "ptc_attn_varlen_hd_bwd: buffers must be 16-byte aligned");
+  const int lp_max = (max_seqlen + 31) & ~31, dk = (head_dim + 15) / 16;
+  const int n_units = (int)(n_seq * H);
+  const int qs = at_split(n_units, lp_max);
+  const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
+  hipStream_t s = (hipStream_t)stream;
+  float* delta = (float*)workspace;
+#define AH_BWD_CASE(DK)                                                                                                        \
+  if (dk == DK) {                                                                                                              \
+    rc = allow_big_lds(attn_hd_bwd_dq_kernel<DK>, hd_dq_lds(DK, lp_max));                                                      \
+    if (rc != PTC_OK) return rc;                                                                                               \
+    rc = allow_big_lds(attn_hd_bwd_dkv_kernel<DK>, hd_dkv_lds(DK, lp_max));                                                    \
+    if (rc != PTC_OK) return rc;                                                                                               \
+    hipLaunchKernelGGL((attn_hd_bwd_dq_kernel<DK>), dim3(grid), dim3(AT_THREADS), hd_dq_lds(DK, lp_max), s,                    \
+                       (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H, head_dim,        \
+                       softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv, delta);                                     \
+    PTC_CHECK_LAUNCH("attn_hd_bwd_dq_kernel");                                                                                 \
+    hipLaunchKernelGGL((attn_hd_bwd_dkv_kernel<DK>), dim3(grid), dim3(AT_THREADS), hd_dkv_lds(DK, lp_max), s,                  \
+                       (const uint16_t*)qkv, (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H, head_dim,         \
+                       softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv);                                            \
+    PTC_CHECK_LAUNCH("attn_hd_bwd_dkv_kernel");                                                                                \
+    return PTC_OK;                                                                                                             \
+  }
+  AH_BWD_CASE(2) AH_BWD_CASE(3) AH_BWD_CASE(4)
+#undef AH_BWD_CASE
+  ptc_set_error("ptc_attn_varlen_hd_bwd: no instance for head_dim=%d", head_dim);
+  return PTC_EUNSUPPORTED;
 }

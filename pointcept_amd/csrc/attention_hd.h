@@ -1,0 +1,494 @@
+// attention_hd.h -- serialized patch attention for head_dim 17..64 (included by attention.hip).
+//
+// PT-v3m3 (Utonia) and LitePT pick head_dim = channels / heads = 18 so that the 3-D RoPE can give every axis a third of the
+// channels (pointcept/models/point_transformer_v3/point_transformer_v3m3_utonia.py:43-51,183,354; pointcept/models/litept/
+// litept_v1.py:236-251; configs/utonia/*: enc_channels (54,...,576) / enc_num_head (3,...,32)).  flash-attn pads such heads
+// to the next multiple of 8 internally; here the head is cut into DK SLABS of 16 channels (zero padded beyond head_dim) and every
+// slab is one more k-step of the same 32x32x16 products the head_dim-16 kernels use, on the same LDS images (one [Lp][16]
+// row-major image per slab, same swizzle, same transposed reads).  What changes against attention.hip:
+//   * S' = K (q c)^T - ref : 2 DK MFMAs (hi + lo part of the scaled query per slab)
+//   * P V : the A operand carries 32 rows = 32 channels per M-block; the row of ones that yields the softmax denominator is row
+//     head_dim, so heads below 32 channels still need ONE block, 32..63 two, 64 three (MB = head_dim / 32 + 1)
+//   * transposed operands of the backward products address TWO slabs at once (lanes 0..15 of each half the even slab, lanes
+//     16..31 the odd one: ds_read_b64_tr_b16 works per 16-lane group), so a 32-row operand is 32 real channels
+//   * rows of qkv / out are head_dim * 2 bytes: 16-byte vector loads when head_dim % 8 == 0, 4-byte loads when it is even
+//     (18), 2-byte loads otherwise
+//   * no software pipelining by hand and one workgroup per CU (K and V^T of a 1024-key window with 32 padded channels take
+//     131 KB): a first correct tier-1 path for the m3 / LitePT files, measured in tools/bench_ops.py attn_hd.
+// LDS capacity bounds the window: head_dim <= 32 up to 1024 keys, <= 48 up to 672, <= 64 up to 512 (ptc_attn_varlen_hd_supported).
+
+#define AH_LDS_LIMIT 163840
+
+// 8 channels [ch0, ch0 + 8) of a row of `D` bf16 channels (zeros beyond D / for invalid rows)
+__device__ __forceinline__ uint4 ah_ld8(const uint16_t* __restrict__ row, int ch0, int D, bool valid) {
+  uint4 v = {0, 0, 0, 0};
+  if (!valid || ch0 >= D) return v;
+  if ((D & 7) == 0) return *reinterpret_cast<const uint4*>(row + ch0);
+  if ((D & 1) == 0) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(row + ch0);
+    v.x = p[0];
+    if (ch0 + 2 < D) v.y = p[1];
+    if (ch0 + 4 < D) v.z = p[2];
+    if (ch0 + 6 < D) v.w = p[3];
+    return v;
+  }
+  uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (ch0 + i < D) w[i >> 1] |= (uint32_t)row[ch0 + i] << (16 * (i & 1));
+  v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+  return v;
+}
+__device__ __forceinline__ s16x8 ah_frag(uint4 u) { return *reinterpret_cast<s16x8*>(&u); }
+__device__ __forceinline__ float ah_sumsq(uint4 v) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = __uint_as_float(w[j] << 16), b = __uint_as_float(w[j] & 0xffff0000u);
+    ss = fmaf(a, a, fmaf(b, b, ss));
+  }
+  return ss;
+}
+__device__ __forceinline__ float ah_dot(uint4 x, uint4 y) {
+  const uint32_t a[4] = {x.x, x.y, x.z, x.w}, b[4] = {y.x, y.y, y.z, y.w};
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s = fmaf(__uint_as_float(a[j] << 16), __uint_as_float(b[j] << 16), s);
+    s = fmaf(__uint_as_float(a[j] & 0xffff0000u), __uint_as_float(b[j] & 0xffff0000u), s);
+  }
+  return s;
+}
+
+// rows [0, Lp) of a [.., D] operand into DK slab images ([lp_max][16] each, rm_off swizzle); returns max |row|^2 of this thread
+template <int DK>
+__device__ __forceinline__ float ah_stage_rows(const uint16_t* __restrict__ src, int64_t row_stride, int D, int L, int Lp,
+                                               int slab_bytes, unsigned char* lds) {
+  float mx = 0.f;
+  for (int row = threadIdx.x; row < Lp; row += AT_THREADS) {
+    const uint16_t* p = src + (int64_t)row * row_stride;
+    const bool valid = row < L;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < DK; ++j) {
+      const uint4 v0 = ah_ld8(p, 16 * j, D, valid), v1 = ah_ld8(p, 16 * j + 8, D, valid);
+      *reinterpret_cast<uint4*>(lds + j * slab_bytes + rm_off(row, 0)) = v0;
+      *reinterpret_cast<uint4*>(lds + j * slab_bytes + rm_off(row, 1)) = v1;
+      ss += ah_sumsq(v0) + ah_sumsq(v1);
+    }
+    mx = fmaxf(mx, ss);
+  }
+  return mx;
+}
+// V^T image [D + 1][pitch] with the key permutation of stage_transposed; row D = 1.0 for keys < L (softmax denominator)
+template <int DK>
+__device__ __forceinline__ void ah_stage_vt(const uint16_t* __restrict__ src, int64_t row_stride, int D, int L, int Lp, int pitch,
+                                            unsigned char* lds) {
+  uint32_t* t32 = reinterpret_cast<uint32_t*>(lds);
+  for (int p = threadIdx.x; p < Lp / 2; p += AT_THREADS) {
+    const int ra = 2 * p, rb = 2 * p + 1;
+    const uint16_t* pa = src + (int64_t)ra * row_stride;
+    const uint16_t* pb = src + (int64_t)rb * row_stride;
+    const int w = vt_pos(ra) >> 1;
+#pragma unroll
+    for (int j = 0; j < DK; ++j) {
+      uint16_t ea[16], eb[16];
+      *reinterpret_cast<uint4*>(ea) = ah_ld8(pa, 16 * j, D, ra < L);
+      *reinterpret_cast<uint4*>(ea + 8) = ah_ld8(pa, 16 * j + 8, D, ra < L);
+      *reinterpret_cast<uint4*>(eb) = ah_ld8(pb, 16 * j, D, rb < L);
+      *reinterpret_cast<uint4*>(eb + 8) = ah_ld8(pb, 16 * j + 8, D, rb < L);
+#pragma unroll
+      for (int d = 0; d < 16; ++d)
+        if (16 * j + d < D) t32[((16 * j + d) * pitch) / 2 + w] = (uint32_t)ea[d] | ((uint32_t)eb[d] << 16);
+    }
+  }
+  for (int key = threadIdx.x; key < Lp; key += AT_THREADS)
+    reinterpret_cast<uint16_t*>(lds + (size_t)D * pitch * 2)[vt_pos(key)] = key < L ? (uint16_t)0x3F80 : (uint16_t)0;
+}
+// NaN rows for units longer than max_seqlen (see at_poison_rows)
+__device__ __forceinline__ void ah_poison_rows(uint16_t* rows, int64_t row_stride, int D, int L, float* side) {
+  for (int q = threadIdx.x; q < L; q += AT_THREADS) {
+    for (int d = 0; d < D; ++d) rows[(int64_t)q * row_stride + d] = (uint16_t)0x7FC0;
+    if (side) side[q] = __uint_as_float(0x7FC00000u);
+  }
+}
+// register r of lane half h2 holds row crow(r, h2): the (register, half) that hold row `row` of a 32-row block
+__device__ __forceinline__ float ah_pick_row(const f32x16& acc, int row) {
+  const int r = (row & 3) + 4 * (row >> 3);
+  float v = acc[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) v = (i == r) ? acc[i] : v;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// LDS: K slabs DK x [lp_max][16] | V^T [D + 1][pitch] | AT_WAVES floats
+template <int DK, int MB>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu, int H, int D, float scale, int64_t total,
+                   int lp_max, int n_units, int qs, uint16_t* __restrict__ out, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lunit = at_unit(n_units * qs);
+  if (lunit >= n_units * qs) return;
+  const int unit = lunit / qs, part = lunit - unit * qs;
+  const int seq = unit / H, head = unit % H;
+  const int a = cu[seq], L = cu[seq + 1] - a;
+  if (L <= 0) return;
+  const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
+  const int64_t rs = (int64_t)3 * H * D, os = (int64_t)H * D;
+  if (Lp > lp_max) {
+    if (part == 0) ah_poison_rows(out + ((int64_t)a * H + head) * D, os, D, L, lse + (int64_t)head * total + a);
+    return;
+  }
+  const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
+  if (t_lo >= n_tiles) return;
+  const int pitch = lp_max + 8, slab = lp_max * 32;
+  unsigned char* Ksm = smem;
+  unsigned char* Vt = smem + (size_t)DK * slab;
+  float* red = reinterpret_cast<float*>(Vt + (size_t)(D + 1) * pitch * 2);
+  const int lane = ptc_lane(), wave = threadIdx.x >> 6;
+  const uint16_t* qbase = qkv + ((int64_t)a * 3 * H + head) * D;            // q row t: qbase + t * rs; k: + H*D; v: + 2*H*D
+  float kn = ah_stage_rows<DK>(qbase + (int64_t)H * D, rs, D, L, Lp, slab, Ksm);
+  ah_stage_vt<DK>(qbase + (int64_t)2 * H * D, rs, D, L, Lp, pitch, Vt);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) kn = fmaxf(kn, __shfl_xor(kn, o, 64));
+  if (lane == 0) red[wave] = kn;
+  __syncthreads();
+  float kmax2 = red[0];
+#pragma unroll
+  for (int w = 1; w < AT_WAVES; ++w) kmax2 = fmaxf(kmax2, red[w]);
+
+  const int col = lane & 31, h2 = lane >> 5;
+  const float c = scale * AT_LOG2E;
+  const unsigned char* vbase[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    const int row = 32 * m + col;
+    vbase[m] = Vt + ((size_t)(row <= D ? row : (col & 15)) * pitch + 8 * h2) * 2;   // rows > D feed outputs nobody reads
+  }
+  const unsigned char* kbase = Ksm + rm_off(col, h2);
+  const int den_row = D & 31;                                                        // block MB - 1 holds the denominator row
+
+  for (int qt = t_lo + wave; qt < t_hi; qt += AT_WAVES) {
+    const int q = qt * 32 + col;
+    const uint16_t* qrow = qbase + (int64_t)q * rs;
+    s16x8 qhi[DK], qlo[DK];
+    float qn = 0.f;
+#pragma unroll
+    for (int j = 0; j < DK; ++j) {
+      const uint4 u = ah_ld8(qrow, 16 * j + 8 * h2, D, q < L);
+      qn += ah_sumsq(u);
+      split_scaled(ah_frag(u), c, qhi[j], qlo[j]);
+    }
+    qn += __shfl_xor(qn, 32, 64);
+    const float bnd = sqrtf(qn * kmax2) * c * 1.0009765625f + 1e-3f;
+    f32x16 acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = zero16();
+    float ref2;
+    if (__builtin_amdgcn_ballot_w64(bnd > AT_FIXED_REF_MAX) == 0) {
+      ref2 = bnd;
+      const f32x16 negb = splat16(-bnd);
+      for (int kt = 0; kt < n_tiles; ++kt) {
+        f32x16 s = negb;
+#pragma unroll
+        for (int j = 0; j < DK; ++j) {
+          const s16x8 kf = *reinterpret_cast<const s16x8*>(kbase + j * slab + kt * 1024);
+          s = mfma32(kf, qhi[j], s);
+          s = mfma32(kf, qlo[j], s);
+        }
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i]), __builtin_amdgcn_exp2f(s[2 * i + 1]));
+        const s16x8 p0 = make_frag(pk[0], pk[1], pk[2], pk[3]), p1 = make_frag(pk[4], pk[5], pk[6], pk[7]);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          acc[m] = mfma32(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64), p0, acc[m]);
+          acc[m] = mfma32(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64 + 32), p1, acc[m]);
+        }
+      }
+    } else {
+      float mrun = -INFINITY;
+      for (int kt = 0; kt < n_tiles; ++kt) {
+        f32x16 s = zero16();
+#pragma unroll
+        for (int j = 0; j < DK; ++j) {
+          const s16x8 kf = *reinterpret_cast<const s16x8*>(kbase + j * slab + kt * 1024);
+          s = mfma32(kf, qhi[j], s);
+          s = mfma32(kf, qlo[j], s);
+        }
+        if (kt == n_tiles - 1 && L < Lp) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kt * 32 + crow(r, h2) >= L) s[r] = -INFINITY;
+        }
+        float mt = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(mrun, mt);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - m_new);
+        mrun = m_new;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][r] *= alpha;
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i] - mrun), __builtin_amdgcn_exp2f(s[2 * i + 1] - mrun));
+        const s16x8 p0 = make_frag(pk[0], pk[1], pk[2], pk[3]), p1 = make_frag(pk[4], pk[5], pk[6], pk[7]);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          acc[m] = mfma32(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64), p0, acc[m]);
+          acc[m] = mfma32(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64 + 32), p1, acc[m]);
+        }
+      }
+      ref2 = mrun;
+    }
+    const float l = __shfl(ah_pick_row(acc[MB - 1], den_row), col + 32 * ((den_row >> 2) & 1), 64);
+    const float inv = 1.f / l;
+    if (q < L) {
+      uint16_t* o = out + ((int64_t)(a + q) * H + head) * D;
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {                       // registers r, r + 1 = channels ch, ch + 1 (ch even)
+          const int ch = 32 * m + crow(r, h2);
+          const uint32_t w = pack_bf16x2(acc[m][r] * inv, acc[m][r + 1] * inv);
+          if (ch + 1 < D && (D & 1) == 0) *reinterpret_cast<uint32_t*>(o + ch) = w;
+          else {
+            if (ch < D) o[ch] = (uint16_t)(w & 0xffffu);
+            if (ch + 1 < D) o[ch + 1] = (uint16_t)(w >> 16);
+          }
+        }
+      if (h2 == 0) lse[(int64_t)head * total + a + q] = ref2 * AT_LN2 + __logf(l);
+    }
+  }
+}
+
+// transposed 32-row operand over a slab PAIR: lanes 0..15 of each half address slab 2m, lanes 16..31 slab 2m + 1
+// (slab 2m again when the pair is incomplete: those rows only reach outputs at channels >= 16 DK, never written)
+template <int DK>
+__device__ __forceinline__ int ah_pair_off(int m, int col, int slab_bytes) {
+  const int j = (col >= 16 && 2 * m + 1 < DK) ? 2 * m + 1 : 2 * m;
+  return j * slab_bytes;
+}
+__device__ __forceinline__ void ah_store_col(uint16_t* row, int ch, int D, float v) {
+  if (ch < D) row[ch] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ + delta
+// LDS: V slabs | K slabs
+template <int DK>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
+                      const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, int D, float scale, int64_t total,
+                      int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, float* __restrict__ delta) {
+  constexpr int MP = (DK + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lunit = at_unit(n_units * qs);
+  if (lunit >= n_units * qs) return;
+  const int unit = lunit / qs, part = lunit - unit * qs;
+  const int seq = unit / H, head = unit % H;
+  const int a = cu[seq], L = cu[seq + 1] - a;
+  if (L <= 0) return;
+  const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
+  const int64_t rs = (int64_t)3 * H * D, os = (int64_t)H * D;
+  uint16_t* dqbase = dqkv + ((int64_t)a * 3 * H + head) * D;
+  if (Lp > lp_max) {
+    if (part == 0) ah_poison_rows(dqbase, rs, D, L, nullptr);
+    return;
+  }
+  const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
+  if (t_lo >= n_tiles) return;
+  const int slab = lp_max * 32;
+  unsigned char* Vsm = smem;
+  unsigned char* Ksm = smem + (size_t)DK * slab;
+  const uint16_t* qbase = qkv + ((int64_t)a * 3 * H + head) * D;
+  ah_stage_rows<DK>(qbase + (int64_t)2 * H * D, rs, D, L, Lp, slab, Vsm);
+  ah_stage_rows<DK>(qbase + (int64_t)H * D, rs, D, L, Lp, slab, Ksm);
+  __syncthreads();
+
+  const int lane = ptc_lane(), wave = threadIdx.x >> 6;
+  const int col = lane & 31, h2 = lane >> 5;
+  const float c = scale * AT_LOG2E;
+  const TrAddr ta = tr_addr(lane);
+  const int rmo = rm_off(col, h2);
+  int poff[MP];
+#pragma unroll
+  for (int m = 0; m < MP; ++m) poff[m] = ah_pair_off<DK>(m, col, slab);
+
+  for (int qt = t_lo + wave; qt < t_hi; qt += AT_WAVES) {
+    const int q = qt * 32 + col;
+    const bool qv = q < L;
+    const uint16_t* qrow = qbase + (int64_t)q * rs;
+    const int64_t orow = ((int64_t)(a + q) * H + head) * D;
+    s16x8 qhi[DK], qlo[DK], dof[DK];
+    float dl = 0.f;
+#pragma unroll
+    for (int j = 0; j < DK; ++j) {
+      const uint4 uq = ah_ld8(qrow, 16 * j + 8 * h2, D, qv);
+      const uint4 ud = ah_ld8(dout + orow, 16 * j + 8 * h2, D, qv);
+      const uint4 uo = ah_ld8(out + orow, 16 * j + 8 * h2, D, qv);
+      dl += ah_dot(ud, uo);
+      dof[j] = ah_frag(ud);
+      split_scaled(ah_frag(uq), c, qhi[j], qlo[j]);
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    const float l2 = qv ? lse[(int64_t)head * total + a + q] * AT_LOG2E : INFINITY;
+    if (qv && h2 == 0) delta[(int64_t)head * total + a + q] = dl;
+    const f32x16 negl = splat16(-l2), negd = splat16(-dl);
+    f32x16 acc[MP];
+#pragma unroll
+    for (int m = 0; m < MP; ++m) acc[m] = zero16();
+    for (int kt = 0; kt < n_tiles; ++kt) {
+      f32x16 s = negl, dp = negd;
+#pragma unroll
+      for (int j = 0; j < DK; ++j) {
+        const s16x8 kf = *reinterpret_cast<const s16x8*>(Ksm + j * slab + kt * 1024 + rmo);
+        const s16x8 vf = *reinterpret_cast<const s16x8*>(Vsm + j * slab + kt * 1024 + rmo);
+        s = mfma32(kf, qhi[j], s);
+        s = mfma32(kf, qlo[j], s);
+        dp = mfma32(vf, dof[j], dp);
+      }
+      uint32_t pk[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i]) * dp[2 * i], __builtin_amdgcn_exp2f(s[2 * i + 1]) * dp[2 * i + 1]);
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) {
+        const s16x8 dsf = make_frag(pk[4 * mm], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]);
+#pragma unroll
+        for (int m = 0; m < MP; ++m) acc[m] = mfma32(ld_tr_frag(Ksm + poff[m], ta, kt * 32 + 16 * mm), dsf, acc[m]);   // dQ^T[d][q]
+      }
+    }
+    if (qv) {
+      uint16_t* o = dqbase + (int64_t)q * rs;
+#pragma unroll
+      for (int m = 0; m < MP; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ah_store_col(o, 32 * m + crow(r, h2), D, acc[m][r] * scale);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+// LDS: Q slabs | dO slabs | aux [lp_max][4] bf16 (lse_hi, lse_lo, delta_hi, delta_lo)
+template <int DK>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                       const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, int D, float scale, int64_t total,
+                       int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv) {
+  constexpr int MP = (DK + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lunit = at_unit(n_units * qs);
+  if (lunit >= n_units * qs) return;
+  const int unit = lunit / qs, part = lunit - unit * qs;
+  const int seq = unit / H, head = unit % H;
+  const int a = cu[seq], L = cu[seq + 1] - a;
+  if (L <= 0) return;
+  const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
+  const int64_t rs = (int64_t)3 * H * D, os = (int64_t)H * D;
+  uint16_t* dbase = dqkv + ((int64_t)a * 3 * H + head) * D;
+  if (Lp > lp_max) {
+    if (part == 0) {
+      ah_poison_rows(dbase + (int64_t)H * D, rs, D, L, nullptr);
+      ah_poison_rows(dbase + (int64_t)2 * H * D, rs, D, L, nullptr);
+    }
+    return;
+  }
+  const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
+  if (t_lo >= n_tiles) return;
+  const int slab = lp_max * 32;
+  unsigned char* Qsm = smem;
+  unsigned char* dOsm = smem + (size_t)DK * slab;
+  uint2* aux = reinterpret_cast<uint2*>(smem + (size_t)2 * DK * slab);
+  const uint16_t* qbase = qkv + ((int64_t)a * 3 * H + head) * D;
+  ah_stage_rows<DK>(qbase, rs, D, L, Lp, slab, Qsm);
+  ah_stage_rows<DK>(dout + ((int64_t)a * H + head) * D, os, D, L, Lp, slab, dOsm);
+  for (int q = threadIdx.x; q < Lp; q += AT_THREADS) {
+    const float l2 = q < L ? lse[(int64_t)head * total + a + q] * AT_LOG2E : AT_PAD_LSE;
+    const float dl = q < L ? delta[(int64_t)head * total + a + q] : 0.f;
+    const uint32_t hi = pack_bf16x2(l2, dl);
+    const uint32_t lo = pack_bf16x2(l2 - __uint_as_float(hi << 16), dl - __uint_as_float(hi & 0xffff0000u));
+    uint2 w;
+    w.x = (hi & 0xffffu) | (lo << 16);
+    w.y = (hi >> 16) | (lo & 0xffff0000u);
+    aux[q] = w;
+  }
+  __syncthreads();
+
+  const int lane = ptc_lane(), wave = threadIdx.x >> 6;
+  const int col = lane & 31, h2 = lane >> 5;
+  const float c = scale * AT_LOG2E;
+  const TrAddr ta = tr_addr(lane);
+  const int rmo = rm_off(col, h2);
+  const uint32_t m1 = 0xBF80BF80u;
+  const s16x8 bS = make_frag(h2 == 0 ? m1 : 0u, 0u, 0u, 0u);
+  const s16x8 bD = make_frag(0u, h2 == 0 ? m1 : 0u, 0u, 0u);
+  int poff[MP];
+#pragma unroll
+  for (int m = 0; m < MP; ++m) poff[m] = ah_pair_off<DK>(m, col, slab);
+
+  for (int kt = t_lo + wave; kt < t_hi; kt += AT_WAVES) {
+    const int key = kt * 32 + col;
+    const uint16_t* krow = qbase + (int64_t)key * rs + (int64_t)H * D;
+    s16x8 khi[DK], klo[DK], vf[DK];
+#pragma unroll
+    for (int j = 0; j < DK; ++j) {
+      split_scaled(ah_frag(ah_ld8(krow, 16 * j + 8 * h2, D, key < L)), c, khi[j], klo[j]);
+      vf[j] = ah_frag(ah_ld8(krow + (int64_t)H * D, 16 * j + 8 * h2, D, key < L));
+    }
+    f32x16 dv[MP], dk[MP];
+#pragma unroll
+    for (int m = 0; m < MP; ++m) { dv[m] = zero16(); dk[m] = zero16(); }
+    for (int qt = 0; qt < n_tiles; ++qt) {
+      const uint2 ax = aux[qt * 32 + col];
+      const s16x8 af = make_frag(ax.x, ax.y, 0u, 0u);
+      f32x16 s = mfma32(af, bS, zero16());
+      f32x16 dp = mfma32(af, bD, zero16());
+#pragma unroll
+      for (int j = 0; j < DK; ++j) {
+        const s16x8 qf = *reinterpret_cast<const s16x8*>(Qsm + j * slab + qt * 1024 + rmo);
+        const s16x8 dof = *reinterpret_cast<const s16x8*>(dOsm + j * slab + qt * 1024 + rmo);
+        s = mfma32(qf, khi[j], s);
+        s = mfma32(qf, klo[j], s);
+        dp = mfma32(dof, vf[j], dp);
+      }
+      uint32_t pp[8], ps[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float p0 = __builtin_amdgcn_exp2f(s[2 * i]), p1 = __builtin_amdgcn_exp2f(s[2 * i + 1]);
+        pp[i] = pack_bf16x2(p0, p1);
+        ps[i] = pack_bf16x2(p0 * dp[2 * i], p1 * dp[2 * i + 1]);
+      }
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) {
+        const s16x8 pf = make_frag(pp[4 * mm], pp[4 * mm + 1], pp[4 * mm + 2], pp[4 * mm + 3]);
+        const s16x8 dsf = make_frag(ps[4 * mm], ps[4 * mm + 1], ps[4 * mm + 2], ps[4 * mm + 3]);
+#pragma unroll
+        for (int m = 0; m < MP; ++m) {
+          dv[m] = mfma32(pf, ld_tr_frag(dOsm + poff[m], ta, qt * 32 + 16 * mm), dv[m]);   // dV[key][d]
+          dk[m] = mfma32(dsf, ld_tr_frag(Qsm + poff[m], ta, qt * 32 + 16 * mm), dk[m]);   // dK[key][d]
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MP; ++m) {
+      const int ch = 32 * m + col;                                // D[i = key][j = d]: lane column = channel, registers = keys
+      if (ch < D && (col < 16 || 2 * m + 1 < DK)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kk = kt * 32 + crow(r, h2);
+          if (kk < L) {
+            uint16_t* o = dbase + (int64_t)kk * rs;
+            o[(int64_t)H * D + ch] = (uint16_t)(pack_bf16x2(dk[m][r] * scale, 0.f) & 0xffffu);
+            o[(int64_t)2 * H * D + ch] = (uint16_t)(pack_bf16x2(dv[m][r], 0.f) & 0xffffu);
+          }
+        }
+      }
+    }
+  }
+}

@@ -3,10 +3,11 @@
     flash_attn.flash_attn_varlen_qkvpacked_func(qkv[T,3,H,D] bf16, cu_seqlens int32[S+1], max_seqlen,
                                                 dropout_p=0.0, softmax_scale=None, causal=False) -> [T,H,D]
 head_dim 16 and max_seqlen <= 1024 (every PT-v3m1 / m2 configuration) run on the gfx950 MFMA window-attention kernels
-(attention.hip).  Other head dims (PT-v3m3 / LitePT use multiples of 3 for their 3-D RoPE) are served by
-PyTorch-ROCm's scaled_dot_product_attention on the GPU, one batched call per distinct sequence length -- a library
-path that exists so those model files run through the operator-level API, not a tuned one (it needs the sequence
-lengths on the host: one sync per call).  dropout_p must be 0 (all reference PTv3 configs); causal / alibi / softcap /
+(attention.hip); head_dim 17..64 (PT-v3m3 / LitePT use 18: a multiple of 3 for their 3-D RoPE) on their multi-slab form
+(attention_hd.h; windows up to 1024 keys for head_dim <= 32, 672 for <= 48, 512 for <= 64).  Anything else (head_dim < 16,
+> 64, longer windows) is served by PyTorch-ROCm's scaled_dot_product_attention on the GPU, one batched call per distinct
+sequence length -- a library path that exists so such calls run through the operator-level API, not a tuned one (it
+needs the sequence lengths on the host: one sync per call).  dropout_p must be 0 (all reference PTv3 configs); causal / alibi / softcap /
 local windows raise.
 """
 from __future__ import annotations
@@ -15,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import functional as PF
+from . import ops
 from ._lib import PtcoreError
 
 
@@ -49,7 +51,7 @@ def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
     if qkv.dim() != 4 or qkv.shape[1] != 3:
         raise PtcoreError(f"flash_attn_varlen_qkvpacked_func: qkv must be [T,3,H,D], got {tuple(qkv.shape)}")
     _require_gpu(qkv)
-    if qkv.shape[3] != 16 or int(max_seqlen) > 1024:
+    if not ops.attn_hd_supported(int(qkv.shape[3]), int(max_seqlen)):
         if softmax_scale is None:
             softmax_scale = qkv.shape[3] ** -0.5
         return _sdpa_varlen(qkv, cu_seqlens, float(softmax_scale))

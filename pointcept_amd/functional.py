@@ -10,6 +10,7 @@ uses floating-point atomics and every result is bit-reproducible run to run:
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional
 
@@ -200,6 +201,7 @@ def _merge_duplicate_rows(g: torch.Tensor, rep: torch.Tensor) -> torch.Tensor:
 
 
 _rev_index_cache = {}
+_LEGACY_LAUNCHES = os.environ.get("PTC_LEGACY_LAUNCHES", "0") == "1"   # A/B switch: two-launch weight mirror / DropPath masks
 
 
 def _reverse_index(n: int, device) -> torch.Tensor:
@@ -249,7 +251,9 @@ class _SparseConv(Function):
         dfeat = dw = dbias = None
         if ctx.needs_input_grad[0]:
             wt = w.permute(2, 1, 0)
-            if ctx.mirror:   # W' = W.permute(ci, k, co).flip(k), contiguous, in ONE launch (flip + contiguous were two)
+            if ctx.mirror and _LEGACY_LAUNCHES:
+                wt = wt.flip(1).contiguous()
+            elif ctx.mirror:   # W' = W.permute(ci, k, co).flip(k), contiguous, in ONE launch (flip + contiguous were two)
                 wt = wt.index_select(1, _reverse_index(wt.shape[1], wt.device))
             else:
                 wt = wt.contiguous()

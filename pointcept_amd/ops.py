@@ -629,18 +629,30 @@ def add_norm_bwd(dz_in, dy, z, u, row_scale, g_a, st_a, g_b, st_b, want_affine_a
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
+def attn_hd_supported(head_dim: int, max_seqlen: int) -> bool:
+    """True when (head_dim, max_seqlen) is served by the MFMA window-attention kernels: head_dim 16 up to 1024 keys,
+    17..32 up to 1024, ..48 up to 672, ..64 up to 512 (the window's operands stay in LDS)."""
+    if head_dim == 16:
+        return 1 <= int(max_seqlen) <= 1024
+    return bool(lib().ptc_attn_varlen_hd_supported(int(head_dim), int(max_seqlen)))
+
+
 def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, softmax_scale: float):
-    """qkv [T,3,H,16] bf16 -> (out [T,H,16] bf16, lse [H,T] fp32)."""
+    """qkv [T,3,H,D] bf16 -> (out [T,H,D] bf16, lse [H,T] fp32); D = 16 (attention.hip) or 17..64 (attention_hd.h)."""
     require_cuda(qkv, cu_seqlens)
-    if qkv.dtype != torch.bfloat16 or qkv.dim() != 4 or qkv.shape[1] != 3 or qkv.shape[3] != 16:
-        raise PtcoreError(f"qkv must be bf16 [T,3,H,16], got {qkv.dtype} {tuple(qkv.shape)}")
+    if qkv.dtype != torch.bfloat16 or qkv.dim() != 4 or qkv.shape[1] != 3:
+        raise PtcoreError(f"qkv must be bf16 [T,3,H,D], got {qkv.dtype} {tuple(qkv.shape)}")
     qkv = qkv.contiguous()
     cu = cu_seqlens.to(torch.int32).contiguous()
-    T, _, H, _ = qkv.shape
-    out = torch.empty((T, H, 16), dtype=torch.bfloat16, device=qkv.device)
+    T, _, H, D = qkv.shape
+    out = torch.empty((T, H, D), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((H, T), dtype=torch.float32, device=qkv.device)
-    check(lib().ptc_attn_varlen_fwd(ptr(qkv), ptr(cu), cu.numel() - 1, T, H, int(max_seqlen), float(softmax_scale),
-                                    _lib.PTC_BF16, ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_fwd")
+    if D == 16:
+        check(lib().ptc_attn_varlen_fwd(ptr(qkv), ptr(cu), cu.numel() - 1, T, H, int(max_seqlen), float(softmax_scale),
+                                        _lib.PTC_BF16, ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_fwd")
+    else:
+        check(lib().ptc_attn_varlen_hd_fwd(ptr(qkv), ptr(cu), cu.numel() - 1, T, H, D, int(max_seqlen), float(softmax_scale),
+                                           _lib.PTC_BF16, ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_hd_fwd")
     return out, lse
 
 
@@ -650,13 +662,18 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_sc
     out = out.contiguous()
     dout = dout.to(torch.bfloat16).contiguous()
     cu = cu_seqlens.to(torch.int32).contiguous()
-    T, _, H, _ = qkv.shape
+    T, _, H, D = qkv.shape
     dqkv = torch.empty_like(qkv)
     nbytes = lib().ptc_attn_varlen_bwd_workspace_bytes(T, H)
     ws = _ws(nbytes, qkv.device)
-    check(lib().ptc_attn_varlen_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), cu.numel() - 1, T, H,
-                                    int(max_seqlen), float(softmax_scale), _lib.PTC_BF16, ptr(dqkv), ptr(ws), nbytes,
-                                    stream_ptr()), "ptc_attn_varlen_bwd")
+    if D == 16:
+        check(lib().ptc_attn_varlen_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), cu.numel() - 1, T, H,
+                                        int(max_seqlen), float(softmax_scale), _lib.PTC_BF16, ptr(dqkv), ptr(ws), nbytes,
+                                        stream_ptr()), "ptc_attn_varlen_bwd")
+    else:
+        check(lib().ptc_attn_varlen_hd_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), cu.numel() - 1, T, H, D,
+                                           int(max_seqlen), float(softmax_scale), _lib.PTC_BF16, ptr(dqkv), ptr(ws), nbytes,
+                                           stream_ptr()), "ptc_attn_varlen_hd_bwd")
     return dqkv
 
 

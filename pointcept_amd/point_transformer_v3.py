@@ -17,10 +17,10 @@ BatchNorm / GELU / residual adds stay on PyTorch-ROCm (ATen).
 Behaviours of the reference that change numerics are reproduced on purpose:
 stale sparse_conv_feat in the first decoder block's CPE (D.1), per-point DropPath (D.2), CPU-RNG
 order shuffling (D.3), bf16 attention regardless of the AMP dtype (D.4).
-Not implemented (raise): head_dim != 16 or attention dropout with enable_flash=True.  PDNorm (pdnorm_bn / pdnorm_ln, the
+Not implemented (raise): head_dim outside 16..64 or attention dropout with enable_flash=True.  PDNorm (pdnorm_bn / pdnorm_ln, the
 PPT multi-dataset configs) selects among the engine's own per-condition norm layers; those blocks take the unfused path.
 `enable_flash=False` follows the reference's patch-size rule (min(smallest scene, patch_size), ptv3m1:173-176) and runs the
-same attention kernel when it can (no RPE / dropout, head_dim 16; bf16 operands), else the dense [P,H,K,K] branch of
+same attention kernel when it can (no RPE / dropout, head_dim 16..64; bf16 operands), else the dense [P,H,K,K] branch of
 :190-206 (RPE bias, upcasts, dropout) in torch ops on the GPU.
 """
 from __future__ import annotations
@@ -173,7 +173,7 @@ class SerializedAttention(PointModule):
     """ptv3m1:51-222.  enable_flash=True: the MFMA window-attention kernels (attention.hip) behind the
     flash_attn_varlen_qkvpacked_func contract.  enable_flash=False: the reference's second branch -- the patch size
     shrinks to the smallest scene of the batch (:173-176) so every patch is full; without RPE / attention dropout /
-    head_dim != 16 that is still the same kernel (bf16 operands, fp32 accumulation), otherwise the dense
+    head_dim outside 16..64 that is still the same kernel (bf16 operands, fp32 accumulation), otherwise the dense
     [P, H, K, K] formulation of :190-206 in torch ops on the GPU (RPE bias, upcasts, dropout)."""
 
     def __init__(self, channels, num_heads, patch_size, qkv_bias=True, qk_scale=None, attn_drop=0.0, proj_drop=0.0,
@@ -189,8 +189,8 @@ class SerializedAttention(PointModule):
             assert enable_rpe is False, "Set enable_rpe to False when enable Flash Attention"               # ptv3m1:78-86
             assert upcast_attention is False, "Set upcast_attention to False when enable Flash Attention"
             assert upcast_softmax is False, "Set upcast_softmax to False when enable Flash Attention"
-            if channels // num_heads != 16:
-                raise PtcoreError(f"engine flash attention needs head_dim 16, got {channels // num_heads}")
+            if not 16 <= channels // num_heads <= 64:
+                raise PtcoreError(f"engine flash attention needs 16 <= head_dim <= 64, got {channels // num_heads}")
             if attn_drop != 0.0:
                 raise PtcoreError("attention dropout is not implemented in the flash branch (every reference config uses 0.0)")
             self.patch_size = patch_size
@@ -206,8 +206,9 @@ class SerializedAttention(PointModule):
 
     def _kernel_ok(self) -> bool:
         drop = self.attn_drop.p if isinstance(self.attn_drop, nn.Dropout) else self.attn_drop
-        return (self.rpe is None and self.channels // self.num_heads == 16 and self.patch_size <= 1024
-                and (drop == 0.0 or not self.training))
+        hd = self.channels // self.num_heads
+        fits = self.patch_size <= (1024 if hd <= 32 else 672 if hd <= 48 else 512)       # ops.attn_hd_supported, host-side
+        return self.rpe is None and 16 <= hd <= 64 and fits and (drop == 0.0 or not self.training)
 
     @torch.no_grad()
     def get_rel_pos(self, point, order):
@@ -360,6 +361,9 @@ class Block(PointModule):
         if p == 0.0 or not self.training:
             return None
         keep = 1.0 - p
+        if PF._LEGACY_LAUNCHES:
+            mask = torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep)
+            return mask.div_(keep) if keep > 0.0 and getattr(dp, "scale_by_keep", True) else mask
         if not (keep > 0.0 and getattr(dp, "scale_by_keep", True)):
             return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep)
         ones = Block._ones.get(device)

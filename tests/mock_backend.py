@@ -218,6 +218,7 @@ _STANDINS = dict(
     gather_rows=gather_rows, segment_csr_fwd=segment_csr_fwd, segment_csr_bwd=segment_csr_bwd, HashTable=HashTable,
     rulebook_subm=rulebook_subm, rulebook_down=rulebook_down, spconv_fwd=spconv_fwd, spconv_wgrad=spconv_wgrad,
     attn_varlen_fwd=attn_varlen_fwd, attn_varlen_bwd=attn_varlen_bwd, cross_entropy_fwd=cross_entropy_fwd,
+    attn_hd_supported=lambda d, k: 16 <= d <= 64 and k <= (1024 if d <= 32 else 672 if d <= 48 else 512),
     cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum, voxel_keys=voxel_keys,
     layer_norm_supported=lambda c: False, batch_norm_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)
 

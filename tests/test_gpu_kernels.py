@@ -763,6 +763,91 @@ def test_attention_large_logits(cuda):
     _close("attn_lse_peaked", lse, ref_lse, 1e-3, 3e-2)
 
 
+@pytest.mark.parametrize("D,lens,H", [(18, [1024, 700, 33], 3), (18, [1, 2, 31, 32, 33, 65], 6), (24, [1024, 330], 2),
+                                      (32, [1024, 48, 17], 2), (17, [257, 64], 3), (40, [672, 100], 2), (48, [512, 512, 9], 4),
+                                      (64, [512, 300], 2), (33, [96], 1)])
+def test_attention_other_head_dims_fwd_bwd(cuda, D, lens, H):
+    """head_dim 17..64 (PT-v3m3 / LitePT use 18, point_transformer_v3m3_utonia.py:354, litept_v1.py:244-256): the
+    multi-slab kernels of attention_hd.h against the oracle, same bars as the head_dim-16 kernels."""
+    from pointcept_amd import ops
+
+    assert ops.attn_hd_supported(D, max(lens))
+    g = torch.Generator().manual_seed(sum(lens) + H + D)
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    qkv = (torch.randn(T, 3, H, D, generator=g) * 1.5).to(torch.bfloat16)
+    scale = D ** -0.5
+    out, lse = ops.attn_varlen_fwd(qkv.to(cuda), cu.to(cuda), max(lens), scale)
+    assert out.shape == (T, H, D) and lse.shape == (H, T)
+    q32 = qkv.float().requires_grad_(True)
+    ref, ref_lse = oops.attention_varlen(q32, cu, scale, return_lse=True)
+    vmax = float(qkv[:, 2].float().abs().max())
+    _close(f"attn_hd{D}_fwd", out, ref, 1.0 / 64, 2.0 ** -9 * vmax)
+    _close(f"attn_hd{D}_lse", lse, ref_lse, 1e-3, 2e-2)
+    dout = torch.randn(T, H, D, generator=g).to(torch.bfloat16)
+    ref.backward(dout.float())
+    dqkv = ops.attn_varlen_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale)
+    gmax = float(q32.grad.abs().max())
+    _close(f"attn_hd{D}_bwd", dqkv, q32.grad, 1.0 / 32, 1e-2 * gmax)
+    d2 = ops.attn_varlen_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale)
+    assert torch.equal(dqkv, d2), "backward is not bit-reproducible"
+
+
+def test_attention_other_head_dims_large_logits_and_limits(cuda):
+    """Peaked rows take the online-softmax loop; windows that do not fit LDS are refused (the flash_attn API then uses
+    the library path); a sequence longer than max_seqlen poisons its rows instead of overrunning LDS."""
+    from pointcept_amd import ops
+    from pointcept_amd._lib import PtcoreError
+    from pointcept_amd.flash_attn_api import flash_attn_varlen_qkvpacked_func
+
+    g = torch.Generator().manual_seed(5)
+    L, H, D = 512, 2, 18
+    qkv = torch.randn(L, 3, H, D, generator=g)
+    qkv[:, 0] *= 6.0
+    qkv[:, 1] *= 6.0
+    qkv = qkv.to(torch.bfloat16)
+    cu = torch.tensor([0, L], dtype=torch.int32)
+    out, lse = ops.attn_varlen_fwd(qkv.to(cuda), cu.to(cuda), L, 0.25)
+    ref, ref_lse = oops.attention_varlen(qkv.float(), cu, 0.25, return_lse=True)
+    _close("attn_hd_fwd_peaked", out, ref, 1.0 / 64, 1e-2)
+    _close("attn_hd_lse_peaked", lse, ref_lse, 1e-3, 3e-2)
+
+    assert ops.attn_hd_supported(32, 1024) and ops.attn_hd_supported(48, 672) and ops.attn_hd_supported(64, 512)
+    assert not ops.attn_hd_supported(48, 1024) and not ops.attn_hd_supported(64, 1024) and not ops.attn_hd_supported(72, 64)
+    big = torch.randn(1024, 3, 2, 64, generator=g).to(torch.bfloat16).to(cuda)
+    cu1 = torch.tensor([0, 1024], dtype=torch.int32, device=cuda)
+    with pytest.raises(PtcoreError):
+        ops.attn_varlen_fwd(big, cu1, 1024, 0.125)
+    o = flash_attn_varlen_qkvpacked_func(big, cu1, 1024)              # library path, still the same contract
+    r = oops.attention_varlen(big.float().cpu(), cu1.cpu(), 64 ** -0.5)
+    _close("attn_hd_library_path", o, r, 1.0 / 64, 2e-2)
+
+    short = (torch.randn(200, 3, 2, 18, generator=g)).to(torch.bfloat16).to(cuda)
+    cu2 = torch.tensor([0, 200], dtype=torch.int32, device=cuda)
+    o, l = ops.attn_varlen_fwd(short, cu2, 64, 0.25)                    # max_seqlen lies: 200 > 64
+    assert torch.isnan(o.float()).all() and torch.isnan(l).all()
+
+
+def test_flash_attn_api_head_dim_18_autograd(cuda):
+    """The call PT-v3m3 / LitePT make (head_dim 18) through the flash_attn mirror, with autograd."""
+    from pointcept_amd.flash_attn_api import flash_attn_varlen_qkvpacked_func
+
+    g = torch.Generator().manual_seed(8)
+    lens, H, D = [1024, 1024, 513], 6, 18
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    x = (torch.randn(T, 3, H, D, generator=g)).to(torch.bfloat16)
+    xq = x.to(cuda).requires_grad_(True)
+    o = flash_attn_varlen_qkvpacked_func(xq, cu.to(cuda), max_seqlen=1024, dropout_p=0.0, softmax_scale=D ** -0.5)
+    w = torch.randn(T, H, D, generator=g)
+    (o.float() * w.to(cuda)).sum().backward()
+    x32 = x.float().requires_grad_(True)
+    r = oops.attention_varlen(x32, cu, D ** -0.5)
+    (r * w).sum().backward()
+    _close("fa18_fwd", o, r, 1.0 / 64, 2.0 ** -9 * float(x[:, 2].float().abs().max()))
+    _close("fa18_bwd", xq.grad, x32.grad, 1.0 / 32, 1e-2 * float(x32.grad.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------------
 # I. ends of the step: coordinate maxima, cross entropy
 # ------------------------------------------------------------------------------------------------

@@ -292,10 +292,29 @@ def bench_front_end(rows, results):
                 f"({r['knn16_Gdist_per_s']:.0f} G dist/s) | FPS 100k -> 2048 {r['fps_100k_2048_us']:.0f} us")
 
 
+def bench_attention_hd(rows, n_seq, H, D, results, L=1024):
+    """head_dim 17..64 kernels (attention_hd.h) at a PT-v3m3 / LitePT-like shape, beside the SDPA library path."""
+    T = n_seq * L
+    qkv = torch.randn(T, 3, H, D, device=DEV).to(torch.bfloat16)
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=DEV)
+    sc = D ** -0.5
+    out, lse = ops.attn_varlen_fwd(qkv, cu, L, sc)
+    do = torch.randn_like(out)
+    fl = L * L * D * n_seq * H
+    r = {"shape": [n_seq, L, H, D]}
+    r["fwd"] = roof(T * H * D * 8, 4.0 * fl, timeit(lambda: ops.attn_varlen_fwd(qkv, cu, L, sc), iters=10))
+    r["bwd"] = roof(T * H * D * 16, 10.0 * fl, timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
+    blk = qkv.reshape(n_seq, L, 3, H, D).permute(2, 0, 3, 1, 4).contiguous()
+    r["sdpa_fwd"] = roof(T * H * D * 8, 4.0 * fl, timeit(lambda: F.scaled_dot_product_attention(blk[0], blk[1], blk[2], scale=sc), iters=10))
+    results.append(r)
+    rows.append(f"attention_hd n_seq={n_seq:4d} L={L} H={H:2d} D={D:2d} | fwd {r['fwd']['us']:8.1f} us {r['fwd']['TFLOPs']:7.1f} TF/s | "
+                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s | library SDPA fwd on pre-gathered [n,H,L,D] {r['sdpa_fwd']['us']:8.1f} us")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of sections: linear,ln,attn,spconv,stages,losses,front")
+    ap.add_argument("--only", default="", help="comma list of sections: linear,ln,attn,attn_hd,spconv,stages,losses,front")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     want = lambda name: not only or name in only  # noqa: E731
@@ -318,6 +337,10 @@ def main():
     if want("attn"):
         for n_seq, H in ((800, 2), (800, 4), (200, 4), (48, 8), (16, 16)):
             bench_attention(rows, n_seq, H, res["attn"])
+    if want("attn_hd"):
+        res["attn_hd"] = []
+        for n_seq, H, D, L in ((800, 3, 18, 1024), (200, 6, 18, 1024), (48, 12, 18, 1024), (200, 4, 32, 1024), (200, 4, 48, 672), (200, 4, 64, 512)):
+            bench_attention_hd(rows, n_seq, H, D, res["attn_hd"], L)
     if want("spconv"):
         bench_spconv(rows, res["spconv"])
     if want("stages"):
