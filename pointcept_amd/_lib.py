@@ -116,7 +116,8 @@ def lib():
     # hipcc (the GPU box): a stale .so can never meet newer ctypes signatures silently
     from . import build as _build
 
-    _build.build()
+    variant = os.environ.get("PTC_LIB_VARIANT", "")      # compiler-flag A/B builds, see build.VARIANTS
+    LIB_PATH = _build.build(variant=variant)
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # fail loudly: no fallback path exists

@@ -21,6 +21,10 @@ BUILD = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libptcore.so")
 PROBE_LIB = os.path.join(HERE, "libptcore_hostprobe.so")
 
+
+def lib_path(variant: str = "") -> str:
+    return os.path.join(HERE, f"libptcore_{variant}.so") if variant else LIB
+
 HIP_SOURCES = [
     "serialize.hip",
     "scan_sort.hip",
@@ -53,6 +57,10 @@ HIP_FLAGS = [
     "-Wall",
     "-Wno-unused-function",
 ]
+# attention.hip: no SLP packing of the scalar f32 multiplies into v_pk_mul_f32 (beside MFMAs a packed f32 op costs more than
+# the two scalar ones it replaces, MI355X_MICROARCH.md per-instruction constants): backward 1460 -> 1406 us at the bench shape.
+# NOT global: the implicit-GEMM kernels lose 15-18 % without SLP at 96 / 128 channels (profiles/r02_o_slp_ab.txt).
+PER_FILE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(src: str, dst: str, extra: list[str]) -> bool:
@@ -77,8 +85,19 @@ def _run(cmd: list[str]) -> None:
         sys.stderr.write(r.stderr)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+# Compiler-flag variants for A/B measurements in ONE GPU session: `python -m pointcept_amd.build --variant NAME` builds
+# libptcore_NAME.so next to the default library (objects under csrc/build_NAME); PTC_LIB_VARIANT=NAME makes _lib.lib() load it.
+VARIANTS = {
+    "slp": [],                         # every file with the compiler's default SLP packing (no PER_FILE_FLAGS)
+    "noslp": ["-fno-slp-vectorize"],   # no file with it
+}
+
+
+def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
     """Compile every HIP source for gfx950 and link libptcore.so.  Returns the library path."""
+    LIB = lib_path(variant)
+    BUILD = os.path.join(HERE, "csrc", "build" + ("_" + variant if variant else ""))
+    HIP_FLAGS = globals()["HIP_FLAGS"] + (VARIANTS[variant] if variant else [])
     if not os.path.exists(HIPCC):
         if os.path.exists(LIB):
             return LIB  # GPU box without a compiler: use the prebuilt in-tree library
@@ -95,7 +114,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(op)
         if force or _newer(sp, op, hdrs):
             if src.endswith(".hip"):
-                cmd = [HIPCC] + HIP_FLAGS + ["-c", sp, "-o", op]
+                cmd = [HIPCC] + HIP_FLAGS + (PER_FILE_FLAGS.get(src, []) if not variant else []) + ["-c", sp, "-o", op]
             else:
                 import zlib
 
@@ -126,5 +145,6 @@ def build_host_probe(force: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build(force="--force" in sys.argv, verbose=True, variant=var))
     print(build_host_probe(force="--force" in sys.argv))

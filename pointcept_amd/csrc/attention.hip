@@ -57,6 +57,7 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define AT_MIN_WAVES 4          // waves per SIMD the register budget must allow (two 8-wave workgroups per CU)
 #define AT_LOG2E 1.4426950408889634f
 #define AT_LN2 0.6931471805599453f
+#define AT_BWD_PIPE_DEFAULT 0     // backward loop form (0 = in order, 3 = two-stage pipeline at one workgroup per CU), see attn_bwd_dq_kernel
 #define AT_FWD_DEFAULT 2         // forward variant bit mask (1 = Q1, 2 = PRIO, 4 = TRUNC), see attn_fwd_kernel
 #define AT_FIXED_REF_MAX 64.0f   // largest Cauchy-Schwarz bound (exp2 domain) served by the fixed-reference loop
 
@@ -441,7 +442,15 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 // backward, part 1: dQ (query-stationary) + delta = rowsum(dO * O)
 // ================================================================================================
 // LDS: V row-major [lp_max][16] | K row-major [lp_max][16]
-__global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
+// PIPE: 0 = one tile per trip, products and vector work in program order (default);
+//       3 = two-stage software pipeline, two tiles per trip with ping-pong registers (the S' / dP' products of tile kt+1 are
+//           issued before the exp / multiply / pack of tile kt), compiled for a 256-register budget, i.e. one workgroup per
+//           CU.  Same arithmetic in the same order: bit-identical results.  MEASURED SLOWER (dec0 shape: 1487 vs 1406 us;
+//           within the 128-register budget of two workgroups per CU the second S' / dP' pair spills: 2499 us; with
+//           sched_group_barrier pins on top: 8895 us; profiles/r02_o_slp_ab.txt) -- four in-order waves per SIMD already
+//           interleave better than two pipelined ones.  Kept behind PTC_ATTN_BWD_PIPE=3 as the A/B form.
+template <int PIPE>
+__global__ void __launch_bounds__(AT_THREADS, PIPE >= 3 ? 2 : AT_MIN_WAVES)
 attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                    const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
                    int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, float* __restrict__ delta, int prio) {
@@ -490,23 +499,55 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
     split_scaled(qf, c, qhi, qlo);
     const f32x16 negl = splat16(-l2), negd = splat16(-dl);
     f32x16 acc = zero16();
-    for (int kt = 0; kt < n_tiles; ++kt) {
-      const s16x8 kf = *reinterpret_cast<const s16x8*>(Ksm + kt * 1024 + rmo);
-      const s16x8 vf = *reinterpret_cast<const s16x8*>(Vsm + kt * 1024 + rmo);
-      f32x16 s = mfma32(kf, qhi, negl);                 // S'^T = k.(q c) - lse  (exp2 domain)
-      s = mfma32(kf, qlo, s);
-      const f32x16 dp = mfma32(vf, dof, negd);          // dP^T - delta
-      // keys >= L have k = 0, so whatever (finite) dS they get multiplies K^T = 0 below
-      uint32_t pk[8];
+    if constexpr (PIPE == 0) {
+      for (int kt = 0; kt < n_tiles; ++kt) {
+        const s16x8 kf = *reinterpret_cast<const s16x8*>(Ksm + kt * 1024 + rmo);
+        const s16x8 vf = *reinterpret_cast<const s16x8*>(Vsm + kt * 1024 + rmo);
+        f32x16 s = mfma32(kf, qhi, negl);                 // S'^T = k.(q c) - lse  (exp2 domain)
+        s = mfma32(kf, qlo, s);
+        const f32x16 dp = mfma32(vf, dof, negd);          // dP^T - delta
+        // keys >= L have k = 0, so whatever (finite) dS they get multiplies K^T = 0 below
+        uint32_t pk[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i]) * dp[2 * i], __builtin_amdgcn_exp2f(s[2 * i + 1]) * dp[2 * i + 1]);
+        for (int i = 0; i < 8; ++i)
+          pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i]) * dp[2 * i], __builtin_amdgcn_exp2f(s[2 * i + 1]) * dp[2 * i + 1]);
 #pragma unroll
-      for (int mm = 0; mm < 2; ++mm) {
-        const s16x8 dsf = make_frag(pk[4 * mm], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]);
-        const s16x8 ktf = ld_tr_frag(Ksm, ta, kt * 32 + 16 * mm);
-        acc = mfma32(ktf, dsf, acc);                    // dQ^T[d][q]
+        for (int mm = 0; mm < 2; ++mm) {
+          const s16x8 dsf = make_frag(pk[4 * mm], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]);
+          const s16x8 ktf = ld_tr_frag(Ksm, ta, kt * 32 + 16 * mm);
+          acc = mfma32(ktf, dsf, acc);                    // dQ^T[d][q]
+        }
       }
+    } else {
+      const unsigned char* kb = Ksm + rmo;
+      const unsigned char* vb = Vsm + rmo;
+      s16x8 kf = *reinterpret_cast<const s16x8*>(kb), vf = *reinterpret_cast<const s16x8*>(vb);
+      f32x16 sa, da, sb, db;
+      sa = mfma32(kf, qhi, negl);
+      sa = mfma32(kf, qlo, sa);
+      da = mfma32(vf, dof, negd);
+      // one step: consume (s, dp) of tile kt, produce (sn, dpn) of tile kt + 1 (clamped: the last step recomputes the last tile, unused)
+      auto step = [&](const f32x16& sc, const f32x16& dc, f32x16& sn, f32x16& dn, int kt) {
+        const int nx = (kt + 1 < n_tiles ? kt + 1 : kt) * 1024;
+        kf = *reinterpret_cast<const s16x8*>(kb + nx);
+        vf = *reinterpret_cast<const s16x8*>(vb + nx);
+        const s16x8 kt0 = ld_tr_frag(Ksm, ta, kt * 32), kt1 = ld_tr_frag(Ksm, ta, kt * 32 + 16);
+        sn = mfma32(kf, qhi, negl);
+        sn = mfma32(kf, qlo, sn);
+        dn = mfma32(vf, dof, negd);
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(sc[2 * i]) * dc[2 * i], __builtin_amdgcn_exp2f(sc[2 * i + 1]) * dc[2 * i + 1]);
+        acc = mfma32(kt0, make_frag(pk[0], pk[1], pk[2], pk[3]), acc);
+        acc = mfma32(kt1, make_frag(pk[4], pk[5], pk[6], pk[7]), acc);
+      };
+      int kt = 0;
+      for (; kt + 1 < n_tiles; kt += 2) {
+        step(sa, da, sb, db, kt);
+        step(sb, db, sa, da, kt + 1);
+      }
+      if (kt < n_tiles) step(sa, da, sb, db, kt);
     }
     if (qv) {
       uint16_t* o = dqkv + qkv_off(a + q, 0, H, head);
@@ -524,7 +565,8 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
 // ================================================================================================
 // LDS: Q row-major [lp_max][16] | dO row-major [lp_max][16] | aux [lp_max][4] bf16 = (lse_hi, lse_lo, delta_hi, delta_lo)
 #define AT_PAD_LSE 1.0e30f   // lse of padding queries: exp2(s - 1e30) = 0 and, unlike +inf, 1e30 * 0 = 0 in the delta product
-__global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
+template <int PIPE>   // as attn_bwd_dq_kernel
+__global__ void __launch_bounds__(AT_THREADS, PIPE >= 3 ? 2 : AT_MIN_WAVES)
 attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                     const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
                     int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, int prio) {
@@ -580,32 +622,75 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
     s16x8 khi, klo;
     split_scaled(kf, c, khi, klo);
     f32x16 dv = zero16(), dk = zero16();
-    for (int qt = 0; qt < n_tiles; ++qt) {
-      const s16x8 qf = *reinterpret_cast<const s16x8*>(Qsm + qt * 1024 + rmo);
-      const s16x8 dof = *reinterpret_cast<const s16x8*>(dOsm + qt * 1024 + rmo);
-      const uint2 ax = aux[qt * 32 + col];                                      // h2 = 1 lanes meet B = 0: any finite value
-      const s16x8 af = make_frag(ax.x, ax.y, 0u, 0u);
-      f32x16 s = mfma32(af, bS, zero16());            // -lse[q]          S'[q][key]: lane = key, regs = queries crow(r,h2)
-      s = mfma32(qf, khi, s);
-      s = mfma32(qf, klo, s);
-      f32x16 dp = mfma32(af, bD, zero16());           // -delta[q]
-      dp = mfma32(dof, vf, dp);                       // dP[q][key] - delta[q]
-      uint32_t pp[8], ps[8];
+    if constexpr (PIPE == 0) {
+      for (int qt = 0; qt < n_tiles; ++qt) {
+        const s16x8 qf = *reinterpret_cast<const s16x8*>(Qsm + qt * 1024 + rmo);
+        const s16x8 dof = *reinterpret_cast<const s16x8*>(dOsm + qt * 1024 + rmo);
+        const uint2 ax = aux[qt * 32 + col];                                      // h2 = 1 lanes meet B = 0: any finite value
+        const s16x8 af = make_frag(ax.x, ax.y, 0u, 0u);
+        f32x16 s = mfma32(af, bS, zero16());            // -lse[q]          S'[q][key]: lane = key, regs = queries crow(r,h2)
+        s = mfma32(qf, khi, s);
+        s = mfma32(qf, klo, s);
+        f32x16 dp = mfma32(af, bD, zero16());           // -delta[q]
+        dp = mfma32(dof, vf, dp);                       // dP[q][key] - delta[q]
+        uint32_t pp[8], ps[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float p0 = __builtin_amdgcn_exp2f(s[2 * i]), p1 = __builtin_amdgcn_exp2f(s[2 * i + 1]);
-        pp[i] = pack_bf16x2(p0, p1);
-        ps[i] = pack_bf16x2(p0 * dp[2 * i], p1 * dp[2 * i + 1]);
-      }
+        for (int i = 0; i < 8; ++i) {
+          const float p0 = __builtin_amdgcn_exp2f(s[2 * i]), p1 = __builtin_amdgcn_exp2f(s[2 * i + 1]);
+          pp[i] = pack_bf16x2(p0, p1);
+          ps[i] = pack_bf16x2(p0 * dp[2 * i], p1 * dp[2 * i + 1]);
+        }
 #pragma unroll
-      for (int mm = 0; mm < 2; ++mm) {
-        const s16x8 pf = make_frag(pp[4 * mm], pp[4 * mm + 1], pp[4 * mm + 2], pp[4 * mm + 3]);     // P^T[key][q slots]
-        const s16x8 dsf = make_frag(ps[4 * mm], ps[4 * mm + 1], ps[4 * mm + 2], ps[4 * mm + 3]);    // dS^T
-        const s16x8 dotf = ld_tr_frag(dOsm, ta, qt * 32 + 16 * mm);                                 // dO[q slots][d]
-        const s16x8 qtf = ld_tr_frag(Qsm, ta, qt * 32 + 16 * mm);                                   // Q[q slots][d]
-        dv = mfma32(pf, dotf, dv);   // dV[key][d]
-        dk = mfma32(dsf, qtf, dk);   // dK[key][d]
+        for (int mm = 0; mm < 2; ++mm) {
+          const s16x8 pf = make_frag(pp[4 * mm], pp[4 * mm + 1], pp[4 * mm + 2], pp[4 * mm + 3]);     // P^T[key][q slots]
+          const s16x8 dsf = make_frag(ps[4 * mm], ps[4 * mm + 1], ps[4 * mm + 2], ps[4 * mm + 3]);    // dS^T
+          const s16x8 dotf = ld_tr_frag(dOsm, ta, qt * 32 + 16 * mm);                                 // dO[q slots][d]
+          const s16x8 qtf = ld_tr_frag(Qsm, ta, qt * 32 + 16 * mm);                                   // Q[q slots][d]
+          dv = mfma32(pf, dotf, dv);   // dV[key][d]
+          dk = mfma32(dsf, qtf, dk);   // dK[key][d]
+        }
       }
+    } else {
+      const unsigned char* qb = Qsm + rmo;
+      const unsigned char* ob = dOsm + rmo;
+      s16x8 qf = *reinterpret_cast<const s16x8*>(qb), dof = *reinterpret_cast<const s16x8*>(ob);
+      uint2 ax = aux[col];
+      auto sdp = [&](f32x16& s, f32x16& dp) {
+        const s16x8 af = make_frag(ax.x, ax.y, 0u, 0u);
+        s = mfma32(af, bS, zero16());
+        s = mfma32(qf, khi, s);
+        s = mfma32(qf, klo, s);
+        dp = mfma32(af, bD, zero16());
+        dp = mfma32(dof, vf, dp);
+      };
+      f32x16 sa, da, sb, db;
+      sdp(sa, da);
+      auto step = [&](const f32x16& sc, const f32x16& dc, f32x16& sn, f32x16& dn, int qt) {
+        const int nx = qt + 1 < n_tiles ? qt + 1 : qt;
+        qf = *reinterpret_cast<const s16x8*>(qb + nx * 1024);
+        dof = *reinterpret_cast<const s16x8*>(ob + nx * 1024);
+        ax = aux[nx * 32 + col];
+        const s16x8 do0 = ld_tr_frag(dOsm, ta, qt * 32), do1 = ld_tr_frag(dOsm, ta, qt * 32 + 16);
+        const s16x8 qt0 = ld_tr_frag(Qsm, ta, qt * 32), qt1 = ld_tr_frag(Qsm, ta, qt * 32 + 16);
+        sdp(sn, dn);
+        uint32_t pp[8], ps[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float p0 = __builtin_amdgcn_exp2f(sc[2 * i]), p1 = __builtin_amdgcn_exp2f(sc[2 * i + 1]);
+          pp[i] = pack_bf16x2(p0, p1);
+          ps[i] = pack_bf16x2(p0 * dc[2 * i], p1 * dc[2 * i + 1]);
+        }
+        dv = mfma32(make_frag(pp[0], pp[1], pp[2], pp[3]), do0, dv);
+        dk = mfma32(make_frag(ps[0], ps[1], ps[2], ps[3]), qt0, dk);
+        dv = mfma32(make_frag(pp[4], pp[5], pp[6], pp[7]), do1, dv);
+        dk = mfma32(make_frag(ps[4], ps[5], ps[6], ps[7]), qt1, dk);
+      };
+      int qt = 0;
+      for (; qt + 1 < n_tiles; qt += 2) {
+        step(sa, da, sb, db, qt);
+        step(sb, db, sa, da, qt + 1);
+      }
+      if (qt < n_tiles) step(sa, da, sb, db, qt);
     }
     // D[i = key][j = d]: lane column = d (valid < 16), regs = keys crow(r,h2)
     if (col < 16) {
@@ -935,10 +1020,6 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
     PTC_CHECK_LAUNCH("attn_bwd_fused_kernel");
     return PTC_OK;
   }
-  rc = allow_big_lds(attn_bwd_dq_kernel, dq_lds_bytes(lp_max));
-  if (rc != PTC_OK) return rc;
-  rc = allow_big_lds(attn_bwd_dkv_kernel, dkv_lds_bytes(lp_max));
-  if (rc != PTC_OK) return rc;
   const int n_units = (int)(n_seq * H);
   const int qs = at_split(n_units, lp_max);
   const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
@@ -947,15 +1028,28 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   // half simply starves the other.  Off; PTC_ATTN_BWD_PRIO=1 is the A/B switch.
   int prio = 0;
   if (const char* e = getenv("PTC_ATTN_BWD_PRIO")) prio = atoi(e);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(grid), dim3(AT_THREADS), dq_lds_bytes(lp_max), s,
-                     (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H,
-                     softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv, delta, prio);
-  PTC_CHECK_LAUNCH("attn_bwd_dq_kernel");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(grid), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s,
-                     (const uint16_t*)qkv, (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H,
-                     softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv, prio);
-  PTC_CHECK_LAUNCH("attn_bwd_dkv_kernel");
-  return PTC_OK;
+  int pipe = AT_BWD_PIPE_DEFAULT;
+  if (const char* e = getenv("PTC_ATTN_BWD_PIPE")) pipe = atoi(e);
+#define AT_BWD_CASE(P)                                                                                                         \
+  if (pipe == P) {                                                                                                             \
+    rc = allow_big_lds(attn_bwd_dq_kernel<P>, dq_lds_bytes(lp_max));                                                           \
+    if (rc != PTC_OK) return rc;                                                                                               \
+    rc = allow_big_lds(attn_bwd_dkv_kernel<P>, dkv_lds_bytes(lp_max));                                                         \
+    if (rc != PTC_OK) return rc;                                                                                               \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<P>, dim3(grid), dim3(AT_THREADS), dq_lds_bytes(lp_max), s, (const uint16_t*)qkv,     \
+                       (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H, softmax_scale, total, lp_max, n_units, \
+                       qs, (uint16_t*)dqkv, delta, prio);                                                                      \
+    PTC_CHECK_LAUNCH("attn_bwd_dq_kernel");                                                                                    \
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<P>, dim3(grid), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s, (const uint16_t*)qkv,   \
+                       (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H, softmax_scale, total, lp_max, n_units,  \
+                       qs, (uint16_t*)dqkv, prio);                                                                             \
+    PTC_CHECK_LAUNCH("attn_bwd_dkv_kernel");                                                                                   \
+    return PTC_OK;                                                                                                             \
+  }
+  AT_BWD_CASE(0) AT_BWD_CASE(3)
+#undef AT_BWD_CASE
+  ptc_set_error("ptc_attn_varlen_bwd: PTC_ATTN_BWD_PIPE=%d is not a variant", pipe);
+  return PTC_EINVAL;
 }
 
 // ------------------------------------------------------------------------------------------------

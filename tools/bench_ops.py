@@ -114,17 +114,23 @@ def bench_attention(rows, n_seq, H, results, L=1024):
     r["fwd_variants"] = var
     r["bwd"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
                     timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
-    os.environ["PTC_ATTN_BWD_PRIO"] = "1"
-    r["bwd_noprio"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
-                           timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
-    os.environ.pop("PTC_ATTN_BWD_PRIO", None)
+    base_dq = ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc)
+    pv = []
+    for m in (0, 3):   # PTC_ATTN_BWD_PIPE: loop forms of the dQ / dK+dV kernels (bit-identical results)
+        os.environ["PTC_ATTN_BWD_PIPE"] = str(m)
+        t = timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10)
+        same = bool(torch.equal(ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), base_dq))
+        pv.append((m, t * 1e6, same))
+    os.environ.pop("PTC_ATTN_BWD_PIPE", None)
+    r["bwd_pipe_variants"] = pv
     os.environ["PTC_ATTN_BWD"] = "1"
     r["bwd2"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
                      timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
     os.environ.pop("PTC_ATTN_BWD", None)
     results.append(r)
     rows.append(f"attention n_seq={n_seq:4d} L={L} H={H:2d} | fwd {r['fwd']['us']:8.1f} us {r['fwd']['TFLOPs']:7.1f} TF/s | "
-                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s (with s_setprio: {r['bwd_noprio']['us']:8.1f}) | bwd single-pass (experiment) {r['bwd2']['us']:8.1f} us (10 L^2 D)")
+                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s | bwd single-pass (experiment) {r['bwd2']['us']:8.1f} us (10 L^2 D)")
+    rows.append("    bwd loop forms (PTC_ATTN_BWD_PIPE: us, bit-identical to the default): " + "  ".join(f"{m}: {t:.1f} us {ok}" for m, t, ok in pv))
     rows.append("    fwd variants (mask: us, max|diff|/max|out| vs mask 0): " + "  ".join(f"{m}: {t:.1f} us {d:.1e}" for m, t, d in r["fwd_variants"]))
 
 

@@ -30,7 +30,7 @@ for sec in "$@"; do
           cd $R; TOP=30 python tools/prof_top.py $O/${TAG}_profsp 5 $O/${TAG}_spunet_kernel_stats.csv > $O/${TAG}_profsp_top.log 2>&1; rm -rf $O/${TAG}_profsp;;
     ab:*) envs=$(echo "${sec#ab:}" | tr ',' ' '); name=$(echo "${sec#ab:}" | tr -c 'A-Za-z0-9=\n' '_');
           env $envs timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_${name}.log 2>&1; echo "$sec: $(tail -1 $O/${TAG}_bench_${name}.log | cut -c1-200)";;
-    prof) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $O/${TAG}_prof.log 2>&1
+    prof) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_prof.log 2>&1
           cd $R; TOP=30 python tools/prof_top.py $O/${TAG}_prof 5 $O/${TAG}_kernel_stats.csv > $O/${TAG}_prof_top.log 2>&1; rm -rf $O/${TAG}_prof;;
     roof) cd /tmp
           timeout 600 rocprofv3 --kernel-trace --stats -d $O/${TAG}_roof_stats -- python $R/tools/roofline_kernel.py > $O/${TAG}_roof_stats.log 2>&1
