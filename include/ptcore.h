@@ -307,13 +307,14 @@ int ptc_layer_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
  * `x + drop_path(attn)` then `norm2`, `x + drop_path(mlp)` then the cast feeding the next conv):
  *     z = a + row_scale * f(u),  f = LayerNorm_A (normA != 0) or identity      [n,c] fp32
  *     y = LayerNorm_B(z) (normB != 0) or y = z, stored as y_dtype; y may be NULL
- *   u: [n,c] bf16 or f32 (branch output), a: [n,c] fp32 (residual stream), row_scale: [n] fp32 or
+ *   u: [n,c] bf16 or f32 (branch output), a: [n,c] fp32 (residual stream) or bf16 (first block of a stage: the
+ *   pooling / unpooling output; da is then written as bf16 too, a_dtype / da_dtype), row_scale: [n] fp32 or
  *   NULL (DropPath keep-mask / keep_prob, per POINT: timm DropPath on [N,C]).
  *   statA / statB: [2][n] fp32 (mean, rstd) saved for the backward when the norm is present.
  * Backward: da = dz_in + LN_B'(dy) (or + dy);  du = row_scale * LN_A'(da) (or row_scale * da);
  *   dz_in (fp32) and dy may each be NULL (not both); affine gradients fp32 [c], any may be NULL.
  * ------------------------------------------------------------------------------------------ */
-int ptc_add_norm_fwd(const void* u, int u_dtype, const float* a, const float* row_scale, int64_t n, int c,
+int ptc_add_norm_fwd(const void* u, int u_dtype, const void* a, int a_dtype, const float* row_scale, int64_t n, int c,
                      const float* gA, const float* bA, float epsA, int normA, const float* gB,
                      const float* bB, float epsB, int normB, float* z, void* y, int y_dtype,
                      float* statA, float* statB, ptc_stream_t stream);
@@ -321,7 +322,7 @@ size_t ptc_add_norm_bwd_workspace_bytes(int64_t n, int c);
 int ptc_add_norm_bwd(const float* dz_in, const void* dy, int dy_dtype, const float* z, const void* u,
                      int u_dtype, const float* row_scale, int64_t n, int c, const float* gA,
                      const float* statA, int normA, const float* gB, const float* statB, int normB,
-                     float* da, void* du, float* dgA, float* dbA, float* dgB, float* dbB,
+                     void* da, int da_dtype, void* du, float* dgA, float* dbA, float* dgB, float* dbB,
                      void* workspace, size_t workspace_bytes, ptc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -251,7 +251,7 @@ extern "C" int ptc_layer_norm_bwd(const void* dy, int dy_dtype, const void* x, i
 
 // ================================================================================================
 // Fused residual + normalisation of the PTv3 Block (ptv3m1:318-338):
-//     z = a + s_row * f(u),   f = LayerNorm_A or identity          (a: fp32 residual stream)
+//     z = a + s_row * f(u),   f = LayerNorm_A or identity          (a: fp32 residual stream; bf16 where a stage begins)
 //     y = LayerNorm_B(z)  or  y = z                                (y: operand of the next GEMM / conv)
 // covers the three residual joints of a block in one pass each:
 //     x1 = x + LN(cpe);  y1 = norm1(x1)      |  x2 = x1 + droppath(attn);  y2 = norm2(x2)
@@ -262,7 +262,7 @@ extern "C" int ptc_layer_norm_bwd(const void* dy, int dy_dtype, const void* x, i
 // ================================================================================================
 template <typename TU, typename TY, int LPR>
 __global__ void __launch_bounds__(LN_THREADS)
-add_norm_fwd_kernel(const TU* __restrict__ u, const float* __restrict__ a, const float* __restrict__ row_scale, int64_t n,
+add_norm_fwd_kernel(const TU* __restrict__ u, const void* __restrict__ a, int a_bf16, const float* __restrict__ row_scale, int64_t n,
                     const float* __restrict__ gA, const float* __restrict__ bA, float epsA, int normA,
                     const float* __restrict__ gB, const float* __restrict__ bB, float epsB, int normB,
                     float* __restrict__ z, TY* __restrict__ y, float* __restrict__ statA, float* __restrict__ statB) {
@@ -278,7 +278,9 @@ add_norm_fwd_kernel(const TU* __restrict__ u, const float* __restrict__ a, const
   for (int64_t row = (int64_t)blockIdx.x * RPB + rib; row < n; row += (int64_t)gridDim.x * RPB) {
     float v[LN_VEC], r[LN_VEC];
     ln_load8<TU>(u + row * C + slot * LN_VEC, v);
-    ln_load8<float>(a + row * C + slot * LN_VEC, r);
+    // the residual operand is fp32 (the stream) or bf16 (first block of a stage: the pooling / unpooling output)
+    if (a_bf16) ln_load8<bf16_t>(reinterpret_cast<const bf16_t*>(a) + row * C + slot * LN_VEC, r);
+    else ln_load8<float>(reinterpret_cast<const float*>(a) + row * C + slot * LN_VEC, r);
     if (normA) {
       float s = 0.f;
 #pragma unroll
@@ -321,7 +323,7 @@ add_norm_bwd_kernel(const float* __restrict__ dz_in, const TY* __restrict__ dy, 
                     const TU* __restrict__ u, const float* __restrict__ row_scale, int64_t n,
                     const float* __restrict__ gA, const float* __restrict__ statA, int normA,
                     const float* __restrict__ gB, const float* __restrict__ statB, int normB,
-                    float* __restrict__ da, TU* __restrict__ du, float* __restrict__ partial /*[grid][4][C]*/) {
+                    void* __restrict__ da, int da_bf16, TU* __restrict__ du, float* __restrict__ partial /*[grid][4][C]*/) {
   constexpr int C = LPR * LN_VEC;
   constexpr int RPB = LN_THREADS / LPR;
   __shared__ float red[4][LN_THREADS][LN_VEC + 1];
@@ -365,7 +367,8 @@ add_norm_bwd_kernel(const float* __restrict__ dz_in, const TY* __restrict__ dy, 
         for (int i = 0; i < LN_VEC; ++i) dz[i] += g[i];
       }
     }
-    ln_store8<float>(da + row * C + slot * LN_VEC, dz);
+    if (da_bf16) ln_store8<bf16_t>(reinterpret_cast<bf16_t*>(da) + row * C + slot * LN_VEC, dz);   // the gradient autograd would cast anyway
+    else ln_store8<float>(reinterpret_cast<float*>(da) + row * C + slot * LN_VEC, dz);
     const float sc = row_scale ? row_scale[row] : 1.f;
     float o[LN_VEC];
     if (normA) {
@@ -437,12 +440,12 @@ static int an_grid(int64_t n, int lpr) {
 }
 
 template <typename TU, typename TY>
-static int launch_an_fwd(const void* u, const float* a, const float* row_scale, int64_t n, int c, const float* gA,
+static int launch_an_fwd(const void* u, const void* a, int a_bf16, const float* row_scale, int64_t n, int c, const float* gA,
                          const float* bA, float epsA, int normA, const float* gB, const float* bB, float epsB, int normB,
                          float* z, void* y, float* statA, float* statB, hipStream_t s) {
 #define AN_FWD_CASE(LPR)                                                                                                \
   hipLaunchKernelGGL((add_norm_fwd_kernel<TU, TY, LPR>), dim3(ln_grid(n, LPR)), dim3(LN_THREADS), 0, s, (const TU*)u, a, \
-                     row_scale, n, gA, bA, epsA, normA, gB, bB, epsB, normB, z, (TY*)y, statA, statB)
+                     a_bf16, row_scale, n, gA, bA, epsA, normA, gB, bB, epsB, normB, z, (TY*)y, statA, statB)
   switch (c / LN_VEC) {
     case 4: AN_FWD_CASE(4); break;
     case 8: AN_FWD_CASE(8); break;
@@ -455,7 +458,7 @@ static int launch_an_fwd(const void* u, const float* a, const float* row_scale, 
   return PTC_OK;
 }
 
-extern "C" int ptc_add_norm_fwd(const void* u, int u_dtype, const float* a, const float* row_scale, int64_t n, int c,
+extern "C" int ptc_add_norm_fwd(const void* u, int u_dtype, const void* a, int a_dtype, const float* row_scale, int64_t n, int c,
                                 const float* gA, const float* bA, float epsA, int normA, const float* gB, const float* bB,
                                 float epsB, int normB, float* z, void* y, int y_dtype, float* statA, float* statB,
                                 ptc_stream_t stream) {
@@ -466,13 +469,15 @@ extern "C" int ptc_add_norm_fwd(const void* u, int u_dtype, const float* a, cons
   PTC_REQUIRE((!normA || statA) && (!(normB && y) || statB), PTC_EINVAL, "ptc_add_norm_fwd: missing statistics buffer");
   PTC_REQUIRE(u_dtype == PTC_BF16 || u_dtype == PTC_F32, PTC_EUNSUPPORTED, "ptc_add_norm_fwd: u must be bf16 or f32");
   PTC_REQUIRE(!y || y_dtype == PTC_BF16 || y_dtype == PTC_F32, PTC_EUNSUPPORTED, "ptc_add_norm_fwd: y must be bf16 or f32");
+  PTC_REQUIRE(a_dtype == PTC_BF16 || a_dtype == PTC_F32, PTC_EUNSUPPORTED, "ptc_add_norm_fwd: a must be bf16 or f32");
+  const int a_bf16 = a_dtype == PTC_BF16;
   hipStream_t s = (hipStream_t)stream;
   if (u_dtype == PTC_BF16) {
-    if (y_dtype == PTC_BF16) return launch_an_fwd<bf16_t, bf16_t>(u, a, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
-    return launch_an_fwd<bf16_t, float>(u, a, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
+    if (y_dtype == PTC_BF16) return launch_an_fwd<bf16_t, bf16_t>(u, a, a_bf16, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
+    return launch_an_fwd<bf16_t, float>(u, a, a_bf16, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
   }
-  if (y_dtype == PTC_BF16) return launch_an_fwd<float, bf16_t>(u, a, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
-  return launch_an_fwd<float, float>(u, a, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
+  if (y_dtype == PTC_BF16) return launch_an_fwd<float, bf16_t>(u, a, a_bf16, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
+  return launch_an_fwd<float, float>(u, a, a_bf16, row_scale, n, c, gA, bA, epsA, normA, gB, bB, epsB, normB, z, y, statA, statB, s);
 }
 
 extern "C" size_t ptc_add_norm_bwd_workspace_bytes(int64_t n, int c) {
@@ -483,12 +488,12 @@ extern "C" size_t ptc_add_norm_bwd_workspace_bytes(int64_t n, int c) {
 template <typename TU, typename TY>
 static int launch_an_bwd(const float* dz_in, const void* dy, const float* z, const void* u, const float* row_scale, int64_t n,
                          int c, const float* gA, const float* statA, int normA, const float* gB, const float* statB, int normB,
-                         float* da, void* du, float* dgA, float* dbA, float* dgB, float* dbB, void* ws, hipStream_t s) {
+                         void* da, int da_bf16, void* du, float* dgA, float* dbA, float* dgB, float* dbB, void* ws, hipStream_t s) {
   const int lpr = c / LN_VEC;
   const int grid = an_grid(n, lpr);
 #define AN_BWD_CASE(LPR)                                                                                               \
   hipLaunchKernelGGL((add_norm_bwd_kernel<TU, TY, LPR>), dim3(grid), dim3(LN_THREADS), 0, s, dz_in, (const TY*)dy, z,  \
-                     (const TU*)u, row_scale, n, gA, statA, normA, gB, statB, normB, da, (TU*)du, (float*)ws)
+                     (const TU*)u, row_scale, n, gA, statA, normA, gB, statB, normB, da, da_bf16, (TU*)du, (float*)ws)
   switch (lpr) {
     case 4: AN_BWD_CASE(4); break;
     case 8: AN_BWD_CASE(8); break;
@@ -508,7 +513,7 @@ static int launch_an_bwd(const float* dz_in, const void* dy, const float* z, con
 
 extern "C" int ptc_add_norm_bwd(const float* dz_in, const void* dy, int dy_dtype, const float* z, const void* u, int u_dtype,
                                 const float* row_scale, int64_t n, int c, const float* gA, const float* statA, int normA,
-                                const float* gB, const float* statB, int normB, float* da, void* du, float* dgA, float* dbA,
+                                const float* gB, const float* statB, int normB, void* da, int da_dtype, void* du, float* dgA, float* dbA,
                                 float* dgB, float* dbB, void* workspace, size_t workspace_bytes, ptc_stream_t stream) {
   PTC_REQUIRE(n >= 0, PTC_EINVAL, "ptc_add_norm_bwd: n < 0");
   PTC_REQUIRE(ln_supported_c(c), PTC_EUNSUPPORTED, "ptc_add_norm_bwd: C=%d not in {32,64,128,256,512}", c);
@@ -524,10 +529,12 @@ extern "C" int ptc_add_norm_bwd(const float* dz_in, const void* dy, int dy_dtype
   PTC_REQUIRE(workspace_bytes >= ptc_add_norm_bwd_workspace_bytes(n, c), PTC_EWORKSPACE, "ptc_add_norm_bwd: workspace too small");
   PTC_REQUIRE(u_dtype == PTC_BF16 || u_dtype == PTC_F32, PTC_EUNSUPPORTED, "ptc_add_norm_bwd: u must be bf16 or f32");
   PTC_REQUIRE(!dy || dy_dtype == PTC_BF16 || dy_dtype == PTC_F32, PTC_EUNSUPPORTED, "ptc_add_norm_bwd: dy must be bf16 or f32");
+  PTC_REQUIRE(da_dtype == PTC_BF16 || da_dtype == PTC_F32, PTC_EUNSUPPORTED, "ptc_add_norm_bwd: da must be bf16 or f32");
+  const int da_bf16 = da_dtype == PTC_BF16;
   if (u_dtype == PTC_BF16) {
-    if (dy_dtype == PTC_BF16) return launch_an_bwd<bf16_t, bf16_t>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, du, dgA, dbA, dgB, dbB, workspace, s);
-    return launch_an_bwd<bf16_t, float>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, du, dgA, dbA, dgB, dbB, workspace, s);
+    if (dy_dtype == PTC_BF16) return launch_an_bwd<bf16_t, bf16_t>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, da_bf16, du, dgA, dbA, dgB, dbB, workspace, s);
+    return launch_an_bwd<bf16_t, float>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, da_bf16, du, dgA, dbA, dgB, dbB, workspace, s);
   }
-  if (dy_dtype == PTC_BF16) return launch_an_bwd<float, bf16_t>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, du, dgA, dbA, dgB, dbB, workspace, s);
-  return launch_an_bwd<float, float>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, du, dgA, dbA, dgB, dbB, workspace, s);
+  if (dy_dtype == PTC_BF16) return launch_an_bwd<float, bf16_t>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, da_bf16, du, dgA, dbA, dgB, dbB, workspace, s);
+  return launch_an_bwd<float, float>(dz_in, dy, z, u, row_scale, n, c, gA, statA, normA, gB, statB, normB, da, da_bf16, du, dgA, dbA, dgB, dbB, workspace, s);
 }

@@ -45,6 +45,10 @@ class Linear(nn.Linear):
     def forward(self, x: torch.Tensor, tab_fwd: Optional[torch.Tensor] = None,
                 tab_bwd: Optional[torch.Tensor] = None) -> torch.Tensor:
         _require_gpu(x, "Linear")
+        if x.dtype == torch.float32 and x.is_cuda and torch.is_autocast_enabled("cuda"):
+            t = PF.cast_twin(x, torch.get_autocast_dtype("cuda"))    # the copy the producing kernel already wrote
+            if t is not None:
+                x = t
         if tab_fwd is not None or _own_linear_ok(x, self.weight):
             return PF.linear(x, self.weight, self.bias, tab_fwd, tab_bwd)
         return F.linear(x, self.weight, self.bias)

@@ -286,13 +286,14 @@ def segment_csr_fwd(src: torch.Tensor, perm: Optional[torch.Tensor], indptr: tor
 
 
 def segment_csr_bwd(grad_out: torch.Tensor, perm: Optional[torch.Tensor], indptr: torch.Tensor,
-                    arg: Optional[torch.Tensor], n_src: int, reduce: str) -> torch.Tensor:
+                    arg: Optional[torch.Tensor], n_src: int, reduce: str, covers_all: bool = False) -> torch.Tensor:
     require_cuda(grad_out, perm, indptr, arg)
     grad_out = grad_out.contiguous()
     n_seg, c = indptr.numel() - 1, grad_out.shape[1]
     # rows outside every segment (none when perm is a full permutation) must read as zero
     covered = int(n_src)
-    gsrc = torch.zeros((covered, c), dtype=grad_out.dtype, device=grad_out.device)
+    alloc = torch.empty if covers_all else torch.zeros      # covers_all: every row belongs to a segment and gets written
+    gsrc = alloc((covered, c), dtype=grad_out.dtype, device=grad_out.device)
     check(lib().ptc_segment_csr_bwd(ptr(grad_out), ptr(perm), ptr(indptr), ptr(arg), n_seg, covered, c,
                                     dtype_code(grad_out), _lib.REDUCE_CODES[reduce], ptr(gsrc), stream_ptr()),
           "ptc_segment_csr_bwd")
@@ -588,8 +589,8 @@ def add_norm_fwd(u, a, row_scale, norm_a, norm_b, y_dtype):
     require_cuda(u, a, row_scale)
     u = u.contiguous()
     a = a.contiguous()
-    if a.dtype != torch.float32:
-        raise PtcoreError("add_norm: the residual stream `a` must be fp32")
+    if a.dtype not in (torch.float32, torch.bfloat16):
+        raise PtcoreError("add_norm: the residual operand `a` must be fp32 or bf16")
     n, c = u.shape
     dev = u.device
     z = torch.empty((n, c), dtype=torch.float32, device=dev)
@@ -599,21 +600,22 @@ def add_norm_fwd(u, a, row_scale, norm_a, norm_b, y_dtype):
     ga, ba, ea = norm_a if norm_a is not None else (None, None, 0.0)
     gb, bb, eb = norm_b if norm_b is not None else (None, None, 0.0)
     rs = None if row_scale is None else row_scale.to(torch.float32).contiguous()
-    check(lib().ptc_add_norm_fwd(ptr(u), dtype_code(u), ptr(a), ptr(rs), n, c, ptr(ga), ptr(ba), float(ea),
+    check(lib().ptc_add_norm_fwd(ptr(u), dtype_code(u), ptr(a), dtype_code(a), ptr(rs), n, c, ptr(ga), ptr(ba), float(ea),
                                  int(norm_a is not None), ptr(gb), ptr(bb), float(eb), int(norm_b is not None), ptr(z), ptr(y),
                                  _DT[y_dtype] if y_dtype is not None else 0, ptr(st_a), ptr(st_b), stream_ptr()),
           "ptc_add_norm_fwd")
     return z, y, st_a, st_b
 
 
-def add_norm_bwd(dz_in, dy, z, u, row_scale, g_a, st_a, g_b, st_b, want_affine_a: bool, want_affine_b: bool):
-    """-> (da fp32, du (u.dtype), dgA, dbA, dgB, dbB)"""
+def add_norm_bwd(dz_in, dy, z, u, row_scale, g_a, st_a, g_b, st_b, want_affine_a: bool, want_affine_b: bool,
+                 da_dtype: torch.dtype = torch.float32):
+    """-> (da (da_dtype: the dtype of the forward's `a`), du (u.dtype), dgA, dbA, dgB, dbB)"""
     require_cuda(dz_in, dy, z, u, row_scale)
     n, c = u.shape
     dev = u.device
     dz_in = None if dz_in is None else dz_in.to(torch.float32).contiguous()
     dy = None if dy is None else dy.contiguous()
-    da = torch.empty((n, c), dtype=torch.float32, device=dev)
+    da = torch.empty((n, c), dtype=da_dtype, device=dev)
     du = torch.empty_like(u)
     mk = lambda want: torch.empty(c, dtype=torch.float32, device=dev) if want else None  # noqa: E731
     dga, dba, dgb, dbb = mk(want_affine_a), mk(want_affine_a), mk(want_affine_b), mk(want_affine_b)
@@ -621,7 +623,7 @@ def add_norm_bwd(dz_in, dy, z, u, row_scale, g_a, st_a, g_b, st_b, want_affine_a
     ws = _ws(nbytes, dev)
     check(lib().ptc_add_norm_bwd(ptr(dz_in), ptr(dy), dtype_code(dy) if dy is not None else 0, ptr(z), ptr(u), dtype_code(u),
                                  ptr(row_scale), n, c, ptr(g_a), ptr(st_a), int(st_a is not None), ptr(g_b), ptr(st_b),
-                                 int(st_b is not None), ptr(da), ptr(du), ptr(dga), ptr(dba), ptr(dgb), ptr(dbb), ptr(ws),
+                                 int(st_b is not None), ptr(da), dtype_code(da), ptr(du), ptr(dga), ptr(dba), ptr(dgb), ptr(dbb), ptr(ws),
                                  nbytes, stream_ptr()), "ptc_add_norm_bwd")
     return da, du, dga, dba, dgb, dbb
 

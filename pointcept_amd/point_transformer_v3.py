@@ -401,6 +401,8 @@ class Block(PointModule):
         x3, xb = PF.add_norm(h, x2, self._row_keep_scale(n, dev), None, None, gemm_dt if auto else None)  # + droppath(mlp)
         point.feat = x3
         point.sparse_conv_feat = sc.replace_feature(xb if xb is not None else x3)    # next conv's operand, already cast
+        if xb is not None:
+            PF.register_cast_twin(x3, xb)     # ... and the operand of any Linear that reads the stream (pooling, unpooling, head)
         return point
 
     def forward(self, point: Point):
@@ -469,7 +471,7 @@ class SerializedPooling(PointModule):
             grid_coord = point.grid_coord[head] >> pooling_depth
             batch = point.batch[head]
         point_dict = AttrDict(
-            feat=PF.segment_csr(self.proj(point.feat), idx_ptr, self.reduce, perm=order0),   # ptv3m1:416-418
+            feat=PF.segment_csr(self.proj(point.feat), idx_ptr, self.reduce, perm=order0, covers_all=True),   # ptv3m1:416-418
             coord=PF.segment_csr(point.coord, idx_ptr, "mean", perm=order0),                   # ptv3m1:419-421
             grid_coord=grid_coord,
             serialized_code=child_code,

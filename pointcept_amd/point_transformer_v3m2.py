@@ -136,7 +136,7 @@ class GridPooling(PointModule):
             child_grid = g[head]
             child_batch = point.batch[head]
         point_dict = AttrDict(
-            feat=PF.segment_csr(self.proj(point.feat), idx_ptr, self.reduce, perm=order0),     # :407-409
+            feat=PF.segment_csr(self.proj(point.feat), idx_ptr, self.reduce, perm=order0, covers_all=True),     # :407-409
             coord=PF.segment_csr(point.coord, idx_ptr, "mean", perm=order0),                    # :410-412
             grid_coord=child_grid,
             batch=child_batch,

@@ -110,7 +110,7 @@ def segment_csr_fwd(src, perm, indptr, reduce):
     return out, arg
 
 
-def segment_csr_bwd(grad_out, perm, indptr, arg, n_src, reduce):
+def segment_csr_bwd(grad_out, perm, indptr, arg, n_src, reduce, covers_all=False):
     indptr = indptr.long()
     n_seg, c = indptr.numel() - 1, grad_out.shape[1]
     g = torch.zeros((int(n_src), c), dtype=grad_out.dtype)

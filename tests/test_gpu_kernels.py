@@ -681,6 +681,42 @@ def test_add_norm_fused_joint(cuda, c, mode):
             _close("an_db" + name, m.bias.grad, ref_grads["b" + name], 1e-3, 2e-3 * float(ref_grads["b" + name].abs().max()))
 
 
+@pytest.mark.parametrize("c", [64, 256])
+def test_add_norm_bf16_residual_operand_and_unused_outputs(cuda, c):
+    """First block of a stage: the residual operand `a` is the bf16 output of the pooling / unpooling.  The kernel reads it
+    as bf16 (same values as a.float()) and writes da as bf16 (the cast autograd would apply); an output nobody uses gets no
+    materialised zero gradient and the result equals the fp32-operand call on the same values."""
+    from pointcept_amd import functional as PF
+
+    n = 2049
+    g = torch.Generator().manual_seed(c)
+    u = (torch.randn(n, c, generator=g)).to(torch.bfloat16).to(cuda)
+    a16 = torch.randn(n, c, generator=g).to(torch.bfloat16).to(cuda)
+    nb = torch.nn.LayerNorm(c).to(cuda)
+    dz, dy = torch.randn(n, c, generator=g).to(cuda), torch.randn(n, c, generator=g).to(torch.bfloat16).to(cuda)
+    res = {}
+    for tag, a in (("bf16", a16.clone().requires_grad_(True)), ("fp32", a16.float().requires_grad_(True))):
+        ue = u.clone().requires_grad_(True)
+        nb.zero_grad(set_to_none=True)
+        z, y = PF.add_norm(ue, a, None, None, nb, torch.bfloat16)
+        ((z * dz).sum() + (y.float() * dy.float()).sum()).backward()
+        res[tag] = (z, y, a.grad, ue.grad, nb.weight.grad.clone())
+    assert res["bf16"][2].dtype == torch.bfloat16 and res["fp32"][2].dtype == torch.float32
+    assert torch.equal(res["bf16"][0], res["fp32"][0]) and torch.equal(res["bf16"][1], res["fp32"][1])
+    assert torch.equal(res["bf16"][2], res["fp32"][2].to(torch.bfloat16))
+    assert torch.equal(res["bf16"][3], res["fp32"][3]) and torch.equal(res["bf16"][4], res["fp32"][4])
+    # only z used / only y used: the other gradient is absent, not zeros
+    for use_z in (True, False):
+        ue, ae = u.clone().requires_grad_(True), a16.float().requires_grad_(True)
+        z, y = PF.add_norm(ue, ae, None, None, nb, torch.bfloat16)
+        ((z * dz).sum() if use_z else (y.float() * dy.float()).sum()).backward()
+        ur, ar = u.float().requires_grad_(True), a16.float().requires_grad_(True)
+        zr = ar + ur
+        ((zr * dz).sum() if use_z else (torch.nn.functional.layer_norm(zr, (c,), nb.weight.detach(), nb.bias.detach(), nb.eps) * dy.float()).sum()).backward()
+        _close("an_unused_da", ae.grad, ar.grad, 1e-3, 2e-3 * float(ar.grad.abs().max()))
+        _close("an_unused_du", ue.grad, ur.grad, 1.0 / 64, 2e-2 * float(ur.grad.abs().max()))
+
+
 def test_layer_norm_empty_and_unsupported(cuda):
     from pointcept_amd import ops
     from pointcept_amd._lib import PtcoreError

@@ -44,6 +44,7 @@ class Log(TorchDispatchMode):
     def __init__(self):
         super().__init__()
         self.rows = collections.defaultdict(lambda: [0, 0])
+        self.shapes = collections.defaultdict(collections.Counter)
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
@@ -62,6 +63,10 @@ class Log(TorchDispatchMode):
                 e = self.rows[(name, frame)]
                 e[0] += 1
                 e[1] += n
+                if n >= (4 << 20):
+                    ins = [f"{tuple(a.shape)} {str(a.dtype)[6:]}" for a in args if isinstance(a, torch.Tensor)]
+                    o = out[0] if isinstance(out, (tuple, list)) else out
+                    self.shapes[(name, frame)][" , ".join(ins) + f" -> {str(o.dtype)[6:]}"] += 1
         return out
 
 
@@ -82,3 +87,9 @@ for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])[:40]:
 print("== by (op, innermost engine frame), sorted by count")
 for (name, frame), (c, b) in sorted(log.rows.items(), key=lambda kv: -kv[1][0])[:120]:
     print(f"{c:6d} {b / 1e6:10.1f} MB  {name:34s} {frame}")
+
+print("== operands of the ops that write >= 4 MB (count x inputs -> output dtype), by site")
+for (name, frame), ctr in sorted(log.shapes.items(), key=lambda kv: -log.rows[kv[0]][1]):
+    print(f"{name:28s} {frame}   [{log.rows[(name, frame)][1] / 1e6:.1f} MB]")
+    for sh, c in ctr.most_common(12):
+        print(f"      {c:3d} x {sh}")
