@@ -147,7 +147,8 @@ def attention_roofline(device, scenes: int, points: int):
     # gfx950 + WRITE_SIZE, separate --pmc runs: tools/gpu_session.sh roof); not re-measured inside bench.py
     try:
         pm = _latest_profile("*attn_pmc.json")
-        k = json.load(open(pm))["kernels"]["attn_fwd_kernel"]
+        ks = json.load(open(pm))["kernels"]
+        k = ks[sorted(n for n in ks if n.startswith("attn_fwd_kernel"))[0]]    # r02 files carry the template arguments
         if (n_seq, H) == (800, 4):
             out["traffic"] = round(k["hbm_bytes"])
             out["traffic_source"] = os.path.relpath(pm, ROOT)

@@ -219,6 +219,53 @@ def _reverse_index(n: int, device) -> torch.Tensor:
     return t
 
 
+# ---- weight gradients on a second HIP stream (measured, OFF) ---------------------------------------
+# Inside one backward the weight gradient (wgrad + its split reduction) and the input gradient (dgrad) are independent.  On the
+# deep stages (N <= ~50k rows) neither fills 256 CUs, so issuing them on two streams (joined before the Function returns:
+# autograd, DDP's bucket hooks and the allocator see the ordering of a single stream) looked like free overlap.  Measured in one
+# session (profiles/r02_t_bench_ab.txt): off 51.1 / 51.8 ms per step, launches with <= 65536 rows forked 52.6 / 52.8 ms, every
+# launch forked 53.6 ms -- the two cross-stream waits per Function (~220 Functions per step) cost more than the small kernels
+# gain.  PTC_WGRAD_STREAM: 0 = off (default), 1 = launches with <= PTC_WGRAD_STREAM_MAX_ROWS rows, 2 = every launch; same
+# kernels on the same data, bit-identical results.
+_WGRAD_STREAM = int(os.environ.get("PTC_WGRAD_STREAM", "0"))
+_WGRAD_STREAM_MAX_ROWS = int(os.environ.get("PTC_WGRAD_STREAM_MAX_ROWS", "65536"))
+_side_streams = {}
+
+
+class _Fork:
+    """with _Fork(t, rows) as f: <side work>   ...main-stream work...   f.join(side outputs)"""
+
+    def __init__(self, ref: torch.Tensor, rows: int):
+        self.on = bool(ref.is_cuda and (_WGRAD_STREAM == 2 or (_WGRAD_STREAM == 1 and rows <= _WGRAD_STREAM_MAX_ROWS)))
+        self.ctx = None
+        if self.on:
+            self.main = torch.cuda.current_stream(ref.device)
+            side = _side_streams.get(ref.device)
+            if side is None:
+                side = _side_streams[ref.device] = torch.cuda.Stream(ref.device)
+            self.side = side
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.main)          # everything the side work reads has been enqueued on main
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
+
+    def join(self, *outs):
+        if self.on:
+            self.main.wait_stream(self.side)
+            for o in outs:                             # allocated from the side stream's pool, consumed on main
+                if o is not None:
+                    o.record_stream(self.main)
+
+
 # ---- cast twins of activations --------------------------------------------------------------------
 # The fused residual joint writes the fp32 stream x AND its autocast-dtype copy in one pass (add_norm: y = cast(z)).  GEMM
 # wrappers that would cast x again (pooling / unpooling projections, the segmentation head: 13 casts of [N, C] per step at
@@ -282,6 +329,12 @@ class _SparseConv(Function):
         c_out, kv, c_in = ctx.shape
         g = _pad_to(grad.to(f.dtype), 1, 16).contiguous()
         dfeat = dw = dbias = None
+        fork = _Fork(g, g.shape[0])
+        with fork:                                   # independent of the input gradient: second stream (see _Fork)
+            if ctx.needs_input_grad[1]:
+                dw = ops.spconv_wgrad(f, g, nbr)[:c_out, :, :c_in].to(ctx.w_dtype)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                dbias = ops.column_sum(grad)
         if ctx.needs_input_grad[0]:
             wt = w.permute(2, 1, 0)
             if ctx.mirror and _LEGACY_LAUNCHES:
@@ -296,10 +349,7 @@ class _SparseConv(Function):
             if dup_in is not None:
                 own = dup_in == torch.arange(dup_in.numel(), device=dup_in.device, dtype=dup_in.dtype)
                 dfeat = dfeat * own[:, None].to(dfeat.dtype)
-        if ctx.needs_input_grad[1]:
-            dw = ops.spconv_wgrad(f, g, nbr)[:c_out, :, :c_in].to(ctx.w_dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbias = ops.column_sum(grad)
+        fork.join(dw, dbias)
         return dfeat, dw, dbias, None, None, None, None, None, None
 
 
@@ -353,6 +403,19 @@ class _Linear(Function):
         c_out, c_in = ctx.shape
         g = _pad_to(grad.to(xp.dtype), 1, 16).contiguous()
         dx = dw = db = None
+        want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
+        fork = _Fork(g, g.shape[0])
+        with fork:                                   # weight / bias gradients on the second stream (see _Fork)
+            if ctx.needs_input_grad[1] or want_b:
+                if tab_fwd is not None or xp.dtype == torch.float32 or g.shape[0] >= _OWN_WGRAD_MIN_ROWS:
+                    res = ops.spconv_wgrad(xp, g, tab_fwd, want_bias=want_b)
+                    dwp, dbp = res if want_b else (res, None)
+                    dw = dwp[:c_out, 0, :c_in].to(ctx.w_dtype)
+                else:
+                    dw = (g.t() @ xp)[:c_out, :c_in].to(ctx.w_dtype)
+                    dbp = ops.column_sum(g) if want_b else None
+                if want_b:
+                    db = dbp[:c_out].to(ctx.b_dtype)
         if ctx.needs_input_grad[0]:
             if tab_bwd is not None or xp.dtype == torch.float32 or _own_gemm(xp.shape[0], g.shape[1], xp.dtype):
                 wt = wp.t().contiguous()[:, None, :]                       # [c_in, 1, c_out]
@@ -362,17 +425,7 @@ class _Linear(Function):
             else:
                 dx = g @ wp
             dx = dx[:, :c_in].to(ctx.in_dtype)
-        want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] or want_b:
-            if tab_fwd is not None or xp.dtype == torch.float32 or g.shape[0] >= _OWN_WGRAD_MIN_ROWS:
-                res = ops.spconv_wgrad(xp, g, tab_fwd, want_bias=want_b)
-                dwp, dbp = res if want_b else (res, None)
-                dw = dwp[:c_out, 0, :c_in].to(ctx.w_dtype)
-            else:
-                dw = (g.t() @ xp)[:c_out, :c_in].to(ctx.w_dtype)
-                dbp = ops.column_sum(g) if want_b else None
-            if want_b:
-                db = dbp[:c_out].to(ctx.b_dtype)
+        fork.join(dw, db)
         return dx, dw, db, None, None
 
 
@@ -613,23 +666,31 @@ class _MLP(Function):
         x_dt, w1_dt, b1_dt, w2_dt, b2_dt = ctx.dtypes
         g = dout.to(xp.dtype).contiguous()
         n = g.shape[0]
-        # fc2: weight / bias gradients, then the input gradient THROUGH the activation
-        if n >= _OWN_WGRAD_MIN_ROWS:
-            res = ops.spconv_wgrad(a, g, None, want_bias=b2_dt is not None)
-            dw2, db2 = res if b2_dt is not None else (res, None)
-            dw2 = dw2[:, 0, :]
-        else:
-            dw2 = (g.t() @ a).float()
-            db2 = ops.column_sum(g) if b2_dt is not None else None
+        # fc2: weight / bias gradients (second stream, see _Fork) beside the input gradient THROUGH the activation
+        fork2 = _Fork(g, n)
+        with fork2:
+            if n >= _OWN_WGRAD_MIN_ROWS:
+                res = ops.spconv_wgrad(a, g, None, want_bias=b2_dt is not None)
+                dw2, db2 = res if b2_dt is not None else (res, None)
+                dw2 = dw2[:, 0, :]
+            else:
+                dw2 = (g.t() @ a).float()
+                db2 = ops.column_sum(g) if b2_dt is not None else None
+            dw2 = dw2.to(w2_dt)
+            db2 = None if db2 is None else db2.to(b2_dt)
         dh = ops.linear_gelu_bwd_input(g, w2c.t().contiguous(), h)
-        # fc1
-        if n >= _OWN_WGRAD_MIN_ROWS:
-            res = ops.spconv_wgrad(xp, dh, None, want_bias=b1_dt is not None)
-            dw1, db1 = res if b1_dt is not None else (res, None)
-            dw1 = dw1[:, 0, :]
-        else:
-            dw1 = (dh.t() @ xp).float()
-            db1 = ops.column_sum(dh) if b1_dt is not None else None
+        # fc1: the same split
+        fork1 = _Fork(dh, n)
+        with fork1:
+            if n >= _OWN_WGRAD_MIN_ROWS:
+                res = ops.spconv_wgrad(xp, dh, None, want_bias=b1_dt is not None)
+                dw1, db1 = res if b1_dt is not None else (res, None)
+                dw1 = dw1[:, 0, :]
+            else:
+                dw1 = (dh.t() @ xp).float()
+                db1 = ops.column_sum(dh) if b1_dt is not None else None
+            dw1 = dw1.to(w1_dt)
+            db1 = None if db1 is None else db1.to(b1_dt)
         dx = None
         if ctx.needs_input_grad[0]:
             if _own_gemm(n, dh.shape[1], xp.dtype):
@@ -637,7 +698,9 @@ class _MLP(Function):
             else:
                 dx = dh @ w1c
             dx = dx.to(x_dt)
-        return (dx, dw1.to(w1_dt), None if db1 is None else db1.to(b1_dt), dw2.to(w2_dt), None if db2 is None else db2.to(b2_dt))
+        fork2.join(dw2, db2)
+        fork1.join(dw1, db1)
+        return dx, dw1, db1, dw2, db2
 
 
 def mlp_gelu_supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
