@@ -189,6 +189,12 @@ __device__ __forceinline__ s16x8 ld_tr_frag(const unsigned char* img, TrAddr a, 
   return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+__device__ __forceinline__ s16x8 ld_tr_pair(const unsigned char* plo, const unsigned char* phi) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)plo);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)phi);
+  return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 // XCD-aware order: workgroup b runs on XCD b % 8, so logical unit = (b % 8) * per + b / 8 gives every
 // XCD a contiguous run of (sequence, head) units -- the H heads of a sequence read interleaved
 // 32-byte pieces of the same qkv rows and share one L2 instead of re-fetching them per XCD.
@@ -449,7 +455,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 //           within the 128-register budget of two workgroups per CU the second S' / dP' pair spills: 2499 us; with
 //           sched_group_barrier pins on top: 8895 us; profiles/r02_o_slp_ab.txt) -- four in-order waves per SIMD already
 //           interleave better than two pipelined ones.  Kept behind PTC_ATTN_BWD_PIPE=3 as the A/B form.
-template <int PIPE>
+template <int PIPE, int LP>   // LP = lp_max at compile time (1024: image distances become immediate offsets) or 0 = runtime
 __global__ void __launch_bounds__(AT_THREADS, PIPE >= 3 ? 2 : AT_MIN_WAVES)
 attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                    const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
@@ -500,9 +506,15 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
     const f32x16 negl = splat16(-l2), negd = splat16(-dl);
     f32x16 acc = zero16();
     if constexpr (PIPE == 0) {
-      for (int kt = 0; kt < n_tiles; ++kt) {
-        const s16x8 kf = *reinterpret_cast<const s16x8*>(Ksm + kt * 1024 + rmo);
-        const s16x8 vf = *reinterpret_cast<const s16x8*>(Vsm + kt * 1024 + rmo);
+      // three per-lane LDS pointers advanced once per trip, everything else immediate offsets (see attn_bwd_dkv_kernel);
+      // the V image sits KOFF bytes BEFORE the K image
+      const int KOFF = LP ? LP * 32 : lp_max * 32;
+      const unsigned char* pv = Vsm + rmo;
+      const unsigned char* pl = Ksm + ta.lo;
+      const unsigned char* ph = Ksm + ta.hi;
+      auto tile = [&](const int o) {
+        const s16x8 vf = *reinterpret_cast<const s16x8*>(pv + o);
+        const s16x8 kf = *reinterpret_cast<const s16x8*>(pv + o + KOFF);
         f32x16 s = mfma32(kf, qhi, negl);                 // S'^T = k.(q c) - lse  (exp2 domain)
         s = mfma32(kf, qlo, s);
         const f32x16 dp = mfma32(vf, dof, negd);          // dP^T - delta
@@ -514,10 +526,17 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) {
           const s16x8 dsf = make_frag(pk[4 * mm], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]);
-          const s16x8 ktf = ld_tr_frag(Ksm, ta, kt * 32 + 16 * mm);
+          const s16x8 ktf = ld_tr_pair(pl + o + 512 * mm, ph + o + 512 * mm);
           acc = mfma32(ktf, dsf, acc);                    // dQ^T[d][q]
         }
+      };
+      int kt = 0;
+      for (; kt + 1 < n_tiles; kt += 2) {
+        tile(0);
+        tile(1024);
+        pv += 2048; pl += 2048; ph += 2048;
       }
+      if (kt < n_tiles) tile(0);
     } else {
       const unsigned char* kb = Ksm + rmo;
       const unsigned char* vb = Vsm + rmo;
@@ -565,7 +584,7 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
 // ================================================================================================
 // LDS: Q row-major [lp_max][16] | dO row-major [lp_max][16] | aux [lp_max][4] bf16 = (lse_hi, lse_lo, delta_hi, delta_lo)
 #define AT_PAD_LSE 1.0e30f   // lse of padding queries: exp2(s - 1e30) = 0 and, unlike +inf, 1e30 * 0 = 0 in the delta product
-template <int PIPE>   // as attn_bwd_dq_kernel
+template <int PIPE, int LP>   // PIPE as attn_bwd_dq_kernel; LP = lp_max at compile time (1024: image distances become immediates) or 0
 __global__ void __launch_bounds__(AT_THREADS, PIPE >= 3 ? 2 : AT_MIN_WAVES)
 attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                     const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
@@ -623,10 +642,20 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
     split_scaled(kf, c, khi, klo);
     f32x16 dv = zero16(), dk = zero16();
     if constexpr (PIPE == 0) {
-      for (int qt = 0; qt < n_tiles; ++qt) {
-        const s16x8 qf = *reinterpret_cast<const s16x8*>(Qsm + qt * 1024 + rmo);
-        const s16x8 dof = *reinterpret_cast<const s16x8*>(dOsm + qt * 1024 + rmo);
-        const uint2 ax = aux[qt * 32 + col];                                      // h2 = 1 lanes meet B = 0: any finite value
+      // Four per-lane LDS pointers (row-major fragment, aux word, the two halves of the transposed fragments), advanced
+      // once per trip; everything else is an immediate offset (the dO image sits DOFF bytes after the Q image, 16 rows
+      // are 512 bytes, the second tile of a trip 1024): the address arithmetic of the r01 form (7 pointers, 14 VALU per
+      // tile of ~72 -- the kernel is instruction-issue bound, 90 % of cycles issue, profiles/r02_p_attn_pmc.json) shrinks
+      // to 2 VALU per tile.
+      const int DOFF = LP ? LP * 32 : lp_max * 32;
+      const unsigned char* pq = Qsm + rmo;
+      const unsigned char* pl = Qsm + ta.lo;
+      const unsigned char* ph = Qsm + ta.hi;
+      const unsigned char* pa = reinterpret_cast<const unsigned char*>(aux) + col * 8;
+      auto tile = [&](const int o, const int oa) {          // o = byte offset of the tile in the row-major images, oa in aux
+        const s16x8 qf = *reinterpret_cast<const s16x8*>(pq + o);
+        const s16x8 dof = *reinterpret_cast<const s16x8*>(pq + o + DOFF);
+        const uint2 ax = *reinterpret_cast<const uint2*>(pa + oa);                // h2 = 1 lanes meet B = 0: any finite value
         const s16x8 af = make_frag(ax.x, ax.y, 0u, 0u);
         f32x16 s = mfma32(af, bS, zero16());            // -lse[q]          S'[q][key]: lane = key, regs = queries crow(r,h2)
         s = mfma32(qf, khi, s);
@@ -644,12 +673,19 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
         for (int mm = 0; mm < 2; ++mm) {
           const s16x8 pf = make_frag(pp[4 * mm], pp[4 * mm + 1], pp[4 * mm + 2], pp[4 * mm + 3]);     // P^T[key][q slots]
           const s16x8 dsf = make_frag(ps[4 * mm], ps[4 * mm + 1], ps[4 * mm + 2], ps[4 * mm + 3]);    // dS^T
-          const s16x8 dotf = ld_tr_frag(dOsm, ta, qt * 32 + 16 * mm);                                 // dO[q slots][d]
-          const s16x8 qtf = ld_tr_frag(Qsm, ta, qt * 32 + 16 * mm);                                   // Q[q slots][d]
+          const s16x8 dotf = ld_tr_pair(pl + o + DOFF + 512 * mm, ph + o + DOFF + 512 * mm);          // dO[q slots][d]
+          const s16x8 qtf = ld_tr_pair(pl + o + 512 * mm, ph + o + 512 * mm);                         // Q[q slots][d]
           dv = mfma32(pf, dotf, dv);   // dV[key][d]
           dk = mfma32(dsf, qtf, dk);   // dK[key][d]
         }
+      };
+      int qt = 0;
+      for (; qt + 1 < n_tiles; qt += 2) {
+        tile(0, 0);
+        tile(1024, 256);
+        pq += 2048; pl += 2048; ph += 2048; pa += 512;
       }
+      if (qt < n_tiles) tile(0, 0);
     } else {
       const unsigned char* qb = Qsm + rmo;
       const unsigned char* ob = dOsm + rmo;
@@ -1030,23 +1066,23 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   if (const char* e = getenv("PTC_ATTN_BWD_PRIO")) prio = atoi(e);
   int pipe = AT_BWD_PIPE_DEFAULT;
   if (const char* e = getenv("PTC_ATTN_BWD_PIPE")) pipe = atoi(e);
-#define AT_BWD_CASE(P)                                                                                                         \
-  if (pipe == P) {                                                                                                             \
-    rc = allow_big_lds(attn_bwd_dq_kernel<P>, dq_lds_bytes(lp_max));                                                           \
+#define AT_BWD_CASE(P, LP)                                                                                                     \
+  if (pipe == P && (LP == 0 ? lp_max != 1024 : lp_max == LP)) {                                                                                                             \
+    rc = allow_big_lds((attn_bwd_dq_kernel<P, LP>), dq_lds_bytes(lp_max));                                                           \
     if (rc != PTC_OK) return rc;                                                                                               \
-    rc = allow_big_lds(attn_bwd_dkv_kernel<P>, dkv_lds_bytes(lp_max));                                                         \
+    rc = allow_big_lds((attn_bwd_dkv_kernel<P, LP>), dkv_lds_bytes(lp_max));                                                         \
     if (rc != PTC_OK) return rc;                                                                                               \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<P>, dim3(grid), dim3(AT_THREADS), dq_lds_bytes(lp_max), s, (const uint16_t*)qkv,     \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<P, LP>), dim3(grid), dim3(AT_THREADS), dq_lds_bytes(lp_max), s, (const uint16_t*)qkv,     \
                        (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H, softmax_scale, total, lp_max, n_units, \
                        qs, (uint16_t*)dqkv, delta, prio);                                                                      \
     PTC_CHECK_LAUNCH("attn_bwd_dq_kernel");                                                                                    \
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<P>, dim3(grid), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s, (const uint16_t*)qkv,   \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, LP>), dim3(grid), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s, (const uint16_t*)qkv,   \
                        (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H, softmax_scale, total, lp_max, n_units,  \
                        qs, (uint16_t*)dqkv, prio);                                                                             \
     PTC_CHECK_LAUNCH("attn_bwd_dkv_kernel");                                                                                   \
     return PTC_OK;                                                                                                             \
   }
-  AT_BWD_CASE(0) AT_BWD_CASE(3)
+  AT_BWD_CASE(0, 1024) AT_BWD_CASE(0, 0) AT_BWD_CASE(3, 1024) AT_BWD_CASE(3, 0)
 #undef AT_BWD_CASE
   ptc_set_error("ptc_attn_varlen_bwd: PTC_ATTN_BWD_PIPE=%d is not a variant", pipe);
   return PTC_EINVAL;
