@@ -183,25 +183,30 @@ __device__ __forceinline__ void f2_epilogue_ex(f32x4 (&acc)[2][NTILES], T* __res
 template <typename T, int NTILES, int S, int EPI = 0>
 __global__ void __launch_bounds__(256)
 linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-               const int32_t* __restrict__ nbr, int64_t n_out, int c_in, int c_out, T* __restrict__ out,
+               const int32_t* __restrict__ nbr, int64_t n_out, int c_in, int c_out, int nh, T* __restrict__ out,
                const T* __restrict__ aux_in, T* __restrict__ aux_out, uint32_t in_bytes) {
+  // A workgroup owns `nh` column blocks of NT channels (W of all of them in LDS) and walks them per row tile with the
+  // row fragments held in registers: the input is read ONCE.  (One column block per workgroup and gridDim.y = 2 read
+  // every input row from two workgroups and ran at 0.31-0.45 of the HBM roof for c_out = 192 / 256 against 0.56-0.77
+  // for c_out <= 128, N = 819200: profiles/r02_v_linear_probe.txt.)
   using M = Mma<T>;
   const __amdgpu_buffer_rsrc_t in_buf = ptc_buf(in, in_bytes);
   constexpr int NT = NTILES * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int pitch = c_in + 8;
-  T* wl = reinterpret_cast<T*>(smem);  // [NT][pitch]
+  T* wl = reinterpret_cast<T*>(smem);  // [nh][NT][pitch]
+  float* bl = reinterpret_cast<float*>(smem + (((size_t)nh * NT * pitch * 2 + 15) & ~(size_t)15));   // [nh][NT] bias
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.y * NT;
+  const int n0 = blockIdx.y * NT * nh;
   const int vpr = c_in >> 3;
-  for (int q = threadIdx.x; q < NT * vpr; q += 256) {
+  for (int q = threadIdx.x; q < nh * NT * vpr; q += 256) {
     const int n = q / vpr, cc = q - n * vpr;
-    *reinterpret_cast<uint4*>(wl + lds_row_of_channel<NTILES>(n) * pitch + cc * 8) =
+    const int h = n / NT, nl = n - h * NT;
+    *reinterpret_cast<uint4*>(wl + (h * NT + lds_row_of_channel<NTILES>(nl)) * pitch + cc * 8) =
         *reinterpret_cast<const uint4*>(w + (int64_t)(n0 + n) * c_in + cc * 8);
   }
-  f32x4 breg[NTILES];
-  sc_bias_regs<NTILES>(bias, n0, g, breg);
+  for (int q = threadIdx.x; q < nh * NT; q += 256) bl[q] = bias ? bias[n0 + q] : 0.f;
   __syncthreads();
 
   const int64_t tiles = (n_out + F2_ROWS - 1) / F2_ROWS;
@@ -233,24 +238,33 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
   for (; tile < tiles; tile += gridDim.x) {
     load_rows(na, nb, pa, pb);                       // next tile's rows (entries fetched one round ago)
     load_idx(tile + 2 * (int64_t)gridDim.x, na, nb);  // entries of the tile after next
-    f32x4 acc[2][NTILES];
-#pragma unroll
-    for (int t = 0; t < NTILES; ++t) { acc[0][t] = breg[t]; acc[1][t] = breg[t]; }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const int col = s * 32 + g * 8;
-      const T* wrow = wl + r * pitch + col;
+    const int64_t rowA = tile * F2_ROWS + wave * 32 + r;
+#pragma unroll 1
+    for (int h = 0; h < nh; ++h) {
+      f32x4 acc[2][NTILES];
+      // accumulators start at the bias of the channel they are stored to (sc_bias_regs mapping), read from LDS: a
+      // global load here would queue behind the rows prefetched for the next tile
 #pragma unroll
       for (int t = 0; t < NTILES; ++t) {
-        typename M::frag fw = M::zero();
-        if (col < c_in) fw = ld_frag<T>(wrow + t * 16 * pitch);
-        acc[0][t] = M::mma(fw, ca[s], acc[0][t]);
-        acc[1][t] = M::mma(fw, cb[s], acc[1][t]);
+        const int gs = TileGroups<NTILES>::gstart(t), G = TileGroups<NTILES>::gsize(t);
+        acc[0][t] = *reinterpret_cast<const f32x4*>(bl + h * NT + 16 * gs + 4 * G * g + 4 * (t - gs));
+        acc[1][t] = acc[0][t];
       }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int col = s * 32 + g * 8;
+        const T* wrow = wl + (h * NT + r) * pitch + col;
+#pragma unroll
+        for (int t = 0; t < NTILES; ++t) {
+          typename M::frag fw = M::zero();
+          if (col < c_in) fw = ld_frag<T>(wrow + t * 16 * pitch);
+          acc[0][t] = M::mma(fw, ca[s], acc[0][t]);
+          acc[1][t] = M::mma(fw, cb[s], acc[1][t]);
+        }
+      }
+      if constexpr (EPI == 0) sc_epilogue<T, NTILES>(acc, nullptr, out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);
+      else f2_epilogue_ex<T, NTILES, EPI>(acc, out, aux_in, aux_out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);
     }
-    const int64_t rowA = tile * F2_ROWS + wave * 32 + r;
-    if constexpr (EPI == 0) sc_epilogue<T, NTILES>(acc, nullptr, out, rowA, rowA + 16, n_out, c_out, n0, g);
-    else f2_epilogue_ex<T, NTILES, EPI>(acc, out, aux_in, aux_out, rowA, rowA + 16, n_out, c_out, n0, g);
 #pragma unroll
     for (int s = 0; s < S; ++s) { ca[s] = pa[s]; cb[s] = pb[s]; }
   }
@@ -292,20 +306,26 @@ static int launch_fwd2(const void* in, int64_t n_in, const void* w, const float*
                        int c_in, int c_out, void* out, hipStream_t s, int epi = 0, const void* aux_in = nullptr, void* aux_out = nullptr) {
   constexpr int NT = NTILES * 16;
   if (kv == 1) {
-    const size_t lds = (size_t)NT * (c_in + 8) * 2;
+    // column blocks per workgroup: as many as keep W within 64 KB of LDS (two workgroups per CU), see linear2_kernel
+    const int nblk = c_out / NT;
+    int nh = 1;
+    for (int cand = 4; cand >= 2; --cand)
+      if (nblk % cand == 0 && (size_t)cand * NT * (c_in + 8) * 2 + (size_t)cand * NT * 4 + 16 <= 64 * 1024) { nh = cand; break; }
+    if (const char* e = getenv("PTC_LINEAR2_NH")) { if (atoi(e) == 1) nh = 1; }   // A/B switch: the one-block form
+    const size_t lds = (((size_t)nh * NT * (c_in + 8) * 2 + 15) & ~(size_t)15) + (size_t)nh * NT * 4;
     const int64_t tiles = ptc_cdiv(n_out, F2_ROWS);
     const int64_t per_cu = lds > 40 * 1024 ? 2 : 4;
-    int64_t gx = 256 * per_cu / (c_out / NT);
+    int64_t gx = 256 * per_cu / (nblk / nh);
     if (gx > tiles) gx = tiles;
     if (gx < 1) gx = 1;
-    dim3 grid((unsigned)gx, (unsigned)(c_out / NT));
+    dim3 grid((unsigned)gx, (unsigned)(nblk / nh));
     const int S = (c_in + 31) / 32;
 #define L2_LAUNCH(SS, EE)                                                                                               \
   {                                                                                                                     \
     auto kern = linear2_kernel<T, NTILES, SS, EE>;                                                                      \
     if (lds > 48 * 1024)                                                                                                \
       PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, c_in, c_out, (T*)out,   \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, c_in, c_out, nh, (T*)out, \
                        (const T*)aux_in, (T*)aux_out, (uint32_t)((uint64_t)n_in * c_in * sizeof(T)));                   \
   }
 #define L2_CASE(SS)                                                                                                     \

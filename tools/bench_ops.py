@@ -336,6 +336,11 @@ def main():
         bench_linear(rows, 819200, 64, 256, res["linear"])
         bench_linear(rows, 819200, 256, 64, res["linear"])
         bench_linear(rows, 819200, 64, 32, res["linear"])   # seg head (20 padded to 32)
+    if "linprobe" in only:   # shape sweep at the stage-0 row count: which of (c_in, c_out) costs the bandwidth?
+        res["linprobe"] = []
+        for cin, cout in ((32, 32), (32, 64), (32, 128), (32, 256), (64, 32), (64, 64), (64, 128), (64, 192), (64, 256), (128, 64),
+                          (128, 128), (128, 256), (256, 64), (256, 128)):
+            bench_linear(rows, 819200, cin, cout, res["linprobe"])
     if want("ln"):
         for n, c in stages:
             bench_ln(rows, n, c, res["ln"])
