@@ -359,6 +359,23 @@ int ptc_attn_varlen_hd_bwd(const void* qkv, const void* out, const void* dout, c
                            int head_dim, int max_seqlen, float softmax_scale, int dtype, void* dqkv,
                            void* workspace, size_t workspace_bytes, ptc_stream_t stream);
 
+/* Window attention with PTv3's relative position bias (the non-flash branch with enable_rpe=True,
+ * pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:29-48,104-112,190-206), head_dim 16:
+ *   softmax(scale q k^T + sum_a rpe_table[a R + clamp(gc_i[a] - gc_j[a], -B, B) + B][h]) v     (i = query, j = key)
+ *   grid_coord : [total, 3] int32, rows in the SAME (serialized, padded) order as qkv; values in [0, 2^16)
+ *   rpe_table  : [3 R, H] fp32, R = 2 pos_bnd + 1 (RPE.rpe_table);  d_rpe_table: same shape, overwritten
+ * The bias is evaluated per pair in the tile loop; nothing of size L^2 is materialised.  d_rpe_table is accumulated with
+ * float atomics (order-dependent rounding, like the reference's index_select backward); dqkv is bit-reproducible. */
+int ptc_attn_rpe_fwd(const void* qkv, const int32_t* cu_seqlens, const int32_t* grid_coord,
+                     const float* rpe_table, int pos_bnd, int64_t n_seq, int64_t total, int H,
+                     int max_seqlen, float softmax_scale, int dtype, void* out, float* lse,
+                     ptc_stream_t stream);
+int ptc_attn_rpe_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                     const int32_t* cu_seqlens, const int32_t* grid_coord, const float* rpe_table,
+                     int pos_bnd, int64_t n_seq, int64_t total, int H, int max_seqlen,
+                     float softmax_scale, int dtype, void* dqkv, float* d_rpe_table, void* workspace,
+                     size_t workspace_bytes, ptc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * I. Ends of the step.
  * ptc_coord_max: out3[a] = max_i grid_coord[i][a] (0 for n == 0).  Replaces the reductions behind

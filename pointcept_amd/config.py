@@ -16,6 +16,8 @@ settings), and so a regression can be bisected without a rebuild.
                      fc1's epilogue and GELU' into the epilogue of fc2's input gradient
   PTC_PREFETCH_LEVELS=0  every SerializedPooling fetches its own sizes (two host syncs per stage) instead of the one
                      up-front copy of all level sizes (ptc_pool_level_counts)
+  PTC_RPE_KERNEL=0   the RPE attention branch (enable_flash=False, enable_rpe=True) keeps the dense [P,H,K,K] torch
+                     formulation under bf16 autocast instead of the window-attention kernels of csrc/attention_rpe.h
   PTC_FUSE_BLOCK=0   the three residual joints of a PTv3 Block run as separate LayerNorm / add / cast
                      kernels instead of the fused add_norm passes
 """
@@ -38,3 +40,4 @@ SORT_POINTS = _flag("PTC_SORT_POINTS", True)
 FUSE_BLOCK = _flag("PTC_FUSE_BLOCK", True)
 FUSE_MLP = _flag("PTC_FUSE_MLP", True)
 PREFETCH_LEVELS = _flag("PTC_PREFETCH_LEVELS", True)
+RPE_KERNEL = _flag("PTC_RPE_KERNEL", True)

@@ -961,6 +961,7 @@ attn_bwd_fused_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
 }
 
 #include "attention_hd.h"
+#include "attention_rpe.h"
 
 // ================================================================================================
 // host side
@@ -1175,4 +1176,69 @@ extern "C" int ptc_attn_varlen_hd_bwd(const void* qkv, const void* out, const vo
 #undef AH_BWD_CASE
   ptc_set_error("ptc_attn_varlen_hd_bwd: no instance for head_dim=%d", head_dim);
   return PTC_EUNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------
+// relative-position-bias attention, head_dim 16 (attention_rpe.h)
+// ------------------------------------------------------------------------------------------------
+static int rpe_check(const char* name, const void* qkv, const int32_t* cu, const int32_t* gc, const float* table, int pos_bnd,
+                     int64_t n_seq, int64_t total, int H, int max_seqlen, int dtype) {
+  int rc = check_common(name, qkv, cu, n_seq, total, H, max_seqlen, dtype);
+  if (rc != PTC_OK) return rc;
+  PTC_REQUIRE(pos_bnd >= 0 && pos_bnd <= 4096, PTC_EINVAL, "%s: pos_bnd=%d out of range", name, pos_bnd);
+  PTC_REQUIRE(n_seq == 0 || (gc && table), PTC_EINVAL, "%s: null buffer", name);
+  return PTC_OK;
+}
+
+extern "C" int ptc_attn_rpe_fwd(const void* qkv, const int32_t* cu_seqlens, const int32_t* grid_coord, const float* rpe_table,
+                                int pos_bnd, int64_t n_seq, int64_t total, int H, int max_seqlen, float softmax_scale, int dtype,
+                                void* out, float* lse, ptc_stream_t stream) {
+  int rc = rpe_check("ptc_attn_rpe_fwd", qkv, cu_seqlens, grid_coord, rpe_table, pos_bnd, n_seq, total, H, max_seqlen, dtype);
+  if (rc != PTC_OK) return rc;
+  if (n_seq == 0 || total == 0) return PTC_OK;
+  PTC_REQUIRE(out && lse, PTC_EINVAL, "ptc_attn_rpe_fwd: null buffer");
+  const int lp_max = (max_seqlen + 31) & ~31, R = 2 * pos_bnd + 1;
+  const size_t lds = (size_t)lp_max * 32 + (size_t)17 * (lp_max + 8) * 2 + 64 + ar_extra_lds(lp_max, R);
+  PTC_REQUIRE(lds <= AH_LDS_LIMIT, PTC_EUNSUPPORTED, "ptc_attn_rpe_fwd: max_seqlen=%d with pos_bnd=%d does not fit LDS", max_seqlen, pos_bnd);
+  rc = allow_big_lds(attn_rpe_fwd_kernel, lds);
+  if (rc != PTC_OK) return rc;
+  const int n_units = (int)(n_seq * H);
+  hipLaunchKernelGGL(attn_rpe_fwd_kernel, dim3((unsigned)(8 * ((n_units + 7) / 8))), dim3(AT_THREADS), lds, (hipStream_t)stream,
+                     (const uint16_t*)qkv, cu_seqlens, grid_coord, rpe_table, R, pos_bnd, H, softmax_scale, total, lp_max, n_units,
+                     (uint16_t*)out, lse);
+  PTC_CHECK_LAUNCH("attn_rpe_fwd_kernel");
+  return PTC_OK;
+}
+
+extern "C" int ptc_attn_rpe_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
+                                const int32_t* grid_coord, const float* rpe_table, int pos_bnd, int64_t n_seq, int64_t total, int H,
+                                int max_seqlen, float softmax_scale, int dtype, void* dqkv, float* d_rpe_table, void* workspace,
+                                size_t workspace_bytes, ptc_stream_t stream) {
+  int rc = rpe_check("ptc_attn_rpe_bwd", qkv, cu_seqlens, grid_coord, rpe_table, pos_bnd, n_seq, total, H, max_seqlen, dtype);
+  if (rc != PTC_OK) return rc;
+  const int R = 2 * pos_bnd + 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (d_rpe_table) PTC_HIP(hipMemsetAsync(d_rpe_table, 0, (size_t)3 * R * H * sizeof(float), s));
+  if (n_seq == 0 || total == 0) return PTC_OK;
+  PTC_REQUIRE(out && dout && lse && dqkv && d_rpe_table && workspace, PTC_EINVAL, "ptc_attn_rpe_bwd: null buffer");
+  PTC_REQUIRE(workspace_bytes >= ptc_attn_varlen_bwd_workspace_bytes(total, H), PTC_EWORKSPACE, "ptc_attn_rpe_bwd: workspace too small");
+  const int lp_max = (max_seqlen + 31) & ~31;
+  const size_t lds_q = (size_t)lp_max * 64 + ar_extra_lds(lp_max, R), lds_kv = (size_t)lp_max * 72 + ar_extra_lds(lp_max, R);
+  PTC_REQUIRE(lds_kv <= AH_LDS_LIMIT, PTC_EUNSUPPORTED, "ptc_attn_rpe_bwd: max_seqlen=%d with pos_bnd=%d does not fit LDS", max_seqlen, pos_bnd);
+  rc = allow_big_lds(attn_rpe_bwd_dq_kernel, lds_q);
+  if (rc != PTC_OK) return rc;
+  rc = allow_big_lds(attn_rpe_bwd_dkv_kernel, lds_kv);
+  if (rc != PTC_OK) return rc;
+  const int n_units = (int)(n_seq * H);
+  const unsigned grid = (unsigned)(8 * ((n_units + 7) / 8));
+  float* delta = (float*)workspace;
+  hipLaunchKernelGGL(attn_rpe_bwd_dq_kernel, dim3(grid), dim3(AT_THREADS), lds_q, s, (const uint16_t*)qkv, (const uint16_t*)out,
+                     (const uint16_t*)dout, lse, cu_seqlens, grid_coord, rpe_table, R, pos_bnd, H, softmax_scale, total, lp_max,
+                     n_units, (uint16_t*)dqkv, delta, d_rpe_table);
+  PTC_CHECK_LAUNCH("attn_rpe_bwd_dq_kernel");
+  hipLaunchKernelGGL(attn_rpe_bwd_dkv_kernel, dim3(grid), dim3(AT_THREADS), lds_kv, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse,
+                     (const float*)delta, cu_seqlens, grid_coord, rpe_table, R, pos_bnd, H, softmax_scale, total, lp_max, n_units,
+                     (uint16_t*)dqkv);
+  PTC_CHECK_LAUNCH("attn_rpe_bwd_dkv_kernel");
+  return PTC_OK;
 }

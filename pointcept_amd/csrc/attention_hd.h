@@ -295,7 +295,7 @@ attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
-  const int64_t rs = (int64_t)3 * H * D, os = (int64_t)H * D;
+  const int64_t rs = (int64_t)3 * H * D;
   uint16_t* dqbase = dqkv + ((int64_t)a * 3 * H + head) * D;
   if (Lp > lp_max) {
     if (part == 0) ah_poison_rows(dqbase, rs, D, L, nullptr);

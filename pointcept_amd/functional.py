@@ -555,6 +555,33 @@ def attn_varlen_qkvpacked(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqle
     return _AttnVarlen.apply(qkv, cu_seqlens, int(max_seqlen), float(softmax_scale))
 
 
+class _AttnRpe(Function):
+    @staticmethod
+    def forward(ctx, qkv, rpe_table, cu_seqlens, grid_coord, max_seqlen, softmax_scale, pos_bnd):
+        out, lse = ops.attn_rpe_fwd(qkv, cu_seqlens, max_seqlen, softmax_scale, grid_coord, rpe_table.float(), pos_bnd)
+        ctx.save_for_backward(qkv, out, lse, cu_seqlens, grid_coord, rpe_table)
+        ctx.args = (max_seqlen, softmax_scale, pos_bnd)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        qkv, out, lse, cu, gc, tab = ctx.saved_tensors
+        max_seqlen, scale, pos_bnd = ctx.args
+        dqkv, dtab = ops.attn_rpe_bwd(qkv, out, dout.contiguous(), lse, cu, max_seqlen, scale, gc, tab.float(), pos_bnd)
+        return dqkv, dtab.to(tab.dtype), None, None, None, None, None
+
+
+def attn_rpe_qkvpacked(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, softmax_scale: float,
+                       grid_coord: torch.Tensor, rpe_table: torch.Tensor, pos_bnd: int) -> torch.Tensor:
+    """The reference's dense attention branch with RPE (ptv3m1:29-48,190-206) on the window-attention kernels:
+    softmax(scale q k^T + rpe(grid_coord_i - grid_coord_j)) v per window, qkv [T,3,H,16] bf16 in serialized order,
+    grid_coord [T,3] int32 in the same order, rpe_table [3(2B+1), H] (differentiable)."""
+    if qkv.dtype != torch.bfloat16:
+        raise PtcoreError("attn_rpe_qkvpacked expects bf16 qkv")
+    return _AttnRpe.apply(qkv, rpe_table, cu_seqlens, grid_coord, int(max_seqlen), float(softmax_scale), int(pos_bnd))
+
+
 # ------------------------------------------------------------------------------------------------
 # cross entropy
 # ------------------------------------------------------------------------------------------------

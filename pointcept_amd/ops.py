@@ -679,6 +679,50 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_sc
     return dqkv
 
 
+def attn_rpe_supported(head_dim: int, max_seqlen: int, pos_bnd: int) -> bool:
+    """RPE attention kernels (attention_rpe.h): head_dim 16, windows whose images + coordinates + table fit LDS."""
+    lp = (int(max_seqlen) + 31) & ~31
+    r = 2 * int(pos_bnd) + 1
+    return head_dim == 16 and 1 <= max_seqlen <= 1024 and lp * 72 + lp * 8 + ((3 * r + 3) & ~3) * 8 <= 163840
+
+
+def attn_rpe_fwd(qkv, cu_seqlens, max_seqlen: int, softmax_scale: float, grid_coord, rpe_table, pos_bnd: int):
+    """qkv [T,3,H,16] bf16, grid_coord [T,3] int32 (same row order), rpe_table [3(2B+1),H] fp32 -> (out [T,H,16] bf16, lse [H,T])."""
+    require_cuda(qkv, cu_seqlens, grid_coord, rpe_table)
+    if qkv.dtype != torch.bfloat16 or qkv.dim() != 4 or qkv.shape[1] != 3 or qkv.shape[3] != 16:
+        raise PtcoreError(f"qkv must be bf16 [T,3,H,16], got {qkv.dtype} {tuple(qkv.shape)}")
+    T, _, H, _ = qkv.shape
+    if grid_coord.dtype != torch.int32 or tuple(grid_coord.shape) != (T, 3):
+        raise PtcoreError(f"grid_coord must be int32 [{T},3], got {grid_coord.dtype} {tuple(grid_coord.shape)}")
+    if rpe_table.dtype != torch.float32 or tuple(rpe_table.shape) != (3 * (2 * int(pos_bnd) + 1), H):
+        raise PtcoreError(f"rpe_table must be fp32 [{3 * (2 * int(pos_bnd) + 1)},{H}], got {rpe_table.dtype} {tuple(rpe_table.shape)}")
+    qkv, gc, tab = qkv.contiguous(), grid_coord.contiguous(), rpe_table.contiguous()
+    cu = cu_seqlens.to(torch.int32).contiguous()
+    out = torch.empty((T, H, 16), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((H, T), dtype=torch.float32, device=qkv.device)
+    check(lib().ptc_attn_rpe_fwd(ptr(qkv), ptr(cu), ptr(gc), ptr(tab), int(pos_bnd), cu.numel() - 1, T, H, int(max_seqlen),
+                                 float(softmax_scale), _lib.PTC_BF16, ptr(out), ptr(lse), stream_ptr()), "ptc_attn_rpe_fwd")
+    return out, lse
+
+
+def attn_rpe_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_scale: float, grid_coord, rpe_table, pos_bnd: int):
+    """-> (dqkv like qkv, d_rpe_table fp32 like rpe_table)"""
+    require_cuda(qkv, out, dout, lse, cu_seqlens, grid_coord, rpe_table)
+    qkv, out = qkv.contiguous(), out.contiguous()
+    dout = dout.to(torch.bfloat16).contiguous()
+    gc, tab = grid_coord.contiguous(), rpe_table.contiguous()
+    cu = cu_seqlens.to(torch.int32).contiguous()
+    T, _, H, _ = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    dtab = torch.empty_like(tab)
+    nbytes = lib().ptc_attn_varlen_bwd_workspace_bytes(T, H)
+    ws = _ws(nbytes, qkv.device)
+    check(lib().ptc_attn_rpe_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), ptr(gc), ptr(tab), int(pos_bnd), cu.numel() - 1,
+                                 T, H, int(max_seqlen), float(softmax_scale), _lib.PTC_BF16, ptr(dqkv), ptr(dtab), ptr(ws), nbytes,
+                                 stream_ptr()), "ptc_attn_rpe_bwd")
+    return dqkv, dtab
+
+
 # ------------------------------------------------------------------------------------------------
 # ends of the step: coordinate maxima, cross-entropy
 # ------------------------------------------------------------------------------------------------

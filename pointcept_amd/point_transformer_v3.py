@@ -219,7 +219,34 @@ class SerializedAttention(PointModule):
             point[key] = g.unsqueeze(2) - g.unsqueeze(1)
         return point[key]
 
+    def _rpe_kernel_ok(self, point) -> bool:
+        """RPE branch on the window-attention kernels (attention_rpe.h) instead of the dense [P,H,K,K] formulation: when the
+        operands would be bf16 anyway (bf16 autocast: the reference's matmuls then run in bf16 whatever the upcast flags say;
+        the kernel keeps fp32 logits, softmax and accumulation), no attention dropout is active, head_dim 16.  An fp32 run
+        (no autocast) keeps the torch formulation: its results must not be rounded to bf16."""
+        drop = self.attn_drop.p if isinstance(self.attn_drop, nn.Dropout) else self.attn_drop
+        return (config.RPE_KERNEL and self.rpe is not None and point.feat.is_cuda and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and (drop == 0.0 or not self.training)
+                and ops.attn_rpe_supported(self.channels // self.num_heads, self.patch_size, self.rpe.pos_bnd))
+
+    def _forward_rpe_kernel(self, point):
+        H, K, C = self.num_heads, self.patch_size, self.channels
+        pad, unpad, cu_seqlens = self.get_padding_and_inverse(point)
+        order = point.serialized_order[self.order_index][pad]
+        inverse = unpad[point.serialized_inverse[self.order_index]]
+        key = f"_ptc_rpe_coord_{self.order_index}"
+        if key not in point.keys():                                   # the role of get_rel_pos' cache (ptv3m1:104-112): O(N), not O(N K)
+            point[key] = point.grid_coord[order].to(torch.int32)
+        qkv = self.qkv(point.feat)[order]                              # ptv3m1:188
+        out = PF.attn_rpe_qkvpacked(qkv.to(torch.bfloat16).reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale, point[key],
+                                    self.rpe.rpe_table, self.rpe.pos_bnd)
+        feat = out.reshape(-1, C).to(qkv.dtype)[inverse]               # ptv3m1:206,216
+        point.feat = self.proj_drop(self.proj(feat))
+        return point
+
     def _forward_dense(self, point):
+        if self._rpe_kernel_ok(point):
+            return self._forward_rpe_kernel(point)
         H, K, C = self.num_heads, self.patch_size, self.channels
         pad, unpad, _ = self.get_padding_and_inverse(point)
         order = point.serialized_order[self.order_index][pad]

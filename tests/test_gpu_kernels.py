@@ -884,6 +884,63 @@ def test_flash_attn_api_head_dim_18_autograd(cuda):
     _close("fa18_bwd", xq.grad, x32.grad, 1.0 / 32, 1e-2 * float(x32.grad.abs().max()))
 
 
+def _rpe_reference(qkv, cu, scale, gc, table, bnd):
+    """ptv3m1:29-48,190-206 on the CPU in fp32, window by window (the oracle of the RPE kernels)."""
+    T, _, H, D = qkv.shape
+    R = 2 * bnd + 1
+    out = torch.zeros(T, H, D)
+    lse = torch.zeros(H, T)
+    for a, b in zip(cu[:-1].tolist(), cu[1:].tolist()):
+        if b <= a:
+            continue
+        q, k, v = (qkv[a:b, j].permute(1, 0, 2) for j in range(3))                  # [H, L, D]
+        rel = gc[a:b, None, :].long() - gc[None, a:b, :].long()                     # [L(query), L(key), 3]
+        idx = rel.clamp(-bnd, bnd) + bnd + torch.arange(3) * R
+        bias = table[idx.reshape(-1)].view(b - a, b - a, 3, H).sum(2).permute(2, 0, 1)
+        logits = (q * scale) @ k.transpose(1, 2) + bias
+        lse[:, a:b] = torch.logsumexp(logits, dim=-1)
+        out[a:b] = (torch.softmax(logits, dim=-1) @ v).permute(1, 0, 2)
+    return out, lse
+
+
+@pytest.mark.parametrize("lens,H,bnd", [([256, 256], 2, 20), ([1024, 1024, 1024], 4, 32), ([200, 200, 200], 3, 18), ([33], 1, 4),
+                                        ([1024, 330], 2, 32)])
+def test_attention_rpe_fwd_bwd(cuda, lens, H, bnd):
+    """relative-position-bias attention kernels against the reference formulation (fp32, CPU): output, lse,
+    dqkv and the table gradient.  dqkv is bit-reproducible; the table gradient is summed with float atomics."""
+    from pointcept_amd import functional as PF
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(sum(lens) + H + bnd)
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    qkv = (torch.randn(T, 3, H, 16, generator=g) * 1.2).to(torch.bfloat16)
+    gc = torch.randint(0, 3 * bnd, (T, 3), generator=g).to(torch.int32)          # offsets beyond +-bnd get clamped
+    gc[::7] += 40000                                                               # large coordinates: 16-bit packing
+    table = torch.randn(3 * (2 * bnd + 1), H, generator=g) * 0.5
+    scale = 0.25
+    assert ops.attn_rpe_supported(16, max(lens), bnd)
+    out, lse = ops.attn_rpe_fwd(qkv.to(cuda), cu.to(cuda), max(lens), scale, gc.to(cuda), table.to(cuda), bnd)
+    q32, t32 = qkv.float().requires_grad_(True), table.clone().requires_grad_(True)
+    ref, ref_lse = _rpe_reference(q32, cu, scale, gc, t32, bnd)
+    vmax = float(qkv[:, 2].float().abs().max())
+    _close("rpe_fwd", out, ref, 1.0 / 64, 2.0 ** -9 * vmax)
+    _close("rpe_lse", lse, ref_lse, 1e-3, 2e-2)
+    dout = torch.randn(T, H, 16, generator=g).to(torch.bfloat16)
+    ref.backward(dout.float())
+    dqkv, dtab = ops.attn_rpe_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale, gc.to(cuda), table.to(cuda), bnd)
+    _close("rpe_dqkv", dqkv, q32.grad, 1.0 / 32, 1e-2 * float(q32.grad.abs().max()))
+    _close("rpe_dtable", dtab, t32.grad, 2e-2, 1e-2 * float(t32.grad.abs().max()))
+    d2, _ = ops.attn_rpe_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale, gc.to(cuda), table.to(cuda), bnd)
+    assert torch.equal(dqkv, d2), "dqkv is not bit-reproducible"
+    # autograd wrapper
+    xq, tq = qkv.to(cuda).requires_grad_(True), table.to(cuda).requires_grad_(True)
+    o = PF.attn_rpe_qkvpacked(xq, cu.to(cuda), max(lens), scale, gc.to(cuda), tq, bnd)
+    (o.float() * dout.to(cuda).float()).sum().backward()
+    assert torch.equal(xq.grad, dqkv)
+    _close("rpe_dtable_autograd", tq.grad, t32.grad, 2e-2, 1e-2 * float(t32.grad.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------------
 # I. ends of the step: coordinate maxima, cross entropy
 # ------------------------------------------------------------------------------------------------

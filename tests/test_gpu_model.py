@@ -282,6 +282,55 @@ def test_ptv3_dense_rpe_branch_matches_reference_golden_and_oracle(cuda):
     assert float(eng.dec.dec0.block0.attn.rpe.rpe_table.grad.abs().max()) > 0
 
 
+def test_ptv3_rpe_branch_on_the_kernels_under_bf16_autocast(cuda, monkeypatch):
+    """A13 under bf16 autocast: the RPE branch runs on the window-attention kernels (attention_rpe.h).  Same model, same
+    batch, same seeds with the kernels and with the dense torch formulation (PTC_RPE_KERNEL=0 semantics via config): features,
+    loss and every gradient (the RPE tables included) agree to bf16 accuracy; both against the fp32 oracle."""
+    from pointcept_amd import config, synthetic
+    from pointcept_amd import point_transformer_v3 as m
+
+    g = np.load(os.path.join(GOLD, "ptv3_rpe.npz"))
+    orc, eng = _models(RPE_CFG, seed=2)
+    eng = eng.to(cuda).train()
+    batch = synthetic.collate([synthetic.indoor_scene(int(s), int(n)) for s, n in zip(g["scene_seeds"], g["n_points"])])
+    res = {}
+    calls = {"n": 0}
+    real = m.PF.attn_rpe_qkvpacked
+
+    def spy(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(m.PF, "attn_rpe_qkvpacked", spy)
+    for tag, on in (("kernel", True), ("dense", False)):
+        monkeypatch.setattr(config, "RPE_KERNEL", on)
+        eng.zero_grad(set_to_none=True)
+        torch.manual_seed(6)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            feat = eng(synthetic.to_torch(batch, cuda)).feat
+        loss = feat.float().pow(2).mean()
+        loss.backward()
+        res[tag] = (feat.detach().float().cpu(), float(loss), {k: p.grad.detach().float().cpu().clone() for k, p in eng.named_parameters()})
+    n_rpe_blocks = sum(1 for mod in eng.modules() if isinstance(mod, m.SerializedAttention))
+    assert calls["n"] == n_rpe_blocks, (calls, n_rpe_blocks)           # every attention of the kernel run went through the kernels
+    fk, fd = res["kernel"][0], res["dense"][0]
+    scale = float(fd.abs().max())
+    assert float((fk - fd).abs().max()) <= 3e-2 * scale
+    assert abs(res["kernel"][1] - res["dense"][1]) <= 2e-2 * abs(res["dense"][1])
+    orc.train()
+    torch.manual_seed(6)
+    fo = orc({k: torch.from_numpy(v) for k, v in batch.items()}).feat
+    fo.pow(2).mean().backward()
+    go = {k: p.grad for k, p in orc.named_parameters()}
+    for name in res["kernel"][2]:
+        r = go[name]
+        if float(r.norm()) > 1e-6:
+            ek = float((res["kernel"][2][name] - r).norm() / r.norm())
+            ed = float((res["dense"][2][name] - r).norm() / r.norm())
+            assert ek <= max(2.0 * ed, 0.0) + 3e-2, (name, ek, ed)      # no worse than the bf16 torch formulation (+3 %)
+    assert float(res["kernel"][2]["dec.dec0.block0.attn.rpe.rpe_table"].abs().max()) > 0
+
+
 def test_ptv3_enable_flash_false_uses_the_shrunk_patch(cuda):
     """enable_flash=False without RPE: same data-dependent patch size (ptv3m1:173-176), served by the window-attention
     kernel (bf16 operands) -- compared with the oracle's dense fp32 branch."""

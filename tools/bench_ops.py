@@ -317,6 +317,41 @@ def bench_attention_hd(rows, n_seq, H, D, results, L=1024):
                 f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s | library SDPA fwd on pre-gathered [n,H,L,D] {r['sdpa_fwd']['us']:8.1f} us")
 
 
+def bench_attention_rpe(rows, n_seq, H, L, results):
+    """A13: RPE attention kernels (attention_rpe.h) beside the reference's dense formulation (ptv3m1:190-206) in torch on the GPU."""
+    bnd = int((4 * L) ** (1 / 3) * 2)
+    T = n_seq * L
+    qkv = torch.randn(T, 3, H, 16, device=DEV).to(torch.bfloat16)
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32, device=DEV)
+    gc = torch.randint(0, 2 * bnd, (T, 3), device=DEV, dtype=torch.int32)
+    table = torch.randn(3 * (2 * bnd + 1), H, device=DEV) * 0.02
+    sc = 0.25
+    out, lse = ops.attn_rpe_fwd(qkv, cu, L, sc, gc, table, bnd)
+    do = torch.randn_like(out)
+    fl = L * L * 16 * n_seq * H
+    r = {"shape": [n_seq, L, H], "pos_bnd": bnd}
+    r["fwd"] = roof(T * H * 16 * 8, 4.0 * fl, timeit(lambda: ops.attn_rpe_fwd(qkv, cu, L, sc, gc, table, bnd), iters=5))
+    r["bwd"] = roof(T * H * 16 * 16, 10.0 * fl, timeit(lambda: ops.attn_rpe_bwd(qkv, out, do, lse, cu, L, sc, gc, table, bnd), iters=5))
+
+    def dense():
+        q, k, v = qkv.reshape(n_seq, L, 3, H, 16).permute(2, 0, 3, 1, 4).unbind(0)
+        g = gc.reshape(n_seq, L, 3).long()
+        rel = g.unsqueeze(2) - g.unsqueeze(1)
+        idx = rel.clamp(-bnd, bnd) + bnd + torch.arange(3, device=DEV) * (2 * bnd + 1)
+        bias = table.index_select(0, idx.reshape(-1)).view(idx.shape + (-1,)).sum(3).permute(0, 3, 1, 2)
+        attn = torch.softmax((q.float() * sc) @ k.float().transpose(-2, -1) + bias, dim=-1).to(qkv.dtype)
+        return (attn @ v).transpose(1, 2)
+
+    try:
+        r["dense_fwd_us"] = timeit(dense, iters=3) * 1e6
+    except RuntimeError as e:   # out of memory at large shapes is the point of the comparison
+        r["dense_fwd_us"] = float("nan")
+        r["dense_error"] = str(e)[:80]
+    results.append(r)
+    rows.append(f"attention_rpe n_seq={n_seq:4d} L={L} H={H:2d} bnd={bnd} | fwd {r['fwd']['us']:8.1f} us | bwd {r['bwd']['us']:8.1f} us | "
+                f"dense torch formulation fwd {r['dense_fwd_us']:10.1f} us ([P,H,K,K] fp32 = {n_seq * H * L * L * 4 / 1e9:.2f} GB)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -348,6 +383,10 @@ def main():
     if want("attn"):
         for n_seq, H in ((800, 2), (800, 4), (200, 4), (48, 8), (16, 16)):
             bench_attention(rows, n_seq, H, res["attn"])
+    if "attn_rpe" in only:
+        res["attn_rpe"] = []
+        for n_seq, H, L in ((64, 4, 256), (200, 4, 1024), (800, 4, 1024)):
+            bench_attention_rpe(rows, n_seq, H, L, res["attn_rpe"])
     if want("attn_hd"):
         res["attn_hd"] = []
         for n_seq, H, D, L in ((800, 3, 18, 1024), (200, 6, 18, 1024), (48, 12, 18, 1024), (200, 4, 32, 1024), (200, 4, 48, 672), (200, 4, 64, 512)):
