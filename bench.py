@@ -329,6 +329,14 @@ def main():
         raise SystemExit(self_launch(args))
     from pointcept_amd import dp
 
+    # The ONE JSON line must be the last thing on stdout.  RCCL printf()s a version banner into the C stdout buffer when its first
+    # communicator comes up, and that buffer is flushed at process exit -- AFTER the line (seen on the GPU box: profiles/
+    # r02_y_ddp_single_rank.txt).  So file descriptor 1 is pointed at stderr for the whole run and the line is written to the
+    # saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank, local_rank, world = dp.env_rank()
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a different GPU count than asked")
@@ -377,6 +385,7 @@ def main():
             "value": round(args.batch * world * args.steps / dt, 4),
             "unit": "scenes/s",
             "n_gpus": world,
+            "ddp": type(step_model).__name__ == "DistributedDataParallel",
             "rccl_ranks": ranks,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -422,8 +431,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_points, args.points, args.cpu_iters, not args.ce_only)
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if torch.distributed.is_initialized():
         dp.barrier(device)
         torch.distributed.destroy_process_group()
 

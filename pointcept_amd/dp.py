@@ -13,6 +13,11 @@ import torch
 import torch.distributed as dist
 
 
+# PTC_FORCE_DDP=1: initialise the process group and wrap in DistributedDataParallel even at world size 1 -- the only way to run
+# RCCL, DDP's bucket hooks and the engine's autograd Functions together on a one-GPU box (tests/test_gpu_model.py)
+_FORCE = os.environ.get("PTC_FORCE_DDP", "0") == "1"
+
+
 def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -20,7 +25,7 @@ def env_rank():
 def init_distributed(backend: str | None = None, device: torch.device | None = None) -> None:
     """init_process_group from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
     rank, _, world = env_rank()
-    if world <= 1 or dist.is_initialized():
+    if (world <= 1 and not _FORCE) or dist.is_initialized():
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
@@ -38,7 +43,7 @@ def wrap_ddp(model: torch.nn.Module, device: torch.device, bucket_cap_mb: int = 
     stay per-rank as in the reference).  bucket_cap_mb: PTv3's 185 MB of fp32
     gradients go out in ~8 buckets as backward produces them; xGMI is point-to-point, so the
     per-bucket ring time (~0.3 ms) hides under the remaining backward."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
         return model
     ids = [device.index] if device.type == "cuda" else None
     return torch.nn.parallel.DistributedDataParallel(

@@ -331,6 +331,30 @@ def test_ptv3_rpe_branch_on_the_kernels_under_bf16_autocast(cuda, monkeypatch):
     assert float(res["kernel"][2]["dec.dec0.block0.attn.rpe.rpe_table"].abs().max()) > 0
 
 
+def test_bench_step_under_ddp_over_rccl_single_rank(cuda):
+    """The N > 1 path of bench.py on the one GPU a gpurun box has: PTC_FORCE_DDP=1 initialises the "nccl" (= RCCL) process
+    group at world size 1 and wraps the model in DistributedDataParallel (bucket hooks, gradient_as_bucket_view, the
+    all-reduce launched on RCCL's stream) around the engine's autograd Functions.  Same seeds with and without the wrapper:
+    the loss after the timed steps must be identical (a one-rank all-reduce averages over one rank)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--points", "20000", "--no-secondary", "--no-cpu-baseline"]
+    lines = {}
+    for tag, force in (("ddp", "1"), ("plain", "0")):
+        env = dict(os.environ, PTC_FORCE_DDP=force, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29531")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert lines["ddp"]["ddp"] is True and lines["plain"]["ddp"] is False
+    assert lines["ddp"]["n_gpus"] == 1 and lines["ddp"]["rccl_ranks"] == 1
+    assert lines["ddp"]["config"]["final_loss"] == lines["plain"]["config"]["final_loss"], (lines["ddp"]["config"], lines["plain"]["config"])
+
+
 def test_ptv3_enable_flash_false_uses_the_shrunk_patch(cuda):
     """enable_flash=False without RPE: same data-dependent patch size (ptv3m1:173-176), served by the window-attention
     kernel (bf16 operands) -- compared with the oracle's dense fp32 branch."""
