@@ -103,6 +103,20 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
             return LIB  # GPU box without a compiler: use the prebuilt in-tree library
         raise RuntimeError(f"hipcc not found at {HIPCC} and no prebuilt {LIB}")
     os.makedirs(BUILD, exist_ok=True)
+    # one builder at a time: the ranks of a multi-GPU job all pass through here (lib() -> build()); if the snapshot's
+    # mtimes ever asked for a rebuild, N concurrent hipcc runs would write the same objects.  The others wait, then find
+    # everything up to date.
+    import fcntl
+
+    with open(os.path.join(BUILD, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose, variant, LIB, BUILD, HIP_FLAGS)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool, variant: str, LIB: str, BUILD: str, HIP_FLAGS: list) -> str:
     hdrs = _headers()
     jobs = []
     objs = []
