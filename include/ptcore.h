@@ -476,6 +476,33 @@ int ptc_batch_norm_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dt
                            void* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                            ptc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * M. libs/pointops2: the pair-list attention operators of Stratified Transformer (fp32), reference wrappers
+ *    libs/pointops2/functions/pointops.py:93-961, kernels libs/pointops2/src/{attention,attention_v2,rpe,rpe_v2}/.
+ *    (kNN / FPS / grouping / interpolation / subtraction / aggregation of pointops2 = sections L and E.)
+ *    Pairs m = 0..M-1: query i0[m], key i1[m]; offsets [Nq+1] = CSR of the pairs by query or NULL (then i0 may be unsorted);
+ *    T(m,h,c) = sum_a table[rel_idx[m,a], h, c, a], table [L, H, d, 3], rel_idx [M, 3] int32.
+ *  ptc_pair_dot_fwd      : out[m,h] = [with_qk] q[i0].k[i1] + [table_q] q[i0].Tq + [table_k] k[i1].Tk
+ *        = attention_step1(_v2) (with_qk, no tables), dot_prod_with_idx (table_q only), dot_prod_with_idx_v2 / _v3 (both tables)
+ *  ptc_pair_dot_bwd      : dq (segment loops with offsets, else atomics), dk, d tables (atomics; any may be NULL)
+ *  ptc_pair_aggregate_fwd: out[n,h,c] = sum_{pairs of n} attn[m,h] (v[i1[m],h,c] + [table_v] Tv)
+ *        = attention_step2(_v2), attention_step2_with_rel_pos_value(_v2)
+ *  ptc_pair_aggregate_bwd: dattn [M,H], dv [Nv,H,d], d table (atomics)
+ * ------------------------------------------------------------------------------------------ */
+int ptc_pair_dot_fwd(const float* q, const float* k, const int32_t* i0, const int32_t* i1, const float* table_q,
+                     const float* table_k, const int32_t* rel_idx, int with_qk, int64_t M, int H, int d, float* out,
+                     ptc_stream_t stream);
+int ptc_pair_dot_bwd(const float* grad_out, const float* q, const float* k, const int32_t* i0, const int32_t* offsets,
+                     const int32_t* i1, const float* table_q, const float* table_k, const int32_t* rel_idx, int with_qk,
+                     int64_t M, int64_t Nq, int64_t Nk, int64_t L, int H, int d, float* dq, float* dk, float* dtable_q,
+                     float* dtable_k, ptc_stream_t stream);
+int ptc_pair_aggregate_fwd(const float* attn, const float* v, const int32_t* i0, const int32_t* offsets, const int32_t* i1,
+                           const float* table_v, const int32_t* rel_idx, int64_t M, int64_t Nq, int H, int d, float* out,
+                           ptc_stream_t stream);
+int ptc_pair_aggregate_bwd(const float* grad_out, const float* attn, const float* v, const int32_t* i0, const int32_t* i1,
+                           const float* table_v, const int32_t* rel_idx, int64_t M, int64_t Nv, int64_t L, int H, int d,
+                           float* dattn, float* dv, float* dtable_v, ptc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,7 @@ HIP_SOURCES = [
     "lovasz.hip",
     "voxelize.hip",
     "pointops.hip",
+    "pointops2.hip",
     "bn.hip",
     "rope.hip",
     "evalhist.hip",
@@ -60,7 +61,8 @@ HIP_FLAGS = [
 # attention.hip: no SLP packing of the scalar f32 multiplies into v_pk_mul_f32 (beside MFMAs a packed f32 op costs more than
 # the two scalar ones it replaces, MI355X_MICROARCH.md per-instruction constants): backward 1460 -> 1406 us at the bench shape.
 # NOT global: the implicit-GEMM kernels lose 15-18 % without SLP at 96 / 128 channels (profiles/r02_o_slp_ab.txt).
-PER_FILE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
+# pointops2.hip: hardware fp32 atomic adds for the scatter gradients (the default expands atomicAdd(float) into a CAS loop)
+PER_FILE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"], "pointops2.hip": ["-munsafe-fp-atomics"]}
 
 
 def _newer(src: str, dst: str, extra: list[str]) -> bool:

@@ -1,5 +1,5 @@
 """Operator-level drop-in (SURVEY 8(b) level B3): make `import spconv.pytorch`, `import flash_attn`
-`import torch_scatter`, `import pointops` and `import pointrope` resolve to the engine, so the reference's model files
+`import torch_scatter`, `import pointops`, `import pointops2.pointops` and `import pointrope` resolve to the engine, so the reference's model files
 (point_transformer_v3m1_base.py, spconv_unet_v1m1_base.py, structure.py, modules.py) run UNMODIFIED
 on libptcore.so.  Call once before importing pointcept.models:
 
@@ -15,7 +15,7 @@ import types
 
 
 def install(force: bool = False) -> None:
-    from . import flash_attn_api, pointops_api, pointrope_api, spconv_api, torch_scatter_api
+    from . import flash_attn_api, pointops2_api, pointops_api, pointrope_api, spconv_api, torch_scatter_api
 
     def put(name, module):
         if force or name not in sys.modules:
@@ -33,4 +33,14 @@ def install(force: bool = False) -> None:
     ts.segment_csr = torch_scatter_api.segment_csr
     put("torch_scatter", ts)
     put("pointops", pointops_api)
+    # libs/pointops2: `import pointops2.pointops as pointops` (stratified_transformer_v1m1_origin.py:21, v1m2_refine.py:31)
+    p2 = types.ModuleType("pointops2")
+    p2.pointops = pointops2_api
+    p2f = types.ModuleType("pointops2.functions")
+    p2f.pointops = pointops2_api
+    p2.functions = p2f
+    put("pointops2", p2)
+    put("pointops2.pointops", pointops2_api)
+    put("pointops2.functions", p2f)
+    put("pointops2.functions.pointops", pointops2_api)
     put("pointrope", pointrope_api)      # libs/pointrope: `import pointrope as _kernels` (litept_v1.py:26)

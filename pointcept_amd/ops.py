@@ -895,3 +895,87 @@ def linear_gelu_bwd_input(g: torch.Tensor, weight_t: torch.Tensor, h: torch.Tens
     check(lib().ptc_linear_fwd_ex(ptr(g), n, ptr(weight_t), 0, c_in, c_out, dtype_code(g), 2, ptr(h), ptr(out), 0, stream_ptr()),
           "ptc_linear_fwd_ex")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# libs/pointops2: pair-list attention operators (csrc/pointops2.hip), fp32
+# ------------------------------------------------------------------------------------------------
+def _p2_check(name, t, shape=None, dtype=torch.float32):
+    if t is None:
+        return
+    if t.dtype != dtype or not t.is_contiguous():
+        raise PtcoreError(f"{name}: expected a contiguous {dtype} tensor, got {t.dtype} (contiguous={t.is_contiguous()})")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise PtcoreError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
+def pair_dot_fwd(q, k, i0, i1, table_q, table_k, rel_idx, with_qk: bool) -> torch.Tensor:
+    """out[m,h] = [with_qk] q[i0[m],h].k[i1[m],h] + [table_q] q[i0[m],h].Tq(m,h) + [table_k] k[i1[m],h].Tk(m,h)"""
+    require_cuda(q, k, i0, i1, table_q, table_k, rel_idx)
+    _, H, d = q.shape
+    M = i0.numel()
+    _p2_check("q", q)
+    _p2_check("k", k, (k.shape[0], H, d) if k is not None else None)
+    _p2_check("i0", i0, (M,), torch.int32)
+    _p2_check("i1", i1, (M,), torch.int32)
+    _p2_check("rel_idx", rel_idx, (M, 3), torch.int32)
+    for nm, t in (("table_q", table_q), ("table_k", table_k)):
+        _p2_check(nm, t, (t.shape[0], H, d, 3) if t is not None else None)
+    out = torch.empty((M, H), dtype=torch.float32, device=q.device)
+    check(lib().ptc_pair_dot_fwd(ptr(q), ptr(k), ptr(i0), ptr(i1), ptr(table_q), ptr(table_k), ptr(rel_idx), int(bool(with_qk)), M, H, d,
+                                 ptr(out), stream_ptr()), "ptc_pair_dot_fwd")
+    return out
+
+
+def pair_dot_bwd(g, q, k, i0, offsets, i1, table_q, table_k, rel_idx, with_qk: bool, want_q=True, want_k=True, want_tq=True,
+                 want_tk=True):
+    require_cuda(g, q, k, i0, offsets, i1, table_q, table_k, rel_idx)
+    Nq, H, d = q.shape
+    M = i0.numel()
+    _p2_check("grad_out", g, (M, H))
+    if offsets is not None and offsets.numel() != Nq + 1:
+        raise PtcoreError(f"offsets must have {Nq + 1} entries (one segment per query row), got {offsets.numel()}")
+    Nk = k.shape[0] if k is not None else 0
+    L = table_q.shape[0] if table_q is not None else (table_k.shape[0] if table_k is not None else 0)
+    dq = torch.empty_like(q) if want_q else None
+    dk = torch.empty_like(k) if (want_k and k is not None) else None
+    dtq = torch.empty_like(table_q) if (want_tq and table_q is not None) else None
+    dtk = torch.empty_like(table_k) if (want_tk and table_k is not None) else None
+    check(lib().ptc_pair_dot_bwd(ptr(g), ptr(q), ptr(k), ptr(i0), ptr(offsets), ptr(i1), ptr(table_q), ptr(table_k), ptr(rel_idx),
+                                 int(bool(with_qk)), M, Nq, Nk, L, H, d, ptr(dq), ptr(dk), ptr(dtq), ptr(dtk), stream_ptr()),
+          "ptc_pair_dot_bwd")
+    return dq, dk, dtq, dtk
+
+
+def pair_aggregate_fwd(attn, v, i0, offsets, i1, table_v, rel_idx, n_q: int) -> torch.Tensor:
+    """out[n,h,c] = sum_{m: i0[m] = n} attn[m,h] (v[i1[m],h,c] + [table_v] Tv(m,h,c)), out [n_q, H, d]"""
+    require_cuda(attn, v, i0, offsets, i1, table_v, rel_idx)
+    _, H, d = v.shape
+    M = i1.numel()
+    _p2_check("attn", attn, (M, H))
+    _p2_check("v", v)
+    _p2_check("i0", i0, (M,), torch.int32)
+    _p2_check("i1", i1, (M,), torch.int32)
+    _p2_check("rel_idx", rel_idx, (M, 3), torch.int32)
+    _p2_check("table", table_v, (table_v.shape[0], H, d, 3) if table_v is not None else None)
+    if offsets is not None and offsets.numel() != int(n_q) + 1:
+        raise PtcoreError(f"offsets must have {int(n_q) + 1} entries, got {offsets.numel()}")
+    out = torch.empty((int(n_q), H, d), dtype=torch.float32, device=v.device)
+    check(lib().ptc_pair_aggregate_fwd(ptr(attn), ptr(v), ptr(i0), ptr(offsets), ptr(i1), ptr(table_v), ptr(rel_idx), M, int(n_q), H, d,
+                                       ptr(out), stream_ptr()), "ptc_pair_aggregate_fwd")
+    return out
+
+
+def pair_aggregate_bwd(g, attn, v, i0, i1, table_v, rel_idx, want_attn=True, want_v=True, want_tv=True):
+    require_cuda(g, attn, v, i0, i1, table_v, rel_idx)
+    Nv, H, d = v.shape
+    M = i1.numel()
+    _p2_check("grad_out", g, (g.shape[0], H, d))
+    L = table_v.shape[0] if table_v is not None else 0
+    da = torch.empty_like(attn) if want_attn else None
+    dv = torch.empty_like(v) if want_v else None
+    dtv = torch.empty_like(table_v) if (want_tv and table_v is not None) else None
+    check(lib().ptc_pair_aggregate_bwd(ptr(g), ptr(attn), ptr(v), ptr(i0), ptr(i1), ptr(table_v), ptr(rel_idx), M, Nv, L, H, d, ptr(da),
+                                       ptr(dv), ptr(dtv), stream_ptr()), "ptc_pair_aggregate_bwd")
+    return da, dv, dtv
+

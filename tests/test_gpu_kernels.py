@@ -1720,3 +1720,115 @@ def test_ptv1_ptv2_operators_match_their_definitions(cuda):
     ref = np.zeros((n, g, c), np.float64)
     np.add.at(ref, it, (aw[:, :, None] * k[ir]).astype(np.float64))
     assert np.allclose(fus, ref, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# M. libs/pointops2 (Stratified Transformer operators)
+# ------------------------------------------------------------------------------------------------
+def _p2_case(seed, M=80000, N=3500, hdim=16, h=6, L=31):
+    """the workload of the reference's operator tests (libs/pointops2/functions/test_relative_pos_encoding_op_step1_v3.py:13-47)"""
+    g = torch.Generator().manual_seed(seed)
+    q, k, v = (torch.rand(N, h, hdim, generator=g) for _ in range(3))
+    tq, tk, tv = (torch.rand(L, h, hdim, 3, generator=g) for _ in range(3))
+    i0 = torch.sort((torch.rand(M, generator=g) * N).long()).values
+    i1 = (torch.rand(M, generator=g) * N).long()
+    rel = (torch.rand(M, 3, generator=g) * L).long()
+    attn = torch.rand(M, h, generator=g)
+    return q, k, v, tq, tk, tv, i0, i1, rel, attn
+
+
+def _p2_grads(fn, inputs, w):
+    leaves = [t.clone().requires_grad_(True) for t in inputs]
+    out = fn(*leaves)
+    (out * w.to(out.device, out.dtype)).sum().backward()
+    return out.detach(), [t.grad for t in leaves]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_pointops2_pair_operators_match_the_reference_formulations(cuda, seed):
+    """Every name of libs/pointops2/functions/pointops.py that Stratified Transformer calls, forward and gradients, against the torch
+    formulations of the reference's own operator tests (oracle/pointops2.py, fp64).  v1 / v2 / v3 forms must agree with each other."""
+    from oracle import pointops2 as orc
+    from pointcept_amd import pointops2_api as p2
+
+    q, k, v, tq, tk, tv, i0, i1, rel, attn = _p2_case(seed)
+    N, M = q.shape[0], i0.numel()
+    off = orc.offsets_of(i0, N)
+    n_max = int((off[1:] - off[:-1]).max())
+    dev = lambda *ts: [t.to(cuda) for t in ts]  # noqa: E731
+    i0d, i1d, reld, offd = i0.int().to(cuda), i1.int().to(cuda), rel.int().to(cuda), off.to(cuda)
+    g = torch.Generator().manual_seed(seed + 10)
+    w_mh, w_n = torch.rand(M, q.shape[1], generator=g), torch.rand(N, q.shape[1], q.shape[2], generator=g)
+    d64 = lambda *ts: [t.double() for t in ts]  # noqa: E731
+
+    def cmp(tag, got, ref, rtol=2e-5):
+        scale = float(ref.abs().max()) + 1e-30
+        err = float((got.detach().cpu().double() - ref).abs().max())
+        assert err <= rtol * scale, f"{tag}: max err {err:.3e} vs scale {scale:.3e}"
+
+    # attention_step1 / _v2
+    ref, rg = _p2_grads(lambda a, b: orc.attention_step1(a, b, i0, i1), d64(q, k), w_mh)
+    for tag, fn in (("step1", lambda a, b: p2.attention_step1(a, b, i0d, i1d)), ("step1_v2", lambda a, b: p2.attention_step1_v2(a, b, i1d, offd, n_max))):
+        out, gr = _p2_grads(fn, dev(q, k), w_mh)
+        cmp(tag, out, ref)
+        for name, a, b in zip(("dq", "dk"), gr, rg):
+            cmp(f"{tag}.{name}", a, b, 1e-4)
+    # dot_prod_with_idx (one table)
+    ref, rg = _p2_grads(lambda a, t: orc.dot_prod_with_idx(a, i0, t, rel), d64(q, tq), w_mh)
+    out, gr = _p2_grads(lambda a, t: p2.dot_prod_with_idx(a, i0d, t, reld), dev(q, tq), w_mh)
+    cmp("dot_prod", out, ref)
+    cmp("dot_prod.dq", gr[0], rg[0], 1e-4)
+    cmp("dot_prod.dtable", gr[1], rg[1], 1e-4)
+    # _v2 / _v3 (both tables)
+    ref, rg = _p2_grads(lambda a, b, t, u: orc.dot_prod_with_idx_v3(a, i0, b, i1, t, u, rel), d64(q, k, tq, tk), w_mh)
+    for tag, fn in (("dot_prod_v2", lambda a, b, t, u: p2.dot_prod_with_idx_v2(a, i0d, b, i1d, t, u, reld)),
+                    ("dot_prod_v3", lambda a, b, t, u: p2.dot_prod_with_idx_v3(a, offd, n_max, b, i1d, t, u, reld))):
+        out, gr = _p2_grads(fn, dev(q, k, tq, tk), w_mh)
+        cmp(tag, out, ref)
+        for name, a, b in zip(("dq", "dk", "dtq", "dtk"), gr, rg):
+            cmp(f"{tag}.{name}", a, b, 1e-4)
+    # attention_step2 / with_rel_pos_value / _v2
+    ref, rg = _p2_grads(lambda a, b: orc.attention_step2(a, b, i0, i1, N), d64(attn, v), w_n)
+    out, gr = _p2_grads(lambda a, b: p2.attention_step2(a, b, i0d, i1d), dev(attn, v), w_n[: int(i0.max()) + 1])
+    cmp("step2", out, ref[: int(i0.max()) + 1], 1e-4)
+    ref, rg = _p2_grads(lambda a, b, t: orc.attention_step2(a, b, i0, i1, N, t, rel), d64(attn, v, tv), w_n)
+    for tag, fn in (("step2_rel", lambda a, b, t: p2.attention_step2_with_rel_pos_value(a, b, i0d, i1d, t, reld)),
+                    ("step2_rel_v2", lambda a, b, t: p2.attention_step2_with_rel_pos_value_v2(a, b, offd, n_max, i1d, t, reld))):
+        out, gr = _p2_grads(fn, dev(attn, v, tv), w_n)
+        cmp(tag, out, ref, 1e-4)
+        for name, a, b in zip(("dattn", "dv", "dtable"), gr, rg):
+            cmp(f"{tag}.{name}", a, b, 1e-4)
+    # the offsets form is a fixed-order segment loop: bit-reproducible
+    a1 = p2.attention_step2_with_rel_pos_value_v2(attn.to(cuda), v.to(cuda), offd, n_max, i1d, tv.to(cuda), reld)
+    a2 = p2.attention_step2_with_rel_pos_value_v2(attn.to(cuda), v.to(cuda), offd, n_max, i1d, tv.to(cuda), reld)
+    assert torch.equal(a1, a2)
+
+
+def test_pointops2_shared_families_and_import_names(cuda):
+    """furthestsampling / knnquery / grouping / queryandgroup / interpolation under pointops2's argument order, through
+    `import pointops2.pointops` as the Stratified Transformer files import it."""
+    import pointcept_amd.compat as compat
+
+    compat.install()
+    import pointops2.pointops as pointops
+    from oracle import pointops as orc1
+
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.rand(3000, 3, generator=g)
+    feat = torch.randn(3000, 8, generator=g)
+    offset = torch.tensor([1400, 3000], dtype=torch.int32)
+    new_offset = torch.tensor([350, 750], dtype=torch.int32)
+    idx = pointops.furthestsampling(xyz.to(cuda), offset.to(cuda), new_offset.to(cuda))
+    ref_idx = orc1.farthest_point_sampling(xyz.numpy(), offset.numpy(), new_offset.numpy())
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    new_xyz = xyz[idx.cpu().long()]
+    nidx, dist = pointops.knnquery(8, xyz.to(cuda), new_xyz.to(cuda), offset.to(cuda), new_offset.to(cuda))
+    ridx, rdist = orc1.knn_query(8, xyz.numpy(), offset.numpy(), new_xyz.numpy(), new_offset.numpy())
+    assert np.array_equal(nidx.cpu().numpy(), ridx) and np.allclose(dist.cpu().numpy(), rdist, atol=1e-6)
+    grouped = pointops.queryandgroup(8, xyz.to(cuda), new_xyz.to(cuda), feat.to(cuda), None, offset.to(cuda), new_offset.to(cuda), use_xyz=True)
+    ref_g = torch.cat([xyz[torch.from_numpy(ridx).long()] - new_xyz[:, None], feat[torch.from_numpy(ridx).long()]], -1)
+    assert torch.allclose(grouped.cpu(), ref_g, atol=1e-6)
+    assert torch.equal(pointops.grouping(feat.to(cuda), nidx).cpu(), feat[torch.from_numpy(ridx).long()])
+    up = pointops.interpolation(new_xyz.to(cuda), xyz.to(cuda), feat[idx.cpu().long()].to(cuda), new_offset.to(cuda), offset.to(cuda))
+    assert up.shape == (3000, 8) and torch.isfinite(up).all()
+

@@ -109,3 +109,41 @@ def test_attention_varlen_matches_sdpa():
         assert torch.allclose(out[a:b], ref, atol=1e-5)
         s = (q[0] * 0.25) @ k[0].transpose(1, 2)
         assert torch.allclose(lse[:, a:b], torch.logsumexp(s, -1), atol=1e-5)
+
+
+def test_pointops2_oracle_against_the_kernels_index_arithmetic():
+    """oracle/pointops2.py (the torch formulations of the reference's operator tests) against a literal loop over the flat
+    index arithmetic of the CUDA kernels (table[r * C * 3 + h * d * 3 + i * 3 + a], q[n * C + h * d + i]:
+    libs/pointops2/src/rpe_v2/relative_pos_encoding_cuda_kernel_v2.cu:248-282,398-437) on a small case."""
+    from oracle import pointops2 as orc
+
+    g = torch.Generator().manual_seed(0)
+    N, M, h, d, L = 7, 23, 2, 4, 5
+    q, k, v = (torch.rand(N, h, d, generator=g, dtype=torch.float64) for _ in range(3))
+    tq, tk, tv = (torch.rand(L, h, d, 3, generator=g, dtype=torch.float64) for _ in range(3))
+    i0 = torch.sort(torch.randint(0, N, (M,), generator=g)).values
+    i1 = torch.randint(0, N, (M,), generator=g)
+    rel = torch.randint(0, L, (M, 3), generator=g)
+    attn = torch.rand(M, h, generator=g, dtype=torch.float64)
+    C = h * d
+    qf, kf, vf, tqf, tkf, tvf = (t.reshape(-1) for t in (q, k, v, tq, tk, tv))
+    out1 = torch.zeros(M, h, dtype=torch.float64)
+    out3 = torch.zeros(M, h, dtype=torch.float64)
+    agg = torch.zeros(N, h, d, dtype=torch.float64)
+    for m in range(M):
+        r1, r2, r3 = (int(x) for x in rel[m])
+        for hh in range(h):
+            for i in range(d):
+                t_q = tqf[r1 * C * 3 + hh * d * 3 + i * 3] + tqf[r2 * C * 3 + hh * d * 3 + i * 3 + 1] + tqf[r3 * C * 3 + hh * d * 3 + i * 3 + 2]
+                t_k = tkf[r1 * C * 3 + hh * d * 3 + i * 3] + tkf[r2 * C * 3 + hh * d * 3 + i * 3 + 1] + tkf[r3 * C * 3 + hh * d * 3 + i * 3 + 2]
+                t_v = tvf[r1 * C * 3 + hh * d * 3 + i * 3] + tvf[r2 * C * 3 + hh * d * 3 + i * 3 + 1] + tvf[r3 * C * 3 + hh * d * 3 + i * 3 + 2]
+                qv, kv = qf[int(i0[m]) * C + hh * d + i], kf[int(i1[m]) * C + hh * d + i]
+                out1[m, hh] += qv * kv
+                out3[m, hh] += qv * t_q + kv * t_k
+                agg[int(i0[m]), hh, i] += attn[m, hh] * (vf[int(i1[m]) * C + hh * d + i] + t_v)
+    assert torch.allclose(orc.attention_step1(q, k, i0, i1), out1, atol=1e-12)
+    assert torch.allclose(orc.dot_prod_with_idx_v3(q, i0, k, i1, tq, tk, rel), out3, atol=1e-12)
+    assert torch.allclose(orc.attention_step2(attn, v, i0, i1, N, tv, rel), agg, atol=1e-12)
+    off = orc.offsets_of(i0, N)
+    assert off.numel() == N + 1 and int(off[-1]) == M and all(int(off[n]) <= int(off[n + 1]) for n in range(N))
+
