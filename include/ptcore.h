@@ -364,12 +364,14 @@ int ptc_attn_varlen_hd_bwd(const void* qkv, const void* out, const void* dout, c
  *   softmax(scale q k^T + sum_a rpe_table[a R + clamp(gc_i[a] - gc_j[a], -B, B) + B][h]) v     (i = query, j = key)
  *   grid_coord : [total, 3] int32, rows in the SAME (serialized, padded) order as qkv; values in [0, 2^16)
  *   rpe_table  : [3 R, H] fp32, R = 2 pos_bnd + 1 (RPE.rpe_table);  d_rpe_table: same shape, overwritten
- * The bias is evaluated per pair in the tile loop; nothing of size L^2 is materialised.  d_rpe_table is accumulated with
- * float atomics (order-dependent rounding, like the reference's index_select backward); dqkv is bit-reproducible. */
+ * The bias is evaluated per pair in the tile loop; nothing of size L^2 is materialised.  d_rpe_table is accumulated in
+ * 2^-24 fixed point with 64-bit integer atomics (order-independent: bit-reproducible, unlike the reference's float
+ * atomicAdd) and converted at the end; workspace = ptc_attn_rpe_bwd_workspace_bytes. */
 int ptc_attn_rpe_fwd(const void* qkv, const int32_t* cu_seqlens, const int32_t* grid_coord,
                      const float* rpe_table, int pos_bnd, int64_t n_seq, int64_t total, int H,
                      int max_seqlen, float softmax_scale, int dtype, void* out, float* lse,
                      ptc_stream_t stream);
+size_t ptc_attn_rpe_bwd_workspace_bytes(int64_t total, int H, int pos_bnd);
 int ptc_attn_rpe_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                      const int32_t* cu_seqlens, const int32_t* grid_coord, const float* rpe_table,
                      int pos_bnd, int64_t n_seq, int64_t total, int H, int max_seqlen,

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "ptc_pair_aggregate_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr,
                                        c_ptr, c_ptr]),
     "ptc_attn_rpe_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_i64, c_int, c_int, c_f32, c_int, c_ptr, c_ptr, c_ptr]),
+    "ptc_attn_rpe_bwd_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
     "ptc_attn_rpe_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_i64, c_int, c_int, c_f32, c_int, c_ptr,
                                  c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_attn_varlen_hd_fwd": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_int, c_ptr, c_ptr, c_ptr]),

@@ -1210,6 +1210,10 @@ extern "C" int ptc_attn_rpe_fwd(const void* qkv, const int32_t* cu_seqlens, cons
   return PTC_OK;
 }
 
+extern "C" size_t ptc_attn_rpe_bwd_workspace_bytes(int64_t total, int H, int pos_bnd) {
+  return ptc_attn_varlen_bwd_workspace_bytes(total, H) + ptc_align_up((size_t)3 * (2 * (size_t)(pos_bnd > 0 ? pos_bnd : 0) + 1) * H * 8, 256);
+}
+
 extern "C" int ptc_attn_rpe_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
                                 const int32_t* grid_coord, const float* rpe_table, int pos_bnd, int64_t n_seq, int64_t total, int H,
                                 int max_seqlen, float softmax_scale, int dtype, void* dqkv, float* d_rpe_table, void* workspace,
@@ -1218,10 +1222,14 @@ extern "C" int ptc_attn_rpe_bwd(const void* qkv, const void* out, const void* do
   if (rc != PTC_OK) return rc;
   const int R = 2 * pos_bnd + 1;
   hipStream_t s = (hipStream_t)stream;
-  if (d_rpe_table) PTC_HIP(hipMemsetAsync(d_rpe_table, 0, (size_t)3 * R * H * sizeof(float), s));
-  if (n_seq == 0 || total == 0) return PTC_OK;
+  if (n_seq == 0 || total == 0) {
+    if (d_rpe_table) PTC_HIP(hipMemsetAsync(d_rpe_table, 0, (size_t)3 * R * H * sizeof(float), s));
+    return PTC_OK;
+  }
   PTC_REQUIRE(out && dout && lse && dqkv && d_rpe_table && workspace, PTC_EINVAL, "ptc_attn_rpe_bwd: null buffer");
-  PTC_REQUIRE(workspace_bytes >= ptc_attn_varlen_bwd_workspace_bytes(total, H), PTC_EWORKSPACE, "ptc_attn_rpe_bwd: workspace too small");
+  PTC_REQUIRE(workspace_bytes >= ptc_attn_rpe_bwd_workspace_bytes(total, H, pos_bnd), PTC_EWORKSPACE, "ptc_attn_rpe_bwd: workspace too small");
+  unsigned long long* dt_fix = (unsigned long long*)((char*)workspace + ptc_attn_varlen_bwd_workspace_bytes(total, H));
+  PTC_HIP(hipMemsetAsync(dt_fix, 0, (size_t)3 * R * H * 8, s));
   const int lp_max = (max_seqlen + 31) & ~31;
   const size_t lds_q = (size_t)lp_max * 64 + ar_extra_lds(lp_max, R), lds_kv = (size_t)lp_max * 72 + ar_extra_lds(lp_max, R);
   PTC_REQUIRE(lds_kv <= AH_LDS_LIMIT, PTC_EUNSUPPORTED, "ptc_attn_rpe_bwd: max_seqlen=%d with pos_bnd=%d does not fit LDS", max_seqlen, pos_bnd);
@@ -1234,8 +1242,11 @@ extern "C" int ptc_attn_rpe_bwd(const void* qkv, const void* out, const void* do
   float* delta = (float*)workspace;
   hipLaunchKernelGGL(attn_rpe_bwd_dq_kernel, dim3(grid), dim3(AT_THREADS), lds_q, s, (const uint16_t*)qkv, (const uint16_t*)out,
                      (const uint16_t*)dout, lse, cu_seqlens, grid_coord, rpe_table, R, pos_bnd, H, softmax_scale, total, lp_max,
-                     n_units, (uint16_t*)dqkv, delta, d_rpe_table);
+                     n_units, (uint16_t*)dqkv, delta, dt_fix);
   PTC_CHECK_LAUNCH("attn_rpe_bwd_dq_kernel");
+  hipLaunchKernelGGL(attn_rpe_table_finish_kernel, dim3((unsigned)ptc_cdiv((int64_t)3 * R * H, 256)), dim3(256), 0, s,
+                     (const unsigned long long*)dt_fix, (int64_t)3 * R * H, d_rpe_table);
+  PTC_CHECK_LAUNCH("attn_rpe_table_finish_kernel");
   hipLaunchKernelGGL(attn_rpe_bwd_dkv_kernel, dim3(grid), dim3(AT_THREADS), lds_kv, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse,
                      (const float*)delta, cu_seqlens, grid_coord, rpe_table, R, pos_bnd, H, softmax_scale, total, lp_max, n_units,
                      (uint16_t*)dqkv);

@@ -9,9 +9,11 @@
 // evaluated per (query, key) pair inside the tile loop from the two rows' packed coordinates (LDS) and the head's 3 R table
 // entries (LDS, pre-multiplied by log2 e): nothing of size K^2 ever exists.  Same operand layout, LDS images and MFMA products as
 // attention.hip; the loops are the plain in-order forms (online softmax in the forward: the bias moves the row maximum, so the
-// norm bound of the fast path does not apply).  The table gradient d table[a R + idx][h] += dS[i][j] is accumulated with LDS float
-// atomics per workgroup and one global atomic per entry at the end: like the reference's index_select backward (atomicAdd) it
-// is not bit-reproducible run to run; dQ / dK / dV are.
+// norm bound of the fast path does not apply).  The table gradient d table[a R + idx][h] += dS[i][j] is accumulated in 2^-24 FIXED
+// POINT: 64-bit integer atomics in LDS per workgroup (ds_add_u64 runs at full rate; ds_add_f32 is executed lane by lane on gfx950
+// -- the float version of this kernel took 58 ms at the dec0 shape), one 64-bit global atomic per entry at the end, one tiny
+// conversion launch.  Integer sums do not depend on the order of the additions: the table gradient is bit-reproducible too
+// (the reference's index_select backward, atomicAdd on floats, is not).
 // Per pair the bias costs ~14 VALU + 3 LDS reads against ~1.6 VALU for the rest of the tile: this branch is ~10x slower than
 // the flash branch by construction, and ~K^2-memory-free, which is what makes K = 1024 with RPE runnable at all.
 
@@ -38,15 +40,16 @@ __device__ __forceinline__ float ar_bias(int qx, int qy, int qz, uint2 kc, const
   return tb[ix] + tb[iy] + tb[iz];
 }
 
-static size_t ar_extra_lds(int lp_max, int R) { return (size_t)lp_max * 8 + (size_t)((3 * R + 3) & ~3) * 4 * 2; }
+#define AR_FIX_SCALE 16777216.f            // 2^24: resolution 6e-8, range +-5e11 per table entry
+static size_t ar_extra_lds(int lp_max, int R) { return (size_t)lp_max * 8 + (size_t)((3 * R + 3) & ~3) * 4 * 3; }   // coords | table f32 | d table i64
 
 // stage the coordinates of rows [0, Lp) and the head's table column (scaled by log2 e; second copy zeroed = gradient accumulator)
 __device__ __forceinline__ void ar_stage(const int32_t* __restrict__ gc, int64_t a, int L, int Lp, const float* __restrict__ table,
-                                         int H, int head, int R, uint2* coords, float* tl, float* dtl) {
+                                         int H, int head, int R, uint2* coords, float* tl, unsigned long long* dtl) {
   for (int row = threadIdx.x; row < Lp; row += AR_THREADS) coords[row] = ar_pack(gc, a + row, row < L);
   for (int i = threadIdx.x; i < 3 * R; i += AR_THREADS) {
     tl[i] = table[(int64_t)i * H + head] * AT_LOG2E;
-    if (dtl) dtl[i] = 0.f;
+    if (dtl) dtl[i] = 0ull;
   }
 }
 
@@ -142,7 +145,7 @@ __global__ void __launch_bounds__(AR_THREADS, 2)
 attn_rpe_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                        const float* __restrict__ lse, const int32_t* __restrict__ cu, const int32_t* __restrict__ gc,
                        const float* __restrict__ table, int R, int B, int H, float scale, int64_t total, int lp_max, int n_units,
-                       uint16_t* __restrict__ dqkv, float* __restrict__ delta, float* __restrict__ dtable) {
+                       uint16_t* __restrict__ dqkv, float* __restrict__ delta, unsigned long long* __restrict__ dtable_fix) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int unit = at_unit(n_units);
   if (unit >= n_units) return;
@@ -158,7 +161,7 @@ attn_rpe_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
   unsigned char* Ksm = smem + (size_t)lp_max * 32;
   uint2* coords = reinterpret_cast<uint2*>(smem + (size_t)lp_max * 64);
   float* tl = reinterpret_cast<float*>(coords + lp_max);
-  float* dtl = tl + ((3 * R + 3) & ~3);
+  unsigned long long* dtl = reinterpret_cast<unsigned long long*>(tl + ((3 * R + 3) & ~3));   // 16-byte aligned: lp_max * 72 + 16 k
   const int64_t rs = (int64_t)3 * H * 16;
   stage_row_major(qkv + qkv_off(a, 2, H, head), rs, L, Lp, Vsm);
   stage_row_major(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
@@ -171,7 +174,7 @@ attn_rpe_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
   const TrAddr ta = tr_addr(lane);
   const int rmo = rm_off(col, h2);
   const float* tb = tl + B;
-  float* dtb = dtl + B;
+  unsigned long long* dtb = dtl + B;
   for (int qt = wave; qt < n_tiles; qt += AT_WAVES) {
     const int q = qt * 32 + col;
     const bool qv = q < L;
@@ -205,10 +208,11 @@ attn_rpe_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
         const float b = ar_bias(qx, qy, qz, coords[key], tb, R, B, ix, iy, iz);
         // keys >= L: k = 0 and v = 0 give a finite P; it must not reach the table gradient (dQ is safe: it multiplies K = 0)
         ds[r] = (qv && key < L) ? __builtin_amdgcn_exp2f(s[r] + b) * dp[r] : 0.f;
-        if (ds[r] != 0.f) {
-          atomicAdd(dtb + ix, ds[r]);
-          atomicAdd(dtb + iy, ds[r]);
-          atomicAdd(dtb + iz, ds[r]);
+        const unsigned long long fx = (unsigned long long)__float2ll_rn(ds[r] * AR_FIX_SCALE);   // two's complement: adds of negatives wrap correctly
+        if (fx != 0ull) {
+          atomicAdd(dtb + ix, fx);
+          atomicAdd(dtb + iy, fx);
+          atomicAdd(dtb + iz, fx);
         }
       }
 #pragma unroll
@@ -229,7 +233,12 @@ attn_rpe_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 3 * R; i += AR_THREADS)
-    if (dtl[i] != 0.f) atomicAdd(dtable + (int64_t)i * H + head, dtl[i]);
+    if (dtl[i] != 0ull) atomicAdd(dtable_fix + (int64_t)i * H + head, dtl[i]);
+}
+
+__global__ void attn_rpe_table_finish_kernel(const unsigned long long* __restrict__ fix, int64_t n, float* __restrict__ dtable) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dtable[i] = (float)((double)(long long)fix[i] * (1.0 / (double)AR_FIX_SCALE));
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV

@@ -715,7 +715,7 @@ def attn_rpe_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_scale
     T, _, H, _ = qkv.shape
     dqkv = torch.empty_like(qkv)
     dtab = torch.empty_like(tab)
-    nbytes = lib().ptc_attn_varlen_bwd_workspace_bytes(T, H)
+    nbytes = lib().ptc_attn_rpe_bwd_workspace_bytes(T, H, int(pos_bnd))
     ws = _ws(nbytes, qkv.device)
     check(lib().ptc_attn_rpe_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), ptr(gc), ptr(tab), int(pos_bnd), cu.numel() - 1,
                                  T, H, int(max_seqlen), float(softmax_scale), _lib.PTC_BF16, ptr(dqkv), ptr(dtab), ptr(ws), nbytes,

@@ -907,7 +907,7 @@ def _rpe_reference(qkv, cu, scale, gc, table, bnd):
                                         ([1024, 330], 2, 32)])
 def test_attention_rpe_fwd_bwd(cuda, lens, H, bnd):
     """relative-position-bias attention kernels against the reference formulation (fp32, CPU): output, lse,
-    dqkv and the table gradient.  dqkv is bit-reproducible; the table gradient is summed with float atomics."""
+    dqkv and the table gradient (2^-24 fixed-point integer atomics: bit-reproducible as well)."""
     from pointcept_amd import functional as PF
     from pointcept_amd import ops
 
@@ -931,8 +931,9 @@ def test_attention_rpe_fwd_bwd(cuda, lens, H, bnd):
     dqkv, dtab = ops.attn_rpe_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale, gc.to(cuda), table.to(cuda), bnd)
     _close("rpe_dqkv", dqkv, q32.grad, 1.0 / 32, 1e-2 * float(q32.grad.abs().max()))
     _close("rpe_dtable", dtab, t32.grad, 2e-2, 1e-2 * float(t32.grad.abs().max()))
-    d2, _ = ops.attn_rpe_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale, gc.to(cuda), table.to(cuda), bnd)
+    d2, t2 = ops.attn_rpe_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale, gc.to(cuda), table.to(cuda), bnd)
     assert torch.equal(dqkv, d2), "dqkv is not bit-reproducible"
+    assert torch.equal(dtab, t2), "the fixed-point table gradient is not bit-reproducible"
     # autograd wrapper
     xq, tq = qkv.to(cuda).requires_grad_(True), table.to(cuda).requires_grad_(True)
     o = PF.attn_rpe_qkvpacked(xq, cu.to(cuda), max(lens), scale, gc.to(cuda), tq, bnd)
