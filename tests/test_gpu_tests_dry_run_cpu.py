@@ -11,7 +11,8 @@ import mock_backend
 MODEL_TESTS = ["test_ptv3_tiny_forward_matches_reference_golden_and_oracle", "test_ptv3_two_scenes_forward_backward_vs_oracle",
                "test_ptv3_outdoor_depth12_four_channels", "test_ptv3_mix3d_duplicate_voxels",
                "test_ptv3_dense_rpe_branch_matches_reference_golden_and_oracle", "test_ptv3_enable_flash_false_uses_the_shrunk_patch",
-               "test_ptv3_enc_mode_chain_matches_reference_golden_and_oracle", "test_ptv3m2_matches_reference_golden"]
+               "test_ptv3_enc_mode_chain_matches_reference_golden_and_oracle", "test_ptv3m2_matches_reference_golden",
+               "test_ptv3_pdnorm_ppt_configuration_matches_reference_golden"]
 SPUNET_TESTS = ["test_spunet_tiny_matches_reference_golden_and_oracle", "test_spunet_base_channels_single_scene_and_duplicates",
                 "test_spunet_enc_mode", "test_reference_style_model_file_runs_on_the_engine_through_compat"]
 
