@@ -478,6 +478,13 @@ int ptc_batch_norm_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dt
                            void* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                            ptc_stream_t stream);
 
+/* Backward-pass weight layouts of every layer in one launch (16-bit elements):
+ *   dst[ci][j][co] = src[co][m(j)][ci]; desc [n][6] int64 = { src, dst, c_out, taps_src, c_in, taps_dst | mode << 32 } (device),
+ *   mode 0: m(j) = taps_src - 1 - j (the mirrored-weight dgrad of a submanifold convolution, `functional._SparseConv`; plain
+ *   transpose at taps = 1: nn.Linear), 1: m(j) = 0 (one matrix repeated taps_dst times), 2: m(j) = j;
+ *   prefix [n+1] int64 = first output element of every entry, total = prefix[n]. */
+int ptc_weight_layouts(const int64_t* desc, const int64_t* prefix, int n, int64_t total, ptc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * M. libs/pointops2: the pair-list attention operators of Stratified Transformer (fp32), reference wrappers
  *    libs/pointops2/functions/pointops.py:93-961, kernels libs/pointops2/src/{attention,attention_v2,rpe,rpe_v2}/.

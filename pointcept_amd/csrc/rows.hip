@@ -262,3 +262,43 @@ extern "C" int ptc_segment_csr_bwd(const void* grad_out, const int64_t* perm, co
   });
   return PTC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward-pass weight layouts, all weights of the model in ONE launch.
+// The input-gradient GEMMs read W as [c_in][taps][c_out] (taps mirrored for a submanifold convolution run over its own
+// table, functional._SparseConv; plain transpose for nn.Linear; the same matrix repeated for a kv = 2 gather-fused Linear).
+// Produced per layer these were 118 transposes + 23 index_selects per training step (profiles/r02_r_trace_copies.txt); here every
+// stale layout is refreshed together, right after the multi-tensor weight cast, from a descriptor table the caller keeps on the
+// device:  desc[e] = { src, dst, c_out, taps_src, c_in, taps_dst | mode << 32 },  prefix[e] = first output element of entry e.
+//   dst[ci][j][co] = src[co][m(j)][ci],   mode 0: m(j) = taps_src - 1 - j (mirror; plain transpose when taps = 1)
+//                                          mode 1: m(j) = 0 (replicate)     mode 2: m(j) = j
+// 16-bit elements.  One thread per output element: coalesced stores, strided loads of L2-resident weights.
+__global__ void __launch_bounds__(256)
+weight_layouts_kernel(const int64_t* __restrict__ desc, const int64_t* __restrict__ prefix, int n, int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  int lo = 0, hi = n - 1;                       // largest e with prefix[e] <= t
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= t) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* d = desc + (int64_t)lo * 6;
+  const uint16_t* src = reinterpret_cast<const uint16_t*>(d[0]);
+  uint16_t* dst = reinterpret_cast<uint16_t*>(d[1]);
+  const int64_t co_n = d[2], ks = d[3], ci_n = d[4];
+  const int64_t kd = d[5] & 0xffffffffll;
+  const int mode = (int)(d[5] >> 32);
+  const int64_t o = t - prefix[lo];
+  const int64_t co = o % co_n, j = (o / co_n) % kd, ci = o / (co_n * kd);
+  const int64_t m = mode == 0 ? ks - 1 - j : (mode == 1 ? 0 : j);
+  dst[o] = src[(co * ks + m) * ci_n + ci];
+}
+
+extern "C" int ptc_weight_layouts(const int64_t* desc, const int64_t* prefix, int n, int64_t total, ptc_stream_t stream) {
+  PTC_REQUIRE(n >= 0 && total >= 0, PTC_EINVAL, "ptc_weight_layouts: bad sizes");
+  if (n == 0 || total == 0) return PTC_OK;
+  PTC_REQUIRE(desc && prefix, PTC_EINVAL, "ptc_weight_layouts: null buffer");
+  hipLaunchKernelGGL(weight_layouts_kernel, dim3((unsigned)ptc_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, desc, prefix, n, total);
+  PTC_CHECK_LAUNCH("weight_layouts_kernel");
+  return PTC_OK;
+}

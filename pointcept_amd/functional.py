@@ -41,9 +41,58 @@ class _CastCache:
     def __init__(self, cuda_only: bool = True):
         self.entries = {}   # (data_ptr, numel, dtype) -> [weakref(owner), shadow (flat), version]
         self.cuda_only = cuda_only   # False only in the CPU unit test of this class
+        # backward-pass layouts of the shadows ([c_in][taps][c_out], see layout()): shadow data_ptr -> entry, and
+        # (shadow data_ptr, mode, taps_dst) -> [entry, buffer, shadow generation the buffer was made from, dims]
+        self.by_shadow = {}
+        self.layouts = {}
+        self._desc = None   # (signature, desc tensor, prefix tensor, total)
 
     def invalidate(self) -> None:
         self.entries.clear()
+        self.by_shadow.clear()
+        self.layouts.clear()
+        self._desc = None
+
+    _MODES = {"mirror": 0, "repeat": 1, "keep": 2}
+
+    def layout(self, w: torch.Tensor, mode: str, taps_dst: int = 0) -> Optional[torch.Tensor]:
+        """[c_in, taps', c_out] layout of a weight shadow for the input-gradient GEMMs: w = what get() returned, shape
+        [c_out, c_in] or [c_out, taps, c_in]; mode "mirror" (taps reversed: submanifold dgrad; the plain transpose when
+        taps = 1), "keep" (tap order kept) or "repeat" (taps = 1 matrix repeated taps_dst times).  Persistent buffers; every
+        stale layout of the model is rewritten in ONE launch (ptc_weight_layouts) the first time one is asked for after the
+        shadows were refreshed.  None when w is not a cache shadow (fp32 runs, padded copies): the caller permutes itself."""
+        if _LEGACY_LAUNCHES or not w.is_cuda or w.dim() not in (2, 3) or not w.is_contiguous() or w.element_size() != 2:
+            return None
+        e = self.by_shadow.get(w.data_ptr())
+        if e is None or e[1].numel() != w.numel():
+            return None
+        co, ks, ci = (w.shape[0], 1, w.shape[1]) if w.dim() == 2 else tuple(w.shape)
+        kd = int(taps_dst) if mode == "repeat" else ks
+        if mode == "repeat" and ks != 1:
+            return None
+        key = (w.data_ptr(), mode, kd)
+        lay = self.layouts.get(key)
+        if lay is None:
+            lay = self.layouts[key] = [e, torch.empty(ci * kd * co, dtype=w.dtype, device=w.device), None, (co, ks, ci, kd, self._MODES[mode])]
+            self._desc = None
+        if lay[2] != e[3]:
+            self._refresh_layouts(w.device)
+        return lay[1].view(ci, kd, co)
+
+    def _refresh_layouts(self, device) -> None:
+        live = [(k, v) for k, v in self.layouts.items() if v[0][0]() is not None and v[1].device == device]
+        sig = tuple(k for k, _ in live)
+        if self._desc is None or self._desc[0] != sig:
+            rows, prefix, total = [], [0], 0
+            for _, (e, buf, _, (co, ks, ci, kd, mode)) in live:
+                rows.append([e[1].data_ptr(), buf.data_ptr(), co, ks, ci, kd | (mode << 32)])
+                total += ci * kd * co
+                prefix.append(total)
+            self._desc = (sig, torch.tensor(rows, dtype=torch.int64, device=device), torch.tensor(prefix, dtype=torch.int64, device=device), total)
+        _, desc, prefix, total = self._desc
+        ops.weight_layouts(desc, prefix, len(live), total)
+        for _, v in live:
+            v[2] = v[0][3]
 
     def get(self, w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
         if w.dtype == dt:
@@ -60,13 +109,19 @@ class _CastCache:
         if e is None:
             entries = self.entries
 
-            def _drop(_ref, key=key, entries=entries):
+            def _drop(_ref, key=key, entries=entries, cache=self):
                 cur = entries.get(key)
                 if cur is not None and cur[0] is _ref:
                     del entries[key]
+                    ptr = cur[1].data_ptr()
+                    cache.by_shadow.pop(ptr, None)
+                    for k in [k for k in cache.layouts if k[0] == ptr]:
+                        del cache.layouts[k]
+                    cache._desc = None
 
-            e = [weakref.ref(owner, _drop), torch.empty(w.numel(), dtype=dt, device=w.device), -1]
+            e = [weakref.ref(owner, _drop), torch.empty(w.numel(), dtype=dt, device=w.device), -1, 0]   # ..., generation of the shadow
             self.entries[key] = e
+            self.by_shadow[e[1].data_ptr()] = e
         # one multi-tensor copy refreshes every stale shadow (the first miss after an optimizer step)
         stale, srcs = [], []
         for x in list(self.entries.values()):
@@ -78,6 +133,7 @@ class _CastCache:
             torch._foreach_copy_([x[1] for x in stale], srcs)
         for x, o in zip(stale, srcs):
             x[2] = x[0]()._version
+            x[3] += 1
         return e[1].view(w.shape)
 
 
@@ -336,13 +392,15 @@ class _SparseConv(Function):
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 dbias = ops.column_sum(grad)
         if ctx.needs_input_grad[0]:
-            wt = w.permute(2, 1, 0)
-            if ctx.mirror and _LEGACY_LAUNCHES:
-                wt = wt.flip(1).contiguous()
-            elif ctx.mirror:   # W' = W.permute(ci, k, co).flip(k), contiguous, in ONE launch (flip + contiguous were two)
-                wt = wt.index_select(1, _reverse_index(wt.shape[1], wt.device))
-            else:
-                wt = wt.contiguous()
+            wt = _cast_cache.layout(w, "mirror" if ctx.mirror else "keep")   # all layers' layouts in one launch per step
+            if wt is None:
+                wt = w.permute(2, 1, 0)
+                if ctx.mirror and _LEGACY_LAUNCHES:
+                    wt = wt.flip(1).contiguous()
+                elif ctx.mirror:   # W' = W.permute(ci, k, co).flip(k), contiguous, in ONE launch (flip + contiguous were two)
+                    wt = wt.index_select(1, _reverse_index(wt.shape[1], wt.device))
+                else:
+                    wt = wt.contiguous()
             gm = g if dup_out is None else _merge_duplicate_rows(g, dup_out)
             blk = None if ctx.blocks is None else ctx.blocks.get(gm.shape[1], wt.shape[0], gm.dtype)
             dfeat = ops.spconv_fwd(gm, wt, None, nbr_t, blk)[:, :c_in].to(ctx.in_dtype)
@@ -418,9 +476,12 @@ class _Linear(Function):
                     db = dbp[:c_out].to(ctx.b_dtype)
         if ctx.needs_input_grad[0]:
             if tab_bwd is not None or xp.dtype == torch.float32 or _own_gemm(xp.shape[0], g.shape[1], xp.dtype):
-                wt = wp.t().contiguous()[:, None, :]                       # [c_in, 1, c_out]
-                if tab_bwd is not None and tab_bwd.shape[0] > 1:
-                    wt = wt.expand(-1, tab_bwd.shape[0], -1).contiguous()   # same W for every slot
+                slots = tab_bwd.shape[0] if tab_bwd is not None else 1
+                wt = _cast_cache.layout(wp, "repeat", slots) if slots > 1 else _cast_cache.layout(wp, "mirror")
+                if wt is None:
+                    wt = wp.t().contiguous()[:, None, :]                       # [c_in, 1, c_out]
+                    if slots > 1:
+                        wt = wt.expand(-1, slots, -1).contiguous()              # same W for every slot
                 dx = ops.spconv_fwd(g, wt, None, tab_bwd)
             else:
                 dx = g @ wp
@@ -705,7 +766,8 @@ class _MLP(Function):
                 db2 = ops.column_sum(g) if b2_dt is not None else None
             dw2 = dw2.to(w2_dt)
             db2 = None if db2 is None else db2.to(b2_dt)
-        dh = ops.linear_gelu_bwd_input(g, w2c.t().contiguous(), h)
+        w2t = _cast_cache.layout(w2c, "mirror")
+        dh = ops.linear_gelu_bwd_input(g, w2c.t().contiguous() if w2t is None else w2t[:, 0, :], h)
         # fc1: the same split
         fork1 = _Fork(dh, n)
         with fork1:
@@ -721,7 +783,8 @@ class _MLP(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if _own_gemm(n, dh.shape[1], xp.dtype):
-                dx = ops.spconv_fwd(dh, w1c.t().contiguous()[:, None, :], None, None)
+                w1t = _cast_cache.layout(w1c, "mirror")
+                dx = ops.spconv_fwd(dh, w1c.t().contiguous()[:, None, :] if w1t is None else w1t, None, None)
             else:
                 dx = dh @ w1c
             dx = dx.to(x_dt)

@@ -897,6 +897,12 @@ def linear_gelu_bwd_input(g: torch.Tensor, weight_t: torch.Tensor, h: torch.Tens
     return out
 
 
+def weight_layouts(desc: torch.Tensor, prefix: torch.Tensor, n: int, total: int) -> None:
+    """functional._CastCache: rewrite every backward-pass weight layout described by desc [n,6] / prefix [n+1] (device int64)."""
+    require_cuda(desc, prefix)
+    check(lib().ptc_weight_layouts(ptr(desc), ptr(prefix), int(n), int(total), stream_ptr()), "ptc_weight_layouts")
+
+
 # ------------------------------------------------------------------------------------------------
 # libs/pointops2: pair-list attention operators (csrc/pointops2.hip), fp32
 # ------------------------------------------------------------------------------------------------

@@ -1723,6 +1723,39 @@ def test_ptv1_ptv2_operators_match_their_definitions(cuda):
     assert np.allclose(fus, ref, atol=1e-4)
 
 
+def test_weight_layout_cache_one_launch_refresh(cuda):
+    """functional._CastCache.layout: the [c_in][taps][c_out] layouts the input-gradient GEMMs read (mirrored taps for a
+    submanifold convolution, transpose for nn.Linear, the repeated matrix of the kv = 2 gather-fused Linear) equal the torch
+    permutations they replace, follow the weights through optimizer-style in-place updates, and die with the parameter."""
+    from pointcept_amd import functional as PF
+
+    cache = PF._CastCache()
+    g = torch.Generator().manual_seed(4)
+    conv = torch.nn.Parameter(torch.randn(64, 27, 32, generator=g).to(cuda))
+    lin = torch.nn.Parameter(torch.randn(96, 32, generator=g).to(cuda))
+    down = torch.nn.Parameter(torch.randn(48, 8, 16, generator=g).to(cuda))
+
+    def check():
+        sc, sl, sd = cache.get(conv, torch.bfloat16), cache.get(lin, torch.bfloat16), cache.get(down, torch.bfloat16)
+        assert torch.equal(cache.layout(sc, "mirror"), sc.permute(2, 1, 0).flip(1).contiguous())
+        assert torch.equal(cache.layout(sd, "keep"), sd.permute(2, 1, 0).contiguous())
+        assert torch.equal(cache.layout(sl, "mirror"), sl.t().contiguous()[:, None, :])
+        assert torch.equal(cache.layout(sl, "repeat", 2), sl.t().contiguous()[:, None, :].expand(-1, 2, -1).contiguous())
+        assert cache.layout(sl.float(), "mirror") is None and cache.layout(sc[:, :, :16].contiguous(), "mirror") is None
+        return cache.layout(sl, "mirror").data_ptr()
+
+    p0 = check()
+    with torch.no_grad():
+        for p in (conv, lin, down):
+            p.mul_(1.5).add_(0.25)
+    assert check() == p0                      # same persistent buffers, new contents
+    n = len(cache.layouts)
+    del lin
+    import gc
+    gc.collect()
+    assert len(cache.layouts) == n - 2        # both layouts of the Linear went with it
+
+
 # ------------------------------------------------------------------------------------------------
 # M. libs/pointops2 (Stratified Transformer operators)
 # ------------------------------------------------------------------------------------------------
