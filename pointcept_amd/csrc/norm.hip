@@ -418,9 +418,22 @@ add_norm_partial_reduce_kernel(const float* __restrict__ partial, int blocks, in
   const int cx = threadIdx.x & 31, sy = threadIdx.x >> 5;
   const int t = blockIdx.x * 32 + cx;
   const int which = t / c, ch = t - which * c;
-  float s = 0.f;
-  if (t < 4 * c)
-    for (int b = sy; b < blocks; b += 32) s += partial[((int64_t)b * 4 + which) * c + ch];
+  // four independent accumulators: the loop was one dependent load chain of blocks / 32 steps (11 us per call for 2 MB, 44 calls per
+  // step); the summation order stays fixed
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (t < 4 * c) {
+    const float* p = partial + (int64_t)which * c + ch;
+    const int64_t st = (int64_t)4 * c;
+    int b = sy;
+    for (; b + 96 < blocks; b += 128) {
+      s0 += p[(int64_t)b * st];
+      s1 += p[(int64_t)(b + 32) * st];
+      s2 += p[(int64_t)(b + 64) * st];
+      s3 += p[(int64_t)(b + 96) * st];
+    }
+    for (; b < blocks; b += 32) s0 += p[(int64_t)b * st];
+  }
+  const float s = (s0 + s1) + (s2 + s3);
   red[sy][cx] = s;
   __syncthreads();
   if (sy == 0 && t < 4 * c) {
