@@ -75,21 +75,26 @@ class _CastCache:
         if lay is None:
             lay = self.layouts[key] = [e, torch.empty(ci * kd * co, dtype=w.dtype, device=w.device), None, (co, ks, ci, kd, self._MODES[mode])]
             self._desc = None
-        if lay[2] != e[3]:
+            self._refresh_layouts(w.device, only=key)      # first use: just this one (the table is rebuilt at the next full refresh)
+        elif lay[2] != e[3]:
             self._refresh_layouts(w.device)
         return lay[1].view(ci, kd, co)
 
-    def _refresh_layouts(self, device) -> None:
-        live = [(k, v) for k, v in self.layouts.items() if v[0][0]() is not None and v[1].device == device]
+    def _refresh_layouts(self, device, only=None) -> None:
+        live = [(k, v) for k, v in self.layouts.items() if v[0][0]() is not None and v[1].device == device and (only is None or k == only)]
         sig = tuple(k for k, _ in live)
-        if self._desc is None or self._desc[0] != sig:
+        if only is not None or self._desc is None or self._desc[0] != sig:
             rows, prefix, total = [], [0], 0
             for _, (e, buf, _, (co, ks, ci, kd, mode)) in live:
                 rows.append([e[1].data_ptr(), buf.data_ptr(), co, ks, ci, kd | (mode << 32)])
                 total += ci * kd * co
                 prefix.append(total)
-            self._desc = (sig, torch.tensor(rows, dtype=torch.int64, device=device), torch.tensor(prefix, dtype=torch.int64, device=device), total)
-        _, desc, prefix, total = self._desc
+            built = (sig, torch.tensor(rows, dtype=torch.int64, device=device), torch.tensor(prefix, dtype=torch.int64, device=device), total)
+            if only is None:
+                self._desc = built
+        else:
+            built = self._desc
+        _, desc, prefix, total = built
         ops.weight_layouts(desc, prefix, len(live), total)
         for _, v in live:
             v[2] = v[0][3]
