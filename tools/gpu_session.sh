@@ -58,6 +58,21 @@ for sec in "$@"; do
             rm -rf $O/${TAG}_ck_${cs}_stats $O/${TAG}_ck_${cs}_fetch $O/${TAG}_ck_${cs}_write $O/${TAG}_ck_${cs}_tcc $O/${TAG}_ck_${cs}_tcp $O/${TAG}_ck_${cs}_sq $O/${TAG}_ck_${cs}_sq2
             cd /tmp
           done; unset PTC_CK_CASE; tail -3 $O/${TAG}_ck_s1_tcp.log;;
+    linpmc) cd /tmp
+          for sh in 32,128 64,128 64,256; do
+            export PTC_LK_SHAPE=$sh; tg=${TAG}_lk_${sh/,/_}
+            timeout 300 rocprofv3 --kernel-trace --stats -d $O/${tg}_stats -- python $R/tools/linear_kernels.py > $O/${tg}_stats.log 2>&1
+            timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/${tg}_fetch -- python $R/tools/linear_kernels.py > $O/${tg}_fetch.log 2>&1
+            timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/${tg}_write -- python $R/tools/linear_kernels.py > $O/${tg}_write.log 2>&1
+            timeout 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr -d $O/${tg}_tcp -- python $R/tools/linear_kernels.py > $O/${tg}_tcp.log 2>&1
+            timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/${tg}_tcc -- python $R/tools/linear_kernels.py > $O/${tg}_tcc.log 2>&1
+            timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE -d $O/${tg}_sq -- python $R/tools/linear_kernels.py > $O/${tg}_sq.log 2>&1
+            timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS -d $O/${tg}_sq2 -- python $R/tools/linear_kernels.py > $O/${tg}_sq2.log 2>&1
+            cd $R; python tools/pmc_summary.py --stats $O/${tg}_stats --pmc $O/${tg}_fetch $O/${tg}_write $O/${tg}_tcp $O/${tg}_tcc $O/${tg}_sq $O/${tg}_sq2 \
+              --kernels linear2_kernel --out $O/${TAG}_linear_pmc_${sh/,/_}.json > $O/${tg}_pmc.log 2>&1
+            rm -rf $O/${tg}_stats $O/${tg}_fetch $O/${tg}_write $O/${tg}_tcp $O/${tg}_tcc $O/${tg}_sq $O/${tg}_sq2
+            cd /tmp
+          done; unset PTC_LK_SHAPE; ls $O | grep linear_pmc;;
     *) echo "unknown section $sec";;
   esac
 done
