@@ -122,16 +122,19 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   // !BNC: the MFMA operand itself (lane l: row l & 15, piece l >> 4)
   frag ga[4][RT];
   bool anyv[4][RT];                  // wave-level "any neighbour at this step"
-  int32_t idxN[KPC][RT], idxNN[KPC][RT];
+  // KPC = 16 is the c_in = 8 form (the 6 -> 32 stems, padded to 8): a 32-slot MFMA step spans FOUR table rows, one per lane
+  // group, so a lane keeps the entries of ITS table row of each step: ix[s][j] = entry of table row 16 c + 4 s + g
+  constexpr int KI = KPC == 16 ? 4 : KPC;
+  int32_t idxN[KI][RT], idxNN[KI][RT];
   const int lrow = BNC ? (lane >> 2) : r;       // tile row whose table entry this lane needs
   const int lpiece = BNC ? (lane & 3) : g;      // 16-byte piece of the 64-byte step this lane loads
-  auto load_idx = [&](int c, int32_t (&ix)[KPC][RT]) {
+  auto load_idx = [&](int c, int32_t (&ix)[KI][RT]) {
     // GEN = false: c_in divides 128 or is a multiple of it, a chunk holds exactly KPC whole table rows
     // (or a slice of one); GEN = true (c_in = 96, 160, 192, ...): rows straddle chunks, everything by division
     const int kfirst = (GEN || KPC == 1) ? (c * 128) / c_in : c * KPC;
 #pragma unroll
-    for (int kk = 0; kk < KPC; ++kk) {
-      const int k = kfirst + kk;
+    for (int kk = 0; kk < KI; ++kk) {
+      const int k = KPC == 16 ? kfirst + 4 * kk + lpiece : kfirst + kk;
 #pragma unroll
       for (int j = 0; j < RT; ++j) {
         const int64_t row = row0 + j * 16 + lrow;
@@ -141,10 +144,13 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       }
     }
   };
-  auto issue = [&](int c, int s, const int32_t (&ix)[KPC][RT]) {
+  auto issue = [&](int c, int s, const int32_t (&ix)[KI][RT]) {
     const int v0 = c * 128 + s * 32;                 // flattened contraction index of this step
     int kk, cbase;
-    if constexpr (GEN) {
+    if constexpr (KPC == 16) {
+      kk = s;                                        // this lane's table row of the step; its 8 channels are the whole input row
+      cbase = 0;
+    } else if constexpr (GEN) {
       const int k = v0 / c_in;
       kk = k - (c * 128) / c_in;
       cbase = v0 - k * c_in + lpiece * 8;
@@ -225,7 +231,7 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       __syncthreads();
       wload(c + 2);
 #pragma unroll
-      for (int kk = 0; kk < KPC; ++kk)
+      for (int kk = 0; kk < KI; ++kk)
 #pragma unroll
         for (int j = 0; j < RT; ++j) idxN[kk][j] = idxNN[kk][j];
     }
@@ -264,7 +270,7 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       __syncthreads();
       wload(c + 2);
 #pragma unroll
-      for (int kk = 0; kk < KPC; ++kk)
+      for (int kk = 0; kk < KI; ++kk)
 #pragma unroll
         for (int j = 0; j < RT; ++j) idxN[kk][j] = idxNN[kk][j];
     }
@@ -279,6 +285,9 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 
 static inline bool conv3_supported(int dtype, int kv, int c_in, int c_out, const int32_t* nbr) {
   if (dtype == PTC_F32 || nbr == nullptr || kv < 2) return false;
+  // c_in = 8: the stems (6 input channels padded to 8, k = 5): four table rows per MFMA step instead of one table row per
+  // half-empty step in conv2 (685 -> see profiles/r02_am_stem.txt)
+  if (c_in == 8) return c_out % 32 == 0 && getenv("PTC_CONV3_C8_OFF") == nullptr;
   if (c_out % 32 != 0 || c_in % 32 != 0) return false;
   // 32 -> 32 convolutions (PTv3 stage 0, SpUNet level 0) stay on conv2: with 2 MFMAs per gathered fragment the
   // chunk pipeline has nothing to amortise and measured slower (1.17 vs 0.91 ms per step, r01_z)
@@ -335,8 +344,8 @@ static int launch_conv3(const void* in, int64_t n_in, const void* w, const float
     if (atoi(e) == 2) big = false;
   }
   // table rows one 128-wide chunk can touch: 1 (c_in % 128 == 0), 4 (c_in = 32), else 2
-  const int kpc = c_in % 128 == 0 ? 1 : (c_in == 32 ? 4 : 2);
-  const bool gen = !(c_in == 32 || c_in == 64 || c_in % 128 == 0);   // table rows straddle chunks (kpc == 2)
+  const int kpc = c_in == 8 ? 16 : (c_in % 128 == 0 ? 1 : (c_in == 32 ? 4 : 2));
+  const bool gen = !(c_in == 8 || c_in == 32 || c_in == 64 || c_in % 128 == 0);   // table rows straddle chunks (kpc == 2)
 #define C3_CASE(K, N, G)                                                                                                   \
   if (kpc == K && nt == N && gen == G)                                                                                     \
     return big ? launch_conv3_i<T, 4, K, N, G>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s)                           \
@@ -344,6 +353,7 @@ static int launch_conv3(const void* in, int64_t n_in, const void* w, const float
   C3_CASE(1, 4, false) C3_CASE(2, 4, false) C3_CASE(4, 4, false) C3_CASE(2, 4, true)
   C3_CASE(1, 2, false) C3_CASE(2, 2, false) C3_CASE(2, 2, true) C3_CASE(4, 2, false)
   C3_CASE(1, 6, false) C3_CASE(2, 6, false) C3_CASE(4, 6, false) C3_CASE(2, 6, true)
+  C3_CASE(16, 2, false) C3_CASE(16, 4, false) C3_CASE(16, 6, false)
 #undef C3_CASE
   ptc_set_error("conv3: c_in=%d c_out=%d unsupported", c_in, c_out);
   return PTC_EUNSUPPORTED;

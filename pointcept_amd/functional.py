@@ -367,8 +367,11 @@ class _SparseConv(Function):
     def forward(ctx, feat, weight, bias, nbr, nbr_t, mirror, dup_out, dup_in, blocks):
         dt = _autocast_dtype(feat)
         c_out, kv, c_in = weight.shape
-        f = _pad_to(feat.to(dt), 1, 16).contiguous()
-        w = _pad_to(_pad_to(_cast_cache.get(weight, dt), 2, 16), 0, 16).contiguous()
+        # channels are padded to 16; a stem (c_in <= 8: 6 colour + normal channels, k = 5) only to 8: its gathered rows are then 16
+        # bytes and conv3 packs four table rows into one MFMA step (csrc/conv3.h, KPC = 16)
+        cpad = 8 if (c_in <= 8 and kv > 1 and dt != torch.float32) else 16
+        f = _pad_to(feat.to(dt), 1, cpad).contiguous()
+        w = _pad_to(_pad_to(_cast_cache.get(weight, dt), 2, cpad), 0, 16).contiguous()
         b = None if bias is None else _pad_to(bias.float(), 0, 16)
         # (padding the 6 -> 16 channel stem further to 32 so that conv3 takes it was measured SLOWER than conv2:
         #  1.20 ms vs 0.74 ms for the 125-offset table, r01_u)
