@@ -153,6 +153,14 @@ def attention_roofline(device, scenes: int, points: int):
             out["traffic"] = round(k["hbm_bytes"])
             out["traffic_source"] = os.path.relpath(pm, ROOT)
             out["mfma_busy_frac"] = round(k["SQ_VALU_MFMA_BUSY_CYCLES_mean"] * 32 / (k["GRBM_GUI_ACTIVE_mean"] * 1024), 3)
+            # what actually bounds the kernel, from the same committed PMC passes: instruction issue and the vector
+            # pipe, at the shader clock the part sustains under this kernel (GRBM_GUI_ACTIVE cycles per microsecond)
+            g = k["GRBM_GUI_ACTIVE_mean"]
+            out["valu_busy_frac"] = round(k["SQ_ACTIVE_INST_VALU_mean"] * 4 / (g * 32), 3)
+            out["inst_issue_busy_frac"] = round(k["SQ_ACTIVE_INST_ANY_mean"] * 4 / (g * 32), 3)
+            out["shader_clock_ghz_under_kernel"] = round(g / k["avg_us"] / 1e3, 2)
+            out["bound_note"] = ("head_dim 16: one v_exp per 64 MFMA flops; the kernel is instruction-issue / VALU bound (see *_busy_frac), "
+                                 "the MFMA peak is the nominal roof SURVEY 8(d) asks for")
     except Exception:
         pass
     return out
