@@ -19,8 +19,6 @@
 
 #define AR_THREADS AT_THREADS
 
-struct ArGeom { int R, B; };
-
 // packed coordinates of a row: .x = x | y << 16, .y = z   (grid coordinates are < 2^16: serialization depth <= 16, structure.py:77)
 __device__ __forceinline__ uint2 ar_pack(const int32_t* __restrict__ gc, int64_t row, bool valid) {
   uint2 c = {0u, 0u};
