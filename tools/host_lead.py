@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""How far does the host run ahead of the GPU in the bench step?  Enqueue time (step() returns, no sync) vs completed time per step:
+if the two are close the step is host-bound and 8 ranks sharing one host will scale worse than the GPU work suggests."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+args = bench.parse() if hasattr(bench, "parse") else None
+sys.argv = [sys.argv[0]]
+args = bench.parse()
+dev = torch.device("cuda:0")
+torch.manual_seed(1234)
+model, opt, batch, loss_of = bench.build_ptv3(args, dev, 0)
+step = bench.make_step(model, opt, batch, args.amp, loss_of, dev)
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+enq, tot = [], []
+for _ in range(8):
+    t0 = time.perf_counter()
+    step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    enq.append((t1 - t0) * 1e3)
+    tot.append((t2 - t0) * 1e3)
+print(f"host enqueue per step: mean {sum(enq) / len(enq):.1f} ms (min {min(enq):.1f}); step complete: mean {sum(tot) / len(tot):.1f} ms; "
+      f"host lead {sum(tot) / len(tot) - sum(enq) / len(enq):.1f} ms; host syncs inside the step make enqueue >= the GPU time up to the last sync")
