@@ -180,7 +180,7 @@ __device__ __forceinline__ void f2_epilogue_ex(f32x4 (&acc)[2][NTILES], T* __res
   }
 }
 
-// Row-contiguous stores through a wave-private LDS slice (EPI 0 and the two outputs of EPI 1).  In the MFMA accumulator layout the four lanes that hold one output
+// Row-contiguous stores through a wave-private LDS slice (every epilogue; EPI 2 also fetches its h rows that way).  In the MFMA accumulator layout the four lanes that hold one output
 // row are 16 lanes apart; the texture-address unit charges such a store like a scattered one (tools/probe_gather.hip: 57 cycles
 // per KB against 15-19 when adjacent lanes share a line) and rocprofv3 shows linear2 with TA_BUSY 58-66 % at N = 819200, the
 // epilogue stores being 60-75 % of its vector-memory instructions (profiles/r02_aj_linear_pmc_*.json).  Here each 16-row half of
@@ -189,32 +189,63 @@ __device__ __forceinline__ void f2_epilogue_ex(f32x4 (&acc)[2][NTILES], T* __res
 #define F2_OUT_ROWS 16
 template <typename T, int NTILES, int EPI>
 __device__ __forceinline__ void f2_store_rows_lds(f32x4 (&acc)[2][NTILES], unsigned char* slice, T* __restrict__ out,
-                                                  T* __restrict__ aux_out, int64_t row0, int64_t n_out, int c_out, int n0, int r, int g,
-                                                  int lane) {
+                                                  const T* __restrict__ aux_in, T* __restrict__ aux_out, int64_t row0, int64_t n_out,
+                                                  int c_out, int n0, int r, int g, int lane) {
   static_assert(sizeof(T) == 2, "16-bit features only");
-  static_assert(EPI == 0 || EPI == 1, "plain store or fc1 (h, GELU(h)) store");
   constexpr int NT = NTILES * 16, RB = NT * 2, P = RB + 16, PIECES = RB / 16;
+  auto wsync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
 #pragma unroll
-  for (int pass = 0; pass <= EPI; ++pass) {          // EPI 1: pass 0 writes h, pass 1 writes GELU(h) (f2_epilogue_ex semantics)
+  for (int pass = 0; pass <= (EPI == 1 ? 1 : 0); ++pass) {   // EPI 1: pass 0 writes h, pass 1 writes GELU(h) (f2_epilogue_ex semantics)
     T* dstbase = pass ? aux_out : out;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      if constexpr (EPI == 2) {
+        // h = aux_in rows of this half, fetched row-contiguously (whole lines) and handed to the lanes in accumulator layout
+        // through the same slice
+#pragma unroll
+        for (int it = 0; it < (F2_OUT_ROWS * PIECES + 63) / 64; ++it) {
+          const int q = it * 64 + lane, row = q / PIECES, piece = q - row * PIECES;
+          const int64_t grow = row0 + s * 16 + row;
+          if (row < F2_OUT_ROWS) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (grow < n_out) v = *reinterpret_cast<const uint4*>(aux_in + grow * c_out + n0 + piece * 8);
+            *reinterpret_cast<uint4*>(slice + row * P + piece * 16) = v;
+          }
+        }
+        wsync();
+      }
 #pragma unroll
       for (int t = 0; t < NTILES; ++t) {
         const int gs = TileGroups<NTILES>::gstart(t), G = TileGroups<NTILES>::gsize(t);
         if (t != gs) continue;
+        unsigned char* dst = slice + r * P + (16 * gs + 4 * G * g) * 2;
+        T hv[16];
+        if constexpr (EPI == 2) {
+          if (G == 4) { *reinterpret_cast<uint4*>(hv) = reinterpret_cast<const uint4*>(dst)[0]; *reinterpret_cast<uint4*>(hv + 8) = reinterpret_cast<const uint4*>(dst)[1]; }
+          else if (G == 2) { *reinterpret_cast<uint4*>(hv) = reinterpret_cast<const uint4*>(dst)[0]; }
+          else { *reinterpret_cast<uint2*>(hv) = reinterpret_cast<const uint2*>(dst)[0]; }
+        }
         uint32_t pk[8];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           f32x4 v = acc[s][(gs + tt) < NTILES ? (gs + tt) : t];
-          if (pass) {
+          if (EPI == 1 && pass) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = f2_gelu(ptc_to_float(ptc_from_float<T>(v[e])));   // the activation sees h as stored
+          }
+          if constexpr (EPI == 2) {
+            if (tt < G) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= f2_gelu_grad(ptc_to_float(hv[4 * tt + e]));
+            }
           }
           pk[2 * tt] = sc_pack2<T>(v[0], v[1]);
           pk[2 * tt + 1] = sc_pack2<T>(v[2], v[3]);
         }
-        unsigned char* dst = slice + r * P + (16 * gs + 4 * G * g) * 2;
         if (G == 4) {
           reinterpret_cast<uint4*>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
           reinterpret_cast<uint4*>(dst)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
@@ -224,9 +255,7 @@ __device__ __forceinline__ void f2_store_rows_lds(f32x4 (&acc)[2][NTILES], unsig
           reinterpret_cast<uint2*>(dst)[0] = make_uint2(pk[0], pk[1]);
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wsync();
 #pragma unroll
       for (int it = 0; it < (F2_OUT_ROWS * PIECES + 63) / 64; ++it) {
         const int q = it * 64 + lane, row = q / PIECES, piece = q - row * PIECES;
@@ -236,9 +265,7 @@ __device__ __forceinline__ void f2_store_rows_lds(f32x4 (&acc)[2][NTILES], unsig
           *reinterpret_cast<uint4*>(dstbase + grow * c_out + n0 + piece * 8) = v;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();      // the slice is rewritten by the next half / pass / tile
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wsync();      // the slice is rewritten by the next half / pass / tile
     }
   }
 }
@@ -260,7 +287,7 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
   const int pitch = c_in + 8;
   T* wl = reinterpret_cast<T*>(smem);  // [nh][NT][pitch]
   float* bl = reinterpret_cast<float*>(smem + (((size_t)nh * NT * pitch * 2 + 15) & ~(size_t)15));   // [nh][NT] bias
-  unsigned char* oslice = reinterpret_cast<unsigned char*>(bl + nh * NT) + (threadIdx.x >> 6) * f2_out_slice_bytes(NT);   // EPI 0 only
+  unsigned char* oslice = reinterpret_cast<unsigned char*>(bl + nh * NT) + (threadIdx.x >> 6) * f2_out_slice_bytes(NT);   // when lds_store
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.y * NT * nh;
@@ -327,11 +354,9 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
           acc[1][t] = M::mma(fw, cb[s], acc[1][t]);
         }
       }
-      if constexpr (EPI == 0 || EPI == 1) {
-        if (lds_store) f2_store_rows_lds<T, NTILES, EPI>(acc, oslice, out, aux_out, tile * F2_ROWS + wave * 32, n_out, c_out, n0 + h * NT, r, g, lane);
-        else if constexpr (EPI == 0) sc_epilogue<T, NTILES>(acc, nullptr, out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);
-        else f2_epilogue_ex<T, NTILES, EPI>(acc, out, aux_in, aux_out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);
-      } else f2_epilogue_ex<T, NTILES, EPI>(acc, out, aux_in, aux_out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);
+      if (lds_store) f2_store_rows_lds<T, NTILES, EPI>(acc, oslice, out, aux_in, aux_out, tile * F2_ROWS + wave * 32, n_out, c_out, n0 + h * NT, r, g, lane);
+      else if constexpr (EPI == 0) sc_epilogue<T, NTILES>(acc, nullptr, out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);
+      else f2_epilogue_ex<T, NTILES, EPI>(acc, out, aux_in, aux_out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) { ca[s] = pa[s]; cb[s] = pb[s]; }
@@ -379,6 +404,8 @@ static int launch_fwd2(const void* in, int64_t n_in, const void* w, const float*
     // row-contiguous stores through LDS (f2_store_rows_lds): where the extra 4 slices do not cost a workgroup per CU.  Measured
     // at N = 819200 (profiles/r02_ak_linear_probe.txt): 32->256 118 -> 99 us, 64->128 70 -> 61, 64->256 121 -> 107; at 128 / 256
     // input channels W alone takes 35-68 KB and the lost workgroup costs more than the stores gain (128->128 89 -> 96 us).
+    // EPI 2 (GELU' dgrad) has the LDS form too (h fetched row-contiguously through the slice) but measured neutral to slightly
+    // slower on the whole step (r02_ar: 150.0 vs 151.2 scenes/s): three LDS phases per half; it stays on the direct epilogue
     bool lds_store = (epi == 0 || epi == 1) && c_in <= 64;
     if (const char* e = getenv("PTC_LINEAR2_LDS_STORE")) { if (atoi(e) == 0) lds_store = false; }   // A/B switch
     const size_t slices = lds_store ? 4 * f2_out_slice_bytes(NT) : 0;
