@@ -444,3 +444,40 @@ def test_ptv3m2_module_port_matches_the_reference_file(layer_scale):
     assert feats[0].shape == feats[1].shape == (960, 64)
     assert _rel(feats[1], feats[0]) < 1e-3
     _grad_check(eng, ref, 3e-2)
+
+
+def test_cast_twin_registry_identity_version_and_lifetime():
+    """functional.register_cast_twin / cast_twin: the bf16 copy a residual joint wrote is handed out only for THE tensor it was
+    registered for, only while that tensor is unmodified, only in the registered dtype / shape -- and the entry dies with it."""
+    import gc
+
+    from pointcept_amd import functional as PF
+
+    x = torch.randn(10, 4)
+    tw = x.to(torch.bfloat16)
+    PF.register_cast_twin(x, tw)
+    assert PF.cast_twin(x, torch.bfloat16) is tw
+    assert PF.cast_twin(x, torch.float16) is None                      # another dtype
+    assert PF.cast_twin(x.clone(), torch.bfloat16) is None              # equal values, different tensor
+    assert PF.cast_twin(x[:5], torch.bfloat16) is None                  # a view is a different tensor object
+    x.add_(1.0)                                                          # in-place write moves the version counter
+    assert PF.cast_twin(x, torch.bfloat16) is None
+    y = torch.randn(3, 2)
+    PF.register_cast_twin(y, y.to(torch.bfloat16))
+    n = len(PF._act_twins)
+    del y
+    gc.collect()
+    assert len(PF._act_twins) == n - 1
+
+
+def test_pointops2_offsets_to_pair_index():
+    """pointops2_api._index_from_offsets: CSR offsets of the pairs by query -> query index of every pair (the inverse of the
+    `index_0_offsets` the Stratified Transformer files build from a sorted `index_0`), empty segments included."""
+    from oracle import pointops2 as orc
+    from pointcept_amd import pointops2_api as p2
+
+    i0 = torch.tensor([0, 0, 0, 2, 2, 5, 5, 5, 5], dtype=torch.int64)
+    off = orc.offsets_of(i0, 7)
+    assert off.tolist() == [0, 3, 3, 5, 5, 5, 9, 9]
+    assert torch.equal(p2._index_from_offsets(off, i0.numel()).long(), i0)
+
