@@ -180,101 +180,67 @@ __device__ __forceinline__ void f2_epilogue_ex(f32x4 (&acc)[2][NTILES], T* __res
   }
 }
 
-// Row-contiguous stores through a wave-private LDS slice (every epilogue; EPI 2 also fetches its h rows that way).  In the MFMA accumulator layout the four lanes that hold one output
-// row are 16 lanes apart; the texture-address unit charges such a store like a scattered one (tools/probe_gather.hip: 57 cycles
-// per KB against 15-19 when adjacent lanes share a line) and rocprofv3 shows linear2 with TA_BUSY 58-66 % at N = 819200, the
-// epilogue stores being 60-75 % of its vector-memory instructions (profiles/r02_aj_linear_pmc_*.json).  Here each 16-row half of
-// a wave's tile is written to LDS as [row][channel] (pitch + 16 B: the 16 rows of a ds_write_b128 pass land on distinct banks) and read
-// back 16 B per lane in row-major order, so that every global store instruction writes whole, consecutive 128-byte lines.
+// Row-contiguous stores through a wave-private LDS slice (plain epilogue, c_in <= 64 only).  In the MFMA accumulator layout the four lanes that
+// hold one output row are 16 lanes apart; the texture-address unit charges such a store like a scattered one (tools/probe_gather.hip:
+// 57 cycles per KB against 15-19 when adjacent lanes share a line) and rocprofv3 shows linear2 with TA_BUSY 58-66 % at N = 819200, the
+// epilogue stores being 60-75 % of its vector-memory instructions (profiles/r02_aj_linear_pmc_*.json).  Each 16-row half of a wave's
+// tile is written to LDS as [row][channel] (pitch + 16 B: the 16 rows of a ds_write_b128 pass land on distinct banks) and read back 16 B
+// per lane in row-major order, so that every global store instruction writes whole, consecutive 128-byte lines: 32->256 118 -> 99 us,
+// 64->128 70 -> 61, 64->256 121 -> 107 (profiles/r02_ak_linear_probe.txt).  A COMPILE-TIME variant (LDSS): carrying it as a run-time
+// branch inside every instance cost the GELU epilogues and the 128 / 256-channel instances 10-60 % (registers; kernel stats of r02_at
+// against r02_ag), and the LDS forms of the two GELU epilogues themselves measured slower -- they keep the direct epilogue.
 #define F2_OUT_ROWS 16
-template <typename T, int NTILES, int EPI>
-__device__ __forceinline__ void f2_store_rows_lds(f32x4 (&acc)[2][NTILES], unsigned char* slice, T* __restrict__ out,
-                                                  const T* __restrict__ aux_in, T* __restrict__ aux_out, int64_t row0, int64_t n_out,
-                                                  int c_out, int n0, int r, int g, int lane) {
+template <typename T, int NTILES>
+__device__ __forceinline__ void f2_store_rows_lds(f32x4 (&acc)[2][NTILES], unsigned char* slice, T* __restrict__ out, int64_t row0,
+                                                  int64_t n_out, int c_out, int n0, int r, int g, int lane) {
   static_assert(sizeof(T) == 2, "16-bit features only");
   constexpr int NT = NTILES * 16, RB = NT * 2, P = RB + 16, PIECES = RB / 16;
-  auto wsync = [] {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) {
+      const int gs = TileGroups<NTILES>::gstart(t), G = TileGroups<NTILES>::gsize(t);
+      if (t != gs) continue;
+      uint32_t pk[8];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const f32x4 v = acc[s][(gs + tt) < NTILES ? (gs + tt) : t];
+        pk[2 * tt] = sc_pack2<T>(v[0], v[1]);
+        pk[2 * tt + 1] = sc_pack2<T>(v[2], v[3]);
+      }
+      unsigned char* dst = slice + r * P + (16 * gs + 4 * G * g) * 2;
+      if (G == 4) {
+        reinterpret_cast<uint4*>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        reinterpret_cast<uint4*>(dst)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+      } else if (G == 2) {
+        reinterpret_cast<uint4*>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      } else {
+        reinterpret_cast<uint2*>(dst)[0] = make_uint2(pk[0], pk[1]);
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
 #pragma unroll
-  for (int pass = 0; pass <= (EPI == 1 ? 1 : 0); ++pass) {   // EPI 1: pass 0 writes h, pass 1 writes GELU(h) (f2_epilogue_ex semantics)
-    T* dstbase = pass ? aux_out : out;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if constexpr (EPI == 2) {
-        // h = aux_in rows of this half, fetched row-contiguously (whole lines) and handed to the lanes in accumulator layout
-        // through the same slice
-#pragma unroll
-        for (int it = 0; it < (F2_OUT_ROWS * PIECES + 63) / 64; ++it) {
-          const int q = it * 64 + lane, row = q / PIECES, piece = q - row * PIECES;
-          const int64_t grow = row0 + s * 16 + row;
-          if (row < F2_OUT_ROWS) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (grow < n_out) v = *reinterpret_cast<const uint4*>(aux_in + grow * c_out + n0 + piece * 8);
-            *reinterpret_cast<uint4*>(slice + row * P + piece * 16) = v;
-          }
-        }
-        wsync();
+    for (int it = 0; it < (F2_OUT_ROWS * PIECES + 63) / 64; ++it) {
+      const int q = it * 64 + lane, row = q / PIECES, piece = q - row * PIECES;
+      const int64_t grow = row0 + s * 16 + row;
+      if (row < F2_OUT_ROWS && grow < n_out) {
+        const uint4 v = *reinterpret_cast<const uint4*>(slice + row * P + piece * 16);
+        *reinterpret_cast<uint4*>(out + grow * c_out + n0 + piece * 8) = v;
       }
-#pragma unroll
-      for (int t = 0; t < NTILES; ++t) {
-        const int gs = TileGroups<NTILES>::gstart(t), G = TileGroups<NTILES>::gsize(t);
-        if (t != gs) continue;
-        unsigned char* dst = slice + r * P + (16 * gs + 4 * G * g) * 2;
-        T hv[16];
-        if constexpr (EPI == 2) {
-          if (G == 4) { *reinterpret_cast<uint4*>(hv) = reinterpret_cast<const uint4*>(dst)[0]; *reinterpret_cast<uint4*>(hv + 8) = reinterpret_cast<const uint4*>(dst)[1]; }
-          else if (G == 2) { *reinterpret_cast<uint4*>(hv) = reinterpret_cast<const uint4*>(dst)[0]; }
-          else { *reinterpret_cast<uint2*>(hv) = reinterpret_cast<const uint2*>(dst)[0]; }
-        }
-        uint32_t pk[8];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          f32x4 v = acc[s][(gs + tt) < NTILES ? (gs + tt) : t];
-          if (EPI == 1 && pass) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = f2_gelu(ptc_to_float(ptc_from_float<T>(v[e])));   // the activation sees h as stored
-          }
-          if constexpr (EPI == 2) {
-            if (tt < G) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] *= f2_gelu_grad(ptc_to_float(hv[4 * tt + e]));
-            }
-          }
-          pk[2 * tt] = sc_pack2<T>(v[0], v[1]);
-          pk[2 * tt + 1] = sc_pack2<T>(v[2], v[3]);
-        }
-        if (G == 4) {
-          reinterpret_cast<uint4*>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-          reinterpret_cast<uint4*>(dst)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-        } else if (G == 2) {
-          reinterpret_cast<uint4*>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        } else {
-          reinterpret_cast<uint2*>(dst)[0] = make_uint2(pk[0], pk[1]);
-        }
-      }
-      wsync();
-#pragma unroll
-      for (int it = 0; it < (F2_OUT_ROWS * PIECES + 63) / 64; ++it) {
-        const int q = it * 64 + lane, row = q / PIECES, piece = q - row * PIECES;
-        const int64_t grow = row0 + s * 16 + row;
-        if (row < F2_OUT_ROWS && grow < n_out) {
-          const uint4 v = *reinterpret_cast<const uint4*>(slice + row * P + piece * 16);
-          *reinterpret_cast<uint4*>(dstbase + grow * c_out + n0 + piece * 8) = v;
-        }
-      }
-      wsync();      // the slice is rewritten by the next half / pass / tile
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();      // the slice is rewritten by the next half / tile
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 __host__ __device__ static inline size_t f2_out_slice_bytes(int nt) { return (size_t)F2_OUT_ROWS * (nt * 2 + 16); }
 
-template <typename T, int NTILES, int S, int EPI = 0>
+template <typename T, int NTILES, int S, int EPI = 0, bool LDSS = false>
 __global__ void __launch_bounds__(256)
 linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-               const int32_t* __restrict__ nbr, int64_t n_out, int c_in, int c_out, int nh, int lds_store, T* __restrict__ out,
+               const int32_t* __restrict__ nbr, int64_t n_out, int c_in, int c_out, int nh, T* __restrict__ out,
                const T* __restrict__ aux_in, T* __restrict__ aux_out, uint32_t in_bytes) {
   // A workgroup owns `nh` column blocks of NT channels (W of all of them in LDS) and walks them per row tile with the
   // row fragments held in registers: the input is read ONCE.  (One column block per workgroup and gridDim.y = 2 read
@@ -287,7 +253,7 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
   const int pitch = c_in + 8;
   T* wl = reinterpret_cast<T*>(smem);  // [nh][NT][pitch]
   float* bl = reinterpret_cast<float*>(smem + (((size_t)nh * NT * pitch * 2 + 15) & ~(size_t)15));   // [nh][NT] bias
-  unsigned char* oslice = reinterpret_cast<unsigned char*>(bl + nh * NT) + (threadIdx.x >> 6) * f2_out_slice_bytes(NT);   // when lds_store
+  [[maybe_unused]] unsigned char* oslice = reinterpret_cast<unsigned char*>(bl + nh * NT) + (threadIdx.x >> 6) * f2_out_slice_bytes(NT);   // LDSS only
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.y * NT * nh;
@@ -354,7 +320,7 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
           acc[1][t] = M::mma(fw, cb[s], acc[1][t]);
         }
       }
-      if (lds_store) f2_store_rows_lds<T, NTILES, EPI>(acc, oslice, out, aux_in, aux_out, tile * F2_ROWS + wave * 32, n_out, c_out, n0 + h * NT, r, g, lane);
+      if constexpr (LDSS) f2_store_rows_lds<T, NTILES>(acc, oslice, out, tile * F2_ROWS + wave * 32, n_out, c_out, n0 + h * NT, r, g, lane);
       else if constexpr (EPI == 0) sc_epilogue<T, NTILES>(acc, nullptr, out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);
       else f2_epilogue_ex<T, NTILES, EPI>(acc, out, aux_in, aux_out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);
     }
@@ -401,12 +367,7 @@ static int launch_fwd2(const void* in, int64_t n_in, const void* w, const float*
   if (kv == 1) {
     // column blocks per workgroup: as many as keep W within 64 KB of LDS (two workgroups per CU), see linear2_kernel
     const int nblk = c_out / NT;
-    // row-contiguous stores through LDS (f2_store_rows_lds): where the extra 4 slices do not cost a workgroup per CU.  Measured
-    // at N = 819200 (profiles/r02_ak_linear_probe.txt): 32->256 118 -> 99 us, 64->128 70 -> 61, 64->256 121 -> 107; at 128 / 256
-    // input channels W alone takes 35-68 KB and the lost workgroup costs more than the stores gain (128->128 89 -> 96 us).
-    // EPI 2 (GELU' dgrad) has the LDS form too (h fetched row-contiguously through the slice) but measured neutral to slightly
-    // slower on the whole step (r02_ar: 150.0 vs 151.2 scenes/s): three LDS phases per half; it stays on the direct epilogue
-    bool lds_store = (epi == 0 || epi == 1) && c_in <= 64;
+    bool lds_store = epi == 0 && c_in <= 64;          // see f2_store_rows_lds
     if (const char* e = getenv("PTC_LINEAR2_LDS_STORE")) { if (atoi(e) == 0) lds_store = false; }   // A/B switch
     const size_t slices = lds_store ? 4 * f2_out_slice_bytes(NT) : 0;
     int nh = 1;
@@ -415,31 +376,35 @@ static int launch_fwd2(const void* in, int64_t n_in, const void* w, const float*
     if (const char* e = getenv("PTC_LINEAR2_NH")) { if (atoi(e) == 1) nh = 1; }   // A/B switch: the one-block form
     const size_t lds = (((size_t)nh * NT * (c_in + 8) * 2 + 15) & ~(size_t)15) + (size_t)nh * NT * 4 + slices;
     const int64_t tiles = ptc_cdiv(n_out, F2_ROWS);
-    int64_t per_cu = (160 * 1024) / (int64_t)lds;
-    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    int64_t per_cu = lds > 40 * 1024 ? 2 : 4;
+    if (lds_store) { per_cu = (160 * 1024) / (int64_t)lds; per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu); }
     int64_t gx = 256 * per_cu / (nblk / nh);
     if (gx > tiles) gx = tiles;
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)(nblk / nh));
     const int S = (c_in + 31) / 32;
-#define L2_LAUNCH(SS, EE)                                                                                               \
+#define L2_LAUNCH(SS, EE) L2_LAUNCH_X(SS, EE, false)
+#define L2_LAUNCH_X(SS, EE, LL)                                                                                         \
   {                                                                                                                     \
-    auto kern = linear2_kernel<T, NTILES, SS, EE>;                                                                      \
+    auto kern = linear2_kernel<T, NTILES, SS, EE, LL>;                                                                      \
     if (lds > 48 * 1024)                                                                                                \
       PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, c_in, c_out, nh, lds_store ? 1 : 0, (T*)out, \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, c_in, c_out, nh, (T*)out, \
                        (const T*)aux_in, (T*)aux_out, (uint32_t)((uint64_t)n_in * c_in * sizeof(T)));                   \
   }
 #define L2_CASE(SS)                                                                                                     \
   case SS: {                                                                                                            \
     if (epi == 1) L2_LAUNCH(SS, 1) else if (epi == 2) L2_LAUNCH(SS, 2) else L2_LAUNCH(SS, 0)                              \
   } break;
-    switch (S) {
+    if (lds_store && S == 1) L2_LAUNCH_X(1, 0, true)
+    else if (lds_store && S == 2) L2_LAUNCH_X(2, 0, true)
+    else switch (S) {
       L2_CASE(1) L2_CASE(2) L2_CASE(3) L2_CASE(4) L2_CASE(5) L2_CASE(6) L2_CASE(7) L2_CASE(8)
       default: ptc_set_error("linear2: c_in=%d unsupported", c_in); return PTC_EUNSUPPORTED;
     }
 #undef L2_CASE
 #undef L2_LAUNCH
+#undef L2_LAUNCH_X
     PTC_CHECK_LAUNCH("linear2_kernel");
     return PTC_OK;
   }
