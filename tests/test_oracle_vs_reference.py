@@ -232,3 +232,29 @@ def test_collate_and_mix3d_match_the_reference_functions():
         for k in a:
             assert torch.equal(a[k].to(torch.float64), b[k].to(torch.float64)), (mix, k)
     assert b["offset"].tolist() == [800, 1700, 1800]
+
+
+def test_rpe_window_attention_oracle_vs_reference_modules(R):
+    """The oracle of the RPE attention kernels (`_rpe_reference` in tests/test_gpu_kernels.py) against the reference's own RPE
+    module and dense-branch arithmetic (point_transformer_v3m1_base.py:29-48,104-112,190-206) on one window: same table, same
+    coordinates, same q / k / v -- the bias tensor and the attention output."""
+    import test_gpu_kernels as T
+
+    g = torch.Generator().manual_seed(12)
+    K, H, D = 96, 3, 16
+    rpe = R["ptv3"].RPE(patch_size=K, num_heads=H)
+    with torch.no_grad():
+        rpe.rpe_table.copy_(torch.randn(rpe.rpe_table.shape, generator=g) * 0.3)
+    bnd = rpe.pos_bnd
+    gc = torch.randint(0, 3 * bnd, (K, 3), generator=g)
+    qkv = torch.randn(K, 3, H, D, generator=g)
+    scale = D ** -0.5
+    # the reference's lines, written out for one patch (N' = 1)
+    rel_pos = gc.reshape(-1, K, 3).unsqueeze(2) - gc.reshape(-1, K, 3).unsqueeze(1)        # get_rel_pos :104-112
+    q, k, v = qkv.reshape(-1, K, 3, H, D).permute(2, 0, 3, 1, 4).unbind(dim=0)             # :193-195
+    attn = (q * scale) @ k.transpose(-2, -1) + rpe(rel_pos)                                 # :200-202
+    want = (torch.softmax(attn.float(), dim=-1) @ v).transpose(1, 2).reshape(K, H, D)      # :203-206
+    got, lse = T._rpe_reference(qkv, torch.tensor([0, K], dtype=torch.int32), scale, gc.int(), rpe.rpe_table.detach(), bnd)
+    assert torch.allclose(got, want.detach(), atol=1e-5)
+    assert torch.allclose(lse, torch.logsumexp(attn.detach()[0], dim=-1), atol=1e-5)
+
