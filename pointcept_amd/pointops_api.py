@@ -9,6 +9,8 @@ datasets/modelnet.py:100).  Same names, argument order and return conventions; `
     grouping(idx, feat, xyz, new_xyz=None, with_xyz=False)            -> [m, nsample, c (+3)]   (differentiable gather)
     interpolation(xyz, new_xyz, feat, offset, new_offset, k=3)        -> [n, c]  inverse-distance weights over k-NN
     knn_query_and_group(feat, xyz, offset, new_xyz, new_offset, idx=None, nsample=None, with_xyz=False)
+    ball_query_and_group(...), query_and_group(nsample, xyz, new_xyz, feat, idx, offset, new_offset, dilation=0, ...)  (utils.py)
+    grouping2(input, idx), interpolation2(xyz, new_xyz, input, offset, new_offset, k=3)
     offset2batch / batch2offset
 
     ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None)  -> (idx, dist)   HIP (pointops.hip)
@@ -69,6 +71,58 @@ def knn_query_and_group(feat, xyz, offset=None, new_xyz=None, new_offset=None, i
         assert nsample is not None
         idx, _ = knn_query(nsample, xyz, offset, new_xyz, new_offset)
     return grouping(idx, feat, xyz, new_xyz, with_xyz), idx
+
+
+def grouping2(input, idx):
+    """libs/pointops/functions/grouping.py:5-63 (`Grouping.apply`): input [n, c], idx [m, nsample] -> [m, nsample, c]; the
+    custom CUDA backward (atomicAdd scatter) is torch's index backward here."""
+    m, nsample = idx.shape
+    return input[idx.reshape(-1).long()].view(m, nsample, input.shape[1])
+
+
+def interpolation2(xyz, new_xyz, input, offset, new_offset, k=3):
+    """libs/pointops/functions/interpolation.py:30-61: the custom-Function form of `interpolation`; the weights are constants of
+    the geometry, so autograd through the weighted gather gives the same gradient."""
+    return interpolation(xyz, new_xyz, input, offset, new_offset, k)
+
+
+def ball_query_and_group(feat, xyz, offset=None, new_xyz=None, new_offset=None, idx=None, max_radio=None, min_radio=0, nsample=None,
+                         with_xyz=False):
+    """libs/pointops/functions/utils.py:21-39 (argument names as there, `radio` included)."""
+    if idx is None:
+        assert nsample is not None and offset is not None
+        assert max_radio is not None and min_radio is not None
+        idx, _ = ball_query(nsample, max_radio, min_radio, xyz, offset, new_xyz, new_offset)
+    return grouping(idx, feat, xyz, new_xyz, with_xyz), idx
+
+
+def query_and_group(nsample, xyz, new_xyz, feat, idx, offset, new_offset, dilation=0, with_feat=True, with_xyz=True):
+    """libs/pointops/functions/utils.py:42-99: kNN grouping with DILATION -- 1 + (nsample - 1)(dilation + 1) neighbours are
+    queried and every (dilation + 1)-th kept; a scene with fewer points than that keeps the stride that still spans it
+    (`soft_dilation`).  Returns idx alone when with_feat is False, else (grouped [m, nsample, c (+3)], idx)."""
+    if new_xyz is None:
+        new_xyz = xyz
+    if idx is None:
+        total = 1 + (nsample - 1) * (dilation + 1)
+        wide, _ = knn_query(total, xyz, offset, new_xyz, new_offset)              # [m, total]
+        ends, new_ends = [int(v) for v in offset.tolist()], [int(v) for v in new_offset.tolist()]
+        parts, start, new_start = [], 0, 0
+        for end, new_end in zip(ends, new_ends):
+            count = end - start
+            stride = ((count - 1) / (nsample - 1) - 1) if count < total else dilation      # the reference's soft_dilation
+            cols = [int((stride + 1) * j) for j in range(nsample)]
+            parts.append(wide[new_start:new_end, cols])
+            start, new_start = end, new_end
+        idx = torch.cat(parts, dim=0)
+    if not with_feat:
+        return idx
+    m, c = new_xyz.shape[0], feat.shape[1]
+    flat = idx.reshape(-1).long()
+    grouped_feat = feat[flat].view(m, nsample, c)
+    if with_xyz:
+        grouped_xyz = xyz[flat].view(m, nsample, 3) - new_xyz.unsqueeze(1)
+        return torch.cat((grouped_xyz, grouped_feat), -1), idx
+    return grouped_feat, idx
 
 
 def ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None):

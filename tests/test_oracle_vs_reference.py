@@ -258,3 +258,105 @@ def test_rpe_window_attention_oracle_vs_reference_modules(R):
     assert torch.allclose(got, want.detach(), atol=1e-5)
     assert torch.allclose(lse, torch.logsumexp(attn.detach()[0], dim=-1), atol=1e-5)
 
+
+def test_pointops2_mirror_has_the_reference_names_and_argument_order():
+    """pointcept_amd/pointops2_api.py against libs/pointops2/functions/pointops.py, read with `ast` (the file imports a CUDA
+    extension and cannot be imported): every public name Stratified Transformer can reach -- `X = Class.apply` aliases take the
+    forward's parameters after ctx, plain functions their own -- exists in the mirror with the same positional parameter names."""
+    import ast
+    import inspect
+    import os
+
+    from pointcept_amd import pointops2_api as p2
+
+    src = "/root/reference/libs/pointops2/functions/pointops.py"
+    tree = ast.parse(open(src).read())
+    classes = {n.name: n for n in tree.body if isinstance(n, ast.ClassDef)}
+    want = {}
+    for n in tree.body:
+        if isinstance(n, ast.FunctionDef):
+            want[n.name] = [a.arg for a in n.args.args]
+        elif isinstance(n, ast.Assign) and isinstance(n.value, ast.Attribute) and n.value.attr == "apply":
+            cls = classes[n.value.value.id]
+            fwd = next(f for f in cls.body if isinstance(f, ast.FunctionDef) and f.name == "forward")
+            want[n.targets[0].id] = [a.arg for a in fwd.args.args][1:]
+    assert {"attention_step1_v2", "dot_prod_with_idx_v3", "attention_step2_with_rel_pos_value_v2", "furthestsampling", "knnquery",
+            "queryandgroup", "interpolation"} <= set(want)
+    for name, params in want.items():
+        assert hasattr(p2, name), f"pointops2 mirror lacks {name}"
+        got = [p for p in inspect.signature(getattr(p2, name)).parameters]
+        assert got[:len(params)] == params, (name, got, params)
+    assert os.path.exists(src)
+
+
+def test_pointops_mirror_names_arguments_and_python_helpers(monkeypatch):
+    """pointcept_amd/pointops_api.py against libs/pointops/functions/*.py: (1) every exported name exists with the reference's
+    positional parameter names (read with `ast`: the package imports a CUDA extension); (2) the pure-Python helpers of utils.py
+    (knn_query_and_group, ball_query_and_group, query_and_group with dilation / soft dilation) are executed FROM THE REFERENCE FILE
+    with `pointops` bound to CPU stand-ins (oracle/pointops.py) and compared with the mirror running on the same stand-ins."""
+    import ast
+    import glob
+    import inspect
+    import sys
+    import types
+
+    from oracle import pointops as orc
+    from pointcept_amd import pointops_api as p1
+
+    want = {}
+    for f in sorted(glob.glob("/root/reference/libs/pointops/functions/*.py")):
+        if f.endswith("__init__.py"):
+            continue
+        tree = ast.parse(open(f).read())
+        classes = {n.name: n for n in tree.body if isinstance(n, ast.ClassDef)}
+        for n in tree.body:
+            if isinstance(n, ast.FunctionDef):
+                want[n.name] = [a.arg for a in n.args.args]
+            elif isinstance(n, ast.Assign) and isinstance(n.value, ast.Attribute) and n.value.attr == "apply":
+                fwd = next(x for x in classes[n.value.value.id].body if isinstance(x, ast.FunctionDef) and x.name == "forward")
+                want[n.targets[0].id] = [a.arg for a in fwd.args.args][1:]
+    assert len(want) >= 17
+    for name, params in want.items():
+        assert hasattr(p1, name), f"pointops mirror lacks {name}"
+        got = [p for p in inspect.signature(getattr(p1, name)).parameters]
+        assert got[:len(params)] == params, (name, got, params)
+
+    # (2) CPU stand-ins for the three kernels the helpers call
+    def knn(nsample, xyz, offset, new_xyz=None, new_offset=None):
+        if new_xyz is None:
+            new_xyz, new_offset = xyz, offset
+        i, d = orc.knn_query(nsample, xyz.numpy(), offset.numpy(), new_xyz.numpy(), new_offset.numpy())
+        return torch.from_numpy(i), torch.from_numpy(d)
+
+    def ball(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None):
+        if new_xyz is None:
+            new_xyz, new_offset = xyz, offset
+        i, d = orc.ball_query(nsample, max_radius, min_radius, xyz.numpy(), offset.numpy(), new_xyz.numpy(), new_offset.numpy())
+        return torch.from_numpy(i), torch.from_numpy(d)
+
+    stub = types.ModuleType("pointops")
+    stub.knn_query, stub.ball_query, stub.grouping = knn, ball, p1.grouping
+    monkeypatch.setitem(sys.modules, "pointops", stub)
+    ref = types.ModuleType("ref_pointops_utils")
+    exec(compile(open("/root/reference/libs/pointops/functions/utils.py").read(), "utils.py", "exec"), ref.__dict__)
+    monkeypatch.setattr(p1, "knn_query", knn)
+    monkeypatch.setattr(p1, "ball_query", ball)
+
+    g = torch.Generator().manual_seed(2)
+    xyz = torch.rand(260, 3, generator=g)
+    feat = torch.randn(260, 5, generator=g)
+    offset = torch.tensor([200, 212, 260], dtype=torch.int32)           # the middle scene (12 points) triggers the soft dilation
+    new_xyz, new_offset = xyz[::4].contiguous(), torch.tensor([50, 53, 65], dtype=torch.int32)
+    for dil in (0, 1, 2):
+        a, ia = ref.query_and_group(8, xyz, new_xyz, feat, None, offset, new_offset, dilation=dil)
+        b, ib = p1.query_and_group(8, xyz, new_xyz, feat, None, offset, new_offset, dilation=dil)
+        assert torch.equal(ia, ib) and torch.equal(a, b), dil
+        assert torch.equal(ref.query_and_group(8, xyz, new_xyz, feat, None, offset, new_offset, dilation=dil, with_feat=False),
+                           p1.query_and_group(8, xyz, new_xyz, feat, None, offset, new_offset, dilation=dil, with_feat=False))
+    a, ia = ref.knn_query_and_group(feat, xyz, offset, new_xyz, new_offset, nsample=6, with_xyz=True)
+    b, ib = p1.knn_query_and_group(feat, xyz, offset, new_xyz, new_offset, nsample=6, with_xyz=True)
+    assert torch.equal(ia, ib) and torch.equal(a, b)
+    a, ia = ref.ball_query_and_group(feat, xyz, offset, new_xyz, new_offset, max_radio=0.3, min_radio=0.0, nsample=6, with_xyz=True)
+    b, ib = p1.ball_query_and_group(feat, xyz, offset, new_xyz, new_offset, max_radio=0.3, min_radio=0.0, nsample=6, with_xyz=True)
+    assert torch.equal(ia, ib) and torch.equal(a, b)
+
