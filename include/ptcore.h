@@ -285,6 +285,19 @@ int ptc_rope3d(void* tokens, int dtype, const int64_t* positions, int64_t n_toke
                ptc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * G1c. PT-v3m3 `Point3DRoPE` on the packed qkv rows (pointcept/models/point_transformer_v3/point_transformer_v3m3_utonia.py:43-102,
+ * call site :274-323: q, k = rope(q, k, coord[order]); flash-attn reads stack([q', k', v]).to(bf16)).
+ *   src [n_tokens, slabs, H, D] of src_dtype -> dst (same shape) of dst_dtype: the first `rot_slabs` slabs (q, k) are rotated, the
+ *   rest (v) converted / copied; src == dst (one dtype) rotates in place.  xyz [n_tokens, 3] fp32 = the continuous coordinates of
+ *   the rows (after the training-time shift / jitter / rescale of :276-300); inv_freq [D/6] fp32 = the module's buffer (:53-56).
+ *   Per head: three chunks of D/3, element i of a chunk's first half pairs with element i of its second half (rotate_half, :75-77):
+ *   (u, v) <- (u cos f - sign v sin f, v cos f + sign u sin f),  f = xyz[a] * inv_freq[i];  fp32 math.
+ *   sign = +1 forward, -1 for the gradient (the rotation is orthogonal).  D % 6 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int ptc_rope3d_xyz(const void* src, int src_dtype, void* dst, int dst_dtype, const float* xyz, const float* inv_freq,
+                   int64_t n_tokens, int slabs, int rot_slabs, int H, int D, float sign, ptc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * G2. LayerNorm over channels of [n, c] features (nn.LayerNorm inside every PTv3 Block:
  * ptv3m1:286 cpe.2, :289 norm1, :305 norm2).  c in {32,64,128,256,512} (ptc_layer_norm_supported).
  *   fwd: y = (x-mean)*rstd*gamma + beta, statistics in fp32; y dtype may differ from x

@@ -55,6 +55,7 @@ _SIGNATURES = {
                                  c_ptr]),
     "ptc_seg_eval_hist": (c_int, [c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_ptr, c_ptr]),
     "ptc_rope3d": (c_int, [c_ptr, c_int, c_ptr, c_i64, c_int, c_int, c_f32, c_f32, c_ptr]),
+    "ptc_rope3d_xyz": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_f32, c_ptr]),
     "ptc_layer_norm_supported": (c_int, [c_int]),
     "ptc_layer_norm_fwd": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
     "ptc_layer_norm_bwd_workspace_bytes": (c_size, [c_i64, c_int]),

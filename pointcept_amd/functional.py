@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from . import ops
+from . import config, ops
 from ._lib import PtcoreError
 
 
@@ -649,6 +649,48 @@ def attn_rpe_qkvpacked(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: 
     if qkv.dtype != torch.bfloat16:
         raise PtcoreError("attn_rpe_qkvpacked expects bf16 qkv")
     return _AttnRpe.apply(qkv, rpe_table, cu_seqlens, grid_coord, int(max_seqlen), float(softmax_scale), int(pos_bnd))
+
+
+# ------------------------------------------------------------------------------------------------
+# PT-v3m3 Point3DRoPE on packed qkv rows
+# ------------------------------------------------------------------------------------------------
+class _RopeXYZ(Function):
+    """ptc_rope3d_xyz: q / k slabs rotated, v converted, one pass, bf16 out; backward = the inverse rotation of the gradient."""
+
+    @staticmethod
+    def forward(ctx, qkv, xyz, inv_freq):
+        ctx.save_for_backward(xyz, inv_freq)
+        ctx.in_dtype = qkv.dtype
+        return ops.rope3d_xyz(qkv.contiguous(), xyz, inv_freq, 2, 1.0, torch.bfloat16)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xyz, inv_freq = ctx.saved_tensors
+        return ops.rope3d_xyz(g.contiguous(), xyz, inv_freq, 2, -1.0, ctx.in_dtype), None, None
+
+
+def rope_xyz_torch(qkv: torch.Tensor, xyz: torch.Tensor, inv_freq: torch.Tensor) -> torch.Tensor:
+    """The reference's arithmetic (point_transformer_v3m3_utonia.py:58-101,303-323) on the packed layout, in torch ops:
+    qkv [n, 3, H, D] of any float dtype -> bf16; q and k are rotated in fp32 (bf16 * fp32 promotes there too), v is only cast."""
+    n, _, H, D = qkv.shape
+    Q = D // 6
+    emb = xyz[:, :, None] * inv_freq[None, None, :]                       # [n, 3, Q]   (:62-67)
+    cos, sin = emb.cos()[:, None, None, :, None, :], emb.sin()[:, None, None, :, None, :]   # over (slab, head, axis, half, i)
+    t = qkv[:, :2].float().reshape(n, 2, H, 3, 2, Q)
+    u, v = t[..., 0:1, :], t[..., 1:2, :]
+    rot = torch.cat((u * cos + (-v) * sin, v * cos + u * sin), dim=-2)     # x cos + rotate_half(x) sin  (:75-77,91-92)
+    return torch.cat((rot.reshape(n, 2, H, D).to(torch.bfloat16), qkv[:, 2:].to(torch.bfloat16)), dim=1)
+
+
+def rope_xyz_qkvpacked(qkv: torch.Tensor, xyz: torch.Tensor, inv_freq: torch.Tensor) -> torch.Tensor:
+    """qkv [n, 3, H, D] (D % 6 == 0) -> bf16 [n, 3, H, D] with Point3DRoPE applied to q and k: what flash-attn receives at
+    point_transformer_v3m3_utonia.py:319-323.  `config.ROPE_XYZ_KERNEL` selects the HIP kernel (default: torch ops on the GPU)."""
+    if qkv.dim() != 4 or qkv.shape[1] != 3 or qkv.shape[3] % 6 != 0:
+        raise PtcoreError(f"rope_xyz_qkvpacked: qkv {tuple(qkv.shape)} must be [n, 3, H, D] with D % 6 == 0")
+    if config.ROPE_XYZ_KERNEL:
+        return _RopeXYZ.apply(qkv, xyz.float().contiguous(), inv_freq.float().contiguous())
+    return rope_xyz_torch(qkv, xyz, inv_freq)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -541,6 +541,27 @@ def rope3d_(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
     return tokens
 
 
+def rope3d_xyz(qkv: torch.Tensor, xyz: torch.Tensor, inv_freq: torch.Tensor, rot_slabs: int, sign: float,
+               out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """PT-v3m3 Point3DRoPE on packed rows: qkv [n, S, H, D] -> same shape in `out_dtype` (default: qkv's), the first `rot_slabs`
+    slabs rotated with xyz [n, 3] fp32 and inv_freq [D/6] fp32, the rest converted (point_transformer_v3m3_utonia.py:43-102,274-323).
+    sign = +1 forward / -1 gradient."""
+    require_cuda(qkv, xyz, inv_freq)
+    if qkv.dim() != 4 or not qkv.is_contiguous():
+        raise PtcoreError("rope3d_xyz: qkv must be contiguous [n, slabs, H, D]")
+    n, S, H, D = qkv.shape
+    if D % 6 != 0:
+        raise PtcoreError(f"rope3d_xyz: head dim {D} must be a multiple of 6")
+    if xyz.dtype != torch.float32 or tuple(xyz.shape) != (n, 3) or not xyz.is_contiguous():
+        raise PtcoreError("rope3d_xyz: xyz must be contiguous fp32 [n, 3]")
+    if inv_freq.dtype != torch.float32 or inv_freq.numel() != D // 6 or not inv_freq.is_contiguous():
+        raise PtcoreError(f"rope3d_xyz: inv_freq must be contiguous fp32 [{D // 6}]")
+    out = torch.empty(qkv.shape, dtype=out_dtype or qkv.dtype, device=qkv.device)
+    check(lib().ptc_rope3d_xyz(ptr(qkv), dtype_code(qkv), ptr(out), dtype_code(out), ptr(xyz), ptr(inv_freq), n, S, int(rot_slabs), H, D,
+                               float(sign), stream_ptr()), "ptc_rope3d_xyz")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # layer norm
 # ------------------------------------------------------------------------------------------------

@@ -364,7 +364,7 @@ class Block(PointModule):
             norm_layer(channels),
         )
         self.norm1 = PointSequential(norm_layer(channels))
-        self.attn = SerializedAttention(
+        self.attn = self._build_attn(
             channels=channels, patch_size=patch_size, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
             attn_drop=attn_drop, proj_drop=proj_drop, order_index=order_index, enable_rpe=enable_rpe,
             enable_flash=enable_flash, upcast_attention=upcast_attention, upcast_softmax=upcast_softmax)
@@ -376,6 +376,10 @@ class Block(PointModule):
             for m in (self.norm1[0], self.norm2[0]):
                 if isinstance(m, PNN.LayerNorm):
                     m.gemm_consumer = True
+
+    def _build_attn(self, **kw):
+        """the attention module of this block family (PT-v3m3 builds its RoPE variant here)"""
+        return SerializedAttention(**kw)
 
     _ones = {}   # device -> persistent ones buffer (grown on demand): source operand of the one-launch mask below
 

@@ -214,6 +214,7 @@ class Embedding(PointModule):
 
 class PointTransformerV3(PointModule):
     """registry name "PT-v3m2" (:544)"""
+    block_cls = None        # = Block (set below the class); derived families substitute theirs
 
     def __init__(self, in_channels=6, order=("z", "z-trans"), stride=(2, 2, 2, 2), enc_depths=(3, 3, 3, 12, 3),
                  enc_channels=(48, 96, 192, 384, 512), enc_num_head=(3, 6, 12, 24, 32), enc_patch_size=(1024, 1024, 1024, 1024, 1024),
@@ -231,6 +232,7 @@ class PointTransformerV3(PointModule):
         assert self.enc_mode or self.num_stages == len(dec_num_head) + 1 == len(dec_patch_size) + 1
         ln_layer, act_layer = PNN.LayerNorm, PNN.GELU
         self.embedding = Embedding(in_channels, enc_channels[0], norm_layer=ln_layer, act_layer=act_layer, mask_token=mask_token)
+        Block = self.block_cls
         block_kw = dict(mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop,
                         layer_scale=layer_scale, norm_layer=ln_layer, act_layer=act_layer, pre_norm=pre_norm, enable_rpe=enable_rpe,
                         enable_flash=enable_flash, upcast_attention=upcast_attention, upcast_softmax=upcast_softmax)
@@ -244,7 +246,8 @@ class PointTransformerV3(PointModule):
                         name="down")
             for i in range(enc_depths[s]):
                 enc.add(Block(channels=enc_channels[s], num_heads=enc_num_head[s], patch_size=enc_patch_size[s], drop_path=dp[i],
-                              order_index=i % len(self.order), cpe_indice_key=f"stage{s}", **block_kw), name=f"block{i}")
+                              order_index=i % len(self.order), cpe_indice_key=f"stage{s}", **block_kw, **self._extra_block_kw(False)),
+                        name=f"block{i}")
             if len(enc) != 0:
                 self.enc.add(module=enc, name=f"enc{s}")
         if not self.enc_mode:
@@ -259,12 +262,17 @@ class PointTransformerV3(PointModule):
                                       traceable=traceable), name="up")
                 for i in range(dec_depths[s]):
                     dec.add(Block(channels=dec_channels[s], num_heads=dec_num_head[s], patch_size=dec_patch_size[s], drop_path=dp[i],
-                                  order_index=i % len(self.order), cpe_indice_key=f"stage{s}", **block_kw), name=f"block{i}")
+                                  order_index=i % len(self.order), cpe_indice_key=f"stage{s}", **block_kw, **self._extra_block_kw(True)),
+                            name=f"block{i}")
                 self.dec.add(module=dec, name=f"dec{s}")
         if self.freeze_encoder:
             for p in list(self.embedding.parameters()) + list(self.enc.parameters()):
                 p.requires_grad = False
         self.apply(self._init_weights)
+
+    def _extra_block_kw(self, decoder: bool) -> dict:
+        """block kwargs a derived family adds (PT-v3m3: the RoPE settings)"""
+        return {}
 
     @staticmethod
     def _init_weights(module):
@@ -284,3 +292,6 @@ class PointTransformerV3(PointModule):
         if not self.enc_mode:
             point = self.dec(point)
         return point
+
+
+PointTransformerV3.block_cls = Block

@@ -392,3 +392,29 @@ def test_oracle_pointrope_matches_reference_golden():
             n_in = tok[..., a * 2 * Q:a * 2 * Q + Q] ** 2 + tok[..., a * 2 * Q + Q:a * 2 * Q + 2 * Q] ** 2
             n_out = out[..., a * 2 * Q:a * 2 * Q + Q] ** 2 + out[..., a * 2 * Q + Q:a * 2 * Q + 2 * Q] ** 2
             assert np.allclose(n_in, n_out, rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_rope_xyz_matches_the_reference_class_golden():
+    """oracle/pointrope.py::rope_xyz (PT-v3m3 Point3DRoPE) against the outputs of the reference's own class stored in
+    tests/golden/ptv3m3_tiny.npz (rope_*, tests/golden/make_golden_m3.py); the inverse sign undoes the rotation; the engine's torch
+    formulation on the packed layout (functional.rope_xyz_torch) gives the same numbers before its bf16 rounding."""
+    from oracle import pointrope as orope
+    from pointcept_amd import functional as PF
+
+    g = np.load(os.path.join(GOLD, "ptv3m3_tiny.npz"))
+    assert int(g["n_rope_cases"]) == 3
+    for ci in range(int(g["n_rope_cases"])):
+        q, k, xyz, f = g[f"rope_q_{ci}"], g[f"rope_k_{ci}"], g[f"rope_xyz_{ci}"], g[f"rope_inv_freq_{ci}"]
+        D = q.shape[-1]
+        base = float(g[f"rope_base_{ci}"])
+        np.testing.assert_allclose(f, 1.0 / base ** (np.arange(0, D // 3, 2, dtype=np.float32) / np.float32(D // 3)), rtol=1e-6)
+        for t, want in ((q, g[f"rope_q_out_{ci}"]), (k, g[f"rope_k_out_{ci}"])):
+            got = orope.rope_xyz(t, xyz, f)
+            assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), ci
+            assert np.abs(orope.rope_xyz(got, xyz, f, -1.0) - t).max() <= 4e-6 * np.abs(t).max()
+        qkv = torch.stack((torch.from_numpy(q), torch.from_numpy(k), torch.from_numpy(k)), dim=1)
+        out = PF.rope_xyz_torch(qkv, torch.from_numpy(xyz), torch.from_numpy(f))
+        assert out.dtype == torch.bfloat16 and out.shape == qkv.shape
+        want = torch.stack((torch.from_numpy(g[f"rope_q_out_{ci}"]), torch.from_numpy(g[f"rope_k_out_{ci}"]), torch.from_numpy(k)), dim=1)
+        assert torch.equal(out, want.to(torch.bfloat16)), ci                      # same fp32 arithmetic, one rounding
+

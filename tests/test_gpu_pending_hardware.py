@@ -1,0 +1,118 @@
+"""GPU tests of code written AFTER round 2's GPU time was spent: they have never run on an MI355X.
+
+They are real `-m gpu` tests (same structure and bars as their neighbours in test_gpu_kernels.py / test_gpu_model.py) but stay out
+of the default GPU run until a first hardware pass -- `PTC_RUN_PENDING=1 python -m pytest tests/test_gpu_pending_hardware.py -m gpu`
+is the first command of the next GPU session; each test that passes there moves to its permanent file.  Their bodies run on the
+CPU stand-ins in every CPU run (tests/test_gpu_tests_dry_run_cpu.py), so the python, the goldens and the host logic are exercised.
+
+  * ptc_rope3d_xyz        PT-v3m3's Point3DRoPE as one pass over the packed qkv rows (csrc/rope.hip), off by default
+                          (config.ROPE_XYZ_KERNEL) for the same reason
+  * PT-v3m3 module port   pointcept_amd/point_transformer_v3m3.py against the golden of the reference's own model file
+  * LitePT module port    pointcept_amd/litept.py against the golden of the reference's own model file
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("PTC_RUN_PENDING") != "1" and torch.cuda.is_available(),
+                                 reason="never run on hardware yet: opt in with PTC_RUN_PENDING=1 (see the module docstring)")]
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
+M3_CFG = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 2, 1), enc_channels=(36, 72, 72, 144, 144), enc_num_head=(2, 4, 4, 8, 8),
+              dec_depths=(1, 1, 1, 1), dec_channels=(36, 72, 72, 144), dec_num_head=(2, 4, 4, 8), enc_patch_size=(128,) * 5,
+              dec_patch_size=(128,) * 4, drop_path=0.0, shuffle_orders=False, layer_scale=0.5, rope_base=10)   # = make_golden_m3.py
+
+
+def test_rope3d_xyz_kernel_matches_reference_golden_and_inverts(cuda):
+    """ptc_rope3d_xyz against the outputs of the reference's Point3DRoPE class (tests/golden/ptv3m3_tiny.npz, rope_*): fp32 in / out
+    to 2e-6 (sin / cos of the device library against torch's), bf16 in -> bf16 out equal to the rounded fp32 result up to one ulp,
+    the value slab converted and otherwise untouched, in place == out of place, and sign = -1 undoes sign = +1 (orthogonality),
+    also at 819200 rows."""
+    from pointcept_amd import ops
+
+    g = np.load(os.path.join(GOLD, "ptv3m3_tiny.npz"))
+    for ci in range(int(g["n_rope_cases"])):
+        q, k = torch.from_numpy(g[f"rope_q_{ci}"]), torch.from_numpy(g[f"rope_k_{ci}"])
+        xyz, inv_freq = torch.from_numpy(g[f"rope_xyz_{ci}"]).to(cuda), torch.from_numpy(g[f"rope_inv_freq_{ci}"]).to(cuda)
+        v = torch.randn(q.shape, generator=torch.Generator().manual_seed(ci))
+        qkv = torch.stack((q, k, v), dim=1).contiguous().to(cuda)                       # [n, 3, H, D]
+        want = torch.stack((torch.from_numpy(g[f"rope_q_out_{ci}"]), torch.from_numpy(g[f"rope_k_out_{ci}"]), v), dim=1).to(cuda)
+        out = ops.rope3d_xyz(qkv, xyz, inv_freq, 2, 1.0)
+        assert out.dtype == torch.float32 and (out - want).abs().max() <= 2e-6 * max(1.0, float(want.abs().max())), ci
+        assert torch.equal(out[:, 2], qkv[:, 2])
+        back = ops.rope3d_xyz(out, xyz, inv_freq, 2, -1.0)
+        assert (back - qkv).abs().max() <= 4e-6 * float(qkv.abs().max())
+        # 16-bit operand in, bf16 out: the fp32 result of the ROUNDED operand, rounded once
+        qb = qkv.to(torch.bfloat16)
+        out_b = ops.rope3d_xyz(qb, xyz, inv_freq, 2, 1.0, torch.bfloat16)
+        ref_b = ops.rope3d_xyz(qb.float(), xyz, inv_freq, 2, 1.0).to(torch.bfloat16)
+        assert out_b.dtype == torch.bfloat16 and torch.equal(out_b[:, 2], qb[:, 2])
+        diff = (out_b.float() - ref_b.float()).abs()
+        assert float(diff.max()) <= 2 ** -7 * float(ref_b.float().abs().max()) and float((diff > 0).float().mean()) < 0.01
+        # the library call in place
+        from pointcept_amd._lib import lib
+        from pointcept_amd.ops import check, dtype_code, ptr, stream_ptr
+        buf = qb.clone()
+        n, S, H, D = buf.shape
+        check(lib().ptc_rope3d_xyz(ptr(buf), dtype_code(buf), ptr(buf), dtype_code(buf), ptr(xyz), ptr(inv_freq), n, S, 2, H, D, 1.0,
+                                   stream_ptr()), "ptc_rope3d_xyz")
+        assert torch.equal(buf, out_b)
+    # full size: 819200 padded rows, 3 heads of 18 (Utonia stage 0), round trip
+    gen = torch.Generator(device=cuda).manual_seed(3)
+    n, H, D = 819200, 3, 18
+    qkv = torch.randn(n, 3, H, D, device=cuda, generator=gen).to(torch.bfloat16)
+    xyz = torch.rand(n, 3, device=cuda, generator=gen) * 8.0
+    inv_freq = (1.0 / (10.0 ** (torch.arange(0, D // 3, 2).float() / (D // 3)))).to(cuda)
+    out = ops.rope3d_xyz(qkv, xyz, inv_freq, 2, 1.0, torch.float32)
+    assert torch.isfinite(out).all()
+    nq, no = qkv[:, :2].float().reshape(n, 2 * H, 3, 2, D // 6).pow(2).sum(3), out[:, :2].reshape(n, 2 * H, 3, 2, D // 6).pow(2).sum(3)
+    assert (nq - no).abs().max() <= 1e-4 * float(nq.max())                              # every rotated pair keeps its length
+    back = ops.rope3d_xyz(out, xyz, inv_freq, 2, -1.0, torch.float32)
+    assert (back - qkv.float()).abs().max() <= 1e-5 * float(qkv.float().abs().max())
+
+
+@pytest.mark.parametrize("rope_kernel", [False, True])
+def test_ptv3m3_matches_reference_golden(cuda, rope_kernel, monkeypatch):
+    """the engine's module-level PT-v3m3 (m2 + Point3DRoPE; head_dim 18, 36 / 72 / 144 channels as in the reference's
+    Utonia configs) against tests/golden/ptv3m3_tiny.npz = the REFERENCE's own point_transformer_v3m3_utonia.py: state-dict keys,
+    eval features, train-mode loss and every gradient norm -- with the rotation in torch ops and on ptc_rope3d_xyz."""
+    from oracle import ptv3_model as om
+    from pointcept_amd import config, synthetic
+    from pointcept_amd.point_transformer_v3m3 import PointTransformerV3 as M3
+
+    monkeypatch.setattr(config, "ROPE_XYZ_KERNEL", rope_kernel)
+    g = np.load(os.path.join(GOLD, "ptv3m3_tiny.npz"))
+    torch.manual_seed(0)
+    eng = M3(**M3_CFG)
+    assert list(eng.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    sd = om.deterministic_state_dict(eng, 37)
+    assert abs(float(sum(float(v.double().abs().sum()) for v in sd.values())) - float(g["weight_checksum"])) < 1e-6 * float(g["weight_checksum"])
+    eng.load_state_dict(sd)
+    eng = eng.to(cuda)
+    batch = synthetic.collate([synthetic.indoor_scene(int(s), int(n)) for s, n in zip(g["scene_seeds"], g["n_points"])])
+    assert batch["grid_coord"].sum() == g["input_checksum"][0]
+    inp = synthetic.to_torch(batch, cuda)
+    inp["grid_size"] = 0.02
+    eng.eval()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        out = eng(dict(inp)).feat.float().cpu().numpy()
+    assert np.isfinite(out).all()
+    err = np.abs(out[::8] - g["feat_rows"]).max() / float(g["feat_absmax"])
+    assert err < 2e-2, f"engine PT-v3m3 vs reference golden: rel err {err:.3e}"
+    eng.train()
+    torch.manual_seed(5)
+    f = eng(dict(inp)).feat
+    loss = (f * torch.linspace(-1, 1, f.shape[1], device=f.device)).pow(2).mean()
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 2e-2 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    ref = dict(zip([str(k) for k in g["grad_names"]], g["grad_norms"]))
+    gmax = max(ref.values())
+    for name, p in eng.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        gn, rn = float(p.grad.norm()), ref[name]
+        assert abs(gn - rn) <= 0.1 * rn + 1e-4 * gmax, (name, gn, rn)

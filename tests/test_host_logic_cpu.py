@@ -446,6 +446,59 @@ def test_ptv3m2_module_port_matches_the_reference_file(layer_scale):
     _grad_check(eng, ref, 3e-2)
 
 
+M3_TINY = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), enc_channels=(48, 96, 96, 192, 192), enc_num_head=(2, 4, 4, 8, 8),
+               dec_depths=(1, 1, 1, 1), dec_channels=(48, 96, 96, 192), dec_num_head=(2, 4, 4, 8), enc_patch_size=(128,) * 5,
+               dec_patch_size=(128,) * 4, drop_path=0.0, shuffle_orders=False)
+
+
+@pytest.mark.needs_reference
+@pytest.mark.parametrize("variant", ["eval_default", "train_aug", "dec_rope_off", "rope_off"])
+def test_ptv3m3_module_port_matches_the_reference_file(variant):
+    """the engine's module-level PT-v3m3 (pointcept_amd/point_transformer_v3m3.py: m2 + Point3DRoPE on q / k from the
+    continuous coordinates, head_dim 24) against the REFERENCE's own point_transformer_v3m3_utonia.py on the oracle's third-party
+    stand-ins: same state-dict keys and shapes (incl. the rope.inv_freq buffers), same features, same gradients; the training-time
+    shift / jitter / rescale of the rope coordinates consumes the RNG exactly as the reference does (same seed -> same features)."""
+    import importlib
+
+    from oracle import ptv3_model as om
+    from oracle import ref_import
+    from pointcept_amd.point_transformer_v3m3 import PointTransformerV3 as EngM3
+
+    ref_import.load()
+    R_m3 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m3_utonia")
+    cfg = dict(M3_TINY, rope_base=10)
+    if variant == "train_aug":
+        cfg.update(shift_coords=0.5, jitter_coords=1.1, rescale_coords=1.2, layer_scale=0.5)
+    elif variant == "dec_rope_off":
+        cfg.update(dec_rope_enable=False)
+    elif variant == "rope_off":
+        cfg.update(rope_base=None)
+    torch.manual_seed(0)
+    ref, eng = R_m3.PointTransformerV3(**cfg), EngM3(**cfg)
+    assert list(ref.state_dict().keys()) == list(eng.state_dict().keys())
+    assert any(k.endswith("rope.inv_freq") for k in eng.state_dict()) == (variant != "rope_off")
+    for (k, a), (_, b) in zip(ref.state_dict().items(), eng.state_dict().items()):
+        assert a.shape == b.shape, k
+        if k.endswith("inv_freq"):
+            assert torch.equal(a, b), k
+    sd = om.deterministic_state_dict(ref, 31)
+    ref.load_state_dict(sd)
+    eng.load_state_dict(sd)
+    mb = _batch([700, 260], seed0=620)
+    mb["grid_size"] = 0.02
+    feats = []
+    with mock_backend.cpu_ops():
+        for net in (ref, eng):
+            net.train(variant != "eval_default")
+            torch.manual_seed(9)
+            f = net({k: v for k, v in mb.items()}).feat
+            (f * torch.linspace(-1, 1, f.shape[1])).pow(2).mean().backward()
+            feats.append(f.detach())
+    assert feats[0].shape == feats[1].shape == (960, 48)
+    assert _rel(feats[1], feats[0]) < 1e-3
+    _grad_check(eng, ref, 3e-2)
+
+
 def test_cast_twin_registry_identity_version_and_lifetime():
     """functional.register_cast_twin / cast_twin: the bf16 copy a residual joint wrote is handed out only for THE tensor it was
     registered for, only while that tensor is unmodified, only in the registered dtype / shape -- and the entry dies with it."""

@@ -360,3 +360,29 @@ def test_pointops_mirror_names_arguments_and_python_helpers(monkeypatch):
     b, ib = p1.ball_query_and_group(feat, xyz, offset, new_xyz, new_offset, max_radio=0.3, min_radio=0.0, nsample=6, with_xyz=True)
     assert torch.equal(ia, ib) and torch.equal(a, b)
 
+
+def test_rope_xyz_oracle_matches_the_reference_point3drope_live():
+    """oracle/pointrope.py::rope_xyz against the reference's Point3DRoPE class executed here (fresh random cases, several head dims
+    and bases), and the engine's Point3DRoPE module (same buffer, same forward contract) against the same class."""
+    import importlib
+
+    from oracle import pointrope as orope
+    from oracle import ref_import
+    from pointcept_amd.point_transformer_v3m3 import Point3DRoPE as EngRope
+
+    ref_import.load()
+    m3 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m3_utonia")
+    g = torch.Generator().manual_seed(77)
+    for n, H, D, base in ((129, 2, 18, 10), (64, 5, 24, 10000), (33, 1, 6, 100), (50, 3, 60, 10)):
+        q, k = torch.randn(n, H, D, generator=g), torch.randn(n, H, D, generator=g)
+        xyz = (torch.rand(n, 3, generator=g) - 0.5) * 20.0
+        ref = m3.Point3DRoPE(head_dim=D, base=base)
+        eng = EngRope(head_dim=D, base=base)
+        assert torch.equal(ref.inv_freq, eng.inv_freq) and list(ref.state_dict()) == list(eng.state_dict()) == ["inv_freq"]
+        qr, kr = ref(q, k, xyz)
+        qe, ke = eng(q, k, xyz)
+        assert torch.equal(qr, qe) and torch.equal(kr, ke)
+        for t, want in ((q, qr), (k, kr)):
+            got = orope.rope_xyz(t.numpy(), xyz.numpy(), ref.inv_freq.numpy())
+            assert np.abs(got - want.numpy()).max() <= 2e-6 * max(1.0, float(want.abs().max()))
+
