@@ -252,11 +252,12 @@ def scatter_min(src, index, dim=0, out=None, dim_size=None):
 
 def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
                                      **unused):
-    """CPU stand-in for flash_attn (ptv3m1:208-214): bf16 in, fp32 math, bf16 out.  Lets the
-    reference run its FLASH branch (enable_flash=True) unmodified on CPU."""
-    assert qkv.dtype == torch.bfloat16 and dropout_p == 0 and not causal
+    """CPU stand-in for flash_attn (ptv3m1:208-214): 16-bit in (bf16 at the PTv3 call sites, fp16 at LitePT's,
+    litept_v1.py:235-260), fp32 math, same 16-bit type out.  Lets the reference run its FLASH branch (enable_flash=True)
+    unmodified on CPU."""
+    assert qkv.dtype in (torch.bfloat16, torch.float16) and dropout_p == 0 and not causal
     scale = qkv.shape[-1] ** -0.5 if softmax_scale is None else softmax_scale
-    return ops.attention_varlen(qkv.float(), cu_seqlens.tolist(), scale).to(torch.bfloat16)
+    return ops.attention_varlen(qkv.float(), cu_seqlens.tolist(), scale).to(qkv.dtype)
 
 
 def install_third_party(mods=None):

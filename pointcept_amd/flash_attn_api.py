@@ -7,7 +7,8 @@ head_dim 16 and max_seqlen <= 1024 (every PT-v3m1 / m2 configuration) run on the
 (attention_hd.h; windows up to 1024 keys for head_dim <= 32, 672 for <= 48, 512 for <= 64).  Anything else (head_dim < 16,
 > 64, longer windows) is served by PyTorch-ROCm's scaled_dot_product_attention on the GPU, one batched call per distinct
 sequence length -- a library path that exists so such calls run through the operator-level API, not a tuned one (it
-needs the sequence lengths on the host: one sync per call).  dropout_p must be 0 (all reference PTv3 configs); causal / alibi / softcap /
+needs the sequence lengths on the host: one sync per call).  fp16 qkv (LitePT's call site) runs on the same kernels after a cast to
+bf16 and comes back as fp16.  dropout_p must be 0 (all reference PTv3 configs); causal / alibi / softcap /
 local windows raise.
 """
 from __future__ import annotations
@@ -55,4 +56,8 @@ def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
         if softmax_scale is None:
             softmax_scale = qkv.shape[3] ** -0.5
         return _sdpa_varlen(qkv, cu_seqlens, float(softmax_scale))
+    if qkv.dtype == torch.float16:
+        # LitePT's call site hands over fp16 (litept_v1.py:235-260).  The window-attention kernels take bf16 operands with fp32
+        # accumulation: fp16 operands are re-rounded to bf16 (three mantissa bits) and the result returned as fp16.
+        return PF.attn_varlen_qkvpacked(qkv.to(torch.bfloat16), cu_seqlens, max_seqlen, softmax_scale).to(torch.float16)
     return PF.attn_varlen_qkvpacked(qkv, cu_seqlens, max_seqlen, softmax_scale)

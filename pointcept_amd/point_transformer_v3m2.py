@@ -149,11 +149,12 @@ class GridPooling(PointModule):
                 point_dict[key] = point[key]
         if "grid_size" in point.keys():
             point_dict["grid_size"] = point.grid_size * self.stride
+        self._extra_keys(point, point_dict, order0, idx_ptr)
         if self.traceable:
             point_dict["pooling_inverse"] = cluster
             point_dict["pooling_parent"] = point
-            point_dict["idx_ptr"] = idx_ptr
-        order = point.order
+            if self.trace_idx_ptr:
+                point_dict["idx_ptr"] = idx_ptr
         child = Point(point_dict)
         child["_ptc_pool_csr"] = (order0, idx_ptr)      # gather-form backward of the unpooling gather
         child["_ptc_n_dup"] = 0                         # one row per cell
@@ -161,9 +162,17 @@ class GridPooling(PointModule):
             child = self.norm(child)
         if getattr(self, "act", None) is not None:
             child = self.act(child)
-        child.serialization(order=order, shuffle_orders=self.shuffle_orders)                    # :461 (re-serialize)
+        self._serialize_child(point, child)
         child.sparsify()
         return child
+
+    trace_idx_ptr = True          # m2 / m3 record the CSR on the child (:436); LitePT does not
+
+    def _extra_keys(self, point, point_dict, order0, idx_ptr):
+        """keys a derived family pools in addition (LitePT: `mask`)"""
+
+    def _serialize_child(self, point, child):
+        child.serialization(order=point.order, shuffle_orders=self.shuffle_orders)              # :461 (re-serialize)
 
 
 class GridUnpooling(PointModule):

@@ -58,7 +58,82 @@ class Point3DRoPE(nn.Module):
         return torch.cat((rot, qkv[:, 2:].float()), dim=1)
 
 
-class SerializedAttention(_AttnM1):
+class RopeAttention(_AttnM1):
+    """m1's serialized attention with a rotation of q and k between the qkv GEMM and the window-attention kernels.  A derived class
+    says whether the rotation is on (`_rope_on`) and supplies the rows' positions and frequencies (`_rope_inputs`)."""
+
+    def _rope_on(self) -> bool:
+        raise NotImplementedError
+
+    def _rope_inputs(self, point, order):
+        """-> (xyz [n, 3] fp32 positions of the padded, serialized rows; inv_freq [head_dim / 6] fp32)"""
+        raise NotImplementedError
+
+    def _rotate_for_dense(self, qkv, point, order):
+        """[n, 3, H, D] -> fp32 rotated q, k (dense branch)"""
+        xyz, inv_freq = self._rope_inputs(point, order)
+        n, _, H, D = qkv.shape
+        Q = D // 6
+        emb = xyz[:, :, None] * inv_freq[None, None, :]
+        cos, sin = emb.cos()[:, None, None, :, None, :], emb.sin()[:, None, None, :, None, :]
+        t = qkv[:, :2].float().reshape(n, 2, H, 3, 2, Q)
+        u, v = t[..., 0:1, :], t[..., 1:2, :]
+        rot = torch.cat((u * cos + (-v) * sin, v * cos + u * sin), dim=-2).reshape(n, 2, H, D)
+        return rot[:, 0], rot[:, 1]
+
+    def _forward_dense_rope(self, point):
+        """enable_flash=False with the rotation (utonia.py:303-318): rotation on [n, H, D], then the dense [P, H, K, K] formulation."""
+        H, K, C = self.num_heads, self.patch_size, self.channels
+        pad, unpad, _ = self.get_padding_and_inverse(point)
+        order = point.serialized_order[self.order_index][pad]
+        inverse = unpad[point.serialized_inverse[self.order_index]]
+        qkv = self.qkv(point.feat)[order].reshape(-1, 3, H, C // H)
+        q, k = self._rotate_for_dense(qkv, point, order)
+        q, k = (t.reshape(-1, K, H, C // H).permute(0, 2, 1, 3) for t in (q, k))
+        v = qkv[:, 2].reshape(-1, K, H, C // H).permute(0, 2, 1, 3)
+        if self.upcast_attention:
+            q, k = q.float(), k.float()
+        attn = (q * self.scale) @ k.transpose(-2, -1)
+        if self.rpe is not None:
+            attn = attn + self.rpe(self.get_rel_pos(point, order))
+        if self.upcast_softmax:
+            attn = attn.float()
+        attn = torch.softmax(attn, dim=-1)
+        attn = self.attn_drop(attn).to(qkv.dtype)
+        feat = (attn @ v).transpose(1, 2).reshape(-1, C)[inverse]
+        point.feat = self.proj_drop(self.proj(feat))
+        return point
+
+    def forward(self, point):
+        if not self._rope_on():
+            return super().forward(point)
+        if not self.enable_flash:
+            _, offset_host = point._host_facts()
+            smallest = min(b - a for a, b in zip([0] + list(offset_host[:-1]), offset_host))
+            self.patch_size = min(int(smallest), self.patch_size_max)      # utonia.py:258-261
+            if not self._kernel_ok():
+                return self._forward_dense_rope(point)
+        H, K, C = self.num_heads, self.patch_size, self.channels
+        pad, _, cu_seqlens = self.get_padding_and_inverse(point)
+        gidx, inv, dup_of_point, gidx_primary, tabs = self._index_maps(point)
+        order = point.serialized_order[self.order_index][pad] if gidx is None else gidx
+        xyz, inv_freq = self._rope_inputs(point, order)
+        if tabs is not None:
+            qkv_s = self.qkv(point.feat, tabs[0], tabs[1])                                     # padded, serialized rows (:272)
+            qkv_r = PF.rope_xyz_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, inv_freq)       # :303-305,319-321 (bf16)
+            out = PF.attn_varlen_qkvpacked(qkv_r, cu_seqlens, K, self.scale)
+            feat = self.proj(out.reshape(-1, C).to(qkv_s.dtype), tabs[2], tabs[3])
+        else:
+            qkv = self.qkv(point.feat)
+            qkv_s = PF.gather_rows(qkv, gidx, inv, dup_of_point)
+            qkv_r = PF.rope_xyz_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, inv_freq)
+            out = PF.attn_varlen_qkvpacked(qkv_r, cu_seqlens, K, self.scale)
+            feat = self.proj(PF.gather_rows(out.reshape(-1, C), inv, gidx_primary).to(qkv.dtype))
+        point.feat = self.proj_drop(feat)
+        return point
+
+
+class SerializedAttention(RopeAttention):
     """:125-367.  rope_base falsy = m1 / m2 attention."""
 
     def __init__(self, channels, num_heads, patch_size, qkv_bias=True, qk_scale=None, attn_drop=0.0, proj_drop=0.0, order_index=0,
@@ -91,56 +166,11 @@ class SerializedAttention(_AttnM1):
                 rope_coord *= torch.empty(1, **dd).uniform_(-rescale_max, rescale_max).exp()
         return rope_coord
 
-    def _forward_dense_rope(self, point):
-        """enable_flash=False with RoPE (:303-318): rotation on [n, H, D], then the dense [P, H, K, K] formulation."""
-        H, K, C = self.num_heads, self.patch_size, self.channels
-        pad, unpad, _ = self.get_padding_and_inverse(point)
-        order = point.serialized_order[self.order_index][pad]
-        inverse = unpad[point.serialized_inverse[self.order_index]]
-        qkv = self.qkv(point.feat)[order].reshape(-1, 3, H, C // H)
-        rot = self.rope._rotate_packed(qkv, self._rope_coord(point, order))
-        q, k = (t.reshape(-1, K, H, C // H).permute(0, 2, 1, 3) for t in (rot[:, 0], rot[:, 1]))
-        v = qkv[:, 2].reshape(-1, K, H, C // H).permute(0, 2, 1, 3)
-        if self.upcast_attention:
-            q, k = q.float(), k.float()
-        attn = (q * self.scale) @ k.transpose(-2, -1)
-        if self.rpe is not None:
-            attn = attn + self.rpe(self.get_rel_pos(point, order))
-        if self.upcast_softmax:
-            attn = attn.float()
-        attn = torch.softmax(attn, dim=-1)
-        attn = self.attn_drop(attn).to(qkv.dtype)
-        feat = (attn @ v).transpose(1, 2).reshape(-1, C)[inverse]
-        point.feat = self.proj_drop(self.proj(feat))
-        return point
+    def _rope_on(self) -> bool:
+        return bool(self.rope_base)
 
-    def forward(self, point):
-        if not self.rope_base:
-            return super().forward(point)
-        if not self.enable_flash:
-            _, offset_host = point._host_facts()
-            smallest = min(b - a for a, b in zip([0] + list(offset_host[:-1]), offset_host))
-            self.patch_size = min(int(smallest), self.patch_size_max)      # :258-261
-            if not self._kernel_ok():
-                return self._forward_dense_rope(point)
-        H, K, C = self.num_heads, self.patch_size, self.channels
-        pad, _, cu_seqlens = self.get_padding_and_inverse(point)
-        gidx, inv, dup_of_point, gidx_primary, tabs = self._index_maps(point)
-        order = point.serialized_order[self.order_index][pad] if gidx is None else gidx
-        xyz = self._rope_coord(point, order)
-        if tabs is not None:
-            qkv_s = self.qkv(point.feat, tabs[0], tabs[1])                                     # padded, serialized rows (:272)
-            qkv_r = PF.rope_xyz_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, self.rope.inv_freq)   # :303-305,319-321 (bf16)
-            out = PF.attn_varlen_qkvpacked(qkv_r, cu_seqlens, K, self.scale)
-            feat = self.proj(out.reshape(-1, C).to(qkv_s.dtype), tabs[2], tabs[3])
-        else:
-            qkv = self.qkv(point.feat)
-            qkv_s = PF.gather_rows(qkv, gidx, inv, dup_of_point)
-            qkv_r = PF.rope_xyz_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, self.rope.inv_freq)
-            out = PF.attn_varlen_qkvpacked(qkv_r, cu_seqlens, K, self.scale)
-            feat = self.proj(PF.gather_rows(out.reshape(-1, C), inv, gidx_primary).to(qkv.dtype))
-        point.feat = self.proj_drop(feat)
-        return point
+    def _rope_inputs(self, point, order):
+        return self._rope_coord(point, order), self.rope.inv_freq
 
 
 class Block(_BlockM2):

@@ -116,3 +116,51 @@ def test_ptv3m3_matches_reference_golden(cuda, rope_kernel, monkeypatch):
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
         gn, rn = float(p.grad.norm()), ref[name]
         assert abs(gn - rn) <= 0.1 * rn + 1e-4 * gmax, (name, gn, rn)
+
+
+LITEPT_CFG = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 2, 1), enc_channels=(36, 72, 72, 144, 144), enc_num_head=(2, 4, 4, 8, 8),
+                  enc_patch_size=(128,) * 5, dec_channels=(36, 72, 72, 144), dec_num_head=(2, 4, 4, 8), dec_patch_size=(128,) * 4,
+                  drop_path=0.0, shuffle_orders=False)                                             # = make_golden_litept.py
+
+
+def test_litept_matches_reference_golden(cuda):
+    """the engine's module-level LitePT-v1 (pointcept_amd/litept.py: convolution stages, PointROPE attention stages with
+    head_dim 18, grid pooling with and without re-serialization, un-pooling decoder) against tests/golden/litept_tiny.npz = the
+    REFERENCE's own litept_v1.py running libs/pointrope's own pointrope_cpu: state-dict keys, eval features, train-mode loss and
+    every gradient norm.  (The reference's attention operands are fp16, the engine's bf16: inside the 2e-2 bar.)"""
+    from oracle import ptv3_model as om
+    from pointcept_amd import synthetic
+    from pointcept_amd.litept import LitePT
+
+    g = np.load(os.path.join(GOLD, "litept_tiny.npz"))
+    torch.manual_seed(0)
+    eng = LitePT(**LITEPT_CFG)
+    assert list(eng.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    sd = om.deterministic_state_dict(eng, 43)
+    assert abs(float(sum(float(v.double().abs().sum()) for v in sd.values())) - float(g["weight_checksum"])) < 1e-6 * float(g["weight_checksum"])
+    eng.load_state_dict(sd)
+    eng = eng.to(cuda)
+    batch = synthetic.collate([synthetic.indoor_scene(int(s), int(n)) for s, n in zip(g["scene_seeds"], g["n_points"])])
+    assert batch["grid_coord"].sum() == g["input_checksum"][0]
+    inp = synthetic.to_torch(batch, cuda)
+    inp["grid_size"] = 0.02
+    eng.eval()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        out = eng(dict(inp)).feat.float().cpu().numpy()
+    assert np.isfinite(out).all()
+    err = np.abs(out[::8] - g["feat_rows"]).max() / float(g["feat_absmax"])
+    assert err < 2e-2, f"engine LitePT vs reference golden: rel err {err:.3e}"
+    eng.train()
+    torch.manual_seed(5)
+    f = eng(dict(inp)).feat
+    loss = (f * torch.linspace(-1, 1, f.shape[1], device=f.device)).pow(2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-2 * abs(float(g["loss"])), (float(loss.detach()), float(g["loss"]))
+    ref = dict(zip([str(k) for k in g["grad_names"]], g["grad_norms"]))
+    gmax = max(ref.values())
+    for name, p in eng.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        gn, rn = float(p.grad.norm()), ref[name]
+        assert abs(gn - rn) <= 0.1 * rn + 1e-4 * gmax, (name, gn, rn)
+

@@ -52,11 +52,15 @@ def test_gpu_fullsize_test_bodies_on_cpu_standins(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name,kw", [("test_ptv3m3_matches_reference_golden", dict(rope_kernel=False)),
-                                     ("test_ptv3m3_matches_reference_golden", dict(rope_kernel=True))])
+                                     ("test_ptv3m3_matches_reference_golden", dict(rope_kernel=True)),
+                                     ("test_litept_matches_reference_golden", None)])
 def test_gpu_pending_hardware_test_bodies_on_cpu_standins(name, kw, monkeypatch):
     """tests/test_gpu_pending_hardware.py (never run on an MI355X yet): bodies on the CPU stand-ins"""
     import test_gpu_pending_hardware as T
 
     with mock_backend.cpu_ops():
-        getattr(T, name)(torch.device("cpu"), monkeypatch=monkeypatch, **kw)
+        if kw is None:
+            getattr(T, name)(torch.device("cpu"))
+        else:
+            getattr(T, name)(torch.device("cpu"), monkeypatch=monkeypatch, **kw)
 
