@@ -179,6 +179,17 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen, softmax_scale):
     return q.grad.to(torch.bfloat16)
 
 
+def rope3d_(tokens, positions, base, fwd):
+    from oracle import pointrope as orope
+
+    H, D = tokens.shape[-2], tokens.shape[-1]
+    t = tokens.detach().float().reshape(1, -1, H, D).numpy()
+    out = orope.pointrope(t, positions.reshape(1, -1, 3).numpy(), float(base), float(fwd))
+    with torch.no_grad():
+        tokens.copy_(torch.from_numpy(out).reshape(tokens.shape).to(tokens.dtype))
+    return tokens
+
+
 def rope3d_xyz(qkv, xyz, inv_freq, rot_slabs, sign, out_dtype=None):
     from oracle import pointrope as orope
 
@@ -228,7 +239,7 @@ _STANDINS = dict(
     attn_tables=attn_tables, pool_level_counts=pool_level_counts, pool_maps=pool_maps, pool_child_codes=pool_child_codes,
     gather_rows=gather_rows, segment_csr_fwd=segment_csr_fwd, segment_csr_bwd=segment_csr_bwd, HashTable=HashTable,
     rulebook_subm=rulebook_subm, rulebook_down=rulebook_down, spconv_fwd=spconv_fwd, spconv_wgrad=spconv_wgrad,
-    attn_varlen_fwd=attn_varlen_fwd, attn_varlen_bwd=attn_varlen_bwd, cross_entropy_fwd=cross_entropy_fwd, rope3d_xyz=rope3d_xyz,
+    attn_varlen_fwd=attn_varlen_fwd, attn_varlen_bwd=attn_varlen_bwd, cross_entropy_fwd=cross_entropy_fwd, rope3d_xyz=rope3d_xyz, rope3d_=rope3d_,
     attn_hd_supported=lambda d, k: 16 <= d <= 64 and k <= (1024 if d <= 32 else 672 if d <= 48 else 512),
     cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum, voxel_keys=voxel_keys,
     layer_norm_supported=lambda c: False, batch_norm_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)

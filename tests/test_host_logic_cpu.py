@@ -289,6 +289,59 @@ def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
                 sys.modules[k] = v
 
 
+@pytest.mark.needs_reference
+def test_b3_reference_litept_file_runs_unmodified_on_the_engine_operators(monkeypatch):
+    """B3 for LitePT: the REFERENCE's own litept_v1.py imported with `spconv.pytorch`, `flash_attn`, `torch_scatter` AND `pointrope`
+    bound to pointcept_amd.compat.install() (its PointROPE_func then calls the engine's `pointrope.pointrope`, its attention hands
+    fp16 rows to the engine's flash_attn mirror), against the same file on the oracle's stand-ins + libs/pointrope's own CPU kernel."""
+    import importlib
+    import sys
+    import types
+
+    import pointcept_amd.compat as compat
+    from oracle import ptv3_model as om
+
+    R = _import_reference_litept(monkeypatch)                    # reference file on oracle/shims.py + pointrope_cpu
+    names = ["spconv", "spconv.pytorch", "spconv.pytorch.modules", "flash_attn", "torch_scatter", "pointrope",
+             "pointcept.models.utils", "pointcept.models.utils.structure", "pointcept.models.utils.misc",
+             "pointcept.models.utils.serialization", "pointcept.models.modules", "pointcept.models.builder",
+             "pointcept.models.litept", "pointcept.models.litept.litept_v1"]
+    names += [k for k in list(sys.modules) if k.startswith("pointcept.models.utils.serialization.")]
+    saved = {k: sys.modules.pop(k, None) for k in names}
+    try:
+        compat.install(force=True)
+        pkg = types.ModuleType("pointcept.models.litept")
+        pkg.__path__ = [saved["pointcept.models.litept"].__path__[0]]
+        sys.modules["pointcept.models.litept"] = pkg
+        E = importlib.import_module("pointcept.models.litept.litept_v1")
+        assert E is not R and E.spconv.__name__ == "pointcept_amd.spconv_api" and hasattr(E, "PointROPE_func")
+        assert E._kernels.__name__ == "pointcept_amd.pointrope_api"
+        cfg = dict(LITEPT_TINY)
+        torch.manual_seed(0)
+        a, b = R.LitePT(**cfg), E.LitePT(**cfg)
+        sd = om.deterministic_state_dict(a, 44)
+        a.load_state_dict(sd)
+        b.load_state_dict(sd)
+        mb = _batch([600, 240], seed0=640)
+        mb["grid_size"] = 0.02
+        feats = []
+        with mock_backend.cpu_ops():
+            for net in (a, b):
+                net.train()
+                torch.manual_seed(9)
+                f = net({k: v for k, v in mb.items()}).feat
+                (f * torch.linspace(-1, 1, f.shape[1])).pow(2).mean().backward()
+                feats.append(f.detach())
+        assert _rel(feats[1], feats[0]) < 1e-2            # fp16 rows re-rounded to bf16 inside the engine's attention mirror
+        _grad_check(b, a, 6e-2)
+    finally:
+        for k in names:
+            sys.modules.pop(k, None)
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+
+
 def test_physically_sorted_working_copy_and_restore():
     """Point.physically_sorted re-expresses every per-point tensor and all k serialization maps in the row order of the
     first curve; restore_order brings features back (and its backward routes gradients to the caller's rows)."""
