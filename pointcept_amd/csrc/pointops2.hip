@@ -182,6 +182,12 @@ p2_pair_agg_bwd_scatter_kernel(const float* __restrict__ go, const float* __rest
 }
 
 static unsigned p2_grid(int64_t n) { return (unsigned)ptc_cdiv(n > 0 ? n : 1, P2_THREADS); }
+// one thread per work item on a 1-D grid: the item count must fit 2^31 - 1 workgroups
+static bool p2_fits(int64_t a, int64_t b, int64_t c = 1) {
+  if (a == 0 || b == 0 || c == 0) return true;
+  const int64_t lim = (int64_t)0x7fffffff * P2_THREADS;
+  return a <= lim / b && a * b <= lim / c;
+}
 
 extern "C" int ptc_pair_dot_fwd(const float* q, const float* k, const int32_t* i0, const int32_t* i1, const float* table_q,
                                 const float* table_k, const int32_t* rel_idx, int with_qk, int64_t M, int H, int d, float* out,
@@ -191,7 +197,7 @@ extern "C" int ptc_pair_dot_fwd(const float* q, const float* k, const int32_t* i
   PTC_REQUIRE(q && i0 && out, PTC_EINVAL, "ptc_pair_dot_fwd: null buffer");
   PTC_REQUIRE(!(with_qk || table_k) || (k && i1), PTC_EINVAL, "ptc_pair_dot_fwd: the q.k / k.table terms need k and i1");
   PTC_REQUIRE(!(table_q || table_k) || rel_idx, PTC_EINVAL, "ptc_pair_dot_fwd: tables need rel_idx");
-  PTC_REQUIRE(M * H < (1ll << 40), PTC_EUNSUPPORTED, "ptc_pair_dot_fwd: too many pairs");
+  PTC_REQUIRE(p2_fits(M, H), PTC_EUNSUPPORTED, "ptc_pair_dot_fwd: too many pairs");
   hipLaunchKernelGGL(p2_pair_dot_fwd_kernel, dim3(p2_grid(M * H)), dim3(P2_THREADS), 0, (hipStream_t)stream, q, k, i0, i1, table_q,
                      table_k, rel_idx, with_qk, M, H, d, out);
   PTC_CHECK_LAUNCH("p2_pair_dot_fwd_kernel");
@@ -203,6 +209,7 @@ extern "C" int ptc_pair_dot_bwd(const float* grad_out, const float* q, const flo
                                 int64_t M, int64_t Nq, int64_t Nk, int64_t L, int H, int d, float* dq, float* dk, float* dtable_q,
                                 float* dtable_k, ptc_stream_t stream) {
   PTC_REQUIRE(M >= 0 && Nq >= 0 && Nk >= 0 && L >= 0 && H >= 1 && d >= 1, PTC_EINVAL, "ptc_pair_dot_bwd: bad sizes");
+  PTC_REQUIRE(p2_fits(M, H, d) && p2_fits(Nq, H, d), PTC_EUNSUPPORTED, "ptc_pair_dot_bwd: too many work items for one launch");
   hipStream_t s = (hipStream_t)stream;
   const size_t row = (size_t)H * d * sizeof(float);
   const bool seg = offsets != nullptr;
@@ -236,6 +243,7 @@ extern "C" int ptc_pair_aggregate_fwd(const float* attn, const float* v, const i
                                       const float* table_v, const int32_t* rel_idx, int64_t M, int64_t Nq, int H, int d, float* out,
                                       ptc_stream_t stream) {
   PTC_REQUIRE(M >= 0 && Nq >= 0 && H >= 1 && d >= 1, PTC_EINVAL, "ptc_pair_aggregate_fwd: bad sizes");
+  PTC_REQUIRE(p2_fits(M, H, d) && p2_fits(Nq, H, d), PTC_EUNSUPPORTED, "ptc_pair_aggregate_fwd: too many work items for one launch");
   hipStream_t s = (hipStream_t)stream;
   if (Nq == 0) return PTC_OK;
   PTC_REQUIRE(out, PTC_EINVAL, "ptc_pair_aggregate_fwd: null buffer");
@@ -259,6 +267,7 @@ extern "C" int ptc_pair_aggregate_bwd(const float* grad_out, const float* attn, 
                                       const float* table_v, const int32_t* rel_idx, int64_t M, int64_t Nv, int64_t L, int H, int d,
                                       float* dattn, float* dv, float* dtable_v, ptc_stream_t stream) {
   PTC_REQUIRE(M >= 0 && Nv >= 0 && L >= 0 && H >= 1 && d >= 1, PTC_EINVAL, "ptc_pair_aggregate_bwd: bad sizes");
+  PTC_REQUIRE(p2_fits(M, H, d), PTC_EUNSUPPORTED, "ptc_pair_aggregate_bwd: too many work items for one launch");
   hipStream_t s = (hipStream_t)stream;
   const size_t row = (size_t)H * d * sizeof(float);
   if (dv) PTC_HIP(hipMemsetAsync(dv, 0, (size_t)Nv * row, s));

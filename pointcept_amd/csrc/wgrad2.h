@@ -315,6 +315,9 @@ static inline int w2_env_int(const char* name, int dflt) {
 
 static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out, bool want_bias = false) {
   static const int cot_max = w2_env_int("PTC_W2_COT_MAX", 8), cit_max = w2_env_int("PTC_W2_CIT_MAX", 4);  // tuning knobs
+  // workgroups aimed at per launch and 32-row steps a workgroup must at least own (sweep knobs for the small weight gradients of
+  // the deep stages: 103 launches of ~29 us per step at 1008 workgroups x ~5 steps per wave)
+  static const int target_wgs = w2_env_int("PTC_W2_TARGET_WGS", 1024), min_steps = w2_env_int("PTC_W2_MIN_STEPS", 16);
   W2Plan p;
   // channel tiles: 64x64 accumulators by default; channel counts that are multiples of 32 but not of 64
   // (SpUNet's 96-channel decoder) take 32-wide input tiles / a 96-wide output tile so that no MFMA runs on padding
@@ -338,8 +341,8 @@ static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out, bool wa
   p.ci_blocks = (int)ptc_cdiv(c_in, p.cit * 16);
   p.groups = (int)ptc_cdiv(kv, p.kg);
   const int64_t steps = ptc_cdiv(n_out, W2_ROWS);
-  int64_t gx = 1024 / ((int64_t)p.groups * p.co_blocks * p.ci_blocks);
-  const int64_t max_gx = ptc_cdiv(steps, 16);  // at least ~4 steps per wave
+  int64_t gx = (int64_t)target_wgs / ((int64_t)p.groups * p.co_blocks * p.ci_blocks);
+  const int64_t max_gx = ptc_cdiv(steps, min_steps > 0 ? min_steps : 16);  // at least ~4 steps per wave
   if (gx > max_gx) gx = max_gx;
   if (gx > 512) gx = 512;
   if (gx < 1) gx = 1;

@@ -376,6 +376,18 @@ def main():
         for cin, cout in ((32, 32), (32, 64), (32, 128), (32, 256), (64, 32), (64, 64), (64, 128), (64, 192), (64, 256), (128, 64),
                           (128, 128), (128, 256), (256, 64), (256, 128)):
             bench_linear(rows, 819200, cin, cout, res["linprobe"])
+    if "wgrad_small" in only:   # the weight gradients of the deep stages (~103 launches of ~29 us per step), own vs library
+        res["wgrad_small"] = []
+        dt = torch.bfloat16
+        for n, cin, cout in ((11400, 256, 768), (11400, 256, 256), (11400, 256, 1024), (11400, 1024, 256), (2640, 512, 1536), (2640, 512, 512),
+                             (49256, 128, 384), (49256, 128, 128), (49256, 128, 512), (49256, 512, 128)):
+            x, g = torch.randn(n, cin, device=DEV).to(dt), torch.randn(n, cout, device=DEV).to(dt)
+            t_own = timeit(lambda: ops.spconv_wgrad(x, g, None, want_bias=True), iters=50)
+            t_lib = timeit(lambda: (g.t() @ x, g.sum(0)), iters=50)
+            by, fl = n * (cin + cout) * 2 + cin * cout * 4, 2.0 * n * cin * cout
+            res["wgrad_small"].append({"shape": [n, cin, cout], "own": roof(by, fl, t_own), "lib": roof(by, fl, t_lib)})
+            rows.append(f"wgrad n={n:6d} {cin:4d}->{cout:4d} | own {t_own * 1e6:7.1f} us  lib {t_lib * 1e6:7.1f} us | roof frac own "
+                        f"{res['wgrad_small'][-1]['own']['roof_frac']}")
     if want("ln"):
         for n, c in stages:
             bench_ln(rows, n, c, res["ln"])

@@ -4,6 +4,8 @@
 #   bench      bench.py (default switches)   ab:<ENV=V,...>  bench.py with switches (no cpu baseline)
 #   prof       rocprofv3 kernel stats of bench.py
 #   roof       rocprofv3 stats + PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) of the roofline kernel
+#   pending    tests/test_gpu_pending_hardware.py with PTC_RUN_PENDING=1 (code that has not run on hardware yet)
+#   w2sweep    small weight gradients of the deep stages under the PTC_W2_TARGET_WGS / PTC_W2_MIN_STEPS plan knobs
 TAG=${1:-s}; shift
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
@@ -73,6 +75,11 @@ for sec in "$@"; do
             rm -rf $O/${tg}_stats $O/${tg}_fetch $O/${tg}_write $O/${tg}_tcp $O/${tg}_tcc $O/${tg}_sq $O/${tg}_sq2
             cd /tmp
           done; unset PTC_LK_SHAPE; ls $O | grep linear_pmc;;
+    pending) PTC_RUN_PENDING=1 timeout 900 python -m pytest tests/test_gpu_pending_hardware.py -q -m gpu > $O/${TAG}_pending.log 2>&1; echo "pending rc=$?" >> $O/${TAG}_env.log; tail -15 $O/${TAG}_pending.log;;
+    w2sweep) for wgs in 1024 768 512 384 256; do for ms in 16 8 32; do
+            echo "== PTC_W2_TARGET_WGS=$wgs PTC_W2_MIN_STEPS=$ms" >> $O/${TAG}_w2sweep.log
+            PTC_W2_TARGET_WGS=$wgs PTC_W2_MIN_STEPS=$ms timeout 300 python tools/bench_ops.py --only wgrad_small >> $O/${TAG}_w2sweep.log 2>&1
+          done; done; grep -v "^$" $O/${TAG}_w2sweep.log | cut -c1-200 | tail -80;;
     *) echo "unknown section $sec";;
   esac
 done
