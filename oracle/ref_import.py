@@ -14,6 +14,10 @@ import types
 
 REF = os.environ.get("POINTCEPT_REFERENCE", "/root/reference")
 
+# /root/reference is read-only by contract: importing its files must not drop __pycache__ directories next to them.  The flag is
+# process-wide and set at import of this module, i.e. before any reference file is imported (the cost is re-parsing ~20 files).
+sys.dont_write_bytecode = True
+
 
 def available() -> bool:
     return os.path.isdir(os.path.join(REF, "pointcept", "models"))

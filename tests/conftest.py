@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+sys.dont_write_bytecode = True     # the needs_reference tests import files from /root/reference, which must stay untouched
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
