@@ -342,6 +342,61 @@ def test_b3_reference_litept_file_runs_unmodified_on_the_engine_operators(monkey
                 sys.modules[k] = v
 
 
+@pytest.mark.needs_reference
+def test_b3_reference_spunet_variants_run_unmodified_on_the_engine_operators():
+    """B3 for the other SparseUNet files of the reference -- spconv_unet_v1m2_bn_momentum.py ("SpUNet-v1m2") and
+    spconv_unet_v1m3_pdnorm.py ("SpUNet-v1m3": prompt-driven BatchNorm, modules called with [tensor, condition, context] lists) --
+    imported with `spconv.pytorch` bound to pointcept_amd.compat.install(), against the same files on the oracle's stand-ins."""
+    import importlib
+    import sys
+
+    import pointcept_amd.compat as compat
+    from oracle import ptv3_model as om
+    from oracle import ref_import
+
+    ref_import.load()
+    mods = ["pointcept.models.sparse_unet.spconv_unet_v1m2_bn_momentum", "pointcept.models.sparse_unet.spconv_unet_v1m3_pdnorm"]
+    for m in mods:
+        sys.modules.pop(m, None)
+    builder = sys.modules["pointcept.models.builder"]
+    for name in ("SpUNet-v1m2", "SpUNet-v1m3"):
+        builder.MODELS._module_dict.pop(name, None)
+    R = [importlib.import_module(m) for m in mods]
+    names = ["spconv", "spconv.pytorch", "spconv.pytorch.modules", "flash_attn", "torch_scatter", "pointcept.models.builder"] + mods
+    saved = {k: sys.modules.pop(k, None) for k in names}
+    try:
+        compat.install(force=True)
+        E = [importlib.import_module(m) for m in mods]
+        assert all(e is not r and e.spconv.__name__ == "pointcept_amd.spconv_api" for e, r in zip(E, R))
+        batch = _batch([500, 220], seed0=650)
+        scfg = dict(base_channels=16, channels=(16, 32, 32, 48, 48, 32, 32, 16), layers=(1, 1, 1, 1, 1, 1, 1, 1))
+        cases = [(0, dict(in_channels=6, num_classes=13, bn_momentum=0.02, **scfg), {}),
+                 (1, dict(in_channels=6, num_classes=13, context_channels=32, zero_init=False, **scfg),
+                  dict(condition="S3DIS", context=torch.randn(1, 32, generator=torch.Generator().manual_seed(2))))]
+        with mock_backend.cpu_ops():
+            for mi, cfg, extra in cases:
+                torch.manual_seed(0)
+                a, b = R[mi].SpUNetBase(**cfg), E[mi].SpUNetBase(**cfg)
+                assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+                sd = om.deterministic_state_dict(a, 45 + mi)
+                a.load_state_dict(sd)
+                b.load_state_dict(sd)
+                outs = []
+                for net in (a, b):
+                    net.train()
+                    o = net({**{k: v for k, v in batch.items()}, **extra})
+                    torch.nn.functional.cross_entropy(o, batch["segment"] % 13, ignore_index=-1).backward()
+                    outs.append(o.detach())
+                assert outs[0].shape == (720, 13) and _rel(outs[1], outs[0]) < 1e-4, mods[mi]
+                _grad_check(b, a, 2e-3)
+    finally:
+        for k in names:
+            sys.modules.pop(k, None)
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+
+
 def test_physically_sorted_working_copy_and_restore():
     """Point.physically_sorted re-expresses every per-point tensor and all k serialization maps in the row order of the
     first curve; restore_order brings features back (and its backward routes gradients to the caller's rows)."""
