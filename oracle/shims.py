@@ -240,6 +240,30 @@ def scatter(src, index, dim=0, dim_size=None, reduce="sum"):
     return out
 
 
+def voxel_grid(pos, size, batch=None, start=None, end=None):
+    """torch_geometric.nn.pool.voxel_grid (third party, absent here; point_transformer_v2m2_base.py:15,254-256) = torch_cluster's
+    grid_cluster on [pos | batch]: cell = trunc((pos - start) / size) per dimension, linearised with x fastest and the batch index
+    slowest (number of cells per dimension from `end`, default the data maximum).  Only the ORDER of the ids matters to the caller
+    (it runs torch.unique on them and needs scenes to stay contiguous)."""
+    pos = pos.unsqueeze(-1) if pos.dim() == 1 else pos
+    dim = pos.shape[1]
+    if batch is None:
+        batch = pos.new_zeros(pos.shape[0], dtype=torch.long)
+    p = torch.cat([pos, batch.view(-1, 1).to(pos.dtype)], dim=-1)
+    sz = torch.tensor(([float(size)] * dim if not isinstance(size, (list, tuple)) else list(size)) + [1.0], dtype=pos.dtype)
+    st = torch.zeros(dim + 1, dtype=pos.dtype) if start is None or not isinstance(start, (list, tuple, torch.Tensor)) else torch.cat(
+        [torch.as_tensor(start, dtype=pos.dtype).reshape(-1), pos.new_zeros(1)])
+    if start is not None and not isinstance(start, (list, tuple, torch.Tensor)):
+        st = torch.tensor([float(start)] * dim + [0.0], dtype=pos.dtype)
+    elif start is None:
+        st = p.min(0).values
+    en = p.max(0).values if end is None else torch.cat([torch.as_tensor(end, dtype=pos.dtype).reshape(-1), batch.max().to(pos.dtype).reshape(1)])
+    p = p - st.unsqueeze(0)
+    num = torch.div(en - st, sz).to(torch.long) + 1
+    stride = torch.cat([torch.ones(1, dtype=torch.long), num.cumprod(0)])[: dim + 1]
+    return (torch.div(p, sz.unsqueeze(0)).to(torch.long) * stride.unsqueeze(0)).sum(1)
+
+
 def scatter_min(src, index, dim=0, out=None, dim_size=None):
     """torch_scatter.scatter_min over dim 0 (pointcept/datasets/utils.py:249): (per-group minimum, unused argmin)."""
     assert dim == 0
@@ -283,3 +307,5 @@ def install_third_party(mods=None):
         Identity=Identity, modules=sp_modules)
     tg = mod("torch_geometric")
     tg.utils = mod("torch_geometric.utils", scatter=scatter)
+    tg.nn = mod("torch_geometric.nn")
+    tg.nn.pool = mod("torch_geometric.nn.pool", voxel_grid=voxel_grid)

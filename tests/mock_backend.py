@@ -179,6 +179,27 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen, softmax_scale):
     return q.grad.to(torch.bfloat16)
 
 
+def knn_query(nsample, xyz, offset, new_xyz, new_offset):
+    from oracle import pointops as opo
+
+    i, d = opo.knn_query(int(nsample), _np(xyz), _np(offset), _np(new_xyz), _np(new_offset))
+    return torch.from_numpy(i), torch.from_numpy(d)
+
+
+def ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz, new_offset, order=None):
+    from oracle import pointops as opo
+
+    i, d = opo.ball_query(int(nsample), float(max_radius), float(min_radius), _np(xyz), _np(offset), _np(new_xyz), _np(new_offset),
+                          order=None if order is None else _np(order))
+    return torch.from_numpy(i), torch.from_numpy(d)
+
+
+def farthest_point_sampling(xyz, offset, new_offset):
+    from oracle import pointops as opo
+
+    return torch.from_numpy(opo.farthest_point_sampling(_np(xyz), _np(offset), _np(new_offset)))
+
+
 def rope3d_(tokens, positions, base, fwd):
     from oracle import pointrope as orope
 
@@ -239,7 +260,8 @@ _STANDINS = dict(
     attn_tables=attn_tables, pool_level_counts=pool_level_counts, pool_maps=pool_maps, pool_child_codes=pool_child_codes,
     gather_rows=gather_rows, segment_csr_fwd=segment_csr_fwd, segment_csr_bwd=segment_csr_bwd, HashTable=HashTable,
     rulebook_subm=rulebook_subm, rulebook_down=rulebook_down, spconv_fwd=spconv_fwd, spconv_wgrad=spconv_wgrad,
-    attn_varlen_fwd=attn_varlen_fwd, attn_varlen_bwd=attn_varlen_bwd, cross_entropy_fwd=cross_entropy_fwd, rope3d_xyz=rope3d_xyz, rope3d_=rope3d_,
+    attn_varlen_fwd=attn_varlen_fwd, attn_varlen_bwd=attn_varlen_bwd, cross_entropy_fwd=cross_entropy_fwd, rope3d_xyz=rope3d_xyz, rope3d_=rope3d_, knn_query=knn_query, ball_query=ball_query,
+    farthest_point_sampling=farthest_point_sampling,
     attn_hd_supported=lambda d, k: 16 <= d <= 64 and k <= (1024 if d <= 32 else 672 if d <= 48 else 512),
     cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum, voxel_keys=voxel_keys,
     layer_norm_supported=lambda c: False, batch_norm_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)

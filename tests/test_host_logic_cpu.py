@@ -397,6 +397,88 @@ def test_b3_reference_spunet_variants_run_unmodified_on_the_engine_operators():
                 sys.modules[k] = v
 
 
+@pytest.mark.needs_reference
+def test_b3_reference_ptv1_ptv2_files_run_unmodified_on_the_pointops_mirror(monkeypatch):
+    """B3 for libs/pointops' callers: the REFERENCE's own point_transformer_seg.py ("PointTransformer-Seg26": farthest point sampling,
+    kNN grouping with relative coordinates, inverse-distance interpolation) and point_transformer_v2m2_base.py ("PT-v2m2": kNN,
+    grouping, torch_scatter pooling) imported with `pointops` / `torch_scatter` bound to pointcept_amd.compat.install(), against the
+    same files on the reference's own pointops python package (oracle/pointops_c.py stand-ins for its compiled kernels) and the
+    oracle's torch_scatter stand-in: same logits, same gradients."""
+    import importlib
+    import sys
+    import types
+
+    import pointcept_amd.compat as compat
+    from oracle import pointops_c, ref_import
+    from oracle import ptv3_model as om
+
+    ref_import.load()
+    P = pointops_c.load_reference_package()
+    # point_transformer_seg.py:100 builds its offsets with torch.cuda.IntTensor: on this GPU-less container the constructor is pointed
+    # at the CPU equivalent (the file itself stays untouched)
+    monkeypatch.setattr(torch.cuda, "IntTensor", lambda v: torch.tensor(v, dtype=torch.int32), raising=False)
+    mods = ["pointcept.models.point_transformer.point_transformer_seg", "pointcept.models.point_transformer_v2.point_transformer_v2m2_base"]
+    pkgs = {"pointcept.models.point_transformer": "/pointcept/models/point_transformer",
+            "pointcept.models.point_transformer_v2": "/pointcept/models/point_transformer_v2"}
+
+    def fresh_import():
+        for k in list(pkgs) + mods + ["pointcept.models.point_transformer.utils"]:
+            sys.modules.pop(k, None)
+        for k, rel in pkgs.items():
+            pk = types.ModuleType(k)
+            pk.__path__ = [ref_import.REF + rel]
+            sys.modules[k] = pk
+        reg = sys.modules["pointcept.models.builder"].MODELS._module_dict
+        for name in ("PointTransformer-Seg26", "PointTransformer-Seg38", "PointTransformer-Seg50", "PT-v2m2"):
+            reg.pop(name, None)
+        return [importlib.import_module(m) for m in mods]
+
+    names = ["pointops", "torch_scatter", "pointcept.models.builder"]
+    saved = {k: sys.modules.get(k) for k in names + list(pkgs) + mods + ["pointcept.models.point_transformer.utils"]}
+    try:
+        sys.modules["pointops"] = P                                # reference side: its own python package
+        R = fresh_import()
+        sys.modules.pop("pointcept.models.builder", None)
+        compat.install(force=True)                                 # engine side: the mirrors
+        sys.modules["pointcept.models.builder"] = saved["pointcept.models.builder"]
+        E = fresh_import()
+        assert E[0].pointops.__name__ == "pointcept_amd.pointops_api" and R[0].pointops is P
+        assert E[1].segment_csr.__module__ == "pointcept_amd.torch_scatter_api"
+        g = torch.Generator().manual_seed(8)
+        n_pts = 2600                                            # PTv1 keeps 1 / 256 of the points in its last stage
+        coord = torch.rand(n_pts, 3, generator=g) * torch.tensor([2.0, 2.0, 1.0])
+        data = dict(coord=coord, feat=torch.cat([coord, torch.rand(n_pts, 3, generator=g)], 1), offset=torch.tensor([1500, n_pts]),
+                    segment=torch.randint(0, 13, (n_pts,), generator=g))
+        v2cfg = dict(in_channels=6, num_classes=13, patch_embed_depth=1, patch_embed_channels=12, patch_embed_groups=3,
+                     patch_embed_neighbours=8, enc_depths=(1, 1), enc_channels=(24, 48), enc_groups=(3, 6), enc_neighbours=(8, 8),
+                     dec_depths=(1, 1), dec_channels=(12, 24), dec_groups=(3, 3), dec_neighbours=(8, 8), grid_sizes=(0.25, 0.5))
+        builders = [(lambda m: m.PointTransformerSeg26(in_channels=6, num_classes=13)), (lambda m: m.PointTransformerV2(**v2cfg))]
+        with mock_backend.cpu_ops():
+            for mi, build in enumerate(builders):
+                torch.manual_seed(0)
+                a, b = build(R[mi]), build(E[mi])
+                assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+                sd = om.deterministic_state_dict(a, 47 + mi)
+                a.load_state_dict(sd)
+                b.load_state_dict(sd)
+                outs = []
+                for net in (a, b):
+                    net.train()
+                    o = net({k: v.clone() for k, v in data.items()})
+                    torch.nn.functional.cross_entropy(o, data["segment"]).backward()
+                    outs.append(o.detach())
+                assert outs[0].shape == (n_pts, 13) and _rel(outs[1], outs[0]) < 1e-4, mods[mi]
+                ga = dict(a.named_parameters())
+                gmax = max(float(p.grad.norm()) for p in ga.values())
+                for name, p in b.named_parameters():        # (biases in front of a BatchNorm have a zero gradient: fp32 noise on both sides)
+                    assert float((p.grad - ga[name].grad).norm()) <= 2e-3 * float(ga[name].grad.norm()) + 2e-5 * gmax, (mods[mi], name)
+    finally:
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
+
+
 def test_physically_sorted_working_copy_and_restore():
     """Point.physically_sorted re-expresses every per-point tensor and all k serialization maps in the row order of the
     first curve; restore_order brings features back (and its backward routes gradients to the caller's rows)."""

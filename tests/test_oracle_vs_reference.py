@@ -386,3 +386,94 @@ def test_rope_xyz_oracle_matches_the_reference_point3drope_live():
             got = orope.rope_xyz(t.numpy(), xyz.numpy(), ref.inv_freq.numpy())
             assert np.abs(got - want.numpy()).max() <= 2e-6 * max(1.0, float(want.abs().max()))
 
+
+def test_pointops_mirror_against_the_reference_python_package():
+    """libs/pointops end to end above the kernels: the REFERENCE's own python package (libs/pointops/functions/*.py -- autograd
+    Functions, sqrt / inverse-distance weights / masks / argument defaults) imported on CPU stand-ins of its compiled `_C` kernels
+    (oracle/pointops_c.py), against the engine's mirror (pointcept_amd/pointops_api.py on the CPU stand-ins of ITS kernels): every
+    exported operator, forward and gradients, on a ragged three-scene batch incl. -1 (missing neighbour) slots."""
+    import mock_backend
+    from oracle import pointops_c
+    from pointcept_amd import pointops_api as M
+
+    P = pointops_c.load_reference_package()
+    g = torch.Generator().manual_seed(11)
+    xyz = torch.rand(230, 3, generator=g)
+    offset = torch.tensor([100, 106, 230], dtype=torch.int32)            # the middle scene has 6 points: fewer than nsample
+    new_xyz = xyz[::3].contiguous()
+    new_offset = torch.tensor([34, 36, 77], dtype=torch.int32)
+    feat = torch.randn(230, 8, generator=g)
+
+    def both(fn_name, *args, **kw):
+        with mock_backend.cpu_ops():
+            return getattr(P, fn_name)(*args, **kw), getattr(M, fn_name)(*args, **kw)
+
+    def same(a, b, tol=0.0):
+        if isinstance(a, (tuple, list)):
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                same(x, y, tol)
+            return
+        assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+        if tol == 0.0:
+            assert torch.equal(a, b)
+        else:
+            assert float((a.float() - b.float()).abs().max()) <= tol * max(1.0, float(a.float().abs().max()))
+
+    # ---- queries and sampling (integer outputs exact; distances: same arithmetic)
+    same(*both("knn_query", 8, xyz, offset))
+    same(*both("knn_query", 5, xyz, offset, new_xyz, new_offset))
+    same(*both("ball_query", 6, 0.3, 0.0, xyz, offset, new_xyz, new_offset))
+    torch.manual_seed(3)
+    with mock_backend.cpu_ops():
+        r = P.random_ball_query(6, 0.4, 0.05, xyz, offset, new_xyz, new_offset)
+    torch.manual_seed(3)
+    with mock_backend.cpu_ops():
+        e = M.random_ball_query(6, 0.4, 0.05, xyz, offset, new_xyz, new_offset)      # same randperm calls in the same order
+    same(r, e)
+    fps_off = torch.tensor([25, 27, 58], dtype=torch.int32)
+    same(*both("farthest_point_sampling", xyz, offset, fps_off))
+
+    # ---- differentiable operators: outputs and every gradient
+    with mock_backend.cpu_ops():
+        idx, _ = M.knn_query(8, xyz, offset, new_xyz, new_offset)                      # has -1 slots in the 6-point scene
+    assert int((idx < 0).sum()) > 0
+    idx_full = idx.clamp(min=0)
+    n, ns = 77, 8
+    pos = torch.randn(n, ns, 8, generator=g)
+    wgt = torch.randn(n, ns, 4, generator=g)
+    it, ir = torch.randint(0, 230, (500,), generator=g), torch.randint(0, 230, (500,), generator=g)
+    qk = torch.randn(230, 2, 4, generator=g)
+    kk = torch.randn(230, 2, 4, generator=g)
+    aw = torch.randn(500, 2, generator=g)
+    cases = [
+        ("grouping", lambda T, f, x: T.grouping(idx, f, x, new_xyz, with_xyz=True), (feat, xyz)),
+        ("grouping", lambda T, f, x: T.grouping(idx, f, x), (feat, xyz)),
+        ("grouping2", lambda T, f: T.grouping2(f, idx_full), (feat,)),
+        ("interpolation", lambda T, f: T.interpolation(xyz, new_xyz, f, offset, new_offset), (feat,)),
+        ("interpolation2", lambda T, f: T.interpolation2(xyz, new_xyz, f, offset, new_offset, 3), (feat,)),
+        ("subtraction", lambda T, a, b: T.subtraction(a, b, idx_full[:, :5].contiguous() % 77), (feat[:77].contiguous(), feat[77:154].contiguous())),
+        ("aggregation", lambda T, a, p, w: T.aggregation(a, p, w, idx_full % 77), (feat[:77].contiguous(), pos, wgt)),
+        ("attention_relation_step", lambda T, q, k: T.attention_relation_step(q, k, torch.ones(4), it.int(), ir.int()), (qk, kk)),
+        ("attention_fusion_step", lambda T, w, v: T.attention_fusion_step(w, v, it.int(), ir.int()), (aw, kk)),
+        ("knn_query_and_group", lambda T, f: T.knn_query_and_group(f, xyz, offset, new_xyz, new_offset, nsample=4, with_xyz=True)[0], (feat,)),
+        ("ball_query_and_group", lambda T, f: T.ball_query_and_group(f, xyz, offset, new_xyz, new_offset, max_radio=0.35, min_radio=0.0,
+                                                                      nsample=5, with_xyz=True)[0], (feat,)),
+        ("query_and_group", lambda T, f: T.query_and_group(4, xyz, new_xyz, f, None, offset, new_offset, dilation=1)[0], (feat,)),
+    ]
+    for name, fn, tensors in cases:
+        outs, grads = [], []
+        for T in (P, M):
+            leaves = [t.clone().requires_grad_(True) for t in tensors]
+            with mock_backend.cpu_ops():
+                o = fn(T, *leaves)
+            probe = torch.randn(o.shape, generator=torch.Generator().manual_seed(1))
+            (o * probe).sum().backward()
+            outs.append(o.detach())
+            grads.append([t.grad for t in leaves])
+        same(outs[0], outs[1], 1e-6)
+        for a, b in zip(*grads):
+            assert (a is None) == (b is None), name
+            if a is not None:
+                same(a, b, 1e-5)
+
