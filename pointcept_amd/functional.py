@@ -103,6 +103,8 @@ class _CastCache:
         if w.dtype == dt:
             return w
         owner = w._base if w._base is not None else w     # conv weights arrive as views of the Parameter
+        if owner.grad_fn is not None:                      # a weight COMPUTED this step (folded conv + Linear): nothing to cache
+            return w.to(dt)
         if not w.is_contiguous() or (self.cuda_only and not w.is_cuda) or owner.numel() != w.numel() or not owner.is_contiguous():
             return w.to(dt)
         key = (w.data_ptr(), w.numel(), dt)

@@ -804,6 +804,54 @@ def test_flash_attn_mirror_accepts_fp16_like_liteptS_call_site():
     assert _rel(out.detach().float(), want) < 5e-3 and float(qkv.grad.float().abs().max()) > 0
 
 
+def test_folded_cpe_conv_and_linear_is_the_same_function(monkeypatch):
+    """config.FOLD_CPE (default off, a round-3 candidate): Linear(SubMConv3d(x)) as ONE convolution with weights W_lin W_k -- same
+    output and same gradients for all four parameter tensors and the input at operator level (1e-5), and a whole PT-v3m1 step with
+    the switch on agrees with the switch off at the bf16 level of the attention operands."""
+    from oracle import ptv3_model as om
+    from pointcept_amd import config
+    from pointcept_amd import nn as PNN
+    from pointcept_amd import spconv_api as spconv
+    from pointcept_amd.point_transformer_v3 import PointTransformerV3
+
+    batch = _batch([300, 120], seed0=660)
+    torch.manual_seed(1)
+    conv = spconv.SubMConv3d(16, 16, kernel_size=3, bias=True, indice_key="t")
+    lin = PNN.Linear(16, 24)
+    idx = torch.cat([torch.repeat_interleave(torch.arange(2), torch.tensor([300, 120]))[:, None].int(), batch["grid_coord"].int()], 1)
+    res = []
+    with mock_backend.cpu_ops():
+        for folded in (False, True):
+            feat = torch.randn(420, 16, generator=torch.Generator().manual_seed(2)).requires_grad_(True)
+            x = spconv.SparseConvTensor(feat, idx.contiguous(), [int(batch["grid_coord"].max()) + 8] * 3, 2)
+            for p in list(conv.parameters()) + list(lin.parameters()):
+                p.grad = None
+            out = conv(x, post_linear=lin).features if folded else lin(conv(x).features)
+            (out * torch.linspace(-1, 1, 24)).pow(2).sum().backward()
+            res.append([out.detach(), feat.grad] + [p.grad.clone() for p in list(conv.parameters()) + list(lin.parameters())])
+    for a, b in zip(*res):
+        assert _rel(b, a) < 1e-5
+    # whole model, fp32: the switch changes nothing beyond fp32 rounding
+    cfg = dict(TINY, enable_flash=True)
+    outs = []
+    for fold in (False, True):
+        monkeypatch.setattr(config, "FOLD_CPE", fold)
+        torch.manual_seed(0)
+        net = PointTransformerV3(**cfg)
+        net.load_state_dict(om.deterministic_state_dict(net, 24))
+        with mock_backend.cpu_ops():
+            net.train()
+            torch.manual_seed(9)
+            f = net({k: v for k, v in batch.items()}).feat
+            (f * torch.linspace(-1, 1, f.shape[1])).pow(2).mean().backward()
+        outs.append((f.detach(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    # (fp32 differences of 1e-6 upstream flip bf16 roundings of the attention operands: the model-level bar is the bf16 one)
+    assert _rel(outs[1][0], outs[0][0]) < 5e-3
+    gmax = max(float(g.norm()) for g in outs[0][1].values())
+    for k, g in outs[0][1].items():
+        assert float((outs[1][1][k] - g).norm()) <= 3e-2 * float(g.norm()) + 1e-4 * gmax, k
+
+
 def test_cast_twin_registry_identity_version_and_lifetime():
     """functional.register_cast_twin / cast_twin: the bf16 copy a residual joint wrote is handed out only for THE tensor it was
     registered for, only while that tensor is unmodified, only in the registered dtype / shape -- and the entry dies with it."""
