@@ -193,11 +193,11 @@ extern "C" int ptc_pair_dot_fwd(const float* q, const float* k, const int32_t* i
                                 const float* table_k, const int32_t* rel_idx, int with_qk, int64_t M, int H, int d, float* out,
                                 ptc_stream_t stream) {
   PTC_REQUIRE(M >= 0 && H >= 1 && d >= 1, PTC_EINVAL, "ptc_pair_dot_fwd: bad sizes");
+  PTC_REQUIRE(p2_fits(M, H), PTC_EUNSUPPORTED, "ptc_pair_dot_fwd: too many pairs");
   if (M == 0) return PTC_OK;
   PTC_REQUIRE(q && i0 && out, PTC_EINVAL, "ptc_pair_dot_fwd: null buffer");
   PTC_REQUIRE(!(with_qk || table_k) || (k && i1), PTC_EINVAL, "ptc_pair_dot_fwd: the q.k / k.table terms need k and i1");
   PTC_REQUIRE(!(table_q || table_k) || rel_idx, PTC_EINVAL, "ptc_pair_dot_fwd: tables need rel_idx");
-  PTC_REQUIRE(p2_fits(M, H), PTC_EUNSUPPORTED, "ptc_pair_dot_fwd: too many pairs");
   hipLaunchKernelGGL(p2_pair_dot_fwd_kernel, dim3(p2_grid(M * H)), dim3(P2_THREADS), 0, (hipStream_t)stream, q, k, i0, i1, table_q,
                      table_k, rel_idx, with_qk, M, H, d, out);
   PTC_CHECK_LAUNCH("p2_pair_dot_fwd_kernel");

@@ -345,6 +345,15 @@ def test_argument_validation_returns_error_codes():
     assert rc == -2 and b"max_seqlen" in L.ptc_last_error()
     rc = L.ptc_spconv_fwd(None, 10, None, None, None, 10, 27, 6, 32, 2, None, None)
     assert rc == -2 and b"c_in" in L.ptc_last_error()
+    # the round-2 entry points: unsupported head dims, bad signs, empty inputs, launches that would not fit a grid
+    assert L.ptc_rope3d_xyz(None, 2, None, 2, None, None, 10, 3, 2, 4, 20, 1.0, None) == -2 and b"multiple of 6" in L.ptc_last_error()
+    assert L.ptc_rope3d_xyz(None, 2, None, 2, None, None, 10, 3, 2, 4, 18, 0.5, None) == -1 and b"sign" in L.ptc_last_error()
+    assert L.ptc_rope3d_xyz(None, 2, None, 2, None, None, 10, 3, 4, 4, 18, 1.0, None) == -1            # more rotated slabs than slabs
+    assert L.ptc_rope3d_xyz(None, 2, None, 2, None, None, 0, 3, 2, 4, 18, 1.0, None) == 0              # nothing to do
+    assert L.ptc_rope3d_xyz(None, 2, None, 2, None, None, 10, 3, 2, 4, 18, 1.0, None) == -1 and b"null" in L.ptc_last_error()
+    assert L.ptc_rope3d(None, 2, None, 10, 4, 20, 100.0, 1.0, None) == -2
+    assert L.ptc_pair_dot_fwd(None, None, None, None, None, None, None, 1, 1 << 50, 8, 16, None, None) == -2 and b"too many" in L.ptc_last_error()
+    assert L.ptc_pair_dot_fwd(None, None, None, None, None, None, None, 1, 0, 8, 16, None, None) == 0
 
 
 def test_ops_refuse_cpu_tensors():
