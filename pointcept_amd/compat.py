@@ -44,3 +44,34 @@ def install(force: bool = False) -> None:
     put("pointops2.functions", p2f)
     put("pointops2.functions.pointops", pointops2_api)
     put("pointrope", pointrope_api)      # libs/pointrope: `import pointrope as _kernels` (litept_v1.py:26)
+
+
+# ------------------------------------------------------------------------------------------------
+# module level: the engine's backbones under the reference's registry names
+# ------------------------------------------------------------------------------------------------
+MODEL_CLASSES = {                                   # registry name (reference file:line) -> (engine module, class)
+    "PT-v3m1": ("point_transformer_v3", "PointTransformerV3"),        # point_transformer_v3m1_base.py:518
+    "PT-v3m2": ("point_transformer_v3m2", "PointTransformerV3"),      # point_transformer_v3m2_sonata.py:544
+    "PT-v3m3": ("point_transformer_v3m3", "PointTransformerV3"),      # point_transformer_v3m3_utonia.py:686
+    "LitePT-v1": ("litept", "LitePT"),                                # litept_v1.py:593
+    "SpUNet-v1m1": ("sparse_unet", "SpUNetBase"),                     # spconv_unet_v1m1_base.py:88
+}
+
+
+def register_models(registry, names=None, force: bool = True) -> list:
+    """Registers the engine's module-level ports in the reference's `MODELS` registry (pointcept/models/builder.py) under the
+    names the reference's configs use, replacing the CUDA-library implementations (`force=True`), so that
+    `MODELS.build(cfg.model.backbone)` constructs them.  Returns the names registered.
+
+        from pointcept.models.builder import MODELS
+        import pointcept_amd.compat; pointcept_amd.compat.register_models(MODELS)
+    """
+    import importlib
+
+    done = []
+    for name in (names or MODEL_CLASSES):
+        mod, cls = MODEL_CLASSES[name]
+        registry.register_module(name, force=force, module=getattr(importlib.import_module(f"{__package__}.{mod}"), cls))
+        done.append(name)
+    return done
+

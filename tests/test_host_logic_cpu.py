@@ -852,6 +852,36 @@ def test_folded_cpe_conv_and_linear_is_the_same_function(monkeypatch):
         assert float((outs[1][1][k] - g).norm()) <= 3e-2 * float(g.norm()) + 1e-4 * gmax, k
 
 
+@pytest.mark.needs_reference
+def test_register_models_in_the_reference_registry():
+    """B1 in one call: compat.register_models puts the engine's five module-level ports into the reference's MODELS registry
+    (pointcept/utils/registry.py) under the names its configs use; MODELS.build then constructs the engine classes from a
+    reference-style config dict, and the originals come back when the test restores them."""
+    import sys
+
+    import pointcept_amd.compat as compat
+    from oracle import ref_import
+
+    ref_import.load()
+    MODELS = sys.modules["pointcept.models.builder"].MODELS
+    saved = dict(MODELS._module_dict)
+    try:
+        names = compat.register_models(MODELS)
+        assert set(names) == {"PT-v3m1", "PT-v3m2", "PT-v3m3", "LitePT-v1", "SpUNet-v1m1"}
+        for n in names:
+            assert MODELS.get(n).__module__.startswith("pointcept_amd."), n
+        net = MODELS.build(dict(type="PT-v3m3", in_channels=6, order=ORDERS, enc_depths=(1, 1), enc_channels=(36, 72), enc_num_head=(2, 4),
+                                stride=(2,), enc_patch_size=(64, 64), dec_depths=(1,), dec_channels=(36,), dec_num_head=(2,),
+                                dec_patch_size=(64,), rope_base=10))
+        assert type(net).__module__ == "pointcept_amd.point_transformer_v3m3" and any(k.endswith("rope.inv_freq") for k in net.state_dict())
+        sp = MODELS.build(dict(type="SpUNet-v1m1", in_channels=6, num_classes=20, base_channels=16, channels=(16, 32, 32, 48, 48, 32, 32, 16),
+                               layers=(1,) * 8))
+        assert type(sp).__module__ == "pointcept_amd.sparse_unet"
+    finally:
+        MODELS._module_dict.clear()
+        MODELS._module_dict.update(saved)
+
+
 def test_cast_twin_registry_identity_version_and_lifetime():
     """functional.register_cast_twin / cast_twin: the bf16 copy a residual joint wrote is handed out only for THE tensor it was
     registered for, only while that tensor is unmodified, only in the registered dtype / shape -- and the entry dies with it."""
