@@ -200,6 +200,51 @@ def farthest_point_sampling(xyz, offset, new_offset):
     return torch.from_numpy(opo.farthest_point_sampling(_np(xyz), _np(offset), _np(new_offset)))
 
 
+def _pair_dot(q, k, i0, i1, tq, tk, rel, with_qk):
+    from oracle import pointops2 as o2
+
+    out = 0
+    if with_qk:
+        out = out + o2.attention_step1(q, k, i0, i1)
+    if tq is not None:
+        out = out + o2.dot_prod_with_idx(q, i0, tq, rel)
+    if tk is not None:
+        out = out + o2.dot_prod_with_idx(k, i1, tk, rel)
+    return out
+
+
+def pair_dot_fwd(q, k, i0, i1, table_q, table_k, rel_idx, with_qk):
+    return _pair_dot(q, k, i0, i1, table_q, table_k, rel_idx, with_qk).detach()
+
+
+def pair_dot_bwd(g, q, k, i0, offsets, i1, table_q, table_k, rel_idx, with_qk, want_q=True, want_k=True, want_tq=True, want_tk=True):
+    leaves = [None if t is None else t.detach().clone().requires_grad_(True) for t in (q, k, table_q, table_k)]
+    with torch.enable_grad():
+        out = _pair_dot(leaves[0], leaves[1], i0, i1, leaves[2], leaves[3], rel_idx, with_qk)
+        live = [t for t in leaves if t is not None]
+        gr = dict(zip([id(t) for t in live], torch.autograd.grad(out, live, g, allow_unused=True)))
+    res = [None if t is None else (gr[id(t)] if gr[id(t)] is not None else torch.zeros_like(t)) for t in leaves]
+    return tuple(r if w else None for r, w in zip(res, (want_q, want_k, want_tq, want_tk)))
+
+
+def pair_aggregate_fwd(attn, v, i0, offsets, i1, table_v, rel_idx, n_q):
+    from oracle import pointops2 as o2
+
+    return o2.attention_step2(attn, v, i0, i1, int(n_q), table_v, rel_idx).detach()
+
+
+def pair_aggregate_bwd(g, attn, v, i0, i1, table_v, rel_idx, want_attn=True, want_v=True, want_tv=True):
+    from oracle import pointops2 as o2
+
+    leaves = [None if t is None else t.detach().clone().requires_grad_(True) for t in (attn, v, table_v)]
+    with torch.enable_grad():
+        out = o2.attention_step2(leaves[0], leaves[1], i0, i1, g.shape[0], leaves[2], rel_idx)
+        live = [t for t in leaves if t is not None]
+        gr = dict(zip([id(t) for t in live], torch.autograd.grad(out, live, g)))
+    res = [None if t is None else gr[id(t)] for t in leaves]
+    return tuple(r if w else None for r, w in zip(res, (want_attn, want_v, want_tv)))
+
+
 def rope3d_(tokens, positions, base, fwd):
     from oracle import pointrope as orope
 
@@ -261,7 +306,8 @@ _STANDINS = dict(
     gather_rows=gather_rows, segment_csr_fwd=segment_csr_fwd, segment_csr_bwd=segment_csr_bwd, HashTable=HashTable,
     rulebook_subm=rulebook_subm, rulebook_down=rulebook_down, spconv_fwd=spconv_fwd, spconv_wgrad=spconv_wgrad,
     attn_varlen_fwd=attn_varlen_fwd, attn_varlen_bwd=attn_varlen_bwd, cross_entropy_fwd=cross_entropy_fwd, rope3d_xyz=rope3d_xyz, rope3d_=rope3d_, knn_query=knn_query, ball_query=ball_query,
-    farthest_point_sampling=farthest_point_sampling,
+    farthest_point_sampling=farthest_point_sampling, pair_dot_fwd=pair_dot_fwd, pair_dot_bwd=pair_dot_bwd,
+    pair_aggregate_fwd=pair_aggregate_fwd, pair_aggregate_bwd=pair_aggregate_bwd,
     attn_hd_supported=lambda d, k: 16 <= d <= 64 and k <= (1024 if d <= 32 else 672 if d <= 48 else 512),
     cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum, voxel_keys=voxel_keys,
     layer_norm_supported=lambda c: False, batch_norm_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)

@@ -477,3 +477,88 @@ def test_pointops_mirror_against_the_reference_python_package():
             if a is not None:
                 same(a, b, 1e-5)
 
+
+def test_pointops2_mirror_against_the_reference_python_module(monkeypatch):
+    """libs/pointops2 above its kernels: the REFERENCE's own libs/pointops2/functions/pointops.py (autograd Functions, N_q from
+    index0.max(), the merged / sorted rel_idx bookkeeping of dot_prod_with_idx_v2, argument orders of the v1 / v2 / v3 generations)
+    executed on CPU stand-ins of `pointops2_cuda` (oracle/pointops2_c.py), against the engine's mirror
+    (pointcept_amd/pointops2_api.py on the CPU stand-ins of ITS two pair operators): every attention / relative-position operator,
+    forward and gradients, on a pair list sorted by query (what the Stratified Transformer builds) with per-query offsets."""
+    import mock_backend
+    from oracle import pointops2_c
+    from pointcept_amd import pointops2_api as M2
+
+    # the reference file allocates with torch.cuda.FloatTensor / IntTensor and calls .cuda(): CPU equivalents for this test
+    class _F:
+        def __new__(cls, *shape):
+            return torch.empty(*shape, dtype=torch.float32)
+    monkeypatch.setattr(torch.cuda, "FloatTensor", _F, raising=False)
+    def _int_tensor(*a):                                         # (sizes...) or (values), like the legacy constructor
+        return torch.empty(*a, dtype=torch.int32) if all(isinstance(x, int) for x in a) else torch.tensor(a[0], dtype=torch.int32)
+    monkeypatch.setattr(torch.cuda, "IntTensor", _int_tensor, raising=False)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    P2 = pointops2_c.load_reference_module()
+
+    g = torch.Generator().manual_seed(21)
+    N, h, d, L = 90, 3, 8, 11
+    counts = torch.randint(0, 9, (N,), generator=g)
+    counts[-1] = max(int(counts[-1]), 1)                        # the last query owns pairs: index0.max() + 1 == N
+    index0 = torch.repeat_interleave(torch.arange(N), counts).int()
+    M = index0.numel()
+    index1 = torch.randint(0, N, (M,), generator=g).int()
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(counts, 0)]).int()
+    n_max = int(counts.max())
+    rel_idx = torch.randint(0, L, (M, 3), generator=g).int()
+    q, k, v = (torch.randn(N, h, d, generator=g) for _ in range(3))
+    attn = torch.randn(M, h, generator=g)
+    tq, tk, tv = (torch.randn(L, h, d, 3, generator=g) for _ in range(3))
+    cases = [
+        ("attention_step1", lambda T, a, b: T.attention_step1(a, b, index0, index1), (q, k)),
+        ("attention_step1_v2", lambda T, a, b: T.attention_step1_v2(a, b, index1, offsets, n_max), (q, k)),
+        ("attention_step2", lambda T, a, b: T.attention_step2(a, b, index0, index1), (attn, v)),
+        ("attention_step2_v2", lambda T, a, b: T.attention_step2_v2(a, b, index0, index1), (attn, v)),
+        ("dot_prod_with_idx", lambda T, a, t: T.dot_prod_with_idx(a, index0, t, rel_idx), (q, tq)),
+        ("dot_prod_with_idx_v2", lambda T, a, b, t1, t2: T.dot_prod_with_idx_v2(a, index0, b, index1, t1, t2, rel_idx), (q, k, tq, tk)),
+        ("dot_prod_with_idx_v3", lambda T, a, b, t1, t2: T.dot_prod_with_idx_v3(a, offsets, n_max, b, index1, t1, t2, rel_idx), (q, k, tq, tk)),
+        ("attention_step2_with_rel_pos_value", lambda T, a, b, t: T.attention_step2_with_rel_pos_value(a, b, index0, index1, t, rel_idx),
+         (attn, v, tv)),
+        ("attention_step2_with_rel_pos_value_v2",
+         lambda T, a, b, t: T.attention_step2_with_rel_pos_value_v2(a, b, offsets, n_max, index1, t, rel_idx), (attn, v, tv)),
+    ]
+    for name, fn, tensors in cases:
+        outs, grads = [], []
+        for T in (P2, M2):
+            leaves = [t.clone().requires_grad_(True) for t in tensors]
+            with mock_backend.cpu_ops():
+                o = fn(T, *leaves)
+                probe = torch.randn(o.shape, generator=torch.Generator().manual_seed(1))
+                (o * probe).sum().backward()
+            outs.append(o.detach())
+            grads.append([t.grad for t in leaves])
+        assert outs[0].shape == outs[1].shape, name
+        assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * max(1.0, float(outs[0].abs().max())), name
+        for a, b in zip(*grads):
+            assert (a is None) == (b is None), name
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), name
+    # the families shared with libs/pointops, through the names pointops2 gives them
+    xyz = torch.rand(200, 3, generator=g)
+    off = torch.tensor([120, 200], dtype=torch.int32)
+    feat = torch.randn(200, 6, generator=g)
+    with mock_backend.cpu_ops():
+        new_off = torch.tensor([30, 50], dtype=torch.int32)
+        a, b = P2.furthestsampling(xyz, off, new_off), M2.furthestsampling(xyz, off, new_off)
+        assert torch.equal(a, b)
+        new_xyz = xyz[a.long()].contiguous()
+        (ia, da), (ib, db) = P2.knnquery(6, xyz, new_xyz, off, new_off), M2.knnquery(6, xyz, new_xyz, off, new_off)
+        assert torch.equal(ia, ib) and torch.equal(da, db)
+        assert torch.equal(P2.grouping(feat, ia), M2.grouping(feat, ia))
+        ra = P2.queryandgroup(6, xyz, new_xyz, feat, None, off, new_off, use_xyz=True, return_indx=True)
+        rb = M2.queryandgroup(6, xyz, new_xyz, feat, None, off, new_off, use_xyz=True, return_indx=True)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1])
+        pa, oa = P2.Divide2Patch(8, xyz, off, return_offset=True)
+        pb, ob = M2.Divide2Patch(8, xyz, off, return_offset=True)
+        assert torch.equal(pa, pb) and torch.equal(oa, ob)
+        for fn in ("interpolation", "interpolation_v2", "interpolation2"):
+            assert float((getattr(P2, fn)(new_xyz, xyz, feat[:50].contiguous(), new_off, off) -
+                          getattr(M2, fn)(new_xyz, xyz, feat[:50].contiguous(), new_off, off)).abs().max()) <= 1e-5, fn
+
