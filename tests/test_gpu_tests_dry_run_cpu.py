@@ -64,3 +64,17 @@ def test_gpu_pending_hardware_test_bodies_on_cpu_standins(name, kw, monkeypatch)
         else:
             getattr(T, name)(torch.device("cpu"), monkeypatch=monkeypatch, **kw)
 
+
+@pytest.mark.parametrize("mod,name", [("test_gpu_model", "test_ptv3_mix3d_duplicate_voxels"),
+                                      ("test_gpu_spunet", "test_spunet_base_channels_single_scene_and_duplicates")])
+def test_duplicate_voxel_tests_with_the_segmented_merge(mod, name, monkeypatch):
+    """the Mix3D / duplicate-coordinate model tests with functional._MERGE_DUP_SEGMENTED on (the one-launch merge, off by default)"""
+    import importlib
+
+    from pointcept_amd import functional as PF
+
+    monkeypatch.setattr(PF, "_MERGE_DUP_SEGMENTED", True)
+    T = importlib.import_module(mod)
+    with mock_backend.cpu_ops():
+        getattr(T, name)(torch.device("cpu"))
+

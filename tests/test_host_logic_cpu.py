@@ -882,6 +882,41 @@ def test_register_models_in_the_reference_registry():
         MODELS._module_dict.update(saved)
 
 
+def test_duplicate_row_merge_segmented_form_equals_the_loop(monkeypatch):
+    """functional._merge_duplicate_rows: the one-launch segmented form (PTC_MERGE_DUP_SEGMENTED, off by default until it has run on
+    hardware) against the per-multiplicity loop, on representatives with 1 .. 4 copies; the CSR is built once per representative
+    tensor and dropped with it."""
+    import gc
+
+    from pointcept_amd import functional as PF
+
+    g = torch.Generator().manual_seed(6)
+    n = 500
+    rep = torch.arange(n)
+    src = torch.randperm(n, generator=g)[:120]
+    for j, r in enumerate(src.tolist()):              # row r becomes a copy of a LOWER row (the representative is the lowest row)
+        if r > 0:
+            rep[r] = int(torch.randint(0, r, (1,), generator=g))
+    rep = torch.where(rep[rep] != rep, rep[rep], rep)             # chains collapse onto the true lowest row ...
+    rep = torch.where(rep[rep] != rep, rep[rep], rep)
+    rep = torch.where(rep[rep] != rep, rep[rep], rep)
+    assert bool((rep[rep] == rep).all()) and int((rep != torch.arange(n)).sum()) > 50
+    grad = torch.randn(n, 24, generator=g)
+    with mock_backend.cpu_ops():
+        monkeypatch.setattr(PF, "_MERGE_DUP_SEGMENTED", False)
+        want = PF._merge_duplicate_rows(grad, rep)
+        monkeypatch.setattr(PF, "_MERGE_DUP_SEGMENTED", True)
+        got = PF._merge_duplicate_rows(grad, rep)
+        again = PF._merge_duplicate_rows(grad * 2, rep)
+    assert torch.allclose(got, want, rtol=0, atol=1e-6) and torch.allclose(again, want * 2, rtol=0, atol=2e-6)
+    assert torch.equal(got[rep != torch.arange(n)], grad[rep != torch.arange(n)])       # copies keep their own rows
+    assert id(rep) in PF._dup_csr
+    k = id(rep)
+    del rep
+    gc.collect()
+    assert k not in PF._dup_csr
+
+
 def test_cast_twin_registry_identity_version_and_lifetime():
     """functional.register_cast_twin / cast_twin: the bf16 copy a residual joint wrote is handed out only for THE tensor it was
     registered for, only while that tensor is unmodified, only in the registered dtype / shape -- and the entry dies with it."""
