@@ -104,7 +104,10 @@ def self_launch(args) -> int:
 # ----------------------------------------------------------------------------------------------------------------
 # rooflines of the two dominant kernels, timed live
 # ----------------------------------------------------------------------------------------------------------------
-def _time_launches(fn, iters=10, warm=3):
+def _time_launches(fn, iters=40, warm=25):
+    # 25 untimed launches first: in an otherwise idle process the first few launches of a ~0.5 ms kernel run below the clock the
+    # part sustains under it (the same kernel measured 548 us as the first timing of a process and 476 us later in the same process,
+    # profiles/r02_h_attn_variants.txt; rocprofv3 averages 455-470 us) -- the HIP-event average must describe the steady state
     for _ in range(warm):
         fn()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
