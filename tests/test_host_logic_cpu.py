@@ -15,6 +15,12 @@ TINY = dict(in_channels=6, order=ORDERS, enc_depths=(1, 1, 1, 1, 1), dec_depths=
             dec_patch_size=(128,) * 4, drop_path=0.0, shuffle_orders=True)
 
 
+# every sys.modules entry pointcept_amd.compat.install() writes: B3 tests snapshot and restore them all, so that a later test that
+# imports a reference file afresh binds to the oracle's third-party stand-ins again
+COMPAT_NAMES = ["spconv", "spconv.pytorch", "spconv.pytorch.modules", "flash_attn", "torch_scatter", "pointops", "pointops2",
+                "pointops2.pointops", "pointops2.functions", "pointops2.functions.pointops", "pointrope"]
+
+
 def _rel(a, b):
     return float((a.detach().float() - b.detach().float()).abs().max() / b.detach().float().abs().max().clamp(min=1e-12))
 
@@ -194,7 +200,7 @@ def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
     R = ref_import.load()                                        # reference files on oracle/shims.py
     R_m2 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m2_sonata")
     R_m3 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m3_utonia")
-    names = ["spconv", "spconv.pytorch", "spconv.pytorch.modules", "flash_attn", "torch_scatter",
+    names = COMPAT_NAMES + [
              "pointcept.models.utils", "pointcept.models.utils.structure", "pointcept.models.utils.misc",
              "pointcept.models.utils.serialization", "pointcept.models.modules", "pointcept.models.builder",
              "pointcept.models.point_transformer_v3.point_transformer_v3m1_base",
@@ -302,8 +308,7 @@ def test_b3_reference_litept_file_runs_unmodified_on_the_engine_operators(monkey
     from oracle import ptv3_model as om
 
     R = _import_reference_litept(monkeypatch)                    # reference file on oracle/shims.py + pointrope_cpu
-    names = ["spconv", "spconv.pytorch", "spconv.pytorch.modules", "flash_attn", "torch_scatter", "pointrope",
-             "pointcept.models.utils", "pointcept.models.utils.structure", "pointcept.models.utils.misc",
+    names = COMPAT_NAMES + ["pointcept.models.utils", "pointcept.models.utils.structure", "pointcept.models.utils.misc",
              "pointcept.models.utils.serialization", "pointcept.models.modules", "pointcept.models.builder",
              "pointcept.models.litept", "pointcept.models.litept.litept_v1"]
     names += [k for k in list(sys.modules) if k.startswith("pointcept.models.utils.serialization.")]
@@ -362,7 +367,7 @@ def test_b3_reference_spunet_variants_run_unmodified_on_the_engine_operators():
     for name in ("SpUNet-v1m2", "SpUNet-v1m3"):
         builder.MODELS._module_dict.pop(name, None)
     R = [importlib.import_module(m) for m in mods]
-    names = ["spconv", "spconv.pytorch", "spconv.pytorch.modules", "flash_attn", "torch_scatter", "pointcept.models.builder"] + mods
+    names = COMPAT_NAMES + ["pointcept.models.builder"] + mods
     saved = {k: sys.modules.pop(k, None) for k in names}
     try:
         compat.install(force=True)
@@ -433,7 +438,7 @@ def test_b3_reference_ptv1_ptv2_files_run_unmodified_on_the_pointops_mirror(monk
             reg.pop(name, None)
         return [importlib.import_module(m) for m in mods]
 
-    names = ["pointops", "torch_scatter", "pointcept.models.builder"]
+    names = COMPAT_NAMES + ["pointcept.models.builder"]
     saved = {k: sys.modules.get(k) for k in names + list(pkgs) + mods + ["pointcept.models.point_transformer.utils"]}
     try:
         sys.modules["pointops"] = P                                # reference side: its own python package
@@ -472,6 +477,62 @@ def test_b3_reference_ptv1_ptv2_files_run_unmodified_on_the_pointops_mirror(monk
                 gmax = max(float(p.grad.norm()) for p in ga.values())
                 for name, p in b.named_parameters():        # (biases in front of a BatchNorm have a zero gradient: fp32 noise on both sides)
                     assert float((p.grad - ga[name].grad).norm()) <= 2e-3 * float(ga[name].grad.norm()) + 2e-5 * gmax, (mods[mi], name)
+    finally:
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
+
+
+@pytest.mark.needs_reference
+def test_b3_reference_oacnns_file_runs_unmodified_on_the_engine_operators():
+    """B3 for another spconv caller of the reference: oacnns_v1m1_base.py ("OACNNs": three stem convolutions under one indice_key,
+    strided down / inverse up convolutions, k = 1 head, torch_geometric voxel pooling around them) on the engine's spconv mirror."""
+    import importlib
+    import sys
+    import types
+
+    import pointcept_amd.compat as compat
+    from oracle import ptv3_model as om
+    from oracle import ref_import
+
+    ref_import.load()
+    mod = "pointcept.models.oacnns.oacnns_v1m1_base"
+
+    def fresh_import():
+        for k in ("pointcept.models.oacnns", mod):
+            sys.modules.pop(k, None)
+        pk = types.ModuleType("pointcept.models.oacnns")
+        pk.__path__ = [ref_import.REF + "/pointcept/models/oacnns"]
+        sys.modules["pointcept.models.oacnns"] = pk
+        sys.modules["pointcept.models.builder"].MODELS._module_dict.pop("OACNNs", None)
+        return importlib.import_module(mod)
+
+    names = COMPAT_NAMES + ["pointcept.models.oacnns", mod]
+    saved = {k: sys.modules.get(k) for k in names}
+    try:
+        R = fresh_import()
+        compat.install(force=True)
+        E = fresh_import()
+        assert E is not R and E.spconv.__name__ == "pointcept_amd.spconv_api" and R.spconv.__name__ != E.spconv.__name__
+        cfg = dict(in_channels=6, num_classes=13, embed_channels=16, enc_num_ref=[4, 4], enc_channels=[16, 32], groups=[2, 4], enc_depth=[1, 1],
+                   down_ratio=[2, 2], dec_channels=[16, 32], point_grid_size=[[4, 8], [2, 4]], dec_depth=[1, 1])
+        batch = _batch([500, 220], seed0=670)
+        torch.manual_seed(0)
+        a, b = R.OACNNs(**cfg), E.OACNNs(**cfg)
+        assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+        sd = om.deterministic_state_dict(a, 50)
+        a.load_state_dict(sd)
+        b.load_state_dict(sd)
+        outs = []
+        with mock_backend.cpu_ops():
+            for net in (a, b):
+                net.train()
+                o = net({k: v for k, v in batch.items()})
+                torch.nn.functional.cross_entropy(o, batch["segment"] % 13, ignore_index=-1).backward()
+                outs.append(o.detach())
+        assert outs[0].shape == (720, 13) and _rel(outs[1], outs[0]) < 1e-4
+        _grad_check(b, a, 2e-3)
     finally:
         for k, v in saved.items():
             sys.modules.pop(k, None)
