@@ -103,8 +103,18 @@ def main():
     ap.add_argument("--lib", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pointcept_amd", "libptcore.so"))
     ap.add_argument("--save")
     ap.add_argument("--diff")
+    ap.add_argument("--spills", action="store_true", help="list the kernels that use scratch memory (register spills) with their register counts")
     a = ap.parse_args()
     fp = fingerprint(a.lib)
+    if a.spills:
+        rows = [(int(v.get(".private_segment_fixed_size") or 0), int(v.get(".vgpr_count") or 0), int(v.get(".group_segment_fixed_size") or 0), k[5:])
+                for k, v in fp.items() if k.startswith("meta:")]
+        rows = sorted((r for r in rows if r[0] > 0), reverse=True)
+        print(f"{len(rows)} of {sum(1 for k in fp if k.startswith('meta:'))} kernels use scratch (bytes per lane | VGPRs | static LDS | kernel)")
+        for sc, vg, lds, nm in rows:
+            dem = subprocess.run(["c++filt", nm], capture_output=True, text=True).stdout.strip()
+            print(f"  {sc:5d} | {vg:3d} | {lds:6d} | {dem[:120]}")
+        return
     if a.save:
         json.dump(fp, open(a.save, "w"), indent=0, sort_keys=True)
         print(f"{len([k for k in fp if not k.startswith('meta:')])} kernels / device functions -> {a.save}")
