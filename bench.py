@@ -71,6 +71,8 @@ def parse(argv=None):
                          "reported with its own metric name")
     ap.add_argument("--cpu-sample-points", type=int, default=10240)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-fp16-recipe", action="store_true",
+                    help="skip the extra measurement of the same step under the reference's fp16 autocast + GradScaler recipe")
     ap.add_argument("--stub", action="store_true",
                     help="launcher / DP plumbing check without a GPU: gloo backend, CPU tensors, a small torch model "
                          "(tests/test_dp_gloo.py); never a benchmark result")
@@ -289,6 +291,26 @@ def make_step(step_model, opt, batch, amp: str, loss_of, device):
     return step
 
 
+def fp16_recipe_in_a_child(args):
+    """The same PT-v3m1 step under the reference's own mixed-precision recipe -- fp16 autocast + torch.amp.GradScaler
+    (configs/_base_/default_runtime.py:19, engines/train.py:203-231) -- measured by a CHILD process running this file with
+    `--amp fp16` (the headline line stays bf16 autocast: same operand width, no scaler).  A child, so that nothing it does can take
+    the parent's already measured numbers with it; its one JSON line is read from a pipe."""
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--amp", "fp16", "--steps", "5", "--warmup", "2", "--batch", str(args.batch),
+               "--points", str(args.points), "--no-secondary", "--no-cpu-baseline", "--no-fp16-recipe"] + (["--ce-only"] if args.ce_only else [])
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+        line = [ln for ln in res.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if res.returncode != 0 or not line:
+            return {"error": f"child exit code {res.returncode}"}
+        j = json.loads(line[-1])
+        return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "warmup": j["warmup"],
+                "amp": j["config"]["amp"], "final_loss": j["config"]["final_loss"], "measured_by": "child process: bench.py --amp fp16"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def build_ptv3(args, device, rank):
     from pointcept_amd import synthetic
     from pointcept_amd.point_transformer_v3 import PointTransformerV3
@@ -440,6 +462,8 @@ def main():
                 del st2, m2, o2, b2
             except Exception as e:
                 out["secondary"] = {"error": repr(e)}
+        if not args.stub and args.model == "ptv3" and world == 1 and amp == "bf16" and not args.no_secondary and not args.no_fp16_recipe:
+            out["recipe_fp16"] = fp16_recipe_in_a_child(args)
         if not args.stub and args.model == "ptv3" and world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_points, args.points, args.cpu_iters, not args.ce_only)

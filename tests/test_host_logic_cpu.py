@@ -978,6 +978,44 @@ def test_duplicate_row_merge_segmented_form_equals_the_loop(monkeypatch):
     assert k not in PF._dup_csr
 
 
+def test_bench_fp16_recipe_child_process_plumbing(monkeypatch):
+    """bench.py measures the reference's fp16 + GradScaler recipe in a CHILD process (crash isolation for the headline numbers): the
+    child's command line parses to the intended switches, its JSON line is picked out of a noisy stdout, failures become an
+    {"error": ...} object instead of an exception."""
+    import json
+    import subprocess
+    import sys
+    import types
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--batch", "4", "--points", "2048"])
+    import bench
+
+    a = bench.parse()
+
+    def fake_run(cmd, **kw):
+        assert kw.get("timeout") and cmd[0] == sys.executable and cmd[1].endswith("bench.py")
+        assert not any(k in kw["env"] for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
+        monkeypatch.setattr(sys, "argv", cmd[1:])
+        b = bench.parse()
+        assert b.amp == "fp16" and b.no_secondary and b.no_cpu_baseline and b.no_fp16_recipe and (b.batch, b.points, b.gpus) == (4, 2048, 1)
+        line = json.dumps({"value": 150.0, "unit": "scenes/s", "ms_per_step": 53.3, "steps": 5, "warmup": 2,
+                           "config": {"amp": "fp16 autocast + GradScaler", "final_loss": 4.4}})
+        return types.SimpleNamespace(returncode=0, stdout=("NCCL version banner\n" + line + "\n").encode())
+
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    r = bench.fp16_recipe_in_a_child(a)
+    assert r["value"] == 150.0 and r["amp"].startswith("fp16") and "error" not in r
+    monkeypatch.setattr(bench.subprocess, "run", lambda *x, **k: types.SimpleNamespace(returncode=-11, stdout=b""))
+    assert "error" in bench.fp16_recipe_in_a_child(a)
+
+    def boom(*x, **k):
+        raise subprocess.TimeoutExpired("bench", 1)
+
+    monkeypatch.setattr(bench.subprocess, "run", boom)
+    assert "TimeoutExpired" in bench.fp16_recipe_in_a_child(a)["error"]
+
+
 def test_cast_twin_registry_identity_version_and_lifetime():
     """functional.register_cast_twin / cast_twin: the bf16 copy a residual joint wrote is handed out only for THE tensor it was
     registered for, only while that tensor is unmodified, only in the registered dtype / shape -- and the entry dies with it."""
