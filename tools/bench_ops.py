@@ -376,6 +376,18 @@ def main():
         for cin, cout in ((32, 32), (32, 64), (32, 128), (32, 256), (64, 32), (64, 64), (64, 128), (64, 192), (64, 256), (128, 64),
                           (128, 128), (128, 256), (256, 64), (256, 128)):
             bench_linear(rows, 819200, cin, cout, res["linprobe"])
+    if "rope" in only:   # PT-v3m3 / LitePT rotation on the packed qkv rows: ptc_rope3d_xyz against the torch formulation it replaces
+        from pointcept_amd import functional as PF
+        res["rope"] = []
+        for n, H, D in ((819200, 3, 18), (204800, 6, 18), (51200, 12, 18), (819200, 2, 24)):
+            qkv = torch.randn(n, 3, H, D, device=DEV).to(torch.bfloat16)
+            xyz = torch.rand(n, 3, device=DEV) * 8.0
+            f = (1.0 / (10.0 ** (torch.arange(0, D // 3, 2).float() / (D // 3)))).to(DEV)
+            t_k = timeit(lambda: ops.rope3d_xyz(qkv, xyz, f, 2, 1.0, torch.bfloat16))
+            t_t = timeit(lambda: PF.rope_xyz_torch(qkv, xyz, f))
+            by = n * 3 * H * D * 2 * 2 + n * 12
+            res["rope"].append({"shape": [n, H, D], "kernel": roof(by, 0.0, t_k), "torch_ops": roof(by, 0.0, t_t)})
+            rows.append(f"rope n={n:7d} H={H:2d} D={D:2d} | kernel {t_k * 1e6:8.1f} us ({by / t_k / 1e9:6.0f} GB/s)  torch ops {t_t * 1e6:8.1f} us")
     if "wgrad_small" in only:   # the weight gradients of the deep stages (~103 launches of ~29 us per step), own vs library
         res["wgrad_small"] = []
         dt = torch.bfloat16

@@ -75,7 +75,8 @@ for sec in "$@"; do
             rm -rf $O/${tg}_stats $O/${tg}_fetch $O/${tg}_write $O/${tg}_tcp $O/${tg}_tcc $O/${tg}_sq $O/${tg}_sq2
             cd /tmp
           done; unset PTC_LK_SHAPE; ls $O | grep linear_pmc;;
-    pending) PTC_RUN_PENDING=1 timeout 900 python -m pytest tests/test_gpu_pending_hardware.py -q -m gpu > $O/${TAG}_pending.log 2>&1; echo "pending rc=$?" >> $O/${TAG}_env.log; tail -15 $O/${TAG}_pending.log;;
+    pending) PTC_RUN_PENDING=1 timeout 900 python -m pytest tests/test_gpu_pending_hardware.py -q -m gpu > $O/${TAG}_pending.log 2>&1; echo "pending rc=$?" >> $O/${TAG}_env.log; tail -15 $O/${TAG}_pending.log
+          timeout 300 python tools/bench_ops.py --only rope > $O/${TAG}_rope_ops.log 2>&1; cat $O/${TAG}_rope_ops.log | cut -c1-160;;
     w2sweep) for wgs in 1024 768 512 384 256; do for ms in 16 8 32; do
             echo "== PTC_W2_TARGET_WGS=$wgs PTC_W2_MIN_STEPS=$ms" >> $O/${TAG}_w2sweep.log
             PTC_W2_TARGET_WGS=$wgs PTC_W2_MIN_STEPS=$ms timeout 300 python tools/bench_ops.py --only wgrad_small >> $O/${TAG}_w2sweep.log 2>&1
