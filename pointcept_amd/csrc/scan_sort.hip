@@ -199,8 +199,11 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
     } else {
       rank[it] = 0;
     }
-    // the lowest peer lane publishes the new running count (one writer per digit per wave)
+    // the lowest peer lane publishes the new running count (one writer per digit per wave) -- after EVERY lane of the wave has read
+    // the old one: the wave barrier states the lockstep this step relies on (no instruction; it pins the order for the compiler)
+    __builtin_amdgcn_wave_barrier();
     if (valid && (peers & lt_mask) == 0ull) wave_hist[wave][d] = before + __popcll(peers);
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
   // exclusive prefix over waves, per digit (thread t <-> digit t); `run` ends as this block's count of digit t

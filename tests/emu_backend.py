@@ -19,33 +19,8 @@ def available() -> bool:
 
 FILES = None      # None = every .hip of pointcept_amd/csrc
 
-# The emulator's own translation unit: the fiber switch, the dynamic-LDS arrays, and a CONTRACT-LEVEL stand-in for ptc_sort_keys.
-# The radix sort's scatter kernel (scan_sort.hip) relies on the lockstep execution of a wave between two collectives (every lane
-# reads a running LDS counter, then the lowest lane of each digit group publishes the new value -- one instruction slot each on the
-# hardware); lanes run one after the other here, so that kernel is compiled under another name and not used.  Everything that
-# CALLS the sort (rulebooks of strided convolutions, pooling maps, Lovasz) runs on the stand-in: stable, bits [begin, end).
-_RUNTIME_CPP = r"""
-#define EMU_IMPLEMENTATION 1
-#include <hip/hip_runtime.h>
-#include <algorithm>
-#include <numeric>
-extern "C" int ptc_sort_keys(const int64_t* keys, int64_t n, int k, int begin_bit, int end_bit, int64_t* order, int64_t* inverse, void*,
-                             size_t, void*) {
-  const int nb = end_bit - begin_bit;
-  const uint64_t mask = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
-  for (int r = 0; r < k; ++r) {
-    const int64_t* kr = keys + (int64_t)r * n;
-    int64_t* o = order + (int64_t)r * n;
-    std::iota(o, o + n, (int64_t)0);
-    std::stable_sort(o, o + n, [&](int64_t a, int64_t b) {
-      return (((uint64_t)kr[a] >> begin_bit) & mask) < (((uint64_t)kr[b] >> begin_bit) & mask);
-    });
-    if (inverse)
-      for (int64_t i = 0; i < n; ++i) inverse[(int64_t)r * n + o[i]] = i;
-  }
-  return 0;
-}
-"""
+# The emulator's own translation unit: the fiber switch and the dynamic-LDS arrays.
+_RUNTIME_CPP = "#define EMU_IMPLEMENTATION 1\n#include <hip/hip_runtime.h>\n"
 
 
 def build(verbose: bool = False):
@@ -81,7 +56,7 @@ def build(verbose: bool = False):
         objs.append(o)
         # spconv.hip instantiates ~200 implicit-GEMM kernels whose always-inline bodies take the optimiser 4.5 minutes: -O0 (9 s)
         opt = "-O0" if os.path.basename(u) in ("spconv.hip",) else "-O1"
-        extra = ["-Dptc_sort_keys=ptc_sort_keys_radix_not_emulated"] if os.path.basename(u) == "scan_sort.hip" else []
+        extra = []
         procs.append((u, subprocess.Popen([CLANG, "-x", "c++", "-std=c++17", opt, "-fPIC", "-w", "-I", shim] + extra + ["-c", u, "-o", o],
                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
     errs = []

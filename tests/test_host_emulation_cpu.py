@@ -9,9 +9,11 @@ emulator's matrix / transpose-read / buffer-load models are themselves validated
 (GPU tier, round 2) reproduce their oracles here: implicit GEMM convolution forward / input gradient / weight gradient
 (16x16x32 MFMA, ds_read_b64_tr_b16, raw buffer loads), window attention forward / backward for head_dim 16 and 18 and with RPE
 (32x32x16 MFMA), norms, maps, rulebooks, reductions.
-What it is not: timing, memory ordering between waves, anything that relies on the LOCKSTEP execution of a wave between two
-collectives (the radix sort's rank / publish step reads and writes one LDS counter in the same instruction slot: not emulated,
-its tests stay GPU-only), the summation order inside an MFMA.
+What it is not: timing, memory ordering between waves, the summation order inside an MFMA -- and code that relies on the LOCKSTEP
+execution of a wave between two collectives without saying so.  (The radix sort's rank / publish step did: every lane reads a
+running LDS counter and the lowest lane of each digit group then publishes the new value.  It now states the lockstep with two
+`__builtin_amdgcn_wave_barrier()` -- no instruction, the gfx950 binary is byte-identical (tools/kernel_fingerprint.py) -- which the
+emulator honours as a wave-level wait; the sort and everything built on it runs here since.)
 ptc_rope3d_xyz (written after round 2's GPU time was spent) has only ever run here."""
 import ctypes
 import os
@@ -176,6 +178,7 @@ EMULATED_GPU_TESTS = [
     ("test_pointops2_pair_operators_match_the_reference_formulations", dict(seed=0)),
     # LDS + shuffles + workgroup barriers
     ("test_exclusive_scan", dict(n=1000)), ("test_exclusive_scan", dict(n=70000)),
+    ("test_sort_keys_stable", dict(n=65)), ("test_sort_keys_stable", dict(n=4097)), ("test_sort_keys_bit_window", dict()),
     ("test_patch_pad_maps", dict(counts=[10, 3, 7], K=4)), ("test_patch_pad_maps", dict(counts=[1024, 1025, 5000, 1], K=1024)),
     ("test_attn_tables_match_index_algebra", dict(counts=[48, 49, 100, 7], K=48)),
     ("test_pool_level_counts", dict(row=0)), ("test_coord_max", dict(n=5000, dtype=torch.int32)),
@@ -195,8 +198,7 @@ EMULATED_GPU_TESTS = [
     ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6)),
     ("test_attention_rpe_fwd_bwd", dict(lens=[200, 200, 200], H=3, bnd=18)),
 ]   # (in-place GPU tests -- rope3d, cross entropy -- are not in the list: with device = cpu their `.to(device)` aliases the input the
-#    oracle is then fed with; tests that construct `pointcept_amd.nn` modules or open a CUDA autocast region cannot run on CPU tensors;
-#    the radix-sort tests rely on wave lockstep, see the module docstring)
+#    oracle is then fed with; tests that construct `pointcept_amd.nn` modules or open a CUDA autocast region cannot run on CPU tensors)
 
 
 @pytest.mark.parametrize("name,kw", EMULATED_GPU_TESTS, ids=[f"{n}-{i}" for i, (n, _) in enumerate(EMULATED_GPU_TESTS)])
