@@ -111,3 +111,23 @@ def emulated_ops():
     finally:
         for mod, name, val in saved:
             setattr(mod, name, val)
+
+
+@contextlib.contextmanager
+def hybrid(real_ops):
+    """The model-level CPU backend (tests/mock_backend.py: oracle stand-ins behind the ops' contracts, GPU guards lifted) with the
+    ops named in `real_ops` running their REAL kernels on the host emulation instead."""
+    import mock_backend
+    from pointcept_amd import ops
+
+    orig = {n: getattr(ops, n) for n in real_ops}
+    with mock_backend.cpu_ops(), emulated_ops():
+        saved = {n: getattr(ops, n) for n in real_ops}
+        try:
+            for n, f in orig.items():
+                setattr(ops, n, f)
+            yield
+        finally:
+            for n, f in saved.items():
+                setattr(ops, n, f)
+
