@@ -211,6 +211,18 @@ __host__ __device__ __forceinline__ int at_split(int n_units, int lp_max) {
   return qs;
 }
 
+// PTC_ATTN_SPLIT=<1|2|4> forces the split where the shape allows it (A/B knob).  Why one would: at the bench shape 3200 units fill the
+// 512 workgroup slots 6.25 times -- seven rounds of work for 6.25, 10.7 % of the launch idle in the last round -- while 6400 half
+// units take 13 rounds for 12.5 (3.8 %), at the price of staging the other side twice.  Not measured yet; the default is unchanged.
+static inline int at_split_host(int n_units, int lp_max) {
+  int qs = at_split(n_units, lp_max);
+  if (const char* e = getenv("PTC_ATTN_SPLIT")) {
+    const int want = atoi(e);
+    if ((want == 1 || want == 2 || want == 4) && (lp_max >> 5) / (2 * want) >= AT_WAVES) qs = want;
+  }
+  return qs;
+}
+
 // A sequence longer than max_seqlen (cu_seqlens built for a larger patch than the caller's max_seqlen, or a caller
 // of the flash_attn API passing inconsistent arguments) would overrun the LDS images, which are sized from
 // max_seqlen.  Such units write NaN to every output row they own (16 bf16 per row, optionally the fp32 side vector) and
@@ -1008,7 +1020,7 @@ extern "C" int ptc_attn_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, i
   const size_t lds = fwd_lds_bytes(lp_max);
   hipStream_t s = (hipStream_t)stream;
   const int n_units = (int)(n_seq * H);
-  const int qs = at_split(n_units, lp_max);
+  const int qs = at_split_host(n_units, lp_max);
   int mode = AT_FWD_DEFAULT;
   if (const char* e = getenv("PTC_ATTN_FWD")) mode = atoi(e);
 #define AT_FWD_CASE(M, Q1, PRIO, TRUNC)                                                                                        \
@@ -1058,7 +1070,7 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
     return PTC_OK;
   }
   const int n_units = (int)(n_seq * H);
-  const int qs = at_split(n_units, lp_max);
+  const int qs = at_split_host(n_units, lp_max);
   const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
   // s_setprio 1 on waves 4..7 as in the forward: measured NEUTRAL to harmful here (H = 4: 1440 vs 1423 us, H = 2: 842 vs 776 us,
   // profiles/r02_h_attn_variants.txt) -- the backward loops are not pinned with sched_group_barrier, so the prioritised
@@ -1121,7 +1133,7 @@ extern "C" int ptc_attn_varlen_hd_fwd(const void* qkv, const int32_t* cu_seqlens
   const int lp_max = (max_seqlen + 31) & ~31, dk = (head_dim + 15) / 16, mb = head_dim / 32 + 1;
   const size_t lds = hd_fwd_lds(dk, head_dim, lp_max);
   const int n_units = (int)(n_seq * H);
-  const int qs = at_split(n_units, lp_max);
+  const int qs = at_split_host(n_units, lp_max);
   hipStream_t s = (hipStream_t)stream;
 #define AH_FWD_CASE(DK, MB)                                                                                                    \
   if (dk == DK && mb == MB) {                                                                                                  \
@@ -1152,7 +1164,7 @@ extern "C" int ptc_attn_varlen_hd_bwd(const void* qkv, const void* out, const vo
               "ptc_attn_varlen_hd_bwd: buffers must be 16-byte aligned");
   const int lp_max = (max_seqlen + 31) & ~31, dk = (head_dim + 15) / 16;
   const int n_units = (int)(n_seq * H);
-  const int qs = at_split(n_units, lp_max);
+  const int qs = at_split_host(n_units, lp_max);
   const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)workspace;
