@@ -56,7 +56,9 @@ def build(verbose: bool = False):
         objs.append(o)
         # spconv.hip instantiates ~200 implicit-GEMM kernels whose always-inline bodies take the optimiser 4.5 minutes: -O0 (9 s)
         opt = "-O0" if os.path.basename(u) in ("spconv.hip",) else "-O1"
-        extra = []
+        # PTC_EMU_ASAN=1: AddressSanitizer on the kernels' GLOBAL and HEAP accesses (not their stacks: lanes run on switched stacks), to
+        # be used with  LD_PRELOAD=<clang's libclang_rt.asan-x86_64.so> ASAN_OPTIONS=detect_leaks=0  (tools/emu_asan.sh)
+        extra = ["-fsanitize=address", "-mllvm", "-asan-stack=0", "-g"] if os.environ.get("PTC_EMU_ASAN") == "1" else []
         procs.append((u, subprocess.Popen([CLANG, "-x", "c++", "-std=c++17", opt, "-fPIC", "-w", "-I", shim] + extra + ["-c", u, "-o", o],
                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
     errs = []
@@ -67,7 +69,8 @@ def build(verbose: bool = False):
     if errs:
         raise RuntimeError("host emulation build failed:\n" + "\n".join(errs))
     out = os.path.join(d, "libptc_host_emu.so")
-    r = subprocess.run([CLANG, "-shared", "-o", out] + objs + ["-lm"], capture_output=True, text=True)
+    link = ["-fsanitize=address", "-shared-libasan"] if os.environ.get("PTC_EMU_ASAN") == "1" else []
+    r = subprocess.run([CLANG, "-shared", "-o", out] + link + objs + ["-lm"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("host emulation link failed:\n" + r.stderr[-3000:])
     _lib_cache["lib"] = ctypes.CDLL(out)
