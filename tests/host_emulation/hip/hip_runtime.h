@@ -96,6 +96,7 @@ __asm__(
     "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n");
 #endif
 
+extern unsigned char smem[];
 namespace emu {
 inline void yield_to_scheduler() { State& s = S(); emu_switch(&s.cur->sp, s.sched_sp); }
 inline void wave_sync() { S().cur->state = 1; yield_to_scheduler(); }
@@ -187,11 +188,20 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
   s.block_dim = block;
   s.grid_dim = grid;
   s.body = &body;
+  // canary behind the dynamic LDS the launch asked for: a workgroup that writes past its allocation is reported (on the hardware
+  // that is a memory fault or a silent corruption of the neighbouring workgroup's LDS)
+  const size_t guard = shmem + 4096 <= (size_t)EMU_LDS ? 4096 : (size_t)EMU_LDS - shmem;
   for (unsigned z = 0; z < grid.z; ++z)
     for (unsigned y = 0; y < grid.y; ++y)
       for (unsigned x = 0; x < grid.x; ++x) {
         s.block_idx = dim3(x, y, z);
+        memset(smem + shmem, 0xC3, guard);
         run_block();
+        for (size_t i = 0; i < guard; ++i)
+          if (smem[shmem + i] != 0xC3) {
+            fprintf(stderr, "host emulation: workgroup (%u,%u,%u) wrote dynamic LDS byte %zu, %zu were allocated\n", x, y, z, shmem + i, shmem);
+            abort();
+          }
       }
 }
 // per-lane exchange slot of the current wave
@@ -211,7 +221,7 @@ inline int lane_id() { return S().cur->lane; }
 
 // dynamic LDS (`extern __shared__ ... smem[]` / `lh[]` after the build script's token substitution)
 #ifdef EMU_IMPLEMENTATION
-alignas(64) unsigned char smem[emu::EMU_LDS];
+alignas(64) unsigned char smem[emu::EMU_LDS + 4096];
 alignas(64) unsigned int lh[emu::EMU_LDS / 4];
 #endif
 
