@@ -498,6 +498,12 @@ int ptc_batch_norm_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dt
  *   prefix [n+1] int64 = first output element of every entry, total = prefix[n]. */
 int ptc_weight_layouts(const int64_t* desc, const int64_t* prefix, int n, int64_t total, ptc_stream_t stream);
 
+/* fp32 master weights -> 16-bit shadows of every stale weight in one launch (what torch._foreach_copy_ does in ~29 multi-tensor
+ * launches after each optimizer step; functional._CastCache):  desc [n][3] int64 = { src (fp32), dst (dst_dtype), n_elements } (device),
+ * prefix [n+1] int64 = first UNIT of 8 elements of every entry (entries rounded up to whole units), total_units = prefix[n];
+ * dst_dtype = PTC_BF16 | PTC_F16; round-to-nearest-even like Tensor.to(). */
+int ptc_cast_many(const int64_t* desc, const int64_t* prefix, int n, int64_t total_units, int dst_dtype, ptc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * M. libs/pointops2: the pair-list attention operators of Stratified Transformer (fp32), reference wrappers
  *    libs/pointops2/functions/pointops.py:93-961, kernels libs/pointops2/src/{attention,attention_v2,rpe,rpe_v2}/.

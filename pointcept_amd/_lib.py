@@ -70,6 +70,7 @@ _SIGNATURES = {
     "ptc_attn_varlen_bwd_workspace_bytes": (c_size, [c_i64, c_int]),
     "ptc_attn_varlen_hd_supported": (c_int, [c_int, c_int]),
     "ptc_weight_layouts": (c_int, [c_ptr, c_ptr, c_int, c_i64, c_ptr]),
+    "ptc_cast_many": (c_int, [c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr]),
     "ptc_pair_dot_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "ptc_pair_dot_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_i64, c_i64, c_i64, c_int,
                                  c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),

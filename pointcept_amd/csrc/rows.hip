@@ -302,3 +302,51 @@ extern "C" int ptc_weight_layouts(const int64_t* desc, const int64_t* prefix, in
   PTC_CHECK_LAUNCH("weight_layouts_kernel");
   return PTC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// fp32 master weights -> 16-bit shadows, all stale ones of the model in ONE launch.
+// torch._foreach_copy_ does this in ~29 multi-tensor launches of ~14 us (486 tensors, 46 M elements: 0.40 ms per step,
+// profiles/r02_ag_bench_kernel_stats.csv) -- ten times the 35 us the 276 MB take at the HBM rate.  One thread converts one UNIT of
+// 8 consecutive elements of one tensor: desc[e] = { src (fp32), dst (16 bit), n_elements }, prefix[e] = first unit of entry e
+// (every entry is rounded up to whole units), total_units = prefix[n].
+template <typename TO>
+__global__ void __launch_bounds__(256)
+cast_many_kernel(const int64_t* __restrict__ desc, const int64_t* __restrict__ prefix, int n, int64_t total_units) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total_units; u += stride) {
+    int lo = 0, hi = n - 1;                       // largest e with prefix[e] <= u
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= u) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* d = desc + (int64_t)lo * 3;
+    const float* src = reinterpret_cast<const float*>(d[0]);
+    TO* dst = reinterpret_cast<TO*>(d[1]);
+    const int64_t cnt = d[2], base = (u - prefix[lo]) * 8;
+    if (base + 8 <= cnt && (((uintptr_t)(src + base)) & 15) == 0 && (((uintptr_t)(dst + base)) & 15) == 0) {
+      const float4 a = reinterpret_cast<const float4*>(src + base)[0], b = reinterpret_cast<const float4*>(src + base)[1];
+      TO v[8] = {ptc_from_float<TO>(a.x), ptc_from_float<TO>(a.y), ptc_from_float<TO>(a.z), ptc_from_float<TO>(a.w),
+                 ptc_from_float<TO>(b.x), ptc_from_float<TO>(b.y), ptc_from_float<TO>(b.z), ptc_from_float<TO>(b.w)};
+      *reinterpret_cast<uint4*>(dst + base) = *reinterpret_cast<const uint4*>(v);
+    } else {
+      for (int e = 0; e < 8; ++e)
+        if (base + e < cnt) dst[base + e] = ptc_from_float<TO>(src[base + e]);
+    }
+  }
+}
+
+extern "C" int ptc_cast_many(const int64_t* desc, const int64_t* prefix, int n, int64_t total_units, int dst_dtype, ptc_stream_t stream) {
+  PTC_REQUIRE(n >= 0 && total_units >= 0, PTC_EINVAL, "ptc_cast_many: bad sizes");
+  PTC_REQUIRE(dst_dtype == PTC_BF16 || dst_dtype == PTC_F16, PTC_EUNSUPPORTED, "ptc_cast_many: the shadows are bf16 or f16");
+  if (n == 0 || total_units == 0) return PTC_OK;
+  PTC_REQUIRE(desc && prefix, PTC_EINVAL, "ptc_cast_many: null buffer");
+  int64_t grid = ptc_cdiv(total_units, 256);
+  if (grid > 65536) grid = 65536;
+  if (dst_dtype == PTC_BF16)
+    hipLaunchKernelGGL(cast_many_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, desc, prefix, n, total_units);
+  else
+    hipLaunchKernelGGL(cast_many_kernel<f16_t>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, desc, prefix, n, total_units);
+  PTC_CHECK_LAUNCH("cast_many_kernel");
+  return PTC_OK;
+}
+

@@ -924,6 +924,13 @@ def weight_layouts(desc: torch.Tensor, prefix: torch.Tensor, n: int, total: int)
     check(lib().ptc_weight_layouts(ptr(desc), ptr(prefix), int(n), int(total), stream_ptr()), "ptc_weight_layouts")
 
 
+def cast_many(desc: torch.Tensor, prefix: torch.Tensor, n: int, total_units: int, dst_dtype: torch.dtype) -> None:
+    """functional._CastCache: refresh the 16-bit shadows described by desc [n,3] / prefix [n+1] (device int64) from their fp32 weights."""
+    require_cuda(desc, prefix)
+    code = {torch.bfloat16: _lib.PTC_BF16, torch.float16: _lib.PTC_F16}[dst_dtype]
+    check(lib().ptc_cast_many(ptr(desc), ptr(prefix), int(n), int(total_units), code, stream_ptr()), "ptc_cast_many")
+
+
 # ------------------------------------------------------------------------------------------------
 # libs/pointops2: pair-list attention operators (csrc/pointops2.hip), fp32
 # ------------------------------------------------------------------------------------------------

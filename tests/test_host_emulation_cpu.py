@@ -298,3 +298,41 @@ def test_whole_ptv3_step_with_every_kernel_on_the_emulation():
     with emu_backend.hybrid(names):
         T.test_ptv3_two_scenes_forward_backward_vs_oracle(torch.device("cpu"))
 
+
+def test_cast_many_kernel_on_the_emulation_and_in_the_cast_cache(monkeypatch):
+    """ptc_cast_many (one launch for the per-step fp32 -> 16-bit refresh of all weight shadows; PTC_CAST_MANY, off by default): on the
+    emulation, for bf16 and f16, tensors whose sizes are not multiples of the 8-element unit and whose storage is not 16-byte
+    aligned -- bit-identical to Tensor.to(); and through functional._CastCache (second step reuses the descriptor table, an
+    in-place update of one weight refreshes it)."""
+    import emu_backend
+    from pointcept_amd import functional as PF
+    from pointcept_amd import ops
+
+    if not emu_backend.available():
+        pytest.skip("no host clang++ under /opt/rocm")
+    g = torch.Generator().manual_seed(9)
+    big = torch.randn(4096 + 3, generator=g)
+    srcs = [torch.randn(n, generator=g) * 3 for n in (1, 7, 8, 9, 64, 1000, 27 * 32 * 32)] + [big[3:1003]]       # the last one: unaligned view
+    for dt in (torch.bfloat16, torch.float16):
+        dsts = [torch.full((s.numel(),), float("nan")).to(dt) for s in srcs]
+        rows, prefix = [], [0]
+        for s_, d_ in zip(srcs, dsts):
+            rows.append([s_.data_ptr(), d_.data_ptr(), s_.numel()])
+            prefix.append(prefix[-1] + (s_.numel() + 7) // 8)
+        with emu_backend.emulated_ops():
+            ops.cast_many(torch.tensor(rows, dtype=torch.int64), torch.tensor(prefix, dtype=torch.int64), len(rows), prefix[-1], dt)
+        for s_, d_ in zip(srcs, dsts):
+            assert torch.equal(d_, s_.to(dt)), (dt, s_.numel())
+    # through the cache
+    monkeypatch.setattr(PF, "_CAST_MANY", True)
+    cache = PF._CastCache(cuda_only=False)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))      # the cache only takes the kernel route for CUDA tensors
+    ws = [torch.nn.Parameter(torch.randn(24, 16, generator=g)), torch.nn.Parameter(torch.randn(5, 27, 8, generator=g))]
+    with emu_backend.emulated_ops():
+        for step in range(3):
+            for w in ws:
+                assert torch.equal(cache.get(w, torch.bfloat16), w.detach().to(torch.bfloat16)), step
+            with torch.no_grad():
+                ws[step % 2].mul_(1.5)                                                # the optimizer moves a weight: version counter
+    assert cache._cast_desc is not None
+
