@@ -336,3 +336,15 @@ def test_cast_many_kernel_on_the_emulation_and_in_the_cast_cache(monkeypatch):
                 ws[step % 2].mul_(1.5)                                                # the optimizer moves a weight: version counter
     assert cache._cast_desc is not None
 
+
+def test_pending_rope_kernel_gpu_test_body_on_the_emulation():
+    """tests/test_gpu_pending_hardware.py::test_rope3d_xyz_kernel_matches_reference_golden_and_inverts, body unchanged (golden cases,
+    dtype pairs, the in-place library call, the 819200-row round trip), on the emulated kernel."""
+    import emu_backend
+    import test_gpu_pending_hardware as P
+
+    if not emu_backend.available():
+        pytest.skip("no host clang++ under /opt/rocm")
+    with emu_backend.emulated_ops():
+        P.test_rope3d_xyz_kernel_matches_reference_golden_and_inverts(torch.device("cpu"))
+
