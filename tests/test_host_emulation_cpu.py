@@ -257,13 +257,15 @@ def test_ptv3m3_model_with_its_real_attention_and_rope_kernels_on_the_emulation(
 
 
 INDEX_AND_ATTENTION_OPS = ["coord_max", "serialize_encode", "sort_keys", "patch_pad_maps", "attn_tables", "pool_level_counts", "pool_maps",
-                           "pool_child_codes", "gather_rows", "segment_csr_fwd", "segment_csr_bwd", "HashTable", "rulebook_subm",
+                           "pool_child_codes", "gather_rows", "segment_csr_fwd", "segment_csr_bwd", "HashTable", "rulebook_subm", "rulebook_down",
                            "attn_varlen_fwd", "attn_varlen_bwd", "attn_hd_supported"]
 
 
 @pytest.mark.parametrize("mod,name", [("test_gpu_model", "test_ptv3_tiny_forward_matches_reference_golden_and_oracle"),
                                       ("test_gpu_model", "test_ptv3_two_scenes_forward_backward_vs_oracle"),
-                                      ("test_gpu_pending_hardware", "test_litept_matches_reference_golden")])
+                                      ("test_gpu_pending_hardware", "test_litept_matches_reference_golden"),
+                                      ("test_gpu_spunet", "test_spunet_tiny_matches_reference_golden_and_oracle"),
+                                      ("test_gpu_spunet", "test_spunet_base_channels_single_scene_and_duplicates")])
 def test_models_with_their_real_index_pipeline_and_attention_on_the_emulation(mod, name):
     """Model-level GPU tests, bodies unchanged, on the hybrid backend: the whole INDEX pipeline of the engine -- coordinate maxima,
     space-filling-curve keys, radix sort, pad / attention / pooling maps, voxel hash and submanifold rulebooks -- the row gathers,
