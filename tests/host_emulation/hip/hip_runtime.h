@@ -82,6 +82,8 @@ struct State {
   void* sched_sp = nullptr;
   dim3 block_idx, block_dim, grid_dim;
   const std::function<void()>* body = nullptr;
+  // PTC_EMU_STATS=1: per launch, the number of lane-level MFMA / transposing-LDS-read / buffer-load executions
+  unsigned long long n_mfma = 0, n_tr = 0, n_buf = 0, n_buf_oob = 0, n_shfl = 0;
 };
 inline State& S() { static State s; return s; }
 }  // namespace emu
@@ -180,8 +182,10 @@ inline void run_block() {
     }
   }
 }
-inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body, const char* what = "") {
   State& s = S();
+  const bool stats = getenv("PTC_EMU_STATS") != nullptr;
+  s.n_mfma = s.n_tr = s.n_buf = s.n_buf_oob = s.n_shfl = 0;
   const size_t n = (size_t)block.x * block.y * block.z;
   if (n == 0 || n > EMU_MAX_THREADS || shmem > EMU_LDS) { fprintf(stderr, "host emulation: launch shape not supported\n"); abort(); }
   s.n_threads = (int)n;
@@ -203,6 +207,10 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
             abort();
           }
       }
+  if (stats)
+    fprintf(stderr, "[emu] %-48.48s grid %u x %u x %u, %u threads, LDS %zu B | wave-level: MFMA %llu  ds_read_tr %llu  buffer loads %llu "
+                    "(%.0f %% of their dwords out of range)  shuffles/ballots %llu\n", what, grid.x, grid.y, grid.z, block.x * block.y * block.z,
+            shmem, s.n_mfma / 64, s.n_tr / 64, s.n_buf / 64, s.n_buf ? 25.0 * s.n_buf_oob / s.n_buf : 0.0, s.n_shfl / 64);
 }
 // per-lane exchange slot of the current wave
 inline unsigned char* slot(int lane) { State& s = S(); return s.waves[s.cur->wave].x[lane]; }
@@ -214,7 +222,7 @@ inline int lane_id() { return S().cur->lane; }
 #define blockDim (emu::S().block_dim)
 #define gridDim (emu::S().grid_dim)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  emu::launch(dim3(grid), dim3(block), (size_t)(shmem), std::function<void()>([&]() { kernel(__VA_ARGS__); }))
+  emu::launch(dim3(grid), dim3(block), (size_t)(shmem), std::function<void()>([&]() { kernel(__VA_ARGS__); }), #kernel)
 #define __syncthreads() emu::block_sync()
 #define __threadfence() ((void)0)
 #define __threadfence_block() ((void)0)
@@ -313,6 +321,7 @@ inline bool takes_part(int lane, unsigned id) { return my_wave().stamp[lane & 63
 template <typename T> inline T exchange(T v, int src_lane) {   // every lane publishes v, then reads lane src_lane's value
   static_assert(sizeof(T) <= EMU_SLOT, "exchange slot too small");
   memcpy(slot(lane_id()), &v, sizeof(T));
+  ++S().n_shfl;
   const unsigned id = enter();
   wave_sync();
   T r = v;                                                     // a source lane outside the collective: undefined on the hardware
@@ -369,6 +378,7 @@ inline ACC mfma(const EL* a, const EL* b, ACC c, CVT cvt) {
   unsigned char* me = slot(l);
   memcpy(me, a, sizeof(EL) * E);
   memcpy(me + 32, b, sizeof(EL) * E);
+  ++S().n_mfma;
   enter();
   wave_sync();
   constexpr int NOUT = M * M / 64;
@@ -411,6 +421,7 @@ template <typename P> static inline emu_s16x4 emu_ds_read_tr16_b64(P p) {
   const int l = emu::lane_id(), grp = l & ~15, j = l & 15;
   const void* addr = (const void*)p;
   memcpy(emu::slot(l), &addr, sizeof(addr));
+  ++emu::S().n_tr;
   emu::enter();
   emu::wave_sync();
   emu_s16x4 out;
@@ -433,9 +444,11 @@ static inline __amdgpu_buffer_rsrc_t emu_make_rsrc(void* p, int, int num, int) {
 static inline emu_i32x4 emu_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
   const uint32_t off = (uint32_t)voff + (uint32_t)soff;
   emu_i32x4 v = {0, 0, 0, 0};
+  ++emu::S().n_buf;
   for (int d = 0; d < 4; ++d) {
     const uint64_t o = (uint64_t)off + 4u * d;
     if (o + 4 <= r.num_records) { int w; memcpy(&w, r.base + o, 4); v[d] = w; }
+    else ++emu::S().n_buf_oob;
   }
   return v;
 }
