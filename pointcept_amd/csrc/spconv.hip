@@ -216,6 +216,7 @@ static int dispatch_fwd(const void* in, const void* w, const float* bias, const 
 #include "conv3.h"
 #include "conv4.h"
 #include "conv5.h"
+#include "conv6.h"
 
 // experiment switch (read per call, ~50 ns): PTC_CONV3=0 keeps the table convolutions on conv2
 static bool ptc_use_conv3() {
@@ -236,6 +237,10 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
   hipStream_t s = (hipStream_t)stream;
   // the second- and third-generation kernels gather through raw buffer loads (32-bit offsets, < 2 GiB tensors)
   const bool buf_ok = (uint64_t)n_in * (uint64_t)c_in * ptc_dtype_size(dtype) <= PTC_BUF_MAX_BYTES;
+  if (buf_ok && ptc_use_conv3() && conv6_enabled() && c_in == 64 && conv5_supported(dtype, kv, c_in, c_out, nbr, n_in)) {
+    if (dtype == PTC_BF16) return launch_conv6<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_out, out, s);   // candidate: compacted gathers
+    return launch_conv6<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_out, out, s);
+  }
   if (buf_ok && ptc_use_conv3() && conv5_enabled() && conv5_supported(dtype, kv, c_in, c_out, nbr, n_in)) {
     if (dtype == PTC_BF16) return launch_conv5<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
     return launch_conv5<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
