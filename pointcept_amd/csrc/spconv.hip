@@ -237,9 +237,9 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
   hipStream_t s = (hipStream_t)stream;
   // the second- and third-generation kernels gather through raw buffer loads (32-bit offsets, < 2 GiB tensors)
   const bool buf_ok = (uint64_t)n_in * (uint64_t)c_in * ptc_dtype_size(dtype) <= PTC_BUF_MAX_BYTES;
-  if (buf_ok && ptc_use_conv3() && conv6_enabled() && c_in == 64 && conv5_supported(dtype, kv, c_in, c_out, nbr, n_in)) {
-    if (dtype == PTC_BF16) return launch_conv6<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_out, out, s);   // candidate: compacted gathers
-    return launch_conv6<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_out, out, s);
+  if (buf_ok && ptc_use_conv3() && conv6_takes(c_in) && conv5_supported(dtype, kv, c_in, c_out, nbr, n_in)) {
+    if (dtype == PTC_BF16) return launch_conv6<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);   // candidate: compacted gathers
+    return launch_conv6<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
   }
   if (buf_ok && ptc_use_conv3() && conv5_enabled() && conv5_supported(dtype, kv, c_in, c_out, nbr, n_in)) {
     if (dtype == PTC_BF16) return launch_conv5<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);

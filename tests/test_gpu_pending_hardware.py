@@ -9,7 +9,7 @@ CPU stand-ins in every CPU run (tests/test_gpu_tests_dry_run_cpu.py), so the pyt
                           (config.ROPE_XYZ_KERNEL) for the same reason
   * PT-v3m3 module port   pointcept_amd/point_transformer_v3m3.py against the golden of the reference's own model file
   * LitePT module port    pointcept_amd/litept.py against the golden of the reference's own model file
-  * conv6 (PTC_CONV6=1)   conv5 with compacted gathers for c_in = 64 (csrc/conv6.h), off by default; bit-identical to conv5 on the
+  * conv6 (PTC_CONV6=1|2) conv5 with compacted gathers for c_in = 64 (2: and 32) (csrc/conv6.h), off by default; bit-identical to conv5 on the
                           host emulation (tests/test_host_emulation_cpu.py)
 """
 import os
@@ -168,11 +168,12 @@ def test_litept_matches_reference_golden(cuda):
 
 
 
-@pytest.mark.parametrize("cout,n_pts,dup", [(64, 2100, False), (96, 2100, True), (32, 1500, False), (128, 1500, True)])
-def test_spconv_fwd_compacted_gathers_are_bit_identical(cuda, cout, n_pts, dup, monkeypatch):
+@pytest.mark.parametrize("cin,cout,n_pts,dup", [(64, 64, 2100, False), (64, 96, 2100, True), (64, 32, 1500, False), (64, 128, 1500, True),
+                                                (32, 32, 2100, True), (32, 64, 2100, False), (32, 96, 1500, True)])
+def test_spconv_fwd_compacted_gathers_are_bit_identical(cuda, cin, cout, n_pts, dup, monkeypatch):
     """conv6 (csrc/conv6.h: per 8-tap chunk the present (tile row, tap) pairs are ranked with a ballot and only those rows are
     gathered, 8 pairs per 1-KB instruction instead of one tap row set per instruction) writes the same LDS images as conv5 and runs
-    the same MFMA sequence: outputs IDENTICAL to conv5 for c_in = 64, bf16 and f16, ragged row counts, duplicate voxels; and within
+    the same MFMA sequence: outputs IDENTICAL to conv5 for c_in = 64 and (PTC_CONV6=2) c_in = 32, bf16 and f16, ragged row counts, duplicate voxels; and within
     the 16-bit bar of the fp32 oracle."""
     from oracle import ops as oops
     from pointcept_amd import ops
@@ -181,18 +182,46 @@ def test_spconv_fwd_compacted_gathers_are_bit_identical(cuda, cout, n_pts, dup, 
     ind = _scene_indices(n_pts, dup=dup)
     nbr = oops.subm_rulebook(ind, 3)
     kv = nbr.shape[0]
-    g = torch.Generator().manual_seed(cout)
+    g = torch.Generator().manual_seed(cin + cout)
     nbr_d = _t(nbr, cuda)
     for dtype in (torch.bfloat16, torch.float16):
-        feat = (torch.randn(ind.shape[0], 64, generator=g) * 0.5).to(dtype).to(cuda)
-        w = (torch.randn(cout, kv, 64, generator=g) / (kv * 64) ** 0.5 * 2).to(dtype).to(cuda)
+        feat = (torch.randn(ind.shape[0], cin, generator=g) * 0.5).to(dtype).to(cuda)
+        w = (torch.randn(cout, kv, cin, generator=g) / (kv * cin) ** 0.5 * 2).to(dtype).to(cuda)
         bias = torch.randn(cout, generator=g).to(cuda)
         monkeypatch.delenv("PTC_CONV6", raising=False)
         base = ops.spconv_fwd(feat, w, bias, nbr_d)
-        monkeypatch.setenv("PTC_CONV6", "1")
+        monkeypatch.setenv("PTC_CONV6", "2")
         got = ops.spconv_fwd(feat, w, bias, nbr_d)
         monkeypatch.delenv("PTC_CONV6", raising=False)
         assert torch.isfinite(got.float()).all()
         assert torch.equal(got, base), f"{dtype}: max diff {(got.float() - base.float()).abs().max().item()}"
         rtol, atol = _tols(dtype)
         _close(f"conv6_{dtype}", got, oops.gather_conv(feat.float().cpu(), w.float().cpu(), bias.cpu(), nbr), rtol, atol)
+
+
+def test_spconv_fwd_compacted_gathers_other_tables(cuda, monkeypatch):
+    """conv6 on the other gather tables of the models: the strided k = 2 table (n_out != n_in, 8 taps = whole chunks), k = 5 (125
+    taps: a half-filled last chunk), and tables of 1 and 33 rows (partial row tiles); c_in 32 and 64; IDENTICAL to conv5."""
+    from oracle import ops as oops
+    from pointcept_amd import ops
+    from test_gpu_kernels import _close, _scene_indices, _t, _tols
+
+    ind = _scene_indices(1500, dup=True)
+    cases = [("down2", oops.down_rulebook(ind)[2], ind.shape[0]), ("subm5", oops.subm_rulebook(ind, 5), ind.shape[0]),
+             ("one_row", oops.subm_rulebook(ind[:1], 3), 1), ("33_rows", oops.subm_rulebook(ind[:33], 3), 33)]
+    for name, nbr, n_in in cases:
+        kv = nbr.shape[0]
+        nbr_d = _t(nbr, cuda)
+        for cin in (32, 64):
+            g = torch.Generator().manual_seed(kv + cin)
+            feat = (torch.randn(n_in, cin, generator=g) * 0.5).to(torch.bfloat16).to(cuda)
+            w = (torch.randn(64, kv, cin, generator=g) / (kv * cin) ** 0.5 * 2).to(torch.bfloat16).to(cuda)
+            bias = torch.randn(64, generator=g).to(cuda)
+            monkeypatch.delenv("PTC_CONV6", raising=False)
+            base = ops.spconv_fwd(feat, w, bias, nbr_d)
+            monkeypatch.setenv("PTC_CONV6", "2")
+            got = ops.spconv_fwd(feat, w, bias, nbr_d)
+            monkeypatch.delenv("PTC_CONV6", raising=False)
+            assert torch.equal(got, base), f"{name} c_in={cin}: max diff {(got.float() - base.float()).abs().max().item()}"
+            rtol, atol = _tols(torch.bfloat16)
+            _close(f"conv6_{name}_{cin}", got, oops.gather_conv(feat.float().cpu(), w.float().cpu(), bias.cpu(), nbr), rtol, atol)

@@ -352,10 +352,11 @@ def test_pending_rope_kernel_gpu_test_body_on_the_emulation():
 
 
 
-@pytest.mark.parametrize("cout,n_pts,dup", [(64, 1200, False), (96, 900, True), (32, 900, True), (128, 700, True)])
-def test_pending_conv6_compacted_gathers_gpu_test_body_on_the_emulation(cout, n_pts, dup, monkeypatch, capfd):
+@pytest.mark.parametrize("cin,cout,n_pts,dup", [(64, 64, 1200, False), (64, 96, 900, True), (64, 32, 900, True), (64, 128, 700, True),
+                                                (32, 32, 1200, True), (32, 64, 900, False), (32, 96, 900, True)])
+def test_pending_conv6_compacted_gathers_gpu_test_body_on_the_emulation(cin, cout, n_pts, dup, monkeypatch, capfd):
     """tests/test_gpu_pending_hardware.py::test_spconv_fwd_compacted_gathers_are_bit_identical, body unchanged, on the emulated
-    conv5 / conv6 kernels (PTC_CONV6, off by default, never run on hardware): bit-identical outputs, same MFMA count, fewer
+    conv5 / conv6 kernels (PTC_CONV6, off by default, never run on hardware; c_in 64 and 32): bit-identical outputs, same MFMA count, fewer
     wave-level gather instructions (the emulator's work counters)."""
     import re
 
@@ -366,7 +367,7 @@ def test_pending_conv6_compacted_gathers_gpu_test_body_on_the_emulation(cout, n_
         pytest.skip("no host clang++ under /opt/rocm")
     monkeypatch.setenv("PTC_EMU_STATS", "1")
     with emu_backend.emulated_ops():
-        P.test_spconv_fwd_compacted_gathers_are_bit_identical(torch.device("cpu"), cout, n_pts, dup, monkeypatch)
+        P.test_spconv_fwd_compacted_gathers_are_bit_identical(torch.device("cpu"), cin, cout, n_pts, dup, monkeypatch)
     err = capfd.readouterr().err
     rows = re.findall(r"\[emu\].*?LDS (\d+) B.*?MFMA (\d+)\s+ds_read_tr (\d+)\s+buffer loads (\d+)", err)
     rows = [r for r in rows if int(r[1]) > 0]                        # the convolution launches (rulebook kernels have no MFMA)
@@ -375,3 +376,14 @@ def test_pending_conv6_compacted_gathers_gpu_test_body_on_the_emulation(cout, n_
         assert int(b[0]) > int(a[0]), (a, b)                         # conv6's LDS footprint (list + two image sets), not conv5 twice
         assert a[1] == b[1], (a, b)                                  # same MFMA work
         assert int(b[3]) < 0.85 * int(a[3]), (a, b)                  # fewer wave-level gather instructions
+
+
+def test_pending_conv6_other_tables_gpu_test_body_on_the_emulation(monkeypatch):
+    """tests/test_gpu_pending_hardware.py::test_spconv_fwd_compacted_gathers_other_tables, body unchanged, on the emulated kernels"""
+    import emu_backend
+    import test_gpu_pending_hardware as P
+
+    if not emu_backend.available():
+        pytest.skip("no host clang++ under /opt/rocm")
+    with emu_backend.emulated_ops():
+        P.test_spconv_fwd_compacted_gathers_other_tables(torch.device("cpu"), monkeypatch)
