@@ -549,6 +549,8 @@ static int launch_wgrad2_inst(const W2Plan& p, const void* in, int64_t n_in, con
   return PTC_OK;
 }
 
+#include "wgrad3.h"
+
 template <typename T>
 static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
                          float* dw, float* dbias, void* ws, hipStream_t s) {
@@ -558,6 +560,9 @@ static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const i
   float* bias_partial = nullptr;
   if (dbias) bias_partial = p.gx > 1 ? (float*)((char*)ws + ptc_align_up((size_t)p.gx * (size_t)count * sizeof(float), 256)) : dbias;
   int rc = PTC_EUNSUPPORTED;
+  if (wgrad3_takes(p, nbr, c_in, dbias != nullptr))   // candidate: compacted gathers
+    rc = launch_wgrad3<T>(p, in, n_in, dout, nbr, n_out, kv, c_out, partial, s);
+  else {
 #define W2_CASE(COT, CIT, KG)                                                                                         \
   if (p.cot == COT && p.cit == CIT && p.kg == KG)                                                                     \
     rc = launch_wgrad2_inst<T, COT, CIT, KG>(p, in, n_in, dout, nbr, n_out, kv, c_in, c_out, partial, bias_partial, s);
@@ -565,6 +570,7 @@ static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const i
   W2_CASE(6, 1, 1) W2_CASE(6, 2, 1) W2_CASE(6, 4, 1) W2_CASE(8, 1, 1) W2_CASE(8, 2, 1) W2_CASE(8, 4, 1)
   W2_CASE(2, 1, 16) W2_CASE(2, 2, 4) W2_CASE(4, 2, 4) W2_CASE(2, 4, 4) W2_CASE(4, 4, 2) W2_CASE(6, 2, 2)
 #undef W2_CASE
+  }
   if (rc != PTC_OK) {
     if (rc == PTC_EUNSUPPORTED) ptc_set_error("ptc_spconv_wgrad: no wgrad2 instance for tiles (%d,%d,%d)", p.cot, p.cit, p.kg);
     return rc;

@@ -11,6 +11,8 @@ CPU stand-ins in every CPU run (tests/test_gpu_tests_dry_run_cpu.py), so the pyt
   * LitePT module port    pointcept_amd/litept.py against the golden of the reference's own model file
   * conv6 (PTC_CONV6=1|2) conv5 with compacted gathers for c_in = 64 (2: and 32) (csrc/conv6.h), off by default; bit-identical to conv5 on the
                           host emulation (tests/test_host_emulation_cpu.py)
+  * wgrad3 (PTC_WGRAD3=1) wgrad2 with compacted gathers for the 64-input-channel instance (csrc/wgrad3.h), off by default; bit-identical
+                          to wgrad2 on the host emulation
 """
 import os
 
@@ -225,3 +227,35 @@ def test_spconv_fwd_compacted_gathers_other_tables(cuda, monkeypatch):
             assert torch.equal(got, base), f"{name} c_in={cin}: max diff {(got.float() - base.float()).abs().max().item()}"
             rtol, atol = _tols(torch.bfloat16)
             _close(f"conv6_{name}_{cin}", got, oops.gather_conv(feat.float().cpu(), w.float().cpu(), bias.cpu(), nbr), rtol, atol)
+
+
+def test_spconv_wgrad_compacted_gathers_are_bit_identical(cuda, monkeypatch):
+    """wgrad3 (csrc/wgrad3.h: one entry load per 32-row step, present (table row, row) pairs ranked with a ballot and gathered 8 per
+    instruction, written rows cleared after the step) feeds wgrad2's MFMA sequence the same operands: dw IDENTICAL to wgrad2 for
+    c_in = 64 at c_out 48 / 64 / 128, bf16 and f16, duplicate voxels, the strided k = 2 table (n_out != n_in), 1 and 33 rows; and
+    within the fp32-accumulation bar of the oracle."""
+    from oracle import ops as oops
+    from pointcept_amd import ops
+    from test_gpu_kernels import _scene_indices, _t
+
+    ind = _scene_indices(700, dup=True)
+    cases = [("subm3", oops.subm_rulebook(ind, 3), ind.shape[0]), ("down2", oops.down_rulebook(ind)[2], ind.shape[0]),
+             ("one_row", oops.subm_rulebook(ind[:1], 3), 1), ("33_rows", oops.subm_rulebook(ind[:33], 3), 33)]
+    for name, nbr, n_in in cases:
+        kv, n_out = nbr.shape
+        nbr_d = _t(nbr, cuda)
+        for dtype in (torch.bfloat16, torch.float16):
+            for cout in (64, 128, 48):
+                g = torch.Generator().manual_seed(kv + cout)
+                feat = (torch.randn(n_in, 64, generator=g) * 0.5).to(dtype).to(cuda)
+                dout = (torch.randn(n_out, cout, generator=g) * 0.5).to(dtype).to(cuda)
+                monkeypatch.delenv("PTC_WGRAD3", raising=False)
+                base = ops.spconv_wgrad(feat, dout, nbr_d)
+                monkeypatch.setenv("PTC_WGRAD3", "1")
+                got = ops.spconv_wgrad(feat, dout, nbr_d)
+                monkeypatch.delenv("PTC_WGRAD3", raising=False)
+                assert torch.equal(got, base), f"{name} {dtype} c_out={cout}: max diff {(got - base).abs().max().item()}"
+                x, dy = feat.float().cpu(), dout.float().cpu()
+                nb = torch.from_numpy(np.ascontiguousarray(nbr)).long()
+                want = torch.stack([dy.t() @ torch.where((nb[k] >= 0).view(-1, 1), x[nb[k].clamp(min=0)], torch.zeros(1)) for k in range(kv)], 1)
+                assert float((got.cpu() - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max())), (name, dtype, cout)

@@ -387,3 +387,27 @@ def test_pending_conv6_other_tables_gpu_test_body_on_the_emulation(monkeypatch):
         pytest.skip("no host clang++ under /opt/rocm")
     with emu_backend.emulated_ops():
         P.test_spconv_fwd_compacted_gathers_other_tables(torch.device("cpu"), monkeypatch)
+
+
+def test_pending_wgrad3_compacted_gathers_gpu_test_body_on_the_emulation(monkeypatch, capfd):
+    """tests/test_gpu_pending_hardware.py::test_spconv_wgrad_compacted_gathers_are_bit_identical, body unchanged, on the emulated
+    wgrad2 / wgrad3 kernels (PTC_WGRAD3, off by default, never run on hardware); the work counters prove the variant ran: same MFMA
+    and transposing-read counts, fewer wave-level gather instructions."""
+    import re
+
+    import emu_backend
+    import test_gpu_pending_hardware as P
+
+    if not emu_backend.available():
+        pytest.skip("no host clang++ under /opt/rocm")
+    monkeypatch.setenv("PTC_EMU_STATS", "1")
+    with emu_backend.emulated_ops():
+        P.test_spconv_wgrad_compacted_gathers_are_bit_identical(torch.device("cpu"), monkeypatch)
+    err = capfd.readouterr().err
+    rows = re.findall(r"\[emu\].*?LDS (\d+) B.*?MFMA (\d+)\s+ds_read_tr (\d+)\s+buffer loads (\d+)", err)
+    rows = [r for r in rows if int(r[2]) > 0]                       # the weight-gradient launches (transposing reads)
+    assert len(rows) == 48, len(rows)                                # 4 tables x 2 dtypes x 3 widths x (wgrad2, wgrad3)
+    for a, b in zip(rows[0::2], rows[1::2]):
+        assert int(b[0]) == int(a[0]) + 4 * 512, (a, b)             # wgrad3's LDS footprint: + the pair list of each wave
+        assert a[1] == b[1] and a[2] == b[2], (a, b)                # same MFMA and fragment-read work
+        assert int(b[3]) < int(a[3]), (a, b)                        # fewer wave-level buffer loads

