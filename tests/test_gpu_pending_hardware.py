@@ -11,7 +11,7 @@ CPU stand-ins in every CPU run (tests/test_gpu_tests_dry_run_cpu.py), so the pyt
   * LitePT module port    pointcept_amd/litept.py against the golden of the reference's own model file
   * conv6 (PTC_CONV6=1|2) conv5 with compacted gathers for c_in = 64 (2: and 32) (csrc/conv6.h), off by default; bit-identical to conv5 on the
                           host emulation (tests/test_host_emulation_cpu.py)
-  * wgrad3 (PTC_WGRAD3=1) wgrad2 with compacted gathers for the 64-input-channel instance (csrc/wgrad3.h), off by default; bit-identical
+  * wgrad3 (PTC_WGRAD3=1|2) wgrad2 with compacted gathers for the 64- (2: and 32-) input-channel instances (csrc/wgrad3.h), off by default; bit-identical
                           to wgrad2 on the host emulation
 """
 import os
@@ -232,7 +232,7 @@ def test_spconv_fwd_compacted_gathers_other_tables(cuda, monkeypatch):
 def test_spconv_wgrad_compacted_gathers_are_bit_identical(cuda, monkeypatch):
     """wgrad3 (csrc/wgrad3.h: one entry load per 32-row step, present (table row, row) pairs ranked with a ballot and gathered 8 per
     instruction, written rows cleared after the step) feeds wgrad2's MFMA sequence the same operands: dw IDENTICAL to wgrad2 for
-    c_in = 64 at c_out 48 / 64 / 128, bf16 and f16, duplicate voxels, the strided k = 2 table (n_out != n_in), 1 and 33 rows; and
+    c_in = 64 at c_out 48 / 64 / 128 and (PTC_WGRAD3=2) c_in = 32 at c_out 32 / 64, bf16 and f16, duplicate voxels, the strided k = 2 table (n_out != n_in), 1 and 33 rows; and
     within the fp32-accumulation bar of the oracle."""
     from oracle import ops as oops
     from pointcept_amd import ops
@@ -245,17 +245,17 @@ def test_spconv_wgrad_compacted_gathers_are_bit_identical(cuda, monkeypatch):
         kv, n_out = nbr.shape
         nbr_d = _t(nbr, cuda)
         for dtype in (torch.bfloat16, torch.float16):
-            for cout in (64, 128, 48):
+            for cin, cout in ((64, 64), (64, 128), (64, 48), (32, 32), (32, 64)):
                 g = torch.Generator().manual_seed(kv + cout)
-                feat = (torch.randn(n_in, 64, generator=g) * 0.5).to(dtype).to(cuda)
+                feat = (torch.randn(n_in, cin, generator=g) * 0.5).to(dtype).to(cuda)
                 dout = (torch.randn(n_out, cout, generator=g) * 0.5).to(dtype).to(cuda)
                 monkeypatch.delenv("PTC_WGRAD3", raising=False)
                 base = ops.spconv_wgrad(feat, dout, nbr_d)
-                monkeypatch.setenv("PTC_WGRAD3", "1")
+                monkeypatch.setenv("PTC_WGRAD3", "2")
                 got = ops.spconv_wgrad(feat, dout, nbr_d)
                 monkeypatch.delenv("PTC_WGRAD3", raising=False)
-                assert torch.equal(got, base), f"{name} {dtype} c_out={cout}: max diff {(got - base).abs().max().item()}"
+                assert torch.equal(got, base), f"{name} {dtype} {cin}->{cout}: max diff {(got - base).abs().max().item()}"
                 x, dy = feat.float().cpu(), dout.float().cpu()
                 nb = torch.from_numpy(np.ascontiguousarray(nbr)).long()
                 want = torch.stack([dy.t() @ torch.where((nb[k] >= 0).view(-1, 1), x[nb[k].clamp(min=0)], torch.zeros(1)) for k in range(kv)], 1)
-                assert float((got.cpu() - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max())), (name, dtype, cout)
+                assert float((got.cpu() - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max())), (name, dtype, cin, cout)

@@ -406,8 +406,8 @@ def test_pending_wgrad3_compacted_gathers_gpu_test_body_on_the_emulation(monkeyp
     err = capfd.readouterr().err
     rows = re.findall(r"\[emu\].*?LDS (\d+) B.*?MFMA (\d+)\s+ds_read_tr (\d+)\s+buffer loads (\d+)", err)
     rows = [r for r in rows if int(r[2]) > 0]                       # the weight-gradient launches (transposing reads)
-    assert len(rows) == 48, len(rows)                                # 4 tables x 2 dtypes x 3 widths x (wgrad2, wgrad3)
+    assert len(rows) == 80, len(rows)                                # 4 tables x 2 dtypes x 5 shapes x (wgrad2, wgrad3)
     for a, b in zip(rows[0::2], rows[1::2]):
-        assert int(b[0]) == int(a[0]) + 4 * 512, (a, b)             # wgrad3's LDS footprint: + the pair list of each wave
+        assert int(b[0]) in (int(a[0]) + 4 * 512, int(a[0]) + 4 * 1024), (a, b)   # wgrad3's LDS footprint: + the pair list of each wave
         assert a[1] == b[1] and a[2] == b[2], (a, b)                # same MFMA and fragment-read work
         assert int(b[3]) < int(a[3]), (a, b)                        # fewer wave-level buffer loads
