@@ -208,7 +208,7 @@ def test_spconv_fwd_compacted_gathers_other_tables(cuda, monkeypatch):
     from pointcept_amd import ops
     from test_gpu_kernels import _close, _scene_indices, _t, _tols
 
-    ind = _scene_indices(1500, dup=True)
+    ind = _scene_indices(600, dup=True)
     cases = [("down2", oops.down_rulebook(ind)[2], ind.shape[0]), ("subm5", oops.subm_rulebook(ind, 5), ind.shape[0]),
              ("one_row", oops.subm_rulebook(ind[:1], 3), 1), ("33_rows", oops.subm_rulebook(ind[:33], 3), 33)]
     for name, nbr, n_in in cases:
@@ -238,7 +238,7 @@ def test_spconv_wgrad_compacted_gathers_are_bit_identical(cuda, monkeypatch):
     from pointcept_amd import ops
     from test_gpu_kernels import _scene_indices, _t
 
-    ind = _scene_indices(700, dup=True)
+    ind = _scene_indices(350, dup=True)
     cases = [("subm3", oops.subm_rulebook(ind, 3), ind.shape[0]), ("down2", oops.down_rulebook(ind)[2], ind.shape[0]),
              ("one_row", oops.subm_rulebook(ind[:1], 3), 1), ("33_rows", oops.subm_rulebook(ind[:33], 3), 33)]
     for name, nbr, n_in in cases:
