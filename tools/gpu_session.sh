@@ -6,6 +6,8 @@
 #   roof       rocprofv3 stats + PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) of the roofline kernel
 #   pending    tests/test_gpu_pending_hardware.py with PTC_RUN_PENDING=1 (code that has not run on hardware yet)
 #   conv6      tools/bench_ops.py --only stages,spconv with conv5 / wgrad2 (default), PTC_CONV6 = PTC_WGRAD3 = 1 (c_in 64) and = 2 (c_in 32 too); run `pending` first
+#              (conv6 is dispatched before conv5 whatever PTC_CONV5 / PTC_CONV3_* say: under PTC_CONV6 every column of a
+#              c_in-64 (=2: and c_in-32) row of `stages` is conv6 -- compare the conv5 and wgrad columns ACROSS the three logs)
 #   w2sweep    small weight gradients of the deep stages under the PTC_W2_TARGET_WGS / PTC_W2_MIN_STEPS plan knobs
 TAG=${1:-s}; shift
 export TMPDIR=/tmp
