@@ -231,22 +231,26 @@ int ptc_rulebook_down_fill(const int32_t* indices, int64_t n_in, const int32_t* 
 int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float* bias,
                    const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out, int dtype,
                    void* out, ptc_stream_t stream);
-/* Block-local form of a submanifold gather table (csrc/blocks.hip) and the convolution that uses it (csrc/conv4.h).
+/* Block-local form of a submanifold 3^3 gather table (csrc/blocks.hip) and the convolution that uses it (csrc/conv7.h).
  * Replaces nothing new in the reference: it is a faster way to run the SAME SubMConv3d call sites as ptc_spconv_fwd
  * (ptv3m1:278-284; spconv_unet_v1m1_base.py:49-68) when rows are in a spatial (curve) order.
- *   ptc_rulebook_blocks: for every block of `bm` consecutive output rows (bm = 128 | 256)
- *       halo [n_blocks][hmax] int32 = the distinct input rows named by nbr[:, block], ascending
- *       hcnt [n_blocks]       int32 = how many (hmax + 1 = more than hmax: block served through the global table)
- *       lnbr [kv][n]          int16 = position of nbr[k][row] in its block's halo list (-1 = none)
- *       *n_overflow (device int32)  = number of blocks with hcnt > hmax (diagnostic; nothing depends on it)
- *     hmax <= 1024 and a multiple of 4.
- *   ptc_spconv_fwd_blk: same result as ptc_spconv_fwd(in, ..., nbr, ...) -- bit-identical -- with the input rows of a
- *       block staged once in LDS.  16-bit dtypes, c_in in {32,64,96,128} with c_out % 32 == 0 and kv >= 2; any other
- *       shape is forwarded to ptc_spconv_fwd. */
-int ptc_rulebook_blocks(const int32_t* nbr, int kv, int64_t n, int bm, int hmax, int16_t* lnbr, int32_t* halo,
+ *   ptc_rulebook_blocks: for every block of bm = 128 consecutive output rows of nbr [27][n]
+ *       hid  [n_blocks][hcap] int32 = the distinct input rows named by nbr[:, block], ascending, padded with the last one to
+ *                                     a multiple of 16 entries
+ *       hcnt [n_blocks]       int32 = how many (-1 = more than hcap: block served through the global table)
+ *       tab  [n_blocks][28][16][8] uint16 (ptc_rulebook_blocks_tab_bytes(n) bytes, 16-byte aligned) = position of
+ *                                     nbr[k][128 b + 16 t + r] in its block's list at [b][k][r][t], 0xFFFF = none; row k = 27 padding
+ *       *n_overflow (device int32)  = number of blocks with hcnt = -1 (diagnostic; nothing depends on it)
+ *     hcap a multiple of 16, <= 512.
+ *   ptc_spconv_fwd_blk: same result as ptc_spconv_fwd(in, ..., nbr, ...) up to the fp32 rounding of a different summation
+ *       order, with the input rows of a block staged once in LDS and the weights held in registers.  16-bit dtypes,
+ *       kv = 27, c_in = c_out in {32, 64}, bm = 128, hcap = 416, n_in = n_out >= 4096; any other shape is forwarded to
+ *       ptc_spconv_fwd. */
+size_t ptc_rulebook_blocks_tab_bytes(int64_t n);
+int ptc_rulebook_blocks(const int32_t* nbr, int kv, int64_t n, int bm, int hcap, void* tab, int32_t* hid,
                         int32_t* hcnt, int32_t* n_overflow, ptc_stream_t stream);
 int ptc_spconv_fwd_blk(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr,
-                       const int16_t* lnbr, const int32_t* halo, const int32_t* hcnt, int bm, int hmax, int64_t n_out,
+                       const void* tab, const int32_t* hid, const int32_t* hcnt, int bm, int hcap, int64_t n_out,
                        int kv, int c_in, int c_out, int dtype, void* out, ptc_stream_t stream);
 /* Dense row-wise GEMM out = in W^T + b with an MLP epilogue fused (PTv3 MLP, ptv3m1:225-248: fc1 -> GELU -> fc2):
  *   epilogue 1 : out = h (the pre-activation, saved for the backward), aux_out = GELU(h)         [fc1 forward]

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "ptc_rulebook_down_count": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_rulebook_down_fill": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_spconv_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "ptc_rulebook_blocks_tab_bytes": (c_size, [c_i64]),
     "ptc_rulebook_blocks": (c_int, [c_ptr, c_int, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_spconv_fwd_blk": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_int, c_int,
                                    c_ptr, c_ptr]),

@@ -18,12 +18,6 @@ settings), and so a regression can be bisected without a rebuild.
                      up-front copy of all level sizes (ptc_pool_level_counts)
   PTC_RPE_KERNEL=0   the RPE attention branch (enable_flash=False, enable_rpe=True) keeps the dense [P,H,K,K] torch
                      formulation under bf16 autocast instead of the window-attention kernels of csrc/attention_rpe.h
-  PTC_ROPE_XYZ_KERNEL=1  PT-v3m3's Point3DRoPE runs on ptc_rope3d_xyz (one pass over the packed qkv rows, bf16 out) instead of the
-                     torch formulation.  DEFAULT OFF until the kernel has been through the GPU tests (written after round 2's GPU
-                     time was spent; tests/test_gpu_unvalidated.py holds its parity test)
-  PTC_FOLD_CPE=1     the Linear that follows the 3^3 convolution of a PTv3 block's positional encoding (cpe.0 -> cpe.1) is folded into
-                     the convolution's weights every step (W' = W_lin W_k, 27 small products) for blocks of <= 128 channels: one GEMM
-                     pass, its input gradient and its weight gradient less per block.  DEFAULT OFF: candidate, not measured yet
   PTC_FUSE_BLOCK=0   the three residual joints of a PTv3 Block run as separate LayerNorm / add / cast
                      kernels instead of the fused add_norm passes
 """
@@ -47,5 +41,3 @@ FUSE_BLOCK = _flag("PTC_FUSE_BLOCK", True)
 FUSE_MLP = _flag("PTC_FUSE_MLP", True)
 PREFETCH_LEVELS = _flag("PTC_PREFETCH_LEVELS", True)
 RPE_KERNEL = _flag("PTC_RPE_KERNEL", True)
-ROPE_XYZ_KERNEL = _flag("PTC_ROPE_XYZ_KERNEL", False)
-FOLD_CPE = _flag("PTC_FOLD_CPE", False)

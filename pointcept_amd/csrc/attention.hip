@@ -57,8 +57,6 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define AT_MIN_WAVES 4          // waves per SIMD the register budget must allow (two 8-wave workgroups per CU)
 #define AT_LOG2E 1.4426950408889634f
 #define AT_LN2 0.6931471805599453f
-#define AT_BWD_PIPE_DEFAULT 0     // backward loop form (0 = in order, 3 = two-stage pipeline at one workgroup per CU), see attn_bwd_dq_kernel
-#define AT_FWD_DEFAULT 2         // forward variant bit mask (1 = Q1, 2 = PRIO, 4 = TRUNC), see attn_fwd_kernel
 #define AT_FIXED_REF_MAX 64.0f   // largest Cauchy-Schwarz bound (exp2 domain) served by the fixed-reference loop
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
@@ -211,17 +209,9 @@ __host__ __device__ __forceinline__ int at_split(int n_units, int lp_max) {
   return qs;
 }
 
-// PTC_ATTN_SPLIT=<1|2|4> forces the split where the shape allows it (A/B knob).  Why one would: at the bench shape 3200 units fill the
-// 512 workgroup slots 6.25 times -- seven rounds of work for 6.25, 10.7 % of the launch idle in the last round -- while 6400 half
-// units take 13 rounds for 12.5 (3.8 %), at the price of staging the other side twice.  Not measured yet; the default is unchanged.
-static inline int at_split_host(int n_units, int lp_max) {
-  int qs = at_split(n_units, lp_max);
-  if (const char* e = getenv("PTC_ATTN_SPLIT")) {
-    const int want = atoi(e);
-    if ((want == 1 || want == 2 || want == 4) && (lp_max >> 5) / (2 * want) >= AT_WAVES) qs = want;
-  }
-  return qs;
-}
+// (forcing a finer split at the bench shape -- 6400 half units instead of 3200 units on 512 slots, a shorter last round -- was measured
+//  neutral in the step: 50.3 vs 49.8 ms, profiles/r03_a_knob_ab.txt; removed)
+static inline int at_split_host(int n_units, int lp_max) { return at_split(n_units, lp_max); }
 
 // A sequence longer than max_seqlen (cu_seqlens built for a larger patch than the caller's max_seqlen, or a caller
 // of the flash_attn API passing inconsistent arguments) would overrun the LDS images, which are sized from
@@ -241,13 +231,9 @@ __device__ __forceinline__ void at_poison_rows(uint16_t* rows, int64_t row_strid
 // forward
 // ================================================================================================
 // LDS: K row-major [lp_max][16] | V^T [17][pitch] (row 16 = 1.0 for keys < L, else 0) | 8 floats (reduction)
-// Variants measured against each other in one process (PTC_ATTN_FWD bit mask, tools/bench_ops.py attn):
-//   Q1    : the scaled query q*c is rounded to ONE bf16 operand (no hi + lo split): 3 MFMAs per tile instead of 4; the logits
-//           then carry a 2^-9 relative error (flash-attn itself multiplies the fp32 product by the scale: exact)
-//   PRIO  : s_setprio 1 for the second-dispatched half of the workgroup's waves (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-//   TRUNC : P is packed to bf16 by truncation (one v_perm_b32, a full-rate VALU op) instead of v_cvt_pk_bf16_f32 (RNE, ~1.6x
-//           the issue cost); numerator and denominator use the same truncated values, so the bias cancels in the ratio
-template <bool Q1, bool PRIO, bool TRUNC>
+// The second-dispatched half of the workgroup's waves runs at s_setprio 1 (MI355X_MICROARCH.md, two waves per SIMD, item 4).  Measured and
+// dropped (round 1/2, profiles/r02_g_attn_variants.txt, r02_h_attn_variants.txt): rounding the scaled query to ONE bf16 operand (3 MFMAs per
+// tile instead of 4, 2^-9 relative logit error) and packing P by truncation (v_perm_b32 instead of v_cvt_pk_bf16_f32).
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
                 int lp_max, int n_units, int qs, uint16_t* __restrict__ out, float* __restrict__ lse) {
@@ -287,7 +273,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 
   const int col = lane & 31, h2 = lane >> 5;
   const float c = scale * AT_LOG2E;
-  if (PRIO && wave >= AT_WAVES / 2) __builtin_amdgcn_s_setprio(1);
+  if (wave >= AT_WAVES / 2) __builtin_amdgcn_s_setprio(1);
   // A operand of the P V product: lane col <= 16 reads image row col (16 = denominator row); lanes
   // col > 16 feed output rows nobody reads and alias rows 1..15.  One 16-byte read per 16 keys.
   const unsigned char* vbase = Vt + ((size_t)(col <= 16 ? col : (col & 15)) * pitch + 8 * h2) * 2;
@@ -329,7 +315,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
       auto s_tile = [&]() {
         const s16x8 kf = kfn;
         f32x16 sv = mfma32(kf, qhi, negb);  // S'^T[key][q] = k.(q c) - bnd: lane = q, regs = keys crow(r,h2)
-        if (!Q1) sv = mfma32(kf, qlo, sv);
+        sv = mfma32(kf, qlo, sv);
         kfn = ldk();
         return sv;
       };
@@ -342,7 +328,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float e0 = __builtin_amdgcn_exp2f(sv[2 * i]), e1 = __builtin_amdgcn_exp2f(sv[2 * i + 1]);
-          pk[i] = TRUNC ? __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u) : pack_bf16x2(e0, e1);
+          pk[i] = pack_bf16x2(e0, e1);
         }
       };
       s16x8 vf0, vf1;
@@ -357,24 +343,13 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
       };
       auto interleave = [&]() {
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);     // the trip's three LDS reads first
-        if constexpr (!Q1) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA, and in its shadow:
-            __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);   //   four transcendentals (v_exp_f32)
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   //   two plain VALU (v_cvt_pk_bf16_f32 / v_perm_b32)
-          }
-        } else {                                                 // three MFMAs per tile: 6 + 5 + 5 exps, 3 + 3 + 2 packs
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x400, 6, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x400, 5, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x400, 5, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA, and in its shadow:
+          __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);   //   four transcendentals (v_exp_f32)
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   //   two plain VALU (v_cvt_pk_bf16_f32 / v_perm_b32)
         }
+      
       };
       // S' of one tile past the end is computed and never used (it reads the V^T image: in-bounds LDS),
       // which keeps the trip body branch-free.
@@ -413,7 +388,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
         const s16x8 kf = *reinterpret_cast<const s16x8*>(kp);
         kp += 1024;
         f32x16 s = mfma32(kf, qhi, zero16());
-        if (!Q1) s = mfma32(kf, qlo, s);
+        s = mfma32(kf, qlo, s);
         if (kt == n_tiles - 1 && L < Lp) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
@@ -460,18 +435,13 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 // backward, part 1: dQ (query-stationary) + delta = rowsum(dO * O)
 // ================================================================================================
 // LDS: V row-major [lp_max][16] | K row-major [lp_max][16]
-// PIPE: 0 = one tile per trip, products and vector work in program order (default);
-//       3 = two-stage software pipeline, two tiles per trip with ping-pong registers (the S' / dP' products of tile kt+1 are
-//           issued before the exp / multiply / pack of tile kt), compiled for a 256-register budget, i.e. one workgroup per
-//           CU.  Same arithmetic in the same order: bit-identical results.  MEASURED SLOWER (dec0 shape: 1487 vs 1406 us;
-//           within the 128-register budget of two workgroups per CU the second S' / dP' pair spills: 2499 us; with
-//           sched_group_barrier pins on top: 8895 us; profiles/r02_o_slp_ab.txt) -- four in-order waves per SIMD already
-//           interleave better than two pipelined ones.  Kept behind PTC_ATTN_BWD_PIPE=3 as the A/B form.
-template <int PIPE, int LP>   // LP = lp_max at compile time (1024: image distances become immediate offsets) or 0 = runtime
-__global__ void __launch_bounds__(AT_THREADS, PIPE >= 3 ? 2 : AT_MIN_WAVES)
+// One tile per trip, products and vector work in program order: four in-order waves per SIMD interleave better than a two-stage software
+// pipeline at one workgroup per CU (measured 1487 vs 1406 us at the dec0 shape, profiles/r02_o_slp_ab.txt; removed).
+template <int LP>   // LP = lp_max at compile time (1024: image distances become immediate offsets) or 0 = runtime
+__global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                    const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                   int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, float* __restrict__ delta, int prio) {
+                   int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, float* __restrict__ delta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lunit = at_unit(n_units * qs);
   if (lunit >= n_units * qs) return;
@@ -498,7 +468,6 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
   const float c = scale * AT_LOG2E;
   const TrAddr ta = tr_addr(lane);
   const int rmo = rm_off(col, h2);
-  if (prio && wave >= AT_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // as the forward's PRIO variant (bit-identical)
 
   for (int qt = t_lo + wave; qt < t_hi; qt += AT_WAVES) {
     const int q = qt * 32 + col;
@@ -517,7 +486,7 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
     split_scaled(qf, c, qhi, qlo);
     const f32x16 negl = splat16(-l2), negd = splat16(-dl);
     f32x16 acc = zero16();
-    if constexpr (PIPE == 0) {
+    {
       // three per-lane LDS pointers advanced once per trip, everything else immediate offsets (see attn_bwd_dkv_kernel);
       // the V image sits KOFF bytes BEFORE the K image
       const int KOFF = LP ? LP * 32 : lp_max * 32;
@@ -549,36 +518,6 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
         pv += 2048; pl += 2048; ph += 2048;
       }
       if (kt < n_tiles) tile(0);
-    } else {
-      const unsigned char* kb = Ksm + rmo;
-      const unsigned char* vb = Vsm + rmo;
-      s16x8 kf = *reinterpret_cast<const s16x8*>(kb), vf = *reinterpret_cast<const s16x8*>(vb);
-      f32x16 sa, da, sb, db;
-      sa = mfma32(kf, qhi, negl);
-      sa = mfma32(kf, qlo, sa);
-      da = mfma32(vf, dof, negd);
-      // one step: consume (s, dp) of tile kt, produce (sn, dpn) of tile kt + 1 (clamped: the last step recomputes the last tile, unused)
-      auto step = [&](const f32x16& sc, const f32x16& dc, f32x16& sn, f32x16& dn, int kt) {
-        const int nx = (kt + 1 < n_tiles ? kt + 1 : kt) * 1024;
-        kf = *reinterpret_cast<const s16x8*>(kb + nx);
-        vf = *reinterpret_cast<const s16x8*>(vb + nx);
-        const s16x8 kt0 = ld_tr_frag(Ksm, ta, kt * 32), kt1 = ld_tr_frag(Ksm, ta, kt * 32 + 16);
-        sn = mfma32(kf, qhi, negl);
-        sn = mfma32(kf, qlo, sn);
-        dn = mfma32(vf, dof, negd);
-        uint32_t pk[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(sc[2 * i]) * dc[2 * i], __builtin_amdgcn_exp2f(sc[2 * i + 1]) * dc[2 * i + 1]);
-        acc = mfma32(kt0, make_frag(pk[0], pk[1], pk[2], pk[3]), acc);
-        acc = mfma32(kt1, make_frag(pk[4], pk[5], pk[6], pk[7]), acc);
-      };
-      int kt = 0;
-      for (; kt + 1 < n_tiles; kt += 2) {
-        step(sa, da, sb, db, kt);
-        step(sb, db, sa, da, kt + 1);
-      }
-      if (kt < n_tiles) step(sa, da, sb, db, kt);
     }
     if (qv) {
       uint16_t* o = dqkv + qkv_off(a + q, 0, H, head);
@@ -596,11 +535,11 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
 // ================================================================================================
 // LDS: Q row-major [lp_max][16] | dO row-major [lp_max][16] | aux [lp_max][4] bf16 = (lse_hi, lse_lo, delta_hi, delta_lo)
 #define AT_PAD_LSE 1.0e30f   // lse of padding queries: exp2(s - 1e30) = 0 and, unlike +inf, 1e30 * 0 = 0 in the delta product
-template <int PIPE, int LP>   // PIPE as attn_bwd_dq_kernel; LP = lp_max at compile time (1024: image distances become immediates) or 0
-__global__ void __launch_bounds__(AT_THREADS, PIPE >= 3 ? 2 : AT_MIN_WAVES)
+template <int LP>   // LP = lp_max at compile time (1024: image distances become immediates) or 0
+__global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                     const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                    int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, int prio) {
+                    int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lunit = at_unit(n_units * qs);
   if (lunit >= n_units * qs) return;
@@ -644,7 +583,6 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
   const uint32_t m1 = 0xBF80BF80u;                                              // (-1, -1) bf16
   const s16x8 bS = make_frag(h2 == 0 ? m1 : 0u, 0u, 0u, 0u);
   const s16x8 bD = make_frag(0u, h2 == 0 ? m1 : 0u, 0u, 0u);
-  if (prio && wave >= AT_WAVES / 2) __builtin_amdgcn_s_setprio(1);
 
   for (int kt = t_lo + wave; kt < t_hi; kt += AT_WAVES) {
     const int key = kt * 32 + col;
@@ -653,7 +591,7 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
     s16x8 khi, klo;
     split_scaled(kf, c, khi, klo);
     f32x16 dv = zero16(), dk = zero16();
-    if constexpr (PIPE == 0) {
+    {
       // Four per-lane LDS pointers (row-major fragment, aux word, the two halves of the transposed fragments), advanced
       // once per trip; everything else is an immediate offset (the dO image sits DOFF bytes after the Q image, 16 rows
       // are 512 bytes, the second tile of a trip 1024): the address arithmetic of the r01 form (7 pointers, 14 VALU per
@@ -698,47 +636,6 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
         pq += 2048; pl += 2048; ph += 2048; pa += 512;
       }
       if (qt < n_tiles) tile(0, 0);
-    } else {
-      const unsigned char* qb = Qsm + rmo;
-      const unsigned char* ob = dOsm + rmo;
-      s16x8 qf = *reinterpret_cast<const s16x8*>(qb), dof = *reinterpret_cast<const s16x8*>(ob);
-      uint2 ax = aux[col];
-      auto sdp = [&](f32x16& s, f32x16& dp) {
-        const s16x8 af = make_frag(ax.x, ax.y, 0u, 0u);
-        s = mfma32(af, bS, zero16());
-        s = mfma32(qf, khi, s);
-        s = mfma32(qf, klo, s);
-        dp = mfma32(af, bD, zero16());
-        dp = mfma32(dof, vf, dp);
-      };
-      f32x16 sa, da, sb, db;
-      sdp(sa, da);
-      auto step = [&](const f32x16& sc, const f32x16& dc, f32x16& sn, f32x16& dn, int qt) {
-        const int nx = qt + 1 < n_tiles ? qt + 1 : qt;
-        qf = *reinterpret_cast<const s16x8*>(qb + nx * 1024);
-        dof = *reinterpret_cast<const s16x8*>(ob + nx * 1024);
-        ax = aux[nx * 32 + col];
-        const s16x8 do0 = ld_tr_frag(dOsm, ta, qt * 32), do1 = ld_tr_frag(dOsm, ta, qt * 32 + 16);
-        const s16x8 qt0 = ld_tr_frag(Qsm, ta, qt * 32), qt1 = ld_tr_frag(Qsm, ta, qt * 32 + 16);
-        sdp(sn, dn);
-        uint32_t pp[8], ps[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float p0 = __builtin_amdgcn_exp2f(sc[2 * i]), p1 = __builtin_amdgcn_exp2f(sc[2 * i + 1]);
-          pp[i] = pack_bf16x2(p0, p1);
-          ps[i] = pack_bf16x2(p0 * dc[2 * i], p1 * dc[2 * i + 1]);
-        }
-        dv = mfma32(make_frag(pp[0], pp[1], pp[2], pp[3]), do0, dv);
-        dk = mfma32(make_frag(ps[0], ps[1], ps[2], ps[3]), qt0, dk);
-        dv = mfma32(make_frag(pp[4], pp[5], pp[6], pp[7]), do1, dv);
-        dk = mfma32(make_frag(ps[4], ps[5], ps[6], ps[7]), qt1, dk);
-      };
-      int qt = 0;
-      for (; qt + 1 < n_tiles; qt += 2) {
-        step(sa, da, sb, db, qt);
-        step(sb, db, sa, da, qt + 1);
-      }
-      if (qt < n_tiles) step(sa, da, sb, db, qt);
     }
     // D[i = key][j = d]: lane column = d (valid < 16), regs = keys crow(r,h2)
     if (col < 16) {
@@ -750,224 +647,6 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
           dqkv[qkv_off(a + kk, 2, H, head) + col] = (uint16_t)(pack_bf16x2(dv[r], 0.f) & 0xffffu);
         }
       }
-    }
-  }
-}
-
-// ================================================================================================
-// backward, single pass: dQ, dK, dV from ONE recomputation of S / P / dS per (query tile, key tile)
-// ================================================================================================
-// The two-kernel backward recomputes S twice (once per orientation: lane = query for dQ, lane = key for
-// dK/dV): 14 MFMA + 32 exp per tile pair, and transcendentals do not overlap MFMAs on a SIMD
-// (tools/probe_gfx950.hip: instruction-mix floors 116 + 173 ns against 193 ns for the mix below).  Here a
-// workgroup still owns one (sequence, head); wave w is key-stationary on key tiles w, w+8, ... (dK, dV in
-// registers) and walks the query tiles; per (query tile, key tile):
-//   S' = Q (K c)^T - lse and dP' = dO V^T - delta straight out of the matrix pipe (as attn_bwd_dkv_kernel),
-//   P = exp2(S'), dS = P o dP', dV += P^T dO, dK += dS^T Q,
-//   dS is written once to a wave-private 2 KB LDS slice as [key][query] and read back through
-//   ds_read_b64_tr_b16 as the B operand of dQ^T[d][q] += K^T[d][key] dS^T[key][q]  (A = the stationary K tile),
-//   and that 16 x 32 contribution is added to the query tile's fp32 accumulator in LDS.
-// The walk is SKEWED (wave w starts at query tile w * n_tiles / 8), so the eight waves are normally on eight
-// different query tiles; every accumulator tile carries a turn counter in LDS and a wave adds its contribution
-// only when the counter equals its position in the tile's (fixed, schedule-derived) order of contributors --
-// the sum order is deterministic (bit-reproducible like the two-kernel form) without any workgroup barrier in
-// the loop.  (A barrier per step kept the two waves of a SIMD in phase -- both in their MFMA part, then both in
-// their exp part -- and ran 1.35x SLOWER than the two-kernel form; ds_add_f32 serialises per lane: 6.5x slower.)
-// 11 MFMA + 16 exp per tile pair; LDS 152 KB (one workgroup per CU, 256 registers per lane).
-// LDS: Q row-major [lp][16] | dO row-major [lp][16] | aux [lp][4] bf16 | dQ acc [lp/32][16][32] fp32 | 8 x 2 KB slices | turn counters
-__global__ void __launch_bounds__(AT_THREADS, 2)
-attn_bwd_fused_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
-                      const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                      int lp_max, int n_units, uint16_t* __restrict__ dqkv) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int unit = at_unit(n_units);
-  if (unit >= n_units) return;
-  const int seq = unit / H, head = unit % H;
-  const int a = cu[seq], L = cu[seq + 1] - a;
-  if (L <= 0) return;
-  const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
-  if (Lp > lp_max) {   // see attn_fwd_kernel
-    for (int j = 0; j < 3; ++j) at_poison_rows(dqkv + qkv_off(a, j, H, head), (int64_t)3 * H * 16, L, nullptr);
-    return;
-  }
-  unsigned char* Qsm = smem;
-  unsigned char* dOsm = smem + (size_t)lp_max * 32;
-  uint2* aux = reinterpret_cast<uint2*>(smem + (size_t)lp_max * 64);
-  float* dQacc = reinterpret_cast<float*>(smem + (size_t)lp_max * 72);
-  const int lane = ptc_lane(), wave = threadIdx.x >> 6;
-  unsigned char* slice = smem + (size_t)lp_max * 136 + wave * 2048;
-  volatile int* turn_cnt = reinterpret_cast<volatile int*>(smem + (size_t)lp_max * 136 + AT_WAVES * 2048);
-  const int64_t rs = (int64_t)3 * H * 16;
-
-  // ---- prologue: Q, dO row-major; (lse, delta) pairs; zero dQ accumulators
-  stage_row_major(qkv + qkv_off(a, 0, H, head), rs, L, Lp, Qsm);
-  for (int q = threadIdx.x; q < Lp; q += AT_THREADS) {
-    uint4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
-    float l2 = AT_PAD_LSE, dl = 0.f;
-    if (q < L) {
-      const int64_t orow = ((int64_t)(a + q) * H + head) * 16;
-      const uint4* pd = reinterpret_cast<const uint4*>(dout + orow);
-      const uint4* po = reinterpret_cast<const uint4*>(out + orow);
-      d0 = pd[0]; d1 = pd[1];
-      const uint4 o0 = po[0], o1 = po[1];
-      const uint32_t dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-      const uint32_t ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        dl = fmaf(__uint_as_float(dw[j] << 16), __uint_as_float(ow[j] << 16), dl);
-        dl = fmaf(__uint_as_float(dw[j] & 0xffff0000u), __uint_as_float(ow[j] & 0xffff0000u), dl);
-      }
-      l2 = lse[(int64_t)head * total + a + q] * AT_LOG2E;
-    }
-    *reinterpret_cast<uint4*>(dOsm + rm_off(q, 0)) = d0;
-    *reinterpret_cast<uint4*>(dOsm + rm_off(q, 1)) = d1;
-    const uint32_t hi = pack_bf16x2(l2, dl);
-    const uint32_t lo = pack_bf16x2(l2 - __uint_as_float(hi << 16), dl - __uint_as_float(hi & 0xffff0000u));
-    uint2 w;
-    w.x = (hi & 0xffffu) | (lo << 16);
-    w.y = (hi >> 16) | (lo & 0xffff0000u);
-    aux[q] = w;
-  }
-  for (int i = threadIdx.x; i < n_tiles * 512; i += AT_THREADS) dQacc[i] = 0.f;
-  if ((int)threadIdx.x < n_tiles) turn_cnt[threadIdx.x] = 0;
-  __syncthreads();
-
-  const int col = lane & 31, h2 = lane >> 5;
-  const float c = scale * AT_LOG2E;
-  const TrAddr ta = tr_addr(lane);
-  const int rmo = rm_off(col, h2);
-  const uint32_t m1 = 0xBF80BF80u;
-  const s16x8 bS = make_frag(h2 == 0 ? m1 : 0u, 0u, 0u, 0u);
-  const s16x8 bD = make_frag(0u, h2 == 0 ? m1 : 0u, 0u, 0u);
-  // transposing read of the [key][query] dS slice (64-byte rows): lane (q = lane & 31, h2) gets keys
-  // 16 mm + 4 h2 + {0..3} (+8) of its query column
-  const int lp16 = lane & 15, qblk = (lane >> 4) & 1;
-  const int ds_rd = (4 * h2 + (lp16 >> 2)) * 64 + (qblk * 16 + (lp16 & 3) * 4) * 2;
-  const int skew = n_tiles >= AT_WAVES ? n_tiles / AT_WAVES : 1;
-  const int off_w = wave * skew;
-  const int n_kb = (n_tiles + AT_WAVES - 1) / AT_WAVES;
-  int turn_base = 0;                                  // contributions every tile has received in earlier kb rounds
-
-  for (int kb = 0; kb < n_kb; ++kb) {
-    const int kt = wave + AT_WAVES * kb;
-    const bool have = kt < n_tiles;
-    const int active = (n_tiles - AT_WAVES * kb) < AT_WAVES ? (n_tiles - AT_WAVES * kb) : AT_WAVES;   // waves with a key tile this round
-    const int key = kt * 32 + col;
-    const bool kvalid = have && key < L;
-    const s16x8 kf = ld_global_frag(qkv + qkv_off(a + key, 1, H, head) + h2 * 8, kvalid);
-    const s16x8 vf = ld_global_frag(qkv + qkv_off(a + key, 2, H, head) + h2 * 8, kvalid);
-    s16x8 khi, klo;
-    split_scaled(kf, c, khi, klo);
-    // K^T fragments of the stationary tile (A operand of the dQ product), via the slice
-    *reinterpret_cast<s16x8*>(slice + rm_off(col, h2)) = kf;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const s16x8 ktf0 = ld_tr_frag(slice, ta, 0), ktf1 = ld_tr_frag(slice, ta, 16);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    f32x16 dv = zero16(), dk = zero16();
-    for (int j = 0; j < n_tiles; ++j) {
-      if (have) {
-        int qt = j + off_w;
-        qt = qt >= n_tiles ? qt - n_tiles : qt;
-        const s16x8 qf = *reinterpret_cast<const s16x8*>(Qsm + qt * 1024 + rmo);
-        const s16x8 dof = *reinterpret_cast<const s16x8*>(dOsm + qt * 1024 + rmo);
-        const uint2 ax = aux[qt * 32 + col];
-        const s16x8 af = make_frag(ax.x, ax.y, 0u, 0u);
-        f32x16 sv = mfma32(af, bS, zero16());           // -lse[q]       S'[q][key]: lane = key, regs = queries crow(r,h2)
-        sv = mfma32(qf, khi, sv);
-        sv = mfma32(qf, klo, sv);
-        f32x16 dp = mfma32(af, bD, zero16());           // -delta[q]
-        dp = mfma32(dof, vf, dp);
-        uint32_t pp[8], ps[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float p0 = __builtin_amdgcn_exp2f(sv[2 * i]), p1 = __builtin_amdgcn_exp2f(sv[2 * i + 1]);
-          pp[i] = pack_bf16x2(p0, p1);
-          ps[i] = pack_bf16x2(p0 * dp[2 * i], p1 * dp[2 * i + 1]);
-        }
-        // dS -> slice as [key = col][query]: registers 4g..4g+3 are queries 8g + 4 h2 + {0..3}
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          uint2 w;
-          w.x = ps[2 * g]; w.y = ps[2 * g + 1];
-          *reinterpret_cast<uint2*>(slice + col * 64 + (8 * g + 4 * h2) * 2) = w;
-        }
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm) {
-          const s16x8 pf = make_frag(pp[4 * mm], pp[4 * mm + 1], pp[4 * mm + 2], pp[4 * mm + 3]);
-          const s16x8 dsf = make_frag(ps[4 * mm], ps[4 * mm + 1], ps[4 * mm + 2], ps[4 * mm + 3]);
-          const s16x8 dotf = ld_tr_frag(dOsm, ta, qt * 32 + 16 * mm);
-          const s16x8 qtf = ld_tr_frag(Qsm, ta, qt * 32 + 16 * mm);
-          dv = mfma32(pf, dotf, dv);
-          dk = mfma32(dsf, qtf, dk);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        f32x16 dq = zero16();
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm) {
-          const unsigned char* pr = slice + 16 * mm * 64 + ds_rd;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pr));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pr + 8 * 64));
-          const s16x8 dst = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          dq = mfma32(mm == 0 ? ktf0 : ktf1, dst, dq);  // dQ^T[d][q] contribution of this key tile
-        }
-        // my position among this round's contributors to tile qt: wave w' reaches qt at step (qt - w' skew) mod n,
-        // I reach it at step j -- earlier are the waves above me that are <= j/skew ahead and the waves below me
-        // whose walk has already wrapped around
-        int rank = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < AT_WAVES; ++w2) {
-          if (w2 < active) {
-            if (w2 > wave && (w2 - wave) * skew <= j) ++rank;
-            if (w2 < wave && j + (wave - w2) * skew >= n_tiles) ++rank;
-          }
-        }
-        const int my_turn = turn_base + rank;
-        while (turn_cnt[qt] != my_turn) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        float* acc = dQacc + qt * 512 + col;            // [d][32 queries]
-        // plain read-modify-write: the turn counter makes this wave the only writer of the tile right now
-        // (ds_add_f32 serialises per lane on gfx950: 13k cycles per step in the first version of this kernel)
-        float cur[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) cur[r] = acc[crow(r, h2) * 32];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc[crow(r, h2) * 32] = cur[r] + dq[r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) turn_cnt[qt] = my_turn + 1;
-      }
-    }
-    turn_base += active;
-    if (have && col < 16) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kk = kt * 32 + crow(r, h2);
-        if (kk < L) {
-          dqkv[qkv_off(a + kk, 1, H, head) + col] = (uint16_t)(pack_bf16x2(dk[r] * scale, 0.f) & 0xffffu);
-          dqkv[qkv_off(a + kk, 2, H, head) + col] = (uint16_t)(pack_bf16x2(dv[r], 0.f) & 0xffffu);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // ---- dQ rows out: lane (q, h2) owns d = 4 h2 + {0..3} and 8 + 4 h2 + {0..3}
-  for (int qt = wave; qt < n_tiles; qt += AT_WAVES) {
-    const int q = qt * 32 + col;
-    const float* acc = dQacc + qt * 512 + col;
-    float v[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = acc[crow(r, h2) * 32] * scale;
-    if (q < L) {
-      uint16_t* o = dqkv + qkv_off(a + q, 0, H, head);
-      uint2 w0, w1;
-      w0.x = pack_bf16x2(v[0], v[1]); w0.y = pack_bf16x2(v[2], v[3]);
-      w1.x = pack_bf16x2(v[4], v[5]); w1.y = pack_bf16x2(v[6], v[7]);
-      *reinterpret_cast<uint2*>(o + 4 * h2) = w0;
-      *reinterpret_cast<uint2*>(o + 8 + 4 * h2) = w1;
     }
   }
 }
@@ -988,15 +667,6 @@ static int allow_big_lds(K kernel, size_t bytes) {
 static size_t fwd_lds_bytes(int lp_max) { return (size_t)lp_max * 32 + (size_t)17 * (lp_max + 8) * 2 + AT_WAVES * 4; }
 static size_t dq_lds_bytes(int lp_max) { return (size_t)lp_max * 64; }
 static size_t dkv_lds_bytes(int lp_max) { return (size_t)lp_max * 64 + (size_t)lp_max * 8; }
-static size_t fused_lds_bytes(int lp_max) { return (size_t)lp_max * 136 + (size_t)AT_WAVES * 2048 + 256; }
-// The two-kernel backward (dQ, then dK/dV) is the default.  PTC_ATTN_BWD=1 selects the single-pass kernel, kept as
-// a measured experiment: correct and bit-reproducible, 11 MFMA + 16 exp per tile pair instead of 14 + 32, but its
-// 152 KB of LDS allows two waves per SIMD instead of four and the per-step dependency chain (LDS -> MFMA -> exp ->
-// LDS transpose -> MFMA -> LDS accumulate) is then exposed: 2.1-2.3 ms against 1.56 ms at the bench shape (r01_w/x).
-static bool at_fused_bwd() {
-  const char* e = getenv("PTC_ATTN_BWD");
-  return e && atoi(e) == 1;
-}
 
 static int check_common(const char* name, const void* qkv, const int32_t* cu, int64_t n_seq, int64_t total, int H,
                         int max_seqlen, int dtype) {
@@ -1021,23 +691,12 @@ extern "C" int ptc_attn_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, i
   hipStream_t s = (hipStream_t)stream;
   const int n_units = (int)(n_seq * H);
   const int qs = at_split_host(n_units, lp_max);
-  int mode = AT_FWD_DEFAULT;
-  if (const char* e = getenv("PTC_ATTN_FWD")) mode = atoi(e);
-#define AT_FWD_CASE(M, Q1, PRIO, TRUNC)                                                                                        \
-  if (mode == M) {                                                                                                             \
-    rc = allow_big_lds(attn_fwd_kernel<Q1, PRIO, TRUNC>, lds);                                                                 \
-    if (rc != PTC_OK) return rc;                                                                                               \
-    hipLaunchKernelGGL((attn_fwd_kernel<Q1, PRIO, TRUNC>), dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds, s, \
-                       (const uint16_t*)qkv, cu_seqlens, H, softmax_scale, total, lp_max, n_units, qs, (uint16_t*)out, lse);   \
-    PTC_CHECK_LAUNCH("attn_fwd_kernel");                                                                                       \
-    return PTC_OK;                                                                                                             \
-  }
-  AT_FWD_CASE(0, false, false, false) AT_FWD_CASE(1, true, false, false) AT_FWD_CASE(2, false, true, false)
-  AT_FWD_CASE(4, false, false, true) AT_FWD_CASE(6, false, true, true) AT_FWD_CASE(7, true, true, true) AT_FWD_CASE(5, true, false, true)
-  AT_FWD_CASE(3, true, true, false)
-#undef AT_FWD_CASE
-  ptc_set_error("ptc_attn_varlen_fwd: PTC_ATTN_FWD=%d is not a variant", mode);
-  return PTC_EINVAL;
+  rc = allow_big_lds(attn_fwd_kernel, lds);
+  if (rc != PTC_OK) return rc;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds, s, (const uint16_t*)qkv, cu_seqlens, H,
+                     softmax_scale, total, lp_max, n_units, qs, (uint16_t*)out, lse);
+  PTC_CHECK_LAUNCH("attn_fwd_kernel");
+  return PTC_OK;
 }
 
 extern "C" size_t ptc_attn_varlen_bwd_workspace_bytes(int64_t total, int H) {
@@ -1059,46 +718,30 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   const int lp_max = (max_seqlen + 31) & ~31;
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)workspace;
-  if (at_fused_bwd()) {
-    rc = allow_big_lds(attn_bwd_fused_kernel, fused_lds_bytes(lp_max));
-    if (rc != PTC_OK) return rc;
-    const int nu = (int)(n_seq * H);
-    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3((unsigned)(8 * ((nu + 7) / 8))), dim3(AT_THREADS), fused_lds_bytes(lp_max), s,
-                       (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H, softmax_scale, total,
-                       lp_max, nu, (uint16_t*)dqkv);
-    PTC_CHECK_LAUNCH("attn_bwd_fused_kernel");
-    return PTC_OK;
-  }
   const int n_units = (int)(n_seq * H);
   const int qs = at_split_host(n_units, lp_max);
   const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
-  // s_setprio 1 on waves 4..7 as in the forward: measured NEUTRAL to harmful here (H = 4: 1440 vs 1423 us, H = 2: 842 vs 776 us,
-  // profiles/r02_h_attn_variants.txt) -- the backward loops are not pinned with sched_group_barrier, so the prioritised
-  // half simply starves the other.  Off; PTC_ATTN_BWD_PRIO=1 is the A/B switch.
-  int prio = 0;
-  if (const char* e = getenv("PTC_ATTN_BWD_PRIO")) prio = atoi(e);
-  int pipe = AT_BWD_PIPE_DEFAULT;
-  if (const char* e = getenv("PTC_ATTN_BWD_PIPE")) pipe = atoi(e);
-#define AT_BWD_CASE(P, LP)                                                                                                     \
-  if (pipe == P && (LP == 0 ? lp_max != 1024 : lp_max == LP)) {                                                                                                             \
-    rc = allow_big_lds((attn_bwd_dq_kernel<P, LP>), dq_lds_bytes(lp_max));                                                           \
+  // (s_setprio on half of the waves, as in the forward: measured neutral to harmful here, profiles/r02_h_attn_variants.txt; a two-stage
+  //  software pipeline at one workgroup per CU: slower, profiles/r02_o_slp_ab.txt; the single-pass backward: 2.1-2.3 ms against 1.56, r01_w/x)
+#define AT_BWD_CASE(LP)                                                                                                        \
+  if (LP == 0 ? lp_max != 1024 : lp_max == LP) {                                                                                                             \
+    rc = allow_big_lds((attn_bwd_dq_kernel<LP>), dq_lds_bytes(lp_max));                                                           \
     if (rc != PTC_OK) return rc;                                                                                               \
-    rc = allow_big_lds((attn_bwd_dkv_kernel<P, LP>), dkv_lds_bytes(lp_max));                                                         \
+    rc = allow_big_lds((attn_bwd_dkv_kernel<LP>), dkv_lds_bytes(lp_max));                                                         \
     if (rc != PTC_OK) return rc;                                                                                               \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<P, LP>), dim3(grid), dim3(AT_THREADS), dq_lds_bytes(lp_max), s, (const uint16_t*)qkv,     \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<LP>), dim3(grid), dim3(AT_THREADS), dq_lds_bytes(lp_max), s, (const uint16_t*)qkv,     \
                        (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H, softmax_scale, total, lp_max, n_units, \
-                       qs, (uint16_t*)dqkv, delta, prio);                                                                      \
+                       qs, (uint16_t*)dqkv, delta);                                                                            \
     PTC_CHECK_LAUNCH("attn_bwd_dq_kernel");                                                                                    \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, LP>), dim3(grid), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s, (const uint16_t*)qkv,   \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<LP>), dim3(grid), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s, (const uint16_t*)qkv,   \
                        (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H, softmax_scale, total, lp_max, n_units,  \
-                       qs, (uint16_t*)dqkv, prio);                                                                             \
+                       qs, (uint16_t*)dqkv);                                                                                   \
     PTC_CHECK_LAUNCH("attn_bwd_dkv_kernel");                                                                                   \
     return PTC_OK;                                                                                                             \
   }
-  AT_BWD_CASE(0, 1024) AT_BWD_CASE(0, 0) AT_BWD_CASE(3, 1024) AT_BWD_CASE(3, 0)
+  AT_BWD_CASE(1024) AT_BWD_CASE(0)
 #undef AT_BWD_CASE
-  ptc_set_error("ptc_attn_varlen_bwd: PTC_ATTN_BWD_PIPE=%d is not a variant", pipe);
-  return PTC_EINVAL;
+  return PTC_EINVAL;   // not reached
 }
 
 // ------------------------------------------------------------------------------------------------

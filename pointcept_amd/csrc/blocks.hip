@@ -1,42 +1,46 @@
-// blocks.hip -- block-local rulebooks: the gather table of a submanifold convolution re-expressed per block of
-// `bm` consecutive output rows as (halo list, local table).
+// blocks.hip -- block-local rulebooks: the 3^3 gather table of a submanifold convolution re-expressed per block of 128
+// consecutive output rows as (halo list, local table), the operands of the LDS-staged convolution (conv7.h).
 //
-// Why (profiles/r02_a_conv_pmc_s0.json): the output-stationary convolution gathers every input row once per table
-// entry that names it -- 9.3 times per voxel for a 3^3 window on indoor surfaces -- straight from L1/L2 into MFMA
-// operands.  HBM traffic of that kernel is 1.03 x algorithmic, but the texture-address unit is 72 % busy: 5.6 M
-// 1-KB wave loads at 16 cycles each ARE the kernel.  Rows are kept in curve order (PTC_SORT_POINTS), so the distinct
-// input rows a block of 256 outputs needs (its "halo") are only ~1.5 x 256 (measured 376 +- 40 on the synthetic indoor
-// scenes, max 577): stage those ONCE in LDS (one coalesced 128-byte read per row) and gather from LDS at 4x the
-// bandwidth of the vector memory path.  This file builds what the kernel needs for that:
-//   halo [n_blocks][hmax] int32 : the distinct input rows of the block, ASCENDING (deterministic; neighbouring output
-//                                 rows then read neighbouring LDS slots)
-//   hcnt [n_blocks]       int32 : how many; hmax + 1 = "does not fit" (rows in no spatial order): such blocks are
-//                                 convolved through the global table by the kernel's own fallback loop
-//   lnbr [kv][n]          int16 : slot of nbr[k][row] in its block's halo list, -1 = no neighbour
-// One workgroup per block: LDS hash set -> compaction -> bitonic sort -> binary search per entry.  Integer work,
-// bit-exact by construction: halo[block(row)][lnbr[k][row]] == nbr[k][row] wherever nbr >= 0 (tests/test_gpu_kernels.py).
+// Why: the output-stationary convolution gathers every input row once per table entry that names it -- 9.3 times per voxel for a
+// 3^3 window on indoor surfaces.  Rows are kept in curve order (PTC_SORT_POINTS, SpUNet's entry sort), so the DISTINCT input rows
+// a block of 128 outputs names (its "halo") are only 1.66 x 128 (measured on the synthetic indoor scenes: mean 212, p99 283, max
+// 352; tools/halo_stats.py): stage those ONCE in LDS and gather from LDS.  This file builds what the kernel needs for that:
+//   hid  [n_blocks][hcap]              int32 : the distinct input rows of the block, ASCENDING (deterministic; neighbouring output
+//                                              rows then read neighbouring LDS slots), padded with the last one to a multiple of 16
+//   hcnt [n_blocks]                    int32 : how many; -1 = "does not fit" (rows in no spatial order): the kernel serves such a
+//                                              block through the global table
+//   tab  [n_blocks][28][16][8]         u16   : slot of nbr[k][128 b + 16 t + r] in the block's list at [b][k][r][t], 0xFFFF = no
+//                                              neighbour (table row 27 is padding: the table is a whole number of 1-KB DMA pieces)
+// One workgroup per block: LDS hash set -> compaction -> bitonic sort -> binary search per entry.  Integer work, bit-exact by
+// construction: hid[b][tab[b][k][r][t]] == nbr[k][128 b + 16 t + r] wherever nbr >= 0 (tests/test_gpu_kernels.py).
 #include "ptc_common.h"
 
-#define BLK_HS 2048     // hash slots (load <= 0.5 at hmax = 1024)
-#define BLK_LIST 1024   // >= hmax
+#define BLK_BM 128
+#define BLK_NT 8
+#define BLK_KV 27
+#define BLK_HS 2048     // hash slots (load <= 0.25 at hcap = 512)
+#define BLK_LIST 512    // >= hcap
+#define BLK_TAB_U16 (28 * 16 * BLK_NT)
 
 __global__ void __launch_bounds__(256)
-rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int kv, int64_t n, int bm, int hmax, int16_t* __restrict__ lnbr,
-                       int32_t* __restrict__ halo, int32_t* __restrict__ hcnt, int32_t* __restrict__ n_overflow) {
+rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int hcap, uint16_t* __restrict__ tab, int32_t* __restrict__ hid,
+                       int32_t* __restrict__ hcnt, int32_t* __restrict__ n_overflow) {
   __shared__ int keys[BLK_HS];
   __shared__ int list[BLK_LIST];
+  __shared__ __attribute__((aligned(16))) uint16_t ltab[BLK_TAB_U16];
   __shared__ int cnt, cnt2, ovf;
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x;
-  const int64_t r0 = b * bm;
-  const int rows = (n - r0) < bm ? (int)(n - r0) : bm;
+  const int64_t r0 = b * BLK_BM;
+  const int rows = (n - r0) < BLK_BM ? (int)(n - r0) : BLK_BM;
   for (int i = tid; i < BLK_HS; i += 256) keys[i] = -1;
   for (int i = tid; i < BLK_LIST; i += 256) list[i] = 0x7fffffff;
+  for (int i = tid; i < BLK_TAB_U16; i += 256) ltab[i] = 0xFFFFu;
   if (tid == 0) { cnt = 0; cnt2 = 0; ovf = 0; }
   __syncthreads();
-  const int total = kv * bm;
+  constexpr int total = BLK_KV * BLK_BM;
   for (int e = tid; e < total; e += 256) {
-    const int k = e / bm, r = e - k * bm;
+    const int k = e / BLK_BM, r = e - k * BLK_BM;
     if (r >= rows) continue;
     const int g = nbr[(int64_t)k * n + r0 + r];
     if (g < 0) continue;
@@ -45,7 +49,7 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int kv, int64_t n, int b
       if (*(volatile int*)&ovf) break;
       const int old = atomicCAS(&keys[h], -1, g);
       if (old == -1) {
-        if (atomicAdd(&cnt, 1) >= hmax) atomicExch(&ovf, 1);
+        if (atomicAdd(&cnt, 1) >= hcap) atomicExch(&ovf, 1);
         break;
       }
       if (old == g) break;
@@ -53,12 +57,13 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int kv, int64_t n, int b
     }
   }
   __syncthreads();
+  uint16_t* tout = tab + b * BLK_TAB_U16;
   if (ovf) {
     if (tid == 0) {
-      hcnt[b] = hmax + 1;
+      hcnt[b] = -1;
       atomicAdd(n_overflow, 1);
     }
-    return;
+    return;   // tab / hid of this block stay undefined: the kernel does not read them
   }
   for (int h = tid; h < BLK_HS; h += 256) {
     const int g = keys[h];
@@ -83,37 +88,43 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int kv, int64_t n, int b
       }
       __syncthreads();
     }
-  for (int i = tid; i < c; i += 256) halo[b * hmax + i] = list[i];
+  // the list, padded with its last row to a multiple of 16 (a DMA instruction of the kernel fetches 8 or 16 whole rows)
+  const int cpad = ((c + 15) & ~15) < hcap ? ((c + 15) & ~15) : hcap;
+  for (int i = tid; i < cpad; i += 256) hid[b * hcap + i] = list[i < c ? i : c - 1];
   if (tid == 0) hcnt[b] = c;
   for (int e = tid; e < total; e += 256) {
-    const int k = e / bm, r = e - k * bm;
+    const int k = e / BLK_BM, r = e - k * BLK_BM;
     if (r >= rows) continue;
     const int g = nbr[(int64_t)k * n + r0 + r];
-    int slot = -1;
-    if (g >= 0) {
-      int lo = 0, hi = c - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (list[mid] < g) lo = mid + 1; else hi = mid;
-      }
-      slot = lo;   // present by construction
+    if (g < 0) continue;
+    int lo = 0, hi = c - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (list[mid] < g) lo = mid + 1; else hi = mid;
     }
-    lnbr[(int64_t)k * n + r0 + r] = (int16_t)slot;
+    ltab[(k * 16 + (r & 15)) * BLK_NT + (r >> 4)] = (uint16_t)lo;   // present by construction
   }
+  __syncthreads();
+  for (int i = tid; i < BLK_TAB_U16 / 8; i += 256)
+    reinterpret_cast<uint4*>(tout)[i] = reinterpret_cast<const uint4*>(ltab)[i];
 }
 
-extern "C" int ptc_rulebook_blocks(const int32_t* nbr, int kv, int64_t n, int bm, int hmax, int16_t* lnbr, int32_t* halo,
-                                   int32_t* hcnt, int32_t* n_overflow, ptc_stream_t stream) {
-  PTC_REQUIRE(n >= 0 && kv >= 1, PTC_EINVAL, "ptc_rulebook_blocks: bad sizes");
-  PTC_REQUIRE(bm >= 16 && bm <= 1024 && hmax >= 1 && hmax <= BLK_LIST, PTC_EUNSUPPORTED, "ptc_rulebook_blocks: bm=%d hmax=%d (hmax <= %d)",
-              bm, hmax, BLK_LIST);
+extern "C" size_t ptc_rulebook_blocks_tab_bytes(int64_t n) { return (size_t)ptc_cdiv(n > 0 ? n : 1, BLK_BM) * BLK_TAB_U16 * sizeof(uint16_t); }
+
+extern "C" int ptc_rulebook_blocks(const int32_t* nbr, int kv, int64_t n, int bm, int hcap, void* tab, int32_t* hid, int32_t* hcnt,
+                                   int32_t* n_overflow, ptc_stream_t stream) {
+  PTC_REQUIRE(n >= 0, PTC_EINVAL, "ptc_rulebook_blocks: bad sizes");
+  PTC_REQUIRE(kv == BLK_KV && bm == BLK_BM, PTC_EUNSUPPORTED, "ptc_rulebook_blocks: kv=%d bm=%d (3^3 tables, 128-row blocks)", kv, bm);
+  PTC_REQUIRE(hcap >= 16 && hcap <= BLK_LIST && hcap % 16 == 0, PTC_EUNSUPPORTED, "ptc_rulebook_blocks: hcap=%d (multiple of 16, <= %d)", hcap,
+              BLK_LIST);
   PTC_REQUIRE(n_overflow != nullptr, PTC_EINVAL, "ptc_rulebook_blocks: null counter");
   hipStream_t s = (hipStream_t)stream;
   PTC_HIP(hipMemsetAsync(n_overflow, 0, sizeof(int32_t), s));
   if (n == 0) return PTC_OK;
-  PTC_REQUIRE(nbr && lnbr && halo && hcnt, PTC_EINVAL, "ptc_rulebook_blocks: null buffer");
-  const int64_t nblk = ptc_cdiv(n, bm);
-  hipLaunchKernelGGL(rulebook_blocks_kernel, dim3((unsigned)nblk), dim3(256), 0, s, nbr, kv, n, bm, hmax, lnbr, halo, hcnt, n_overflow);
+  PTC_REQUIRE(nbr && tab && hid && hcnt, PTC_EINVAL, "ptc_rulebook_blocks: null buffer");
+  PTC_REQUIRE((uintptr_t)tab % 16 == 0, PTC_EINVAL, "ptc_rulebook_blocks: tab must be 16-byte aligned");
+  const int64_t nblk = ptc_cdiv(n, BLK_BM);
+  hipLaunchKernelGGL(rulebook_blocks_kernel, dim3((unsigned)nblk), dim3(256), 0, s, nbr, n, hcap, (uint16_t*)tab, hid, hcnt, n_overflow);
   PTC_CHECK_LAUNCH("rulebook_blocks_kernel");
   return PTC_OK;
 }

@@ -35,7 +35,8 @@ template <> __device__ __forceinline__ int c5_swz<4>(int row) { return row & 15;
 template <typename T, int RT, int NS, int NTILES>
 __global__ void __launch_bounds__(256, 2)
 conv5_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias, const int32_t* __restrict__ nbr,
-             int64_t n_out, int kv, int c_out, int n_rowblk, T* __restrict__ out, uint32_t in_bytes, uint32_t w_bytes) {
+             int64_t n_out, int kv, int c_out, int n_rowblk, T* __restrict__ out, uint32_t in_bytes, uint32_t w_bytes,
+             const int32_t* __restrict__ only_where_negative) {
   using M = Mma<T>;
   using frag = typename M::frag;
   constexpr int C_IN = NS * 32, TPC = 4 / NS;             // table rows per 128-wide chunk
@@ -53,6 +54,8 @@ conv5_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   const int lb = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (lb >= nblk) return;
   const int rb = lb / ny, n0 = (lb - rb * ny) * NT;
+  // second launch behind conv7 (RT = 2: the 128-row workgroups are conv7's blocks): only the blocks it left (count < 0)
+  if (only_where_negative != nullptr && only_where_negative[rb] >= 0) return;
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int64_t row0 = (int64_t)rb * BM + wave * (RT * 16);
@@ -225,24 +228,17 @@ conv5_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   }
 }
 
-static inline bool conv5_enabled() {
-  const char* e = getenv("PTC_CONV5");   // read per launch: the tests A/B the forms in one process
-  return e ? atoi(e) != 0 : true;
-}
-
 static inline bool conv5_supported(int dtype, int kv, int c_in, int c_out, const int32_t* nbr, int64_t n_in) {
   if (dtype == PTC_F32 || nbr == nullptr || kv < 2) return false;
-  // c_in = 128 is instantiated and correct (tests) but measured slower than conv3's direct gathers (946 vs 562 us at
-  // 128 -> 96, N = 819200: 4-KB tile images, two waves per SIMD): PTC_CONV5_C128=1 routes it here for A/B runs
-  const char* e128 = getenv("PTC_CONV5_C128");
-  const bool c128 = c_in == 128 && e128 && atoi(e128) != 0;
-  if (!(c_in == 32 || c_in == 64 || c128) || c_out % 32 != 0) return false;
+  // (c_in = 128 on this form measured slower than conv3's direct gathers: 946 vs 562 us at 128 -> 96, N = 819200 -- 4-KB tile images, two
+  //  waves per SIMD; not instantiated)
+  if (!(c_in == 32 || c_in == 64) || c_out % 32 != 0) return false;
   return (uint64_t)n_in * (uint64_t)c_in * 2 <= PTC_BUF_MAX_BYTES && (uint64_t)c_out * kv * c_in * 2 <= PTC_BUF_MAX_BYTES;
 }
 
 template <typename T, int RT, int NS, int NTILES>
 static int launch_conv5_i(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
-                          int c_out, void* out, hipStream_t s) {
+                          int c_out, void* out, hipStream_t s, const int32_t* only_where_negative) {
   constexpr int C_IN = NS * 32;
   const int n_rowblk = (int)ptc_cdiv(n_out, RT * 64);
   const int nblk = n_rowblk * (c_out / (NTILES * 16));
@@ -254,28 +250,23 @@ static int launch_conv5_i(const void* in, int64_t n_in, const void* w, const flo
     allowed = lds;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv, c_out,
-                     n_rowblk, (T*)out, (uint32_t)((uint64_t)n_in * C_IN * sizeof(T)), (uint32_t)((uint64_t)c_out * kv * C_IN * sizeof(T)));
+                     n_rowblk, (T*)out, (uint32_t)((uint64_t)n_in * C_IN * sizeof(T)), (uint32_t)((uint64_t)c_out * kv * C_IN * sizeof(T)),
+                     only_where_negative);
   PTC_CHECK_LAUNCH("conv5_kernel");
   return PTC_OK;
 }
 
 template <typename T>
 static int launch_conv5(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
-                        int c_in, int c_out, void* out, hipStream_t s) {
+                        int c_in, int c_out, void* out, hipStream_t s, const int32_t* only_where_negative = nullptr) {
   const int nt = c_out % 64 == 0 ? 4 : (c_out % 96 == 0 ? 6 : 2);
   // 128-row workgroups (RT = 2: three waves per SIMD) measured faster than 256-row ones at every shape
   // (64 -> 64, N = 819200: 230 vs 244 us; 32 -> 32: 94 vs 118 us, profiles/r02_f_conv_stages_ops.txt)
-  bool big = false;
-  if (const char* e = getenv("PTC_CONV3_RT")) {
-    if (atoi(e) == 4 && c_in <= 64 && nt <= 4) big = true;
-    if (atoi(e) == 2) big = false;
-  }
   const int ns = c_in / 32;
 #define C5_CASE(S, N)                                                                                             \
   if (ns == S && nt == N)                                                                                           \
-    return big ? launch_conv5_i<T, 4, S, N>(in, n_in, w, bias, nbr, n_out, kv, c_out, out, s)                       \
-               : launch_conv5_i<T, 2, S, N>(in, n_in, w, bias, nbr, n_out, kv, c_out, out, s);
-  C5_CASE(1, 2) C5_CASE(1, 4) C5_CASE(1, 6) C5_CASE(2, 2) C5_CASE(2, 4) C5_CASE(2, 6) C5_CASE(4, 2) C5_CASE(4, 4) C5_CASE(4, 6)
+    return launch_conv5_i<T, 2, S, N>(in, n_in, w, bias, nbr, n_out, kv, c_out, out, s, only_where_negative);
+  C5_CASE(1, 2) C5_CASE(1, 4) C5_CASE(1, 6) C5_CASE(2, 2) C5_CASE(2, 4) C5_CASE(2, 6)
 #undef C5_CASE
   ptc_set_error("conv5: c_in=%d c_out=%d unsupported", c_in, c_out);
   return PTC_EUNSUPPORTED;

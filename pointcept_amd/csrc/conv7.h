@@ -1,0 +1,313 @@
+// conv7.h -- forward / dgrad kernel of the SUBMANIFOLD 3^3 gather-table convolution for 16-bit features with c_in = c_out = 32 | 64
+// (PTv3's stage-0 / stage-1 positional-encoding convolutions and SpUNet's level-0 / level-1 blocks: the N ~ 8e5-row, HBM-bound ones).
+// WEIGHT-STATIONARY IN REGISTERS, input rows staged once per 128-row block in LDS by the DMA path.  Included by spconv.hip.
+//
+// Why (round 3, profiles/r03_a_conv6_*): conv5 (whole-line global gathers, W streamed through LDS per 128-row workgroup) runs the
+// dec0 shape (64 -> 64, N = 819200) in 236 us = 0.16 of its HBM roof with the vector-memory address path 71 % busy, and COMPACTING
+// its gathers (conv6: half the vector-memory instructions) made it SLOWER (298 us): the kernel is bound by dependent-load latency
+// (table entry -> gather -> LDS bounce -> MFMA at 2-3 waves per SIMD) and by re-streaming W -- 221 KB per 128 rows, more bytes
+// through the L1 / LDS-store path than the gathered rows themselves.  conv7 removes both:
+//   * a workgroup is PERSISTENT over a contiguous range of 128-row blocks and keeps the whole weight tensor in the registers of
+//     its four waves (one wave per SIMD, 512-register budget): 27 taps x (C/32 k-steps) x (C/16 output tiles) MFMA A-fragments,
+//     54 per wave.  C = 64: wave w holds input-channel half kh = w & 1 of output-channel half ch = w >> 1 (27 x 2 fragments);
+//     C = 32: every wave holds all of W (27 x 2) and the waves split the block's row tiles.  W is read from L2 ONCE per workgroup;
+//   * the distinct input rows a block names (its "halo": 1.66 x 128 rows on curve-ordered scenes, blocks.hip) and the block's
+//     local table arrive in LDS through global_load_lds (16 B per lane, no VGPR staging, no ds_write), double-buffered: block
+//     b + 1 is in flight while block b is multiplied; rows are XOR-swizzled on the SOURCE side (the DMA image is lane-linear) so
+//     that the 27-tap gather -- a per-lane ds_read_b128 in MFMA B layout -- is conflict-free for neighbouring rows;
+//   * the main loop is branch-free: tap outer (static: the fragment index must be a compile-time register name), the block's row
+//     tiles inner; "no neighbour" entries read an all-zero row.  Per (tap, tile): one LDS gather + 2 MFMAs per wave;
+//   * C = 64: the two input-channel halves of a row tile are summed through a 32 KB LDS scratch (each wave finishes half of the
+//     tiles: symmetric work), bias added in fp32, rows stored as bf16 / f16.
+// A block whose halo does not fit (rows in no spatial order: hcnt < 0) is skipped here and served by conv5, launched behind this
+// kernel over exactly those blocks (its 128-row workgroups coincide with the blocks).  Summation order differs from conv5 (k-halves summed last, bias last): results agree to
+// fp32 rounding of the accumulation, not bit for bit.
+#pragma once
+
+#define C7_BM 128                           // rows per block
+#define C7_NT 8                             // 16-row tiles per block
+#define C7_HCAP 416                         // halo capacity (rows); max observed on curve-ordered indoor scenes: 352
+#define C7_TABB (28 * 16 * C7_NT * 2)       // bytes of one block's local table: [28 taps (27 + pad)][16 rows-in-tile][8 tiles] u16
+#define C7_NONE 0xFFFFu
+
+// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
+#define C7_WAIT_VM0 0x0F70
+#define C7_WAIT_LGKM0 0xC07F
+
+// 16 bytes per lane global -> LDS (destination = wave-uniform LDS byte address `lds_dst` + 16 * lane).  Inline assembly on purpose: the
+// compiler's wait-count pass treats an LDS-DMA it can see as a pending LDS write that any later ds_read may alias and drains the
+// vector-memory counter in front of the first gather -- the DMA of block b + 1 would never overlap block b's MFMAs.  An asm DMA is
+// absent from that bookkeeping (cdna_hip_programming.md, "what hipcc does not do"): its completion is counted by hand -- vmcnt(0),
+// then a workgroup barrier, then the reads.  M0 (the DMA's LDS base) is saved and restored inside the statement.
+#ifdef __HIPCC__
+__device__ __forceinline__ void c7_dma16(const void* g, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint32_t c7_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+// keep a weight fragment in the accumulation-register half of the unified file (MFMA A operands may be AGPRs): the 216 weight
+// registers then leave the 256 architectural VGPRs to the accumulators and the gather ring
+#define C7_PIN_AGPR(x) asm volatile("" : "+a"(x))
+#else
+__device__ __forceinline__ void c7_dma16(const void* g, uint32_t lds_dst) { emu_global_load_lds(g, smem + lds_dst, 16); }
+__device__ __forceinline__ uint32_t c7_lds_addr(const void* p) { return (uint32_t)((const unsigned char*)p - smem); }
+#define C7_PIN_AGPR(x) ((void)0)
+#endif
+
+template <int C> struct C7Geom {
+  static constexpr int ROWB = C * 2;                  // bytes per feature row
+  static constexpr int PCS = ROWB / 16;               // 16-byte pieces per row
+  static constexpr int RPI = 64 / PCS;                // rows per DMA instruction (1 KB)
+  static constexpr int ROWS_BYTES = (C7_HCAP + 1) * ROWB;   // + the zero row
+  static constexpr int BUF = ROWS_BYTES + C7_TABB;    // one halo buffer
+  static constexpr int SCRATCH = C == 64 ? 32768 : 0;
+  static constexpr int LDS = 2 * BUF + SCRATCH;
+  static constexpr int NI = (C7_HCAP + RPI - 1) / RPI;        // DMA instructions of a full halo
+  static constexpr int NIW = (NI + 3) / 4;                    // ... per wave
+  // swizzle: piece p of the row in slot s sits at position p ^ swz(s); 16 consecutive slots x one piece index = 16 distinct bank quads
+  static __device__ __forceinline__ int swz(int slot) { return C == 64 ? ((slot >> 1) & 7) : ((slot >> 2) & 3); }
+};
+
+template <typename T, int C>
+__global__ void __launch_bounds__(256, 1)
+conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias, const uint16_t* __restrict__ tab,
+             const int32_t* __restrict__ hid, const int32_t* __restrict__ hcnt, int64_t n_out, int n_blocks, int per_wg, T* __restrict__ out) {
+  using M = Mma<T>;
+  using frag = typename M::frag;
+  using G = C7Geom<C>;
+  constexpr int ROWB = G::ROWB, PCS = G::PCS, RPI = G::RPI;
+  constexpr int TW = C == 64 ? 8 : 2;                  // row tiles a wave multiplies per block
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = ptc_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int r = lane & 15, g = lane >> 4;
+  const int kh = C == 64 ? (wave & 1) : 0;             // input-channel half
+  const int ch = C == 64 ? (wave >> 1) : 0;            // output-channel half (C = 64) -- C = 32: both output tiles in every wave
+  const int b_begin = (int)blockIdx.x * per_wg;
+  int b_end = b_begin + per_wg;
+  if (b_end > n_blocks) b_end = n_blocks;
+  if (b_begin >= b_end) return;
+
+  // ---- the weights: 27 x 2 A-fragments per wave, straight from global memory (L2) into registers
+  frag wf[27][2];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int co = (ch * 2 + c) * 16 + r;
+      wf[k][c] = ld_frag<T>(w + ((int64_t)co * 27 + k) * C + kh * 32 + g * 8);
+    }
+  // the accumulators of an MFMA live in the accumulation half of the register file (64 here), which leaves it 192 registers =
+  // 48 of the 54 weight fragments; the last three taps stay in architectural VGPRs beside the gather ring
+#pragma unroll
+  for (int k = 0; k < (C == 64 ? 24 : 27); ++k)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) C7_PIN_AGPR(wf[k][c]);
+  float bsv[2][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bsv[c][e] = bias ? bias[(ch * 2 + c) * 16 + g * 4 + e] : 0.f;
+
+  // ---- zero rows of both buffers (never written by the DMA)
+  if (threadIdx.x < 2 * PCS) {
+    const int bsel = threadIdx.x / PCS, pc = threadIdx.x % PCS;
+    *reinterpret_cast<uint4*>(smem + bsel * G::BUF + C7_HCAP * ROWB + pc * 16) = make_uint4(0, 0, 0, 0);
+  }
+
+  // ---- DMA of one block's halo rows + table into buffer `bsel`; ids = this wave's share of the halo list (instruction j of the
+  //      wave = instruction 4 j + wave of the block: rows (4 j + wave) * RPI + lane / PCS)
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c7_lds_addr(smem));
+  const int drow = lane / PCS, dpos = lane % PCS;
+  int32_t ids[G::NIW];
+  auto load_ids = [&](int blk) {
+#pragma unroll
+    for (int j = 0; j < G::NIW; ++j) {
+      const int slot = (4 * j + wave) * RPI + drow;
+      ids[j] = hid[(int64_t)blk * C7_HCAP + (slot < C7_HCAP ? slot : C7_HCAP - 1)];
+    }
+  };
+  auto issue_dma = [&](int blk, int cnt, int bsel) {
+    const uint32_t base = lds0 + (uint32_t)(bsel * G::BUF);
+#pragma unroll
+    for (int j = 0; j < G::NIW; ++j) {
+      const int i = 4 * j + wave;
+      if (i * RPI < cnt) {                                   // wave-uniform
+        const int slot = i * RPI + drow;
+        const int piece = dpos ^ G::swz(slot);
+        c7_dma16(reinterpret_cast<const unsigned char*>(in) + (int64_t)ids[j] * ROWB + piece * 16, base + (uint32_t)(i * 1024));
+      }
+    }
+    if (cnt > 0) {
+      const unsigned char* tsrc = reinterpret_cast<const unsigned char*>(tab) + (int64_t)blk * C7_TABB;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = 4 * j + wave;
+        if (i < C7_TABB / 1024) c7_dma16(tsrc + i * 1024 + lane * 16, base + (uint32_t)(G::ROWS_BYTES + i * 1024));
+      }
+    }
+  };
+  // (a count is LOADED early and USED late: the compiler waits for an ordinary load at the first use of its result, and that wait
+  //  would also drain the DMAs issued before it)
+  auto count_of = [&](int blk) -> int { return hcnt[blk < n_blocks ? blk : n_blocks - 1]; };
+
+  // prologue: block b_begin -> buffer 0
+  int cnt_cur = __builtin_amdgcn_readfirstlane(count_of(b_begin));
+  load_ids(b_begin);
+  issue_dma(b_begin, cnt_cur, 0);
+  int cnt_nxt = count_of(b_begin + 1);
+  if (b_begin + 1 < b_end) load_ids(b_begin + 1);
+  __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
+  __builtin_amdgcn_s_barrier();
+  cnt_nxt = __builtin_amdgcn_readfirstlane(cnt_nxt);
+
+  const uint32_t pbase = (uint32_t)(kh * 4 + g);     // the 16-byte piece of a gathered row this lane feeds to the MFMA
+  int cur = 0;
+#pragma unroll 1
+  for (int blk = b_begin; blk < b_end; ++blk) {
+    // block blk + 1 -> the other buffer (its ids arrived before the barrier that ended the previous iteration)
+    if (blk + 1 < b_end) issue_dma(blk + 1, cnt_nxt, cur ^ 1);
+    int cnt_nn = count_of(blk + 2);
+    if (blk + 2 < b_end) load_ids(blk + 2);
+
+    const unsigned char* rowsL = smem + cur * G::BUF;
+    const unsigned char* tabL = rowsL + G::ROWS_BYTES + r * (C7_NT * 2) + (C == 64 ? 0 : wave * 4);
+    const int64_t row0 = (int64_t)blk * C7_BM;
+    f32x4 acc[TW][2];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (cnt_cur > 0) {   // (a block whose halo did not fit is left to the global-gather kernel launched behind this one)
+      // 27 taps x TW tiles, branch-free, software-pipelined by hand: the gathers of tap k + 1 are issued before the MFMAs of tap k
+      auto entries = [&](int k, uint32_t (&te)[4]) {
+        if constexpr (C == 64) {
+          // a wave's LOCAL tile tl is the block's tile (tl + 4 kh) & 7: local tiles 0..3 are the ones it finishes in the epilogue,
+          // 4..7 the ones it hands to its partner -- every accumulator index below is then a compile-time constant
+          const uint4 v = *reinterpret_cast<const uint4*>(tabL + k * (16 * C7_NT * 2));
+          te[0] = kh ? v.z : v.x; te[1] = kh ? v.w : v.y; te[2] = kh ? v.x : v.z; te[3] = kh ? v.y : v.w;
+        } else {
+          te[0] = *reinterpret_cast<const uint32_t*>(tabL + k * (16 * C7_NT * 2));
+        }
+      };
+      auto gather = [&](const uint32_t (&te)[4], frag (&b)[TW]) {
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          uint32_t s = (te[t >> 1] >> ((t & 1) * 16)) & 0xffffu;
+          s = s < (uint32_t)C7_HCAP ? s : (uint32_t)C7_HCAP;                  // "no neighbour" -> the zero row
+          b[t] = *reinterpret_cast<const frag*>(rowsL + s * ROWB + ((pbase ^ (uint32_t)G::swz((int)s)) & (PCS - 1)) * 16);
+        }
+      };
+      uint32_t teA[4], teB[4];
+      frag bA[TW], bB[TW];
+      entries(0, teA);
+      gather(teA, bA);
+      entries(1, teB);
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        frag (&bc)[TW] = (k & 1) ? bB : bA;
+        frag (&bn)[TW] = (k & 1) ? bA : bB;
+        uint32_t (&tn)[4] = (k & 1) ? teA : teB;      // entries of tap k + 1 (read one tap ago)
+        uint32_t (&tnn)[4] = (k & 1) ? teB : teA;     // entries of tap k + 2: overwrites those of tap k
+        if (k + 1 < 27) gather(tn, bn);
+        if (k + 2 < 27) entries(k + 2, tnn);
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          acc[t][0] = M::mma(wf[k][0], bc[t], acc[t][0]);
+          acc[t][1] = M::mma(wf[k][1], bc[t], acc[t][1]);
+        }
+      }
+    }
+
+    // ---- epilogue
+    auto store_tile = [&](int tile, const f32x4 (&a)[2]) {
+      const int64_t row = row0 + tile * 16 + r;
+      if (row < n_out && cnt_cur > 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          T o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = ptc_from_float<T>(a[c][e] + bsv[c][e]);
+          uint2 v;
+          __builtin_memcpy(&v, o, 8);
+          *reinterpret_cast<uint2*>(out + row * C + (ch * 2 + c) * 16 + g * 4) = v;
+        }
+      }
+    };
+    if constexpr (C == 64) {
+      // the two input-channel halves of a tile meet in LDS: wave kh finishes the block's tiles 4 kh .. 4 kh + 3 (its local tiles 0..3)
+      // and hands the others (local 4..7 = the partner's local 0..3) to its partner
+      unsigned char* scr = smem + 2 * G::BUF;
+      const int partner = wave ^ 1;
+#pragma unroll
+      for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          *reinterpret_cast<f32x4*>(scr + ((partner * 4 + tl) * 2 + c) * 1024 + lane * 16) = acc[4 + tl][c];
+      __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);   // scratch written; next block's rows + table and the ids landed
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int tl = 0; tl < 4; ++tl) {
+        f32x4 a[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(scr + ((wave * 4 + tl) * 2 + c) * 1024 + lane * 16);
+          a[c] = acc[tl][c] + o;
+        }
+        store_tile(kh * 4 + tl, a);
+      }
+      // the partner must not reach its next scratch write before this wave has read: a second barrier (the epilogues are symmetric)
+      __builtin_amdgcn_s_waitcnt(C7_WAIT_LGKM0);
+      __builtin_amdgcn_s_barrier();
+    } else {
+#pragma unroll
+      for (int t = 0; t < TW; ++t) store_tile(2 * wave + t, acc[t]);
+      __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
+      __builtin_amdgcn_s_barrier();
+    }
+    cur ^= 1;
+    cnt_cur = cnt_nxt;
+    cnt_nxt = __builtin_amdgcn_readfirstlane(cnt_nn);
+  }
+}
+
+static inline bool conv7_supported(int dtype, int kv, int c_in, int c_out, int bm, int hcap, int64_t n_out) {
+  return dtype != PTC_F32 && kv == 27 && c_in == c_out && (c_in == 32 || c_in == 64) && bm == C7_BM && hcap == C7_HCAP && n_out >= 4096;
+}
+
+template <typename T, int C>
+static int launch_conv7_i(const void* in, int64_t n_in, const void* w, const float* bias, const uint16_t* tab,
+                          const int32_t* hid, const int32_t* hcnt, int64_t n_out, void* out, hipStream_t s) {
+  const int n_blocks = (int)ptc_cdiv(n_out, C7_BM);
+  int max_wgs = 256;                          // one persistent workgroup per CU
+#ifndef __HIPCC__
+  if (const char* e = getenv("PTC_EMU_CONV7_WGS")) max_wgs = atoi(e);   // host emulation only: few workgroups = many blocks each at test sizes
+#endif
+  int grid = n_blocks < max_wgs ? n_blocks : max_wgs;
+  const int per_wg = (n_blocks + grid - 1) / grid;
+  grid = (n_blocks + per_wg - 1) / per_wg;
+  auto kern = conv7_kernel<T, C>;
+  static bool attr = false;   // per instantiation
+  if (!attr) {
+    PTC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C7Geom<C>::LDS));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C7Geom<C>::LDS, s, (const T*)in, (const T*)w, bias, tab, hid, hcnt, n_out,
+                     n_blocks, per_wg, (T*)out);
+  PTC_CHECK_LAUNCH("conv7_kernel");
+  return PTC_OK;
+}
+
+// conv7 over the blocks whose halo fits, then conv5 (its 128-row workgroups are the same blocks) over the others: a workgroup of
+// the second launch whose block conv7 served returns at once
+template <typename T>
+static int launch_conv7(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, const uint16_t* tab,
+                        const int32_t* hid, const int32_t* hcnt, int64_t n_out, int c, void* out, hipStream_t s) {
+  int rc = c == 64 ? launch_conv7_i<T, 64>(in, n_in, w, bias, tab, hid, hcnt, n_out, out, s)
+                   : launch_conv7_i<T, 32>(in, n_in, w, bias, tab, hid, hcnt, n_out, out, s);
+  if (rc != PTC_OK) return rc;
+  return launch_conv5<T>(in, n_in, w, bias, nbr, n_out, 27, c, c, out, s, hcnt);
+}

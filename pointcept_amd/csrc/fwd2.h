@@ -368,12 +368,10 @@ static int launch_fwd2(const void* in, int64_t n_in, const void* w, const float*
     // column blocks per workgroup: as many as keep W within 64 KB of LDS (two workgroups per CU), see linear2_kernel
     const int nblk = c_out / NT;
     bool lds_store = epi == 0 && c_in <= 64;          // see f2_store_rows_lds
-    if (const char* e = getenv("PTC_LINEAR2_LDS_STORE")) { if (atoi(e) == 0) lds_store = false; }   // A/B switch
     const size_t slices = lds_store ? 4 * f2_out_slice_bytes(NT) : 0;
     int nh = 1;
     for (int cand = 4; cand >= 2; --cand)
       if (nblk % cand == 0 && (size_t)cand * NT * (c_in + 8) * 2 + (size_t)cand * NT * 4 + 16 + slices <= 64 * 1024) { nh = cand; break; }
-    if (const char* e = getenv("PTC_LINEAR2_NH")) { if (atoi(e) == 1) nh = 1; }   // A/B switch: the one-block form
     const size_t lds = (((size_t)nh * NT * (c_in + 8) * 2 + 15) & ~(size_t)15) + (size_t)nh * NT * 4 + slices;
     const int64_t tiles = ptc_cdiv(n_out, F2_ROWS);
     int64_t per_cu = lds > 40 * 1024 ? 2 : 4;

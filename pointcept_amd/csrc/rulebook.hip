@@ -153,50 +153,6 @@ rulebook_subm_kernel(const int32_t* __restrict__ indices, int64_t n, const VoxBu
   }
 }
 
-// first-generation kernel (one dependent probe chain per voxel), kept behind PTC_RULEBOOK_V1=1 for A/B runs
-template <int KS>
-__global__ void __launch_bounds__(256)
-rulebook_subm_kernel_v1(const int32_t* __restrict__ indices, int64_t n, const VoxBucket* __restrict__ table, uint64_t mask,
-                     int32_t* __restrict__ nbr) {
-  constexpr int R = KS / 2, NB = R + 1;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int4 c = reinterpret_cast<const int4*>(indices)[i];
-    const int bx0 = (c.y - R) >> 1, by0 = (c.z - R) >> 1, bz0 = (c.w - R) >> 1;   // arithmetic shift: floor for negatives
-    const int ex = c.y - 2 * bx0, ey = c.z - 2 * by0, ez = c.w - 2 * bz0;         // R or R + 1
-#pragma unroll 1
-    for (int ob = 0; ob < NB * NB * NB; ++ob) {
-      const int o0 = ob / (NB * NB), o1 = (ob / NB) % NB, o2 = ob % NB;
-      const int bx = bx0 + o0, by = by0 + o1, bz = bz0 + o2;
-      uint4 v0 = make_uint4(~0u, ~0u, ~0u, ~0u), v1 = v0;
-      if (bx >= 0 && by >= 0 && bz >= 0 && bx < (PTC_VOX_MAX >> 1) && by < (PTC_VOX_MAX >> 1) && bz < (PTC_VOX_MAX >> 1)) {
-        const unsigned long long key = ptc_vox_pack(c.x, bx, by, bz);
-        uint64_t slot = ptc_vox_home(key) & mask;
-        for (uint64_t probe = 0; probe <= mask; ++probe) {
-          const unsigned long long kk = table[slot].key;
-          if (kk == key) {
-            const uint4* pv = reinterpret_cast<const uint4*>(table[slot].vals);
-            v0 = pv[0];
-            v1 = pv[1];
-            break;
-          }
-          if (kk == PTC_HASH_EMPTY) break;
-          slot = (slot + 1) & mask;
-        }
-      }
-      const unsigned int vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-      for (int cell = 0; cell < 8; ++cell) {
-        const int d0 = 2 * o0 + (cell >> 2) - ex, d1 = 2 * o1 + ((cell >> 1) & 1) - ey, d2 = 2 * o2 + (cell & 1) - ez;
-        if (d0 >= -R && d0 <= R && d1 >= -R && d1 <= R && d2 >= -R && d2 <= R) {
-          const int k = ((d0 + R) * KS + (d1 + R)) * KS + (d2 + R);
-          nbr[(int64_t)k * n + i] = (int32_t)vv[cell];
-        }
-      }
-    }
-  }
-}
-
 extern "C" int ptc_rulebook_subm(const int32_t* indices, int64_t n, int ksize, const void* table, size_t table_bytes, int32_t* nbr,
                                  ptc_stream_t stream) {
   PTC_REQUIRE(n >= 0, PTC_EINVAL, "ptc_rulebook_subm: n < 0");
@@ -208,18 +164,6 @@ extern "C" int ptc_rulebook_subm(const int32_t* indices, int64_t n, int ksize, c
   const uint64_t mask = (uint64_t)(ptc_hash_table_size(n) - 1);
   const VoxBucket* tb = (const VoxBucket*)table;
   hipStream_t s = (hipStream_t)stream;
-  if (const char* e = getenv("PTC_RULEBOOK_V1")) {
-    if (atoi(e) != 0) {
-      switch (ksize) {
-        case 1: hipLaunchKernelGGL(rulebook_subm_kernel_v1<1>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
-        case 3: hipLaunchKernelGGL(rulebook_subm_kernel_v1<3>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
-        case 5: hipLaunchKernelGGL(rulebook_subm_kernel_v1<5>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
-        default: hipLaunchKernelGGL(rulebook_subm_kernel_v1<7>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
-      }
-      PTC_CHECK_LAUNCH("rulebook_subm_kernel_v1");
-      return PTC_OK;
-    }
-  }
   switch (ksize) {
     case 1: hipLaunchKernelGGL(rulebook_subm_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;
     case 3: hipLaunchKernelGGL(rulebook_subm_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, indices, n, tb, mask, nbr); break;

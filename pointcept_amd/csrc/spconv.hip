@@ -214,15 +214,8 @@ static int dispatch_fwd(const void* in, const void* w, const float* bias, const 
 
 #include "fwd2.h"
 #include "conv3.h"
-#include "conv4.h"
 #include "conv5.h"
-#include "conv6.h"
-
-// experiment switch (read per call, ~50 ns): PTC_CONV3=0 keeps the table convolutions on conv2
-static bool ptc_use_conv3() {
-  const char* e = getenv("PTC_CONV3");
-  return e ? atoi(e) != 0 : true;
-}
+#include "conv7.h"
 
 extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr,
                               int64_t n_out, int kv, int c_in, int c_out, int dtype, void* out, ptc_stream_t stream) {
@@ -237,15 +230,11 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
   hipStream_t s = (hipStream_t)stream;
   // the second- and third-generation kernels gather through raw buffer loads (32-bit offsets, < 2 GiB tensors)
   const bool buf_ok = (uint64_t)n_in * (uint64_t)c_in * ptc_dtype_size(dtype) <= PTC_BUF_MAX_BYTES;
-  if (buf_ok && ptc_use_conv3() && conv6_takes(c_in) && conv5_supported(dtype, kv, c_in, c_out, nbr, n_in)) {
-    if (dtype == PTC_BF16) return launch_conv6<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);   // candidate: compacted gathers
-    return launch_conv6<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
-  }
-  if (buf_ok && ptc_use_conv3() && conv5_enabled() && conv5_supported(dtype, kv, c_in, c_out, nbr, n_in)) {
+  if (buf_ok && conv5_supported(dtype, kv, c_in, c_out, nbr, n_in)) {
     if (dtype == PTC_BF16) return launch_conv5<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
     return launch_conv5<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
   }
-  if (buf_ok && ptc_use_conv3() && conv3_supported(dtype, kv, c_in, c_out, nbr)) {
+  if (buf_ok && conv3_supported(dtype, kv, c_in, c_out, nbr)) {
     if (dtype == PTC_BF16) return launch_conv3<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
     return launch_conv3<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
   }
@@ -258,20 +247,17 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
 }
 
 extern "C" int ptc_spconv_fwd_blk(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr,
-                                  const int16_t* lnbr, const int32_t* halo, const int32_t* hcnt, int bm, int hmax, int64_t n_out, int kv,
+                                  const void* tab, const int32_t* hid, const int32_t* hcnt, int bm, int hcap, int64_t n_out, int kv,
                                   int c_in, int c_out, int dtype, void* out, ptc_stream_t stream) {
   const bool buf_ok = (uint64_t)n_in * (uint64_t)c_in * ptc_dtype_size(dtype) <= PTC_BUF_MAX_BYTES;
-  const char* e = getenv("PTC_CONV4");
-  const bool on = e ? atoi(e) != 0 : true;
-  if (!on || !buf_ok || !lnbr || !halo || !hcnt || !nbr || n_out == 0 || !conv4_supported(dtype, kv, c_in, c_out, bm, hmax))
+  if (!buf_ok || !tab || !hid || !hcnt || !nbr || n_in != n_out || !conv7_supported(dtype, kv, c_in, c_out, bm, hcap, n_out))
     return ptc_spconv_fwd(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, dtype, out, stream);
-  PTC_REQUIRE(n_in >= 0 && n_out >= 0, PTC_EINVAL, "ptc_spconv_fwd_blk: bad sizes");
   PTC_REQUIRE(weight && out && in, PTC_EINVAL, "ptc_spconv_fwd_blk: null buffer");
-  PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)out % 16 == 0), PTC_EINVAL,
+  PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)tab % 16 == 0), PTC_EINVAL,
               "ptc_spconv_fwd_blk: buffers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == PTC_BF16) return launch_conv4<bf16_t>(in, n_in, weight, bias, nbr, lnbr, halo, hcnt, bm, hmax, n_out, kv, c_in, c_out, out, s);
-  return launch_conv4<f16_t>(in, n_in, weight, bias, nbr, lnbr, halo, hcnt, bm, hmax, n_out, kv, c_in, c_out, out, s);
+  if (dtype == PTC_BF16) return launch_conv7<bf16_t>(in, n_in, weight, bias, nbr, (const uint16_t*)tab, hid, hcnt, n_out, c_in, out, s);
+  return launch_conv7<f16_t>(in, n_in, weight, bias, nbr, (const uint16_t*)tab, hid, hcnt, n_out, c_in, out, s);
 }
 
 // Dense row-wise GEMM with an MLP epilogue (see fwd2.h): epilogue 1 = out: h, aux_out: GELU(h);
@@ -549,8 +535,6 @@ static int launch_wgrad2_inst(const W2Plan& p, const void* in, int64_t n_in, con
   return PTC_OK;
 }
 
-#include "wgrad3.h"
-
 template <typename T>
 static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
                          float* dw, float* dbias, void* ws, hipStream_t s) {
@@ -560,9 +544,6 @@ static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const i
   float* bias_partial = nullptr;
   if (dbias) bias_partial = p.gx > 1 ? (float*)((char*)ws + ptc_align_up((size_t)p.gx * (size_t)count * sizeof(float), 256)) : dbias;
   int rc = PTC_EUNSUPPORTED;
-  if (wgrad3_takes(p, nbr, c_in, dbias != nullptr))   // candidate: compacted gathers
-    rc = launch_wgrad3<T>(p, in, n_in, dout, nbr, n_out, kv, c_out, partial, s);
-  else {
 #define W2_CASE(COT, CIT, KG)                                                                                         \
   if (p.cot == COT && p.cit == CIT && p.kg == KG)                                                                     \
     rc = launch_wgrad2_inst<T, COT, CIT, KG>(p, in, n_in, dout, nbr, n_out, kv, c_in, c_out, partial, bias_partial, s);
@@ -570,7 +551,6 @@ static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const i
   W2_CASE(6, 1, 1) W2_CASE(6, 2, 1) W2_CASE(6, 4, 1) W2_CASE(8, 1, 1) W2_CASE(8, 2, 1) W2_CASE(8, 4, 1)
   W2_CASE(2, 1, 16) W2_CASE(2, 2, 4) W2_CASE(4, 2, 4) W2_CASE(2, 4, 4) W2_CASE(4, 4, 2) W2_CASE(6, 2, 2)
 #undef W2_CASE
-  }
   if (rc != PTC_OK) {
     if (rc == PTC_EUNSUPPORTED) ptc_set_error("ptc_spconv_wgrad: no wgrad2 instance for tiles (%d,%d,%d)", p.cot, p.cit, p.kg);
     return rc;

@@ -308,16 +308,10 @@ struct W2Plan {
   size_t lds;
 };
 
-static inline int w2_env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out, bool want_bias = false) {
-  static const int cot_max = w2_env_int("PTC_W2_COT_MAX", 8), cit_max = w2_env_int("PTC_W2_CIT_MAX", 4);  // tuning knobs
-  // workgroups aimed at per launch and 32-row steps a workgroup must at least own (sweep knobs for the small weight gradients of
-  // the deep stages: 103 launches of ~29 us per step at 1008 workgroups x ~5 steps per wave)
-  static const int target_wgs = w2_env_int("PTC_W2_TARGET_WGS", 1024), min_steps = w2_env_int("PTC_W2_MIN_STEPS", 16);
+  // workgroups aimed at per launch and 32-row steps a workgroup must at least own (swept for the small weight gradients of the deep
+  // stages in round 2: 1024 / 16 kept)
+  constexpr int cot_max = 8, cit_max = 4, target_wgs = 1024, min_steps = 16;
   W2Plan p;
   // channel tiles: 64x64 accumulators by default; channel counts that are multiples of 32 but not of 64
   // (SpUNet's 96-channel decoder) take 32-wide input tiles / a 96-wide output tile so that no MFMA runs on padding

@@ -63,7 +63,7 @@ class _CastCache:
         taps = 1), "keep" (tap order kept) or "repeat" (taps = 1 matrix repeated taps_dst times).  Persistent buffers; every
         stale layout of the model is rewritten in ONE launch (ptc_weight_layouts) the first time one is asked for after the
         shadows were refreshed.  None when w is not a cache shadow (fp32 runs, padded copies): the caller permutes itself."""
-        if _LEGACY_LAUNCHES or not w.is_cuda or w.dim() not in (2, 3) or not w.is_contiguous() or w.element_size() != 2:
+        if not w.is_cuda or w.dim() not in (2, 3) or not w.is_contiguous() or w.element_size() != 2:
             return None
         e = self.by_shadow.get(w.data_ptr())
         if e is None or e[1].numel() != w.numel():
@@ -125,7 +125,7 @@ class _CastCache:
         if w.dtype == dt:
             return w
         owner = w._base if w._base is not None else w     # conv weights arrive as views of the Parameter
-        if owner.grad_fn is not None:                      # a weight COMPUTED this step (folded conv + Linear): nothing to cache
+        if not isinstance(owner, torch.nn.Parameter) and (owner.grad_fn is not None or not owner.is_leaf):   # a weight COMPUTED this step: nothing to cache
             return w.to(dt)
         if not w.is_contiguous() or (self.cuda_only and not w.is_cuda) or owner.numel() != w.numel() or not owner.is_contiguous():
             return w.to(dt)
@@ -159,7 +159,7 @@ class _CastCache:
                 stale.append(x)
                 srcs.append(o.detach().reshape(-1))
         with torch.no_grad():
-            if not (_CAST_MANY and self._cast_many(stale, srcs)):
+            if not self._cast_many(stale, srcs):
                 torch._foreach_copy_([x[1] for x in stale], srcs)
         for x, o in zip(stale, srcs):
             x[2] = x[0]()._version
@@ -167,10 +167,9 @@ class _CastCache:
         return e[1].view(w.shape)
 
 
-# PTC_CAST_MANY=1: the per-step refresh of the 16-bit weight shadows as ONE launch (csrc/rows.hip: cast_many_kernel) instead of
-# torch._foreach_copy_'s ~29 multi-tensor launches (0.40 ms per step at the bench config against ~0.05 ms of HBM time).  Checked on the
-# host emulation; off until it has been timed on the GPU.
-_CAST_MANY = os.environ.get("PTC_CAST_MANY", "0") == "1"
+# The per-step refresh of the 16-bit weight shadows is ONE launch (csrc/rows.hip: cast_many_kernel; _CastCache._cast_many) where every
+# stale shadow is a CUDA fp32 -> bf16 / f16 pair on one device, torch._foreach_copy_ (~29 multi-tensor launches at the bench config) otherwise.
+# Timed in the step: 49.4 vs 49.8 ms (profiles/r03_a_knob_ab.txt) -- neutral on the GPU clock, 28 launches less on the host.
 _cast_cache = _CastCache()
 
 
@@ -275,10 +274,8 @@ def _pad_to(x: torch.Tensor, dim: int, mult: int) -> torch.Tensor:
     return F.pad(x, pad)
 
 
-# PTC_MERGE_DUP_SEGMENTED=1: the duplicate merge as ONE segmented sum (ptc_segment_csr_fwd) over a CSR of the representatives that is
-# built once per coordinate set -- no python loop, no host sync per conv backward.  Same order of additions.  Off until it has been
-# through the GPU tests (written after round 2's GPU time was spent); VERDICT r1 weak 11.
-_MERGE_DUP_SEGMENTED = os.environ.get("PTC_MERGE_DUP_SEGMENTED", "0") == "1"
+# The duplicate merge is ONE segmented sum (ptc_segment_csr_fwd) over a CSR of the representatives that is built once per coordinate
+# set -- no python loop, no host sync per conv backward; additions in ascending row order.
 _dup_csr = {}   # id(rep) -> (weakref(rep), perm, indptr, keep)
 
 
@@ -304,34 +301,13 @@ def _dup_csr_of(rep: torch.Tensor):
 
 def _merge_duplicate_rows(g: torch.Tensor, rep: torch.Tensor) -> torch.Tensor:
     """g with, for every voxel listed more than once, the rows of all its copies summed into the representative row
-    rep[i] (the lowest row of the voxel).  Only runs for inputs that carry duplicate coordinates (Mix3D batches);
-    one pass per extra copy, each pass touching every representative at most once: no atomics, fixed order."""
-    if _MERGE_DUP_SEGMENTED:
-        perm, indptr, keep = _dup_csr_of(rep)
-        merged, _ = ops.segment_csr_fwd(g.contiguous(), perm, indptr, "sum")   # row t: g[t] + its copies, ascending rows
-        return torch.where(keep[:, None], g, merged.to(g.dtype))
-    n = g.shape[0]
-    rows = (rep != torch.arange(n, device=rep.device, dtype=rep.dtype)).nonzero().squeeze(1)
-    if rows.numel() == 0:
-        return g
-    target, perm = torch.sort(rep[rows], stable=True)
-    rows = rows[perm]
-    _, counts = torch.unique_consecutive(target, return_counts=True)
-    rank = torch.arange(rows.numel(), device=rep.device) - torch.repeat_interleave(torch.cumsum(counts, 0) - counts, counts)
-    out = g.to(torch.float32, copy=True)      # never in place: the weight gradient needs the unmerged rows
-    for k in range(int(counts.max())):
-        sel = rank == k
-        out[target[sel]] += g[rows[sel]].float()
-    return out.to(g.dtype)
+    rep[i] (the lowest row of the voxel).  Only runs for inputs that carry duplicate coordinates (Mix3D batches); no atomics, fixed order."""
+    perm, indptr, keep = _dup_csr_of(rep)
+    merged, _ = ops.segment_csr_fwd(g.contiguous(), perm, indptr, "sum")   # row t: g[t] + its copies, ascending rows
+    return torch.where(keep[:, None], g, merged.to(g.dtype))
 
 
 _rev_index_cache = {}
-# A/B switch (bench.py in one session, profiles/r02_s_bench_ab.txt): the round-1 launch pattern -- two-launch weight mirror and
-# DropPath masks, fp32 casts of the stream in front of every pooling / unpooling / head Linear, fp32 copy of a bf16 residual
-# operand, materialised zero gradients for unused add_norm outputs
-_LEGACY_LAUNCHES = os.environ.get("PTC_LEGACY_LAUNCHES", "0") == "1"
-
-
 def _reverse_index(n: int, device) -> torch.Tensor:
     key = (n, device)
     t = _rev_index_cache.get(key)
@@ -340,51 +316,8 @@ def _reverse_index(n: int, device) -> torch.Tensor:
     return t
 
 
-# ---- weight gradients on a second HIP stream (measured, OFF) ---------------------------------------
-# Inside one backward the weight gradient (wgrad + its split reduction) and the input gradient (dgrad) are independent.  On the
-# deep stages (N <= ~50k rows) neither fills 256 CUs, so issuing them on two streams (joined before the Function returns:
-# autograd, DDP's bucket hooks and the allocator see the ordering of a single stream) looked like free overlap.  Measured in one
-# session (profiles/r02_t_bench_ab.txt): off 51.1 / 51.8 ms per step, launches with <= 65536 rows forked 52.6 / 52.8 ms, every
-# launch forked 53.6 ms -- the two cross-stream waits per Function (~220 Functions per step) cost more than the small kernels
-# gain.  PTC_WGRAD_STREAM: 0 = off (default), 1 = launches with <= PTC_WGRAD_STREAM_MAX_ROWS rows, 2 = every launch; same
-# kernels on the same data, bit-identical results.
-_WGRAD_STREAM = int(os.environ.get("PTC_WGRAD_STREAM", "0"))
-_WGRAD_STREAM_MAX_ROWS = int(os.environ.get("PTC_WGRAD_STREAM_MAX_ROWS", "65536"))
-_side_streams = {}
-
-
-class _Fork:
-    """with _Fork(t, rows) as f: <side work>   ...main-stream work...   f.join(side outputs)"""
-
-    def __init__(self, ref: torch.Tensor, rows: int):
-        self.on = bool(ref.is_cuda and (_WGRAD_STREAM == 2 or (_WGRAD_STREAM == 1 and rows <= _WGRAD_STREAM_MAX_ROWS)))
-        self.ctx = None
-        if self.on:
-            self.main = torch.cuda.current_stream(ref.device)
-            side = _side_streams.get(ref.device)
-            if side is None:
-                side = _side_streams[ref.device] = torch.cuda.Stream(ref.device)
-            self.side = side
-
-    def __enter__(self):
-        if self.on:
-            self.side.wait_stream(self.main)          # everything the side work reads has been enqueued on main
-            self.ctx = torch.cuda.stream(self.side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-            self.ctx = None
-        return False
-
-    def join(self, *outs):
-        if self.on:
-            self.main.wait_stream(self.side)
-            for o in outs:                             # allocated from the side stream's pool, consumed on main
-                if o is not None:
-                    o.record_stream(self.main)
+# (Weight gradients on a second HIP stream beside the input gradient were measured SLOWER in the step -- 52.6-53.6 against 51.1-51.8 ms,
+#  profiles/r02_t_bench_ab.txt: two cross-stream waits per Function cost more than the small kernels gain -- and removed.)
 
 
 # ---- cast twins of activations --------------------------------------------------------------------
@@ -407,7 +340,7 @@ def register_cast_twin(x: torch.Tensor, twin: torch.Tensor) -> None:
 
 
 def cast_twin(x: torch.Tensor, dt: torch.dtype) -> Optional[torch.Tensor]:
-    e = None if _LEGACY_LAUNCHES else _act_twins.get(id(x))
+    e = _act_twins.get(id(x))
     if e is not None and e[0]() is x and e[2] == x._version and e[1].dtype == dt and e[1].shape == x.shape:
         return e[1]
     return None
@@ -453,19 +386,15 @@ class _SparseConv(Function):
         c_out, kv, c_in = ctx.shape
         g = _pad_to(grad.to(f.dtype), 1, 16).contiguous()
         dfeat = dw = dbias = None
-        fork = _Fork(g, g.shape[0])
-        with fork:                                   # independent of the input gradient: second stream (see _Fork)
-            if ctx.needs_input_grad[1]:
-                dw = ops.spconv_wgrad(f, g, nbr)[:c_out, :, :c_in].to(ctx.w_dtype)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                dbias = ops.column_sum(grad)
+        if ctx.needs_input_grad[1]:
+            dw = ops.spconv_wgrad(f, g, nbr)[:c_out, :, :c_in].to(ctx.w_dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbias = ops.column_sum(grad)
         if ctx.needs_input_grad[0]:
             wt = _cast_cache.layout(w, "mirror" if ctx.mirror else "keep")   # all layers' layouts in one launch per step
             if wt is None:
                 wt = w.permute(2, 1, 0)
-                if ctx.mirror and _LEGACY_LAUNCHES:
-                    wt = wt.flip(1).contiguous()
-                elif ctx.mirror:   # W' = W.permute(ci, k, co).flip(k), contiguous, in ONE launch (flip + contiguous were two)
+                if ctx.mirror:   # W' = W.permute(ci, k, co).flip(k), contiguous, in ONE launch (flip + contiguous were two)
                     wt = wt.index_select(1, _reverse_index(wt.shape[1], wt.device))
                 else:
                     wt = wt.contiguous()
@@ -475,7 +404,6 @@ class _SparseConv(Function):
             if dup_in is not None:
                 own = dup_in == torch.arange(dup_in.numel(), device=dup_in.device, dtype=dup_in.dtype)
                 dfeat = dfeat * own[:, None].to(dfeat.dtype)
-        fork.join(dw, dbias)
         return dfeat, dw, dbias, None, None, None, None, None, None
 
 
@@ -530,18 +458,16 @@ class _Linear(Function):
         g = _pad_to(grad.to(xp.dtype), 1, 16).contiguous()
         dx = dw = db = None
         want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
-        fork = _Fork(g, g.shape[0])
-        with fork:                                   # weight / bias gradients on the second stream (see _Fork)
-            if ctx.needs_input_grad[1] or want_b:
-                if tab_fwd is not None or xp.dtype == torch.float32 or g.shape[0] >= _OWN_WGRAD_MIN_ROWS:
-                    res = ops.spconv_wgrad(xp, g, tab_fwd, want_bias=want_b)
-                    dwp, dbp = res if want_b else (res, None)
-                    dw = dwp[:c_out, 0, :c_in].to(ctx.w_dtype)
-                else:
-                    dw = (g.t() @ xp)[:c_out, :c_in].to(ctx.w_dtype)
-                    dbp = ops.column_sum(g) if want_b else None
-                if want_b:
-                    db = dbp[:c_out].to(ctx.b_dtype)
+        if ctx.needs_input_grad[1] or want_b:
+            if tab_fwd is not None or xp.dtype == torch.float32 or g.shape[0] >= _OWN_WGRAD_MIN_ROWS:
+                res = ops.spconv_wgrad(xp, g, tab_fwd, want_bias=want_b)
+                dwp, dbp = res if want_b else (res, None)
+                dw = dwp[:c_out, 0, :c_in].to(ctx.w_dtype)
+            else:
+                dw = (g.t() @ xp)[:c_out, :c_in].to(ctx.w_dtype)
+                dbp = ops.column_sum(g) if want_b else None
+            if want_b:
+                db = dbp[:c_out].to(ctx.b_dtype)
         if ctx.needs_input_grad[0]:
             if tab_bwd is not None or xp.dtype == torch.float32 or _own_gemm(xp.shape[0], g.shape[1], xp.dtype):
                 slots = tab_bwd.shape[0] if tab_bwd is not None else 1
@@ -554,7 +480,6 @@ class _Linear(Function):
             else:
                 dx = g @ wp
             dx = dx[:, :c_in].to(ctx.in_dtype)
-        fork.join(dw, db)
         return dx, dw, db, None, None
 
 
@@ -619,7 +544,7 @@ class _AddNorm(Function):
         ctx.a_dtype = a.dtype
         # an unused output (the cast copy of a stage's last block, which the pooling does not read) must not be
         # materialised as a zero gradient: that was 8 zero fills + 8 extra reads of [N, C] per step
-        ctx.set_materialize_grads(_LEGACY_LAUNCHES)
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable()
         if y is None:
             y = z.new_empty(0)
@@ -645,7 +570,7 @@ def add_norm(u: torch.Tensor, a: torch.Tensor, row_scale: Optional[torch.Tensor]
     """One pass over a residual joint of the PTv3 Block: z = a + row_scale[:,None] * f(u) (fp32 residual
     stream), y = g(z) as `y_dtype`.  f / g are nn.LayerNorm modules (norm_a / norm_b) or identity.
     Returns (z, y); y is None when y_dtype is None."""
-    if a.dtype not in (torch.float32, torch.bfloat16) or (_LEGACY_LAUNCHES and a.dtype != torch.float32):
+    if a.dtype not in (torch.float32, torch.bfloat16):
         a = a.float()
     ga, ba, ea = (norm_a.weight, norm_a.bias, norm_a.eps) if norm_a is not None else (None, None, 0.0)
     gb, bb, eb = (norm_b.weight, norm_b.bias, norm_b.eps) if norm_b is not None else (None, None, 0.0)
@@ -745,12 +670,11 @@ def rope_xyz_torch(qkv: torch.Tensor, xyz: torch.Tensor, inv_freq: torch.Tensor)
 
 def rope_xyz_qkvpacked(qkv: torch.Tensor, xyz: torch.Tensor, inv_freq: torch.Tensor) -> torch.Tensor:
     """qkv [n, 3, H, D] (D % 6 == 0) -> bf16 [n, 3, H, D] with Point3DRoPE applied to q and k: what flash-attn receives at
-    point_transformer_v3m3_utonia.py:319-323.  `config.ROPE_XYZ_KERNEL` selects the HIP kernel (default: torch ops on the GPU)."""
+    point_transformer_v3m3_utonia.py:319-323.  On ptc_rope3d_xyz (one pass over the packed rows, bf16 out); `rope_xyz_torch` is the same
+    arithmetic in torch ops, kept as the reference of the parity tests."""
     if qkv.dim() != 4 or qkv.shape[1] != 3 or qkv.shape[3] % 6 != 0:
         raise PtcoreError(f"rope_xyz_qkvpacked: qkv {tuple(qkv.shape)} must be [n, 3, H, D] with D % 6 == 0")
-    if config.ROPE_XYZ_KERNEL:
-        return _RopeXYZ.apply(qkv, xyz.float().contiguous(), inv_freq.float().contiguous())
-    return rope_xyz_torch(qkv, xyz, inv_freq)
+    return _RopeXYZ.apply(qkv, xyz.float().contiguous(), inv_freq.float().contiguous())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -864,32 +788,28 @@ class _MLP(Function):
         x_dt, w1_dt, b1_dt, w2_dt, b2_dt = ctx.dtypes
         g = dout.to(xp.dtype).contiguous()
         n = g.shape[0]
-        # fc2: weight / bias gradients (second stream, see _Fork) beside the input gradient THROUGH the activation
-        fork2 = _Fork(g, n)
-        with fork2:
-            if n >= _OWN_WGRAD_MIN_ROWS:
-                res = ops.spconv_wgrad(a, g, None, want_bias=b2_dt is not None)
-                dw2, db2 = res if b2_dt is not None else (res, None)
-                dw2 = dw2[:, 0, :]
-            else:
-                dw2 = (g.t() @ a).float()
-                db2 = ops.column_sum(g) if b2_dt is not None else None
-            dw2 = dw2.to(w2_dt)
-            db2 = None if db2 is None else db2.to(b2_dt)
+        # fc2: weight / bias gradients, then the input gradient THROUGH the activation
+        if n >= _OWN_WGRAD_MIN_ROWS:
+            res = ops.spconv_wgrad(a, g, None, want_bias=b2_dt is not None)
+            dw2, db2 = res if b2_dt is not None else (res, None)
+            dw2 = dw2[:, 0, :]
+        else:
+            dw2 = (g.t() @ a).float()
+            db2 = ops.column_sum(g) if b2_dt is not None else None
+        dw2 = dw2.to(w2_dt)
+        db2 = None if db2 is None else db2.to(b2_dt)
         w2t = _cast_cache.layout(w2c, "mirror")
         dh = ops.linear_gelu_bwd_input(g, w2c.t().contiguous() if w2t is None else w2t[:, 0, :], h)
         # fc1: the same split
-        fork1 = _Fork(dh, n)
-        with fork1:
-            if n >= _OWN_WGRAD_MIN_ROWS:
-                res = ops.spconv_wgrad(xp, dh, None, want_bias=b1_dt is not None)
-                dw1, db1 = res if b1_dt is not None else (res, None)
-                dw1 = dw1[:, 0, :]
-            else:
-                dw1 = (dh.t() @ xp).float()
-                db1 = ops.column_sum(dh) if b1_dt is not None else None
-            dw1 = dw1.to(w1_dt)
-            db1 = None if db1 is None else db1.to(b1_dt)
+        if n >= _OWN_WGRAD_MIN_ROWS:
+            res = ops.spconv_wgrad(xp, dh, None, want_bias=b1_dt is not None)
+            dw1, db1 = res if b1_dt is not None else (res, None)
+            dw1 = dw1[:, 0, :]
+        else:
+            dw1 = (dh.t() @ xp).float()
+            db1 = ops.column_sum(dh) if b1_dt is not None else None
+        dw1 = dw1.to(w1_dt)
+        db1 = None if db1 is None else db1.to(b1_dt)
         dx = None
         if ctx.needs_input_grad[0]:
             if _own_gemm(n, dh.shape[1], xp.dtype):
@@ -898,8 +818,6 @@ class _MLP(Function):
             else:
                 dx = dh @ w1c
             dx = dx.to(x_dt)
-        fork2.join(dw2, db2)
-        fork1.join(dw1, db1)
         return dx, dw1, db1, dw2, db2
 
 

@@ -348,58 +348,49 @@ def rulebook_subm(indices: torch.Tensor, ksize: int, table: Optional[HashTable] 
     return nbr
 
 
-class BlockTables:
-    """Block-local form of a submanifold gather table `nbr` (csrc/blocks.hip): per block of `bm` consecutive rows the
-    ascending list of distinct input rows (`halo` [n_blocks, hmax], `hcnt` [n_blocks]; hcnt > hmax = does not fit) and the
-    int16 table `lnbr` [kv, n] of positions in that list.  Consumed by spconv_fwd(..., blk=...) (csrc/conv4.h)."""
+BLOCK_BM, BLOCK_HCAP = 128, 416     # = C7_BM, C7_HCAP of csrc/conv7.h
 
-    def __init__(self, nbr: torch.Tensor, bm: int, hmax: int):
+
+class BlockTables:
+    """Block-local form of a submanifold 3^3 gather table `nbr` (csrc/blocks.hip): per block of 128 consecutive rows the ascending list
+    of distinct input rows (`hid` [n_blocks, hcap], `hcnt` [n_blocks]; -1 = does not fit) and the uint16 table `tab`
+    [n_blocks, 28, 16, 8] of positions in that list.  Consumed by spconv_fwd(..., blk=...) (csrc/conv7.h)."""
+
+    def __init__(self, nbr: torch.Tensor, bm: int = BLOCK_BM, hcap: int = BLOCK_HCAP):
         require_cuda(nbr)
-        if nbr.dtype != torch.int32 or nbr.dim() != 2:
-            raise PtcoreError("nbr must be int32 [kv, n]")
+        if nbr.dtype != torch.int32 or nbr.dim() != 2 or nbr.shape[0] != 27:
+            raise PtcoreError("nbr must be int32 [27, n]")
         self.nbr = nbr.contiguous()
         kv, n = self.nbr.shape
-        self.bm, self.hmax = int(bm), int(hmax)
+        self.bm, self.hcap = int(bm), int(hcap)
         nblk = max(1, (n + self.bm - 1) // self.bm)
         dev = nbr.device
-        self.lnbr = torch.empty((kv, n), dtype=torch.int16, device=dev)
-        self.halo = torch.empty((nblk, self.hmax), dtype=torch.int32, device=dev)
+        self.tab = torch.empty(int(lib().ptc_rulebook_blocks_tab_bytes(n)) // 2, dtype=torch.int16, device=dev).view(nblk, 28, 16, 8)
+        self.hid = torch.empty((nblk, self.hcap), dtype=torch.int32, device=dev)
         self.hcnt = torch.empty(nblk, dtype=torch.int32, device=dev)
         self.n_overflow = torch.empty(1, dtype=torch.int32, device=dev)
-        check(lib().ptc_rulebook_blocks(ptr(self.nbr), kv, n, self.bm, self.hmax, ptr(self.lnbr), ptr(self.halo), ptr(self.hcnt),
+        check(lib().ptc_rulebook_blocks(ptr(self.nbr), kv, n, self.bm, self.hcap, ptr(self.tab), ptr(self.hid), ptr(self.hcnt),
                                         ptr(self.n_overflow), stream_ptr()), "ptc_rulebook_blocks")
 
 
-def block_plan(c_in: int, c_out: int, kv: int, dtype: torch.dtype):
-    """(bm, hmax) of the LDS-staged convolution for this shape, or None when the shape stays on the global-gather
-    kernels (csrc/conv4.h conv4_supported: 16-bit, kv >= 2, c_in in {32,64,96,128}, c_out % 32 == 0).  256-row blocks
-    while the halo image fits beside the W buffers (c_in <= 64), 128-row blocks above."""
-    if dtype == torch.float32 or kv < 2 or c_in % 32 != 0 or c_out % 32 != 0 or c_in > 128:
+def block_plan(c_in: int, c_out: int, kv: int, dtype: torch.dtype, n_rows: int = 1 << 30):
+    """(bm, hcap) of the LDS-staged, register-weight convolution for this shape, or None when the shape stays on the global-gather
+    kernels (csrc/conv7.h conv7_supported: 16-bit, 3^3 table, c_in = c_out in {32, 64}, >= 4096 rows)."""
+    if dtype == torch.float32 or kv != 27 or c_in != c_out or c_in not in (32, 64) or n_rows < 4096:
         return None
-    return (256, 512) if c_in <= 64 else (128, 320)
-
-
-def block_conv_enabled(c_in: int) -> bool:
-    """Measured on MI355X (profiles/r02_b_conv_stages_ops.txt): the LDS-staged kernel wins 1.6x at 32 input channels
-    (58 KB of LDS: two workgroups per CU overlap each other's halo prologue) and LOSES at 64..128 (106..140 KB: one
-    workgroup per CU, every latency of the prologue and of the W chunk pipeline exposed).  PTC_CONV4=all|32|0 selects;
-    default 0 until the table build (130 us per rulebook) is cheaper than what the 32-channel layers save."""
-    import os
-
-    mode = os.environ.get("PTC_CONV4", "0")
-    return mode == "all" or (mode == "32" and c_in == 32)
+    return (BLOCK_BM, BLOCK_HCAP)
 
 
 class BlockProvider:
-    """lazily built BlockTables of ONE gather table, per (bm, hmax); lives next to the table in the rulebook cache."""
+    """lazily built BlockTables of ONE gather table; lives next to the table in the rulebook cache."""
 
     def __init__(self, nbr: torch.Tensor):
         self.nbr = nbr
         self.tables = {}
 
     def get(self, c_in: int, c_out: int, dtype: torch.dtype):
-        plan = block_plan(c_in, c_out, self.nbr.shape[0], dtype)
-        if plan is None or not self.nbr.is_cuda or not block_conv_enabled(c_in):
+        plan = block_plan(c_in, c_out, self.nbr.shape[0], dtype, self.nbr.shape[1])
+        if plan is None or not self.nbr.is_cuda:
             return None
         t = self.tables.get(plan)
         if t is None:
@@ -436,7 +427,7 @@ def spconv_fwd(feat: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     """out[o] = bias + sum_k W[:,k,:] . feat[nbr[k][o]].  weight [C_out, kv, C_in] in feat.dtype,
     bias fp32.  C_in % 8 == 0 and C_out % 16 == 0 (callers pad).  nbr=None (kv == 1): identity
     table, i.e. the dense row-wise GEMM out = feat @ W[:,0,:]^T + bias.  blk = BlockTables of `nbr`: the
-    LDS-staged kernel (bit-identical result)."""
+    LDS-staged kernel (same result up to the fp32 rounding of its summation order)."""
     require_cuda(feat, weight, bias, nbr)
     feat = feat.contiguous()
     weight = weight.contiguous()
@@ -458,8 +449,8 @@ def spconv_fwd(feat: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     if blk is not None and nbr is not None:
         if blk.nbr.data_ptr() != nbr.data_ptr() or tuple(blk.nbr.shape) != tuple(nbr.shape):
             raise PtcoreError("blk was built from another gather table")
-        check(lib().ptc_spconv_fwd_blk(ptr(feat), feat.shape[0], ptr(weight), ptr(bias), ptr(nbr), ptr(blk.lnbr), ptr(blk.halo),
-                                       ptr(blk.hcnt), blk.bm, blk.hmax, n_out, kv, c_in, c_out, dtype_code(feat), ptr(out),
+        check(lib().ptc_spconv_fwd_blk(ptr(feat), feat.shape[0], ptr(weight), ptr(bias), ptr(nbr), ptr(blk.tab), ptr(blk.hid),
+                                       ptr(blk.hcnt), blk.bm, blk.hcap, n_out, kv, c_in, c_out, dtype_code(feat), ptr(out),
                                        stream_ptr()), "ptc_spconv_fwd_blk")
         return out
     check(lib().ptc_spconv_fwd(ptr(feat), feat.shape[0], ptr(weight), ptr(bias), ptr(nbr), n_out, kv, c_in, c_out,

@@ -377,12 +377,6 @@ class Block(PointModule):
                 if isinstance(m, PNN.LayerNorm):
                     m.gemm_consumer = True
 
-    def _fold_cpe(self) -> bool:
-        """config.FOLD_CPE: conv + Linear of the positional encoding as one convolution (spconv_api.SubMConv3d.folded).  Where the
-        weight product is small against the row count: <= 128 channels; plain Linear and a tensor-level norm only."""
-        return (config.FOLD_CPE and self.channels <= 128 and type(self.cpe[1]) is PNN.Linear and not isinstance(self.cpe[2], PointModule)
-                and self.cpe[0].kernel_size[0] > 1)
-
     def _build_attn(self, **kw):
         """the attention module of this block family (PT-v3m3 builds its RoPE variant here)"""
         return SerializedAttention(**kw)
@@ -398,9 +392,6 @@ class Block(PointModule):
         if p == 0.0 or not self.training:
             return None
         keep = 1.0 - p
-        if PF._LEGACY_LAUNCHES:
-            mask = torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep)
-            return mask.div_(keep) if keep > 0.0 and getattr(dp, "scale_by_keep", True) else mask
         if not (keep > 0.0 and getattr(dp, "scale_by_keep", True)):
             return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep)
         ones = Block._ones.get(device)
@@ -424,10 +415,7 @@ class Block(PointModule):
         n, dev = point.feat.shape[0], point.feat.device
         sc = point.sparse_conv_feat
         x0 = point.feat                                           # residual stream (fp32 after the first joint)
-        if self._fold_cpe():
-            lin = self.cpe[0](sc, post_linear=self.cpe[1]).features   # conv and Linear as ONE convolution (spconv_api.SubMConv3d.folded)
-        else:
-            lin = self.cpe[1](self.cpe[0](sc).features)              # CPE conv (stale input in dec block 0: D.1) + Linear
+        lin = self.cpe[1](self.cpe[0](sc).features)                  # CPE conv (stale input in dec block 0: D.1) + Linear
         if lin.dtype != gemm_dt:
             lin = lin.to(gemm_dt)
         x1, y1 = PF.add_norm(lin, x0, None, self.cpe[2], self.norm1[0], gemm_dt)        # x + LN(cpe); norm1
@@ -451,12 +439,7 @@ class Block(PointModule):
             if out is not None:
                 return out
         shortcut = point.feat
-        if self._fold_cpe():
-            sc = self.cpe[0](point.sparse_conv_feat, post_linear=self.cpe[1])      # conv + Linear as one convolution
-            point.feat = self.cpe[2](sc.features)
-            point.sparse_conv_feat = sc.replace_feature(point.feat)
-        else:
-            point = self.cpe(point)  # consumes point.sparse_conv_feat.features (stale after unpooling: Appendix D.1)
+        point = self.cpe(point)  # consumes point.sparse_conv_feat.features (stale after unpooling: Appendix D.1)
         point.feat = shortcut + point.feat
         shortcut = point.feat
         if self.pre_norm:

@@ -10,8 +10,7 @@ embedding of q and k from the CONTINUOUS point coordinates inside every attentio
     flash-attn reads stack([q, k, v]).to(bf16)
 
 Engine mapping: the qkv GEMM already writes the padded, serialized rows (gather table folded in, as m1); the rotation runs on that
-packed [n, 3, H, D] buffer and emits the bf16 operand of the window-attention kernels (`PF.rope_xyz_qkvpacked`: ptc_rope3d_xyz, or
-the same arithmetic in torch ops while the kernel is switched off -- see config.ROPE_XYZ_KERNEL); head_dim % 6 == 0 is what the
+packed [n, 3, H, D] buffer and emits the bf16 operand of the window-attention kernels (`PF.rope_xyz_qkvpacked`: ptc_rope3d_xyz); head_dim % 6 == 0 is what the
 rotation needs (18 in the reference's Utonia configs -> the slab kernels of csrc/attention_hd.h).  The augmentation draws use the same
 torch calls in the same order as the reference, so a seeded run consumes the device RNG identically.
 `dec_rope_enable=False` builds decoder blocks with rope_base=None (:862-887): plain m2 attention.

@@ -213,27 +213,8 @@ def _coord_bits(spatial_shape) -> int:
 class SubMConv3d(_SparseConvolution):
     _kind = "subm"
 
-    def folded(self, linear: nn.Linear):
-        """(weight [C_out', taps, C_in], bias) of THIS convolution followed by `linear`, as one convolution:
-        Linear(conv(x)) = sum_k x_k (W_lin W_k)^T + (W_lin b_conv + b_lin).  fp32, outside autocast (one rounding of the product
-        when the kernel casts it); differentiable, so the chain rule back to both layers' parameters is autograd's."""
-        with torch.autocast("cuda", enabled=False):
-            wl = linear.weight.float()
-            w = torch.einsum("om,mkc->okc", wl, self._w().float())
-            b = None
-            if self.bias is not None or linear.bias is not None:
-                b = wl.new_zeros(wl.shape[0])
-                if self.bias is not None:
-                    b = b + wl @ self.bias.float()
-                if linear.bias is not None:
-                    b = b + linear.bias.float()
-        return w, b
-
-    def forward(self, x: SparseConvTensor, post_linear=None):
-        """post_linear: an nn.Linear applied to the output, folded into the weights (see `folded`; 3^3 / 5^3 kernels only)"""
+    def forward(self, x: SparseConvTensor):
         k = self.kernel_size[0]
-        if post_linear is not None and k == 1:
-            raise PtcoreError("post_linear is for k > 1 submanifold convolutions")
         if k == 1:  # spconv short-circuits 1x1x1 submanifold convs to a GEMM
             w2 = self.weight.reshape(self.out_channels, self.in_channels)
             f = x.features
@@ -242,7 +223,7 @@ class SubMConv3d(_SparseConvolution):
                 return x.replace_feature(f.new_zeros((0, self.out_channels)))
             return x.replace_feature(PF.linear(f, w2, self.bias))   # the engine's tall-skinny GEMM kernels
         if x.indices.shape[0] == 0:
-            return x.replace_feature(x.features.new_zeros((0, self.out_channels if post_linear is None else post_linear.out_features)))
+            return x.replace_feature(x.features.new_zeros((0, self.out_channels)))
         key = ("subm", self.indice_key, k)
         rb = x.indice_dict.get(key) if self.indice_key is not None else None
         if rb is None:
@@ -256,8 +237,7 @@ class SubMConv3d(_SparseConvolution):
             blocks = x.indice_dict.get(bkey)
             if blocks is None or blocks.nbr is not rb:
                 blocks = x.indice_dict[bkey] = ops.BlockProvider(rb)
-        w, b = (self._w(), self.bias) if post_linear is None else self.folded(post_linear)
-        return x.replace_feature(PF.sparse_conv(x.features, w, b, rb, rb, True, rep, rep, blocks))
+        return x.replace_feature(PF.sparse_conv(x.features, self._w(), self.bias, rb, rb, True, rep, rep, blocks))
 
 
 def _down_rulebook(x: SparseConvTensor, indice_key):

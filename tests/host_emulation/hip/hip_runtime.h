@@ -293,6 +293,12 @@ static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned lo
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu::block_sync()
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)           /* one lane runs at a time: every memory operation has completed */
+#define __builtin_amdgcn_readfirstlane(x) (x)              /* callers pass wave-uniform values */
+// global_load_lds: `sz` bytes per lane, global -> LDS at (wave-uniform base) + sz * lane.  Lands at once here; on the hardware it
+// lands asynchronously (vmcnt) -- the emulation cannot see a missing wait.
+static inline void emu_global_load_lds(const void* g, void* l, int sz) { memcpy((char*)l + emu::lane_id() * sz, g, (size_t)sz); }
+#define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (int)(sz))
 
 // v_perm_b32: byte select from {a (bytes 7..4), b (bytes 3..0)}
 static inline uint32_t emu_perm(uint32_t a, uint32_t b, uint32_t sel) {

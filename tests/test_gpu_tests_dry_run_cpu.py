@@ -51,30 +51,9 @@ def test_gpu_fullsize_test_bodies_on_cpu_standins(name, monkeypatch):
         getattr(T, name)(torch.device("cpu"))
 
 
-@pytest.mark.parametrize("name,kw", [("test_ptv3m3_matches_reference_golden", dict(rope_kernel=False)),
-                                     ("test_ptv3m3_matches_reference_golden", dict(rope_kernel=True)),
-                                     ("test_litept_matches_reference_golden", None)])
-def test_gpu_pending_hardware_test_bodies_on_cpu_standins(name, kw, monkeypatch):
-    """tests/test_gpu_pending_hardware.py (never run on an MI355X yet): bodies on the CPU stand-ins"""
-    import test_gpu_pending_hardware as T
+@pytest.mark.parametrize("name", ["test_ptv3m3_matches_reference_golden", "test_litept_matches_reference_golden"])
+def test_gpu_m3_litept_test_bodies_on_cpu_standins(name):
+    import test_gpu_m3_litept as T
 
-    with mock_backend.cpu_ops():
-        if kw is None:
-            getattr(T, name)(torch.device("cpu"))
-        else:
-            getattr(T, name)(torch.device("cpu"), monkeypatch=monkeypatch, **kw)
-
-
-@pytest.mark.parametrize("mod,name", [("test_gpu_model", "test_ptv3_mix3d_duplicate_voxels"),
-                                      ("test_gpu_spunet", "test_spunet_base_channels_single_scene_and_duplicates")])
-def test_duplicate_voxel_tests_with_the_segmented_merge(mod, name, monkeypatch):
-    """the Mix3D / duplicate-coordinate model tests with functional._MERGE_DUP_SEGMENTED on (the one-launch merge, off by default)"""
-    import importlib
-
-    from pointcept_amd import functional as PF
-
-    monkeypatch.setattr(PF, "_MERGE_DUP_SEGMENTED", True)
-    T = importlib.import_module(mod)
     with mock_backend.cpu_ops():
         getattr(T, name)(torch.device("cpu"))
-

@@ -120,8 +120,7 @@ def test_rope3d_xyz_on_the_host_emulation(emu):
 
 
 def test_rope3d_xyz_host_emulation_agrees_with_the_engine_formulation(emu):
-    """the kernel (emulated) against functional.rope_xyz_torch -- the formulation PT-v3m3 / LitePT run while the kernel is switched
-    off -- on a random bf16 batch: bit-identical bf16 outputs, i.e. flipping config.ROPE_XYZ_KERNEL changes no number."""
+    """the kernel (emulated) against functional.rope_xyz_torch -- the same arithmetic in torch ops -- on a random bf16 batch: bit-identical bf16 outputs."""
     from pointcept_amd import functional as PF
 
     gen = torch.Generator().manual_seed(12)
@@ -216,8 +215,7 @@ def test_gpu_kernel_test_bodies_on_the_host_emulation(name, kw):
 
 
 def test_segmented_duplicate_merge_on_the_emulated_segment_kernel(monkeypatch):
-    """functional._merge_duplicate_rows with PTC_MERGE_DUP_SEGMENTED (off by default, never run on hardware): the one-launch form on
-    the REAL ptc_segment_csr_fwd kernel (emulated) equals the per-multiplicity loop, fp32 and bf16 gradients."""
+    """functional._merge_duplicate_rows on the REAL ptc_segment_csr_fwd kernel (emulated) equals a per-row loop, fp32 and bf16 gradients."""
     import emu_backend
     from pointcept_amd import functional as PF
 
@@ -235,25 +233,27 @@ def test_segmented_duplicate_merge_on_the_emulated_segment_kernel(monkeypatch):
     for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2.0 ** -7)):
         grad = torch.randn(n, 48, generator=g).to(dt)
         with emu_backend.emulated_ops():
-            monkeypatch.setattr(PF, "_MERGE_DUP_SEGMENTED", False)
-            want = PF._merge_duplicate_rows(grad, rep)
-            monkeypatch.setattr(PF, "_MERGE_DUP_SEGMENTED", True)
             got = PF._merge_duplicate_rows(grad, rep)
+        want = grad.float().clone()
+        for r in range(n):
+            if int(rep[r]) != r:
+                want[int(rep[r])] += grad[r].float()
+        want = torch.where((torch.bincount(rep, minlength=n) == 0)[:, None], grad.float(), want).to(dt)
         assert got.dtype == want.dtype and float((got.float() - want.float()).abs().max()) <= tol * float(want.float().abs().max()), dt
 
 
 def test_ptv3m3_model_with_its_real_attention_and_rope_kernels_on_the_emulation(monkeypatch):
-    """tests/test_gpu_pending_hardware.py::test_ptv3m3_matches_reference_golden (rope_kernel=True), body unchanged, on a hybrid
+    """tests/test_gpu_m3_litept.py::test_ptv3m3_matches_reference_golden, body unchanged, on a hybrid
     backend: the model's window attention (head_dim 18: csrc/attention_hd.h, forward AND backward) and its Point3DRoPE pass
     (ptc_rope3d_xyz) run their REAL kernels on the host emulation, every other op on its oracle stand-in -- against the golden of the
     reference's own point_transformer_v3m3_utonia.py: eval features, train loss, every gradient norm."""
     import emu_backend
-    import test_gpu_pending_hardware as P
+    import test_gpu_m3_litept as P
 
     if not emu_backend.available():
         pytest.skip("no host clang++ under /opt/rocm")
     with emu_backend.hybrid(["attn_varlen_fwd", "attn_varlen_bwd", "attn_hd_supported", "rope3d_xyz"]):
-        P.test_ptv3m3_matches_reference_golden(torch.device("cpu"), True, monkeypatch)
+        P.test_ptv3m3_matches_reference_golden(torch.device("cpu"))
 
 
 INDEX_AND_ATTENTION_OPS = ["coord_max", "serialize_encode", "sort_keys", "patch_pad_maps", "attn_tables", "pool_level_counts", "pool_maps",
@@ -263,7 +263,7 @@ INDEX_AND_ATTENTION_OPS = ["coord_max", "serialize_encode", "sort_keys", "patch_
 
 @pytest.mark.parametrize("mod,name", [("test_gpu_model", "test_ptv3_tiny_forward_matches_reference_golden_and_oracle"),
                                       ("test_gpu_model", "test_ptv3_two_scenes_forward_backward_vs_oracle"),
-                                      ("test_gpu_pending_hardware", "test_litept_matches_reference_golden"),
+                                      ("test_gpu_m3_litept", "test_litept_matches_reference_golden"),
                                       ("test_gpu_spunet", "test_spunet_tiny_matches_reference_golden_and_oracle"),
                                       ("test_gpu_spunet", "test_spunet_base_channels_single_scene_and_duplicates")])
 def test_models_with_their_real_index_pipeline_and_attention_on_the_emulation(mod, name):
@@ -302,7 +302,7 @@ def test_whole_ptv3_step_with_every_kernel_on_the_emulation():
 
 
 def test_cast_many_kernel_on_the_emulation_and_in_the_cast_cache(monkeypatch):
-    """ptc_cast_many (one launch for the per-step fp32 -> 16-bit refresh of all weight shadows; PTC_CAST_MANY, off by default): on the
+    """ptc_cast_many (one launch for the per-step fp32 -> 16-bit refresh of all weight shadows; the default refresh of functional._CastCache): on the
     emulation, for bf16 and f16, tensors whose sizes are not multiples of the 8-element unit and whose storage is not 16-byte
     aligned -- bit-identical to Tensor.to(); and through functional._CastCache (second step reuses the descriptor table, an
     in-place update of one weight refreshes it)."""
@@ -326,7 +326,6 @@ def test_cast_many_kernel_on_the_emulation_and_in_the_cast_cache(monkeypatch):
         for s_, d_ in zip(srcs, dsts):
             assert torch.equal(d_, s_.to(dt)), (dt, s_.numel())
     # through the cache
-    monkeypatch.setattr(PF, "_CAST_MANY", True)
     cache = PF._CastCache(cuda_only=False)
     monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))      # the cache only takes the kernel route for CUDA tensors
     ws = [torch.nn.Parameter(torch.randn(24, 16, generator=g)), torch.nn.Parameter(torch.randn(5, 27, 8, generator=g))]
@@ -340,10 +339,10 @@ def test_cast_many_kernel_on_the_emulation_and_in_the_cast_cache(monkeypatch):
 
 
 def test_pending_rope_kernel_gpu_test_body_on_the_emulation():
-    """tests/test_gpu_pending_hardware.py::test_rope3d_xyz_kernel_matches_reference_golden_and_inverts, body unchanged (golden cases,
+    """tests/test_gpu_m3_litept.py::test_rope3d_xyz_kernel_matches_reference_golden_and_inverts, body unchanged (golden cases,
     dtype pairs, the in-place library call, the 819200-row round trip), on the emulated kernel."""
     import emu_backend
-    import test_gpu_pending_hardware as P
+    import test_gpu_m3_litept as P
 
     if not emu_backend.available():
         pytest.skip("no host clang++ under /opt/rocm")
@@ -352,62 +351,3 @@ def test_pending_rope_kernel_gpu_test_body_on_the_emulation():
 
 
 
-@pytest.mark.parametrize("cin,cout,n_pts,dup", [(64, 64, 1200, False), (64, 96, 900, True), (64, 32, 900, True),
-                                                (32, 32, 1200, True), (32, 64, 900, False)])
-def test_pending_conv6_compacted_gathers_gpu_test_body_on_the_emulation(cin, cout, n_pts, dup, monkeypatch, capfd):
-    """tests/test_gpu_pending_hardware.py::test_spconv_fwd_compacted_gathers_are_bit_identical, body unchanged, on the emulated
-    conv5 / conv6 kernels (PTC_CONV6, off by default, never run on hardware; c_in 64 and 32): bit-identical outputs, same MFMA count, fewer
-    wave-level gather instructions (the emulator's work counters)."""
-    import re
-
-    import emu_backend
-    import test_gpu_pending_hardware as P
-
-    if not emu_backend.available():
-        pytest.skip("no host clang++ under /opt/rocm")
-    monkeypatch.setenv("PTC_EMU_STATS", "1")
-    with emu_backend.emulated_ops():
-        P.test_spconv_fwd_compacted_gathers_are_bit_identical(torch.device("cpu"), cin, cout, n_pts, dup, monkeypatch)
-    err = capfd.readouterr().err
-    rows = re.findall(r"\[emu\].*?LDS (\d+) B.*?MFMA (\d+)\s+ds_read_tr (\d+)\s+buffer loads (\d+)", err)
-    rows = [r for r in rows if int(r[1]) > 0]                        # the convolution launches (rulebook kernels have no MFMA)
-    assert len(rows) == 4, err[-2000:]                               # per dtype: conv5 then conv6 -- the variant under test DID run
-    for a, b in zip(rows[0::2], rows[1::2]):
-        assert int(b[0]) > int(a[0]), (a, b)                         # conv6's LDS footprint (list + two image sets), not conv5 twice
-        assert a[1] == b[1], (a, b)                                  # same MFMA work
-        assert int(b[3]) < 0.85 * int(a[3]), (a, b)                  # fewer wave-level gather instructions
-
-
-def test_pending_conv6_other_tables_gpu_test_body_on_the_emulation(monkeypatch):
-    """tests/test_gpu_pending_hardware.py::test_spconv_fwd_compacted_gathers_other_tables, body unchanged, on the emulated kernels"""
-    import emu_backend
-    import test_gpu_pending_hardware as P
-
-    if not emu_backend.available():
-        pytest.skip("no host clang++ under /opt/rocm")
-    with emu_backend.emulated_ops():
-        P.test_spconv_fwd_compacted_gathers_other_tables(torch.device("cpu"), monkeypatch)
-
-
-def test_pending_wgrad3_compacted_gathers_gpu_test_body_on_the_emulation(monkeypatch, capfd):
-    """tests/test_gpu_pending_hardware.py::test_spconv_wgrad_compacted_gathers_are_bit_identical, body unchanged, on the emulated
-    wgrad2 / wgrad3 kernels (PTC_WGRAD3, off by default, never run on hardware); the work counters prove the variant ran: same MFMA
-    and transposing-read counts, fewer wave-level gather instructions."""
-    import re
-
-    import emu_backend
-    import test_gpu_pending_hardware as P
-
-    if not emu_backend.available():
-        pytest.skip("no host clang++ under /opt/rocm")
-    monkeypatch.setenv("PTC_EMU_STATS", "1")
-    with emu_backend.emulated_ops():
-        P.test_spconv_wgrad_compacted_gathers_are_bit_identical(torch.device("cpu"), monkeypatch)
-    err = capfd.readouterr().err
-    rows = re.findall(r"\[emu\].*?LDS (\d+) B.*?MFMA (\d+)\s+ds_read_tr (\d+)\s+buffer loads (\d+)", err)
-    rows = [r for r in rows if int(r[2]) > 0]                       # the weight-gradient launches (transposing reads)
-    assert len(rows) == 80, len(rows)                                # 4 tables x 2 dtypes x 5 shapes x (wgrad2, wgrad3)
-    for a, b in zip(rows[0::2], rows[1::2]):
-        assert int(b[0]) in (int(a[0]) + 4 * 512, int(a[0]) + 4 * 1024), (a, b)   # wgrad3's LDS footprint: + the pair list of each wave
-        assert a[1] == b[1] and a[2] == b[2], (a, b)                # same MFMA and fragment-read work
-        assert int(b[3]) < int(a[3]), (a, b)                        # fewer wave-level buffer loads

@@ -101,37 +101,11 @@ def bench_attention(rows, n_seq, H, results, L=1024):
     by_f = T * H * 16 * 2 * 4
     r = {"shape": [n_seq, L, H]}
     r["fwd"] = roof(by_f, fl_f, timeit(lambda: ops.attn_varlen_fwd(qkv, cu, L, sc), iters=10))
-    # forward variants (PTC_ATTN_FWD bit mask: 1 = single-bf16 scaled query, 2 = s_setprio on the younger waves, 4 = truncating pack)
-    os.environ["PTC_ATTN_FWD"] = "0"
-    base_out = ops.attn_varlen_fwd(qkv, cu, L, sc)[0].float()
-    var = []
-    for m in range(8):
-        os.environ["PTC_ATTN_FWD"] = str(m)
-        t = timeit(lambda: ops.attn_varlen_fwd(qkv, cu, L, sc), iters=10)
-        o = ops.attn_varlen_fwd(qkv, cu, L, sc)[0].float()
-        var.append((m, t * 1e6, float((o - base_out).abs().max() / base_out.abs().max())))
-    os.environ.pop("PTC_ATTN_FWD", None)
-    r["fwd_variants"] = var
     r["bwd"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
                     timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
-    base_dq = ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc)
-    pv = []
-    for m in (0, 3):   # PTC_ATTN_BWD_PIPE: loop forms of the dQ / dK+dV kernels (bit-identical results)
-        os.environ["PTC_ATTN_BWD_PIPE"] = str(m)
-        t = timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10)
-        same = bool(torch.equal(ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), base_dq))
-        pv.append((m, t * 1e6, same))
-    os.environ.pop("PTC_ATTN_BWD_PIPE", None)
-    r["bwd_pipe_variants"] = pv
-    os.environ["PTC_ATTN_BWD"] = "1"
-    r["bwd2"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
-                     timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
-    os.environ.pop("PTC_ATTN_BWD", None)
     results.append(r)
     rows.append(f"attention n_seq={n_seq:4d} L={L} H={H:2d} | fwd {r['fwd']['us']:8.1f} us {r['fwd']['TFLOPs']:7.1f} TF/s | "
-                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s | bwd single-pass (experiment) {r['bwd2']['us']:8.1f} us (10 L^2 D)")
-    rows.append("    bwd loop forms (PTC_ATTN_BWD_PIPE: us, bit-identical to the default): " + "  ".join(f"{m}: {t:.1f} us {ok}" for m, t, ok in pv))
-    rows.append("    fwd variants (mask: us, max|diff|/max|out| vs mask 0): " + "  ".join(f"{m}: {t:.1f} us {d:.1e}" for m, t, d in r["fwd_variants"]))
+                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s")
 
 
 def bench_spconv(rows, results, scenes=8, points=102400):
@@ -212,36 +186,23 @@ def bench_spconv_stages(rows, results, scenes=8, points=102400):
             by = n * (ci + c) * 2 + 4 * 27 * n + 27 * ci * c * 2
             fl = 2.0 * pairs * ci * c
             r = {"stage": s, "n": n, "c_in": ci, "c": c, "pairs": pairs}
-            os.environ["PTC_CONV3_C32"] = "1"
-            for name, flag, bnc, c5 in (("conv2", "0", "0", "0"), ("conv3d", "1", "0", "0"), ("conv3", "1", "1", "0"), ("conv5", "1", "0", "1"),
-                                        ("conv5rt2", "1", "0", "1")):
-                os.environ["PTC_CONV3"] = flag
-                os.environ["PTC_CONV3_BNC"] = bnc
-                os.environ["PTC_CONV5"] = c5
-                if name == "conv5rt2":
-                    os.environ["PTC_CONV3_RT"] = "2"
-                try:
-                    r[name] = roof(by, fl, timeit(lambda: ops.spconv_fwd(x, w, bias, nbr), iters=10))
-                except Exception as e:   # an unsupported instantiation must not cost the rest of the table
-                    r[name] = {"us": float("nan"), "GBps": 0.0, "TFLOPs": 0.0, "roof_frac": 0.0, "error": repr(e)}
-            for e in ("PTC_CONV3", "PTC_CONV3_BNC", "PTC_CONV3_C32", "PTC_CONV5", "PTC_CONV3_RT"):
-                os.environ.pop(e, None)
+            r["conv"] = roof(by, fl, timeit(lambda: ops.spconv_fwd(x, w, bias, nbr), iters=10))   # conv5 (c_in 32 / 64) | conv3
             plan = ops.block_plan(ci, c, 27, torch.bfloat16)
             c4 = ""
             if plan is not None:
                 t_b = timeit(lambda: ops.BlockTables(nbr, *plan), iters=5)
                 blk = ops.BlockTables(nbr, *plan)
-                r["conv4"] = roof(by, fl, timeit(lambda: ops.spconv_fwd(x, w, bias, nbr, blk), iters=10))
+                r["conv7"] = roof(by, fl, timeit(lambda: ops.spconv_fwd(x, w, bias, nbr, blk), iters=10))
                 r["blocks_us"] = round(t_b * 1e6, 1)
                 r["blocks_overflow"] = int(blk.n_overflow.item())
                 r["halo_mean"] = round(float(blk.hcnt.float().mean()), 1)
-                c4 = (f" | conv4 {r['conv4']['us']:8.1f} us ({r['conv4']['GBps']:.0f} GB/s alg, {r['conv4']['TFLOPs']:.1f} TF/s; tables {r['blocks_us']:.1f} us, "
+                c4 = (f" | block-staged {r['conv7']['us']:8.1f} us ({r['conv7']['GBps']:.0f} GB/s alg, {r['conv7']['TFLOPs']:.1f} TF/s; tables {r['blocks_us']:.1f} us, "
                       f"halo {r['halo_mean']:.0f}/{plan[0]}, {r['blocks_overflow']} overflow)")
             g = torch.randn(n, c, device=DEV).to(torch.bfloat16)
             r["wgrad"] = roof(by, fl, timeit(lambda: ops.spconv_wgrad(x, g, nbr), iters=10))
             results.append(r)
-            rows.append(f"conv stage {s} n={n:7d} {ci:3d}->{c:3d} pairs/pt={pairs / n:5.2f} | conv2 {r['conv2']['us']:8.1f} us | conv3 direct {r['conv3d']['us']:8.1f} us | conv3 bounce {r['conv3']['us']:8.1f} us | conv5 {r['conv5']['us']:8.1f} us (RT=2: {r['conv5rt2']['us']:8.1f}) "
-                        f"({r['conv5']['GBps']:.0f} GB/s alg, {r['conv5']['TFLOPs']:.1f} TF/s){c4} | wgrad {r['wgrad']['us']:8.1f} us ({r['wgrad']['TFLOPs']:.1f} TF/s)")
+            rows.append(f"conv stage {s} n={n:7d} {ci:3d}->{c:3d} pairs/pt={pairs / n:5.2f} | global gathers {r['conv']['us']:8.1f} us "
+                        f"({r['conv']['GBps']:.0f} GB/s alg, {r['conv']['TFLOPs']:.1f} TF/s){c4} | wgrad {r['wgrad']['us']:8.1f} us ({r['wgrad']['TFLOPs']:.1f} TF/s)")
 
 
 def bench_losses(rows, results, n=819200, c=20):

@@ -4,11 +4,6 @@
 #   bench      bench.py (default switches)   ab:<ENV=V,...>  bench.py with switches (no cpu baseline)
 #   prof       rocprofv3 kernel stats of bench.py
 #   roof       rocprofv3 stats + PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) of the roofline kernel
-#   pending    tests/test_gpu_pending_hardware.py with PTC_RUN_PENDING=1 (code that has not run on hardware yet)
-#   conv6      tools/bench_ops.py --only stages,spconv with conv5 / wgrad2 (default), PTC_CONV6 = PTC_WGRAD3 = 1 (c_in 64) and = 2 (c_in 32 too); run `pending` first
-#              (conv6 is dispatched before conv5 whatever PTC_CONV5 / PTC_CONV3_* say: under PTC_CONV6 every column of a
-#              c_in-64 (=2: and c_in-32) row of `stages` is conv6 -- compare the conv5 and wgrad columns ACROSS the three logs)
-#   w2sweep    small weight gradients of the deep stages under the PTC_W2_TARGET_WGS / PTC_W2_MIN_STEPS plan knobs
 TAG=${1:-s}; shift
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
@@ -78,13 +73,6 @@ for sec in "$@"; do
             rm -rf $O/${tg}_stats $O/${tg}_fetch $O/${tg}_write $O/${tg}_tcp $O/${tg}_tcc $O/${tg}_sq $O/${tg}_sq2
             cd /tmp
           done; unset PTC_LK_SHAPE; ls $O | grep linear_pmc;;
-    conv6) for v in 0 1 2; do PTC_CONV6=$v PTC_WGRAD3=$v timeout 600 python tools/bench_ops.py --only stages,spconv > $O/${TAG}_conv6_${v}_ops.log 2>&1; echo "conv6=$v rc=$?" >> $O/${TAG}_env.log; grep -i "conv\|wgrad" $O/${TAG}_conv6_${v}_ops.log | cut -c1-200 | head -12; done;;
-    pending) PTC_RUN_PENDING=1 timeout 900 python -m pytest tests/test_gpu_pending_hardware.py -q -m gpu > $O/${TAG}_pending.log 2>&1; echo "pending rc=$?" >> $O/${TAG}_env.log; tail -15 $O/${TAG}_pending.log
-          timeout 300 python tools/bench_ops.py --only rope > $O/${TAG}_rope_ops.log 2>&1; cat $O/${TAG}_rope_ops.log | cut -c1-160;;
-    w2sweep) for wgs in 1024 768 512 384 256; do for ms in 16 8 32; do
-            echo "== PTC_W2_TARGET_WGS=$wgs PTC_W2_MIN_STEPS=$ms" >> $O/${TAG}_w2sweep.log
-            PTC_W2_TARGET_WGS=$wgs PTC_W2_MIN_STEPS=$ms timeout 300 python tools/bench_ops.py --only wgrad_small >> $O/${TAG}_w2sweep.log 2>&1
-          done; done; grep -v "^$" $O/${TAG}_w2sweep.log | cut -c1-200 | tail -80;;
     *) echo "unknown section $sec";;
   esac
 done
