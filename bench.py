@@ -193,21 +193,26 @@ def gather_roofline(device, batch):
     x = torch.randn(n, c, generator=g).to(torch.bfloat16).to(device)
     w = (torch.randn(c, kv, c, generator=g) * 0.05).to(torch.bfloat16).to(device)
     bias = torch.zeros(c, device=device)
-    ms = _time_launches(lambda: ops.spconv_fwd(x, w, bias, nbr))
-    nbytes = n * c * 2 * 2 + 4 * kv * n + kv * c * c * 2
+    blk = ops.BlockTables(nbr)       # the block-local tables the model builds once per rulebook (conv7: weights in registers, halo rows by DMA)
+    ms = _time_launches(lambda: ops.spconv_fwd(x, w, bias, nbr, blk))
+    ms_global = _time_launches(lambda: ops.spconv_fwd(x, w, bias, nbr), iters=10, warm=5)   # conv5, the round-2 kernel, for the record
+    # bytes = N C e (in) + N C e (out) + table + kv C C e (weights); the table this kernel READS is the block-local
+    # uint16 one (28 * 2 B per row) + the halo lists; the pair-list form of 8(d) (8 B per pair) is reported beside it
+    nbytes = n * c * 2 * 2 + blk.tab.numel() * 2 + int(blk.hcnt.sum().item()) * 4 + kv * c * c * 2
+    nbytes_pairs = n * c * 2 * 2 + 8 * pairs + kv * c * c * 2
     flops = 2.0 * pairs * c * c
     achieved = nbytes / (ms * 1e-3) / 1e9
-    out = {"kernel": "conv5_kernel (SubM k=3, 64->64, stage 0; conv3_kernel before r02_c)", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+    out = {"kernel": "conv7_kernel (SubM k=3, 64->64, stage 0; conv5_kernel in round 2)", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "launch_ms": round(ms, 4),
-           "shape": {"n": n, "c_in": c, "c_out": c, "kv": kv, "pairs": pairs},
+           "shape": {"n": n, "c_in": c, "c_out": c, "kv": kv, "pairs": pairs, "halo_rows_per_128_row_block": round(float(blk.hcnt.float().mean()), 1)},
            "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
+           "frac_by_pair_list_formula": round(nbytes_pairs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+           "global_gather_kernel_launch_ms": round(ms_global, 4),
            "useful_tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
     try:
         pm = _latest_profile("*conv_pmc_s0.json")
         ks = json.load(open(pm))["kernels"]
-        cands = [v for kn, v in ks.items() if kn.startswith("conv5_kernel<bf16_t, 2, 2, 4>") and "hbm_bytes" in v]
-        if not cands:    # PMC files from before conv5: the conv3 instance of the same shape (same operands, same order)
-            cands = [v for kn, v in ks.items() if kn.startswith("conv3_kernel<bf16_t, 4, 2, 4, false>") and "hbm_bytes" in v]
+        cands = [v for kn, v in ks.items() if kn.startswith("conv7_kernel<bf16_t, 64>") and "hbm_bytes" in v]
         k = cands[0]
         out["traffic"] = round(k["hbm_bytes"])
         out["traffic_source"] = os.path.relpath(pm, ROOT)

@@ -238,10 +238,14 @@ int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float
  *       hid  [n_blocks][hcap] int32 = the distinct input rows named by nbr[:, block], ascending, padded with the last one to
  *                                     a multiple of 16 entries
  *       hcnt [n_blocks]       int32 = how many (-1 = more than hcap: block served through the global table)
- *       tab  [n_blocks][28][16][8] uint16 (ptc_rulebook_blocks_tab_bytes(n) bytes, 16-byte aligned) = position of
- *                                     nbr[k][128 b + 16 t + r] in its block's list at [b][k][r][t], 0xFFFF = none; row k = 27 padding
+ *       tab  [2][n_blocks][28][16][8] uint16 (ptc_rulebook_blocks_tab_bytes(n) bytes, 16-byte aligned): at [v][b][k][r][t]
+ *                                     the byte offset, inside the convolution kernel's LDS image of the block's rows, of the
+ *                                     first 16 bytes of row nbr[k][128 b + 16 t + r] -- v = 0: 128-byte rows (64 channels),
+ *                                     slot * 128 + ((slot >> 1) & 7) * 16; v = 1: 64-byte rows (32 channels), slot * 64 +
+ *                                     ((slot >> 2) & 3) * 16, slot = position in the block's list; none = hcap * row bytes;
+ *                                     row k = 27 padding
  *       *n_overflow (device int32)  = number of blocks with hcnt = -1 (diagnostic; nothing depends on it)
- *     hcap a multiple of 16, <= 512.
+ *     hcap a multiple of 16, < 512.
  *   ptc_spconv_fwd_blk: same result as ptc_spconv_fwd(in, ..., nbr, ...) up to the fp32 rounding of a different summation
  *       order, with the input rows of a block staged once in LDS and the weights held in registers.  16-bit dtypes,
  *       kv = 27, c_in = c_out in {32, 64}, bm = 128, hcap = 416, n_in = n_out >= 4096; any other shape is forwarded to

@@ -9,10 +9,14 @@
 //                                              rows then read neighbouring LDS slots), padded with the last one to a multiple of 16
 //   hcnt [n_blocks]                    int32 : how many; -1 = "does not fit" (rows in no spatial order): the kernel serves such a
 //                                              block through the global table
-//   tab  [n_blocks][28][16][8]         u16   : slot of nbr[k][128 b + 16 t + r] in the block's list at [b][k][r][t], 0xFFFF = no
-//                                              neighbour (table row 27 is padding: the table is a whole number of 1-KB DMA pieces)
+//   tab  [2][n_blocks][28][16][8]      u16   : at [v][b][k][r][t] the LDS BYTE OFFSET, inside the kernel's image of the block's
+//                                              rows, of piece 0 of row nbr[k][128 b + 16 t + r]: v = 0 for 128-byte rows (64
+//                                              channels): slot * 128 + ((slot >> 1) & 7) * 16, v = 1 for 64-byte rows (32
+//                                              channels): slot * 64 + ((slot >> 2) & 3) * 16 -- the kernel XORs the piece it
+//                                              wants into bits 4.. and adds the image base; "no neighbour" = hcap * row bytes
+//                                              (an all-zero row).  Table row 27 is padding: a whole number of 1-KB DMA pieces
 // One workgroup per block: LDS hash set -> compaction -> bitonic sort -> binary search per entry.  Integer work, bit-exact by
-// construction: hid[b][tab[b][k][r][t]] == nbr[k][128 b + 16 t + r] wherever nbr >= 0 (tests/test_gpu_kernels.py).
+// construction: hid[b][tab[0][b][k][r][t] >> 7] == nbr[k][128 b + 16 t + r] wherever nbr >= 0 (tests/test_gpu_kernels.py).
 #include "ptc_common.h"
 
 #define BLK_BM 128
@@ -23,11 +27,11 @@
 #define BLK_TAB_U16 (28 * 16 * BLK_NT)
 
 __global__ void __launch_bounds__(256)
-rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int hcap, uint16_t* __restrict__ tab, int32_t* __restrict__ hid,
+rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int64_t n_blocks, int hcap, uint16_t* __restrict__ tab, int32_t* __restrict__ hid,
                        int32_t* __restrict__ hcnt, int32_t* __restrict__ n_overflow) {
   __shared__ int keys[BLK_HS];
   __shared__ int list[BLK_LIST];
-  __shared__ __attribute__((aligned(16))) uint16_t ltab[BLK_TAB_U16];
+  __shared__ __attribute__((aligned(16))) uint16_t ltab[2][BLK_TAB_U16];
   __shared__ int cnt, cnt2, ovf;
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x;
@@ -35,7 +39,10 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int hcap, uin
   const int rows = (n - r0) < BLK_BM ? (int)(n - r0) : BLK_BM;
   for (int i = tid; i < BLK_HS; i += 256) keys[i] = -1;
   for (int i = tid; i < BLK_LIST; i += 256) list[i] = 0x7fffffff;
-  for (int i = tid; i < BLK_TAB_U16; i += 256) ltab[i] = 0xFFFFu;
+  for (int i = tid; i < BLK_TAB_U16; i += 256) {
+    ltab[0][i] = (uint16_t)(hcap * 128);
+    ltab[1][i] = (uint16_t)(hcap * 64);
+  }
   if (tid == 0) { cnt = 0; cnt2 = 0; ovf = 0; }
   __syncthreads();
   constexpr int total = BLK_KV * BLK_BM;
@@ -57,7 +64,6 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int hcap, uin
     }
   }
   __syncthreads();
-  uint16_t* tout = tab + b * BLK_TAB_U16;
   if (ovf) {
     if (tid == 0) {
       hcnt[b] = -1;
@@ -102,20 +108,24 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int hcap, uin
       const int mid = (lo + hi) >> 1;
       if (list[mid] < g) lo = mid + 1; else hi = mid;
     }
-    ltab[(k * 16 + (r & 15)) * BLK_NT + (r >> 4)] = (uint16_t)lo;   // present by construction
+    const int at = (k * 16 + (r & 15)) * BLK_NT + (r >> 4);   // `lo` = the slot, present by construction
+    ltab[0][at] = (uint16_t)(lo * 128 + ((lo >> 1) & 7) * 16);
+    ltab[1][at] = (uint16_t)(lo * 64 + ((lo >> 2) & 3) * 16);
   }
   __syncthreads();
-  for (int i = tid; i < BLK_TAB_U16 / 8; i += 256)
-    reinterpret_cast<uint4*>(tout)[i] = reinterpret_cast<const uint4*>(ltab)[i];
+  for (int v = 0; v < 2; ++v) {
+    uint16_t* tout = tab + ((int64_t)v * n_blocks + b) * BLK_TAB_U16;
+    for (int i = tid; i < BLK_TAB_U16 / 8; i += 256) reinterpret_cast<uint4*>(tout)[i] = reinterpret_cast<const uint4*>(ltab[v])[i];
+  }
 }
 
-extern "C" size_t ptc_rulebook_blocks_tab_bytes(int64_t n) { return (size_t)ptc_cdiv(n > 0 ? n : 1, BLK_BM) * BLK_TAB_U16 * sizeof(uint16_t); }
+extern "C" size_t ptc_rulebook_blocks_tab_bytes(int64_t n) { return (size_t)2 * ptc_cdiv(n > 0 ? n : 1, BLK_BM) * BLK_TAB_U16 * sizeof(uint16_t); }
 
 extern "C" int ptc_rulebook_blocks(const int32_t* nbr, int kv, int64_t n, int bm, int hcap, void* tab, int32_t* hid, int32_t* hcnt,
                                    int32_t* n_overflow, ptc_stream_t stream) {
   PTC_REQUIRE(n >= 0, PTC_EINVAL, "ptc_rulebook_blocks: bad sizes");
   PTC_REQUIRE(kv == BLK_KV && bm == BLK_BM, PTC_EUNSUPPORTED, "ptc_rulebook_blocks: kv=%d bm=%d (3^3 tables, 128-row blocks)", kv, bm);
-  PTC_REQUIRE(hcap >= 16 && hcap <= BLK_LIST && hcap % 16 == 0, PTC_EUNSUPPORTED, "ptc_rulebook_blocks: hcap=%d (multiple of 16, <= %d)", hcap,
+  PTC_REQUIRE(hcap >= 16 && hcap < BLK_LIST && hcap % 16 == 0, PTC_EUNSUPPORTED, "ptc_rulebook_blocks: hcap=%d (multiple of 16, <= %d)", hcap,
               BLK_LIST);
   PTC_REQUIRE(n_overflow != nullptr, PTC_EINVAL, "ptc_rulebook_blocks: null counter");
   hipStream_t s = (hipStream_t)stream;
@@ -124,7 +134,7 @@ extern "C" int ptc_rulebook_blocks(const int32_t* nbr, int kv, int64_t n, int bm
   PTC_REQUIRE(nbr && tab && hid && hcnt, PTC_EINVAL, "ptc_rulebook_blocks: null buffer");
   PTC_REQUIRE((uintptr_t)tab % 16 == 0, PTC_EINVAL, "ptc_rulebook_blocks: tab must be 16-byte aligned");
   const int64_t nblk = ptc_cdiv(n, BLK_BM);
-  hipLaunchKernelGGL(rulebook_blocks_kernel, dim3((unsigned)nblk), dim3(256), 0, s, nbr, n, hcap, (uint16_t*)tab, hid, hcnt, n_overflow);
+  hipLaunchKernelGGL(rulebook_blocks_kernel, dim3((unsigned)nblk), dim3(256), 0, s, nbr, n, nblk, hcap, (uint16_t*)tab, hid, hcnt, n_overflow);
   PTC_CHECK_LAUNCH("rulebook_blocks_kernel");
   return PTC_OK;
 }

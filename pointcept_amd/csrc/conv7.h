@@ -14,7 +14,8 @@
 //   * the distinct input rows a block names (its "halo": 1.66 x 128 rows on curve-ordered scenes, blocks.hip) and the block's
 //     local table arrive in LDS through global_load_lds (16 B per lane, no VGPR staging, no ds_write), double-buffered: block
 //     b + 1 is in flight while block b is multiplied; rows are XOR-swizzled on the SOURCE side (the DMA image is lane-linear) so
-//     that the 27-tap gather -- a per-lane ds_read_b128 in MFMA B layout -- is conflict-free for neighbouring rows;
+//     that the 27-tap gather -- a per-lane ds_read_b128 in MFMA B layout -- is conflict-free for neighbouring rows; the table
+//     holds ready-made LDS byte offsets, so a gather costs two vector-ALU instructions (field extract, xor-add);
 //   * the main loop is branch-free: tap outer (static: the fragment index must be a compile-time register name), the block's row
 //     tiles inner; "no neighbour" entries read an all-zero row.  Per (tap, tile): one LDS gather + 2 MFMAs per wave;
 //   * C = 64: the two input-channel halves of a row tile are summed through a 32 KB LDS scratch (each wave finishes half of the
@@ -27,8 +28,8 @@
 #define C7_BM 128                           // rows per block
 #define C7_NT 8                             // 16-row tiles per block
 #define C7_HCAP 416                         // halo capacity (rows); max observed on curve-ordered indoor scenes: 352
-#define C7_TABB (28 * 16 * C7_NT * 2)       // bytes of one block's local table: [28 taps (27 + pad)][16 rows-in-tile][8 tiles] u16
-#define C7_NONE 0xFFFFu
+#define C7_TABB (28 * 16 * C7_NT * 2)       // bytes of one block's local table: [28 taps (27 + pad)][16 rows-in-tile][8 tiles] u16, each
+                                            // entry = LDS byte offset of piece 0 of the neighbour row inside the row image (blocks.hip)
 
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
 #define C7_WAIT_VM0 0x0F70
@@ -141,7 +142,7 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       }
     }
     if (cnt > 0) {
-      const unsigned char* tsrc = reinterpret_cast<const unsigned char*>(tab) + (int64_t)blk * C7_TABB;
+      const unsigned char* tsrc = reinterpret_cast<const unsigned char*>(tab) + ((int64_t)(C == 64 ? 0 : n_blocks) + blk) * C7_TABB;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int i = 4 * j + wave;
@@ -163,7 +164,7 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   __builtin_amdgcn_s_barrier();
   cnt_nxt = __builtin_amdgcn_readfirstlane(cnt_nxt);
 
-  const uint32_t pbase = (uint32_t)(kh * 4 + g);     // the 16-byte piece of a gathered row this lane feeds to the MFMA
+  const uint32_t pxor = (uint32_t)(kh * 4 + g) << 4;   // the 16-byte piece of a gathered row this lane feeds to the MFMA
   int cur = 0;
 #pragma unroll 1
   for (int blk = b_begin; blk < b_end; ++blk) {
@@ -187,8 +188,9 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
         if constexpr (C == 64) {
           // a wave's LOCAL tile tl is the block's tile (tl + 4 kh) & 7: local tiles 0..3 are the ones it finishes in the epilogue,
           // 4..7 the ones it hands to its partner -- every accumulator index below is then a compile-time constant
-          const uint4 v = *reinterpret_cast<const uint4*>(tabL + k * (16 * C7_NT * 2));
-          te[0] = kh ? v.z : v.x; te[1] = kh ? v.w : v.y; te[2] = kh ? v.x : v.z; te[3] = kh ? v.y : v.w;
+          const uint2 lo = *reinterpret_cast<const uint2*>(tabL + k * (16 * C7_NT * 2) + kh * 8);
+          const uint2 hi = *reinterpret_cast<const uint2*>(tabL + k * (16 * C7_NT * 2) + (1 - kh) * 8);
+          te[0] = lo.x; te[1] = lo.y; te[2] = hi.x; te[3] = hi.y;
         } else {
           te[0] = *reinterpret_cast<const uint32_t*>(tabL + k * (16 * C7_NT * 2));
         }
@@ -196,9 +198,8 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       auto gather = [&](const uint32_t (&te)[4], frag (&b)[TW]) {
 #pragma unroll
         for (int t = 0; t < TW; ++t) {
-          uint32_t s = (te[t >> 1] >> ((t & 1) * 16)) & 0xffffu;
-          s = s < (uint32_t)C7_HCAP ? s : (uint32_t)C7_HCAP;                  // "no neighbour" -> the zero row
-          b[t] = *reinterpret_cast<const frag*>(rowsL + s * ROWB + ((pbase ^ (uint32_t)G::swz((int)s)) & (PCS - 1)) * 16);
+          const uint32_t off = (t & 1) ? (te[t >> 1] >> 16) : (te[t >> 1] & 0xffffu);     // piece 0 of the row (the zero row for "none")
+          b[t] = *reinterpret_cast<const frag*>(rowsL + ((off ^ pxor)));                     // this lane's piece: XOR into bits 4..
         }
       };
       uint32_t teA[4], teB[4];
@@ -206,6 +207,7 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       entries(0, teA);
       gather(teA, bA);
       entries(1, teB);
+      __builtin_amdgcn_sched_barrier(0);      // the pinned interleave below starts here: nothing of the prologue may fill its slots
 #pragma unroll
       for (int k = 0; k < 27; ++k) {
         frag (&bc)[TW] = (k & 1) ? bB : bA;
@@ -218,6 +220,15 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
         for (int t = 0; t < TW; ++t) {
           acc[t][0] = M::mma(wf[k][0], bc[t], acc[t][0]);
           acc[t][1] = M::mma(wf[k][1], bc[t], acc[t][1]);
+        }
+        // pin the interleave (one wave per SIMD: nothing else hides the LDS latency): per row tile, the two address instructions and
+        // the gather of the NEXT tap's tile, then the two MFMAs of this tap's tile; the table read of tap k + 2 rides in the first group
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   // the table read of tap k + 2
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // 2 VALU (field extract, xor-add)
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // 1 LDS gather
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                 // 2 MFMA
         }
       }
     }
@@ -263,10 +274,11 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       __builtin_amdgcn_s_waitcnt(C7_WAIT_LGKM0);
       __builtin_amdgcn_s_barrier();
     } else {
-#pragma unroll
-      for (int t = 0; t < TW; ++t) store_tile(2 * wave + t, acc[t]);
+      // wait for the DMA of the next block BEFORE the stores of this one are issued: they retire during the next block's MFMAs
       __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
       __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int t = 0; t < TW; ++t) store_tile(2 * wave + t, acc[t]);
     }
     cur ^= 1;
     cnt_cur = cnt_nxt;

@@ -272,7 +272,8 @@ def _tols(dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cin,cout,ksize", [(8, 32, 5), (32, 32, 3), (64, 64, 3), (96, 96, 3), (128, 48, 3),
                                             (192, 128, 3), (256, 256, 3), (16, 16, 3), (128, 96, 3), (96, 64, 3), (32, 192, 3),
-                                            (8, 48, 5), (8, 64, 5), (16, 48, 3), (8, 48, 3)])   # the last four: LitePT's 6 -> 36 stem family
+                                            (8, 48, 5), (8, 64, 5), (16, 48, 3), (8, 48, 3),    # LitePT's 6 -> 36 stem family
+                                            (48, 48, 3), (80, 80, 3), (144, 144, 3), (48, 80, 3), (80, 48, 3)])   # 36 / 72 / 144 channels padded to 16
 def test_spconv_fwd_and_wgrad(cuda, dtype, cin, cout, ksize):
     from pointcept_amd import ops
 
@@ -361,7 +362,7 @@ def test_rulebook_blocks(cuda, ordered):
     bm, hcap = bt.bm, bt.hcap
     tab, hid, hcnt = bt.tab.cpu().numpy().astype(np.uint16), bt.hid.cpu().numpy(), bt.hcnt.cpu().numpy()
     nblk = (n + bm - 1) // bm
-    assert hcnt.shape == (nblk,) and tab.shape == (nblk, 28, 16, 8)
+    assert hcnt.shape == (nblk,) and tab.shape == (2, nblk, 28, 16, 8)
     n_ovf = 0
     for b in range(nblk):
         e = nbr[:, b * bm:(b + 1) * bm]
@@ -376,10 +377,15 @@ def test_rulebook_blocks(cuda, ordered):
         cpad = min((c + 15) // 16 * 16, hcap)
         assert (hid[b, c:cpad] == want[-1]).all()                    # padding: whole DMA instructions fetch valid rows
         rows = e.shape[1]
-        le = tab[b, :27].transpose(0, 2, 1).reshape(27, 128)[:, :rows]      # [k][16 t + r]
-        assert np.array_equal(le == 0xFFFF, e < 0)
-        assert np.array_equal(hid[b][np.where(le != 0xFFFF, le, 0)][e >= 0], e[e >= 0])
-        assert (tab[b, 27] == 0xFFFF).all() and (tab[b, :27].transpose(0, 2, 1).reshape(27, 128)[:, rows:] == 0xFFFF).all()
+        for v, (rowb, sw_shift, sw_mask) in enumerate(((128, 1, 7), (64, 2, 3))):      # 64-channel rows, 32-channel rows
+            none = hcap * rowb
+            full = tab[v, b, :27].transpose(0, 2, 1).reshape(27, 128).astype(np.int64)  # [k][16 t + r]
+            le = full[:, :rows]
+            assert np.array_equal(le == none, e < 0)
+            slot = le // rowb
+            assert np.array_equal((le % rowb)[e >= 0], ((((slot >> sw_shift) & sw_mask) * 16))[e >= 0])     # piece 0 at its swizzled position
+            assert np.array_equal(hid[b][np.where(le != none, slot, 0)][e >= 0], e[e >= 0])
+            assert (tab[v, b, 27] == none).all() and (full[:, rows:] == none).all()
     assert int(bt.n_overflow.item()) == n_ovf
     if ordered:
         assert n_ovf == 0, "curve-ordered rows must fit their halo budget"
@@ -455,6 +461,39 @@ def test_spconv_block_staged_full_size(cuda):
         lhs = ops.spconv_fwd(xs, w, None, nbr, blk).float()
         rhs = ops.spconv_fwd(x, w, None, nbr, blk).float() + ops.spconv_fwd(x2, w, None, nbr, blk).float()
         assert float((lhs - rhs).abs().max()) <= 2.0 ** -5 * float(rhs.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,ksize,bias", [(36, 36, 3, True), (72, 72, 3, True), (6, 36, 5, False), (36, 72, 3, False), (144, 144, 3, True)])
+def test_sparse_conv_autograd_channels_not_multiple_of_16(cuda, cin, cout, ksize, bias):
+    """functional.sparse_conv (the autograd wrapper: channel padding to 16 / 8, weight shadows, mirrored-weight input gradient, weight
+    and bias gradients) at LitePT's / PT-v3m3's channel counts (36, 72, 144; the 6 -> 36 stem) under bf16 autocast against the
+    oracle's autograd in fp32: output, d feat, d weight, d bias."""
+    from pointcept_amd import functional as PF
+    from pointcept_amd import ops
+
+    ind = _scene_indices(1800)
+    nbr = oops.subm_rulebook(ind, ksize)
+    kv, n = nbr.shape
+    g = torch.Generator().manual_seed(cin * 17 + cout)
+    feat = (torch.randn(n, cin, generator=g) * 0.5)
+    w = (torch.randn(cout, kv, cin, generator=g) / (kv * cin) ** 0.5 * 2)
+    b = torch.randn(cout, generator=g) if bias else None
+    dout = torch.randn(n, cout, generator=g)
+    fr, wr = feat.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = None if b is None else b.clone().requires_grad_(True)
+    ref = oops.gather_conv(fr, wr, br, nbr)
+    ref.backward(dout)
+    fe, we = feat.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True)
+    be = None if b is None else b.to(cuda).requires_grad_(True)
+    nbr_d = _t(nbr, cuda)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = PF.sparse_conv(fe, we, be, nbr_d, nbr_d, True)
+    out.float().backward(dout.to(cuda))
+    _close("sparse_conv_out", out.float(), ref.detach(), 1.0 / 64, 1e-2 * float(ref.abs().max()))
+    _close("sparse_conv_dfeat", fe.grad, fr.grad, 1.0 / 32, 2e-2 * float(fr.grad.abs().max()))
+    _close("sparse_conv_dw", we.grad, wr.grad, 1.0 / 32, 2e-2 * float(wr.grad.abs().max()))
+    if bias:
+        _close("sparse_conv_db", be.grad, br.grad, 1.0 / 64, 1e-2 * float(br.grad.abs().max()))
 
 
 def test_spconv_dgrad_via_mirrored_table(cuda):

@@ -106,6 +106,10 @@ def test_ptv3m3_matches_reference_golden(cuda):
         gn, rn = float(p.grad.norm()), ref[name]
         if not abs(gn - rn) <= 0.1 * rn + 1e-4 * gmax:
             bad.append((name, round(gn, 5), round(float(rn), 5)))
+    if bad:   # the whole list for the next reader (pytest truncates the assertion message)
+        os.makedirs(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out", "grad_norm_mismatch.txt"), "a") as fh:
+            fh.write(f"{type(eng).__name__}: parameter, engine |grad|, reference |grad|\n" + "\n".join(f"  {n} {a} {b}" for n, a, b in bad) + "\n")
     assert not bad, bad
 
 
@@ -156,4 +160,8 @@ def test_litept_matches_reference_golden(cuda):
         gn, rn = float(p.grad.norm()), ref[name]
         if not abs(gn - rn) <= 0.1 * rn + 1e-4 * gmax:
             bad.append((name, round(gn, 5), round(float(rn), 5)))
+    if bad:   # the whole list for the next reader (pytest truncates the assertion message)
+        os.makedirs(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out", "grad_norm_mismatch.txt"), "a") as fh:
+            fh.write(f"{type(eng).__name__}: parameter, engine |grad|, reference |grad|\n" + "\n".join(f"  {n} {a} {b}" for n, a, b in bad) + "\n")
     assert not bad, bad

@@ -74,8 +74,12 @@ def main():
         go = torch.randn(n, c, generator=g).to(torch.bfloat16).to(DEV)
         info[f"conv_c{c}"] = {"alg_bytes": n * c * 2 * 2 + 4 * 27 * n + 27 * c * c * 2, "alg_flops": 2.0 * pairs * c * c,
                               "gathered_bytes": pairs * c * 2}
+        blk = ops.BlockTables(nbr)     # conv7's block tables (rulebook_blocks_kernel)
+        info[f"conv_c{c}"]["halo_rows_mean"] = round(float(blk.hcnt.float().mean()), 1)
+        info[f"conv_c{c}"]["alg_bytes_pair_list"] = n * c * 2 * 2 + 8 * pairs + 27 * c * c * 2      # SURVEY 8(d)'s formula
         for _ in range(ITERS):
-            ops.spconv_fwd(x, w, bias, nbr)
+            ops.spconv_fwd(x, w, bias, nbr)            # conv5: global gathers
+            ops.spconv_fwd(x, w, bias, nbr, blk)       # conv7: register weights + DMA-staged halo
             ops.spconv_wgrad(x, go, nbr)
         if s == 0:
             # the gather-fused qkv GEMM: kv = 1 table = a permutation (serialization order)
