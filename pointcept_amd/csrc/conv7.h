@@ -75,7 +75,7 @@ template <int C> struct C7Geom {
 template <typename T, int C>
 __global__ void __launch_bounds__(256, 1)
 conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias, const uint16_t* __restrict__ tab,
-             const int32_t* __restrict__ hid, const int32_t* __restrict__ hcnt, int64_t n_out, int n_blocks, int per_wg, T* __restrict__ out) {
+             const int32_t* __restrict__ hid, const int32_t* __restrict__ hcnt, int64_t n_out, int n_blocks, int per_wg, T* __restrict__ out, int dbg) {
   using M = Mma<T>;
   using frag = typename M::frag;
   using G = C7Geom<C>;
@@ -169,7 +169,7 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 #pragma unroll 1
   for (int blk = b_begin; blk < b_end; ++blk) {
     // block blk + 1 -> the other buffer (its ids arrived before the barrier that ended the previous iteration)
-    if (blk + 1 < b_end) issue_dma(blk + 1, cnt_nxt, cur ^ 1);
+    if (blk + 1 < b_end && !(dbg & 1)) issue_dma(blk + 1, cnt_nxt, cur ^ 1);
     int cnt_nn = count_of(blk + 2);
     if (blk + 2 < b_end) load_ids(blk + 2);
 
@@ -182,7 +182,7 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 #pragma unroll
       for (int c = 0; c < 2; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (cnt_cur > 0) {   // (a block whose halo did not fit is left to the global-gather kernel launched behind this one)
+    if (cnt_cur > 0 && !(dbg & 2)) {   // (a block whose halo did not fit is left to the global-gather kernel launched behind this one)
       // 27 taps x TW tiles, branch-free, software-pipelined by hand: the gathers of tap k + 1 are issued before the MFMAs of tap k
       auto entries = [&](int k, uint32_t (&te)[4]) {
         if constexpr (C == 64) {
@@ -248,7 +248,10 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
         }
       }
     };
-    if constexpr (C == 64) {
+    if (dbg & 4) {
+      __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
+      __builtin_amdgcn_s_barrier();
+    } else if constexpr (C == 64) {
       // the two input-channel halves of a tile meet in LDS: wave kh finishes the block's tiles 4 kh .. 4 kh + 3 (its local tiles 0..3)
       // and hands the others (local 4..7 = the partner's local 0..3) to its partner
       unsigned char* scr = smem + 2 * G::BUF;
@@ -308,7 +311,7 @@ static int launch_conv7_i(const void* in, int64_t n_in, const void* w, const flo
     attr = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C7Geom<C>::LDS, s, (const T*)in, (const T*)w, bias, tab, hid, hcnt, n_out,
-                     n_blocks, per_wg, (T*)out);
+                     n_blocks, per_wg, (T*)out, getenv("PTC_CONV7_DBG") ? atoi(getenv("PTC_CONV7_DBG")) : 0);
   PTC_CHECK_LAUNCH("conv7_kernel");
   return PTC_OK;
 }

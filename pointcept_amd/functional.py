@@ -735,6 +735,9 @@ def lovasz_softmax(logits: torch.Tensor, target: torch.Tensor, ignore_index: int
 class _BatchNormAct(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
+        # dense rows for the kernels -- AND for the tensor the backward reads: a Linear / conv output with a channel count that is not a
+        # multiple of 16 arrives as a column slice of the padded GEMM output (36 of 48 columns: LitePT; found on hardware in round 3)
+        x = x.contiguous()
         y, mean, rstd = ops.batch_norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, act)
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         ctx.training, ctx.act = training, act

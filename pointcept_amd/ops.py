@@ -846,7 +846,7 @@ def batch_norm_act_fwd(x, gamma, beta, running_mean, running_var, training: bool
 def batch_norm_act_bwd(dy, x, gamma, beta, mean, rstd, training: bool, act: str, want_affine: bool = True):
     """-> (dx [N,C] x.dtype, dgamma [C] f32 | None, dbeta [C] f32 | None)"""
     require_cuda(dy, x, mean, rstd)
-    dy = dy.contiguous()
+    dy, x = dy.contiguous(), x.contiguous()
     n, c = x.shape
     dx = torch.empty_like(x)
     dg = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine else None

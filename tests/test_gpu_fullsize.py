@@ -11,7 +11,8 @@ inputs and weights:
         (oracle/ops.py _AttnKernelRounding): the evidence that the deviation is attention rounding and nothing else;
   (iii) SpUNet-v1m1 BASE layers (2,3,4,6,2,2,2,2) on one 100000-voxel scene, forward;
   (iv)  PT-v3m1 outdoor (in_channels 4, depth 12 grid) on one ~120k-voxel LiDAR-like scene, forward;
-  (v)   one optimizer step under fp16 autocast + torch.amp.GradScaler exactly as engines/train.py:203-231.
+  (v)   one optimizer step under fp16 autocast + torch.amp.GradScaler exactly as engines/train.py:203-231;
+  (vi)  (i) again at B = 2 with ragged scene sizes 102400 + 77777: the padding-borrow path of the patch maps at stage 0.
 The oracle needs ~10-40 s per case on the GPU box's host cores; sizes were chosen so the whole file stays under 5 min.
 """
 import os
@@ -61,9 +62,13 @@ def _rel_fro(a, b):
 
 
 def _report(name, lines):
+    """gpurun_out/<name> on an MI355X run; gpurun_out/dryrun_<name> when the bodies run on the CPU stand-ins (scaled scenes): the
+    dry run must never overwrite the hardware evidence"""
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", name), "w") as f:
-        f.write("\n".join(lines) + "\n")
+    on_gpu = torch.cuda.is_available() and SCALE == 1.0
+    head = [f"# {'MI355X run (' + torch.cuda.get_device_name(0) + ')' if on_gpu else 'CPU dry run on oracle stand-ins, scene scale ' + str(SCALE)}"]
+    with open(os.path.join("gpurun_out", name if on_gpu else "dryrun_" + name), "w") as f:
+        f.write("\n".join(head + lines) + "\n")
 
 
 def _chain(point):
@@ -132,6 +137,62 @@ def test_ptv3_base_one_full_scene_maps_and_logits(cuda):
     assert _rel_max(le, lo) < 2e-2, lines[-2]
     # bf16 activations through 22 blocks: per-element bar 8e-2 of the logit range, mean-square bar 3e-2, and the
     # PREDICTIONS (what mIoU is computed from) must agree on >= 97 % of the voxels
+    assert _rel_max(la, lo) < 8e-2 and _rel_fro(la, lo) < 3e-2, lines[-1]
+    assert agree32 > 0.995 and agree16 > 0.97, lines[-2:]
+
+
+def test_ptv3_base_two_ragged_full_scenes_padding_borrow(cuda):
+    """base depth, B = 2 with scene sizes 102400 and 77777 -- 77777 = 75 x 1024 + 977, so the last patch of the
+    second scene BORROWS 47 ranks from the previous patch at stage 0 (ptv3m1:144-154), and every deeper stage pads both scenes.
+    Pad / unpad / cu_seqlens of every stage bit-exact against the oracle, logits (fp32 engine and the bf16 autocast path) inside the
+    bars of the one-scene test."""
+    from oracle import ptv3_model as om
+    from pointcept_amd import synthetic
+    from pointcept_amd.segmentor import DefaultSegmentorV2
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    scene = synthetic.collate([synthetic.indoor_scene(21, _n(102400)), synthetic.indoor_scene(22, _n(77777))])
+    host = {k: torch.from_numpy(v) for k, v in scene.items()}
+    lines = [f"scenes: {_n(102400)} + {_n(77777)} voxels"]
+    enc_cfg = {k: v for k, v in BASE.items() if not k.startswith("dec_")}
+    orc_e, eng_e = _pair(dict(enc_cfg, enc_mode=True), seed=3)
+    eng_e = eng_e.to(cuda).eval()
+    orc_e.eval()
+    with torch.no_grad():
+        torch.manual_seed(11)
+        pe = eng_e(synthetic.to_torch(scene, cuda))
+        torch.manual_seed(11)
+        po = orc_e(dict(host))
+    for s_, (a, b) in enumerate(zip(_chain(pe), _chain(po))):
+        assert a.feat.shape[0] == b.feat.shape[0], f"stage {s_}"
+        for key in ("serialized_order", "serialized_inverse", "offset", "pad", "unpad", "cu_seqlens_key"):
+            assert torch.equal(a[key].cpu().long(), b[key].long()), f"stage {s_}: {key}"
+        n_pad = int(a["pad"].numel())
+        lines.append(f"stage {s_}: n = {a.feat.shape[0]}, padded slots {n_pad}, sequences {int(a['cu_seqlens_key'].numel()) - 1}, feat rel_max {_rel_max(a.feat, b.feat):.3e}")
+        assert _rel_max(a.feat, b.feat) < 2e-2, f"stage {s_} encoder features"
+    if SCALE == 1.0:
+        assert int(_chain(pe)[0]["pad"].numel()) == 102400 + 76 * 1024        # the borrow path: 77777 -> 76 full patches
+    del orc_e, eng_e, pe, po
+    orc_b, eng_b = _pair(BASE, seed=3)
+    orc = om.SegmentorV2(20, 64, orc_b).eval()
+    eng = DefaultSegmentorV2(20, 64, eng_b)
+    eng.seg_head.load_state_dict(orc.seg_head.state_dict())
+    eng = eng.to(cuda).eval()
+    dev_in = synthetic.to_torch(scene, cuda)
+    with torch.no_grad():
+        torch.manual_seed(11)
+        lo = orc({k: v for k, v in host.items() if k != "segment"})["seg_logits"]
+        torch.manual_seed(11)
+        le = eng({k: v for k, v in dev_in.items() if k != "segment"})["seg_logits"]
+        torch.manual_seed(11)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            la = eng({k: v for k, v in dev_in.items() if k != "segment"})["seg_logits"]
+    agree32 = float((le.argmax(1).cpu() == lo.argmax(1)).float().mean())
+    agree16 = float((la.float().argmax(1).cpu() == lo.argmax(1)).float().mean())
+    lines += [f"logits fp32 engine  vs oracle: rel_max {_rel_max(le, lo):.3e} rel_fro {_rel_fro(le, lo):.3e} argmax agreement {agree32:.4f}",
+              f"logits bf16 autocast vs oracle: rel_max {_rel_max(la, lo):.3e} rel_fro {_rel_fro(la, lo):.3e} argmax agreement {agree16:.4f}"]
+    _report("fullsize_ptv3_two_scenes_forward.txt", lines)
+    assert _rel_max(le, lo) < 2e-2, lines[-2]
     assert _rel_max(la, lo) < 8e-2 and _rel_fro(la, lo) < 3e-2, lines[-1]
     assert agree32 > 0.995 and agree16 > 0.97, lines[-2:]
 

@@ -463,6 +463,35 @@ def test_spconv_block_staged_full_size(cuda):
         assert float((lhs - rhs).abs().max()) <= 2.0 ** -5 * float(rhs.abs().max())
 
 
+@pytest.mark.parametrize("c,width", [(36, 48), (72, 80), (64, 64)])
+def test_batch_norm_act_on_a_column_slice_of_a_padded_gemm_output(cuda, c, width):
+    """functional.batch_norm_act on x = wide[:, :c] (what a Linear / conv with a channel count that is not a multiple of 16 hands to
+    the norm that follows it: LitePT's 36 / 72 channels): forward, input gradient, affine gradients against ATen in fp32.  The backward
+    used to read the saved NON-contiguous view as dense rows (wrong gradients on hardware only: the CPU stand-ins honour strides)."""
+    from pointcept_amd import functional as PF
+
+    g = torch.Generator().manual_seed(c)
+    n = 3000
+    wide = (torch.randn(n, width, generator=g) * 2 + 0.3).to(cuda)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(cuda), torch.randn(c, generator=g).to(cuda)
+    dy = torch.randn(n, c, generator=g).to(cuda)
+    for act in ("none", "gelu"):
+        xr = wide[:, :c].clone().requires_grad_(True)
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        y = torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.01, 1e-3)
+        y = torch.nn.functional.gelu(y) if act == "gelu" else y
+        y.backward(dy)
+        we = wide.clone().requires_grad_(True)
+        ge, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        ye = PF.batch_norm_act(we[:, :c], ge, be, None, None, True, 0.01, 1e-3, act)
+        ye.backward(dy)
+        _close(f"bn_{act}_fwd", ye, y, 1e-4, 1e-4)
+        _close(f"bn_{act}_dx", we.grad[:, :c], xr.grad, 1e-3, 1e-4)
+        assert float(we.grad[:, c:].abs().max()) == 0.0 if width > c else True
+        _close(f"bn_{act}_dgamma", ge.grad, gr.grad, 1e-3, 1e-3)
+        _close(f"bn_{act}_dbeta", be.grad, br.grad, 1e-3, 1e-3)
+
+
 @pytest.mark.parametrize("cin,cout,ksize,bias", [(36, 36, 3, True), (72, 72, 3, True), (6, 36, 5, False), (36, 72, 3, False), (144, 144, 3, True)])
 def test_sparse_conv_autograd_channels_not_multiple_of_16(cuda, cin, cout, ksize, bias):
     """functional.sparse_conv (the autograd wrapper: channel padding to 16 / 8, weight shadows, mirrored-weight input gradient, weight
@@ -483,14 +512,16 @@ def test_sparse_conv_autograd_channels_not_multiple_of_16(cuda, cin, cout, ksize
     br = None if b is None else b.clone().requires_grad_(True)
     ref = oops.gather_conv(fr, wr, br, nbr)
     ref.backward(dout)
-    fe, we = feat.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True)
+    stem = cin <= 8                       # a stem's input is data: no input gradient (and no 8-channel input-gradient kernel)
+    fe, we = feat.to(cuda).requires_grad_(not stem), w.to(cuda).requires_grad_(True)
     be = None if b is None else b.to(cuda).requires_grad_(True)
     nbr_d = _t(nbr, cuda)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = PF.sparse_conv(fe, we, be, nbr_d, nbr_d, True)
     out.float().backward(dout.to(cuda))
     _close("sparse_conv_out", out.float(), ref.detach(), 1.0 / 64, 1e-2 * float(ref.abs().max()))
-    _close("sparse_conv_dfeat", fe.grad, fr.grad, 1.0 / 32, 2e-2 * float(fr.grad.abs().max()))
+    if not stem:
+        _close("sparse_conv_dfeat", fe.grad, fr.grad, 1.0 / 32, 2e-2 * float(fr.grad.abs().max()))
     _close("sparse_conv_dw", we.grad, wr.grad, 1.0 / 32, 2e-2 * float(wr.grad.abs().max()))
     if bias:
         _close("sparse_conv_db", be.grad, br.grad, 1.0 / 64, 1e-2 * float(br.grad.abs().max()))

@@ -33,7 +33,8 @@ def test_gpu_spunet_test_bodies_on_cpu_standins(name):
         getattr(T, name)(torch.device("cpu"))
 
 
-FULLSIZE_TESTS = ["test_ptv3_base_one_full_scene_maps_and_logits", "test_ptv3_base_train_step_gradients_vs_oracle",
+FULLSIZE_TESTS = ["test_ptv3_base_one_full_scene_maps_and_logits", "test_ptv3_base_two_ragged_full_scenes_padding_borrow",
+                  "test_ptv3_base_train_step_gradients_vs_oracle",
                   "test_spunet_base_one_full_scene_forward", "test_ptv3_outdoor_full_scene_forward"]
 
 
