@@ -238,9 +238,9 @@ int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float
  *       hid  [n_blocks][hcap] int32 = the distinct input rows named by nbr[:, block], ascending, padded with the last one to
  *                                     a multiple of 16 entries
  *       hcnt [n_blocks]       int32 = how many (-1 = more than hcap: block served through the global table)
- *       tab  [2][n_blocks][28][16][8] uint16 (ptc_rulebook_blocks_tab_bytes(n) bytes, 16-byte aligned): at [v][b][k][r][t]
+ *       tab  [2][n_blocks][28][32][4] uint16 (ptc_rulebook_blocks_tab_bytes(n) bytes, 16-byte aligned): at [v][b][k][r][t]
  *                                     the byte offset, inside the convolution kernel's LDS image of the block's rows, of the
- *                                     first 16 bytes of row nbr[k][128 b + 16 t + r] -- v = 0: 128-byte rows (64 channels),
+ *                                     first 16 bytes of row nbr[k][128 b + 32 t + r] -- v = 0: 128-byte rows (64 channels),
  *                                     slot * 128 + ((slot >> 1) & 7) * 16; v = 1: 64-byte rows (32 channels), slot * 64 +
  *                                     ((slot >> 2) & 3) * 16, slot = position in the block's list; none = hcap * row bytes;
  *                                     row k = 27 padding

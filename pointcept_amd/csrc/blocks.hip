@@ -9,14 +9,14 @@
 //                                              rows then read neighbouring LDS slots), padded with the last one to a multiple of 16
 //   hcnt [n_blocks]                    int32 : how many; -1 = "does not fit" (rows in no spatial order): the kernel serves such a
 //                                              block through the global table
-//   tab  [2][n_blocks][28][16][8]      u16   : at [v][b][k][r][t] the LDS BYTE OFFSET, inside the kernel's image of the block's
-//                                              rows, of piece 0 of row nbr[k][128 b + 16 t + r]: v = 0 for 128-byte rows (64
+//   tab  [2][n_blocks][28][32][4]      u16   : at [v][b][k][r][t] (r = row in its 32-row tile t) the LDS BYTE OFFSET, inside the kernel's image of the block's
+//                                              rows, of piece 0 of row nbr[k][128 b + 32 t + r]: v = 0 for 128-byte rows (64
 //                                              channels): slot * 128 + ((slot >> 1) & 7) * 16, v = 1 for 64-byte rows (32
 //                                              channels): slot * 64 + ((slot >> 2) & 3) * 16 -- the kernel XORs the piece it
 //                                              wants into bits 4.. and adds the image base; "no neighbour" = hcap * row bytes
 //                                              (an all-zero row).  Table row 27 is padding: a whole number of 1-KB DMA pieces
 // One workgroup per block: LDS hash set -> compaction -> bitonic sort -> binary search per entry.  Integer work, bit-exact by
-// construction: hid[b][tab[0][b][k][r][t] >> 7] == nbr[k][128 b + 16 t + r] wherever nbr >= 0 (tests/test_gpu_kernels.py).
+// construction: hid[b][tab[0][b][k][r][t] >> 7] == nbr[k][128 b + 32 t + r] wherever nbr >= 0 (tests/test_gpu_kernels.py).
 #include "ptc_common.h"
 
 #define BLK_BM 128
@@ -108,7 +108,7 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int64_t n_blo
       const int mid = (lo + hi) >> 1;
       if (list[mid] < g) lo = mid + 1; else hi = mid;
     }
-    const int at = (k * 16 + (r & 15)) * BLK_NT + (r >> 4);   // `lo` = the slot, present by construction
+    const int at = (k * 32 + (r & 31)) * 4 + (r >> 5);         // [tap][row in 32-row tile][tile]; `lo` = the slot, present by construction
     ltab[0][at] = (uint16_t)(lo * 128 + ((lo >> 1) & 7) * 16);
     ltab[1][at] = (uint16_t)(lo * 64 + ((lo >> 2) & 3) * 16);
   }

@@ -8,16 +8,18 @@
 // (table entry -> gather -> LDS bounce -> MFMA at 2-3 waves per SIMD) and by re-streaming W -- 221 KB per 128 rows, more bytes
 // through the L1 / LDS-store path than the gathered rows themselves.  conv7 removes both:
 //   * a workgroup is PERSISTENT over a contiguous range of 128-row blocks and keeps the whole weight tensor in the registers of
-//     its four waves (one wave per SIMD, 512-register budget): 27 taps x (C/32 k-steps) x (C/16 output tiles) MFMA A-fragments,
-//     54 per wave.  C = 64: wave w holds input-channel half kh = w & 1 of output-channel half ch = w >> 1 (27 x 2 fragments);
+//     its four waves (one wave per SIMD, 512-register budget) as 32x32x16 MFMA A-fragments (32 output x 16 input channels), 54 per
+//     wave.  C = 64: wave w holds input-channel half kh = w & 1 of output-channel half ch = w >> 1 (27 taps x 2 k-steps);
 //     C = 32: every wave holds all of W (27 x 2) and the waves split the block's row tiles.  W is read from L2 ONCE per workgroup;
 //   * the distinct input rows a block names (its "halo": 1.66 x 128 rows on curve-ordered scenes, blocks.hip) and the block's
 //     local table arrive in LDS through global_load_lds (16 B per lane, no VGPR staging, no ds_write), double-buffered: block
 //     b + 1 is in flight while block b is multiplied; rows are XOR-swizzled on the SOURCE side (the DMA image is lane-linear) so
 //     that the 27-tap gather -- a per-lane ds_read_b128 in MFMA B layout -- is conflict-free for neighbouring rows; the table
 //     holds ready-made LDS byte offsets, so a gather costs two vector-ALU instructions (field extract, xor-add);
-//   * the main loop is branch-free: tap outer (static: the fragment index must be a compile-time register name), the block's row
-//     tiles inner; "no neighbour" entries read an all-zero row.  Per (tap, tile): one LDS gather + 2 MFMAs per wave;
+//   * the main loop is branch-free: tap outer (static: the fragment index must be a compile-time register name), the block's
+//     32-row tiles inner; "no neighbour" entries read an all-zero row.  Per (tap, tile, k-step): one LDS gather + one 32-cycle MFMA
+//     per wave.  (The first version used 16x16x32 MFMAs: at one wave per SIMD a 16-cycle MFMA hides ~1 other instruction and the loop
+//     ran at 36 cycles per MFMA -- tools/probe_mfma_agpr.hip, profiles/r03_f_probe_mfma_agpr.txt; a 32-cycle MFMA hides ~5);
 //   * C = 64: the two input-channel halves of a row tile are summed through a 32 KB LDS scratch (each wave finishes half of the
 //     tiles: symmetric work), bias added in fp32, rows stored as bf16 / f16.
 // A block whose halo does not fit (rows in no spatial order: hcnt < 0) is skipped here and served by conv5, launched behind this
@@ -72,45 +74,51 @@ template <int C> struct C7Geom {
   static __device__ __forceinline__ int swz(int slot) { return C == 64 ? ((slot >> 1) & 7) : ((slot >> 2) & 3); }
 };
 
+typedef __attribute__((ext_vector_type(16))) float c7_f32x16;
+template <typename T> struct C7Mma;
+template <> struct C7Mma<bf16_t> {
+  static __device__ __forceinline__ c7_f32x16 mma(s16x8 a, s16x8 b, c7_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct C7Mma<f16_t> {
+  static __device__ __forceinline__ c7_f32x16 mma(h16x8 a, h16x8 b, c7_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
 template <typename T, int C>
 __global__ void __launch_bounds__(256, 1)
 conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias, const uint16_t* __restrict__ tab,
-             const int32_t* __restrict__ hid, const int32_t* __restrict__ hcnt, int64_t n_out, int n_blocks, int per_wg, T* __restrict__ out, int dbg) {
-  using M = Mma<T>;
-  using frag = typename M::frag;
+             const int32_t* __restrict__ hid, const int32_t* __restrict__ hcnt, int64_t n_out, int n_blocks, int per_wg, T* __restrict__ out) {
+  using frag = typename Mma<T>::frag;
+  using MM = C7Mma<T>;
   using G = C7Geom<C>;
   constexpr int ROWB = G::ROWB, PCS = G::PCS, RPI = G::RPI;
-  constexpr int TW = C == 64 ? 8 : 2;                  // row tiles a wave multiplies per block
+  constexpr int TW = C == 64 ? 4 : 1;                  // 32-row tiles a wave multiplies per block
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = ptc_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int r = lane & 15, g = lane >> 4;
+  const int j = lane & 31, h = lane >> 5;              // MFMA 32x32x16: A row (output channel) / B column (row of the tile), k-group
   const int kh = C == 64 ? (wave & 1) : 0;             // input-channel half
-  const int ch = C == 64 ? (wave >> 1) : 0;            // output-channel half (C = 64) -- C = 32: both output tiles in every wave
+  const int ch = C == 64 ? (wave >> 1) : 0;            // output-channel half (C = 64); C = 32: all 32 output channels in every wave
   const int b_begin = (int)blockIdx.x * per_wg;
   int b_end = b_begin + per_wg;
   if (b_end > n_blocks) b_end = n_blocks;
   if (b_begin >= b_end) return;
 
-  // ---- the weights: 27 x 2 A-fragments per wave, straight from global memory (L2) into registers
+  // ---- the weights: 27 taps x 2 k-steps of 16 = 54 A-fragments (32 output channels x 16 input channels) per wave, straight from
+  //      global memory (L2) into registers
   frag wf[27][2];
 #pragma unroll
   for (int k = 0; k < 27; ++k)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int co = (ch * 2 + c) * 16 + r;
-      wf[k][c] = ld_frag<T>(w + ((int64_t)co * 27 + k) * C + kh * 32 + g * 8);
-    }
-  // the accumulators of an MFMA live in the accumulation half of the register file (64 here), which leaves it 192 registers =
-  // 48 of the 54 weight fragments; the last three taps stay in architectural VGPRs beside the gather ring
+    for (int ks = 0; ks < 2; ++ks) wf[k][ks] = ld_frag<T>(w + ((int64_t)(ch * 32 + j) * 27 + k) * C + kh * 32 + ks * 16 + h * 8);
+  // the accumulators of an MFMA live in the accumulation half of the register file (64 of its 256 registers here), which leaves it
+  // 192 registers = 48 of the 54 weight fragments; the last three taps stay in architectural VGPRs beside the gather ring
 #pragma unroll
   for (int k = 0; k < (C == 64 ? 24 : 27); ++k)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) C7_PIN_AGPR(wf[k][c]);
-  float bsv[2][4];
+    for (int ks = 0; ks < 2; ++ks) C7_PIN_AGPR(wf[k][ks]);
+  // D[i][jj] of the 32x32 MFMA: lane (jj = row, h) holds output channels i = 8 (r / 4) + 4 h + r % 4, r = 0..15
+  float bsv[16];
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) bsv[c][e] = bias ? bias[(ch * 2 + c) * 16 + g * 4 + e] : 0.f;
+  for (int r = 0; r < 16; ++r) bsv[r] = bias ? bias[ch * 32 + 8 * (r >> 2) + 4 * h + (r & 3)] : 0.f;
 
   // ---- zero rows of both buffers (never written by the DMA)
   if (threadIdx.x < 2 * PCS) {
@@ -118,34 +126,34 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
     *reinterpret_cast<uint4*>(smem + bsel * G::BUF + C7_HCAP * ROWB + pc * 16) = make_uint4(0, 0, 0, 0);
   }
 
-  // ---- DMA of one block's halo rows + table into buffer `bsel`; ids = this wave's share of the halo list (instruction j of the
-  //      wave = instruction 4 j + wave of the block: rows (4 j + wave) * RPI + lane / PCS)
+  // ---- DMA of one block's halo rows + table into buffer `bsel`; ids = this wave's share of the halo list (instruction q of the
+  //      wave = instruction 4 q + wave of the block: rows (4 q + wave) * RPI + lane / PCS)
   const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c7_lds_addr(smem));
   const int drow = lane / PCS, dpos = lane % PCS;
   int32_t ids[G::NIW];
   auto load_ids = [&](int blk) {
 #pragma unroll
-    for (int j = 0; j < G::NIW; ++j) {
-      const int slot = (4 * j + wave) * RPI + drow;
-      ids[j] = hid[(int64_t)blk * C7_HCAP + (slot < C7_HCAP ? slot : C7_HCAP - 1)];
+    for (int q = 0; q < G::NIW; ++q) {
+      const int slot = (4 * q + wave) * RPI + drow;
+      ids[q] = hid[(int64_t)blk * C7_HCAP + (slot < C7_HCAP ? slot : C7_HCAP - 1)];
     }
   };
   auto issue_dma = [&](int blk, int cnt, int bsel) {
     const uint32_t base = lds0 + (uint32_t)(bsel * G::BUF);
 #pragma unroll
-    for (int j = 0; j < G::NIW; ++j) {
-      const int i = 4 * j + wave;
+    for (int q = 0; q < G::NIW; ++q) {
+      const int i = 4 * q + wave;
       if (i * RPI < cnt) {                                   // wave-uniform
         const int slot = i * RPI + drow;
         const int piece = dpos ^ G::swz(slot);
-        c7_dma16(reinterpret_cast<const unsigned char*>(in) + (int64_t)ids[j] * ROWB + piece * 16, base + (uint32_t)(i * 1024));
+        c7_dma16(reinterpret_cast<const unsigned char*>(in) + (int64_t)ids[q] * ROWB + piece * 16, base + (uint32_t)(i * 1024));
       }
     }
     if (cnt > 0) {
       const unsigned char* tsrc = reinterpret_cast<const unsigned char*>(tab) + ((int64_t)(C == 64 ? 0 : n_blocks) + blk) * C7_TABB;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int i = 4 * j + wave;
+      for (int q = 0; q < 2; ++q) {
+        const int i = 4 * q + wave;
         if (i < C7_TABB / 1024) c7_dma16(tsrc + i * 1024 + lane * 16, base + (uint32_t)(G::ROWS_BYTES + i * 1024));
       }
     }
@@ -164,114 +172,119 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   __builtin_amdgcn_s_barrier();
   cnt_nxt = __builtin_amdgcn_readfirstlane(cnt_nxt);
 
-  const uint32_t pxor = (uint32_t)(kh * 4 + g) << 4;   // the 16-byte piece of a gathered row this lane feeds to the MFMA
+  // the 16-byte piece of a gathered row this lane feeds to k-step ks: input channels kh * 32 + ks * 16 + h * 8 ..
+  const uint32_t pxor0 = (uint32_t)(kh * 4 + h) << 4, pxor1 = (uint32_t)(kh * 4 + 2 + h) << 4;
   int cur = 0;
 #pragma unroll 1
   for (int blk = b_begin; blk < b_end; ++blk) {
     // block blk + 1 -> the other buffer (its ids arrived before the barrier that ended the previous iteration)
-    if (blk + 1 < b_end && !(dbg & 1)) issue_dma(blk + 1, cnt_nxt, cur ^ 1);
+    if (blk + 1 < b_end) issue_dma(blk + 1, cnt_nxt, cur ^ 1);
     int cnt_nn = count_of(blk + 2);
     if (blk + 2 < b_end) load_ids(blk + 2);
 
     const unsigned char* rowsL = smem + cur * G::BUF;
-    const unsigned char* tabL = rowsL + G::ROWS_BYTES + r * (C7_NT * 2) + (C == 64 ? 0 : wave * 4);
+    // table [28 taps][32 rows of a tile][4 tiles] u16; a wave's LOCAL tile tl is the block's tile (tl + 2 kh) & 3 (C = 64: local tiles
+    // 0, 1 are the ones it finishes in the epilogue, 2, 3 the ones it hands to its partner -- every accumulator index is then a
+    // compile-time constant); C = 32: wave w multiplies tile w
+    const unsigned char* tabL = rowsL + G::ROWS_BYTES + j * 8 + (C == 64 ? 0 : wave * 2);
     const int64_t row0 = (int64_t)blk * C7_BM;
-    f32x4 acc[TW][2];
+    c7_f32x16 acc[C == 64 ? 4 : 2];                      // C = 32: one accumulator per k-step (no dependent MFMA pair)
 #pragma unroll
-    for (int t = 0; t < TW; ++t)
+    for (int t = 0; t < (C == 64 ? 4 : 2); ++t)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    if (cnt_cur > 0 && !(dbg & 2)) {   // (a block whose halo did not fit is left to the global-gather kernel launched behind this one)
-      // 27 taps x TW tiles, branch-free, software-pipelined by hand: the gathers of tap k + 1 are issued before the MFMAs of tap k
-      auto entries = [&](int k, uint32_t (&te)[4]) {
+    if (cnt_cur > 0) {   // (a block whose halo did not fit is left to the global-gather kernel launched behind this one)
+      // 27 taps x TW tiles x 2 k-steps, branch-free, software-pipelined by hand: the gathers of tap k + 1 are issued before the MFMAs of tap k
+      auto entries = [&](int k, uint32_t (&te)[2]) {
         if constexpr (C == 64) {
-          // a wave's LOCAL tile tl is the block's tile (tl + 4 kh) & 7: local tiles 0..3 are the ones it finishes in the epilogue,
-          // 4..7 the ones it hands to its partner -- every accumulator index below is then a compile-time constant
-          const uint2 lo = *reinterpret_cast<const uint2*>(tabL + k * (16 * C7_NT * 2) + kh * 8);
-          const uint2 hi = *reinterpret_cast<const uint2*>(tabL + k * (16 * C7_NT * 2) + (1 - kh) * 8);
-          te[0] = lo.x; te[1] = lo.y; te[2] = hi.x; te[3] = hi.y;
+          te[0] = *reinterpret_cast<const uint32_t*>(tabL + k * 256 + kh * 4);
+          te[1] = *reinterpret_cast<const uint32_t*>(tabL + k * 256 + (1 - kh) * 4);
         } else {
-          te[0] = *reinterpret_cast<const uint32_t*>(tabL + k * (16 * C7_NT * 2));
+          te[0] = *reinterpret_cast<const uint16_t*>(tabL + k * 256);
         }
       };
-      auto gather = [&](const uint32_t (&te)[4], frag (&b)[TW]) {
+      auto gather = [&](const uint32_t (&te)[2], frag (&b)[TW][2]) {
 #pragma unroll
         for (int t = 0; t < TW; ++t) {
-          const uint32_t off = (t & 1) ? (te[t >> 1] >> 16) : (te[t >> 1] & 0xffffu);     // piece 0 of the row (the zero row for "none")
-          b[t] = *reinterpret_cast<const frag*>(rowsL + ((off ^ pxor)));                     // this lane's piece: XOR into bits 4..
+          const uint32_t off = C == 64 ? ((t & 1) ? (te[t >> 1] >> 16) : (te[t >> 1] & 0xffffu)) : te[0];   // piece 0 of the row (zero row: "none")
+          b[t][0] = *reinterpret_cast<const frag*>(rowsL + (off ^ pxor0));
+          b[t][1] = *reinterpret_cast<const frag*>(rowsL + (off ^ pxor1));
         }
       };
-      uint32_t teA[4], teB[4];
-      frag bA[TW], bB[TW];
+      uint32_t teA[2], teB[2];
+      frag bA[TW][2], bB[TW][2];
       entries(0, teA);
       gather(teA, bA);
       entries(1, teB);
       __builtin_amdgcn_sched_barrier(0);      // the pinned interleave below starts here: nothing of the prologue may fill its slots
 #pragma unroll
       for (int k = 0; k < 27; ++k) {
-        frag (&bc)[TW] = (k & 1) ? bB : bA;
-        frag (&bn)[TW] = (k & 1) ? bA : bB;
-        uint32_t (&tn)[4] = (k & 1) ? teA : teB;      // entries of tap k + 1 (read one tap ago)
-        uint32_t (&tnn)[4] = (k & 1) ? teB : teA;     // entries of tap k + 2: overwrites those of tap k
+        frag (&bc)[TW][2] = (k & 1) ? bB : bA;
+        frag (&bn)[TW][2] = (k & 1) ? bA : bB;
+        uint32_t (&tn)[2] = (k & 1) ? teA : teB;      // entries of tap k + 1 (read one tap ago)
+        uint32_t (&tnn)[2] = (k & 1) ? teB : teA;     // entries of tap k + 2: overwrites those of tap k
         if (k + 1 < 27) gather(tn, bn);
         if (k + 2 < 27) entries(k + 2, tnn);
+        // k-step outer, tile inner: two MFMAs on one accumulator are TW MFMAs apart
 #pragma unroll
-        for (int t = 0; t < TW; ++t) {
-          acc[t][0] = M::mma(wf[k][0], bc[t], acc[t][0]);
-          acc[t][1] = M::mma(wf[k][1], bc[t], acc[t][1]);
-        }
-        // pin the interleave (one wave per SIMD: nothing else hides the LDS latency): per row tile, the two address instructions and
-        // the gather of the NEXT tap's tile, then the two MFMAs of this tap's tile; the table read of tap k + 2 rides in the first group
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   // the table read of tap k + 2
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int t = 0; t < TW; ++t) {
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // 2 VALU (field extract, xor-add)
+          for (int t = 0; t < TW; ++t) {
+            c7_f32x16& a = acc[C == 64 ? t : ks];
+            a = MM::mma(wf[k][ks], bc[t][ks], a);
+          }
+        // pin the interleave (one wave per SIMD: nothing else hides the LDS latency, and a 32-cycle MFMA hides ~5 other issues):
+        // per MFMA one address computation + gather of the NEXT tap; the table read of tap k + 2 rides in front
+        __builtin_amdgcn_sched_group_barrier(0x100, C == 64 ? 2 : 1, 0);
+#pragma unroll
+        for (int q = 0; q < 2 * TW; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // <= 2 VALU (field extract, xor-add)
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // 1 LDS gather
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                 // 2 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // 1 MFMA
         }
       }
     }
 
-    // ---- epilogue
-    auto store_tile = [&](int tile, const f32x4 (&a)[2]) {
-      const int64_t row = row0 + tile * 16 + r;
+    // ---- epilogue: lane (j, h) holds, of row j of a tile, output channels ch * 32 + 8 q + 4 h + 0..3, q = 0..3
+    auto store_tile = [&](int tile, const c7_f32x16& a) {
+      const int64_t row = row0 + tile * 32 + j;
       if (row < n_out && cnt_cur > 0) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int q = 0; q < 4; ++q) {
           T o[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = ptc_from_float<T>(a[c][e] + bsv[c][e]);
+          for (int e = 0; e < 4; ++e) o[e] = ptc_from_float<T>(a[4 * q + e] + bsv[4 * q + e]);
           uint2 v;
           __builtin_memcpy(&v, o, 8);
-          *reinterpret_cast<uint2*>(out + row * C + (ch * 2 + c) * 16 + g * 4) = v;
+          *reinterpret_cast<uint2*>(out + row * C + ch * 32 + 8 * q + 4 * h) = v;
         }
       }
     };
-    if (dbg & 4) {
-      __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
-      __builtin_amdgcn_s_barrier();
-    } else if constexpr (C == 64) {
-      // the two input-channel halves of a tile meet in LDS: wave kh finishes the block's tiles 4 kh .. 4 kh + 3 (its local tiles 0..3)
-      // and hands the others (local 4..7 = the partner's local 0..3) to its partner
+    if constexpr (C == 64) {
+      // the two input-channel halves of a tile meet in LDS: wave kh finishes the block's tiles 2 kh, 2 kh + 1 (its local tiles 0, 1)
+      // and hands the others (local 2, 3 = the partner's local 0, 1) to its partner
       unsigned char* scr = smem + 2 * G::BUF;
       const int partner = wave ^ 1;
 #pragma unroll
-      for (int tl = 0; tl < 4; ++tl)
+      for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-          *reinterpret_cast<f32x4*>(scr + ((partner * 4 + tl) * 2 + c) * 1024 + lane * 16) = acc[4 + tl][c];
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[2 + tl][4 * q], acc[2 + tl][4 * q + 1], acc[2 + tl][4 * q + 2], acc[2 + tl][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(scr + ((partner * 2 + tl) * 4 + q) * 1024 + lane * 16) = v;
+        }
       __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);   // scratch written; next block's rows + table and the ids landed
       __builtin_amdgcn_s_barrier();
 #pragma unroll
-      for (int tl = 0; tl < 4; ++tl) {
-        f32x4 a[2];
+      for (int tl = 0; tl < 2; ++tl) {
+        c7_f32x16 a = acc[tl];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(scr + ((wave * 4 + tl) * 2 + c) * 1024 + lane * 16);
-          a[c] = acc[tl][c] + o;
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(scr + ((wave * 2 + tl) * 4 + q) * 1024 + lane * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[4 * q + e] += o[e];
         }
-        store_tile(kh * 4 + tl, a);
+        store_tile(2 * kh + tl, a);
       }
       // the partner must not reach its next scratch write before this wave has read: a second barrier (the epilogues are symmetric)
       __builtin_amdgcn_s_waitcnt(C7_WAIT_LGKM0);
@@ -280,8 +293,10 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       // wait for the DMA of the next block BEFORE the stores of this one are issued: they retire during the next block's MFMAs
       __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
       __builtin_amdgcn_s_barrier();
+      c7_f32x16 a = acc[0];
 #pragma unroll
-      for (int t = 0; t < TW; ++t) store_tile(2 * wave + t, acc[t]);
+      for (int r = 0; r < 16; ++r) a[r] += acc[1][r];
+      store_tile(wave, a);
     }
     cur ^= 1;
     cnt_cur = cnt_nxt;
@@ -311,7 +326,7 @@ static int launch_conv7_i(const void* in, int64_t n_in, const void* w, const flo
     attr = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C7Geom<C>::LDS, s, (const T*)in, (const T*)w, bias, tab, hid, hcnt, n_out,
-                     n_blocks, per_wg, (T*)out, getenv("PTC_CONV7_DBG") ? atoi(getenv("PTC_CONV7_DBG")) : 0);
+                     n_blocks, per_wg, (T*)out);
   PTC_CHECK_LAUNCH("conv7_kernel");
   return PTC_OK;
 }

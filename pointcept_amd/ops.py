@@ -354,7 +354,7 @@ BLOCK_BM, BLOCK_HCAP = 128, 416     # = C7_BM, C7_HCAP of csrc/conv7.h
 class BlockTables:
     """Block-local form of a submanifold 3^3 gather table `nbr` (csrc/blocks.hip): per block of 128 consecutive rows the ascending list
     of distinct input rows (`hid` [n_blocks, hcap], `hcnt` [n_blocks]; -1 = does not fit) and the uint16 tables `tab`
-    [2, n_blocks, 28, 16, 8] of LDS byte offsets of those rows (0: 64-channel rows, 1: 32-channel rows; include/ptcore.h).  Consumed by
+    [2, n_blocks, 28, 32, 4] of LDS byte offsets of those rows (0: 64-channel rows, 1: 32-channel rows; include/ptcore.h).  Consumed by
     spconv_fwd(..., blk=...) (csrc/conv7.h)."""
 
     def __init__(self, nbr: torch.Tensor, bm: int = BLOCK_BM, hcap: int = BLOCK_HCAP):
@@ -366,7 +366,7 @@ class BlockTables:
         self.bm, self.hcap = int(bm), int(hcap)
         nblk = max(1, (n + self.bm - 1) // self.bm)
         dev = nbr.device
-        self.tab = torch.empty(int(lib().ptc_rulebook_blocks_tab_bytes(n)) // 2, dtype=torch.int16, device=dev).view(2, nblk, 28, 16, 8)
+        self.tab = torch.empty(int(lib().ptc_rulebook_blocks_tab_bytes(n)) // 2, dtype=torch.int16, device=dev).view(2, nblk, 28, 32, 4)
         self.hid = torch.empty((nblk, self.hcap), dtype=torch.int32, device=dev)
         self.hcnt = torch.empty(nblk, dtype=torch.int32, device=dev)
         self.n_overflow = torch.empty(1, dtype=torch.int32, device=dev)

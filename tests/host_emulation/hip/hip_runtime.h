@@ -419,7 +419,11 @@ template <typename V, typename ACC> static inline ACC emu_mfma_32x32x16_bf16(V a
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_16x16x32_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu_mfma_16x16x32_f16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_16x16x4_f32((a), (b), (c))
+template <typename V, typename ACC> static inline ACC emu_mfma_32x32x16_f16(V a, V b, ACC c) {
+  return emu::mfma<32, 2, 8, uint16_t>((const uint16_t*)&a, (const uint16_t*)&b, c, emu::f16_bits_to_float);
+}
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32x16_bf16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16_f16((a), (b), (c))
 
 // ---- ds_read_b64_tr_b16 --------------------------------------------------------------------------------------------------
 typedef short emu_s16x4 __attribute__((ext_vector_type(4)));

@@ -362,7 +362,7 @@ def test_rulebook_blocks(cuda, ordered):
     bm, hcap = bt.bm, bt.hcap
     tab, hid, hcnt = bt.tab.cpu().numpy().astype(np.uint16), bt.hid.cpu().numpy(), bt.hcnt.cpu().numpy()
     nblk = (n + bm - 1) // bm
-    assert hcnt.shape == (nblk,) and tab.shape == (2, nblk, 28, 16, 8)
+    assert hcnt.shape == (nblk,) and tab.shape == (2, nblk, 28, 32, 4)
     n_ovf = 0
     for b in range(nblk):
         e = nbr[:, b * bm:(b + 1) * bm]
@@ -379,7 +379,7 @@ def test_rulebook_blocks(cuda, ordered):
         rows = e.shape[1]
         for v, (rowb, sw_shift, sw_mask) in enumerate(((128, 1, 7), (64, 2, 3))):      # 64-channel rows, 32-channel rows
             none = hcap * rowb
-            full = tab[v, b, :27].transpose(0, 2, 1).reshape(27, 128).astype(np.int64)  # [k][16 t + r]
+            full = tab[v, b, :27].transpose(0, 2, 1).reshape(27, 128).astype(np.int64)  # [k][32 t + r]
             le = full[:, :rows]
             assert np.array_equal(le == none, e < 0)
             slot = le // rowb
