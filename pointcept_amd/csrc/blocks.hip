@@ -45,11 +45,18 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int64_t n_blo
   }
   if (tid == 0) { cnt = 0; cnt2 = 0; ovf = 0; }
   __syncthreads();
-  constexpr int total = BLK_KV * BLK_BM;
-  for (int e = tid; e < total; e += 256) {
-    const int k = e / BLK_BM, r = e - k * BLK_BM;
-    if (r >= rows) continue;
-    const int g = nbr[(int64_t)k * n + r0 + r];
+  // the block's 27 x 128 table entries, 14 per thread, fetched ONCE with every load in flight together (the kernel is latency-bound:
+  // the first version walked them one dependent load at a time, twice -- 140 us per rulebook at N = 819200, r03_c_conv_pmc_s0.json)
+  constexpr int total = BLK_KV * BLK_BM, EPT = (total + 255) / 256;
+  int ent[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = tid + 256 * i, k = e / BLK_BM, r = e - k * BLK_BM;
+    ent[i] = (e < total && r < rows) ? nbr[(int64_t)k * n + r0 + r] : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int g = ent[i];
     if (g < 0) continue;
     unsigned h = ((unsigned)g * 2654435761u) >> 21;   // 11 bits
     for (int probe = 0; probe < BLK_HS; ++probe) {
@@ -98,11 +105,11 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int64_t n_blo
   const int cpad = ((c + 15) & ~15) < hcap ? ((c + 15) & ~15) : hcap;
   for (int i = tid; i < cpad; i += 256) hid[b * hcap + i] = list[i < c ? i : c - 1];
   if (tid == 0) hcnt[b] = c;
-  for (int e = tid; e < total; e += 256) {
-    const int k = e / BLK_BM, r = e - k * BLK_BM;
-    if (r >= rows) continue;
-    const int g = nbr[(int64_t)k * n + r0 + r];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int g = ent[i];
     if (g < 0) continue;
+    const int e = tid + 256 * i, k = e / BLK_BM, r = e - k * BLK_BM;
     int lo = 0, hi = c - 1;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;

@@ -34,7 +34,7 @@
 #define C3_FPAD 64
 #define C3_BUF(NTILES) (4 * (NTILES) * (C3_FRAG + C3_FPAD))   // one W chunk: NTILES tiles x 4 steps
 
-template <typename T, int RT, int KPC, int NTILES, bool GEN>
+template <typename T, int RT, int KPC, int NTILES, bool GEN, bool IDENT = false>
 __global__ void __launch_bounds__(256, 2)
 conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
              const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int n_rowblk, T* __restrict__ out,
@@ -118,7 +118,10 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       for (int j = 0; j < RT; ++j) {
         const int64_t row = row0 + j * 16 + lrow;
         const bool ok = k < kv && row < n_out;
-        const int32_t e = nbr[(int64_t)(k < kv ? k : kv - 1) * n_out + (row < n_out ? row : n_out - 1)];   // always in bounds
+        // IDENT: the identity table of a dense row-wise GEMM (nn.Linear with a contraction wider than linear2's 256 channels:
+        // PTv3's fc2 / proj / qkv of the 128..512-channel stages, K = 512 .. 2048) -- no table in memory
+        const int32_t e = IDENT ? (int32_t)(row < n_out ? row : n_out - 1)
+                                : nbr[(int64_t)(k < kv ? k : kv - 1) * n_out + (row < n_out ? row : n_out - 1)];   // always in bounds
         ix[kk][j] = ok ? e : -1;
       }
     }
@@ -206,6 +209,11 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   }
 }
 
+// dense row-wise GEMM out = in W^T + b on the same kernel (identity table): contractions wider than linear2's 256 channels
+static inline bool conv3_dense_supported(int dtype, int kv, int c_in, int c_out, const int32_t* nbr) {
+  return dtype != PTC_F32 && nbr == nullptr && kv == 1 && c_in > 256 && c_in % 128 == 0 && c_out % 32 == 0;
+}
+
 static inline bool conv3_supported(int dtype, int kv, int c_in, int c_out, const int32_t* nbr) {
   if (dtype == PTC_F32 || nbr == nullptr || kv < 2) return false;
   // c_in = 8: the stems (6 input channels padded to 8, k = 5): four table rows per MFMA step instead of one table row per
@@ -216,13 +224,13 @@ static inline bool conv3_supported(int dtype, int kv, int c_in, int c_out, const
   return !(c_in == 32 && c_out % 64 != 0 && c_out % 96 != 0);
 }
 
-template <typename T, int RT, int KPC, int NTILES, bool GEN>
+template <typename T, int RT, int KPC, int NTILES, bool GEN, bool IDENT = false>
 static int launch_conv3_i(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
                           int c_in, int c_out, void* out, hipStream_t s) {
   const int n_rowblk = (int)ptc_cdiv(n_out, RT * 64);
   const int nblk = n_rowblk * (c_out / (NTILES * 16));
   const size_t lds = 2 * C3_BUF(NTILES);
-  auto kern = conv3_kernel<T, RT, KPC, NTILES, GEN>;
+  auto kern = conv3_kernel<T, RT, KPC, NTILES, GEN, IDENT>;
   static size_t allowed = 48 * 1024;   // per instantiation
   if (lds > allowed) {
     PTC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -244,6 +252,16 @@ static int launch_conv3(const void* in, int64_t n_in, const void* w, const float
   // table rows one 128-wide chunk can touch: 1 (c_in % 128 == 0), 4 (c_in = 32), else 2
   const int kpc = c_in == 8 ? 16 : (c_in % 128 == 0 ? 1 : (c_in == 32 ? 4 : 2));
   const bool gen = !(c_in == 8 || c_in == 32 || c_in == 64 || c_in % 128 == 0);   // table rows straddle chunks (kpc == 2)
+  if (nbr == nullptr) {   // dense GEMM (kv = 1, c_in % 128 == 0): identity-table instances
+#define C3_ID_CASE(N)                                                                                                        \
+  if (nt == N)                                                                                                             \
+    return big ? launch_conv3_i<T, 4, 1, N, false, true>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s)               \
+               : launch_conv3_i<T, 2, 1, N, false, true>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+    C3_ID_CASE(4) C3_ID_CASE(2) C3_ID_CASE(6)
+#undef C3_ID_CASE
+    ptc_set_error("conv3 (dense): c_in=%d c_out=%d unsupported", c_in, c_out);
+    return PTC_EUNSUPPORTED;
+  }
 #define C3_CASE(K, N, G)                                                                                                   \
   if (kpc == K && nt == N && gen == G)                                                                                     \
     return big ? launch_conv3_i<T, 4, K, N, G>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s)                           \

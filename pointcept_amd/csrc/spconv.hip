@@ -234,7 +234,7 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
     if (dtype == PTC_BF16) return launch_conv5<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
     return launch_conv5<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
   }
-  if (buf_ok && conv3_supported(dtype, kv, c_in, c_out, nbr)) {
+  if (buf_ok && (conv3_supported(dtype, kv, c_in, c_out, nbr) || conv3_dense_supported(dtype, kv, c_in, c_out, nbr))) {
     if (dtype == PTC_BF16) return launch_conv3<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
     return launch_conv3<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
   }

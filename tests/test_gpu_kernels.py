@@ -567,9 +567,12 @@ def test_spconv_down_up_tables(cuda):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("n,cin,cout", [(1, 32, 96), (5000, 32, 96), (3001, 64, 192), (777, 128, 512), (300, 512, 2048),
-                                        (900, 2048, 512), (2500, 64, 20), (4100, 6, 32)])
+                                        (900, 2048, 512), (2500, 64, 20), (4100, 6, 32), (2821, 512, 1536), (12115, 1024, 256),
+                                        (50360, 512, 128), (2821, 512, 512), (70000, 256, 1024)])
 def test_linear_identity_table(cuda, dtype, n, cin, cout):
-    """PF.linear == F.linear (forward, input / weight / bias gradients) incl. channel padding."""
+    """PF.linear == F.linear (forward, input / weight / bias gradients) incl. channel padding; the contractions wider than 256 (the
+    last cases = the qkv / fc2 / proj / fc1-dgrad shapes of PT-v3m1's 128 .. 512-channel stages) run on the identity-table instances of
+    the chunked implicit-GEMM kernel, their small-row weight gradients on the split-K kernel: no library GEMM on the hot path."""
     from pointcept_amd import functional as PF
 
     g = torch.Generator().manual_seed(n + cin + cout)
