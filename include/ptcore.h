@@ -539,6 +539,46 @@ int ptc_pair_aggregate_bwd(const float* grad_out, const float* attn, const float
                            const float* table_v, const int32_t* rel_idx, int64_t M, int64_t Nv, int64_t L, int H, int d,
                            float* dattn, float* dv, float* dtable_v, ptc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * N. One call per PT-v3m1 Block and direction (csrc/block_exec.hip): the kernel sequence of Block.forward (ptv3m1:318-338:
+ *    x += LN(Linear(SubMConv(x))); x += DropPath(Attn(LN(x))); x += DropPath(MLP(LN(x)))) and of its backward, enqueued from C
+ *    instead of from ~16 Python autograd Functions (the host-side launch floor).  Same entry points, same operands, same
+ *    order as the Python-composed path: bit-identical.  bf16 GEMM operands, head_dim 16, c <= 256 (MLP hidden 4 c), pre-norm.
+ *    Arguments are index tables (the enums below; a Python caller reads the names from this header):
+ *      iv  int64 [PTC_BLK_I_COUNT]  sizes and dtype tags         fv  float [PTC_BLK_F_COUNT]  softmax scale, LayerNorm eps
+ *      in  [PTC_BLK_P_COUNT]        inputs: activations, 16-bit weight shadows ([c_out][taps][c_in]), fp32 biases / LayerNorm
+ *                                   parameters, tables, DropPath row scales (NULL = none); for the backward also the incoming
+ *                                   gradients (either may be NULL) and the transposed weight layouts ([c_in][taps'][c_out],
+ *                                   ptc_weight_layouts: conv mirrored, qkv repeated twice)
+ *      out [PTC_BLK_O_COUNT]        forward outputs = what the backward reads back (`sv`): caller-allocated
+ *      g   [PTC_BLK_GS_COUNT]       backward outputs: gradients (G_*; fp32 parameters' gradients, G_X0 in the dtype of x0, G_XC
+ *                                   16-bit) and scratch (S_*), caller-allocated; workspace >= ptc_ptv3_block_workspace_bytes
+ * ------------------------------------------------------------------------------------------ */
+#define PTC_BLK_ABI 1
+enum { PTC_BLK_I_ABI, PTC_BLK_I_N, PTC_BLK_I_NPAD, PTC_BLK_I_NSEQ, PTC_BLK_I_C, PTC_BLK_I_HEADS, PTC_BLK_I_DTYPE, PTC_BLK_I_A_DTYPE,
+       PTC_BLK_I_PATCH, PTC_BLK_I_BLK_BM, PTC_BLK_I_BLK_HCAP, PTC_BLK_I_COUNT };
+enum { PTC_BLK_F_SCALE, PTC_BLK_F_EPS_CPE, PTC_BLK_F_EPS_N1, PTC_BLK_F_EPS_N2, PTC_BLK_F_COUNT };
+enum { PTC_BLK_P_X0, PTC_BLK_P_XC, PTC_BLK_P_NBR, PTC_BLK_P_BLK_TAB, PTC_BLK_P_BLK_HID, PTC_BLK_P_BLK_HCNT, PTC_BLK_P_T_QKV_FWD,
+       PTC_BLK_P_T_QKV_BWD, PTC_BLK_P_T_PROJ_FWD, PTC_BLK_P_T_PROJ_BWD, PTC_BLK_P_CU, PTC_BLK_P_RS1, PTC_BLK_P_RS2,
+       PTC_BLK_P_W_CONV, PTC_BLK_P_B_CONV, PTC_BLK_P_W_LIN, PTC_BLK_P_B_LIN, PTC_BLK_P_G_CPE, PTC_BLK_P_BE_CPE, PTC_BLK_P_G_N1,
+       PTC_BLK_P_BE_N1, PTC_BLK_P_W_QKV, PTC_BLK_P_B_QKV, PTC_BLK_P_W_PROJ, PTC_BLK_P_B_PROJ, PTC_BLK_P_G_N2, PTC_BLK_P_BE_N2,
+       PTC_BLK_P_W_FC1, PTC_BLK_P_B_FC1, PTC_BLK_P_W_FC2, PTC_BLK_P_B_FC2,
+       PTC_BLK_P_DZ3, PTC_BLK_P_DYB3, PTC_BLK_P_WT_CONV, PTC_BLK_P_WT_LIN, PTC_BLK_P_WT_QKV, PTC_BLK_P_WT_PROJ, PTC_BLK_P_WT_FC1,
+       PTC_BLK_P_WT_FC2, PTC_BLK_P_COUNT };
+enum { PTC_BLK_O_CONV, PTC_BLK_O_LIN, PTC_BLK_O_X1, PTC_BLK_O_Y1, PTC_BLK_O_ST_CPE, PTC_BLK_O_ST_N1, PTC_BLK_O_QKV, PTC_BLK_O_ATT,
+       PTC_BLK_O_LSE, PTC_BLK_O_A, PTC_BLK_O_X2, PTC_BLK_O_Y2, PTC_BLK_O_ST_N2, PTC_BLK_O_H, PTC_BLK_O_ACT, PTC_BLK_O_M, PTC_BLK_O_X3,
+       PTC_BLK_O_XB3, PTC_BLK_O_COUNT };
+enum { PTC_BLK_G_X0, PTC_BLK_G_XC, PTC_BLK_G_W_CONV, PTC_BLK_G_B_CONV, PTC_BLK_G_W_LIN, PTC_BLK_G_B_LIN, PTC_BLK_G_G_CPE,
+       PTC_BLK_G_BE_CPE, PTC_BLK_G_G_N1, PTC_BLK_G_BE_N1, PTC_BLK_G_W_QKV, PTC_BLK_G_B_QKV, PTC_BLK_G_W_PROJ, PTC_BLK_G_B_PROJ,
+       PTC_BLK_G_G_N2, PTC_BLK_G_BE_N2, PTC_BLK_G_W_FC1, PTC_BLK_G_B_FC1, PTC_BLK_G_W_FC2, PTC_BLK_G_B_FC2,
+       PTC_BLK_S_DX2, PTC_BLK_S_DM, PTC_BLK_S_DH, PTC_BLK_S_DY2, PTC_BLK_S_DX1, PTC_BLK_S_DA, PTC_BLK_S_DATT, PTC_BLK_S_DQKV,
+       PTC_BLK_S_DY1, PTC_BLK_S_DLIN, PTC_BLK_S_DCONV, PTC_BLK_GS_COUNT };
+int ptc_ptv3_block_abi(void);
+size_t ptc_ptv3_block_workspace_bytes(int64_t n, int64_t n_pad, int c, int heads);
+int ptc_ptv3_block_fwd(const int64_t* iv, const float* fv, const void* const* in, void* const* out, ptc_stream_t stream);
+int ptc_ptv3_block_bwd(const int64_t* iv, const float* fv, const void* const* in, const void* const* sv, void* const* g,
+                       void* workspace, size_t workspace_bytes, ptc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,10 @@ _SIGNATURES = {
     "ptc_rulebook_down_count": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_rulebook_down_fill": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_spconv_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "ptc_ptv3_block_abi": (c_int, []),
+    "ptc_ptv3_block_workspace_bytes": (c_size, [c_i64, c_i64, c_int, c_int]),
+    "ptc_ptv3_block_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "ptc_ptv3_block_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_rulebook_blocks_tab_bytes": (c_size, [c_i64]),
     "ptc_rulebook_blocks": (c_int, [c_ptr, c_int, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_spconv_fwd_blk": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_int, c_int,
@@ -186,6 +190,28 @@ def require_cuda(*tensors) -> None:
 
 def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
+
+
+_blk_enums = None
+
+
+def block_enums():
+    """name -> index of the PTC_BLK_* argument tables of ptc_ptv3_block_fwd / _bwd, read from include/ptcore.h (one definition: the
+    header the library was compiled against -- lib() has checked its hash)."""
+    global _blk_enums
+    if _blk_enums is None:
+        import re
+
+        txt = open(os.path.join(HERE, "..", "include", "ptcore.h")).read()
+        out = {}
+        for body in re.findall(r"enum\s*\{([^}]*)\}", txt):
+            names = [x.strip() for x in body.replace("\n", " ").split(",") if x.strip()]
+            if names and names[0].startswith("PTC_BLK_"):
+                for i, nm in enumerate(names):
+                    out[nm[len("PTC_BLK_"):]] = i
+        out["ABI"] = int(re.search(r"#define\s+PTC_BLK_ABI\s+(\d+)", txt).group(1))
+        _blk_enums = out
+    return _blk_enums
 
 
 _probe = None

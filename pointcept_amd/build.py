@@ -43,6 +43,7 @@ HIP_SOURCES = [
     "bn.hip",
     "rope.hip",
     "evalhist.hip",
+    "block_exec.hip",
 ]
 CXX_SOURCES = ["core.cpp"]
 PROBE_SOURCES = ["host_probe.cpp"]

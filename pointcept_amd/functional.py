@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from . import config, ops
+from . import _lib, config, ops
 from ._lib import PtcoreError
 
 
@@ -752,6 +752,188 @@ def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, tra
     """act(F.batch_norm(x, ...)) over the rows of [N, C] (act in {"none", "gelu", "relu"}), statistics in
     fp32/fp64, output in x's dtype; backward recomputes the pre-activation (nothing but x is saved)."""
     return _BatchNormAct.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps), act)
+
+
+# ------------------------------------------------------------------------------------------------
+# one PT-v3m1 Block = ONE autograd Function = one C call per direction (csrc/block_exec.hip)
+# ------------------------------------------------------------------------------------------------
+_BLK_PARAMS = ("W_CONV", "B_CONV", "W_LIN", "B_LIN", "G_CPE", "BE_CPE", "G_N1", "BE_N1", "W_QKV", "B_QKV", "W_PROJ", "B_PROJ", "G_N2",
+               "BE_N2", "W_FC1", "B_FC1", "W_FC2", "B_FC2")
+_BLK_WEIGHTS = ("W_CONV", "W_LIN", "W_QKV", "W_PROJ", "W_FC1", "W_FC2")
+
+
+class _Slab:
+    """consecutive sub-tensors of one allocation (256-byte aligned pieces)"""
+
+    def __init__(self, dtype, device):
+        self.dtype, self.device, self.items, self.total = dtype, device, [], 0
+
+    def add(self, name, *shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        self.items.append((name, self.total, n, shape))
+        unit = 256 // torch.empty(0, dtype=self.dtype).element_size()
+        self.total += (n + unit - 1) // unit * unit
+
+    def alloc(self):
+        buf = torch.empty(max(self.total, 1), dtype=self.dtype, device=self.device)
+        return buf, {name: buf[off:off + n].view(shape) for name, off, n, shape in self.items}
+
+
+class _BlockFn(Function):
+    """(x3, xb3) = Block(x0, xc): the residual stream after the block (fp32) and its bf16 copy (the operand of the next
+    convolution / Linear).  `meta`: sizes, eps, tables (python object, not differentiated); `params`: the block's 18 parameter
+    tensors in _BLK_PARAMS order (qkv bias may be None)."""
+
+    @staticmethod
+    def forward(ctx, x0, xc, rs1, rs2, meta, *params):
+        import ctypes
+
+        E = _lib.block_enums()
+        L = ops.lib()
+        dt = torch.bfloat16
+        n, c = x0.shape
+        npad, heads, hid = meta["n_pad"], meta["heads"], 4 * c
+        dev = x0.device
+        x0 = x0.contiguous()
+        xc = xc.contiguous()
+        par = dict(zip(_BLK_PARAMS, params))
+        sh = {}
+        for k in _BLK_WEIGHTS:                              # 16-bit shadows [c_out][taps][c_in] (conv) / [c_out][c_in] (Linear)
+            w = par[k]
+            sh[k] = _cast_cache.get(w.reshape(w.shape[0], -1, w.shape[-1]) if w.dim() == 5 else w, dt).contiguous()
+        f32 = {k: (None if par[k] is None else par[k].float().contiguous()) for k in _BLK_PARAMS if k not in _BLK_WEIGHTS}
+        s16 = _Slab(dt, dev)
+        for nm, rows, cols in (("CONV", n, c), ("LIN", n, c), ("Y1", n, c), ("QKV", npad, 3 * c), ("ATT", npad, c), ("A", n, c), ("Y2", n, c),
+                               ("H", n, hid), ("ACT", n, hid), ("M", n, c)):
+            s16.add(nm, rows, cols)
+        s32 = _Slab(torch.float32, dev)
+        for nm, shape in (("X1", (n, c)), ("X2", (n, c)), ("ST_CPE", (2, n)), ("ST_N1", (2, n)), ("ST_N2", (2, n)), ("LSE", (heads, npad))):
+            s32.add(nm, *shape)
+        buf16, o16 = s16.alloc()
+        buf32, o32 = s32.alloc()
+        x3 = torch.empty((n, c), dtype=torch.float32, device=dev)
+        xb3 = torch.empty((n, c), dtype=dt, device=dev)
+        outs = dict(o16)
+        outs.update(o32)
+        outs["X3"], outs["XB3"] = x3, xb3
+        blk = meta["blk"]
+        iv = (ctypes.c_int64 * E["I_COUNT"])()
+        for k, v in (("ABI", E["ABI"]), ("N", n), ("NPAD", npad), ("NSEQ", meta["n_seq"]), ("C", c), ("HEADS", heads), ("DTYPE", _lib.PTC_BF16),
+                     ("A_DTYPE", _lib.dtype_code(x0)), ("PATCH", meta["patch"]), ("BLK_BM", 0 if blk is None else blk.bm),
+                     ("BLK_HCAP", 0 if blk is None else blk.hcap)):
+            iv[E["I_" + k]] = int(v)
+        fv = (ctypes.c_float * E["F_COUNT"])()
+        for k in ("SCALE", "EPS_CPE", "EPS_N1", "EPS_N2"):
+            fv[E["F_" + k]] = float(meta[k.lower()])
+        pin = (ctypes.c_void_p * E["P_COUNT"])()
+        tabs = meta["tabs"]
+        ins = {"X0": x0, "XC": xc, "NBR": meta["nbr"], "BLK_TAB": None if blk is None else blk.tab, "BLK_HID": None if blk is None else blk.hid,
+               "BLK_HCNT": None if blk is None else blk.hcnt, "T_QKV_FWD": tabs[0], "T_QKV_BWD": tabs[1], "T_PROJ_FWD": tabs[2],
+               "T_PROJ_BWD": tabs[3], "CU": meta["cu"], "RS1": rs1, "RS2": rs2}
+        ins.update(sh)
+        ins.update(f32)
+        for k, t in ins.items():
+            pin[E["P_" + k]] = _lib.ptr(t) or None
+        pout = (ctypes.c_void_p * E["O_COUNT"])()
+        for k, t in outs.items():
+            pout[E["O_" + k]] = t.data_ptr()
+        _lib.check(L.ptc_ptv3_block_fwd(iv, fv, pin, pout, ops.stream_ptr()), "ptc_ptv3_block_fwd")
+        ctx.save_for_backward(x0, xc, rs1, rs2, buf16, buf32, x3, xb3, *[sh[k] for k in _BLK_WEIGHTS], *[f32[k] for k in f32])
+        ctx.meta, ctx.layout16, ctx.layout32 = meta, s16.items, s32.items
+        ctx.f32_names = list(f32)
+        ctx.param_shapes = [None if p is None else (tuple(p.shape), p.dtype) for p in params]
+        ctx.set_materialize_grads(False)
+        return x3, xb3
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz3, dyb3):
+        import ctypes
+
+        n_par = len(_BLK_PARAMS)
+        if dz3 is None and dyb3 is None:
+            return (None,) * (5 + n_par)
+        E = _lib.block_enums()
+        L = ops.lib()
+        sv = ctx.saved_tensors
+        x0, xc, rs1, rs2, buf16, buf32, x3, xb3 = sv[:8]
+        sh = dict(zip(_BLK_WEIGHTS, sv[8:8 + len(_BLK_WEIGHTS)]))
+        f32 = dict(zip(ctx.f32_names, sv[8 + len(_BLK_WEIGHTS):]))
+        meta = ctx.meta
+        dt = torch.bfloat16
+        n, c = x0.shape
+        npad, heads, hid = meta["n_pad"], meta["heads"], 4 * c
+        dev = x0.device
+        outs = {name: buf16[off:off + cnt].view(shape) for name, off, cnt, shape in ctx.layout16}
+        outs.update({name: buf32[off:off + cnt].view(shape) for name, off, cnt, shape in ctx.layout32})
+        outs["X3"], outs["XB3"] = x3, xb3
+        # transposed weight layouts of the input-gradient GEMMs (all layers' layouts are refreshed in one launch per step)
+        wt = {"WT_CONV": _cast_cache.layout(sh["W_CONV"], "mirror"), "WT_LIN": _cast_cache.layout(sh["W_LIN"], "mirror"),
+              "WT_QKV": _cast_cache.layout(sh["W_QKV"], "repeat", 2), "WT_PROJ": _cast_cache.layout(sh["W_PROJ"], "mirror"),
+              "WT_FC1": _cast_cache.layout(sh["W_FC1"], "mirror"), "WT_FC2": _cast_cache.layout(sh["W_FC2"], "mirror")}
+        if any(v is None for v in wt.values()):
+            raise PtcoreError("_BlockFn.backward: a weight shadow left the cast cache between forward and backward")
+        # gradients of the parameters: one fp32 slab, views in the parameters' shapes
+        gs = _Slab(torch.float32, dev)
+        for k, spec in zip(_BLK_PARAMS, ctx.param_shapes):
+            if spec is not None:
+                gs.add("G_" + k, *spec[0])
+        gs.add("S_DX2", n, c)
+        gs.add("S_DX1", n, c)
+        if x0.dtype == torch.float32:
+            gs.add("G_X0", n, c)
+        gbuf, g32 = gs.alloc()
+        ss = _Slab(dt, dev)
+        for nm, rows, cols in (("S_DM", n, c), ("S_DH", n, hid), ("S_DY2", n, c), ("S_DA", n, c), ("S_DATT", npad, c), ("S_DQKV", npad, 3 * c),
+                               ("S_DY1", n, c), ("S_DLIN", n, c), ("S_DCONV", n, c), ("G_XC", n, c)):
+            ss.add(nm, rows, cols)
+        if x0.dtype != torch.float32:
+            ss.add("G_X0", n, c)
+        sbuf, g16 = ss.alloc()
+        blk = meta["blk"]
+        iv = (ctypes.c_int64 * E["I_COUNT"])()
+        for k, v in (("ABI", E["ABI"]), ("N", n), ("NPAD", npad), ("NSEQ", meta["n_seq"]), ("C", c), ("HEADS", heads), ("DTYPE", _lib.PTC_BF16),
+                     ("A_DTYPE", _lib.dtype_code(x0)), ("PATCH", meta["patch"]), ("BLK_BM", 0 if blk is None else blk.bm),
+                     ("BLK_HCAP", 0 if blk is None else blk.hcap)):
+            iv[E["I_" + k]] = int(v)
+        fv = (ctypes.c_float * E["F_COUNT"])()
+        for k in ("SCALE", "EPS_CPE", "EPS_N1", "EPS_N2"):
+            fv[E["F_" + k]] = float(meta[k.lower()])
+        tabs = meta["tabs"]
+        dz3c = None if dz3 is None else dz3.float().contiguous()
+        dyb3c = None if dyb3 is None else dyb3.to(dt).contiguous()
+        ins = {"X0": x0, "XC": xc, "NBR": meta["nbr"], "BLK_TAB": None if blk is None else blk.tab, "BLK_HID": None if blk is None else blk.hid,
+               "BLK_HCNT": None if blk is None else blk.hcnt, "T_QKV_FWD": tabs[0], "T_QKV_BWD": tabs[1], "T_PROJ_FWD": tabs[2],
+               "T_PROJ_BWD": tabs[3], "CU": meta["cu"], "RS1": rs1, "RS2": rs2, "DZ3": dz3c, "DYB3": dyb3c}
+        ins.update(sh)
+        ins.update(f32)
+        ins.update(wt)
+        pin = (ctypes.c_void_p * E["P_COUNT"])()
+        for k, t in ins.items():
+            pin[E["P_" + k]] = _lib.ptr(t) or None
+        psv = (ctypes.c_void_p * E["O_COUNT"])()
+        for k, t in outs.items():
+            psv[E["O_" + k]] = t.data_ptr()
+        pg = (ctypes.c_void_p * E["GS_COUNT"])()
+        for k, t in g32.items():
+            pg[E[k]] = t.data_ptr()
+        for k, t in g16.items():
+            pg[E[k]] = t.data_ptr()
+        nbytes = int(L.ptc_ptv3_block_workspace_bytes(n, npad, c, heads))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(L.ptc_ptv3_block_bwd(iv, fv, pin, psv, pg, _lib.ptr(ws), nbytes, ops.stream_ptr()), "ptc_ptv3_block_bwd")
+        dx0 = g32["G_X0"] if x0.dtype == torch.float32 else g16["G_X0"]
+        grads = []
+        for k, spec in zip(_BLK_PARAMS, ctx.param_shapes):
+            grads.append(None if spec is None else (g32["G_" + k] if spec[1] == torch.float32 else g32["G_" + k].to(spec[1])))
+        return (dx0, g16["G_XC"], None, None, None, *grads)
+
+
+def ptv3_block(x0, xc, rs1, rs2, meta, params):
+    """One PT-v3m1 Block through csrc/block_exec.hip -> (x3 fp32, xb3 bf16).  See point_transformer_v3.Block._forward_exec."""
+    return _BlockFn.apply(x0, xc, rs1, rs2, meta, *params)
 
 
 # ------------------------------------------------------------------------------------------------

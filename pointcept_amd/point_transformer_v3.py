@@ -433,9 +433,53 @@ class Block(PointModule):
             PF.register_cast_twin(x3, xb)     # ... and the operand of any Linear that reads the stream (pooling, unpooling, head)
         return point
 
+    def _exec_ok(self, point) -> bool:
+        """the whole block as one C call per direction (csrc/block_exec.hip): the bench configuration class -- bf16 autocast, pre-norm,
+        LayerNorm joints, the window-attention kernel with the gather tables folded into qkv / proj, fused MLP, <= 256 channels"""
+        a = self.attn
+        return (config.EXEC_BLOCK and type(self) is Block and type(a) is SerializedAttention and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and self.channels % 16 == 0 and self.channels <= 256
+                and a.enable_flash and not a.enable_rpe and a.num_heads * 16 == self.channels and config.FUSE_GATHER and config.FUSE_MLP
+                and type(self.cpe[0]) is spconv.SubMConv3d and self.cpe[0].kernel_size[0] == 3 and self.cpe[0].bias is not None
+                and type(self.cpe[1]) is PNN.Linear and self.cpe[1].bias is not None and type(self.mlp[0]) is MLP
+                and type(self.mlp[0].fc1) is PNN.Linear and type(self.mlp[0].fc2) is PNN.Linear and self.mlp[0].fc1.bias is not None
+                and self.mlp[0].fc2.bias is not None and isinstance(self.mlp[0].act, nn.GELU) and getattr(self.mlp[0].act, "approximate", "none") == "none"
+                and self.mlp[0].fc1.out_features == 4 * self.channels
+                and getattr(self.mlp[0].drop, "p", 0.0) == 0.0 and getattr(a.proj_drop, "p", 0.0) == 0.0 and a.proj.bias is not None
+                and all(m.elementwise_affine for m in (self.cpe[2], self.norm1[0], self.norm2[0])) and point.feat.dtype in (torch.float32, torch.bfloat16))
+
+    def _forward_exec(self, point: Point):
+        sc = point.sparse_conv_feat
+        conv = self.cpe[0]
+        nbr, rep, blocks = conv.tables(sc)
+        if rep is not None:                      # duplicate voxels (Mix3D): the adjoint needs the merge passes of the composed path
+            return None
+        a = self.attn
+        _, _, cu = a.get_padding_and_inverse(point)
+        tabs = a._index_maps(point)[4]
+        if tabs is None:
+            return None
+        x0 = point.feat
+        n, c = x0.shape
+        xc = sc.features if sc.features.dtype == torch.bfloat16 else sc.features.to(torch.bfloat16)
+        blk = None if blocks is None else blocks.get(c, c, torch.bfloat16)
+        meta = dict(n_pad=int(tabs[0].shape[1]), n_seq=int(cu.numel()) - 1, heads=a.num_heads, patch=int(a.patch_size), scale=float(a.scale),
+                    eps_cpe=self.cpe[2].eps, eps_n1=self.norm1[0].eps, eps_n2=self.norm2[0].eps, nbr=nbr, blk=blk, tabs=tabs, cu=cu)
+        m = self.mlp[0]
+        params = (conv.weight, conv.bias, self.cpe[1].weight, self.cpe[1].bias, self.cpe[2].weight, self.cpe[2].bias, self.norm1[0].weight,
+                  self.norm1[0].bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, self.norm2[0].weight, self.norm2[0].bias,
+                  m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+        x3, xb = PF.ptv3_block(x0, xc, self._row_keep_scale(n, x0.device), self._row_keep_scale(n, x0.device), meta, params)
+        point.feat = x3
+        point.sparse_conv_feat = sc.replace_feature(xb)
+        PF.register_cast_twin(x3, xb)
+        return point
+
     def forward(self, point: Point):
         if self._fusable(point):
-            out = self._forward_fused(point)
+            out = self._forward_exec(point) if self._exec_ok(point) else None
+            if out is None:
+                out = self._forward_fused(point)
             if out is not None:
                 return out
         shortcut = point.feat

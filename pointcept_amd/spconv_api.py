@@ -213,17 +213,10 @@ def _coord_bits(spatial_shape) -> int:
 class SubMConv3d(_SparseConvolution):
     _kind = "subm"
 
-    def forward(self, x: SparseConvTensor):
+    def tables(self, x: SparseConvTensor):
+        """(gather table [k^3, N] int32, representative rows of duplicate voxels | None, ops.BlockProvider | None) of this convolution
+        on x: built on first use of the indice_key, cached on the tensor (the reference's indice_dict)."""
         k = self.kernel_size[0]
-        if k == 1:  # spconv short-circuits 1x1x1 submanifold convs to a GEMM
-            w2 = self.weight.reshape(self.out_channels, self.in_channels)
-            f = x.features
-            _require_gpu(f, "SubMConv3d")
-            if f.shape[0] == 0:
-                return x.replace_feature(f.new_zeros((0, self.out_channels)))
-            return x.replace_feature(PF.linear(f, w2, self.bias))   # the engine's tall-skinny GEMM kernels
-        if x.indices.shape[0] == 0:
-            return x.replace_feature(x.features.new_zeros((0, self.out_channels)))
         key = ("subm", self.indice_key, k)
         rb = x.indice_dict.get(key) if self.indice_key is not None else None
         if rb is None:
@@ -237,6 +230,20 @@ class SubMConv3d(_SparseConvolution):
             blocks = x.indice_dict.get(bkey)
             if blocks is None or blocks.nbr is not rb:
                 blocks = x.indice_dict[bkey] = ops.BlockProvider(rb)
+        return rb, rep, blocks
+
+    def forward(self, x: SparseConvTensor):
+        k = self.kernel_size[0]
+        if k == 1:  # spconv short-circuits 1x1x1 submanifold convs to a GEMM
+            w2 = self.weight.reshape(self.out_channels, self.in_channels)
+            f = x.features
+            _require_gpu(f, "SubMConv3d")
+            if f.shape[0] == 0:
+                return x.replace_feature(f.new_zeros((0, self.out_channels)))
+            return x.replace_feature(PF.linear(f, w2, self.bias))   # the engine's tall-skinny GEMM kernels
+        if x.indices.shape[0] == 0:
+            return x.replace_feature(x.features.new_zeros((0, self.out_channels)))
+        rb, rep, blocks = self.tables(x)
         return x.replace_feature(PF.sparse_conv(x.features, self._w(), self.bias, rb, rb, True, rep, rep, blocks))
 
 

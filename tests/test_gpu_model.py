@@ -70,6 +70,49 @@ def test_ptv3_tiny_forward_matches_reference_golden_and_oracle(cuda):
     assert torch.equal(pe.cu_seqlens_key.cpu(), po.cu_seqlens_key)
 
 
+def test_block_executor_step_is_bit_identical_to_the_composed_step(cuda, monkeypatch):
+    """config.EXEC_BLOCK (default on): every PT-v3m1 Block as one C call per direction (csrc/block_exec.hip) against the same
+    model with the Blocks composed from ~16 autograd Functions each -- bf16 autocast, drop_path > 0 (the seeded device RNG draws the
+    same DropPath masks), ragged two-scene batch: loss and EVERY parameter gradient must be identical (same kernels, same operands,
+    same order); and the number of Blocks the executor actually served is checked, so that a silent fall-back cannot pass."""
+    from pointcept_amd import config, synthetic
+    from pointcept_amd import functional as PF
+    from pointcept_amd.segmentor import DefaultSegmentorV2
+
+    cfg = dict(TINY, enc_patch_size=(128,) * 5, dec_patch_size=(128,) * 4, enc_depths=(2, 1, 1, 1, 1), drop_path=0.3)
+    _, eng_b = _models(cfg, seed=5)
+    torch.manual_seed(1)
+    eng = DefaultSegmentorV2(20, 64, eng_b).to(cuda).train()
+    batch = synthetic.to_torch(synthetic.collate([synthetic.indoor_scene(41, 5000), synthetic.indoor_scene(42, 900)]), cuda)
+    calls = {"n": 0}
+    real = PF.ptv3_block
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(PF, "ptv3_block", counted)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(config, "EXEC_BLOCK", on)
+        calls["n"] = 0
+        eng.zero_grad(set_to_none=True)
+        for m_ in eng.modules():                                   # same BatchNorm running-statistics start
+            if isinstance(m_, torch.nn.BatchNorm1d):
+                m_.reset_running_stats()
+        torch.manual_seed(9)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = eng(dict(batch))["loss"]
+        loss.backward()
+        res[on] = (float(loss.detach()), {k: p.grad.clone() for k, p in eng.named_parameters()}, calls["n"])
+    n_blocks = sum(1 for m_ in eng.modules() if type(m_).__name__ == "Block")
+    n_wide = sum(1 for m_ in eng.modules() if type(m_).__name__ == "Block" and m_.channels > 256)
+    assert res[True][2] == n_blocks - n_wide and res[False][2] == 0, (res[True][2], res[False][2], n_blocks, n_wide)
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    for k in res[True][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+
+
 def test_ptv3_two_scenes_forward_backward_vs_oracle(cuda):
     """ragged batch (one scene shorter than a patch at deep stages), train mode (BatchNorm batch
     statistics, pooling-order shuffles from the seeded CPU RNG), loss + every parameter gradient."""

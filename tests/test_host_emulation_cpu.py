@@ -350,4 +350,88 @@ def test_pending_rope_kernel_gpu_test_body_on_the_emulation():
         P.test_rope3d_xyz_kernel_matches_reference_golden_and_inverts(torch.device("cpu"))
 
 
+def test_block_executor_is_bit_identical_to_the_composed_path_on_the_emulation(monkeypatch):
+    """csrc/block_exec.hip (one C call per PT-v3m1 Block and direction) against the same Block composed from the functional layer's
+    autograd Functions, every kernel REAL on the host emulation: the two outputs (fp32 stream, bf16 copy), the gradients of both
+    inputs and of all 18 parameters must be IDENTICAL -- 32 channels with DropPath row scales and an fp32 stream, 64 channels with a
+    bf16 stream (first block of a stage) and the block-staged convolution (conv7)."""
+    import numpy as np
 
+    import emu_backend
+    from oracle import maps as omaps
+    from oracle import sfc as osfc
+    from pointcept_amd import functional as PF
+    from pointcept_amd import ops, synthetic
+
+    if not emu_backend.available():
+        pytest.skip("no host clang++ under /opt/rocm")
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))      # the weight-shadow cache only serves CUDA tensors
+    PF.invalidate_weight_casts()
+
+    def run(n_pts, C, H, patch, a_dtype, with_rs, blk_tables):
+        b = synthetic.indoor_batch(2, n_pts)
+        bt = omaps.offset2batch(b["offset"]); gc = b["grid_coord"]
+        depth = int(gc.max()+1).bit_length()
+        code = osfc.encode_c(gc, bt, depth, ("hilbert",))[0]
+        o = np.argsort(code, kind="stable")
+        ind = np.concatenate([bt[o,None], gc[o]],1).astype(np.int32)
+        n = ind.shape[0]
+        g = torch.Generator().manual_seed(C)
+        def P(*s, scale=1.0): return (torch.randn(*s, generator=g)*scale).requires_grad_(True)
+        params = [P(C,3,3,3,C,scale=(27*C)**-0.5), P(C,scale=0.1), P(C,C,scale=C**-0.5), P(C,scale=0.1), (1+P(C,scale=0.1)).detach().requires_grad_(True), P(C,scale=0.1),
+                  (1+P(C,scale=0.1)).detach().requires_grad_(True), P(C,scale=0.1), P(3*C,C,scale=C**-0.5), P(3*C,scale=0.1), P(C,C,scale=C**-0.5), P(C,scale=0.1),
+                  (1+P(C,scale=0.1)).detach().requires_grad_(True), P(C,scale=0.1), P(4*C,C,scale=C**-0.5), P(4*C,scale=0.1), P(C,4*C,scale=(4*C)**-0.5), P(C,scale=0.1)]
+        x0 = torch.randn(n, C, generator=g).to(a_dtype)
+        xc = torch.randn(n, C, generator=g).to(torch.bfloat16)
+        with emu_backend.emulated_ops():
+            nbr = ops.rulebook_subm(torch.from_numpy(ind), 3)
+            offs = torch.from_numpy(b["offset"].astype(np.int64))
+            order = torch.from_numpy(np.argsort(np.random.default_rng(1).permutation(n)))   # some serialization order
+            inverse = torch.empty_like(order); inverse[order] = torch.arange(n)
+            # per-scene order must keep scenes contiguous: build from a key (batch, random)
+            key = torch.from_numpy(bt[o].astype(np.int64))*10**9 + torch.from_numpy(np.random.default_rng(2).integers(0,10**8,n))
+            order = torch.argsort(key); inverse = torch.empty_like(order); inverse[order]=torch.arange(n)
+            pad, unpad, cu, dup = ops.patch_pad_maps(offs, [int(v) for v in offs], patch)
+            tabs = ops.attn_tables(order, inverse, pad, unpad, dup)
+            blk = ops.BlockTables(nbr) if blk_tables else None
+            rs1 = (torch.rand(n, generator=g) > 0.3).float()/0.7 if with_rs else None
+            rs2 = (torch.rand(n, generator=g) > 0.3).float()/0.7 if with_rs else None
+            meta = dict(n_pad=int(tabs[0].shape[1]), n_seq=int(cu.numel())-1, heads=H, patch=patch, scale=16**-0.5, eps_cpe=1e-5, eps_n1=1e-5, eps_n2=1e-5,
+                        nbr=nbr, blk=blk, tabs=tabs, cu=cu)
+            dz = torch.randn(n, C, generator=g); dyb = torch.randn(n, C, generator=g).to(torch.bfloat16)
+            res = []
+            for mode in ("exec", "composed"):
+                for p in params: p.grad = None
+                x0r = x0.clone().requires_grad_(True); xcr = xc.clone().requires_grad_(True)
+                if mode == "exec":
+                    x3, xb = PF.ptv3_block(x0r, xcr, rs1, rs2, meta, params)
+                else:
+                    (wc,bc,wl,bl,gcp,bcp,g1,b1,wq,bq,wp,bp,g2,b2,w1,bb1,w2,bb2) = params
+                    class LN:  # minimal norm holder
+                        def __init__(s,w,b): s.weight,s.bias,s.eps=w,b,1e-5
+                    class BP:
+                        def get(s,*a): return blk
+                    conv = PF.sparse_conv(xcr, wc.reshape(C,27,C), bc, nbr, nbr, True, None, None, BP() if blk is not None else None)
+                    lin = PF.linear(conv, wl, bl)
+                    x1, y1 = PF.add_norm(lin, x0r, None, LN(gcp,bcp), LN(g1,b1), torch.bfloat16)
+                    qkv = PF.linear(y1, wq, bq, tabs[0], tabs[1])
+                    out = PF.attn_varlen_qkvpacked(qkv.reshape(-1,3,H,16), cu, patch, 16**-0.5)
+                    a = PF.linear(out.reshape(-1,C), wp, bp, tabs[2], tabs[3])
+                    x2, y2 = PF.add_norm(a, x1, rs1, None, LN(g2,b2), torch.bfloat16)
+                    m = PF.mlp_gelu(y2, w1, bb1, w2, bb2)
+                    x3, xb = PF.add_norm(m, x2, rs2, None, None, torch.bfloat16)
+                torch.autograd.backward([x3, xb], [dz, dyb])
+                res.append([x3.detach().clone(), xb.detach().clone(), x0r.grad.clone(), xcr.grad.clone()] + [p.grad.clone() for p in params])
+        names = ["x3","xb3","dx0","dxc"]+list(PF._BLK_PARAMS)
+        worst = 0.0
+        for nm,a_,b_ in zip(names,res[0],res[1]):
+            d = float((a_.float()-b_.float()).abs().max()); worst=max(worst,d)
+            if d != 0.0: print("   DIFF", nm, d, float(b_.float().abs().max()))
+        assert worst == 0.0
+        print(f"n={n} C={C} H={H} patch={patch} a={a_dtype} rs={with_rs} blk={blk_tables}: max |exec - composed| over outputs and 22 gradients = {worst}")
+
+    try:
+        run(700, 32, 2, 128, torch.float32, True, False)
+        run(2300, 64, 4, 128, torch.bfloat16, False, True)
+    finally:
+        PF.invalidate_weight_casts()

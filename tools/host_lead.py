@@ -11,8 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-args = bench.parse() if hasattr(bench, "parse") else None
-sys.argv = [sys.argv[0]]
+import argparse
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scenes", type=int, default=8)
+ap.add_argument("--points", type=int, default=102400)
+mine = ap.parse_args()
+sys.argv = [sys.argv[0], "--batch", str(mine.scenes), "--points", str(mine.points)]
 args = bench.parse()
 dev = torch.device("cuda:0")
 torch.manual_seed(1234)
@@ -30,5 +35,8 @@ for _ in range(8):
     t2 = time.perf_counter()
     enq.append((t1 - t0) * 1e3)
     tot.append((t2 - t0) * 1e3)
+from pointcept_amd import config  # noqa: E402
+
+print(f"{mine.scenes} x {mine.points} voxels, block executor {'on' if config.EXEC_BLOCK else 'off'}: ", end="")
 print(f"host enqueue per step: mean {sum(enq) / len(enq):.1f} ms (min {min(enq):.1f}); step complete: mean {sum(tot) / len(tot):.1f} ms; "
       f"host lead {sum(tot) / len(tot) - sum(enq) / len(enq):.1f} ms; host syncs inside the step make enqueue >= the GPU time up to the last sync")
