@@ -167,7 +167,9 @@ def check(rc: int, what: str) -> None:
 
 
 def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # the raw HIP stream of torch's current stream on the current device (torch.cuda.current_stream().cuda_stream builds two
+    # python objects per call: ~10 us x ~130 calls per step in the round-3 host profile, profiles/r03_i_host_profile.txt)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def dtype_code(t: torch.Tensor) -> int:

@@ -762,23 +762,73 @@ _BLK_PARAMS = ("W_CONV", "B_CONV", "W_LIN", "B_LIN", "G_CPE", "BE_CPE", "G_N1", 
 _BLK_WEIGHTS = ("W_CONV", "W_LIN", "W_QKV", "W_PROJ", "W_FC1", "W_FC2")
 
 
-class _Slab:
-    """consecutive sub-tensors of one allocation (256-byte aligned pieces)"""
+def _blk_layout(items, elem_bytes):
+    """[(name, rows, cols)] -> ({name: (byte offset, rows, cols)}, total elements): consecutive 256-byte aligned pieces of one allocation"""
+    unit, off, out = 256 // elem_bytes, 0, {}
+    for name, rows, cols in items:
+        out[name] = (off * elem_bytes, int(rows), int(cols))
+        off += (int(rows) * int(cols) + unit - 1) // unit * unit
+    return out, max(off, 1)
 
-    def __init__(self, dtype, device):
-        self.dtype, self.device, self.items, self.total = dtype, device, [], 0
 
-    def add(self, name, *shape):
-        n = 1
-        for d in shape:
-            n *= int(d)
-        self.items.append((name, self.total, n, shape))
-        unit = 256 // torch.empty(0, dtype=self.dtype).element_size()
-        self.total += (n + unit - 1) // unit * unit
+_blk_plans = {}
 
-    def alloc(self):
-        buf = torch.empty(max(self.total, 1), dtype=self.dtype, device=self.device)
-        return buf, {name: buf[off:off + n].view(shape) for name, off, n, shape in self.items}
+
+def _blk_plan(n, npad, c, heads, x0_f32):
+    """pointer-table layout of one Block call, cached per shape: byte offsets of every saved activation / scratch gradient inside
+    the slabs, as (table index, offset) lists -- the per-call work is then two allocations and ~45 integer stores per direction"""
+    key = (n, npad, c, heads, x0_f32)
+    p = _blk_plans.get(key)
+    if p is not None:
+        return p
+    E = _lib.block_enums()
+    hid = 4 * c
+    l16, t16 = _blk_layout([("CONV", n, c), ("LIN", n, c), ("Y1", n, c), ("QKV", npad, 3 * c), ("ATT", npad, c), ("A", n, c), ("Y2", n, c), ("H", n, hid),
+                            ("ACT", n, hid), ("M", n, c)], 2)
+    l32, t32 = _blk_layout([("X1", n, c), ("X2", n, c), ("ST_CPE", 2, n), ("ST_N1", 2, n), ("ST_N2", 2, n), ("LSE", heads, npad)], 4)
+    shapes = {"W_CONV": (c, 27, c), "B_CONV": (c,), "W_LIN": (c, c), "B_LIN": (c,), "G_CPE": (c,), "BE_CPE": (c,), "G_N1": (c,), "BE_N1": (c,),
+              "W_QKV": (3 * c, c), "B_QKV": (3 * c,), "W_PROJ": (c, c), "B_PROJ": (c,), "G_N2": (c,), "BE_N2": (c,), "W_FC1": (hid, c), "B_FC1": (hid,),
+              "W_FC2": (c, hid), "B_FC2": (c,)}
+    g_items = [("G_" + k, 1, int(torch.Size(shapes[k]).numel())) for k in _BLK_PARAMS] + [("S_DX2", n, c), ("S_DX1", n, c)]
+    if x0_f32:
+        g_items.append(("G_X0", n, c))
+    lg, tg = _blk_layout(g_items, 4)
+    s_items = [("S_DM", n, c), ("S_DH", n, hid), ("S_DY2", n, c), ("S_DA", n, c), ("S_DATT", npad, c), ("S_DQKV", npad, 3 * c), ("S_DY1", n, c),
+               ("S_DLIN", n, c), ("S_DCONV", n, c), ("G_XC", n, c)]
+    if not x0_f32:
+        s_items.append(("G_X0", n, c))
+    ls, ts = _blk_layout(s_items, 2)
+    p = dict(E=E, t16=t16, t32=t32, tg=tg, ts=ts,
+             o16=[(E["O_" + k], v[0]) for k, v in l16.items()], o32=[(E["O_" + k], v[0]) for k, v in l32.items()],
+             g32=[(E[k], v[0]) for k, v in lg.items()], g16=[(E[k], v[0]) for k, v in ls.items()],
+             gparam={k: (lg["G_" + k][0] // 4, int(torch.Size(shapes[k]).numel())) for k in _BLK_PARAMS},
+             gx0=(lg["G_X0"][0] // 4 if x0_f32 else ls["G_X0"][0] // 2), gxc=ls["G_XC"][0] // 2,
+             ws=None)
+    if len(_blk_plans) > 256:
+        _blk_plans.clear()
+    _blk_plans[key] = p
+    return p
+
+
+def _blk_tables(E, x0, meta):
+    import ctypes
+
+    n, c = x0.shape
+    blk = meta["blk"]
+    iv = (ctypes.c_int64 * E["I_COUNT"])()
+    iv[E["I_ABI"]], iv[E["I_N"]], iv[E["I_NPAD"]], iv[E["I_NSEQ"]], iv[E["I_C"]] = E["ABI"], n, meta["n_pad"], meta["n_seq"], c
+    iv[E["I_HEADS"]], iv[E["I_DTYPE"]], iv[E["I_A_DTYPE"]], iv[E["I_PATCH"]] = meta["heads"], _lib.PTC_BF16, _lib.dtype_code(x0), meta["patch"]
+    iv[E["I_BLK_BM"]], iv[E["I_BLK_HCAP"]] = (0, 0) if blk is None else (blk.bm, blk.hcap)
+    fv = (ctypes.c_float * E["F_COUNT"])()
+    fv[E["F_SCALE"]], fv[E["F_EPS_CPE"]], fv[E["F_EPS_N1"]], fv[E["F_EPS_N2"]] = meta["scale"], meta["eps_cpe"], meta["eps_n1"], meta["eps_n2"]
+    pin = (ctypes.c_void_p * E["P_COUNT"])()
+    tabs = meta["tabs"]
+    pin[E["P_NBR"]], pin[E["P_CU"]] = meta["nbr"].data_ptr(), meta["cu"].data_ptr()
+    pin[E["P_T_QKV_FWD"]], pin[E["P_T_QKV_BWD"]] = tabs[0].data_ptr(), tabs[1].data_ptr()
+    pin[E["P_T_PROJ_FWD"]], pin[E["P_T_PROJ_BWD"]] = tabs[2].data_ptr(), tabs[3].data_ptr()
+    if blk is not None:
+        pin[E["P_BLK_TAB"]], pin[E["P_BLK_HID"]], pin[E["P_BLK_HCNT"]] = blk.tab.data_ptr(), blk.hid.data_ptr(), blk.hcnt.data_ptr()
+    return iv, fv, pin
 
 
 class _BlockFn(Function):
@@ -788,62 +838,51 @@ class _BlockFn(Function):
 
     @staticmethod
     def forward(ctx, x0, xc, rs1, rs2, meta, *params):
-        import ctypes
-
-        E = _lib.block_enums()
-        L = ops.lib()
         dt = torch.bfloat16
         n, c = x0.shape
-        npad, heads, hid = meta["n_pad"], meta["heads"], 4 * c
+        npad, heads = meta["n_pad"], meta["heads"]
         dev = x0.device
         x0 = x0.contiguous()
         xc = xc.contiguous()
-        par = dict(zip(_BLK_PARAMS, params))
-        sh = {}
-        for k in _BLK_WEIGHTS:                              # 16-bit shadows [c_out][taps][c_in] (conv) / [c_out][c_in] (Linear)
-            w = par[k]
-            sh[k] = _cast_cache.get(w.reshape(w.shape[0], -1, w.shape[-1]) if w.dim() == 5 else w, dt).contiguous()
-        f32 = {k: (None if par[k] is None else par[k].float().contiguous()) for k in _BLK_PARAMS if k not in _BLK_WEIGHTS}
-        s16 = _Slab(dt, dev)
-        for nm, rows, cols in (("CONV", n, c), ("LIN", n, c), ("Y1", n, c), ("QKV", npad, 3 * c), ("ATT", npad, c), ("A", n, c), ("Y2", n, c),
-                               ("H", n, hid), ("ACT", n, hid), ("M", n, c)):
-            s16.add(nm, rows, cols)
-        s32 = _Slab(torch.float32, dev)
-        for nm, shape in (("X1", (n, c)), ("X2", (n, c)), ("ST_CPE", (2, n)), ("ST_N1", (2, n)), ("ST_N2", (2, n)), ("LSE", (heads, npad))):
-            s32.add(nm, *shape)
-        buf16, o16 = s16.alloc()
-        buf32, o32 = s32.alloc()
+        plan = _blk_plan(n, npad, c, heads, x0.dtype == torch.float32)
+        E = plan["E"]
+        iv, fv, pin = _blk_tables(E, x0, meta)
+        keep = []                                            # tensors the pointer table names (alive until saved / returned)
+        for k, p in zip(_BLK_PARAMS, params):
+            if p is None:
+                continue
+            if k in _BLK_WEIGHTS:                            # 16-bit shadows [c_out][taps][c_in] (conv) / [c_out][c_in] (Linear)
+                t = _cast_cache.get(p.reshape(p.shape[0], -1, p.shape[-1]) if p.dim() == 5 else p, dt)
+            else:
+                t = p if p.dtype == torch.float32 else p.float()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            keep.append(t)
+            pin[E["P_" + k]] = t.data_ptr()
+        pin[E["P_X0"]], pin[E["P_XC"]] = x0.data_ptr(), xc.data_ptr()
+        if rs1 is not None:
+            pin[E["P_RS1"]] = rs1.data_ptr()
+        if rs2 is not None:
+            pin[E["P_RS2"]] = rs2.data_ptr()
+        buf16 = torch.empty(plan["t16"], dtype=dt, device=dev)
+        buf32 = torch.empty(plan["t32"], dtype=torch.float32, device=dev)
         x3 = torch.empty((n, c), dtype=torch.float32, device=dev)
         xb3 = torch.empty((n, c), dtype=dt, device=dev)
-        outs = dict(o16)
-        outs.update(o32)
-        outs["X3"], outs["XB3"] = x3, xb3
-        blk = meta["blk"]
-        iv = (ctypes.c_int64 * E["I_COUNT"])()
-        for k, v in (("ABI", E["ABI"]), ("N", n), ("NPAD", npad), ("NSEQ", meta["n_seq"]), ("C", c), ("HEADS", heads), ("DTYPE", _lib.PTC_BF16),
-                     ("A_DTYPE", _lib.dtype_code(x0)), ("PATCH", meta["patch"]), ("BLK_BM", 0 if blk is None else blk.bm),
-                     ("BLK_HCAP", 0 if blk is None else blk.hcap)):
-            iv[E["I_" + k]] = int(v)
-        fv = (ctypes.c_float * E["F_COUNT"])()
-        for k in ("SCALE", "EPS_CPE", "EPS_N1", "EPS_N2"):
-            fv[E["F_" + k]] = float(meta[k.lower()])
-        pin = (ctypes.c_void_p * E["P_COUNT"])()
-        tabs = meta["tabs"]
-        ins = {"X0": x0, "XC": xc, "NBR": meta["nbr"], "BLK_TAB": None if blk is None else blk.tab, "BLK_HID": None if blk is None else blk.hid,
-               "BLK_HCNT": None if blk is None else blk.hcnt, "T_QKV_FWD": tabs[0], "T_QKV_BWD": tabs[1], "T_PROJ_FWD": tabs[2],
-               "T_PROJ_BWD": tabs[3], "CU": meta["cu"], "RS1": rs1, "RS2": rs2}
-        ins.update(sh)
-        ins.update(f32)
-        for k, t in ins.items():
-            pin[E["P_" + k]] = _lib.ptr(t) or None
+        import ctypes
+
         pout = (ctypes.c_void_p * E["O_COUNT"])()
-        for k, t in outs.items():
-            pout[E["O_" + k]] = t.data_ptr()
-        _lib.check(L.ptc_ptv3_block_fwd(iv, fv, pin, pout, ops.stream_ptr()), "ptc_ptv3_block_fwd")
-        ctx.save_for_backward(x0, xc, rs1, rs2, buf16, buf32, x3, xb3, *[sh[k] for k in _BLK_WEIGHTS], *[f32[k] for k in f32])
-        ctx.meta, ctx.layout16, ctx.layout32 = meta, s16.items, s32.items
-        ctx.f32_names = list(f32)
-        ctx.param_shapes = [None if p is None else (tuple(p.shape), p.dtype) for p in params]
+        b16, b32 = buf16.data_ptr(), buf32.data_ptr()
+        for idx, off in plan["o16"]:
+            pout[idx] = b16 + off
+        for idx, off in plan["o32"]:
+            pout[idx] = b32 + off
+        pout[E["O_X3"]], pout[E["O_XB3"]] = x3.data_ptr(), xb3.data_ptr()
+        _lib.check(ops.lib().ptc_ptv3_block_fwd(iv, fv, pin, pout, ops.stream_ptr()), "ptc_ptv3_block_fwd")
+        ctx.save_for_backward(x0, xc, rs1, rs2, buf16, buf32, x3, xb3, *keep)
+        ctx.meta, ctx.plan = meta, plan
+        ctx.present = [p is not None for p in params]
+        ctx.param_dtypes = [None if p is None else p.dtype for p in params]
+        ctx.param_shapes = [None if p is None else p.shape for p in params]
         ctx.set_materialize_grads(False)
         return x3, xb3
 
@@ -855,80 +894,75 @@ class _BlockFn(Function):
         n_par = len(_BLK_PARAMS)
         if dz3 is None and dyb3 is None:
             return (None,) * (5 + n_par)
-        E = _lib.block_enums()
-        L = ops.lib()
         sv = ctx.saved_tensors
         x0, xc, rs1, rs2, buf16, buf32, x3, xb3 = sv[:8]
-        sh = dict(zip(_BLK_WEIGHTS, sv[8:8 + len(_BLK_WEIGHTS)]))
-        f32 = dict(zip(ctx.f32_names, sv[8 + len(_BLK_WEIGHTS):]))
-        meta = ctx.meta
+        meta, plan = ctx.meta, ctx.plan
+        E = plan["E"]
         dt = torch.bfloat16
         n, c = x0.shape
-        npad, heads, hid = meta["n_pad"], meta["heads"], 4 * c
+        npad, heads = meta["n_pad"], meta["heads"]
         dev = x0.device
-        outs = {name: buf16[off:off + cnt].view(shape) for name, off, cnt, shape in ctx.layout16}
-        outs.update({name: buf32[off:off + cnt].view(shape) for name, off, cnt, shape in ctx.layout32})
-        outs["X3"], outs["XB3"] = x3, xb3
+        iv, fv, pin = _blk_tables(E, x0, meta)
+        it = iter(sv[8:])
+        sh = {}
+        for k, present in zip(_BLK_PARAMS, ctx.present):
+            if present:
+                t = next(it)
+                pin[E["P_" + k]] = t.data_ptr()
+                if k in _BLK_WEIGHTS:
+                    sh[k] = t
         # transposed weight layouts of the input-gradient GEMMs (all layers' layouts are refreshed in one launch per step)
-        wt = {"WT_CONV": _cast_cache.layout(sh["W_CONV"], "mirror"), "WT_LIN": _cast_cache.layout(sh["W_LIN"], "mirror"),
-              "WT_QKV": _cast_cache.layout(sh["W_QKV"], "repeat", 2), "WT_PROJ": _cast_cache.layout(sh["W_PROJ"], "mirror"),
-              "WT_FC1": _cast_cache.layout(sh["W_FC1"], "mirror"), "WT_FC2": _cast_cache.layout(sh["W_FC2"], "mirror")}
-        if any(v is None for v in wt.values()):
-            raise PtcoreError("_BlockFn.backward: a weight shadow left the cast cache between forward and backward")
-        # gradients of the parameters: one fp32 slab, views in the parameters' shapes
-        gs = _Slab(torch.float32, dev)
-        for k, spec in zip(_BLK_PARAMS, ctx.param_shapes):
-            if spec is not None:
-                gs.add("G_" + k, *spec[0])
-        gs.add("S_DX2", n, c)
-        gs.add("S_DX1", n, c)
-        if x0.dtype == torch.float32:
-            gs.add("G_X0", n, c)
-        gbuf, g32 = gs.alloc()
-        ss = _Slab(dt, dev)
-        for nm, rows, cols in (("S_DM", n, c), ("S_DH", n, hid), ("S_DY2", n, c), ("S_DA", n, c), ("S_DATT", npad, c), ("S_DQKV", npad, 3 * c),
-                               ("S_DY1", n, c), ("S_DLIN", n, c), ("S_DCONV", n, c), ("G_XC", n, c)):
-            ss.add(nm, rows, cols)
-        if x0.dtype != torch.float32:
-            ss.add("G_X0", n, c)
-        sbuf, g16 = ss.alloc()
-        blk = meta["blk"]
-        iv = (ctypes.c_int64 * E["I_COUNT"])()
-        for k, v in (("ABI", E["ABI"]), ("N", n), ("NPAD", npad), ("NSEQ", meta["n_seq"]), ("C", c), ("HEADS", heads), ("DTYPE", _lib.PTC_BF16),
-                     ("A_DTYPE", _lib.dtype_code(x0)), ("PATCH", meta["patch"]), ("BLK_BM", 0 if blk is None else blk.bm),
-                     ("BLK_HCAP", 0 if blk is None else blk.hcap)):
-            iv[E["I_" + k]] = int(v)
-        fv = (ctypes.c_float * E["F_COUNT"])()
-        for k in ("SCALE", "EPS_CPE", "EPS_N1", "EPS_N2"):
-            fv[E["F_" + k]] = float(meta[k.lower()])
-        tabs = meta["tabs"]
-        dz3c = None if dz3 is None else dz3.float().contiguous()
-        dyb3c = None if dyb3 is None else dyb3.to(dt).contiguous()
-        ins = {"X0": x0, "XC": xc, "NBR": meta["nbr"], "BLK_TAB": None if blk is None else blk.tab, "BLK_HID": None if blk is None else blk.hid,
-               "BLK_HCNT": None if blk is None else blk.hcnt, "T_QKV_FWD": tabs[0], "T_QKV_BWD": tabs[1], "T_PROJ_FWD": tabs[2],
-               "T_PROJ_BWD": tabs[3], "CU": meta["cu"], "RS1": rs1, "RS2": rs2, "DZ3": dz3c, "DYB3": dyb3c}
-        ins.update(sh)
-        ins.update(f32)
-        ins.update(wt)
-        pin = (ctypes.c_void_p * E["P_COUNT"])()
-        for k, t in ins.items():
-            pin[E["P_" + k]] = _lib.ptr(t) or None
+        for k, mode, slots in (("CONV", "mirror", 0), ("LIN", "mirror", 0), ("QKV", "repeat", 2), ("PROJ", "mirror", 0), ("FC1", "mirror", 0),
+                               ("FC2", "mirror", 0)):
+            wt = _cast_cache.layout(sh["W_" + k], mode, slots)
+            if wt is None:
+                raise PtcoreError("_BlockFn.backward: a weight shadow left the cast cache between forward and backward")
+            pin[E["P_WT_" + k]] = wt.data_ptr()
+        pin[E["P_X0"]], pin[E["P_XC"]] = x0.data_ptr(), xc.data_ptr()
+        if rs1 is not None:
+            pin[E["P_RS1"]] = rs1.data_ptr()
+        if rs2 is not None:
+            pin[E["P_RS2"]] = rs2.data_ptr()
+        dz3c = None if dz3 is None else (dz3 if dz3.dtype == torch.float32 and dz3.is_contiguous() else dz3.float().contiguous())
+        dyb3c = None if dyb3 is None else (dyb3 if dyb3.dtype == dt and dyb3.is_contiguous() else dyb3.to(dt).contiguous())
+        if dz3c is not None:
+            pin[E["P_DZ3"]] = dz3c.data_ptr()
+        if dyb3c is not None:
+            pin[E["P_DYB3"]] = dyb3c.data_ptr()
         psv = (ctypes.c_void_p * E["O_COUNT"])()
-        for k, t in outs.items():
-            psv[E["O_" + k]] = t.data_ptr()
+        b16, b32 = buf16.data_ptr(), buf32.data_ptr()
+        for idx, off in plan["o16"]:
+            psv[idx] = b16 + off
+        for idx, off in plan["o32"]:
+            psv[idx] = b32 + off
+        psv[E["O_X3"]], psv[E["O_XB3"]] = x3.data_ptr(), xb3.data_ptr()
+        gbuf = torch.empty(plan["tg"], dtype=torch.float32, device=dev)
+        sbuf = torch.empty(plan["ts"], dtype=dt, device=dev)
         pg = (ctypes.c_void_p * E["GS_COUNT"])()
-        for k, t in g32.items():
-            pg[E[k]] = t.data_ptr()
-        for k, t in g16.items():
-            pg[E[k]] = t.data_ptr()
-        nbytes = int(L.ptc_ptv3_block_workspace_bytes(n, npad, c, heads))
+        bg, bs = gbuf.data_ptr(), sbuf.data_ptr()
+        for idx, off in plan["g32"]:
+            pg[idx] = bg + off
+        for idx, off in plan["g16"]:
+            pg[idx] = bs + off
+        for k, present in zip(_BLK_PARAMS, ctx.present):
+            if not present:
+                pg[E["G_" + k]] = None
+        if plan["ws"] is None:
+            plan["ws"] = int(ops.lib().ptc_ptv3_block_workspace_bytes(n, npad, c, heads))
+        nbytes = plan["ws"]
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.check(L.ptc_ptv3_block_bwd(iv, fv, pin, psv, pg, _lib.ptr(ws), nbytes, ops.stream_ptr()), "ptc_ptv3_block_bwd")
-        dx0 = g32["G_X0"] if x0.dtype == torch.float32 else g16["G_X0"]
+        _lib.check(ops.lib().ptc_ptv3_block_bwd(iv, fv, pin, psv, pg, ws.data_ptr(), nbytes, ops.stream_ptr()), "ptc_ptv3_block_bwd")
+        dx0 = (gbuf if x0.dtype == torch.float32 else sbuf)[plan["gx0"]:plan["gx0"] + n * c].view(n, c)
+        dxc = sbuf[plan["gxc"]:plan["gxc"] + n * c].view(n, c)
         grads = []
-        for k, spec in zip(_BLK_PARAMS, ctx.param_shapes):
-            grads.append(None if spec is None else (g32["G_" + k] if spec[1] == torch.float32 else g32["G_" + k].to(spec[1])))
-        return (dx0, g16["G_XC"], None, None, None, *grads)
+        for k, present, pdt, shp in zip(_BLK_PARAMS, ctx.present, ctx.param_dtypes, ctx.param_shapes):
+            if not present:
+                grads.append(None)
+                continue
+            off, cnt = plan["gparam"][k]
+            g = gbuf[off:off + cnt].view(shp)
+            grads.append(g if pdt == torch.float32 else g.to(pdt))
+        return (dx0, dxc, None, None, None, *grads)
 
 
 def ptv3_block(x0, xc, rs1, rs2, meta, params):

@@ -705,7 +705,9 @@ class PointTransformerV3(PointModule):
         reference syncs twice per SerializedPooling: torch.unique and the python loop over bincounts).  With the sizes
         known the host never waits for the GPU again during the forward, so it runs far ahead and the short kernels of
         the deep stages find their launches already queued."""
-        strides = [m.stride for m in self.modules() if isinstance(m, SerializedPooling)]
+        strides = self.__dict__.get("_ptc_pool_strides")
+        if strides is None:                      # (walking self.modules() every step cost 0.6 ms of host time, r03_i_host_profile.txt)
+            strides = self.__dict__["_ptc_pool_strides"] = [m.stride for m in self.modules() if isinstance(m, SerializedPooling)]
         if not config.PREFETCH_LEVELS or not strides or not point.feat.is_cuda or point.grid_coord.shape[0] == 0 or len(strides) > 8:
             return
         depth, shifts, cum = point.serialized_depth, [], 0
