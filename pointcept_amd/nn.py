@@ -27,9 +27,10 @@ def _require_gpu(x: torch.Tensor, layer: str) -> None:
         raise PtcoreError(f"pointcept_amd.nn.{layer}: input lives on {x.device} -- the engine has no CPU fallback")
 
 
-# hipBLASLt is well tuned for square-ish GEMMs; the engine kernels win on the tall-skinny shapes of
-# point features (N ~ 1e4..1e6 rows, C <= 512) and on every weight gradient (contraction over N).
-_OWN_MAX_CIN = 512
+# The engine's GEMM kernels serve every nn.Linear of the point-feature shapes (N ~ 1e3..1e6 rows, contractions up to 2048 = the MLP
+# hidden width of the 512-channel stage): functional.linear picks linear2 (<= 256 channels), the identity-table implicit-GEMM kernel
+# (wider, multiples of 128) and wgrad2 for every weight gradient; only shapes outside that set reach F.linear inside it.
+_OWN_MAX_CIN = 2048
 _OWN_MAX_COUT = 2048
 
 
