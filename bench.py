@@ -316,6 +316,19 @@ def fp16_recipe_in_a_child(args):
         return {"error": repr(e)}
 
 
+def build_ptv3_outdoor(args, device, rank):
+    """BASELINE configs[4] on one GPU: PT-v3m1 base with in_channels = 4 (coord | strength), 16 classes
+    (configs/nuscenes/semseg-pt-v3m1-0-base.py:16,122), LiDAR-like sweeps voxelised at 0.05 m (depth-12 grid), ~200k voxels per scene."""
+    from pointcept_amd import synthetic
+    from pointcept_amd.point_transformer_v3 import PointTransformerV3
+    from pointcept_amd.segmentor import DefaultSegmentorV2
+
+    model = DefaultSegmentorV2(16, 64, PointTransformerV3(**dict(PTV3_BASE, in_channels=4)), criteria=("ce", "lovasz")).to(device).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    batch = synthetic.to_torch(synthetic.collate([synthetic.outdoor_scene(5000 + 1000 * rank + i, azimuth_steps=3300) for i in range(args.batch)]), device)
+    return model, opt, batch, (lambda out: out["loss"])
+
+
 def build_ptv3(args, device, rank):
     from pointcept_amd import synthetic
     from pointcept_amd.point_transformer_v3 import PointTransformerV3
@@ -419,6 +432,24 @@ def main():
     step = make_step(step_model, opt, batch, amp, loss_of, device)
     dt, loss = timed_steps(step, args.steps, args.warmup, device)
     last_loss = float(loss.detach())
+    # multi-GPU diagnostics (outside the timed region): every rank's own step time, and the same K steps WITHOUT the gradient exchange
+    # (DDP.no_sync) -- the difference is the all-reduce time the overlap with backward did not hide
+    per_rank_ms, ms_no_sync = None, None
+    if world > 1 and torch.distributed.is_initialized():
+        t = torch.tensor([dt / args.steps * 1e3], dtype=torch.float64, device=device)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        t[0] = (time.perf_counter() - t0) / args.steps * 1e3          # this rank's own clock, no barrier inside
+        torch.distributed.all_gather(allt, t)
+        per_rank_ms = [round(float(x.item()), 3) for x in allt]
+        if hasattr(step_model, "no_sync"):
+            with step_model.no_sync():
+                dt_ns, _ = timed_steps(step, max(2, args.steps // 2), 1, device)
+            ms_no_sync = round(dt_ns / max(2, args.steps // 2) * 1e3, 3)
 
     if rank == 0:
         out = {
@@ -439,6 +470,10 @@ def main():
             "config": {"workload": workload, "global_batch": args.batch * world, "parallelism": f"dp{world}", "params": n_params,
                        "amp": ("fp16 autocast + GradScaler" if amp == "fp16" else "bf16 autocast"), "final_loss": round(last_loss, 4)},
         }
+        if per_rank_ms is not None:
+            out["per_rank_ms_per_step"] = per_rank_ms
+            out["ms_per_step_without_gradient_exchange"] = ms_no_sync
+            out["exposed_allreduce_ms_per_step"] = None if ms_no_sync is None else round(out["ms_per_step"] - ms_no_sync, 3)
         if not args.stub and args.model == "ptv3":
             out["config"]["points_per_gpu"] = int(batch["offset"][-1])
             out["config"]["loss"] = "CrossEntropy(ignore_index=-1)" + ("" if args.ce_only else " + LovaszSoftmax")
@@ -467,6 +502,24 @@ def main():
                 del st2, m2, o2, b2
             except Exception as e:
                 out["secondary"] = {"error": repr(e)}
+        if not args.stub and args.model == "ptv3" and world == 1 and not args.no_secondary:
+            try:      # BASELINE configs[4] (outdoor LiDAR, ~200k voxels per scene, depth-12 grid) on this one GPU
+                torch.cuda.empty_cache()
+                torch.manual_seed(1234)
+                m3, o3, b3, l3 = build_ptv3_outdoor(args, device, rank)
+                st3 = make_step(m3, o3, b3, amp, l3, device)
+                k3 = max(3, min(args.steps, 6))
+                dt3, loss3 = timed_steps(st3, k3, 2, device)
+                n3 = int(b3["offset"][-1])
+                out["secondary_outdoor"] = {"metric": "scenes/sec (fwd+bwd+optimizer) PT-v3m1 outdoor LiDAR semseg @ ~200k voxels (BASELINE configs[4], one GPU)",
+                                            "value": round(args.batch * k3 / dt3, 4), "unit": "scenes/s", "ms_per_step": round(dt3 / k3 * 1e3, 3),
+                                            "steps": k3, "warmup": 2, "final_loss": round(float(loss3.detach()), 4), "voxels_per_gpu": n3,
+                                            "grid_depth": int(b3["grid_coord"].max()).bit_length(),
+                                            "workload": f"PT-v3m1 base, in_channels 4, 16 classes, CE + Lovasz, fwd+bwd+AdamW, {args.batch} scenes x ~{n3 // args.batch} voxels"}
+                del st3, m3, o3, b3
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out["secondary_outdoor"] = {"error": repr(e)}
         if not args.stub and args.model == "ptv3" and world == 1 and amp == "bf16" and not args.no_secondary and not args.no_fp16_recipe:
             out["recipe_fp16"] = fp16_recipe_in_a_child(args)
         if not args.stub and args.model == "ptv3" and world == 1 and not args.no_cpu_baseline:

@@ -563,7 +563,7 @@ def add_norm(u: torch.Tensor, a: torch.Tensor, row_scale: Optional[torch.Tensor]
     """One pass over a residual joint of the PTv3 Block: z = a + row_scale[:,None] * f(u) (fp32 residual
     stream), y = g(z) as `y_dtype`.  f / g are nn.LayerNorm modules (norm_a / norm_b) or identity.
     Returns (z, y); y is None when y_dtype is None."""
-    if a.dtype not in (torch.float32, torch.bfloat16):
+    if a.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         a = a.float()
     ga, ba, ea = (norm_a.weight, norm_a.bias, norm_a.eps) if norm_a is not None else (None, None, 0.0)
     gb, bb, eb = (norm_b.weight, norm_b.bias, norm_b.eps) if norm_b is not None else (None, None, 0.0)

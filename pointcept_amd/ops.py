@@ -602,8 +602,8 @@ def add_norm_fwd(u, a, row_scale, norm_a, norm_b, y_dtype):
     require_cuda(u, a, row_scale)
     u = u.contiguous()
     a = a.contiguous()
-    if a.dtype not in (torch.float32, torch.bfloat16):
-        raise PtcoreError("add_norm: the residual operand `a` must be fp32 or bf16")
+    if a.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise PtcoreError("add_norm: the residual operand `a` must be fp32, bf16 or f16")
     n, c = u.shape
     dev = u.device
     z = torch.empty((n, c), dtype=torch.float32, device=dev)

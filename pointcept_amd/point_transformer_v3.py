@@ -403,14 +403,14 @@ class Block(PointModule):
         return (config.FUSE_BLOCK and self.pre_norm and point.feat.is_cuda and point.feat.dim() == 2
                 and isinstance(self.cpe[2], PNN.LayerNorm) and isinstance(self.norm1[0], PNN.LayerNorm)
                 and isinstance(self.norm2[0], PNN.LayerNorm) and ops.layer_norm_supported(self.channels)
-                and point.feat.shape[0] > 0 and point.feat.dtype in (torch.float32, torch.bfloat16))
+                and point.feat.shape[0] > 0 and point.feat.dtype in (torch.float32, torch.bfloat16, torch.float16))
 
     def _forward_fused(self, point: Point):
         """Same arithmetic as `forward`, with each residual joint (branch output -> [LayerNorm] -> add ->
         [LayerNorm | cast]) done in one pass (PF.add_norm) instead of 3-4 elementwise kernels."""
         auto = torch.is_autocast_enabled("cuda")
         gemm_dt = torch.get_autocast_dtype("cuda") if auto else torch.float32
-        if gemm_dt not in (torch.bfloat16, torch.float32):
+        if gemm_dt not in (torch.bfloat16, torch.float16, torch.float32):
             return None
         n, dev = point.feat.shape[0], point.feat.device
         sc = point.sparse_conv_feat

@@ -194,8 +194,9 @@ attention_step2_v2 = attention_step2
 
 def attention_step2_with_rel_pos_value(attn, v, index0, index1, table, rel_idx):
     attn, v, table = _prep(attn, v, table)
-    return _PairAggregate.apply(attn, v, table, _i32(index0).contiguous(), None, _i32(index1).contiguous(), _i32(rel_idx).contiguous(),
-                                v.shape[0])
+    i0 = _i32(index0).contiguous()
+    n_q = int(i0.max().item()) + 1 if i0.numel() else 0          # pointops.py:776: N_q = index0.max().item() + 1, not N_v
+    return _PairAggregate.apply(attn, v, table, i0, None, _i32(index1).contiguous(), _i32(rel_idx).contiguous(), n_q)
 
 
 def attention_step2_with_rel_pos_value_v2(attn, v, index0_offsets, n_max, index1, table, rel_idx):

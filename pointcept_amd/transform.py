@@ -170,8 +170,9 @@ class SphereCrop:
 
 def collate_fn(batch):
     """pointcept/datasets/utils.py:19-73 for device tensors: concatenate along points; keys containing "offset" become
-    cumulative offsets of the concatenation (:52-60).  (The image / correspondence branches of the multi-modal
-    pre-training datasets, :44-45,61-71, are outside the PTv3 / SpUNet path and raise.)"""
+    cumulative offsets of the concatenation (:52-60); samples that are sequences of tensors get their lengths appended and a
+    cumulative int offset as the last element (:35-40); anything else goes to torch's default_collate (:72).  (The image /
+    correspondence branches of the multi-modal pre-training datasets, :44-45,61-71, are outside the PTv3 / SpUNet path and raise.)"""
     from collections.abc import Mapping, Sequence
 
     if not isinstance(batch, Sequence):
@@ -182,8 +183,13 @@ def collate_fn(batch):
         return list(batch)
     if isinstance(batch[0], (int, float)):
         return torch.tensor(list(batch))
-    if isinstance(batch[0], list):
+    if isinstance(batch[0], list) and not any(isinstance(e, torch.Tensor) for e in batch[0]):
         return torch.cat([torch.tensor(d) for d in batch])
+    if isinstance(batch[0], Sequence):                               # utils.py:35-40: (coord, feat, label, ...) tuples / lists of tensors
+        rows = [list(d) + [torch.tensor([d[0].shape[0]], device=d[0].device if isinstance(d[0], torch.Tensor) else None)] for d in batch]
+        out = [collate_fn(list(samples)) for samples in zip(*rows)]
+        out[-1] = torch.cumsum(out[-1], dim=0).int()
+        return out
     if isinstance(batch[0], Mapping):
         if "img_num" in batch[0] or any("correspondence" in k for k in batch[0]):
             raise PtcoreError("collate_fn: the image / correspondence branches are not part of this engine")
@@ -195,7 +201,9 @@ def collate_fn(batch):
             else:
                 out[key] = collate_fn([d[key] for d in batch])
         return out
-    raise TypeError(f"collate_fn: unsupported element type {type(batch[0])}")
+    from torch.utils.data.dataloader import default_collate
+
+    return default_collate(batch)                                    # utils.py:72
 
 
 def point_collate_fn(batch, mix_prob=0, mix: Optional[bool] = None):

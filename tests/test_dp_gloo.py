@@ -161,6 +161,9 @@ def test_bench_self_launch_gloo_stub():
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 3 and out["warmup"] == 1
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak"
     assert out["value"] > 0 and abs(out["value"] - 4 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-2 * out["value"]
+    # multi-rank diagnostics (VERDICT r2 next 6 ii): every rank's own step time and the step time without the gradient exchange
+    assert len(out["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in out["per_rank_ms_per_step"])
+    assert out["ms_per_step_without_gradient_exchange"] > 0 and out["exposed_allreduce_ms_per_step"] is not None
 
 
 def test_bench_refuses_fewer_gpus_than_asked():

@@ -665,14 +665,16 @@ def test_layer_norm_fwd_bwd(cuda, c, xdt, ydt):
 
 
 @pytest.mark.parametrize("c", [32, 128, 512])
-@pytest.mark.parametrize("mode", ["ln_add_ln", "add_ln_scaled", "add_cast", "fp32"])
+@pytest.mark.parametrize("mode", ["ln_add_ln", "add_ln_scaled", "add_cast", "fp32", "f16_ln_add_ln", "f16_add_ln_scaled", "f16_add_cast"])
 def test_add_norm_fused_joint(cuda, c, mode):
-    """PF.add_norm == a + s * LN_A(u) followed by LN_B / cast, forward and every gradient."""
+    """PF.add_norm == a + s * LN_A(u) followed by LN_B / cast, forward and every gradient; bf16, f16 (the reference's fp16 + GradScaler
+    recipe runs the same fused joints) and fp32 operands."""
     from pointcept_amd import functional as PF
 
     n = 3001
     g = torch.Generator().manual_seed(c + len(mode))
-    udt = torch.float32 if mode == "fp32" else torch.bfloat16
+    udt = torch.float32 if mode == "fp32" else (torch.float16 if mode.startswith("f16_") else torch.bfloat16)
+    mode = mode[4:] if mode.startswith("f16_") else mode
     u = (torch.randn(n, c, generator=g) * 1.5).to(udt)
     a = torch.randn(n, c, generator=g)
     scale = (torch.rand(n, generator=g) > 0.3).float() / 0.7 if mode == "add_ln_scaled" else None
@@ -716,8 +718,9 @@ def test_add_norm_fused_joint(cuda, c, mode):
             _close("an_db" + name, m.bias.grad, ref_grads["b" + name], 1e-3, 2e-3 * float(ref_grads["b" + name].abs().max()))
 
 
+@pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("c", [64, 256])
-def test_add_norm_bf16_residual_operand_and_unused_outputs(cuda, c):
+def test_add_norm_bf16_residual_operand_and_unused_outputs(cuda, c, dt16):
     """First block of a stage: the residual operand `a` is the bf16 output of the pooling / unpooling.  The kernel reads it
     as bf16 (same values as a.float()) and writes da as bf16 (the cast autograd would apply); an output nobody uses gets no
     materialised zero gradient and the result equals the fp32-operand call on the same values."""
@@ -725,25 +728,25 @@ def test_add_norm_bf16_residual_operand_and_unused_outputs(cuda, c):
 
     n = 2049
     g = torch.Generator().manual_seed(c)
-    u = (torch.randn(n, c, generator=g)).to(torch.bfloat16).to(cuda)
-    a16 = torch.randn(n, c, generator=g).to(torch.bfloat16).to(cuda)
+    u = (torch.randn(n, c, generator=g)).to(dt16).to(cuda)
+    a16 = torch.randn(n, c, generator=g).to(dt16).to(cuda)
     nb = torch.nn.LayerNorm(c).to(cuda)
-    dz, dy = torch.randn(n, c, generator=g).to(cuda), torch.randn(n, c, generator=g).to(torch.bfloat16).to(cuda)
+    dz, dy = torch.randn(n, c, generator=g).to(cuda), torch.randn(n, c, generator=g).to(dt16).to(cuda)
     res = {}
     for tag, a in (("bf16", a16.clone().requires_grad_(True)), ("fp32", a16.float().requires_grad_(True))):
         ue = u.clone().requires_grad_(True)
         nb.zero_grad(set_to_none=True)
-        z, y = PF.add_norm(ue, a, None, None, nb, torch.bfloat16)
+        z, y = PF.add_norm(ue, a, None, None, nb, dt16)
         ((z * dz).sum() + (y.float() * dy.float()).sum()).backward()
         res[tag] = (z, y, a.grad, ue.grad, nb.weight.grad.clone())
-    assert res["bf16"][2].dtype == torch.bfloat16 and res["fp32"][2].dtype == torch.float32
+    assert res["bf16"][2].dtype == dt16 and res["fp32"][2].dtype == torch.float32
     assert torch.equal(res["bf16"][0], res["fp32"][0]) and torch.equal(res["bf16"][1], res["fp32"][1])
-    assert torch.equal(res["bf16"][2], res["fp32"][2].to(torch.bfloat16))
+    assert torch.equal(res["bf16"][2], res["fp32"][2].to(dt16))
     assert torch.equal(res["bf16"][3], res["fp32"][3]) and torch.equal(res["bf16"][4], res["fp32"][4])
     # only z used / only y used: the other gradient is absent, not zeros
     for use_z in (True, False):
         ue, ae = u.clone().requires_grad_(True), a16.float().requires_grad_(True)
-        z, y = PF.add_norm(ue, ae, None, None, nb, torch.bfloat16)
+        z, y = PF.add_norm(ue, ae, None, None, nb, dt16)
         ((z * dz).sum() if use_z else (y.float() * dy.float()).sum()).backward()
         ur, ar = u.float().requires_grad_(True), a16.float().requires_grad_(True)
         zr = ar + ur

@@ -3,6 +3,7 @@
 #   tests      whole -m gpu suite            ops     tools/bench_ops.py
 #   bench      bench.py (default switches)   ab:<ENV=V,...>  bench.py with switches (no cpu baseline)
 #   prof       rocprofv3 kernel stats of bench.py
+#   contention tools/host_contention.py: host CPU time per step of 1 vs 8 concurrent processes
 #   hostlead   tools/host_lead.py: host enqueue time per step vs completed time (executor on / off, and a 2 x 20000-voxel step)
 #   roof       rocprofv3 stats + PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) of the roofline kernel
 TAG=${1:-s}; shift
@@ -24,6 +25,7 @@ for sec in "$@"; do
     opsq) timeout 900 python tools/bench_ops.py --quick > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log;;
     bench) timeout 900 python bench.py --steps 10 --warmup 3 > $O/${TAG}_bench.log 2>&1; echo "bench rc=$?" >> $O/${TAG}_env.log; tail -1 $O/${TAG}_bench.log | cut -c1-330;;
     hostlead) timeout 600 python tools/host_lead.py > $O/${TAG}_host_lead.txt 2>&1; PTC_EXEC_BLOCK=0 timeout 600 python tools/host_lead.py >> $O/${TAG}_host_lead.txt 2>&1; timeout 600 python tools/host_lead.py --scenes 2 --points 20000 >> $O/${TAG}_host_lead.txt 2>&1; cat $O/${TAG}_host_lead.txt;;
+    contention) timeout 900 python tools/host_contention.py > $O/${TAG}_host_contention.txt 2>&1; cat $O/${TAG}_host_contention.txt;;
     smoke) timeout 600 python __graft_entry__.py --smoke > $O/${TAG}_smoke.log 2>&1; echo "smoke rc=$?" >> $O/${TAG}_env.log; tail -2 $O/${TAG}_smoke.log;;
     trace) timeout 600 python tools/trace_step.py > $O/${TAG}_trace_step.txt 2>$O/${TAG}_trace_step.err; echo "trace rc=$?" >> $O/${TAG}_env.log; head -5 $O/${TAG}_trace_step.txt;;
     copies) timeout 600 python tools/trace_copies.py > $O/${TAG}_trace_copies.txt 2>$O/${TAG}_trace_copies.err; echo "copies rc=$?" >> $O/${TAG}_env.log; head -30 $O/${TAG}_trace_copies.txt;;

@@ -82,7 +82,7 @@ for (name, frame), (c, b) in log.rows.items():
     tot[name][0] += c
     tot[name][1] += b
 print("== aten ops of one step (count, output MB)")
-for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])[:40]:
+for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])[:60]:
     print(f"{v[0]:6d} {v[1] / 1e6:10.1f} MB  {k}")
 print("== by (op, innermost engine frame), sorted by count")
 for (name, frame), (c, b) in sorted(log.rows.items(), key=lambda kv: -kv[1][0])[:120]:
