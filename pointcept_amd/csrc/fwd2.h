@@ -392,7 +392,9 @@ static int launch_fwd2(const void* in, int64_t n_in, const void* w, const float*
   }
 #define L2_CASE(SS)                                                                                                     \
   case SS: {                                                                                                            \
-    if (epi == 1) L2_LAUNCH(SS, 1) else if (epi == 2) L2_LAUNCH(SS, 2) else L2_LAUNCH(SS, 0)                              \
+    if constexpr (NTILES == 8) {       /* the GELU epilogues exist for 128-wide output tiles: the MLP hidden width 4 C, C % 32 == 0 */ \
+      if (epi == 1) L2_LAUNCH(SS, 1) else if (epi == 2) L2_LAUNCH(SS, 2) else L2_LAUNCH(SS, 0)                            \
+    } else L2_LAUNCH(SS, 0)                                                                                             \
   } break;
     if (lds_store && S == 1) L2_LAUNCH_X(1, 0, true)
     else if (lds_store && S == 2) L2_LAUNCH_X(2, 0, true)

@@ -438,7 +438,7 @@ class Block(PointModule):
         LayerNorm joints, the window-attention kernel with the gather tables folded into qkv / proj, fused MLP, <= 256 channels"""
         a = self.attn
         return (config.EXEC_BLOCK and type(self) is Block and type(a) is SerializedAttention and torch.is_autocast_enabled("cuda")
-                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and self.channels % 16 == 0 and self.channels <= 256
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and self.channels % 32 == 0 and self.channels <= 256
                 and a.enable_flash and not a.enable_rpe and a.num_heads * 16 == self.channels and config.FUSE_GATHER and config.FUSE_MLP
                 and type(self.cpe[0]) is spconv.SubMConv3d and self.cpe[0].kernel_size[0] == 3 and self.cpe[0].bias is not None
                 and type(self.cpe[1]) is PNN.Linear and self.cpe[1].bias is not None and type(self.mlp[0]) is MLP

@@ -2,7 +2,7 @@
 """Does the host side of the step hold up when 8 ranks share one host?  (VERDICT r2 next 6 i.)  The one-GPU box cannot run 8 ranks on 8
 GPUs, but the HOST work of a rank -- the Python that enqueues a step -- is the same whichever GPU it feeds: N processes run the real
 step (the bench model, a small batch so that the one shared GPU is not what they wait for most of the time) concurrently and report, per
-step, their own CPU time (user + system of the process: what each rank asks of the host) and wall time.  N = 1 vs N = 8: if CPU time per
+step, their own CPU time (user + system of the process with blocking -- sleeping -- GPU waits: what each rank asks of the host) and wall time.  N = 1 vs N = 8: if CPU time per
 step stays put the cores do not contend; the wall time under N = 8 additionally contains the queueing on the single shared GPU.
 
     python tools/host_contention.py [--procs 8] [--scenes 2] [--points 20000] [--steps 12]
@@ -18,8 +18,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def worker(a):
+    import ctypes
+
     import torch
 
+    # waits inside the step (the forward reads a few sizes back) must SLEEP, not spin: a spinning wait is booked as CPU time of the
+    # process and, with N processes queueing on one GPU, would be mistaken for host work (hipDeviceScheduleBlockingSync = 4)
+    try:
+        ctypes.CDLL("libamdhip64.so.7").hipSetDeviceFlags(4)
+    except OSError:
+        pass
     sys.path.insert(0, ROOT)
     import bench
 
