@@ -94,13 +94,27 @@ VARIANTS = {
     "slp": [],                         # every file with the compiler's default SLP packing (no PER_FILE_FLAGS)
     "noslp": ["-fno-slp-vectorize"],   # no file with it
 }
+# "d_<MACRO>_<VALUE>": -D<MACRO>=<VALUE> (timing ablations of one kernel, e.g. d_C7_ABLATE_4); only the sources that name the macro
+# (directly or through a header of csrc/) are recompiled, the other objects come from the default build
+
+
+def _variant_flags(variant: str) -> list:
+    if variant.startswith("d_"):
+        macro, val = variant[2:].rsplit("_", 1)
+        return [f"-D{macro}={val}"]
+    return VARIANTS[variant]
+
+
+def _names_macro(src_path: str, macro: str, hdrs: list) -> bool:
+    text = open(src_path).read()
+    return macro in text or any(macro in open(h).read() and f'"{os.path.basename(h)}"' in text for h in hdrs)
 
 
 def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
     """Compile every HIP source for gfx950 and link libptcore.so.  Returns the library path."""
     LIB = lib_path(variant)
     BUILD = os.path.join(HERE, "csrc", "build" + ("_" + variant if variant else ""))
-    HIP_FLAGS = globals()["HIP_FLAGS"] + (VARIANTS[variant] if variant else [])
+    HIP_FLAGS = globals()["HIP_FLAGS"] + (_variant_flags(variant) if variant else [])
     if not os.path.exists(HIPCC):
         if os.path.exists(LIB):
             return LIB  # GPU box without a compiler: use the prebuilt in-tree library
@@ -128,10 +142,13 @@ def _build_locked(force: bool, verbose: bool, variant: str, LIB: str, BUILD: str
         if not os.path.exists(sp):
             raise RuntimeError(f"missing source {sp}")
         op = os.path.join(BUILD, src + ".o")
+        if variant.startswith("d_") and not _names_macro(sp, variant[2:].rsplit("_", 1)[0], hdrs):
+            objs.append(os.path.join(HERE, "csrc", "build", src + ".o"))      # untouched by the macro: the default build's object
+            continue
         objs.append(op)
         if force or _newer(sp, op, hdrs):
             if src.endswith(".hip"):
-                cmd = [HIPCC] + HIP_FLAGS + (PER_FILE_FLAGS.get(src, []) if not variant else []) + ["-c", sp, "-o", op]
+                cmd = [HIPCC] + HIP_FLAGS + (PER_FILE_FLAGS.get(src, []) if not variant or variant.startswith("d_") else []) + ["-c", sp, "-o", op]
             else:
                 import zlib
 

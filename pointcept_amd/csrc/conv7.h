@@ -7,7 +7,7 @@
 // its gathers (conv6: half the vector-memory instructions) made it SLOWER (298 us): the kernel is bound by dependent-load latency
 // (table entry -> gather -> LDS bounce -> MFMA at 2-3 waves per SIMD) and by re-streaming W -- 221 KB per 128 rows, more bytes
 // through the L1 / LDS-store path than the gathered rows themselves.  conv7 removes both:
-//   * a workgroup is PERSISTENT over a contiguous range of 128-row blocks and keeps the whole weight tensor in the registers of
+//   * a workgroup is PERSISTENT over a share of the 128-row blocks and keeps the whole weight tensor in the registers of
 //     its four waves (one wave per SIMD, 512-register budget) as 32x32x16 MFMA A-fragments (32 output x 16 input channels), 54 per
 //     wave.  C = 64: wave w holds input-channel half kh = w & 1 of output-channel half ch = w >> 1 (27 taps x 2 k-steps);
 //     C = 32: every wave holds all of W (27 x 2) and the waves split the block's row tiles.  W is read from L2 ONCE per workgroup;
@@ -16,17 +16,32 @@
 //     b + 1 is in flight while block b is multiplied; rows are XOR-swizzled on the SOURCE side (the DMA image is lane-linear) so
 //     that the 27-tap gather -- a per-lane ds_read_b128 in MFMA B layout -- is conflict-free for neighbouring rows; the table
 //     holds ready-made LDS byte offsets, so a gather costs two vector-ALU instructions (field extract, xor-add);
-//   * the main loop is branch-free: tap outer (static: the fragment index must be a compile-time register name), the block's
-//     32-row tiles inner; "no neighbour" entries read an all-zero row.  Per (tap, tile, k-step): one LDS gather + one 32-cycle MFMA
-//     per wave.  (The first version used 16x16x32 MFMAs: at one wave per SIMD a 16-cycle MFMA hides ~1 other instruction and the loop
-//     ran at 36 cycles per MFMA -- tools/probe_mfma_agpr.hip, profiles/r03_f_probe_mfma_agpr.txt; a 32-cycle MFMA hides ~5);
+//   * tap outer (static: the fragment index must be a compile-time register name), the block's 32-row tiles inner; EMPTY TAPS ARE
+//     SKIPPED by a scalar branch on the tap mask blocks.hip leaves in the table (33 % of the (block, tap) pairs, 46 % of the (tile,
+//     tap) pairs on indoor scenes); inside an active tap "no neighbour" entries read an all-zero row.  Per (tap, tile, k-step): one
+//     LDS gather + one 32-cycle MFMA per wave, the gathers one tap ahead in a rolling register ring.  (The first version used
+//     16x16x32 MFMAs: at one wave per SIMD a 16-cycle MFMA hides ~1 other instruction and the loop ran at 36 cycles per MFMA --
+//     tools/probe_mfma_agpr.hip, profiles/r03_f_probe_mfma_agpr.txt; a 32-cycle MFMA hides ~5);
+//   * workgroups take blocks STRIDED over the scene (not a contiguous range): block cost follows the local geometry and
+//     contiguous ranges left the waves idle for a quarter of the kernel;
 //   * C = 64: the two input-channel halves of a row tile are summed through a 32 KB LDS scratch (each wave finishes half of the
-//     tiles: symmetric work), bias added in fp32, rows stored as bf16 / f16.
+//     tiles: symmetric work), bias added in fp32, rows stored as bf16 / f16 in 16-byte pieces (channel groups traded across the
+//     two 32-lane halves by v_permlane32_swap).
+// Where the cycles of a block go at 64 -> 64 (wave 0, profiles/r03_o_conv7_phases.txt): tap loop 5630 of 8900 (its MFMAs alone: 4500),
+// DMA issue 1020, accumulators -> scratch 430, add + store 1290, first gathers 350, barriers 190.  One wave per SIMD: nothing overlaps
+// the phases outside the tap loop -- that, not the LDS (a conflict-free gather pattern changes nothing) or the MFMA count, is what
+// separates the kernel from its roof.
 // A block whose halo does not fit (rows in no spatial order: hcnt < 0) is skipped here and served by conv5, launched behind this
-// kernel over exactly those blocks (its 128-row workgroups coincide with the blocks).  Summation order differs from conv5 (k-halves summed last, bias last): results agree to
-// fp32 rounding of the accumulation, not bit for bit.
+// kernel over exactly those blocks (its 128-row workgroups coincide with the blocks).  Summation order differs from conv5 (k-halves
+// summed last, bias last): results agree to fp32 rounding of the accumulation, not bit for bit.
 #pragma once
 
+// timing ablations (tools only: `python -m pointcept_amd.build --variant d_C7_ABLATE_<bits>`, results are then WRONG): 1 no halo DMA
+// after the first block, 2 no tap loop, 4 no epilogue at all, 8 no LDS exchange of the k-halves, 16 no global stores, 32 gathers read consecutive slots (no bank conflicts),
+// 64 per-phase cycle counters instead of results (tools/conv7_time.py --phases)
+#ifndef C7_ABLATE
+#define C7_ABLATE 0
+#endif
 #define C7_BM 128                           // rows per block
 #define C7_NT 8                             // 16-row tiles per block
 #define C7_HCAP 416                         // halo capacity (rows); max observed on curve-ordered indoor scenes: 352
@@ -60,6 +75,22 @@ __device__ __forceinline__ uint32_t c7_lds_addr(const void* p) { return (uint32_
 #define C7_PIN_AGPR(x) ((void)0)
 #endif
 
+// a[lanes 32..63] <-> b[lanes 0..31] (v_permlane32_swap): afterwards the low half holds (own a, the high half's a) and the high half
+// (the low half's b, own b)
+#ifdef __HIPCC__
+__device__ __forceinline__ void c7_swap32(uint32_t& a, uint32_t& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+#else
+__device__ __forceinline__ void c7_swap32(uint32_t& a, uint32_t& b) {
+  const int l = emu::lane_id();
+  const uint32_t oa = emu::exchange(a, l ^ 32), ob = emu::exchange(b, l ^ 32);
+  if (l < 32) b = oa; else a = ob;
+}
+#endif
+
 template <int C> struct C7Geom {
   static constexpr int ROWB = C * 2;                  // bytes per feature row
   static constexpr int PCS = ROWB / 16;               // 16-byte pieces per row
@@ -86,7 +117,7 @@ template <> struct C7Mma<f16_t> {
 template <typename T, int C>
 __global__ void __launch_bounds__(256, 1)
 conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias, const uint16_t* __restrict__ tab,
-             const int32_t* __restrict__ hid, const int32_t* __restrict__ hcnt, int64_t n_out, int n_blocks, int per_wg, T* __restrict__ out) {
+             const int32_t* __restrict__ hid, const int32_t* __restrict__ hcnt, int64_t n_out, int n_blocks, T* __restrict__ out) {
   using frag = typename Mma<T>::frag;
   using MM = C7Mma<T>;
   using G = C7Geom<C>;
@@ -97,9 +128,14 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   const int j = lane & 31, h = lane >> 5;              // MFMA 32x32x16: A row (output channel) / B column (row of the tile), k-group
   const int kh = C == 64 ? (wave & 1) : 0;             // input-channel half
   const int ch = C == 64 ? (wave >> 1) : 0;            // output-channel half (C = 64); C = 32: all 32 output channels in every wave
-  const int b_begin = (int)blockIdx.x * per_wg;
-  int b_end = b_begin + per_wg;
-  if (b_end > n_blocks) b_end = n_blocks;
+  // Which blocks: workgroup w takes blocks p(w), p(w) + S, p(w) + 2 S, ... (S = the grid).  STRIDED, not a contiguous range: the cost
+  // of a block follows the local geometry (active taps, halo size) and contiguous ranges left the waves alive for only 74 % of
+  // the kernel's duration (rocprofv3 SQ_WAVE_CYCLES vs GRBM_GUI_ACTIVE, profiles/r03_o_conv7_pmc_sq.json); a strided workgroup samples
+  // the whole scene.  p keeps one round's blocks of an XCD adjacent (hardware workgroup w runs on XCD w % 8, each XCD has its own
+  // L2): XCD x takes blocks x S/8 .. (x + 1) S/8 - 1 of every round, so the halo rows neighbouring blocks share meet in one L2.
+  const int step = (int)gridDim.x;
+  const int b_begin = (step % 8 == 0) ? ((int)blockIdx.x & 7) * (step / 8) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int b_end = n_blocks;
   if (b_begin >= b_end) return;
 
   // ---- the weights: 27 taps x 2 k-steps of 16 = 54 A-fragments (32 output channels x 16 input channels) per wave, straight from
@@ -158,6 +194,8 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       }
     }
   };
+  // (Tried: plain 16-byte loads into 60 staging registers at the top of a block, ds_write_b128 behind its tap loop.  The loads issue
+  //  faster -- 940 vs 1450 cycles per block -- but the stores into LDS cost 780, 270 more than they save: profiles/r03_o_conv7_phases.txt.)
   // (a count is LOADED early and USED late: the compiler waits for an ordinary load at the first use of its result, and that wait
   //  would also drain the DMAs issued before it)
   auto count_of = [&](int blk) -> int { return hcnt[blk < n_blocks ? blk : n_blocks - 1]; };
@@ -166,22 +204,33 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   int cnt_cur = __builtin_amdgcn_readfirstlane(count_of(b_begin));
   load_ids(b_begin);
   issue_dma(b_begin, cnt_cur, 0);
-  int cnt_nxt = count_of(b_begin + 1);
-  if (b_begin + 1 < b_end) load_ids(b_begin + 1);
+  int cnt_nxt = count_of(b_begin + step);
+  if (b_begin + step < b_end) load_ids(b_begin + step);
   __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
   __builtin_amdgcn_s_barrier();
   cnt_nxt = __builtin_amdgcn_readfirstlane(cnt_nxt);
 
   // the 16-byte piece of a gathered row this lane feeds to k-step ks: input channels kh * 32 + ks * 16 + h * 8 ..
   const uint32_t pxor0 = (uint32_t)(kh * 4 + h) << 4, pxor1 = (uint32_t)(kh * 4 + 2 + h) << 4;
+  // (bit 64 of C7_ABLATE: per-phase cycle totals of every workgroup's wave 0 -> the first 64 bytes of output row blockIdx.x)
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  auto tick = [&](int i) {
+    if constexpr ((C7_ABLATE & 64) != 0) {
+      const long long t = clock64();
+      tph[i] += t - tlast;
+      tlast = t;
+    }
+  };
+  if constexpr ((C7_ABLATE & 64) != 0) tlast = clock64();
   int cur = 0;
 #pragma unroll 1
-  for (int blk = b_begin; blk < b_end; ++blk) {
-    // block blk + 1 -> the other buffer (its ids arrived before the barrier that ended the previous iteration)
-    if (blk + 1 < b_end) issue_dma(blk + 1, cnt_nxt, cur ^ 1);
-    int cnt_nn = count_of(blk + 2);
-    if (blk + 2 < b_end) load_ids(blk + 2);
+  for (int blk = b_begin; blk < b_end; blk += step) {
+    // this workgroup's next block -> the other buffer (its ids arrived before the barrier that ended the previous iteration)
+    if (blk + step < b_end && !(C7_ABLATE & 1)) issue_dma(blk + step, cnt_nxt, cur ^ 1);
+    int cnt_nn = count_of(blk + 2 * step);
+    if (blk + 2 * step < b_end) load_ids(blk + 2 * step);
 
+    tick(0);                                            // DMA issue + id loads
     const unsigned char* rowsL = smem + cur * G::BUF;
     // table [28 taps][32 rows of a tile][4 tiles] u16; a wave's LOCAL tile tl is the block's tile (tl + 2 kh) & 3 (C = 64: local tiles
     // 0, 1 are the ones it finishes in the epilogue, 2, 3 the ones it hands to its partner -- every accumulator index is then a
@@ -194,74 +243,132 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    if (cnt_cur > 0) {   // (a block whose halo did not fit is left to the global-gather kernel launched behind this one)
-      // 27 taps x TW tiles x 2 k-steps, branch-free, software-pipelined by hand: the gathers of tap k + 1 are issued before the MFMAs of tap k
+    if (cnt_cur > 0 && !(C7_ABLATE & 2)) {   // (a block whose halo did not fit is left to the global-gather kernel launched behind this one)
+      // (table addresses: the lane part is fixed per block, the tap part is a scalar -- one shift-add per read)
+      uint32_t tabA = (uint32_t)(tabL - smem) + (C == 64 ? kh * 4 : 0), tabB = (uint32_t)(tabL - smem) + (1 - kh) * 4;
+#ifdef __HIPCC__
+      asm volatile("" : "+v"(tabA), "+v"(tabB));           // keep both as registers (not re-derived per use)
+#endif
       auto entries = [&](int k, uint32_t (&te)[2]) {
         if constexpr (C == 64) {
-          te[0] = *reinterpret_cast<const uint32_t*>(tabL + k * 256 + kh * 4);
-          te[1] = *reinterpret_cast<const uint32_t*>(tabL + k * 256 + (1 - kh) * 4);
+          te[0] = *reinterpret_cast<const uint32_t*>(smem + (tabA + (uint32_t)(k * 256)));
+          te[1] = *reinterpret_cast<const uint32_t*>(smem + (tabB + (uint32_t)(k * 256)));
         } else {
-          te[0] = *reinterpret_cast<const uint16_t*>(tabL + k * 256);
+          te[0] = *reinterpret_cast<const uint16_t*>(smem + (tabA + (uint32_t)(k * 256)));
         }
       };
-      auto gather = [&](const uint32_t (&te)[2], frag (&b)[TW][2]) {
-#pragma unroll
-        for (int t = 0; t < TW; ++t) {
-          const uint32_t off = C == 64 ? ((t & 1) ? (te[t >> 1] >> 16) : (te[t >> 1] & 0xffffu)) : te[0];   // piece 0 of the row (zero row: "none")
-          b[t][0] = *reinterpret_cast<const frag*>(rowsL + (off ^ pxor0));
-          b[t][1] = *reinterpret_cast<const frag*>(rowsL + (off ^ pxor1));
-        }
+      auto gather1 = [&](const uint32_t (&te)[2], int t, int ks) -> frag {
+        uint32_t off = C == 64 ? ((t & 1) ? (te[t >> 1] >> 16) : (te[t >> 1] & 0xffffu)) : te[0];   // piece 0 of the row (zero row: "none")
+        if constexpr ((C7_ABLATE & 32) != 0)   // every lane its own consecutive slot: the conflict-free pattern the swizzle is built for
+          off = (off & 0) + (uint32_t)((j + 32 * t) * ROWB + G::swz(j + 32 * t) * 16);
+        return *reinterpret_cast<const frag*>(rowsL + (off ^ (ks ? pxor1 : pxor0)));
       };
-      uint32_t teA[2], teB[2];
-      frag bA[TW][2], bB[TW][2];
-      entries(0, teA);
-      gather(teA, bA);
-      entries(1, teB);
-      __builtin_amdgcn_sched_barrier(0);      // the pinned interleave below starts here: nothing of the prologue may fill its slots
+      // EMPTY TAPS ARE SKIPPED: bit k of the block's (C = 64) / this wave's tile's (C = 32) tap mask (blocks.hip, table row 27) says
+      // whether any row has a neighbour at tap k -- 67 % of the (block, tap) and 54 % of the (32-row tile, tap) pairs on curve-ordered
+      // indoor scenes (tools/halo_stats.py).  The tap loop stays unrolled (the weight fragment of a tap is a register NAME), each tap
+      // one basic block behind a scalar branch; the gather ring runs over the ACTIVE taps only (its table address is data, not a
+      // name) and is a ROLLING single buffer: the B fragment an MFMA has just consumed is at once reloaded with the same (tile,
+      // k-step) of the next active tap and is needed again 2 TW MFMAs later (C = 64: 256 cycles >> the LDS latency).  (Two named
+      // buffers would need both parities of every step as code, and the compiler then copies the accumulators at every join.)
+      const uint32_t mword = *reinterpret_cast<const uint32_t*>(rowsL + G::ROWS_BYTES + 27 * 256 + (C == 64 ? 16 : wave * 4));
+      const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)mword);
+      uint32_t rest = m;                                   // active taps whose table entries have not been read yet
+      auto pop_tap = [&]() -> int {                        // (past the last active tap: tap 26 again -- a few wasted reads, no branch)
+        int k;
+#ifdef __HIPCC__
+        // scalar unit, spelled out: left to itself the compiler runs this chain on the vector ALU, in the MFMAs' issue slots
+        uint32_t nr;
+        asm("s_ff1_i32_b32 %0, %2\n\ts_cmp_eq_u32 %2, 0\n\ts_cselect_b32 %0, 26, %0\n\ts_add_u32 %1, %2, -1\n\ts_and_b32 %1, %1, %2"
+            : "=&s"(k), "=&s"(nr) : "s"(rest) : "scc");
+        rest = nr;
+#else
+        k = rest ? __builtin_ctz(rest) : 26;
+        rest &= rest - 1u;
+#endif
+        return k;
+      };
+      // The reload of a fragment trails its MFMA by LAG MFMAs (C = 64: 2): a gather whose destination is still an operand of an
+      // MFMA in flight is held at issue until that MFMA retires, and behind it, in order, every later MFMA -- reloading "at once"
+      // ran the loop at one MFMA per 60 cycles, its full latency (profiles/r03_o_conv7_ablate.txt).  So the first LAG fragments of
+      // a step are still loaded from the CURRENT tap's entries (they are multiplied at the end of this step), the others from
+      // the next tap's.
+      constexpr int NF = 2 * TW, LAG = C == 64 ? 2 : 0;
+      uint32_t teC[2], teN[2], teNN[2];
+      frag b[NF];                                          // fragment i = (k-step i / TW, tile i % TW)
+      entries(pop_tap(), teC);
 #pragma unroll
-      for (int k = 0; k < 27; ++k) {
-        frag (&bc)[TW][2] = (k & 1) ? bB : bA;
-        frag (&bn)[TW][2] = (k & 1) ? bA : bB;
-        uint32_t (&tn)[2] = (k & 1) ? teA : teB;      // entries of tap k + 1 (read one tap ago)
-        uint32_t (&tnn)[2] = (k & 1) ? teB : teA;     // entries of tap k + 2: overwrites those of tap k
-        if (k + 1 < 27) gather(tn, bn);
-        if (k + 2 < 27) entries(k + 2, tnn);
-        // k-step outer, tile inner: two MFMAs on one accumulator are TW MFMAs apart
+      for (int i = 0; i < NF - LAG; ++i) b[i] = gather1(teC, i % TW, i / TW);
+      entries(pop_tap(), teN);
+      if constexpr (LAG == 0) { teC[0] = teN[0]; teC[1] = teN[1]; }
+      tick(1);                                          // accumulator reset, mask, first gathers
+      ptc_static_for<27>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (m & (1u << k)) {                               // wave-uniform
+          __builtin_amdgcn_sched_barrier(0);               // the pinned interleave below starts here
+          entries(pop_tap(), teNN);                        // the active tap after the next one
+          // k-step outer, tile inner: two MFMAs on one accumulator are TW MFMAs apart
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int t = 0; t < TW; ++t) {
-            c7_f32x16& a = acc[C == 64 ? t : ks];
-            a = MM::mma(wf[k][ks], bc[t][ks], a);
+          for (int i = 0; i < NF; ++i) {
+            c7_f32x16& a = acc[C == 64 ? i % TW : i / TW];
+            a = MM::mma(wf[k][i / TW], b[i], a);
+            const int g = (i + NF - LAG) % NF;             // the fragment consumed LAG MFMAs ago
+            b[g] = gather1(i < LAG ? teC : teN, g % TW, g / TW);
           }
-        // pin the interleave (one wave per SIMD: nothing else hides the LDS latency, and a 32-cycle MFMA hides ~5 other issues):
-        // per MFMA one address computation + gather of the NEXT tap; the table read of tap k + 2 rides in front
-        __builtin_amdgcn_sched_group_barrier(0x100, C == 64 ? 2 : 1, 0);
+          teC[0] = teN[0];
+          teN[0] = teNN[0];
+          if constexpr (C == 64) { teC[1] = teN[1]; teN[1] = teNN[1]; }
+          if constexpr (LAG == 0) { teC[0] = teN[0]; teC[1] = teN[1]; }
+          // pin the interleave (one wave per SIMD: nothing else hides the LDS latency, and a 32-cycle MFMA hides ~5 other issues):
+          // the table read rides in front, then per MFMA: the MFMA, the address computation and one fragment reload
+          __builtin_amdgcn_sched_group_barrier(0x002, C == 64 ? 2 : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, C == 64 ? 2 : 1, 0);
 #pragma unroll
-        for (int q = 0; q < 2 * TW; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // <= 2 VALU (field extract, xor-add)
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // 1 LDS gather
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // 1 MFMA
+          for (int q = 0; q < NF; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // <= 2 VALU: field extract, xor-add
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // 1 LDS gather
+          }
         }
-      }
+      });
+      tick(2);                                          // the tap loop
     }
 
     // ---- epilogue: lane (j, h) holds, of row j of a tile, output channels ch * 32 + 8 q + 4 h + 0..3, q = 0..3
+    // 16-byte stores: lane (j, 0) takes channels 8 q .. 8 q + 7 of q = 0 and 2, lane (j, 1) those of q = 1 and 3 -- the halves of a
+    // row's 8-channel groups trade places across the two 32-lane halves (4 swaps per tile), then 2 stores per tile, each covering
+    // 32 contiguous bytes of every row (the first version: 4 stores of 8 scattered bytes per lane)
     auto store_tile = [&](int tile, const c7_f32x16& a) {
       const int64_t row = row0 + tile * 32 + j;
+      uint32_t pk[4][2];                                   // [q][0 | 1]: channels 8 q + 4 h + (0, 1 | 2, 3) as a 16-bit pair
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          T o[2] = {ptc_from_float<T>(a[4 * q + 2 * e] + bsv[4 * q + 2 * e]), ptc_from_float<T>(a[4 * q + 2 * e + 1] + bsv[4 * q + 2 * e + 1])};
+          __builtin_memcpy(&pk[q][e], o, 4);
+        }
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) c7_swap32(pk[2 * qq][e], pk[2 * qq + 1][e]);
+      // now (pk[2 qq][*], pk[2 qq + 1][*]) = channels 8 (2 qq + h) .. + 7 of row j
       if (row < n_out && cnt_cur > 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          T o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = ptc_from_float<T>(a[4 * q + e] + bsv[4 * q + e]);
-          uint2 v;
-          __builtin_memcpy(&v, o, 8);
-          *reinterpret_cast<uint2*>(out + row * C + ch * 32 + 8 * q + 4 * h) = v;
+        for (int qq = 0; qq < 2; ++qq) {
+          const uint4 v = make_uint4(pk[2 * qq][0], pk[2 * qq][1], pk[2 * qq + 1][0], pk[2 * qq + 1][1]);
+          if constexpr ((C7_ABLATE & 16) != 0) asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));      // (the value stays live: no dead MFMAs)
+          else *reinterpret_cast<uint4*>(out + row * C + ch * 32 + 8 * (2 * qq + h)) = v;
         }
       }
     };
-    if constexpr (C == 64) {
+    if constexpr ((C7_ABLATE & 4) != 0) {
+#pragma unroll
+      for (int t = 0; t < (C == 64 ? 4 : 2); ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(acc[t][r]));
+      __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
+      __builtin_amdgcn_s_barrier();
+    } else if constexpr (C == 64) {
       // the two input-channel halves of a tile meet in LDS: wave kh finishes the block's tiles 2 kh, 2 kh + 1 (its local tiles 0, 1)
       // and hands the others (local 2, 3 = the partner's local 0, 1) to its partner
       unsigned char* scr = smem + 2 * G::BUF;
@@ -271,24 +378,31 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 v = {acc[2 + tl][4 * q], acc[2 + tl][4 * q + 1], acc[2 + tl][4 * q + 2], acc[2 + tl][4 * q + 3]};
-          *reinterpret_cast<f32x4*>(scr + ((partner * 2 + tl) * 4 + q) * 1024 + lane * 16) = v;
+          if constexpr ((C7_ABLATE & 8) != 0) asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+          else *reinterpret_cast<f32x4*>(scr + ((partner * 2 + tl) * 4 + q) * 1024 + lane * 16) = v;
         }
+      tick(3);                                          // accumulators -> scratch
       __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);   // scratch written; next block's rows + table and the ids landed
+      tick(4);                                          // wait: DMA of the next block, scratch writes
       __builtin_amdgcn_s_barrier();
+      tick(5);                                          // barrier
 #pragma unroll
       for (int tl = 0; tl < 2; ++tl) {
         c7_f32x16 a = acc[tl];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(scr + ((wave * 2 + tl) * 4 + q) * 1024 + lane * 16);
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+          if (!(C7_ABLATE & 8)) o = *reinterpret_cast<const f32x4*>(scr + ((wave * 2 + tl) * 4 + q) * 1024 + lane * 16);
 #pragma unroll
           for (int e = 0; e < 4; ++e) a[4 * q + e] += o[e];
         }
         store_tile(2 * kh + tl, a);
       }
       // the partner must not reach its next scratch write before this wave has read: a second barrier (the epilogues are symmetric)
+      tick(6);                                          // partner's half added, rows stored
       __builtin_amdgcn_s_waitcnt(C7_WAIT_LGKM0);
       __builtin_amdgcn_s_barrier();
+      tick(7);                                          // second barrier
     } else {
       // wait for the DMA of the next block BEFORE the stores of this one are issued: they retire during the next block's MFMAs
       __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
@@ -298,9 +412,18 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       for (int r = 0; r < 16; ++r) a[r] += acc[1][r];
       store_tile(wave, a);
     }
-    cur ^= 1;
+    if (!(C7_ABLATE & 1)) cur ^= 1;
     cnt_cur = cnt_nxt;
     cnt_nxt = __builtin_amdgcn_readfirstlane(cnt_nn);
+  }
+  if constexpr ((C7_ABLATE & 64) != 0) {
+    __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
+    __builtin_amdgcn_s_barrier();
+    if (threadIdx.x == 0) {
+      long long* o = reinterpret_cast<long long*>(out + (int64_t)blockIdx.x * C);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = tph[i];
+    }
   }
 }
 
@@ -317,8 +440,6 @@ static int launch_conv7_i(const void* in, int64_t n_in, const void* w, const flo
   if (const char* e = getenv("PTC_EMU_CONV7_WGS")) max_wgs = atoi(e);   // host emulation only: few workgroups = many blocks each at test sizes
 #endif
   int grid = n_blocks < max_wgs ? n_blocks : max_wgs;
-  const int per_wg = (n_blocks + grid - 1) / grid;
-  grid = (n_blocks + per_wg - 1) / per_wg;
   auto kern = conv7_kernel<T, C>;
   static bool attr = false;   // per instantiation
   if (!attr) {
@@ -326,13 +447,14 @@ static int launch_conv7_i(const void* in, int64_t n_in, const void* w, const flo
     attr = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C7Geom<C>::LDS, s, (const T*)in, (const T*)w, bias, tab, hid, hcnt, n_out,
-                     n_blocks, per_wg, (T*)out);
+                     n_blocks, (T*)out);
   PTC_CHECK_LAUNCH("conv7_kernel");
   return PTC_OK;
 }
 
 // conv7 over the blocks whose halo fits, then conv5 (its 128-row workgroups are the same blocks) over the others: a workgroup of
-// the second launch whose block conv7 served returns at once
+// the second launch whose block conv7 served returns at once.  (Tried: the overflow path inside conv7 -- global gathers with the
+// same wave roles.  The second code path costs the 64-channel kernel its register allocation: 512 registers + 572 bytes of scratch.)
 template <typename T>
 static int launch_conv7(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, const uint16_t* tab,
                         const int32_t* hid, const int32_t* hcnt, int64_t n_out, int c, void* out, hipStream_t s) {

@@ -78,3 +78,13 @@ static inline size_t ptc_dtype_size(int dtype) { return dtype == PTC_F32 ? 4 : 2
 
 // ---- wave helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ int ptc_lane() { return threadIdx.x & 63; }
+
+// f(ptc_int<0>{}), f(ptc_int<1>{}), ...: an unrolled loop whose index is a TYPE (a register array indexed by it never turns into a
+// runtime-indexed -- i.e. scratch -- access, whatever the control flow inside f)
+template <int I> struct ptc_int { static constexpr int value = I; };
+template <int N, int I = 0, typename F> __device__ __forceinline__ void ptc_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(ptc_int<I>{});
+    ptc_static_for<N, I + 1>(f);
+  }
+}

@@ -351,7 +351,8 @@ def _curve_sorted_indices(n_pts, batch=2):
 @pytest.mark.parametrize("ordered", [True, False])
 def test_rulebook_blocks(cuda, ordered):
     """block-local rulebook (csrc/blocks.hip): halo lists ascending + distinct + exactly the rows the block names (padded with the last
-    one to a multiple of 16), the uint16 table maps every entry to its position at [block][tap][row in tile][tile]; rows in no spatial
+    one to a multiple of 16), the uint16 table maps every entry to its position at [block][tap][row in tile][tile] and carries the
+    per-tile tap-occupancy masks in its padding row; rows in no spatial
     order overflow and are flagged (count -1), not truncated."""
     from pointcept_amd import ops
 
@@ -385,7 +386,16 @@ def test_rulebook_blocks(cuda, ordered):
             slot = le // rowb
             assert np.array_equal((le % rowb)[e >= 0], ((((slot >> sw_shift) & sw_mask) * 16))[e >= 0])     # piece 0 at its swizzled position
             assert np.array_equal(hid[b][np.where(le != none, slot, 0)][e >= 0], e[e >= 0])
-            assert (tab[v, b, 27] == none).all() and (full[:, rows:] == none).all()
+            assert (full[:, rows:] == none).all()
+            # table row 27: the tap masks (bit k of word t: tile t has a neighbour at tap k; word 4: their OR), then "none" padding
+            pad = tab[v, b, 27].reshape(-1)
+            words = pad[:10].astype(np.uint32)
+            masks = words[0::2] | (words[1::2] << 16)
+            occ = np.zeros((27, 128), bool)
+            occ[:, :rows] = e >= 0
+            want_masks = [sum(1 << k for k in range(27) if occ[k, 32 * t:32 * t + 32].any()) for t in range(4)]
+            assert masks[:4].tolist() == want_masks and int(masks[4]) == (want_masks[0] | want_masks[1] | want_masks[2] | want_masks[3])
+            assert (pad[10:] == none).all()
     assert int(bt.n_overflow.item()) == n_ovf
     if ordered:
         assert n_ovf == 0, "curve-ordered rows must fit their halo budget"

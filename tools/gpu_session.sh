@@ -2,7 +2,7 @@
 # One GPU-box session.  Usage (through gpurun): bash tools/gpu_session.sh <tag> <sections...>
 #   tests      whole -m gpu suite            ops     tools/bench_ops.py
 #   bench      bench.py (default switches)   ab:<ENV=V,...>  bench.py with switches (no cpu baseline)
-#   prof       rocprofv3 kernel stats of bench.py
+#   prof       rocprofv3 kernel stats of ONE steady-state bench.py step (two runs, tools/steady_state_stats.py); profsmall: the 2 x 20000 step
 #   contention tools/host_contention.py: host CPU time per step of 1 vs 8 concurrent processes
 #   hostlead   tools/host_lead.py: host enqueue time per step vs completed time (executor on / off, and a 2 x 20000-voxel step)
 #   roof       rocprofv3 stats + PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) of the roofline kernel
@@ -35,7 +35,13 @@ for sec in "$@"; do
     ab:*) envs=$(echo "${sec#ab:}" | tr ',' ' '); name=$(echo "${sec#ab:}" | tr -c 'A-Za-z0-9=\n' '_');
           env $envs timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_${name}.log 2>&1; echo "$sec: $(tail -1 $O/${TAG}_bench_${name}.log | cut -c1-200)";;
     prof) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_prof.log 2>&1
-          cd $R; TOP=30 python tools/prof_top.py $O/${TAG}_prof 5 $O/${TAG}_kernel_stats.csv > $O/${TAG}_prof_top.log 2>&1; rm -rf $O/${TAG}_prof;;
+          timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof7 -- python $R/bench.py --steps 7 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_prof7.log 2>&1
+          cd $R; TOP=30 python tools/steady_state_stats.py $O/${TAG}_prof 3 $O/${TAG}_prof7 7 $O/${TAG}_kernel_stats.csv > $O/${TAG}_prof_top.log 2>&1
+          python tools/kernel_neighbours.py $O/${TAG}_prof > $O/${TAG}_fill_copy_neighbours.txt 2>&1; rm -rf $O/${TAG}_prof $O/${TAG}_prof7; tail -1 $O/${TAG}_kernel_stats.csv;;
+    profsmall) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profs -- python $R/bench.py --batch 2 --points 20000 --steps 3 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_profs.log 2>&1
+          timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profs7 -- python $R/bench.py --batch 2 --points 20000 --steps 7 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_profs7.log 2>&1
+          cd $R; TOP=30 python tools/steady_state_stats.py $O/${TAG}_profs 3 $O/${TAG}_profs7 7 $O/${TAG}_small_kernel_stats.csv > $O/${TAG}_profs_top.log 2>&1
+          rm -rf $O/${TAG}_profs $O/${TAG}_profs7; tail -1 $O/${TAG}_small_kernel_stats.csv;;
     roof) cd /tmp
           timeout 600 rocprofv3 --kernel-trace --stats -d $O/${TAG}_roof_stats -- python $R/tools/roofline_kernel.py > $O/${TAG}_roof_stats.log 2>&1
           timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_roof_fetch -- python $R/tools/roofline_kernel.py > $O/${TAG}_roof_fetch.log 2>&1
