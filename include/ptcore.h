@@ -243,7 +243,8 @@ int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float
  *                                     first 16 bytes of row nbr[k][128 b + 32 t + r] -- v = 0: 128-byte rows (64 channels),
  *                                     slot * 128 + ((slot >> 1) & 7) * 16; v = 1: 64-byte rows (32 channels), slot * 64 +
  *                                     ((slot >> 2) & 3) * 16, slot = position in the block's list; none = hcap * row bytes;
- *                                     row k = 27 padding
+ *                                     row k = 27: the tap masks in its first 20 bytes -- four uint32, bit k of word t set when
+ *                                     tile t (rows 32 t .. 32 t + 31) has a neighbour at tap k, then their OR -- the rest "none"
  *       *n_overflow (device int32)  = number of blocks with hcnt = -1 (diagnostic; nothing depends on it)
  *     hcap a multiple of 16, < 512.
  *   ptc_spconv_fwd_blk: same result as ptc_spconv_fwd(in, ..., nbr, ...) up to the fp32 rounding of a different summation

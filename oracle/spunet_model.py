@@ -49,8 +49,9 @@ def _stage(n_blocks, c_first, c, key):
 
 class SpUNetBase(nn.Module):
     def __init__(self, in_channels, num_classes, base_channels=32, channels=(32, 64, 128, 256, 256, 128, 96, 96),
-                 layers=(2, 3, 4, 6, 2, 2, 2, 2), enc_mode=False):
+                 layers=(2, 3, 4, 6, 2, 2, 2, 2), enc_mode=False, skip=True):
         super().__init__()
+        self.skip = skip
         S = len(layers) // 2
         assert len(layers) == 2 * S == len(channels)
         self.num_stages, self.enc_mode = S, enc_mode
@@ -71,7 +72,7 @@ class SpUNetBase(nn.Module):
                 self.up.append(sp.SparseSequential(
                     sp.SparseInverseConv3d(channels[2 * S - s - 2], c_dec, kernel_size=2, bias=False, indice_key=key),
                     _bn(c_dec), nn.ReLU()))
-                self.dec.append(_stage(layers[2 * S - s - 1], c_dec + c_enc, c_dec, f"subm{s}"))
+                self.dec.append(_stage(layers[2 * S - s - 1], c_dec + c_enc if skip else c_dec, c_dec, f"subm{s}"))
             c_enc, c_dec = channels[s], channels[2 * S - s - 2]
         c_final = channels[S - 1] if enc_mode else channels[-1]
         self.final = sp.SubMConv3d(c_final, num_classes, kernel_size=1, padding=1, bias=True) \
@@ -83,7 +84,7 @@ class SpUNetBase(nn.Module):
         batch = torch.repeat_interleave(torch.arange(len(offset), device=offset.device), counts)   # misc.py:12-17
         x = sp.SparseConvTensor(
             features=feat, indices=torch.cat([batch[:, None].int(), grid_coord.int()], dim=1).contiguous(),
-            spatial_shape=(grid_coord.max(dim=0).values + 96).tolist(), batch_size=int(batch[-1]) + 1)   # spunet:249-257
+            spatial_shape=(grid_coord.max(dim=0).values + (96 if self.skip else 1)).tolist(), batch_size=int(batch[-1]) + 1)   # spunet:249-257 / :437
         x = self.conv_input(x)
         skips = [x]
         for s in range(self.num_stages):
@@ -93,12 +94,21 @@ class SpUNetBase(nn.Module):
         if not self.enc_mode:
             for s in range(self.num_stages - 1, -1, -1):
                 x = self.up[s](x)
-                x = x.replace_feature(torch.cat([x.features, skips.pop().features], dim=1))                # spunet:272
+                if self.skip:
+                    x = x.replace_feature(torch.cat([x.features, skips.pop().features], dim=1))            # spunet:272
                 x = self.dec[s](x)
         x = self.final(x)
         if self.enc_mode:
             x = x.replace_feature(sp.scatter(x.features, x.indices[:, 0].long(), reduce="mean", dim=0))   # spunet:276-279
         return x.features
+
+
+class SpUNetNoSkipBase(SpUNetBase):
+    """spconv_unet_v1m1_base.py:283-463: no encoder -> decoder concatenation (:456-457 are commented out in the reference)"""
+
+    def __init__(self, in_channels, out_channels, base_channels=32, channels=(32, 64, 128, 256, 256, 128, 96, 96),
+                 layers=(2, 3, 4, 6, 2, 2, 2, 2)):
+        super().__init__(in_channels, out_channels, base_channels, channels, layers, enc_mode=False, skip=False)
 
 
 class Segmentor(nn.Module):

@@ -55,6 +55,7 @@ MODEL_CLASSES = {                                   # registry name (reference f
     "PT-v3m3": ("point_transformer_v3m3", "PointTransformerV3"),      # point_transformer_v3m3_utonia.py:686
     "LitePT-v1": ("litept", "LitePT"),                                # litept_v1.py:593
     "SpUNet-v1m1": ("sparse_unet", "SpUNetBase"),                     # spconv_unet_v1m1_base.py:88
+    "SpUNetNoSkipBase": ("sparse_unet", "SpUNetNoSkipBase"),          # spconv_unet_v1m1_base.py:283 (registered under its class name)
 }
 
 

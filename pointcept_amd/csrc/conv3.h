@@ -248,9 +248,13 @@ static int launch_conv3(const void* in, int64_t n_in, const void* w, const float
   // 64 output channels per workgroup (96 when c_out is a multiple of 96 but not of 64 -- SpUNet's decoder --
   // else 32); 256-row workgroups when they still give every CU a workgroup, else 128-row ones
   const int nt = c_out % 64 == 0 ? 4 : (c_out % 96 == 0 ? 6 : 2);
-  bool big = ptc_cdiv(n_out, 256) * (c_out / (nt * 16)) >= 256;   // >= one 256-row workgroup per CU (r01_ag: N = 50k, C = 128: 79 vs 88 us)
   // table rows one 128-wide chunk can touch: 1 (c_in % 128 == 0), 4 (c_in = 32), else 2
   const int kpc = c_in == 8 ? 16 : (c_in % 128 == 0 ? 1 : (c_in == 32 ? 4 : 2));
+  // >= one 256-row workgroup per CU (r01_ag: N = 50k, C = 128: 79 vs 88 us).  96-wide tiles: 256 rows x 96 channels of accumulators
+  // sit at the 256-register cap -- the c_in = 32 / 8 forms spilled 84-100 bytes per lane and are built with 128 rows only; the
+  // c_in = 96 / 192 form keeps 256 rows with 16 bytes of scratch because it is FASTER than the spill-free 128-row one (SpUNet step
+  // 28.4 vs 29.6 ms, profiles/r03_q_spunet_nt6_ab.txt); c_in % 128 == 0 does not spill
+  const bool big = (nt != 6 || kpc <= 2) && ptc_cdiv(n_out, 256) * (c_out / (nt * 16)) >= 256;
   const bool gen = !(c_in == 8 || c_in == 32 || c_in == 64 || c_in % 128 == 0);   // table rows straddle chunks (kpc == 2)
   if (nbr == nullptr) {   // dense GEMM (kv = 1, c_in % 128 == 0): identity-table instances
 #define C3_ID_CASE(N)                                                                                                        \
@@ -268,9 +272,13 @@ static int launch_conv3(const void* in, int64_t n_in, const void* w, const float
                : launch_conv3_i<T, 2, K, N, G>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
   C3_CASE(1, 4, false) C3_CASE(2, 4, false) C3_CASE(4, 4, false) C3_CASE(2, 4, true)
   C3_CASE(1, 2, false) C3_CASE(2, 2, false) C3_CASE(2, 2, true) C3_CASE(4, 2, false)
-  C3_CASE(1, 6, false) C3_CASE(2, 6, false) C3_CASE(4, 6, false) C3_CASE(2, 6, true)
-  C3_CASE(16, 2, false) C3_CASE(16, 4, false) C3_CASE(16, 6, false)
+  C3_CASE(16, 2, false) C3_CASE(16, 4, false)
+  C3_CASE(1, 6, false) C3_CASE(2, 6, false) C3_CASE(2, 6, true)
 #undef C3_CASE
+#define C3_CASE6(K, G)                                                                                                     \
+  if (kpc == K && nt == 6 && gen == G) return launch_conv3_i<T, 2, K, 6, G>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  C3_CASE6(4, false) C3_CASE6(16, false)
+#undef C3_CASE6
   ptc_set_error("conv3: c_in=%d c_out=%d unsupported", c_in, c_out);
   return PTC_EUNSUPPORTED;
 }

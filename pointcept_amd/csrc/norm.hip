@@ -188,12 +188,15 @@ extern "C" int ptc_layer_norm_fwd(const void* x, int64_t n, int c, int in_dtype,
   PTC_REQUIRE(out_dtype == PTC_F32 || out_dtype == in_dtype || in_dtype == PTC_F32, PTC_EUNSUPPORTED,
               "ptc_layer_norm_fwd: unsupported dtype pair %d -> %d", in_dtype, out_dtype);
   hipStream_t s = (hipStream_t)stream;
-  PTC_DISPATCH_DTYPE(in_dtype, TI, {
-    if (out_dtype == PTC_F32) return launch_ln_fwd<TI, float>(x, n, c, gamma, beta, eps, y, mean, rstd, s);
-    if (out_dtype == PTC_BF16) return launch_ln_fwd<TI, bf16_t>(x, n, c, gamma, beta, eps, y, mean, rstd, s);
-    return launch_ln_fwd<TI, f16_t>(x, n, c, gamma, beta, eps, y, mean, rstd, s);
-  });
-  return PTC_OK;
+  // (the seven pairs the check above admits; bf16 <-> f16 pairs are not instantiated)
+#define LN_PAIR(DI, DO, TI, TO) \
+  if (in_dtype == DI && out_dtype == DO) return launch_ln_fwd<TI, TO>(x, n, c, gamma, beta, eps, y, mean, rstd, s);
+  LN_PAIR(PTC_F32, PTC_F32, float, float) LN_PAIR(PTC_F32, PTC_BF16, float, bf16_t) LN_PAIR(PTC_F32, PTC_F16, float, f16_t)
+  LN_PAIR(PTC_BF16, PTC_BF16, bf16_t, bf16_t) LN_PAIR(PTC_BF16, PTC_F32, bf16_t, float)
+  LN_PAIR(PTC_F16, PTC_F16, f16_t, f16_t) LN_PAIR(PTC_F16, PTC_F32, f16_t, float)
+#undef LN_PAIR
+  ptc_set_error("ptc_layer_norm_fwd: bad dtype codes %d -> %d", in_dtype, out_dtype);
+  return PTC_EINVAL;
 }
 
 extern "C" size_t ptc_layer_norm_bwd_workspace_bytes(int64_t n, int c) {
@@ -241,12 +244,14 @@ extern "C" int ptc_layer_norm_bwd(const void* dy, int dy_dtype, const void* x, i
   PTC_REQUIRE(workspace_bytes >= ptc_layer_norm_bwd_workspace_bytes(n, c), PTC_EWORKSPACE, "ptc_layer_norm_bwd: workspace too small");
   PTC_REQUIRE(dy_dtype == PTC_F32 || dy_dtype == x_dtype || x_dtype == PTC_F32, PTC_EUNSUPPORTED,
               "ptc_layer_norm_bwd: unsupported dtype pair dy %d / x %d", dy_dtype, x_dtype);
-  PTC_DISPATCH_DTYPE(x_dtype, TX, {
-    if (dy_dtype == PTC_F32) return launch_ln_bwd<float, TX>(dy, x, mean, rstd, gamma, n, c, dx, dgamma, dbeta, workspace, s);
-    if (dy_dtype == PTC_BF16) return launch_ln_bwd<bf16_t, TX>(dy, x, mean, rstd, gamma, n, c, dx, dgamma, dbeta, workspace, s);
-    return launch_ln_bwd<f16_t, TX>(dy, x, mean, rstd, gamma, n, c, dx, dgamma, dbeta, workspace, s);
-  });
-  return PTC_OK;
+#define LN_PAIR(DG, DX, TG, TX) \
+  if (dy_dtype == DG && x_dtype == DX) return launch_ln_bwd<TG, TX>(dy, x, mean, rstd, gamma, n, c, dx, dgamma, dbeta, workspace, s);
+  LN_PAIR(PTC_F32, PTC_F32, float, float) LN_PAIR(PTC_F32, PTC_BF16, float, bf16_t) LN_PAIR(PTC_F32, PTC_F16, float, f16_t)
+  LN_PAIR(PTC_BF16, PTC_BF16, bf16_t, bf16_t) LN_PAIR(PTC_BF16, PTC_F32, bf16_t, float)
+  LN_PAIR(PTC_F16, PTC_F16, f16_t, f16_t) LN_PAIR(PTC_F16, PTC_F32, f16_t, float)
+#undef LN_PAIR
+  ptc_set_error("ptc_layer_norm_bwd: bad dtype codes dy %d / x %d", dy_dtype, x_dtype);
+  return PTC_EINVAL;
 }
 
 // ================================================================================================

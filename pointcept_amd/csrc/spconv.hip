@@ -549,7 +549,7 @@ static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const i
   if (p.cot == COT && p.cit == CIT && p.kg == KG)                                                                     \
     rc = launch_wgrad2_inst<T, COT, CIT, KG>(p, in, n_in, dout, nbr, n_out, kv, c_in, c_out, partial, bias_partial, s);
   W2_CASE(2, 1, 1) W2_CASE(2, 2, 1) W2_CASE(2, 4, 1) W2_CASE(4, 1, 1) W2_CASE(4, 2, 1) W2_CASE(4, 4, 1)
-  W2_CASE(6, 1, 1) W2_CASE(6, 2, 1) W2_CASE(6, 4, 1) W2_CASE(8, 1, 1) W2_CASE(8, 2, 1) W2_CASE(8, 4, 1)
+  W2_CASE(6, 1, 1) W2_CASE(6, 2, 1) W2_CASE(6, 4, 1) W2_CASE(8, 1, 1) W2_CASE(8, 2, 1)   // (8, 4, 1): never planned (w2_plan caps 64-wide input tiles at 64 outputs), spilled
   W2_CASE(2, 1, 16) W2_CASE(2, 2, 4) W2_CASE(4, 2, 4) W2_CASE(2, 4, 4) W2_CASE(4, 4, 2) W2_CASE(6, 2, 2)
 #undef W2_CASE
   if (rc != PTC_OK) {

@@ -61,9 +61,10 @@ class BasicBlock(spconv.SparseModule):
 
 class SpUNetBase(nn.Module):
     def __init__(self, in_channels, num_classes, base_channels=32, channels=(32, 64, 128, 256, 256, 128, 96, 96),
-                 layers=(2, 3, 4, 6, 2, 2, 2, 2), enc_mode=False):
+                 layers=(2, 3, 4, 6, 2, 2, 2, 2), enc_mode=False, skip=True):
         super().__init__()
         assert len(layers) % 2 == 0 and len(layers) == len(channels)
+        self.skip = skip      # False: the decoder does not read the encoder's features (SpUNetNoSkipBase below)
         self.in_channels, self.num_classes, self.base_channels = in_channels, num_classes, base_channels
         self.channels, self.layers = channels, layers
         self.num_stages = len(layers) // 2
@@ -93,7 +94,7 @@ class SpUNetBase(nn.Module):
                     norm_fn(dec_channels), PNN.ReLU()))
                 PNN.absorb_activations(self.up[-1]._modules.values())
                 self.dec.append(spconv.SparseSequential(OrderedDict(
-                    (f"block{i}", BasicBlock(dec_channels + enc_channels if i == 0 else dec_channels, dec_channels,
+                    (f"block{i}", BasicBlock(dec_channels + enc_channels if i == 0 and skip else dec_channels, dec_channels,
                                              norm_fn=norm_fn, indice_key=f"subm{s}"))
                     for i in range(layers[len(channels) - s - 1]))))
             enc_channels = channels[s]
@@ -141,7 +142,7 @@ class SpUNetBase(nn.Module):
         n_dup = (rep != torch.arange(n, device=rep.device, dtype=rep.dtype)).sum().reshape(1).to(torch.int64)
         host = torch.cat([ops.coord_max(grid_coord), n_dup]).tolist()
         ops.check_coord_range(host[:3], offset.numel())
-        sparse_shape = [int(m) + 96 for m in host[:3]]  # spconv_unet_v1m1_base.py:250 (one host sync)
+        sparse_shape = [int(m) + (96 if self.skip else 1) for m in host[:3]]  # spconv_unet_v1m1_base.py:250 / :437 (one host sync)
         x = spconv.SparseConvTensor(features=feat, indices=indices, spatial_shape=sparse_shape, batch_size=int(offset.numel()))
         x.indice_dict["__hash__"] = table
         spconv.mark_duplicates(x, host[3] > 0)   # Mix3D batches: the conv backward needs to know (functional._SparseConv)
@@ -156,8 +157,8 @@ class SpUNetBase(nn.Module):
         if not self.enc_mode:
             for s in reversed(range(self.num_stages)):
                 x = self.up[s](x)
-                skip = skips.pop(-1)
-                x = x.replace_feature(torch.cat((x.features, skip.features), dim=1))
+                if self.skip:
+                    x = x.replace_feature(torch.cat((x.features, skips.pop(-1).features), dim=1))
                 x = self.dec[s](x)
         x = self.final(x)
         if self.enc_mode:  # per-scene mean (torch_geometric.utils.scatter(reduce="mean"), :276-279)
@@ -169,3 +170,14 @@ class SpUNetBase(nn.Module):
         if unsort is not None:
             return PF.gather_rows(x.features, unsort, order)     # caller's row order; backward = gather through `order`
         return x.features
+
+
+class SpUNetNoSkipBase(SpUNetBase):
+    """the same U-Net without the encoder -> decoder concatenations (spconv_unet_v1m1_base.py:283-463, registry name
+    `SpUNetNoSkipBase`): decoder blocks take the up-sampled features alone, so their first block has `dec_channels` inputs;
+    state-dict keys and shapes are the reference class's."""
+
+    def __init__(self, in_channels, out_channels, base_channels=32, channels=(32, 64, 128, 256, 256, 128, 96, 96),
+                 layers=(2, 3, 4, 6, 2, 2, 2, 2)):
+        super().__init__(in_channels, out_channels, base_channels=base_channels, channels=channels, layers=layers, skip=False)
+        self.out_channels = out_channels

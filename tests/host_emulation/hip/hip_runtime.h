@@ -294,6 +294,7 @@ static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned lo
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu::block_sync()
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)           /* one lane runs at a time: every memory operation has completed */
+static inline long long clock64() { return 0; }            /* timing probes (conv7 C7_ABLATE & 64) have no meaning here */
 #define __builtin_amdgcn_readfirstlane(x) (x)              /* callers pass wave-uniform values */
 // global_load_lds: `sz` bytes per lane, global -> LDS at (wave-uniform base) + sz * lane.  Lands at once here; on the hardware it
 // lands asynchronously (vmcnt) -- the emulation cannot see a missing wait.

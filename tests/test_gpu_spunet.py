@@ -173,6 +173,35 @@ def test_spunet_enc_mode(cuda):
     assert _rel(out, ref) < 2e-3
 
 
+def test_spunet_no_skip_variant(cuda):
+    """SpUNetNoSkipBase (spconv_unet_v1m1_base.py:283-463: the decoder does not concatenate the encoder's features): same keys and
+    shapes as the oracle restatement of that class, logits and gradients of a train-mode step within the fp32 bars of the v1m1 test"""
+    from oracle import ptv3_model as om
+    from oracle import spunet_model as osp
+    from pointcept_amd import synthetic
+    from pointcept_amd.sparse_unet import SpUNetNoSkipBase
+
+    orc, eng = osp.SpUNetNoSkipBase(6, 20, **TINY), SpUNetNoSkipBase(6, 20, **TINY)
+    assert list(orc.state_dict().keys()) == list(eng.state_dict().keys())
+    assert all(a.shape == b.shape for a, b in zip(orc.state_dict().values(), eng.state_dict().values()))
+    assert eng.dec[0].block0.conv1.in_channels == TINY["channels"][-1]          # no concatenated encoder channels
+    sd = om.deterministic_state_dict(orc, 4)
+    orc.load_state_dict(sd)
+    eng.load_state_dict(sd)
+    eng = eng.to(cuda).train()
+    orc.train()
+    batch = synthetic.collate([synthetic.indoor_scene(61, 3000), synthetic.indoor_scene(62, 700)])
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    ref = orc(tb)
+    torch.nn.functional.cross_entropy(ref, tb["segment"], ignore_index=-1).backward()
+    gb = synthetic.to_torch(batch, cuda)
+    out = eng(gb)
+    torch.nn.functional.cross_entropy(out, gb["segment"], ignore_index=-1).backward()
+    assert _rel(out, ref) < 2e-3
+    worst = max(_rel(pe.grad, po.grad) for (_, pe), (_, po) in zip(eng.named_parameters(), orc.named_parameters()) if po.grad is not None)
+    assert worst < 5e-2, worst
+
+
 def test_spunet_autocast_and_determinism(cuda):
     """bf16 / fp16 autocast (the reference trains under fp16 AMP, train.py:202-208) stay close to fp32, and two runs
     are bit-identical (no atomics)."""

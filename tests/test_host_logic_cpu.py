@@ -287,6 +287,20 @@ def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
                 outs.append(o.detach())
             assert _rel(outs[1], outs[0]) < 1e-4
             _grad_check(d, c, 2e-3)
+            # the no-skip variant of the same reference file (spconv_unet_v1m1_base.py:283-463)
+            c, d = R["spunet"].SpUNetNoSkipBase(6, 20, **scfg), E["spunet"].SpUNetNoSkipBase(6, 20, **scfg)
+            assert list(c.state_dict().keys()) == list(d.state_dict().keys())
+            sd = om.deterministic_state_dict(c, 26)
+            c.load_state_dict(sd)
+            d.load_state_dict(sd)
+            outs = []
+            for net in (c, d):
+                net.train()
+                o = net({k: v for k, v in batch.items()})
+                torch.nn.functional.cross_entropy(o, batch["segment"], ignore_index=-1).backward()
+                outs.append(o.detach())
+            assert _rel(outs[1], outs[0]) < 1e-4
+            _grad_check(d, c, 2e-3)
     finally:
         for k in names:
             sys.modules.pop(k, None)
@@ -867,7 +881,7 @@ def test_flash_attn_mirror_accepts_fp16_like_liteptS_call_site():
 
 @pytest.mark.needs_reference
 def test_register_models_in_the_reference_registry():
-    """B1 in one call: compat.register_models puts the engine's five module-level ports into the reference's MODELS registry
+    """B1 in one call: compat.register_models puts the engine's six module-level ports into the reference's MODELS registry
     (pointcept/utils/registry.py) under the names its configs use; MODELS.build then constructs the engine classes from a
     reference-style config dict, and the originals come back when the test restores them."""
     import sys
@@ -880,7 +894,7 @@ def test_register_models_in_the_reference_registry():
     saved = dict(MODELS._module_dict)
     try:
         names = compat.register_models(MODELS)
-        assert set(names) == {"PT-v3m1", "PT-v3m2", "PT-v3m3", "LitePT-v1", "SpUNet-v1m1"}
+        assert set(names) == {"PT-v3m1", "PT-v3m2", "PT-v3m3", "LitePT-v1", "SpUNet-v1m1", "SpUNetNoSkipBase"}
         for n in names:
             assert MODELS.get(n).__module__.startswith("pointcept_amd."), n
         net = MODELS.build(dict(type="PT-v3m3", in_channels=6, order=ORDERS, enc_depths=(1, 1), enc_channels=(36, 72), enc_num_head=(2, 4),
@@ -890,6 +904,9 @@ def test_register_models_in_the_reference_registry():
         sp = MODELS.build(dict(type="SpUNet-v1m1", in_channels=6, num_classes=20, base_channels=16, channels=(16, 32, 32, 48, 48, 32, 32, 16),
                                layers=(1,) * 8))
         assert type(sp).__module__ == "pointcept_amd.sparse_unet"
+        ns = MODELS.build(dict(type="SpUNetNoSkipBase", in_channels=6, out_channels=20, base_channels=16, channels=(16, 32, 32, 48, 48, 32, 32, 16),
+                               layers=(1,) * 8))
+        assert type(ns).__name__ == "SpUNetNoSkipBase" and type(ns).__module__ == "pointcept_amd.sparse_unet"
     finally:
         MODELS._module_dict.clear()
         MODELS._module_dict.update(saved)
