@@ -68,9 +68,19 @@ template <typename T> __host__ __device__ __forceinline__ BnMap bn_map(int c) {
 // ---- per-channel two-value reduction over rows: workgroup partials --------------------------------
 // MODE 0: (sum x, sum x^2);  MODE 1: (sum dz, sum dz * xhat).  A thread adds <= ~100 values in fp32; the
 // <= 1024 workgroup partials are then summed in fp64 by the finish kernels.
+// the saved statistics of a layer as the backward kernels read them: a = gamma * rstd, b = beta - mean * a are rebuilt per thread
+// (4 loads per channel, once per kernel) instead of by a launch of their own in front of every backward (59 per SpUNet step)
+struct BnStat { const float* gamma; const float* beta; const float* mean; const float* rstd; };
+__device__ __forceinline__ void bn_stat_coef(const BnStat& st, int ch, float& a, float& b, float& mu, float& rs) {
+  rs = st.rstd[ch];
+  mu = st.mean[ch];
+  a = (st.gamma ? st.gamma[ch] : 1.f) * rs;
+  b = __builtin_fmaf(-mu, a, st.beta ? st.beta[ch] : 0.f);
+}
+
 template <typename T, typename TD, int MODE>
 __global__ void __launch_bounds__(BN_THREADS)
-bn_reduce_kernel(const T* __restrict__ x, const TD* __restrict__ dy, const float* __restrict__ coef, int64_t n, int c,
+bn_reduce_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat st, int64_t n, int c,
                  int act, int64_t rows_per_group, float* __restrict__ partial) {
   constexpr int V = BnVec<T>::V;
   __shared__ float red[BN_THREADS][2 * V + 1];
@@ -85,8 +95,7 @@ bn_reduce_kernel(const T* __restrict__ x, const TD* __restrict__ dy, const float
   if (MODE == 1 && r < m.rpi) {
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const int ch = cg * V + j;
-      a[j] = coef[ch]; b[j] = coef[c + ch]; mu[j] = coef[2 * c + ch]; rs[j] = coef[3 * c + ch];
+      bn_stat_coef(st, cg * V + j, a[j], b[j], mu[j], rs[j]);
     }
   }
   if (r < m.rpi) {
@@ -145,14 +154,19 @@ __device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ partia
   for (int u = 0; u < 8; ++u) { a1[u] = 0.0; a2[u] = 0.0; }
   if (ch < c) {
     for (int g0 = part; g0 < groups; g0 += PARTS * 8) {
+      // (all eight loads issued before the first add: unconditional, from a clamped address -- a load under a per-lane condition
+      //  is waited for one by one; these finish kernels were 10 us of pure latency per BatchNorm layer and direction)
+      float2 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int g = g0 + u * PARTS;
-        if (g < groups) {
-          const float2 v = *reinterpret_cast<const float2*>(partial + ((int64_t)g * c + ch) * 2);
-          a1[u] += v.x;
-          a2[u] += v.y;
-        }
+        v[u] = *reinterpret_cast<const float2*>(partial + ((int64_t)(g < groups ? g : groups - 1) * c + ch) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool live = g0 + u * PARTS < groups;
+        a1[u] += live ? (double)v[u].x : 0.0;
+        a2[u] += live ? (double)v[u].y : 0.0;
       }
     }
   }
@@ -232,21 +246,21 @@ bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef, int64_t
 
 // bcoef (fp32, 2*C): [0,C) c1 = a*S1/N | [C,2C) c2 = a*S2/N  (both 0 when the statistics were not batch statistics)
 __global__ void __launch_bounds__(BN_THREADS)
-bn_bwd_finish_kernel(const float* __restrict__ partial, int groups, int64_t n, int c, const float* __restrict__ coef, int training,
+bn_bwd_finish_kernel(const float* __restrict__ partial, int groups, int64_t n, int c, BnStat st, int training,
                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ bcoef) {
   double s1, s2;
   int ch;
   if (!bn_sum_partials(partial, groups, c, s1, s2, ch)) return;
   if (dgamma) dgamma[ch] = (float)s2;
   if (dbeta) dbeta[ch] = (float)s1;
-  const double a = coef[ch];
+  const double a = (st.gamma ? st.gamma[ch] : 1.f) * st.rstd[ch];
   bcoef[ch] = training ? (float)(a * s1 / (double)n) : 0.f;
   bcoef[c + ch] = training ? (float)(a * s2 / (double)n) : 0.f;
 }
 
 template <typename T, typename TD>
 __global__ void __launch_bounds__(BN_THREADS)
-bn_bwd_apply_kernel(const T* __restrict__ x, const TD* __restrict__ dy, const float* __restrict__ coef, const float* __restrict__ bcoef,
+bn_bwd_apply_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat st, const float* __restrict__ bcoef,
                     int64_t n, int c, int act, T* __restrict__ dx) {
   constexpr int V = BnVec<T>::V;
   const BnMap m = bn_map<T>(c);
@@ -256,7 +270,7 @@ bn_bwd_apply_kernel(const T* __restrict__ x, const TD* __restrict__ dy, const fl
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     const int ch = cg * V + j;
-    a[j] = coef[ch]; b[j] = coef[c + ch]; mu[j] = coef[2 * c + ch]; rs[j] = coef[3 * c + ch];
+    bn_stat_coef(st, ch, a[j], b[j], mu[j], rs[j]);
     c1[j] = bcoef[ch]; c2[j] = bcoef[c + ch];
   }
   const int64_t sweep = (int64_t)gridDim.x * m.rpi;
@@ -277,19 +291,6 @@ bn_bwd_apply_kernel(const T* __restrict__ x, const TD* __restrict__ dy, const fl
       xv[j] = a[j] * dz - c1[j] - xhat * c2[j];
     }
     bn_store<T>(dx + e, xv);
-  }
-}
-
-// a = gamma*rstd, b = beta - mean*a from the saved statistics (backward: same coef layout as forward)
-__global__ void __launch_bounds__(BN_THREADS)
-bn_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-               const float* __restrict__ rstd, int c, float* __restrict__ coef) {
-  for (int ch = blockIdx.x * BN_THREADS + threadIdx.x; ch < c; ch += gridDim.x * BN_THREADS) {
-    const float a = (gamma ? gamma[ch] : 1.f) * rstd[ch];
-    coef[ch] = a;
-    coef[c + ch] = (beta ? beta[ch] : 0.f) - mean[ch] * a;
-    coef[2 * c + ch] = mean[ch];
-    coef[3 * c + ch] = rstd[ch];
   }
 }
 
@@ -337,7 +338,7 @@ static int bn_fwd_typed(const void* x, int64_t n, int c, const float* gamma, con
   const BnPlan p = bn_plan(n, m.rpi);
   if (training) {
     hipLaunchKernelGGL((bn_reduce_kernel<T, T, 0>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const T*)nullptr,
-                       (const float*)nullptr, n, c, act, p.rows_per_group, partial);
+                       BnStat{nullptr, nullptr, nullptr, nullptr}, n, c, act, p.rows_per_group, partial);
     PTC_CHECK_LAUNCH("bn_reduce_kernel<stats>");
   }
   hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)ptc_cdiv(c, BN_FIN_CH)), dim3(BN_THREADS), 0, s, partial, p.groups,
@@ -387,19 +388,17 @@ static int bn_bwd_typed(const void* dy, const void* x, const float* gamma, const
   float* bcoef = coef + 4 * c;
   const BnMap m = bn_map<T>(c);
   const BnPlan p = bn_plan(n, m.rpi);
-  // rebuild coef = (a, b, mean, rstd) from the saved statistics
-  hipLaunchKernelGGL(bn_coef_kernel, dim3((unsigned)ptc_cdiv(c, BN_THREADS)), dim3(BN_THREADS), 0, s, gamma, beta, mean, rstd, c, coef);
-  PTC_CHECK_LAUNCH("bn_coef_kernel");
-  hipLaunchKernelGGL((bn_reduce_kernel<T, TD, 1>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, coef, n, c, act,
+  const BnStat st{gamma, beta, mean, rstd};
+  hipLaunchKernelGGL((bn_reduce_kernel<T, TD, 1>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, st, n, c, act,
                      p.rows_per_group, partial);
   PTC_CHECK_LAUNCH("bn_reduce_kernel<bwd>");
-  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)ptc_cdiv(c, BN_FIN_CH)), dim3(BN_THREADS), 0, s, partial, p.groups, n, c, coef,
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)ptc_cdiv(c, BN_FIN_CH)), dim3(BN_THREADS), 0, s, partial, p.groups, n, c, st,
                      training, dgamma, dbeta, bcoef);
   PTC_CHECK_LAUNCH("bn_bwd_finish_kernel");
   int64_t grid = ptc_cdiv(n, (int64_t)m.rpi * 4);
   if (grid > 256 * 16) grid = 256 * 16;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TD>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, coef, bcoef, n, c,
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TD>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, st, bcoef, n, c,
                      act, (T*)dx);
   PTC_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return PTC_OK;
@@ -455,7 +454,7 @@ extern "C" int ptc_column_sum(const void* x, int64_t n, int c, int dtype, float*
     const BnMap m = bn_map<T>(c);                                                                                              \
     const BnPlan p = bn_plan(n, m.rpi);                                                                                        \
     hipLaunchKernelGGL((bn_reduce_kernel<T, T, 0>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const T*)nullptr,    \
-                       (const float*)nullptr, n, c, 0, p.rows_per_group, partial);                                             \
+                       BnStat{nullptr, nullptr, nullptr, nullptr}, n, c, 0, p.rows_per_group, partial);                        \
     PTC_CHECK_LAUNCH("bn_reduce_kernel<colsum>");                                                                              \
     hipLaunchKernelGGL(bn_colsum_finish_kernel, dim3((unsigned)ptc_cdiv(c, BN_FIN_CH)), dim3(BN_THREADS), 0, s, partial, p.groups, c, out); \
     PTC_CHECK_LAUNCH("bn_colsum_finish_kernel");                                                                               \

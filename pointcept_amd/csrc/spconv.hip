@@ -430,21 +430,30 @@ wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int64_t count
   if (i < count) {
     const bool vec = (i + 3 < count) && ((count & 3) == 0);
     for (int p0 = pg; p0 < splits; p0 += 64) {
+      if (vec) {
+        // four loads in flight: unconditional, from a clamped partial (a load under a per-lane condition is waited for one by one)
+        float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int p = p0 + 16 * u;
-        if (p < splits) {
-          const float* src = partial + (int64_t)p * count + i;
-          float4 v;
-          if (vec) {
-            v = *reinterpret_cast<const float4*>(src);
-          } else {
-            v.x = src[0];
-            v.y = i + 1 < count ? src[1] : 0.f;
-            v.z = i + 2 < count ? src[2] : 0.f;
-            v.w = i + 3 < count ? src[3] : 0.f;
+        for (int u = 0; u < 4; ++u) {
+          const int p = p0 + 16 * u;
+          v[u] = *reinterpret_cast<const float4*>(partial + (int64_t)(p < splits ? p : splits - 1) * count + i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool live = p0 + 16 * u < splits;
+          acc[u].x += live ? v[u].x : 0.f; acc[u].y += live ? v[u].y : 0.f; acc[u].z += live ? v[u].z : 0.f; acc[u].w += live ? v[u].w : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = p0 + 16 * u;
+          if (p < splits) {
+            const float* src = partial + (int64_t)p * count + i;
+            acc[u].x += src[0];
+            acc[u].y += i + 1 < count ? src[1] : 0.f;
+            acc[u].z += i + 2 < count ? src[2] : 0.f;
+            acc[u].w += i + 3 < count ? src[3] : 0.f;
           }
-          acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
         }
       }
     }
