@@ -190,6 +190,8 @@ EMULATED_GPU_TESTS = [
     ("test_linear_gather_tables", dict(dtype=torch.bfloat16)),
     ("test_linear_identity_table", dict(dtype=torch.float32, n=1000, cin=32, cout=64)),
     ("test_spconv_fwd_and_wgrad", dict(dtype=torch.bfloat16, cin=32, cout=32, ksize=3)),
+    ("test_rulebook_blocks", dict(ordered=True)), ("test_spconv_fwd_block_staged", dict(c=64, ordered=True, n_rows=4500)),
+    ("test_spconv_fwd_block_staged", dict(c=32, ordered=False, n_rows=4500)),
     ("test_conv_tiny_inputs", dict(n=17)), ("test_spconv_dgrad_via_mirrored_table", dict()), ("test_spconv_down_up_tables", dict()),
     ("test_pool_maps", dict(n_pts=3000)),
     ("test_attention_fwd_bwd", dict(lens=[48, 48, 17], H=2)), ("test_attention_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
@@ -210,6 +212,7 @@ def test_gpu_kernel_test_bodies_on_the_host_emulation(name, kw):
 
     if not emu_backend.available():
         pytest.skip("no host clang++ under /opt/rocm")
+    os.environ["PTC_EMU_CONV7_WGS"] = "3"      # conv7 is persistent: few workgroups = several blocks each at test sizes (emulation only)
     with emu_backend.emulated_ops():
         getattr(T, name)(torch.device("cpu"), **kw)
 
