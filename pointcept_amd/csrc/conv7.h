@@ -195,7 +195,9 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
     }
   };
   // (Tried: plain 16-byte loads into 60 staging registers at the top of a block, ds_write_b128 behind its tap loop.  The loads issue
-  //  faster -- 940 vs 1450 cycles per block -- but the stores into LDS cost 780, 270 more than they save: profiles/r03_o_conv7_phases.txt.)
+  //  faster -- 940 vs 1450 cycles per block -- but the stores into LDS cost 780, 270 more than they save: profiles/r03_o_conv7_phases.txt.
+  //  Also tried: the halo ids as two lane-linear vectors per wave + a cross-lane read per piece instead of 13 small loads: the
+  //  dependent chain load -> ds_bpermute -> address -> DMA issues SLOWER, 1350 vs 1020 cycles per block.)
   // (a count is LOADED early and USED late: the compiler waits for an ordinary load at the first use of its result, and that wait
   //  would also drain the DMAs issued before it)
   auto count_of = [&](int blk) -> int { return hcnt[blk < n_blocks ? blk : n_blocks - 1]; };
