@@ -33,6 +33,7 @@ HIP_SOURCES = [
     "rulebook.hip",
     "blocks.hip",
     "spconv.hip",
+    "conv7.hip",
     "norm.hip",
     "attention.hip",
     "loss.hip",
@@ -63,7 +64,10 @@ HIP_FLAGS = [
 # the two scalar ones it replaces, MI355X_MICROARCH.md per-instruction constants): backward 1460 -> 1406 us at the bench shape.
 # NOT global: the implicit-GEMM kernels lose 15-18 % without SLP at 96 / 128 channels (profiles/r02_o_slp_ab.txt).
 # pointops2.hip: hardware fp32 atomic adds for the scatter gradients (the default expands atomicAdd(float) into a CAS loop)
-PER_FILE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"], "pointops2.hip": ["-munsafe-fp-atomics"]}
+# conv7.hip: MFMA accumulators in architectural VGPRs (one wave per SIMD: the default puts them in AGPRs and every block pays 128
+# register moves; see the head of the file)
+PER_FILE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"], "pointops2.hip": ["-munsafe-fp-atomics"],
+                  "conv7.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _newer(src: str, dst: str, extra: list[str]) -> bool:
@@ -93,6 +97,7 @@ def _run(cmd: list[str]) -> None:
 VARIANTS = {
     "slp": [],                         # every file with the compiler's default SLP packing (no PER_FILE_FLAGS)
     "noslp": ["-fno-slp-vectorize"],   # no file with it
+    "vgprform": ["-mllvm", "-amdgpu-mfma-vgpr-form"],   # every file with MFMA accumulators in architectural VGPRs where they fit (conv7.hip has it by default)
 }
 # "d_<MACRO>_<VALUE>": -D<MACRO>=<VALUE> (timing ablations of one kernel, e.g. d_C7_ABLATE_4); only the sources that name the macro
 # (directly or through a header of csrc/) are recompiled, the other objects come from the default build

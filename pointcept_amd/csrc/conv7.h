@@ -48,6 +48,16 @@
 #define C7_TABB (28 * 16 * C7_NT * 2)       // bytes of one block's local table: [28 taps (27 + pad)][16 rows-in-tile][8 tiles] u16, each
                                             // entry = LDS byte offset of piece 0 of the neighbour row inside the row image (blocks.hip)
 
+static inline bool conv7_supported(int dtype, int kv, int c_in, int c_out, int bm, int hcap, int64_t n_out) {
+  return dtype != PTC_F32 && kv == 27 && c_in == c_out && (c_in == 32 || c_in == 64) && bm == C7_BM && hcap == C7_HCAP && n_out >= 4096;
+}
+
+
+// the entry point of conv7.hip (its own translation unit: built with MFMA accumulators in architectural VGPRs, see build.py)
+int ptc_conv7_launch(int dtype, const void* in, int64_t n_in, const void* w, const float* bias, const uint16_t* tab, const int32_t* hid,
+                     const int32_t* hcnt, int64_t n_out, int c, void* out, hipStream_t s);
+
+#ifdef PTC_CONV7_IMPL
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
 #define C7_WAIT_VM0 0x0F70
 #define C7_WAIT_LGKM0 0xC07F
@@ -429,10 +439,6 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   }
 }
 
-static inline bool conv7_supported(int dtype, int kv, int c_in, int c_out, int bm, int hcap, int64_t n_out) {
-  return dtype != PTC_F32 && kv == 27 && c_in == c_out && (c_in == 32 || c_in == 64) && bm == C7_BM && hcap == C7_HCAP && n_out >= 4096;
-}
-
 template <typename T, int C>
 static int launch_conv7_i(const void* in, int64_t n_in, const void* w, const float* bias, const uint16_t* tab,
                           const int32_t* hid, const int32_t* hcnt, int64_t n_out, void* out, hipStream_t s) {
@@ -453,15 +459,4 @@ static int launch_conv7_i(const void* in, int64_t n_in, const void* w, const flo
   PTC_CHECK_LAUNCH("conv7_kernel");
   return PTC_OK;
 }
-
-// conv7 over the blocks whose halo fits, then conv5 (its 128-row workgroups are the same blocks) over the others: a workgroup of
-// the second launch whose block conv7 served returns at once.  (Tried: the overflow path inside conv7 -- global gathers with the
-// same wave roles.  The second code path costs the 64-channel kernel its register allocation: 512 registers + 572 bytes of scratch.)
-template <typename T>
-static int launch_conv7(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, const uint16_t* tab,
-                        const int32_t* hid, const int32_t* hcnt, int64_t n_out, int c, void* out, hipStream_t s) {
-  int rc = c == 64 ? launch_conv7_i<T, 64>(in, n_in, w, bias, tab, hid, hcnt, n_out, out, s)
-                   : launch_conv7_i<T, 32>(in, n_in, w, bias, tab, hid, hcnt, n_out, out, s);
-  if (rc != PTC_OK) return rc;
-  return launch_conv5<T>(in, n_in, w, bias, nbr, n_out, 27, c, c, out, s, hcnt);
-}
+#endif  // PTC_CONV7_IMPL

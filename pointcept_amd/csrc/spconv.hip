@@ -256,8 +256,14 @@ extern "C" int ptc_spconv_fwd_blk(const void* in, int64_t n_in, const void* weig
   PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)tab % 16 == 0), PTC_EINVAL,
               "ptc_spconv_fwd_blk: buffers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == PTC_BF16) return launch_conv7<bf16_t>(in, n_in, weight, bias, nbr, (const uint16_t*)tab, hid, hcnt, n_out, c_in, out, s);
-  return launch_conv7<f16_t>(in, n_in, weight, bias, nbr, (const uint16_t*)tab, hid, hcnt, n_out, c_in, out, s);
+  // conv7 (conv7.hip) over the blocks whose halo fits, then conv5 (its 128-row workgroups are the same blocks) over the others: a
+  // workgroup of the second launch whose block conv7 served returns at once.  (Tried: the overflow path inside conv7 -- global gathers
+  // with the same wave roles.  The second code path costs the 64-channel kernel its register allocation: 512 registers + 572 bytes
+  // of scratch.)
+  const int rc = ptc_conv7_launch(dtype, in, n_in, weight, bias, (const uint16_t*)tab, hid, hcnt, n_out, c_in, out, s);
+  if (rc != PTC_OK) return rc;
+  if (dtype == PTC_BF16) return launch_conv5<bf16_t>(in, n_in, weight, bias, nbr, n_out, 27, c_in, c_in, out, s, hcnt);
+  return launch_conv5<f16_t>(in, n_in, weight, bias, nbr, n_out, 27, c_in, c_in, out, s, hcnt);
 }
 
 // Dense row-wise GEMM with an MLP epilogue (see fwd2.h): epilogue 1 = out: h, aux_out: GELU(h);

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 if "--all" in sys.argv:
-    variants = [""] + sorted(os.path.basename(p)[len("libptcore_"):-3] for p in glob.glob(os.path.join(ROOT, "pointcept_amd", "libptcore_d_*.so")))
+    variants = [""] + sorted(os.path.basename(p)[len("libptcore_"):-3] for p in glob.glob(os.path.join(ROOT, "pointcept_amd", "libptcore_*.so")) if "hostprobe" not in p)
     for v in variants:
         env = dict(os.environ, PTC_LIB_VARIANT=v)
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
