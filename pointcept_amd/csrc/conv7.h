@@ -304,6 +304,9 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       // ran the loop at one MFMA per 60 cycles, its full latency (profiles/r03_o_conv7_ablate.txt).  So the first LAG fragments of
       // a step are still loaded from the CURRENT tap's entries (they are multiplied at the end of this step), the others from
       // the next tap's.
+      // (C = 32, one tile = two MFMAs per tap: its loop runs 2460 cycles per block for 930 cycles of MFMAs.  A three-tap-deep ring rotated
+      //  by register copies -- gathers two taps ahead -- was measured and is SLOWER, 2620: the copies write registers an MFMA in flight
+      //  still reads and wait for it like the reloads do; profiles/r03_o_conv7_phases.txt section 9.)
       constexpr int NF = 2 * TW, LAG = C == 64 ? 2 : 0;
       uint32_t teC[2], teN[2], teNN[2];
       frag b[NF];                                          // fragment i = (k-step i / TW, tile i % TW)
@@ -417,12 +420,16 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       tick(7);                                          // second barrier
     } else {
       // wait for the DMA of the next block BEFORE the stores of this one are issued: they retire during the next block's MFMAs
+      tick(3);
       __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
+      tick(4);                                          // wait: DMA of the next block
       __builtin_amdgcn_s_barrier();
+      tick(5);                                          // barrier
       c7_f32x16 a = acc[0];
 #pragma unroll
       for (int r = 0; r < 16; ++r) a[r] += acc[1][r];
       store_tile(wave, a);
+      tick(6);                                          // add + store
     }
     if (!(C7_ABLATE & 1)) cur ^= 1;
     cnt_cur = cnt_nxt;

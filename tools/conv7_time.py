@@ -15,7 +15,7 @@ if "--all" in sys.argv:
     for v in variants:
         env = dict(os.environ, PTC_LIB_VARIANT=v)
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
-        print(f"{v or 'product':24s} " + ("\n".join(r.stdout.strip().splitlines()[-2:]) if r.stdout.strip() else r.stderr[-300:]), flush=True)
+        print(f"{v or 'product':24s} " + ("\n".join(r.stdout.strip().splitlines()[-3:]) if r.stdout.strip() else r.stderr[-300:]), flush=True)
     sys.exit(0)
 
 import torch  # noqa: E402
@@ -44,12 +44,12 @@ for c in (64, 32):
     e1.record()
     torch.cuda.synchronize()
     out.append(f"C={c}: {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")
-    if "64" in os.environ.get("PTC_LIB_VARIANT", "").split("_")[-1:] and c == 64:
+    if "64" in os.environ.get("PTC_LIB_VARIANT", "").split("_")[-1:]:
         y = ops.spconv_fwd(x, w, bias, nbr, blk)
         torch.cuda.synchronize()
-        ph = y[:256].contiguous().view(torch.int64)[:, :8].double().cpu()      # [workgroup][phase] cycles of wave 0
+        ph = y[:256].contiguous().view(torch.int64).view(256, -1)[:, :8].double().cpu()      # [workgroup][phase] cycles of wave 0
         names = ["dma issue", "reset+first gathers", "tap loop", "acc->scratch", "wait dma/scratch", "barrier 1", "add+store", "barrier 2"]
         tot = ph.sum(1)
-        print("phases of wave 0, cycles per block (mean over workgroups; 25 blocks each): " +
+        print(f"C={c} phases of wave 0, cycles per block (mean over workgroups; 25 blocks each): " +
               ", ".join(f"{nm} {ph[:, i].mean() / 25:.0f}" for i, nm in enumerate(names)) + f"; sum {tot.mean() / 25:.0f} (min {tot.min() / 25:.0f}, max {tot.max() / 25:.0f})")
 print(f"n={n}  " + "   ".join(out) + "   (conv7 + the empty conv5 launch behind it)")
