@@ -42,6 +42,9 @@
 #ifndef C7_ABLATE
 #define C7_ABLATE 0
 #endif
+#ifndef C7_LAG
+#define C7_LAG 2                            // MFMAs between a fragment's use and its reload (C = 64; 3 and 4 measured: see conv7_time)
+#endif
 #define C7_BM 128                           // rows per block
 #define C7_NT 8                             // 16-row tiles per block
 #define C7_HCAP 416                         // halo capacity (rows); max observed on curve-ordered indoor scenes: 352
@@ -307,7 +310,7 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       // (C = 32, one tile = two MFMAs per tap: its loop runs 2460 cycles per block for 930 cycles of MFMAs.  A three-tap-deep ring rotated
       //  by register copies -- gathers two taps ahead -- was measured and is SLOWER, 2620: the copies write registers an MFMA in flight
       //  still reads and wait for it like the reloads do; profiles/r03_o_conv7_phases.txt section 9.)
-      constexpr int NF = 2 * TW, LAG = C == 64 ? 2 : 0;
+      constexpr int NF = 2 * TW, LAG = C == 64 ? C7_LAG : 0;
       uint32_t teC[2], teN[2], teNN[2];
       frag b[NF];                                          // fragment i = (k-step i / TW, tile i % TW)
       entries(pop_tap(), teC);
