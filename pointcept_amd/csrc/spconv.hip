@@ -20,6 +20,7 @@
 // Roofline: bytes = N_in*C_in*e + N_out*C_out*e + 4*kv*N_out (table) + kv*C_in*C_out*e,
 // flops = 2*P*C_in*C_out; HBM-bound for C <= 64, MFMA-bound above.
 #include "ptc_common.h"
+#include "spconv_internal.h"
 
 #include "mma.h"
 #include "wgrad2.h"
@@ -420,14 +421,13 @@ spconv_wgrad_kernel(const T* __restrict__ in, const T* __restrict__ dout, const 
 // owns 64 consecutive outputs (16 lanes x float4); 16 thread groups split the partial index, each keeps four
 // independent 16-byte loads in flight (the first version walked the partials with one dependent 4-byte load
 // at a time: 9.5 us per call, latency-bound), partial sums meet in LDS in a fixed order.
-__global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int64_t count, float* __restrict__ dw, int nb1,
-                    const float* __restrict__ partial2, int64_t count2, float* __restrict__ out2) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, int splits, int64_t count, float* __restrict__ dw, int nb1,
+                                                  const float* __restrict__ partial2, int64_t count2, float* __restrict__ out2, int bid) {
   __shared__ float4 red[16][16];
-  if ((int)blockIdx.x >= nb1) {
+  if (bid >= nb1) {
     partial = partial2; count = count2; dw = out2;
   }
-  const int64_t blk = (int)blockIdx.x >= nb1 ? (int64_t)blockIdx.x - nb1 : (int64_t)blockIdx.x;
+  const int64_t blk = bid >= nb1 ? (int64_t)bid - nb1 : (int64_t)bid;
   const int lane = threadIdx.x & 15, pg = threadIdx.x >> 4;   // 16 lanes x float4 = 64 outputs, 16 partial groups
   const int64_t i = blk * 64 + lane * 4;
   float4 acc[4];
@@ -483,6 +483,51 @@ wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int64_t count
     if (i + 2 < count) dw[i + 2] = r.z;
     if (i + 3 < count) dw[i + 3] = r.w;
   }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int64_t count, float* __restrict__ dw, int nb1,
+                    const float* __restrict__ partial2, int64_t count2, float* __restrict__ out2) {
+  wgrad_reduce_body(partial, splits, count, dw, nb1, partial2, count2, out2, (int)blockIdx.x);
+}
+
+// the reductions of several weight gradients in one launch (the Block executor: six per Block backward): workgroup b belongs to the job
+// whose block range holds b and does there exactly what wgrad_reduce_kernel does
+struct WgradReduceMulti {
+  int n;
+  int start[PTC_WGRAD_JOBS_MAX + 1];   // first workgroup of job j; start[n] = grid
+  int nb1[PTC_WGRAD_JOBS_MAX];
+  PtcWgradJob job[PTC_WGRAD_JOBS_MAX];
+};
+__global__ void __launch_bounds__(256)
+wgrad_reduce_multi_kernel(WgradReduceMulti m) {
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < PTC_WGRAD_JOBS_MAX; ++q)
+    if (q < m.n && (int)blockIdx.x >= m.start[q]) j = q;
+  const PtcWgradJob& J = m.job[j];
+  wgrad_reduce_body(J.partial, J.splits, J.count, J.dw, m.nb1[j], J.bias_partial, J.c_out, J.dbias, (int)blockIdx.x - m.start[j]);
+}
+
+int ptc_wgrad_reduce_jobs(const PtcWgradJob* jobs, int n, ptc_stream_t stream) {
+  PTC_REQUIRE(jobs && n >= 0 && n <= PTC_WGRAD_JOBS_MAX, PTC_EINVAL, "ptc_wgrad_reduce_jobs: %d jobs", n);
+  WgradReduceMulti m;
+  m.n = 0;
+  int grid = 0;
+  for (int q = 0; q < n; ++q) {
+    if (jobs[q].splits <= 0) continue;
+    const int nb1 = (int)ptc_cdiv(jobs[q].count, 64), nb2 = jobs[q].dbias ? (int)ptc_cdiv(jobs[q].c_out, 64) : 0;
+    m.start[m.n] = grid;
+    m.nb1[m.n] = nb1;
+    m.job[m.n] = jobs[q];
+    grid += nb1 + nb2;
+    ++m.n;
+  }
+  if (m.n == 0) return PTC_OK;
+  for (int q = m.n; q <= PTC_WGRAD_JOBS_MAX; ++q) m.start[q] = grid;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, m);
+  PTC_CHECK_LAUNCH("wgrad_reduce_multi_kernel");
+  return PTC_OK;
 }
 
 static int launch_wgrad_reduce(const float* partial, int splits, int64_t count, float* dw, const float* bias_partial, int64_t c_out,
@@ -553,7 +598,7 @@ static int launch_wgrad2_inst(const W2Plan& p, const void* in, int64_t n_in, con
 
 template <typename T>
 static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
-                         float* dw, float* dbias, void* ws, hipStream_t s) {
+                         float* dw, float* dbias, void* ws, hipStream_t s, PtcWgradJob* defer = nullptr) {
   const W2Plan p = w2_plan(n_out, kv, c_in, c_out, dbias != nullptr);
   const int64_t count = (int64_t)c_out * kv * c_in;
   float* partial = p.gx > 1 ? (float*)ws : dw;
@@ -571,13 +616,33 @@ static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const i
     if (rc == PTC_EUNSUPPORTED) ptc_set_error("ptc_spconv_wgrad: no wgrad2 instance for tiles (%d,%d,%d)", p.cot, p.cit, p.kg);
     return rc;
   }
+  if (defer) {   // the caller batches the reduction (ptc_wgrad_reduce_jobs)
+    *defer = PtcWgradJob{partial, p.gx > 1 ? p.gx : 0, count, dw, bias_partial, (int64_t)c_out, dbias};
+    return PTC_OK;
+  }
   if (p.gx > 1) return launch_wgrad_reduce(partial, p.gx, count, dw, bias_partial, c_out, dbias, s);
   return PTC_OK;
 }
 
+static int spconv_wgrad_impl(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
+                             int dtype, float* dw, float* dbias, void* workspace, size_t workspace_bytes, ptc_stream_t stream, PtcWgradJob* defer);
+
 extern "C" int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out,
                                 int kv, int c_in, int c_out, int dtype, float* dw, float* dbias, void* workspace,
                                 size_t workspace_bytes, ptc_stream_t stream) {
+  return spconv_wgrad_impl(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dtype, dw, dbias, workspace, workspace_bytes, stream, nullptr);
+}
+
+int ptc_spconv_wgrad_deferred(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
+                              int dtype, float* dw, float* dbias, void* workspace, size_t workspace_bytes, ptc_stream_t stream,
+                              PtcWgradJob* job) {
+  PTC_REQUIRE(job != nullptr, PTC_EINVAL, "ptc_spconv_wgrad_deferred: null job");
+  *job = PtcWgradJob{nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
+  return spconv_wgrad_impl(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dtype, dw, dbias, workspace, workspace_bytes, stream, job);
+}
+
+static int spconv_wgrad_impl(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
+                             int dtype, float* dw, float* dbias, void* workspace, size_t workspace_bytes, ptc_stream_t stream, PtcWgradJob* defer) {
   PTC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1, PTC_EINVAL, "ptc_spconv_wgrad: bad sizes");
   PTC_REQUIRE(c_in >= 8 && c_in % 8 == 0 && c_out >= 8 && c_out % 8 == 0, PTC_EUNSUPPORTED,
               "ptc_spconv_wgrad: c_in=%d c_out=%d must be multiples of 8", c_in, c_out);
@@ -594,8 +659,8 @@ extern "C" int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, 
   PTC_REQUIRE(nbr || (kv == 1 && n_in >= n_out), PTC_EINVAL, "ptc_spconv_wgrad: nbr may be NULL only for kv == 1 (identity table)");
   // wgrad2 gathers through raw buffer loads (< 2 GiB operands); larger ones take the v1 kernel
   const bool buf_ok = (uint64_t)n_in * c_in * 2 <= PTC_BUF_MAX_BYTES && (uint64_t)n_out * c_out * 2 <= PTC_BUF_MAX_BYTES;
-  if (dtype == PTC_BF16 && buf_ok) return launch_wgrad2<bf16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s);
-  if (dtype == PTC_F16 && buf_ok) return launch_wgrad2<f16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s);
+  if (dtype == PTC_BF16 && buf_ok) return launch_wgrad2<bf16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s, defer);
+  if (dtype == PTC_F16 && buf_ok) return launch_wgrad2<f16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s, defer);
   PTC_DISPATCH_DTYPE(dtype, T, return launch_wgrad<T>(in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s));
   return PTC_OK;
 }

@@ -1,0 +1,25 @@
+// spconv_internal.h -- C++-side entry points of spconv.hip for the other translation units of the library (block_exec.hip).
+// Not part of the C-ABI (include/ptcore.h): the Block executor uses them to batch the split-K reductions of a Block's weight gradients.
+#pragma once
+#include "ptc_common.h"
+
+// what is left to do for one weight gradient whose partial sums were written by its kernel: dw[i] = sum_p partial[p][i] (and the bias
+// segment).  splits == 0: nothing (the kernel wrote dw itself, or the call took a path that reduces at once).
+struct PtcWgradJob {
+  const float* partial;
+  int splits;
+  int64_t count;
+  float* dw;
+  const float* bias_partial;
+  int64_t c_out;
+  float* dbias;
+};
+
+// ptc_spconv_wgrad with the reduction left to the caller: same arguments, same partials, same workspace layout; `job` describes the
+// reduction still owed.  The workspace must stay untouched until ptc_wgrad_reduce_jobs has been enqueued.
+int ptc_spconv_wgrad_deferred(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
+                              int dtype, float* dw, float* dbias, void* workspace, size_t workspace_bytes, ptc_stream_t stream,
+                              PtcWgradJob* job);
+// ONE launch for up to PTC_WGRAD_JOBS_MAX reductions (bit-identical to the separate launches: same per-output summation order)
+#define PTC_WGRAD_JOBS_MAX 8
+int ptc_wgrad_reduce_jobs(const PtcWgradJob* jobs, int n, ptc_stream_t stream);
