@@ -89,6 +89,41 @@ scan_apply_kernel(const int32_t* __restrict__ in, int64_t n, const int64_t* __re
   for (int j = 0; j < SCAN_ITEMS; ++j) { int64_t i = base + j; if (i < n) out[i] = ex; ex += v[j]; }
 }
 
+// n <= SCAN1_MAX: the whole scan in ONE workgroup of 1024 threads (16 items per thread and sweep, a carry across sweeps) -- one launch
+// instead of three (the digit histograms of the deep stages' sorts, the pad / pooling maps); integer arithmetic: the result is the same
+// whatever the grouping.
+#define SCAN1_THREADS 1024
+#define SCAN1_ITEMS 16
+#define SCAN1_MAX (SCAN1_THREADS * SCAN1_ITEMS)   // one sweep: measured, a 4-sweep scan (25 us) is slower than the three launches it replaces (23 us)
+__global__ void __launch_bounds__(SCAN1_THREADS)
+scan_single_kernel(const int32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+  __shared__ int64_t wsum[SCAN1_THREADS / 64], wex[SCAN1_THREADS / 64 + 1];
+  const int lane = ptc_lane(), wave = threadIdx.x >> 6;
+  int64_t carry = 0;
+  for (int64_t sweep = 0; sweep < n; sweep += (int64_t)SCAN1_THREADS * SCAN1_ITEMS) {
+    const int64_t base = sweep + (int64_t)threadIdx.x * SCAN1_ITEMS;
+    int32_t v[SCAN1_ITEMS];
+    int64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN1_ITEMS; ++j) { const int64_t i = base + j; v[j] = (i < n) ? in[i] : 0; s += v[j]; }
+    const int64_t inc = wave_inclusive_scan_i64(s);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+      const int64_t w = lane < SCAN1_THREADS / 64 ? wsum[lane] : 0;
+      const int64_t winc = wave_inclusive_scan_i64(w);
+      if (lane < SCAN1_THREADS / 64) wex[lane] = winc - w;
+      if (lane == SCAN1_THREADS / 64 - 1) wex[SCAN1_THREADS / 64] = winc;
+    }
+    __syncthreads();
+    int64_t ex = carry + wex[wave] + inc - s;
+#pragma unroll
+    for (int j = 0; j < SCAN1_ITEMS; ++j) { const int64_t i = base + j; if (i < n) out[i] = ex; ex += v[j]; }
+    carry += wex[SCAN1_THREADS / 64];
+    __syncthreads();
+  }
+}
+
 static int64_t scan_num_tiles(int64_t n) { return ptc_cdiv(n > 0 ? n : 1, SCAN_TILE); }
 
 extern "C" size_t ptc_exclusive_scan_workspace_bytes(int64_t n) {
@@ -98,6 +133,11 @@ extern "C" size_t ptc_exclusive_scan_workspace_bytes(int64_t n) {
 // internal: scan on stream with caller-provided workspace
 static int exclusive_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* ws, hipStream_t s) {
   if (n <= 0) return PTC_OK;
+  if (n <= SCAN1_MAX) {
+    hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN1_THREADS), 0, s, in, n, out);
+    PTC_CHECK_LAUNCH("scan_single_kernel");
+    return PTC_OK;
+  }
   int64_t tiles = scan_num_tiles(n);
   int64_t* tile_sums = (int64_t*)ws;
   hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, n, tile_sums);
