@@ -110,7 +110,7 @@ def test_sort_keys_bit_window(cuda):
     assert np.array_equal(order0.cpu().numpy(), np.tile(np.arange(30000), (2, 1)))
 
 
-@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 300001])
+@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 16383, 16384, 16385, 300001])   # <= 16384: the one-workgroup single-launch form
 def test_exclusive_scan(cuda, n):
     from pointcept_amd import ops
 

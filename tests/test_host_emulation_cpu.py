@@ -176,7 +176,8 @@ EMULATED_GPU_TESTS = [
     ("test_rulebook_subm", dict(ksize=5, dup=False)), ("test_rulebook_down", dict()),
     ("test_pointops2_pair_operators_match_the_reference_formulations", dict(seed=0)),
     # LDS + shuffles + workgroup barriers
-    ("test_exclusive_scan", dict(n=1000)), ("test_exclusive_scan", dict(n=70000)),
+    ("test_exclusive_scan", dict(n=1000)), ("test_exclusive_scan", dict(n=16384)), ("test_exclusive_scan", dict(n=16385)),
+    ("test_exclusive_scan", dict(n=70000)),
     ("test_sort_keys_stable", dict(n=65)), ("test_sort_keys_stable", dict(n=4097)), ("test_sort_keys_bit_window", dict()),
     ("test_patch_pad_maps", dict(counts=[10, 3, 7], K=4)), ("test_patch_pad_maps", dict(counts=[1024, 1025, 5000, 1], K=1024)),
     ("test_attn_tables_match_index_algebra", dict(counts=[48, 49, 100, 7], K=48)),
