@@ -33,10 +33,17 @@ coord_max_kernel(const CoordT* __restrict__ gc, int64_t n, unsigned long long* _
     m1 = b > m1 ? b : m1;
     m2 = c > m2 ? c : m2;
   }
-  if (ptc_lane() == 0) {  // integer max: order-independent, exact
-    atomicMax(out3 + 0, m0);
-    atomicMax(out3 + 1, m1);
-    atomicMax(out3 + 2, m2);
+  // one set of atomics per WORKGROUP (the first version issued them per wave: 24576 64-bit atomics on three addresses serialised in
+  // the L2 -- 114 us for a 20 MB read, profiles/r03_y_bench_kernel_stats.csv); integer max: order-independent, exact
+  __shared__ unsigned long long wm[4][3];
+  const int wave = threadIdx.x >> 6;
+  if (ptc_lane() == 0) { wm[wave][0] = m0; wm[wave][1] = m1; wm[wave][2] = m2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    unsigned long long m = wm[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) m = wm[w][threadIdx.x] > m ? wm[w][threadIdx.x] : m;
+    atomicMax(out3 + threadIdx.x, m);
   }
 }
 
@@ -48,7 +55,7 @@ extern "C" int ptc_coord_max(const void* grid_coord, int coord_is_i64, int64_t n
   if (n == 0) return PTC_OK;
   PTC_REQUIRE(grid_coord != nullptr, PTC_EINVAL, "ptc_coord_max: null buffer");
   int64_t grid = ptc_cdiv(n, 256 * 4);
-  if (grid > 2048) grid = 2048;
+  if (grid > 512) grid = 512;
   if (coord_is_i64)
     hipLaunchKernelGGL(coord_max_kernel<int64_t>, dim3((unsigned)grid), dim3(256), 0, s, (const int64_t*)grid_coord, n,
                        (unsigned long long*)out3);
