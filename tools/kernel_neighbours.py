@@ -50,3 +50,8 @@ for t in targets:
     print(f"== {t}: {total} launches in the trace")
     for (prev, nxt, grid), c in hist.most_common(25):
         print(f"{c:6d}  grid {grid:>9s}  after {prev:70s}  before {nxt}")
+    big = [(k, c) for k, c in hist.items() if k[2].isdigit() and int(k[2]) >= 4_000_000]
+    if big:
+        print(f"   -- launches of {t} with a grid of >= 4M work-items (large tensors), whatever their rank:")
+        for (prev, nxt, grid), c in sorted(big, key=lambda kc: -int(kc[0][2])):
+            print(f"{c:6d}  grid {grid:>9s}  after {prev:70s}  before {nxt}")
