@@ -78,7 +78,7 @@ def _newer(src: str, dst: str, extra: list[str]) -> bool:
 
 
 def _headers() -> list[str]:
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hs.append(os.path.join(HERE, "..", "include", "ptcore.h"))
     return hs
 

@@ -115,31 +115,30 @@ extern "C" int ptc_ptv3_block_bwd(const int64_t* iv, const float* fv, const void
   void* ws = workspace;                  // scratch of the calls that finish inside themselves
   const size_t wb = W.common;
   PtcWgradJob jobs[6];
+  PtcWgradCall calls[5];                 // the five Linear weight gradients: recorded where their operands become final, enqueued together at the end
   auto wgws = [&](int i) { return (void*)((char*)workspace + W.off[i]); };
   // 9'. x3 = x2 + rs2 * m, xb3 = cast(x3):  dx2 = dz3 + dyb3;  dm = rs2 * dx2
   RUN(ptc_add_norm_bwd((const float*)P(in, PTC_BLK_P_DZ3), P(in, PTC_BLK_P_DYB3), dt, (const float*)P(sv, PTC_BLK_O_X3), P(sv, PTC_BLK_O_M), dt, rs2, n, c,
                        nullptr, nullptr, 0, nullptr, nullptr, 0, g[PTC_BLK_S_DX2], PTC_F32, g[PTC_BLK_S_DM], nullptr, nullptr, nullptr, nullptr, ws, wb, s));
   // 8'. MLP: fc2 weight / bias gradients, dh = (dm W2) * GELU'(h), fc1 weight / bias gradients, dy2 = dh W1
-  RUN(ptc_spconv_wgrad_deferred(P(sv, PTC_BLK_O_ACT), n, g[PTC_BLK_S_DM], nullptr, n, 1, hid, c, dt, M<float>(g, PTC_BLK_G_W_FC2), M<float>(g, PTC_BLK_G_B_FC2), wgws(0),
-                                W.wg[0], s, &jobs[0]));
+  calls[0] = PtcWgradCall{P(sv, PTC_BLK_O_ACT), n, g[PTC_BLK_S_DM], nullptr, n, 1, hid, c, dt, M<float>(g, PTC_BLK_G_W_FC2), M<float>(g, PTC_BLK_G_B_FC2), wgws(0), W.wg[0]};
   RUN(ptc_linear_fwd_ex(g[PTC_BLK_S_DM], n, P(in, PTC_BLK_P_WT_FC2), nullptr, c, hid, dt, 2, P(sv, PTC_BLK_O_H), g[PTC_BLK_S_DH], nullptr, s));
-  RUN(ptc_spconv_wgrad_deferred(P(sv, PTC_BLK_O_Y2), n, g[PTC_BLK_S_DH], nullptr, n, 1, c, hid, dt, M<float>(g, PTC_BLK_G_W_FC1), M<float>(g, PTC_BLK_G_B_FC1), wgws(1),
-                                W.wg[1], s, &jobs[1]));
+  calls[1] = PtcWgradCall{P(sv, PTC_BLK_O_Y2), n, g[PTC_BLK_S_DH], nullptr, n, 1, c, hid, dt, M<float>(g, PTC_BLK_G_W_FC1), M<float>(g, PTC_BLK_G_B_FC1), wgws(1), W.wg[1]};
   RUN(ptc_spconv_fwd(g[PTC_BLK_S_DH], n, P(in, PTC_BLK_P_WT_FC1), nullptr, nullptr, n, 1, hid, c, dt, g[PTC_BLK_S_DY2], s));
   // 7'. x2 = x1 + rs1 * a, y2 = norm2(x2):  dx1 = dx2 + LN'(dy2);  da = rs1 * dx1
   RUN(ptc_add_norm_bwd(M<float>(g, PTC_BLK_S_DX2), g[PTC_BLK_S_DY2], dt, (const float*)P(sv, PTC_BLK_O_X2), P(sv, PTC_BLK_O_A), dt, rs1, n, c, nullptr, nullptr, 0,
                        (const float*)P(in, PTC_BLK_P_G_N2), (const float*)P(sv, PTC_BLK_O_ST_N2), 1, g[PTC_BLK_S_DX1], PTC_F32, g[PTC_BLK_S_DA], nullptr, nullptr,
                        M<float>(g, PTC_BLK_G_G_N2), M<float>(g, PTC_BLK_G_BE_N2), ws, wb, s));
   // 6'. proj: weight / bias gradients over the inverse table, datt through the table of the padded slots
-  RUN(ptc_spconv_wgrad_deferred(P(sv, PTC_BLK_O_ATT), np, g[PTC_BLK_S_DA], (const int32_t*)P(in, PTC_BLK_P_T_PROJ_FWD), n, 1, c, c, dt, M<float>(g, PTC_BLK_G_W_PROJ),
-                                M<float>(g, PTC_BLK_G_B_PROJ), wgws(2), W.wg[2], s, &jobs[2]));
+  calls[2] = PtcWgradCall{P(sv, PTC_BLK_O_ATT), np, g[PTC_BLK_S_DA], (const int32_t*)P(in, PTC_BLK_P_T_PROJ_FWD), n, 1, c, c, dt, M<float>(g, PTC_BLK_G_W_PROJ),
+                          M<float>(g, PTC_BLK_G_B_PROJ), wgws(2), W.wg[2]};
   RUN(ptc_spconv_fwd(g[PTC_BLK_S_DA], n, P(in, PTC_BLK_P_WT_PROJ), nullptr, (const int32_t*)P(in, PTC_BLK_P_T_PROJ_BWD), np, 1, c, c, dt, g[PTC_BLK_S_DATT], s));
   // 5'. attention
   RUN(ptc_attn_varlen_bwd(P(sv, PTC_BLK_O_QKV), P(sv, PTC_BLK_O_ATT), g[PTC_BLK_S_DATT], (const float*)P(sv, PTC_BLK_O_LSE), (const int32_t*)P(in, PTC_BLK_P_CU), n_seq,
                           np, H, patch, fv[PTC_BLK_F_SCALE], dt, g[PTC_BLK_S_DQKV], ws, wb, s));
   // 4'. qkv: weight / bias gradients over the gather table, dy1 through the two-slot table (a point sits in <= 2 padded slots)
-  RUN(ptc_spconv_wgrad_deferred(P(sv, PTC_BLK_O_Y1), n, g[PTC_BLK_S_DQKV], (const int32_t*)P(in, PTC_BLK_P_T_QKV_FWD), np, 1, c, 3 * c, dt, M<float>(g, PTC_BLK_G_W_QKV),
-                                M<float>(g, PTC_BLK_G_B_QKV), wgws(3), W.wg[3], s, &jobs[3]));
+  calls[3] = PtcWgradCall{P(sv, PTC_BLK_O_Y1), n, g[PTC_BLK_S_DQKV], (const int32_t*)P(in, PTC_BLK_P_T_QKV_FWD), np, 1, c, 3 * c, dt, M<float>(g, PTC_BLK_G_W_QKV),
+                          M<float>(g, PTC_BLK_G_B_QKV), wgws(3), W.wg[3]};
   RUN(ptc_spconv_fwd(g[PTC_BLK_S_DQKV], np, P(in, PTC_BLK_P_WT_QKV), nullptr, (const int32_t*)P(in, PTC_BLK_P_T_QKV_BWD), n, 2, 3 * c, c, dt, g[PTC_BLK_S_DY1], s));
   // 3'. x1 = x0 + LN_cpe(lin), y1 = norm1(x1):  dx0 = dx1 + LN_n1'(dy1);  dlin = LN_cpe'(dx0)
   RUN(ptc_add_norm_bwd(M<float>(g, PTC_BLK_S_DX1), g[PTC_BLK_S_DY1], dt, (const float*)P(sv, PTC_BLK_O_X1), P(sv, PTC_BLK_O_LIN), dt, nullptr, n, c,
@@ -147,15 +146,16 @@ extern "C" int ptc_ptv3_block_bwd(const int64_t* iv, const float* fv, const void
                        (const float*)P(sv, PTC_BLK_O_ST_N1), 1, g[PTC_BLK_G_X0], a_dt, g[PTC_BLK_S_DLIN], M<float>(g, PTC_BLK_G_G_CPE), M<float>(g, PTC_BLK_G_BE_CPE),
                        M<float>(g, PTC_BLK_G_G_N1), M<float>(g, PTC_BLK_G_BE_N1), ws, wb, s));
   // 2'. the Linear of the positional encoding
-  RUN(ptc_spconv_wgrad_deferred(P(sv, PTC_BLK_O_CONV), n, g[PTC_BLK_S_DLIN], nullptr, n, 1, c, c, dt, M<float>(g, PTC_BLK_G_W_LIN), M<float>(g, PTC_BLK_G_B_LIN), wgws(4),
-                                W.wg[4], s, &jobs[4]));
+  calls[4] = PtcWgradCall{P(sv, PTC_BLK_O_CONV), n, g[PTC_BLK_S_DLIN], nullptr, n, 1, c, c, dt, M<float>(g, PTC_BLK_G_W_LIN), M<float>(g, PTC_BLK_G_B_LIN), wgws(4), W.wg[4]};
   RUN(ptc_spconv_fwd(g[PTC_BLK_S_DLIN], n, P(in, PTC_BLK_P_WT_LIN), nullptr, nullptr, n, 1, c, c, dt, g[PTC_BLK_S_DCONV], s));
   // 1'. the convolution: weight gradient, bias gradient, input gradient over the same table with mirrored weights
   RUN(ptc_spconv_wgrad_deferred(P(in, PTC_BLK_P_XC), n, g[PTC_BLK_S_DCONV], nbr, n, 27, c, c, dt, M<float>(g, PTC_BLK_G_W_CONV), nullptr, wgws(5), W.wg[5], s, &jobs[5]));
   RUN(ptc_column_sum(g[PTC_BLK_S_DCONV], n, c, dt, M<float>(g, PTC_BLK_G_B_CONV), ws, wb, s));
   RUN(ptc_spconv_fwd_blk(g[PTC_BLK_S_DCONV], n, P(in, PTC_BLK_P_WT_CONV), nullptr, nbr, P(in, PTC_BLK_P_BLK_TAB), (const int32_t*)P(in, PTC_BLK_P_BLK_HID),
                          (const int32_t*)P(in, PTC_BLK_P_BLK_HCNT), (int)iv[PTC_BLK_I_BLK_BM], (int)iv[PTC_BLK_I_BLK_HCAP], n, 27, c, c, dt, g[PTC_BLK_G_XC], s));
-  // the split-K reductions of the six weight gradients above: one launch (their partial sums have been waiting in their own regions)
+  // the five Linear weight gradients in one grouped launch (their operands -- saved activations and the scratch gradients above -- are
+  // all still in place), then the split-K reductions of all six weight gradients in one launch
+  RUN(ptc_spconv_wgrad_group(calls, 5, jobs, s));
   RUN(ptc_wgrad_reduce_jobs(jobs, 6, s));
   return PTC_OK;
 }

@@ -627,6 +627,69 @@ static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const i
 static int spconv_wgrad_impl(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
                              int dtype, float* dw, float* dbias, void* workspace, size_t workspace_bytes, ptc_stream_t stream, PtcWgradJob* defer);
 
+// the grouped launch: calls[i] that are wgrad2-eligible and planned on the (4, 4, 1) instance share one launch of wgrad2_group_kernel
+template <typename T>
+static int launch_wgrad2_group(const PtcWgradCall* const* cs, int m, PtcWgradJob* const* jobs, hipStream_t s) {
+  W2Group<T> g;
+  g.n = m;
+  int grid = 0;
+  size_t lds = 0;
+  for (int q = 0; q < m; ++q) {
+    const PtcWgradCall& c = *cs[q];
+    const W2Plan p = w2_plan(c.n_out, c.kv, c.c_in, c.c_out, c.dbias != nullptr);
+    const int64_t count = (int64_t)c.c_out * c.kv * c.c_in;
+    float* partial = p.gx > 1 ? (float*)c.workspace : c.dw;
+    float* bias_partial = nullptr;
+    if (c.dbias) bias_partial = p.gx > 1 ? (float*)((char*)c.workspace + ptc_align_up((size_t)p.gx * (size_t)count * sizeof(float), 256)) : c.dbias;
+    const int nblocks = p.co_blocks * p.ci_blocks, total = p.gx * p.groups * nblocks;
+    g.start[q] = grid;
+    g.p[q] = W2Problem<T>{(const T*)c.in, (const T*)c.dout, c.nbr, c.n_out, c.kv, c.c_in, c.c_out, ptc_cdiv(c.n_out, W2_ROWS), p.ci_blocks, partial,
+                          bias_partial, p.gx, p.groups, nblocks, (uint32_t)((uint64_t)c.n_in * c.c_in * sizeof(T)),
+                          (uint32_t)((uint64_t)c.n_out * c.c_out * sizeof(T))};
+    grid += 8 * ((total + 7) / 8);            // every problem starts on a multiple of 8: its XCD-first numbering stays its own
+    lds = p.lds;
+    *jobs[q] = PtcWgradJob{partial, p.gx > 1 ? p.gx : 0, count, c.dw, bias_partial, (int64_t)c.c_out, c.dbias};
+  }
+  for (int q = m; q <= W2_GROUP_MAX; ++q) g.start[q] = grid;
+  auto kern = wgrad2_group_kernel<T, 4, 4, 1>;
+  if (lds > 48 * 1024) PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, g);
+  PTC_CHECK_LAUNCH("wgrad2_group_kernel");
+  return PTC_OK;
+}
+
+int ptc_spconv_wgrad_group(const PtcWgradCall* calls, int n, PtcWgradJob* jobs, ptc_stream_t stream) {
+  PTC_REQUIRE(calls && jobs && n >= 0, PTC_EINVAL, "ptc_spconv_wgrad_group: null tables");
+  const PtcWgradCall* grp[W2_GROUP_MAX];
+  PtcWgradJob* gj[W2_GROUP_MAX];
+  int m = 0, gdtype = -1;
+  for (int i = 0; i < n; ++i) {
+    const PtcWgradCall& c = calls[i];
+    jobs[i] = PtcWgradJob{nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
+    bool grouped = false;
+    if (c.n_out > 0 && c.in && c.dout && c.dw && c.workspace && (c.dtype == PTC_BF16 || c.dtype == PTC_F16) && (c.nbr || (c.kv == 1 && c.n_in >= c.n_out)) &&
+        c.c_in % 8 == 0 && c.c_out % 8 == 0 && (uint64_t)c.n_in * c.c_in * 2 <= PTC_BUF_MAX_BYTES && (uint64_t)c.n_out * c.c_out * 2 <= PTC_BUF_MAX_BYTES &&
+        c.workspace_bytes >= ptc_spconv_wgrad_workspace_bytes(c.n_out, c.kv, c.c_in, c.c_out)) {
+      const W2Plan p = w2_plan(c.n_out, c.kv, c.c_in, c.c_out, c.dbias != nullptr);
+      if (p.cot == 4 && p.cit == 4 && p.kg == 1 && m < W2_GROUP_MAX && (gdtype < 0 || gdtype == c.dtype)) {
+        grp[m] = &c; gj[m] = &jobs[i]; ++m; gdtype = c.dtype;
+        grouped = true;
+      }
+    }
+    if (!grouped) {   // its own launch (and every argument check of the plain entry point)
+      const int rc = spconv_wgrad_impl(c.in, c.n_in, c.dout, c.nbr, c.n_out, c.kv, c.c_in, c.c_out, c.dtype, c.dw, c.dbias, c.workspace, c.workspace_bytes,
+                                       stream, &jobs[i]);
+      if (rc != PTC_OK) return rc;
+    }
+  }
+  if (m == 1) {
+    const PtcWgradCall& c = *grp[0];
+    return spconv_wgrad_impl(c.in, c.n_in, c.dout, c.nbr, c.n_out, c.kv, c.c_in, c.c_out, c.dtype, c.dw, c.dbias, c.workspace, c.workspace_bytes, stream, gj[0]);
+  }
+  if (m > 1) return gdtype == PTC_BF16 ? launch_wgrad2_group<bf16_t>(grp, m, gj, (hipStream_t)stream) : launch_wgrad2_group<f16_t>(grp, m, gj, (hipStream_t)stream);
+  return PTC_OK;
+}
+
 extern "C" int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out,
                                 int kv, int c_in, int c_out, int dtype, float* dw, float* dbias, void* workspace,
                                 size_t workspace_bytes, ptc_stream_t stream) {

@@ -20,6 +20,13 @@ struct PtcWgradJob {
 int ptc_spconv_wgrad_deferred(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
                               int dtype, float* dw, float* dbias, void* workspace, size_t workspace_bytes, ptc_stream_t stream,
                               PtcWgradJob* job);
+// Several weight gradients enqueued together: those that share the (4, 4, 1) kernel instance of wgrad2 (the Linear layers of a Block from
+// 64 channels up) run as ONE launch, the others as their own; every reduction is left to the caller (jobs[i] for calls[i]).
+struct PtcWgradCall {
+  const void* in; int64_t n_in; const void* dout; const int32_t* nbr; int64_t n_out; int kv, c_in, c_out, dtype;
+  float* dw; float* dbias; void* workspace; size_t workspace_bytes;
+};
+int ptc_spconv_wgrad_group(const PtcWgradCall* calls, int n, PtcWgradJob* jobs, ptc_stream_t stream);
 // ONE launch for up to PTC_WGRAD_JOBS_MAX reductions (bit-identical to the separate launches: same per-output summation order)
 #define PTC_WGRAD_JOBS_MAX 8
 int ptc_wgrad_reduce_jobs(const PtcWgradJob* jobs, int n, ptc_stream_t stream);

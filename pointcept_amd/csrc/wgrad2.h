@@ -69,235 +69,46 @@ __global__ void __launch_bounds__(256, 2)   // two waves per SIMD: <= 256 regist
 wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_t* __restrict__ nbr, int64_t n_out, int kv,
               int c_in, int c_out, int64_t steps_total, int ci_blocks, float* __restrict__ partial,
               float* __restrict__ bias_partial, int gx, int groups, int nblocks, uint32_t in_bytes, uint32_t dout_bytes) {
-  using M = Mma<T>;
-  const __amdgpu_buffer_rsrc_t in_buf = ptc_buf(in, in_bytes), dout_buf = ptc_buf(dout, dout_bytes);
-  constexpr bool PIPE = W2Pipe<COT, CIT, KG>::value;
-  constexpr int NI = PIPE ? KG : 2;                    // gathered-row images per wave
-  constexpr int WAVE_BYTES = (COT + NI * CIT) * W2_PLANE;  // dout image + `in` images
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned char* D = smem + wave * WAVE_BYTES;
-  unsigned char* I0 = D + COT * W2_PLANE;
-  // 1-D grid, XCD-first numbering (workgroup b runs on XCD b % 8): logical id l = (row worker * blocks + channel
-  // block) * groups + table-row group, so the `groups` workgroups that stream the SAME dout rows (and gather
-  // overlapping neighbourhoods) run on one XCD at the same time and share its L2 -- dout left HBM once per group
-  // (14x for a 3^3 table) in the (x, y, z)-grid form.
-  const int total = gx * groups * nblocks;
-  const int per_xcd = (total + 7) >> 3;
-  const int lid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if (lid >= total) return;
-  const int bgrp = lid % groups, bz = (lid / groups) % nblocks, bx = lid / (groups * nblocks);
-  const int k0 = bgrp * KG;
-  const int nk = (kv - k0) < KG ? (kv - k0) : KG;
-  const int co0 = (bz / ci_blocks) * COT * 16, ci0 = (bz % ci_blocks) * CIT * 16;
-  const int64_t workers = (int64_t)gx * 4, worker = (int64_t)bx * 4 + wave;
-  // the fused bias gradient (one extra MFMA against ones per dout fragment) exists in the KG == 1 instances
-  // only -- the host plans KG = 1 whenever dbias is requested; grouped instances have no registers to spare
-  const bool do_bias = KG == 1 && bias_partial != nullptr && bgrp == 0 && (bz % ci_blocks) == 0;
+#define W2_VB_LOW ((int)(blockIdx.x & 7))
+#define W2_VB_HIGH ((int)(blockIdx.x >> 3))
+#include "wgrad2_body.inc"
+#undef W2_VB_LOW
+#undef W2_VB_HIGH
+}
 
-  f32x4 acc[KG][COT][CIT];
-  f32x4 accb[COT];
+// Several weight gradients of ONE kernel instance in one launch (the Block executor: the five Linear layers of a Block share the
+// (4, 4, 1) instance from 64 channels up): workgroup b belongs to the problem whose range holds b and runs there exactly what the
+// single launch runs -- same plan, same partials, bit-identical -- while the small problems of the deep stages fill the chip together.
+#define W2_GROUP_MAX 6
+template <typename T> struct W2Problem {
+  const T* in; const T* dout; const int32_t* nbr; int64_t n_out; int kv, c_in, c_out; int64_t steps_total; int ci_blocks;
+  float* partial; float* bias_partial; int gx, groups, nblocks; uint32_t in_bytes, dout_bytes;
+};
+template <typename T> struct W2Group { int n; int start[W2_GROUP_MAX + 1]; W2Problem<T> p[W2_GROUP_MAX]; };
+template <typename T, int COT, int CIT, int KG>
+__global__ void __launch_bounds__(256, 2)
+wgrad2_group_kernel(W2Group<T> g) {
+  int pj = 0;
 #pragma unroll
-  for (int kk = 0; kk < KG; ++kk)
-#pragma unroll
-    for (int a = 0; a < COT; ++a)
-#pragma unroll
-      for (int b = 0; b < CIT; ++b) acc[kk][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int a = 0; a < COT; ++a) accb[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  typename M::frag ones;
-  {
-    uint16_t one = std::is_same<T, bf16_t>::value ? 0x3F80 : 0x3C00;
-    uint16_t o8[8] = {one, one, one, one, one, one, one, one};
-    __builtin_memcpy(&ones, o8, sizeof(ones));
-  }
-
-  // All prefetch loads are UNCONDITIONAL: feature rows through raw buffer loads (absent rows = out-of-range offsets =
-  // zeros, mma.h), table entries from clamped addresses.  A load under an exec-masked branch makes the compiler fall
-  // back to s_waitcnt vmcnt(0) at every use, which serialised the step-ahead prefetch against the MFMAs it was
-  // meant to overlap (ISA of r01_aj).
-  // table entries of the rows this lane stages, for every table row of the group
-  auto load_idx = [&](int64_t s, int32_t (&ix)[KG][CIT]) {
-    const int64_t r0 = s * W2_ROWS;
-#pragma unroll
-    for (int kk = 0; kk < KG; ++kk)
-#pragma unroll
-      for (int i = 0; i < CIT; ++i) {
-        const int row = (i * 64 + lane) / (2 * CIT);
-        const int64_t rr = r0 + row;
-        const bool ok = kk < nk && rr < n_out && s < steps_total;
-        int32_t j;
-        if (nbr) {   // wave-uniform
-          const int kc = kk < nk ? kk : nk - 1;
-          j = nbr[(int64_t)(k0 + kc) * n_out + (rr < n_out ? rr : n_out - 1)];
-        } else {
-          j = (int32_t)rr;
-        }
-        ix[kk][i] = ok ? j : -1;
-      }
-  };
-  auto load_dout = [&](int64_t s, uint4 (&pd)[COT]) {
-    const int64_t r0 = s * W2_ROWS;
-#pragma unroll
-    for (int i = 0; i < COT; ++i) {
-      const int v = i * 64 + lane, row = v / (2 * COT), piece = v % (2 * COT);
-      const int64_t rr = r0 + row;
-      const int ch = co0 + piece * 8;
-      const bool ok = rr < n_out && ch < c_out && s < steps_total;
-      pd[i] = ptc_buf_load16(dout_buf, ok ? ((uint32_t)rr * (uint32_t)c_out + (uint32_t)ch) * 2u : PTC_BUF_OOB);
-    }
-  };
-  auto store_dout = [&](const uint4 (&pd)[COT]) {
-#pragma unroll
-    for (int i = 0; i < COT; ++i) {
-      const int v = i * 64 + lane, row = v / (2 * COT), piece = v % (2 * COT);
-      *reinterpret_cast<uint4*>(D + w2_off(row, piece)) = pd[i];
-    }
-  };
-  auto gather = [&](const int32_t (&ixk)[CIT], uint4 (&pi)[CIT]) {
-#pragma unroll
-    for (int i = 0; i < CIT; ++i) {
-      const int piece = (i * 64 + lane) % (2 * CIT);
-      const int ch = ci0 + piece * 8;
-      const bool ok = ixk[i] >= 0 && ch < c_in;
-      pi[i] = ptc_buf_load16(in_buf, ok ? ((uint32_t)ixk[i] * (uint32_t)c_in + (uint32_t)ch) * 2u : PTC_BUF_OOB);
-    }
-  };
-  auto store_in = [&](unsigned char* buf, const uint4 (&pi)[CIT]) {
-#pragma unroll
-    for (int i = 0; i < CIT; ++i) {
-      const int v = i * 64 + lane, row = v / (2 * CIT), piece = v % (2 * CIT);
-      *reinterpret_cast<uint4*>(buf + w2_off(row, piece)) = pi[i];
-    }
-  };
-
-  if constexpr (PIPE) {
-    int32_t idx[KG][CIT];
-    uint4 pd[COT], pi[KG][CIT];
-    load_idx(worker, idx);
-    load_dout(worker, pd);
-#pragma unroll
-    for (int kk = 0; kk < KG; ++kk) gather(idx[kk], pi[kk]);
-    load_idx(worker + workers, idx);
-    for (int64_t s = worker; s < steps_total; s += workers) {
-      // 1. step s lands in the wave's LDS slice
-      store_dout(pd);
-#pragma unroll
-      for (int kk = 0; kk < KG; ++kk)
-        if (kk < nk) store_in(I0 + kk * CIT * W2_PLANE, pi[kk]);
-      // 2. step s + workers goes out, entries of the one after it too
-      load_dout(s + workers, pd);
-#pragma unroll
-      for (int kk = 0; kk < KG; ++kk) gather(idx[kk], pi[kk]);
-      load_idx(s + 2 * workers, idx);
-      // 3. multiply step s
-      w2_wave_sync();
-      typename M::frag A[COT];
-#pragma unroll
-      for (int a = 0; a < COT; ++a) A[a] = w2_frag<T>(D, a, lane);
-      if constexpr (KG == 1) {
-        if (do_bias) {
-#pragma unroll
-          for (int a = 0; a < COT; ++a) accb[a] = M::mma(A[a], ones, accb[a]);
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk < KG; ++kk) {
-        if (kk < nk) {
-          typename M::frag B[CIT];
-#pragma unroll
-          for (int b = 0; b < CIT; ++b) B[b] = w2_frag<T>(I0 + kk * CIT * W2_PLANE, b, lane);
-#pragma unroll
-          for (int a = 0; a < COT; ++a)
-#pragma unroll
-            for (int b = 0; b < CIT; ++b) acc[kk][a][b] = M::mma(A[a], B[b], acc[kk][a][b]);
-        }
-      }
-      w2_wave_sync();  // the slice is rewritten at the top of the next trip
-    }
-  } else {
-    unsigned char* I[2] = {I0, I0 + CIT * W2_PLANE};
-    for (int64_t s = worker; s < steps_total; s += workers) {
-      int32_t idx[KG][CIT];
-      load_idx(s, idx);
-      uint4 pd[COT];
-      load_dout(s, pd);
-      store_dout(pd);
-      uint4 pre[CIT];
-      gather(idx[0], pre);
-      w2_wave_sync();
-      typename M::frag A[COT];
-#pragma unroll
-      for (int a = 0; a < COT; ++a) A[a] = w2_frag<T>(D, a, lane);
-      if constexpr (KG == 1) {
-        if (do_bias) {
-#pragma unroll
-          for (int a = 0; a < COT; ++a) accb[a] = M::mma(A[a], ones, accb[a]);
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk < KG; ++kk) {
-        if (kk < nk) {
-          unsigned char* buf = I[kk & 1];
-          store_in(buf, pre);
-          if (kk + 1 < KG && kk + 1 < nk) gather(idx[(kk + 1) < KG ? (kk + 1) : 0], pre);  // next table row goes out first
-          w2_wave_sync();
-          typename M::frag B[CIT];
-#pragma unroll
-          for (int b = 0; b < CIT; ++b) B[b] = w2_frag<T>(buf, b, lane);
-#pragma unroll
-          for (int a = 0; a < COT; ++a)
-#pragma unroll
-            for (int b = 0; b < CIT; ++b) acc[kk][a][b] = M::mma(A[a], B[b], acc[kk][a][b]);
-        }
-      }
-    }
-  }
-
-  // ---- sum the four waves through LDS, write this workgroup's partial ------------------------------
-  // D[i = co][j = ci]: lane (j = lane & 15, g = lane >> 4) holds co = 16 a + 4 g + e, ci = 16 b + j
-  float* red = reinterpret_cast<float*>(smem);  // [4 waves][CIT][4][64] floats <= 16 KB
-  float* pout = partial + (int64_t)bx * c_out * kv * c_in;
-#pragma unroll
-  for (int kk = 0; kk < KG; ++kk) {
-#pragma unroll
-    for (int a = 0; a < COT; ++a) {
-      __syncthreads();
-      if (kk < nk) {
-#pragma unroll
-        for (int b = 0; b < CIT; ++b)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) red[((wave * CIT + b) * 4 + e) * 64 + lane] = acc[kk][a][b][e];
-      }
-      __syncthreads();
-      if (kk < nk) {
-#pragma unroll
-        for (int i = 0; i < CIT; ++i) {
-          const int q = i * 256 + threadIdx.x;  // (b, e, lane)
-          const int ln = q & 63, e = (q >> 6) & 3, b = q >> 8;
-          const float v = red[q] + red[CIT * 256 + q] + red[2 * CIT * 256 + q] + red[3 * CIT * 256 + q];
-          const int co = co0 + 16 * a + 4 * (ln >> 4) + e, ci = ci0 + 16 * b + (ln & 15);
-          if (co < c_out && ci < c_in) pout[((int64_t)co * kv + (k0 + kk)) * c_in + ci] = v;
-        }
-      }
-    }
-  }
-  if (do_bias) {  // every column j of accb holds the same column sum; take j = 0
-    __syncthreads();
-    if ((lane & 15) == 0) {
-#pragma unroll
-      for (int a = 0; a < COT; ++a)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[wave * COT * 16 + 16 * a + 4 * (lane >> 4) + e] = accb[a][e];
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < COT * 16) {
-      const int co = co0 + threadIdx.x;
-      if (co < c_out)
-        bias_partial[(int64_t)bx * c_out + co] = red[threadIdx.x] + red[COT * 16 + threadIdx.x] +
-                                                         red[2 * COT * 16 + threadIdx.x] + red[3 * COT * 16 + threadIdx.x];
-    }
-  }
+  for (int q = 1; q < W2_GROUP_MAX; ++q)
+    if (q < g.n && (int)blockIdx.x >= g.start[q]) pj = q;
+  const int vb = (int)blockIdx.x - g.start[pj];
+  const T* __restrict__ in = g.p[pj].in;
+  const T* __restrict__ dout = g.p[pj].dout;
+  const int32_t* __restrict__ nbr = g.p[pj].nbr;
+  const int64_t n_out = g.p[pj].n_out;
+  const int kv = g.p[pj].kv, c_in = g.p[pj].c_in, c_out = g.p[pj].c_out;
+  const int64_t steps_total = g.p[pj].steps_total;
+  const int ci_blocks = g.p[pj].ci_blocks;
+  float* __restrict__ partial = g.p[pj].partial;
+  float* __restrict__ bias_partial = g.p[pj].bias_partial;
+  const int gx = g.p[pj].gx, groups = g.p[pj].groups, nblocks = g.p[pj].nblocks;
+  const uint32_t in_bytes = g.p[pj].in_bytes, dout_bytes = g.p[pj].dout_bytes;
+#define W2_VB_LOW (vb & 7)
+#define W2_VB_HIGH (vb >> 3)
+#include "wgrad2_body.inc"
+#undef W2_VB_LOW
+#undef W2_VB_HIGH
 }
 
 // ---- host-side plan ----------------------------------------------------------------------------

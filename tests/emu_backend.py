@@ -38,7 +38,8 @@ def build(verbose: bool = False):
     os.makedirs(csrc)
     os.makedirs(os.path.join(d, "include"))
     shutil.copy(os.path.join(root, "include", "ptcore.h"), os.path.join(d, "include", "ptcore.h"))
-    for f in glob.glob(os.path.join(root, "pointcept_amd", "csrc", "*.h")) + glob.glob(os.path.join(root, "pointcept_amd", "csrc", "*.hip")) + \
+    for f in glob.glob(os.path.join(root, "pointcept_amd", "csrc", "*.h")) + glob.glob(os.path.join(root, "pointcept_amd", "csrc", "*.inc")) + \
+            glob.glob(os.path.join(root, "pointcept_amd", "csrc", "*.hip")) + \
             glob.glob(os.path.join(root, "pointcept_amd", "csrc", "*.cpp")):
         txt = open(f).read()
         txt = re.sub(r"extern\s+__shared__", "extern", txt)
