@@ -1,13 +1,11 @@
 """Engine feature switches (environment variables, read once at import).
 
-Every switch selects between two implementations that are BOTH on libptcore.so / PyTorch-ROCm GPU
-code -- there is no CPU path to switch to.  They exist so one GPU session can A/B a fusion against
+Every switch selects between two forms of the same math that are BOTH on libptcore.so -- there is no CPU path and no
+library (hipBLASLt / ATen / SDPA) backend to switch to (round 4: PTC_OWN_LINEAR / PTC_OWN_NORM are gone; the library
+comparison lives in tools/linear_kernels.py).  They exist so one GPU session can A/B a fusion against
 the unfused form of the same math (tests/test_gpu_model.py runs the oracle comparison under both
 settings), and so a regression can be bisected without a rebuild.
 
-  PTC_OWN_LINEAR=0   nn.Linear layers of the PTv3 path run on hipBLASLt (F.linear) instead of the
-                     identity-table MFMA kernels of csrc/spconv.hip
-  PTC_OWN_NORM=0     nn.LayerNorm runs on ATen instead of csrc/norm.hip
   PTC_FUSE_GATHER=0  serialized attention gathers / un-gathers rows with ptc_gather_rows instead of
                      folding the permutation into the qkv / proj GEMMs (kv = 1 gather tables)
   PTC_SORT_POINTS=0  PT-v3m1 keeps the caller's (dataloader) row order at stage 0 instead of physically
@@ -35,8 +33,6 @@ def _flag(name: str, default: bool) -> bool:
     return v.strip().lower() not in ("0", "false", "off", "no", "")
 
 
-OWN_LINEAR = _flag("PTC_OWN_LINEAR", True)
-OWN_NORM = _flag("PTC_OWN_NORM", True)
 FUSE_GATHER = _flag("PTC_FUSE_GATHER", True)
 SORT_POINTS = _flag("PTC_SORT_POINTS", True)
 FUSE_BLOCK = _flag("PTC_FUSE_BLOCK", True)

@@ -459,11 +459,9 @@ static int launch_conv7_i(const void* in, int64_t n_in, const void* w, const flo
 #endif
   int grid = n_blocks < max_wgs ? n_blocks : max_wgs;
   auto kern = conv7_kernel<T, C>;
-  static bool attr = false;   // per instantiation
-  if (!attr) {
-    PTC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C7Geom<C>::LDS));
-    attr = true;
-  }
+  // every launch, like the other large-LDS kernels: the attribute is per DEVICE (a process-wide flag left the second GPU of a process
+  // without it) and the call is a host-side table write
+  PTC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C7Geom<C>::LDS));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C7Geom<C>::LDS, s, (const T*)in, (const T*)w, bias, tab, hid, hcnt, n_out,
                      n_blocks, (T*)out);
   PTC_CHECK_LAUNCH("conv7_kernel");

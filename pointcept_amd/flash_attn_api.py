@@ -5,16 +5,13 @@
 head_dim 16 and max_seqlen <= 1024 (every PT-v3m1 / m2 configuration) run on the gfx950 MFMA window-attention kernels
 (attention.hip); head_dim 17..64 (PT-v3m3 / LitePT use 18: a multiple of 3 for their 3-D RoPE) on their multi-slab form
 (attention_hd.h; windows up to 1024 keys for head_dim <= 32, 672 for <= 48, 512 for <= 64).  Anything else (head_dim < 16,
-> 64, longer windows) is served by PyTorch-ROCm's scaled_dot_product_attention on the GPU, one batched call per distinct
-sequence length -- a library path that exists so such calls run through the operator-level API, not a tuned one (it
-needs the sequence lengths on the host: one sync per call).  fp16 qkv (LitePT's call site) runs on the same kernels after a cast to
+> 64, longer windows) raises PtcoreError: there is no library (SDPA) backend behind this mirror (round 4).  fp16 qkv (LitePT's call site) runs on the same kernels after a cast to
 bf16 and comes back as fp16.  dropout_p must be 0 (all reference PTv3 configs); causal / alibi / softcap /
 local windows raise.
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from . import functional as PF
 from . import ops
@@ -24,22 +21,6 @@ from ._lib import PtcoreError
 def _require_gpu(t: torch.Tensor) -> None:
     if not t.is_cuda:
         raise PtcoreError("flash_attn_varlen_qkvpacked_func: qkv must live on a GPU (there is no CPU fallback)")
-
-
-def _sdpa_varlen(qkv: torch.Tensor, cu_seqlens: torch.Tensor, softmax_scale) -> torch.Tensor:
-    T, _, H, D = qkv.shape
-    cu = cu_seqlens.tolist()
-    out = torch.empty((T, H, D), dtype=qkv.dtype, device=qkv.device)
-    by_len = {}
-    for a, b in zip(cu[:-1], cu[1:]):
-        if b > a:
-            by_len.setdefault(b - a, []).append(a)
-    for length, starts in by_len.items():
-        rows = (torch.tensor(starts, device=qkv.device)[:, None] + torch.arange(length, device=qkv.device)[None]).reshape(-1)
-        blk = qkv[rows].reshape(len(starts), length, 3, H, D).permute(2, 0, 3, 1, 4)     # [3, n, H, L, D]
-        o = F.scaled_dot_product_attention(blk[0], blk[1], blk[2], dropout_p=0.0, is_causal=False, scale=softmax_scale)
-        out[rows] = o.permute(0, 2, 1, 3).reshape(-1, H, D).to(out.dtype)
-    return out
 
 
 def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
@@ -53,9 +34,9 @@ def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
         raise PtcoreError(f"flash_attn_varlen_qkvpacked_func: qkv must be [T,3,H,D], got {tuple(qkv.shape)}")
     _require_gpu(qkv)
     if not ops.attn_hd_supported(int(qkv.shape[3]), int(max_seqlen)):
-        if softmax_scale is None:
-            softmax_scale = qkv.shape[3] ** -0.5
-        return _sdpa_varlen(qkv, cu_seqlens, float(softmax_scale))
+        # no library (SDPA) backend behind this mirror: outside the kernels' range the call fails loudly
+        raise PtcoreError(f"flash_attn_varlen_qkvpacked_func: head_dim={int(qkv.shape[3])} with max_seqlen={int(max_seqlen)} is outside the "
+                          "window-attention kernels' range (head_dim 16..32: 1024 keys, ..48: 672, ..64: 512) -- PTC_EUNSUPPORTED")
     if qkv.dtype == torch.float16:
         # LitePT's call site hands over fp16 (litept_v1.py:235-260).  The window-attention kernels take bf16 operands with fp32
         # accumulation: fp16 operands are re-rounded to bf16 (three mantissa bits) and the result returned as fp16.

@@ -789,20 +789,24 @@ def _blk_plan(n, npad, c, heads, x0_f32):
     shapes = {"W_CONV": (c, 27, c), "B_CONV": (c,), "W_LIN": (c, c), "B_LIN": (c,), "G_CPE": (c,), "BE_CPE": (c,), "G_N1": (c,), "BE_N1": (c,),
               "W_QKV": (3 * c, c), "B_QKV": (3 * c,), "W_PROJ": (c, c), "B_PROJ": (c,), "G_N2": (c,), "BE_N2": (c,), "W_FC1": (hid, c), "B_FC1": (hid,),
               "W_FC2": (c, hid), "B_FC2": (c,)}
-    g_items = [("G_" + k, 1, int(torch.Size(shapes[k]).numel())) for k in _BLK_PARAMS] + [("S_DX2", n, c), ("S_DX1", n, c)]
+    # the parameter gradients in their OWN small slab (~12 C^2 floats): AccumulateGrad keeps the returned views -- and with them their
+    # storage -- alive as long as .grad lives; sharing a slab with the 3 N C floats of fp32 scratch pinned ~77 MB per stage-0 Block
+    # (ADVICE r3).  The fp32 scratch gradients (and dx0 of an fp32 stream) live in a second, transient slab.
+    lg, tg = _blk_layout([("G_" + k, 1, int(torch.Size(shapes[k]).numel())) for k in _BLK_PARAMS], 4)
+    gs_items = [("S_DX2", n, c), ("S_DX1", n, c)]
     if x0_f32:
-        g_items.append(("G_X0", n, c))
-    lg, tg = _blk_layout(g_items, 4)
+        gs_items.append(("G_X0", n, c))
+    lgs, tgs = _blk_layout(gs_items, 4)
     s_items = [("S_DM", n, c), ("S_DH", n, hid), ("S_DY2", n, c), ("S_DA", n, c), ("S_DATT", npad, c), ("S_DQKV", npad, 3 * c), ("S_DY1", n, c),
                ("S_DLIN", n, c), ("S_DCONV", n, c), ("G_XC", n, c)]
     if not x0_f32:
         s_items.append(("G_X0", n, c))
     ls, ts = _blk_layout(s_items, 2)
-    p = dict(E=E, t16=t16, t32=t32, tg=tg, ts=ts,
+    p = dict(E=E, t16=t16, t32=t32, tg=tg, tgs=tgs, ts=ts,
              o16=[(E["O_" + k], v[0]) for k, v in l16.items()], o32=[(E["O_" + k], v[0]) for k, v in l32.items()],
-             g32=[(E[k], v[0]) for k, v in lg.items()], g16=[(E[k], v[0]) for k, v in ls.items()],
+             g32=[(E[k], v[0]) for k, v in lg.items()], g32s=[(E[k], v[0]) for k, v in lgs.items()], g16=[(E[k], v[0]) for k, v in ls.items()],
              gparam={k: (lg["G_" + k][0] // 4, int(torch.Size(shapes[k]).numel())) for k in _BLK_PARAMS},
-             gx0=(lg["G_X0"][0] // 4 if x0_f32 else ls["G_X0"][0] // 2), gxc=ls["G_XC"][0] // 2,
+             gx0=(lgs["G_X0"][0] // 4 if x0_f32 else ls["G_X0"][0] // 2), gxc=ls["G_XC"][0] // 2,
              ws=None)
     if len(_blk_plans) > 256:
         _blk_plans.clear()
@@ -905,6 +909,7 @@ class _BlockFn(Function):
         iv, fv, pin = _blk_tables(E, x0, meta)
         it = iter(sv[8:])
         sh = {}
+        keep_wt = []
         for k, present in zip(_BLK_PARAMS, ctx.present):
             if present:
                 t = next(it)
@@ -914,9 +919,14 @@ class _BlockFn(Function):
         # transposed weight layouts of the input-gradient GEMMs (all layers' layouts are refreshed in one launch per step)
         for k, mode, slots in (("CONV", "mirror", 0), ("LIN", "mirror", 0), ("QKV", "repeat", 2), ("PROJ", "mirror", 0), ("FC1", "mirror", 0),
                                ("FC2", "mirror", 0)):
-            wt = _cast_cache.layout(sh["W_" + k], mode, slots)
+            w = sh["W_" + k]
+            wt = _cast_cache.layout(w, mode, slots)
             if wt is None:
-                raise PtcoreError("_BlockFn.backward: a weight shadow left the cast cache between forward and backward")
+                # the shadow is not (or no longer) a cache entry -- a non-leaf / re-parametrised weight, or the cache was invalidated
+                # between forward and backward: build this one layout here (the composed path does the same), never fail the step
+                w3 = w if w.dim() == 3 else w[:, None, :]
+                wt = (w3.flip(1).permute(2, 1, 0) if mode == "mirror" else w3.permute(2, 1, 0).expand(-1, slots, -1)).contiguous()
+                keep_wt.append(wt)
             pin[E["P_WT_" + k]] = wt.data_ptr()
         pin[E["P_X0"]], pin[E["P_XC"]] = x0.data_ptr(), xc.data_ptr()
         if rs1 is not None:
@@ -936,12 +946,15 @@ class _BlockFn(Function):
         for idx, off in plan["o32"]:
             psv[idx] = b32 + off
         psv[E["O_X3"]], psv[E["O_XB3"]] = x3.data_ptr(), xb3.data_ptr()
-        gbuf = torch.empty(plan["tg"], dtype=torch.float32, device=dev)
+        gbuf = torch.empty(plan["tg"], dtype=torch.float32, device=dev)          # parameter gradients only (small, long-lived)
+        gscr = torch.empty(plan["tgs"], dtype=torch.float32, device=dev)         # fp32 scratch gradients (+ dx0 of an fp32 stream)
         sbuf = torch.empty(plan["ts"], dtype=dt, device=dev)
         pg = (ctypes.c_void_p * E["GS_COUNT"])()
-        bg, bs = gbuf.data_ptr(), sbuf.data_ptr()
+        bg, bgs, bs = gbuf.data_ptr(), gscr.data_ptr(), sbuf.data_ptr()
         for idx, off in plan["g32"]:
             pg[idx] = bg + off
+        for idx, off in plan["g32s"]:
+            pg[idx] = bgs + off
         for idx, off in plan["g16"]:
             pg[idx] = bs + off
         for k, present in zip(_BLK_PARAMS, ctx.present):
@@ -952,7 +965,7 @@ class _BlockFn(Function):
         nbytes = plan["ws"]
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.check(ops.lib().ptc_ptv3_block_bwd(iv, fv, pin, psv, pg, ws.data_ptr(), nbytes, ops.stream_ptr()), "ptc_ptv3_block_bwd")
-        dx0 = (gbuf if x0.dtype == torch.float32 else sbuf)[plan["gx0"]:plan["gx0"] + n * c].view(n, c)
+        dx0 = (gscr if x0.dtype == torch.float32 else sbuf)[plan["gx0"]:plan["gx0"] + n * c].view(n, c)
         dxc = sbuf[plan["gxc"]:plan["gxc"] + n * c].view(n, c)
         grads = []
         for k, present, pdt, shp in zip(_BLK_PARAMS, ctx.present, ctx.param_dtypes, ctx.param_shapes):

@@ -35,7 +35,7 @@ _OWN_MAX_COUT = 2048
 
 
 def _own_linear_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    if not (config.OWN_LINEAR and x.is_cuda and x.dim() == 2 and x.shape[0] > 0):
+    if not (x.is_cuda and x.dim() == 2 and x.shape[0] > 0):
         return False
     if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         return False
@@ -62,7 +62,7 @@ class LayerNorm(nn.LayerNorm):
         _require_gpu(x, "LayerNorm")
         if out_dtype is None and self.gemm_consumer and x.is_cuda and torch.is_autocast_enabled("cuda"):
             out_dtype = torch.get_autocast_dtype("cuda")  # the value autocast's cast would produce anyway
-        if (config.OWN_NORM and x.is_cuda and x.dim() == 2 and len(self.normalized_shape) == 1 and self.elementwise_affine
+        if (x.is_cuda and x.dim() == 2 and len(self.normalized_shape) == 1 and self.elementwise_affine
                 and self.bias is not None and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
                 and ops.layer_norm_supported(x.shape[1]) and x.shape[0] > 0):
             return PF.layer_norm(x, self.weight, self.bias, self.eps, out_dtype)
@@ -78,7 +78,7 @@ class BatchNorm1d(nn.BatchNorm1d):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _require_gpu(x, "BatchNorm1d")
-        use = (config.OWN_NORM and self.affine and x.is_cuda and x.dim() == 2 and x.shape[0] > 1 and ops.batch_norm_supported(x.shape[1], x.dtype)
+        use = (self.affine and x.is_cuda and x.dim() == 2 and x.shape[0] > 1 and ops.batch_norm_supported(x.shape[1], x.dtype)
                and (self.training or self.running_mean is not None))
         if not use:
             y = super().forward(x)
@@ -112,6 +112,6 @@ def absorb_activations(modules) -> None:
     """modules: the ORDERED children of a sequential container.  Marks every (BatchNorm1d, GELU|ReLU) pair."""
     mods = list(modules)
     for a, b in zip(mods[:-1], mods[1:]):
-        if isinstance(a, BatchNorm1d) and a.act == "none" and isinstance(b, (GELU, ReLU)) and not b.absorbed and config.OWN_NORM:
+        if isinstance(a, BatchNorm1d) and a.act == "none" and isinstance(b, (GELU, ReLU)) and not b.absorbed:
             a.act = "gelu" if isinstance(b, GELU) else "relu"
             b.absorbed = True

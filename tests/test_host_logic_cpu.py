@@ -240,7 +240,7 @@ def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
             assert _rel(fm[1], fm[0]) < 1e-3
             _grad_check(m_b, m_a, 3e-2)
             # PT-v3m3 (Utonia; 3-D RoPE inside attention needs head_dim % 3 == 0): flash_attn_varlen_qkvpacked_func then
-            # takes the library (SDPA) path of pointcept_amd/flash_attn_api.py instead of the head_dim-16 kernels
+            # takes the head_dim 17..64 kernels (here: their CPU stand-in) instead of the head_dim-16 ones
             m3cfg = dict(m2cfg, enc_channels=(48, 96, 96, 192, 192), enc_num_head=(2, 4, 4, 8, 8), dec_channels=(48, 96, 96, 192),
                          dec_num_head=(2, 4, 4, 8))
             m3cfg.pop("layer_scale")
@@ -256,7 +256,7 @@ def test_b3_reference_model_files_run_unmodified_on_the_engine_operators():
                 f = net({k: v for k, v in mb.items()}).feat
                 (f * torch.linspace(-1, 1, f.shape[1])).pow(2).mean().backward()
                 fu.append(f.detach())
-            assert _rel(fu[1], fu[0]) < 2e-2             # bf16 SDPA vs the fp32-math stand-in
+            assert _rel(fu[1], fu[0]) < 2e-2             # bf16 attention vs the fp32-math stand-in
             _grad_check(u_b, u_a, 6e-2)
             cfg = dict(TINY, enable_flash=True)
             batch = _batch([500, 220], seed0=500)
