@@ -243,20 +243,34 @@ int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float
  *                                     first 16 bytes of row nbr[k][128 b + 32 t + r] -- v = 0: 128-byte rows (64 channels),
  *                                     slot * 128 + ((slot >> 1) & 7) * 16; v = 1: 64-byte rows (32 channels), slot * 64 +
  *                                     ((slot >> 2) & 3) * 16, slot = position in the block's list; none = hcap * row bytes;
- *                                     row k = 27: the tap masks in its first 20 bytes -- four uint32, bit k of word t set when
- *                                     tile t (rows 32 t .. 32 t + 31) has a neighbour at tap k, then their OR -- the rest "none"
- *       *n_overflow (device int32)  = number of blocks with hcnt = -1 (diagnostic; nothing depends on it)
+ *                                     row k = 27: the tap masks in its first 52 bytes -- four uint32, bit k of word t set when
+ *                                     tile t (rows 32 t .. 32 t + 31) has a neighbour at tap k, then their OR, then eight
+ *                                     uint32, bit k of word s set when one of the rows {32 t + 4 s + q : t, q = 0..3} has one
+ *                                     (the 16-row MFMA steps of ptc_spconv_wgrad_blk) -- the rest "none"
+ *       *n_overflow (device int32)  = number of blocks with hcnt = -1; ptc_spconv_wgrad_blk reads it ON THE DEVICE to choose its
+ *                                     kernel (no host copy is ever made)
  *     hcap a multiple of 16, < 512.
  *   ptc_spconv_fwd_blk: same result as ptc_spconv_fwd(in, ..., nbr, ...) up to the fp32 rounding of a different summation
  *       order, with the input rows of a block staged once in LDS and the weights held in registers.  16-bit dtypes,
  *       kv = 27, c_in = c_out in {32, 64}, bm = 128, hcap = 416, n_in = n_out >= 4096; any other shape is forwarded to
- *       ptc_spconv_fwd. */
+ *       ptc_spconv_fwd.
+ *   ptc_spconv_wgrad_blk (round 4): dw of the same convolution (= ptc_spconv_wgrad(in, dout, nbr) without the bias gradient, up to
+ *       the fp32 rounding of a different summation order; bit-reproducible) with the whole gradient held in MFMA accumulators
+ *       of persistent workgroups and both operands built from the block's LDS images by transposing reads (csrc/wgrad7.h).
+ *       Same shape range as ptc_spconv_fwd_blk; other shapes are forwarded to ptc_spconv_wgrad.  When *n_overflow != 0 (a block
+ *       whose halo did not fit) the call is served by the global-gather kernel instead -- decided on the device, both kernels are
+ *       always enqueued.  workspace >= ptc_spconv_wgrad_blk_workspace_bytes.
+ *       Replaces spconv's weight-gradient kernel behind SubMConv3d (ptv3m1:278-284, spunet:49-68) under autograd. */
 size_t ptc_rulebook_blocks_tab_bytes(int64_t n);
 int ptc_rulebook_blocks(const int32_t* nbr, int kv, int64_t n, int bm, int hcap, void* tab, int32_t* hid,
                         int32_t* hcnt, int32_t* n_overflow, ptc_stream_t stream);
 int ptc_spconv_fwd_blk(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr,
                        const void* tab, const int32_t* hid, const int32_t* hcnt, int bm, int hcap, int64_t n_out,
                        int kv, int c_in, int c_out, int dtype, void* out, ptc_stream_t stream);
+size_t ptc_spconv_wgrad_blk_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out);
+int ptc_spconv_wgrad_blk(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, const void* tab, const int32_t* hid,
+                         const int32_t* hcnt, const int32_t* n_overflow, int bm, int hcap, int64_t n_out, int kv, int c_in,
+                         int c_out, int dtype, float* dw, void* workspace, size_t workspace_bytes, ptc_stream_t stream);
 /* Dense row-wise GEMM out = in W^T + b with an MLP epilogue fused (PTv3 MLP, ptv3m1:225-248: fc1 -> GELU -> fc2):
  *   epilogue 1 : out = h (the pre-activation, saved for the backward), aux_out = GELU(h)         [fc1 forward]
  *   epilogue 2 : out = (in W^T) * GELU'(aux_in), aux_in = h [n, c_out]                          [fc2 input gradient]
@@ -555,11 +569,11 @@ int ptc_pair_aggregate_bwd(const float* grad_out, const float* attn, const float
  *      g   [PTC_BLK_GS_COUNT]       backward outputs: gradients (G_*; fp32 parameters' gradients, G_X0 in the dtype of x0, G_XC
  *                                   16-bit) and scratch (S_*), caller-allocated; workspace >= ptc_ptv3_block_workspace_bytes
  * ------------------------------------------------------------------------------------------ */
-#define PTC_BLK_ABI 1
+#define PTC_BLK_ABI 2
 enum { PTC_BLK_I_ABI, PTC_BLK_I_N, PTC_BLK_I_NPAD, PTC_BLK_I_NSEQ, PTC_BLK_I_C, PTC_BLK_I_HEADS, PTC_BLK_I_DTYPE, PTC_BLK_I_A_DTYPE,
        PTC_BLK_I_PATCH, PTC_BLK_I_BLK_BM, PTC_BLK_I_BLK_HCAP, PTC_BLK_I_COUNT };
 enum { PTC_BLK_F_SCALE, PTC_BLK_F_EPS_CPE, PTC_BLK_F_EPS_N1, PTC_BLK_F_EPS_N2, PTC_BLK_F_COUNT };
-enum { PTC_BLK_P_X0, PTC_BLK_P_XC, PTC_BLK_P_NBR, PTC_BLK_P_BLK_TAB, PTC_BLK_P_BLK_HID, PTC_BLK_P_BLK_HCNT, PTC_BLK_P_T_QKV_FWD,
+enum { PTC_BLK_P_X0, PTC_BLK_P_XC, PTC_BLK_P_NBR, PTC_BLK_P_BLK_TAB, PTC_BLK_P_BLK_HID, PTC_BLK_P_BLK_HCNT, PTC_BLK_P_BLK_NOVF, PTC_BLK_P_T_QKV_FWD,
        PTC_BLK_P_T_QKV_BWD, PTC_BLK_P_T_PROJ_FWD, PTC_BLK_P_T_PROJ_BWD, PTC_BLK_P_CU, PTC_BLK_P_RS1, PTC_BLK_P_RS2,
        PTC_BLK_P_W_CONV, PTC_BLK_P_B_CONV, PTC_BLK_P_W_LIN, PTC_BLK_P_B_LIN, PTC_BLK_P_G_CPE, PTC_BLK_P_BE_CPE, PTC_BLK_P_G_N1,
        PTC_BLK_P_BE_N1, PTC_BLK_P_W_QKV, PTC_BLK_P_B_QKV, PTC_BLK_P_W_PROJ, PTC_BLK_P_B_PROJ, PTC_BLK_P_G_N2, PTC_BLK_P_BE_N2,

@@ -53,6 +53,9 @@ _SIGNATURES = {
     "ptc_rulebook_blocks": (c_int, [c_ptr, c_int, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_spconv_fwd_blk": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_int, c_int,
                                    c_ptr, c_ptr]),
+    "ptc_spconv_wgrad_blk_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
+    "ptc_spconv_wgrad_blk": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_int, c_int,
+                                     c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_linear_supported_ex": (c_int, [c_int, c_int, c_int]),
     "ptc_linear_fwd_ex": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_spconv_wgrad_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),

@@ -18,6 +18,8 @@ settings), and so a regression can be bisected without a rebuild.
                      formulation under bf16 autocast instead of the window-attention kernels of csrc/attention_rpe.h
   PTC_EXEC_BLOCK=0   a PT-v3m1 Block is enqueued by ~16 Python autograd Functions (the fused joints below) instead of one C call per
                      direction (csrc/block_exec.hip: same kernels, same operands, bit-identical; ~20 ms less host time per step)
+  PTC_WGRAD_BLK=0    the weight gradient of the 32 / 64-channel submanifold convolutions runs on the global-gather kernel (wgrad2) instead
+                     of the block-staged, accumulator-stationary one (csrc/wgrad7.h)
   PTC_FUSE_BLOCK=0   the three residual joints of a PTv3 Block run as separate LayerNorm / add / cast
                      kernels instead of the fused add_norm passes
 """
@@ -40,3 +42,4 @@ EXEC_BLOCK = _flag("PTC_EXEC_BLOCK", True)
 FUSE_MLP = _flag("PTC_FUSE_MLP", True)
 PREFETCH_LEVELS = _flag("PTC_PREFETCH_LEVELS", True)
 RPE_KERNEL = _flag("PTC_RPE_KERNEL", True)
+WGRAD_BLK = _flag("PTC_WGRAD_BLK", True)

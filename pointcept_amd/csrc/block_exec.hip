@@ -42,7 +42,7 @@ static BlkWs blk_ws(int64_t n, int64_t n_pad, int c, int heads) {
   w.wg[2] = ptc_spconv_wgrad_workspace_bytes(n, 1, c, c);          // proj
   w.wg[3] = ptc_spconv_wgrad_workspace_bytes(n_pad, 1, c, 3 * c);  // qkv
   w.wg[4] = ptc_spconv_wgrad_workspace_bytes(n, 1, c, c);          // the Linear of the positional encoding
-  w.wg[5] = ptc_spconv_wgrad_workspace_bytes(n, 27, c, c);         // the convolution
+  w.wg[5] = ptc_spconv_wgrad_blk_workspace_bytes(n, 27, c, c);     // the convolution (block-staged weight gradient where it applies)
   size_t o = w.common;
   for (int i = 0; i < 6; ++i) { w.off[i] = o; o += ptc_align_up(w.wg[i], 256); }
   w.total = o;
@@ -149,7 +149,9 @@ extern "C" int ptc_ptv3_block_bwd(const int64_t* iv, const float* fv, const void
   calls[4] = PtcWgradCall{P(sv, PTC_BLK_O_CONV), n, g[PTC_BLK_S_DLIN], nullptr, n, 1, c, c, dt, M<float>(g, PTC_BLK_G_W_LIN), M<float>(g, PTC_BLK_G_B_LIN), wgws(4), W.wg[4]};
   RUN(ptc_spconv_fwd(g[PTC_BLK_S_DLIN], n, P(in, PTC_BLK_P_WT_LIN), nullptr, nullptr, n, 1, c, c, dt, g[PTC_BLK_S_DCONV], s));
   // 1'. the convolution: weight gradient, bias gradient, input gradient over the same table with mirrored weights
-  RUN(ptc_spconv_wgrad_deferred(P(in, PTC_BLK_P_XC), n, g[PTC_BLK_S_DCONV], nbr, n, 27, c, c, dt, M<float>(g, PTC_BLK_G_W_CONV), nullptr, wgws(5), W.wg[5], s, &jobs[5]));
+  RUN(ptc_spconv_wgrad_blk_deferred(P(in, PTC_BLK_P_XC), n, g[PTC_BLK_S_DCONV], nbr, P(in, PTC_BLK_P_BLK_TAB), (const int32_t*)P(in, PTC_BLK_P_BLK_HID),
+                                    (const int32_t*)P(in, PTC_BLK_P_BLK_HCNT), (const int32_t*)P(in, PTC_BLK_P_BLK_NOVF), (int)iv[PTC_BLK_I_BLK_BM],
+                                    (int)iv[PTC_BLK_I_BLK_HCAP], n, 27, c, c, dt, M<float>(g, PTC_BLK_G_W_CONV), wgws(5), W.wg[5], s, &jobs[5]));
   RUN(ptc_column_sum(g[PTC_BLK_S_DCONV], n, c, dt, M<float>(g, PTC_BLK_G_B_CONV), ws, wb, s));
   RUN(ptc_spconv_fwd_blk(g[PTC_BLK_S_DCONV], n, P(in, PTC_BLK_P_WT_CONV), nullptr, nbr, P(in, PTC_BLK_P_BLK_TAB), (const int32_t*)P(in, PTC_BLK_P_BLK_HID),
                          (const int32_t*)P(in, PTC_BLK_P_BLK_HCNT), (int)iv[PTC_BLK_I_BLK_BM], (int)iv[PTC_BLK_I_BLK_HCAP], n, 27, c, c, dt, g[PTC_BLK_G_XC], s));

@@ -19,7 +19,10 @@
 //                                              (rows 32 t .. 32 t + 31 of the block) has at least one neighbour at tap k, then
 //                                              their OR; the kernel skips the MFMAs of empty (tile | block, tap) pairs -- 46 % of
 //                                              the (32-row tile, tap) pairs and 33 % of the (block, tap) pairs on curve-ordered
-//                                              indoor scenes (tools/halo_stats.py).  The rest of row 27 holds "no neighbour"
+//                                              indoor scenes (tools/halo_stats.py).  Bytes 20..51 (round 4): eight more uint32, bit k
+//                                              of word s set when one of the 16 rows {32 t + 4 s + q : t, q = 0..3} -- an MFMA step
+//                                              of the weight-gradient kernel, wgrad7.h -- has a neighbour at tap k.  The rest of
+//                                              row 27 holds "no neighbour"
 // One workgroup per block: LDS hash set -> compaction -> bitonic sort -> binary search per entry.  Integer work, bit-exact by
 // construction: hid[b][tab[0][b][k][r][t] >> 7] == nbr[k][128 b + 32 t + r] wherever nbr >= 0 (tests/test_gpu_kernels.py).
 #include "ptc_common.h"
@@ -38,7 +41,7 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int64_t n_blo
   __shared__ int list[BLK_LIST];
   __shared__ __attribute__((aligned(16))) uint16_t ltab[2][BLK_TAB_U16];
   __shared__ int cnt, cnt2, ovf;
-  __shared__ unsigned tmask[4];
+  __shared__ unsigned tmask[4], smask[8];
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x;
   const int64_t r0 = b * BLK_BM;
@@ -51,6 +54,7 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int64_t n_blo
   }
   if (tid == 0) { cnt = 0; cnt2 = 0; ovf = 0; }
   if (tid < 4) tmask[tid] = 0u;
+  if (tid < 8) smask[tid] = 0u;
   __syncthreads();
   // the block's 27 x 128 table entries, 14 per thread, fetched ONCE with every load in flight together (the kernel is latency-bound:
   // the first version walked them one dependent load at a time, twice -- 140 us per rulebook at N = 819200, r03_c_conv_pmc_s0.json)
@@ -126,12 +130,15 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int64_t n_blo
     ltab[0][at] = (uint16_t)(lo * 128 + ((lo >> 1) & 7) * 16);
     ltab[1][at] = (uint16_t)(lo * 64 + ((lo >> 2) & 3) * 16);
     atomicOr(&tmask[r >> 5], 1u << k);
+    atomicOr(&smask[(r & 31) >> 2], 1u << k);
   }
   __syncthreads();
   if (tid < 2) {                       // the tap masks, in the padding row of both variants
     uint32_t* mw = reinterpret_cast<uint32_t*>(&ltab[tid][27 * 128]);
     mw[0] = tmask[0]; mw[1] = tmask[1]; mw[2] = tmask[2]; mw[3] = tmask[3];
     mw[4] = tmask[0] | tmask[1] | tmask[2] | tmask[3];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mw[5 + q] = smask[q];     // per MFMA step of the weight-gradient kernel (wgrad7.h)
   }
   __syncthreads();
   for (int v = 0; v < 2; ++v) {

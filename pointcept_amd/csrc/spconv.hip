@@ -217,6 +217,7 @@ static int dispatch_fwd(const void* in, const void* w, const float* bias, const 
 #include "conv3.h"
 #include "conv5.h"
 #include "conv7.h"
+#include "wgrad7.h"
 
 extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr,
                               int64_t n_out, int kv, int c_in, int c_out, int dtype, void* out, ptc_stream_t stream) {
@@ -506,7 +507,9 @@ wgrad_reduce_multi_kernel(WgradReduceMulti m) {
   for (int q = 1; q < PTC_WGRAD_JOBS_MAX; ++q)
     if (q < m.n && (int)blockIdx.x >= m.start[q]) j = q;
   const PtcWgradJob& J = m.job[j];
-  wgrad_reduce_body(J.partial, J.splits, J.count, J.dw, m.nb1[j], J.bias_partial, J.c_out, J.dbias, (int)blockIdx.x - m.start[j]);
+  const bool alt = J.gate != nullptr && *J.gate != 0;      // (uniform) which producer ran: see PtcWgradJob
+  wgrad_reduce_body(alt ? J.alt_partial : J.partial, alt ? J.alt_splits : J.splits, J.count, J.dw, m.nb1[j], J.bias_partial, J.c_out, J.dbias,
+                    (int)blockIdx.x - m.start[j]);
 }
 
 int ptc_wgrad_reduce_jobs(const PtcWgradJob* jobs, int n, ptc_stream_t stream) {
@@ -560,6 +563,16 @@ extern "C" size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_
   return ptc_align_up(splits * (size_t)c_out * kv * c_in * sizeof(float), 256) + ptc_align_up(splits * (size_t)c_out * sizeof(float), 256);
 }
 
+// the block-staged weight gradient keeps its partials (one per persistent workgroup sequence, wgrad7.h) BEHIND the region above, which
+// stays wgrad2's: the two kernels of ptc_spconv_wgrad_blk are gated on a device-side word and must not share partials
+static size_t wgrad_blk_extra_bytes(int64_t n_out, int kv, int c_in, int c_out) {
+  if (kv != 27 || c_in != c_out || (c_in != 32 && c_in != 64) || n_out < 4096) return 0;
+  return ptc_align_up((size_t)wgrad7_splits(n_out, c_in) * (size_t)c_out * kv * c_in * sizeof(float), 256);
+}
+extern "C" size_t ptc_spconv_wgrad_blk_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out) {
+  return ptc_spconv_wgrad_workspace_bytes(n_out, kv, c_in, c_out) + wgrad_blk_extra_bytes(n_out, kv, c_in, c_out);
+}
+
 template <typename T>
 static int launch_wgrad(const void* in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in,
                         int c_out, float* dw, float* dbias, void* ws, hipStream_t s) {
@@ -584,30 +597,31 @@ static int launch_wgrad(const void* in, const void* dout, const int32_t* nbr, in
 // ---- v2 (16-bit features): wave-private staging + transposing LDS reads, see wgrad2.h -----------
 template <typename T, int COT, int CIT, int KG>
 static int launch_wgrad2_inst(const W2Plan& p, const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv,
-                              int c_in, int c_out, float* partial, float* bias_partial, hipStream_t s) {
+                              int c_in, int c_out, float* partial, float* bias_partial, hipStream_t s, const int32_t* gate = nullptr) {
   auto kern = wgrad2_kernel<T, COT, CIT, KG>;
   if (p.lds > 48 * 1024)
     PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
   const int nblocks = p.co_blocks * p.ci_blocks, total = p.gx * p.groups * nblocks;
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(256), p.lds, s, (const T*)in, (const T*)dout, nbr, n_out, kv,
                      c_in, c_out, ptc_cdiv(n_out, W2_ROWS), p.ci_blocks, partial, bias_partial, p.gx, p.groups, nblocks,
-                     (uint32_t)((uint64_t)n_in * c_in * sizeof(T)), (uint32_t)((uint64_t)n_out * c_out * sizeof(T)));
+                     (uint32_t)((uint64_t)n_in * c_in * sizeof(T)), (uint32_t)((uint64_t)n_out * c_out * sizeof(T)), gate);
   PTC_CHECK_LAUNCH("wgrad2_kernel");
   return PTC_OK;
 }
 
 template <typename T>
 static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
-                         float* dw, float* dbias, void* ws, hipStream_t s, PtcWgradJob* defer = nullptr) {
+                         float* dw, float* dbias, void* ws, hipStream_t s, PtcWgradJob* defer = nullptr, const int32_t* gate = nullptr) {
   const W2Plan p = w2_plan(n_out, kv, c_in, c_out, dbias != nullptr);
   const int64_t count = (int64_t)c_out * kv * c_in;
-  float* partial = p.gx > 1 ? (float*)ws : dw;
+  // gated (ptc_spconv_wgrad_blk): the partials always go to the workspace -- dw belongs to whichever producer the reduction picks
+  float* partial = (p.gx > 1 || gate) ? (float*)ws : dw;
   float* bias_partial = nullptr;
   if (dbias) bias_partial = p.gx > 1 ? (float*)((char*)ws + ptc_align_up((size_t)p.gx * (size_t)count * sizeof(float), 256)) : dbias;
   int rc = PTC_EUNSUPPORTED;
 #define W2_CASE(COT, CIT, KG)                                                                                         \
   if (p.cot == COT && p.cit == CIT && p.kg == KG)                                                                     \
-    rc = launch_wgrad2_inst<T, COT, CIT, KG>(p, in, n_in, dout, nbr, n_out, kv, c_in, c_out, partial, bias_partial, s);
+    rc = launch_wgrad2_inst<T, COT, CIT, KG>(p, in, n_in, dout, nbr, n_out, kv, c_in, c_out, partial, bias_partial, s, gate);
   W2_CASE(2, 1, 1) W2_CASE(2, 2, 1) W2_CASE(2, 4, 1) W2_CASE(4, 1, 1) W2_CASE(4, 2, 1) W2_CASE(4, 4, 1)
   W2_CASE(6, 1, 1) W2_CASE(6, 2, 1) W2_CASE(6, 4, 1) W2_CASE(8, 1, 1) W2_CASE(8, 2, 1)   // (8, 4, 1): never planned (w2_plan caps 64-wide input tiles at 64 outputs), spilled
   W2_CASE(2, 1, 16) W2_CASE(2, 2, 4) W2_CASE(4, 2, 4) W2_CASE(2, 4, 4) W2_CASE(4, 4, 2) W2_CASE(6, 2, 2)
@@ -617,7 +631,7 @@ static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const i
     return rc;
   }
   if (defer) {   // the caller batches the reduction (ptc_wgrad_reduce_jobs)
-    *defer = PtcWgradJob{partial, p.gx > 1 ? p.gx : 0, count, dw, bias_partial, (int64_t)c_out, dbias};
+    *defer = PtcWgradJob{partial, (p.gx > 1 || gate) ? p.gx : 0, count, dw, bias_partial, (int64_t)c_out, dbias};
     return PTC_OK;
   }
   if (p.gx > 1) return launch_wgrad_reduce(partial, p.gx, count, dw, bias_partial, c_out, dbias, s);
@@ -702,6 +716,44 @@ int ptc_spconv_wgrad_deferred(const void* in, int64_t n_in, const void* dout, co
   PTC_REQUIRE(job != nullptr, PTC_EINVAL, "ptc_spconv_wgrad_deferred: null job");
   *job = PtcWgradJob{nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
   return spconv_wgrad_impl(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dtype, dw, dbias, workspace, workspace_bytes, stream, job);
+}
+
+// ---- block-staged weight gradient (wgrad7.h): 3^3 submanifold table, c_in = c_out = 32 | 64, 16-bit features, block tables of blocks.hip ----
+// Two producers, gated on the table builder's device-side overflow counter (no host synchronisation): wgrad7 when every block's halo fits,
+// wgrad2 over the whole tensor when one did not; the reduction sums the partials of whichever ran.  Shapes outside wgrad7's range take
+// ptc_spconv_wgrad unchanged.
+int ptc_spconv_wgrad_blk_deferred(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, const void* tab, const int32_t* hid,
+                                  const int32_t* hcnt, const int32_t* n_overflow, int bm, int hcap, int64_t n_out, int kv, int c_in, int c_out,
+                                  int dtype, float* dw, void* workspace, size_t workspace_bytes, ptc_stream_t stream, PtcWgradJob* job) {
+  PTC_REQUIRE(job != nullptr, PTC_EINVAL, "ptc_spconv_wgrad_blk: null job");
+  *job = PtcWgradJob{nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
+  const bool buf_ok = (uint64_t)n_in * c_in * 2 <= PTC_BUF_MAX_BYTES && (uint64_t)n_out * c_out * 2 <= PTC_BUF_MAX_BYTES;
+  if (!buf_ok || !tab || !hid || !hcnt || !n_overflow || !nbr || n_in != n_out || !wgrad7_supported(dtype, kv, c_in, c_out, bm, hcap, n_out))
+    return spconv_wgrad_impl(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dtype, dw, nullptr, workspace, workspace_bytes, stream, job);
+  PTC_REQUIRE(in && dout && dw && workspace, PTC_EINVAL, "ptc_spconv_wgrad_blk: null buffer");
+  PTC_REQUIRE(workspace_bytes >= ptc_spconv_wgrad_blk_workspace_bytes(n_out, kv, c_in, c_out), PTC_EWORKSPACE, "ptc_spconv_wgrad_blk: workspace too small");
+  PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)tab % 16 == 0), PTC_EINVAL,
+              "ptc_spconv_wgrad_blk: buffers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  float* p7 = (float*)((char*)workspace + ptc_spconv_wgrad_workspace_bytes(n_out, kv, c_in, c_out));
+  int rc = ptc_wgrad7_launch(dtype, in, dout, (const uint16_t*)tab, hid, hcnt, n_overflow, n_out, c_in, p7, s);
+  if (rc != PTC_OK) return rc;
+  PtcWgradJob j2;
+  rc = dtype == PTC_BF16 ? launch_wgrad2<bf16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, nullptr, workspace, s, &j2, n_overflow)
+                         : launch_wgrad2<f16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, nullptr, workspace, s, &j2, n_overflow);
+  if (rc != PTC_OK) return rc;
+  *job = PtcWgradJob{p7, wgrad7_splits(n_out, c_in), (int64_t)c_out * kv * c_in, dw, nullptr, (int64_t)c_out, nullptr, n_overflow, j2.partial, j2.splits};
+  return PTC_OK;
+}
+
+extern "C" int ptc_spconv_wgrad_blk(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, const void* tab, const int32_t* hid,
+                                    const int32_t* hcnt, const int32_t* n_overflow, int bm, int hcap, int64_t n_out, int kv, int c_in, int c_out,
+                                    int dtype, float* dw, void* workspace, size_t workspace_bytes, ptc_stream_t stream) {
+  PtcWgradJob job;
+  const int rc = ptc_spconv_wgrad_blk_deferred(in, n_in, dout, nbr, tab, hid, hcnt, n_overflow, bm, hcap, n_out, kv, c_in, c_out, dtype, dw, workspace,
+                                               workspace_bytes, stream, &job);
+  if (rc != PTC_OK) return rc;
+  return ptc_wgrad_reduce_jobs(&job, 1, stream);
 }
 
 static int spconv_wgrad_impl(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,

@@ -13,6 +13,10 @@ struct PtcWgradJob {
   const float* bias_partial;
   int64_t c_out;
   float* dbias;
+  // device-side choice between two producers (ptc_spconv_wgrad_blk): *gate != 0 -> sum alt_partial[0 .. alt_splits) instead
+  const int32_t* gate = nullptr;
+  const float* alt_partial = nullptr;
+  int alt_splits = 0;
 };
 
 // ptc_spconv_wgrad with the reduction left to the caller: same arguments, same partials, same workspace layout; `job` describes the
@@ -20,6 +24,10 @@ struct PtcWgradJob {
 int ptc_spconv_wgrad_deferred(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
                               int dtype, float* dw, float* dbias, void* workspace, size_t workspace_bytes, ptc_stream_t stream,
                               PtcWgradJob* job);
+// ptc_spconv_wgrad_blk (block-staged weight gradient of a 3^3 submanifold convolution, wgrad7.h) with the reduction left to the caller
+int ptc_spconv_wgrad_blk_deferred(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, const void* tab, const int32_t* hid,
+                                  const int32_t* hcnt, const int32_t* n_overflow, int bm, int hcap, int64_t n_out, int kv, int c_in, int c_out,
+                                  int dtype, float* dw, void* workspace, size_t workspace_bytes, ptc_stream_t stream, PtcWgradJob* job);
 // Several weight gradients enqueued together: those that share the (4, 4, 1) kernel instance of wgrad2 (the Linear layers of a Block from
 // 64 channels up) run as ONE launch, the others as their own; every reduction is left to the caller (jobs[i] for calls[i]).
 struct PtcWgradCall {

@@ -23,6 +23,9 @@
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
 #define W2_ROWS 32  // rows per wave step
+#ifndef W2_SKIP_EMPTY
+#define W2_SKIP_EMPTY 1   // 0: timing A/B only (`python -m pointcept_amd.build --variant d_W2_SKIP_EMPTY_0`)
+#endif
 // Byte stride between the 16-channel planes of an image.  32 rows x 32 B = 1024 B would put every plane on the SAME
 // banks (1024 = 4 x 256 B): the eight lanes that store one row (pieces 0..7 = planes 0..3) then collide 4-way on every
 // ds_write_b128 -- rocprofv3 PMC at the dec0 shape: SQ_LDS_BANK_CONFLICT = 100.8 M cycles, 44 % of the kernel's
@@ -68,7 +71,11 @@ template <typename T, int COT, int CIT, int KG>
 __global__ void __launch_bounds__(256, 2)   // two waves per SIMD: <= 256 registers
 wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_t* __restrict__ nbr, int64_t n_out, int kv,
               int c_in, int c_out, int64_t steps_total, int ci_blocks, float* __restrict__ partial,
-              float* __restrict__ bias_partial, int gx, int groups, int nblocks, uint32_t in_bytes, uint32_t dout_bytes) {
+              float* __restrict__ bias_partial, int gx, int groups, int nblocks, uint32_t in_bytes, uint32_t dout_bytes,
+              const int32_t* __restrict__ gate) {
+  // ptc_spconv_wgrad_blk: this kernel serves the call only when some 128-row block overflowed the block-staged kernel's halo capacity
+  // (the device-side counter of blocks.hip is nonzero); otherwise wgrad7 did, and every workgroup returns at once
+  if (gate != nullptr && *gate == 0) return;
 #define W2_VB_LOW ((int)(blockIdx.x & 7))
 #define W2_VB_HIGH ((int)(blockIdx.x >> 3))
 #include "wgrad2_body.inc"

@@ -49,7 +49,10 @@ static inline bool wgrad7_supported(int dtype, int kv, int c_in, int c_out, int 
 #define W7_MAX_WGS 256                       // one persistent workgroup per CU
 // workgroups walking DISTINCT block sequences = fp32 partials per call (C = 64: two workgroups -- the output-channel halves -- per sequence)
 static inline int wgrad7_splits(int64_t n_out, int c) {
-  const int64_t nb = ptc_cdiv(n_out, C7_BM), cap = c == 64 ? W7_MAX_WGS / 2 : W7_MAX_WGS;
+  int64_t nb = ptc_cdiv(n_out, C7_BM), cap = c == 64 ? W7_MAX_WGS / 2 : W7_MAX_WGS;
+#ifndef __HIPCC__
+  if (const char* e = getenv("PTC_EMU_CONV7_WGS")) cap = atoi(e);   // host emulation only: several blocks per workgroup at test sizes
+#endif
   return (int)(nb < cap ? nb : cap);
 }
 
@@ -301,10 +304,7 @@ template <typename T, int C>
 static int launch_wgrad7_i(const void* in, const void* dout, const uint16_t* tab, const int32_t* hid, const int32_t* hcnt, const int32_t* gate,
                            int64_t n_out, float* partial, hipStream_t s) {
   const int n_blocks = (int)ptc_cdiv(n_out, C7_BM);
-  int seqs = wgrad7_splits(n_out, C);
-#ifndef __HIPCC__
-  if (const char* e = getenv("PTC_EMU_CONV7_WGS")) seqs = atoi(e) < seqs ? atoi(e) : seqs;   // host emulation only: several blocks per workgroup at test sizes
-#endif
+  const int seqs = wgrad7_splits(n_out, C);
   const int grid = C == 64 ? 2 * seqs : seqs;
   auto kern = wgrad7_kernel<T, C>;
   PTC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W7Geom<C>::LDS));

@@ -387,7 +387,9 @@ class _SparseConv(Function):
         g = _pad_to(grad.to(f.dtype), 1, 16).contiguous()
         dfeat = dw = dbias = None
         if ctx.needs_input_grad[1]:
-            dw = ops.spconv_wgrad(f, g, nbr)[:c_out, :, :c_in].to(ctx.w_dtype)
+            # submanifold 3^3, 32 | 64 channels: the block-staged weight gradient over the tables the forward built (csrc/wgrad7.h)
+            blkw = None if (ctx.blocks is None or not config.WGRAD_BLK) else ctx.blocks.get(f.shape[1], g.shape[1], f.dtype)
+            dw = ops.spconv_wgrad(f, g, nbr, blk=blkw)[:c_out, :, :c_in].to(ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = ops.column_sum(grad)
         if ctx.needs_input_grad[0]:
@@ -832,6 +834,8 @@ def _blk_tables(E, x0, meta):
     pin[E["P_T_PROJ_FWD"]], pin[E["P_T_PROJ_BWD"]] = tabs[2].data_ptr(), tabs[3].data_ptr()
     if blk is not None:
         pin[E["P_BLK_TAB"]], pin[E["P_BLK_HID"]], pin[E["P_BLK_HCNT"]] = blk.tab.data_ptr(), blk.hid.data_ptr(), blk.hcnt.data_ptr()
+        if config.WGRAD_BLK:      # (NULL: the executor's convolution weight gradient stays on the global-gather kernel)
+            pin[E["P_BLK_NOVF"]] = blk.n_overflow.data_ptr()
     return iv, fv, pin
 
 

@@ -459,9 +459,12 @@ def spconv_fwd(feat: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     return out
 
 
-def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: Optional[torch.Tensor], want_bias: bool = False):
+def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: Optional[torch.Tensor], want_bias: bool = False,
+                 blk: Optional["BlockTables"] = None):
     """dw [C_out, kv, C_in] fp32 = sum_o dout[o]^T (x) feat[nbr[k][o]]  (nbr=None: identity, kv=1);
-    with want_bias also dbias [C_out] fp32 = column sums of dout (fused).  Returns dw or (dw, dbias)."""
+    with want_bias also dbias [C_out] fp32 = column sums of dout (fused).  Returns dw or (dw, dbias).  blk = BlockTables of `nbr`
+    (and no bias gradient): the block-staged, accumulator-stationary kernel (csrc/wgrad7.h; same result up to the fp32 rounding of
+    its summation order)."""
     require_cuda(feat, dout, nbr)
     feat = feat.contiguous()
     dout = dout.contiguous()
@@ -474,6 +477,15 @@ def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: Optional[torch.Ten
         kv, n_out = 1, dout.shape[0]
     c_in, c_out = feat.shape[1], dout.shape[1]
     dw = torch.empty((c_out, kv, c_in), dtype=torch.float32, device=feat.device)
+    if blk is not None and nbr is not None and not want_bias:
+        if blk.nbr.data_ptr() != nbr.data_ptr() or tuple(blk.nbr.shape) != tuple(nbr.shape):
+            raise PtcoreError("blk was built from another gather table")
+        nbytes = lib().ptc_spconv_wgrad_blk_workspace_bytes(n_out, kv, c_in, c_out)
+        ws = _ws(nbytes, feat.device)
+        check(lib().ptc_spconv_wgrad_blk(ptr(feat), feat.shape[0], ptr(dout), ptr(nbr), ptr(blk.tab), ptr(blk.hid), ptr(blk.hcnt),
+                                         ptr(blk.n_overflow), blk.bm, blk.hcap, n_out, kv, c_in, c_out, dtype_code(feat), ptr(dw), ptr(ws),
+                                         nbytes, stream_ptr()), "ptc_spconv_wgrad_blk")
+        return dw
     db = torch.empty(c_out, dtype=torch.float32, device=feat.device) if want_bias else None
     nbytes = lib().ptc_spconv_wgrad_workspace_bytes(n_out, kv, c_in, c_out)
     ws = _ws(nbytes, feat.device)

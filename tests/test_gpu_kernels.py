@@ -387,15 +387,18 @@ def test_rulebook_blocks(cuda, ordered):
             assert np.array_equal((le % rowb)[e >= 0], ((((slot >> sw_shift) & sw_mask) * 16))[e >= 0])     # piece 0 at its swizzled position
             assert np.array_equal(hid[b][np.where(le != none, slot, 0)][e >= 0], e[e >= 0])
             assert (full[:, rows:] == none).all()
-            # table row 27: the tap masks (bit k of word t: tile t has a neighbour at tap k; word 4: their OR), then "none" padding
+            # table row 27: the tap masks (bit k of word t: tile t has a neighbour at tap k; word 4: their OR; words 5..12: bit k of
+            # word 5 + s set when one of the rows {32 t + 4 s + q} -- an MFMA step of wgrad7 -- has one), then "none" padding
             pad = tab[v, b, 27].reshape(-1)
-            words = pad[:10].astype(np.uint32)
+            words = pad[:26].astype(np.uint32)
             masks = words[0::2] | (words[1::2] << 16)
             occ = np.zeros((27, 128), bool)
             occ[:, :rows] = e >= 0
             want_masks = [sum(1 << k for k in range(27) if occ[k, 32 * t:32 * t + 32].any()) for t in range(4)]
             assert masks[:4].tolist() == want_masks and int(masks[4]) == (want_masks[0] | want_masks[1] | want_masks[2] | want_masks[3])
-            assert (pad[10:] == none).all()
+            step_rows = [[32 * t + 4 * s_ + q for t in range(4) for q in range(4)] for s_ in range(8)]
+            assert masks[5:13].tolist() == [sum(1 << k for k in range(27) if occ[k, step_rows[s_]].any()) for s_ in range(8)]
+            assert (pad[26:] == none).all()
     assert int(bt.n_overflow.item()) == n_ovf
     if ordered:
         assert n_ovf == 0, "curve-ordered rows must fit their halo budget"
@@ -442,6 +445,44 @@ def test_spconv_fwd_block_staged(cuda, c, ordered, n_rows=35000):
         _close(f"conv7_nobias_{dtype}", nb, ref - bias, rtol, atol)
 
 
+@pytest.mark.parametrize("c", [32, 64])
+@pytest.mark.parametrize("ordered", [True, False])
+def test_spconv_wgrad_block_staged(cuda, c, ordered, n_rows=35000):
+    """wgrad7 (the whole weight gradient held in MFMA accumulators of persistent workgroups, both operands built from a block's LDS
+    images by transposing reads, empty (step, tap) pairs skipped, csrc/wgrad7.h): against the fp32 oracle (autograd of the gather
+    convolution) and within fp32 summation-order noise of the global-gather kernel wgrad2 on the same table.  The un-ordered case has
+    overflowing blocks: the device-side gate hands the call to wgrad2 (same result as the plain entry point, bit for bit).  Ragged row
+    count, several blocks per persistent workgroup, bf16 and f16, bit-reproducible."""
+    from pointcept_amd import ops
+
+    ind = _curve_sorted_indices(n_rows)      # (the host-emulation tier runs this body with 4500 rows)
+    if not ordered:
+        rng = np.random.default_rng(c)
+        h = ind.shape[0] // 2
+        ind = np.concatenate([ind[:h], ind[h:][rng.permutation(ind.shape[0] - h)]])
+    nbr = oops.subm_rulebook(ind, 3)
+    n = nbr.shape[1]
+    nbr_d = _t(nbr, cuda)
+    bt = ops.BlockTables(nbr_d)
+    assert (int(bt.n_overflow.item()) == 0) == ordered
+    g = torch.Generator().manual_seed(c * 77)
+    for dtype in (torch.bfloat16, torch.float16):
+        feat = (torch.randn(n, c, generator=g) * 0.5).to(dtype)
+        dout = (torch.randn(n, c, generator=g) * 0.5).to(dtype)
+        wr = torch.zeros(c, 27, c, requires_grad=True)
+        oops.gather_conv(feat.float(), wr, None, nbr).backward(dout.float())
+        base = ops.spconv_wgrad(feat.to(cuda), dout.to(cuda), nbr_d)
+        got = ops.spconv_wgrad(feat.to(cuda), dout.to(cuda), nbr_d, blk=bt)
+        assert got.shape == (c, 27, c) and torch.isfinite(got).all()
+        scale = float(wr.grad.abs().max())
+        _close(f"wgrad7_{dtype}", got, wr.grad, 1e-4, 1e-3 * scale)
+        if ordered:   # fp32 accumulation in another order: a few ulps of the partial sums
+            assert float((got - base).abs().max()) <= 2e-5 * scale * max(1.0, (n / 4096) ** 0.5)
+        else:         # the gate picked wgrad2: the same partials, the same reduction
+            assert torch.equal(got, base)
+        assert torch.equal(got, ops.spconv_wgrad(feat.to(cuda), dout.to(cuda), nbr_d, blk=bt)), "wgrad7 must be bit-reproducible"
+
+
 def test_spconv_block_staged_full_size(cuda):
     """BASELINE size: 8 x 102400 voxels in curve order, 64 -> 64 and 32 -> 32: conv7 within summation-order noise of the global-gather
     kernel, no block overflows; and -- size-independent property -- linearity: conv(x1 + x2) == conv(x1) + conv(x2) to the output rounding."""
@@ -471,6 +512,15 @@ def test_spconv_block_staged_full_size(cuda):
         lhs = ops.spconv_fwd(xs, w, None, nbr, blk).float()
         rhs = ops.spconv_fwd(x, w, None, nbr, blk).float() + ops.spconv_fwd(x2, w, None, nbr, blk).float()
         assert float((lhs - rhs).abs().max()) <= 2.0 ** -5 * float(rhs.abs().max())
+        # the block-staged weight gradient (wgrad7) against the global-gather one (wgrad2) on the same operands: fp32 sums of ~7.6 M
+        # products per tap in two different orders; and a size-independent property: for dout = 1 and x = 1 every entry of tap k
+        # equals the number of (row, neighbour) pairs of tap k
+        dw7, dw2 = ops.spconv_wgrad(x, x2, nbr, blk=blk), ops.spconv_wgrad(x, x2, nbr)
+        assert float((dw7 - dw2).abs().max()) <= 1e-3 * float(dw2.abs().max())
+        ones = torch.ones(n, c, dtype=torch.bfloat16, device=cuda)
+        cnt = ops.spconv_wgrad(ones, ones, nbr, blk=blk)
+        pairs = (nbr >= 0).sum(1).float()
+        assert torch.equal(cnt, pairs[None, :, None].expand(c, 27, c))
 
 
 @pytest.mark.parametrize("c,width", [(36, 48), (72, 80), (64, 64)])

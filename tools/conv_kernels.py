@@ -81,6 +81,7 @@ def main():
             ops.spconv_fwd(x, w, bias, nbr)            # conv5: global gathers
             ops.spconv_fwd(x, w, bias, nbr, blk)       # conv7: register weights + DMA-staged halo
             ops.spconv_wgrad(x, go, nbr)
+            ops.spconv_wgrad(x, go, nbr, blk=blk)      # wgrad7: accumulator-stationary, operands from the staged block images
         if s == 0:
             # the gather-fused qkv GEMM: kv = 1 table = a permutation (serialization order)
             perm = torch.randperm(n, generator=g).int().to(DEV)[None].contiguous()
