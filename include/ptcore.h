@@ -241,7 +241,7 @@ int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float
  *       tab  [2][n_blocks][28][32][4] uint16 (ptc_rulebook_blocks_tab_bytes(n) bytes, 16-byte aligned): at [v][b][k][r][t]
  *                                     the byte offset, inside the convolution kernel's LDS image of the block's rows, of the
  *                                     first 16 bytes of row nbr[k][128 b + 32 t + r] -- v = 0: 128-byte rows (64 channels),
- *                                     slot * 128 + ((slot >> 1) & 7) * 16; v = 1: 64-byte rows (32 channels), slot * 64 +
+ *                                     slot * 128 + ((((slot >> 1) & 1) << 2) | ((slot >> 2) & 3)) * 16; v = 1: 64-byte rows (32 channels), slot * 64 +
  *                                     ((slot >> 2) & 3) * 16, slot = position in the block's list; none = hcap * row bytes;
  *                                     row k = 27: the tap masks in its first 52 bytes -- four uint32, bit k of word t set when
  *                                     tile t (rows 32 t .. 32 t + 31) has a neighbour at tap k, then their OR, then eight

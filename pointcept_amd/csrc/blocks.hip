@@ -11,7 +11,7 @@
 //                                              block through the global table
 //   tab  [2][n_blocks][28][32][4]      u16   : at [v][b][k][r][t] (r = row in its 32-row tile t) the LDS BYTE OFFSET, inside the kernel's image of the block's
 //                                              rows, of piece 0 of row nbr[k][128 b + 32 t + r]: v = 0 for 128-byte rows (64
-//                                              channels): slot * 128 + ((slot >> 1) & 7) * 16, v = 1 for 64-byte rows (32
+//                                              channels): slot * 128 + PTC_SWZ64(slot) * 16 (ptc_common.h), v = 1 for 64-byte rows (32
 //                                              channels): slot * 64 + ((slot >> 2) & 3) * 16 -- the kernel XORs the piece it
 //                                              wants into bits 4.. and adds the image base; "no neighbour" = hcap * row bytes
 //                                              (an all-zero row).  Table row 27 (padding: a whole number of 1-KB DMA pieces) carries
@@ -127,7 +127,7 @@ rulebook_blocks_kernel(const int32_t* __restrict__ nbr, int64_t n, int64_t n_blo
       if (list[mid] < g) lo = mid + 1; else hi = mid;
     }
     const int at = (k * 32 + (r & 31)) * 4 + (r >> 5);         // [tap][row in 32-row tile][tile]; `lo` = the slot, present by construction
-    ltab[0][at] = (uint16_t)(lo * 128 + ((lo >> 1) & 7) * 16);
+    ltab[0][at] = (uint16_t)(lo * 128 + PTC_SWZ64(lo) * 16);
     ltab[1][at] = (uint16_t)(lo * 64 + ((lo >> 2) & 3) * 16);
     atomicOr(&tmask[r >> 5], 1u << k);
     atomicOr(&smask[(r & 31) >> 2], 1u << k);

@@ -42,6 +42,10 @@
 #ifndef C7_ABLATE
 #define C7_ABLATE 0
 #endif
+#ifndef C7_DMA_SADDR
+#define C7_DMA_SADDR 0                      // 1: DMA source = SGPR base + 32-bit lane offset (wgrad7's form) instead of 64-bit lane pointers: measured
+                                            // SLOWER here, 148.0 vs 141.4 us at 64 -> 64 (profiles/r04_c_conv7_time.txt)
+#endif
 #ifndef C7_LAG
 #define C7_LAG 2                            // MFMAs between a fragment's use and its reload (C = 64; 3 and 4 measured: see conv7_time)
 #endif
@@ -76,6 +80,14 @@ __device__ __forceinline__ void c7_dma16(const void* g, uint32_t lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
 }
+// the same in the SGPR-base + 32-bit-VGPR-offset form (round 4): a piece costs one 32-bit multiply-add of address arithmetic instead of
+// a 64-bit add chain, and nothing per-lane and 64 bits wide is loop-invariant (with the 64-bit form the compiler hoists one lane
+// pointer per piece out of the block loop -- 26 registers, spilled in wgrad7's first builds).  Tensors < 2 GiB (the host checks).
+__device__ __forceinline__ void c7_dma16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ uint32_t c7_lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
@@ -84,6 +96,9 @@ __device__ __forceinline__ uint32_t c7_lds_addr(const void* p) {
 #define C7_PIN_AGPR(x) asm volatile("" : "+a"(x))
 #else
 __device__ __forceinline__ void c7_dma16(const void* g, uint32_t lds_dst) { emu_global_load_lds(g, smem + lds_dst, 16); }
+__device__ __forceinline__ void c7_dma16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  emu_global_load_lds(reinterpret_cast<const unsigned char*>(sbase) + voff, smem + lds_dst, 16);
+}
 __device__ __forceinline__ uint32_t c7_lds_addr(const void* p) { return (uint32_t)((const unsigned char*)p - smem); }
 #define C7_PIN_AGPR(x) ((void)0)
 #endif
@@ -115,7 +130,7 @@ template <int C> struct C7Geom {
   static constexpr int NI = (C7_HCAP + RPI - 1) / RPI;        // DMA instructions of a full halo
   static constexpr int NIW = (NI + 3) / 4;                    // ... per wave
   // swizzle: piece p of the row in slot s sits at position p ^ swz(s); 16 consecutive slots x one piece index = 16 distinct bank quads
-  static __device__ __forceinline__ int swz(int slot) { return C == 64 ? ((slot >> 1) & 7) : ((slot >> 2) & 3); }
+  static __device__ __forceinline__ int swz(int slot) { return C == 64 ? PTC_SWZ64(slot) : ((slot >> 2) & 3); }
 };
 
 typedef __attribute__((ext_vector_type(16))) float c7_f32x16;
@@ -195,7 +210,8 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       if (i * RPI < cnt) {                                   // wave-uniform
         const int slot = i * RPI + drow;
         const int piece = dpos ^ G::swz(slot);
-        c7_dma16(reinterpret_cast<const unsigned char*>(in) + (int64_t)ids[q] * ROWB + piece * 16, base + (uint32_t)(i * 1024));
+        if constexpr (C7_DMA_SADDR) c7_dma16s(in, (uint32_t)ids[q] * (uint32_t)ROWB + (uint32_t)(piece * 16), base + (uint32_t)(i * 1024));
+        else c7_dma16(reinterpret_cast<const unsigned char*>(in) + (int64_t)ids[q] * ROWB + piece * 16, base + (uint32_t)(i * 1024));
       }
     }
     if (cnt > 0) {
@@ -203,7 +219,10 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int i = 4 * q + wave;
-        if (i < C7_TABB / 1024) c7_dma16(tsrc + i * 1024 + lane * 16, base + (uint32_t)(G::ROWS_BYTES + i * 1024));
+        if (i < C7_TABB / 1024) {
+          if constexpr (C7_DMA_SADDR) c7_dma16s(tsrc, (uint32_t)(i * 1024 + lane * 16), base + (uint32_t)(G::ROWS_BYTES + i * 1024));
+          else c7_dma16(tsrc + i * 1024 + lane * 16, base + (uint32_t)(G::ROWS_BYTES + i * 1024));
+        }
       }
     }
   };

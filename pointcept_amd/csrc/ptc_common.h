@@ -76,6 +76,14 @@ template <> __device__ __forceinline__ f16_t ptc_from_float<f16_t>(float v) { f1
 
 static inline size_t ptc_dtype_size(int dtype) { return dtype == PTC_F32 ? 4 : 2; }
 
+// XOR swizzle of the 16-byte pieces of a 128-byte row in the block-staged LDS images (blocks.hip writes it into the table entries,
+// conv7.h / wgrad7.h apply it on the source side of their DMA): piece p of the row in slot s sits at position p ^ PTC_SWZ64(s).
+// Bits 0-1 = bits 2-3 of the slot, bit 2 = bit 1 of the slot -- a bijection of (s >> 1) & 7, so 16 consecutive slots x one piece index
+// still cover the 16 bank quads once (conv7's ds_read_b128 gathers), AND the 64-byte half of four consecutive slots covers the four
+// 64-byte bank quarters once (wgrad7's ds_read_b64_tr_b16 gathers: a 32-lane pass reads 4 rows x 64 bytes; with the round-3 swizzle
+// (s >> 1) & 7 slots s and s + 2 met in one quarter: 2-way conflicts on every gather of the weight-gradient kernel, r04_b).
+#define PTC_SWZ64(s) (((((s) >> 1) & 1) << 2) | (((s) >> 2) & 3))
+
 // ---- wave helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ int ptc_lane() { return threadIdx.x & 63; }
 

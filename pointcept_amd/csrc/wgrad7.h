@@ -10,28 +10,34 @@
 // through the vector-memory path per 128 output rows where the block's operands are 43 KB (profiles/r03_p_conv_pmc_s0.json: TA_BUSY
 // 62 %, HBM traffic 1.47 x algorithmic, matrix pipe 22 %).  Here:
 //   * a workgroup is PERSISTENT over a strided share of the blocks (the same XCD-aware order as conv7) and keeps its part of the
-//     gradient dw[C][27][C] in the ACCUMULATION registers of its four waves as 32x32 fp32 MFMA tiles.  C = 64: a workgroup owns ONE
-//     output-channel half ch (two workgroups of one XCD, dispatched back to back, walk the same blocks: the second finds the halo in
-//     the L2), wave (kh, tp) the input-channel half kh of the taps k = tp (mod 2): 14 x 16 = 224 of the 256 AGPRs, which leaves every
-//     architectural VGPR to the pipeline.  (All 27 taps x one 32x32 quadrant per wave = 432 accumulator registers was the first version:
-//     16 of the 27 tiles fit the AGPR file, the compiler shuttles the other 11 through it around every MFMA -- 944 v_accvgpr_write -- and
-//     spills 125 registers; `-amdgpu-mfma-vgpr-form` crashes its AGPR-rewrite pass at that pressure.)  C = 32: wave w owns the taps
-//     k = w (mod 4) (7 x 16 registers).  The gradient leaves the chip ONCE per workgroup (one fp32 partial per workgroup pair / per
-//     workgroup, summed by the deterministic reduction of spconv.hip);
+//     gradient dw[C][27][C] in the ACCUMULATION registers of its four waves as 32x32 fp32 MFMA tiles.  Wave w owns the taps
+//     k = w (mod 4) -- seven tap slots -- for all input channels; C = 64: a workgroup owns ONE output-channel half ch (two workgroups of
+//     one XCD, dispatched back to back, walk the same blocks: the second finds the halo in the L2): 7 x 2 tiles = 224 of the 256
+//     AGPRs, which leaves every architectural VGPR to the pipeline; C = 32: 7 tiles.  (All 27 taps x one 32x32 quadrant per wave = 432
+//     accumulator registers was the first build: 16 of the 27 tiles fit the AGPR file, the compiler shuttles the other 11 through it
+//     around every MFMA -- 944 v_accvgpr_write -- and spills 125 registers; `-amdgpu-mfma-vgpr-form` crashes its AGPR-rewrite pass at that
+//     pressure.)  The gradient leaves the chip ONCE per workgroup (one fp32 partial per workgroup pair / per workgroup, summed by the
+//     deterministic reduction of spconv.hip);
 //   * the contraction index of a 32x32x16 MFMA is a ROW, so both operands are needed channel-major.  They come out of the row-major
 //     LDS images through ds_read_b64_tr_b16, whose 16 lanes address FOUR ROWS INDEPENDENTLY (each lane supplies the address of 8 bytes
 //     of "its" row): for the gathered operand the four row addresses are table entries -- the 27-tap gather and the transposition are
 //     the same LDS instruction, nothing is materialised.  An MFMA step contracts the 16 rows {32 t + 4 s + q : t = 0..3, q = 0..3} of a
 //     block (4 rows of each of its four 32-row tiles): lane group hh = lane >> 5 takes tiles 2 hh and 2 hh + 1, whose table entries are
 //     ADJACENT uint16 in conv7's table layout [tap][row in tile][tile] -- one ds_read_b32 per (tap, step) and lane;
-//   * EMPTY (step, tap) PAIRS ARE SKIPPED by scalar branches on the per-step tap masks blocks.hip leaves in the table's padding row;
-//     inside an active pair "no neighbour" entries read the all-zero row;
-//   * step outer (a dynamic loop of 8), tap inner (static: the accumulator of a tap is a register NAME): consecutive MFMAs write
-//     different accumulators; table entries run 4 taps ahead of their MFMA, the gathered fragment 2 taps ahead, in static rings;
+//   * tap slot outer (static: the accumulators of a tap are register NAMES), the eight steps of the block inner.  An EMPTY TAP (33 % of
+//     the (block, tap) pairs on curve-ordered scenes, the block mask of blocks.hip) is one scalar branch; inside an active tap every
+//     gather is unconditional ("no neighbour" entries read the all-zero row) -- 8 KH MFMAs with two transposing reads and two vector-
+//     ALU instructions each, the compiler's wait counts exact.  (v1 -- profiles/r04_a_wgrad7_v1_time.txt: 287 us at 64 -> 64 -- skipped at
+//     (step, tap) granularity: one MFMA per pair behind ~10 scalar instructions of mask tests and branches, paid by the empty pairs
+//     too: 112 slots x ~58 cycles per block where the MFMAs of the active ones are 1800.  At one wave per SIMD an instruction of ANY
+//     kind is an issue slot of ~4 cycles; an MFMA hides seven.)  The A fragments of the eight steps are read once per block; table
+//     words run one tap ahead, gathered fragments three steps ahead in a ring of six, across tap boundaries when the next tap is
+//     active;
 //   * block b + 1 (halo rows, table, dout rows) is in flight through global_load_lds while block b is multiplied (conv7's scheme:
 //     asm DMA invisible to the compiler's wait-count pass, completion counted by hand).  The halo image keeps conv7's XOR swizzle (the
 //     table entries carry it), the dout image holds the workgroup's 32 output channels at 64 bytes per row: the four rows of a transposing
-//     read are 256 contiguous bytes = all 64 banks once.  Buffer 1 sits 64 KB after buffer 0: "image base + (entry ^ piece)" is then ONE xor (entries < 64 KB).
+//     read are 256 contiguous bytes = all 64 banks once.  Buffer 1 sits 64 KB after buffer 0: "image base + (entry ^ piece)" is then ONE
+//     xor (entries < 64 KB).
 // A block whose halo did not fit (hcnt < 0: rows in no spatial order) cannot be served here; the host entry point therefore GATES the
 // two kernels on the device-side overflow counter of the table builder: this kernel runs when it is zero, wgrad2 over the whole tensor
 // when it is not, each returning at once otherwise -- no host synchronisation, and the reduction reads the partials of whichever ran.
@@ -40,8 +46,10 @@
 #pragma once
 
 #define W7_BUF1 65536                        // LDS byte offset of buffer 1 (halo image + table); buffer 0 at 0
-#define W7_DT 8                              // table entries are read W7_DT slots ahead of their MFMA,
-#define W7_DG 4                              // gathered fragments W7_DG slots ahead (rings of W7_DT - W7_DG + 1 words / W7_DG + 2 fragments)
+#ifndef W7_DMA_INLINE
+#define W7_DMA_INLINE 1                      // the next block's DMA instructions inside the MFMA stream (0: in front of it; timing A/B)
+#endif
+#define W7_DMA_EVERY 2                       // ... one per this many (step, tap) pairs
 
 static inline bool wgrad7_supported(int dtype, int kv, int c_in, int c_out, int bm, int hcap, int64_t n_out) {
   return conv7_supported(dtype, kv, c_in, c_out, bm, hcap, n_out);
@@ -60,42 +68,6 @@ int ptc_wgrad7_launch(int dtype, const void* in, const void* dout, const uint16_
                       const int32_t* gate, int64_t n_out, int c, float* partial, hipStream_t s);
 
 #ifdef PTC_WGRAD7_IMPL
-// ---- the pipeline's LDS reads as inline assembly (absent from the compiler's wait-count bookkeeping) + hand-counted waits.  `addr` =
-//      LDS byte address (the dynamic LDS of this kernel starts at 0: checked at entry).  Host emulation: plain loads, no waits.
-#ifdef __HIPCC__
-template <int OFF> __device__ __forceinline__ uint32_t w7_lds_u32(uint32_t addr) {
-  uint32_t v;
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
-template <typename F> __device__ __forceinline__ void w7_tr_pair(F& f, uint32_t a0, uint32_t a1) {
-  typedef int w7_i32x2 __attribute__((ext_vector_type(2)));
-  w7_i32x2 lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
-  const ptc_i32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-  __builtin_memcpy(&f, &v, sizeof(f));
-}
-// wait until at most N LDS operations are outstanding; the operand ties the wait to the first use of the value it guards
-template <int N, typename F> __device__ __forceinline__ void w7_wait_frag(F& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
-template <int N> __device__ __forceinline__ void w7_wait_word(uint32_t& w) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w) : "n"(N)); }
-__device__ __forceinline__ void w7_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
-template <int OFF> __device__ __forceinline__ uint32_t w7_lds_u32(uint32_t addr) { return *reinterpret_cast<const uint32_t*>(smem + addr + OFF); }
-template <typename F> __device__ __forceinline__ void w7_tr_pair(F& f, uint32_t a0, uint32_t a1) { f = ld_tr_pair16<F>(smem + a0, smem + a1); }
-template <int N, typename F> __device__ __forceinline__ void w7_wait_frag(F&) {}
-template <int N> __device__ __forceinline__ void w7_wait_word(uint32_t&) {}
-__device__ __forceinline__ void w7_wait_all() {}
-#endif
-
-// table reads certainly issued by slots lo .. hi of the stream (slot j reads the word of pair j + DT while that pair exists; slots start at -DT)
-constexpr int w7_certain(int lo, int hi, int tot) {
-  int n = 0;
-  for (int j = lo; j <= hi; ++j)
-    if (j >= -W7_DT && j + W7_DT < tot) ++n;
-  return n;
-}
-
 template <int C> struct W7Geom {
   static constexpr int ROWB = C * 2, PCS = ROWB / 16, RPI = 64 / PCS;
   static constexpr int ROWS_BYTES = (C7_HCAP + 1) * ROWB;                       // + the zero row
@@ -105,10 +77,9 @@ template <int C> struct W7Geom {
   static constexpr int LDS = DOUT0 + 2 * DOUT_BYTES;
   static constexpr int NI = (C7_HCAP + RPI - 1) / RPI, NIW = (NI + 3) / 4;      // DMA instructions of a full halo / per wave
   static constexpr int NDW = DOUT_BYTES / 1024 / 4;                             // dout DMA instructions per wave
-  static constexpr int NA = C == 64 ? 14 : 7;                                   // accumulators (taps) per wave: taps TM a + (tp | wave)
-  static constexpr int TM = C == 64 ? 2 : 4;
-  static constexpr int TSTRIDE = TM * 256;                                      // table bytes between two taps of a wave
-  static __device__ __forceinline__ int swz(int slot) { return C == 64 ? ((slot >> 1) & 7) : ((slot >> 2) & 3); }
+  static constexpr int NA = 7;                                                  // tap slots per wave: taps 4 a + wave
+  static constexpr int KH = C / 32;                                             // 32-channel input halves (accumulators per tap slot)
+  static __device__ __forceinline__ int swz(int slot) { return C == 64 ? PTC_SWZ64(slot) : ((slot >> 2) & 3); }
   static_assert(ROWS_BYTES + C7_TABB <= W7_BUF1, "buffer 0 must end before buffer 1");
   static_assert(LDS <= 163840, "LDS budget");
 };
@@ -126,8 +97,7 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
   const int lane = ptc_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lp = lane & 15, g4 = lane >> 4, hh = g4 >> 1, cb = g4 & 1;   // transposing-read roles: 16-lane group g4 = (k-group hh, channel block cb)
   const int q = lp >> 2, c4 = lp & 3;                                    // ... lane: row q of the read's four, channels 4 c4 .. 4 c4 + 3 of the block
-  const int kh = C == 64 ? (wave & 1) : 0;                               // input-channel half (B operand)
-  const int tw = C == 64 ? (wave >> 1) : wave;                           // this wave's taps: TM a + tw
+  const int tw = wave;                                                   // this wave's taps: 4 a + tw, a = 0..6 (k = 27 never active)
   // C = 64: workgroup = (block sequence, output-channel half ch); hardware workgroup b runs on XCD b % 8, so the two halves of a sequence
   // are b = x + 8 (2 p) and x + 8 (2 p + 1): same XCD, dispatched back to back.  Sequence `seq` of `step` takes blocks seq', seq' + step, ..
   // with seq' as in conv7 (one round's blocks of an XCD adjacent)
@@ -137,9 +107,10 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
   const int b_begin = (step % 8 == 0) ? (vb & 7) * (step / 8) + (vb >> 3) : vb;
   const int b_end = n_blocks;
 
-  c7_f32x16 acc[NA];
+  constexpr int KH = G::KH;
+  c7_f32x16 acc[NA * KH];                                                // [tap slot a][input-channel half kh]
 #pragma unroll
-  for (int a = 0; a < NA; ++a)
+  for (int a = 0; a < NA * KH; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
@@ -150,9 +121,6 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
       *reinterpret_cast<uint4*>(smem + bsel * W7_BUF1 + C7_HCAP * ROWB + pc * 16) = make_uint4(0, 0, 0, 0);
     }
     const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c7_lds_addr(smem));
-#ifdef __HIPCC__
-    if (lds0 != 0) __builtin_trap();                       // the pipeline's assembly reads address LDS from 0 (no static LDS in this kernel)
-#endif
     const int drow = lane / PCS, dpos = lane % PCS;
     int32_t ids[G::NIW];
     auto load_ids = [&](int blk) {
@@ -162,43 +130,45 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
         ids[i] = hid[(int64_t)blk * C7_HCAP + (slot < C7_HCAP ? slot : C7_HCAP - 1)];
       }
     };
-    auto issue_dma = [&](int blk, int cnt, int bsel) {
+    // one DMA instruction (1 KB) of a block's operands: pieces 0 .. NIW - 1 = halo rows (this wave's share), then the table (2), then the
+    // 32 output channels of the block's dout rows this workgroup owns (NDW; 64 bytes per row: the four rows of a transposing read are
+    // 256 contiguous bytes = all 64 banks once; rows past the end repeat the last row -- their table entries are "no neighbour", the
+    // products are zero).  cnt = the block's halo count, 0 = there is no such block.
+    constexpr int NP = G::NIW + 2 + G::NDW;
+    auto dma_piece = [&](auto pc, int blk, int cnt, int bsel, const int32_t (&idv)[G::NIW]) {
+      constexpr int P = decltype(pc)::value;
       const uint32_t base = lds0 + (uint32_t)(bsel * W7_BUF1);
-#pragma unroll
-      for (int i = 0; i < G::NIW; ++i) {
-        const int ii = 4 * i + wave;
+      if constexpr (P < G::NIW) {
+        const int ii = 4 * P + wave;
         if (ii * RPI < cnt) {                                  // wave-uniform
           const int slot = ii * RPI + drow;
           const int piece = dpos ^ G::swz(slot);
-          c7_dma16(reinterpret_cast<const unsigned char*>(in) + (int64_t)ids[i] * ROWB + piece * 16, base + (uint32_t)(ii * 1024));
+          c7_dma16s(in, (uint32_t)idv[P] * (uint32_t)ROWB + (uint32_t)(piece * 16), base + (uint32_t)(ii * 1024));
         }
-      }
-      if (cnt > 0) {
-        const unsigned char* tsrc = reinterpret_cast<const unsigned char*>(tab) + ((int64_t)(C == 64 ? 0 : n_blocks) + blk) * C7_TABB;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int ii = 4 * i + wave;
-          if (ii < C7_TABB / 1024) c7_dma16(tsrc + ii * 1024 + lane * 16, base + (uint32_t)(G::ROWS_BYTES + ii * 1024));
+      } else if constexpr (P < G::NIW + 2) {
+        const int ii = 4 * (P - G::NIW) + wave;
+        if (cnt > 0 && ii < C7_TABB / 1024) {
+          const unsigned char* tsrc = reinterpret_cast<const unsigned char*>(tab) + ((int64_t)(C == 64 ? 0 : n_blocks) + blk) * C7_TABB;
+          c7_dma16s(tsrc, (uint32_t)(ii * 1024 + lane * 16), base + (uint32_t)(G::ROWS_BYTES + ii * 1024));
         }
-        // the 32 output channels of the block's dout rows this workgroup owns, 64 bytes per row (the four rows of a transposing read
-        // are 256 contiguous bytes: all 64 banks once).  Rows past the end repeat the last row: their table entries are "no neighbour",
-        // the products are zero.
-#pragma unroll
-        for (int i = 0; i < G::NDW; ++i) {
-          const int ii = 4 * i + wave;
-          const int P = ii * 64 + lane, R = P >> 2, pos = P & 3;
+      } else {
+        if (cnt > 0) {
+          const int ii = 4 * (P - G::NIW - 2) + wave;
+          const int Pq = ii * 64 + lane, R = Pq >> 2, pos = Pq & 3;
           int64_t row = (int64_t)blk * C7_BM + R;
           row = row < n_out ? row : n_out - 1;
-          c7_dma16(reinterpret_cast<const unsigned char*>(dout) + row * ROWB + ch * 64 + pos * 16,
-                   lds0 + (uint32_t)(G::DOUT0 + bsel * G::DOUT_BYTES + ii * 1024));
+          c7_dma16s(dout, (uint32_t)row * (uint32_t)ROWB + (uint32_t)(ch * 64 + pos * 16), lds0 + (uint32_t)(G::DOUT0 + bsel * G::DOUT_BYTES + ii * 1024));
         }
       }
+    };
+    auto issue_dma = [&](int blk, int cnt, int bsel, const int32_t (&idv)[G::NIW]) {
+      ptc_static_for<NP>([&](auto pc) { dma_piece(pc, blk, cnt, bsel, idv); });
     };
     auto count_of = [&](int blk) -> int { return hcnt[blk < n_blocks ? blk : n_blocks - 1]; };
 
     int cnt_cur = __builtin_amdgcn_readfirstlane(count_of(b_begin));
     load_ids(b_begin);
-    issue_dma(b_begin, cnt_cur, 0);
+    issue_dma(b_begin, cnt_cur, 0, ids);
     int cnt_nxt = count_of(b_begin + step);
     if (b_begin + step < b_end) load_ids(b_begin + step);
     __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);
@@ -208,7 +178,7 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
     // lane constants of the two transposing reads of a fragment (read i = 0 | 1: the rows of tile 2 hh + i)
     //   gathered operand: address = image base + (entry ^ pcx), pcx = the 16-byte piece this lane reads of a row (XORed into the
     //   swizzled piece-0 offset the table holds) | the 8-byte half of that piece
-    const uint32_t pcx = (uint32_t)(((C == 64 ? kh * 4 : 0) + cb * 2 + (c4 >> 1)) << 4) | (uint32_t)((c4 & 1) << 3);
+    const uint32_t pcx = (uint32_t)((cb * 2 + (c4 >> 1)) << 4) | (uint32_t)((c4 & 1) << 3);     // input-channel half kh: | (kh << 6)
     //   dout operand: row 32 (2 hh + i) + 4 s + q of the 64-byte-per-row image, channel block cb, 8-byte chunk c4
     const uint32_t aoff = (uint32_t)((64 * hh + q) * G::DROWB + cb * 32 + c4 * 8);
     //   table: [tap][row in tile = 4 s + q][tile]: one uint32 = tiles (2 hh, 2 hh + 1); accumulator a = tap TM a + tw
@@ -216,65 +186,59 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
     int cur = 0;
 #pragma unroll 1
     for (int blk = b_begin; blk < b_end; blk += step) {
-      if (blk + step < b_end) issue_dma(blk + step, cnt_nxt, cur ^ 1);
+      // the next block's operands -> the other buffer.  W7_DMA_INLINE: the DMA instructions ride in the MFMA shadows of this block's
+      // stream (one every W7_DMA_EVERY pairs from the first pair on) instead of in front of it; either way every piece has been issued
+      // long before the wait at the end of the block
+      const int cnt_dma = blk + step < b_end ? cnt_nxt : 0;
+      int32_t idd[G::NIW];
+#pragma unroll
+      for (int i = 0; i < G::NIW; ++i) idd[i] = ids[i];
+      if constexpr (!W7_DMA_INLINE) issue_dma(blk + step, cnt_dma, cur ^ 1, idd);
       int cnt_nn = count_of(blk + 2 * step);
       if (blk + 2 * step < b_end) load_ids(blk + 2 * step);
 
-      if (cnt_cur > 0) {
+      {   // (no `if (cnt_cur > 0)`: the gate at the kernel's entry guarantees that every block fits, and a conditional around the stream puts
+          //  every accumulator through a join -- the register allocator then homes the tiles in VGPRs and moves all 224 registers in and
+          //  out of the accumulation file once per block)
         const uint32_t ibase = (uint32_t)(cur * W7_BUF1);
-        const uint32_t pcb = pcx | ibase;                                        // entries < 64 KB: base + (e ^ pcx) = e ^ (pcx | base)
-        const uint32_t tadr = ibase + toff;                                      // this lane's table word of tap slot 0, step 0
-        const uint32_t aadr = (uint32_t)(G::DOUT0 + cur * G::DOUT_BYTES) + aoff; // this lane's dout bytes of read 0, step 0
-        // the eight per-step tap masks (blocks.hip, table row 27), this wave's taps only: bit TM a of ms[s] = tap TM a + tw at step s
-        uint32_t ms[8];
-        {
-          const unsigned char* mrow = smem + ibase + G::ROWS_BYTES + 27 * 256 + 20;
+        uint32_t pcb[KH];                                                        // entries < 64 KB: base + (e ^ piece) = e ^ (piece | base)
 #pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint32_t*>(mrow + 4 * s));
-            ms[s] = (m >> tw) & (C == 64 ? 0x5555555u : 0x1111111u);             // (k < 27 follows: the masks have 27 bits)
-          }
-        }
-        // The pipeline: ONE static stream over the 8 x NA (step, tap slot) pairs of the block, L = s NA + a.  Slot L: M(L) = the MFMA,
-        // G(L + DG) = the two transposing gathers of a later pair, T(L + DT) = the table word of a still later one (slots -DT .. -1 are
-        // the prologue); the A fragment of step s + 1 is read at the first slot of step s.  Everything is a compile-time name: accumulator
-        // (a), ring slots (L), mask register (s), LDS offsets (immediates) -- ~110 bytes of code per pair.  The LDS reads of the stream
-        // are INLINE ASSEMBLY with hand-counted waits (w7_wait_*): the gathers are conditional, LDS results return in order, and the
-        // compiler -- which cannot know which gathers were issued -- guards a use with the count that is safe on EVERY path (the first
-        // build waited, in front of every gather, for a read issued three instructions earlier, and in front of every conditional MFMA
-        // for everything).  The counts below are the reads CERTAINLY issued behind the one needed: in front of M(L) the table reads of
-        // slots L - DG .. L - 1, in front of G(L + DG) those of slots L + DG - DT + 1 .. L - 1.  With every gather in between issued, a
-        // wait for "at most c outstanding" ends with the (c - 3)-th newest read of slot L - 2 (a slot issues two gathers and one table
-        // word): c = DG = 4 and c = DT - DG - 1 = 3 keep every wait on reads at least two MFMAs old.  A fragment buffer is rewritten two MFMAs after the MFMA that read it (a reload whose destination an
-        // MFMA in flight still reads is held until it retires, conv7.h).
-        constexpr int TOT = 8 * NA, RB = W7_DG + 2, RT = W7_DT - W7_DG + 1;
-        uint32_t te[RT];
-        frag bf[RB], af[2];
-        w7_tr_pair(af[0], aadr, aadr + 32 * G::DROWB);
-        ptc_static_for<W7_DT + TOT>([&](auto sc) {
-          constexpr int L = decltype(sc)::value - W7_DT;
-          if constexpr (L >= 0) {
-            constexpr int s = L / NA, a = L % NA;
-            if constexpr (a == 0 && s + 1 < 8) w7_tr_pair(af[(s + 1) % 2], aadr + (s + 1) * 4 * G::DROWB, aadr + (s + 1) * 4 * G::DROWB + 32 * G::DROWB);
-            if ((ms[s] >> (G::TM * a)) & 1u) {
-              w7_wait_frag<w7_certain(L - W7_DG, L - 1, TOT)>(bf[L % RB]);
-              acc[a] = MM::mma(af[s % 2], bf[L % RB], acc[a]);
-            }
-          }
-          if constexpr (L + W7_DG >= 0 && L + W7_DG < TOT) {
-            constexpr int Lg = L + W7_DG, s = Lg / NA, a = Lg % NA;
-            if ((ms[s] >> (G::TM * a)) & 1u) {
-              uint32_t& e = te[Lg % RT];
-              w7_wait_word<w7_certain(Lg - W7_DT + 1, L - 1, TOT)>(e);
-              w7_tr_pair(bf[Lg % RB], (e & 0xffffu) ^ pcb, (e >> 16) ^ pcb);
-            }
-          }
-          if constexpr (L + W7_DT < TOT) {
-            constexpr int Lt = L + W7_DT, s = Lt / NA, a = Lt % NA;
-            te[Lt % RT] = w7_lds_u32<s * 32 + a * G::TSTRIDE>(tadr);
-          }
+        for (int kh = 0; kh < KH; ++kh) pcb[kh] = pcx | (uint32_t)(kh << 6) | ibase;
+        const unsigned char* tb = smem + ibase + toff;                           // this lane's table word of (tap slot 0, step 0)
+        const unsigned char* ab = smem + (uint32_t)(G::DOUT0 + cur * G::DOUT_BYTES) + aoff;   // this lane's dout bytes of read 0, step 0
+        // ONE straight-line stream over the 8 x 7 (step, tap slot) pairs of the block, L = 7 st + a: KH MFMAs per pair on the tap's own
+        // accumulators (consecutive MFMAs write different tiles), the gathered fragments three pairs ahead in a ring of six, the A
+        // fragment (dout^T, 32 output channels x 16 rows) and the seven table words of step st + 1 read at the first pair of step st.
+        // NO branch: see the head of the file for what the branching versions cost.  "No neighbour" entries read the all-zero row.
+        frag af[2];                                                              // A fragment of step st in af[st % 2]
+        uint32_t te[2][NA];                                                      // table words of step st in te[st % 2]
+        frag bfr[6][KH];
+        auto sload = [&](auto sc) {
+          constexpr int st = decltype(sc)::value;
+          af[st % 2] = ld_tr_pair16<frag>(ab + st * 4 * G::DROWB, ab + st * 4 * G::DROWB + 32 * G::DROWB);
+#pragma unroll
+          for (int a = 0; a < NA; ++a) te[st % 2][a] = *reinterpret_cast<const uint32_t*>(tb + a * 1024 + st * 32);
+        };
+        auto gload = [&](auto lc) {
+          constexpr int L = decltype(lc)::value, st = L / NA, a = L % NA;
+          const uint32_t e = te[st % 2][a];
+#pragma unroll
+          for (int kh = 0; kh < KH; ++kh) bfr[L % 6][kh] = ld_tr_pair16<frag>(smem + ((e & 0xffffu) ^ pcb[kh]), smem + ((e >> 16) ^ pcb[kh]));
+        };
+        sload(ptc_int<0>{});
+        gload(ptc_int<0>{});
+        gload(ptc_int<1>{});
+        gload(ptc_int<2>{});
+        ptc_static_for<8 * NA>([&](auto lc) {
+          constexpr int L = decltype(lc)::value, st = L / NA, a = L % NA;
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (a == 0 && st + 1 < 8) sload(ptc_int<(st + 1 < 8 ? st + 1 : st)>{});
+#pragma unroll
+          for (int kh = 0; kh < KH; ++kh) acc[a * KH + kh] = MM::mma(af[st % 2], bfr[L % 6][kh], acc[a * KH + kh]);
+          if constexpr (L + 3 < 8 * NA) gload(ptc_int<(L + 3 < 8 * NA ? L + 3 : L)>{});
+          if constexpr (W7_DMA_INLINE && L % W7_DMA_EVERY == 0 && L / W7_DMA_EVERY < NP)
+            dma_piece(ptc_int<(L / W7_DMA_EVERY < NP ? L / W7_DMA_EVERY : 0)>{}, blk + step, cnt_dma, cur ^ 1, idd);
         });
-        w7_wait_all();                                                           // (table words of skipped pairs)
       }
       __builtin_amdgcn_s_waitcnt(C7_WAIT_VM0 & C7_WAIT_LGKM0);   // the next block's rows, table, dout and the ids landed
       __builtin_amdgcn_s_barrier();
@@ -289,13 +253,15 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
   const int jj = lane & 31;
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
-    const int k = G::TM * a + tw;
+    const int k = 4 * a + tw;
     if (k < 27) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = ch * 32 + 8 * (r >> 2) + 4 * hh + (r & 3), ci = kh * 32 + jj;
-        pout[((int64_t)co * 27 + k) * C + ci] = acc[a][r];
-      }
+      for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = ch * 32 + 8 * (r >> 2) + 4 * hh + (r & 3), ci = kh * 32 + jj;
+          pout[((int64_t)co * 27 + k) * C + ci] = acc[a * KH + kh][r];
+        }
     }
   }
 }

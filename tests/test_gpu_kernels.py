@@ -378,13 +378,14 @@ def test_rulebook_blocks(cuda, ordered):
         cpad = min((c + 15) // 16 * 16, hcap)
         assert (hid[b, c:cpad] == want[-1]).all()                    # padding: whole DMA instructions fetch valid rows
         rows = e.shape[1]
-        for v, (rowb, sw_shift, sw_mask) in enumerate(((128, 1, 7), (64, 2, 3))):      # 64-channel rows, 32-channel rows
+        swz = (lambda sl: (((sl >> 1) & 1) << 2) | ((sl >> 2) & 3), lambda sl: (sl >> 2) & 3)       # PTC_SWZ64 (csrc/ptc_common.h) / 32-channel rows
+        for v, rowb in enumerate((128, 64)):      # 64-channel rows, 32-channel rows
             none = hcap * rowb
             full = tab[v, b, :27].transpose(0, 2, 1).reshape(27, 128).astype(np.int64)  # [k][32 t + r]
             le = full[:, :rows]
             assert np.array_equal(le == none, e < 0)
             slot = le // rowb
-            assert np.array_equal((le % rowb)[e >= 0], ((((slot >> sw_shift) & sw_mask) * 16))[e >= 0])     # piece 0 at its swizzled position
+            assert np.array_equal((le % rowb)[e >= 0], (swz[v](slot) * 16)[e >= 0])     # piece 0 at its swizzled position
             assert np.array_equal(hid[b][np.where(le != none, slot, 0)][e >= 0], e[e >= 0])
             assert (full[:, rows:] == none).all()
             # table row 27: the tap masks (bit k of word t: tile t has a neighbour at tap k; word 4: their OR; words 5..12: bit k of

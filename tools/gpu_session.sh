@@ -23,7 +23,11 @@ for sec in "$@"; do
     probe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_gfx950 tools/probe_gfx950.hip > $O/${TAG}_probe.log 2>&1 && timeout 300 /tmp/probe_gfx950 >> $O/${TAG}_probe.log 2>&1; tail -20 $O/${TAG}_probe.log | cut -c1-200;;
     pgather) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_gather tools/probe_gather.hip > $O/${TAG}_probe_gather.log 2>&1 && timeout 300 /tmp/probe_gather >> $O/${TAG}_probe_gather.log 2>&1; cat $O/${TAG}_probe_gather.log | cut -c1-250;;
     opsq) timeout 900 python tools/bench_ops.py --quick > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log;;
+    w7v:*) PTC_LIB_VARIANT=${sec#w7v:} timeout 600 python tools/wgrad7_time.py > $O/${TAG}_wgrad7_time_${sec#w7v:}.txt 2>&1; cat $O/${TAG}_wgrad7_time_${sec#w7v:}.txt;;
+    c7t) timeout 600 python tools/conv7_time.py --all > $O/${TAG}_conv7_time.txt 2>&1; cat $O/${TAG}_conv7_time.txt;;
     w7) timeout 600 python tools/wgrad7_time.py > $O/${TAG}_wgrad7_time.txt 2>&1; cat $O/${TAG}_wgrad7_time.txt;;
+    w7prof) cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d $O/${TAG}_w7prof -- python $R/tools/wgrad7_time.py > $O/${TAG}_w7prof.log 2>&1
+          cd $R; TOP=12 python tools/prof_top.py $O/${TAG}_w7prof 1 $O/${TAG}_wgrad7_kernel_stats.csv > $O/${TAG}_w7prof_top.log 2>&1; rm -rf $O/${TAG}_w7prof; head -14 $O/${TAG}_wgrad7_kernel_stats.csv | cut -c1-150;;
     bench) timeout 900 python bench.py --steps 10 --warmup 3 > $O/${TAG}_bench.log 2>&1; echo "bench rc=$?" >> $O/${TAG}_env.log; tail -1 $O/${TAG}_bench.log | cut -c1-330;;
     hostlead) timeout 600 python tools/host_lead.py > $O/${TAG}_host_lead.txt 2>&1; PTC_EXEC_BLOCK=0 timeout 600 python tools/host_lead.py >> $O/${TAG}_host_lead.txt 2>&1; timeout 600 python tools/host_lead.py --scenes 2 --points 20000 >> $O/${TAG}_host_lead.txt 2>&1; cat $O/${TAG}_host_lead.txt;;
     contention) timeout 900 python tools/host_contention.py > $O/${TAG}_host_contention.txt 2>&1; cat $O/${TAG}_host_contention.txt;;
