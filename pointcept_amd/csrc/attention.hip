@@ -69,6 +69,25 @@ __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __uint_
 __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+typedef __attribute__((ext_vector_type(4))) float at_f32x4;
+__device__ __forceinline__ at_f32x4 mfma16(s16x8 a, s16x8 b, at_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// a[lanes 16..31] <-> b[lanes 0..15] and a[lanes 48..63] <-> b[lanes 32..47] (v_permlane16_swap: the odd 16-lane rows of the first
+// operand trade places with the even rows of the second)
+#ifdef __HIPCC__
+__device__ __forceinline__ void at_swap16(uint32_t& a, uint32_t& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+#else
+__device__ __forceinline__ void at_swap16(uint32_t& a, uint32_t& b) {
+  const int l = emu::lane_id();
+  const uint32_t oa = emu::exchange(a, l ^ 16), ob = emu::exchange(b, l ^ 16);
+  if (l & 16) a = ob; else b = oa;
+}
+#endif
 __device__ __forceinline__ f32x16 splat16(float v) {
   f32x16 z;
 #pragma unroll
@@ -432,11 +451,48 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 }
 
 // ================================================================================================
-// backward, part 1: dQ (query-stationary) + delta = rowsum(dO * O)
+// backward (round 4 form)
 // ================================================================================================
+// Two kernels as before (recompute P from q, k, lse; no atomics, no cross-wave reductions, bit-reproducible): dQ query-stationary, dK / dV
+// key-stationary.  What changed against rounds 1-3 (14 MFMAs of 32 cycles per (query tile, key tile) pair over the two kernels, and
+// v_exp_f32 does not overlap with them: 448 + ~150 cycles of floor per pair and SIMD against 890 measured, profiles/r03_p_attn_pmc.json):
+//   * every product whose CONTRACTION runs over a tile side (dQ += dS K, dK += dS^T Q, dV += P^T dO) is a 16x16x32 MFMA: head_dim 16 is
+//     exactly its output height, where the 32x32x16 form computed 32 output rows and read 16.  A 32-row side is two MFMAs of 16
+//     cycles instead of two of 32.  The operand the softmax produces (P / dS in the 32x32 accumulator layout: lane = column, 16 rows in
+//     registers) becomes the 16x16x32 B operand (lane = column mod 16, 8 contraction rows) through FOUR v_permlane16_swap per operand:
+//     the packed registers of rows {0-3, 8-11} + 4 h2 and those of rows {16-19, 24-27} + 4 h2 trade their odd / even 16-lane groups, which
+//     puts all 32 rows of columns 0-15 into one register quadruple and all 32 rows of columns 16-31 into the other.  The matching A
+//     operand (K^T, Q^T, dO^T for the same row order) comes from the row-major LDS images through ds_read_b64_tr_b16 as before;
+//   * key-stationary kernel: the per-QUERY constants (lse, delta) vary along the register index of the accumulator, and entered through one
+//     extra MFMA each (bf16 hi + lo pairs against -1 slots).  They are now the C OPERAND of the first product, read from fp32 LDS
+//     arrays with four broadcast ds_read_b128 each (a lane's 16 rows are four runs of 4): two 32-cycle MFMAs less per tile and the
+//     constants exact;
+//   * results leave as 8-byte stores (a lane of a 16x16 tile holds 4 consecutive channels of one row) instead of 2-byte ones.
+// Per 32x32 tile: dQ 3 x 32 + 2 x 16 = 128 matrix-pipe cycles (was 160), dK / dV 3 x 32 + 4 x 16 = 160 (was 288).
+
+// contraction-row order of the 16x16x32 operands built from a 32x32 accumulator: slot (g = lane >> 4, j) <-> row at_krow(g) + j (j < 4),
+// at_krow(g) + 8 + (j - 4) (j >= 4)
+__device__ __forceinline__ int at_krow(int g) { return 16 * (g & 1) + 4 * (g >> 1); }
+struct TrAddr16 { int lo, hi; };   // byte offsets of the two ds_read_b64_tr_b16 of a 16x16x32 A operand for row base 0
+__device__ __forceinline__ TrAddr16 tr_addr16(int lane) {
+  const int lp = lane & 15, g = lane >> 4;
+  const int row = at_krow(g) + (lp >> 2), cq = lp & 3;
+  TrAddr16 a;
+  a.lo = rm_off(row, cq >> 1) + ((cq & 1) << 3);
+  a.hi = rm_off(row + 8, cq >> 1) + ((cq & 1) << 3);
+  return a;
+}
+// P / dS of a 32x32 tile (8 packed registers: pk[i] = rows crow(2 i), crow(2 i + 1) of column lane & 31) -> the two 16x16x32 B operands
+// (columns 0-15 | 16-31)
+__device__ __forceinline__ void at_to_b16(uint32_t (&pk)[8], s16x8& lo, s16x8& hi) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) at_swap16(pk[j], pk[4 + j]);
+  lo = make_frag(pk[0], pk[1], pk[2], pk[3]);
+  hi = make_frag(pk[4], pk[5], pk[6], pk[7]);
+}
+
+// ---- part 1: dQ (query-stationary) + delta = rowsum(dO * O) ------------------------------------------------------------------
 // LDS: V row-major [lp_max][16] | K row-major [lp_max][16]
-// One tile per trip, products and vector work in program order: four in-order waves per SIMD interleave better than a two-stage software
-// pipeline at one workgroup per CU (measured 1487 vs 1406 us at the dec0 shape, profiles/r02_o_slp_ab.txt; removed).
 template <int LP>   // LP = lp_max at compile time (1024: image distances become immediate offsets) or 0 = runtime
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
@@ -466,7 +522,7 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const int col = lane & 31, h2 = lane >> 5;
   const float c = scale * AT_LOG2E;
-  const TrAddr ta = tr_addr(lane);
+  const TrAddr16 ta = tr_addr16(lane);
   const int rmo = rm_off(col, h2);
 
   for (int qt = t_lo + wave; qt < t_hi; qt += AT_WAVES) {
@@ -485,10 +541,9 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
     s16x8 qhi, qlo;
     split_scaled(qf, c, qhi, qlo);
     const f32x16 negl = splat16(-l2), negd = splat16(-dl);
-    f32x16 acc = zero16();
+    at_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};    // dQ^T[d = 4 g + e][q = 32 qt + (0 | 16) + lane & 15]
     {
-      // three per-lane LDS pointers advanced once per trip, everything else immediate offsets (see attn_bwd_dkv_kernel);
-      // the V image sits KOFF bytes BEFORE the K image
+      // three per-lane LDS pointers advanced once per trip, everything else immediate offsets; the V image sits KOFF bytes BEFORE the K image
       const int KOFF = LP ? LP * 32 : lp_max * 32;
       const unsigned char* pv = Vsm + rmo;
       const unsigned char* pl = Ksm + ta.lo;
@@ -496,7 +551,7 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
       auto tile = [&](const int o) {
         const s16x8 vf = *reinterpret_cast<const s16x8*>(pv + o);
         const s16x8 kf = *reinterpret_cast<const s16x8*>(pv + o + KOFF);
-        f32x16 s = mfma32(kf, qhi, negl);                 // S'^T = k.(q c) - lse  (exp2 domain)
+        f32x16 s = mfma32(kf, qhi, negl);                 // S'^T = k.(q c) - lse  (exp2 domain): lane = query, registers = keys crow(r, h2)
         s = mfma32(kf, qlo, s);
         const f32x16 dp = mfma32(vf, dof, negd);          // dP^T - delta
         // keys >= L have k = 0, so whatever (finite) dS they get multiplies K^T = 0 below
@@ -504,12 +559,11 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i]) * dp[2 * i], __builtin_amdgcn_exp2f(s[2 * i + 1]) * dp[2 * i + 1]);
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm) {
-          const s16x8 dsf = make_frag(pk[4 * mm], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]);
-          const s16x8 ktf = ld_tr_pair(pl + o + 512 * mm, ph + o + 512 * mm);
-          acc = mfma32(ktf, dsf, acc);                    // dQ^T[d][q]
-        }
+        s16x8 ds0, ds1;
+        at_to_b16(pk, ds0, ds1);                          // dS^T as B operands: queries 0-15 | 16-31 of the tile, all 32 keys each
+        const s16x8 ktf = ld_tr_pair(pl + o, ph + o);     // K^T[d][key slots]
+        acc0 = mfma16(ktf, ds0, acc0);
+        acc1 = mfma16(ktf, ds1, acc1);
       };
       int kt = 0;
       for (; kt + 1 < n_tiles; kt += 2) {
@@ -519,22 +573,25 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
       }
       if (kt < n_tiles) tile(0);
     }
-    if (qv) {
-      uint16_t* o = dqkv + qkv_off(a + q, 0, H, head);
-      uint2 w0, w1;
-      w0.x = pack_bf16x2(acc[0] * scale, acc[1] * scale); w0.y = pack_bf16x2(acc[2] * scale, acc[3] * scale);
-      w1.x = pack_bf16x2(acc[4] * scale, acc[5] * scale); w1.y = pack_bf16x2(acc[6] * scale, acc[7] * scale);
-      *reinterpret_cast<uint2*>(o + 4 * h2) = w0;
-      *reinterpret_cast<uint2*>(o + 8 + 4 * h2) = w1;
+    // lane (n = lane & 15, g = lane >> 4) holds channels 4 g .. 4 g + 3 of queries 32 qt + n (acc0) and 32 qt + 16 + n (acc1)
+    const int g = lane >> 4, n = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int qq = qt * 32 + 16 * t + n;
+      if (qq < L) {
+        const at_f32x4 v = t ? acc1 : acc0;
+        uint2 w;
+        w.x = pack_bf16x2(v[0] * scale, v[1] * scale);
+        w.y = pack_bf16x2(v[2] * scale, v[3] * scale);
+        *reinterpret_cast<uint2*>(dqkv + qkv_off(a + qq, 0, H, head) + 4 * g) = w;
+      }
     }
   }
 }
 
-// ================================================================================================
-// backward, part 2: dK, dV (key-stationary).  Needs delta written by part 1 (same stream).
-// ================================================================================================
-// LDS: Q row-major [lp_max][16] | dO row-major [lp_max][16] | aux [lp_max][4] bf16 = (lse_hi, lse_lo, delta_hi, delta_lo)
-#define AT_PAD_LSE 1.0e30f   // lse of padding queries: exp2(s - 1e30) = 0 and, unlike +inf, 1e30 * 0 = 0 in the delta product
+// ---- part 2: dK, dV (key-stationary).  Needs delta written by part 1 (same stream). -------------------------------------------------
+// LDS: Q row-major [lp_max][16] | dO row-major [lp_max][16] | -lse * log2 e fp32 [lp_max] | -delta fp32 [lp_max]
+#define AT_PAD_LSE 1.0e30f   // lse of padding queries: exp2(s - 1e30) = 0
 template <int LP>   // LP = lp_max at compile time (1024: image distances become immediates) or 0
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -558,31 +615,21 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
   const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
   if (t_lo >= n_tiles) return;
   unsigned char* Qsm = smem;
-  unsigned char* dOsm = smem + (size_t)lp_max * 32;
-  uint2* aux = reinterpret_cast<uint2*>(smem + (size_t)lp_max * 64);
+  float* nl = reinterpret_cast<float*>(smem + (size_t)lp_max * 64);            // -lse * log2 e per query
+  float* nd = nl + lp_max;                                                     // -delta per query
   stage_row_major(qkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, Lp, Qsm);
-  stage_row_major(dout + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, Lp, dOsm);
+  stage_row_major(dout + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, Lp, smem + (size_t)lp_max * 32);
   for (int q = threadIdx.x; q < Lp; q += AT_THREADS) {
-    const float l2 = q < L ? lse[(int64_t)head * total + a + q] * AT_LOG2E : AT_PAD_LSE;
-    const float dl = q < L ? delta[(int64_t)head * total + a + q] : 0.f;
-    const uint32_t hi = pack_bf16x2(l2, dl);                                    // (lse_hi, delta_hi)
-    const uint32_t lo = pack_bf16x2(l2 - __uint_as_float(hi << 16), dl - __uint_as_float(hi & 0xffff0000u));
-    uint2 w;
-    w.x = (hi & 0xffffu) | (lo << 16);                                          // lse_hi, lse_lo
-    w.y = (hi >> 16) | (lo & 0xffff0000u);                                      // delta_hi, delta_lo
-    aux[q] = w;
+    nl[q] = q < L ? -lse[(int64_t)head * total + a + q] * AT_LOG2E : -AT_PAD_LSE;
+    nd[q] = q < L ? -delta[(int64_t)head * total + a + q] : 0.f;
   }
   __syncthreads();
 
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const int col = lane & 31, h2 = lane >> 5;
   const float c = scale * AT_LOG2E;
-  const TrAddr ta = tr_addr(lane);
+  const TrAddr16 ta = tr_addr16(lane);
   const int rmo = rm_off(col, h2);
-  // B operands of the two "constant" products: -1 in the contraction slots that hold lse / delta
-  const uint32_t m1 = 0xBF80BF80u;                                              // (-1, -1) bf16
-  const s16x8 bS = make_frag(h2 == 0 ? m1 : 0u, 0u, 0u, 0u);
-  const s16x8 bD = make_frag(0u, h2 == 0 ? m1 : 0u, 0u, 0u);
 
   for (int kt = t_lo + wave; kt < t_hi; kt += AT_WAVES) {
     const int key = kt * 32 + col;
@@ -590,27 +637,30 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
     const s16x8 vf = ld_global_frag(qkv + qkv_off(a + key, 2, H, head) + h2 * 8, key < L);
     s16x8 khi, klo;
     split_scaled(kf, c, khi, klo);
-    f32x16 dv = zero16(), dk = zero16();
+    at_f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;    // dV^T / dK^T [d = 4 g + e][key = 32 kt + (0 | 16) + lane & 15]
     {
-      // Four per-lane LDS pointers (row-major fragment, aux word, the two halves of the transposed fragments), advanced
-      // once per trip; everything else is an immediate offset (the dO image sits DOFF bytes after the Q image, 16 rows
-      // are 512 bytes, the second tile of a trip 1024): the address arithmetic of the r01 form (7 pointers, 14 VALU per
-      // tile of ~72 -- the kernel is instruction-issue bound, 90 % of cycles issue, profiles/r02_p_attn_pmc.json) shrinks
-      // to 2 VALU per tile.
-      const int DOFF = LP ? LP * 32 : lp_max * 32;
+      // Per-lane LDS pointers (row-major fragment, the two halves of the transposed fragments, the constants of the lane's first row
+      // run), advanced once per trip; everything else is an immediate offset (the dO image sits DOFF bytes after the Q image, the delta
+      // array lp_max floats after the lse array)
+      const int DOFF = LP ? LP * 32 : lp_max * 32, NOFF = (LP ? LP : lp_max) * 4;
       const unsigned char* pq = Qsm + rmo;
       const unsigned char* pl = Qsm + ta.lo;
       const unsigned char* ph = Qsm + ta.hi;
-      const unsigned char* pa = reinterpret_cast<const unsigned char*>(aux) + col * 8;
-      auto tile = [&](const int o, const int oa) {          // o = byte offset of the tile in the row-major images, oa in aux
+      const unsigned char* pc = reinterpret_cast<const unsigned char*>(nl) + 16 * h2;       // rows crow(r, h2) = 8 (r / 4) + 4 h2 + r % 4
+      auto tile = [&](const int o, const int oc) {          // o = byte offset of the tile in the row-major images, oc in the constant arrays
         const s16x8 qf = *reinterpret_cast<const s16x8*>(pq + o);
         const s16x8 dof = *reinterpret_cast<const s16x8*>(pq + o + DOFF);
-        const uint2 ax = *reinterpret_cast<const uint2*>(pa + oa);                // h2 = 1 lanes meet B = 0: any finite value
-        const s16x8 af = make_frag(ax.x, ax.y, 0u, 0u);
-        f32x16 s = mfma32(af, bS, zero16());            // -lse[q]          S'[q][key]: lane = key, regs = queries crow(r,h2)
-        s = mfma32(qf, khi, s);
+        // C operands: -lse / -delta of the lane's 16 queries = four runs of four consecutive rows (the same for every lane of a half: broadcast reads)
+        f32x16 s, dp;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const at_f32x4 l4 = *reinterpret_cast<const at_f32x4*>(pc + oc + 32 * r4);
+          const at_f32x4 d4 = *reinterpret_cast<const at_f32x4*>(pc + oc + 32 * r4 + NOFF);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s[4 * r4 + e] = l4[e]; dp[4 * r4 + e] = d4[e]; }
+        }
+        s = mfma32(qf, khi, s);                         // S'[q][key] = q.(k c) - lse (exp2 domain): lane = key, registers = queries crow(r, h2)
         s = mfma32(qf, klo, s);
-        f32x16 dp = mfma32(af, bD, zero16());           // -delta[q]
         dp = mfma32(dof, vf, dp);                       // dP[q][key] - delta[q]
         uint32_t pp[8], ps[8];
 #pragma unroll
@@ -619,33 +669,38 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
           pp[i] = pack_bf16x2(p0, p1);
           ps[i] = pack_bf16x2(p0 * dp[2 * i], p1 * dp[2 * i + 1]);
         }
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm) {
-          const s16x8 pf = make_frag(pp[4 * mm], pp[4 * mm + 1], pp[4 * mm + 2], pp[4 * mm + 3]);     // P^T[key][q slots]
-          const s16x8 dsf = make_frag(ps[4 * mm], ps[4 * mm + 1], ps[4 * mm + 2], ps[4 * mm + 3]);    // dS^T
-          const s16x8 dotf = ld_tr_pair(pl + o + DOFF + 512 * mm, ph + o + DOFF + 512 * mm);          // dO[q slots][d]
-          const s16x8 qtf = ld_tr_pair(pl + o + 512 * mm, ph + o + 512 * mm);                         // Q[q slots][d]
-          dv = mfma32(pf, dotf, dv);   // dV[key][d]
-          dk = mfma32(dsf, qtf, dk);   // dK[key][d]
-        }
+        s16x8 p0f, p1f, s0f, s1f;
+        at_to_b16(pp, p0f, p1f);                        // P as B operands: keys 0-15 | 16-31 of the tile, all 32 queries each
+        at_to_b16(ps, s0f, s1f);
+        const s16x8 dotf = ld_tr_pair(pl + o + DOFF, ph + o + DOFF);      // dO^T[d][query slots]
+        const s16x8 qtf = ld_tr_pair(pl + o, ph + o);                     // Q^T[d][query slots]
+        dv0 = mfma16(dotf, p0f, dv0);
+        dv1 = mfma16(dotf, p1f, dv1);
+        dk0 = mfma16(qtf, s0f, dk0);
+        dk1 = mfma16(qtf, s1f, dk1);
       };
       int qt = 0;
       for (; qt + 1 < n_tiles; qt += 2) {
         tile(0, 0);
-        tile(1024, 256);
-        pq += 2048; pl += 2048; ph += 2048; pa += 512;
+        tile(1024, 128);
+        pq += 2048; pl += 2048; ph += 2048; pc += 256;
       }
       if (qt < n_tiles) tile(0, 0);
     }
-    // D[i = key][j = d]: lane column = d (valid < 16), regs = keys crow(r,h2)
-    if (col < 16) {
+    // lane (n = lane & 15, g = lane >> 4) holds channels 4 g .. 4 g + 3 of keys 32 kt + n (.0) and 32 kt + 16 + n (.1)
+    const int g = lane >> 4, n = lane & 15;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kk = kt * 32 + crow(r, h2);
-        if (kk < L) {
-          dqkv[qkv_off(a + kk, 1, H, head) + col] = (uint16_t)(pack_bf16x2(dk[r] * scale, 0.f) & 0xffffu);
-          dqkv[qkv_off(a + kk, 2, H, head) + col] = (uint16_t)(pack_bf16x2(dv[r], 0.f) & 0xffffu);
-        }
+    for (int t = 0; t < 2; ++t) {
+      const int kk = kt * 32 + 16 * t + n;
+      if (kk < L) {
+        const at_f32x4 vk = t ? dk1 : dk0, vv = t ? dv1 : dv0;
+        uint2 wk, wv;
+        wk.x = pack_bf16x2(vk[0] * scale, vk[1] * scale);
+        wk.y = pack_bf16x2(vk[2] * scale, vk[3] * scale);
+        wv.x = pack_bf16x2(vv[0], vv[1]);
+        wv.y = pack_bf16x2(vv[2], vv[3]);
+        *reinterpret_cast<uint2*>(dqkv + qkv_off(a + kk, 1, H, head) + 4 * g) = wk;
+        *reinterpret_cast<uint2*>(dqkv + qkv_off(a + kk, 2, H, head) + 4 * g) = wv;
       }
     }
   }
@@ -665,8 +720,10 @@ static int allow_big_lds(K kernel, size_t bytes) {
 }
 
 static size_t fwd_lds_bytes(int lp_max) { return (size_t)lp_max * 32 + (size_t)17 * (lp_max + 8) * 2 + AT_WAVES * 4; }
-static size_t dq_lds_bytes(int lp_max) { return (size_t)lp_max * 64; }
-static size_t dkv_lds_bytes(int lp_max) { return (size_t)lp_max * 64 + (size_t)lp_max * 8; }
+// (PTC_AT_BWD_PAD_LDS: occupancy probe of tools only -- extra dynamic LDS per workgroup, e.g. 20000 = one workgroup per CU)
+static size_t at_bwd_pad() { const char* e = getenv("PTC_AT_BWD_PAD_LDS"); return e ? (size_t)atoi(e) : 0; }
+static size_t dq_lds_bytes(int lp_max) { return (size_t)lp_max * 64 + at_bwd_pad(); }
+static size_t dkv_lds_bytes(int lp_max) { return (size_t)lp_max * 64 + (size_t)lp_max * 8 + at_bwd_pad(); }
 
 static int check_common(const char* name, const void* qkv, const int32_t* cu, int64_t n_seq, int64_t total, int H,
                         int max_seqlen, int dtype) {

@@ -25,6 +25,9 @@ for sec in "$@"; do
     opsq) timeout 900 python tools/bench_ops.py --quick > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log;;
     w7v:*) PTC_LIB_VARIANT=${sec#w7v:} timeout 600 python tools/wgrad7_time.py > $O/${TAG}_wgrad7_time_${sec#w7v:}.txt 2>&1; cat $O/${TAG}_wgrad7_time_${sec#w7v:}.txt;;
     c7t) timeout 600 python tools/conv7_time.py --all > $O/${TAG}_conv7_time.txt 2>&1; cat $O/${TAG}_conv7_time.txt;;
+    attnpad) for pad in 0 20000; do echo "PTC_AT_BWD_PAD_LDS=$pad"; PTC_AT_BWD_PAD_LDS=$pad timeout 300 python tools/bench_ops.py --only attn 2>&1 | grep "attention n_seq= 800"; done > $O/${TAG}_attn_pad.txt 2>&1; cat $O/${TAG}_attn_pad.txt;;
+    attnprof) cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d $O/${TAG}_ap -- python $R/tools/bench_ops.py --only attn > $O/${TAG}_ap.log 2>&1
+          cd $R; TOP=12 python tools/prof_top.py $O/${TAG}_ap 1 $O/${TAG}_attn_kernel_stats.csv > $O/${TAG}_ap_top.log 2>&1; rm -rf $O/${TAG}_ap; head -8 $O/${TAG}_attn_kernel_stats.csv | cut -c1-150;;
     w7) timeout 600 python tools/wgrad7_time.py > $O/${TAG}_wgrad7_time.txt 2>&1; cat $O/${TAG}_wgrad7_time.txt;;
     w7prof) cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d $O/${TAG}_w7prof -- python $R/tools/wgrad7_time.py > $O/${TAG}_w7prof.log 2>&1
           cd $R; TOP=12 python tools/prof_top.py $O/${TAG}_w7prof 1 $O/${TAG}_wgrad7_kernel_stats.csv > $O/${TAG}_w7prof_top.log 2>&1; rm -rf $O/${TAG}_w7prof; head -14 $O/${TAG}_wgrad7_kernel_stats.csv | cut -c1-150;;
