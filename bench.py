@@ -66,9 +66,9 @@ def parse(argv=None):
     ap.add_argument("--lovasz", action="store_true", help="(kept for old command lines; CE + Lovasz is the default)")
     ap.add_argument("--amp", default="bf16", choices=["bf16", "fp16"],
                     help="autocast dtype; fp16 adds torch.amp.GradScaler exactly as engines/train.py:203-231")
-    ap.add_argument("--model", default="ptv3", choices=["ptv3", "spunet"],
-                    help="ptv3 = BASELINE.json metric (configs[2]); spunet = configs[1] (SpUNet-v1m1, 100000 voxels/scene), "
-                         "reported with its own metric name")
+    ap.add_argument("--model", default="ptv3", choices=["ptv3", "spunet", "ptv3-outdoor"],
+                    help="ptv3 = BASELINE.json metric (configs[2]); spunet = configs[1] (SpUNet-v1m1, 100000 voxels/scene); ptv3-outdoor = "
+                         "configs[4] (LiDAR sweeps, depth-12 grid) as the main model (profiling); each reported with its own metric name")
     ap.add_argument("--cpu-sample-points", type=int, default=10240)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-fp16-recipe", action="store_true",
@@ -394,6 +394,8 @@ def main():
     os.dup2(2, 1)
 
     rank, local_rank, world = dp.env_rank()
+    # one Python process per GPU shares the host: NUMA-local cores and a bounded thread pool per rank (no-op at world size 1)
+    affinity = dp.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a different GPU count than asked")
     if args.stub:
@@ -421,6 +423,12 @@ def main():
         model, opt, batch, loss_of = build_spunet(args, device, rank, points)
         metric = "scenes/sec (fwd+bwd+optimizer) SpUNet-v1m1 ScanNet-semseg @ 100k voxels"
         workload = f"SpUNet-v1m1 (39.2M params) + CE, fwd+bwd+SGD, {args.batch} scenes x {points} voxels per GPU"
+        amp = args.amp
+    elif args.model == "ptv3-outdoor":
+        model, opt, batch, loss_of = build_ptv3_outdoor(args, device, rank)
+        points = int(batch["offset"][-1]) // args.batch
+        metric = "scenes/sec (fwd+bwd+optimizer) PT-v3m1 outdoor LiDAR semseg @ ~200k voxels (BASELINE configs[4])"
+        workload = f"PT-v3m1 base, in_channels 4, 16 classes, CE + Lovasz, fwd+bwd+AdamW, {args.batch} scenes x ~{points} voxels per GPU"
         amp = args.amp
     else:
         model, opt, batch, loss_of = build_ptv3(args, device, rank)
@@ -474,6 +482,7 @@ def main():
         }
         if per_rank_ms is not None:
             out["per_rank_ms_per_step"] = per_rank_ms
+            out["cpu_affinity_rank0"] = affinity
             out["ms_per_step_without_gradient_exchange"] = ms_no_sync
             out["exposed_allreduce_ms_per_step"] = None if ms_no_sync is None else round(out["ms_per_step"] - ms_no_sync, 3)
         if not args.stub and args.model == "ptv3":

@@ -485,6 +485,37 @@ int ptc_farthest_point_sampling(const float* xyz, const int32_t* offset, const i
 int ptc_ball_query(const float* xyz, const int32_t* offset, const float* new_xyz, const int32_t* new_offset, const int32_t* order,
                    int b, int64_t n, int64_t m, int nsample, float min_radius, float max_radius, int32_t* idx, float* dist2,
                    ptc_stream_t stream);
+/* Edge-list operators (round 4): grouping, interpolation, aggregation, subtraction of libs/pointops as operations on the edge list
+ * E = {(t, s) -> j = idx[t * nsample + s]} (idx int32 [m, nsample], -1 = empty slot: gathers zeros, receives no gradient).  fp32 rows,
+ * like the reference kernels.  Every gradient of a GATHERED operand is a segmented sum over the edges sorted by source row (fixed
+ * order, no atomics) where the reference scatters with atomicAdd.
+ *   ptc_edge_rows_fwd    per-edge rows into out[e * out_stride + out_col0 .. + c):
+ *        mode 0  src[j]          grouping_forward_cuda, libs/pointops/src/grouping/grouping_cuda_kernel.cu:5-15 (functions/grouping.py:8-25)
+ *        mode 1  a[t] - src[j]   subtraction_forward_cuda, src/subtraction/subtraction_cuda_kernel.cu:5-17 (functions/subtraction.py:8-22)
+ *        mode 2  src[j] - a[t]   (0 for j < 0) the relative coordinates of grouping(with_xyz=True), functions/grouping.py:44-68
+ *   ptc_edge_reduce_fwd  per-target sums over the nsample edges of a row, out [m, c]:
+ *        mode 0  sum_s w[t,s] src[j]                               interpolation_forward_cuda, src/interpolation/interpolation_cuda_kernel.cu:6-20
+ *        mode 1  sum_s (src[j][c] + pos[t,s,c]) w[t,s,c % w_c]     aggregation_forward_cuda, src/aggregation/aggregation_cuda_kernel.cu:5-21
+ *        mode 2  sum_s pos[(t,s) * pos_stride + pos_col0 + c]      gradient of subtraction's input1 (subtraction_cuda_kernel.cu:19-33);
+ *                idx != NULL: empty slots (idx < 0) are left out of the sum
+ *   ptc_edge_csr_keys / ptc_edge_csr_ptr  the edge CSR by source row: keys [E] int64 (j, or n_src for empty slots) for ptc_sort_keys over
+ *        bits [0, bit_length(n_src)), then indptr [n_src + 1] int64 from the sorted order (indptr[j] = edges with key < j)
+ *   ptc_edge_scatter_bwd grad_src[j] = sum over the edges of source row j, ascending edge index, of coef(e) g[row(e)]:
+ *        mode 0 grouping (coef 1, row e), 1 subtraction (coef -1, row e), 2 interpolation (coef w[e], row e / nsample),
+ *        mode 3 aggregation (coef w[e, c % w_c], row e / nsample); g rows may be a column window (g_stride, g_col0) of wider rows
+ *        -- grouping_backward_cuda / interpolation_backward_cuda / aggregation_backward_cuda / subtraction_backward_cuda without atomics
+ *   ptc_aggregation_edge_bwd  grad_position [m, nsample, c] and grad_weight [m, nsample, w_c] of aggregation
+ *        (aggregation_cuda_kernel.cu:23-39; one producer per element) */
+int ptc_edge_rows_fwd(int mode, const float* src, const float* a, const int32_t* idx, int64_t n_edges, int nsample, int c,
+                      int64_t n_src, float* out, int64_t out_stride, int out_col0, ptc_stream_t stream);
+int ptc_edge_reduce_fwd(int mode, const float* src, const float* pos, int64_t pos_stride, int pos_col0, const float* w,
+                        const int32_t* idx, int64_t m, int nsample, int c, int w_c, int64_t n_src, float* out, ptc_stream_t stream);
+int ptc_edge_csr_keys(const int32_t* idx, int64_t n_edges, int64_t n_src, int64_t* keys, ptc_stream_t stream);
+int ptc_edge_csr_ptr(const int64_t* keys, const int64_t* order, int64_t n_edges, int64_t n_src, int64_t* indptr, ptc_stream_t stream);
+int ptc_edge_scatter_bwd(int mode, const int64_t* order, const int64_t* indptr, const float* g, int64_t g_stride, int g_col0,
+                         const float* w, int nsample, int c, int w_c, int64_t n_src, float* grad_src, ptc_stream_t stream);
+int ptc_aggregation_edge_bwd(const float* src, const float* pos, const float* w, const int32_t* idx, const float* g, int64_t m,
+                             int nsample, int c, int w_c, int64_t n_src, float* grad_pos, float* grad_w, ptc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * J. BatchNorm1d over the rows of [n, c] features with the following activation fused:

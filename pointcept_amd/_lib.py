@@ -107,6 +107,12 @@ _SIGNATURES = {
     "ptc_cross_entropy_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_i64, c_ptr, c_i64, c_ptr]),
     "ptc_knn_query": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
     "ptc_ball_query": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_i64, c_int, c_f32, c_f32, c_ptr, c_ptr, c_ptr]),
+    "ptc_edge_rows_fwd": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_i64, c_ptr, c_i64, c_int, c_ptr]),
+    "ptc_edge_reduce_fwd": (c_int, [c_int, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_i64, c_ptr, c_ptr]),
+    "ptc_edge_csr_keys": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "ptc_edge_csr_ptr": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "ptc_edge_scatter_bwd": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_i64, c_ptr, c_ptr]),
+    "ptc_aggregation_edge_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     "ptc_farthest_point_sampling": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     "ptc_voxel_keys": (c_int, [c_ptr, c_i64, ctypes.c_double, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_lovasz_softmax_workspace_bytes": (c_size, [c_i64, c_int]),

@@ -41,6 +41,7 @@ HIP_SOURCES = [
     "lovasz.hip",
     "voxelize.hip",
     "pointops.hip",
+    "pointops_edges.hip",
     "pointops2.hip",
     "bn.hip",
     "rope.hip",

@@ -30,6 +30,12 @@
 //  input channels, profiles/r02_d_conv_stages_ops.txt: the rows still left L2 as half lines.  Removed; conv5.h is the form that coalesces.)
 #pragma once
 
+#ifndef C3_NT8
+#define C3_NT8 1              // 0: timing A/B only (`python -m pointcept_amd.build --variant d_C3_NT8_0`)
+#endif
+#ifndef C3_NT8_MIN_WGS
+#define C3_NT8_MIN_WGS 256    // fewest 256-row x 128-column workgroups for which the wide tile is used
+#endif
 #define C3_FRAG 1024
 #define C3_FPAD 64
 #define C3_BUF(NTILES) (4 * (NTILES) * (C3_FRAG + C3_FPAD))   // one W chunk: NTILES tiles x 4 steps
@@ -72,9 +78,16 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
     wdst[ps] = ((prow >> 4) * 4 + qd) * (C3_FRAG + C3_FPAD) + (prow & 15) * 16;
   }
   uint4 wreg[WP][4];
-  auto wload = [&](int c) {
+  // SPLIT (NTILES = 8): buffer (c + 1) & 1 is free for the whole of chunk c (its readers passed the barrier that ended chunk c - 1), so
+  // pass 0 of W(c + 1) is stored in the MIDDLE of chunk c and pass 1 loaded only then: the staging registers of one pass (16) instead
+  // of two (32) are live across the chunk's MFMAs -- the 128-column instance sits at the 256-register cap
+  constexpr bool SPLIT = NTILES == 8;
+  // (pass range [p0, p1): the two-pass instances -- 96 / 128 output channels -- stage their passes at different points of a chunk,
+  //  see SPLIT below, so that only ONE pass of staging registers is live across the MFMAs)
+  auto wload = [&](int c, int p0 = 0, int p1 = 4) {
 #pragma unroll
-    for (int ps = 0; ps < WP; ++ps)
+    for (int ps = 0; ps < WP; ++ps) {
+      if (ps < p0 || ps >= p1) continue;
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         // UNCONDITIONAL load from a clamped address, zeroed by a select: a load under an exec-masked branch
@@ -87,14 +100,17 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
         if (!ok) v = make_uint4(0, 0, 0, 0);
         wreg[ps][gq] = v;
       }
+    }
   };
-  auto wstore = [&](int buf) {
+  auto wstore = [&](int buf, int p0 = 0, int p1 = 4) {
 #pragma unroll
-    for (int ps = 0; ps < WP; ++ps)
+    for (int ps = 0; ps < WP; ++ps) {
+      if (ps < p0 || ps >= p1) continue;
       if (wthread[ps]) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<uint4*>(smem + buf * C3_BUF(NTILES) + wdst[ps] + gq * 256) = wreg[ps][gq];
       }
+    }
   };
 
   // ---- gather ring
@@ -172,7 +188,7 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 #pragma unroll
   for (int s = 0; s < 4; ++s) issue(0, s, idxN);
   load_idx(1, idxN);
-  wload(1);
+  if constexpr (SPLIT) wload(1, 0, 1); else wload(1);
   __syncthreads();
 
 #pragma unroll 1
@@ -181,21 +197,32 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
     load_idx(c + 2, idxNN);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      frag wf[NTILES];
+      // (NTILES = 8: the W fragments of a step in two halves of four -- 16 registers less live at the 256-register cap)
+      constexpr int WH = NTILES > 6 ? NTILES / 2 : NTILES;
 #pragma unroll
-      for (int t = 0; t < NTILES; ++t) wf[t] = *reinterpret_cast<const frag*>(wb + (t * 4 + s) * (C3_FRAG + C3_FPAD));
+      for (int t0 = 0; t0 < NTILES; t0 += WH) {
+        frag wf[WH];
 #pragma unroll
-      for (int j = 0; j < RT; ++j) {
-        if (anyv[s][j]) {
+        for (int t = 0; t < WH; ++t) wf[t] = *reinterpret_cast<const frag*>(wb + ((t0 + t) * 4 + s) * (C3_FRAG + C3_FPAD));
 #pragma unroll
-          for (int t = 0; t < NTILES; ++t) acc[j][t] = M::mma(wf[t], ga[s][j], acc[j][t]);
+        for (int j = 0; j < RT; ++j) {
+          if (anyv[s][j]) {
+#pragma unroll
+            for (int t = 0; t < WH; ++t) acc[j][t0 + t] = M::mma(wf[t], ga[s][j], acc[j][t0 + t]);
+          }
         }
       }
       issue(c + 1, s, idxN);
+      if constexpr (SPLIT) {
+        if (s == 1) {
+          wstore((c + 1) & 1, 0, 1);
+          wload(c + 1, 1, 2);
+        }
+      }
     }
-    wstore((c + 1) & 1);
+    if constexpr (SPLIT) wstore((c + 1) & 1, 1, 2); else wstore((c + 1) & 1);
     __syncthreads();
-    wload(c + 2);
+    if constexpr (SPLIT) wload(c + 2, 0, 1); else wload(c + 2);
 #pragma unroll
     for (int kk = 0; kk < KI; ++kk)
 #pragma unroll
@@ -247,7 +274,7 @@ static int launch_conv3(const void* in, int64_t n_in, const void* w, const float
                         int c_in, int c_out, void* out, hipStream_t s) {
   // 64 output channels per workgroup (96 when c_out is a multiple of 96 but not of 64 -- SpUNet's decoder --
   // else 32); 256-row workgroups when they still give every CU a workgroup, else 128-row ones
-  const int nt = c_out % 64 == 0 ? 4 : (c_out % 96 == 0 ? 6 : 2);
+  int nt = c_out % 64 == 0 ? 4 : (c_out % 96 == 0 ? 6 : 2);
   // table rows one 128-wide chunk can touch: 1 (c_in % 128 == 0), 4 (c_in = 32), else 2
   const int kpc = c_in == 8 ? 16 : (c_in % 128 == 0 ? 1 : (c_in == 32 ? 4 : 2));
   // >= one 256-row workgroup per CU (r01_ag: N = 50k, C = 128: 79 vs 88 us).  96-wide tiles: 256 rows x 96 channels of accumulators
@@ -256,6 +283,19 @@ static int launch_conv3(const void* in, int64_t n_in, const void* w, const float
   // 28.4 vs 29.6 ms, profiles/r03_q_spunet_nt6_ab.txt); c_in % 128 == 0 does not spill
   const bool big = (nt != 6 || kpc <= 2) && ptc_cdiv(n_out, 256) * (c_out / (nt * 16)) >= 256;
   const bool gen = !(c_in == 8 || c_in == 32 || c_in == 64 || c_in % 128 == 0);   // table rows straddle chunks (kpc == 2)
+#if C3_NT8
+  // 128 output channels per workgroup at c_in % 128 == 0 (round 4): the gathered rows are the B operand of TWICE as many MFMAs.  The
+  // kernel is bound by the address path of its gathers at 64 columns (a 1-KB wave gather in B-operand layout costs ~57 address cycles,
+  // profiles/r02_e_probe_gather.txt: 8 waves x 4 row tiles per step = 1824 cycles per CU against 1024 matrix-pipe cycles per SIMD),
+  // so the same gathers feeding 128 columns halve the time per flop; RT = 4 keeps the LDS reads of W at half the LDS bandwidth
+  // (PTC_C3_NT8_MIN_WGS: the CPU emulation tier and tools/conv_kernels.py lower the threshold to reach the instance at test sizes)
+  static const long nt8_min = getenv("PTC_C3_NT8_MIN_WGS") ? atol(getenv("PTC_C3_NT8_MIN_WGS")) : C3_NT8_MIN_WGS;
+  const bool nt8 = kpc == 1 && c_out % 128 == 0 && ptc_cdiv(n_out, 256) * (c_out / 128) >= nt8_min;
+  if (nt8) {
+    if (nbr == nullptr) return launch_conv3_i<T, 4, 1, 8, false, true>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+    return launch_conv3_i<T, 4, 1, 8, false>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  }
+#endif
   if (nbr == nullptr) {   // dense GEMM (kv = 1, c_in % 128 == 0): identity-table instances
 #define C3_ID_CASE(N)                                                                                                        \
   if (nt == N)                                                                                                             \

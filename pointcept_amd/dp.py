@@ -37,6 +37,63 @@ def init_distributed(backend: str | None = None, device: torch.device | None = N
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
 
 
+def _parse_cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def _gpu_local_cores(index: int) -> List[int] | None:
+    """cores of the NUMA node the GPU hangs off (sysfs `local_cpulist` of its PCI function), None when unknown"""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+            return _parse_cpulist(f.read()) or None
+    except Exception:
+        return None
+
+
+def rank_core_share(local_rank: int, local_world: int, allowed: List[int], numa_cores: List[List[int] | None] | None = None,
+                    reserve: int = 0) -> List[int]:
+    """The cores rank `local_rank` of `local_world` ranks on this node may run on: the cores of its GPU's NUMA node (`numa_cores[r]`,
+    restricted to `allowed`) divided evenly among the ranks that share that node, or an even slice of `allowed` when the
+    topology is unknown.  Pure function of its arguments (tests/test_dp_gloo.py); disjoint across ranks by construction."""
+    allowed = sorted(allowed)
+    if numa_cores is not None and all(c for c in numa_cores):
+        mine = [c for c in numa_cores[local_rank] if c in set(allowed)]
+        peers = [r for r in range(local_world) if numa_cores[r] == numa_cores[local_rank]]
+        if mine and len(mine) >= len(peers):
+            per = len(mine) // len(peers)
+            k = peers.index(local_rank)
+            return mine[k * per:(k + 1) * per]
+    per = max(1, len(allowed) // max(1, local_world))
+    lo = (local_rank * per) % len(allowed)
+    return allowed[lo:lo + per] or allowed
+
+
+def pin_rank_to_cores(local_rank: int, local_world: int, max_threads: int = 8) -> dict:
+    """One Python process per GPU shares the host (pointcept/engines/train.py:185-246 under launch.py:106-136): give every rank its own
+    NUMA-local cores and a bounded intra-op thread pool, so that eight enqueue threads (~25 ms of one core per step each) and their
+    OpenMP / ATen pools do not migrate across sockets or oversubscribe each other.  Returns what was done (goes into bench.py's line)."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return {"pinned": False}
+    allowed = sorted(os.sched_getaffinity(0))
+    numa = None
+    if torch.cuda.is_available() and torch.cuda.device_count() >= local_world:
+        numa = [_gpu_local_cores(r) for r in range(local_world)]
+    cores = rank_core_share(local_rank, local_world, allowed, numa)
+    os.sched_setaffinity(0, cores)
+    nt = max(1, min(max_threads, len(cores)))
+    os.environ["OMP_NUM_THREADS"] = str(nt)
+    torch.set_num_threads(nt)
+    return {"pinned": True, "cores": len(cores), "first_core": cores[0], "numa_local": bool(numa and all(numa)), "threads": nt}
+
+
 def wrap_ddp(model: torch.nn.Module, device: torch.device, bucket_cap_mb: int = 25,
              find_unused_parameters: bool = False) -> torch.nn.Module:
     """DDP wrapper (defaults.py:22-43 semantics: broadcast_buffers=False, so BatchNorm statistics

@@ -252,6 +252,91 @@ def farthest_point_sampling(xyz, offset, new_offset):
 
 
 # ------------------------------------------------------------------------------------------------
+# edge-list operators of libs/pointops (grouping / interpolation / aggregation / subtraction): csrc/pointops_edges.hip
+# ------------------------------------------------------------------------------------------------
+def _f32_rows(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise PtcoreError(f"{name} must be float32 (the reference kernels are fp32-only)")
+    return t.contiguous()
+
+
+def _edge_idx(idx: torch.Tensor):
+    if idx.dim() != 2:
+        raise PtcoreError("idx must be [m, nsample]")
+    return idx.to(torch.int32).contiguous()
+
+
+def edge_rows(mode: int, src, a, idx, out=None, out_col0: int = 0):
+    """Per-edge rows (mode 0 src[j], 1 a[t] - src[j], 2 src[j] - a[t] with zeros for empty slots) -> out [m, nsample, c], or written
+    into the column window [out_col0, out_col0 + c) of a caller's wider `out` [m, nsample, width]."""
+    require_cuda(src, a, idx, out)
+    src, idx = _f32_rows(src, "src"), _edge_idx(idx)
+    a = None if a is None else _f32_rows(a, "a")
+    m, ns = idx.shape
+    c = src.shape[1]
+    if out is None:
+        out = torch.empty((m, ns, c), dtype=torch.float32, device=src.device)
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.shape[:2] != (m, ns):
+        raise PtcoreError("edge_rows: out must be a contiguous fp32 [m, nsample, width] tensor")
+    check(lib().ptc_edge_rows_fwd(int(mode), ptr(src), ptr(a), ptr(idx), m * ns, ns, c, src.shape[0], ptr(out), out.shape[2], int(out_col0),
+                                  stream_ptr()), "ptc_edge_rows_fwd")
+    return out
+
+
+def edge_reduce(mode: int, src, pos, w, idx, m: int, nsample: int, c: int, w_c: int = 1, pos_stride: int = 0, pos_col0: int = 0):
+    """Per-target sums over the nsample edges of a row -> [m, c] (mode 0 interpolation, 1 aggregation, 2 plain row sums of `pos`)."""
+    require_cuda(src, pos, w, idx)
+    out = torch.empty((m, c), dtype=torch.float32, device=(pos if src is None else src).device)
+    n_src = 0 if src is None else src.shape[0]
+    check(lib().ptc_edge_reduce_fwd(int(mode), ptr(src), ptr(pos), int(pos_stride), int(pos_col0), ptr(w), ptr(idx), int(m), int(nsample),
+                                    int(c), int(w_c), n_src, ptr(out), stream_ptr()), "ptc_edge_reduce_fwd")
+    return out
+
+
+class EdgeCSR:
+    """The edges of idx [m, nsample] sorted by source row (stable: ascending edge index inside a row) + the CSR pointer: what the
+    segmented, atomics-free gradients of the gathered operands walk.  Built on first use: the engine's radix sort over
+    bit_length(n_src) bits and two small kernels."""
+
+    def __init__(self, idx: torch.Tensor, n_src: int):
+        require_cuda(idx)
+        self.idx, self.n_src = _edge_idx(idx), int(n_src)
+        self.order = self.indptr = None
+
+    def build(self):
+        if self.order is None:
+            e = self.idx.numel()
+            keys = torch.empty(e, dtype=torch.int64, device=self.idx.device)
+            check(lib().ptc_edge_csr_keys(ptr(self.idx), e, self.n_src, ptr(keys), stream_ptr()), "ptc_edge_csr_keys")
+            self.order, _ = sort_keys(keys, 0, max(1, int(self.n_src).bit_length()), want_inverse=False) if e else (keys, None)
+            self.indptr = torch.empty(self.n_src + 1, dtype=torch.int64, device=self.idx.device)
+            check(lib().ptc_edge_csr_ptr(ptr(keys), ptr(self.order), e, self.n_src, ptr(self.indptr), stream_ptr()), "ptc_edge_csr_ptr")
+        return self
+
+
+def edge_scatter_bwd(mode: int, csr: EdgeCSR, g, w, nsample: int, c: int, w_c: int = 1, g_col0: int = 0):
+    """grad of the gathered operand [n_src, c]: segmented sum over the edges of every source row (fixed order, no atomics).
+    g: [E or m, width] rows (fp32, contiguous); the window [g_col0, g_col0 + c) of each row is summed."""
+    require_cuda(g, w)
+    csr.build()
+    g = _f32_rows(g, "grad").reshape(-1, g.shape[-1])
+    out = torch.empty((csr.n_src, c), dtype=torch.float32, device=g.device)
+    check(lib().ptc_edge_scatter_bwd(int(mode), ptr(csr.order), ptr(csr.indptr), ptr(g), g.shape[1], int(g_col0), ptr(w), int(nsample), int(c),
+                                     int(w_c), csr.n_src, ptr(out), stream_ptr()), "ptc_edge_scatter_bwd")
+    return out
+
+
+def aggregation_edge_bwd(src, pos, w, idx, g):
+    """-> (grad_position [m, nsample, c], grad_weight [m, nsample, w_c]) of libs/pointops aggregation."""
+    require_cuda(src, pos, w, idx, g)
+    m, ns, c = pos.shape
+    gp, gw = torch.empty_like(pos), torch.empty_like(w)
+    check(lib().ptc_aggregation_edge_bwd(ptr(src), ptr(pos), ptr(w), ptr(idx), ptr(g), m, ns, c, w.shape[-1], src.shape[0], ptr(gp), ptr(gw),
+                                         stream_ptr()), "ptc_aggregation_edge_bwd")
+    return gp, gw
+
+
+# ------------------------------------------------------------------------------------------------
 # rows
 # ------------------------------------------------------------------------------------------------
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, idx2: Optional[torch.Tensor] = None) -> torch.Tensor:

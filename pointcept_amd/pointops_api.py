@@ -6,8 +6,8 @@ datasets/modelnet.py:100).  Same names, argument order and return conventions; `
 
     knn_query(nsample, xyz, offset, new_xyz=None, new_offset=None) -> (idx [m, nsample] int32, dist [m, nsample] fp32)
     farthest_point_sampling(xyz, offset, new_offset)                 -> idx [new_offset[-1]] int32
-    grouping(idx, feat, xyz, new_xyz=None, with_xyz=False)            -> [m, nsample, c (+3)]   (differentiable gather)
-    interpolation(xyz, new_xyz, feat, offset, new_offset, k=3)        -> [n, c]  inverse-distance weights over k-NN
+    grouping(idx, feat, xyz, new_xyz=None, with_xyz=False)            -> [m, nsample, c (+3)]   HIP (pointops_edges.hip), fwd + bwd
+    interpolation(xyz, new_xyz, feat, offset, new_offset, k=3)        -> [n, c]  inverse-distance weights over k-NN; HIP fwd + bwd
     knn_query_and_group(feat, xyz, offset, new_xyz, new_offset, idx=None, nsample=None, with_xyz=False)
     ball_query_and_group(...), query_and_group(nsample, xyz, new_xyz, feat, idx, offset, new_offset, dilation=0, ...)  (utils.py)
     grouping2(input, idx), interpolation2(xyz, new_xyz, input, offset, new_offset, k=3)
@@ -15,7 +15,9 @@ datasets/modelnet.py:100).  Same names, argument order and return conventions; `
 
     ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None)  -> (idx, dist)   HIP (pointops.hip)
     random_ball_query(..., order=None)                                                          -> (idx, dist)   HIP
-    subtraction / aggregation / attention_relation_step / attention_fusion_step (PTv1 / PTv2)  differentiable torch / segment ops
+    subtraction / aggregation (PTv1)                                                            HIP (pointops_edges.hip), fwd + bwd,
+                                                                                                 gradients as segmented sums (no atomics)
+    attention_relation_step / attention_fusion_step (PTv2)                                      differentiable torch / segment ops
 
 Tie order (equal distances: lower index first) is fixed here and implementation-defined in the reference.
 """
@@ -38,32 +40,78 @@ def farthest_point_sampling(xyz, offset, new_offset):
     return ops.farthest_point_sampling(xyz, offset, new_offset)
 
 
+class _EdgeGather(torch.autograd.Function):
+    """out[t, s] = [xyz[j] - new_xyz[t] |] feat[j] for j = idx[t, s] (zeros for j < 0): ptc_edge_rows_fwd; every gradient a segmented sum
+    over the edges sorted by source row (ptc_edge_scatter_bwd): fixed order, where grouping_backward_cuda scatters with atomicAdd."""
+
+    @staticmethod
+    def forward(ctx, feat, xyz, new_xyz, idx):
+        idx = idx.to(torch.int32).contiguous()
+        m, ns = idx.shape
+        c = feat.shape[1]
+        f32 = feat.float()
+        if xyz is None:
+            out = ops.edge_rows(0, f32, None, idx)
+        else:
+            out = torch.empty((m, ns, 3 + c), dtype=torch.float32, device=feat.device)
+            ops.edge_rows(2, xyz.float(), new_xyz.float(), idx, out=out, out_col0=0)
+            ops.edge_rows(0, f32, None, idx, out=out, out_col0=3)
+        ctx.save_for_backward(idx)
+        ctx.meta = (feat.shape[0], c, xyz is not None, None if xyz is None else xyz.shape[0], feat.dtype)
+        return out.to(feat.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        n, c, with_xyz, n_xyz, dtype = ctx.meta
+        m, ns = idx.shape
+        g = g.float().contiguous()
+        col0 = 3 if with_xyz else 0
+        d_feat = d_xyz = d_new = None
+        if ctx.needs_input_grad[0]:
+            d_feat = ops.edge_scatter_bwd(0, ops.EdgeCSR(idx, n), g, None, ns, c, g_col0=col0).to(dtype)
+        if with_xyz and ctx.needs_input_grad[1]:
+            d_xyz = ops.edge_scatter_bwd(0, ops.EdgeCSR(idx, n_xyz), g, None, ns, 3, g_col0=0)
+        if with_xyz and ctx.needs_input_grad[2]:
+            d_new = -ops.edge_reduce(2, None, g, None, idx, m, ns, 3, pos_stride=g.shape[-1], pos_col0=0)
+        return d_feat, d_xyz, d_new, None
+
+
 def grouping(idx, feat, xyz, new_xyz=None, with_xyz=False):
     """libs/pointops/functions/grouping.py:44-68: rows gathered by idx (-1 -> zeros); with_xyz prepends the neighbour
-    offsets xyz[idx] - new_xyz (zeroed for -1 slots)."""
+    offsets xyz[idx] - new_xyz (zeroed for -1 slots).  One kernel per operand, written straight into the [m, nsample, 3 + c] result."""
     if new_xyz is None:
         new_xyz = xyz
-    m, nsample, c = idx.shape[0], idx.shape[1], feat.shape[1]
-    flat = idx.reshape(-1).long()
-    present = (flat >= 0)
-    safe = flat.clamp(min=0)
-    grouped_feat = (feat[safe] * present[:, None].to(feat.dtype)).view(m, nsample, c)
-    if not with_xyz:
-        return grouped_feat
-    grouped_xyz = (xyz[safe] * present[:, None].to(xyz.dtype)).view(m, nsample, 3) - new_xyz.unsqueeze(1)
-    grouped_xyz = grouped_xyz * present.view(m, nsample, 1).to(xyz.dtype)
-    return torch.cat((grouped_xyz, grouped_feat), -1)
+    if with_xyz:
+        return _EdgeGather.apply(feat, xyz, new_xyz, idx)
+    return _EdgeGather.apply(feat, None, None, idx)
+
+
+class _EdgeInterpolate(torch.autograd.Function):
+    """out[t] = sum_i weight[t, i] feat[idx[t, i]] (interpolation_forward_cuda); gradient of feat = segmented sum over the edges sorted by
+    source row (interpolation_backward_cuda without its atomics).  The weights are constants of the geometry (interpolation.py:30-61)."""
+
+    @staticmethod
+    def forward(ctx, feat, idx, weight):
+        idx = idx.to(torch.int32).contiguous()
+        weight = weight.float().contiguous()
+        ctx.save_for_backward(idx, weight)
+        ctx.meta = (feat.shape[0], feat.shape[1])
+        return ops.edge_reduce(0, feat.float().contiguous(), None, weight, idx, idx.shape[0], idx.shape[1], feat.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, weight = ctx.saved_tensors
+        n, c = ctx.meta
+        return ops.edge_scatter_bwd(2, ops.EdgeCSR(idx, n), g.float().contiguous(), weight, idx.shape[1], c), None, None
 
 
 def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
-    """libs/pointops/functions/interpolation.py:8-27: inverse-distance weighting over the k nearest source points."""
+    """libs/pointops/functions/interpolation.py:8-27: inverse-distance weighting over the k nearest source points (fp32 result)."""
     idx, dist = knn_query(k, xyz, offset, new_xyz, new_offset)
     recip = 1.0 / (dist + 1e-8)
     weight = recip / recip.sum(dim=1, keepdim=True)
-    out = torch.zeros((new_xyz.shape[0], feat.shape[1]), dtype=torch.float32, device=xyz.device)
-    for i in range(k):
-        out = out + feat[idx[:, i].long(), :] * weight[:, i].unsqueeze(-1)
-    return out
+    return _EdgeInterpolate.apply(feat, idx, weight)
 
 
 def knn_query_and_group(feat, xyz, offset=None, new_xyz=None, new_offset=None, idx=None, nsample=None, with_xyz=False):
@@ -75,9 +123,8 @@ def knn_query_and_group(feat, xyz, offset=None, new_xyz=None, new_offset=None, i
 
 def grouping2(input, idx):
     """libs/pointops/functions/grouping.py:5-63 (`Grouping.apply`): input [n, c], idx [m, nsample] -> [m, nsample, c]; the
-    custom CUDA backward (atomicAdd scatter) is torch's index backward here."""
-    m, nsample = idx.shape
-    return input[idx.reshape(-1).long()].view(m, nsample, input.shape[1])
+    custom CUDA backward (atomicAdd scatter) is the segmented sum of `_EdgeGather` here."""
+    return _EdgeGather.apply(input, None, None, idx)
 
 
 def interpolation2(xyz, new_xyz, input, offset, new_offset, k=3):
@@ -116,13 +163,9 @@ def query_and_group(nsample, xyz, new_xyz, feat, idx, offset, new_offset, dilati
         idx = torch.cat(parts, dim=0)
     if not with_feat:
         return idx
-    m, c = new_xyz.shape[0], feat.shape[1]
-    flat = idx.reshape(-1).long()
-    grouped_feat = feat[flat].view(m, nsample, c)
     if with_xyz:
-        grouped_xyz = xyz[flat].view(m, nsample, 3) - new_xyz.unsqueeze(1)
-        return torch.cat((grouped_xyz, grouped_feat), -1), idx
-    return grouped_feat, idx
+        return _EdgeGather.apply(feat, xyz, new_xyz, idx), idx
+    return _EdgeGather.apply(feat, None, None, idx), idx
 
 
 def ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None):
@@ -148,22 +191,55 @@ def random_ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz=None
     return ops.ball_query(int(nsample), max_radius, min_radius, xyz, offset, new_xyz, new_offset, order=order)
 
 
+class _EdgeSubtract(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input1, input2, idx):
+        idx = idx.to(torch.int32).contiguous()
+        ctx.save_for_backward(idx)
+        ctx.meta = (input2.shape[0], input1.shape[1])
+        return ops.edge_rows(1, input2.float().contiguous(), input1.float().contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        n2, c = ctx.meta
+        m, ns = idx.shape
+        g = g.float().contiguous()
+        d1 = ops.edge_reduce(2, None, g, None, None, m, ns, c, pos_stride=c, pos_col0=0) if ctx.needs_input_grad[0] else None
+        d2 = ops.edge_scatter_bwd(1, ops.EdgeCSR(idx, n2), g, None, ns, c) if ctx.needs_input_grad[1] else None
+        return d1, d2, None
+
+
 def subtraction(input1, input2, idx):
-    """libs/pointops/functions/subtraction.py / src/subtraction/subtraction_cuda_kernel.cu:5-30:
-    out[n, s, :] = input1[n, :] - input2[idx[n, s], :]   (differentiable; the CUDA backward scatters with atomics, torch's
-    index backward here)."""
-    n, ns = idx.shape
-    return input1.unsqueeze(1) - input2[idx.reshape(-1).long()].view(n, ns, -1)
+    """libs/pointops/functions/subtraction.py / src/subtraction/subtraction_cuda_kernel.cu:5-36:
+    out[n, s, :] = input1[n, :] - input2[idx[n, s], :]; backward: row sums for input1, the negated segmented sum over the edges of every
+    source row for input2 (the CUDA backward scatters both with atomicAdd)."""
+    return _EdgeSubtract.apply(input1, input2, idx)
+
+
+class _EdgeAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, position, weight, idx):
+        idx = idx.to(torch.int32).contiguous()
+        input, position, weight = input.float().contiguous(), position.float().contiguous(), weight.float().contiguous()
+        n, ns, c = position.shape
+        ctx.save_for_backward(input, position, weight, idx)
+        return ops.edge_reduce(1, input, position, weight, idx, n, ns, c, w_c=weight.shape[-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        input, position, weight, idx = ctx.saved_tensors
+        n, ns, c = position.shape
+        g = g.float().contiguous()
+        d_in = ops.edge_scatter_bwd(3, ops.EdgeCSR(idx, input.shape[0]), g, weight, ns, c, w_c=weight.shape[-1]) if ctx.needs_input_grad[0] else None
+        d_pos, d_w = ops.aggregation_edge_bwd(input, position, weight, idx, g)
+        return d_in, d_pos, d_w, None
 
 
 def aggregation(input, position, weight, idx):
-    """libs/pointops/functions/aggregation.py / src/aggregation/aggregation_cuda_kernel.cu:5-39 (PTv1 vector attention):
-    out[n, c] = sum_s (input[idx[n, s], c] + position[n, s, c]) * weight[n, s, c % w_c]."""
-    n, ns, c = position.shape
-    w_c = weight.shape[-1]
-    g = input[idx.reshape(-1).long()].view(n, ns, c) + position
-    w = weight.repeat(1, 1, c // w_c) if c != w_c else weight          # channel c uses weight column c % w_c
-    return (g * w).sum(1)
+    """libs/pointops/functions/aggregation.py / src/aggregation/aggregation_cuda_kernel.cu:5-45 (PTv1 vector attention):
+    out[n, c] = sum_s (input[idx[n, s], c] + position[n, s, c]) * weight[n, s, c % w_c]; three gradients, none of them atomic."""
+    return _EdgeAggregate.apply(input, position, weight, idx)
 
 
 def _csr_by_target(index_target, n):

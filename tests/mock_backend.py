@@ -156,7 +156,7 @@ def spconv_fwd(feat, weight, bias, nbr, blk=None):
     return out.to(feat.dtype)
 
 
-def spconv_wgrad(feat, dout, nbr, want_bias=False):
+def spconv_wgrad(feat, dout, nbr, want_bias=False, blk=None):
     f, g = feat.float(), dout.float()
     if nbr is None:
         dw = (g.t() @ f)[:, None, :]
@@ -300,6 +300,74 @@ def voxel_keys(coord, grid_size):
             torch.from_numpy(v["key"].view(np.int64).copy()))
 
 
+# ---- edge-list operators of libs/pointops (csrc/pointops_edges.hip): plain torch restatements of the reference kernels' sums
+def _edge_src_rows(src, idx):
+    flat = idx.reshape(-1).long()
+    ok = (flat >= 0) & (flat < src.shape[0])
+    return src[flat.clamp(0, max(src.shape[0] - 1, 0))] * ok[:, None].to(src.dtype), ok
+
+
+def edge_rows(mode, src, a, idx, out=None, out_col0=0):
+    m, ns = idx.shape
+    c = src.shape[1]
+    rows, ok = _edge_src_rows(src.float(), idx)
+    rows = rows.view(m, ns, c)
+    if mode == 1:
+        rows = a.float()[:, None, :] - rows
+    elif mode == 2:
+        rows = (rows - a.float()[:, None, :]) * ok.view(m, ns, 1).float()
+    if out is None:
+        return rows.contiguous()
+    out[:, :, out_col0:out_col0 + c] = rows
+    return out
+
+
+def edge_reduce(mode, src, pos, w, idx, m, nsample, c, w_c=1, pos_stride=0, pos_col0=0):
+    if mode == 2:
+        g = pos.reshape(m, nsample, -1)[:, :, pos_col0:pos_col0 + c].float()
+        if idx is not None:
+            g = g * (idx.reshape(m, nsample, 1) >= 0).float()
+        return g.sum(1)
+    rows, _ = _edge_src_rows(src.float(), idx)
+    rows = rows.view(m, nsample, c)
+    if mode == 0:
+        return (rows * w.float().view(m, nsample, 1)).sum(1)
+    return ((rows + pos.float()) * w.float().repeat(1, 1, c // w_c)).sum(1)
+
+
+class EdgeCSR:
+    def __init__(self, idx, n_src):
+        self.idx, self.n_src = idx.to(torch.int32), int(n_src)
+
+    def build(self):
+        return self
+
+
+def edge_scatter_bwd(mode, csr, g, w, nsample, c, w_c=1, g_col0=0):
+    idx = csr.idx.reshape(-1).long()
+    g = g.float().reshape(-1, g.shape[-1])[:, g_col0:g_col0 + c]
+    if mode >= 2:
+        g = g.repeat_interleave(nsample, dim=0)
+    if mode == 1:
+        g = -g
+    elif mode == 2:
+        g = g * w.float().reshape(-1, 1)
+    elif mode == 3:
+        g = g * w.float().reshape(-1, w_c).repeat(1, c // w_c)
+    ok = (idx >= 0) & (idx < csr.n_src)
+    return torch.zeros(csr.n_src, c, dtype=torch.float32).index_add_(0, idx[ok], g[ok])
+
+
+def aggregation_edge_bwd(src, pos, w, idx, g):
+    m, ns, c = pos.shape
+    w_c = w.shape[-1]
+    rows, _ = _edge_src_rows(src.float(), idx)
+    x = rows.view(m, ns, c) + pos.float()
+    gp = g.float()[:, None, :] * w.float().repeat(1, 1, c // w_c)
+    gw = (g.float()[:, None, :] * x).view(m, ns, c // w_c, w_c).sum(2)
+    return gp, gw
+
+
 _STANDINS = dict(
     coord_max=coord_max, serialize_encode=serialize_encode, sort_keys=sort_keys, patch_pad_maps=patch_pad_maps,
     attn_tables=attn_tables, pool_level_counts=pool_level_counts, pool_maps=pool_maps, pool_child_codes=pool_child_codes,
@@ -309,6 +377,7 @@ _STANDINS = dict(
     farthest_point_sampling=farthest_point_sampling, pair_dot_fwd=pair_dot_fwd, pair_dot_bwd=pair_dot_bwd,
     pair_aggregate_fwd=pair_aggregate_fwd, pair_aggregate_bwd=pair_aggregate_bwd,
     attn_hd_supported=lambda d, k: 16 <= d <= 64 and k <= (1024 if d <= 32 else 672 if d <= 48 else 512),
+    edge_rows=edge_rows, edge_reduce=edge_reduce, EdgeCSR=EdgeCSR, edge_scatter_bwd=edge_scatter_bwd, aggregation_edge_bwd=aggregation_edge_bwd,
     cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum, voxel_keys=voxel_keys,
     layer_norm_supported=lambda c: False, batch_norm_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)
 

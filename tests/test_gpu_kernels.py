@@ -304,7 +304,8 @@ def test_spconv_fwd_and_wgrad(cuda, dtype, cin, cout, ksize):
     (32, 64, 3, 1300), (64, 64, 3, 1300), (64, 128, 3, 1300), (128, 128, 3, 1300), (256, 64, 3, 1300), (512, 128, 3, 1300),
     (64, 128, 2, 1300), (128, 64, 5, 1300), (32, 32, 3, 1300), (96, 96, 3, 1300), (128, 96, 3, 1300), (160, 32, 3, 1300),
     (192, 64, 2, 1300), (64, 32, 3, 1300), (64, 96, 3, 1300), (32, 96, 3, 1300), (32, 64, 5, 1300), (128, 64, 2, 1300),
-    (128, 128, 3, 17000), (96, 96, 3, 34000), (128, 96, 3, 34000), (160, 32, 3, 34000), (256, 64, 3, 34000)])
+    (128, 128, 3, 17000), (96, 96, 3, 34000), (128, 96, 3, 34000), (160, 32, 3, 34000), (256, 64, 3, 34000),
+    (256, 256, 3, 34000), (128, 128, 3, 72000)])      # the last two: 128-column workgroups (conv3 NTILES = 8, round 4)
 def test_spconv_fwd_chunked_pipeline(cuda, cin, cout, ksize, n_pts):
     """conv3 (double-buffered W chunks, fragment-order LDS, gather ring: c_in >= 96) and conv5 (whole-row coalesced gathers
     through swizzled wave-private tile images: c_in = 32 / 64): every chunking case (4 / 2 / 1 table rows per 128-channel
@@ -629,7 +630,8 @@ def test_spconv_down_up_tables(cuda):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("n,cin,cout", [(1, 32, 96), (5000, 32, 96), (3001, 64, 192), (777, 128, 512), (300, 512, 2048),
                                         (900, 2048, 512), (2500, 64, 20), (4100, 6, 32), (2821, 512, 1536), (12115, 1024, 256),
-                                        (50360, 512, 128), (2821, 512, 512), (70000, 256, 1024)])
+                                        (50360, 512, 128), (2821, 512, 512), (70000, 256, 1024),
+                                        (16500, 512, 512)])    # 65 x 4 wide (128-column) workgroups: conv3's NTILES = 8 instance, forward and dgrad
 def test_linear_identity_table(cuda, dtype, n, cin, cout):
     """PF.linear == F.linear (forward, input / weight / bias gradients) incl. channel padding; the contractions wider than 256 (the
     last cases = the qkv / fc2 / proj / fc1-dgrad shapes of PT-v3m1's 128 .. 512-channel stages) run on the identity-table instances of
@@ -1599,6 +1601,88 @@ def test_pointops_fps_grouping_interpolation(cuda):
     assert up.shape == (sum(sizes), 5)
     assert torch.allclose(up[got.long()], vals, atol=1e-4)
     assert float(up.abs().max()) <= float(vals.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("c,w_c", [(8, 4), (3, 1), (32, 8), (6, 2), (64, 64)])
+def test_pointops_edge_operators(cuda, c, w_c):
+    """grouping / interpolation / aggregation / subtraction on their kernels (csrc/pointops_edges.hip) against the restatements of the
+    reference's CUDA kernels (oracle/pointops_c.py: C++ signatures, in-place outputs), forward and every gradient; -1 slots, repeated
+    sources, channel counts that are not multiples of 4, gradients bit-reproducible (segmented sums, no atomics)."""
+    from oracle import pointops_c as R
+    from pointcept_amd import pointops_api as po
+
+    g = torch.Generator().manual_seed(100 * c + w_c)
+    n, m, ns = 700, 333, 7
+    idx = torch.randint(0, n, (m, ns), generator=g).int()
+    idx[::5, 3] = idx[::5, 2]                                   # repeated sources inside a row
+    holes = idx.clone()
+    holes[torch.rand(m, ns, generator=g) < 0.15] = -1           # empty neighbour slots
+    feat, xyz, new_xyz = torch.randn(n, c, generator=g), torch.rand(n, 3, generator=g), torch.rand(m, 3, generator=g)
+
+    def run(fn, *tensors):
+        leaves = [t.clone().to(cuda).requires_grad_(True) for t in tensors]
+        out = fn(*leaves)
+        probe = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(cuda)
+        (out * probe).sum().backward()
+        return out.detach().cpu(), [t.grad.cpu() for t in leaves], probe.cpu()
+
+    def close(name, a, b, tol=1e-5):
+        assert a.shape == b.shape and a.dtype == b.dtype, (name, a.shape, b.shape, a.dtype, b.dtype)
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), name
+
+    # grouping with holes and relative coordinates (functions/grouping.py:44-68 on grouping_forward_cuda)
+    out, (df, dx, dn), probe = run(lambda f, x, q: po.grouping(holes.to(cuda), f, x, q, with_xyz=True), feat, xyz, new_xyz)
+    mask = (holes >= 0).float()[:, :, None]
+    safe = holes.clamp(min=0)
+    want = torch.zeros(m, ns, c)
+    R.grouping_forward_cuda(m, ns, c, feat, safe, want)
+    want_xyz = torch.zeros(m, ns, 3)
+    R.grouping_forward_cuda(m, ns, 3, xyz, safe, want_xyz)
+    want = torch.cat([(want_xyz - new_xyz[:, None, :]) * mask, want * mask], -1)
+    close("grouping", out, want, 0.0)
+    gf, gx = torch.zeros(n, c), torch.zeros(n, 3)
+    R.grouping_backward_cuda(m, ns, c, (probe[:, :, 3:] * mask).contiguous(), safe, gf)
+    R.grouping_backward_cuda(m, ns, 3, (probe[:, :, :3] * mask).contiguous(), safe, gx)
+    close("grouping d_feat", df, gf)
+    close("grouping d_xyz", dx, gx)
+    close("grouping d_new_xyz", dn, -(probe[:, :, :3] * mask).sum(1))
+    out2, (df2,), _ = run(lambda f: po.grouping2(f, idx.to(cuda)), feat)
+    want = torch.zeros(m, ns, c)
+    R.grouping_forward_cuda(m, ns, c, feat, idx, want)
+    close("grouping2", out2, want, 0.0)
+    again = run(lambda f: po.grouping2(f, idx.to(cuda)), feat)[1][0]
+    assert torch.equal(df2, again), "segmented-sum gradients must be bit-reproducible"
+
+    # interpolation (interpolation_forward / backward_cuda) through its Function with explicit weights
+    wgt = torch.rand(m, ns, generator=g)
+    out, (df,), probe = run(lambda f: po._EdgeInterpolate.apply(f, idx.to(cuda), wgt.to(cuda)), feat)
+    want, gf = torch.zeros(m, c), torch.zeros(n, c)
+    R.interpolation_forward_cuda(m, c, ns, feat, idx, wgt, want)
+    R.interpolation_backward_cuda(m, c, ns, probe, idx, wgt, gf)
+    close("interpolation", out, want)
+    close("interpolation d_feat", df, gf)
+
+    # subtraction
+    a = torch.randn(m, c, generator=g)
+    out, (d1, d2), probe = run(lambda x, y: po.subtraction(x, y, idx.to(cuda)), a, feat)
+    want, g1, g2 = torch.zeros(m, ns, c), torch.zeros(m, c), torch.zeros(n, c)
+    R.subtraction_forward_cuda(m, ns, c, a, feat, idx, want)
+    R.subtraction_backward_cuda(m, ns, c, idx, probe, g1, g2)
+    close("subtraction", out, want, 0.0)
+    close("subtraction d1", d1, g1)
+    close("subtraction d2", d2, g2)
+
+    # aggregation (PTv1 vector attention): c channels share w_c weight columns
+    pos, w = torch.randn(m, ns, c, generator=g), torch.randn(m, ns, w_c, generator=g)
+    idx_a = idx % m                                           # aggregation gathers from its own [m, c] input
+    out, (di, dp, dw), probe = run(lambda x, p, q: po.aggregation(x, p, q, idx_a.to(cuda)), a, pos, w)
+    want, gi, gp, gw = torch.zeros(m, c), torch.zeros(m, c), torch.zeros(m, ns, c), torch.zeros(m, ns, w_c)
+    R.aggregation_forward_cuda(m, ns, c, w_c, a, pos, w, idx_a, want)
+    R.aggregation_backward_cuda(m, ns, c, w_c, a, pos, w, idx_a, probe, gi, gp, gw)
+    close("aggregation", out, want)
+    close("aggregation d_input", di, gi)
+    close("aggregation d_position", dp, gp)
+    close("aggregation d_weight", dw, gw)
 
 
 def test_pointops_through_compat_and_unsupported(cuda):

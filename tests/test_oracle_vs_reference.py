@@ -342,11 +342,18 @@ def test_pointops_mirror_names_arguments_and_python_helpers(monkeypatch):
     monkeypatch.setattr(p1, "knn_query", knn)
     monkeypatch.setattr(p1, "ball_query", ball)
 
+    import mock_backend
+
     g = torch.Generator().manual_seed(2)
     xyz = torch.rand(260, 3, generator=g)
     feat = torch.randn(260, 5, generator=g)
     offset = torch.tensor([200, 212, 260], dtype=torch.int32)           # the middle scene (12 points) triggers the soft dilation
     new_xyz, new_offset = xyz[::4].contiguous(), torch.tensor([50, 53, 65], dtype=torch.int32)
+    with mock_backend.cpu_ops():        # the mirror's gathers are kernels (csrc/pointops_edges.hip): CPU stand-ins behind ops.*
+        _helpers_body(ref, p1, xyz, new_xyz, feat, offset, new_offset)
+
+
+def _helpers_body(ref, p1, xyz, new_xyz, feat, offset, new_offset):
     for dil in (0, 1, 2):
         a, ia = ref.query_and_group(8, xyz, new_xyz, feat, None, offset, new_offset, dilation=dil)
         b, ib = p1.query_and_group(8, xyz, new_xyz, feat, None, offset, new_offset, dilation=dil)
@@ -465,10 +472,10 @@ def test_pointops_mirror_against_the_reference_python_package():
         outs, grads = [], []
         for T in (P, M):
             leaves = [t.clone().requires_grad_(True) for t in tensors]
-            with mock_backend.cpu_ops():
+            with mock_backend.cpu_ops():          # forward AND backward: the mirror's gradients are kernels too (segmented sums)
                 o = fn(T, *leaves)
-            probe = torch.randn(o.shape, generator=torch.Generator().manual_seed(1))
-            (o * probe).sum().backward()
+                probe = torch.randn(o.shape, generator=torch.Generator().manual_seed(1))
+                (o * probe).sum().backward()
             outs.append(o.detach())
             grads.append([t.grad for t in leaves])
         same(outs[0], outs[1], 1e-6)

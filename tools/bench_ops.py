@@ -152,21 +152,25 @@ def bench_spconv(rows, results, scenes=8, points=102400):
     results.append(r)
 
 
-def bench_spconv_stages(rows, results, scenes=8, points=102400):
+def bench_spconv_stages(rows, results, scenes=8, points=102400, outdoor=False):
     """CPE convolution (k=3 SubM, C -> C) forward at the five PTv3 stages of the bench batch, rows in
     Hilbert order as in the model (config.SORT_POINTS), conv2 vs conv3."""
     from pointcept_amd import synthetic
 
-    b = synthetic.to_torch(synthetic.indoor_batch(scenes, points), DEV)
+    if outdoor:   # BASELINE configs[4]: LiDAR sweeps on a depth-12 grid; pooling thins these scenes far less than the indoor ones
+        b = synthetic.to_torch(synthetic.collate([synthetic.outdoor_scene(5000 + i, azimuth_steps=3300) for i in range(scenes)]), DEV)
+    else:
+        b = synthetic.to_torch(synthetic.indoor_batch(scenes, points), DEV)
+    depth = 12 if outdoor else 8
     batch = torch.repeat_interleave(torch.arange(scenes, device=DEV), torch.diff(b["offset"], prepend=b["offset"].new_zeros(1)))
     gc = b["grid_coord"]
-    for s, chans in enumerate(((32, 64, (128, 96), 96), (64, 32, 128), (128,), (256,), (512,))):
+    for s, chans in enumerate(((32, 64), (64,), (128,), (256,), (512,)) if outdoor else ((32, 64, (128, 96), 96), (64, 32, 128), (128,), (256,), (512,))):
         key = (batch << 48) | ((gc[:, 0] >> s) << 32) | ((gc[:, 1] >> s) << 16) | (gc[:, 2] >> s)
         uk = torch.unique(key)
         bb = uk >> 48
         cc = torch.stack([(uk >> 32) & 0xffff, (uk >> 16) & 0xffff, uk & 0xffff], 1)
-        code = ops.serialize_encode(cc, bb, 8 - s, ("hilbert",))
-        order, _ = ops.sort_keys(code, 0, 3 * (8 - s) + 3)
+        code = ops.serialize_encode(cc, bb, depth - s, ("hilbert",))
+        order, _ = ops.sort_keys(code, 0, 3 * (depth - s) + 3)
         cc, bb = cc[order[0]], bb[order[0]]
         ind = torch.cat([bb[:, None].int(), cc.int()], 1).contiguous()
         n = ind.shape[0]
@@ -380,6 +384,11 @@ def main():
         bench_spconv(rows, res["spconv"])
     if want("stages"):
         bench_spconv_stages(rows, res["stages"])
+    if "stages_outdoor" in only:   # the same table on the LiDAR geometry of BASELINE configs[4] (deep stages keep 19-43 % of the voxels) + its dense Linears
+        bench_spconv_stages(rows, res["stages"], outdoor=True)
+        for n, c in ((437000, 256), (274000, 512)):
+            for cin, cout in ((c, 3 * c), (c, c), (c, 4 * c), (4 * c, c)):
+                bench_linear(rows, n, cin, cout, res["linear"])
     if want("losses"):
         bench_losses(rows, res["losses"])
     if want("front"):

@@ -42,10 +42,24 @@ for sec in "$@"; do
           cd $R; TOP=30 python tools/prof_top.py $O/${TAG}_profsp 5 $O/${TAG}_spunet_kernel_stats.csv > $O/${TAG}_profsp_top.log 2>&1; rm -rf $O/${TAG}_profsp;;
     ab:*) envs=$(echo "${sec#ab:}" | tr ',' ' '); name=$(echo "${sec#ab:}" | tr -c 'A-Za-z0-9=\n' '_');
           env $envs timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_${name}.log 2>&1; echo "$sec: $(tail -1 $O/${TAG}_bench_${name}.log | cut -c1-200)";;
+    abo:*) envs=$(echo "${sec#abo:}" | tr ',' ' '); name=$(echo "${sec#abo:}" | tr -c 'A-Za-z0-9=\n' '_');
+          env $envs timeout 600 python bench.py --model ptv3-outdoor --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --no-fp16-recipe > $O/${TAG}_outdoor_${name}.log 2>&1; echo "$sec: $(tail -1 $O/${TAG}_outdoor_${name}.log | cut -c1-260)";;
+    abs:*) envs=$(echo "${sec#abs:}" | tr ',' ' '); name=$(echo "${sec#abs:}" | tr -c 'A-Za-z0-9=\n' '_');
+          env $envs timeout 600 python bench.py --model spunet --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_spunet_${name}.log 2>&1; echo "$sec: $(tail -1 $O/${TAG}_spunet_${name}.log | cut -c1-260)";;
     prof) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_prof.log 2>&1
           timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof7 -- python $R/bench.py --steps 7 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_prof7.log 2>&1
           cd $R; TOP=30 python tools/steady_state_stats.py $O/${TAG}_prof 3 $O/${TAG}_prof7 7 $O/${TAG}_kernel_stats.csv > $O/${TAG}_prof_top.log 2>&1
           python tools/kernel_neighbours.py $O/${TAG}_prof > $O/${TAG}_fill_copy_neighbours.txt 2>&1; rm -rf $O/${TAG}_prof $O/${TAG}_prof7; tail -1 $O/${TAG}_kernel_stats.csv;;
+    profoutdoor) cd /tmp; BA="--model ptv3-outdoor --no-cpu-baseline --no-secondary --no-fp16-recipe --warmup 1"
+          timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profo2 -- python $R/bench.py --steps 2 $BA > $O/${TAG}_profo2.log 2>&1
+          timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profo5 -- python $R/bench.py --steps 5 $BA > $O/${TAG}_profo5.log 2>&1
+          cd $R; TOP=40 python tools/steady_state_stats.py $O/${TAG}_profo2 2 $O/${TAG}_profo5 5 $O/${TAG}_outdoor_kernel_stats.csv > $O/${TAG}_profo_top.log 2>&1
+          rm -rf $O/${TAG}_profo2 $O/${TAG}_profo5; head -25 $O/${TAG}_outdoor_kernel_stats.csv | cut -c1-150; tail -1 $O/${TAG}_outdoor_kernel_stats.csv;;
+    traffic) cd /tmp; BA="--no-cpu-baseline --no-secondary --no-fp16-recipe --warmup 1"
+          for c in FETCH_SIZE WRITE_SIZE; do for k in 2 5; do
+            timeout 600 rocprofv3 --pmc $c -d $O/${TAG}_tr_${c}_$k -- python $R/bench.py --steps $k $BA > $O/${TAG}_tr_${c}_$k.log 2>&1; done; done
+          cd $R; TOP=45 python tools/step_traffic.py $O/${TAG}_tr_FETCH_SIZE_2 $O/${TAG}_tr_FETCH_SIZE_5 $O/${TAG}_tr_WRITE_SIZE_2 $O/${TAG}_tr_WRITE_SIZE_5 2 5 $O/${TAG}_step_traffic.txt > /dev/null 2>$O/${TAG}_step_traffic.err
+          rm -rf $O/${TAG}_tr_FETCH_SIZE_2 $O/${TAG}_tr_FETCH_SIZE_5 $O/${TAG}_tr_WRITE_SIZE_2 $O/${TAG}_tr_WRITE_SIZE_5; head -16 $O/${TAG}_step_traffic.txt;;
     profsmall) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profs -- python $R/bench.py --batch 2 --points 20000 --steps 3 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_profs.log 2>&1
           timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profs7 -- python $R/bench.py --batch 2 --points 20000 --steps 7 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_profs7.log 2>&1
           cd $R; TOP=30 python tools/steady_state_stats.py $O/${TAG}_profs 3 $O/${TAG}_profs7 7 $O/${TAG}_small_kernel_stats.csv > $O/${TAG}_profs_top.log 2>&1
