@@ -66,6 +66,32 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
+// F16 I/O (round 4): under the reference's fp16 autocast the call site casts its operands itself -- qkv.to(bfloat16) in front of the
+// bf16 kernel, feat.to(qkv.dtype) behind it (ptv3m1:209,215), and autograd the two gradients the other way.  Those four [N', 3 C] /
+// [N', C] passes (2.4 ms of the fp16 recipe's step, profiles/r03_v_fp16_recipe_kernel_stats.csv) live in the kernels' load / store
+// paths here: F16 = true reads f16 qkv / out / dout and rounds them to bf16 (RNE, what .to(bfloat16) does), and writes
+// f16(bf16(result)) -- bit for bit the tensors the reference's casts produce around a bf16 kernel.  The arithmetic stays bf16.
+typedef _Float16 at_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t at_f16x2_to_bf16x2(uint32_t w) {
+  at_h2 h;
+  __builtin_memcpy(&h, &w, 4);
+  return pack_bf16x2((float)h[0], (float)h[1]);
+}
+__device__ __forceinline__ uint32_t at_bf16x2_to_f16x2(uint32_t w) {
+  const at_h2 h = {(_Float16)__uint_as_float(w << 16), (_Float16)__uint_as_float(w & 0xffff0000u)};
+  uint32_t r;
+  __builtin_memcpy(&r, &h, 4);
+  return r;
+}
+template <bool F16> __device__ __forceinline__ uint4 at_in(uint4 v) {
+  if constexpr (F16) return make_uint4(at_f16x2_to_bf16x2(v.x), at_f16x2_to_bf16x2(v.y), at_f16x2_to_bf16x2(v.z), at_f16x2_to_bf16x2(v.w));
+  return v;
+}
+template <bool F16> __device__ __forceinline__ uint32_t at_out(uint32_t w) {
+  if constexpr (F16) return at_bf16x2_to_f16x2(w);
+  return w;
+}
+
 __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -105,10 +131,11 @@ __device__ __forceinline__ s16x8 make_frag(uint32_t a, uint32_t b, uint32_t c, u
   uint4 u = {a, b, c, d};
   return *reinterpret_cast<s16x8*>(&u);
 }
+template <bool F16 = false>
 __device__ __forceinline__ s16x8 ld_global_frag(const uint16_t* p, bool valid) {
-  s16x8 f = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (valid) f = *reinterpret_cast<const s16x8*>(p);
-  return f;
+  uint4 u = {0, 0, 0, 0};
+  if (valid) u = at_in<F16>(*reinterpret_cast<const uint4*>(p));
+  return *reinterpret_cast<s16x8*>(&u);
 }
 // x * c -> bf16 hi + bf16 lo (hi + lo = x*c to 2^-17 relative)
 __device__ __forceinline__ void split_scaled(s16x8 x, float c, s16x8& hi, s16x8& lo) {
@@ -129,6 +156,7 @@ __device__ __forceinline__ void split_scaled(s16x8 x, float c, s16x8& hi, s16x8&
 __device__ __forceinline__ int rm_off(int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
 
 // stage rows [0,Lp) (zeros beyond L) row-major; returns this thread's max over its rows of |row|^2
+template <bool F16 = false>
 __device__ __forceinline__ float stage_row_major(const uint16_t* __restrict__ src, int64_t row_stride, int L, int Lp,
                                                  unsigned char* lds) {
   float mx = 0.f;
@@ -136,8 +164,8 @@ __device__ __forceinline__ float stage_row_major(const uint16_t* __restrict__ sr
     uint4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
     if (row < L) {
       const uint4* p = reinterpret_cast<const uint4*>(src + (int64_t)row * row_stride);
-      v0 = p[0];
-      v1 = p[1];
+      v0 = at_in<F16>(p[0]);
+      v1 = at_in<F16>(p[1]);
     }
     *reinterpret_cast<uint4*>(lds + rm_off(row, 0)) = v0;
     *reinterpret_cast<uint4*>(lds + rm_off(row, 1)) = v1;
@@ -163,6 +191,7 @@ __device__ __forceinline__ int vt_pos(int key) {
   const int kk = key & 15;
   return (key & ~15) + 8 * ((kk >> 2) & 1) + (kk & 3) + 4 * (kk >> 3);
 }
+template <bool F16 = false>
 __device__ __forceinline__ void stage_transposed(const uint16_t* __restrict__ src, int64_t row_stride, int L, int Lp,
                                                  int pitch, unsigned char* lds) {
   uint32_t* t32 = reinterpret_cast<uint32_t*>(lds);
@@ -171,11 +200,11 @@ __device__ __forceinline__ void stage_transposed(const uint16_t* __restrict__ sr
     const int ra = 2 * p, rb = 2 * p + 1;
     if (ra < L) {
       const uint4* q = reinterpret_cast<const uint4*>(src + (int64_t)ra * row_stride);
-      a0 = q[0]; a1 = q[1];
+      a0 = at_in<F16>(q[0]); a1 = at_in<F16>(q[1]);
     }
     if (rb < L) {
       const uint4* q = reinterpret_cast<const uint4*>(src + (int64_t)rb * row_stride);
-      b0 = q[0]; b1 = q[1];
+      b0 = at_in<F16>(q[0]); b1 = at_in<F16>(q[1]);
     }
     uint16_t ea[16], eb[16];
     *reinterpret_cast<uint4*>(ea) = a0; *reinterpret_cast<uint4*>(ea + 8) = a1;
@@ -236,8 +265,10 @@ static inline int at_split_host(int n_units, int lp_max) { return at_split(n_uni
 // of the flash_attn API passing inconsistent arguments) would overrun the LDS images, which are sized from
 // max_seqlen.  Such units write NaN to every output row they own (16 bf16 per row, optionally the fp32 side vector) and
 // return: the error is loud in the loss, memory stays intact.
+template <bool F16 = false>
 __device__ __forceinline__ void at_poison_rows(uint16_t* rows, int64_t row_stride, int L, float* side) {
-  const uint4 nan4 = {0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u};
+  constexpr uint32_t nn = F16 ? 0x7E007E00u : 0x7FC07FC0u;
+  const uint4 nan4 = {nn, nn, nn, nn};
   for (int q = threadIdx.x; q < L; q += AT_THREADS) {
     uint4* o = reinterpret_cast<uint4*>(rows + (int64_t)q * row_stride);
     o[0] = nan4;
@@ -253,6 +284,7 @@ __device__ __forceinline__ void at_poison_rows(uint16_t* rows, int64_t row_strid
 // The second-dispatched half of the workgroup's waves runs at s_setprio 1 (MI355X_MICROARCH.md, two waves per SIMD, item 4).  Measured and
 // dropped (round 1/2, profiles/r02_g_attn_variants.txt, r02_h_attn_variants.txt): rounding the scaled query to ONE bf16 operand (3 MFMAs per
 // tile instead of 4, 2^-9 relative logit error) and packing P by truncation (v_perm_b32 instead of v_cvt_pk_bf16_f32).
+template <bool F16>
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
                 int lp_max, int n_units, int qs, uint16_t* __restrict__ out, float* __restrict__ lse) {
@@ -265,7 +297,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
   if (Lp > lp_max) {   // sequence longer than the caller's max_seqlen: LDS is sized from max_seqlen -- poison, never overrun
-    if (part == 0) at_poison_rows(out + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, lse + (int64_t)head * total + a);
+    if (part == 0) at_poison_rows<F16>(out + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, lse + (int64_t)head * total + a);
     return;
   }
   const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
@@ -276,8 +308,8 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
   float* red = reinterpret_cast<float*>(Vt + (size_t)17 * pitch * 2);  // [AT_WAVES]
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const int64_t rs = (int64_t)3 * H * 16;
-  float kn = stage_row_major(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
-  stage_transposed(qkv + qkv_off(a, 2, H, head), rs, L, Lp, pitch, Vt);
+  float kn = stage_row_major<F16>(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
+  stage_transposed<F16>(qkv + qkv_off(a, 2, H, head), rs, L, Lp, pitch, Vt);
   // row 16: the denominator row of the P V product.  Zero beyond L, so padding keys (k = 0, finite P)
   // reach neither the numerator (V^T = 0) nor the denominator: no masking in the key loop.
   for (int key = threadIdx.x; key < Lp; key += AT_THREADS)
@@ -301,7 +333,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 
   for (int qt = t_lo + wave; qt < t_hi; qt += AT_WAVES) {
     const int q = qt * 32 + col;
-    const s16x8 qf = ld_global_frag(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, q < L);
+    const s16x8 qf = ld_global_frag<F16>(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, q < L);
     float qn = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -441,8 +473,8 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
     if (q < L) {
       uint16_t* o = out + ((int64_t)(a + q) * H + head) * 16;
       uint2 w0, w1;
-      w0.x = pack_bf16x2(acc[0] * inv, acc[1] * inv); w0.y = pack_bf16x2(acc[2] * inv, acc[3] * inv);
-      w1.x = pack_bf16x2(acc[4] * inv, acc[5] * inv); w1.y = pack_bf16x2(acc[6] * inv, acc[7] * inv);
+      w0.x = at_out<F16>(pack_bf16x2(acc[0] * inv, acc[1] * inv)); w0.y = at_out<F16>(pack_bf16x2(acc[2] * inv, acc[3] * inv));
+      w1.x = at_out<F16>(pack_bf16x2(acc[4] * inv, acc[5] * inv)); w1.y = at_out<F16>(pack_bf16x2(acc[6] * inv, acc[7] * inv));
       *reinterpret_cast<uint2*>(o + 4 * h2) = w0;       // d = 4*h2 + {0..3}
       *reinterpret_cast<uint2*>(o + 8 + 4 * h2) = w1;   // d = 8 + 4*h2 + {0..3}
       if (h2 == 0) lse[(int64_t)head * total + a + q] = ref2 * AT_LN2 + __logf(l);
@@ -493,7 +525,7 @@ __device__ __forceinline__ void at_to_b16(uint32_t (&pk)[8], s16x8& lo, s16x8& h
 
 // ---- part 1: dQ (query-stationary) + delta = rowsum(dO * O) ------------------------------------------------------------------
 // LDS: V row-major [lp_max][16] | K row-major [lp_max][16]
-template <int LP>   // LP = lp_max at compile time (1024: image distances become immediate offsets) or 0 = runtime
+template <int LP, bool F16>   // LP = lp_max at compile time (1024: image distances become immediate offsets) or 0 = runtime
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                    const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
@@ -507,7 +539,7 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
   if (Lp > lp_max) {   // see attn_fwd_kernel
-    if (part == 0) at_poison_rows(dqkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, nullptr);
+    if (part == 0) at_poison_rows<F16>(dqkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, nullptr);
     return;
   }
   const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
@@ -515,8 +547,8 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
   unsigned char* Vsm = smem;
   unsigned char* Ksm = smem + (size_t)lp_max * 32;
   const int64_t rs = (int64_t)3 * H * 16;
-  stage_row_major(qkv + qkv_off(a, 2, H, head), rs, L, Lp, Vsm);
-  stage_row_major(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
+  stage_row_major<F16>(qkv + qkv_off(a, 2, H, head), rs, L, Lp, Vsm);
+  stage_row_major<F16>(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
   __syncthreads();
 
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
@@ -528,10 +560,10 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
   for (int qt = t_lo + wave; qt < t_hi; qt += AT_WAVES) {
     const int q = qt * 32 + col;
     const bool qv = q < L;
-    const s16x8 qf = ld_global_frag(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, qv);
+    const s16x8 qf = ld_global_frag<F16>(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, qv);
     const int64_t orow = ((int64_t)(a + q) * H + head) * 16 + h2 * 8;
-    const s16x8 dof = ld_global_frag(dout + orow, qv);
-    const s16x8 of = ld_global_frag(out + orow, qv);
+    const s16x8 dof = ld_global_frag<F16>(dout + orow, qv);
+    const s16x8 of = ld_global_frag<F16>(out + orow, qv);
     float dl = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) dl += bf16_bits_to_float((uint16_t)dof[j]) * bf16_bits_to_float((uint16_t)of[j]);
@@ -581,8 +613,8 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
       if (qq < L) {
         const at_f32x4 v = t ? acc1 : acc0;
         uint2 w;
-        w.x = pack_bf16x2(v[0] * scale, v[1] * scale);
-        w.y = pack_bf16x2(v[2] * scale, v[3] * scale);
+        w.x = at_out<F16>(pack_bf16x2(v[0] * scale, v[1] * scale));
+        w.y = at_out<F16>(pack_bf16x2(v[2] * scale, v[3] * scale));
         *reinterpret_cast<uint2*>(dqkv + qkv_off(a + qq, 0, H, head) + 4 * g) = w;
       }
     }
@@ -592,7 +624,7 @@ attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict_
 // ---- part 2: dK, dV (key-stationary).  Needs delta written by part 1 (same stream). -------------------------------------------------
 // LDS: Q row-major [lp_max][16] | dO row-major [lp_max][16] | -lse * log2 e fp32 [lp_max] | -delta fp32 [lp_max]
 #define AT_PAD_LSE 1.0e30f   // lse of padding queries: exp2(s - 1e30) = 0
-template <int LP>   // LP = lp_max at compile time (1024: image distances become immediates) or 0
+template <int LP, bool F16>   // LP = lp_max at compile time (1024: image distances become immediates) or 0
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                     const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
@@ -607,8 +639,8 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
   if (Lp > lp_max) {   // see attn_fwd_kernel
     if (part == 0) {
-      at_poison_rows(dqkv + qkv_off(a, 1, H, head), (int64_t)3 * H * 16, L, nullptr);
-      at_poison_rows(dqkv + qkv_off(a, 2, H, head), (int64_t)3 * H * 16, L, nullptr);
+      at_poison_rows<F16>(dqkv + qkv_off(a, 1, H, head), (int64_t)3 * H * 16, L, nullptr);
+      at_poison_rows<F16>(dqkv + qkv_off(a, 2, H, head), (int64_t)3 * H * 16, L, nullptr);
     }
     return;
   }
@@ -617,8 +649,8 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
   unsigned char* Qsm = smem;
   float* nl = reinterpret_cast<float*>(smem + (size_t)lp_max * 64);            // -lse * log2 e per query
   float* nd = nl + lp_max;                                                     // -delta per query
-  stage_row_major(qkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, Lp, Qsm);
-  stage_row_major(dout + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, Lp, smem + (size_t)lp_max * 32);
+  stage_row_major<F16>(qkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, Lp, Qsm);
+  stage_row_major<F16>(dout + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, Lp, smem + (size_t)lp_max * 32);
   for (int q = threadIdx.x; q < Lp; q += AT_THREADS) {
     nl[q] = q < L ? -lse[(int64_t)head * total + a + q] * AT_LOG2E : -AT_PAD_LSE;
     nd[q] = q < L ? -delta[(int64_t)head * total + a + q] : 0.f;
@@ -633,8 +665,8 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
 
   for (int kt = t_lo + wave; kt < t_hi; kt += AT_WAVES) {
     const int key = kt * 32 + col;
-    const s16x8 kf = ld_global_frag(qkv + qkv_off(a + key, 1, H, head) + h2 * 8, key < L);
-    const s16x8 vf = ld_global_frag(qkv + qkv_off(a + key, 2, H, head) + h2 * 8, key < L);
+    const s16x8 kf = ld_global_frag<F16>(qkv + qkv_off(a + key, 1, H, head) + h2 * 8, key < L);
+    const s16x8 vf = ld_global_frag<F16>(qkv + qkv_off(a + key, 2, H, head) + h2 * 8, key < L);
     s16x8 khi, klo;
     split_scaled(kf, c, khi, klo);
     at_f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;    // dV^T / dK^T [d = 4 g + e][key = 32 kt + (0 | 16) + lane & 15]
@@ -695,10 +727,10 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
       if (kk < L) {
         const at_f32x4 vk = t ? dk1 : dk0, vv = t ? dv1 : dv0;
         uint2 wk, wv;
-        wk.x = pack_bf16x2(vk[0] * scale, vk[1] * scale);
-        wk.y = pack_bf16x2(vk[2] * scale, vk[3] * scale);
-        wv.x = pack_bf16x2(vv[0], vv[1]);
-        wv.y = pack_bf16x2(vv[2], vv[3]);
+        wk.x = at_out<F16>(pack_bf16x2(vk[0] * scale, vk[1] * scale));
+        wk.y = at_out<F16>(pack_bf16x2(vk[2] * scale, vk[3] * scale));
+        wv.x = at_out<F16>(pack_bf16x2(vv[0], vv[1]));
+        wv.y = at_out<F16>(pack_bf16x2(vv[2], vv[3]));
         *reinterpret_cast<uint2*>(dqkv + qkv_off(a + kk, 1, H, head) + 4 * g) = wk;
         *reinterpret_cast<uint2*>(dqkv + qkv_off(a + kk, 2, H, head) + 4 * g) = wv;
       }
@@ -726,8 +758,11 @@ static size_t dq_lds_bytes(int lp_max) { return (size_t)lp_max * 64 + at_bwd_pad
 static size_t dkv_lds_bytes(int lp_max) { return (size_t)lp_max * 64 + (size_t)lp_max * 8 + at_bwd_pad(); }
 
 static int check_common(const char* name, const void* qkv, const int32_t* cu, int64_t n_seq, int64_t total, int H,
-                        int max_seqlen, int dtype) {
-  PTC_REQUIRE(dtype == PTC_BF16, PTC_EUNSUPPORTED, "%s: only bf16 is implemented (the reference casts qkv to bf16, ptv3m1:209)", name);
+                        int max_seqlen, int dtype, bool f16_io = false) {
+  // f16_io (the head_dim-16 window kernels): PTC_F16 = f16 tensors in and out around the same bf16 arithmetic, i.e. the reference's
+  // qkv.to(bfloat16) / feat.to(qkv.dtype) casts folded into the load / store paths (see at_in / at_out)
+  PTC_REQUIRE(dtype == PTC_BF16 || (f16_io && dtype == PTC_F16), PTC_EUNSUPPORTED,
+              "%s: bf16 arithmetic only (the reference casts qkv to bf16, ptv3m1:209)%s", name, f16_io ? "; tensors bf16 or f16" : "");
   PTC_REQUIRE(n_seq >= 0 && total >= 0 && H >= 1, PTC_EINVAL, "%s: bad sizes", name);
   PTC_REQUIRE(max_seqlen >= 1 && max_seqlen <= AT_MAX_L, PTC_EUNSUPPORTED, "%s: max_seqlen=%d not in [1,%d]", name, max_seqlen, AT_MAX_L);
   PTC_REQUIRE(n_seq * H < (1ll << 29), PTC_EUNSUPPORTED, "%s: grid too large", name);
@@ -739,7 +774,7 @@ static int check_common(const char* name, const void* qkv, const int32_t* cu, in
 extern "C" int ptc_attn_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, int64_t n_seq, int64_t total, int H,
                                    int max_seqlen, float softmax_scale, int dtype, void* out, float* lse,
                                    ptc_stream_t stream) {
-  int rc = check_common("ptc_attn_varlen_fwd", qkv, cu_seqlens, n_seq, total, H, max_seqlen, dtype);
+  int rc = check_common("ptc_attn_varlen_fwd", qkv, cu_seqlens, n_seq, total, H, max_seqlen, dtype, true);
   if (rc != PTC_OK) return rc;
   if (n_seq == 0 || total == 0) return PTC_OK;
   PTC_REQUIRE(out && lse, PTC_EINVAL, "ptc_attn_varlen_fwd: null buffer");
@@ -748,12 +783,18 @@ extern "C" int ptc_attn_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, i
   hipStream_t s = (hipStream_t)stream;
   const int n_units = (int)(n_seq * H);
   const int qs = at_split_host(n_units, lp_max);
-  rc = allow_big_lds(attn_fwd_kernel, lds);
-  if (rc != PTC_OK) return rc;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds, s, (const uint16_t*)qkv, cu_seqlens, H,
-                     softmax_scale, total, lp_max, n_units, qs, (uint16_t*)out, lse);
-  PTC_CHECK_LAUNCH("attn_fwd_kernel");
-  return PTC_OK;
+#define AT_FWD_CASE(F16)                                                                                                                   \
+  if ((dtype == PTC_F16) == F16) {                                                                                                          \
+    rc = allow_big_lds(attn_fwd_kernel<F16>, lds);                                                                                          \
+    if (rc != PTC_OK) return rc;                                                                                                            \
+    hipLaunchKernelGGL(attn_fwd_kernel<F16>, dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds, s, (const uint16_t*)qkv, \
+                       cu_seqlens, H, softmax_scale, total, lp_max, n_units, qs, (uint16_t*)out, lse);                                      \
+    PTC_CHECK_LAUNCH("attn_fwd_kernel");                                                                                                    \
+    return PTC_OK;                                                                                                                          \
+  }
+  AT_FWD_CASE(false) AT_FWD_CASE(true)
+#undef AT_FWD_CASE
+  return PTC_EINVAL;   // not reached
 }
 
 extern "C" size_t ptc_attn_varlen_bwd_workspace_bytes(int64_t total, int H) {
@@ -764,7 +805,7 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
                                    const int32_t* cu_seqlens, int64_t n_seq, int64_t total, int H, int max_seqlen,
                                    float softmax_scale, int dtype, void* dqkv, void* workspace, size_t workspace_bytes,
                                    ptc_stream_t stream) {
-  int rc = check_common("ptc_attn_varlen_bwd", qkv, cu_seqlens, n_seq, total, H, max_seqlen, dtype);
+  int rc = check_common("ptc_attn_varlen_bwd", qkv, cu_seqlens, n_seq, total, H, max_seqlen, dtype, true);
   if (rc != PTC_OK) return rc;
   if (n_seq == 0 || total == 0) return PTC_OK;
   PTC_REQUIRE(out && dout && lse && dqkv && workspace, PTC_EINVAL, "ptc_attn_varlen_bwd: null buffer");
@@ -780,23 +821,23 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
   // (s_setprio on half of the waves, as in the forward: measured neutral to harmful here, profiles/r02_h_attn_variants.txt; a two-stage
   //  software pipeline at one workgroup per CU: slower, profiles/r02_o_slp_ab.txt; the single-pass backward: 2.1-2.3 ms against 1.56, r01_w/x)
-#define AT_BWD_CASE(LP)                                                                                                        \
-  if (LP == 0 ? lp_max != 1024 : lp_max == LP) {                                                                                                             \
-    rc = allow_big_lds((attn_bwd_dq_kernel<LP>), dq_lds_bytes(lp_max));                                                           \
+#define AT_BWD_CASE(LP, F16)                                                                                                        \
+  if ((LP == 0 ? lp_max != 1024 : lp_max == LP) && (dtype == PTC_F16) == F16) {                                                                                                             \
+    rc = allow_big_lds((attn_bwd_dq_kernel<LP, F16>), dq_lds_bytes(lp_max));                                                           \
     if (rc != PTC_OK) return rc;                                                                                               \
-    rc = allow_big_lds((attn_bwd_dkv_kernel<LP>), dkv_lds_bytes(lp_max));                                                         \
+    rc = allow_big_lds((attn_bwd_dkv_kernel<LP, F16>), dkv_lds_bytes(lp_max));                                                         \
     if (rc != PTC_OK) return rc;                                                                                               \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<LP>), dim3(grid), dim3(AT_THREADS), dq_lds_bytes(lp_max), s, (const uint16_t*)qkv,     \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<LP, F16>), dim3(grid), dim3(AT_THREADS), dq_lds_bytes(lp_max), s, (const uint16_t*)qkv,     \
                        (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H, softmax_scale, total, lp_max, n_units, \
                        qs, (uint16_t*)dqkv, delta);                                                                            \
     PTC_CHECK_LAUNCH("attn_bwd_dq_kernel");                                                                                    \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<LP>), dim3(grid), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s, (const uint16_t*)qkv,   \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<LP, F16>), dim3(grid), dim3(AT_THREADS), dkv_lds_bytes(lp_max), s, (const uint16_t*)qkv,   \
                        (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H, softmax_scale, total, lp_max, n_units,  \
                        qs, (uint16_t*)dqkv);                                                                                   \
     PTC_CHECK_LAUNCH("attn_bwd_dkv_kernel");                                                                                   \
     return PTC_OK;                                                                                                             \
   }
-  AT_BWD_CASE(1024) AT_BWD_CASE(0)
+  AT_BWD_CASE(1024, false) AT_BWD_CASE(0, false) AT_BWD_CASE(1024, true) AT_BWD_CASE(0, true)
 #undef AT_BWD_CASE
   return PTC_EINVAL;   // not reached
 }

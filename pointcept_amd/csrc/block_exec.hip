@@ -58,7 +58,9 @@ extern "C" int ptc_ptv3_block_fwd(const int64_t* iv, const float* fv, const void
   const int64_t n = iv[PTC_BLK_I_N], np = iv[PTC_BLK_I_NPAD], n_seq = iv[PTC_BLK_I_NSEQ];
   const int c = (int)iv[PTC_BLK_I_C], H = (int)iv[PTC_BLK_I_HEADS], dt = (int)iv[PTC_BLK_I_DTYPE], hid = 4 * c;
   const int a_dt = (int)iv[PTC_BLK_I_A_DTYPE], patch = (int)iv[PTC_BLK_I_PATCH];
-  PTC_REQUIRE(dt == PTC_BF16, PTC_EUNSUPPORTED, "ptc_ptv3_block_fwd: bf16 GEMM operands only");
+  // f16 (round 4): the reference's fp16-autocast recipe -- every GEMM, joint and convolution on f16 operands; the window attention
+  // keeps its bf16 arithmetic and does the call site's casts (ptv3m1:209,215) in its load / store paths (attention.hip, F16 I/O)
+  PTC_REQUIRE(dt == PTC_BF16 || dt == PTC_F16, PTC_EUNSUPPORTED, "ptc_ptv3_block_fwd: 16-bit GEMM operands only");
   PTC_REQUIRE(c % 16 == 0 && c <= 256 && H * 16 == c, PTC_EUNSUPPORTED, "ptc_ptv3_block_fwd: c=%d heads=%d (head_dim 16, c <= 256)", c, H);
   if (n == 0) return PTC_OK;
   const int32_t* nbr = (const int32_t*)P(in, PTC_BLK_P_NBR);

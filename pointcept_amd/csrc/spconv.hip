@@ -566,8 +566,8 @@ extern "C" size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_
 // the block-staged weight gradient keeps its partials (one per persistent workgroup sequence, wgrad7.h) BEHIND the region above, which
 // stays wgrad2's: the two kernels of ptc_spconv_wgrad_blk are gated on a device-side word and must not share partials
 static size_t wgrad_blk_extra_bytes(int64_t n_out, int kv, int c_in, int c_out) {
-  if (kv != 27 || c_in != c_out || (c_in != 32 && c_in != 64) || n_out < 4096) return 0;
-  return ptc_align_up((size_t)wgrad7_splits(n_out, c_in) * (size_t)c_out * kv * c_in * sizeof(float), 256);
+  if (!wgrad7_supported(PTC_BF16, kv, c_in, c_out, C7_BM, C7_HCAP, n_out)) return 0;
+  return ptc_align_up((size_t)wgrad7_splits(n_out, c_in, c_out) * (size_t)c_out * kv * c_in * sizeof(float), 256);
 }
 extern "C" size_t ptc_spconv_wgrad_blk_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out) {
   return ptc_spconv_wgrad_workspace_bytes(n_out, kv, c_in, c_out) + wgrad_blk_extra_bytes(n_out, kv, c_in, c_out);
@@ -736,13 +736,13 @@ int ptc_spconv_wgrad_blk_deferred(const void* in, int64_t n_in, const void* dout
               "ptc_spconv_wgrad_blk: buffers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   float* p7 = (float*)((char*)workspace + ptc_spconv_wgrad_workspace_bytes(n_out, kv, c_in, c_out));
-  int rc = ptc_wgrad7_launch(dtype, in, dout, (const uint16_t*)tab, hid, hcnt, n_overflow, n_out, c_in, p7, s);
+  int rc = ptc_wgrad7_launch(dtype, in, dout, (const uint16_t*)tab, hid, hcnt, n_overflow, n_out, c_in, c_out, p7, s);
   if (rc != PTC_OK) return rc;
   PtcWgradJob j2;
   rc = dtype == PTC_BF16 ? launch_wgrad2<bf16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, nullptr, workspace, s, &j2, n_overflow)
                          : launch_wgrad2<f16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, nullptr, workspace, s, &j2, n_overflow);
   if (rc != PTC_OK) return rc;
-  *job = PtcWgradJob{p7, wgrad7_splits(n_out, c_in), (int64_t)c_out * kv * c_in, dw, nullptr, (int64_t)c_out, nullptr, n_overflow, j2.partial, j2.splits};
+  *job = PtcWgradJob{p7, wgrad7_splits(n_out, c_in, c_out), (int64_t)c_out * kv * c_in, dw, nullptr, (int64_t)c_out, nullptr, n_overflow, j2.partial, j2.splits};
   return PTC_OK;
 }
 

@@ -41,6 +41,12 @@
 // A block whose halo did not fit (hcnt < 0: rows in no spatial order) cannot be served here; the host entry point therefore GATES the
 // two kernels on the device-side overflow counter of the table builder: this kernel runs when it is zero, wgrad2 over the whole tensor
 // when it is not, each returning at once otherwise -- no host synchronisation, and the reduction reads the partials of whichever ran.
+// CHANNEL SLICES (round 4, the 128 .. 512-channel stages; c_in % 64 == 0, c_out % 32 == 0, c_in and c_out independent): the C = 64 geometry
+// with a workgroup owning ONE (32 output channels) x (64 input channels) slice of dw for all 27 taps -- the same 224 accumulation
+// registers -- and staging only ITS 128 bytes of every halo row and ITS 64 bytes of every dout row.  (c_out / 32)(c_in / 64) workgroups
+// walk one block sequence (same XCD, dispatched back to back: the slices of a row come out of one L2); 256 / slices sequences.  wgrad2 at
+// these widths re-streams dout and re-gathers its rows once per (64 x 64 channel tile, tap pair): 16 x 14 times at 256 channels -- 95 TF/s
+// on the outdoor stage-3 shape (profiles/r04_h_ops_outdoor.txt).
 // Summation order differs from wgrad2 (rows of a block in step order, blocks in the workgroup's stride order): results agree to fp32
 // rounding of the accumulation, and are bit-reproducible run to run.
 #pragma once
@@ -51,21 +57,30 @@
 #endif
 #define W7_DMA_EVERY 2                       // ... one per this many (step, tap) pairs
 
-static inline bool wgrad7_supported(int dtype, int kv, int c_in, int c_out, int bm, int hcap, int64_t n_out) {
-  return conv7_supported(dtype, kv, c_in, c_out, bm, hcap, n_out);
-}
 #define W7_MAX_WGS 256                       // one persistent workgroup per CU
-// workgroups walking DISTINCT block sequences = fp32 partials per call (C = 64: two workgroups -- the output-channel halves -- per sequence)
-static inline int wgrad7_splits(int64_t n_out, int c) {
-  int64_t nb = ptc_cdiv(n_out, C7_BM), cap = c == 64 ? W7_MAX_WGS / 2 : W7_MAX_WGS;
+static inline bool wgrad7_sliced(int c_in, int c_out) { return c_in % 64 == 0 && c_out % 32 == 0 && c_in <= 1024 && c_out <= 1024 && !(c_in == 64 && c_out == 64); }
+static inline int wgrad7_slices(int c_in, int c_out) { return wgrad7_sliced(c_in, c_out) ? (c_in / 64) * (c_out / 32) : (c_in == 64 ? 2 : 1); }
+static inline bool wgrad7_supported(int dtype, int kv, int c_in, int c_out, int bm, int hcap, int64_t n_out) {
+  if (conv7_supported(dtype, kv, c_in, c_out, bm, hcap, n_out)) return true;
+  return dtype != PTC_F32 && kv == 27 && bm == C7_BM && hcap == C7_HCAP && n_out >= 1024 && wgrad7_sliced(c_in, c_out) &&
+         wgrad7_slices(c_in, c_out) <= W7_MAX_WGS;
+}
+// workgroups walking DISTINCT block sequences = fp32 partials per call (C = 64: two workgroups -- the output-channel halves -- per sequence;
+// channel slices: (c_out / 32)(c_in / 64) workgroups per sequence, and at least FOUR blocks per sequence -- every sequence writes a full
+// fp32 copy of dw, which at 256+ channels outweighs the operands of a short sequence)
+static inline int wgrad7_splits(int64_t n_out, int c_in, int c_out) {
+  int64_t nb = ptc_cdiv(n_out, C7_BM), cap = W7_MAX_WGS / wgrad7_slices(c_in, c_out);
+  if (wgrad7_sliced(c_in, c_out) && cap > (nb + 3) / 4) cap = (nb + 3) / 4;
+  if (cap < 1) cap = 1;
 #ifndef __HIPCC__
   if (const char* e = getenv("PTC_EMU_CONV7_WGS")) cap = atoi(e);   // host emulation only: several blocks per workgroup at test sizes
 #endif
+  if (cap >= 8 && wgrad7_sliced(c_in, c_out)) cap &= ~7;             // whole rounds of the eight XCDs
   return (int)(nb < cap ? nb : cap);
 }
 
 int ptc_wgrad7_launch(int dtype, const void* in, const void* dout, const uint16_t* tab, const int32_t* hid, const int32_t* hcnt,
-                      const int32_t* gate, int64_t n_out, int c, float* partial, hipStream_t s);
+                      const int32_t* gate, int64_t n_out, int c_in, int c_out, float* partial, hipStream_t s);
 
 #ifdef PTC_WGRAD7_IMPL
 template <int C> struct W7Geom {
@@ -84,10 +99,12 @@ template <int C> struct W7Geom {
   static_assert(LDS <= 163840, "LDS budget");
 };
 
-template <typename T, int C>
+template <typename T, int C, bool SL = false>
 __global__ void __launch_bounds__(256, 1)
 wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16_t* __restrict__ tab, const int32_t* __restrict__ hid,
-              const int32_t* __restrict__ hcnt, const int32_t* __restrict__ gate, int64_t n_out, int n_blocks, float* __restrict__ partial) {
+              const int32_t* __restrict__ hcnt, const int32_t* __restrict__ gate, int64_t n_out, int n_blocks, float* __restrict__ partial,
+              int c_in_full, int c_out_full) {
+  static_assert(!SL || C == 64, "channel slices use the 64-channel geometry");
   using frag = typename Mma<T>::frag;
   using MM = C7Mma<T>;
   using G = W7Geom<C>;
@@ -101,9 +118,24 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
   // C = 64: workgroup = (block sequence, output-channel half ch); hardware workgroup b runs on XCD b % 8, so the two halves of a sequence
   // are b = x + 8 (2 p) and x + 8 (2 p + 1): same XCD, dispatched back to back.  Sequence `seq` of `step` takes blocks seq', seq' + step, ..
   // with seq' as in conv7 (one round's blocks of an XCD adjacent)
-  const int wgs = (int)gridDim.x, vb = C == 64 ? (wgs % 16 == 0 ? (((int)blockIdx.x >> 4) << 3 | ((int)blockIdx.x & 7)) : ((int)blockIdx.x >> 1)) : (int)blockIdx.x;
-  const int ch = C == 64 ? (wgs % 16 == 0 ? (((int)blockIdx.x >> 3) & 1) : ((int)blockIdx.x & 1)) : 0;
-  const int step = C == 64 ? wgs / 2 : wgs;
+  // SL: n_sl = (c_out / 32)(c_in / 64) slices per sequence; sequence s, slice t <-> hardware workgroup (s % 8) + 8 (t + n_sl (s / 8)) when the
+  // sequences come in whole rounds of eight (the generalisation of the C = 64 rule), else s n_sl + t
+  const int wgs = (int)gridDim.x;
+  const int n_ci = SL ? c_in_full / 64 : 1, n_sl = SL ? n_ci * (c_out_full / 32) : (C == 64 ? 2 : 1);
+  const int step = wgs / n_sl;
+  int vb, sl;
+  if constexpr (SL) {
+    const int bx = (int)blockIdx.x;
+    if (step % 8 == 0) { vb = (bx & 7) + 8 * ((bx >> 3) / n_sl); sl = (bx >> 3) % n_sl; }
+    else { vb = bx / n_sl; sl = bx - vb * n_sl; }
+  } else {
+    vb = C == 64 ? (wgs % 16 == 0 ? (((int)blockIdx.x >> 4) << 3 | ((int)blockIdx.x & 7)) : ((int)blockIdx.x >> 1)) : (int)blockIdx.x;
+    sl = C == 64 ? (wgs % 16 == 0 ? (((int)blockIdx.x >> 3) & 1) : ((int)blockIdx.x & 1)) : 0;
+  }
+  const int ch = SL ? sl / n_ci : sl;                         // 32-channel block of dout / dw rows this workgroup owns
+  const int cib = SL ? sl - ch * n_ci : 0;                    // SL: 64-channel block of the input rows
+  const uint32_t in_pitch = SL ? (uint32_t)c_in_full * 2u : (uint32_t)ROWB, in_col = (uint32_t)cib * 128u;       // bytes
+  const uint32_t do_pitch = SL ? (uint32_t)c_out_full * 2u : (uint32_t)ROWB;
   const int b_begin = (step % 8 == 0) ? (vb & 7) * (step / 8) + (vb >> 3) : vb;
   const int b_end = n_blocks;
 
@@ -143,7 +175,7 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
         if (ii * RPI < cnt) {                                  // wave-uniform
           const int slot = ii * RPI + drow;
           const int piece = dpos ^ G::swz(slot);
-          c7_dma16s(in, (uint32_t)idv[P] * (uint32_t)ROWB + (uint32_t)(piece * 16), base + (uint32_t)(ii * 1024));
+          c7_dma16s(in, (uint32_t)idv[P] * in_pitch + in_col + (uint32_t)(piece * 16), base + (uint32_t)(ii * 1024));
         }
       } else if constexpr (P < G::NIW + 2) {
         const int ii = 4 * (P - G::NIW) + wave;
@@ -157,7 +189,7 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
           const int Pq = ii * 64 + lane, R = Pq >> 2, pos = Pq & 3;
           int64_t row = (int64_t)blk * C7_BM + R;
           row = row < n_out ? row : n_out - 1;
-          c7_dma16s(dout, (uint32_t)row * (uint32_t)ROWB + (uint32_t)(ch * 64 + pos * 16), lds0 + (uint32_t)(G::DOUT0 + bsel * G::DOUT_BYTES + ii * 1024));
+          c7_dma16s(dout, (uint32_t)row * do_pitch + (uint32_t)(ch * 64 + pos * 16), lds0 + (uint32_t)(G::DOUT0 + bsel * G::DOUT_BYTES + ii * 1024));
         }
       }
     };
@@ -249,7 +281,8 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
   }
 
   // ---- this workgroup's partial: D[i = co][j = ci] of tap k: lane (j = lane & 31, hh) holds co = 8 (r / 4) + 4 hh + r % 4
-  float* pout = partial + (int64_t)vb * ((int64_t)C * 27 * C);
+  const int cif = SL ? c_in_full : C, cof = SL ? c_out_full : C;
+  float* pout = partial + (int64_t)vb * ((int64_t)cof * 27 * cif);
   const int jj = lane & 31;
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
@@ -259,23 +292,23 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
       for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int co = ch * 32 + 8 * (r >> 2) + 4 * hh + (r & 3), ci = kh * 32 + jj;
-          pout[((int64_t)co * 27 + k) * C + ci] = acc[a * KH + kh][r];
+          const int co = ch * 32 + 8 * (r >> 2) + 4 * hh + (r & 3), ci = cib * 64 + kh * 32 + jj;
+          pout[((int64_t)co * 27 + k) * cif + ci] = acc[a * KH + kh][r];
         }
     }
   }
 }
 
-template <typename T, int C>
+template <typename T, int C, bool SL = false>
 static int launch_wgrad7_i(const void* in, const void* dout, const uint16_t* tab, const int32_t* hid, const int32_t* hcnt, const int32_t* gate,
-                           int64_t n_out, float* partial, hipStream_t s) {
+                           int64_t n_out, int c_in, int c_out, float* partial, hipStream_t s) {
   const int n_blocks = (int)ptc_cdiv(n_out, C7_BM);
-  const int seqs = wgrad7_splits(n_out, C);
-  const int grid = C == 64 ? 2 * seqs : seqs;
-  auto kern = wgrad7_kernel<T, C>;
+  const int seqs = wgrad7_splits(n_out, c_in, c_out);
+  const int grid = seqs * wgrad7_slices(c_in, c_out);
+  auto kern = wgrad7_kernel<T, C, SL>;
   PTC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W7Geom<C>::LDS));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), W7Geom<C>::LDS, s, (const T*)in, (const T*)dout, tab, hid, hcnt, gate, n_out, n_blocks,
-                     partial);
+                     partial, c_in, c_out);
   PTC_CHECK_LAUNCH("wgrad7_kernel");
   return PTC_OK;
 }

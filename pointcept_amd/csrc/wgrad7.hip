@@ -23,10 +23,14 @@ __device__ __forceinline__ F ld_tr_pair16(const unsigned char* p0, const unsigne
 #include "wgrad7.h"
 
 int ptc_wgrad7_launch(int dtype, const void* in, const void* dout, const uint16_t* tab, const int32_t* hid, const int32_t* hcnt,
-                      const int32_t* gate, int64_t n_out, int c, float* partial, hipStream_t s) {
+                      const int32_t* gate, int64_t n_out, int c_in, int c_out, float* partial, hipStream_t s) {
+  if (wgrad7_sliced(c_in, c_out)) {   // 128 .. 512-channel stages: (32 x 64)-channel slices of dw on the 64-channel geometry
+    if (dtype == PTC_BF16) return launch_wgrad7_i<bf16_t, 64, true>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s);
+    return launch_wgrad7_i<f16_t, 64, true>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s);
+  }
   if (dtype == PTC_BF16)
-    return c == 64 ? launch_wgrad7_i<bf16_t, 64>(in, dout, tab, hid, hcnt, gate, n_out, partial, s)
-                   : launch_wgrad7_i<bf16_t, 32>(in, dout, tab, hid, hcnt, gate, n_out, partial, s);
-  return c == 64 ? launch_wgrad7_i<f16_t, 64>(in, dout, tab, hid, hcnt, gate, n_out, partial, s)
-                 : launch_wgrad7_i<f16_t, 32>(in, dout, tab, hid, hcnt, gate, n_out, partial, s);
+    return c_in == 64 ? launch_wgrad7_i<bf16_t, 64>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s)
+                      : launch_wgrad7_i<bf16_t, 32>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s);
+  return c_in == 64 ? launch_wgrad7_i<f16_t, 64>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s)
+                    : launch_wgrad7_i<f16_t, 32>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s);
 }

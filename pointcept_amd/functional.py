@@ -596,8 +596,10 @@ class _AttnVarlen(Function):
 def attn_varlen_qkvpacked(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
                           softmax_scale: Optional[float] = None) -> torch.Tensor:
     """flash_attn.flash_attn_varlen_qkvpacked_func semantics (ptv3m1:208-214), dropout 0,
-    non-causal, qkv [T,3,H,16] bf16 -> [T,H,16] bf16."""
-    if qkv.dtype != torch.bfloat16:
+    non-causal, qkv [T,3,H,16] bf16 -> [T,H,16] bf16.  f16 qkv with head_dim 16 = the reference's fp16-autocast call site INCLUDING its
+    casts: `flash_attn(qkv.to(bfloat16)).to(qkv.dtype)` -- bf16 arithmetic, f16 tensors, the four cast passes (two forward, two
+    backward) folded into the kernels' loads and stores."""
+    if qkv.dtype != torch.bfloat16 and not (qkv.dtype == torch.float16 and qkv.shape[-1] == 16):
         raise PtcoreError("attn_varlen_qkvpacked expects bf16 (the reference casts with .to(torch.bfloat16), ptv3m1:209)")
     if softmax_scale is None:
         softmax_scale = qkv.shape[-1] ** -0.5
@@ -823,7 +825,8 @@ def _blk_tables(E, x0, meta):
     blk = meta["blk"]
     iv = (ctypes.c_int64 * E["I_COUNT"])()
     iv[E["I_ABI"]], iv[E["I_N"]], iv[E["I_NPAD"]], iv[E["I_NSEQ"]], iv[E["I_C"]] = E["ABI"], n, meta["n_pad"], meta["n_seq"], c
-    iv[E["I_HEADS"]], iv[E["I_DTYPE"]], iv[E["I_A_DTYPE"]], iv[E["I_PATCH"]] = meta["heads"], _lib.PTC_BF16, _lib.dtype_code(x0), meta["patch"]
+    iv[E["I_HEADS"]], iv[E["I_DTYPE"]], iv[E["I_A_DTYPE"]], iv[E["I_PATCH"]] = (meta["heads"], _lib.PTC_F16 if meta["dt"] == torch.float16 else _lib.PTC_BF16,
+                                                                              _lib.dtype_code(x0), meta["patch"])
     iv[E["I_BLK_BM"]], iv[E["I_BLK_HCAP"]] = (0, 0) if blk is None else (blk.bm, blk.hcap)
     fv = (ctypes.c_float * E["F_COUNT"])()
     fv[E["F_SCALE"]], fv[E["F_EPS_CPE"]], fv[E["F_EPS_N1"]], fv[E["F_EPS_N2"]] = meta["scale"], meta["eps_cpe"], meta["eps_n1"], meta["eps_n2"]
@@ -846,7 +849,7 @@ class _BlockFn(Function):
 
     @staticmethod
     def forward(ctx, x0, xc, rs1, rs2, meta, *params):
-        dt = torch.bfloat16
+        dt = meta["dt"]            # the autocast dtype of the step: bf16, or f16 (the reference's fp16 recipe)
         n, c = x0.shape
         npad, heads = meta["n_pad"], meta["heads"]
         dev = x0.device
@@ -906,7 +909,7 @@ class _BlockFn(Function):
         x0, xc, rs1, rs2, buf16, buf32, x3, xb3 = sv[:8]
         meta, plan = ctx.meta, ctx.plan
         E = plan["E"]
-        dt = torch.bfloat16
+        dt = meta["dt"]
         n, c = x0.shape
         npad, heads = meta["n_pad"], meta["heads"]
         dev = x0.device

@@ -460,11 +460,18 @@ class BlockTables:
 
 
 def block_plan(c_in: int, c_out: int, kv: int, dtype: torch.dtype, n_rows: int = 1 << 30):
-    """(bm, hcap) of the LDS-staged, register-weight convolution for this shape, or None when the shape stays on the global-gather
-    kernels (csrc/conv7.h conv7_supported: 16-bit, 3^3 table, c_in = c_out in {32, 64}, >= 4096 rows)."""
-    if dtype == torch.float32 or kv != 27 or c_in != c_out or c_in not in (32, 64) or n_rows < 4096:
+    """(bm, hcap) of the block-local tables for this shape, or None when the shape stays on the global-gather kernels.  Two consumers:
+    the LDS-staged, register-weight convolution (csrc/conv7.h conv7_supported: 16-bit, 3^3 table, c_in = c_out in {32, 64}, >= 4096
+    rows) and the accumulator-stationary weight gradient (csrc/wgrad7.h: the same shapes, plus -- round 4 -- every c_in % 64 == 0,
+    c_out % 32 == 0 shape of the 128 .. 512-channel stages as (32 x 64)-channel slices; the forward of those shapes takes the tables and
+    falls back to the global-gather kernel inside ptc_spconv_fwd_blk)."""
+    if dtype == torch.float32 or kv != 27:
         return None
-    return (BLOCK_BM, BLOCK_HCAP)
+    if c_in == c_out and c_in in (32, 64):
+        return (BLOCK_BM, BLOCK_HCAP) if n_rows >= 4096 else None
+    if c_in % 64 == 0 and c_out % 32 == 0 and c_in <= 1024 and c_out <= 1024 and (c_in // 64) * (c_out // 32) <= 256 and n_rows >= 1024:
+        return (BLOCK_BM, BLOCK_HCAP)
+    return None
 
 
 class BlockProvider:
@@ -750,18 +757,21 @@ def attn_hd_supported(head_dim: int, max_seqlen: int) -> bool:
 
 
 def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, softmax_scale: float):
-    """qkv [T,3,H,D] bf16 -> (out [T,H,D] bf16, lse [H,T] fp32); D = 16 (attention.hip) or 17..64 (attention_hd.h)."""
+    """qkv [T,3,H,D] bf16 -> (out [T,H,D] bf16, lse [H,T] fp32); D = 16 (attention.hip) or 17..64 (attention_hd.h).
+    D = 16 also takes f16 qkv: the SAME bf16 arithmetic with the reference's qkv.to(bfloat16) / feat.to(qkv.dtype) casts
+    (ptv3m1:209,215) done in the kernel's load / store paths -- out comes back f16, bit for bit what the two cast passes produce."""
     require_cuda(qkv, cu_seqlens)
-    if qkv.dtype != torch.bfloat16 or qkv.dim() != 4 or qkv.shape[1] != 3:
-        raise PtcoreError(f"qkv must be bf16 [T,3,H,D], got {qkv.dtype} {tuple(qkv.shape)}")
+    f16_io = qkv.dtype == torch.float16 and qkv.dim() == 4 and qkv.shape[3] == 16
+    if (qkv.dtype != torch.bfloat16 and not f16_io) or qkv.dim() != 4 or qkv.shape[1] != 3:
+        raise PtcoreError(f"qkv must be bf16 [T,3,H,D] (or f16 with D = 16), got {qkv.dtype} {tuple(qkv.shape)}")
     qkv = qkv.contiguous()
     cu = cu_seqlens.to(torch.int32).contiguous()
     T, _, H, D = qkv.shape
-    out = torch.empty((T, H, D), dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty((T, H, D), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((H, T), dtype=torch.float32, device=qkv.device)
     if D == 16:
         check(lib().ptc_attn_varlen_fwd(ptr(qkv), ptr(cu), cu.numel() - 1, T, H, int(max_seqlen), float(softmax_scale),
-                                        _lib.PTC_BF16, ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_fwd")
+                                        dtype_code(qkv), ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_fwd")
     else:
         check(lib().ptc_attn_varlen_hd_fwd(ptr(qkv), ptr(cu), cu.numel() - 1, T, H, D, int(max_seqlen), float(softmax_scale),
                                            _lib.PTC_BF16, ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_hd_fwd")
@@ -772,7 +782,7 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_sc
     require_cuda(qkv, out, dout, lse, cu_seqlens)
     qkv = qkv.contiguous()
     out = out.contiguous()
-    dout = dout.to(torch.bfloat16).contiguous()
+    dout = dout.to(qkv.dtype).contiguous()       # (f16 qkv, D = 16: f16 out / dout / dqkv, the casts live in the kernels, see attn_varlen_fwd)
     cu = cu_seqlens.to(torch.int32).contiguous()
     T, _, H, D = qkv.shape
     dqkv = torch.empty_like(qkv)
@@ -780,7 +790,7 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_sc
     ws = _ws(nbytes, qkv.device)
     if D == 16:
         check(lib().ptc_attn_varlen_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), cu.numel() - 1, T, H,
-                                        int(max_seqlen), float(softmax_scale), _lib.PTC_BF16, ptr(dqkv), ptr(ws), nbytes,
+                                        int(max_seqlen), float(softmax_scale), dtype_code(qkv), ptr(dqkv), ptr(ws), nbytes,
                                         stream_ptr()), "ptc_attn_varlen_bwd")
     else:
         check(lib().ptc_attn_varlen_hd_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), cu.numel() - 1, T, H, D,

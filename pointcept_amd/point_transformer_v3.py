@@ -319,8 +319,13 @@ class SerializedAttention(PointModule):
             # writes the padded, serialized qkv directly (ptv3m1:188); proj reads the attention output
             # through the inverse table (ptv3m1:216,219).  Two full gather passes less per block.
             qkv_s = self.qkv(point.feat, tabs[0], tabs[1])
-            out = PF.attn_varlen_qkvpacked(qkv_s.to(torch.bfloat16).reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale)
-            feat = self.proj(out.reshape(-1, C).to(qkv_s.dtype), tabs[2], tabs[3])   # ptv3m1:215
+            if qkv_s.dtype == torch.float16 and C // H == 16:
+                # fp16 autocast: qkv.to(bfloat16) and feat.to(qkv.dtype) (ptv3m1:209,215) happen inside the kernels' loads and stores
+                out = PF.attn_varlen_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale)
+                feat = self.proj(out.reshape(-1, C), tabs[2], tabs[3])
+            else:
+                out = PF.attn_varlen_qkvpacked(qkv_s.to(torch.bfloat16).reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale)
+                feat = self.proj(out.reshape(-1, C).to(qkv_s.dtype), tabs[2], tabs[3])   # ptv3m1:215
         else:
             qkv = self.qkv(point.feat)
             # padded, serialized qkv in bf16 (ptv3m1:188,209); backward = gather through (inv, dup)
@@ -434,11 +439,11 @@ class Block(PointModule):
         return point
 
     def _exec_ok(self, point) -> bool:
-        """the whole block as one C call per direction (csrc/block_exec.hip): the bench configuration class -- bf16 autocast, pre-norm,
-        LayerNorm joints, the window-attention kernel with the gather tables folded into qkv / proj, fused MLP, <= 256 channels"""
+        """the whole block as one C call per direction (csrc/block_exec.hip): the bench configuration class -- bf16 or fp16 autocast,
+        pre-norm, LayerNorm joints, the window-attention kernel with the gather tables folded into qkv / proj, fused MLP, <= 256 channels"""
         a = self.attn
         return (config.EXEC_BLOCK and type(self) is Block and type(a) is SerializedAttention and torch.is_autocast_enabled("cuda")
-                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and self.channels % 32 == 0 and self.channels <= 256
+                and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16) and self.channels % 32 == 0 and self.channels <= 256
                 and a.enable_flash and not a.enable_rpe and a.num_heads * 16 == self.channels and config.FUSE_GATHER and config.FUSE_MLP
                 and type(self.cpe[0]) is spconv.SubMConv3d and self.cpe[0].kernel_size[0] == 3 and self.cpe[0].bias is not None
                 and type(self.cpe[1]) is PNN.Linear and self.cpe[1].bias is not None and type(self.mlp[0]) is MLP
@@ -446,7 +451,8 @@ class Block(PointModule):
                 and self.mlp[0].fc2.bias is not None and isinstance(self.mlp[0].act, nn.GELU) and getattr(self.mlp[0].act, "approximate", "none") == "none"
                 and self.mlp[0].fc1.out_features == 4 * self.channels
                 and getattr(self.mlp[0].drop, "p", 0.0) == 0.0 and getattr(a.proj_drop, "p", 0.0) == 0.0 and a.proj.bias is not None
-                and all(m.elementwise_affine for m in (self.cpe[2], self.norm1[0], self.norm2[0])) and point.feat.dtype in (torch.float32, torch.bfloat16))
+                and all(m.elementwise_affine for m in (self.cpe[2], self.norm1[0], self.norm2[0]))
+                and point.feat.dtype in (torch.float32, torch.get_autocast_dtype("cuda")))
 
     def _forward_exec(self, point: Point):
         sc = point.sparse_conv_feat
@@ -461,9 +467,10 @@ class Block(PointModule):
             return None
         x0 = point.feat
         n, c = x0.shape
-        xc = sc.features if sc.features.dtype == torch.bfloat16 else sc.features.to(torch.bfloat16)
-        blk = None if blocks is None else blocks.get(c, c, torch.bfloat16)
-        meta = dict(n_pad=int(tabs[0].shape[1]), n_seq=int(cu.numel()) - 1, heads=a.num_heads, patch=int(a.patch_size), scale=float(a.scale),
+        dt = torch.get_autocast_dtype("cuda")
+        xc = sc.features if sc.features.dtype == dt else sc.features.to(dt)
+        blk = None if blocks is None else blocks.get(c, c, dt)
+        meta = dict(dt=dt, n_pad=int(tabs[0].shape[1]), n_seq=int(cu.numel()) - 1, heads=a.num_heads, patch=int(a.patch_size), scale=float(a.scale),
                     eps_cpe=self.cpe[2].eps, eps_n1=self.norm1[0].eps, eps_n2=self.norm2[0].eps, nbr=nbr, blk=blk, tabs=tabs, cu=cu)
         m = self.mlp[0]
         params = (conv.weight, conv.bias, self.cpe[1].weight, self.cpe[1].bias, self.cpe[2].weight, self.cpe[2].bias, self.norm1[0].weight,

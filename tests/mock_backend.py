@@ -167,16 +167,17 @@ def spconv_wgrad(feat, dout, nbr, want_bias=False, blk=None):
 
 
 def attn_varlen_fwd(qkv, cu_seqlens, max_seqlen, softmax_scale):
-    out, lse = oops.attention_varlen(qkv.float(), cu_seqlens.tolist(), float(softmax_scale), return_lse=True)
-    return out.to(torch.bfloat16), lse
+    # f16 qkv (head_dim 16): the reference's casts around its bf16 kernel, flash_attn(qkv.to(bfloat16)).to(qkv.dtype)
+    out, lse = oops.attention_varlen(qkv.to(torch.bfloat16).float(), cu_seqlens.tolist(), float(softmax_scale), return_lse=True)
+    return out.to(torch.bfloat16).to(qkv.dtype), lse
 
 
 def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen, softmax_scale):
-    q = qkv.detach().float().requires_grad_(True)
+    q = qkv.detach().to(torch.bfloat16).float().requires_grad_(True)
     with torch.enable_grad():
         o = oops.attention_varlen(q, cu_seqlens.tolist(), float(softmax_scale))
-    o.backward(dout.float())
-    return q.grad.to(torch.bfloat16)
+    o.backward(dout.to(torch.bfloat16).float())
+    return q.grad.to(torch.bfloat16).to(qkv.dtype)
 
 
 def knn_query(nsample, xyz, offset, new_xyz, new_offset):

@@ -447,7 +447,7 @@ def test_spconv_fwd_block_staged(cuda, c, ordered, n_rows=35000):
         _close(f"conv7_nobias_{dtype}", nb, ref - bias, rtol, atol)
 
 
-@pytest.mark.parametrize("c", [32, 64])
+@pytest.mark.parametrize("c", [32, 64, 128, (128, 96), 256, (192, 64)])
 @pytest.mark.parametrize("ordered", [True, False])
 def test_spconv_wgrad_block_staged(cuda, c, ordered, n_rows=35000):
     """wgrad7 (the whole weight gradient held in MFMA accumulators of persistent workgroups, both operands built from a block's LDS
@@ -457,6 +457,12 @@ def test_spconv_wgrad_block_staged(cuda, c, ordered, n_rows=35000):
     count, several blocks per persistent workgroup, bf16 and f16, bit-reproducible."""
     from pointcept_amd import ops
 
+    # (c_in, c_out) pairs and c >= 128: the channel-sliced form (round 4) -- (c_out / 32)(c_in / 64) workgroups per block sequence, each
+    # with one (32 x 64)-channel slice of dw; fewer rows there (the oracle's autograd convolution is the slow part)
+    c_in, c_out = c if isinstance(c, tuple) else (c, c)
+    if c_in > 64:
+        n_rows = min(n_rows, 9000)
+    c = c_in
     ind = _curve_sorted_indices(n_rows)      # (the host-emulation tier runs this body with 4500 rows)
     if not ordered:
         rng = np.random.default_rng(c)
@@ -469,13 +475,13 @@ def test_spconv_wgrad_block_staged(cuda, c, ordered, n_rows=35000):
     assert (int(bt.n_overflow.item()) == 0) == ordered
     g = torch.Generator().manual_seed(c * 77)
     for dtype in (torch.bfloat16, torch.float16):
-        feat = (torch.randn(n, c, generator=g) * 0.5).to(dtype)
-        dout = (torch.randn(n, c, generator=g) * 0.5).to(dtype)
-        wr = torch.zeros(c, 27, c, requires_grad=True)
+        feat = (torch.randn(n, c_in, generator=g) * 0.5).to(dtype)
+        dout = (torch.randn(n, c_out, generator=g) * 0.5).to(dtype)
+        wr = torch.zeros(c_out, 27, c_in, requires_grad=True)
         oops.gather_conv(feat.float(), wr, None, nbr).backward(dout.float())
         base = ops.spconv_wgrad(feat.to(cuda), dout.to(cuda), nbr_d)
         got = ops.spconv_wgrad(feat.to(cuda), dout.to(cuda), nbr_d, blk=bt)
-        assert got.shape == (c, 27, c) and torch.isfinite(got).all()
+        assert got.shape == (c_out, 27, c_in) and torch.isfinite(got).all()
         scale = float(wr.grad.abs().max())
         _close(f"wgrad7_{dtype}", got, wr.grad, 1e-4, 1e-3 * scale)
         if ordered:   # fp32 accumulation in another order: a few ulps of the partial sums
@@ -861,6 +867,27 @@ def test_attention_fwd_bwd(cuda, lens, H):
     fro = lambda a, b: float((a.float().cpu() - b.detach()).norm() / b.detach().norm())
     assert fro(out, ref) < 2.0 ** -8, fro(out, ref)
     assert fro(dqkv, q32.grad) < 2.0 ** -7, fro(dqkv, q32.grad)
+
+
+@pytest.mark.parametrize("lens,H", [([1024, 330], 4), ([1, 2, 31, 32, 33, 65], 3)])
+def test_attention_f16_io_equals_the_reference_cast_passes(cuda, lens, H):
+    """fp16 autocast call site (ptv3m1:209,215): flash_attn(qkv.to(bfloat16)).to(qkv.dtype) and its autograd.  With f16 tensors the kernels do
+    the four casts in their load / store paths -- bit for bit the tensors the separate cast passes produce around the bf16 kernels
+    (forward output, and dqkv for an f16 dout), including values that only f16 can hold (rounded to bf16 on the way in)."""
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(sum(lens) * 3 + H)
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).to(cuda)
+    qkv = (torch.randn(T, 3, H, 16, generator=g) * 1.5).to(torch.float16).to(cuda)        # 11-bit mantissas: .to(bfloat16) rounds
+    scale = 16 ** -0.5
+    out16, lse16 = ops.attn_varlen_fwd(qkv, cu, max(lens), scale)
+    out_b, lse_b = ops.attn_varlen_fwd(qkv.to(torch.bfloat16), cu, max(lens), scale)
+    assert out16.dtype == torch.float16 and torch.equal(out16, out_b.to(torch.float16)) and torch.equal(lse16, lse_b)
+    dout = torch.randn(T, H, 16, generator=g).to(torch.float16).to(cuda)
+    d16 = ops.attn_varlen_bwd(qkv, out16, dout, lse16, cu, max(lens), scale)
+    d_b = ops.attn_varlen_bwd(qkv.to(torch.bfloat16), out_b, dout.to(torch.bfloat16), lse_b, cu, max(lens), scale)
+    assert d16.dtype == torch.float16 and torch.equal(d16, d_b.to(torch.float16))
 
 
 def test_attention_large_logits(cuda):

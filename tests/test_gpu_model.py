@@ -70,7 +70,8 @@ def test_ptv3_tiny_forward_matches_reference_golden_and_oracle(cuda):
     assert torch.equal(pe.cu_seqlens_key.cpu(), po.cu_seqlens_key)
 
 
-def test_block_executor_step_is_bit_identical_to_the_composed_step(cuda, monkeypatch):
+@pytest.mark.parametrize("amp", [torch.bfloat16, torch.float16])
+def test_block_executor_step_is_bit_identical_to_the_composed_step(cuda, monkeypatch, amp):
     """config.EXEC_BLOCK (default on): every PT-v3m1 Block as one C call per direction (csrc/block_exec.hip) against the same
     model with the Blocks composed from ~16 autograd Functions each -- bf16 autocast, drop_path > 0 (the seeded device RNG draws the
     same DropPath masks), ragged two-scene batch: loss and EVERY parameter gradient must be identical (same kernels, same operands,
@@ -101,9 +102,9 @@ def test_block_executor_step_is_bit_identical_to_the_composed_step(cuda, monkeyp
             if isinstance(m_, torch.nn.BatchNorm1d):
                 m_.reset_running_stats()
         torch.manual_seed(9)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=amp):       # f16 (round 4): the reference's recipe; the attention kernels do the call site's casts
             loss = eng(dict(batch))["loss"]
-        loss.backward()
+        (loss * (1024.0 if amp == torch.float16 else 1.0)).backward()       # a fixed loss scale stands in for GradScaler
         res[on] = (float(loss.detach()), {k: p.grad.clone() for k, p in eng.named_parameters()}, calls["n"])
     n_blocks = sum(1 for m_ in eng.modules() if type(m_).__name__ == "Block")
     n_wide = sum(1 for m_ in eng.modules() if type(m_).__name__ == "Block" and m_.channels > 256)

@@ -196,10 +196,11 @@ EMULATED_GPU_TESTS = [
     ("test_spconv_fwd_block_staged", dict(c=32, ordered=False, n_rows=4500)),
     ("test_spconv_wgrad_block_staged", dict(c=64, ordered=True, n_rows=4500)), ("test_spconv_wgrad_block_staged", dict(c=32, ordered=True, n_rows=4500)),
     ("test_spconv_wgrad_block_staged", dict(c=64, ordered=False, n_rows=4500)),
+    ("test_spconv_wgrad_block_staged", dict(c=128, ordered=True, n_rows=2500)), ("test_spconv_wgrad_block_staged", dict(c=(128, 96), ordered=True, n_rows=2500)),
     ("test_conv_tiny_inputs", dict(n=17)), ("test_spconv_dgrad_via_mirrored_table", dict()), ("test_spconv_down_up_tables", dict()),
     ("test_pool_maps", dict(n_pts=3000)),
     ("test_attention_fwd_bwd", dict(lens=[48, 48, 17], H=2)), ("test_attention_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
-    ("test_attention_large_logits", dict()),
+    ("test_attention_large_logits", dict()), ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
     ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6)),
     ("test_attention_rpe_fwd_bwd", dict(lens=[200, 200, 200], H=3, bnd=18)),
 ]   # (in-place GPU tests -- rope3d, cross entropy -- are not in the list: with device = cpu their `.to(device)` aliases the input the

@@ -204,9 +204,13 @@ def bench_spconv_stages(rows, results, scenes=8, points=102400, outdoor=False):
                       f"halo {r['halo_mean']:.0f}/{plan[0]}, {r['blocks_overflow']} overflow)")
             g = torch.randn(n, c, device=DEV).to(torch.bfloat16)
             r["wgrad"] = roof(by, fl, timeit(lambda: ops.spconv_wgrad(x, g, nbr), iters=10))
+            w7 = ""
+            if plan is not None:   # the accumulator-stationary weight gradient on the block tables (csrc/wgrad7.h; channel slices above 64)
+                r["wgrad7"] = roof(by, fl, timeit(lambda: ops.spconv_wgrad(x, g, nbr, blk=blk), iters=10))
+                w7 = f" | block-staged wgrad {r['wgrad7']['us']:8.1f} us ({r['wgrad7']['TFLOPs']:.1f} TF/s)"
             results.append(r)
             rows.append(f"conv stage {s} n={n:7d} {ci:3d}->{c:3d} pairs/pt={pairs / n:5.2f} | global gathers {r['conv']['us']:8.1f} us "
-                        f"({r['conv']['GBps']:.0f} GB/s alg, {r['conv']['TFLOPs']:.1f} TF/s){c4} | wgrad {r['wgrad']['us']:8.1f} us ({r['wgrad']['TFLOPs']:.1f} TF/s)")
+                        f"({r['conv']['GBps']:.0f} GB/s alg, {r['conv']['TFLOPs']:.1f} TF/s){c4} | wgrad {r['wgrad']['us']:8.1f} us ({r['wgrad']['TFLOPs']:.1f} TF/s){w7}")
 
 
 def bench_losses(rows, results, n=819200, c=20):

@@ -23,10 +23,11 @@ ap.add_argument("--scenes", type=int, default=2)
 ap.add_argument("--points", type=int, default=102400)
 ap.add_argument("--order", default="z")
 ap.add_argument("--stride", type=int, default=1, help="grid stride of the level (2 = after one pooling)")
+ap.add_argument("--outdoor", action="store_true", help="LiDAR sweeps of BASELINE configs[4] instead of the indoor rooms")
 a = ap.parse_args()
 halo, occ_tile, occ_half, occ_blk, nbrs = [], [], [], [], []
 for s in range(a.scenes):
-    sc = synthetic.indoor_scene(s, a.points)
+    sc = synthetic.outdoor_scene(5000 + s, azimuth_steps=3300) if a.outdoor else synthetic.indoor_scene(s, a.points)
     gc = np.unique(sc["grid_coord"] // a.stride, axis=0)
     code = sfc.encode_c(gc, None, 16, [a.order])[0]
     gc = gc[np.argsort(code, kind="stable")]

@@ -27,6 +27,7 @@ for _ in range(3):
     step()
 torch.cuda.synchronize()
 enq, tot = [], []
+ms0 = torch.cuda.memory_stats()
 for _ in range(8):
     t0 = time.perf_counter()
     step()
@@ -36,6 +37,13 @@ for _ in range(8):
     enq.append((t1 - t0) * 1e3)
     tot.append((t2 - t0) * 1e3)
 from pointcept_amd import config  # noqa: E402
+
+ms1 = torch.cuda.memory_stats()
+# device allocations / frees inside the timed steps: a hipFree synchronises the device (a step whose allocator keeps growing and
+# trimming shows up here, not in the kernel profile)
+print(f"allocator over the 8 timed steps: {ms1['num_device_alloc'] - ms0['num_device_alloc']} device allocations, "
+      f"{ms1['num_device_free'] - ms0['num_device_free']} device frees, {ms1['num_alloc_retries'] - ms0['num_alloc_retries']} retries; "
+      f"reserved {ms1['reserved_bytes.all.current'] / 2**30:.2f} GiB, peak allocated {ms1['allocated_bytes.all.peak'] / 2**30:.2f} GiB")
 
 print(f"{mine.scenes} x {mine.points} voxels, block executor {'on' if config.EXEC_BLOCK else 'off'}: ", end="")
 print(f"host enqueue per step: mean {sum(enq) / len(enq):.1f} ms (min {min(enq):.1f}); step complete: mean {sum(tot) / len(tot):.1f} ms; "
