@@ -36,11 +36,29 @@
 #ifndef C3_NT8_MIN_WGS
 #define C3_NT8_MIN_WGS 256    // fewest 256-row x 128-column workgroups for which the wide tile is used
 #endif
+#ifndef C3_NT8_SMALL
+#define C3_NT8_SMALL 1        // 0: timing A/B only
+#endif
+#ifndef C3_NT8_SMALL_MIN_WGS
+#define C3_NT8_SMALL_MIN_WGS 128
+#endif
+#ifndef C3_DEEP
+#define C3_DEEP 1             // 0: timing A/B only (`python -m pointcept_amd.build --variant d_C3_DEEP_0`)
+#endif
+#ifndef C3_DEEP_MAX_WGS
+#define C3_DEEP_MAX_WGS 1024  // most 128-row x 64-column workgroups for which the two-chunk ring is used: at most one per CU.  (Measured: 2 821 rows x 512 channels
+                              // 138 -> 118 us; 12 115 x 256 and 50 360 x 128 -- 380 / 788 workgroups -- unchanged: those are bound by the address path of their
+                              // gathers, not by latency, profiles/r04_m_ops_stages.txt)
+#endif
 #define C3_FRAG 1024
 #define C3_FPAD 64
 #define C3_BUF(NTILES) (4 * (NTILES) * (C3_FRAG + C3_FPAD))   // one W chunk: NTILES tiles x 4 steps
 
-template <typename T, int RT, int KPC, int NTILES, bool GEN, bool IDENT = false>
+// DEEP (round 4, the deep stages of the indoor scenes: 2 800 .. 50 000 rows at 128 .. 512 channels -- fewer workgroups than two per CU):
+// the gathers run TWO chunks ahead through two ring slots.  A 128-row x 64-column chunk is 32 MFMAs per wave = ~512 matrix-pipe cycles,
+// against ~2 us of L2 latency under load: with one or two waves per SIMD the one-chunk ring stalled every chunk (stage 4, 2 821 rows x
+// 512 channels: 138 us = 135 TF/s for a problem whose MFMAs take 24 us).
+template <typename T, int RT, int KPC, int NTILES, bool GEN, bool IDENT = false, bool DEEP = false>
 __global__ void __launch_bounds__(256, 2)
 conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
              const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int n_rowblk, T* __restrict__ out,
@@ -77,14 +95,16 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
     const int prow = lds_row_of_channel<NTILES>(wr);
     wdst[ps] = ((prow >> 4) * 4 + qd) * (C3_FRAG + C3_FPAD) + (prow & 15) * 16;
   }
-  uint4 wreg[WP][4];
+  constexpr int WSETS = DEEP ? 2 : 1;   // DEEP: W(c + 1) and W(c + 2) are in flight at the same time (register set = chunk parity)
+  uint4 wreg[WSETS][WP][4];
   // SPLIT (NTILES = 8): buffer (c + 1) & 1 is free for the whole of chunk c (its readers passed the barrier that ended chunk c - 1), so
   // pass 0 of W(c + 1) is stored in the MIDDLE of chunk c and pass 1 loaded only then: the staging registers of one pass (16) instead
   // of two (32) are live across the chunk's MFMAs -- the 128-column instance sits at the 256-register cap
   constexpr bool SPLIT = NTILES == 8;
   // (pass range [p0, p1): the two-pass instances -- 96 / 128 output channels -- stage their passes at different points of a chunk,
   //  see SPLIT below, so that only ONE pass of staging registers is live across the MFMAs)
-  auto wload = [&](int c, int p0 = 0, int p1 = 4) {
+  auto wload_s = [&](auto wset, int c, int p0, int p1) {
+    constexpr int WS = decltype(wset)::value;
 #pragma unroll
     for (int ps = 0; ps < WP; ++ps) {
       if (ps < p0 || ps >= p1) continue;
@@ -98,25 +118,29 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
         const int vc = v0 < KV ? v0 : KV - 8;
         uint4 v = *reinterpret_cast<const uint4*>(wsrc[ps] - qd * 32 + vc);
         if (!ok) v = make_uint4(0, 0, 0, 0);
-        wreg[ps][gq] = v;
+        wreg[WS][ps][gq] = v;
       }
     }
   };
-  auto wstore = [&](int buf, int p0 = 0, int p1 = 4) {
+  auto wload = [&](int c, int p0 = 0, int p1 = 4) { wload_s(ptc_int<0>{}, c, p0, p1); };
+  auto wstore_s = [&](auto wset, int buf, int p0, int p1) {
+    constexpr int WS = decltype(wset)::value;
 #pragma unroll
     for (int ps = 0; ps < WP; ++ps) {
       if (ps < p0 || ps >= p1) continue;
       if (wthread[ps]) {
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<uint4*>(smem + buf * C3_BUF(NTILES) + wdst[ps] + gq * 256) = wreg[ps][gq];
+        for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<uint4*>(smem + buf * C3_BUF(NTILES) + wdst[ps] + gq * 256) = wreg[WS][ps][gq];
       }
     }
   };
+  auto wstore = [&](int buf, int p0 = 0, int p1 = 4) { wstore_s(ptc_int<0>{}, buf, p0, p1); };
 
   // ---- gather ring
   // a ring slot holds the MFMA operand itself (lane l: row l & 15, piece l >> 4)
-  frag ga[4][RT];
-  bool anyv[4][RT];                  // wave-level "any neighbour at this step"
+  constexpr int NSLOT = DEEP ? 2 : 1;
+  frag ga[NSLOT][4][RT];
+  bool anyv[NSLOT][4][RT];           // wave-level "any neighbour at this step"
   // KPC = 16 is the c_in = 8 form (the 6 -> 32 stems, padded to 8): a 32-slot MFMA step spans FOUR table rows, one per lane
   // group, so a lane keeps the entries of ITS table row of each step: ix[s][j] = entry of table row 16 c + 4 s + g
   constexpr int KI = KPC == 16 ? 4 : KPC;
@@ -142,7 +166,8 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       }
     }
   };
-  auto issue = [&](int c, int s, const int32_t (&ix)[KI][RT]) {
+  auto issue = [&](int c, int s, const int32_t (&ix)[KI][RT], auto slot) {
+    constexpr int SL = decltype(slot)::value;
     const int v0 = c * 128 + s * 32;                 // flattened contraction index of this step
     int kk, cbase;
     if constexpr (KPC == 16) {
@@ -167,8 +192,8 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
         i = ix[kk][j];                                               // kk is a compile-time constant after unrolling
       }
       // one unconditional buffer load: absent neighbours are out-of-range offsets and come back as zeros
-      ga[s][j] = ld_frag_buf<T>(in_buf, i >= 0 ? ((uint32_t)i * (uint32_t)c_in + (uint32_t)cbase) * 2u : PTC_BUF_OOB);
-      anyv[s][j] = __builtin_amdgcn_ballot_w64(i >= 0) != 0;
+      ga[SL][s][j] = ld_frag_buf<T>(in_buf, i >= 0 ? ((uint32_t)i * (uint32_t)c_in + (uint32_t)cbase) * 2u : PTC_BUF_OOB);
+      anyv[SL][s][j] = __builtin_amdgcn_ballot_w64(i >= 0) != 0;
     }
   };
   f32x4 acc[RT][NTILES];
@@ -181,20 +206,31 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       for (int t = 0; t < NTILES; ++t) acc[j][t] = breg[t];
   }
 
-  // ---- prologue: W(0) -> LDS, gathers of chunk 0 in flight, W(1) and idx(1) requested
+  // ---- prologue: W(0) -> LDS, gathers of chunk 0 (DEEP: and of chunk 1) in flight, W(1) and the next table entries requested
+  constexpr int AHEAD = DEEP ? 2 : 1;               // chunks between a gather and its MFMAs
   wload(0);
   load_idx(0, idxN);
   wstore(0);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) issue(0, s, idxN);
+  for (int s = 0; s < 4; ++s) issue(0, s, idxN, ptc_int<0>{});
   load_idx(1, idxN);
-  if constexpr (SPLIT) wload(1, 0, 1); else wload(1);
+  if constexpr (DEEP) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) issue(1, s, idxN, ptc_int<1>{});
+    load_idx(2, idxN);
+  }
+  static_assert(!(SPLIT && DEEP), "the two-pass W staging and the two-chunk ring are separate instances");
+  if constexpr (DEEP) {           // W(1) -> set 1, W(2) -> set 0 (its first content, W(0), is in LDS already)
+    wload_s(ptc_int<1>{}, 1, 0, 4);
+    wload_s(ptc_int<0>{}, 2, 0, 4);
+  } else if constexpr (SPLIT) wload(1, 0, 1); else wload(1);
   __syncthreads();
 
-#pragma unroll 1
-  for (int c = 0; c < nchunks; ++c) {
+  // one chunk: multiply ring slot `slot`, refill it with chunk c + AHEAD, stage W(c + 1)
+  auto chunk = [&](int c, auto slot) {
+    constexpr int SL = decltype(slot)::value;
     const unsigned char* wb = smem + (c & 1) * C3_BUF(NTILES) + lane * 16;
-    load_idx(c + 2, idxNN);
+    load_idx(c + AHEAD + 1, idxNN);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       // (NTILES = 8: the W fragments of a step in two halves of four -- 16 registers less live at the 256-register cap)
@@ -206,13 +242,13 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
         for (int t = 0; t < WH; ++t) wf[t] = *reinterpret_cast<const frag*>(wb + ((t0 + t) * 4 + s) * (C3_FRAG + C3_FPAD));
 #pragma unroll
         for (int j = 0; j < RT; ++j) {
-          if (anyv[s][j]) {
+          if (anyv[SL][s][j]) {
 #pragma unroll
-            for (int t = 0; t < WH; ++t) acc[j][t0 + t] = M::mma(wf[t], ga[s][j], acc[j][t0 + t]);
+            for (int t = 0; t < WH; ++t) acc[j][t0 + t] = M::mma(wf[t], ga[SL][s][j], acc[j][t0 + t]);
           }
         }
       }
-      issue(c + 1, s, idxN);
+      issue(c + AHEAD, s, idxN, slot);
       if constexpr (SPLIT) {
         if (s == 1) {
           wstore((c + 1) & 1, 0, 1);
@@ -220,13 +256,31 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
         }
       }
     }
-    if constexpr (SPLIT) wstore((c + 1) & 1, 1, 2); else wstore((c + 1) & 1);
-    __syncthreads();
-    if constexpr (SPLIT) wload(c + 2, 0, 1); else wload(c + 2);
+    if constexpr (DEEP) {         // W(c + 1) was requested two chunks ago into the set of ITS parity; that set then takes W(c + 3)
+      wstore_s(ptc_int<1 - SL>{}, (c + 1) & 1, 0, 4);
+      __syncthreads();
+      wload_s(ptc_int<1 - SL>{}, c + 3, 0, 4);
+    } else {
+      if constexpr (SPLIT) wstore((c + 1) & 1, 1, 2); else wstore((c + 1) & 1);
+      __syncthreads();
+      if constexpr (SPLIT) wload(c + 2, 0, 1); else wload(c + 2);
+    }
 #pragma unroll
     for (int kk = 0; kk < KI; ++kk)
 #pragma unroll
       for (int j = 0; j < RT; ++j) idxN[kk][j] = idxNN[kk][j];
+  };
+  if constexpr (DEEP) {
+    int c = 0;
+#pragma unroll 1
+    for (; c + 1 < nchunks; c += 2) {
+      chunk(c, ptc_int<0>{});
+      chunk(c + 1, ptc_int<1>{});
+    }
+    if (c < nchunks) chunk(c, ptc_int<0>{});
+  } else {
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) chunk(c, ptc_int<0>{});
   }
 
 #pragma unroll
@@ -251,13 +305,13 @@ static inline bool conv3_supported(int dtype, int kv, int c_in, int c_out, const
   return !(c_in == 32 && c_out % 64 != 0 && c_out % 96 != 0);
 }
 
-template <typename T, int RT, int KPC, int NTILES, bool GEN, bool IDENT = false>
+template <typename T, int RT, int KPC, int NTILES, bool GEN, bool IDENT = false, bool DEEP = false>
 static int launch_conv3_i(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
                           int c_in, int c_out, void* out, hipStream_t s) {
   const int n_rowblk = (int)ptc_cdiv(n_out, RT * 64);
   const int nblk = n_rowblk * (c_out / (NTILES * 16));
   const size_t lds = 2 * C3_BUF(NTILES);
-  auto kern = conv3_kernel<T, RT, KPC, NTILES, GEN, IDENT>;
+  auto kern = conv3_kernel<T, RT, KPC, NTILES, GEN, IDENT, DEEP>;
   static size_t allowed = 48 * 1024;   // per instantiation
   if (lds > allowed) {
     PTC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -283,6 +337,13 @@ static int launch_conv3(const void* in, int64_t n_in, const void* w, const float
   // 28.4 vs 29.6 ms, profiles/r03_q_spunet_nt6_ab.txt); c_in % 128 == 0 does not spill
   const bool big = (nt != 6 || kpc <= 2) && ptc_cdiv(n_out, 256) * (c_out / (nt * 16)) >= 256;
   const bool gen = !(c_in == 8 || c_in == 32 || c_in == 64 || c_in % 128 == 0);   // table rows straddle chunks (kpc == 2)
+#if C3_DEEP
+  // few workgroups (the deep stages of indoor scenes): the 128-row x 64-column form with its gathers two chunks ahead (see DEEP above)
+  if (kpc == 1 && nt == 4 && !big && ptc_cdiv(n_out, 128) * (c_out / 64) <= C3_DEEP_MAX_WGS) {
+    if (nbr == nullptr) return launch_conv3_i<T, 2, 1, 4, false, true, true>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+    return launch_conv3_i<T, 2, 1, 4, false, false, true>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  }
+#endif
 #if C3_NT8
   // 128 output channels per workgroup at c_in % 128 == 0 (round 4): the gathered rows are the B operand of TWICE as many MFMAs.  The
   // kernel is bound by the address path of its gathers at 64 columns (a 1-KB wave gather in B-operand layout costs ~57 address cycles,
@@ -295,6 +356,15 @@ static int launch_conv3(const void* in, int64_t n_in, const void* w, const float
     if (nbr == nullptr) return launch_conv3_i<T, 4, 1, 8, false, true>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
     return launch_conv3_i<T, 4, 1, 8, false>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
   }
+#if C3_NT8_SMALL
+  // the same wide tile on 128-row workgroups for the mid-sized problems (indoor stages 2 / 3: 12 000 .. 50 000 rows): they are bound by the
+  // address path too (8 waves x 54 chunks x 8 gathers x ~57 cycles per CU = 85 us at 12 115 rows x 256 channels, measured 99 us), and
+  // the 128-column tile halves the gathers per flop
+  if (kpc == 1 && c_out % 128 == 0 && ptc_cdiv(n_out, 128) * (c_out / 128) >= C3_NT8_SMALL_MIN_WGS) {
+    if (nbr == nullptr) return launch_conv3_i<T, 2, 1, 8, false, true>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+    return launch_conv3_i<T, 2, 1, 8, false>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+  }
+#endif
 #endif
   if (nbr == nullptr) {   // dense GEMM (kv = 1, c_in % 128 == 0): identity-table instances
 #define C3_ID_CASE(N)                                                                                                        \

@@ -41,8 +41,9 @@
 // A block whose halo did not fit (hcnt < 0: rows in no spatial order) cannot be served here; the host entry point therefore GATES the
 // two kernels on the device-side overflow counter of the table builder: this kernel runs when it is zero, wgrad2 over the whole tensor
 // when it is not, each returning at once otherwise -- no host synchronisation, and the reduction reads the partials of whichever ran.
-// CHANNEL SLICES (round 4, the 128 .. 512-channel stages; c_in % 64 == 0, c_out % 32 == 0, c_in and c_out independent): the C = 64 geometry
-// with a workgroup owning ONE (32 output channels) x (64 input channels) slice of dw for all 27 taps -- the same 224 accumulation
+// CHANNEL SLICES (round 4, the 128 .. 512-channel stages and SpUNet's 96-channel decoder; c_in % 32 == 0, c_out % 32 == 0, c_in and c_out
+// independent): the C = 64 geometry (the C = 32 one when c_in is not a multiple of 64)
+// with a workgroup owning ONE (32 output channels) x (64 | 32 input channels) slice of dw for all 27 taps -- the same 224 accumulation
 // registers -- and staging only ITS 128 bytes of every halo row and ITS 64 bytes of every dout row.  (c_out / 32)(c_in / 64) workgroups
 // walk one block sequence (same XCD, dispatched back to back: the slices of a row come out of one L2); 256 / slices sequences.  wgrad2 at
 // these widths re-streams dout and re-gathers its rows once per (64 x 64 channel tile, tap pair): 16 x 14 times at 256 channels -- 95 TF/s
@@ -58,8 +59,15 @@
 #define W7_DMA_EVERY 2                       // ... one per this many (step, tap) pairs
 
 #define W7_MAX_WGS 256                       // one persistent workgroup per CU
-static inline bool wgrad7_sliced(int c_in, int c_out) { return c_in % 64 == 0 && c_out % 32 == 0 && c_in <= 1024 && c_out <= 1024 && !(c_in == 64 && c_out == 64); }
-static inline int wgrad7_slices(int c_in, int c_out) { return wgrad7_sliced(c_in, c_out) ? (c_in / 64) * (c_out / 32) : (c_in == 64 ? 2 : 1); }
+// channel slices: input-channel blocks of 64 (c_in % 64 == 0: the 64-channel geometry) or of 32 (c_in % 32 == 0 only -- SpUNet's 96-channel
+// decoder: the 32-channel geometry), output-channel blocks of 32
+static inline bool wgrad7_sliced(int c_in, int c_out) {
+  return c_in % 32 == 0 && c_out % 32 == 0 && c_in <= 1024 && c_out <= 1024 && !(c_in == c_out && (c_in == 64 || c_in == 32));
+}
+static inline int wgrad7_slice_cin(int c_in) { return c_in % 64 == 0 ? 64 : 32; }
+static inline int wgrad7_slices(int c_in, int c_out) {
+  return wgrad7_sliced(c_in, c_out) ? (c_in / wgrad7_slice_cin(c_in)) * (c_out / 32) : (c_in == 64 ? 2 : 1);
+}
 static inline bool wgrad7_supported(int dtype, int kv, int c_in, int c_out, int bm, int hcap, int64_t n_out) {
   if (conv7_supported(dtype, kv, c_in, c_out, bm, hcap, n_out)) return true;
   return dtype != PTC_F32 && kv == 27 && bm == C7_BM && hcap == C7_HCAP && n_out >= 1024 && wgrad7_sliced(c_in, c_out) &&
@@ -70,7 +78,15 @@ static inline bool wgrad7_supported(int dtype, int kv, int c_in, int c_out, int 
 // fp32 copy of dw, which at 256+ channels outweighs the operands of a short sequence)
 static inline int wgrad7_splits(int64_t n_out, int c_in, int c_out) {
   int64_t nb = ptc_cdiv(n_out, C7_BM), cap = W7_MAX_WGS / wgrad7_slices(c_in, c_out);
-  if (wgrad7_sliced(c_in, c_out) && cap > (nb + 3) / 4) cap = (nb + 3) / 4;
+  if (wgrad7_sliced(c_in, c_out)) {
+    if (cap > (nb + 3) / 4) cap = (nb + 3) / 4;
+    // ... and no more sequences than keep the partials (one fp32 dw per sequence, written and read once) below four times the operands:
+    // 2821 rows at 512 channels are 9 MB of operands against 28 MB per partial -- two sequences ran 136 us where wgrad2 takes 98
+    // (profiles/r04_l_ops_stages.txt)
+    const int64_t partial = (int64_t)27 * c_in * c_out * 4, operands = n_out * (int64_t)(c_in + c_out) * 2;
+    const int64_t by_traffic = 4 * operands / partial;
+    if (cap > by_traffic) cap = by_traffic;
+  }
   if (cap < 1) cap = 1;
 #ifndef __HIPCC__
   if (const char* e = getenv("PTC_EMU_CONV7_WGS")) cap = atoi(e);   // host emulation only: several blocks per workgroup at test sizes
@@ -104,7 +120,7 @@ __global__ void __launch_bounds__(256, 1)
 wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16_t* __restrict__ tab, const int32_t* __restrict__ hid,
               const int32_t* __restrict__ hcnt, const int32_t* __restrict__ gate, int64_t n_out, int n_blocks, float* __restrict__ partial,
               int c_in_full, int c_out_full) {
-  static_assert(!SL || C == 64, "channel slices use the 64-channel geometry");
+
   using frag = typename Mma<T>::frag;
   using MM = C7Mma<T>;
   using G = W7Geom<C>;
@@ -121,7 +137,7 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
   // SL: n_sl = (c_out / 32)(c_in / 64) slices per sequence; sequence s, slice t <-> hardware workgroup (s % 8) + 8 (t + n_sl (s / 8)) when the
   // sequences come in whole rounds of eight (the generalisation of the C = 64 rule), else s n_sl + t
   const int wgs = (int)gridDim.x;
-  const int n_ci = SL ? c_in_full / 64 : 1, n_sl = SL ? n_ci * (c_out_full / 32) : (C == 64 ? 2 : 1);
+  const int n_ci = SL ? c_in_full / C : 1, n_sl = SL ? n_ci * (c_out_full / 32) : (C == 64 ? 2 : 1);
   const int step = wgs / n_sl;
   int vb, sl;
   if constexpr (SL) {
@@ -133,8 +149,8 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
     sl = C == 64 ? (wgs % 16 == 0 ? (((int)blockIdx.x >> 3) & 1) : ((int)blockIdx.x & 1)) : 0;
   }
   const int ch = SL ? sl / n_ci : sl;                         // 32-channel block of dout / dw rows this workgroup owns
-  const int cib = SL ? sl - ch * n_ci : 0;                    // SL: 64-channel block of the input rows
-  const uint32_t in_pitch = SL ? (uint32_t)c_in_full * 2u : (uint32_t)ROWB, in_col = (uint32_t)cib * 128u;       // bytes
+  const int cib = SL ? sl - ch * n_ci : 0;                    // SL: C-channel block of the input rows
+  const uint32_t in_pitch = SL ? (uint32_t)c_in_full * 2u : (uint32_t)ROWB, in_col = (uint32_t)cib * (uint32_t)ROWB;       // bytes
   const uint32_t do_pitch = SL ? (uint32_t)c_out_full * 2u : (uint32_t)ROWB;
   const int b_begin = (step % 8 == 0) ? (vb & 7) * (step / 8) + (vb >> 3) : vb;
   const int b_end = n_blocks;
@@ -292,7 +308,7 @@ wgrad7_kernel(const T* __restrict__ in, const T* __restrict__ dout, const uint16
       for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int co = ch * 32 + 8 * (r >> 2) + 4 * hh + (r & 3), ci = cib * 64 + kh * 32 + jj;
+          const int co = ch * 32 + 8 * (r >> 2) + 4 * hh + (r & 3), ci = cib * C + kh * 32 + jj;
           pout[((int64_t)co * 27 + k) * cif + ci] = acc[a * KH + kh][r];
         }
     }

@@ -24,9 +24,13 @@ __device__ __forceinline__ F ld_tr_pair16(const unsigned char* p0, const unsigne
 
 int ptc_wgrad7_launch(int dtype, const void* in, const void* dout, const uint16_t* tab, const int32_t* hid, const int32_t* hcnt,
                       const int32_t* gate, int64_t n_out, int c_in, int c_out, float* partial, hipStream_t s) {
-  if (wgrad7_sliced(c_in, c_out)) {   // 128 .. 512-channel stages: (32 x 64)-channel slices of dw on the 64-channel geometry
-    if (dtype == PTC_BF16) return launch_wgrad7_i<bf16_t, 64, true>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s);
-    return launch_wgrad7_i<f16_t, 64, true>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s);
+  if (wgrad7_sliced(c_in, c_out)) {   // 96 .. 512-channel layers: (32 x 64 | 32)-channel slices of dw on the 64- / 32-channel geometry
+    if (wgrad7_slice_cin(c_in) == 64) {
+      if (dtype == PTC_BF16) return launch_wgrad7_i<bf16_t, 64, true>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s);
+      return launch_wgrad7_i<f16_t, 64, true>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s);
+    }
+    if (dtype == PTC_BF16) return launch_wgrad7_i<bf16_t, 32, true>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s);
+    return launch_wgrad7_i<f16_t, 32, true>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s);
   }
   if (dtype == PTC_BF16)
     return c_in == 64 ? launch_wgrad7_i<bf16_t, 64>(in, dout, tab, hid, hcnt, gate, n_out, c_in, c_out, partial, s)

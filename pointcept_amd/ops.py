@@ -462,14 +462,15 @@ class BlockTables:
 def block_plan(c_in: int, c_out: int, kv: int, dtype: torch.dtype, n_rows: int = 1 << 30):
     """(bm, hcap) of the block-local tables for this shape, or None when the shape stays on the global-gather kernels.  Two consumers:
     the LDS-staged, register-weight convolution (csrc/conv7.h conv7_supported: 16-bit, 3^3 table, c_in = c_out in {32, 64}, >= 4096
-    rows) and the accumulator-stationary weight gradient (csrc/wgrad7.h: the same shapes, plus -- round 4 -- every c_in % 64 == 0,
-    c_out % 32 == 0 shape of the 128 .. 512-channel stages as (32 x 64)-channel slices; the forward of those shapes takes the tables and
+    rows) and the accumulator-stationary weight gradient (csrc/wgrad7.h: the same shapes, plus -- round 4 -- every c_in % 32 == 0,
+    c_out % 32 == 0 shape (the 128 .. 512-channel stages, SpUNet's 96-channel decoder) as (32 x 64 | 32)-channel slices; the forward of those shapes takes the tables and
     falls back to the global-gather kernel inside ptc_spconv_fwd_blk)."""
     if dtype == torch.float32 or kv != 27:
         return None
     if c_in == c_out and c_in in (32, 64):
         return (BLOCK_BM, BLOCK_HCAP) if n_rows >= 4096 else None
-    if c_in % 64 == 0 and c_out % 32 == 0 and c_in <= 1024 and c_out <= 1024 and (c_in // 64) * (c_out // 32) <= 256 and n_rows >= 1024:
+    if c_in % 32 == 0 and c_out % 32 == 0 and c_in <= 1024 and c_out <= 1024 and (c_in // (64 if c_in % 64 == 0 else 32)) * (c_out // 32) <= 256 \
+            and n_rows >= 1024:
         return (BLOCK_BM, BLOCK_HCAP)
     return None
 

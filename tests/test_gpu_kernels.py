@@ -447,7 +447,7 @@ def test_spconv_fwd_block_staged(cuda, c, ordered, n_rows=35000):
         _close(f"conv7_nobias_{dtype}", nb, ref - bias, rtol, atol)
 
 
-@pytest.mark.parametrize("c", [32, 64, 128, (128, 96), 256, (192, 64)])
+@pytest.mark.parametrize("c", [32, 64, 128, (128, 96), 256, (192, 64), 96, (32, 64), (96, 32)])
 @pytest.mark.parametrize("ordered", [True, False])
 def test_spconv_wgrad_block_staged(cuda, c, ordered, n_rows=35000):
     """wgrad7 (the whole weight gradient held in MFMA accumulators of persistent workgroups, both operands built from a block's LDS
@@ -460,7 +460,7 @@ def test_spconv_wgrad_block_staged(cuda, c, ordered, n_rows=35000):
     # (c_in, c_out) pairs and c >= 128: the channel-sliced form (round 4) -- (c_out / 32)(c_in / 64) workgroups per block sequence, each
     # with one (32 x 64)-channel slice of dw; fewer rows there (the oracle's autograd convolution is the slow part)
     c_in, c_out = c if isinstance(c, tuple) else (c, c)
-    if c_in > 64:
+    if c_in > 64 or c_in != c_out:
         n_rows = min(n_rows, 9000)
     c = c_in
     ind = _curve_sorted_indices(n_rows)      # (the host-emulation tier runs this body with 4500 rows)
