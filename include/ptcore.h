@@ -380,6 +380,19 @@ int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void* dout, cons
                         int max_seqlen, float softmax_scale, int dtype, void* dqkv,
                         void* workspace, size_t workspace_bytes, ptc_stream_t stream);
 
+/* The same operator WITH attention dropout (`dropout_p = self.attn_drop if self.training else 0`, ptv3m1:212; flash-attn's semantics:
+ * softmax over all keys, then every probability dropped with probability dropout_p in [0, 1) and the survivors scaled by
+ * 1 / (1 - dropout_p); lse is that of the undropped scores).  The mask is a pure function of (seed, sequence, head, query, key) --
+ * a 32-bit integer hash compared with dropout_p 2^32 (csrc/attention_drop.h: ad_unit_key / ad_keep; restated in oracle/ops.py) --
+ * regenerated by the backward from the same seed; it is NOT flash-attn's Philox stream.  head_dim 16, bf16 or f16 tensors. */
+int ptc_attn_varlen_dropout_fwd(const void* qkv, const int32_t* cu_seqlens, int64_t n_seq, int64_t total, int H, int max_seqlen,
+                                float softmax_scale, int dtype, float dropout_p, uint64_t seed, void* out, float* lse,
+                                ptc_stream_t stream);
+int ptc_attn_varlen_dropout_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
+                                int64_t n_seq, int64_t total, int H, int max_seqlen, float softmax_scale, int dtype,
+                                float dropout_p, uint64_t seed, void* dqkv, void* workspace, size_t workspace_bytes,
+                                ptc_stream_t stream);
+
 /* Same operator for head_dim 17..64 (PT-v3m3 / LitePT: head_dim 18, flash_attn_varlen_qkvpacked_func as called at
  * pointcept/models/point_transformer_v3/point_transformer_v3m3_utonia.py:353-359 and pointcept/models/litept/litept_v1.py:244-256):
  *   qkv [total, 3, H, head_dim] bf16 packed, out [total, H, head_dim], lse [H, total] fp32, dqkv like qkv.

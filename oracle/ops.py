@@ -177,16 +177,46 @@ def attention_varlen_kernel_rounding(qkv: torch.Tensor, cu_seqlens, softmax_scal
 # ------------------------------------------------------------------------------------------------
 # variable-length attention (flash_attn.flash_attn_varlen_qkvpacked_func semantics; ptv3m1:208-214)
 # ------------------------------------------------------------------------------------------------
-def attention_varlen(qkv: torch.Tensor, cu_seqlens, softmax_scale: float, return_lse: bool = False):
+def attn_dropout_keep(seed: int, unit: int, lq: int, lk: int, p: float) -> torch.Tensor:
+    """keep mask [lq, lk] (bool) of attention dropout inside the (sequence, head) unit `unit` = sequence * H + head: the integer hash
+    of pointcept_amd/csrc/attention_drop.h (ad_unit_key / ad_keep) restated in numpy uint32 arithmetic.  TEST INFRASTRUCTURE: the
+    random stream of attention dropout is an implementation detail of the attention library (flash-attn's Philox stream in the
+    reference); parity of the kernels is stated against softmax-then-drop with THIS mask."""
+    M = 0xFFFFFFFF
+    seed_lo, seed_hi = seed & M, (seed >> 32) & M
+    h = (seed_lo ^ ((unit * 0x9E3779B1) & M)) & M
+    h ^= h >> 16; h = (h * 0x7FEB352D) & M; h ^= h >> 15; h = (h * 0x846CA68B) & M; h ^= h >> 16
+    h ^= (seed_hi * 0xC2B2AE3D) & M
+    h ^= h >> 15; h = (h * 0x2C1B3C6D) & M; h ^= h >> 12
+    uk = np.uint64(h)
+    q = np.arange(lq, dtype=np.uint64)[:, None]
+    k = np.arange(lk, dtype=np.uint64)[None, :]
+    m64 = np.uint64(M)
+    x = (((q << np.uint64(10)) | k) ^ uk) & m64
+    x = (x * np.uint64(0x9E3779B1)) & m64; x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x85EBCA77)) & m64; x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE3D)) & m64; x ^= x >> np.uint64(16)
+    t = float(np.float32(p)) * 4294967296.0          # the C side computes the threshold from the float it is handed
+    thresh = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+    return torch.from_numpy(x >= np.uint64(thresh))
+
+
+def attention_varlen(qkv: torch.Tensor, cu_seqlens, softmax_scale: float, return_lse: bool = False, dropout_p: float = 0.0, seed: int = 0):
     """qkv [T,3,H,D]; per sequence [cu[i],cu[i+1]) and head: softmax(scale q k^T) v, non-causal,
-    fp32 math on the given values (callers round qkv to bf16 first to mirror ptv3m1:209)."""
+    fp32 math on the given values (callers round qkv to bf16 first to mirror ptv3m1:209).  dropout_p > 0: flash-attn's attention
+    dropout (softmax over all keys, then drop + rescale by 1 / (1 - p); lse of the undropped scores) with the mask of attn_dropout_keep."""
     cu = [int(v) for v in cu_seqlens]
     T, _, H, D = qkv.shape
     outs, lses = [], []
-    for a, b in zip(cu[:-1], cu[1:]):
+    for si, (a, b) in enumerate(zip(cu[:-1], cu[1:])):
         q, k, v = (qkv[a:b, j].transpose(0, 1).float() for j in range(3))  # [H, L, D]
         s = (q * softmax_scale) @ k.transpose(1, 2)
         lses.append(torch.logsumexp(s, dim=-1))  # [H, L]
+        if dropout_p > 0.0:
+            pm = torch.softmax(s, dim=-1)
+            keep = torch.stack([attn_dropout_keep(seed, si * H + h, b - a, b - a, dropout_p) for h in range(H)]).to(pm.dtype)
+            outs.append(((pm * keep / (1.0 - float(np.float32(dropout_p)))) @ v).transpose(0, 1))
+            continue
         outs.append((torch.softmax(s, dim=-1) @ v).transpose(0, 1))  # [L, H, D]
     out = torch.cat(outs, dim=0) if outs else qkv.new_zeros(0, H, D).float()
     if return_lse:

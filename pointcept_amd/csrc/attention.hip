@@ -740,6 +740,7 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
 
 #include "attention_hd.h"
 #include "attention_rpe.h"
+#include "attention_drop.h"
 
 // ================================================================================================
 // host side
@@ -839,6 +840,89 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   }
   AT_BWD_CASE(1024, false) AT_BWD_CASE(0, false) AT_BWD_CASE(1024, true) AT_BWD_CASE(0, true)
 #undef AT_BWD_CASE
+  return PTC_EINVAL;   // not reached
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention dropout, head_dim 16 (attention_drop.h)
+// ------------------------------------------------------------------------------------------------
+static int drop_params(const char* name, float p, uint32_t* thresh, float* rp) {
+  PTC_REQUIRE(p >= 0.f && p < 1.f, PTC_EINVAL, "%s: dropout_p=%g must lie in [0, 1)", name, (double)p);
+  const double t = (double)p * 4294967296.0;
+  *thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  *rp = 1.f / (1.f - p);
+  return PTC_OK;
+}
+
+extern "C" int ptc_attn_varlen_dropout_fwd(const void* qkv, const int32_t* cu_seqlens, int64_t n_seq, int64_t total, int H, int max_seqlen,
+                                           float softmax_scale, int dtype, float dropout_p, uint64_t seed, void* out, float* lse,
+                                           ptc_stream_t stream) {
+  int rc = check_common("ptc_attn_varlen_dropout_fwd", qkv, cu_seqlens, n_seq, total, H, max_seqlen, dtype, true);
+  if (rc != PTC_OK) return rc;
+  uint32_t thresh;
+  float rp;
+  rc = drop_params("ptc_attn_varlen_dropout_fwd", dropout_p, &thresh, &rp);
+  if (rc != PTC_OK) return rc;
+  if (n_seq == 0 || total == 0) return PTC_OK;
+  PTC_REQUIRE(out && lse, PTC_EINVAL, "ptc_attn_varlen_dropout_fwd: null buffer");
+  const int lp_max = (max_seqlen + 31) & ~31;
+  const size_t lds = fwd_lds_bytes(lp_max);
+  const int n_units = (int)(n_seq * H);
+  const unsigned grid = (unsigned)(8 * ((n_units + 7) / 8));
+#define AD_FWD_CASE(F16)                                                                                                             \
+  if ((dtype == PTC_F16) == F16) {                                                                                                   \
+    rc = allow_big_lds(attn_drop_fwd_kernel<F16>, lds);                                                                              \
+    if (rc != PTC_OK) return rc;                                                                                                     \
+    hipLaunchKernelGGL(attn_drop_fwd_kernel<F16>, dim3(grid), dim3(AT_THREADS), lds, (hipStream_t)stream, (const uint16_t*)qkv,      \
+                       cu_seqlens, H, softmax_scale, total, lp_max, n_units, thresh, rp, (uint32_t)seed, (uint32_t)(seed >> 32),     \
+                       (uint16_t*)out, lse);                                                                                         \
+    PTC_CHECK_LAUNCH("attn_drop_fwd_kernel");                                                                                        \
+    return PTC_OK;                                                                                                                   \
+  }
+  AD_FWD_CASE(false) AD_FWD_CASE(true)
+#undef AD_FWD_CASE
+  return PTC_EINVAL;   // not reached
+}
+
+extern "C" int ptc_attn_varlen_dropout_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
+                                           int64_t n_seq, int64_t total, int H, int max_seqlen, float softmax_scale, int dtype,
+                                           float dropout_p, uint64_t seed, void* dqkv, void* workspace, size_t workspace_bytes,
+                                           ptc_stream_t stream) {
+  int rc = check_common("ptc_attn_varlen_dropout_bwd", qkv, cu_seqlens, n_seq, total, H, max_seqlen, dtype, true);
+  if (rc != PTC_OK) return rc;
+  uint32_t thresh;
+  float rp;
+  rc = drop_params("ptc_attn_varlen_dropout_bwd", dropout_p, &thresh, &rp);
+  if (rc != PTC_OK) return rc;
+  if (n_seq == 0 || total == 0) return PTC_OK;
+  PTC_REQUIRE(out && dout && lse && dqkv && workspace, PTC_EINVAL, "ptc_attn_varlen_dropout_bwd: null buffer");
+  PTC_REQUIRE(workspace_bytes >= ptc_attn_varlen_bwd_workspace_bytes(total, H), PTC_EWORKSPACE, "ptc_attn_varlen_dropout_bwd: workspace too small");
+  PTC_REQUIRE(((uintptr_t)out % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0), PTC_EINVAL,
+              "ptc_attn_varlen_dropout_bwd: buffers must be 16-byte aligned");
+  const int lp_max = (max_seqlen + 31) & ~31;
+  hipStream_t s = (hipStream_t)stream;
+  float* delta = (float*)workspace;
+  const int n_units = (int)(n_seq * H);
+  const unsigned grid = (unsigned)(8 * ((n_units + 7) / 8));
+  const size_t lds_q = (size_t)lp_max * 64, lds_kv = (size_t)lp_max * 64 + (size_t)lp_max * 8;
+#define AD_BWD_CASE(F16)                                                                                                             \
+  if ((dtype == PTC_F16) == F16) {                                                                                                   \
+    rc = allow_big_lds(attn_drop_bwd_dq_kernel<F16>, lds_q);                                                                         \
+    if (rc != PTC_OK) return rc;                                                                                                     \
+    rc = allow_big_lds(attn_drop_bwd_dkv_kernel<F16>, lds_kv);                                                                       \
+    if (rc != PTC_OK) return rc;                                                                                                     \
+    hipLaunchKernelGGL(attn_drop_bwd_dq_kernel<F16>, dim3(grid), dim3(AT_THREADS), lds_q, s, (const uint16_t*)qkv, (const uint16_t*)out, \
+                       (const uint16_t*)dout, lse, cu_seqlens, H, softmax_scale, total, lp_max, n_units, thresh, rp, (uint32_t)seed, \
+                       (uint32_t)(seed >> 32), (uint16_t*)dqkv, delta);                                                              \
+    PTC_CHECK_LAUNCH("attn_drop_bwd_dq_kernel");                                                                                     \
+    hipLaunchKernelGGL(attn_drop_bwd_dkv_kernel<F16>, dim3(grid), dim3(AT_THREADS), lds_kv, s, (const uint16_t*)qkv,                 \
+                       (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H, softmax_scale, total, lp_max, n_units, thresh, \
+                       rp, (uint32_t)seed, (uint32_t)(seed >> 32), (uint16_t*)dqkv);                                                 \
+    PTC_CHECK_LAUNCH("attn_drop_bwd_dkv_kernel");                                                                                    \
+    return PTC_OK;                                                                                                                   \
+  }
+  AD_BWD_CASE(false) AD_BWD_CASE(true)
+#undef AD_BWD_CASE
   return PTC_EINVAL;   // not reached
 }
 

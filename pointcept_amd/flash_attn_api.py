@@ -6,8 +6,8 @@ head_dim 16 and max_seqlen <= 1024 (every PT-v3m1 / m2 configuration) run on the
 (attention.hip); head_dim 17..64 (PT-v3m3 / LitePT use 18: a multiple of 3 for their 3-D RoPE) on their multi-slab form
 (attention_hd.h; windows up to 1024 keys for head_dim <= 32, 672 for <= 48, 512 for <= 64).  Anything else (head_dim < 16,
 > 64, longer windows) raises PtcoreError: there is no library (SDPA) backend behind this mirror (round 4).  fp16 qkv (LitePT's call site) runs on the same kernels after a cast to
-bf16 and comes back as fp16.  dropout_p must be 0 (all reference PTv3 configs); causal / alibi / softcap /
-local windows raise.
+bf16 and comes back as fp16.  dropout_p > 0 (head_dim 16): attention dropout with flash-attn's semantics and the engine's own counter-based
+mask (csrc/attention_drop.h; seed from torch's CPU generator).  causal / alibi / softcap / local windows raise.
 """
 from __future__ import annotations
 
@@ -26,8 +26,9 @@ def _require_gpu(t: torch.Tensor) -> None:
 def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
                                      window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
                                      return_attn_probs=False):
-    if dropout_p not in (0, 0.0):
-        raise PtcoreError("flash_attn_varlen_qkvpacked_func: dropout_p > 0 is not implemented")
+    dropout_p = float(dropout_p)
+    if dropout_p != 0.0 and int(qkv.shape[3]) != 16:
+        raise PtcoreError("flash_attn_varlen_qkvpacked_func: dropout_p > 0 is implemented for head_dim 16 (csrc/attention_drop.h)")
     if causal or alibi_slopes is not None or softcap != 0.0 or tuple(window_size) != (-1, -1) or return_attn_probs:
         raise PtcoreError("flash_attn_varlen_qkvpacked_func: only plain non-causal attention is implemented")
     if qkv.dim() != 4 or qkv.shape[1] != 3:
@@ -40,5 +41,5 @@ def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
     if qkv.dtype == torch.float16:
         # LitePT's call site hands over fp16 (litept_v1.py:235-260).  The window-attention kernels take bf16 operands with fp32
         # accumulation: fp16 operands are re-rounded to bf16 (three mantissa bits) and the result returned as fp16.
-        return PF.attn_varlen_qkvpacked(qkv.to(torch.bfloat16), cu_seqlens, max_seqlen, softmax_scale).to(torch.float16)
-    return PF.attn_varlen_qkvpacked(qkv, cu_seqlens, max_seqlen, softmax_scale)
+        return PF.attn_varlen_qkvpacked(qkv.to(torch.bfloat16), cu_seqlens, max_seqlen, softmax_scale, dropout_p).to(torch.float16)
+    return PF.attn_varlen_qkvpacked(qkv, cu_seqlens, max_seqlen, softmax_scale, dropout_p)

@@ -579,31 +579,37 @@ def add_norm(u: torch.Tensor, a: torch.Tensor, row_scale: Optional[torch.Tensor]
 # ------------------------------------------------------------------------------------------------
 class _AttnVarlen(Function):
     @staticmethod
-    def forward(ctx, qkv, cu_seqlens, max_seqlen, softmax_scale):
-        out, lse = ops.attn_varlen_fwd(qkv, cu_seqlens, max_seqlen, softmax_scale)
+    def forward(ctx, qkv, cu_seqlens, max_seqlen, softmax_scale, dropout_p, seed):
+        out, lse = ops.attn_varlen_fwd(qkv, cu_seqlens, max_seqlen, softmax_scale, dropout_p, seed)
         ctx.save_for_backward(qkv, out, lse, cu_seqlens)
-        ctx.max_seqlen, ctx.scale = max_seqlen, softmax_scale
+        ctx.max_seqlen, ctx.scale, ctx.drop = max_seqlen, softmax_scale, (dropout_p, seed)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         qkv, out, lse, cu = ctx.saved_tensors
-        dqkv = ops.attn_varlen_bwd(qkv, out, dout.contiguous(), lse, cu, ctx.max_seqlen, ctx.scale)
-        return dqkv, None, None, None
+        dqkv = ops.attn_varlen_bwd(qkv, out, dout.contiguous(), lse, cu, ctx.max_seqlen, ctx.scale, *ctx.drop)
+        return dqkv, None, None, None, None, None
 
 
 def attn_varlen_qkvpacked(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
-                          softmax_scale: Optional[float] = None) -> torch.Tensor:
-    """flash_attn.flash_attn_varlen_qkvpacked_func semantics (ptv3m1:208-214), dropout 0,
+                          softmax_scale: Optional[float] = None, dropout_p: float = 0.0, seed: Optional[int] = None) -> torch.Tensor:
+    """flash_attn.flash_attn_varlen_qkvpacked_func semantics (ptv3m1:208-214),
     non-causal, qkv [T,3,H,16] bf16 -> [T,H,16] bf16.  f16 qkv with head_dim 16 = the reference's fp16-autocast call site INCLUDING its
     casts: `flash_attn(qkv.to(bfloat16)).to(qkv.dtype)` -- bf16 arithmetic, f16 tensors, the four cast passes (two forward, two
-    backward) folded into the kernels' loads and stores."""
+    backward) folded into the kernels' loads and stores.  dropout_p > 0 (head_dim 16): attention dropout; the mask is a function of
+    `seed` (default: drawn from torch's CPU generator, so torch.manual_seed reproduces a step) and is regenerated by the backward."""
     if qkv.dtype != torch.bfloat16 and not (qkv.dtype == torch.float16 and qkv.shape[-1] == 16):
         raise PtcoreError("attn_varlen_qkvpacked expects bf16 (the reference casts with .to(torch.bfloat16), ptv3m1:209)")
     if softmax_scale is None:
         softmax_scale = qkv.shape[-1] ** -0.5
-    return _AttnVarlen.apply(qkv, cu_seqlens, int(max_seqlen), float(softmax_scale))
+    dropout_p = float(dropout_p)
+    if not 0.0 <= dropout_p < 1.0:
+        raise PtcoreError("dropout_p must lie in [0, 1)")
+    if dropout_p > 0.0 and seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())        # CPU generator: no device synchronisation
+    return _AttnVarlen.apply(qkv, cu_seqlens, int(max_seqlen), float(softmax_scale), dropout_p, int(seed or 0))
 
 
 class _AttnRpe(Function):

@@ -757,7 +757,7 @@ def attn_hd_supported(head_dim: int, max_seqlen: int) -> bool:
     return bool(lib().ptc_attn_varlen_hd_supported(int(head_dim), int(max_seqlen)))
 
 
-def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, softmax_scale: float):
+def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, softmax_scale: float, dropout_p: float = 0.0, seed: int = 0):
     """qkv [T,3,H,D] bf16 -> (out [T,H,D] bf16, lse [H,T] fp32); D = 16 (attention.hip) or 17..64 (attention_hd.h).
     D = 16 also takes f16 qkv: the SAME bf16 arithmetic with the reference's qkv.to(bfloat16) / feat.to(qkv.dtype) casts
     (ptv3m1:209,215) done in the kernel's load / store paths -- out comes back f16, bit for bit what the two cast passes produce."""
@@ -770,7 +770,12 @@ def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int
     T, _, H, D = qkv.shape
     out = torch.empty((T, H, D), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((H, T), dtype=torch.float32, device=qkv.device)
-    if D == 16:
+    if dropout_p > 0.0:       # attention dropout (csrc/attention_drop.h): head_dim 16; the mask is a function of `seed`, regenerated by the backward
+        if D != 16:
+            raise PtcoreError("attention dropout is implemented for head_dim 16")
+        check(lib().ptc_attn_varlen_dropout_fwd(ptr(qkv), ptr(cu), cu.numel() - 1, T, H, int(max_seqlen), float(softmax_scale), dtype_code(qkv),
+                                                float(dropout_p), int(seed), ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_dropout_fwd")
+    elif D == 16:
         check(lib().ptc_attn_varlen_fwd(ptr(qkv), ptr(cu), cu.numel() - 1, T, H, int(max_seqlen), float(softmax_scale),
                                         dtype_code(qkv), ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_fwd")
     else:
@@ -779,7 +784,7 @@ def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int
     return out, lse
 
 
-def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_scale: float) -> torch.Tensor:
+def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_scale: float, dropout_p: float = 0.0, seed: int = 0) -> torch.Tensor:
     require_cuda(qkv, out, dout, lse, cu_seqlens)
     qkv = qkv.contiguous()
     out = out.contiguous()
@@ -789,7 +794,11 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_sc
     dqkv = torch.empty_like(qkv)
     nbytes = lib().ptc_attn_varlen_bwd_workspace_bytes(T, H)
     ws = _ws(nbytes, qkv.device)
-    if D == 16:
+    if dropout_p > 0.0:
+        check(lib().ptc_attn_varlen_dropout_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), cu.numel() - 1, T, H, int(max_seqlen),
+                                                float(softmax_scale), dtype_code(qkv), float(dropout_p), int(seed), ptr(dqkv), ptr(ws), nbytes,
+                                                stream_ptr()), "ptc_attn_varlen_dropout_bwd")
+    elif D == 16:
         check(lib().ptc_attn_varlen_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), cu.numel() - 1, T, H,
                                         int(max_seqlen), float(softmax_scale), dtype_code(qkv), ptr(dqkv), ptr(ws), nbytes,
                                         stream_ptr()), "ptc_attn_varlen_bwd")

@@ -191,8 +191,8 @@ class SerializedAttention(PointModule):
             assert upcast_softmax is False, "Set upcast_softmax to False when enable Flash Attention"
             if not 16 <= channels // num_heads <= 64:
                 raise PtcoreError(f"engine flash attention needs 16 <= head_dim <= 64, got {channels // num_heads}")
-            if attn_drop != 0.0:
-                raise PtcoreError("attention dropout is not implemented in the flash branch (every reference config uses 0.0)")
+            if attn_drop != 0.0 and channels // num_heads != 16:      # csrc/attention_drop.h: head_dim 16 (every PT-v3m1 / m2 stage)
+                raise PtcoreError("attention dropout in the flash branch is implemented for head_dim 16 (every reference config uses 0.0)")
             self.patch_size = patch_size
             self.attn_drop = attn_drop
         else:
@@ -319,18 +319,20 @@ class SerializedAttention(PointModule):
             # writes the padded, serialized qkv directly (ptv3m1:188); proj reads the attention output
             # through the inverse table (ptv3m1:216,219).  Two full gather passes less per block.
             qkv_s = self.qkv(point.feat, tabs[0], tabs[1])
+            drop = float(self.attn_drop) if (self.enable_flash and self.training) else 0.0        # ptv3m1:212
             if qkv_s.dtype == torch.float16 and C // H == 16:
                 # fp16 autocast: qkv.to(bfloat16) and feat.to(qkv.dtype) (ptv3m1:209,215) happen inside the kernels' loads and stores
-                out = PF.attn_varlen_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale)
+                out = PF.attn_varlen_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale, drop)
                 feat = self.proj(out.reshape(-1, C), tabs[2], tabs[3])
             else:
-                out = PF.attn_varlen_qkvpacked(qkv_s.to(torch.bfloat16).reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale)
+                out = PF.attn_varlen_qkvpacked(qkv_s.to(torch.bfloat16).reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale, drop)
                 feat = self.proj(out.reshape(-1, C).to(qkv_s.dtype), tabs[2], tabs[3])   # ptv3m1:215
         else:
             qkv = self.qkv(point.feat)
             # padded, serialized qkv in bf16 (ptv3m1:188,209); backward = gather through (inv, dup)
             qkv_s = PF.gather_rows(qkv.to(torch.bfloat16), gidx, inv, dup_of_point)
-            out = PF.attn_varlen_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale)
+            out = PF.attn_varlen_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale,
+                                           float(self.attn_drop) if (self.enable_flash and self.training) else 0.0)
             feat = PF.gather_rows(out.reshape(-1, C), inv, gidx_primary)      # ptv3m1:216
             feat = feat.to(qkv.dtype)                                          # ptv3m1:215
             feat = self.proj(feat)
@@ -445,6 +447,7 @@ class Block(PointModule):
         return (config.EXEC_BLOCK and type(self) is Block and type(a) is SerializedAttention and torch.is_autocast_enabled("cuda")
                 and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16) and self.channels % 32 == 0 and self.channels <= 256
                 and a.enable_flash and not a.enable_rpe and a.num_heads * 16 == self.channels and config.FUSE_GATHER and config.FUSE_MLP
+                and (a.attn_drop == 0.0 or not self.training)
                 and type(self.cpe[0]) is spconv.SubMConv3d and self.cpe[0].kernel_size[0] == 3 and self.cpe[0].bias is not None
                 and type(self.cpe[1]) is PNN.Linear and self.cpe[1].bias is not None and type(self.mlp[0]) is MLP
                 and type(self.mlp[0].fc1) is PNN.Linear and type(self.mlp[0].fc2) is PNN.Linear and self.mlp[0].fc1.bias is not None

@@ -890,6 +890,41 @@ def test_attention_f16_io_equals_the_reference_cast_passes(cuda, lens, H):
     assert d16.dtype == torch.float16 and torch.equal(d16, d_b.to(torch.float16))
 
 
+@pytest.mark.parametrize("lens,H,p", [([1024, 330], 4, 0.1), ([1, 2, 31, 32, 33, 65], 3, 0.25), ([200], 2, 0.5)])
+def test_attention_dropout_fwd_bwd(cuda, lens, H, p):
+    """Attention dropout on the flash path (ptv3m1:212, dropout_p = attn_drop in training): flash-attn's semantics -- softmax over all
+    keys, then drop with probability p and rescale by 1 / (1 - p), lse of the undropped scores -- against the oracle applying the SAME
+    keep mask (oracle/ops.py::attn_dropout_keep restates the kernels' integer hash), forward and backward; the mask is a function of
+    the seed only (same seed: bit-identical results, another seed: another mask), its keep rate is 1 - p, and p = 0 through the same
+    entry point reproduces the plain kernels' tolerance."""
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(sum(lens) + H)
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    qkv = (torch.randn(T, 3, H, 16, generator=g) * 1.5).to(torch.bfloat16)
+    scale, seed = 16 ** -0.5, 0x1234_5678_9ABC_DEF
+    out, lse = ops.attn_varlen_fwd(qkv.to(cuda), cu.to(cuda), max(lens), scale, p, seed)
+    q32 = qkv.float().requires_grad_(True)
+    ref, ref_lse = oops.attention_varlen(q32, cu, scale, return_lse=True, dropout_p=p, seed=seed)
+    vmax = float(qkv[:, 2].float().abs().max())
+    _close("attn_drop_fwd", out, ref, 1.0 / 64, 2.0 ** -9 * vmax / (1 - p))
+    _close("attn_drop_lse", lse, ref_lse, 1e-3, 2e-2)
+    dout = torch.randn(T, H, 16, generator=g).to(torch.bfloat16)
+    ref.backward(dout.float())
+    dqkv = ops.attn_varlen_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale, p, seed)
+    gmax = float(q32.grad.abs().max())
+    _close("attn_drop_bwd", dqkv, q32.grad, 1.0 / 32, 1e-2 * gmax)
+    fro = lambda a, b: float((a.float().cpu() - b.detach()).norm() / b.detach().norm())
+    assert fro(out, ref) < 2.0 ** -8 and fro(dqkv, q32.grad) < 2.0 ** -7, (fro(out, ref), fro(dqkv, q32.grad))
+    again, _ = ops.attn_varlen_fwd(qkv.to(cuda), cu.to(cuda), max(lens), scale, p, seed)
+    other, _ = ops.attn_varlen_fwd(qkv.to(cuda), cu.to(cuda), max(lens), scale, p, seed + 1)
+    assert torch.equal(out, again) and not torch.equal(out, other)
+    keep = oops.attn_dropout_keep(seed, 0, lens[0], lens[0], p).float().mean()
+    if lens[0] >= 200:
+        assert abs(float(keep) - (1 - p)) < 0.01, float(keep)
+
+
 def test_attention_large_logits(cuda):
     """Peaked softmax (online-max path): one key dominates each query."""
     from pointcept_amd import ops

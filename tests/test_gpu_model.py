@@ -114,6 +114,45 @@ def test_block_executor_step_is_bit_identical_to_the_composed_step(cuda, monkeyp
         assert torch.equal(res[True][1][k], res[False][1][k]), k
 
 
+def test_ptv3_attention_dropout_on_the_flash_path(cuda):
+    """enable_flash=True with attn_drop > 0 (ptv3m1:212: dropout_p = attn_drop while training): the model constructs, a seeded training
+    step is reproducible and differs from the step without dropout, eval mode ignores the dropout, and every gradient is finite."""
+    from pointcept_amd import synthetic
+    from pointcept_amd.segmentor import DefaultSegmentorV2
+
+    cfg = dict(TINY, enc_patch_size=(128,) * 5, dec_patch_size=(128,) * 4)
+    batch = synthetic.to_torch(synthetic.collate([synthetic.indoor_scene(51, 3000), synthetic.indoor_scene(52, 700)]), cuda)
+    res = {}
+    for drop in (0.0, 0.2):
+        from pointcept_amd.point_transformer_v3 import PointTransformerV3
+
+        _, eng0 = _models(cfg, seed=3)                                  # (the oracle model has no attention dropout: same weights, engine only)
+        eng_b = PointTransformerV3(**dict(cfg, attn_drop=drop))
+        eng_b.load_state_dict(eng0.state_dict())
+        torch.manual_seed(2)
+        eng = DefaultSegmentorV2(20, 64, eng_b).to(cuda)
+        eng.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            ev = eng(dict(batch))["loss"]
+        eng.train()
+        losses = []
+        for rep in range(2):
+            eng.zero_grad(set_to_none=True)
+            for m_ in eng.modules():
+                if isinstance(m_, torch.nn.BatchNorm1d):
+                    m_.reset_running_stats()
+            torch.manual_seed(21)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = eng(dict(batch))["loss"]
+            loss.backward()
+            losses.append(float(loss.detach()))
+            assert all(torch.isfinite(p.grad).all() for p in eng.parameters() if p.grad is not None)
+        assert losses[0] == losses[1], losses
+        res[drop] = (float(ev), losses[0])
+    assert res[0.0][0] == res[0.2][0]            # eval: dropout inactive, identical weights -> identical loss
+    assert res[0.0][1] != res[0.2][1] and abs(res[0.0][1] - res[0.2][1]) < 0.5 * abs(res[0.0][1])
+
+
 def test_ptv3_two_scenes_forward_backward_vs_oracle(cuda):
     """ragged batch (one scene shorter than a patch at deep stages), train mode (BatchNorm batch
     statistics, pooling-order shuffles from the seeded CPU RNG), loss + every parameter gradient."""

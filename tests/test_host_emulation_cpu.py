@@ -202,7 +202,8 @@ EMULATED_GPU_TESTS = [
     ("test_conv_tiny_inputs", dict(n=17)), ("test_spconv_dgrad_via_mirrored_table", dict()), ("test_spconv_down_up_tables", dict()),
     ("test_pool_maps", dict(n_pts=3000)),
     ("test_attention_fwd_bwd", dict(lens=[48, 48, 17], H=2)), ("test_attention_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
-    ("test_attention_large_logits", dict()), ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
+    ("test_attention_large_logits", dict()), ("test_attention_dropout_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3, p=0.25)),
+    ("test_attention_dropout_fwd_bwd", dict(lens=[200], H=2, p=0.5)), ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
     ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6)),
     ("test_attention_rpe_fwd_bwd", dict(lens=[200, 200, 200], H=3, bnd=18)),
 ]   # (in-place GPU tests -- rope3d, cross entropy -- are not in the list: with device = cpu their `.to(device)` aliases the input the
