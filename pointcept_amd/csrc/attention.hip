@@ -941,7 +941,9 @@ extern "C" int ptc_attn_varlen_hd_supported(int head_dim, int max_seqlen) {
 
 static int hd_check(const char* name, const void* qkv, const int32_t* cu, int64_t n_seq, int64_t total, int H, int D,
                     int max_seqlen, int dtype) {
-  int rc = check_common(name, qkv, cu, n_seq, total, H, max_seqlen, dtype);
+  // PTC_F16 here = f16 OPERANDS (f16 MFMAs, P / dS rounded to f16: what flash-attn does with fp16 tensors, LitePT's call site) -- not the
+  // f16 I/O around bf16 arithmetic of the head_dim-16 kernels
+  int rc = check_common(name, qkv, cu, n_seq, total, H, max_seqlen, dtype, true);
   if (rc != PTC_OK) return rc;
   PTC_REQUIRE(ptc_attn_varlen_hd_supported(D, max_seqlen), PTC_EUNSUPPORTED,
               "%s: head_dim=%d with max_seqlen=%d is outside the LDS-resident range (17..32: 1024 keys, ..48: 672, ..64: 512)", name, D,
@@ -960,17 +962,18 @@ extern "C" int ptc_attn_varlen_hd_fwd(const void* qkv, const int32_t* cu_seqlens
   const int n_units = (int)(n_seq * H);
   const int qs = at_split_host(n_units, lp_max);
   hipStream_t s = (hipStream_t)stream;
-#define AH_FWD_CASE(DK, MB)                                                                                                    \
-  if (dk == DK && mb == MB) {                                                                                                  \
-    rc = allow_big_lds(attn_hd_fwd_kernel<DK, MB>, lds);                                                                       \
+#define AH_FWD_CASE(DK, MB, F16)                                                                                                    \
+  if (dk == DK && mb == MB && (dtype == PTC_F16) == F16) {                                                                                                  \
+    rc = allow_big_lds(attn_hd_fwd_kernel<DK, MB, F16>, lds);                                                                       \
     if (rc != PTC_OK) return rc;                                                                                               \
-    hipLaunchKernelGGL((attn_hd_fwd_kernel<DK, MB>), dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds, s,  \
+    hipLaunchKernelGGL((attn_hd_fwd_kernel<DK, MB, F16>), dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds, s,  \
                        (const uint16_t*)qkv, cu_seqlens, H, head_dim, softmax_scale, total, lp_max, n_units, qs, (uint16_t*)out, \
                        lse);                                                                                                   \
     PTC_CHECK_LAUNCH("attn_hd_fwd_kernel");                                                                                    \
     return PTC_OK;                                                                                                             \
   }
-  AH_FWD_CASE(2, 1) AH_FWD_CASE(2, 2) AH_FWD_CASE(3, 2) AH_FWD_CASE(4, 2) AH_FWD_CASE(4, 3)
+  AH_FWD_CASE(2, 1, false) AH_FWD_CASE(2, 2, false) AH_FWD_CASE(3, 2, false) AH_FWD_CASE(4, 2, false) AH_FWD_CASE(4, 3, false)
+  AH_FWD_CASE(2, 1, true) AH_FWD_CASE(2, 2, true) AH_FWD_CASE(3, 2, true) AH_FWD_CASE(4, 2, true) AH_FWD_CASE(4, 3, true)
 #undef AH_FWD_CASE
   ptc_set_error("ptc_attn_varlen_hd_fwd: no instance for head_dim=%d", head_dim);
   return PTC_EUNSUPPORTED;
@@ -993,23 +996,23 @@ extern "C" int ptc_attn_varlen_hd_bwd(const void* qkv, const void* out, const vo
   const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)workspace;
-#define AH_BWD_CASE(DK)                                                                                                        \
-  if (dk == DK) {                                                                                                              \
-    rc = allow_big_lds(attn_hd_bwd_dq_kernel<DK>, hd_dq_lds(DK, lp_max));                                                      \
+#define AH_BWD_CASE(DK, F16)                                                                                                        \
+  if (dk == DK && (dtype == PTC_F16) == F16) {                                                                                                              \
+    rc = allow_big_lds(attn_hd_bwd_dq_kernel<DK, F16>, hd_dq_lds(DK, lp_max));                                                      \
     if (rc != PTC_OK) return rc;                                                                                               \
-    rc = allow_big_lds(attn_hd_bwd_dkv_kernel<DK>, hd_dkv_lds(DK, lp_max));                                                    \
+    rc = allow_big_lds(attn_hd_bwd_dkv_kernel<DK, F16>, hd_dkv_lds(DK, lp_max));                                                    \
     if (rc != PTC_OK) return rc;                                                                                               \
-    hipLaunchKernelGGL((attn_hd_bwd_dq_kernel<DK>), dim3(grid), dim3(AT_THREADS), hd_dq_lds(DK, lp_max), s,                    \
+    hipLaunchKernelGGL((attn_hd_bwd_dq_kernel<DK, F16>), dim3(grid), dim3(AT_THREADS), hd_dq_lds(DK, lp_max), s,                    \
                        (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H, head_dim,        \
                        softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv, delta);                                     \
     PTC_CHECK_LAUNCH("attn_hd_bwd_dq_kernel");                                                                                 \
-    hipLaunchKernelGGL((attn_hd_bwd_dkv_kernel<DK>), dim3(grid), dim3(AT_THREADS), hd_dkv_lds(DK, lp_max), s,                  \
+    hipLaunchKernelGGL((attn_hd_bwd_dkv_kernel<DK, F16>), dim3(grid), dim3(AT_THREADS), hd_dkv_lds(DK, lp_max), s,                  \
                        (const uint16_t*)qkv, (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H, head_dim,         \
                        softmax_scale, total, lp_max, n_units, qs, (uint16_t*)dqkv);                                            \
     PTC_CHECK_LAUNCH("attn_hd_bwd_dkv_kernel");                                                                                \
     return PTC_OK;                                                                                                             \
   }
-  AH_BWD_CASE(2) AH_BWD_CASE(3) AH_BWD_CASE(4)
+  AH_BWD_CASE(2, false) AH_BWD_CASE(3, false) AH_BWD_CASE(4, false) AH_BWD_CASE(2, true) AH_BWD_CASE(3, true) AH_BWD_CASE(4, true)
 #undef AH_BWD_CASE
   ptc_set_error("ptc_attn_varlen_hd_bwd: no instance for head_dim=%d", head_dim);
   return PTC_EUNSUPPORTED;

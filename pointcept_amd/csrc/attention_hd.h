@@ -19,6 +19,55 @@
 
 #define AH_LDS_LIMIT 163840
 
+// ---- element traits: bf16 (the PT-v3 call sites cast their operands to bf16 themselves, ptv3m3:353) or f16 (LitePT hands flash-attn its
+// fp16 autocast tensors, pointcept/models/litept/litept_v1.py:259-265: f16 operands, f16 P / dS, fp32 accumulation -- round 4; until then
+// f16 operands were re-rounded to bf16, three mantissa bits short of the reference's arithmetic for that call site)
+typedef _Float16 ah_f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16> struct AE;
+template <> struct AE<false> {
+  static constexpr uint16_t ONE = 0x3F80, NAN16 = 0x7FC0;
+  static constexpr uint32_t NEG1X2 = 0xBF80BF80u;
+  static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
+  static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) { return mfma32(a, b, c); }
+  static __device__ __forceinline__ float pad_lse() { return AT_PAD_LSE; }
+};
+template <> struct AE<true> {
+  static constexpr uint16_t ONE = 0x3C00, NAN16 = 0x7E00;
+  static constexpr uint32_t NEG1X2 = 0xBC00BC00u;
+  static __device__ __forceinline__ float lo(uint32_t w) { at_h2 h; __builtin_memcpy(&h, &w, 4); return (float)h[0]; }
+  static __device__ __forceinline__ float hi(uint32_t w) { at_h2 h; __builtin_memcpy(&h, &w, 4); return (float)h[1]; }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    const at_h2 h = {(_Float16)a, (_Float16)b};      // v_cvt_f16_f32, RNE
+    uint32_t r;
+    __builtin_memcpy(&r, &h, 4);
+    return r;
+  }
+  static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+    ah_f16x8 fa, fb;
+    __builtin_memcpy(&fa, &a, 16);
+    __builtin_memcpy(&fb, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c, 0, 0, 0);
+  }
+  // lse of padding queries: the largest finite f16 keeps hi + lo finite (1e30 would be inf - inf); exp2(s - 60000) = 0 all the same
+  static __device__ __forceinline__ float pad_lse() { return 60000.f; }
+};
+// x * c -> 16-bit hi + lo parts (hi + lo = x c to ~2^-17 (bf16) / 2^-22 (f16) relative)
+template <bool F16>
+__device__ __forceinline__ void ah_split_scaled(s16x8 x, float c, s16x8& hi, s16x8& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t w = (uint32_t)(uint16_t)x[2 * j] | ((uint32_t)(uint16_t)x[2 * j + 1] << 16);
+    const float a = AE<F16>::lo(w) * c, b = AE<F16>::hi(w) * c;
+    h[j] = AE<F16>::pack2(a, b);
+    l[j] = AE<F16>::pack2(a - AE<F16>::lo(h[j]), b - AE<F16>::hi(h[j]));
+  }
+  hi = make_frag(h[0], h[1], h[2], h[3]);
+  lo = make_frag(l[0], l[1], l[2], l[3]);
+}
+
 // 8 channels [ch0, ch0 + 8) of a row of `D` bf16 channels (zeros beyond D / for invalid rows)
 __device__ __forceinline__ uint4 ah_ld8(const uint16_t* __restrict__ row, int ch0, int D, bool valid) {
   uint4 v = {0, 0, 0, 0};
@@ -40,29 +89,31 @@ __device__ __forceinline__ uint4 ah_ld8(const uint16_t* __restrict__ row, int ch
   return v;
 }
 __device__ __forceinline__ s16x8 ah_frag(uint4 u) { return *reinterpret_cast<s16x8*>(&u); }
+template <bool F16>
 __device__ __forceinline__ float ah_sumsq(uint4 v) {
   const uint32_t w[4] = {v.x, v.y, v.z, v.w};
   float ss = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float a = __uint_as_float(w[j] << 16), b = __uint_as_float(w[j] & 0xffff0000u);
+    const float a = AE<F16>::lo(w[j]), b = AE<F16>::hi(w[j]);
     ss = fmaf(a, a, fmaf(b, b, ss));
   }
   return ss;
 }
+template <bool F16>
 __device__ __forceinline__ float ah_dot(uint4 x, uint4 y) {
   const uint32_t a[4] = {x.x, x.y, x.z, x.w}, b[4] = {y.x, y.y, y.z, y.w};
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    s = fmaf(__uint_as_float(a[j] << 16), __uint_as_float(b[j] << 16), s);
-    s = fmaf(__uint_as_float(a[j] & 0xffff0000u), __uint_as_float(b[j] & 0xffff0000u), s);
+    s = fmaf(AE<F16>::lo(a[j]), AE<F16>::lo(b[j]), s);
+    s = fmaf(AE<F16>::hi(a[j]), AE<F16>::hi(b[j]), s);
   }
   return s;
 }
 
 // rows [0, Lp) of a [.., D] operand into DK slab images ([lp_max][16] each, rm_off swizzle); returns max |row|^2 of this thread
-template <int DK>
+template <int DK, bool F16>
 __device__ __forceinline__ float ah_stage_rows(const uint16_t* __restrict__ src, int64_t row_stride, int D, int L, int Lp,
                                                int slab_bytes, unsigned char* lds) {
   float mx = 0.f;
@@ -75,14 +126,14 @@ __device__ __forceinline__ float ah_stage_rows(const uint16_t* __restrict__ src,
       const uint4 v0 = ah_ld8(p, 16 * j, D, valid), v1 = ah_ld8(p, 16 * j + 8, D, valid);
       *reinterpret_cast<uint4*>(lds + j * slab_bytes + rm_off(row, 0)) = v0;
       *reinterpret_cast<uint4*>(lds + j * slab_bytes + rm_off(row, 1)) = v1;
-      ss += ah_sumsq(v0) + ah_sumsq(v1);
+      ss += ah_sumsq<F16>(v0) + ah_sumsq<F16>(v1);
     }
     mx = fmaxf(mx, ss);
   }
   return mx;
 }
 // V^T image [D + 1][pitch] with the key permutation of stage_transposed; row D = 1.0 for keys < L (softmax denominator)
-template <int DK>
+template <int DK, bool F16>
 __device__ __forceinline__ void ah_stage_vt(const uint16_t* __restrict__ src, int64_t row_stride, int D, int L, int Lp, int pitch,
                                             unsigned char* lds) {
   uint32_t* t32 = reinterpret_cast<uint32_t*>(lds);
@@ -104,12 +155,13 @@ __device__ __forceinline__ void ah_stage_vt(const uint16_t* __restrict__ src, in
     }
   }
   for (int key = threadIdx.x; key < Lp; key += AT_THREADS)
-    reinterpret_cast<uint16_t*>(lds + (size_t)D * pitch * 2)[vt_pos(key)] = key < L ? (uint16_t)0x3F80 : (uint16_t)0;
+    reinterpret_cast<uint16_t*>(lds + (size_t)D * pitch * 2)[vt_pos(key)] = key < L ? AE<F16>::ONE : (uint16_t)0;
 }
 // NaN rows for units longer than max_seqlen (see at_poison_rows)
+template <bool F16>
 __device__ __forceinline__ void ah_poison_rows(uint16_t* rows, int64_t row_stride, int D, int L, float* side) {
   for (int q = threadIdx.x; q < L; q += AT_THREADS) {
-    for (int d = 0; d < D; ++d) rows[(int64_t)q * row_stride + d] = (uint16_t)0x7FC0;
+    for (int d = 0; d < D; ++d) rows[(int64_t)q * row_stride + d] = AE<F16>::NAN16;
     if (side) side[q] = __uint_as_float(0x7FC00000u);
   }
 }
@@ -124,7 +176,7 @@ __device__ __forceinline__ float ah_pick_row(const f32x16& acc, int row) {
 
 // ------------------------------------------------------------------------------------------------ forward
 // LDS: K slabs DK x [lp_max][16] | V^T [D + 1][pitch] | AT_WAVES floats
-template <int DK, int MB>
+template <int DK, int MB, bool F16>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu, int H, int D, float scale, int64_t total,
                    int lp_max, int n_units, int qs, uint16_t* __restrict__ out, float* __restrict__ lse) {
@@ -138,7 +190,7 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
   const int64_t rs = (int64_t)3 * H * D, os = (int64_t)H * D;
   if (Lp > lp_max) {
-    if (part == 0) ah_poison_rows(out + ((int64_t)a * H + head) * D, os, D, L, lse + (int64_t)head * total + a);
+    if (part == 0) ah_poison_rows<F16>(out + ((int64_t)a * H + head) * D, os, D, L, lse + (int64_t)head * total + a);
     return;
   }
   const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
@@ -149,8 +201,8 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
   float* red = reinterpret_cast<float*>(Vt + (size_t)(D + 1) * pitch * 2);
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const uint16_t* qbase = qkv + ((int64_t)a * 3 * H + head) * D;            // q row t: qbase + t * rs; k: + H*D; v: + 2*H*D
-  float kn = ah_stage_rows<DK>(qbase + (int64_t)H * D, rs, D, L, Lp, slab, Ksm);
-  ah_stage_vt<DK>(qbase + (int64_t)2 * H * D, rs, D, L, Lp, pitch, Vt);
+  float kn = ah_stage_rows<DK, F16>(qbase + (int64_t)H * D, rs, D, L, Lp, slab, Ksm);
+  ah_stage_vt<DK, F16>(qbase + (int64_t)2 * H * D, rs, D, L, Lp, pitch, Vt);
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) kn = fmaxf(kn, __shfl_xor(kn, o, 64));
   if (lane == 0) red[wave] = kn;
@@ -178,8 +230,8 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
 #pragma unroll
     for (int j = 0; j < DK; ++j) {
       const uint4 u = ah_ld8(qrow, 16 * j + 8 * h2, D, q < L);
-      qn += ah_sumsq(u);
-      split_scaled(ah_frag(u), c, qhi[j], qlo[j]);
+      qn += ah_sumsq<F16>(u);
+      ah_split_scaled<F16>(ah_frag(u), c, qhi[j], qlo[j]);
     }
     qn += __shfl_xor(qn, 32, 64);
     const float bnd = sqrtf(qn * kmax2) * c * 1.0009765625f + 1e-3f;
@@ -187,7 +239,9 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = zero16();
     float ref2;
-    if (__builtin_amdgcn_ballot_w64(bnd > AT_FIXED_REF_MAX) == 0) {
+    // (f16 operands: P = exp2(S' - ref) is rounded to f16, whose exponent range ends at 2^-24 -- a Cauchy-Schwarz reference up to 64 above the
+    //  row's true maximum would flush the whole row to zero; f16 always takes the running-maximum loop, P <= 1 with its largest entry = 1)
+    if (!F16 && __builtin_amdgcn_ballot_w64(bnd > AT_FIXED_REF_MAX) == 0) {
       ref2 = bnd;
       const f32x16 negb = splat16(-bnd);
       for (int kt = 0; kt < n_tiles; ++kt) {
@@ -195,17 +249,17 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
 #pragma unroll
         for (int j = 0; j < DK; ++j) {
           const s16x8 kf = *reinterpret_cast<const s16x8*>(kbase + j * slab + kt * 1024);
-          s = mfma32(kf, qhi[j], s);
-          s = mfma32(kf, qlo[j], s);
+          s = AE<F16>::mfma(kf, qhi[j], s);
+          s = AE<F16>::mfma(kf, qlo[j], s);
         }
         uint32_t pk[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i]), __builtin_amdgcn_exp2f(s[2 * i + 1]));
+        for (int i = 0; i < 8; ++i) pk[i] = AE<F16>::pack2(__builtin_amdgcn_exp2f(s[2 * i]), __builtin_amdgcn_exp2f(s[2 * i + 1]));
         const s16x8 p0 = make_frag(pk[0], pk[1], pk[2], pk[3]), p1 = make_frag(pk[4], pk[5], pk[6], pk[7]);
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-          acc[m] = mfma32(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64), p0, acc[m]);
-          acc[m] = mfma32(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64 + 32), p1, acc[m]);
+          acc[m] = AE<F16>::mfma(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64), p0, acc[m]);
+          acc[m] = AE<F16>::mfma(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64 + 32), p1, acc[m]);
         }
       }
     } else {
@@ -215,8 +269,8 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
 #pragma unroll
         for (int j = 0; j < DK; ++j) {
           const s16x8 kf = *reinterpret_cast<const s16x8*>(kbase + j * slab + kt * 1024);
-          s = mfma32(kf, qhi[j], s);
-          s = mfma32(kf, qlo[j], s);
+          s = AE<F16>::mfma(kf, qhi[j], s);
+          s = AE<F16>::mfma(kf, qlo[j], s);
         }
         if (kt == n_tiles - 1 && L < Lp) {
 #pragma unroll
@@ -237,12 +291,12 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
         uint32_t pk[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i] - mrun), __builtin_amdgcn_exp2f(s[2 * i + 1] - mrun));
+          pk[i] = AE<F16>::pack2(__builtin_amdgcn_exp2f(s[2 * i] - mrun), __builtin_amdgcn_exp2f(s[2 * i + 1] - mrun));
         const s16x8 p0 = make_frag(pk[0], pk[1], pk[2], pk[3]), p1 = make_frag(pk[4], pk[5], pk[6], pk[7]);
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-          acc[m] = mfma32(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64), p0, acc[m]);
-          acc[m] = mfma32(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64 + 32), p1, acc[m]);
+          acc[m] = AE<F16>::mfma(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64), p0, acc[m]);
+          acc[m] = AE<F16>::mfma(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64 + 32), p1, acc[m]);
         }
       }
       ref2 = mrun;
@@ -256,7 +310,7 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {                       // registers r, r + 1 = channels ch, ch + 1 (ch even)
           const int ch = 32 * m + crow(r, h2);
-          const uint32_t w = pack_bf16x2(acc[m][r] * inv, acc[m][r + 1] * inv);
+          const uint32_t w = AE<F16>::pack2(acc[m][r] * inv, acc[m][r + 1] * inv);
           if (ch + 1 < D && (D & 1) == 0) *reinterpret_cast<uint32_t*>(o + ch) = w;
           else {
             if (ch < D) o[ch] = (uint16_t)(w & 0xffffu);
@@ -275,13 +329,14 @@ __device__ __forceinline__ int ah_pair_off(int m, int col, int slab_bytes) {
   const int j = (col >= 16 && 2 * m + 1 < DK) ? 2 * m + 1 : 2 * m;
   return j * slab_bytes;
 }
+template <bool F16>
 __device__ __forceinline__ void ah_store_col(uint16_t* row, int ch, int D, float v) {
-  if (ch < D) row[ch] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+  if (ch < D) row[ch] = (uint16_t)(AE<F16>::pack2(v, 0.f) & 0xffffu);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ + delta
 // LDS: V slabs | K slabs
-template <int DK>
+template <int DK, bool F16>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                       const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, int D, float scale, int64_t total,
@@ -298,7 +353,7 @@ attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
   const int64_t rs = (int64_t)3 * H * D;
   uint16_t* dqbase = dqkv + ((int64_t)a * 3 * H + head) * D;
   if (Lp > lp_max) {
-    if (part == 0) ah_poison_rows(dqbase, rs, D, L, nullptr);
+    if (part == 0) ah_poison_rows<F16>(dqbase, rs, D, L, nullptr);
     return;
   }
   const int t_per = (n_tiles + qs - 1) / qs, t_lo = part * t_per, t_hi = (t_lo + t_per) < n_tiles ? (t_lo + t_per) : n_tiles;
@@ -307,8 +362,8 @@ attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
   unsigned char* Vsm = smem;
   unsigned char* Ksm = smem + (size_t)DK * slab;
   const uint16_t* qbase = qkv + ((int64_t)a * 3 * H + head) * D;
-  ah_stage_rows<DK>(qbase + (int64_t)2 * H * D, rs, D, L, Lp, slab, Vsm);
-  ah_stage_rows<DK>(qbase + (int64_t)H * D, rs, D, L, Lp, slab, Ksm);
+  ah_stage_rows<DK, F16>(qbase + (int64_t)2 * H * D, rs, D, L, Lp, slab, Vsm);
+  ah_stage_rows<DK, F16>(qbase + (int64_t)H * D, rs, D, L, Lp, slab, Ksm);
   __syncthreads();
 
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
@@ -332,9 +387,9 @@ attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
       const uint4 uq = ah_ld8(qrow, 16 * j + 8 * h2, D, qv);
       const uint4 ud = ah_ld8(dout + orow, 16 * j + 8 * h2, D, qv);
       const uint4 uo = ah_ld8(out + orow, 16 * j + 8 * h2, D, qv);
-      dl += ah_dot(ud, uo);
+      dl += ah_dot<F16>(ud, uo);
       dof[j] = ah_frag(ud);
-      split_scaled(ah_frag(uq), c, qhi[j], qlo[j]);
+      ah_split_scaled<F16>(ah_frag(uq), c, qhi[j], qlo[j]);
     }
     dl += __shfl_xor(dl, 32, 64);
     const float l2 = qv ? lse[(int64_t)head * total + a + q] * AT_LOG2E : INFINITY;
@@ -349,19 +404,19 @@ attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
       for (int j = 0; j < DK; ++j) {
         const s16x8 kf = *reinterpret_cast<const s16x8*>(Ksm + j * slab + kt * 1024 + rmo);
         const s16x8 vf = *reinterpret_cast<const s16x8*>(Vsm + j * slab + kt * 1024 + rmo);
-        s = mfma32(kf, qhi[j], s);
-        s = mfma32(kf, qlo[j], s);
-        dp = mfma32(vf, dof[j], dp);
+        s = AE<F16>::mfma(kf, qhi[j], s);
+        s = AE<F16>::mfma(kf, qlo[j], s);
+        dp = AE<F16>::mfma(vf, dof[j], dp);
       }
       uint32_t pk[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        pk[i] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * i]) * dp[2 * i], __builtin_amdgcn_exp2f(s[2 * i + 1]) * dp[2 * i + 1]);
+        pk[i] = AE<F16>::pack2(__builtin_amdgcn_exp2f(s[2 * i]) * dp[2 * i], __builtin_amdgcn_exp2f(s[2 * i + 1]) * dp[2 * i + 1]);
 #pragma unroll
       for (int mm = 0; mm < 2; ++mm) {
         const s16x8 dsf = make_frag(pk[4 * mm], pk[4 * mm + 1], pk[4 * mm + 2], pk[4 * mm + 3]);
 #pragma unroll
-        for (int m = 0; m < MP; ++m) acc[m] = mfma32(ld_tr_frag(Ksm + poff[m], ta, kt * 32 + 16 * mm), dsf, acc[m]);   // dQ^T[d][q]
+        for (int m = 0; m < MP; ++m) acc[m] = AE<F16>::mfma(ld_tr_frag(Ksm + poff[m], ta, kt * 32 + 16 * mm), dsf, acc[m]);   // dQ^T[d][q]
       }
     }
     if (qv) {
@@ -369,14 +424,14 @@ attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
 #pragma unroll
       for (int m = 0; m < MP; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ah_store_col(o, 32 * m + crow(r, h2), D, acc[m][r] * scale);
+        for (int r = 0; r < 16; ++r) ah_store_col<F16>(o, 32 * m + crow(r, h2), D, acc[m][r] * scale);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // LDS: Q slabs | dO slabs | aux [lp_max][4] bf16 (lse_hi, lse_lo, delta_hi, delta_lo)
-template <int DK>
+template <int DK, bool F16>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                        const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, int D, float scale, int64_t total,
@@ -394,8 +449,8 @@ attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
   uint16_t* dbase = dqkv + ((int64_t)a * 3 * H + head) * D;
   if (Lp > lp_max) {
     if (part == 0) {
-      ah_poison_rows(dbase + (int64_t)H * D, rs, D, L, nullptr);
-      ah_poison_rows(dbase + (int64_t)2 * H * D, rs, D, L, nullptr);
+      ah_poison_rows<F16>(dbase + (int64_t)H * D, rs, D, L, nullptr);
+      ah_poison_rows<F16>(dbase + (int64_t)2 * H * D, rs, D, L, nullptr);
     }
     return;
   }
@@ -406,13 +461,13 @@ attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
   unsigned char* dOsm = smem + (size_t)DK * slab;
   uint2* aux = reinterpret_cast<uint2*>(smem + (size_t)2 * DK * slab);
   const uint16_t* qbase = qkv + ((int64_t)a * 3 * H + head) * D;
-  ah_stage_rows<DK>(qbase, rs, D, L, Lp, slab, Qsm);
-  ah_stage_rows<DK>(dout + ((int64_t)a * H + head) * D, os, D, L, Lp, slab, dOsm);
+  ah_stage_rows<DK, F16>(qbase, rs, D, L, Lp, slab, Qsm);
+  ah_stage_rows<DK, F16>(dout + ((int64_t)a * H + head) * D, os, D, L, Lp, slab, dOsm);
   for (int q = threadIdx.x; q < Lp; q += AT_THREADS) {
-    const float l2 = q < L ? lse[(int64_t)head * total + a + q] * AT_LOG2E : AT_PAD_LSE;
+    const float l2 = q < L ? lse[(int64_t)head * total + a + q] * AT_LOG2E : AE<F16>::pad_lse();
     const float dl = q < L ? delta[(int64_t)head * total + a + q] : 0.f;
-    const uint32_t hi = pack_bf16x2(l2, dl);
-    const uint32_t lo = pack_bf16x2(l2 - __uint_as_float(hi << 16), dl - __uint_as_float(hi & 0xffff0000u));
+    const uint32_t hi = AE<F16>::pack2(l2, dl);
+    const uint32_t lo = AE<F16>::pack2(l2 - AE<F16>::lo(hi), dl - AE<F16>::hi(hi));
     uint2 w;
     w.x = (hi & 0xffffu) | (lo << 16);
     w.y = (hi >> 16) | (lo & 0xffff0000u);
@@ -425,7 +480,7 @@ attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
   const float c = scale * AT_LOG2E;
   const TrAddr ta = tr_addr(lane);
   const int rmo = rm_off(col, h2);
-  const uint32_t m1 = 0xBF80BF80u;
+  const uint32_t m1 = AE<F16>::NEG1X2;
   const s16x8 bS = make_frag(h2 == 0 ? m1 : 0u, 0u, 0u, 0u);
   const s16x8 bD = make_frag(0u, h2 == 0 ? m1 : 0u, 0u, 0u);
   int poff[MP];
@@ -438,7 +493,7 @@ attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
     s16x8 khi[DK], klo[DK], vf[DK];
 #pragma unroll
     for (int j = 0; j < DK; ++j) {
-      split_scaled(ah_frag(ah_ld8(krow, 16 * j + 8 * h2, D, key < L)), c, khi[j], klo[j]);
+      ah_split_scaled<F16>(ah_frag(ah_ld8(krow, 16 * j + 8 * h2, D, key < L)), c, khi[j], klo[j]);
       vf[j] = ah_frag(ah_ld8(krow + (int64_t)H * D, 16 * j + 8 * h2, D, key < L));
     }
     f32x16 dv[MP], dk[MP];
@@ -447,22 +502,22 @@ attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
     for (int qt = 0; qt < n_tiles; ++qt) {
       const uint2 ax = aux[qt * 32 + col];
       const s16x8 af = make_frag(ax.x, ax.y, 0u, 0u);
-      f32x16 s = mfma32(af, bS, zero16());
-      f32x16 dp = mfma32(af, bD, zero16());
+      f32x16 s = AE<F16>::mfma(af, bS, zero16());
+      f32x16 dp = AE<F16>::mfma(af, bD, zero16());
 #pragma unroll
       for (int j = 0; j < DK; ++j) {
         const s16x8 qf = *reinterpret_cast<const s16x8*>(Qsm + j * slab + qt * 1024 + rmo);
         const s16x8 dof = *reinterpret_cast<const s16x8*>(dOsm + j * slab + qt * 1024 + rmo);
-        s = mfma32(qf, khi[j], s);
-        s = mfma32(qf, klo[j], s);
-        dp = mfma32(dof, vf[j], dp);
+        s = AE<F16>::mfma(qf, khi[j], s);
+        s = AE<F16>::mfma(qf, klo[j], s);
+        dp = AE<F16>::mfma(dof, vf[j], dp);
       }
       uint32_t pp[8], ps[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float p0 = __builtin_amdgcn_exp2f(s[2 * i]), p1 = __builtin_amdgcn_exp2f(s[2 * i + 1]);
-        pp[i] = pack_bf16x2(p0, p1);
-        ps[i] = pack_bf16x2(p0 * dp[2 * i], p1 * dp[2 * i + 1]);
+        pp[i] = AE<F16>::pack2(p0, p1);
+        ps[i] = AE<F16>::pack2(p0 * dp[2 * i], p1 * dp[2 * i + 1]);
       }
 #pragma unroll
       for (int mm = 0; mm < 2; ++mm) {
@@ -470,8 +525,8 @@ attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
         const s16x8 dsf = make_frag(ps[4 * mm], ps[4 * mm + 1], ps[4 * mm + 2], ps[4 * mm + 3]);
 #pragma unroll
         for (int m = 0; m < MP; ++m) {
-          dv[m] = mfma32(pf, ld_tr_frag(dOsm + poff[m], ta, qt * 32 + 16 * mm), dv[m]);   // dV[key][d]
-          dk[m] = mfma32(dsf, ld_tr_frag(Qsm + poff[m], ta, qt * 32 + 16 * mm), dk[m]);   // dK[key][d]
+          dv[m] = AE<F16>::mfma(pf, ld_tr_frag(dOsm + poff[m], ta, qt * 32 + 16 * mm), dv[m]);   // dV[key][d]
+          dk[m] = AE<F16>::mfma(dsf, ld_tr_frag(Qsm + poff[m], ta, qt * 32 + 16 * mm), dk[m]);   // dK[key][d]
         }
       }
     }
@@ -484,8 +539,8 @@ attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
           const int kk = kt * 32 + crow(r, h2);
           if (kk < L) {
             uint16_t* o = dbase + (int64_t)kk * rs;
-            o[(int64_t)H * D + ch] = (uint16_t)(pack_bf16x2(dk[m][r] * scale, 0.f) & 0xffffu);
-            o[(int64_t)2 * H * D + ch] = (uint16_t)(pack_bf16x2(dv[m][r], 0.f) & 0xffffu);
+            o[(int64_t)H * D + ch] = (uint16_t)(AE<F16>::pack2(dk[m][r] * scale, 0.f) & 0xffffu);
+            o[(int64_t)2 * H * D + ch] = (uint16_t)(AE<F16>::pack2(dv[m][r], 0.f) & 0xffffu);
           }
         }
       }

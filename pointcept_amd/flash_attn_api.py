@@ -5,8 +5,8 @@
 head_dim 16 and max_seqlen <= 1024 (every PT-v3m1 / m2 configuration) run on the gfx950 MFMA window-attention kernels
 (attention.hip); head_dim 17..64 (PT-v3m3 / LitePT use 18: a multiple of 3 for their 3-D RoPE) on their multi-slab form
 (attention_hd.h; windows up to 1024 keys for head_dim <= 32, 672 for <= 48, 512 for <= 64).  Anything else (head_dim < 16,
-> 64, longer windows) raises PtcoreError: there is no library (SDPA) backend behind this mirror (round 4).  fp16 qkv (LitePT's call site) runs on the same kernels after a cast to
-bf16 and comes back as fp16.  dropout_p > 0 (head_dim 16): attention dropout with flash-attn's semantics and the engine's own counter-based
+> 64, longer windows) raises PtcoreError: there is no library (SDPA) backend behind this mirror (round 4).  fp16 qkv (LitePT's call site,
+head_dim 18) runs on f16-operand instances of the multi-slab kernels (f16 MFMAs, P / dS rounded to f16, fp32 accumulation).  dropout_p > 0 (head_dim 16): attention dropout with flash-attn's semantics and the engine's own counter-based
 mask (csrc/attention_drop.h; seed from torch's CPU generator).  causal / alibi / softcap / local windows raise.
 """
 from __future__ import annotations
@@ -38,8 +38,9 @@ def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
         # no library (SDPA) backend behind this mirror: outside the kernels' range the call fails loudly
         raise PtcoreError(f"flash_attn_varlen_qkvpacked_func: head_dim={int(qkv.shape[3])} with max_seqlen={int(max_seqlen)} is outside the "
                           "window-attention kernels' range (head_dim 16..32: 1024 keys, ..48: 672, ..64: 512) -- PTC_EUNSUPPORTED")
-    if qkv.dtype == torch.float16:
-        # LitePT's call site hands over fp16 (litept_v1.py:235-260).  The window-attention kernels take bf16 operands with fp32
-        # accumulation: fp16 operands are re-rounded to bf16 (three mantissa bits) and the result returned as fp16.
+    if qkv.dtype == torch.float16 and int(qkv.shape[3]) == 16:
+        # fp16 operands at head_dim 16: the head_dim-16 kernels compute in bf16 (what every PT-v3 call site asks for by casting first);
+        # an fp16 caller of THIS shape gets its operands re-rounded to bf16 (three mantissa bits) and fp16 back -- stated deviation.
+        # head_dim 17..64 (LitePT, litept_v1.py:259-265) runs f16-operand instances: no re-rounding (round 4).
         return PF.attn_varlen_qkvpacked(qkv.to(torch.bfloat16), cu_seqlens, max_seqlen, softmax_scale, dropout_p).to(torch.float16)
     return PF.attn_varlen_qkvpacked(qkv, cu_seqlens, max_seqlen, softmax_scale, dropout_p)

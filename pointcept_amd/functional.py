@@ -598,10 +598,11 @@ def attn_varlen_qkvpacked(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqle
     """flash_attn.flash_attn_varlen_qkvpacked_func semantics (ptv3m1:208-214),
     non-causal, qkv [T,3,H,16] bf16 -> [T,H,16] bf16.  f16 qkv with head_dim 16 = the reference's fp16-autocast call site INCLUDING its
     casts: `flash_attn(qkv.to(bfloat16)).to(qkv.dtype)` -- bf16 arithmetic, f16 tensors, the four cast passes (two forward, two
-    backward) folded into the kernels' loads and stores.  dropout_p > 0 (head_dim 16): attention dropout; the mask is a function of
+    backward) folded into the kernels' loads and stores; f16 qkv with head_dim 17..64 = f16 OPERANDS (f16 MFMAs, f16 P / dS, fp32
+    accumulation: what flash-attn does with LitePT's fp16 tensors, litept_v1.py:259-265).  dropout_p > 0 (head_dim 16): attention dropout; the mask is a function of
     `seed` (default: drawn from torch's CPU generator, so torch.manual_seed reproduces a step) and is regenerated by the backward."""
-    if qkv.dtype != torch.bfloat16 and not (qkv.dtype == torch.float16 and qkv.shape[-1] == 16):
-        raise PtcoreError("attn_varlen_qkvpacked expects bf16 (the reference casts with .to(torch.bfloat16), ptv3m1:209)")
+    if qkv.dtype not in (torch.bfloat16, torch.float16):
+        raise PtcoreError("attn_varlen_qkvpacked expects 16-bit operands (the reference casts with .to(torch.bfloat16), ptv3m1:209)")
     if softmax_scale is None:
         softmax_scale = qkv.shape[-1] ** -0.5
     dropout_p = float(dropout_p)
@@ -646,16 +647,16 @@ class _RopeXYZ(Function):
     """ptc_rope3d_xyz: q / k slabs rotated, v converted, one pass, bf16 out; backward = the inverse rotation of the gradient."""
 
     @staticmethod
-    def forward(ctx, qkv, xyz, inv_freq):
+    def forward(ctx, qkv, xyz, inv_freq, out_dtype):
         ctx.save_for_backward(xyz, inv_freq)
         ctx.in_dtype = qkv.dtype
-        return ops.rope3d_xyz(qkv.contiguous(), xyz, inv_freq, 2, 1.0, torch.bfloat16)
+        return ops.rope3d_xyz(qkv.contiguous(), xyz, inv_freq, 2, 1.0, out_dtype)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
         xyz, inv_freq = ctx.saved_tensors
-        return ops.rope3d_xyz(g.contiguous(), xyz, inv_freq, 2, -1.0, ctx.in_dtype), None, None
+        return ops.rope3d_xyz(g.contiguous(), xyz, inv_freq, 2, -1.0, ctx.in_dtype), None, None, None
 
 
 def rope_xyz_torch(qkv: torch.Tensor, xyz: torch.Tensor, inv_freq: torch.Tensor) -> torch.Tensor:
@@ -671,13 +672,14 @@ def rope_xyz_torch(qkv: torch.Tensor, xyz: torch.Tensor, inv_freq: torch.Tensor)
     return torch.cat((rot.reshape(n, 2, H, D).to(torch.bfloat16), qkv[:, 2:].to(torch.bfloat16)), dim=1)
 
 
-def rope_xyz_qkvpacked(qkv: torch.Tensor, xyz: torch.Tensor, inv_freq: torch.Tensor) -> torch.Tensor:
+def rope_xyz_qkvpacked(qkv: torch.Tensor, xyz: torch.Tensor, inv_freq: torch.Tensor, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
     """qkv [n, 3, H, D] (D % 6 == 0) -> bf16 [n, 3, H, D] with Point3DRoPE applied to q and k: what flash-attn receives at
     point_transformer_v3m3_utonia.py:319-323.  On ptc_rope3d_xyz (one pass over the packed rows, bf16 out); `rope_xyz_torch` is the same
     arithmetic in torch ops, kept as the reference of the parity tests."""
     if qkv.dim() != 4 or qkv.shape[1] != 3 or qkv.shape[3] % 6 != 0:
         raise PtcoreError(f"rope_xyz_qkvpacked: qkv {tuple(qkv.shape)} must be [n, 3, H, D] with D % 6 == 0")
-    return _RopeXYZ.apply(qkv, xyz.float().contiguous(), inv_freq.float().contiguous())
+    # out_dtype: bf16 = PT-v3m3's `qkv.to(torch.bfloat16)` in front of flash-attn; LitePT hands over its autocast dtype (f16 under the fp16 recipe)
+    return _RopeXYZ.apply(qkv, xyz.float().contiguous(), inv_freq.float().contiguous(), out_dtype)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -51,6 +51,11 @@ class PointROPEAttention(RopeAttention):
     def _rope_on(self) -> bool:
         return True
 
+    def _operand_dtype(self, qkv_dtype):
+        """litept_v1.py:239-265: the rotated q / k come back in q.dtype and go to flash-attn uncast -- f16 under the reference's fp16
+        autocast recipe (f16-operand instances of the window-attention kernels), bf16 under bf16 autocast"""
+        return torch.float16 if qkv_dtype == torch.float16 else torch.bfloat16
+
     def _rope_inputs(self, point, order):
         key = f"_ptc_rope_pos_{self.order_index}"
         if key not in point.keys():

@@ -760,11 +760,11 @@ def attn_hd_supported(head_dim: int, max_seqlen: int) -> bool:
 def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, softmax_scale: float, dropout_p: float = 0.0, seed: int = 0):
     """qkv [T,3,H,D] bf16 -> (out [T,H,D] bf16, lse [H,T] fp32); D = 16 (attention.hip) or 17..64 (attention_hd.h).
     D = 16 also takes f16 qkv: the SAME bf16 arithmetic with the reference's qkv.to(bfloat16) / feat.to(qkv.dtype) casts
-    (ptv3m1:209,215) done in the kernel's load / store paths -- out comes back f16, bit for bit what the two cast passes produce."""
+    (ptv3m1:209,215) done in the kernel's load / store paths -- out comes back f16, bit for bit what the two cast passes produce.
+    D = 17..64 with f16 qkv: f16 operands (f16 MFMAs, P rounded to f16), LitePT's call site."""
     require_cuda(qkv, cu_seqlens)
-    f16_io = qkv.dtype == torch.float16 and qkv.dim() == 4 and qkv.shape[3] == 16
-    if (qkv.dtype != torch.bfloat16 and not f16_io) or qkv.dim() != 4 or qkv.shape[1] != 3:
-        raise PtcoreError(f"qkv must be bf16 [T,3,H,D] (or f16 with D = 16), got {qkv.dtype} {tuple(qkv.shape)}")
+    if qkv.dtype not in (torch.bfloat16, torch.float16) or qkv.dim() != 4 or qkv.shape[1] != 3:
+        raise PtcoreError(f"qkv must be bf16 or f16 [T,3,H,D], got {qkv.dtype} {tuple(qkv.shape)}")
     qkv = qkv.contiguous()
     cu = cu_seqlens.to(torch.int32).contiguous()
     T, _, H, D = qkv.shape
@@ -780,7 +780,7 @@ def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int
                                         dtype_code(qkv), ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_fwd")
     else:
         check(lib().ptc_attn_varlen_hd_fwd(ptr(qkv), ptr(cu), cu.numel() - 1, T, H, D, int(max_seqlen), float(softmax_scale),
-                                           _lib.PTC_BF16, ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_hd_fwd")
+                                           dtype_code(qkv), ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_hd_fwd")
     return out, lse
 
 
@@ -804,7 +804,7 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_sc
                                         stream_ptr()), "ptc_attn_varlen_bwd")
     else:
         check(lib().ptc_attn_varlen_hd_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), cu.numel() - 1, T, H, D,
-                                           int(max_seqlen), float(softmax_scale), _lib.PTC_BF16, ptr(dqkv), ptr(ws), nbytes,
+                                           int(max_seqlen), float(softmax_scale), dtype_code(qkv), ptr(dqkv), ptr(ws), nbytes,
                                            stream_ptr()), "ptc_attn_varlen_hd_bwd")
     return dqkv
 

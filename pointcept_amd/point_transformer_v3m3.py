@@ -68,6 +68,10 @@ class RopeAttention(_AttnM1):
         """-> (xyz [n, 3] fp32 positions of the padded, serialized rows; inv_freq [head_dim / 6] fp32)"""
         raise NotImplementedError
 
+    def _operand_dtype(self, qkv_dtype):
+        """dtype of the tensor the call site hands to flash-attn: PT-v3m3 casts to bf16 itself (utonia.py:353)"""
+        return torch.bfloat16
+
     def _rotate_for_dense(self, qkv, point, order):
         """[n, 3, H, D] -> fp32 rotated q, k (dense branch)"""
         xyz, inv_freq = self._rope_inputs(point, order)
@@ -119,13 +123,13 @@ class RopeAttention(_AttnM1):
         xyz, inv_freq = self._rope_inputs(point, order)
         if tabs is not None:
             qkv_s = self.qkv(point.feat, tabs[0], tabs[1])                                     # padded, serialized rows (:272)
-            qkv_r = PF.rope_xyz_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, inv_freq)       # :303-305,319-321 (bf16)
+            qkv_r = PF.rope_xyz_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, inv_freq, self._operand_dtype(qkv_s.dtype))   # :303-305,319-321
             out = PF.attn_varlen_qkvpacked(qkv_r, cu_seqlens, K, self.scale)
             feat = self.proj(out.reshape(-1, C).to(qkv_s.dtype), tabs[2], tabs[3])
         else:
             qkv = self.qkv(point.feat)
             qkv_s = PF.gather_rows(qkv, gidx, inv, dup_of_point)
-            qkv_r = PF.rope_xyz_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, inv_freq)
+            qkv_r = PF.rope_xyz_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, inv_freq, self._operand_dtype(qkv_s.dtype))
             out = PF.attn_varlen_qkvpacked(qkv_r, cu_seqlens, K, self.scale)
             feat = self.proj(PF.gather_rows(out.reshape(-1, C), inv, gidx_primary).to(qkv.dtype))
         point.feat = self.proj_drop(feat)

@@ -167,18 +167,21 @@ def spconv_wgrad(feat, dout, nbr, want_bias=False, blk=None):
 
 
 def attn_varlen_fwd(qkv, cu_seqlens, max_seqlen, softmax_scale, dropout_p=0.0, seed=0):
-    # f16 qkv (head_dim 16): the reference's casts around its bf16 kernel, flash_attn(qkv.to(bfloat16)).to(qkv.dtype)
-    out, lse = oops.attention_varlen(qkv.to(torch.bfloat16).float(), cu_seqlens.tolist(), float(softmax_scale), return_lse=True,
+    # f16 qkv, head_dim 16: the reference's casts around its bf16 kernel, flash_attn(qkv.to(bfloat16)).to(qkv.dtype); other head dims:
+    # f16 operands as they are (LitePT's call site)
+    arith = torch.bfloat16 if qkv.shape[-1] == 16 else qkv.dtype
+    out, lse = oops.attention_varlen(qkv.to(arith).float(), cu_seqlens.tolist(), float(softmax_scale), return_lse=True,
                                      dropout_p=dropout_p, seed=seed)
-    return out.to(torch.bfloat16).to(qkv.dtype), lse
+    return out.to(arith).to(qkv.dtype), lse
 
 
 def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen, softmax_scale, dropout_p=0.0, seed=0):
-    q = qkv.detach().to(torch.bfloat16).float().requires_grad_(True)
+    arith = torch.bfloat16 if qkv.shape[-1] == 16 else qkv.dtype
+    q = qkv.detach().to(arith).float().requires_grad_(True)
     with torch.enable_grad():
         o = oops.attention_varlen(q, cu_seqlens.tolist(), float(softmax_scale), dropout_p=dropout_p, seed=seed)
-    o.backward(dout.to(torch.bfloat16).float())
-    return q.grad.to(torch.bfloat16).to(qkv.dtype)
+    o.backward(dout.to(arith).float())
+    return q.grad.to(arith).to(qkv.dtype)
 
 
 def knn_query(nsample, xyz, offset, new_xyz, new_offset):

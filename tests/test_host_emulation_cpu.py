@@ -204,7 +204,9 @@ EMULATED_GPU_TESTS = [
     ("test_attention_fwd_bwd", dict(lens=[48, 48, 17], H=2)), ("test_attention_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
     ("test_attention_large_logits", dict()), ("test_attention_dropout_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3, p=0.25)),
     ("test_attention_dropout_fwd_bwd", dict(lens=[200], H=2, p=0.5)), ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
-    ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6)),
+    ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.bfloat16)),
+    ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.float16)),
+    ("test_attention_other_head_dims_fwd_bwd", dict(D=40, lens=[200, 100], H=2, dtype=torch.float16)),
     ("test_attention_rpe_fwd_bwd", dict(lens=[200, 200, 200], H=3, bnd=18)),
 ]   # (in-place GPU tests -- rope3d, cross entropy -- are not in the list: with device = cpu their `.to(device)` aliases the input the
 #    oracle is then fed with; tests that construct `pointcept_amd.nn` modules or open a CUDA autocast region cannot run on CPU tensors)

@@ -834,7 +834,7 @@ def test_litept_module_port_matches_the_reference_file(variant, monkeypatch):
     from oracle import ops as oops
     from pointcept_amd import functional as PF
 
-    def rope_fp16(qkv, xyz, inv_freq):
+    def rope_fp16(qkv, xyz, inv_freq, out_dtype=None):
         h = qkv.half()
         rot = PF.rope_xyz_torch.__globals__["torch"].cat((_rot_fp32(h[:, :2].float(), xyz, inv_freq).half(), h[:, 2:]), dim=1)
         return rot
@@ -850,7 +850,7 @@ def test_litept_module_port_matches_the_reference_file(variant, monkeypatch):
 
     monkeypatch.setattr(PF, "rope_xyz_qkvpacked", rope_fp16)
     monkeypatch.setattr(PF, "attn_varlen_qkvpacked",
-                        lambda qkv, cu, k, scale: oops.attention_varlen(qkv.float(), cu.tolist(), scale).to(qkv.dtype))
+                        lambda qkv, cu, k, scale, *a: oops.attention_varlen(qkv.float(), cu.tolist(), scale).to(qkv.dtype))
     eng.zero_grad(set_to_none=True)
     with mock_backend.cpu_ops():
         torch.manual_seed(9)
@@ -863,8 +863,8 @@ def test_litept_module_port_matches_the_reference_file(variant, monkeypatch):
 
 
 def test_flash_attn_mirror_accepts_fp16_like_liteptS_call_site():
-    """litept_v1.py:235-260 hands flash_attn fp16 rows: the mirror runs them on the bf16 window-attention path and returns fp16, with
-    gradients (dtype of the caller's tensor) flowing through both casts."""
+    """litept_v1.py:235-260 hands flash_attn fp16 rows (head_dim 18): the mirror runs them on f16-operand instances of the window-attention
+    kernels and returns fp16, with gradients in the dtype of the caller's tensor."""
     from oracle import ops as oops
     from pointcept_amd import flash_attn_api
 
@@ -875,8 +875,8 @@ def test_flash_attn_mirror_accepts_fp16_like_liteptS_call_site():
         out = flash_attn_api.flash_attn_varlen_qkvpacked_func(qkv, cu, max_seqlen=128, softmax_scale=0.2)
         out.float().pow(2).sum().backward()
     assert out.dtype == torch.float16 and out.shape == (300, 2, 18) and qkv.grad.dtype == torch.float16
-    want = oops.attention_varlen(qkv.detach().to(torch.bfloat16).float(), cu.tolist(), 0.2)
-    assert _rel(out.detach().float(), want) < 5e-3 and float(qkv.grad.float().abs().max()) > 0
+    want = oops.attention_varlen(qkv.detach().float(), cu.tolist(), 0.2)
+    assert _rel(out.detach().float(), want) < 1e-3 and float(qkv.grad.float().abs().max()) > 0
 
 
 @pytest.mark.needs_reference
