@@ -407,6 +407,21 @@ int ptc_attn_varlen_hd_bwd(const void* qkv, const void* out, const void* dout, c
                            const int32_t* cu_seqlens, int64_t n_seq, int64_t total, int H,
                            int head_dim, int max_seqlen, float softmax_scale, int dtype, void* dqkv,
                            void* workspace, size_t workspace_bytes, ptc_stream_t stream);
+/* ... with the 3-D rotary embedding of q and k FUSED into the attention prologue / epilogue (round 4), head_dim 18 = every
+ * PT-v3m3 / LitePT configuration: qkv holds the UN-rotated rows the qkv Linear wrote; the kernels rotate K while staging it and q when
+ * loading it -- pair (x[6 a + i], x[6 a + 3 + i]) by the angle xyz[t][a] * inv_freq[i], fp32, rounded to the operand dtype: Point3DRoPE of
+ * point_transformer_v3m3_utonia.py:58-101,303-323 / libs/pointrope/kernels.cu:19-75 with integer positions -- and apply the inverse
+ * rotation to dq / dk in the backward's epilogue, so dqkv is the gradient of the un-rotated rows.  Replaces the separate pass
+ * ptc_rope3d_xyz (one read + one write of q and k per direction).  xyz [total, 3] fp32 = positions of the padded, serialized rows,
+ * inv_freq [3] fp32.  ptc_attn_varlen_hd_rope_supported: 1 for head_dim 18 with a window the LDS-resident form holds. */
+int ptc_attn_varlen_hd_rope_supported(int head_dim, int max_seqlen);
+int ptc_attn_varlen_hd_rope_fwd(const void* qkv, const int32_t* cu_seqlens, const float* xyz, const float* inv_freq, int64_t n_seq,
+                                int64_t total, int H, int head_dim, int max_seqlen, float softmax_scale, int dtype, void* out, float* lse,
+                                ptc_stream_t stream);
+int ptc_attn_varlen_hd_rope_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
+                                const float* xyz, const float* inv_freq, int64_t n_seq, int64_t total, int H, int head_dim, int max_seqlen,
+                                float softmax_scale, int dtype, void* dqkv, void* workspace, size_t workspace_bytes, ptc_stream_t stream);
+
 
 /* Window attention with PTv3's relative position bias (the non-flash branch with enable_rpe=True,
  * pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:29-48,104-112,190-206), head_dim 16:

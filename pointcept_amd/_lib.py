@@ -80,6 +80,10 @@ _SIGNATURES = {
     "ptc_attn_varlen_dropout_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_f32, c_int, c_f32, ctypes.c_uint64,
                                             c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_attn_varlen_hd_supported": (c_int, [c_int, c_int]),
+    "ptc_attn_varlen_hd_rope_supported": (c_int, [c_int, c_int]),
+    "ptc_attn_varlen_hd_rope_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_int, c_ptr, c_ptr, c_ptr]),
+    "ptc_attn_varlen_hd_rope_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_int, c_ptr,
+                                            c_ptr, c_size, c_ptr]),
     "ptc_weight_layouts": (c_int, [c_ptr, c_ptr, c_int, c_i64, c_ptr]),
     "ptc_cast_many": (c_int, [c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr]),
     "ptc_pair_dot_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_ptr, c_ptr]),

@@ -1018,6 +1018,82 @@ extern "C" int ptc_attn_varlen_hd_bwd(const void* qkv, const void* out, const vo
   return PTC_EUNSUPPORTED;
 }
 
+// ---- the same operator with the 3-D rotary embedding of q and k fused into its prologue / epilogue (head_dim 18; attention_hd.h, ROPE) ----------
+extern "C" int ptc_attn_varlen_hd_rope_supported(int head_dim, int max_seqlen) {
+  if (head_dim != AH_RD) return 0;
+  const int lp_max = (max_seqlen + 31) & ~31;
+  return ptc_attn_varlen_hd_supported(head_dim, max_seqlen) && hd_dkv_lds(2, lp_max) + (size_t)AT_WAVES * 32 * AH_RD * 2 <= AH_LDS_LIMIT;
+}
+
+extern "C" int ptc_attn_varlen_hd_rope_fwd(const void* qkv, const int32_t* cu_seqlens, const float* xyz, const float* inv_freq, int64_t n_seq,
+                                           int64_t total, int H, int head_dim, int max_seqlen, float softmax_scale, int dtype, void* out,
+                                           float* lse, ptc_stream_t stream) {
+  int rc = hd_check("ptc_attn_varlen_hd_rope_fwd", qkv, cu_seqlens, n_seq, total, H, head_dim, max_seqlen, dtype);
+  if (rc != PTC_OK) return rc;
+  PTC_REQUIRE(ptc_attn_varlen_hd_rope_supported(head_dim, max_seqlen), PTC_EUNSUPPORTED, "ptc_attn_varlen_hd_rope_fwd: head_dim=%d (18 only)", head_dim);
+  if (n_seq == 0 || total == 0) return PTC_OK;
+  PTC_REQUIRE(out && lse && xyz && inv_freq, PTC_EINVAL, "ptc_attn_varlen_hd_rope_fwd: null buffer");
+  const int lp_max = (max_seqlen + 31) & ~31;
+  const size_t lds = hd_fwd_lds(2, head_dim, lp_max);
+  const int n_units = (int)(n_seq * H);
+  const int qs = at_split_host(n_units, lp_max);
+  const AhRope rp{xyz, inv_freq};
+#define AH_RF_CASE(F16)                                                                                                                \
+  if ((dtype == PTC_F16) == F16) {                                                                                                     \
+    rc = allow_big_lds(attn_hd_fwd_kernel<2, 1, F16, true>, lds);                                                                      \
+    if (rc != PTC_OK) return rc;                                                                                                       \
+    hipLaunchKernelGGL((attn_hd_fwd_kernel<2, 1, F16, true>), dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds,     \
+                       (hipStream_t)stream, (const uint16_t*)qkv, cu_seqlens, H, head_dim, softmax_scale, total, lp_max, n_units, qs,  \
+                       (uint16_t*)out, lse, rp);                                                                                       \
+    PTC_CHECK_LAUNCH("attn_hd_fwd_kernel(rope)");                                                                                      \
+    return PTC_OK;                                                                                                                     \
+  }
+  AH_RF_CASE(false) AH_RF_CASE(true)
+#undef AH_RF_CASE
+  return PTC_EINVAL;   // not reached
+}
+
+extern "C" int ptc_attn_varlen_hd_rope_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* cu_seqlens,
+                                           const float* xyz, const float* inv_freq, int64_t n_seq, int64_t total, int H, int head_dim,
+                                           int max_seqlen, float softmax_scale, int dtype, void* dqkv, void* workspace, size_t workspace_bytes,
+                                           ptc_stream_t stream) {
+  int rc = hd_check("ptc_attn_varlen_hd_rope_bwd", qkv, cu_seqlens, n_seq, total, H, head_dim, max_seqlen, dtype);
+  if (rc != PTC_OK) return rc;
+  PTC_REQUIRE(ptc_attn_varlen_hd_rope_supported(head_dim, max_seqlen), PTC_EUNSUPPORTED, "ptc_attn_varlen_hd_rope_bwd: head_dim=%d (18 only)", head_dim);
+  if (n_seq == 0 || total == 0) return PTC_OK;
+  PTC_REQUIRE(out && dout && lse && dqkv && workspace && xyz && inv_freq, PTC_EINVAL, "ptc_attn_varlen_hd_rope_bwd: null buffer");
+  PTC_REQUIRE(workspace_bytes >= ptc_attn_varlen_bwd_workspace_bytes(total, H), PTC_EWORKSPACE, "ptc_attn_varlen_hd_rope_bwd: workspace too small");
+  PTC_REQUIRE(((uintptr_t)out % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0), PTC_EINVAL,
+              "ptc_attn_varlen_hd_rope_bwd: buffers must be 16-byte aligned");
+  const int lp_max = (max_seqlen + 31) & ~31;
+  const int n_units = (int)(n_seq * H);
+  const int qs = at_split_host(n_units, lp_max);
+  const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
+  hipStream_t s = (hipStream_t)stream;
+  float* delta = (float*)workspace;
+  const size_t tile = (size_t)AT_WAVES * 32 * AH_RD * 2, lds_q = hd_dq_lds(2, lp_max) + tile, lds_kv = hd_dkv_lds(2, lp_max) + tile;
+  const AhRope rp{xyz, inv_freq};
+#define AH_RB_CASE(F16)                                                                                                                \
+  if ((dtype == PTC_F16) == F16) {                                                                                                     \
+    rc = allow_big_lds(attn_hd_bwd_dq_kernel<2, F16, true>, lds_q);                                                                    \
+    if (rc != PTC_OK) return rc;                                                                                                       \
+    rc = allow_big_lds(attn_hd_bwd_dkv_kernel<2, F16, true>, lds_kv);                                                                  \
+    if (rc != PTC_OK) return rc;                                                                                                       \
+    hipLaunchKernelGGL((attn_hd_bwd_dq_kernel<2, F16, true>), dim3(grid), dim3(AT_THREADS), lds_q, s, (const uint16_t*)qkv,              \
+                       (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H, head_dim, softmax_scale, total, lp_max,        \
+                       n_units, qs, (uint16_t*)dqkv, delta, rp);                                                                       \
+    PTC_CHECK_LAUNCH("attn_hd_bwd_dq_kernel(rope)");                                                                                   \
+    hipLaunchKernelGGL((attn_hd_bwd_dkv_kernel<2, F16, true>), dim3(grid), dim3(AT_THREADS), lds_kv, s, (const uint16_t*)qkv,            \
+                       (const uint16_t*)dout, lse, (const float*)delta, cu_seqlens, H, head_dim, softmax_scale, total, lp_max,         \
+                       n_units, qs, (uint16_t*)dqkv, rp);                                                                              \
+    PTC_CHECK_LAUNCH("attn_hd_bwd_dkv_kernel(rope)");                                                                                  \
+    return PTC_OK;                                                                                                                     \
+  }
+  AH_RB_CASE(false) AH_RB_CASE(true)
+#undef AH_RB_CASE
+  return PTC_EINVAL;   // not reached
+}
+
 // ------------------------------------------------------------------------------------------------
 // relative-position-bias attention, head_dim 16 (attention_rpe.h)
 // ------------------------------------------------------------------------------------------------

@@ -174,12 +174,90 @@ __device__ __forceinline__ float ah_pick_row(const f32x16& acc, int row) {
   return v;
 }
 
+
+// ---- 3-D rotary embedding in the attention PROLOGUE / EPILOGUE (round 4; head_dim 18 = every PT-v3m3 / LitePT config) -------------
+// The rotation of q and k that the reference applies between its qkv Linear and flash-attn (point_transformer_v3m3_utonia.py:58-101,
+// 303-323; libs/pointrope/kernels.cu:19-75 behind litept_v1.py:239-241): per axis a and frequency i the pair
+// (x[6 a + i], x[6 a + 3 + i]) <- (u cos f - v sin f, v cos f + u sin f), f = pos[a] inv_freq[i], computed in fp32 and rounded to the
+// operand dtype.  It used to be its own pass over the packed [n, 3, H, 18] rows (ptc_rope3d_xyz: one read + one write of q and k, and
+// the same again for the gradient); ROPE = true kernels rotate K while they stage it, q when they load it, and turn the gradients
+// of the rotated q / k back (the inverse rotation: sign = -1) in their epilogue -- through a wave-private LDS tile, because a row's
+// pairs sit in different lanes of the accumulator layout; a lane then owns a whole 36-byte row and stores it in one piece.
+#define AH_RD 18                     // head_dim of the fused rotation
+#define AH_RW 9                      // 32-bit words per row
+struct AhRope { const float* xyz; const float* inv_freq; };   // positions [total, 3] fp32 of the padded, serialized rows; frequencies [3]
+// the 9 words of row `row` (global row index t for its position), rotated by sign * angle; invalid rows = zeros
+template <bool F16>
+__device__ __forceinline__ void ah_rope_row(const uint32_t* __restrict__ src, bool valid, const AhRope& rp, int64_t t, float sign,
+                                            uint32_t (&w)[AH_RW]) {
+#pragma unroll
+  for (int i = 0; i < AH_RW; ++i) w[i] = valid ? src[i] : 0u;
+  if (!valid) return;
+  float x[AH_RD];
+#pragma unroll
+  for (int i = 0; i < AH_RW; ++i) { x[2 * i] = AE<F16>::lo(w[i]); x[2 * i + 1] = AE<F16>::hi(w[i]); }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float pos = rp.xyz[t * 3 + a];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float sn, cs;
+      sincosf(pos * rp.inv_freq[i], &sn, &cs);
+      sn *= sign;
+      const float u = x[6 * a + i], v = x[6 * a + 3 + i];
+      ptc_rope_pair(u, v, cs, sn, x[6 * a + i], x[6 * a + 3 + i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < AH_RW; ++i) w[i] = AE<F16>::pack2(x[2 * i], x[2 * i + 1]);
+}
+// the 8-channel chunk [ch0, ch0 + 8) of a rotated row (ch0 in {0, 8, 16, 24})
+__device__ __forceinline__ uint4 ah_rope_chunk(const uint32_t (&w)[AH_RW], int ch0) {
+  uint4 u = {0, 0, 0, 0};
+  if (ch0 == 0) u = make_uint4(w[0], w[1], w[2], w[3]);
+  else if (ch0 == 8) u = make_uint4(w[4], w[5], w[6], w[7]);
+  else if (ch0 == 16) u = make_uint4(w[8], 0, 0, 0);
+  return u;
+}
+// rows [0, Lp) of K (or Q) rotated, into the two slab images; returns this thread's max |row|^2
+template <bool F16>
+__device__ __forceinline__ float ah_stage_rows_rope(const uint16_t* __restrict__ src, int64_t row_stride, int64_t t0, const AhRope& rp, int L, int Lp,
+                                                    int slab_bytes, unsigned char* lds) {
+  float mx = 0.f;
+  for (int row = threadIdx.x; row < Lp; row += AT_THREADS) {
+    uint32_t w[AH_RW];
+    ah_rope_row<F16>(reinterpret_cast<const uint32_t*>(src + (int64_t)row * row_stride), row < L, rp, t0 + row, 1.f, w);
+    const uint4 c0 = ah_rope_chunk(w, 0), c1 = ah_rope_chunk(w, 8), c2 = ah_rope_chunk(w, 16), z = {0, 0, 0, 0};
+    *reinterpret_cast<uint4*>(lds + rm_off(row, 0)) = c0;
+    *reinterpret_cast<uint4*>(lds + rm_off(row, 1)) = c1;
+    *reinterpret_cast<uint4*>(lds + slab_bytes + rm_off(row, 0)) = c2;
+    *reinterpret_cast<uint4*>(lds + slab_bytes + rm_off(row, 1)) = z;
+    mx = fmaxf(mx, ah_sumsq<F16>(c0) + ah_sumsq<F16>(c1) + ah_sumsq<F16>(c2));
+  }
+  return mx;
+}
+// gradient rows of a 32-row tile, sitting 16-bit rounded in the wave's LDS tile [32][AH_RD]: lane r < 32 turns row r back and stores it
+template <bool F16>
+__device__ __forceinline__ void ah_unrope_store(const uint16_t* tile, int lane, int row0, int L, const AhRope& rp, int64_t t0, float scale,
+                                                uint16_t* __restrict__ dst0, int64_t row_stride) {
+  const int row = row0 + (lane & 31);
+  if (lane < 32 && row < L) {
+    uint32_t w[AH_RW];
+    ah_rope_row<F16>(reinterpret_cast<const uint32_t*>(tile + (lane & 31) * AH_RD), true, rp, t0 + row, -1.f, w);
+    uint32_t* o = reinterpret_cast<uint32_t*>(dst0 + (int64_t)row * row_stride);
+#pragma unroll
+    for (int i = 0; i < AH_RW; ++i) o[i] = w[i];
+  }
+  (void)scale;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // LDS: K slabs DK x [lp_max][16] | V^T [D + 1][pitch] | AT_WAVES floats
-template <int DK, int MB, bool F16>
+template <int DK, int MB, bool F16, bool ROPE = false>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu, int H, int D, float scale, int64_t total,
-                   int lp_max, int n_units, int qs, uint16_t* __restrict__ out, float* __restrict__ lse) {
+                   int lp_max, int n_units, int qs, uint16_t* __restrict__ out, float* __restrict__ lse, AhRope rope = AhRope{nullptr, nullptr}) {
+  static_assert(!ROPE || (DK == 2 && MB == 1), "the fused rotation is built for head_dim 18");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lunit = at_unit(n_units * qs);
   if (lunit >= n_units * qs) return;
@@ -201,7 +279,9 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
   float* red = reinterpret_cast<float*>(Vt + (size_t)(D + 1) * pitch * 2);
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const uint16_t* qbase = qkv + ((int64_t)a * 3 * H + head) * D;            // q row t: qbase + t * rs; k: + H*D; v: + 2*H*D
-  float kn = ah_stage_rows<DK, F16>(qbase + (int64_t)H * D, rs, D, L, Lp, slab, Ksm);
+  float kn;
+  if constexpr (ROPE) kn = ah_stage_rows_rope<F16>(qbase + (int64_t)H * D, rs, a, rope, L, Lp, slab, Ksm);
+  else kn = ah_stage_rows<DK, F16>(qbase + (int64_t)H * D, rs, D, L, Lp, slab, Ksm);
   ah_stage_vt<DK, F16>(qbase + (int64_t)2 * H * D, rs, D, L, Lp, pitch, Vt);
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) kn = fmaxf(kn, __shfl_xor(kn, o, 64));
@@ -227,9 +307,13 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
     const uint16_t* qrow = qbase + (int64_t)q * rs;
     s16x8 qhi[DK], qlo[DK];
     float qn = 0.f;
+    uint32_t qw[ROPE ? AH_RW : 1];
+    if constexpr (ROPE) ah_rope_row<F16>(reinterpret_cast<const uint32_t*>(qrow), q < L, rope, (int64_t)a + q, 1.f, qw);
 #pragma unroll
     for (int j = 0; j < DK; ++j) {
-      const uint4 u = ah_ld8(qrow, 16 * j + 8 * h2, D, q < L);
+      uint4 u;
+      if constexpr (ROPE) u = ah_rope_chunk(qw, 16 * j + 8 * h2);
+      else u = ah_ld8(qrow, 16 * j + 8 * h2, D, q < L);
       qn += ah_sumsq<F16>(u);
       ah_split_scaled<F16>(ah_frag(u), c, qhi[j], qlo[j]);
     }
@@ -336,11 +420,13 @@ __device__ __forceinline__ void ah_store_col(uint16_t* row, int ch, int D, float
 
 // ------------------------------------------------------------------------------------------------ backward: dQ + delta
 // LDS: V slabs | K slabs
-template <int DK, bool F16>
+template <int DK, bool F16, bool ROPE = false>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                       const float* __restrict__ lse, const int32_t* __restrict__ cu, int H, int D, float scale, int64_t total,
-                      int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, float* __restrict__ delta) {
+                      int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, float* __restrict__ delta,
+                      AhRope rope = AhRope{nullptr, nullptr}) {
+  static_assert(!ROPE || DK == 2, "the fused rotation is built for head_dim 18");
   constexpr int MP = (DK + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lunit = at_unit(n_units * qs);
@@ -363,7 +449,9 @@ attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
   unsigned char* Ksm = smem + (size_t)DK * slab;
   const uint16_t* qbase = qkv + ((int64_t)a * 3 * H + head) * D;
   ah_stage_rows<DK, F16>(qbase + (int64_t)2 * H * D, rs, D, L, Lp, slab, Vsm);
-  ah_stage_rows<DK, F16>(qbase + (int64_t)H * D, rs, D, L, Lp, slab, Ksm);
+  if constexpr (ROPE) ah_stage_rows_rope<F16>(qbase + (int64_t)H * D, rs, a, rope, L, Lp, slab, Ksm);
+  else ah_stage_rows<DK, F16>(qbase + (int64_t)H * D, rs, D, L, Lp, slab, Ksm);
+  uint16_t* rtile = reinterpret_cast<uint16_t*>(smem + (size_t)2 * DK * slab) + (threadIdx.x >> 6) * 32 * AH_RD;   // ROPE: this wave's [32][18] tile
   __syncthreads();
 
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
@@ -382,9 +470,13 @@ attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
     const int64_t orow = ((int64_t)(a + q) * H + head) * D;
     s16x8 qhi[DK], qlo[DK], dof[DK];
     float dl = 0.f;
+    uint32_t qw[ROPE ? AH_RW : 1];
+    if constexpr (ROPE) ah_rope_row<F16>(reinterpret_cast<const uint32_t*>(qrow), qv, rope, (int64_t)a + q, 1.f, qw);
 #pragma unroll
     for (int j = 0; j < DK; ++j) {
-      const uint4 uq = ah_ld8(qrow, 16 * j + 8 * h2, D, qv);
+      uint4 uq;
+      if constexpr (ROPE) uq = ah_rope_chunk(qw, 16 * j + 8 * h2);
+      else uq = ah_ld8(qrow, 16 * j + 8 * h2, D, qv);
       const uint4 ud = ah_ld8(dout + orow, 16 * j + 8 * h2, D, qv);
       const uint4 uo = ah_ld8(out + orow, 16 * j + 8 * h2, D, qv);
       dl += ah_dot<F16>(ud, uo);
@@ -419,7 +511,19 @@ attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
         for (int m = 0; m < MP; ++m) acc[m] = AE<F16>::mfma(ld_tr_frag(Ksm + poff[m], ta, kt * 32 + 16 * mm), dsf, acc[m]);   // dQ^T[d][q]
       }
     }
-    if (qv) {
+    if constexpr (ROPE) {
+      // gradient of the ROTATED q, rounded as flash-attn returns it, into the wave's tile [query][channel]; then a lane per row turns it back
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = crow(r, h2);
+        if (ch < AH_RD) rtile[col * AH_RD + ch] = (uint16_t)(AE<F16>::pack2(acc[0][r] * scale, 0.f) & 0xffffu);
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the tile is written
+      __builtin_amdgcn_wave_barrier();
+      ah_unrope_store<F16>(rtile, lane, qt * 32, L, rope, a, 1.f, dqbase, rs);
+      __builtin_amdgcn_wave_barrier();
+    } else if (qv) {
       uint16_t* o = dqbase + (int64_t)q * rs;
 #pragma unroll
       for (int m = 0; m < MP; ++m)
@@ -431,11 +535,12 @@ attn_hd_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // LDS: Q slabs | dO slabs | aux [lp_max][4] bf16 (lse_hi, lse_lo, delta_hi, delta_lo)
-template <int DK, bool F16>
+template <int DK, bool F16, bool ROPE = false>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                        const float* __restrict__ delta, const int32_t* __restrict__ cu, int H, int D, float scale, int64_t total,
-                       int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv) {
+                       int lp_max, int n_units, int qs, uint16_t* __restrict__ dqkv, AhRope rope = AhRope{nullptr, nullptr}) {
+  static_assert(!ROPE || DK == 2, "the fused rotation is built for head_dim 18");
   constexpr int MP = (DK + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lunit = at_unit(n_units * qs);
@@ -461,8 +566,10 @@ attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
   unsigned char* dOsm = smem + (size_t)DK * slab;
   uint2* aux = reinterpret_cast<uint2*>(smem + (size_t)2 * DK * slab);
   const uint16_t* qbase = qkv + ((int64_t)a * 3 * H + head) * D;
-  ah_stage_rows<DK, F16>(qbase, rs, D, L, Lp, slab, Qsm);
+  if constexpr (ROPE) ah_stage_rows_rope<F16>(qbase, rs, a, rope, L, Lp, slab, Qsm);
+  else ah_stage_rows<DK, F16>(qbase, rs, D, L, Lp, slab, Qsm);
   ah_stage_rows<DK, F16>(dout + ((int64_t)a * H + head) * D, os, D, L, Lp, slab, dOsm);
+  uint16_t* rtile = reinterpret_cast<uint16_t*>(smem + (size_t)2 * DK * slab + (size_t)lp_max * 8) + (threadIdx.x >> 6) * 32 * AH_RD;   // ROPE: this wave's tile
   for (int q = threadIdx.x; q < Lp; q += AT_THREADS) {
     const float l2 = q < L ? lse[(int64_t)head * total + a + q] * AT_LOG2E : AE<F16>::pad_lse();
     const float dl = q < L ? delta[(int64_t)head * total + a + q] : 0.f;
@@ -491,9 +598,12 @@ attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
     const int key = kt * 32 + col;
     const uint16_t* krow = qbase + (int64_t)key * rs + (int64_t)H * D;
     s16x8 khi[DK], klo[DK], vf[DK];
+    uint32_t kw[ROPE ? AH_RW : 1];
+    if constexpr (ROPE) ah_rope_row<F16>(reinterpret_cast<const uint32_t*>(krow), key < L, rope, (int64_t)a + key, 1.f, kw);
 #pragma unroll
     for (int j = 0; j < DK; ++j) {
-      ah_split_scaled<F16>(ah_frag(ah_ld8(krow, 16 * j + 8 * h2, D, key < L)), c, khi[j], klo[j]);
+      if constexpr (ROPE) ah_split_scaled<F16>(ah_frag(ah_rope_chunk(kw, 16 * j + 8 * h2)), c, khi[j], klo[j]);
+      else ah_split_scaled<F16>(ah_frag(ah_ld8(krow, 16 * j + 8 * h2, D, key < L)), c, khi[j], klo[j]);
       vf[j] = ah_frag(ah_ld8(krow + (int64_t)H * D, 16 * j + 8 * h2, D, key < L));
     }
     f32x16 dv[MP], dk[MP];
@@ -539,11 +649,19 @@ attn_hd_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
           const int kk = kt * 32 + crow(r, h2);
           if (kk < L) {
             uint16_t* o = dbase + (int64_t)kk * rs;
-            o[(int64_t)H * D + ch] = (uint16_t)(AE<F16>::pack2(dk[m][r] * scale, 0.f) & 0xffffu);
+            if constexpr (!ROPE) o[(int64_t)H * D + ch] = (uint16_t)(AE<F16>::pack2(dk[m][r] * scale, 0.f) & 0xffffu);
             o[(int64_t)2 * H * D + ch] = (uint16_t)(AE<F16>::pack2(dv[m][r], 0.f) & 0xffffu);
           }
+          if constexpr (ROPE) rtile[crow(r, h2) * AH_RD + ch] = (uint16_t)(AE<F16>::pack2(dk[m][r] * scale, 0.f) & 0xffffu);   // [key][channel]
         }
       }
+    }
+    if constexpr (ROPE) {      // the gradient of the rotated k, turned back row by row
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+      ah_unrope_store<F16>(rtile, lane, kt * 32, L, rope, a, 1.f, dbase + (int64_t)H * D, rs);
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }

@@ -96,3 +96,12 @@ template <int N, int I = 0, typename F> __device__ __forceinline__ void ptc_stat
     ptc_static_for<N, I + 1>(f);
   }
 }
+
+// One rotary pair (u, v) <- (u cos - v sin, v cos + u sin) with its operation order FIXED (one multiply + one fused multiply-add per
+// output): rope.hip's pass and the rotation fused into the attention kernels (attention_hd.h) must round identically, and the compiler's
+// own contraction of `u * cs - v * sn` picks either product for the fma depending on the surrounding code.
+__host__ __device__ __forceinline__ void ptc_rope_pair(float u, float v, float cs, float sn, float& ru, float& rv) {
+  ru = fmaf(u, cs, -(v * sn));
+  rv = fmaf(v, cs, u * sn);
+}
+

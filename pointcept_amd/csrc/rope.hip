@@ -80,8 +80,10 @@ rope3d_xyz_kernel(const TI* src, TO* dst /* may alias src (in place) */, const f
     const int rot = R * H, all = S * H;
     for (int h = 0; h < rot; ++h, p += D, q += D) {
       const float u = ptc_to_float(p[0]), v = ptc_to_float(p[Q]);
-      q[0] = ptc_from_float<TO>(u * cs - v * sn);                          // x cos + rotate_half(x) sin, :91-92
-      q[Q] = ptc_from_float<TO>(v * cs + u * sn);
+      float ru, rv;
+      ptc_rope_pair(u, v, cs, sn, ru, rv);                                 // x cos + rotate_half(x) sin, :91-92
+      q[0] = ptc_from_float<TO>(ru);
+      q[Q] = ptc_from_float<TO>(rv);
     }
     if (!in_place) {
       for (int h = rot; h < all; ++h, p += D, q += D) {

@@ -682,6 +682,36 @@ def rope_xyz_qkvpacked(qkv: torch.Tensor, xyz: torch.Tensor, inv_freq: torch.Ten
     return _RopeXYZ.apply(qkv, xyz.float().contiguous(), inv_freq.float().contiguous(), out_dtype)
 
 
+class _AttnRope(Function):
+    @staticmethod
+    def forward(ctx, qkv, xyz, inv_freq, cu_seqlens, max_seqlen, softmax_scale):
+        out, lse = ops.attn_rope_fwd(qkv, xyz, inv_freq, cu_seqlens, max_seqlen, softmax_scale)
+        ctx.save_for_backward(qkv, out, lse, xyz, inv_freq, cu_seqlens)
+        ctx.args = (max_seqlen, softmax_scale)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        qkv, out, lse, xyz, inv_freq, cu = ctx.saved_tensors
+        return ops.attn_rope_bwd(qkv, out, dout.contiguous(), lse, xyz, inv_freq, cu, *ctx.args), None, None, None, None, None
+
+
+def attn_rope_qkvpacked(qkv: torch.Tensor, xyz: torch.Tensor, inv_freq: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
+                        softmax_scale: Optional[float] = None, operand_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """Point3DRoPE / PointROPE on q and k, then flash_attn_varlen_qkvpacked_func (point_transformer_v3m3_utonia.py:303-323,353-359;
+    litept_v1.py:239-265): qkv [n, 3, H, D] UN-rotated -> [n, H, D] in `operand_dtype`.  head_dim 18 with qkv already in the operand
+    dtype: ONE operator -- the rotation happens in the attention kernels' prologue and its inverse in their backward epilogue
+    (csrc/attention_hd.h ROPE; no rotated copy of q / k in memory).  Anything else (other head dims, an fp16 qkv that the call site
+    casts to bf16 AFTER the rotation): the rotation pass ptc_rope3d_xyz followed by the attention kernels -- the same arithmetic."""
+    if softmax_scale is None:
+        softmax_scale = qkv.shape[-1] ** -0.5
+    if (qkv.dtype == operand_dtype and operand_dtype in (torch.bfloat16, torch.float16) and qkv.dim() == 4
+            and ops.attn_rope_supported(int(qkv.shape[3]), int(max_seqlen))):
+        return _AttnRope.apply(qkv, xyz.float().contiguous(), inv_freq.float().contiguous(), cu_seqlens, int(max_seqlen), float(softmax_scale))
+    return attn_varlen_qkvpacked(rope_xyz_qkvpacked(qkv, xyz, inv_freq, operand_dtype), cu_seqlens, max_seqlen, softmax_scale)
+
+
 # ------------------------------------------------------------------------------------------------
 # cross entropy
 # ------------------------------------------------------------------------------------------------

@@ -809,6 +809,46 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_sc
     return dqkv
 
 
+def attn_rope_supported(head_dim: int, max_seqlen: int) -> bool:
+    """window attention with the 3-D rotary embedding fused into its prologue / epilogue (csrc/attention_hd.h, ROPE): head_dim 18"""
+    return bool(lib().ptc_attn_varlen_hd_rope_supported(int(head_dim), int(max_seqlen)))
+
+
+def attn_rope_fwd(qkv, xyz, inv_freq, cu_seqlens, max_seqlen: int, softmax_scale: float):
+    """qkv [T,3,H,18] bf16 | f16, UN-rotated; xyz [T,3] fp32 positions of the (padded, serialized) rows; inv_freq [3] fp32
+    -> (out [T,H,18], lse [H,T] fp32) of the attention over the rotated q / k."""
+    require_cuda(qkv, xyz, inv_freq, cu_seqlens)
+    if qkv.dtype not in (torch.bfloat16, torch.float16) or qkv.dim() != 4 or qkv.shape[1] != 3:
+        raise PtcoreError(f"qkv must be bf16 or f16 [T,3,H,18], got {qkv.dtype} {tuple(qkv.shape)}")
+    qkv, xyz, inv_freq = qkv.contiguous(), xyz.float().contiguous(), inv_freq.float().contiguous()
+    T, _, H, D = qkv.shape
+    if xyz.shape != (T, 3) or inv_freq.numel() * 6 != D:
+        raise PtcoreError("attn_rope_fwd: xyz must be [T, 3] and inv_freq [head_dim / 6]")
+    cu = cu_seqlens.to(torch.int32).contiguous()
+    out = torch.empty((T, H, D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((H, T), dtype=torch.float32, device=qkv.device)
+    check(lib().ptc_attn_varlen_hd_rope_fwd(ptr(qkv), ptr(cu), ptr(xyz), ptr(inv_freq), cu.numel() - 1, T, H, D, int(max_seqlen),
+                                            float(softmax_scale), dtype_code(qkv), ptr(out), ptr(lse), stream_ptr()), "ptc_attn_varlen_hd_rope_fwd")
+    return out, lse
+
+
+def attn_rope_bwd(qkv, out, dout, lse, xyz, inv_freq, cu_seqlens, max_seqlen: int, softmax_scale: float) -> torch.Tensor:
+    """-> dqkv: gradient of the UN-rotated rows (the inverse rotation of dq / dk happens in the kernels' epilogue)"""
+    require_cuda(qkv, out, dout, lse, xyz, inv_freq, cu_seqlens)
+    qkv, out = qkv.contiguous(), out.contiguous()
+    dout = dout.to(qkv.dtype).contiguous()
+    xyz, inv_freq = xyz.float().contiguous(), inv_freq.float().contiguous()
+    cu = cu_seqlens.to(torch.int32).contiguous()
+    T, _, H, D = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    nbytes = lib().ptc_attn_varlen_bwd_workspace_bytes(T, H)
+    ws = _ws(nbytes, qkv.device)
+    check(lib().ptc_attn_varlen_hd_rope_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), ptr(xyz), ptr(inv_freq), cu.numel() - 1, T, H, D,
+                                            int(max_seqlen), float(softmax_scale), dtype_code(qkv), ptr(dqkv), ptr(ws), nbytes, stream_ptr()),
+          "ptc_attn_varlen_hd_rope_bwd")
+    return dqkv
+
+
 def attn_rpe_supported(head_dim: int, max_seqlen: int, pos_bnd: int) -> bool:
     """RPE attention kernels (attention_rpe.h): head_dim 16, windows whose images + coordinates + table fit LDS."""
     lp = (int(max_seqlen) + 31) & ~31

@@ -123,14 +123,13 @@ class RopeAttention(_AttnM1):
         xyz, inv_freq = self._rope_inputs(point, order)
         if tabs is not None:
             qkv_s = self.qkv(point.feat, tabs[0], tabs[1])                                     # padded, serialized rows (:272)
-            qkv_r = PF.rope_xyz_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, inv_freq, self._operand_dtype(qkv_s.dtype))   # :303-305,319-321
-            out = PF.attn_varlen_qkvpacked(qkv_r, cu_seqlens, K, self.scale)
+            # rotation (:303-305,319-321) + window attention as one operator where the kernels fuse them (head_dim 18)
+            out = PF.attn_rope_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, inv_freq, cu_seqlens, K, self.scale, self._operand_dtype(qkv_s.dtype))
             feat = self.proj(out.reshape(-1, C).to(qkv_s.dtype), tabs[2], tabs[3])
         else:
             qkv = self.qkv(point.feat)
             qkv_s = PF.gather_rows(qkv, gidx, inv, dup_of_point)
-            qkv_r = PF.rope_xyz_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, inv_freq, self._operand_dtype(qkv_s.dtype))
-            out = PF.attn_varlen_qkvpacked(qkv_r, cu_seqlens, K, self.scale)
+            out = PF.attn_rope_qkvpacked(qkv_s.reshape(-1, 3, H, C // H), xyz, inv_freq, cu_seqlens, K, self.scale, self._operand_dtype(qkv_s.dtype))
             feat = self.proj(PF.gather_rows(out.reshape(-1, C), inv, gidx_primary).to(qkv.dtype))
         point.feat = self.proj_drop(feat)
         return point

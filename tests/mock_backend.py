@@ -381,6 +381,7 @@ _STANDINS = dict(
     attn_varlen_fwd=attn_varlen_fwd, attn_varlen_bwd=attn_varlen_bwd, cross_entropy_fwd=cross_entropy_fwd, rope3d_xyz=rope3d_xyz, rope3d_=rope3d_, knn_query=knn_query, ball_query=ball_query,
     farthest_point_sampling=farthest_point_sampling, pair_dot_fwd=pair_dot_fwd, pair_dot_bwd=pair_dot_bwd,
     pair_aggregate_fwd=pair_aggregate_fwd, pair_aggregate_bwd=pair_aggregate_bwd,
+    attn_rope_supported=lambda d, k: False,      # CPU tier: the rotation pass + the attention stand-in (the same arithmetic)
     attn_hd_supported=lambda d, k: 16 <= d <= 64 and k <= (1024 if d <= 32 else 672 if d <= 48 else 512),
     edge_rows=edge_rows, edge_reduce=edge_reduce, EdgeCSR=EdgeCSR, edge_scatter_bwd=edge_scatter_bwd, aggregation_edge_bwd=aggregation_edge_bwd,
     cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum, voxel_keys=voxel_keys,

@@ -979,6 +979,63 @@ def test_attention_other_head_dims_fwd_bwd(cuda, D, lens, H, dtype):
     assert fro(out, ref) < bar[0] and fro(dqkv, q32.grad) < bar[1], (fro(out, ref), fro(dqkv, q32.grad), bar)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("lens,H", [([1024, 700, 33], 3), ([1, 2, 31, 32, 33, 65], 6)])
+def test_attention_with_fused_rope_equals_the_two_pass_form(cuda, lens, H, dtype):
+    """The 3-D rotary embedding in the attention prologue / epilogue (ptc_attn_varlen_hd_rope_*, head_dim 18) against the two-pass form it
+    replaces -- ptc_rope3d_xyz on the packed rows, then the window-attention kernels, then the inverse rotation of the gradient: the same
+    fp32 rotation rounded to the same operand dtype, so output, lse and the gradient of the UN-rotated qkv are bit-identical; and against the
+    fp32 oracle through the reference's own formulation (rope_xyz_torch = utonia.py:58-101,303-323)."""
+    from pointcept_amd import functional as PF
+    from pointcept_amd import ops
+
+    D = 18
+    assert ops.attn_rope_supported(D, max(lens)) and not ops.attn_rope_supported(24, max(lens))
+    g = torch.Generator().manual_seed(sum(lens) + H)
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).to(cuda)
+    qkv = (torch.randn(T, 3, H, D, generator=g) * 1.5).to(dtype).to(cuda)
+    xyz = (torch.rand(T, 3, generator=g) * 40.0 - 20.0).to(cuda)
+    inv_freq = (1.0 / (100.0 ** (torch.arange(3, dtype=torch.float32) / 3))).to(cuda)
+    dout = torch.randn(T, H, D, generator=g).to(dtype).to(cuda)
+    scale = D ** -0.5
+    out, lse = ops.attn_rope_fwd(qkv, xyz, inv_freq, cu, max(lens), scale)
+    dqkv = ops.attn_rope_bwd(qkv, out, dout, lse, xyz, inv_freq, cu, max(lens), scale)
+    rot = ops.rope3d_xyz(qkv, xyz, inv_freq, 2, 1.0, dtype)
+    out2, lse2 = ops.attn_varlen_fwd(rot, cu, max(lens), scale)
+    d_rot = ops.attn_varlen_bwd(rot, out2, dout, lse2, cu, max(lens), scale)
+    dqkv2 = ops.rope3d_xyz(d_rot, xyz, inv_freq, 2, -1.0, dtype)
+    # the two forms run the same fp32 rotation and round to the same dtype; the compiler may still contract the inlined sincos /
+    # products of the two translation units differently (measured on the MI355X: 1 of 17 712 f16 gradient elements one ulp apart, bf16
+    # and every forward tensor identical; the host emulation: everything identical): at most 0.1 % of the elements, at most one ulp
+    def same(name, x, y):
+        d = (x.float() - y.float()).abs()
+        ulp = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * torch.maximum(x.float().abs(), y.float().abs()).clamp_min(1e-3)
+        assert int((d > 0).sum()) <= max(1, x.numel() // 1000) and bool((d <= ulp).all()), (name, int((d > 0).sum()), float(d.max()))
+
+    same("out", out, out2)
+    assert float((lse - lse2).abs().max()) <= 1e-5
+    same("dqkv", dqkv, dqkv2)
+    # autograd wrapper: the fused operator is what PF.attn_rope_qkvpacked picks for this shape
+    q1 = qkv.clone().requires_grad_(True)
+    o1 = PF.attn_rope_qkvpacked(q1, xyz, inv_freq, cu, max(lens), scale, dtype)
+    o1.backward(dout)
+    assert torch.equal(o1.detach(), out) and torch.equal(q1.grad, dqkv)
+    # against the reference's formulation in fp32
+    q32 = qkv.float().cpu().requires_grad_(True)
+    n = T
+    emb = xyz.cpu()[:, :, None] * inv_freq.cpu()[None, None, :]
+    cos, sin = emb.cos()[:, None, None, :, None, :], emb.sin()[:, None, None, :, None, :]
+    t = q32[:, :2].reshape(n, 2, H, 3, 2, 3)
+    u, v = t[..., 0:1, :], t[..., 1:2, :]
+    rot32 = torch.cat((torch.cat((u * cos - v * sin, v * cos + u * sin), dim=-2).reshape(n, 2, H, D), q32[:, 2:]), dim=1)
+    ref = oops.attention_varlen(rot32, cu.cpu(), scale)
+    ref.backward(dout.float().cpu())
+    fro = lambda a, b: float((a.float().cpu() - b.detach()).norm() / b.detach().norm())
+    bar = (2.0 ** -7, 2.0 ** -6) if dtype == torch.bfloat16 else (2.0 ** -10, 2.0 ** -9)      # operand rounding of the rotated q / k on top of the kernels'
+    assert fro(out, ref) < bar[0] and fro(dqkv, q32.grad) < bar[1], (fro(out, ref), fro(dqkv, q32.grad))
+
+
 def test_attention_other_head_dims_large_logits_and_limits(cuda):
     """Peaked rows take the online-softmax loop; windows that do not fit LDS are refused (by the flash_attn mirror too:
     there is no library path behind it); a sequence longer than max_seqlen poisons its rows instead of overrunning LDS."""

@@ -207,6 +207,8 @@ EMULATED_GPU_TESTS = [
     ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.bfloat16)),
     ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.float16)),
     ("test_attention_other_head_dims_fwd_bwd", dict(D=40, lens=[200, 100], H=2, dtype=torch.float16)),
+    ("test_attention_with_fused_rope_equals_the_two_pass_form", dict(lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.bfloat16)),
+    ("test_attention_with_fused_rope_equals_the_two_pass_form", dict(lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.float16)),
     ("test_attention_rpe_fwd_bwd", dict(lens=[200, 200, 200], H=3, bnd=18)),
 ]   # (in-place GPU tests -- rope3d, cross entropy -- are not in the list: with device = cpu their `.to(device)` aliases the input the
 #    oracle is then fed with; tests that construct `pointcept_amd.nn` modules or open a CUDA autocast region cannot run on CPU tensors)

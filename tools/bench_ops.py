@@ -281,9 +281,19 @@ def bench_attention_hd(rows, n_seq, H, D, results, L=1024):
     r["bwd"] = roof(T * H * D * 16, 10.0 * fl, timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
     blk = qkv.reshape(n_seq, L, 3, H, D).permute(2, 0, 3, 1, 4).contiguous()
     r["sdpa_fwd"] = roof(T * H * D * 8, 4.0 * fl, timeit(lambda: F.scaled_dot_product_attention(blk[0], blk[1], blk[2], scale=sc), iters=10))
+    rope = ""
+    if ops.attn_rope_supported(D, L):   # the rotation of q / k as its own pass (+ its inverse on the gradient) against the fused prologue / epilogue
+        xyz = torch.rand(T, 3, device=DEV) * 40.0
+        inv_freq = (1.0 / (100.0 ** (torch.arange(D // 6, dtype=torch.float32, device=DEV) / (D // 6))))
+        t_pass = timeit(lambda: ops.rope3d_xyz(qkv, xyz, inv_freq, 2, 1.0, torch.bfloat16), iters=10)
+        t_ff = timeit(lambda: ops.attn_rope_fwd(qkv, xyz, inv_freq, cu, L, sc), iters=10)
+        t_fb = timeit(lambda: ops.attn_rope_bwd(qkv, out, do, lse, xyz, inv_freq, cu, L, sc), iters=10)
+        r["rope_pass_us"], r["rope_fused_fwd_us"], r["rope_fused_bwd_us"] = round(t_pass * 1e6, 1), round(t_ff * 1e6, 1), round(t_fb * 1e6, 1)
+        rope = (f" | rotation pass {t_pass * 1e6:6.1f} us per direction; with the rotation fused: fwd {t_ff * 1e6:8.1f} us "
+                f"(two-pass {r['fwd']['us'] + t_pass * 1e6:8.1f}), bwd {t_fb * 1e6:8.1f} us (two-pass {r['bwd']['us'] + t_pass * 1e6:8.1f})")
     results.append(r)
     rows.append(f"attention_hd n_seq={n_seq:4d} L={L} H={H:2d} D={D:2d} | fwd {r['fwd']['us']:8.1f} us {r['fwd']['TFLOPs']:7.1f} TF/s | "
-                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s | library SDPA fwd on pre-gathered [n,H,L,D] {r['sdpa_fwd']['us']:8.1f} us")
+                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s | library SDPA fwd on pre-gathered [n,H,L,D] {r['sdpa_fwd']['us']:8.1f} us{rope}")
 
 
 def bench_attention_rpe(rows, n_seq, H, L, results):

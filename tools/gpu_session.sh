@@ -18,7 +18,7 @@ for sec in "$@"; do
   case $sec in
     tests) timeout 1500 python -m pytest tests -q -m gpu > $O/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> $O/${TAG}_env.log; tail -4 $O/${TAG}_tests.log;;
     ops) timeout 900 python tools/bench_ops.py > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log;;
-    ops:*) timeout 900 python tools/bench_ops.py --only ${sec#ops:} > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log; cat $O/${TAG}_ops.log | cut -c1-220;;
+    ops:*) timeout 900 python tools/bench_ops.py --only ${sec#ops:} > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log; cat $O/${TAG}_ops.log | cut -c1-420;;
     test:*) timeout 1500 python -m pytest tests -q -m gpu -k "${sec#test:}" > $O/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> $O/${TAG}_env.log; tail -15 $O/${TAG}_tests.log;;
     probe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_gfx950 tools/probe_gfx950.hip > $O/${TAG}_probe.log 2>&1 && timeout 300 /tmp/probe_gfx950 >> $O/${TAG}_probe.log 2>&1; tail -20 $O/${TAG}_probe.log | cut -c1-200;;
     pgather) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_gather tools/probe_gather.hip > $O/${TAG}_probe_gather.log 2>&1 && timeout 300 /tmp/probe_gather >> $O/${TAG}_probe_gather.log 2>&1; cat $O/${TAG}_probe_gather.log | cut -c1-250;;
