@@ -271,7 +271,7 @@ def test_ptv3_base_train_step_gradients_vs_oracle(cuda):
         # gradients by 3-5 % per stage; the engine must sit inside that envelope at every stage.  (The two cannot agree
         # rounding for rounding: a different fp32 summation order flips individual bf16 roundings.)
         for k in eng_ps:
-            assert eng_ps[k] <= 2.0 * emu_ps[k] + 5e-3, (k, eng_ps[k], emu_ps[k])
+            assert eng_ps[k] <= 1.3 * emu_ps[k] + 5e-3, (k, eng_ps[k], emu_ps[k])       # measured ratios 0.8 - 1.15 (round 3); 2.0 until round 4
 
 
 def test_spunet_base_one_full_scene_forward(cuda):
