@@ -57,6 +57,10 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define AT_MIN_WAVES 4          // waves per SIMD the register budget must allow (two 8-wave workgroups per CU)
 #define AT_LOG2E 1.4426950408889634f
 #define AT_LN2 0.6931471805599453f
+#ifndef AT_SPLIT_BELOW
+#define AT_SPLIT_BELOW 2048      // launches with fewer (sequence, head) parts than this are split further (at_split); 1024 until round 4: the
+                                 // enc0 launch (1600 units = 3.1 rounds of 512 slots) gains 3-4 % as 3200 half units, profiles/r04_w_attn_split.txt
+#endif
 #define AT_FIXED_REF_MAX 64.0f   // largest Cauchy-Schwarz bound (exp2 domain) served by the fixed-reference loop
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
@@ -253,7 +257,7 @@ __device__ __forceinline__ int at_unit(int n_units) {
 // unit are consecutive workgroups (same XCD); each stages the whole other side again (64 KB, L2-hot).
 __host__ __device__ __forceinline__ int at_split(int n_units, int lp_max) {
   int qs = 1;
-  while (qs < 4 && (long long)n_units * qs < 1024 && (lp_max >> 5) / (2 * qs) >= AT_WAVES) qs *= 2;
+  while (qs < 4 && (long long)n_units * qs < AT_SPLIT_BELOW && (lp_max >> 5) / (2 * qs) >= AT_WAVES) qs *= 2;
   return qs;
 }
 
