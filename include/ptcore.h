@@ -278,6 +278,18 @@ int ptc_spconv_wgrad_blk(const void* in, int64_t n_in, const void* dout, const i
 int ptc_linear_supported_ex(int c_in, int c_out, int dtype);
 int ptc_linear_fwd_ex(const void* in, int64_t n, const void* weight, const float* bias, int c_in, int c_out, int dtype,
                       int epilogue, const void* aux_in, void* out, void* aux_out, ptc_stream_t stream);
+/* A Linear with the residual joint of Block.forward (ptv3m1:318-338) in its EPILOGUE (round 4): the two joints whose branch operand is a
+ * bare Linear output -- `proj` of SerializedAttention (ptv3m1:219) and `fc2` of the MLP (:246) --
+ *     z = a + row_scale * (in W^T + b),   y = LN_B(z) (normB = 1; statB [2][n_out] = mean / rstd) or the cast of z (normB = 0),
+ * in place of ptc_spconv_fwd(nbr = NULL | kv = 1 table) followed by ptc_add_norm_fwd: the 16-bit GEMM output never reaches memory.  The
+ * arithmetic of the joint is ptc_add_norm_fwd's (same lane mapping and statement order): bit-identical results.  16-bit features,
+ * c_out in {32, 64, 128}, c_in in {32, 64, 128, 256}; a / z fp32 [n_out, c_out]; y (may be NULL) in the feature dtype; nbr as in
+ * ptc_spconv_fwd for kv = 1 (the inverse serialization table of `proj`) or NULL. */
+int ptc_linear_joint_supported(int c_in, int c_out, int dtype);
+int ptc_linear_joint_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr, int64_t n_out, int c_in,
+                         int c_out, int dtype, const float* a, const float* row_scale, const float* gB, const float* bB, float epsB,
+                         int normB, float* z, void* y, float* statB, ptc_stream_t stream);
+
 size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out);
 int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32_t* nbr,
                      int64_t n_out, int kv, int c_in, int c_out, int dtype, float* dw, float* dbias,

@@ -12,6 +12,9 @@
 //
 // No device code of its own; compiled with the kernels so that the host emulation (tests/host_emulation) builds it too.
 #include "ptc_common.h"
+#ifndef PTC_BLK_JOINT_EPILOGUE
+#define PTC_BLK_JOINT_EPILOGUE 1     // 0: timing A/B only (`python -m pointcept_amd.build --variant d_PTC_BLK_JOINT_EPILOGUE_0`)
+#endif
 #include "spconv_internal.h"
 
 #define RUN(call)               \
@@ -82,19 +85,34 @@ extern "C" int ptc_ptv3_block_fwd(const int64_t* iv, const float* fv, const void
   RUN(ptc_attn_varlen_fwd(out[PTC_BLK_O_QKV], (const int32_t*)P(in, PTC_BLK_P_CU), n_seq, np, H, patch, fv[PTC_BLK_F_SCALE], dt, out[PTC_BLK_O_ATT],
                           M<float>(out, PTC_BLK_O_LSE), s));
   // 6. proj(att[inverse]) (ptv3m1:216-219)
-  RUN(ptc_spconv_fwd(out[PTC_BLK_O_ATT], np, P(in, PTC_BLK_P_W_PROJ), (const float*)P(in, PTC_BLK_P_B_PROJ), (const int32_t*)P(in, PTC_BLK_P_T_PROJ_FWD), n, 1,
-                     c, c, dt, out[PTC_BLK_O_A], s));
-  // 7. x2 = x1 + droppath(a);  y2 = norm2(x2)
-  RUN(ptc_add_norm_fwd(out[PTC_BLK_O_A], dt, out[PTC_BLK_O_X1], PTC_F32, (const float*)P(in, PTC_BLK_P_RS1), n, c, nullptr, nullptr, 0.f, 0,
-                       (const float*)P(in, PTC_BLK_P_G_N2), (const float*)P(in, PTC_BLK_P_BE_N2), fv[PTC_BLK_F_EPS_N2], 1, M<float>(out, PTC_BLK_O_X2),
-                       out[PTC_BLK_O_Y2], dt, nullptr, M<float>(out, PTC_BLK_O_ST_N2), s));
+  // 6 + 7 in ONE launch where the shape allows (round 4, fwd2_joint.h): the joint x2 = x1 + droppath(a), y2 = norm2(x2) runs in proj's
+  // epilogue, `a` never reaches memory (the backward of this joint does not read it: its branch operand is not normalised)
+  if (PTC_BLK_JOINT_EPILOGUE && ptc_linear_joint_supported(c, c, dt)) {
+    RUN(ptc_linear_joint_fwd(out[PTC_BLK_O_ATT], np, P(in, PTC_BLK_P_W_PROJ), (const float*)P(in, PTC_BLK_P_B_PROJ), (const int32_t*)P(in, PTC_BLK_P_T_PROJ_FWD),
+                             n, c, c, dt, M<float>(out, PTC_BLK_O_X1), (const float*)P(in, PTC_BLK_P_RS1), (const float*)P(in, PTC_BLK_P_G_N2),
+                             (const float*)P(in, PTC_BLK_P_BE_N2), fv[PTC_BLK_F_EPS_N2], 1, M<float>(out, PTC_BLK_O_X2), out[PTC_BLK_O_Y2],
+                             M<float>(out, PTC_BLK_O_ST_N2), s));
+  } else {
+    RUN(ptc_spconv_fwd(out[PTC_BLK_O_ATT], np, P(in, PTC_BLK_P_W_PROJ), (const float*)P(in, PTC_BLK_P_B_PROJ), (const int32_t*)P(in, PTC_BLK_P_T_PROJ_FWD), n, 1,
+                       c, c, dt, out[PTC_BLK_O_A], s));
+    // 7. x2 = x1 + droppath(a);  y2 = norm2(x2)
+    RUN(ptc_add_norm_fwd(out[PTC_BLK_O_A], dt, out[PTC_BLK_O_X1], PTC_F32, (const float*)P(in, PTC_BLK_P_RS1), n, c, nullptr, nullptr, 0.f, 0,
+                         (const float*)P(in, PTC_BLK_P_G_N2), (const float*)P(in, PTC_BLK_P_BE_N2), fv[PTC_BLK_F_EPS_N2], 1, M<float>(out, PTC_BLK_O_X2),
+                         out[PTC_BLK_O_Y2], dt, nullptr, M<float>(out, PTC_BLK_O_ST_N2), s));
+  }
   // 8. MLP: (h, act) = fc1 + GELU in one kernel, then fc2 (ptv3m1:225-248)
   RUN(ptc_linear_fwd_ex(out[PTC_BLK_O_Y2], n, P(in, PTC_BLK_P_W_FC1), (const float*)P(in, PTC_BLK_P_B_FC1), c, hid, dt, 1, nullptr, out[PTC_BLK_O_H],
                         out[PTC_BLK_O_ACT], s));
-  RUN(ptc_spconv_fwd(out[PTC_BLK_O_ACT], n, P(in, PTC_BLK_P_W_FC2), (const float*)P(in, PTC_BLK_P_B_FC2), nullptr, n, 1, hid, c, dt, out[PTC_BLK_O_M], s));
-  // 9. x3 = x2 + droppath(m);  xb3 = cast(x3): the operand of the next convolution / Linear
-  RUN(ptc_add_norm_fwd(out[PTC_BLK_O_M], dt, out[PTC_BLK_O_X2], PTC_F32, (const float*)P(in, PTC_BLK_P_RS2), n, c, nullptr, nullptr, 0.f, 0, nullptr,
-                       nullptr, 0.f, 0, M<float>(out, PTC_BLK_O_X3), out[PTC_BLK_O_XB3], dt, nullptr, nullptr, s));
+  if (PTC_BLK_JOINT_EPILOGUE && ptc_linear_joint_supported(hid, c, dt)) {       // fc2 with joint 9 in its epilogue (4 c <= 256)
+    RUN(ptc_linear_joint_fwd(out[PTC_BLK_O_ACT], n, P(in, PTC_BLK_P_W_FC2), (const float*)P(in, PTC_BLK_P_B_FC2), nullptr, n, hid, c, dt,
+                             M<float>(out, PTC_BLK_O_X2), (const float*)P(in, PTC_BLK_P_RS2), nullptr, nullptr, 0.f, 0, M<float>(out, PTC_BLK_O_X3),
+                             out[PTC_BLK_O_XB3], nullptr, s));
+  } else {
+    RUN(ptc_spconv_fwd(out[PTC_BLK_O_ACT], n, P(in, PTC_BLK_P_W_FC2), (const float*)P(in, PTC_BLK_P_B_FC2), nullptr, n, 1, hid, c, dt, out[PTC_BLK_O_M], s));
+    // 9. x3 = x2 + droppath(m);  xb3 = cast(x3): the operand of the next convolution / Linear
+    RUN(ptc_add_norm_fwd(out[PTC_BLK_O_M], dt, out[PTC_BLK_O_X2], PTC_F32, (const float*)P(in, PTC_BLK_P_RS2), n, c, nullptr, nullptr, 0.f, 0, nullptr,
+                         nullptr, 0.f, 0, M<float>(out, PTC_BLK_O_X3), out[PTC_BLK_O_XB3], dt, nullptr, nullptr, s));
+  }
   return PTC_OK;
 }
 

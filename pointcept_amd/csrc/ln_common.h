@@ -1,0 +1,45 @@
+// ln_common.h -- the row helpers of the LayerNorm / residual-joint kernels (norm.hip), shared with the GEMM epilogue that runs a joint
+// inside linear2_kernel (fwd2.h, EPI 3): a lane holds LN_VEC = 8 consecutive channels of a row, LPR = C / 8 consecutive lanes hold the row.
+#pragma once
+
+#define LN_THREADS 256
+#define LN_VEC 8  // channels per lane
+
+template <typename T>
+__device__ __forceinline__ void ln_load8(const T* p, float (&v)[LN_VEC]);
+template <>
+__device__ __forceinline__ void ln_load8<float>(const float* p, float (&v)[LN_VEC]) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void ln_load8<bf16_t>(const bf16_t* p, float (&v)[LN_VEC]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+template <>
+__device__ __forceinline__ void ln_load8<f16_t>(const f16_t* p, float (&v)[LN_VEC]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const _Float16* h = reinterpret_cast<const _Float16*>(&u);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+}
+template <typename T>
+__device__ __forceinline__ void ln_store8(T* p, const float (&v)[LN_VEC]) {
+  T o[LN_VEC];
+#pragma unroll
+  for (int i = 0; i < LN_VEC; ++i) o[i] = ptc_from_float<T>(v[i]);
+  if (sizeof(T) == 4) { reinterpret_cast<uint4*>(p)[0] = reinterpret_cast<uint4*>(o)[0]; reinterpret_cast<uint4*>(p)[1] = reinterpret_cast<uint4*>(o)[1]; }
+  else reinterpret_cast<uint4*>(p)[0] = reinterpret_cast<uint4*>(o)[0];
+}
+
+// sum over the LPR lanes of a row group (LPR power of two, groups aligned)
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int d = 1; d < LPR; d <<= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+

@@ -214,6 +214,7 @@ static int dispatch_fwd(const void* in, const void* w, const float* bias, const 
 }
 
 #include "fwd2.h"
+#include "fwd2_joint.h"
 #include "conv3.h"
 #include "conv5.h"
 #include "conv7.h"
@@ -285,6 +286,30 @@ extern "C" int ptc_linear_fwd_ex(const void* in, int64_t n, const void* weight, 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == PTC_BF16) return dispatch_fwd2<bf16_t>(in, n, weight, bias, nullptr, n, 1, c_in, c_out, out, s, epilogue, aux_in, aux_out);
   return dispatch_fwd2<f16_t>(in, n, weight, bias, nullptr, n, 1, c_in, c_out, out, s, epilogue, aux_in, aux_out);
+}
+
+// A Linear with the residual joint behind it in its epilogue (fwd2_joint.h): z = a + row_scale * (in W^T + b), y = LN_B(z) | cast(z).
+extern "C" int ptc_linear_joint_supported(int c_in, int c_out, int dtype) { return linear_joint_supported(dtype, c_in, c_out) ? 1 : 0; }
+extern "C" int ptc_linear_joint_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr, int64_t n_out,
+                                    int c_in, int c_out, int dtype, const float* a, const float* row_scale, const float* gB, const float* bB,
+                                    float epsB, int normB, float* z, void* y, float* statB, ptc_stream_t stream) {
+  PTC_REQUIRE(n_out >= 0 && n_in >= 0 && linear_joint_supported(dtype, c_in, c_out), PTC_EUNSUPPORTED,
+              "ptc_linear_joint_fwd: c_in=%d c_out=%d dtype=%d", c_in, c_out, dtype);
+  PTC_REQUIRE((uint64_t)n_in * (uint64_t)c_in * 2 <= PTC_BUF_MAX_BYTES, PTC_EUNSUPPORTED, "ptc_linear_joint_fwd: input of 2 GiB or more");
+  if (n_out == 0) return PTC_OK;
+  PTC_REQUIRE(in && weight && a && z, PTC_EINVAL, "ptc_linear_joint_fwd: null buffer");
+  PTC_REQUIRE(!(normB && y) || statB, PTC_EINVAL, "ptc_linear_joint_fwd: missing statistics buffer");
+  PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)a % 16 == 0) && ((uintptr_t)z % 16 == 0) &&
+              ((uintptr_t)y % 16 == 0), PTC_EINVAL, "ptc_linear_joint_fwd: buffers must be 16-byte aligned");
+  const F2Joint J{a, row_scale, gB, bB, epsB, normB, z, y, statB};
+  hipStream_t s = (hipStream_t)stream;
+#define LJ_DISPATCH(T)                                                                             \
+  if (c_out == 32) return launch_linear_joint<T, 2>(in, n_in, weight, bias, nbr, n_out, c_in, J, s);  \
+  if (c_out == 64) return launch_linear_joint<T, 4>(in, n_in, weight, bias, nbr, n_out, c_in, J, s);  \
+  return launch_linear_joint<T, 8>(in, n_in, weight, bias, nbr, n_out, c_in, J, s);
+  if (dtype == PTC_BF16) { LJ_DISPATCH(bf16_t) }
+  LJ_DISPATCH(f16_t)
+#undef LJ_DISPATCH
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -725,6 +725,34 @@ def add_norm_fwd(u, a, row_scale, norm_a, norm_b, y_dtype):
     return z, y, st_a, st_b
 
 
+def linear_joint_supported(c_in: int, c_out: int, dtype: torch.dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16) and bool(lib().ptc_linear_joint_supported(int(c_in), int(c_out), _DT[dtype]))
+
+
+def linear_joint_fwd(x, weight, bias, table, a, row_scale, norm_b, y_dtype, n_out=None):
+    """z = a + row_scale * (x[table] @ weight^T + bias) (fp32), y = LN_B(z) | cast(z) -- a Linear of the Block with the residual joint behind
+    it in its epilogue (csrc/fwd2_joint.h; bit-identical to spconv_fwd + add_norm_fwd).  weight [c_out, c_in] in x's 16-bit dtype, table
+    None or the kv = 1 gather table [1, n_out] / [n_out] int32 (the inverse serialization table of `proj`), a [n_out, c_out] fp32.
+    Returns (z, y, statB)."""
+    require_cuda(x, weight, bias, table, a, row_scale)
+    x, weight, a = x.contiguous(), weight.contiguous(), a.contiguous()
+    c_out, c_in = weight.shape[0], weight.shape[-1]
+    if a.dtype != torch.float32 or x.dtype != weight.dtype or not linear_joint_supported(c_in, c_out, x.dtype):
+        raise PtcoreError("linear_joint_fwd: unsupported shape / dtype")
+    n = int(a.shape[0]) if n_out is None else int(n_out)
+    tab = None if table is None else table.reshape(-1).to(torch.int32).contiguous()
+    dev = x.device
+    z = torch.empty((n, c_out), dtype=torch.float32, device=dev)
+    y = torch.empty((n, c_out), dtype=y_dtype, device=dev) if y_dtype is not None else None
+    st_b = torch.empty((2, n), dtype=torch.float32, device=dev) if (norm_b is not None and y is not None) else None
+    gb, bb, eb = norm_b if norm_b is not None else (None, None, 0.0)
+    rs = None if row_scale is None else row_scale.to(torch.float32).contiguous()
+    b = None if bias is None else bias.float().contiguous()
+    check(lib().ptc_linear_joint_fwd(ptr(x), x.shape[0], ptr(weight), ptr(b), ptr(tab), n, c_in, c_out, dtype_code(x), ptr(a), ptr(rs), ptr(gb), ptr(bb),
+                                     float(eb), int(norm_b is not None), ptr(z), ptr(y), ptr(st_b), stream_ptr()), "ptc_linear_joint_fwd")
+    return z, y, st_b
+
+
 def add_norm_bwd(dz_in, dy, z, u, row_scale, g_a, st_a, g_b, st_b, want_affine_a: bool, want_affine_b: bool,
                  da_dtype: torch.dtype = torch.float32):
     """-> (da (da_dtype: the dtype of the forward's `a`), du (u.dtype), dgA, dbA, dgB, dbB)"""

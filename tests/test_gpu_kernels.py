@@ -662,6 +662,36 @@ def test_linear_identity_table(cuda, dtype, n, cin, cout):
     _close("linear_db", be.grad, br.grad, 1e-4, 2e-3 * float(br.grad.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (128, 32), (64, 64), (256, 64), (128, 128)])
+def test_linear_with_the_residual_joint_in_its_epilogue(cuda, dtype, cin, cout):
+    """ptc_linear_joint_fwd (fwd2_joint.h): `proj` / `fc2` of a Block with the joint behind them -- z = a + droppath(x W^T + b), y = norm2(z) or
+    the cast of z -- in ONE launch, against the two launches it replaces (the Linear on the same GEMM loop, then ptc_add_norm_fwd): the
+    same arithmetic statement for statement, so z, y and the LayerNorm statistics must be bit-identical; with and without the inverse
+    serialization table, DropPath row factors, LayerNorm; ragged row count."""
+    from pointcept_amd import ops
+
+    assert ops.linear_joint_supported(cin, cout, dtype) and not ops.linear_joint_supported(96, cout, dtype)
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    n, n_in = 3001, 3072
+    x = torch.randn(n_in, cin, generator=g).to(dtype).to(cuda)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dtype).to(cuda)
+    b = torch.randn(cout, generator=g).to(cuda)
+    a = torch.randn(n, cout, generator=g).to(cuda)
+    rs = (torch.rand(n, generator=g) > 0.3).float().to(cuda) / 0.7
+    tab = torch.randint(0, n_in, (n,), generator=g).int().to(cuda)
+    gam, bet = (torch.rand(cout, generator=g) + 0.5).to(cuda), torch.randn(cout, generator=g).to(cuda)
+    for table, scale, norm in ((tab, rs, (gam, bet, 1e-5)), (None, None, None), (None, rs, None), (tab, None, (gam, bet, 1e-5))):
+        xin = x if table is not None else x[:n].contiguous()
+        z, y, st = ops.linear_joint_fwd(xin, w, b, table, a, scale, norm, dtype)
+        u = ops.spconv_fwd(xin, w[:, None, :].contiguous(), b, None if table is None else table[None, :].contiguous())
+        z2, y2, _, st2 = ops.add_norm_fwd(u, a, scale, None, norm, dtype)
+        assert torch.equal(z, z2) and torch.equal(y, y2), (table is not None, scale is not None, norm is not None)
+        assert (st is None) == (st2 is None) and (st is None or torch.equal(st, st2))
+        ref = a.double() + (1.0 if scale is None else scale.double()[:, None]) * u.double()
+        assert float((z.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_linear_gather_tables(cuda, dtype):
     """out = F.linear(x)[gidx] with a padded permutation (duplicated tail rows), gather-form backward."""

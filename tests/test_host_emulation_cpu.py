@@ -190,6 +190,9 @@ EMULATED_GPU_TESTS = [
     ("test_pointops_edge_operators", dict(c=8, w_c=4)), ("test_pointops_edge_operators", dict(c=3, w_c=1)), ("test_pointops_edge_operators", dict(c=6, w_c=2)),
     # MFMA kernels: implicit-GEMM convolution / Linear (16x16x32 bf16 / f16, 16x16x4 f32) and window attention (32x32x16 bf16)
     ("test_linear_gather_tables", dict(dtype=torch.bfloat16)),
+    ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.bfloat16, cin=64, cout=64)),
+    ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.float16, cin=128, cout=32)),
+    ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.bfloat16, cin=128, cout=128)),
     ("test_linear_identity_table", dict(dtype=torch.float32, n=1000, cin=32, cout=64)),
     ("test_spconv_fwd_and_wgrad", dict(dtype=torch.bfloat16, cin=32, cout=32, ksize=3)),
     ("test_spconv_fwd_chunked_pipeline", dict(cin=128, cout=128, ksize=3, n_pts=700)),      # conv3 with the two-chunk gather ring (DEEP)
@@ -411,7 +414,7 @@ def test_block_executor_is_bit_identical_to_the_composed_path_on_the_emulation(m
             blk = ops.BlockTables(nbr) if blk_tables else None
             rs1 = (torch.rand(n, generator=g) > 0.3).float()/0.7 if with_rs else None
             rs2 = (torch.rand(n, generator=g) > 0.3).float()/0.7 if with_rs else None
-            meta = dict(n_pad=int(tabs[0].shape[1]), n_seq=int(cu.numel())-1, heads=H, patch=patch, scale=16**-0.5, eps_cpe=1e-5, eps_n1=1e-5, eps_n2=1e-5,
+            meta = dict(dt=torch.bfloat16, n_pad=int(tabs[0].shape[1]), n_seq=int(cu.numel())-1, heads=H, patch=patch, scale=16**-0.5, eps_cpe=1e-5, eps_n1=1e-5, eps_n2=1e-5,
                         nbr=nbr, blk=blk, tabs=tabs, cu=cu)
             dz = torch.randn(n, C, generator=g); dyb = torch.randn(n, C, generator=g).to(torch.bfloat16)
             res = []
