@@ -285,7 +285,13 @@ int ptc_linear_fwd_ex(const void* in, int64_t n, const void* weight, const float
  * arithmetic of the joint is ptc_add_norm_fwd's (same lane mapping and statement order): bit-identical results.  16-bit features,
  * c_out in {32, 64, 128}, c_in in {32, 64, 128, 256}; a / z fp32 [n_out, c_out]; y (may be NULL) in the feature dtype; nbr as in
  * ptc_spconv_fwd for kv = 1 (the inverse serialization table of `proj`) or NULL. */
+/* ptc_linear_norm_joint_fwd: the joint of the positional encoding, x1 = x0 + LN_cpe(Linear(conv)), y1 = norm1(x1) (ptv3m1:318-323): the branch
+ * operand is normalised first (statA [2][n_out]); the Linear's own output is written too (u_out, feature dtype): the backward of LN_cpe
+ * reads it.  Same kernel, same bit-identity with ptc_spconv_fwd + ptc_add_norm_fwd(normA = 1). */
 int ptc_linear_joint_supported(int c_in, int c_out, int dtype);
+int ptc_linear_norm_joint_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, int64_t n_out, int c_in, int c_out, int dtype,
+                              const float* gA, const float* bA, float epsA, const void* a, int a_dtype, const float* gB, const float* bB, float epsB,
+                              int normB, void* u_out, float* z, void* y, float* statA, float* statB, ptc_stream_t stream);
 int ptc_linear_joint_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr, int64_t n_out, int c_in,
                          int c_out, int dtype, const float* a, const float* row_scale, const float* gB, const float* bB, float epsB,
                          int normB, float* z, void* y, float* statB, ptc_stream_t stream);

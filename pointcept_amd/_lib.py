@@ -58,6 +58,8 @@ _SIGNATURES = {
                                      c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_linear_supported_ex": (c_int, [c_int, c_int, c_int]),
     "ptc_linear_joint_supported": (c_int, [c_int, c_int, c_int]),
+    "ptc_linear_norm_joint_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_int, c_ptr, c_ptr, c_f32, c_int,
+                                          c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_linear_joint_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_int,
                                      c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_linear_fwd_ex": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),

@@ -742,6 +742,7 @@ attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict
   }
 }
 
+#include "attention_bwd1.h"
 #include "attention_hd.h"
 #include "attention_rpe.h"
 #include "attention_drop.h"
@@ -822,6 +823,27 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)workspace;
   const int n_units = (int)(n_seq * H);
+  // launches that fill the chip with whole units take the one-pass kernel (attention_bwd1.h); the deep stages (a few hundred units)
+  // keep the two split kernels below.  PTC_AT_BWD1=0 / 1 forces either form (timing A/B, tests).
+  {
+    const char* e1 = getenv("PTC_AT_BWD1");          // read per call: tests switch it in-process
+    const int forced = e1 ? atoi(e1) : -1;
+    if (forced != 0 && lp_max <= AT_MAX_L && (forced == 1 || n_units >= AT1_MIN_UNITS)) {
+      const unsigned g1 = (unsigned)(8 * ((n_units + 7) / 8));
+#define AT_BWD1_CASE(F16)                                                                                                           \
+      if ((dtype == PTC_F16) == F16) {                                                                                              \
+        rc = allow_big_lds((attn_bwd1_kernel<F16>), bwd1_lds_bytes(lp_max));                                                        \
+        if (rc != PTC_OK) return rc;                                                                                                \
+        hipLaunchKernelGGL((attn_bwd1_kernel<F16>), dim3(g1), dim3(AT_THREADS), bwd1_lds_bytes(lp_max), s, (const uint16_t*)qkv,     \
+                           (const uint16_t*)out, (const uint16_t*)dout, lse, cu_seqlens, H, softmax_scale, total, lp_max, n_units,  \
+                           (uint16_t*)dqkv);                                                                                        \
+        PTC_CHECK_LAUNCH("attn_bwd1_kernel");                                                                                       \
+        return PTC_OK;                                                                                                              \
+      }
+      AT_BWD1_CASE(false) AT_BWD1_CASE(true)
+#undef AT_BWD1_CASE
+    }
+  }
   const int qs = at_split_host(n_units, lp_max);
   const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
   // (s_setprio on half of the waves, as in the forward: measured neutral to harmful here, profiles/r02_h_attn_variants.txt; a two-stage

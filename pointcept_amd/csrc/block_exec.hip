@@ -71,6 +71,14 @@ extern "C" int ptc_ptv3_block_fwd(const int64_t* iv, const float* fv, const void
   RUN(ptc_spconv_fwd_blk(P(in, PTC_BLK_P_XC), n, P(in, PTC_BLK_P_W_CONV), (const float*)P(in, PTC_BLK_P_B_CONV), nbr, P(in, PTC_BLK_P_BLK_TAB),
                          (const int32_t*)P(in, PTC_BLK_P_BLK_HID), (const int32_t*)P(in, PTC_BLK_P_BLK_HCNT), (int)iv[PTC_BLK_I_BLK_BM],
                          (int)iv[PTC_BLK_I_BLK_HCAP], n, 27, c, c, dt, out[PTC_BLK_O_CONV], s));
+  // 2 + 3 in ONE launch where the shape allows (fwd2_joint.h, normA form): the Linear (ptv3m1:285), x1 = x0 + LN_cpe(lin), y1 = norm1(x1);
+  // `lin` is still written (LN_cpe's backward reads it) but not read back
+  if (PTC_BLK_JOINT_EPILOGUE && ptc_linear_joint_supported(c, c, dt)) {
+    RUN(ptc_linear_norm_joint_fwd(out[PTC_BLK_O_CONV], n, P(in, PTC_BLK_P_W_LIN), (const float*)P(in, PTC_BLK_P_B_LIN), n, c, c, dt,
+                                  (const float*)P(in, PTC_BLK_P_G_CPE), (const float*)P(in, PTC_BLK_P_BE_CPE), fv[PTC_BLK_F_EPS_CPE], P(in, PTC_BLK_P_X0), a_dt,
+                                  (const float*)P(in, PTC_BLK_P_G_N1), (const float*)P(in, PTC_BLK_P_BE_N1), fv[PTC_BLK_F_EPS_N1], 1, out[PTC_BLK_O_LIN],
+                                  M<float>(out, PTC_BLK_O_X1), out[PTC_BLK_O_Y1], M<float>(out, PTC_BLK_O_ST_CPE), M<float>(out, PTC_BLK_O_ST_N1), s));
+  } else {
   // 2. ... its Linear (ptv3m1:285)
   RUN(ptc_spconv_fwd(out[PTC_BLK_O_CONV], n, P(in, PTC_BLK_P_W_LIN), (const float*)P(in, PTC_BLK_P_B_LIN), nullptr, n, 1, c, c, dt, out[PTC_BLK_O_LIN], s));
   // 3. x1 = x0 + LN_cpe(lin);  y1 = norm1(x1)
@@ -78,6 +86,7 @@ extern "C" int ptc_ptv3_block_fwd(const int64_t* iv, const float* fv, const void
                        (const float*)P(in, PTC_BLK_P_BE_CPE), fv[PTC_BLK_F_EPS_CPE], 1, (const float*)P(in, PTC_BLK_P_G_N1),
                        (const float*)P(in, PTC_BLK_P_BE_N1), fv[PTC_BLK_F_EPS_N1], 1, M<float>(out, PTC_BLK_O_X1), out[PTC_BLK_O_Y1], dt,
                        M<float>(out, PTC_BLK_O_ST_CPE), M<float>(out, PTC_BLK_O_ST_N1), s));
+  }
   // 4. qkv = Linear(y1)[order[pad]]: the serialization gather rides in the GEMM's row table (ptv3m1:184-188)
   RUN(ptc_spconv_fwd(out[PTC_BLK_O_Y1], n, P(in, PTC_BLK_P_W_QKV), (const float*)P(in, PTC_BLK_P_B_QKV), (const int32_t*)P(in, PTC_BLK_P_T_QKV_FWD), np, 1, c,
                      3 * c, dt, out[PTC_BLK_O_QKV], s));

@@ -25,6 +25,15 @@ struct F2Joint {
   float* z;                // [n, c] fp32
   void* y;                 // [n, c] feature dtype, or NULL
   float* statB;            // [2][n] mean / rstd of LN_B, or NULL
+  // joint `x + LN_A(Linear(.))` (the positional encoding, ptv3m1:318-321): the branch operand is normalised first; its backward reads the
+  // Linear's output, so that is written too (u_out)
+  const float* gA;
+  const float* bA;
+  float epsA;
+  int normA;
+  float* statA;            // [2][n]
+  void* u_out;             // [n, c] feature dtype: the Linear's output (normA only)
+  int a_kind;              // dtype of `a`: 0 fp32 (the stream), 1 bf16, 2 f16 (first Block of a stage: the pooling / unpooling output)
 };
 
 template <typename T, int NTILES, int S>
@@ -51,11 +60,13 @@ linear2_joint_kernel(const T* __restrict__ in, const T* __restrict__ w, const fl
   __syncthreads();
   // LayerNorm B affine of this lane's 8 channels in the read-back mapping (slot = lane % LPR)
   const int slot = lane % LPR;
-  float gb[LN_VEC], bb[LN_VEC];
+  float gb[LN_VEC], bb[LN_VEC], ga[LN_VEC], ba[LN_VEC];
 #pragma unroll
   for (int i = 0; i < LN_VEC; ++i) {
     gb[i] = (J.normB && J.gB) ? J.gB[slot * LN_VEC + i] : 1.f;
     bb[i] = (J.normB && J.bB) ? J.bB[slot * LN_VEC + i] : 0.f;
+    ga[i] = (J.normA && J.gA) ? J.gA[slot * LN_VEC + i] : 1.f;
+    ba[i] = (J.normA && J.bA) ? J.bA[slot * LN_VEC + i] : 0.f;
   }
 
   const int64_t tiles = (n_out + F2_ROWS - 1) / F2_ROWS;
@@ -140,27 +151,28 @@ linear2_joint_kernel(const T* __restrict__ in, const T* __restrict__ w, const fl
         const bool ok = row < F2_OUT_ROWS && grow < n_out;
         float v[LN_VEC], rr[LN_VEC];
         ln_load8<T>(reinterpret_cast<const T*>(slice + (row < F2_OUT_ROWS ? row : 0) * P) + slot * LN_VEC, v);
-        if (ok) ln_load8<float>(J.a + grow * NT + slot * LN_VEC, rr);
-        else {
+        if (ok) {
+          if (J.a_kind == 1) ln_load8<bf16_t>(reinterpret_cast<const bf16_t*>(J.a) + grow * NT + slot * LN_VEC, rr);
+          else if (J.a_kind == 2) ln_load8<f16_t>(reinterpret_cast<const f16_t*>(J.a) + grow * NT + slot * LN_VEC, rr);
+          else ln_load8<float>(J.a + grow * NT + slot * LN_VEC, rr);
+        } else {
 #pragma unroll
           for (int i = 0; i < LN_VEC; ++i) rr[i] = 0.f;
         }
+        if (J.normA) {              // add_norm_fwd_kernel's normA branch: the same ln_normalize
+          if (ok) ln_store8<T>(reinterpret_cast<T*>(J.u_out) + grow * NT + slot * LN_VEC, v);     // v holds T-representable values: exact
+          float mean, rstd;
+          ln_normalize<LPR>(v, J.epsA, ga, ba, mean, rstd);
+          if (ok && slot == 0) { J.statA[grow] = mean; J.statA[n_out + grow] = rstd; }
+        }
         const float sc = (J.row_scale && ok) ? J.row_scale[grow] : 1.f;
 #pragma unroll
-        for (int i = 0; i < LN_VEC; ++i) rr[i] += sc * v[i];
+        for (int i = 0; i < LN_VEC; ++i) rr[i] = fmaf(sc, v[i], rr[i]);
         if (ok) ln_store8<float>(J.z + grow * NT + slot * LN_VEC, rr);
         if (J.y) {
           if (J.normB) {              // (the shuffles run in every lane: rows past the end carry zeros and store nothing)
-            float s1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < LN_VEC; ++i) s1 += rr[i];
-            const float mean = group_sum<LPR>(s1) * (1.f / NT);
-            float q2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < LN_VEC; ++i) { const float d = rr[i] - mean; q2 += d * d; }
-            const float rstd = rsqrtf(group_sum<LPR>(q2) * (1.f / NT) + J.epsB);
-#pragma unroll
-            for (int i = 0; i < LN_VEC; ++i) rr[i] = (rr[i] - mean) * rstd * gb[i] + bb[i];
+            float mean, rstd;
+            ln_normalize<LPR>(rr, J.epsB, gb, bb, mean, rstd);
             if (ok && slot == 0) { J.statB[grow] = mean; J.statB[n_out + grow] = rstd; }
           }
           if (ok) ln_store8<T>(reinterpret_cast<T*>(J.y) + grow * NT + slot * LN_VEC, rr);

@@ -43,3 +43,24 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+
+// LayerNorm of the row a lane group holds, in place; mean / rstd returned for the backward.  Shared by add_norm_fwd_kernel (norm.hip) and
+// the GEMM epilogues that run a joint (fwd2_joint.h), which promise the SAME bits: every multiply-add is an explicit fmaf.  Written as
+// `q += d * d`, -ffp-contract=fast lets the compiler decide per kernel which terms fuse (SLP-packed v_pk_mul_f32 + plain adds in one
+// kernel, a scalar v_fmac_f32 for one of the eight terms in the other: one ulp of variance between the 128-channel instances of the two
+// kernels, found on the MI355X in round 4); an fma intrinsic is never split, and a product feeding one is never merged into it.
+template <int LPR>
+__device__ __forceinline__ void ln_normalize(float (&v)[LN_VEC], float eps, const float (&g)[LN_VEC], const float (&b)[LN_VEC], float& mean,
+                                             float& rstd) {
+  constexpr float inv_c = 1.f / (LPR * LN_VEC);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_VEC; ++i) s += v[i];
+  mean = group_sum<LPR>(s) * inv_c;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_VEC; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  rstd = rsqrtf(fmaf(group_sum<LPR>(q), inv_c, eps));
+#pragma unroll
+  for (int i = 0; i < LN_VEC; ++i) v[i] = fmaf((v[i] - mean) * rstd, g[i], b[i]);
+}

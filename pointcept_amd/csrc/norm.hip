@@ -250,34 +250,18 @@ add_norm_fwd_kernel(const TU* __restrict__ u, const void* __restrict__ a, int a_
     else if (a_bf16 == 2) ln_load8<f16_t>(reinterpret_cast<const f16_t*>(a) + row * C + slot * LN_VEC, r);
     else ln_load8<float>(reinterpret_cast<const float*>(a) + row * C + slot * LN_VEC, r);
     if (normA) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < LN_VEC; ++i) s += v[i];
-      const float mean = group_sum<LPR>(s) * (1.f / C);
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < LN_VEC; ++i) { const float d = v[i] - mean; q += d * d; }
-      const float rstd = rsqrtf(group_sum<LPR>(q) * (1.f / C) + epsA);
-#pragma unroll
-      for (int i = 0; i < LN_VEC; ++i) v[i] = (v[i] - mean) * rstd * ga[i] + ba[i];
+      float mean, rstd;
+      ln_normalize<LPR>(v, epsA, ga, ba, mean, rstd);
       if (slot == 0) { statA[row] = mean; statA[n + row] = rstd; }
     }
     const float sc = row_scale ? row_scale[row] : 1.f;
 #pragma unroll
-    for (int i = 0; i < LN_VEC; ++i) r[i] += sc * v[i];
+    for (int i = 0; i < LN_VEC; ++i) r[i] = fmaf(sc, v[i], r[i]);
     ln_store8<float>(z + row * C + slot * LN_VEC, r);
     if (y) {
       if (normB) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < LN_VEC; ++i) s += r[i];
-        const float mean = group_sum<LPR>(s) * (1.f / C);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < LN_VEC; ++i) { const float d = r[i] - mean; q += d * d; }
-        const float rstd = rsqrtf(group_sum<LPR>(q) * (1.f / C) + epsB);
-#pragma unroll
-        for (int i = 0; i < LN_VEC; ++i) r[i] = (r[i] - mean) * rstd * gb[i] + bb[i];
+        float mean, rstd;
+        ln_normalize<LPR>(r, epsB, gb, bb, mean, rstd);
         if (slot == 0) { statB[row] = mean; statB[n + row] = rstd; }
       }
       ln_store8<TY>(y + row * C + slot * LN_VEC, r);

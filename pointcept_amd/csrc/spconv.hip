@@ -290,9 +290,31 @@ extern "C" int ptc_linear_fwd_ex(const void* in, int64_t n, const void* weight, 
 
 // A Linear with the residual joint behind it in its epilogue (fwd2_joint.h): z = a + row_scale * (in W^T + b), y = LN_B(z) | cast(z).
 extern "C" int ptc_linear_joint_supported(int c_in, int c_out, int dtype) { return linear_joint_supported(dtype, c_in, c_out) ? 1 : 0; }
+static int linear_joint_impl(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr, int64_t n_out, int c_in, int c_out,
+                             int dtype, const F2Joint& J, ptc_stream_t stream);
 extern "C" int ptc_linear_joint_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr, int64_t n_out,
                                     int c_in, int c_out, int dtype, const float* a, const float* row_scale, const float* gB, const float* bB,
                                     float epsB, int normB, float* z, void* y, float* statB, ptc_stream_t stream) {
+  const F2Joint J{a, row_scale, gB, bB, epsB, normB, z, y, statB, nullptr, nullptr, 0.f, 0, nullptr, nullptr, 0};
+  return linear_joint_impl(in, n_in, weight, bias, nbr, n_out, c_in, c_out, dtype, J, stream);
+}
+// ... with the branch operand normalised first: z = a + LN_A(in W^T + b), y = LN_B(z); u_out = the Linear's output (read by the backward)
+extern "C" int ptc_linear_norm_joint_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, int64_t n_out, int c_in, int c_out, int dtype,
+                                         const float* gA, const float* bA, float epsA, const void* a, int a_dtype, const float* gB, const float* bB, float epsB,
+                                         int normB, void* u_out, float* z, void* y, float* statA, float* statB, ptc_stream_t stream) {
+  PTC_REQUIRE(n_out == 0 || (u_out && statA), PTC_EINVAL, "ptc_linear_norm_joint_fwd: null buffer");
+  PTC_REQUIRE((uintptr_t)u_out % 16 == 0, PTC_EINVAL, "ptc_linear_norm_joint_fwd: buffers must be 16-byte aligned");
+  PTC_REQUIRE(a_dtype == PTC_F32 || a_dtype == PTC_BF16 || a_dtype == PTC_F16, PTC_EINVAL, "ptc_linear_norm_joint_fwd: a_dtype %d", a_dtype);
+  const F2Joint J{(const float*)a, nullptr, gB, bB, epsB, normB, z, y, statB, gA, bA, epsA, 1, statA, u_out, a_dtype == PTC_BF16 ? 1 : (a_dtype == PTC_F16 ? 2 : 0)};
+  return linear_joint_impl(in, n_in, weight, bias, nullptr, n_out, c_in, c_out, dtype, J, stream);
+}
+static int linear_joint_impl(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr, int64_t n_out, int c_in, int c_out,
+                             int dtype, const F2Joint& J, ptc_stream_t stream) {
+  const float* a = J.a;
+  float* z = J.z;
+  void* y = J.y;
+  const int normB = J.normB;
+  float* statB = J.statB;
   PTC_REQUIRE(n_out >= 0 && n_in >= 0 && linear_joint_supported(dtype, c_in, c_out), PTC_EUNSUPPORTED,
               "ptc_linear_joint_fwd: c_in=%d c_out=%d dtype=%d", c_in, c_out, dtype);
   PTC_REQUIRE((uint64_t)n_in * (uint64_t)c_in * 2 <= PTC_BUF_MAX_BYTES, PTC_EUNSUPPORTED, "ptc_linear_joint_fwd: input of 2 GiB or more");
@@ -301,7 +323,6 @@ extern "C" int ptc_linear_joint_fwd(const void* in, int64_t n_in, const void* we
   PTC_REQUIRE(!(normB && y) || statB, PTC_EINVAL, "ptc_linear_joint_fwd: missing statistics buffer");
   PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)a % 16 == 0) && ((uintptr_t)z % 16 == 0) &&
               ((uintptr_t)y % 16 == 0), PTC_EINVAL, "ptc_linear_joint_fwd: buffers must be 16-byte aligned");
-  const F2Joint J{a, row_scale, gB, bB, epsB, normB, z, y, statB};
   hipStream_t s = (hipStream_t)stream;
 #define LJ_DISPATCH(T)                                                                             \
   if (c_out == 32) return launch_linear_joint<T, 2>(in, n_in, weight, bias, nbr, n_out, c_in, J, s);  \

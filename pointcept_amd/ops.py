@@ -753,6 +753,30 @@ def linear_joint_fwd(x, weight, bias, table, a, row_scale, norm_b, y_dtype, n_ou
     return z, y, st_b
 
 
+def linear_norm_joint_fwd(x, weight, bias, norm_a, a, norm_b, y_dtype):
+    """u = x @ weight^T + bias (x's dtype), z = a + LN_A(u) (fp32), y = LN_B(z) | cast(z): the Linear of the positional encoding with its
+    joint in the epilogue (ptv3m1:285, 318-323; bit-identical to spconv_fwd + add_norm_fwd with normA).  a fp32 or x's dtype.
+    Returns (u, z, y, statA, statB)."""
+    require_cuda(x, weight, bias, a)
+    x, weight, a = x.contiguous(), weight.contiguous(), a.contiguous()
+    c_out, c_in = weight.shape[0], weight.shape[-1]
+    if x.dtype != weight.dtype or c_in != c_out or not linear_joint_supported(c_in, c_out, x.dtype) or a.dtype not in (torch.float32, x.dtype):
+        raise PtcoreError("linear_norm_joint_fwd: unsupported shape / dtype")
+    n, dev = int(a.shape[0]), x.device
+    u = torch.empty((n, c_out), dtype=x.dtype, device=dev)
+    z = torch.empty((n, c_out), dtype=torch.float32, device=dev)
+    y = torch.empty((n, c_out), dtype=y_dtype, device=dev) if y_dtype is not None else None
+    st_a = torch.empty((2, n), dtype=torch.float32, device=dev)
+    st_b = torch.empty((2, n), dtype=torch.float32, device=dev) if (norm_b is not None and y is not None) else None
+    ga, ba, ea = norm_a
+    gb, bb, eb = norm_b if norm_b is not None else (None, None, 0.0)
+    b = None if bias is None else bias.float().contiguous()
+    check(lib().ptc_linear_norm_joint_fwd(ptr(x), x.shape[0], ptr(weight), ptr(b), n, c_in, c_out, dtype_code(x), ptr(ga), ptr(ba), float(ea), ptr(a),
+                                          dtype_code(a), ptr(gb), ptr(bb), float(eb), int(norm_b is not None), ptr(u), ptr(z), ptr(y), ptr(st_a), ptr(st_b),
+                                          stream_ptr()), "ptc_linear_norm_joint_fwd")
+    return u, z, y, st_a, st_b
+
+
 def add_norm_bwd(dz_in, dy, z, u, row_scale, g_a, st_a, g_b, st_b, want_affine_a: bool, want_affine_b: bool,
                  da_dtype: torch.dtype = torch.float32):
     """-> (da (da_dtype: the dtype of the forward's `a`), du (u.dtype), dgA, dbA, dgB, dbB)"""

@@ -690,6 +690,17 @@ def test_linear_with_the_residual_joint_in_its_epilogue(cuda, dtype, cin, cout):
         assert (st is None) == (st2 is None) and (st is None or torch.equal(st, st2))
         ref = a.double() + (1.0 if scale is None else scale.double()[:, None]) * u.double()
         assert float((z.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    if cin == cout:
+        # the positional-encoding joint (ptc_linear_norm_joint_fwd): the branch operand normalised first, the Linear's output written too;
+        # the residual operand fp32 (the stream) or 16-bit (first Block of a stage)
+        ga2, be2 = (torch.rand(cout, generator=g) + 0.5).to(cuda), torch.randn(cout, generator=g).to(cuda)
+        xin = x[:n].contiguous()
+        for res, norm in ((a, (gam, bet, 1e-5)), (a.to(dtype), (gam, bet, 1e-5)), (a, None)):
+            u, z, y, sa, sb = ops.linear_norm_joint_fwd(xin, w, b, (ga2, be2, 1e-6), res, norm, dtype)
+            u2 = ops.spconv_fwd(xin, w[:, None, :].contiguous(), b, None)
+            z2, y2, sa2, sb2 = ops.add_norm_fwd(u2, res, None, (ga2, be2, 1e-6), norm, dtype)
+            assert torch.equal(u, u2) and torch.equal(z, z2) and torch.equal(y, y2) and torch.equal(sa, sa2), (res.dtype, norm is not None)
+            assert (sb is None) == (sb2 is None) and (sb is None or torch.equal(sb, sb2))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -870,7 +881,10 @@ def test_layer_norm_empty_and_unsupported(cuda):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("lens,H", [([1024], 2), ([1024, 1024, 330], 4), ([48, 48, 17], 2), ([1, 2, 31, 32, 33, 65], 3),
                                     ([128] * 5, 8), ([1000, 24], 32)])
-def test_attention_fwd_bwd(cuda, lens, H):
+def test_attention_fwd_bwd(cuda, lens, H, monkeypatch):
+    """forward and both forms of the backward (the two split kernels; the one-pass kernel of attention_bwd1.h, which launches of >= 256
+    (sequence, head) units take by default) against the fp32 oracle; dK / dV of the two forms are the same sums in the same order
+    (bit-identical), dQ differs in the order of its partial sums only."""
     from pointcept_amd import ops
 
     g = torch.Generator().manual_seed(sum(lens) + H)
@@ -878,6 +892,7 @@ def test_attention_fwd_bwd(cuda, lens, H):
     cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
     qkv = (torch.randn(T, 3, H, 16, generator=g) * 1.5).to(torch.bfloat16)
     scale = 16 ** -0.5
+    fro = lambda a, b: float((a.float().cpu() - b.detach()).norm() / b.detach().norm())  # noqa: E731
     out, lse = ops.attn_varlen_fwd(qkv.to(cuda), cu.to(cuda), max(lens), scale)
     q32 = qkv.float().requires_grad_(True)
     ref, ref_lse = oops.attention_varlen(q32, cu, scale, return_lse=True)
@@ -888,24 +903,32 @@ def test_attention_fwd_bwd(cuda, lens, H):
     _close("attn_lse", lse, ref_lse, 1e-3, 2e-2)         # denominator summed from bf16-rounded P
     dout = torch.randn(T, H, 16, generator=g).to(torch.bfloat16)
     ref.backward(dout.float())
+    monkeypatch.setenv("PTC_AT_BWD1", "0")
     dqkv = ops.attn_varlen_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale)
     gmax = float(q32.grad.abs().max())
     _close("attn_bwd", dqkv, q32.grad, 1.0 / 32, 1e-2 * gmax)
+    monkeypatch.setenv("PTC_AT_BWD1", "1")
+    dqkv1 = ops.attn_varlen_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale)
+    _close("attn_bwd one-pass", dqkv1, q32.grad, 1.0 / 32, 1e-2 * gmax)
+    assert torch.equal(dqkv1[:, 1:], dqkv[:, 1:]), "dK / dV of the one-pass kernel differ from the split kernels'"
+    assert torch.equal(dqkv1, ops.attn_varlen_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu.to(cuda), max(lens), scale)), "not reproducible"
+    assert fro(dqkv1, q32.grad) < 2.0 ** -7, fro(dqkv1, q32.grad)
     # the elementwise bars above are set by the worst element of a cancelling sum; over the whole tensor the kernels sit at the
     # rounding floor of their bf16 operands (P, dS and the outputs are rounded to bf16 as flash-attn rounds them): measured on the
     # MI355X 2.1e-3 (forward) and 3.0-3.3e-3 (backward) relative Frobenius error at every shape (tools/attn_err_probe.py); bars = 2^-8 / 2^-7
-    fro = lambda a, b: float((a.float().cpu() - b.detach()).norm() / b.detach().norm())
     assert fro(out, ref) < 2.0 ** -8, fro(out, ref)
     assert fro(dqkv, q32.grad) < 2.0 ** -7, fro(dqkv, q32.grad)
 
 
 @pytest.mark.parametrize("lens,H", [([1024, 330], 4), ([1, 2, 31, 32, 33, 65], 3)])
-def test_attention_f16_io_equals_the_reference_cast_passes(cuda, lens, H):
+@pytest.mark.parametrize("one_pass", ["0", "1"])
+def test_attention_f16_io_equals_the_reference_cast_passes(cuda, lens, H, one_pass, monkeypatch):
     """fp16 autocast call site (ptv3m1:209,215): flash_attn(qkv.to(bfloat16)).to(qkv.dtype) and its autograd.  With f16 tensors the kernels do
     the four casts in their load / store paths -- bit for bit the tensors the separate cast passes produce around the bf16 kernels
     (forward output, and dqkv for an f16 dout), including values that only f16 can hold (rounded to bf16 on the way in)."""
     from pointcept_amd import ops
 
+    monkeypatch.setenv("PTC_AT_BWD1", one_pass)          # both forms of the backward
     g = torch.Generator().manual_seed(sum(lens) * 3 + H)
     T = sum(lens)
     cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).to(cuda)

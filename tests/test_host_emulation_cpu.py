@@ -206,7 +206,9 @@ EMULATED_GPU_TESTS = [
     ("test_pool_maps", dict(n_pts=3000)),
     ("test_attention_fwd_bwd", dict(lens=[48, 48, 17], H=2)), ("test_attention_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
     ("test_attention_large_logits", dict()), ("test_attention_dropout_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3, p=0.25)),
-    ("test_attention_dropout_fwd_bwd", dict(lens=[200], H=2, p=0.5)), ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
+    ("test_attention_dropout_fwd_bwd", dict(lens=[200], H=2, p=0.5)), ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3, one_pass="0")),
+    ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3, one_pass="1")),
+    ("test_attention_fwd_bwd", dict(lens=[300, 1024], H=1)),
     ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.bfloat16)),
     ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.float16)),
     ("test_attention_other_head_dims_fwd_bwd", dict(D=40, lens=[200, 100], H=2, dtype=torch.float16)),
@@ -218,7 +220,7 @@ EMULATED_GPU_TESTS = [
 
 
 @pytest.mark.parametrize("name,kw", EMULATED_GPU_TESTS, ids=[f"{n}-{i}" for i, (n, _) in enumerate(EMULATED_GPU_TESTS)])
-def test_gpu_kernel_test_bodies_on_the_host_emulation(name, kw):
+def test_gpu_kernel_test_bodies_on_the_host_emulation(name, kw, monkeypatch):
     """tests/test_gpu_kernels.py bodies, unchanged, with device = cpu and pointcept_amd.ops bound to the host emulation of the SAME
     kernel sources: the product's serialization keys, row gathers, segmented reductions (forward and backward), submanifold and
     strided rulebooks (incl. duplicate voxels), rotary embedding and pair-list attention operators against their oracles, on the CPU."""
@@ -228,8 +230,13 @@ def test_gpu_kernel_test_bodies_on_the_host_emulation(name, kw):
     if not emu_backend.available():
         pytest.skip("no host clang++ under /opt/rocm")
     os.environ["PTC_EMU_CONV7_WGS"] = "3"      # conv7 is persistent: few workgroups = several blocks each at test sizes (emulation only)
+    import inspect
+
+    fn = getattr(T, name)
+    if "monkeypatch" in inspect.signature(fn).parameters:
+        kw = dict(kw, monkeypatch=monkeypatch)
     with emu_backend.emulated_ops():
-        getattr(T, name)(torch.device("cpu"), **kw)
+        fn(torch.device("cpu"), **kw)
 
 
 def test_segmented_duplicate_merge_on_the_emulated_segment_kernel(monkeypatch):

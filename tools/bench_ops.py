@@ -103,9 +103,20 @@ def bench_attention(rows, n_seq, H, results, L=1024):
     r["fwd"] = roof(by_f, fl_f, timeit(lambda: ops.attn_varlen_fwd(qkv, cu, L, sc), iters=10))
     r["bwd"] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
                     timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
+    # the two forms of the backward (attention.hip: PTC_AT_BWD1 is read per call): split dQ | dK dV kernels, one-pass kernel
+    prev = os.environ.get("PTC_AT_BWD1")
+    for key, val in (("bwd_split", "0"), ("bwd_one_pass", "1")):
+        os.environ["PTC_AT_BWD1"] = val
+        r[key] = roof(T * H * 16 * 2 * 8, 10.0 * L * L * 16 * n_seq * H,
+                      timeit(lambda: ops.attn_varlen_bwd(qkv, out, do, lse, cu, L, sc), iters=10))
+    if prev is None:
+        del os.environ["PTC_AT_BWD1"]
+    else:
+        os.environ["PTC_AT_BWD1"] = prev
     results.append(r)
     rows.append(f"attention n_seq={n_seq:4d} L={L} H={H:2d} | fwd {r['fwd']['us']:8.1f} us {r['fwd']['TFLOPs']:7.1f} TF/s | "
-                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s")
+                f"bwd {r['bwd']['us']:8.1f} us {r['bwd']['TFLOPs']:7.1f} TF/s (split kernels {r['bwd_split']['us']:8.1f} us, one-pass "
+                f"{r['bwd_one_pass']['us']:8.1f} us)")
 
 
 def bench_spconv(rows, results, scenes=8, points=102400):

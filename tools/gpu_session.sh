@@ -25,6 +25,7 @@ for sec in "$@"; do
     opsq) timeout 900 python tools/bench_ops.py --quick > $O/${TAG}_ops.log 2>&1; echo "ops rc=$?" >> $O/${TAG}_env.log;;
     w7v:*) PTC_LIB_VARIANT=${sec#w7v:} timeout 600 python tools/wgrad7_time.py > $O/${TAG}_wgrad7_time_${sec#w7v:}.txt 2>&1; cat $O/${TAG}_wgrad7_time_${sec#w7v:}.txt;;
     c7t) timeout 600 python tools/conv7_time.py --all > $O/${TAG}_conv7_time.txt 2>&1; cat $O/${TAG}_conv7_time.txt;;
+    attnv:*) PTC_LIB_VARIANT=${sec#attnv:} timeout 300 python tools/bench_ops.py --only attn 2>&1 | grep "attention n_seq" | cut -c1-200 > $O/${TAG}_attn_${sec#attnv:}.txt; echo "variant ${sec#attnv:}"; cat $O/${TAG}_attn_${sec#attnv:}.txt;;
     attnpad) for pad in 0 20000; do echo "PTC_AT_BWD_PAD_LDS=$pad"; PTC_AT_BWD_PAD_LDS=$pad timeout 300 python tools/bench_ops.py --only attn 2>&1 | grep "attention n_seq= 800"; done > $O/${TAG}_attn_pad.txt 2>&1; cat $O/${TAG}_attn_pad.txt;;
     attnprof) cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d $O/${TAG}_ap -- python $R/tools/bench_ops.py --only attn > $O/${TAG}_ap.log 2>&1
           cd $R; TOP=12 python tools/prof_top.py $O/${TAG}_ap 1 $O/${TAG}_attn_kernel_stats.csv > $O/${TAG}_ap_top.log 2>&1; rm -rf $O/${TAG}_ap; head -8 $O/${TAG}_attn_kernel_stats.csv | cut -c1-150;;
@@ -71,7 +72,7 @@ for sec in "$@"; do
           timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $O/${TAG}_roof_sq -- python $R/tools/roofline_kernel.py > $O/${TAG}_roof_sq.log 2>&1
           timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU -d $O/${TAG}_roof_sq2 -- python $R/tools/roofline_kernel.py > $O/${TAG}_roof_sq2.log 2>&1
           cd $R; python tools/pmc_summary.py --stats $O/${TAG}_roof_stats --pmc $O/${TAG}_roof_fetch $O/${TAG}_roof_write $O/${TAG}_roof_sq $O/${TAG}_roof_sq2 \
-            --kernels attn_fwd_kernel,attn_bwd_dq_kernel,attn_bwd_dkv_kernel --out $O/${TAG}_roof_pmc.json > $O/${TAG}_roof_pmc.log 2>&1
+            --kernels attn_fwd_kernel,attn_bwd_dq_kernel,attn_bwd_dkv_kernel,attn_bwd1_kernel --out $O/${TAG}_roof_pmc.json > $O/${TAG}_roof_pmc.log 2>&1
           rm -rf $O/${TAG}_roof_stats $O/${TAG}_roof_fetch $O/${TAG}_roof_write $O/${TAG}_roof_sq $O/${TAG}_roof_sq2; tail -3 $O/${TAG}_roof_sq2.log;;
     convpmc) cd /tmp
           rocprofv3 -L > $O/${TAG}_counters_list.txt 2>&1
