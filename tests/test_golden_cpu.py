@@ -317,15 +317,15 @@ def test_ctypes_signatures_match_the_header():
     def kind(ctype):
         if ctype in (ctypes.c_void_p, ctypes.c_char_p):
             return "ptr"
-        return {ctypes.c_int: "int", ctypes.c_int64: "i64", ctypes.c_size_t: "size", ctypes.c_float: "f32", ctypes.c_double: "f64",
-                ctypes.c_uint64: "u64"}[ctype]
+        # (c_size_t and c_uint64 are the same ctypes class on LP64: size_t and uint64_t are one kind here)
+        return {ctypes.c_int: "int", ctypes.c_int64: "i64", ctypes.c_size_t: "size", ctypes.c_float: "f32", ctypes.c_double: "f64"}[ctype]
 
     def ckind(param):
         param = param.strip()
         if "*" in param or param.startswith("ptc_stream_t"):
             return "ptr"
         base = param.rsplit(" ", 1)[0].replace("const ", "").strip()
-        return {"int": "int", "int64_t": "i64", "size_t": "size", "float": "f32", "double": "f64", "uint64_t": "u64"}[base]
+        return {"int": "int", "int64_t": "i64", "size_t": "size", "float": "f32", "double": "f64", "uint64_t": "size"}[base]
 
     for ret, name, params in decls:
         restype, argtypes = _lib._SIGNATURES[name]
