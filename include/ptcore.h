@@ -590,6 +590,15 @@ int ptc_batch_norm_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dt
                            const float* save_mean, const float* save_rstd, int64_t n, int c, int training, int act,
                            void* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                            ptc_stream_t stream);
+/* ptc_batch_norm_add_act_{fwd,bwd}: y = act(BN(x) + res) -- the tail of the reference's residual block (spconv_unet_v1m1_base.py:79-83:
+ * `out = self.bn2(out); out = out.replace_feature(out.features + self.proj(residual).features); out = self.relu(out)`), three elementwise
+ * passes there, the BatchNorm's own apply pass here.  res / dres have x's dtype; statistics are those of x alone. */
+int ptc_batch_norm_add_act_fwd(const void* x, const void* res, int64_t n, int c, int dtype, const float* gamma, const float* beta, float eps,
+                               float momentum, int training, float* running_mean, float* running_var, int act, void* y, int y_dtype,
+                               float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes, ptc_stream_t stream);
+int ptc_batch_norm_add_act_bwd(const void* dy, int dy_dtype, const void* x, const void* res, int x_dtype, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_rstd, int64_t n, int c, int training, int act, void* dx, void* dres,
+                               float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ptc_stream_t stream);
 
 /* Backward-pass weight layouts of every layer in one launch (16-bit elements):
  *   dst[ci][j][co] = src[co][m(j)][ci]; desc [n][6] int64 = { src, dst, c_out, taps_src, c_in, taps_dst | mode << 32 } (device),

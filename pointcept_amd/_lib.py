@@ -112,6 +112,10 @@ _SIGNATURES = {
                                        c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_batch_norm_act_bwd": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr,
                                        c_ptr, c_ptr, c_size, c_ptr]),
+    "ptc_batch_norm_add_act_fwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_f32, c_f32, c_int, c_ptr, c_ptr, c_int, c_ptr, c_int,
+                                           c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "ptc_batch_norm_add_act_bwd": (c_int, [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr,
+                                           c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_column_sum": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_coord_max": (c_int, [c_ptr, c_int, c_i64, c_ptr, c_ptr]),
     "ptc_cross_entropy_partials": (c_i64, [c_i64]),

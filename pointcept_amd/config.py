@@ -20,6 +20,9 @@ settings), and so a regression can be bisected without a rebuild.
                      direction (csrc/block_exec.hip: same kernels, same operands, bit-identical; ~20 ms less host time per step)
   PTC_WGRAD_BLK=0    the weight gradient of the 32 / 64-channel submanifold convolutions runs on the global-gather kernel (wgrad2) instead
                      of the block-staged, accumulator-stationary one (csrc/wgrad7.h)
+  PTC_FUSE_BN_TAIL=0 SpUNet's residual block runs bn2, the residual add and the ReLU as three passes (the reference's form) instead of in
+                     the BatchNorm's apply pass (ptc_batch_norm_add_act_*), and every BatchNorm site increments its step counter itself
+                     instead of one multi-tensor launch per forward
   PTC_FUSE_BLOCK=0   the three residual joints of a PTv3 Block run as separate LayerNorm / add / cast
                      kernels instead of the fused add_norm passes
 """
@@ -43,3 +46,4 @@ FUSE_MLP = _flag("PTC_FUSE_MLP", True)
 PREFETCH_LEVELS = _flag("PTC_PREFETCH_LEVELS", True)
 RPE_KERNEL = _flag("PTC_RPE_KERNEL", True)
 WGRAD_BLK = _flag("PTC_WGRAD_BLK", True)
+FUSE_BN_TAIL = _flag("PTC_FUSE_BN_TAIL", True)

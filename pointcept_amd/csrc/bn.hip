@@ -81,7 +81,7 @@ __device__ __forceinline__ void bn_stat_coef(const BnStat& st, int ch, float& a,
 template <typename T, typename TD, int MODE>
 __global__ void __launch_bounds__(BN_THREADS)
 bn_reduce_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat st, int64_t n, int c,
-                 int act, int64_t rows_per_group, float* __restrict__ partial) {
+                 int act, int64_t rows_per_group, float* __restrict__ partial, const T* __restrict__ res = nullptr) {
   constexpr int V = BnVec<T>::V;
   __shared__ float red[BN_THREADS][2 * V + 1];
   const BnMap m = bn_map<T>(c);
@@ -113,9 +113,13 @@ bn_reduce_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat st, 
 #pragma unroll
           for (int j = 0; j < V; ++j) dv[j] = ptc_to_float(dy[row * c + cg * V + j]);
         }
+        float rv[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) rv[j] = 0.f;
+        if (res) bn_load<T>(res + row * c + cg * V, rv);          // y = act(BN(x) + res): the pre-activation includes the residual
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-          const float dz = dv[j] * bn_act_grad(fmaf(xv[j], a[j], b[j]), act);
+          const float dz = dv[j] * bn_act_grad(fmaf(xv[j], a[j], b[j]) + rv[j], act);
           s1[j] += dz;
           s2[j] = fmaf(dz, (xv[j] - mu[j]) * rs[j], s2[j]);
         }
@@ -220,7 +224,8 @@ bn_finish_kernel(const float* __restrict__ partial, int groups, int64_t n, int c
 // element and re-loaded 6 coefficients per channel per element: 290 us for 819200 x 64, VALU/L1-bound.)
 template <typename T, typename TY>
 __global__ void __launch_bounds__(BN_THREADS)
-bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef, int64_t n, int c, int act, TY* __restrict__ y) {
+bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef, int64_t n, int c, int act, TY* __restrict__ y,
+                const T* __restrict__ res = nullptr) {
   constexpr int V = BnVec<T>::V;
   const BnMap m = bn_map<T>(c);
   const int cg = threadIdx.x % m.cgs, r = threadIdx.x / m.cgs;
@@ -233,8 +238,12 @@ bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef, int64_t
     const int64_t e = row * c + cg * V;
     float xv[V];
     bn_load<T>(x + e, xv);
+    float rv[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) xv[j] = bn_act(fmaf(xv[j], a[j], b[j]), act);
+    for (int j = 0; j < V; ++j) rv[j] = 0.f;
+    if (res) bn_load<T>(res + e, rv);
+#pragma unroll
+    for (int j = 0; j < V; ++j) xv[j] = bn_act(fmaf(xv[j], a[j], b[j]) + rv[j], act);
     if constexpr (sizeof(TY) == sizeof(T)) {
       bn_store<TY>(reinterpret_cast<TY*>(y) + e, reinterpret_cast<const float(&)[BnVec<TY>::V]>(xv));
     } else {
@@ -261,7 +270,7 @@ bn_bwd_finish_kernel(const float* __restrict__ partial, int groups, int64_t n, i
 template <typename T, typename TD>
 __global__ void __launch_bounds__(BN_THREADS)
 bn_bwd_apply_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat st, const float* __restrict__ bcoef,
-                    int64_t n, int c, int act, T* __restrict__ dx) {
+                    int64_t n, int c, int act, T* __restrict__ dx, const T* __restrict__ res = nullptr, T* __restrict__ dres = nullptr) {
   constexpr int V = BnVec<T>::V;
   const BnMap m = bn_map<T>(c);
   const int cg = threadIdx.x % m.cgs, r = threadIdx.x / m.cgs;
@@ -284,13 +293,19 @@ bn_bwd_apply_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat s
 #pragma unroll
       for (int j = 0; j < V; ++j) dv[j] = ptc_to_float(dy[e + j]);
     }
+    float rv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) rv[j] = 0.f;
+    if (res) bn_load<T>(res + e, rv);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const float dz = dv[j] * bn_act_grad(fmaf(xv[j], a[j], b[j]), act);
+      const float dz = dv[j] * bn_act_grad(fmaf(xv[j], a[j], b[j]) + rv[j], act);
       const float xhat = (xv[j] - mu[j]) * rs[j];
       xv[j] = a[j] * dz - c1[j] - xhat * c2[j];
+      rv[j] = dz;                                     // the residual branch receives the activation's gradient unchanged
     }
     bn_store<T>(dx + e, xv);
+    if (dres) bn_store<T>(dres + e, rv);
   }
 }
 
@@ -331,7 +346,7 @@ extern "C" size_t ptc_batch_norm_workspace_bytes(int64_t n, int c) {
 template <typename T, typename TY>
 static int bn_fwd_typed(const void* x, int64_t n, int c, const float* gamma, const float* beta, float eps, float momentum,
                         int training, float* running_mean, float* running_var, int act, void* y, float* save_mean,
-                        float* save_rstd, char* ws, hipStream_t s) {
+                        float* save_rstd, char* ws, hipStream_t s, const void* res = nullptr) {
   float* partial = (float*)ws;
   float* coef = (float*)(ws + bn_partial_bytes(c));
   const BnMap m = bn_map<T>(c);
@@ -347,15 +362,15 @@ static int bn_fwd_typed(const void* x, int64_t n, int c, const float* gamma, con
   int64_t grid = ptc_cdiv(n, (int64_t)m.rpi * 4);        // >= 4 rows per thread
   if (grid > 256 * 16) grid = 256 * 16;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, (const T*)x, coef, n, c, act, (TY*)y);
+  hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, (const T*)x, coef, n, c, act, (TY*)y, (const T*)res);
   PTC_CHECK_LAUNCH("bn_apply_kernel");
   return PTC_OK;
 }
 
-extern "C" int ptc_batch_norm_act_fwd(const void* x, int64_t n, int c, int dtype, const float* gamma, const float* beta, float eps,
-                                      float momentum, int training, float* running_mean, float* running_var, int act, void* y,
-                                      int y_dtype, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
-                                      ptc_stream_t stream) {
+static int bn_act_fwd_impl(const void* x, const void* res, int64_t n, int c, int dtype, const float* gamma, const float* beta, float eps,
+                           float momentum, int training, float* running_mean, float* running_var, int act, void* y,
+                           int y_dtype, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                           ptc_stream_t stream) {
   PTC_REQUIRE(n >= 0 && ptc_batch_norm_supported(c, dtype), PTC_EUNSUPPORTED, "ptc_batch_norm_act_fwd: n=%lld c=%d dtype=%d unsupported",
               (long long)n, c, dtype);
   PTC_REQUIRE(act >= 0 && act <= 2, PTC_EINVAL, "ptc_batch_norm_act_fwd: bad activation %d", act);
@@ -367,7 +382,8 @@ extern "C" int ptc_batch_norm_act_fwd(const void* x, int64_t n, int c, int dtype
   PTC_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), PTC_EINVAL, "ptc_batch_norm_act_fwd: buffers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
-#define BN_FWD(T, TY) return bn_fwd_typed<T, TY>(x, n, c, gamma, beta, eps, momentum, training, running_mean, running_var, act, y, save_mean, save_rstd, ws, s)
+  PTC_REQUIRE((uintptr_t)res % 16 == 0, PTC_EINVAL, "ptc_batch_norm_add_act_fwd: buffers must be 16-byte aligned");
+#define BN_FWD(T, TY) return bn_fwd_typed<T, TY>(x, n, c, gamma, beta, eps, momentum, training, running_mean, running_var, act, y, save_mean, save_rstd, ws, s, res)
   if (dtype == PTC_F32 && y_dtype == PTC_F32) BN_FWD(float, float);
   if (dtype == PTC_BF16 && y_dtype == PTC_BF16) BN_FWD(bf16_t, bf16_t);
   if (dtype == PTC_F16 && y_dtype == PTC_F16) BN_FWD(f16_t, f16_t);
@@ -380,9 +396,29 @@ extern "C" int ptc_batch_norm_act_fwd(const void* x, int64_t n, int c, int dtype
   return PTC_EUNSUPPORTED;
 }
 
+extern "C" int ptc_batch_norm_act_fwd(const void* x, int64_t n, int c, int dtype, const float* gamma, const float* beta, float eps,
+                                      float momentum, int training, float* running_mean, float* running_var, int act, void* y,
+                                      int y_dtype, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                                      ptc_stream_t stream) {
+  return bn_act_fwd_impl(x, nullptr, n, c, dtype, gamma, beta, eps, momentum, training, running_mean, running_var, act, y, y_dtype, save_mean,
+                         save_rstd, workspace, workspace_bytes, stream);
+}
+// y = act(BN(x) + res): the tail of a residual block (spconv_unet_v1m1_base.py:79-83: out = bn2(conv2(.)); out = relu(out + residual)) in
+// the BatchNorm's own apply pass -- the add and the activation are two more elementwise passes over [N, C] in the reference.  res has x's
+// dtype; the statistics are those of x alone.
+extern "C" int ptc_batch_norm_add_act_fwd(const void* x, const void* res, int64_t n, int c, int dtype, const float* gamma, const float* beta,
+                                          float eps, float momentum, int training, float* running_mean, float* running_var, int act,
+                                          void* y, int y_dtype, float* save_mean, float* save_rstd, void* workspace,
+                                          size_t workspace_bytes, ptc_stream_t stream) {
+  PTC_REQUIRE(res || n == 0, PTC_EINVAL, "ptc_batch_norm_add_act_fwd: null residual");
+  return bn_act_fwd_impl(x, res, n, c, dtype, gamma, beta, eps, momentum, training, running_mean, running_var, act, y, y_dtype, save_mean,
+                         save_rstd, workspace, workspace_bytes, stream);
+}
+
 template <typename T, typename TD>
 static int bn_bwd_typed(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                        int64_t n, int c, int training, int act, void* dx, float* dgamma, float* dbeta, char* ws, hipStream_t s) {
+                        int64_t n, int c, int training, int act, void* dx, float* dgamma, float* dbeta, char* ws, hipStream_t s,
+                        const void* res = nullptr, void* dres = nullptr) {
   float* partial = (float*)ws;
   float* coef = (float*)(ws + bn_partial_bytes(c));
   float* bcoef = coef + 4 * c;
@@ -390,7 +426,7 @@ static int bn_bwd_typed(const void* dy, const void* x, const float* gamma, const
   const BnPlan p = bn_plan(n, m.rpi);
   const BnStat st{gamma, beta, mean, rstd};
   hipLaunchKernelGGL((bn_reduce_kernel<T, TD, 1>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, st, n, c, act,
-                     p.rows_per_group, partial);
+                     p.rows_per_group, partial, (const T*)res);
   PTC_CHECK_LAUNCH("bn_reduce_kernel<bwd>");
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)ptc_cdiv(c, BN_FIN_CH)), dim3(BN_THREADS), 0, s, partial, p.groups, n, c, st,
                      training, dgamma, dbeta, bcoef);
@@ -399,15 +435,15 @@ static int bn_bwd_typed(const void* dy, const void* x, const float* gamma, const
   if (grid > 256 * 16) grid = 256 * 16;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TD>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, st, bcoef, n, c,
-                     act, (T*)dx);
+                     act, (T*)dx, (const T*)res, (T*)dres);
   PTC_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return PTC_OK;
 }
 
-extern "C" int ptc_batch_norm_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
-                                      const float* save_mean, const float* save_rstd, int64_t n, int c, int training, int act,
-                                      void* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                                      ptc_stream_t stream) {
+static int bn_act_bwd_impl(const void* dy, int dy_dtype, const void* x, const void* res, int x_dtype, const float* gamma, const float* beta,
+                           const float* save_mean, const float* save_rstd, int64_t n, int c, int training, int act,
+                           void* dx, void* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                           ptc_stream_t stream) {
   PTC_REQUIRE(n >= 0 && ptc_batch_norm_supported(c, x_dtype), PTC_EUNSUPPORTED, "ptc_batch_norm_act_bwd: n=%lld c=%d dtype=%d unsupported",
               (long long)n, c, x_dtype);
   PTC_REQUIRE(act >= 0 && act <= 2, PTC_EINVAL, "ptc_batch_norm_act_bwd: bad activation %d", act);
@@ -420,7 +456,8 @@ extern "C" int ptc_batch_norm_act_bwd(const void* dy, int dy_dtype, const void* 
   PTC_REQUIRE(dy && x && dx && save_mean && save_rstd && workspace, PTC_EINVAL, "ptc_batch_norm_act_bwd: null buffer");
   PTC_REQUIRE(workspace_bytes >= ptc_batch_norm_workspace_bytes(n, c), PTC_EWORKSPACE, "ptc_batch_norm_act_bwd: workspace too small");
   char* ws = (char*)workspace;
-#define BN_BWD(T, TD) return bn_bwd_typed<T, TD>(dy, x, gamma, beta, save_mean, save_rstd, n, c, training, act, dx, dgamma, dbeta, ws, s)
+  PTC_REQUIRE(((uintptr_t)res % 16 == 0) && ((uintptr_t)dres % 16 == 0), PTC_EINVAL, "ptc_batch_norm_add_act_bwd: buffers must be 16-byte aligned");
+#define BN_BWD(T, TD) return bn_bwd_typed<T, TD>(dy, x, gamma, beta, save_mean, save_rstd, n, c, training, act, dx, dgamma, dbeta, ws, s, res, dres)
   if (x_dtype == PTC_F32 && dy_dtype == PTC_F32) BN_BWD(float, float);
   if (x_dtype == PTC_BF16 && dy_dtype == PTC_BF16) BN_BWD(bf16_t, bf16_t);
   if (x_dtype == PTC_F16 && dy_dtype == PTC_F16) BN_BWD(f16_t, f16_t);
@@ -431,6 +468,23 @@ extern "C" int ptc_batch_norm_act_bwd(const void* dy, int dy_dtype, const void* 
 #undef BN_BWD
   ptc_set_error("ptc_batch_norm_act_bwd: unsupported dtype pair (%d, %d)", x_dtype, dy_dtype);
   return PTC_EUNSUPPORTED;
+}
+
+extern "C" int ptc_batch_norm_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
+                                      const float* save_mean, const float* save_rstd, int64_t n, int c, int training, int act,
+                                      void* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                      ptc_stream_t stream) {
+  return bn_act_bwd_impl(dy, dy_dtype, x, nullptr, x_dtype, gamma, beta, save_mean, save_rstd, n, c, training, act, dx, nullptr, dgamma, dbeta,
+                         workspace, workspace_bytes, stream);
+}
+// backward of ptc_batch_norm_add_act_fwd: dres (x's dtype) = dy * act'(BN(x) + res), dx / dgamma / dbeta the BatchNorm backward of that
+extern "C" int ptc_batch_norm_add_act_bwd(const void* dy, int dy_dtype, const void* x, const void* res, int x_dtype, const float* gamma,
+                                          const float* beta, const float* save_mean, const float* save_rstd, int64_t n, int c, int training,
+                                          int act, void* dx, void* dres, float* dgamma, float* dbeta, void* workspace,
+                                          size_t workspace_bytes, ptc_stream_t stream) {
+  PTC_REQUIRE((res && dres) || n == 0, PTC_EINVAL, "ptc_batch_norm_add_act_bwd: null residual buffers");
+  return bn_act_bwd_impl(dy, dy_dtype, x, res, x_dtype, gamma, beta, save_mean, save_rstd, n, c, training, act, dx, dres, dgamma, dbeta,
+                         workspace, workspace_bytes, stream);
 }
 
 // out[c] (fp32) = sum over rows of x[n, c].  Replaces `grad.float().sum(0)` (the bias gradient of the CPE

@@ -769,12 +769,14 @@ def lovasz_softmax(logits: torch.Tensor, target: torch.Tensor, ignore_index: int
 # ------------------------------------------------------------------------------------------------
 class _BatchNormAct(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act, res):
         # dense rows for the kernels -- AND for the tensor the backward reads: a Linear / conv output with a channel count that is not a
         # multiple of 16 arrives as a column slice of the padded GEMM output (36 of 48 columns: LitePT; found on hardware in round 3)
         x = x.contiguous()
-        y, mean, rstd = ops.batch_norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, act)
-        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        if res is not None:
+            res = res.contiguous()
+        y, mean, rstd = ops.batch_norm_act_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, act, res=res)
+        ctx.save_for_backward(x, weight, bias, mean, rstd, res)
         ctx.training, ctx.act = training, act
         ctx.mark_non_differentiable()
         return y
@@ -782,18 +784,20 @@ class _BatchNormAct(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, weight, bias, mean, rstd = ctx.saved_tensors
-        dx, dg, db = ops.batch_norm_act_bwd(dy, x, weight, bias, mean, rstd, ctx.training, ctx.act, want_affine=weight is not None)
+        x, weight, bias, mean, rstd, res = ctx.saved_tensors
+        out = ops.batch_norm_act_bwd(dy, x, weight, bias, mean, rstd, ctx.training, ctx.act, want_affine=weight is not None, res=res)
+        dx, dg, db = out[:3]
         if weight is not None:
             dg, db = dg.to(weight.dtype), db.to(weight.dtype)
-        return dx, dg, db, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, (out[3] if res is not None else None)
 
 
 def batch_norm_act(x: torch.Tensor, weight, bias, running_mean, running_var, training: bool, momentum: float, eps: float,
-                   act: str = "none") -> torch.Tensor:
-    """act(F.batch_norm(x, ...)) over the rows of [N, C] (act in {"none", "gelu", "relu"}), statistics in
-    fp32/fp64, output in x's dtype; backward recomputes the pre-activation (nothing but x is saved)."""
-    return _BatchNormAct.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps), act)
+                   act: str = "none", residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(F.batch_norm(x, ...) [+ residual]) over the rows of [N, C] (act in {"none", "gelu", "relu"}), statistics in
+    fp32/fp64, output in x's dtype; backward recomputes the pre-activation (nothing but x and the residual is saved).  With
+    `residual` (x's shape and dtype): the tail of a residual block, spconv_unet_v1m1_base.py:79-83, in the BatchNorm's apply pass."""
+    return _BatchNormAct.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps), act, residual)
 
 
 # ------------------------------------------------------------------------------------------------

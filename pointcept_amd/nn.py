@@ -70,28 +70,69 @@ class LayerNorm(nn.LayerNorm):
         return y if out_dtype is None else y.to(out_dtype)
 
 
+# `num_batches_tracked += 1` is one tiny launch per BatchNorm site and step (59 in SpUNet-v1m1, 0.27 ms of its 27.8 ms step in
+# profiles/r04_g_spunet_kernel_stats.csv).  A model's forward may collect them: inside `batched_bn_counters()` the modules append
+# their counter instead of incrementing it, and the context adds 1 to all of them in ONE multi-tensor launch when it closes.
+_bn_pending = None
+
+
+class batched_bn_counters:
+    def __enter__(self):
+        global _bn_pending
+        from . import config
+        self._prev, _bn_pending = _bn_pending, ([] if config.FUSE_BN_TAIL else None)
+        return self
+
+    def __exit__(self, *exc):
+        global _bn_pending
+        pending, _bn_pending = _bn_pending, self._prev
+        if not pending:
+            return False
+        seen, once = set(), []
+        for t in pending:
+            if id(t) in seen:
+                t.add_(1)                      # a module that ran twice in the forward: its second count separately
+            else:
+                seen.add(id(t))
+                once.append(t)
+        if len(once) == 1:
+            once[0].add_(1)
+        elif once:
+            torch._foreach_add_(once, 1)
+        return False
+
+
 class BatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d on [N, C] point features (ptv3m1:581; spconv_unet_v1m1_base.py:110) with the activation
     that FOLLOWS it in the reference absorbed (`act`): the container marks the pair with `absorb_activations`,
     the activation module stays in place (state-dict / module indices unchanged) and becomes a no-op."""
     act = "none"
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, act: Optional[str] = None) -> torch.Tensor:
+        """residual / act (SpUNet's BasicBlock): act(BN(x) + residual) in the same pass, spconv_unet_v1m1_base.py:79-83"""
         _require_gpu(x, "BatchNorm1d")
+        act = self.act if act is None else act
         use = (self.affine and x.is_cuda and x.dim() == 2 and x.shape[0] > 1 and ops.batch_norm_supported(x.shape[1], x.dtype)
                and (self.training or self.running_mean is not None))
+        if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape):
+            use = False
         if not use:
             y = super().forward(x)
-            return y if self.act == "none" else (F.gelu(y) if self.act == "gelu" else F.relu(y))
+            if residual is not None:
+                y = y + residual
+            return y if act == "none" else (F.gelu(y) if act == "gelu" else F.relu(y))
         training = self.training or (self.running_mean is None and self.running_var is None)
         momentum = 0.0 if self.momentum is None else self.momentum
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+            if _bn_pending is not None and self.momentum is not None:
+                _bn_pending.append(self.num_batches_tracked)
+            else:
+                self.num_batches_tracked.add_(1)
             if self.momentum is None:   # cumulative moving average (host value needed: not used by the reference configs)
                 momentum = 1.0 / float(self.num_batches_tracked)
         rm = self.running_mean if (not self.training or self.track_running_stats) else None
         rv = self.running_var if (not self.training or self.track_running_stats) else None
-        return PF.batch_norm_act(x, self.weight, self.bias, rm, rv, training, momentum, self.eps, self.act)
+        return PF.batch_norm_act(x, self.weight, self.bias, rm, rv, training, momentum, self.eps, act, residual)
 
 
 class GELU(nn.GELU):

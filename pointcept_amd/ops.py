@@ -1030,10 +1030,15 @@ def batch_norm_supported(c: int, dtype: torch.dtype) -> bool:
 
 
 def batch_norm_act_fwd(x, gamma, beta, running_mean, running_var, training: bool, momentum: float, eps: float, act: str,
-                       out_dtype: Optional[torch.dtype] = None):
-    """-> (y [N,C] out_dtype, save_mean [C] f32, save_rstd [C] f32); running statistics updated in place."""
-    require_cuda(x, gamma, beta, running_mean, running_var)
+                       out_dtype: Optional[torch.dtype] = None, res: Optional[torch.Tensor] = None):
+    """-> (y [N,C] out_dtype, save_mean [C] f32, save_rstd [C] f32); running statistics updated in place.  res [N,C] (x's dtype):
+    y = act(BN(x) + res), the tail of a residual block in the same apply pass (ptc_batch_norm_add_act_fwd)."""
+    require_cuda(x, gamma, beta, running_mean, running_var, res)
     x = x.contiguous()
+    if res is not None:
+        if res.shape != x.shape or res.dtype != x.dtype:
+            raise PtcoreError("batch_norm_act_fwd: the residual must have x's shape and dtype")
+        res = res.contiguous()
     n, c = x.shape
     out_dtype = out_dtype or x.dtype
     y = torch.empty((n, c), dtype=out_dtype, device=x.device)
@@ -1046,15 +1051,21 @@ def batch_norm_act_fwd(x, gamma, beta, running_mean, running_var, training: bool
     for t in (running_mean, running_var):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             raise PtcoreError("running statistics must be contiguous fp32")
+    if res is not None:
+        check(lib().ptc_batch_norm_add_act_fwd(ptr(x), ptr(res), n, c, dtype_code(x), ptr(g), ptr(b), float(eps), float(momentum),
+                                               int(bool(training)), ptr(running_mean), ptr(running_var), ACT_CODES[act], ptr(y),
+                                               dtype_code(y), ptr(mean), ptr(rstd), ptr(ws), nbytes, stream_ptr()),
+              "ptc_batch_norm_add_act_fwd")
+        return y, mean, rstd
     check(lib().ptc_batch_norm_act_fwd(ptr(x), n, c, dtype_code(x), ptr(g), ptr(b), float(eps), float(momentum), int(bool(training)),
                                        ptr(running_mean), ptr(running_var), ACT_CODES[act], ptr(y), dtype_code(y), ptr(mean),
                                        ptr(rstd), ptr(ws), nbytes, stream_ptr()), "ptc_batch_norm_act_fwd")
     return y, mean, rstd
 
 
-def batch_norm_act_bwd(dy, x, gamma, beta, mean, rstd, training: bool, act: str, want_affine: bool = True):
-    """-> (dx [N,C] x.dtype, dgamma [C] f32 | None, dbeta [C] f32 | None)"""
-    require_cuda(dy, x, mean, rstd)
+def batch_norm_act_bwd(dy, x, gamma, beta, mean, rstd, training: bool, act: str, want_affine: bool = True, res: Optional[torch.Tensor] = None):
+    """-> (dx [N,C] x.dtype, dgamma [C] f32 | None, dbeta [C] f32 | None); with res (the forward's residual): a fourth result dres [N,C]"""
+    require_cuda(dy, x, mean, rstd, res)
     dy, x = dy.contiguous(), x.contiguous()
     n, c = x.shape
     dx = torch.empty_like(x)
@@ -1064,6 +1075,13 @@ def batch_norm_act_bwd(dy, x, gamma, beta, mean, rstd, training: bool, act: str,
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     g = None if gamma is None else gamma.float().contiguous()
     b = None if beta is None else beta.float().contiguous()
+    if res is not None:
+        res = res.contiguous()
+        dres = torch.empty_like(x)
+        check(lib().ptc_batch_norm_add_act_bwd(ptr(dy), dtype_code(dy), ptr(x), ptr(res), dtype_code(x), ptr(g), ptr(b), ptr(mean), ptr(rstd), n, c,
+                                               int(bool(training)), ACT_CODES[act], ptr(dx), ptr(dres), ptr(dg), ptr(db), ptr(ws), nbytes,
+                                               stream_ptr()), "ptc_batch_norm_add_act_bwd")
+        return dx, dg, db, dres
     check(lib().ptc_batch_norm_act_bwd(ptr(dy), dtype_code(dy), ptr(x), dtype_code(x), ptr(g), ptr(b), ptr(mean), ptr(rstd), n, c,
                                        int(bool(training)), ACT_CODES[act], ptr(dx), ptr(dg), ptr(db), ptr(ws), nbytes, stream_ptr()),
           "ptc_batch_norm_act_bwd")

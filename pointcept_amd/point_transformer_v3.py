@@ -695,6 +695,10 @@ class PointTransformerV3(PointModule):
                 self.dec.add(module=dec, name=f"dec{s}")
 
     def forward(self, data_dict):
+        with PNN.batched_bn_counters():          # the BatchNorm sites' `num_batches_tracked += 1` in one launch
+            return self._forward(data_dict)
+
+    def _forward(self, data_dict):
         point = Point(data_dict)
         point.serialization(order=self.order, shuffle_orders=self.shuffle_orders)
         self._prefetch_pool_levels(point)

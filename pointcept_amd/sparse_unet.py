@@ -16,6 +16,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from . import config as _config
 from . import nn as PNN
 from . import spconv_api as spconv
 from .structure import offset2batch
@@ -54,6 +55,8 @@ class BasicBlock(spconv.SparseModule):
         h = self.bn1(out.features)
         out = out.replace_feature(h if getattr(self.bn1, "act", "none") == "relu" else self.relu(h))
         out = self.conv2(out)
+        if isinstance(self.bn2, PNN.BatchNorm1d) and _config.FUSE_BN_TAIL:      # relu(bn2(.) + residual) in the BatchNorm's apply pass (:79-83)
+            return out.replace_feature(self.bn2(out.features, residual=self.proj(residual).features, act="relu"))
         out = out.replace_feature(self.bn2(out.features))
         out = out.replace_feature(self.relu(out.features + self.proj(residual).features))
         return out
@@ -115,6 +118,10 @@ class SpUNetBase(nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     def forward(self, input_dict):
+        with PNN.batched_bn_counters():          # the 59 `num_batches_tracked += 1` of a training step in one launch
+            return self._forward(input_dict)
+
+    def _forward(self, input_dict):
         grid_coord, feat, offset = input_dict["grid_coord"], input_dict["feat"], input_dict["offset"]
         batch = offset2batch(offset)
         from . import config, ops

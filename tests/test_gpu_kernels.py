@@ -1282,6 +1282,46 @@ def test_batch_norm_act_train(cuda, dtype, n, c, act):
     assert torch.equal(again, got.detach()), "bit-reproducible"
 
 
+@pytest.mark.parametrize("dtype,n,c", [(torch.float32, 3000, 64), (torch.bfloat16, 5003, 96), (torch.float16, 2048, 32)])
+def test_batch_norm_add_act_is_the_residual_block_tail(cuda, dtype, n, c):
+    """relu(BN(x) + residual) in the BatchNorm's apply pass (ptc_batch_norm_add_act_{fwd,bwd}; spconv_unet_v1m1_base.py:79-83 runs it as
+    bn2, an add and a ReLU): output, dx, d residual, dgamma, dbeta and the running statistics against torch in fp32 on the same rounded
+    inputs; the residual does not enter the statistics; bit-reproducible."""
+    from pointcept_amd import functional as PF
+
+    g = torch.Generator().manual_seed(n * 3 + c)
+    x = (torch.randn(n, c, generator=g) * 2 + 0.7).to(dtype)
+    r = (torch.randn(n, c, generator=g) * 1.5).to(dtype)
+    w, b = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    dy = torch.randn(n, c, generator=g).to(dtype)
+    rm0, rv0 = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    xr, rr = x.float().clone().requires_grad_(True), r.float().clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    ref = torch.relu(torch.nn.functional.batch_norm(xr, rm, rv, wr, br, True, 0.01, 1e-3) + rr)
+    ref.backward(dy.float())
+    xg, rg = x.to(cuda).requires_grad_(True), r.to(cuda).requires_grad_(True)
+    wg, bg = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    rmg, rvg = rm0.to(cuda), rv0.to(cuda)
+    got = PF.batch_norm_act(xg, wg, bg, rmg, rvg, True, 0.01, 1e-3, "relu", rg)
+    got.backward(dy.to(cuda))
+    assert got.dtype == dtype and rg.grad.dtype == dtype
+    lo = dtype != torch.float32
+    _close("bnr_y", got, ref, 2.0 ** -7 if lo else 2e-5, 2e-2 if lo else 2e-5)
+    _close("bnr_running_mean", rmg, rm, 1e-5, 1e-5)
+    _close("bnr_running_var", rvg, rv, 1e-5, 1e-5)
+    # the ReLU mask is decided on the fp32 pre-activation here and in the reference: elements within rounding of zero may differ
+    mism = ((got.float().cpu() > 0) != (ref > 0)).float().mean()
+    assert float(mism) < 1e-3, float(mism)
+    gmax = float(xr.grad.abs().max())
+    _close("bnr_dx", xg.grad, xr.grad, 2.0 ** -6 if lo else 1e-4, (2e-2 if lo else 1e-4) * max(gmax, 1e-3))
+    _close("bnr_dres", rg.grad, rr.grad, 2.0 ** -7 if lo else 1e-6, 1e-6)
+    _close("bnr_dgamma", wg.grad, wr.grad, 1e-3, 1e-3 * float(wr.grad.abs().max()) + 1e-4)
+    _close("bnr_dbeta", bg.grad, br.grad, 1e-3, 1e-3 * float(br.grad.abs().max()) + 1e-4)
+    again = PF.batch_norm_act(x.to(cuda), w.to(cuda), b.to(cuda), rm0.to(cuda), rv0.to(cuda), True, 0.01, 1e-3, "relu", r.to(cuda))
+    assert torch.equal(again, got.detach()), "bit-reproducible"
+
+
 def test_batch_norm_act_eval_and_module(cuda):
     """eval mode uses the running statistics; the nn.Module wrapper keeps nn.BatchNorm1d's state dict."""
     from pointcept_amd import nn as PNN

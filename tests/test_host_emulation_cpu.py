@@ -186,6 +186,7 @@ EMULATED_GPU_TESTS = [
     ("test_layer_norm_fwd_bwd", dict(c=64, xdt=torch.float32, ydt=torch.float32)),
     ("test_add_norm_fused_joint", dict(c=32, mode="ln_add_ln")), ("test_add_norm_fused_joint", dict(c=128, mode="add_ln_scaled")),
     ("test_batch_norm_act_train", dict(dtype=torch.float32, n=3000, c=64, act="gelu")),
+    ("test_batch_norm_add_act_is_the_residual_block_tail", dict(dtype=torch.bfloat16, n=5003, c=96)),
     ("test_pointops_knn_query", dict(nsample=3)), ("test_seg_eval_hist_matches_the_reference_formula", dict(dtype=torch.float32)),
     ("test_pointops_edge_operators", dict(c=8, w_c=4)), ("test_pointops_edge_operators", dict(c=3, w_c=1)), ("test_pointops_edge_operators", dict(c=6, w_c=2)),
     # MFMA kernels: implicit-GEMM convolution / Linear (16x16x32 bf16 / f16, 16x16x4 f32) and window attention (32x32x16 bf16)
