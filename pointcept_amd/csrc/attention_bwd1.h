@@ -32,7 +32,8 @@
 
 #define AT1_KT 4                     // key tiles per wave: 8 waves x 4 x 32 = AT_MAX_L keys
 #ifndef AT1_MIN_UNITS
-#define AT1_MIN_UNITS 256            // (sequence, head) units from which a launch takes this kernel: one workgroup per CU
+#define AT1_MIN_UNITS 176            // (sequence, head) units from which a launch takes this kernel (one workgroup per CU): 192 units 80 us
+                                     // against 91 for the split kernels, 128 units 76 against 65 (profiles/r04_zc_attn_small_launches.txt)
 #endif
 #define AT1_SLICE 2048               // bytes of a wave's dS slice and of one 32 x 16 fp32 dQ partial
 #ifndef AT1_PIPE

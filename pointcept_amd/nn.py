@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import threading
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -73,19 +75,18 @@ class LayerNorm(nn.LayerNorm):
 # `num_batches_tracked += 1` is one tiny launch per BatchNorm site and step (59 in SpUNet-v1m1, 0.27 ms of its 27.8 ms step in
 # profiles/r04_g_spunet_kernel_stats.csv).  A model's forward may collect them: inside `batched_bn_counters()` the modules append
 # their counter instead of incrementing it, and the context adds 1 to all of them in ONE multi-tensor launch when it closes.
-_bn_pending = None
+_bn_tls = threading.local()       # per thread: nn.DataParallel replicas run their forwards concurrently
 
 
 class batched_bn_counters:
     def __enter__(self):
-        global _bn_pending
         from . import config
-        self._prev, _bn_pending = _bn_pending, ([] if config.FUSE_BN_TAIL else None)
+        self._prev = getattr(_bn_tls, "pending", None)
+        _bn_tls.pending = [] if config.FUSE_BN_TAIL else None
         return self
 
     def __exit__(self, *exc):
-        global _bn_pending
-        pending, _bn_pending = _bn_pending, self._prev
+        pending, _bn_tls.pending = _bn_tls.pending, self._prev
         if not pending:
             return False
         seen, once = set(), []
@@ -124,8 +125,9 @@ class BatchNorm1d(nn.BatchNorm1d):
         training = self.training or (self.running_mean is None and self.running_var is None)
         momentum = 0.0 if self.momentum is None else self.momentum
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            if _bn_pending is not None and self.momentum is not None:
-                _bn_pending.append(self.num_batches_tracked)
+            pending = getattr(_bn_tls, "pending", None)
+            if pending is not None and self.momentum is not None:
+                pending.append(self.num_batches_tracked)
             else:
                 self.num_batches_tracked.add_(1)
             if self.momentum is None:   # cumulative moving average (host value needed: not used by the reference configs)

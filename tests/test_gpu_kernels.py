@@ -882,7 +882,7 @@ def test_layer_norm_empty_and_unsupported(cuda):
 @pytest.mark.parametrize("lens,H", [([1024], 2), ([1024, 1024, 330], 4), ([48, 48, 17], 2), ([1, 2, 31, 32, 33, 65], 3),
                                     ([128] * 5, 8), ([1000, 24], 32)])
 def test_attention_fwd_bwd(cuda, lens, H, monkeypatch):
-    """forward and both forms of the backward (the two split kernels; the one-pass kernel of attention_bwd1.h, which launches of >= 256
+    """forward and both forms of the backward (the two split kernels; the one-pass kernel of attention_bwd1.h, which launches of >= 176
     (sequence, head) units take by default) against the fp32 oracle; dK / dV of the two forms are the same sums in the same order
     (bit-identical), dQ differs in the order of its partial sums only."""
     from pointcept_amd import ops

@@ -395,7 +395,7 @@ def main():
             bench_ln(rows, n, c, res["ln"])
         bench_ln(rows, 819200, 64, res["ln"])
     if want("attn"):
-        for n_seq, H in ((800, 2), (800, 4), (200, 4), (48, 8), (16, 16)):
+        for n_seq, H in ((800, 2), (800, 4), (200, 4), (48, 8), (16, 16), (12, 16), (8, 16), (3, 32)):
             bench_attention(rows, n_seq, H, res["attn"])
     if "attn_rpe" in only:
         res["attn_rpe"] = []
