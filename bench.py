@@ -148,6 +148,18 @@ def attention_roofline(device, scenes: int, points: int):
            "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
            "launch_ms": round(ms, 4), "shape": {"n_seq": n_seq, "L": L, "H": H, "D": D},
            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": T * H * D * 2 * 4}
+    # the backward at the same shape (side key; SURVEY 8(d): 10 L^2 D per (sequence, head) with recomputation -- the one-pass kernel of
+    # csrc/attention_bwd1.h evaluates S' / dP once and issues 8 L^2 D; priced at 8(d)'s figure all the same)
+    try:
+        o, lse = ops.attn_varlen_fwd(qkv, cu, L, scale)
+        do = torch.randn(T, H, D, generator=g).to(torch.bfloat16).to(device)
+        ms_b = _time_launches(lambda: ops.attn_varlen_bwd(qkv, o, do, lse, cu, L, scale), iters=20, warm=10)
+        fb = 10.0 * L * L * D * n_seq * H
+        out["backward"] = {"kernel": "attn_bwd1_kernel", "launch_ms": round(ms_b, 4), "achieved": round(fb / (ms_b * 1e-3) / 1e12, 2),
+                           "frac": round(fb / (ms_b * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": fb,
+                           "algorithmic_bytes_per_launch": T * H * D * 2 * 8}
+    except Exception as e:   # the side key must not take the roofline object with it
+        out["backward"] = {"error": repr(e)}
     # HBM bytes per launch of this kernel at this shape, from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on
     # gfx950 + WRITE_SIZE, separate --pmc runs: tools/gpu_session.sh roof); not re-measured inside bench.py
     try:
