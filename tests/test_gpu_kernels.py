@@ -1061,9 +1061,13 @@ def test_attention_with_fused_rope_equals_the_two_pass_form(cuda, lens, H, dtype
     # the two forms run the same fp32 rotation and round to the same dtype; the compiler may still contract the inlined sincos /
     # products of the two translation units differently (measured on the MI355X: 1 of 17 712 f16 gradient elements one ulp apart, bf16
     # and every forward tensor identical; the host emulation: everything identical): at most 0.1 % of the elements, at most two ulps (11 of 284 634 at the large shape)
+    # A rotated operand that lands one ulp apart perturbs every product of its token's row, so the bar of an element is two ulps of
+    # the LARGEST magnitude of its token (an element-relative bar fails on the small entries of such a row: 2^-11 absolute on an
+    # entry of 0.2 beside entries of 0.4, MI355X, round 4).
     def same(name, x, y):
         d = (x.float() - y.float()).abs()
-        ulp = (2.0 ** -6 if dtype == torch.bfloat16 else 2.0 ** -9) * torch.maximum(x.float().abs(), y.float().abs()).clamp_min(1e-3)      # two ulps
+        row = torch.maximum(x.float().abs(), y.float().abs()).flatten(1).amax(1).clamp_min(1e-3)
+        ulp = ((2.0 ** -6 if dtype == torch.bfloat16 else 2.0 ** -9) * row).reshape(-1, *([1] * (x.dim() - 1)))      # two ulps
         assert int((d > 0).sum()) <= max(1, x.numel() // 1000) and bool((d <= ulp).all()), (name, int((d > 0).sum()), float(d.max()))
 
     same("out", out, out2)
