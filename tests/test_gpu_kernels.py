@@ -1127,6 +1127,31 @@ def test_attention_other_head_dims_large_logits_and_limits(cuda):
     assert torch.isnan(o.float()).all() and torch.isnan(l).all()
 
 
+@pytest.mark.parametrize("one_pass", ["0", "1"])
+def test_attention_backward_poisons_a_sequence_longer_than_max_seqlen(cuda, one_pass, monkeypatch):
+    """head_dim 16, both forms of the backward: cu_seqlens built for longer windows than the caller's max_seqlen (the LDS images are
+    sized from max_seqlen) must not overrun anything -- the overlong sequence's gradient rows come back NaN (loud in the loss), every
+    other sequence's gradient is what it is without the bad neighbour."""
+    from pointcept_amd import ops
+
+    monkeypatch.setenv("PTC_AT_BWD1", one_pass)
+    g = torch.Generator().manual_seed(5)
+    lens, H = [40, 100, 64], 2                                        # max_seqlen = 64: the middle sequence is too long
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).to(cuda)
+    qkv = torch.randn(T, 3, H, 16, generator=g).to(torch.bfloat16).to(cuda)
+    dout = torch.randn(T, H, 16, generator=g).to(torch.bfloat16).to(cuda)
+    out, lse = ops.attn_varlen_fwd(qkv, cu, 64, 0.25)
+    d = ops.attn_varlen_bwd(qkv, out, dout, lse, cu, 64, 0.25)
+    assert torch.isnan(d[40:140].float()).all()
+    keep = torch.cat([torch.arange(0, 40), torch.arange(140, T)]).to(cuda)
+    cu_ok = torch.tensor([0, 40, 104], dtype=torch.int32).to(cuda)
+    q2 = qkv[keep].contiguous()
+    o2, l2 = ops.attn_varlen_fwd(q2, cu_ok, 64, 0.25)
+    d2 = ops.attn_varlen_bwd(q2, o2, dout[keep].contiguous(), l2, cu_ok, 64, 0.25)
+    assert torch.equal(d[keep], d2)
+
+
 def test_flash_attn_api_head_dim_18_autograd(cuda):
     """The call PT-v3m3 / LitePT make (head_dim 18) through the flash_attn mirror, with autograd."""
     from pointcept_amd.flash_attn_api import flash_attn_varlen_qkvpacked_func

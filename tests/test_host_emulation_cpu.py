@@ -212,6 +212,8 @@ EMULATED_GPU_TESTS = [
     ("test_attention_dropout_fwd_bwd", dict(lens=[200], H=2, p=0.5)), ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3, one_pass="0")),
     ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3, one_pass="1")),
     ("test_attention_fwd_bwd", dict(lens=[300, 1024], H=1)),
+    ("test_attention_backward_poisons_a_sequence_longer_than_max_seqlen", dict(one_pass="0")),
+    ("test_attention_backward_poisons_a_sequence_longer_than_max_seqlen", dict(one_pass="1")),
     ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.bfloat16)),
     ("test_attention_other_head_dims_fwd_bwd", dict(D=18, lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.float16)),
     ("test_attention_other_head_dims_fwd_bwd", dict(D=40, lens=[200, 100], H=2, dtype=torch.float16)),
