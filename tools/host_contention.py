@@ -31,6 +31,10 @@ def worker(a):
     sys.path.insert(0, ROOT)
     import bench
 
+    if a.pin > 0:      # what bench.py's self-launcher does for every rank (round 4, dp.pin_rank_to_cores): NUMA-local, disjoint core sets
+        from pointcept_amd import dp
+        dp.pin_rank_to_cores(a.rank, a.procs)
+
     sys.argv = [sys.argv[0], "--batch", str(a.scenes), "--points", str(a.points)]
     args = bench.parse()
     dev = torch.device("cuda:0")
@@ -61,16 +65,18 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--rank", type=int, default=-1)
     ap.add_argument("--dir", default="")
+    ap.add_argument("--pin", type=int, default=-1, help="1 / 0: workers pin themselves like bench.py's ranks (dp.pin_rank_to_cores); default: both")
     a = ap.parse_args()
     if a.rank >= 0:
         return worker(a)
     import tempfile
 
     print(f"host: {os.cpu_count()} cores; workload per process: PT-v3m1 base step, {a.scenes} x {a.points} voxels, {a.steps} timed steps")
-    for n in (1, a.procs):
+    for n, pin in ((1, 0), (a.procs, 0), (a.procs, 1)) if a.pin < 0 else ((1, a.pin), (a.procs, a.pin)):
         d = tempfile.mkdtemp(prefix="ptc_cont_")
         ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank", str(r), "--procs", str(n), "--dir", d, "--scenes", str(a.scenes),
-                                "--points", str(a.points), "--steps", str(a.steps)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                                "--points", str(a.points), "--steps", str(a.steps), "--pin", str(pin)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                               text=True)
               for r in range(n)]
         rows = []
         for p in ps:
@@ -78,7 +84,7 @@ def main():
             rows += [json.loads(l) for l in out.splitlines() if l.startswith("{")]
         cpu = [r["cpu_ms_per_step"] for r in rows]
         wall = [r["wall_ms_per_step"] for r in rows]
-        print(f"{n} concurrent process(es) on ONE GPU: host CPU time per step mean {sum(cpu) / len(cpu):.1f} ms (max {max(cpu):.1f}); "
+        print(f"{n} concurrent process(es) on ONE GPU, {'pinned to NUMA-local disjoint cores' if pin else 'unpinned'}: host CPU time per step mean {sum(cpu) / len(cpu):.1f} ms (max {max(cpu):.1f}); "
               f"wall per step mean {sum(wall) / len(wall):.1f} ms (max {max(wall):.1f})")
     print("reading: CPU time per step = the host work one rank needs; it must stay (about) the same under N = 8 for 8 ranks not to contend for the "
           "host's cores; on an 8-GPU node every rank has its own GPU, so its wall per step is the N = 1 wall (GPU-bound) as long as that CPU time fits under it")
