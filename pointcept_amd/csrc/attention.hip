@@ -489,6 +489,8 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
 // ================================================================================================
 // backward (round 4 form)
 // ================================================================================================
+// (The split form: launches below AT1_MIN_UNITS (sequence, head) units, which it fills the chip with by splitting units; larger launches
+//  take the one-pass kernel of attention_bwd1.h, included below.)
 // Two kernels as before (recompute P from q, k, lse; no atomics, no cross-wave reductions, bit-reproducible): dQ query-stationary, dK / dV
 // key-stationary.  What changed against rounds 1-3 (14 MFMAs of 32 cycles per (query tile, key tile) pair over the two kernels, and
 // v_exp_f32 does not overlap with them: 448 + ~150 cycles of floor per pair and SIMD against 890 measured, profiles/r03_p_attn_pmc.json):
@@ -847,7 +849,8 @@ extern "C" int ptc_attn_varlen_bwd(const void* qkv, const void* out, const void*
   const int qs = at_split_host(n_units, lp_max);
   const unsigned grid = (unsigned)(8 * ((n_units * qs + 7) / 8));
   // (s_setprio on half of the waves, as in the forward: measured neutral to harmful here, profiles/r02_h_attn_variants.txt; a two-stage
-  //  software pipeline at one workgroup per CU: slower, profiles/r02_o_slp_ab.txt; the single-pass backward: 2.1-2.3 ms against 1.56, r01_w/x)
+  //  software pipeline at one workgroup per CU: slower, profiles/r02_o_slp_ab.txt; round 1's single-pass backward -- 32x32 MFMAs throughout, dQ
+  //  accumulated in LDS tiles under a turn counter -- was 2.1-2.3 ms against 1.56, r01_w/x: the one-pass kernel above is a different design)
 #define AT_BWD_CASE(LP, F16)                                                                                                        \
   if ((LP == 0 ? lp_max != 1024 : lp_max == LP) && (dtype == PTC_F16) == F16) {                                                                                                             \
     rc = allow_big_lds((attn_bwd_dq_kernel<LP, F16>), dq_lds_bytes(lp_max));                                                           \
