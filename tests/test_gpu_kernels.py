@@ -1524,6 +1524,41 @@ def test_full_size_attention_properties(cuda):
     assert float(dqkv[:, 1].float().abs().max()) <= 3e-2 * scale
 
 
+def test_full_size_attention_backward_forms_and_linearity(cuda, monkeypatch):
+    """800 sequences x 1024 x 4 heads, the launch the bench step makes most: (a) the one-pass backward (attention_bwd1.h, the default at
+    this size) is bit-reproducible and its dK / dV are bit-identical to the two split kernels'; dQ -- the same products, summed as eight
+    per-wave partials -- agrees with theirs to the rounding of its bf16 output; (b) exact linearity in dO under a power-of-two factor
+    (every product of the backward is linear in dO or in delta = rowsum(dO . O); scaling by 4 is exact in bf16 and fp32); (c) sequences are
+    independent: reversing the order of the sequences reverses the gradient rows and changes nothing else."""
+    from pointcept_amd import ops
+
+    n_seq, L, H = 800, 1024, 4
+    T = n_seq * L
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(T, 3, H, 16, generator=g).to(torch.bfloat16).to(cuda)
+    dout = torch.randn(T, H, 16, generator=g).to(torch.bfloat16).to(cuda)
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32).to(cuda)
+    out, lse = ops.attn_varlen_fwd(qkv, cu, L, 0.25)
+    monkeypatch.delenv("PTC_AT_BWD1", raising=False)
+    d1 = ops.attn_varlen_bwd(qkv, out, dout, lse, cu, L, 0.25)                 # default at 3200 units: the one-pass kernel
+    assert torch.equal(d1, ops.attn_varlen_bwd(qkv, out, dout, lse, cu, L, 0.25)), "not bit-reproducible"
+    monkeypatch.setenv("PTC_AT_BWD1", "1")
+    assert torch.equal(d1, ops.attn_varlen_bwd(qkv, out, dout, lse, cu, L, 0.25)), "the default at this size is not the one-pass kernel"
+    monkeypatch.setenv("PTC_AT_BWD1", "0")
+    d0 = ops.attn_varlen_bwd(qkv, out, dout, lse, cu, L, 0.25)
+    monkeypatch.delenv("PTC_AT_BWD1", raising=False)
+    assert torch.equal(d1[:, 1:], d0[:, 1:]), "dK / dV differ between the two forms"
+    dq1, dq0 = d1[:, 0].float(), d0[:, 0].float()
+    assert float((dq1 - dq0).abs().max()) <= 2.0 ** -7 * float(dq0.abs().max())
+    assert float((dq1 - dq0).norm() / dq0.norm()) < 2.0 ** -9
+    d4 = ops.attn_varlen_bwd(qkv, out, dout * 4, lse, cu, L, 0.25)
+    assert torch.equal(d4.float(), d1.float() * 4), "the backward is not exactly linear in dO"
+    rev = torch.arange(n_seq - 1, -1, -1, device=cuda)
+    perm = (rev[:, None] * L + torch.arange(L, device=cuda)[None, :]).reshape(-1)
+    dr = ops.attn_varlen_bwd(qkv[perm].contiguous(), out[perm].contiguous(), dout[perm].contiguous(), lse[:, perm].contiguous(), cu, L, 0.25)
+    assert torch.equal(dr, d1[perm])
+
+
 @pytest.mark.parametrize("n", [1, 5, 17, 33, 129])
 def test_conv_tiny_inputs(cuda, n):
     """row counts below one tile / one workgroup, through the chunked-pipeline kernel and the weight gradient"""
