@@ -25,7 +25,9 @@
 // pipe 54 % busy, matrix pipe 24 % (r04_z_roof_pmc.json).  Timing probes with parts cut out: the per-query-tile barrier + reduction
 // costs 8 % of the kernel, the dS round trip + dQ products 8 %.  Measured and dropped: a software pipeline that issues S' of pair j + 1
 // and dQ of pair j - 1 ahead of pair j's vector work (1136 us; with a sched_group_barrier sequence 1185 us: the VALU -> MFMA operand
-// hazards cost more s_nop than the shadows hide), and the form without the deferral below (1186 us).
+// hazards cost more s_nop than the shadows hide), the form without the deferral below (1186 us), the next query tile's operands requested
+// before the barrier of the current one (1150 against 1100 us in one session, profiles/r04_zt_attn_one_pass_prefetch_setprio.txt: two
+// more registers spill inside the loop), s_setprio 1 on the second-dispatched half of the waves (no change).
 // LDS: Q [lp][16] | dO [lp][16] | -lse log2 e [lp] | -delta [lp] | dS slices 8 x 2 x 2 KB | dQ partials 2 x 8 x 2 KB = 72 lp + 64 KB (136 KB at
 // 1024): one workgroup of 8 waves per CU, two waves per SIMD.
 #pragma once
@@ -146,14 +148,16 @@ attn_bwd1_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ 
   }
   __syncthreads();
 
-  for (int qt = 0; qt < n_tiles; ++qt) {
+  // the operands of a query tile: row-major and transposed fragments of Q / dO, -lse / -delta of the lane's 16 queries (four runs of
+  // four consecutive rows, broadcast reads) as the C operands of S' / dP
+  s16x8 qf, dof, qtf, dotf;
+  f32x16 cl, cd;
+  auto load_q_tile = [&](int qt) {
     const int o = qt * 1024;
-    const s16x8 qf = *reinterpret_cast<const s16x8*>(Qsm + rmo + o);
-    const s16x8 dof = *reinterpret_cast<const s16x8*>(Dsm + rmo + o);
-    const s16x8 qtf = ld_tr_pair(Qsm + ta.lo + o, Qsm + ta.hi + o);                    // Q^T[d][query slots]
-    const s16x8 dotf = ld_tr_pair(Dsm + ta.lo + o, Dsm + ta.hi + o);                   // dO^T[d][query slots]
-    // C operands: -lse / -delta of the lane's 16 queries = four runs of four consecutive rows (broadcast reads)
-    f32x16 cl, cd;
+    qf = *reinterpret_cast<const s16x8*>(Qsm + rmo + o);
+    dof = *reinterpret_cast<const s16x8*>(Dsm + rmo + o);
+    qtf = ld_tr_pair(Qsm + ta.lo + o, Qsm + ta.hi + o);                    // Q^T[d][query slots]
+    dotf = ld_tr_pair(Dsm + ta.lo + o, Dsm + ta.hi + o);                   // dO^T[d][query slots]
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
       const at_f32x4 l4 = *reinterpret_cast<const at_f32x4*>(nl + qt * 32 + 8 * r4 + 4 * h2);
@@ -161,6 +165,9 @@ attn_bwd1_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 4; ++e) { cl[4 * r4 + e] = l4[e]; cd[4 * r4 + e] = d4[e]; }
     }
+  };
+  for (int qt = 0; qt < n_tiles; ++qt) {
+    load_q_tile(qt);
     at_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;    // dQ^T[d = 4 g + e][q = 32 qt + (0 | 16) + n], summed over the wave's key tiles
     if (AT1_PIPE && n_own == AT1_KT) {
       // full windows: one straight-line body for the wave's four pairs.  The dS tile of pair j goes to slice j & 1 and its transposed reads
