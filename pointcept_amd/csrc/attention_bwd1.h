@@ -27,7 +27,8 @@
 // and dQ of pair j - 1 ahead of pair j's vector work (1136 us; with a sched_group_barrier sequence 1185 us: the VALU -> MFMA operand
 // hazards cost more s_nop than the shadows hide), the form without the deferral below (1186 us), the next query tile's operands requested
 // before the barrier of the current one (1150 against 1100 us in one session, profiles/r04_zt_attn_one_pass_prefetch_setprio.txt: two
-// more registers spill inside the loop), s_setprio 1 on the second-dispatched half of the waves (no change).
+// more registers spill inside the loop), s_setprio 1 on the second-dispatched half of the waves (no change), a barrier that waits for LDS traffic
+// only instead of __syncthreads' vmcnt(0) (1110 vs 1103 us: no change).
 // LDS: Q [lp][16] | dO [lp][16] | -lse log2 e [lp] | -delta [lp] | dS slices 8 x 2 x 2 KB | dQ partials 2 x 8 x 2 KB = 72 lp + 64 KB (136 KB at
 // 1024): one workgroup of 8 waves per CU, two waves per SIMD.
 #pragma once
