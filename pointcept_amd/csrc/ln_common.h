@@ -35,11 +35,34 @@ __device__ __forceinline__ void ln_store8(T* p, const float (&v)[LN_VEC]) {
   else reinterpret_cast<uint4*>(p)[0] = reinterpret_cast<uint4*>(o)[0];
 }
 
-// sum over the LPR lanes of a row group (LPR power of two, groups aligned)
+// sum over the LPR lanes of a row group (LPR power of two, groups aligned).  The butterfly steps inside a 16-lane row are DPP operands
+// of the add itself (quad_perm for partners 1 and 2 lanes away; row_half_mirror / row_mirror for the other quad / the other half
+// of the row: after the earlier steps every lane of a quad / half already holds that quad's / half's sum, so the mirrored lane carries the
+// same value as the lane 4 / 8 away) instead of __shfl_xor's ds_bpermute round trip with its five address instructions: the same additions
+// in the same order, bit for bit (round 4; LN_DPP 0 = the shuffle form, timing A/B: 60 -> 12 instructions per row of the backward joint,
+// no difference in the step -- these kernels wait for HBM, profiles/r04_zr_ln_dpp_ab.txt).  Steps of 16 / 32 lanes keep the shuffle.
+#ifndef LN_DPP
+#define LN_DPP 1
+#endif
+#if defined(__HIPCC__) && LN_DPP
+template <int CTRL>
+__device__ __forceinline__ float ln_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+#endif
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
+#if defined(__HIPCC__) && LN_DPP
+  if (LPR >= 2) v += ln_dpp<0xB1>(v);      // quad_perm [1, 0, 3, 2]
+  if (LPR >= 4) v += ln_dpp<0x4E>(v);      // quad_perm [2, 3, 0, 1]
+  if (LPR >= 8) v += ln_dpp<0x141>(v);     // row_half_mirror
+  if (LPR >= 16) v += ln_dpp<0x140>(v);    // row_mirror
+#pragma unroll
+  for (int d = 16; d < LPR; d <<= 1) v += __shfl_xor(v, d, 64);
+#else
 #pragma unroll
   for (int d = 1; d < LPR; d <<= 1) v += __shfl_xor(v, d, 64);
+#endif
   return v;
 }
 
