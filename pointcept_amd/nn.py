@@ -10,9 +10,8 @@ traded: the kernels accumulate in fp32 and round operands exactly where autocast
 """
 from __future__ import annotations
 
-from typing import Optional
-
 import threading
+from typing import Optional
 
 import torch
 import torch.nn as nn

@@ -1020,3 +1020,30 @@ def test_pointops2_offsets_to_pair_index():
     assert off.tolist() == [0, 3, 3, 5, 5, 5, 9, 9]
     assert torch.equal(p2._index_from_offsets(off, i0.numel()).long(), i0)
 
+
+
+def test_batched_bn_counters_context(monkeypatch):
+    """nn.batched_bn_counters: counters appended inside the context get +1 each when it closes (one multi-tensor launch), a counter that
+    was appended twice gets +2, nested contexts keep their own lists, the switch PTC_FUSE_BN_TAIL=0 turns collecting off (modules then
+    increment by themselves), and the list is per thread."""
+    import threading
+
+    from pointcept_amd import config
+    from pointcept_amd import nn as PNN
+
+    a, b, c = (torch.zeros((), dtype=torch.int64) for _ in range(3))
+    assert getattr(PNN._bn_tls, "pending", None) is None
+    with PNN.batched_bn_counters():
+        PNN._bn_tls.pending += [a, b, a]
+        with PNN.batched_bn_counters():
+            PNN._bn_tls.pending.append(c)
+        assert int(c) == 1 and int(a) == 0          # the inner context closed, the outer one is still collecting
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(getattr(PNN._bn_tls, "pending", None)))
+        t.start()
+        t.join()
+        assert seen == [None]                       # another thread's forward does not see this list
+    assert (int(a), int(b), int(c)) == (2, 1, 1) and PNN._bn_tls.pending is None
+    monkeypatch.setattr(config, "FUSE_BN_TAIL", False)
+    with PNN.batched_bn_counters():
+        assert PNN._bn_tls.pending is None
