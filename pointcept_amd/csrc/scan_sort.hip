@@ -167,6 +167,9 @@ extern "C" int ptc_exclusive_scan_i32(const int32_t* in, int64_t n, int64_t* out
 #define RS_ITERS 16                       // 64-element strips per wave
 #define RS_TILE (RS_THREADS * RS_ITERS)   // 4096 keys per block
 #define RS_RADIX 256
+#ifndef RS_PACK
+#define RS_PACK 1                           // 0: key and row index as separate arrays in every pass (timing A/B)
+#endif
 
 __device__ __forceinline__ uint32_t rs_digit(uint64_t key, int shift, uint32_t mask) {
   return (uint32_t)(key >> shift) & mask;
@@ -193,15 +196,19 @@ rs_histogram_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift, uin
 
 // Stable scatter.  Element order inside a tile: wave w owns strips [w*RS_ITERS, (w+1)*RS_ITERS),
 // strip s covers 64 consecutive keys, lane = position in strip.
-template <bool FIRST>
+// PACK (round 4): the row index rides in the low `idx_bits` bits of the key word itself -- word = (key bits [0, end_bit) << idx_bits) | row,
+// built by the first pass in registers, sorted by its key bits only (`shift` then counts from bit idx_bits) -- so a pass moves 8 bytes
+// per element instead of 12 and the tile needs no value array in LDS (39 KB instead of 55 KB per workgroup).  Used whenever
+// end_bit + ceil(log2 n) <= 64: every sort of the model (28 + 20 bits at the bench size).  Same stable order, bit for bit.
+template <bool FIRST, bool PACK>
 __global__ void __launch_bounds__(RS_THREADS)
 rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in, int64_t n,
                   int shift, uint32_t mask, int n_blocks, const int64_t* __restrict__ offsets,
-                  uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out) {
+                  uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out, int idx_bits, uint64_t key_mask) {
   __shared__ int32_t wave_hist[RS_WAVES][RS_RADIX];
   __shared__ int64_t glob[RS_RADIX];
   __shared__ uint64_t skeys[RS_TILE];      // the tile in digit order (32 KB + 16 KB)
-  __shared__ uint32_t svals[RS_TILE];
+  __shared__ uint32_t svals[PACK ? 1 : RS_TILE];
   const int row = blockIdx.y, blk = blockIdx.x;
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&wave_hist[0][0])[i] = 0;
@@ -210,7 +217,8 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
   __syncthreads();
 
   const uint64_t* k = keys_in + (int64_t)row * n;
-  const uint32_t* ix = FIRST ? nullptr : idx_in + (int64_t)row * n;
+  const uint32_t* ix = (FIRST || PACK) ? nullptr : idx_in + (int64_t)row * n;
+  const int dshift = shift + ((PACK && FIRST) ? idx_bits : 0);    // FIRST packs in registers: the digit is then read from the packed word
   const int64_t base = (int64_t)blk * RS_TILE + (int64_t)wave * (RS_ITERS * 64);
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
@@ -222,8 +230,9 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
     const int64_t i = base + (int64_t)it * 64 + lane;
     const bool valid = i < n;
     key[it] = valid ? k[i] : ~0ull;
-    val[it] = valid ? (FIRST ? (uint32_t)i : ix[i]) : 0u;
-    const uint32_t d = rs_digit(key[it], shift, mask);
+    if (PACK && FIRST && valid) key[it] = ((key[it] & key_mask) << idx_bits) | (uint64_t)i;
+    val[it] = (valid && !PACK) ? (FIRST ? (uint32_t)i : ix[i]) : 0u;
+    const uint32_t d = rs_digit(key[it], dshift, mask);
     // match-any over the wave: lanes holding the same digit
     uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -275,34 +284,34 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
   for (int it = 0; it < RS_ITERS; ++it) {
     const int64_t i = base + (int64_t)it * 64 + lane;
     if (i < n) {
-      const uint32_t d = rs_digit(key[it], shift, mask);
+      const uint32_t d = rs_digit(key[it], dshift, mask);
       const int lp = lstart[d] + wave_hist[wave][d] + rank[it];
       skeys[lp] = key[it];
-      svals[lp] = val[it];
+      if (!PACK) svals[lp] = val[it];
     }
   }
   __syncthreads();
   uint64_t* ko = keys_out + (int64_t)row * n;
-  uint32_t* io = idx_out + (int64_t)row * n;
+  uint32_t* io = PACK ? nullptr : idx_out + (int64_t)row * n;
   const int64_t tile0 = (int64_t)blk * RS_TILE;
   const int cnt = (int)((n - tile0) < RS_TILE ? (n - tile0) : RS_TILE);
   for (int j = threadIdx.x; j < cnt; j += RS_THREADS) {
     const uint64_t kk = skeys[j];
-    const uint32_t d = rs_digit(kk, shift, mask);
+    const uint32_t d = rs_digit(kk, dshift, mask);
     const int64_t dst = glob[d] + (j - lstart[d]);
     ko[dst] = kk;
-    io[dst] = svals[j];
+    if (!PACK) io[dst] = svals[j];
   }
 }
 
 __global__ void __launch_bounds__(256)
-rs_finalize_kernel(const uint32_t* __restrict__ idx, int64_t n, int k, int64_t* __restrict__ order,
-                   int64_t* __restrict__ inverse) {
+rs_finalize_kernel(const uint32_t* __restrict__ idx, const uint64_t* __restrict__ packed, uint64_t idx_mask, int64_t n, int k,
+                   int64_t* __restrict__ order, int64_t* __restrict__ inverse) {
   const int64_t total = n * k;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const int64_t row = t / n, i = t - row * n;
-    const int64_t src = idx ? (int64_t)idx[t] : i;
+    const int64_t src = packed ? (int64_t)(packed[t] & idx_mask) : (idx ? (int64_t)idx[t] : i);
     order[t] = src;
     if (inverse) inverse[row * n + src] = i;
   }
@@ -356,17 +365,25 @@ extern "C" int ptc_sort_keys(const int64_t* keys, int64_t n, int k, int begin_bi
   const uint32_t* cur_i = nullptr;
   int out = 0;
   bool first = true;
+  // the row index packed into the key word (see rs_scatter_kernel) when both fit into 64 bits
+  int idx_bits = 1;
+  while (((int64_t)1 << idx_bits) < n) ++idx_bits;
+  const bool pack = RS_PACK && (end_bit - begin_bit) > 0 && end_bit + idx_bits <= 64;
+  const uint64_t key_mask = end_bit >= 64 ? ~0ull : (((uint64_t)1 << end_bit) - 1);
   for (int shift = begin_bit; shift < end_bit; shift += 8) {
     const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
     const uint32_t mask = (1u << bits) - 1u;
-    hipLaunchKernelGGL(rs_histogram_kernel, dim3(nb, k), dim3(RS_THREADS), 0, s, cur_k, n, shift, mask, nb, hist);
+    const int hshift = shift + ((pack && !first) ? idx_bits : 0);      // later passes read packed words
+    hipLaunchKernelGGL(rs_histogram_kernel, dim3(nb, k), dim3(RS_THREADS), 0, s, cur_k, n, hshift, mask, nb, hist);
     PTC_CHECK_LAUNCH("rs_histogram_kernel");
     int rc = exclusive_scan_i32(hist, nh, offs, scan_ws, s);
     if (rc != PTC_OK) return rc;
-    if (first)
-      hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(nb, k), dim3(RS_THREADS), 0, s, cur_k, cur_i, n, shift, mask, nb, offs, kbuf[out], ibuf[out]);
-    else
-      hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(nb, k), dim3(RS_THREADS), 0, s, cur_k, cur_i, n, shift, mask, nb, offs, kbuf[out], ibuf[out]);
+#define RS_SCATTER(F, P)                                                                                                                          \
+    hipLaunchKernelGGL((rs_scatter_kernel<F, P>), dim3(nb, k), dim3(RS_THREADS), 0, s, cur_k, cur_i, n, (P && !F) ? shift + idx_bits : shift, mask, nb, \
+                       offs, kbuf[out], ibuf[out], idx_bits, key_mask)
+    if (pack) { if (first) RS_SCATTER(true, true); else RS_SCATTER(false, true); }
+    else { if (first) RS_SCATTER(true, false); else RS_SCATTER(false, false); }
+#undef RS_SCATTER
     PTC_CHECK_LAUNCH("rs_scatter_kernel");
     cur_k = kbuf[out];
     cur_i = ibuf[out];
@@ -377,7 +394,9 @@ extern "C" int ptc_sort_keys(const int64_t* keys, int64_t n, int k, int begin_bi
     const int64_t total = n * k;
     int64_t grid = ptc_cdiv(total, 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(rs_finalize_kernel, dim3((unsigned)grid), dim3(256), 0, s, cur_i, n, k, order, inverse);
+    const bool packed_out = pack && !first;
+    hipLaunchKernelGGL(rs_finalize_kernel, dim3((unsigned)grid), dim3(256), 0, s, packed_out ? nullptr : cur_i, packed_out ? cur_k : nullptr,
+                       (((uint64_t)1 << idx_bits) - 1), n, k, order, inverse);
     PTC_CHECK_LAUNCH("rs_finalize_kernel");
   }
   return PTC_OK;
