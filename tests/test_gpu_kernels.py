@@ -110,6 +110,28 @@ def test_sort_keys_bit_window(cuda):
     assert np.array_equal(order0.cpu().numpy(), np.tile(np.arange(30000), (2, 1)))
 
 
+@pytest.mark.parametrize("n", [1, 2, 5000, 8192, 8193])
+def test_sort_keys_at_the_packing_boundary(cuda, n):
+    """The radix passes carry the row index in the low ceil(log2 n) bits of the key word when key bits + index bits fit 64 bits and as a
+    separate array otherwise (scan_sort.hip, round 4): the same stable order on both sides of that boundary, with key bits above
+    end_bit present (they are ignored) and a window that does not start at bit 0."""
+    from pointcept_amd import ops
+
+    rng = np.random.default_rng(n + 3)
+    idx_bits = max(1, int(n - 1).bit_length())
+    for end_bit in (64 - idx_bits - 1, 64 - idx_bits, 64 - idx_bits + 1):            # packs, packs (exactly 64 bits), does not pack
+        for begin_bit in (0, 5):
+            keys = rng.integers(0, 1 << 62, size=(2, n), dtype=np.int64) | (rng.integers(0, 2, size=(2, n), dtype=np.int64) << 62)
+            if n > 10:
+                keys[:, n // 2:] = keys[:, : n - n // 2]                              # duplicates: stability must hold
+            order, inv = ops.sort_keys(_t(keys, cuda), begin_bit, end_bit)
+            window = (keys.astype(np.uint64) >> np.uint64(begin_bit)) & np.uint64((1 << (end_bit - begin_bit)) - 1)
+            ref = np.argsort(window, axis=1, kind="stable")
+            assert np.array_equal(order.cpu().numpy(), ref), (n, begin_bit, end_bit)
+            for r in range(2):
+                assert np.array_equal(inv.cpu().numpy()[r][ref[r]], np.arange(n))
+
+
 @pytest.mark.parametrize("n", [1, 7, 2048, 2049, 16383, 16384, 16385, 300001])   # <= 16384: the one-workgroup single-launch form
 def test_exclusive_scan(cuda, n):
     from pointcept_amd import ops

@@ -199,6 +199,8 @@ EMULATED_GPU_TESTS = [
     ("test_spconv_fwd_chunked_pipeline", dict(cin=128, cout=128, ksize=3, n_pts=700)),      # conv3 with the two-chunk gather ring (DEEP)
     # (sizes: the smallest that still give several 128-row blocks per persistent workgroup / slice sequence -- the emulated MFMA loops
     #  of these six cases were 6 of the CPU tier's 13 minutes at 4500 / 2500 rows)
+    ("test_sort_keys_at_the_packing_boundary", dict(n=1)), ("test_sort_keys_at_the_packing_boundary", dict(n=5000)),
+    ("test_sort_keys_at_the_packing_boundary", dict(n=8193)),
     ("test_rulebook_blocks", dict(ordered=True)), ("test_spconv_fwd_block_staged", dict(c=64, ordered=True, n_rows=2100)),
     ("test_spconv_fwd_block_staged", dict(c=32, ordered=False, n_rows=2100)),
     ("test_spconv_wgrad_block_staged", dict(c=64, ordered=True, n_rows=1600)), ("test_spconv_wgrad_block_staged", dict(c=32, ordered=True, n_rows=1600)),
