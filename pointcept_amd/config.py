@@ -47,3 +47,4 @@ PREFETCH_LEVELS = _flag("PTC_PREFETCH_LEVELS", True)
 RPE_KERNEL = _flag("PTC_RPE_KERNEL", True)
 WGRAD_BLK = _flag("PTC_WGRAD_BLK", True)
 FUSE_BN_TAIL = _flag("PTC_FUSE_BN_TAIL", True)
+BATCH_BN_COUNTERS = _flag("PTC_BATCH_BN_COUNTERS", True)

@@ -128,8 +128,6 @@ class GridPooling(_GridPoolingM2):
         super().__init__(in_channels, out_channels, stride=stride, norm_layer=norm_layer, act_layer=act_layer, reduce=reduce,
                          shuffle_orders=shuffle_orders, traceable=traceable)
         self.re_serialization, self.serialization_order = re_serialization, serialization_order
-        if norm_layer is not None and act_layer is not None:      # norm and act run back to back at the end of forward
-            PNN.absorb_activations([self.norm[0], self.act[0]])
 
     def _extra_keys(self, point, point_dict, order0, idx_ptr):
         if "mask" in point.keys():                                                                 # :488-494
@@ -145,8 +143,6 @@ class GridUnpooling(_GridUnpoolingM2):
 
     def __init__(self, in_channels, skip_channels, out_channels, norm_layer=None, act_layer=None, traceable=False):
         super().__init__(in_channels, skip_channels, out_channels, norm_layer=norm_layer, act_layer=act_layer, traceable=traceable)
-        PNN.absorb_activations(self.proj._modules.values())
-        PNN.absorb_activations(self.proj_skip._modules.values())
 
     def forward(self, point):
         inverse = point.pooling_inverse

@@ -74,6 +74,9 @@ class LayerNorm(nn.LayerNorm):
 # `num_batches_tracked += 1` is one tiny launch per BatchNorm site and step (59 in SpUNet-v1m1, 0.27 ms of its 27.8 ms step in
 # profiles/r04_g_spunet_kernel_stats.csv).  A model's forward may collect them: inside `batched_bn_counters()` the modules append
 # their counter instead of incrementing it, and the context adds 1 to all of them in ONE multi-tensor launch when it closes.
+# Visibility: inside the context `num_batches_tracked` is stale until the exit (nothing in the reference reads it mid-forward; the
+# momentum=None cumulative average, which does, is never deferred).  A forward that raises flushes nothing: the counters of the sites
+# it did visit stay where they were, like the running statistics of the sites it never reached.  Switch: config.BATCH_BN_COUNTERS.
 _bn_tls = threading.local()       # per thread: nn.DataParallel replicas run their forwards concurrently
 
 
@@ -81,12 +84,12 @@ class batched_bn_counters:
     def __enter__(self):
         from . import config
         self._prev = getattr(_bn_tls, "pending", None)
-        _bn_tls.pending = [] if config.FUSE_BN_TAIL else None
+        _bn_tls.pending = [] if config.BATCH_BN_COUNTERS else None
         return self
 
     def __exit__(self, *exc):
         pending, _bn_tls.pending = _bn_tls.pending, self._prev
-        if not pending:
+        if not pending or exc[0] is not None:
             return False
         seen, once = set(), []
         for t in pending:
@@ -103,15 +106,15 @@ class batched_bn_counters:
 
 
 class BatchNorm1d(nn.BatchNorm1d):
-    """nn.BatchNorm1d on [N, C] point features (ptv3m1:581; spconv_unet_v1m1_base.py:110) with the activation
-    that FOLLOWS it in the reference absorbed (`act`): the container marks the pair with `absorb_activations`,
-    the activation module stays in place (state-dict / module indices unchanged) and becomes a no-op."""
-    act = "none"
+    """nn.BatchNorm1d on [N, C] point features (ptv3m1:581; spconv_unet_v1m1_base.py:110).  `forward(x, act=...)` applies the
+    activation that FOLLOWS the norm in the reference in the same pass.  Nothing about that fusion is stored on either module: the
+    containers decide it per forward from the LIVE module tree (`fused_act` below), so a pass that rewrites modules --
+    `nn.SyncBatchNorm.convert_sync_batchnorm` of the reference trainer's `sync_bn=True` path (pointcept/engines/train.py:257-258),
+    quantisers, PEFT wrappers -- simply gets the reference's unfused BatchNorm -> activation sequence."""
 
-    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, act: Optional[str] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, act: str = "none") -> torch.Tensor:
         """residual / act (SpUNet's BasicBlock): act(BN(x) + residual) in the same pass, spconv_unet_v1m1_base.py:79-83"""
         _require_gpu(x, "BatchNorm1d")
-        act = self.act if act is None else act
         use = (self.affine and x.is_cuda and x.dim() == 2 and x.shape[0] > 1 and ops.batch_norm_supported(x.shape[1], x.dtype)
                and (self.training or self.running_mean is not None))
         if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape):
@@ -137,23 +140,38 @@ class BatchNorm1d(nn.BatchNorm1d):
 
 
 class GELU(nn.GELU):
-    absorbed = False  # True: the preceding BatchNorm1d applies it
-
-    def forward(self, x):
-        return x if self.absorbed else super().forward(x)
+    """plain nn.GELU (always applies itself); the class only names the activation the engine's BatchNorm can take over"""
 
 
 class ReLU(nn.ReLU):
-    absorbed = False
-
-    def forward(self, x):
-        return x if self.absorbed else super().forward(x)
+    """plain nn.ReLU, see GELU"""
 
 
-def absorb_activations(modules) -> None:
-    """modules: the ORDERED children of a sequential container.  Marks every (BatchNorm1d, GELU|ReLU) pair."""
-    mods = list(modules)
-    for a, b in zip(mods[:-1], mods[1:]):
-        if isinstance(a, BatchNorm1d) and a.act == "none" and isinstance(b, (GELU, ReLU)) and not b.absorbed:
-            a.act = "gelu" if isinstance(b, GELU) else "relu"
-            b.absorbed = True
+def _hooked(m: nn.Module) -> bool:
+    return bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
+
+
+def fused_act(norm: nn.Module, act: Optional[nn.Module]) -> Optional[str]:
+    """"gelu" / "relu" when `norm` immediately followed by `act` may run as ONE `norm(x, act=...)` call, else None.
+
+    Evaluated at run time on the modules that are in the tree NOW (exact types, so a replaced, wrapped or subclassed norm or
+    activation is never fused; neither is an activation somebody hooked, whose hooks must see its real input).  The caller
+    skips `act` exactly when this returns a name -- there is no state that could go stale."""
+    if type(norm) is not BatchNorm1d or act is None or _hooked(act):
+        return None
+    if type(act) in (GELU, nn.GELU):
+        return "gelu" if getattr(act, "approximate", "none") == "none" else None
+    if type(act) in (ReLU, nn.ReLU):
+        return "relu"
+    return None
+
+
+def plain_feature_runs(modules):
+    """[(module, act_name | None)] over an ordered module list with the fusable (BatchNorm1d, activation) pairs collapsed: the
+    activation of a pair is dropped from the list and named on its norm.  Used by the sequential containers."""
+    mods, out, i = list(modules), [], 0
+    while i < len(mods):
+        kind = fused_act(mods[i], mods[i + 1] if i + 1 < len(mods) else None)
+        out.append((mods[i], kind))
+        i += 2 if kind else 1
+    return out

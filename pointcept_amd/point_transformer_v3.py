@@ -75,7 +75,8 @@ class PointSequential(PointModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for module in self._modules.values():
+        # a (BatchNorm1d, GELU | ReLU) pair that is adjacent in the LIVE module list runs as one call (PNN.fused_act)
+        for module, act in PNN.plain_feature_runs(self._modules.values()):
             if isinstance(module, PointModule):
                 input = module(input)
             elif spconv.is_spconv_module(module):
@@ -85,16 +86,36 @@ class PointSequential(PointModule):
                 else:
                     input = module(input)
             else:
+                run = module if act is None else partial(module, act=act)
                 if isinstance(input, Point):
-                    input.feat = module(input.feat)
+                    input.feat = run(input.feat)
                     if "sparse_conv_feat" in input.keys():
                         input.sparse_conv_feat = input.sparse_conv_feat.replace_feature(input.feat)
                 elif isinstance(input, spconv.SparseConvTensor):
                     if input.indices.shape[0] != 0:
-                        input = input.replace_feature(module(input.features))
+                        input = input.replace_feature(run(input.features))
                 else:
-                    input = module(input)
+                    input = run(input)
         return input
+
+
+def norm_then_act(owner, point):
+    """`point = owner.act(owner.norm(point))` of the pooling modules (ptv3m1:437-440), as ONE BatchNorm pass when both are
+    single-module PointSequentials holding a fusable pair right now (PNN.fused_act), else exactly the two calls."""
+    norm, act = getattr(owner, "norm", None), getattr(owner, "act", None)
+    if (type(norm) is PointSequential and type(act) is PointSequential and len(norm) == 1 and len(act) == 1
+            and not PNN._hooked(norm) and not PNN._hooked(act)):
+        kind = PNN.fused_act(norm[0], act[0])
+        if kind is not None:
+            point.feat = norm[0](point.feat, act=kind)
+            if "sparse_conv_feat" in point.keys():
+                point.sparse_conv_feat = point.sparse_conv_feat.replace_feature(point.feat)
+            return point
+    if norm is not None:
+        point = norm(point)
+    if act is not None:
+        point = act(point)
+    return point
 
 
 class PDNorm(PointModule):
@@ -527,8 +548,6 @@ class SerializedPooling(PointModule):
             self.norm = PointSequential(norm_layer(out_channels))
         if act_layer is not None:
             self.act = PointSequential(act_layer())
-        if norm_layer is not None and act_layer is not None:   # norm and act run back to back at the end of forward
-            PNN.absorb_activations([self.norm[0], self.act[0]])
 
     def forward(self, point: Point):
         pooling_depth = (math.ceil(self.stride) - 1).bit_length()
@@ -576,10 +595,7 @@ class SerializedPooling(PointModule):
         child["_ptc_offset_host"] = list(known) if known is not None else child.offset.tolist()
         child["_ptc_pool_levels"] = levels[1:]
         child["_ptc_n_dup"] = 0   # one row per cluster: pooled coordinates are unique
-        if getattr(self, "norm", None) is not None:
-            child = self.norm(child)
-        if getattr(self, "act", None) is not None:
-            child = self.act(child)
+        child = norm_then_act(self, child)
         child.sparsify()
         return child
 
@@ -595,8 +611,6 @@ class SerializedUnpooling(PointModule):
         if act_layer is not None:
             self.proj.add(act_layer())
             self.proj_skip.add(act_layer())
-        PNN.absorb_activations(self.proj._modules.values())
-        PNN.absorb_activations(self.proj_skip._modules.values())
         self.traceable = traceable
 
     def forward(self, point):
@@ -623,7 +637,6 @@ class Embedding(PointModule):
             self.stem.add(norm_layer(embed_channels), name="norm")
         if act_layer is not None:
             self.stem.add(act_layer(), name="act")
-        PNN.absorb_activations(self.stem._modules.values())
 
     def forward(self, point: Point):
         return self.stem(point)

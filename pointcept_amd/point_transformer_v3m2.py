@@ -26,7 +26,7 @@ from . import functional as PF
 from . import nn as PNN
 from . import ops
 from .point_transformer_v3 import Block as _BlockM1
-from .point_transformer_v3 import DropPath, PointModule, PointSequential
+from .point_transformer_v3 import DropPath, PointModule, PointSequential, norm_then_act
 from .structure import AttrDict, Point
 
 
@@ -158,10 +158,7 @@ class GridPooling(PointModule):
         child = Point(point_dict)
         child["_ptc_pool_csr"] = (order0, idx_ptr)      # gather-form backward of the unpooling gather
         child["_ptc_n_dup"] = 0                         # one row per cell
-        if getattr(self, "norm", None) is not None:
-            child = self.norm(child)
-        if getattr(self, "act", None) is not None:
-            child = self.act(child)
+        child = norm_then_act(self, child)
         self._serialize_child(point, child)
         child.sparsify()
         return child

@@ -42,8 +42,6 @@ class BasicBlock(spconv.SparseModule):
                                        indice_key=indice_key)
         self.bn1 = norm_fn(embed_channels)
         self.relu = nn.ReLU()
-        if isinstance(self.bn1, PNN.BatchNorm1d):
-            self.bn1.act = "relu"   # bn1 is always followed by self.relu (spconv_unet_v1m1_base.py:77): fused
         self.conv2 = spconv.SubMConv3d(embed_channels, embed_channels, kernel_size=3, stride=stride, padding=1,
                                        bias=bias, indice_key=indice_key)
         self.bn2 = norm_fn(embed_channels)
@@ -52,10 +50,12 @@ class BasicBlock(spconv.SparseModule):
     def forward(self, x):
         residual = x
         out = self.conv1(x)
-        h = self.bn1(out.features)
-        out = out.replace_feature(h if getattr(self.bn1, "act", "none") == "relu" else self.relu(h))
+        # both fusions are decided from the modules that are in the tree NOW (PNN.fused_act): after convert_sync_batchnorm or
+        # any other module rewrite the block runs the reference's three-pass form below
+        kind = PNN.fused_act(self.bn1, self.relu)               # bn1 is always followed by self.relu (spconv_unet_v1m1_base.py:77)
+        out = out.replace_feature(self.bn1(out.features, act=kind) if kind else self.relu(self.bn1(out.features)))
         out = self.conv2(out)
-        if isinstance(self.bn2, PNN.BatchNorm1d) and _config.FUSE_BN_TAIL:      # relu(bn2(.) + residual) in the BatchNorm's apply pass (:79-83)
+        if _config.FUSE_BN_TAIL and PNN.fused_act(self.bn2, self.relu) == "relu":   # relu(bn2(.) + residual) in the BatchNorm's apply pass (:79-83)
             return out.replace_feature(self.bn2(out.features, residual=self.proj(residual).features, act="relu"))
         out = out.replace_feature(self.bn2(out.features))
         out = out.replace_feature(self.relu(out.features + self.proj(residual).features))
@@ -77,7 +77,6 @@ class SpUNetBase(nn.Module):
         self.conv_input = spconv.SparseSequential(
             spconv.SubMConv3d(in_channels, base_channels, kernel_size=5, padding=1, bias=False, indice_key="stem"),
             norm_fn(base_channels), PNN.ReLU())
-        PNN.absorb_activations(self.conv_input._modules.values())
         enc_channels, dec_channels = base_channels, channels[-1]
         self.down, self.up, self.enc = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
         self.dec = nn.ModuleList() if not self.enc_mode else None
@@ -86,7 +85,6 @@ class SpUNetBase(nn.Module):
                 spconv.SparseConv3d(enc_channels, channels[s], kernel_size=2, stride=2, bias=False,
                                     indice_key=f"spconv{s + 1}"),
                 norm_fn(channels[s]), PNN.ReLU()))
-            PNN.absorb_activations(self.down[-1]._modules.values())
             self.enc.append(spconv.SparseSequential(OrderedDict(
                 (f"block{i}", BasicBlock(channels[s], channels[s], norm_fn=norm_fn, indice_key=f"subm{s + 1}"))
                 for i in range(layers[s]))))
@@ -95,7 +93,6 @@ class SpUNetBase(nn.Module):
                     spconv.SparseInverseConv3d(channels[len(channels) - s - 2], dec_channels, kernel_size=2, bias=False,
                                                indice_key=f"spconv{s + 1}"),
                     norm_fn(dec_channels), PNN.ReLU()))
-                PNN.absorb_activations(self.up[-1]._modules.values())
                 self.dec.append(spconv.SparseSequential(OrderedDict(
                     (f"block{i}", BasicBlock(dec_channels + enc_channels if i == 0 and skip else dec_channels, dec_channels,
                                              norm_fn=norm_fn, indice_key=f"subm{s}"))

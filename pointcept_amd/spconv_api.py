@@ -23,6 +23,7 @@ import math
 import sys
 import types
 from collections import OrderedDict
+from functools import partial
 
 import torch
 import torch.nn as nn
@@ -154,14 +155,17 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for module in self._modules.values():
+        from . import nn as PNN     # (BatchNorm1d, ReLU | GELU) adjacent in the LIVE module list: one BatchNorm pass (PNN.fused_act)
+        for module, act in PNN.plain_feature_runs(self._modules.values()):
             if is_spconv_module(module):
                 input = module(input)
-            elif isinstance(input, SparseConvTensor):
-                if input.indices.shape[0] != 0:
-                    input = input.replace_feature(module(input.features))
             else:
-                input = module(input)
+                run = module if act is None else partial(module, act=act)
+                if isinstance(input, SparseConvTensor):
+                    if input.indices.shape[0] != 0:
+                        input = input.replace_feature(run(input.features))
+                else:
+                    input = run(input)
         return input
 
 

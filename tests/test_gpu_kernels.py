@@ -1379,9 +1379,9 @@ def test_batch_norm_act_eval_and_module(cuda):
 
     torch.manual_seed(0)
     ref = torch.nn.Sequential(torch.nn.BatchNorm1d(64, eps=1e-3, momentum=0.01), torch.nn.GELU())
-    eng = torch.nn.Sequential(PNN.BatchNorm1d(64, eps=1e-3, momentum=0.01), PNN.GELU())
-    PNN.absorb_activations(eng._modules.values())
-    assert eng[0].act == "gelu" and eng[1].absorbed
+    from pointcept_amd.point_transformer_v3 import PointSequential
+    eng = PointSequential(PNN.BatchNorm1d(64, eps=1e-3, momentum=0.01), PNN.GELU())     # runs as ONE pass (PNN.fused_act)
+    assert PNN.fused_act(eng[0], eng[1]) == "gelu"
     with torch.no_grad():
         ref[0].weight.uniform_(0.5, 1.5); ref[0].bias.normal_()
     assert set(eng.state_dict()) == set(ref.state_dict())

@@ -58,3 +58,15 @@ def test_gpu_m3_litept_test_bodies_on_cpu_standins(name):
 
     with mock_backend.cpu_ops():
         getattr(T, name)(torch.device("cpu"))
+
+
+@pytest.mark.parametrize("name", ["test_sync_bn_conversion_ptv3_keeps_every_activation",
+                                  "test_sync_bn_conversion_spunet_degrades_to_the_three_pass_block",
+                                  "test_sync_bn_conversion_litept_matches_the_reference_golden",
+                                  "test_wrapped_or_hooked_modules_are_never_fused"])
+def test_gpu_sync_bn_test_bodies_on_cpu_standins(name):
+    """nn.SyncBatchNorm.convert_sync_batchnorm (reference trainer, sync_bn=True) on the engine's models"""
+    import test_gpu_sync_bn as T
+
+    with mock_backend.cpu_ops():
+        getattr(T, name)(torch.device("cpu"))

@@ -1024,7 +1024,7 @@ def test_pointops2_offsets_to_pair_index():
 
 def test_batched_bn_counters_context(monkeypatch):
     """nn.batched_bn_counters: counters appended inside the context get +1 each when it closes (one multi-tensor launch), a counter that
-    was appended twice gets +2, nested contexts keep their own lists, the switch PTC_FUSE_BN_TAIL=0 turns collecting off (modules then
+    was appended twice gets +2, nested contexts keep their own lists, the switch PTC_BATCH_BN_COUNTERS=0 turns collecting off (modules then
     increment by themselves), and the list is per thread."""
     import threading
 
@@ -1044,6 +1044,11 @@ def test_batched_bn_counters_context(monkeypatch):
         t.join()
         assert seen == [None]                       # another thread's forward does not see this list
     assert (int(a), int(b), int(c)) == (2, 1, 1) and PNN._bn_tls.pending is None
-    monkeypatch.setattr(config, "FUSE_BN_TAIL", False)
+    with pytest.raises(RuntimeError):               # a forward that raises flushes nothing and still restores the outer list
+        with PNN.batched_bn_counters():
+            PNN._bn_tls.pending.append(b)
+            raise RuntimeError("forward failed")
+    assert int(b) == 1 and PNN._bn_tls.pending is None
+    monkeypatch.setattr(config, "BATCH_BN_COUNTERS", False)
     with PNN.batched_bn_counters():
         assert PNN._bn_tls.pending is None
