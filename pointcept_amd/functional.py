@@ -109,16 +109,19 @@ class _CastCache:
         if len(dts) != 1 or next(iter(dts)) not in (torch.bfloat16, torch.float16) or len({s.device for s in srcs}) != 1:
             return False
         sig = tuple((s.data_ptr(), x[1].data_ptr(), s.numel()) for x, s in zip(stale, srcs))
-        if self._cast_desc is None or self._cast_desc[0] != sig:
+        dt = next(iter(dts))
+        if self._cast_desc is None:
+            self._cast_desc = {}
+        if dt not in self._cast_desc or self._cast_desc[dt][0] != sig:
             rows, prefix, units = [], [0], 0
             for src_ptr, dst_ptr, numel in sig:
                 rows.append([src_ptr, dst_ptr, numel])
                 units += (numel + 7) // 8
                 prefix.append(units)
             dev = srcs[0].device
-            self._cast_desc = (sig, torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(prefix, dtype=torch.int64, device=dev), units)
-        _, desc, prefix, units = self._cast_desc
-        ops.cast_many(desc, prefix, len(sig), units, next(iter(dts)))
+            self._cast_desc[dt] = (sig, torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(prefix, dtype=torch.int64, device=dev), units)
+        _, desc, prefix, units = self._cast_desc[dt]
+        ops.cast_many(desc, prefix, len(sig), units, dt)
         return True
 
     def get(self, w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
@@ -158,9 +161,15 @@ class _CastCache:
             if o is not None and x[2] != o._version:
                 stale.append(x)
                 srcs.append(o.detach().reshape(-1))
+        # per shadow dtype: a process that ran bf16 AND fp16 autocast holds both kinds, and torch._foreach_copy_ on a destination list
+        # of mixed dtypes converts every tensor to the FIRST one's dtype on the CUDA fast path (seen on PyTorch 2.10 / ROCm 7: the
+        # second dtype's shadows received the first dtype's bit patterns -- tools/fp16_stem_probe.py)
         with torch.no_grad():
-            if not self._cast_many(stale, srcs):
-                torch._foreach_copy_([x[1] for x in stale], srcs)
+            for dt_ in {x[1].dtype for x in stale}:
+                grp = [(x, s_) for x, s_ in zip(stale, srcs) if x[1].dtype == dt_]
+                gx, gs = [g_[0] for g_ in grp], [g_[1] for g_ in grp]
+                if not self._cast_many(gx, gs):
+                    torch._foreach_copy_([x[1] for x in gx], gs)
         for x, o in zip(stale, srcs):
             x[2] = x[0]()._version
             x[3] += 1

@@ -390,14 +390,60 @@ def _stage_distances(ga, gb, stage_of):
     return {k: (v[0] ** 0.5) / max(v[1] ** 0.5, 1e-30) for k, v in per_stage.items()}, sorted(per_param, reverse=True)[:6]
 
 
+class _RoundSTE(torch.autograd.Function):
+    """x -> x rounded to `dtype` (kept in fp32); the gradient is rounded the same way: what a 16-bit tensor between two modules does"""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).float(), None
+
+
+def _autocast_rounding_twin(model, dtype):
+    """fp32 copy of an engine model that rounds where 16-bit autocast rounds (spconv + BatchNorm + ReLU under AMP: every conv,
+    norm and activation output is a 16-bit tensor, conv weights are cast): the fp32 kernels -- pinned to the oracle -- plus the
+    ROUNDINGS of the 16-bit path and nothing else.  Hooked activations are never fused (PNN.fused_act), so the twin runs the
+    reference's module sequence."""
+    import copy
+
+    from pointcept_amd import spconv_api
+
+    twin = copy.deepcopy(model)
+    with torch.no_grad():
+        for m in twin.modules():
+            if isinstance(m, spconv_api._SparseConvolution):
+                m.weight.copy_(m.weight.to(dtype).float())
+
+    def hook(m, inp, out):
+        if torch.is_tensor(out):
+            return _RoundSTE.apply(out, dtype) if out.is_floating_point() else out
+        if hasattr(out, "features") and out.features is not None:
+            return out.replace_feature(_RoundSTE.apply(out.features, dtype))
+        return out
+
+    for m in twin.modules():
+        if not list(m.children()) and not isinstance(m, torch.nn.Identity):
+            m.register_forward_hook(hook)
+    return twin
+
+
 def test_spunet_base_two_full_scenes_train_step_vs_oracle(cuda):
     """BASELINE configs[1] end to end, forward AND backward, at 2 x 100000 voxels: SpUNet-v1m1 base
     (scannet/semseg-spunet-v1m1-0-base.py:16-17) in train mode (batch-statistics BatchNorm) + CE, every parameter gradient grouped by
     stage (conv_input, down.s, enc.s, up.s, dec.s, final) against the fp32 CPU oracle -- the sliced wgrad7 instances (96 / 128 / 224 / 192
     channels), the 128-column conv3 instances and the strided / inverse tables on the engine side.  Three engine runs on the same weights:
-    fp32 (algorithm parity: summation order only), bf16 autocast (the bench secondary) and fp16 autocast with a fixed loss scale of
-    1024 (configs[1]'s AMP dtype; GradScaler's unscale is the division below).  Bars: fp32 loss 1e-5 / logits 2e-3 / stages 1e-2;
-    16-bit loss 2e-3 / logits 8e-2 max, 3e-2 Frobenius / stages 8e-2 (measured values in profiles/r05_*_fullsize_spunet_step.txt)."""
+      fp32           algorithm parity (summation order only): loss 1e-5, logits 2e-3, every stage's gradient 1e-2;
+      bf16 autocast  (the bench secondary) and fp16 autocast with a fixed loss scale of 1024 (configs[1]'s AMP dtype; GradScaler's
+                     unscale is the division below): loss 2e-3, logits 8e-2 max / 3e-2 Frobenius, arg-max agreement 0.97.
+    44 convolutions deep with batch-statistics BatchNorm, a 16-bit rounding of every intermediate tensor moves the GRADIENTS of this
+    network by tens of per cent at the deep stages whoever does the rounding (measured 28-53 % for bf16 at enc / down, on the MI355X
+    kernels and on plain torch CPU autocast alike, profiles/r05_b_fullsize_spunet_step.txt).  The 16-bit gradients are therefore
+    judged against an envelope: the SAME engine in fp32 with each module output / gradient rounded to the autocast dtype
+    (_autocast_rounding_twin) deviates from the fp32 oracle by e(stage); the 16-bit kernels must stay inside 1.5 e(stage) + 2e-2."""
     from oracle import ptv3_model as om
     from oracle import spunet_model as osp
     from pointcept_amd import functional as PF
@@ -405,6 +451,7 @@ def test_spunet_base_two_full_scenes_train_step_vs_oracle(cuda):
     from pointcept_amd.sparse_unet import SpUNetBase
 
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    on_gpu = torch.device(cuda).type == "cuda"
     batch = synthetic.collate([synthetic.indoor_scene(61, _n(100000)), synthetic.indoor_scene(62, _n(100000))])
     kw = dict(channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2))
     torch.manual_seed(0)
@@ -423,34 +470,41 @@ def test_spunet_base_two_full_scenes_train_step_vs_oracle(cuda):
     lo, logits_o = float(out_o["loss"].detach()), out_o["seg_logits"].detach()
     dev = synthetic.to_torch(batch, cuda)
     lines = [f"SpUNet-v1m1 base, 2 x {_n(100000)} voxels, train mode, CE; fp32 CPU oracle fwd+bwd {t_orc:.1f} s on {torch.get_num_threads()} threads"]
-    bars = {"fp32": (1e-5, 2e-3, 2e-3, 1e-2), "bf16": (2e-3, 8e-2, 3e-2, 8e-2), "fp16": (2e-3, 8e-2, 3e-2, 8e-2)}
-    failures = []
-    for mode, dtype in (("fp32", None), ("bf16", torch.bfloat16), ("fp16", torch.float16)):
-        eng.load_state_dict(sd)                                    # running statistics back to the start
-        eng.zero_grad(set_to_none=True)
-        scale = 1024.0 if mode == "fp16" else 1.0
-        if dtype is None:
-            logits = eng(dict(dev))
+
+    def step(model, dtype, scale):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=dtype or torch.bfloat16, enabled=dtype is not None):
+            logits = model(dict(dev))
             loss = PF.cross_entropy(logits, dev["segment"], -1)
-        else:
-            with torch.autocast("cuda" if torch.device(cuda).type == "cuda" else "cpu", dtype=dtype if torch.device(cuda).type == "cuda" else torch.bfloat16):
-                logits = eng(dict(dev))
-                loss = PF.cross_entropy(logits, dev["segment"], -1)
         (loss * scale).backward()
-        ge = {n: p.grad.detach().float().cpu() / scale for n, p in eng.named_parameters()}
-        assert all(torch.isfinite(g).all() for g in ge.values()), mode
+        g = {n: p.grad.detach().float().cpu() / scale for n, p in model.named_parameters()}
+        assert all(torch.isfinite(v).all() for v in g.values())
+        return float(loss.detach()), logits.detach().float().cpu(), g
+
+    failures = []
+    modes = (("fp32", None), ("bf16", torch.bfloat16), ("fp16", torch.float16)) if on_gpu else (("fp32", None),)
+    for mode, dtype in modes:      # (the CPU stand-ins have no 16-bit kernels: fp32 only in the dry run)
+        eng.load_state_dict(sd)                                    # running statistics back to the start
+        loss, logits, ge = step(eng, dtype, 1024.0 if mode == "fp16" else 1.0)
         stages, worst = _stage_distances(ge, go, _spunet_stage_of)
-        l_rel = abs(float(loss) - lo) / abs(lo)
-        agree = float((logits.float().argmax(1).cpu() == logits_o.argmax(1)).float().mean())
-        lines.append(f"{mode}: loss engine {float(loss):.6f} oracle {lo:.6f} rel {l_rel:.2e}; logits rel_max {_rel_max(logits, logits_o):.3e} "
+        l_rel = abs(loss - lo) / abs(lo)
+        agree = float((logits.argmax(1) == logits_o.argmax(1)).float().mean())
+        lines.append(f"{mode}: loss engine {loss:.6f} oracle {lo:.6f} rel {l_rel:.2e}; logits rel_max {_rel_max(logits, logits_o):.3e} "
                      f"rel_fro {_rel_fro(logits, logits_o):.3e} argmax {agree:.4f}")
-        lines += [f"   {k:12s} {v:.3e}" for k, v in stages.items()]
+        if dtype is None:
+            lines += [f"   {k:12s} {v:.3e}" for k, v in stages.items()]
+            ok = l_rel < 1e-5 and _rel_max(logits, logits_o) < 2e-3 and max(stages.values()) < 1e-2
+        else:
+            eng.load_state_dict(sd)
+            _, _, gt = step(_autocast_rounding_twin(eng, dtype), None, 1.0)
+            env, _ = _stage_distances(gt, go, _spunet_stage_of)
+            lines.append("   stage        16-bit kernels vs fp32 oracle   fp32 kernels + autocast roundings vs fp32 oracle")
+            lines += [f"   {k:12s} {v:.3e}                       {env[k]:.3e}" for k, v in stages.items()]
+            ok = (l_rel < 2e-3 and _rel_max(logits, logits_o) < 8e-2 and _rel_fro(logits, logits_o) < 3e-2 and agree > 0.97
+                  and all(stages[k] <= 1.5 * env[k] + 2e-2 for k in stages))
         lines += [f"   worst {r:.3e} (|g| {n_:.3e}) {name}" for r, n_, name in worst[:3]]
-        b_loss, b_max, b_fro, b_stage = bars[mode]
-        if torch.device(cuda).type != "cuda" and mode != "fp32":
-            continue                                               # the CPU stand-ins have no 16-bit kernels: fp32 bars only
-        if not (l_rel < b_loss and _rel_max(logits, logits_o) < b_max and _rel_fro(logits, logits_o) < b_fro and max(stages.values()) < b_stage):
-            failures.append((mode, l_rel, _rel_max(logits, logits_o), _rel_fro(logits, logits_o), max(stages.items(), key=lambda kv: kv[1])))
+        if not ok:
+            failures.append(lines[-(len(stages) + 5):])
     _report("fullsize_spunet_step.txt", lines)
     assert not failures, failures
 

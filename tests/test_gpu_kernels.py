@@ -2223,6 +2223,28 @@ def test_weight_layout_cache_one_launch_refresh(cuda):
     assert len(cache.layouts) == n - 2        # both layouts of the Linear went with it
 
 
+def test_weight_shadows_of_two_autocast_dtypes_in_one_process(cuda):
+    """one model, bf16 autocast, fp16 autocast, optimizer-style weight updates in between: the 16-bit weight shadows of BOTH kinds are
+    refreshed in their own dtype (round 5 bug: the mixed refresh went through torch._foreach_copy_, which wrote bf16 bit patterns
+    into the f16 shadows -- SpUNet's stem was 31x off under fp16 after a bf16 run, tools/fp16_stem_probe.py)"""
+    from pointcept_amd import functional as PF
+    from pointcept_amd import nn as PNN
+
+    torch.manual_seed(0)
+    lin = PNN.Linear(64, 96).to(cuda)
+    x = torch.randn(3000, 64, device=cuda)
+    for step in range(3):
+        ref = torch.nn.functional.linear(x, lin.weight, lin.bias)
+        for dt, bar in ((torch.bfloat16, 2e-2), (torch.float16, 3e-3), (torch.bfloat16, 2e-2)):
+            with torch.autocast("cuda", dtype=dt):
+                y = lin(x)
+            assert y.dtype == dt
+            assert float((y.float() - ref).abs().max() / ref.abs().max()) < bar, (step, dt)
+            assert torch.equal(PF._cast_cache.get(lin.weight, dt), lin.weight.detach().to(dt)), (step, dt)
+        with torch.no_grad():
+            lin.weight.mul_(1.25).add_(0.01)
+
+
 # ------------------------------------------------------------------------------------------------
 # M. libs/pointops2 (Stratified Transformer operators)
 # ------------------------------------------------------------------------------------------------

@@ -367,6 +367,17 @@ def test_cast_many_kernel_on_the_emulation_and_in_the_cast_cache(monkeypatch):
             with torch.no_grad():
                 ws[step % 2].mul_(1.5)                                                # the optimizer moves a weight: version counter
     assert cache._cast_desc is not None
+    # a process that ran bf16 AND fp16 autocast holds shadows of both kinds: every refresh must serve each kind in its own dtype
+    # (round 5: torch._foreach_copy_ over a mixed destination list wrote the first dtype's bit patterns into the second's shadows)
+    with emu_backend.emulated_ops():
+        for step in range(3):
+            for dt in (torch.float16, torch.bfloat16):
+                for w in ws:
+                    assert torch.equal(cache.get(w, dt), w.detach().to(dt)), (step, dt)
+            with torch.no_grad():
+                for w in ws:
+                    w.add_(0.125)
+    assert set(cache._cast_desc) == {torch.bfloat16, torch.float16}
 
 
 def test_pending_rope_kernel_gpu_test_body_on_the_emulation():
