@@ -562,6 +562,21 @@ int ptc_edge_scatter_bwd(int mode, const int64_t* order, const int64_t* indptr, 
                          const float* w, int nsample, int c, int w_c, int64_t n_src, float* grad_src, ptc_stream_t stream);
 int ptc_aggregation_edge_bwd(const float* src, const float* pos, const float* w, const int32_t* idx, const float* g, int64_t m,
                              int nsample, int c, int w_c, int64_t n_src, float* grad_pos, float* grad_w, ptc_stream_t stream);
+/* Pair-list attention of libs/pointops (round 5; PTv2's grouped vector attention): a pair m joins row ia[m] of a [n_a, g, c] with row
+ * ib[m] of b [n_b, g, c] (fp32; indices outside their range contribute zeros).
+ *   ptc_pair_dot_weighted  out[m, g] = sum_c a[ia[m], g, c] b[ib[m], g, c] (w ? w[c] : 1)
+ *        = attention_relation_step_forward_cuda (libs/pointops/src/attention/attention_cuda_kernel.cu:9-25; functions/attention.py:11-62)
+ *          with (a, b, w) = (query, key, weight), and d weight of the fusion step (:64-82) with (a, b, w) = (grad_output, value, NULL)
+ *   ptc_pair_segment_sum   A[n, g, c] = sum over the pairs e of row n -- order / indptr: the CSR of the pairs by that row index
+ *        (ptc_edge_csr_*), ascending pair index -- of s[e, g] b[oidx[e], g, c];  out = A (w ? w[c] : 1);  prod = self[n, g, c] A if prod
+ *        = attention_fusion_step_forward_cuda (:46-62) with (s, b) = (weight, value), CSR by index_target, oidx = index_refer;
+ *          d query / d key of the relation step (:27-45) with (s, b, w) = (grad_output, key | query, weight) -- prod summed over its rows
+ *          is d weight --; d value of the fusion step with (s, b) = (weight, grad_output), CSR by index_refer, oidx = index_target.
+ *        One producer per output element, fixed order: no atomicAdd (the reference's sums differ from run to run). */
+int ptc_pair_dot_weighted(const float* a, const float* b, const float* w, const int32_t* ia, const int32_t* ib, int64_t m, int64_t n_a,
+                          int64_t n_b, int g, int c, float* out, ptc_stream_t stream);
+int ptc_pair_segment_sum(const float* s, const float* b, const float* w, const float* self, const int64_t* order, const int64_t* indptr,
+                         const int32_t* oidx, int64_t n_rows, int64_t n_b, int g, int c, float* out, float* prod, ptc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * J. BatchNorm1d over the rows of [n, c] features with the following activation fused:

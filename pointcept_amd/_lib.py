@@ -128,6 +128,8 @@ _SIGNATURES = {
     "ptc_edge_csr_keys": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "ptc_edge_csr_ptr": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "ptc_edge_scatter_bwd": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_i64, c_ptr, c_ptr]),
+    "ptc_pair_dot_weighted": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    "ptc_pair_segment_sum": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "ptc_aggregation_edge_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     "ptc_farthest_point_sampling": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     "ptc_voxel_keys": (c_int, [c_ptr, c_i64, ctypes.c_double, c_ptr, c_ptr, c_ptr, c_ptr]),

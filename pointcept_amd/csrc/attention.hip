@@ -265,6 +265,90 @@ __host__ __device__ __forceinline__ int at_split(int n_units, int lp_max) {
 //  neutral in the step: 50.3 vs 49.8 ms, profiles/r03_a_knob_ab.txt; removed)
 static inline int at_split_host(int n_units, int lp_max) { return at_split(n_units, lp_max); }
 
+// ---- forward launch plan (round 5): whole units first, the LAST partial round in finer parts -----------------------------------
+// Workgroup b runs on XCD b & 7 and the XCD takes its workgroups in order, two per CU: 3200 equal units are 6.25 rounds of its 64
+// slots, i.e. the last quarter round costs a whole one (the "6.25-round tail", ~10 % of the launch).  Splitting EVERY unit only
+// moves the problem (6400 halves = 12.5 rounds, each part pays the staging of the other side again: measured neutral, above).  The
+// plan keeps the first `whole` units of every XCD's chunk whole and cuts only the ones behind them into `qs` parts (query tiles
+// p*per .. (p+1)*per of the unit; every part stages K / V itself, L2-hot): 6 full rounds + one round of quarter units.  Chosen per
+// launch by simulating the XCD's in-order dispatch for the candidates (uniform 1 / 2 / 4, tail 2 / 4) with a part costing
+// AT_STAGE_FRAC + (1 - AT_STAGE_FRAC) / qs of a unit (0.10: what the uniform split of the 1600-unit launch gained, r04_w_attn_split.txt).
+#ifndef AT_STAGE_FRAC
+#define AT_STAGE_FRAC 0.10
+#endif
+struct AtPlan { int whole, qs; };     // per XCD chunk: unit index < whole -> one workgroup; else qs workgroups per unit
+__host__ __device__ __forceinline__ int at_plan_blocks_per_xcd(int n_units, AtPlan p) {
+  const int per_xcd = (n_units + 7) >> 3, w = p.whole < per_xcd ? p.whole : per_xcd;
+  return w + (per_xcd - w) * p.qs;
+}
+// block -> (unit, part, parts); false: nothing to do
+__device__ __forceinline__ bool at_plan_unit(int n_units, int whole, int qs, int& unit, int& part, int& parts) {
+  const int per_xcd = (n_units + 7) >> 3, xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+  const int w = whole < per_xcd ? whole : per_xcd;
+  if (j < w) {
+    unit = xcd * per_xcd + j; part = 0; parts = 1;
+  } else {
+    const int jj = j - w;
+    unit = xcd * per_xcd + w + jj / qs; part = jj % qs; parts = qs;
+    if (w + jj / qs >= per_xcd) return false;
+  }
+  return unit < n_units;
+}
+static double at_plan_makespan(int per_xcd, int slots, AtPlan p) {
+  // in-order list scheduling of the chunk's workgroups on `slots` slots: a min-heap of slot-free times in a flat array
+  if (slots > 512) slots = 512;
+  double heap[512];
+  for (int i = 0; i < slots; ++i) heap[i] = 0.0;
+  const int w = p.whole < per_xcd ? p.whole : per_xcd;
+  const long nblk = w + (long)(per_xcd - w) * p.qs;
+  const double t_part = AT_STAGE_FRAC + (1.0 - AT_STAGE_FRAC) / p.qs;
+  double end = 0.0;
+  for (long b = 0; b < nblk; ++b) {
+    const double t = heap[0] + (b < w ? 1.0 : t_part);      // earliest free slot takes the next workgroup
+    if (t > end) end = t;
+    int i = 0;                                               // replace the root, sift down
+    for (;;) {
+      int c = 2 * i + 1;
+      if (c >= slots) break;
+      if (c + 1 < slots && heap[c + 1] < heap[c]) ++c;
+      if (heap[c] >= t) break;
+      heap[i] = heap[c];
+      i = c;
+    }
+    heap[i] = t;
+  }
+  return end;
+}
+static AtPlan at_plan_host(int n_units, int lp_max) {
+  constexpr int slots_per_xcd = 2 * 256 / 8;                  // gfx950 = MI355X: 256 CUs in 8 XCDs, two 8-wave workgroups per CU (66 KB of LDS each)
+  if (const char* e = getenv("PTC_AT_PLAN")) {                // "whole,qs" (A/B and tests); "0" = the round-4 uniform split
+    int w = 0, q = 0;
+    if (sscanf(e, "%d,%d", &w, &q) == 2 && (q == 1 || q == 2 || q == 4)) return {w, q};
+    const int qs = at_split_host(n_units, lp_max);
+    return {0, qs};
+  }
+  static struct { int n_units, lp_max; AtPlan p; } cache[16];
+  static int n_cache = 0;
+  for (int i = 0; i < n_cache; ++i)
+    if (cache[i].n_units == n_units && cache[i].lp_max == lp_max) return cache[i].p;
+  const int per_xcd = (n_units + 7) >> 3, n_tiles = lp_max >> 5, S = slots_per_xcd;
+  AtPlan best = {per_xcd, 1};
+  double t_best = at_plan_makespan(per_xcd, S, best);
+  auto consider = [&](AtPlan p) {
+    if (n_tiles / p.qs < AT_WAVES) return;                   // every wave of a part keeps at least one query tile
+    const double t = at_plan_makespan(per_xcd, S, p);
+    if (t < t_best * 0.995) { t_best = t; best = p; }
+  };
+  const int full = (per_xcd / S) * S;
+  for (int qs = 2; qs <= 4; qs *= 2) {
+    consider({0, qs});                                       // every unit split (the deep stages: fewer units than slots)
+    if (full > 0 && full < per_xcd) consider({full, qs});    // only the last partial round
+    if (full >= S && full == per_xcd) consider({full - S, qs});   // (exactly full rounds stay whole: nothing to gain)
+  }
+  if (n_cache < 16) cache[n_cache++] = {n_units, lp_max, best};
+  return best;
+}
+
 // A sequence longer than max_seqlen (cu_seqlens built for a larger patch than the caller's max_seqlen, or a caller
 // of the flash_attn API passing inconsistent arguments) would overrun the LDS images, which are sized from
 // max_seqlen.  Such units write NaN to every output row they own (16 bf16 per row, optionally the fp32 side vector) and
@@ -291,11 +375,10 @@ __device__ __forceinline__ void at_poison_rows(uint16_t* rows, int64_t row_strid
 template <bool F16>
 __global__ void __launch_bounds__(AT_THREADS, AT_MIN_WAVES)
 attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu, int H, float scale, int64_t total,
-                int lp_max, int n_units, int qs, uint16_t* __restrict__ out, float* __restrict__ lse) {
+                int lp_max, int n_units, int plan_qs, int plan_whole, uint16_t* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lunit = at_unit(n_units * qs);
-  if (lunit >= n_units * qs) return;
-  const int unit = lunit / qs, part = lunit - unit * qs;
+  int unit, part, qs;
+  if (!at_plan_unit(n_units, plan_whole, plan_qs, unit, part, qs)) return;
   const int seq = unit / H, head = unit % H;
   const int a = cu[seq], L = cu[seq + 1] - a;
   if (L <= 0) return;
@@ -335,9 +418,25 @@ attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu
   const int vstride = 64, voff = 32;                           // bytes per 32-key tile / per 16-key block
   const unsigned char* kbase = Ksm + rm_off(col, h2);
 
-  for (int qt = t_lo + wave; qt < t_hi; qt += AT_WAVES) {
+#ifndef AT_QPREFETCH
+#define AT_QPREFETCH 1           // the next query tile's fragment is requested before this tile's key loop (its latency was exposed at every tile start)
+#endif
+  int qt = t_lo + wave;
+#if AT_QPREFETCH
+  s16x8 qf_next = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (qt < t_hi) qf_next = ld_global_frag<F16>(qkv + qkv_off(a + qt * 32 + col, 0, H, head) + h2 * 8, qt * 32 + col < L);
+#endif
+  for (; qt < t_hi; qt += AT_WAVES) {
     const int q = qt * 32 + col;
+#if AT_QPREFETCH
+    const s16x8 qf = qf_next;
+    if (qt + AT_WAVES < t_hi) {
+      const int qn_ = (qt + AT_WAVES) * 32 + col;
+      qf_next = ld_global_frag<F16>(qkv + qkv_off(a + qn_, 0, H, head) + h2 * 8, qn_ < L);
+    }
+#else
     const s16x8 qf = ld_global_frag<F16>(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, q < L);
+#endif
     float qn = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -790,13 +889,13 @@ extern "C" int ptc_attn_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, i
   const size_t lds = fwd_lds_bytes(lp_max);
   hipStream_t s = (hipStream_t)stream;
   const int n_units = (int)(n_seq * H);
-  const int qs = at_split_host(n_units, lp_max);
+  const AtPlan plan = at_plan_host(n_units, lp_max);
 #define AT_FWD_CASE(F16)                                                                                                                   \
   if ((dtype == PTC_F16) == F16) {                                                                                                          \
     rc = allow_big_lds(attn_fwd_kernel<F16>, lds);                                                                                          \
     if (rc != PTC_OK) return rc;                                                                                                            \
-    hipLaunchKernelGGL(attn_fwd_kernel<F16>, dim3((unsigned)(8 * ((n_units * qs + 7) / 8))), dim3(AT_THREADS), lds, s, (const uint16_t*)qkv, \
-                       cu_seqlens, H, softmax_scale, total, lp_max, n_units, qs, (uint16_t*)out, lse);                                      \
+    hipLaunchKernelGGL(attn_fwd_kernel<F16>, dim3((unsigned)(8 * at_plan_blocks_per_xcd(n_units, plan))), dim3(AT_THREADS), lds, s,           \
+                       (const uint16_t*)qkv, cu_seqlens, H, softmax_scale, total, lp_max, n_units, plan.qs, plan.whole, (uint16_t*)out, lse); \
     PTC_CHECK_LAUNCH("attn_fwd_kernel");                                                                                                    \
     return PTC_OK;                                                                                                                          \
   }

@@ -207,6 +207,77 @@ int eg_grid(int64_t work) {
   return (int)b;
 }
 
+
+// ---- pair-list attention of libs/pointops (PTv2 grouped vector attention; src/attention/attention_cuda_kernel.cu) ---------------
+// A pair m joins row ia[m] of operand a with row ib[m] of operand b; rows are [g, c] fp32.
+//   pair_dot:      out[m, g]    = sum_c a[ia[m], g, c] b[ib[m], g, c] (w ? w[c] : 1)                 one lane group per (pair, group)
+//   pair_segment:  A[n, g, c]   = sum over the pairs e of row n (CSR by the scatter side, ascending pair index) of
+//                                  s[e, g] b[oidx[e], g, c];   out = A (w ? w[c] : 1);   prod = self[n, g, c] A   (optional)
+// The reference forward scatters one product per (pair, group, channel) with atomicAdd into out[m, g] and its backward / fusion
+// step scatter by row index the same way (:9-25, :27-45, :46-62, :64-82): here every output element has ONE producer that adds in a
+// fixed order.  Out-of-range indices contribute zeros.
+__global__ void __launch_bounds__(EG_THREADS)
+pair_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ w, const int32_t* __restrict__ ia,
+                const int32_t* __restrict__ ib, int64_t m, int64_t n_a, int64_t n_b, int g, int c, float* __restrict__ out) {
+  const int64_t total = m * g;
+  for (int64_t t = (int64_t)blockIdx.x * EG_THREADS + threadIdx.x; t < total; t += (int64_t)gridDim.x * EG_THREADS) {
+    const int64_t e = t / g;
+    const int gi = (int)(t - e * g);
+    const int32_t ja = ia[e], jb = ib[e];
+    float s = 0.f;
+    if (ja >= 0 && ja < n_a && jb >= 0 && jb < n_b) {
+      const float* ar = a + ((int64_t)ja * g + gi) * c;
+      const float* br = b + ((int64_t)jb * g + gi) * c;
+      for (int ch = 0; ch < c; ch += 4) {
+        const float4 x = eg_ld4(ar, c, ch), y = eg_ld4(br, c, ch);
+        float4 ww = {1.f, 1.f, 1.f, 1.f};
+        if (w) ww = eg_ld4(w, c, ch);
+        s = fmaf(x.x * y.x, ww.x, s);
+        s = fmaf(x.y * y.y, ww.y, s);
+        s = fmaf(x.z * y.z, ww.z, s);
+        s = fmaf(x.w * y.w, ww.w, s);
+      }
+    }
+    out[t] = s;
+  }
+}
+
+__global__ void __launch_bounds__(EG_THREADS)
+pair_segment_kernel(const float* __restrict__ sc, const float* __restrict__ b, const float* __restrict__ w, const float* __restrict__ self,
+                    const int64_t* __restrict__ order, const int64_t* __restrict__ indptr, const int32_t* __restrict__ oidx, int64_t n_rows,
+                    int64_t n_b, int g, int c, float* __restrict__ out, float* __restrict__ prod) {
+  const int pieces = (c + 3) >> 2;
+  const int64_t total = n_rows * g * pieces;
+  const bool aligned = (c & 3) == 0;
+  for (int64_t v = (int64_t)blockIdx.x * EG_THREADS + threadIdx.x; v < total; v += (int64_t)gridDim.x * EG_THREADS) {
+    const int64_t ng = v / pieces;
+    const int ch = (int)(v - ng * pieces) * 4;
+    const int64_t n = ng / g;
+    const int gi = (int)(ng - n * g);
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t p = indptr[n]; p < indptr[n + 1]; ++p) {
+      const int64_t e = order[p];
+      const int32_t j = oidx[e];
+      if (j < 0 || j >= n_b) continue;
+      const float coef = sc[e * g + gi];
+      const float4 y = eg_ld4(b + ((int64_t)j * g + gi) * c, c, ch);
+      acc.x = fmaf(coef, y.x, acc.x);
+      acc.y = fmaf(coef, y.y, acc.y);
+      acc.z = fmaf(coef, y.z, acc.z);
+      acc.w = fmaf(coef, y.w, acc.w);
+    }
+    if (prod) {
+      const float4 q = eg_ld4(self + ng * c, c, ch);
+      eg_st4(prod + ng * c, c, ch, make_float4(q.x * acc.x, q.y * acc.y, q.z * acc.z, q.w * acc.w), aligned);
+    }
+    if (w) {
+      const float4 ww = eg_ld4(w, c, ch);
+      acc = make_float4(acc.x * ww.x, acc.y * ww.y, acc.z * ww.z, acc.w * ww.w);
+    }
+    eg_st4(out + ng * c, c, ch, acc, aligned);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -275,6 +346,27 @@ int ptc_aggregation_edge_bwd(const float* src, const float* pos, const float* w,
   hipLaunchKernelGGL(aggregation_edge_bwd_kernel, dim3(eg_grid(m * nsample * w_c)), dim3(EG_THREADS), 0, (hipStream_t)stream, src, pos, w, idx, g, m * nsample, nsample, c,
                                                                                                   w_c, n_src, grad_pos, grad_w);
   PTC_CHECK_LAUNCH("ptc_aggregation_edge_bwd");
+  return PTC_OK;
+}
+
+int ptc_pair_dot_weighted(const float* a, const float* b, const float* w, const int32_t* ia, const int32_t* ib, int64_t m, int64_t n_a,
+                          int64_t n_b, int g, int c, float* out, ptc_stream_t stream) {
+  if (m < 0 || n_a < 0 || n_b < 0 || g <= 0 || c <= 0) { ptc_set_error("ptc_pair_dot_weighted: bad shape"); return PTC_EINVAL; }
+  if (m == 0) return PTC_OK;
+  if (!a || !b || !ia || !ib || !out) { ptc_set_error("ptc_pair_dot_weighted: null pointer"); return PTC_EINVAL; }
+  hipLaunchKernelGGL(pair_dot_kernel, dim3(eg_grid(m * g)), dim3(EG_THREADS), 0, (hipStream_t)stream, a, b, w, ia, ib, m, n_a, n_b, g, c, out);
+  PTC_CHECK_LAUNCH("ptc_pair_dot_weighted");
+  return PTC_OK;
+}
+
+int ptc_pair_segment_sum(const float* s, const float* b, const float* w, const float* self, const int64_t* order, const int64_t* indptr,
+                         const int32_t* oidx, int64_t n_rows, int64_t n_b, int g, int c, float* out, float* prod, ptc_stream_t stream) {
+  if (n_rows < 0 || n_b < 0 || g <= 0 || c <= 0) { ptc_set_error("ptc_pair_segment_sum: bad shape"); return PTC_EINVAL; }
+  if (n_rows == 0) return PTC_OK;
+  if (!indptr || !out || (prod && !self)) { ptc_set_error("ptc_pair_segment_sum: null pointer"); return PTC_EINVAL; }
+  hipLaunchKernelGGL(pair_segment_kernel, dim3(eg_grid(n_rows * g * ((c + 3) / 4))), dim3(EG_THREADS), 0, (hipStream_t)stream, s, b, w, self, order, indptr,
+                     oidx, n_rows, n_b, g, c, out, prod);
+  PTC_CHECK_LAUNCH("ptc_pair_segment_sum");
   return PTC_OK;
 }
 

@@ -326,6 +326,48 @@ def edge_scatter_bwd(mode: int, csr: EdgeCSR, g, w, nsample: int, c: int, w_c: i
     return out
 
 
+def pair_dot_weighted(a, b, w, ia, ib) -> torch.Tensor:
+    """out[m, g] = sum_c a[ia[m], g, c] b[ib[m], g, c] (w[c] | 1); a [n_a, g, c], b [n_b, g, c] fp32, ia / ib [m] int32"""
+    require_cuda(a, b, w, ia, ib)
+    a, b = a.float().contiguous(), b.float().contiguous()
+    if a.dim() != 3 or b.dim() != 3 or a.shape[1:] != b.shape[1:]:
+        raise PtcoreError(f"pair_dot_weighted: rows must be [n, g, c], got {tuple(a.shape)} / {tuple(b.shape)}")
+    ia, ib = ia.reshape(-1).to(torch.int32).contiguous(), ib.reshape(-1).to(torch.int32).contiguous()
+    if ia.numel() != ib.numel():
+        raise PtcoreError("pair_dot_weighted: index lists differ in length")
+    w = None if w is None else w.float().contiguous()
+    _, g, c = a.shape
+    if w is not None and w.numel() != c:
+        raise PtcoreError(f"pair_dot_weighted: weight has {w.numel()} entries, rows have {c} channels")
+    out = torch.empty((ia.numel(), g), dtype=torch.float32, device=a.device)
+    check(lib().ptc_pair_dot_weighted(ptr(a), ptr(b), ptr(w), ptr(ia), ptr(ib), ia.numel(), a.shape[0], b.shape[0], g, c, ptr(out),
+                                      stream_ptr()), "ptc_pair_dot_weighted")
+    return out
+
+
+def pair_segment_sum(s, b, w, self_rows, csr: "EdgeCSR", oidx, want_prod: bool = False):
+    """A[n, g, c] = sum over the pairs e of row n (csr: the pairs by that row, ascending) of s[e, g] b[oidx[e], g, c];
+    -> (A * (w | 1), self_rows * A | None).  s [m, g], b [n_b, g, c] fp32, oidx [m] int32."""
+    require_cuda(s, b, w, self_rows, oidx)
+    csr.build()
+    s, b = s.float().contiguous(), b.float().contiguous()
+    oidx = oidx.reshape(-1).to(torch.int32).contiguous()
+    _, g, c = b.shape
+    if s.shape != (oidx.numel(), g):
+        raise PtcoreError(f"pair_segment_sum: coefficients {tuple(s.shape)} for {oidx.numel()} pairs of {g} groups")
+    w = None if w is None else w.float().contiguous()
+    out = torch.empty((csr.n_src, g, c), dtype=torch.float32, device=b.device)
+    prod = None
+    if want_prod:
+        self_rows = self_rows.float().contiguous()
+        if tuple(self_rows.shape) != (csr.n_src, g, c):
+            raise PtcoreError("pair_segment_sum: self rows do not match the output")
+        prod = torch.empty_like(out)
+    check(lib().ptc_pair_segment_sum(ptr(s), ptr(b), ptr(w), ptr(self_rows) if want_prod else None, ptr(csr.order), ptr(csr.indptr), ptr(oidx),
+                                     csr.n_src, b.shape[0], g, c, ptr(out), ptr(prod), stream_ptr()), "ptc_pair_segment_sum")
+    return out, prod
+
+
 def aggregation_edge_bwd(src, pos, w, idx, g):
     """-> (grad_position [m, nsample, c], grad_weight [m, nsample, w_c]) of libs/pointops aggregation."""
     require_cuda(src, pos, w, idx, g)

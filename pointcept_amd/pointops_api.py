@@ -242,32 +242,65 @@ def aggregation(input, position, weight, idx):
     return _EdgeAggregate.apply(input, position, weight, idx)
 
 
-def _csr_by_target(index_target, n):
-    """edges sorted by target row + CSR pointer: the segmented (atomics-free, fixed-order) form of the scatter-adds"""
-    order = torch.sort(index_target.long(), stable=True).indices
-    counts = torch.bincount(index_target.long(), minlength=n)
-    indptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)])
-    return order, indptr
+class _AttnRelation(torch.autograd.Function):
+    """relation[m, g] = sum_c query[it[m], g, c] key[ir[m], g, c] weight[c]  on csrc/pointops_edges.hip (ptc_pair_dot_weighted;
+    the three gradients are segmented sums over the pairs sorted by the row they scatter to: ptc_pair_segment_sum)"""
+
+    @staticmethod
+    def forward(ctx, query, key, weight, index_target, index_refer):
+        ctx.save_for_backward(query, key, weight, index_target, index_refer)
+        return ops.pair_dot_weighted(query, key, weight, index_target, index_refer)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        query, key, weight, it, ir = ctx.saved_tensors
+        g = g.float().contiguous()
+        dq = dk = dw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            dq, qa = ops.pair_segment_sum(g, key, weight, query, ops.EdgeCSR(it.view(-1, 1), query.shape[0]), ir, want_prod=ctx.needs_input_grad[2])
+            if ctx.needs_input_grad[2]:        # d weight[c] = sum_{n, g} query[n, g, c] A[n, g, c]: one fixed-order column sum
+                dw = ops.column_sum(qa.view(-1, qa.shape[-1])).to(weight.dtype).view_as(weight)
+            dq = dq.to(query.dtype) if ctx.needs_input_grad[0] else None
+        if ctx.needs_input_grad[1]:
+            dk, _ = ops.pair_segment_sum(g, query, weight, None, ops.EdgeCSR(ir.view(-1, 1), key.shape[0]), it)
+            dk = dk.to(key.dtype)
+        return dq, dk, dw, None, None
 
 
 def attention_relation_step(query, key, weight, index_target, index_refer):
-    """libs/pointops/functions/attention.py:11-62 / src/attention/attention_cuda_kernel.cu:9-25:
-    relation[m, g] = sum_c query[index_target[m], g, c] * key[index_refer[m], g, c] * weight[c]   (differentiable)"""
-    return (query[index_target.long()] * key[index_refer.long()] * weight).sum(-1)
+    """libs/pointops/functions/attention.py:11-62 / src/attention/attention_cuda_kernel.cu:9-45:
+    relation[m, g] = sum_c query[index_target[m], g, c] * key[index_refer[m], g, c] * weight[c]   (differentiable in query, key and
+    weight; where the reference scatters its three gradients with atomicAdd these are fixed-order segmented sums)"""
+    return _AttnRelation.apply(query, key, weight, index_target, index_refer)
+
+
+class _AttnFusion(torch.autograd.Function):
+    """out[n, g, c] = sum_{m: it[m] = n} weight[m, g] value[ir[m], g, c]: a segmented sum over the pairs sorted by target row"""
+
+    @staticmethod
+    def forward(ctx, weight, value, index_target, index_refer):
+        ctx.save_for_backward(weight, value, index_target, index_refer)
+        out, _ = ops.pair_segment_sum(weight, value, None, None, ops.EdgeCSR(index_target.view(-1, 1), value.shape[0]), index_refer)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        weight, value, it, ir = ctx.saved_tensors
+        g = g.float().contiguous()
+        dweight = dvalue = None
+        if ctx.needs_input_grad[0]:
+            dweight = ops.pair_dot_weighted(g, value, None, it, ir).to(weight.dtype)
+        if ctx.needs_input_grad[1]:
+            dvalue, _ = ops.pair_segment_sum(weight, g, None, None, ops.EdgeCSR(ir.view(-1, 1), value.shape[0]), it)
+            dvalue = dvalue.to(value.dtype)
+        return dweight, dvalue, None, None
 
 
 def attention_fusion_step(weight, value, index_target, index_refer):
-    """libs/pointops/functions/attention.py:64-120 / attention_cuda_kernel.cu:46-62:
-    out[index_target[m], g, c] += weight[m, g] * value[index_refer[m], g, c].  The reference accumulates with atomicAdd
-    (run-to-run different sums); here the edges are sorted by target and reduced per target row in a fixed order
-    (PF.segment_csr "sum": csrc/rows.hip), output [n, g, c]."""
-    from . import functional as PF
-
-    n, g, c = value.shape
-    order, indptr = _csr_by_target(index_target, n)
-    contrib = (weight.unsqueeze(-1) * value[index_refer.long()]).reshape(-1, g * c)
-    if contrib.is_cuda:
-        out = PF.segment_csr(contrib, indptr, "sum", perm=order)
-    else:
-        out = torch.zeros((n, g * c), dtype=contrib.dtype).index_add_(0, index_target.long(), contrib)
-    return out.view(n, g, c)
+    """libs/pointops/functions/attention.py:64-120 / attention_cuda_kernel.cu:46-82:
+    out[index_target[m], g, c] += weight[m, g] * value[index_refer[m], g, c], output [n, g, c] (n = value rows, as the reference
+    allocates it).  The reference accumulates with atomicAdd (run-to-run different sums); here the pairs are sorted by target and each
+    output row adds its pairs in ascending order (ptc_pair_segment_sum), and so do both gradients.  GPU only, like every engine op."""
+    return _AttnFusion.apply(weight, value, index_target, index_refer)

@@ -363,6 +363,18 @@ def edge_scatter_bwd(mode, csr, g, w, nsample, c, w_c=1, g_col0=0):
     return torch.zeros(csr.n_src, c, dtype=torch.float32).index_add_(0, idx[ok], g[ok])
 
 
+def pair_dot_weighted(a, b, w, ia, ib):
+    r = a.float()[ia.reshape(-1).long()] * b.float()[ib.reshape(-1).long()]
+    return (r if w is None else r * w.float().view(1, 1, -1)).sum(-1)
+
+
+def pair_segment_sum(s, b, w, self_rows, csr, oidx, want_prod=False):
+    rows = csr.idx.reshape(-1).long()
+    A = torch.zeros((csr.n_src,) + tuple(b.shape[1:]), dtype=torch.float32).index_add_(0, rows, s.float().unsqueeze(-1) * b.float()[oidx.reshape(-1).long()])
+    prod = self_rows.float() * A if want_prod else None
+    return (A if w is None else A * w.float().view(1, 1, -1)), prod
+
+
 def aggregation_edge_bwd(src, pos, w, idx, g):
     m, ns, c = pos.shape
     w_c = w.shape[-1]
@@ -384,6 +396,7 @@ _STANDINS = dict(
     attn_rope_supported=lambda d, k: False,      # CPU tier: the rotation pass + the attention stand-in (the same arithmetic)
     attn_hd_supported=lambda d, k: 16 <= d <= 64 and k <= (1024 if d <= 32 else 672 if d <= 48 else 512),
     edge_rows=edge_rows, edge_reduce=edge_reduce, EdgeCSR=EdgeCSR, edge_scatter_bwd=edge_scatter_bwd, aggregation_edge_bwd=aggregation_edge_bwd,
+    pair_dot_weighted=pair_dot_weighted, pair_segment_sum=pair_segment_sum,
     cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum, voxel_keys=voxel_keys,
     layer_norm_supported=lambda c: False, batch_norm_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)
 

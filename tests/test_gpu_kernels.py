@@ -942,6 +942,28 @@ def test_attention_fwd_bwd(cuda, lens, H, monkeypatch):
     assert fro(dqkv, q32.grad) < 2.0 ** -7, fro(dqkv, q32.grad)
 
 
+@pytest.mark.parametrize("lens,H", [([1024] * 5 + [700, 33], 3), ([256, 1, 300], 2)])
+def test_attention_forward_launch_plans_agree_bit_for_bit(cuda, lens, H, monkeypatch):
+    """round 5: the forward keeps the first units of every XCD's chunk whole and cuts only the last partial round into 2 / 4 parts
+    (at_plan_host in attention.hip; PTC_AT_PLAN = "whole,qs" forces a plan, "0" the round-4 uniform split).  A query row is computed
+    by exactly one wave over all keys whichever part owns its tile: every plan must give the same bits, with ragged sequences, chunks
+    shorter than `whole`, and more parts than a short sequence has query tiles."""
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(len(lens) + H)
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).to(cuda)
+    qkv = (torch.randn(T, 3, H, 16, generator=g) * 1.5).to(torch.bfloat16).to(cuda)
+    monkeypatch.delenv("PTC_AT_PLAN", raising=False)
+    out0, lse0 = ops.attn_varlen_fwd(qkv, cu, max(lens), 0.25)
+    ref, ref_lse = oops.attention_varlen(qkv.float().cpu(), cu.cpu(), 0.25, return_lse=True)
+    assert float((out0.float().cpu() - ref).norm() / ref.norm()) < 2.0 ** -8
+    for plan in ("0", "0,1", "0,2", "0,4", "1,2", "1,4", "2,4", "3,2", "1000,4"):
+        monkeypatch.setenv("PTC_AT_PLAN", plan)
+        out, lse = ops.attn_varlen_fwd(qkv, cu, max(lens), 0.25)
+        assert torch.equal(out, out0) and torch.equal(lse, lse0), plan
+
+
 @pytest.mark.parametrize("lens,H", [([1024, 330], 4), ([1, 2, 31, 32, 33, 65], 3)])
 @pytest.mark.parametrize("one_pass", ["0", "1"])
 def test_attention_f16_io_equals_the_reference_cast_passes(cuda, lens, H, one_pass, monkeypatch):
@@ -2188,6 +2210,57 @@ def test_ptv1_ptv2_operators_match_their_definitions(cuda):
     ref = np.zeros((n, g, c), np.float64)
     np.add.at(ref, it, (aw[:, :, None] * k[ir]).astype(np.float64))
     assert np.allclose(fus, ref, atol=1e-4)
+
+
+@pytest.mark.parametrize("c", [12, 16, 5])
+def test_pair_list_attention_steps_and_their_gradients(cuda, c):
+    """attention_relation_step / attention_fusion_step of libs/pointops (functions/attention.py:11-120) on ptc_pair_dot_weighted /
+    ptc_pair_segment_sum: forward and ALL five gradients against the oracle's restatement of the reference's CUDA loops
+    (oracle/pointops_c.py: attention_*_{forward,backward}_cuda), including rows no pair touches, repeated pairs, channel counts that are
+    and are not multiples of 4; two runs are bit-identical (the reference's atomicAdd sums are not)."""
+    from oracle import pointops_c as oc
+    from pointcept_amd import pointops_api as po
+
+    g = torch.Generator().manual_seed(c)
+    n, G, m = 400, 3, 5000
+    q, k = torch.randn(n, G, c, generator=g), torch.randn(n, G, c, generator=g)
+    wt = torch.randn(c, generator=g)
+    it = torch.randint(0, n - 40, (m,), generator=g).int()          # rows n-40.. receive nothing
+    ir = torch.randint(0, n, (m,), generator=g).int()
+    it[:50], ir[:50] = it[50:100], ir[50:100]                       # repeated pairs
+    go = torch.randn(m, G, generator=g)
+    # relation step
+    ref = torch.zeros(m, G)
+    oc.attention_relation_step_forward_cuda(m, G, c, q, k, wt, it, ir, ref)
+    gq, gk, gw = torch.zeros(n, G, c), torch.zeros(n, G, c), torch.zeros(c)
+    oc.attention_relation_step_backward_cuda(m, G, c, q, gq, k, gk, wt, gw, it, ir, go)
+    outs = []
+    for _ in range(2):
+        qd, kd, wd = (t.clone().to(cuda).requires_grad_(True) for t in (q, k, wt))
+        rel = po.attention_relation_step(qd, kd, wd, it.to(cuda), ir.to(cuda))
+        rel.backward(go.to(cuda))
+        outs.append((rel.detach(), qd.grad, kd.grad, wd.grad))
+    assert rel.shape == (m, G) and rel.dtype == torch.float32
+    for name, a, b in zip(("relation", "d query", "d key", "d weight"), outs[0], (ref, gq, gk, gw)):
+        assert torch.allclose(a.cpu(), b, rtol=1e-4, atol=1e-4 * float(b.abs().max())), name
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "bit-reproducible"
+    # fusion step
+    aw = torch.randn(m, G, generator=g)
+    ref = torch.zeros(n, G, c)
+    oc.attention_fusion_step_forward_cuda(m, G, c, aw, k, it, ir, ref)
+    gout = torch.randn(n, G, c, generator=g)
+    gaw, gv = torch.zeros(m, G), torch.zeros(n, G, c)
+    oc.attention_fusion_step_backward_cuda(m, G, c, aw, gaw, k, gv, it, ir, gout)
+    outs = []
+    for _ in range(2):
+        awd, vd = aw.clone().to(cuda).requires_grad_(True), k.clone().to(cuda).requires_grad_(True)
+        fus = po.attention_fusion_step(awd, vd, it.to(cuda), ir.to(cuda))
+        fus.backward(gout.to(cuda))
+        outs.append((fus.detach(), awd.grad, vd.grad))
+    assert fus.shape == (n, G, c) and float(fus[n - 40:].abs().max()) == 0.0
+    for name, a, b in zip(("fusion", "d weight", "d value"), outs[0], (ref, gaw, gv)):
+        assert torch.allclose(a.cpu(), b, rtol=1e-4, atol=1e-4 * float(b.abs().max())), name
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "bit-reproducible"
 
 
 def test_weight_layout_cache_one_launch_refresh(cuda):

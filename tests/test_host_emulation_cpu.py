@@ -189,6 +189,7 @@ EMULATED_GPU_TESTS = [
     ("test_batch_norm_add_act_is_the_residual_block_tail", dict(dtype=torch.bfloat16, n=5003, c=96)),
     ("test_pointops_knn_query", dict(nsample=3)), ("test_seg_eval_hist_matches_the_reference_formula", dict(dtype=torch.float32)),
     ("test_pointops_edge_operators", dict(c=8, w_c=4)), ("test_pointops_edge_operators", dict(c=3, w_c=1)), ("test_pointops_edge_operators", dict(c=6, w_c=2)),
+    ("test_pair_list_attention_steps_and_their_gradients", dict(c=12)), ("test_pair_list_attention_steps_and_their_gradients", dict(c=5)),
     # MFMA kernels: implicit-GEMM convolution / Linear (16x16x32 bf16 / f16, 16x16x4 f32) and window attention (32x32x16 bf16)
     ("test_linear_gather_tables", dict(dtype=torch.bfloat16)),
     ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.bfloat16, cin=64, cout=64)),
@@ -209,6 +210,7 @@ EMULATED_GPU_TESTS = [
     ("test_conv_tiny_inputs", dict(n=17)), ("test_spconv_dgrad_via_mirrored_table", dict()), ("test_spconv_down_up_tables", dict()),
     ("test_pool_maps", dict(n_pts=3000)),
     ("test_attention_fwd_bwd", dict(lens=[48, 48, 17], H=2)), ("test_attention_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
+    ("test_attention_forward_launch_plans_agree_bit_for_bit", dict(lens=[256, 1, 300], H=2)),
     ("test_attention_large_logits", dict()), ("test_attention_dropout_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3, p=0.25)),
     ("test_attention_dropout_fwd_bwd", dict(lens=[200], H=2, p=0.5)), ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3, one_pass="0")),
     ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3, one_pass="1")),
