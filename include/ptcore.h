@@ -340,7 +340,9 @@ int ptc_rope3d_xyz(const void* src, int src_dtype, void* dst, int dst_dtype, con
 
 /* ------------------------------------------------------------------------------------------
  * G2. LayerNorm over channels of [n, c] features (nn.LayerNorm inside every PTv3 Block:
- * ptv3m1:286 cpe.2, :289 norm1, :305 norm2).  c in {32,64,128,256,512} (ptc_layer_norm_supported).
+ * ptv3m1:286 cpe.2, :289 norm1, :305 norm2).  ptc_layer_norm_supported(c): 1 = c in {32,64,128,256,512} (c / 8 lanes per row; the
+ * widths the fused joints of G3 also take), 2 = any other even c <= 1024 (one wave per row: the widths of PT-v3m2 / m3 / LitePT,
+ * configs/sonata :45, configs/utonia :21, litept_v1.py:601), 0 = unsupported (odd or wider).
  *   fwd: y = (x-mean)*rstd*gamma + beta, statistics in fp32; y dtype may differ from x
  *        (fp32 out under autocast, or bf16 out when the consumer is a bf16 GEMM);
  *        mean[n], rstd[n] fp32 are saved for the backward.

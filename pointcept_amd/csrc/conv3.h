@@ -292,7 +292,9 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 
 // dense row-wise GEMM out = in W^T + b on the same kernel (identity table): contractions wider than linear2's 256 channels
 static inline bool conv3_dense_supported(int dtype, int kv, int c_in, int c_out, const int32_t* nbr) {
-  return dtype != PTC_F32 && nbr == nullptr && kv == 1 && c_in > 256 && c_in % 128 == 0 && c_out % 32 == 0;
+  // c_in % 128 != 0 (round 5: the MLP widths of PT-v3m2 / m3 / LitePT, 288 .. 2016): the GEN form, whose last 128-wide chunk is partial
+  // (W zero-filled beyond c_in, gathers of table row 1 = out of range = zeros)
+  return dtype != PTC_F32 && nbr == nullptr && kv == 1 && c_in > 256 && c_in % 32 == 0 && c_out % 32 == 0;
 }
 
 static inline bool conv3_supported(int dtype, int kv, int c_in, int c_out, const int32_t* nbr) {
@@ -366,6 +368,14 @@ static int launch_conv3(const void* in, int64_t n_in, const void* w, const float
   }
 #endif
 #endif
+  if (nbr == nullptr && gen) {   // dense GEMM whose contraction is not a multiple of the 128-wide chunk: identity table + general chunking
+#define C3_IDG_CASE(N)                                                                                                       \
+  if (nt == N)                                                                                                             \
+    return (big && N != 6) ? launch_conv3_i<T, 4, 2, N, true, true>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s)      \
+                           : launch_conv3_i<T, 2, 2, N, true, true>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s);
+    C3_IDG_CASE(4) C3_IDG_CASE(2) C3_IDG_CASE(6)
+#undef C3_IDG_CASE
+  }
   if (nbr == nullptr) {   // dense GEMM (kv = 1, c_in % 128 == 0): identity-table instances
 #define C3_ID_CASE(N)                                                                                                        \
   if (nt == N)                                                                                                             \

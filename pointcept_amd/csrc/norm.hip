@@ -112,6 +112,149 @@ ln_partial_reduce_kernel(const float* __restrict__ partial, int blocks, int c, f
   }
 }
 
+// ---- generic widths (round 5): any even C <= LNG_MAX_C, one wave per row ---------------------------------------------------------
+// The instances above need C / 8 to be a power of two (C = 32 .. 512: PT-v3m1).  PT-v3m2 (48 .. 512), PT-v3m3 (54 .. 576) and LitePT
+// (36 .. 504) normalise over other widths (configs/sonata/*:45, configs/utonia/*:21, pointcept/models/litept/litept_v1.py:601); until
+// round 5 those LayerNorms ran on ATen.  Here a lane holds the channel PAIRS 2 l + 128 k, k < LNG_K, of its wave's row (4- / 8-byte
+// accesses, consecutive lanes consecutive pairs), the statistics are two wave reductions (mean, then the centred second moment --
+// the same two-pass arithmetic as above), and the affine-gradient partials stay in the lane's registers over all rows of the wave.
+#define LNG_K 8
+#define LNG_MAX_C (LNG_K * 128)
+template <typename T>
+__device__ __forceinline__ void lng_load2(const T* p, float& a, float& b);
+template <> __device__ __forceinline__ void lng_load2<float>(const float* p, float& a, float& b) { const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y; }
+template <> __device__ __forceinline__ void lng_load2<bf16_t>(const bf16_t* p, float& a, float& b) {
+  const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+  a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void lng_load2<f16_t>(const f16_t* p, float& a, float& b) {
+  const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+  const _Float16* h = reinterpret_cast<const _Float16*>(&u);
+  a = (float)h[0]; b = (float)h[1];
+}
+template <typename T>
+__device__ __forceinline__ void lng_store2(T* p, float a, float b) {
+  T o[2] = {ptc_from_float<T>(a), ptc_from_float<T>(b)};
+  if (sizeof(T) == 4) *reinterpret_cast<uint2*>(p) = *reinterpret_cast<uint2*>(o);
+  else *reinterpret_cast<uint32_t*>(p) = *reinterpret_cast<uint32_t*>(o);
+}
+__device__ __forceinline__ float lng_wave_sum(float v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(LN_THREADS)
+layer_norm_fwd_generic_kernel(const TI* __restrict__ x, int64_t n, int c, const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float eps, TO* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int WPB = LN_THREADS / 64;
+  const float inv_c = 1.f / (float)c;
+  for (int64_t row = (int64_t)blockIdx.x * WPB + wave; row < n; row += (int64_t)gridDim.x * WPB) {
+    float v[LNG_K][2];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LNG_K; ++k) {
+      const int ch = 2 * lane + 128 * k;
+      v[k][0] = v[k][1] = 0.f;
+      if (ch < c) lng_load2<TI>(x + row * c + ch, v[k][0], v[k][1]);
+      s += v[k][0] + v[k][1];
+    }
+    const float mean = lng_wave_sum(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LNG_K; ++k) {
+      if (2 * lane + 128 * k < c) {
+        const float d0 = v[k][0] - mean, d1 = v[k][1] - mean;
+        q = fmaf(d0, d0, q);
+        q = fmaf(d1, d1, q);
+      }
+    }
+    const float rstd = rsqrtf(fmaf(lng_wave_sum(q), inv_c, eps));
+#pragma unroll
+    for (int k = 0; k < LNG_K; ++k) {
+      const int ch = 2 * lane + 128 * k;
+      if (ch < c) {
+        const float g0 = gamma ? gamma[ch] : 1.f, g1 = gamma ? gamma[ch + 1] : 1.f;
+        const float b0 = beta ? beta[ch] : 0.f, b1 = beta ? beta[ch + 1] : 0.f;
+        lng_store2<TO>(y + row * c + ch, fmaf((v[k][0] - mean) * rstd, g0, b0), fmaf((v[k][1] - mean) * rstd, g1, b1));
+      }
+    }
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  }
+}
+
+template <typename TG, typename TX>
+__global__ void __launch_bounds__(LN_THREADS)
+layer_norm_bwd_generic_kernel(const TG* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ mean,
+                              const float* __restrict__ rstd, const float* __restrict__ gamma, int64_t n, int c, TX* __restrict__ dx,
+                              float* __restrict__ partial /*[grid][2][c]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int WPB = LN_THREADS / 64;
+  __shared__ float red[WPB][2][LNG_MAX_C];
+  const float inv_c = 1.f / (float)c;
+  float g[LNG_K][2], dg[LNG_K][2], db[LNG_K][2];
+#pragma unroll
+  for (int k = 0; k < LNG_K; ++k) {
+    const int ch = 2 * lane + 128 * k;
+    g[k][0] = (gamma && ch < c) ? gamma[ch] : 1.f;
+    g[k][1] = (gamma && ch < c) ? gamma[ch + 1] : 1.f;
+    dg[k][0] = dg[k][1] = db[k][0] = db[k][1] = 0.f;
+  }
+  for (int64_t row = (int64_t)blockIdx.x * WPB + wave; row < n; row += (int64_t)gridDim.x * WPB) {
+    const float m = mean[row], rs = rstd[row];
+    float xh[LNG_K][2], w[LNG_K][2];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < LNG_K; ++k) {
+      const int ch = 2 * lane + 128 * k;
+      xh[k][0] = xh[k][1] = w[k][0] = w[k][1] = 0.f;
+      if (ch < c) {
+        float x0, x1, g0, g1;
+        lng_load2<TX>(x + row * c + ch, x0, x1);
+        lng_load2<TG>(dy + row * c + ch, g0, g1);
+        xh[k][0] = (x0 - m) * rs; xh[k][1] = (x1 - m) * rs;
+        w[k][0] = g0 * g[k][0]; w[k][1] = g1 * g[k][1];
+        s1 += w[k][0] * xh[k][0] + w[k][1] * xh[k][1];
+        s2 += w[k][0] + w[k][1];
+        dg[k][0] += g0 * xh[k][0]; dg[k][1] += g1 * xh[k][1];
+        db[k][0] += g0; db[k][1] += g1;
+      }
+    }
+    const float c1 = lng_wave_sum(s1) * inv_c, c2 = lng_wave_sum(s2) * inv_c;
+#pragma unroll
+    for (int k = 0; k < LNG_K; ++k) {
+      const int ch = 2 * lane + 128 * k;
+      if (ch < c) lng_store2<TX>(dx + row * c + ch, (w[k][0] - c2 - xh[k][0] * c1) * rs, (w[k][1] - c2 - xh[k][1] * c1) * rs);
+    }
+  }
+  // the four waves' partials meet in LDS and leave as one [2][c] row per block (fixed order: wave 0 .. 3)
+#pragma unroll
+  for (int k = 0; k < LNG_K; ++k) {
+    const int ch = 2 * lane + 128 * k;
+    if (ch < c) {
+      red[wave][0][ch] = dg[k][0]; red[wave][0][ch + 1] = dg[k][1];
+      red[wave][1][ch] = db[k][0]; red[wave][1][ch + 1] = db[k][1];
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * c; t += LN_THREADS) {
+    const int which = t / c, ch = t - which * c;
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < WPB; ++wv) s += red[wv][which][ch];
+    partial[((int64_t)blockIdx.x * 2 + which) * c + ch] = s;
+  }
+}
+
+static int lng_grid(int64_t n) {
+  int64_t g = ptc_cdiv(n, LN_THREADS / 64);
+  if (g > 2048) g = 2048;
+  return (int)(g < 1 ? 1 : g);
+}
+static bool ln_generic_c(int c) { return c >= 2 && c <= LNG_MAX_C && (c & 1) == 0; }
+
 static int ln_grid(int64_t n, int lpr) {
   const int rpb = LN_THREADS / lpr;
   int64_t g = ptc_cdiv(n, rpb);
@@ -120,11 +263,18 @@ static int ln_grid(int64_t n, int lpr) {
 }
 static bool ln_supported_c(int c) { return c == 32 || c == 64 || c == 128 || c == 256 || c == 512; }
 
-extern "C" int ptc_layer_norm_supported(int c) { return ln_supported_c(c) ? 1 : 0; }
+// 1: the C / 8-lanes-per-row instances (and the fused residual joints, ptc_add_norm_*); 2: the wave-per-row generic form; 0: neither
+extern "C" int ptc_layer_norm_supported(int c) { return ln_supported_c(c) ? 1 : (ln_generic_c(c) ? 2 : 0); }
 
 template <typename TI, typename TO>
 static int launch_ln_fwd(const void* x, int64_t n, int c, const float* gamma, const float* beta, float eps, void* y,
                          float* mean, float* rstd, hipStream_t s) {
+  if (!ln_supported_c(c)) {
+    hipLaunchKernelGGL((layer_norm_fwd_generic_kernel<TI, TO>), dim3(lng_grid(n)), dim3(LN_THREADS), 0, s, (const TI*)x, n, c, gamma, beta, eps,
+                       (TO*)y, mean, rstd);
+    PTC_CHECK_LAUNCH("layer_norm_fwd_generic_kernel");
+    return PTC_OK;
+  }
 #define LN_FWD_CASE(LPR)                                                                                     \
   hipLaunchKernelGGL((layer_norm_fwd_kernel<TI, TO, LPR>), dim3(ln_grid(n, LPR)), dim3(LN_THREADS), 0, s,    \
                      (const TI*)x, n, gamma, beta, eps, (TO*)y, mean, rstd)
@@ -143,7 +293,7 @@ static int launch_ln_fwd(const void* x, int64_t n, int c, const float* gamma, co
 extern "C" int ptc_layer_norm_fwd(const void* x, int64_t n, int c, int in_dtype, const float* gamma, const float* beta,
                                   float eps, void* y, int out_dtype, float* mean, float* rstd, ptc_stream_t stream) {
   PTC_REQUIRE(n >= 0, PTC_EINVAL, "ptc_layer_norm_fwd: n < 0");
-  PTC_REQUIRE(ln_supported_c(c), PTC_EUNSUPPORTED, "ptc_layer_norm_fwd: C=%d not in {32,64,128,256,512}", c);
+  PTC_REQUIRE(ln_supported_c(c) || ln_generic_c(c), PTC_EUNSUPPORTED, "ptc_layer_norm_fwd: C=%d is neither in {32,64,128,256,512} nor even and <= %d", c, LNG_MAX_C);
   if (n == 0) return PTC_OK;
   PTC_REQUIRE(x && y && mean && rstd, PTC_EINVAL, "ptc_layer_norm_fwd: null buffer");
   PTC_REQUIRE(out_dtype == PTC_F32 || out_dtype == in_dtype || in_dtype == PTC_F32, PTC_EUNSUPPORTED,
@@ -161,13 +311,24 @@ extern "C" int ptc_layer_norm_fwd(const void* x, int64_t n, int c, int in_dtype,
 }
 
 extern "C" size_t ptc_layer_norm_bwd_workspace_bytes(int64_t n, int c) {
-  if (!ln_supported_c(c)) return 256;
+  if (!ln_supported_c(c)) return ln_generic_c(c) ? ptc_align_up((size_t)lng_grid(n) * 2 * (size_t)c * sizeof(float), 256) : 256;
   return ptc_align_up((size_t)ln_grid(n, c / LN_VEC) * 2 * (size_t)c * sizeof(float), 256);
 }
 
 template <typename TG, typename TX>
 static int launch_ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                          int64_t n, int c, void* dx, float* dgamma, float* dbeta, void* ws, hipStream_t s) {
+  if (!ln_supported_c(c)) {
+    const int grid = lng_grid(n);
+    hipLaunchKernelGGL((layer_norm_bwd_generic_kernel<TG, TX>), dim3(grid), dim3(LN_THREADS), 0, s, (const TG*)dy, (const TX*)x, mean, rstd, gamma,
+                       n, c, (TX*)dx, (float*)ws);
+    PTC_CHECK_LAUNCH("layer_norm_bwd_generic_kernel");
+    if (dgamma || dbeta) {
+      hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((unsigned)ptc_cdiv(2 * c, 32)), dim3(1024), 0, s, (const float*)ws, grid, c, dgamma, dbeta);
+      PTC_CHECK_LAUNCH("ln_partial_reduce_kernel");
+    }
+    return PTC_OK;
+  }
   const int lpr = c / LN_VEC;
   const int grid = ln_grid(n, lpr);
 #define LN_BWD_CASE(LPR)                                                                                          \
@@ -194,7 +355,7 @@ extern "C" int ptc_layer_norm_bwd(const void* dy, int dy_dtype, const void* x, i
                                   const float* rstd, const float* gamma, int64_t n, int c, void* dx, float* dgamma,
                                   float* dbeta, void* workspace, size_t workspace_bytes, ptc_stream_t stream) {
   PTC_REQUIRE(n >= 0, PTC_EINVAL, "ptc_layer_norm_bwd: n < 0");
-  PTC_REQUIRE(ln_supported_c(c), PTC_EUNSUPPORTED, "ptc_layer_norm_bwd: C=%d not in {32,64,128,256,512}", c);
+  PTC_REQUIRE(ln_supported_c(c) || ln_generic_c(c), PTC_EUNSUPPORTED, "ptc_layer_norm_bwd: C=%d is neither in {32,64,128,256,512} nor even and <= %d", c, LNG_MAX_C);
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {
     if (dgamma) PTC_HIP(hipMemsetAsync(dgamma, 0, (size_t)c * 4, s));

@@ -427,13 +427,18 @@ def sparse_conv(feat, weight, bias, nbr, nbr_t, mirror: bool, dup_out=None, dup_
 # ------------------------------------------------------------------------------------------------
 # dense row-wise GEMM (nn.Linear on [N,C] point features) on the sparse-conv MFMA kernels
 # ------------------------------------------------------------------------------------------------
-# Shape policy: contractions of <= 256 channels run on the persistent linear2 kernel, wider ones that are a multiple of 128 (PTv3's
-# fc2 / dgrad-of-fc1 / qkv / proj of the 128..512-channel stages: K = 512, 1024, 2048) on the chunked implicit-GEMM kernel with an
-# identity table (csrc/conv3.h, IDENT), every weight gradient on the split-K kernel (wgrad2).  Round 2 sent the wide ones and the
-# small-row weight gradients to hipBLASLt (45 library GEMMs per step, VERDICT r2 missing 2); only contractions that are neither
-# <= 256 nor a multiple of 128 (no PT-v3m1 / SpUNet shape) still do.
+# Shape policy: contractions of <= 256 channels run on the persistent linear2 kernel, wider ones on the chunked implicit-GEMM kernel with
+# an identity table (csrc/conv3.h, IDENT: multiples of 128 -- PTv3's fc2 / dgrad-of-fc1 / qkv / proj of the 128..512-channel stages --
+# and, round 5, every multiple of 32 through its general chunking: the 288 .. 2304-wide MLPs of PT-v3m2 / m3 / LitePT), every weight
+# gradient on the split-K kernel (wgrad2).  Operands are zero-padded to the kernels' granularity (`_gemm_pad`): 16 channels, 32 on
+# both sides as soon as either side of the GEMM exceeds 256 (its input-gradient GEMM contracts over the OUTPUT width).  There is no
+# library GEMM behind this file (rounds 2-4 sent what the kernels did not cover to hipBLASLt).
 def _own_gemm(n_rows: int, k: int, dtype: torch.dtype, c_out: int = 32) -> bool:
-    return dtype != torch.float32 and (k <= 256 or (k % 128 == 0 and c_out % 32 == 0))
+    return dtype != torch.float32 and (k <= 256 or (k % 32 == 0 and c_out % 32 == 0))
+
+
+def _gemm_pad(c_in: int, c_out: int, dtype: torch.dtype) -> int:
+    return 32 if (dtype != torch.float32 and (c_in > 256 or c_out > 256)) else 16
 
 
 class _Linear(Function):
@@ -445,13 +450,12 @@ class _Linear(Function):
     def forward(ctx, x, weight, bias, tab_fwd, tab_bwd):
         dt = _autocast_dtype(x)
         c_out, c_in = weight.shape
-        xp = _pad_to(x.to(dt), 1, 16).contiguous()
-        wp = _pad_to(_pad_to(_cast_cache.get(weight, dt), 1, 16), 0, 16).contiguous()
-        if tab_fwd is not None or dt == torch.float32 or _own_gemm(xp.shape[0], xp.shape[1], dt, wp.shape[0]):
-            bp = None if bias is None else _pad_to(bias.float(), 0, 16)
-            out = ops.spconv_fwd(xp, wp[:, None, :], bp, tab_fwd)
-        else:
-            out = F.linear(xp, wp, None if bias is None else _pad_to(bias.to(dt), 0, 16))
+        pad = _gemm_pad(c_in, c_out, dt)
+        xp = _pad_to(x.to(dt), 1, pad).contiguous()
+        wp = _pad_to(_pad_to(_cast_cache.get(weight, dt), 1, pad), 0, pad).contiguous()
+        bp = None if bias is None else _pad_to(bias.float(), 0, pad)
+        out = ops.spconv_fwd(xp, wp[:, None, :], bp, tab_fwd)        # linear2 / conv3 (identity table) / the fp32 kernels: no library GEMM
+        ctx.pad = pad
         ctx.save_for_backward(xp, wp, tab_fwd, tab_bwd)
         ctx.shape = (c_out, c_in)
         ctx.in_dtype, ctx.w_dtype = x.dtype, weight.dtype
@@ -463,7 +467,7 @@ class _Linear(Function):
     def backward(ctx, grad):
         xp, wp, tab_fwd, tab_bwd = ctx.saved_tensors
         c_out, c_in = ctx.shape
-        g = _pad_to(grad.to(xp.dtype), 1, 16).contiguous()
+        g = _pad_to(grad.to(xp.dtype), 1, ctx.pad).contiguous()
         dx = dw = db = None
         want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:
@@ -473,16 +477,13 @@ class _Linear(Function):
             if want_b:
                 db = dbp[:c_out].to(ctx.b_dtype)
         if ctx.needs_input_grad[0]:
-            if tab_bwd is not None or xp.dtype == torch.float32 or _own_gemm(xp.shape[0], g.shape[1], xp.dtype, xp.shape[1]):
-                slots = tab_bwd.shape[0] if tab_bwd is not None else 1
-                wt = _cast_cache.layout(wp, "repeat", slots) if slots > 1 else _cast_cache.layout(wp, "mirror")
-                if wt is None:
-                    wt = wp.t().contiguous()[:, None, :]                       # [c_in, 1, c_out]
-                    if slots > 1:
-                        wt = wt.expand(-1, slots, -1).contiguous()              # same W for every slot
-                dx = ops.spconv_fwd(g, wt, None, tab_bwd)
-            else:
-                dx = g @ wp
+            slots = tab_bwd.shape[0] if tab_bwd is not None else 1
+            wt = _cast_cache.layout(wp, "repeat", slots) if slots > 1 else _cast_cache.layout(wp, "mirror")
+            if wt is None:
+                wt = wp.t().contiguous()[:, None, :]                       # [c_in, 1, c_out]
+                if slots > 1:
+                    wt = wt.expand(-1, slots, -1).contiguous()              # same W for every slot
+            dx = ops.spconv_fwd(g, wt, None, tab_bwd)
             dx = dx[:, :c_in].to(ctx.in_dtype)
         return dx, dw, db, None, None
 
@@ -1056,10 +1057,7 @@ class _MLP(Function):
         xp = x.to(dt).contiguous()
         w1c, w2c = _cast_cache.get(w1, dt).contiguous(), _cast_cache.get(w2, dt).contiguous()
         h, a = ops.linear_gelu_fwd(xp, w1c, b1)
-        if _own_gemm(a.shape[0], a.shape[1], dt, w2c.shape[0]):
-            out = ops.spconv_fwd(a, w2c[:, None, :], None if b2 is None else b2.float(), None)
-        else:
-            out = F.linear(a, w2c, None if b2 is None else b2.to(dt))
+        out = ops.spconv_fwd(a, w2c[:, None, :], None if b2 is None else b2.float(), None)      # shapes: mlp_gelu_supported
         ctx.save_for_backward(xp, h, a, w1c, w2c)
         ctx.dtypes = (x.dtype, w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
         return out
@@ -1087,12 +1085,8 @@ class _MLP(Function):
         db1 = None if db1 is None else db1.to(b1_dt)
         dx = None
         if ctx.needs_input_grad[0]:
-            if _own_gemm(n, dh.shape[1], xp.dtype, xp.shape[1]):
-                w1t = _cast_cache.layout(w1c, "mirror")
-                dx = ops.spconv_fwd(dh, w1c.t().contiguous()[:, None, :] if w1t is None else w1t, None, None)
-            else:
-                dx = dh @ w1c
-            dx = dx.to(x_dt)
+            w1t = _cast_cache.layout(w1c, "mirror")
+            dx = ops.spconv_fwd(dh, w1c.t().contiguous()[:, None, :] if w1t is None else w1t, None, None).to(x_dt)
         return dx, dw1, db1, dw2, db2
 
 
@@ -1101,8 +1095,11 @@ def mlp_gelu_supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> b
         return False
     dt = torch.get_autocast_dtype("cuda") if _autocast_on() else x.dtype
     hidden, c = w1.shape
+    # (fc2 and fc1's input gradient contract over `hidden`: beyond linear2's 256 channels they run on the identity-table kernel, which
+    #  wants 32-channel multiples on both sides -- other widths take the unfused Linear -> GELU -> Linear, whose operands are padded)
     return (dt in (torch.bfloat16, torch.float16) and c % 16 == 0 and hidden % 16 == 0 and w2.shape[0] % 16 == 0
-            and ops.linear_supported_ex(c, hidden, dt) and ops.linear_supported_ex(w2.shape[0], hidden, dt))
+            and ops.linear_supported_ex(c, hidden, dt) and ops.linear_supported_ex(w2.shape[0], hidden, dt)
+            and _own_gemm(0, hidden, dt, w2.shape[0]) and _own_gemm(0, hidden, dt, c))
 
 
 def mlp_gelu(x, w1, b1, w2, b2):

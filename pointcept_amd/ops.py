@@ -708,7 +708,13 @@ _DT = {torch.float32: _lib.PTC_F32, torch.float16: _lib.PTC_F16, torch.bfloat16:
 
 
 def layer_norm_supported(c: int) -> bool:
-    return bool(lib().ptc_layer_norm_supported(int(c)))
+    """the power-of-two instances (C = 32 .. 512): LayerNorm AND the fused residual joints (add_norm_*)"""
+    return lib().ptc_layer_norm_supported(int(c)) == 1
+
+
+def layer_norm_available(c: int) -> bool:
+    """layer_norm_fwd / _bwd take this width (the instances above, or the wave-per-row form: any even C <= 1024)"""
+    return lib().ptc_layer_norm_supported(int(c)) != 0
 
 
 def layer_norm_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype: torch.dtype):

@@ -147,10 +147,8 @@ def rulebook_down(indices, coord_bits, batch_bits):
 
 def spconv_fwd(feat, weight, bias, nbr, blk=None):
     f, w = feat.float(), weight.float()
-    if nbr is None:
-        out = f @ w[:, 0, :].t()
-        if bias is not None:
-            out = out + bias.float()
+    if nbr is None:      # the dense GEMM behind nn.Linear: the same torch call as the oracle model's (bit-identical fp32 sums -- the shrunk
+        out = torch.nn.functional.linear(f, w[:, 0, :], None if bias is None else bias.float())      # dry-run scenes are ill-conditioned)
     else:
         out = oops.gather_conv(f, w, None if bias is None else bias.float(), _np(nbr))
     return out.to(feat.dtype)
@@ -363,6 +361,27 @@ def edge_scatter_bwd(mode, csr, g, w, nsample, c, w_c=1, g_col0=0):
     return torch.zeros(csr.n_src, c, dtype=torch.float32).index_add_(0, idx[ok], g[ok])
 
 
+def layer_norm_fwd(x, gamma, beta, eps, out_dtype):
+    xf = x.float()
+    y = torch.nn.functional.layer_norm(xf, (xf.shape[1],), None if gamma is None else gamma.float(), None if beta is None else beta.float(), eps)
+    return y.to(out_dtype), xf.mean(1), torch.rsqrt(xf.var(1, unbiased=False) + eps)
+
+
+def layer_norm_bwd(dy, x, mean, rstd, gamma, want_affine=True):
+    # torch's own backward of the same call (the oracle model's op): eps is recovered from the saved statistics' definition
+    xf = x.detach().float().requires_grad_(True)
+    g = None if gamma is None else gamma.detach().float().requires_grad_(True)
+    b = None if gamma is None else torch.zeros_like(g).requires_grad_(True)
+    eps = float((1.0 / rstd[0].double() ** 2 - xf[0].double().var(unbiased=False)).clamp(min=0)) if xf.shape[0] else 1e-5
+    with torch.enable_grad():
+        y = torch.nn.functional.layer_norm(xf, (xf.shape[1],), g, b, eps)
+    grads = torch.autograd.grad(y, [xf] + ([g, b] if g is not None else []), dy.float())
+    if gamma is None:
+        xh = (x.float() - mean[:, None]) * rstd[:, None]
+        return grads[0].to(x.dtype), ((dy.float() * xh).sum(0) if want_affine else None), (dy.float().sum(0) if want_affine else None)
+    return grads[0].to(x.dtype), (grads[1] if want_affine else None), (grads[2] if want_affine else None)
+
+
 def pair_dot_weighted(a, b, w, ia, ib):
     r = a.float()[ia.reshape(-1).long()] * b.float()[ib.reshape(-1).long()]
     return (r if w is None else r * w.float().view(1, 1, -1)).sum(-1)
@@ -398,7 +417,7 @@ _STANDINS = dict(
     edge_rows=edge_rows, edge_reduce=edge_reduce, EdgeCSR=EdgeCSR, edge_scatter_bwd=edge_scatter_bwd, aggregation_edge_bwd=aggregation_edge_bwd,
     pair_dot_weighted=pair_dot_weighted, pair_segment_sum=pair_segment_sum,
     cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum, voxel_keys=voxel_keys,
-    layer_norm_supported=lambda c: False, batch_norm_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)
+    layer_norm_supported=lambda c: False, layer_norm_available=lambda c: c % 2 == 0 and c <= 1024, layer_norm_fwd=layer_norm_fwd, layer_norm_bwd=layer_norm_bwd, batch_norm_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)
 
 
 @contextlib.contextmanager

@@ -659,7 +659,12 @@ def test_spconv_down_up_tables(cuda):
 @pytest.mark.parametrize("n,cin,cout", [(1, 32, 96), (5000, 32, 96), (3001, 64, 192), (777, 128, 512), (300, 512, 2048),
                                         (900, 2048, 512), (2500, 64, 20), (4100, 6, 32), (2821, 512, 1536), (12115, 1024, 256),
                                         (50360, 512, 128), (2821, 512, 512), (70000, 256, 1024),
-                                        (16500, 512, 512)])    # 65 x 4 wide (128-column) workgroups: conv3's NTILES = 8 instance, forward and dgrad
+                                        (16500, 512, 512),     # 65 x 4 wide (128-column) workgroups: conv3's NTILES = 8 instance, forward and dgrad
+                                        # round 5: contractions that are no multiple of 128 (general chunking of the identity-table kernel, operands
+                                        # padded to 32): the MLP / qkv shapes of LitePT (36 .. 504), PT-v3m3 (54 .. 576) and PT-v3m2 (48 .. 384)
+                                        (3000, 72, 288), (3000, 288, 72), (2000, 144, 576), (2000, 576, 144), (1500, 252, 1008), (1500, 1008, 252),
+                                        (900, 504, 2016), (900, 2016, 504), (1200, 432, 1728), (1200, 1728, 432), (700, 576, 2304), (700, 2304, 576),
+                                        (40000, 108, 432), (40000, 432, 108), (2500, 216, 648), (5000, 96, 288), (70000, 288, 96), (3000, 864, 216)])
 def test_linear_identity_table(cuda, dtype, n, cin, cout):
     """PF.linear == F.linear (forward, input / weight / bias gradients) incl. channel padding; the contractions wider than 256 (the
     last cases = the qkv / fc2 / proj / fc1-dgrad shapes of PT-v3m1's 128 .. 512-channel stages) run on the identity-table instances of
@@ -770,10 +775,13 @@ def test_linear_gather_tables(cuda, dtype):
     _close("glinear2_dx", ae.grad, ar.grad, rtol, atol * 8)
 
 
-@pytest.mark.parametrize("c", [32, 64, 128, 256, 512])
+@pytest.mark.parametrize("c", [32, 64, 128, 256, 512,
+                               36, 48, 54, 72, 96, 108, 144, 192, 216, 252, 384, 432, 504, 576, 1024, 2])   # round 5: the wave-per-row form
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
 def test_layer_norm_fwd_bwd(cuda, c, xdt, ydt):
+    """c in {32 .. 512}: the C / 8-lanes-per-row instances; every other width: the generic wave-per-row kernels -- the LayerNorm widths of
+    PT-v3m2 (configs/sonata/*:45), PT-v3m3 (configs/utonia/*:21) and LitePT (litept_v1.py:601), plus the edges 2 and 1024"""
     from pointcept_amd import ops
 
     n = 70001 if c <= 64 else 5003
@@ -891,9 +899,11 @@ def test_layer_norm_empty_and_unsupported(cuda):
     from pointcept_amd import ops
     from pointcept_amd._lib import PtcoreError
 
-    assert not ops.layer_norm_supported(48)
-    with pytest.raises(PtcoreError):
-        ops.layer_norm_fwd(torch.zeros(4, 48, device=cuda), None, None, 1e-5, torch.float32)
+    assert not ops.layer_norm_supported(48) and ops.layer_norm_available(48) and ops.layer_norm_available(1024)
+    assert not ops.layer_norm_available(49) and not ops.layer_norm_available(1026)
+    for c in (49, 1026):
+        with pytest.raises(PtcoreError):
+            ops.layer_norm_fwd(torch.zeros(4, c, device=cuda), None, None, 1e-5, torch.float32)
     y, m, r = ops.layer_norm_fwd(torch.zeros(0, 64, device=cuda), None, None, 1e-5, torch.float32)
     assert y.shape == (0, 64)
 

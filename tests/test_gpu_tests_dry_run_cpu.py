@@ -61,6 +61,15 @@ def test_gpu_m3_litept_test_bodies_on_cpu_standins(name):
         getattr(T, name)(torch.device("cpu"))
 
 
+@pytest.mark.parametrize("family", ["m2", "m3", "litept"])
+def test_f2_models_at_shipped_widths_body_on_cpu_standins(family, monkeypatch):
+    """the 48 .. 576-channel configurations of the reference's m2 / m3 / LitePT configs construct and step (host logic, padding rules)"""
+    import test_gpu_m3_litept as T
+
+    with mock_backend.cpu_ops():
+        T.test_f2_models_at_shipped_widths_run_on_the_engine_only(torch.device("cpu"), family, monkeypatch)
+
+
 @pytest.mark.parametrize("name", ["test_sync_bn_conversion_ptv3_keeps_every_activation",
                                   "test_sync_bn_conversion_spunet_degrades_to_the_three_pass_block",
                                   "test_sync_bn_conversion_litept_matches_the_reference_golden",

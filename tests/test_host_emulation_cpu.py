@@ -184,6 +184,8 @@ EMULATED_GPU_TESTS = [
     ("test_pool_level_counts", dict(row=0)), ("test_coord_max", dict(n=5000, dtype=torch.int32)),
     ("test_column_sum", dict(dtype=torch.float32, n=3000, c=64)),
     ("test_layer_norm_fwd_bwd", dict(c=64, xdt=torch.float32, ydt=torch.float32)),
+    ("test_layer_norm_fwd_bwd", dict(c=36, xdt=torch.float32, ydt=torch.bfloat16)), ("test_layer_norm_fwd_bwd", dict(c=432, xdt=torch.bfloat16, ydt=torch.float32)),
+    ("test_layer_norm_fwd_bwd", dict(c=1024, xdt=torch.bfloat16, ydt=torch.bfloat16)), ("test_layer_norm_empty_and_unsupported", dict()),
     ("test_add_norm_fused_joint", dict(c=32, mode="ln_add_ln")), ("test_add_norm_fused_joint", dict(c=128, mode="add_ln_scaled")),
     ("test_batch_norm_act_train", dict(dtype=torch.float32, n=3000, c=64, act="gelu")),
     ("test_batch_norm_add_act_is_the_residual_block_tail", dict(dtype=torch.bfloat16, n=5003, c=96)),
@@ -196,6 +198,8 @@ EMULATED_GPU_TESTS = [
     ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.float16, cin=128, cout=32)),
     ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.bfloat16, cin=128, cout=128)),
     ("test_linear_identity_table", dict(dtype=torch.float32, n=1000, cin=32, cout=64)),
+    ("test_linear_identity_table", dict(dtype=torch.bfloat16, n=300, cin=72, cout=288)), ("test_linear_identity_table", dict(dtype=torch.bfloat16, n=300, cin=288, cout=72)),
+    ("test_linear_identity_table", dict(dtype=torch.float16, n=200, cin=432, cout=108)), ("test_linear_identity_table", dict(dtype=torch.bfloat16, n=150, cin=1008, cout=252)),
     ("test_spconv_fwd_and_wgrad", dict(dtype=torch.bfloat16, cin=32, cout=32, ksize=3)),
     ("test_spconv_fwd_chunked_pipeline", dict(cin=128, cout=128, ksize=3, n_pts=700)),      # conv3 with the two-chunk gather ring (DEEP)
     # (sizes: the smallest that still give several 128-row blocks per persistent workgroup / slice sequence -- the emulated MFMA loops
@@ -329,7 +333,7 @@ def test_whole_ptv3_step_with_every_kernel_on_the_emulation():
 
     if not emu_backend.available():
         pytest.skip("no host clang++ under /opt/rocm")
-    names = [n for n in mock_backend._STANDINS if n not in ("layer_norm_supported", "batch_norm_supported", "linear_supported_ex")]
+    names = [n for n in mock_backend._STANDINS if n not in ("layer_norm_supported", "layer_norm_available", "batch_norm_supported", "linear_supported_ex")]
     with emu_backend.hybrid(names):
         T.test_ptv3_two_scenes_forward_backward_vs_oracle(torch.device("cpu"))
 
