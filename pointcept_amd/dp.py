@@ -61,16 +61,26 @@ def _gpu_local_cores(index: int) -> List[int] | None:
 def rank_core_share(local_rank: int, local_world: int, allowed: List[int], numa_cores: List[List[int] | None] | None = None,
                     reserve: int = 0) -> List[int]:
     """The cores rank `local_rank` of `local_world` ranks on this node may run on: the cores of its GPU's NUMA node (`numa_cores[r]`,
-    restricted to `allowed`) divided evenly among the ranks that share that node, or an even slice of `allowed` when the
-    topology is unknown.  Pure function of its arguments (tests/test_dp_gloo.py); disjoint across ranks by construction."""
+    restricted to `allowed`) divided evenly among the ranks that share that node -- used only when EVERY rank's node is known and
+    has at least one core per rank that shares it (the decision is the same on all ranks, so the NUMA-local shares and the fallback never
+    mix) -- else an even slice of `allowed`.  Pure function of its arguments (tests/test_dp_gloo.py); shares of different ranks are
+    disjoint whenever `allowed` has at least `local_world` cores."""
     allowed = sorted(allowed)
-    if numa_cores is not None and all(c for c in numa_cores):
-        mine = [c for c in numa_cores[local_rank] if c in set(allowed)]
-        peers = [r for r in range(local_world) if numa_cores[r] == numa_cores[local_rank]]
-        if mine and len(mine) >= len(peers):
-            per = len(mine) // len(peers)
-            k = peers.index(local_rank)
-            return mine[k * per:(k + 1) * per]
+    aset = set(allowed)
+
+    def numa_share(r):
+        mine = [c for c in numa_cores[r] if c in aset]
+        peers = [q for q in range(local_world) if numa_cores[q] == numa_cores[r]]
+        if not mine or len(mine) < len(peers):
+            return None
+        per = len(mine) // len(peers)
+        k = peers.index(r)
+        return mine[k * per:(k + 1) * per]
+
+    if numa_cores is not None and len(numa_cores) >= local_world and all(c for c in numa_cores[:local_world]):
+        shares = [numa_share(r) for r in range(local_world)]
+        if all(shares):
+            return shares[local_rank]
     per = max(1, len(allowed) // max(1, local_world))
     lo = (local_rank * per) % len(allowed)
     return allowed[lo:lo + per] or allowed
@@ -79,7 +89,10 @@ def rank_core_share(local_rank: int, local_world: int, allowed: List[int], numa_
 def pin_rank_to_cores(local_rank: int, local_world: int, max_threads: int = 8) -> dict:
     """One Python process per GPU shares the host (pointcept/engines/train.py:185-246 under launch.py:106-136): give every rank its own
     NUMA-local cores and a bounded intra-op thread pool, so that eight enqueue threads (~25 ms of one core per step each) and their
-    OpenMP / ATen pools do not migrate across sockets or oversubscribe each other.  Returns what was done (goes into bench.py's line)."""
+    OpenMP / ATen pools do not migrate across sockets or oversubscribe each other.  Returns what was done (goes into bench.py's line).
+    Call it BEFORE the first parallel torch op of the process: sched_setaffinity(0) moves the calling thread (threads created later
+    inherit its mask; pool threads that already exist keep theirs), and OMP_NUM_THREADS only sizes pools that are not yet built --
+    torch.set_num_threads below resizes the intra-op pool either way."""
     if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return {"pinned": False}
     allowed = sorted(os.sched_getaffinity(0))

@@ -38,9 +38,10 @@ def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
         # no library (SDPA) backend behind this mirror: outside the kernels' range the call fails loudly
         raise PtcoreError(f"flash_attn_varlen_qkvpacked_func: head_dim={int(qkv.shape[3])} with max_seqlen={int(max_seqlen)} is outside the "
                           "window-attention kernels' range (head_dim 16..32: 1024 keys, ..48: 672, ..64: 512) -- PTC_EUNSUPPORTED")
-    if qkv.dtype == torch.float16 and int(qkv.shape[3]) == 16:
+    if qkv.dtype == torch.float16 and int(qkv.shape[3]) == 16 and dropout_p != 0.0:
         # fp16 operands at head_dim 16: the head_dim-16 kernels compute in bf16 (what every PT-v3 call site asks for by casting first);
         # an fp16 caller of THIS shape gets its operands re-rounded to bf16 (three mantissa bits) and fp16 back -- stated deviation.
-        # head_dim 17..64 (LitePT, litept_v1.py:259-265) runs f16-operand instances: no re-rounding (round 4).
+        # Without dropout the f16-I/O instances do both roundings in their load / store paths (same bits, no cast passes: below); the
+        # dropout kernels have bf16 I/O only.  head_dim 17..64 (LitePT, litept_v1.py:259-265) runs f16-operand instances: no re-rounding.
         return PF.attn_varlen_qkvpacked(qkv.to(torch.bfloat16), cu_seqlens, max_seqlen, softmax_scale, dropout_p).to(torch.float16)
     return PF.attn_varlen_qkvpacked(qkv, cu_seqlens, max_seqlen, softmax_scale, dropout_p)

@@ -378,7 +378,7 @@ class _SparseConv(Function):
         # (padding the 6 -> 16 channel stem further to 32 so that conv3 takes it was measured SLOWER than conv2:
         #  1.20 ms vs 0.74 ms for the 125-offset table, r01_u)
         # blocks = ops.BlockProvider of the (submanifold) table: the LDS-staged kernel where the shape allows it
-        blk = None if blocks is None else blocks.get(f.shape[1], w.shape[0], dt)
+        blk = None if blocks is None else blocks.get(f.shape[1], w.shape[0], dt, conv=True)
         out = ops.spconv_fwd(f, w, b, nbr, blk)
         ctx.save_for_backward(f, w, nbr, nbr_t, dup_out, dup_in)
         ctx.blocks = blocks if mirror else None    # SubM: dgrad runs over the same table
@@ -410,7 +410,7 @@ class _SparseConv(Function):
                 else:
                     wt = wt.contiguous()
             gm = g if dup_out is None else _merge_duplicate_rows(g, dup_out)
-            blk = None if ctx.blocks is None else ctx.blocks.get(gm.shape[1], wt.shape[0], gm.dtype)
+            blk = None if ctx.blocks is None else ctx.blocks.get(gm.shape[1], wt.shape[0], gm.dtype, conv=True)
             dfeat = ops.spconv_fwd(gm, wt, None, nbr_t, blk)[:, :c_in].to(ctx.in_dtype)
             if dup_in is not None:
                 own = dup_in == torch.arange(dup_in.numel(), device=dup_in.device, dtype=dup_in.dtype)

@@ -524,9 +524,12 @@ class BlockProvider:
         self.nbr = nbr
         self.tables = {}
 
-    def get(self, c_in: int, c_out: int, dtype: torch.dtype):
+    def get(self, c_in: int, c_out: int, dtype: torch.dtype, conv: bool = False):
+        """conv=True: asked by a forward / input-gradient convolution -- only the shapes conv7 serves (c_in = c_out in {32, 64}) get
+        tables there; the sliced weight gradient of the wider shapes asks with conv=False from the backward, so inference, eval and
+        PTC_WGRAD_BLK=0 never pay the table build (one launch + ~112 B per row) for a kernel that cannot use it."""
         plan = block_plan(c_in, c_out, self.nbr.shape[0], dtype, self.nbr.shape[1])
-        if plan is None or not self.nbr.is_cuda:
+        if plan is None or not self.nbr.is_cuda or (conv and not (c_in == c_out and c_in in (32, 64))):
             return None
         t = self.tables.get(plan)
         if t is None:

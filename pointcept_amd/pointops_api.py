@@ -58,7 +58,9 @@ class _EdgeGather(torch.autograd.Function):
             ops.edge_rows(0, f32, None, idx, out=out, out_col0=3)
         ctx.save_for_backward(idx)
         ctx.meta = (feat.shape[0], c, xyz is not None, None if xyz is None else xyz.shape[0], feat.dtype)
-        return out.to(feat.dtype)
+        # the reference concatenates fp32 coordinate offsets with feat (torch.cat promotes): half-precision features under autocast must
+        # not drag the relative coordinates down to 16 bits -- only the feat-only result goes back to feat's dtype
+        return out.to(feat.dtype if xyz is None else torch.promote_types(xyz.dtype, feat.dtype))
 
     @staticmethod
     def backward(ctx, g):

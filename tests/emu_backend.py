@@ -28,6 +28,11 @@ def build(verbose: bool = False):
     after the token substitution `extern __shared__` -> `extern`, `__shared__` -> `static`; linked into one shared library."""
     if "lib" in _lib_cache:
         return _lib_cache["lib"]
+    pre = os.environ.get("PTC_EMU_LIB")       # a library a parent process built (tests/test_dp_gloo.py hands it to its ranks)
+    if pre and os.path.exists(pre):
+        _lib_cache["lib"] = ctypes.CDLL(pre)
+        _lib_cache["dir"] = os.path.dirname(pre)
+        return _lib_cache["lib"]
     import glob
     import re
     import shutil
@@ -76,7 +81,14 @@ def build(verbose: bool = False):
         raise RuntimeError("host emulation link failed:\n" + r.stderr[-3000:])
     _lib_cache["lib"] = ctypes.CDLL(out)
     _lib_cache["dir"] = d
+    _lib_cache["path"] = out
     return _lib_cache["lib"]
+
+
+def library_path() -> str:
+    """path of the built emulation library (builds it on first use)"""
+    build()
+    return _lib_cache.get("path") or os.environ["PTC_EMU_LIB"]
 
 
 class _EmuLib:

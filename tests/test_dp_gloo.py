@@ -137,6 +137,116 @@ def test_engine_model_under_ddp_gloo_world2():
         assert np.allclose(a, (la + lb) / 2, rtol=2e-2, atol=2e-3 * gmax), n   # = mean of the local gradients (bf16 attention roundings)
 
 
+def _executor_worker(rank, world, port, q, emu_lib):
+    """ONE PT-v3m1 Block through the block executor (csrc/block_exec.hip, every kernel real on the host emulation) under
+    DistributedDataParallel(gradient_as_bucket_view=True, static_graph off) over gloo: the executor returns its 18 parameter gradients as
+    VIEWS of one slab; DDP must take them into its buckets on the first step (grad = None) and on a second step where .grad already IS
+    a bucket view (zero_grad(set_to_none=False): autograd accumulates in place)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      PTC_EMU_LIB=emu_lib)
+    torch.set_num_threads(2)
+    import numpy as np
+
+    import emu_backend
+    from oracle import maps as omaps
+    from oracle import sfc as osfc
+    from pointcept_amd import dp, ops, synthetic
+    from pointcept_amd import functional as PF
+
+    C, H, patch = 32, 2, 64
+
+    class OneBlock(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(0)                     # identical initial weights on every rank
+
+            def P(*s, scale=1.0, one=False):
+                return torch.nn.Parameter(torch.randn(*s, generator=g) * scale + (1.0 if one else 0.0))
+            self.params = torch.nn.ParameterList([
+                P(C, 3, 3, 3, C, scale=(27 * C) ** -0.5), P(C, scale=0.1), P(C, C, scale=C ** -0.5), P(C, scale=0.1), P(C, scale=0.1, one=True), P(C, scale=0.1),
+                P(C, scale=0.1, one=True), P(C, scale=0.1), P(3 * C, C, scale=C ** -0.5), P(3 * C, scale=0.1), P(C, C, scale=C ** -0.5), P(C, scale=0.1),
+                P(C, scale=0.1, one=True), P(C, scale=0.1), P(4 * C, C, scale=C ** -0.5), P(4 * C, scale=0.1), P(C, 4 * C, scale=(4 * C) ** -0.5), P(C, scale=0.1)])
+
+        def forward(self, x0, xc, meta):
+            return PF.ptv3_block(x0, xc, None, None, meta, list(self.params))
+
+    dev = torch.device("cpu")
+    dp.init_distributed(backend="gloo")
+    model = OneBlock()
+    ddp = dp.wrap_ddp(model, dev)
+    assert type(ddp).__name__ == "DistributedDataParallel" and ddp.gradient_as_bucket_view and not ddp.static_graph
+    ref = OneBlock()
+    torch.Tensor.is_cuda = property(lambda self: True)               # the weight-shadow cache only serves CUDA tensors (this process only)
+    out = []
+    with emu_backend.emulated_ops():
+        for it in range(2):
+            b = synthetic.indoor_batch(2, 150 + 40 * rank + 10 * it)        # different scenes per rank and step
+            bt = omaps.offset2batch(b["offset"])
+            code = osfc.encode_c(b["grid_coord"], bt, int(b["grid_coord"].max() + 1).bit_length(), ("hilbert",))[0]
+            o = np.argsort(code, kind="stable")
+            ind = np.concatenate([bt[o, None], b["grid_coord"][o]], 1).astype(np.int32)
+            n = ind.shape[0]
+            g = torch.Generator().manual_seed(100 * rank + it)
+            nbr = ops.rulebook_subm(torch.from_numpy(ind), 3)
+            offs = torch.from_numpy(b["offset"].astype(np.int64))
+            key = torch.from_numpy(bt[o].astype(np.int64)) * 10 ** 9 + torch.randint(0, 10 ** 8, (n,), generator=g)
+            order = torch.argsort(key)
+            inverse = torch.empty_like(order)
+            inverse[order] = torch.arange(n)
+            pad, unpad, cu, dup = ops.patch_pad_maps(offs, [int(v) for v in offs], patch)
+            tabs = ops.attn_tables(order, inverse, pad, unpad, dup)
+            meta = dict(dt=torch.bfloat16, n_pad=int(tabs[0].shape[1]), n_seq=int(cu.numel()) - 1, heads=H, patch=patch, scale=16 ** -0.5, eps_cpe=1e-5,
+                        eps_n1=1e-5, eps_n2=1e-5, nbr=nbr, blk=None, tabs=tabs, cu=cu)
+            x0, xc = torch.randn(n, C, generator=g), torch.randn(n, C, generator=g).to(torch.bfloat16)
+            dz, dyb = torch.randn(n, C, generator=g), torch.randn(n, C, generator=g)
+            if it == 1:
+                ddp.zero_grad(set_to_none=False)                     # .grad stays the bucket view; this step accumulates into it
+            x3, xb = ddp(x0, xc, meta)
+            ((x3 * dz).sum() + (xb.float() * dyb).sum()).backward()
+            views = sum(int(p.grad._base is not None or p.grad.storage_offset() != 0) for p in model.parameters())   # grads living in DDP's buckets
+            ref.zero_grad(set_to_none=True)
+            y3, yb = ref(x0, xc, meta)
+            ((y3 * dz).sum() + (yb.float() * dyb).sum()).backward()
+            out.append(([p.grad.detach().numpy().copy() for p in model.params], [p.grad.detach().numpy().copy() for p in ref.params], views))
+    q.put((rank, out))
+    torch.distributed.destroy_process_group()
+
+
+def test_block_executor_slab_gradients_under_ddp_gloo_world2():
+    """the executor's slab-view parameter gradients through DDP's bucket views, two ranks, two steps; after each
+    step every rank holds the mean of the two ranks' local gradients (the executor run without DDP on the same inputs)."""
+    import numpy as np
+    import pytest
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_backend
+
+    if not emu_backend.available():
+        pytest.skip("no host clang++ under /opt/rocm")
+    lib = emu_backend.library_path()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_executor_worker, args=(r, world, port, q, lib)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for it in range(2):
+        g0, l0, v0 = res[0][it]
+        g1, l1, _ = res[1][it]
+        assert v0 == len(g0), (it, v0)                                              # gradient_as_bucket_view: every .grad is a view of a bucket
+        for k, (a, b, la, lb) in enumerate(zip(g0, g1, l0, l1)):
+            scale = max(float(np.abs(la).max()), float(np.abs(lb).max()), 1e-6)
+            assert np.array_equal(a, b), (it, k)                                   # identical after the all-reduce
+            assert np.allclose(a, (la + lb) / 2, rtol=1e-5, atol=1e-5 * scale), (it, k, float(np.abs(a - (la + lb) / 2).max()), scale)
+            assert float(np.abs(la - lb).max()) > 1e-3 * scale                     # the ranks really saw different data
+
+
 def _run_bench(*argv, env_extra=None, timeout=300):
     import subprocess
 

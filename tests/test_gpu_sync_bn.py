@@ -61,9 +61,14 @@ def _same(fused, conv, run, tag, out_bar=1e-4, grad_bar=5e-3):
     assert _rel(ev_b, ev_a) < out_bar, (tag, "eval", _rel(ev_b, ev_a))
     assert _rel(tr_b, tr_a) < out_bar, (tag, "train", _rel(tr_b, tr_a))
     assert abs(loss_a - loss_b) < out_bar * abs(loss_a), (tag, loss_a, loss_b)
-    gmax = max(float(v.abs().max()) for v in g_a.values())
-    bad = [(k, float((g_b[k] - g_a[k]).norm() / g_a[k].norm().clamp(min=1e-6 * gmax))) for k in g_a]
-    bad = [(k, r) for k, r in bad if r > grad_bar]
+    # gradients per stage (relative Frobenius distance over the stage's parameters): single parameters whose true gradient is zero
+    # (a bias in front of a batch-statistics BatchNorm) or tiny are rounding noise on both sides
+    num, den = {}, {}
+    for k in g_a:
+        st = ".".join(k.split(".")[:2])
+        num[st] = num.get(st, 0.0) + float((g_b[k].double() - g_a[k].double()).pow(2).sum())
+        den[st] = den.get(st, 0.0) + float(g_a[k].double().pow(2).sum())
+    bad = [(st, (num[st] / max(den[st], 1e-300)) ** 0.5) for st in num if (num[st] / max(den[st], 1e-300)) ** 0.5 > grad_bar]
     assert not bad, (tag, bad[:6])
 
 
@@ -82,8 +87,8 @@ def test_sync_bn_conversion_ptv3_keeps_every_activation(cuda):
     orc.load_state_dict(sd)
     eng.load_state_dict(sd)
     eng = eng.to(cuda)
-    batch = synthetic.collate([synthetic.indoor_scene(41, 1800), synthetic.indoor_scene(42, 700)])
-    run = lambda m: m(synthetic.to_torch(batch, cuda)).feat
+    batch = synthetic.collate([synthetic.indoor_scene(41, 12000), synthetic.indoor_scene(42, 5000)])     # ~70 rows at the deepest stage: the
+    run = lambda m: m(synthetic.to_torch(batch, cuda)).feat                                                   # batch statistics stay well conditioned
     conv = _convert(eng)
     _same(eng, conv, run, "ptv3", 1e-2, 5e-2)      # attention operands are bf16 on both sides: fp32 BatchNorm rounding differences flip roundings
     orc.train()
@@ -137,19 +142,22 @@ def test_sync_bn_conversion_litept_matches_the_reference_golden(cuda):
     eng = LitePT(**TL.LITEPT_CFG)
     eng.load_state_dict(om.deterministic_state_dict(eng, 43))
     eng = eng.to(cuda)
-    batch = synthetic.collate([synthetic.indoor_scene(int(s), int(n)) for s, n in zip(g["scene_seeds"], g["n_points"])])
+    gold_batch = synthetic.collate([synthetic.indoor_scene(int(s), int(n)) for s, n in zip(g["scene_seeds"], g["n_points"])])
+    big_batch = synthetic.collate([synthetic.indoor_scene(81, 12000), synthetic.indoor_scene(82, 5000)])
 
-    def run(m):
-        inp = synthetic.to_torch(batch, cuda)
-        inp["grid_size"] = 0.02
-        return m(inp).feat
+    def runner(batch):
+        def run(m):
+            inp = synthetic.to_torch(batch, cuda)
+            inp["grid_size"] = 0.02
+            return m(inp).feat
+        return run
 
     conv = _convert(eng)
-    _same(eng, conv, run, "litept", 1e-2, 5e-2)
+    _same(eng, conv, runner(big_batch), "litept", 1e-2, 5e-2)
     conv.eval()
     torch.manual_seed(5)
     with torch.no_grad():
-        out = run(conv).float().cpu().numpy()
+        out = runner(gold_batch)(conv).float().cpu().numpy()
     err = np.abs(out[::8] - g["feat_rows"]).max() / float(g["feat_absmax"])
     assert err < 2e-2, f"converted LitePT vs reference golden: rel err {err:.3e}"
 

@@ -458,7 +458,7 @@ def test_block_executor_is_bit_identical_to_the_composed_path_on_the_emulation(m
                     class LN:  # minimal norm holder
                         def __init__(s,w,b): s.weight,s.bias,s.eps=w,b,1e-5
                     class BP:
-                        def get(s,*a): return blk
+                        def get(s,*a,**k): return blk
                     conv = PF.sparse_conv(xcr, wc.reshape(C,27,C), bc, nbr, nbr, True, None, None, BP() if blk is not None else None)
                     lin = PF.linear(conv, wl, bl)
                     x1, y1 = PF.add_norm(lin, x0r, None, LN(gcp,bcp), LN(g1,b1), torch.bfloat16)
