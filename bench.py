@@ -343,6 +343,25 @@ def build_ptv3_outdoor(args, device, rank):
     return model, opt, batch, (lambda out: out["loss"])
 
 
+def build_ptv3m2_sonata(args, device, rank):
+    """PT-v3m2 with the channel plan of the reference's Sonata configs (configs/sonata/*:45: enc (48, 96, 192, 384, 512), heads (3, 6, 12, 24,
+    32), patch 1024, 4 orders) plus a decoder of the same widths and a 20-class head, on the bench batch: the LayerNorm widths 48 / 96 / 192
+    / 384 and the 192- / 384- / 768- / 1536-wide MLPs that PT-v3m1 does not have."""
+    from pointcept_amd import synthetic
+    from pointcept_amd.point_transformer_v3m2 import PointTransformerV3 as PTv3m2
+    from pointcept_amd.segmentor import DefaultSegmentorV2
+
+    cfg = dict(in_channels=6, order=("z", "z-trans", "hilbert", "hilbert-trans"), stride=(2, 2, 2, 2), enc_depths=(2, 2, 2, 6, 2),
+               enc_channels=(48, 96, 192, 384, 512), enc_num_head=(3, 6, 12, 24, 32), enc_patch_size=(1024,) * 5, dec_depths=(2, 2, 2, 2),
+               dec_channels=(48, 96, 192, 384), dec_num_head=(3, 6, 12, 24), dec_patch_size=(1024,) * 4, mlp_ratio=4, qkv_bias=True,
+               drop_path=0.3, shuffle_orders=True)
+    model = DefaultSegmentorV2(20, 48, PTv3m2(**cfg), criteria=("ce", "lovasz")).to(device).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    batch = synthetic.to_torch(synthetic.indoor_batch(args.batch, args.points, rank=rank), device)
+    batch["grid_size"] = 0.02
+    return model, opt, batch, (lambda out: out["loss"])
+
+
 def build_ptv3(args, device, rank):
     from pointcept_amd import synthetic
     from pointcept_amd.point_transformer_v3 import PointTransformerV3
@@ -520,8 +539,21 @@ def main():
                 dt2, loss2 = timed_steps(st2, k2, 2, device)
                 out["secondary"] = {"metric": "scenes/sec (fwd+bwd+optimizer) SpUNet-v1m1 ScanNet-semseg @ 100k voxels (BASELINE configs[1])",
                                     "value": round(args.batch * k2 / dt2, 4), "unit": "scenes/s", "ms_per_step": round(dt2 / k2 * 1e3, 3),
-                                    "steps": k2, "warmup": 2, "final_loss": round(float(loss2.detach()), 4),
+                                    "steps": k2, "warmup": 2, "final_loss": round(float(loss2.detach()), 4), "amp": f"{amp} autocast",
                                     "workload": f"SpUNet-v1m1 (39.2M params) + CE, fwd+bwd+SGD, {args.batch} scenes x 100000 voxels"}
+                if amp == "bf16":
+                    # the AMP dtype SURVEY 8(d) names for configs[1] (fp16 autocast + GradScaler, configs/_base_/default_runtime.py:19): the
+                    # same model, weights and batch, a fresh optimizer state; the shadows of both dtypes live side by side (functional._CastCache)
+                    try:
+                        o2h = torch.optim.SGD(m2.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
+                        st2h = make_step(m2, o2h, b2, "fp16", l2, device)
+                        dt2h, loss2h = timed_steps(st2h, k2, 3, device)
+                        out["secondary"]["recipe_fp16"] = {"value": round(args.batch * k2 / dt2h, 4), "unit": "scenes/s", "ms_per_step": round(dt2h / k2 * 1e3, 3),
+                                                           "steps": k2, "warmup": 3, "amp": "fp16 autocast + GradScaler",
+                                                           "final_loss": round(float(loss2h.detach()), 4)}
+                        del st2h, o2h
+                    except Exception as e:
+                        out["secondary"]["recipe_fp16"] = {"error": repr(e)}
                 del st2, m2, o2, b2
             except Exception as e:
                 out["secondary"] = {"error": repr(e)}
@@ -543,6 +575,23 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:
                 out["secondary_outdoor"] = {"error": repr(e)}
+        if not args.stub and args.model == "ptv3" and world == 1 and not args.no_secondary:
+            try:      # SURVEY 8(f).2 at the widths the reference ships: PT-v3m2 with configs/sonata's channel plan on the bench batch
+                torch.cuda.empty_cache()
+                torch.manual_seed(1234)
+                m4, o4, b4, l4 = build_ptv3m2_sonata(args, device, rank)
+                st4 = make_step(m4, o4, b4, amp, l4, device)
+                k4 = max(3, min(args.steps, 6))
+                dt4, loss4 = timed_steps(st4, k4, 2, device)
+                out["secondary_f2"] = {"metric": "scenes/sec (fwd+bwd+optimizer) PT-v3m2 (Sonata widths 48..512) semseg @ ~100k pts, one GPU",
+                                       "value": round(args.batch * k4 / dt4, 4), "unit": "scenes/s", "ms_per_step": round(dt4 / k4 * 1e3, 3),
+                                       "steps": k4, "warmup": 2, "final_loss": round(float(loss4.detach()), 4),
+                                       "workload": f"PT-v3m2 enc (48, 96, 192, 384, 512) / dec (48, 96, 192, 384), head_dim 16, CE + Lovasz, fwd+bwd+AdamW, "
+                                                   f"{args.batch} scenes x {args.points} voxels; LayerNorm / GEMM widths outside PT-v3m1's on the engine's generic kernels"}
+                del st4, m4, o4, b4
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out["secondary_f2"] = {"error": repr(e)}
         if not args.stub and args.model == "ptv3" and world == 1 and amp == "bf16" and not args.no_secondary and not args.no_fp16_recipe:
             out["recipe_fp16"] = fp16_recipe_in_a_child(args)
         if not args.stub and args.model == "ptv3" and world == 1 and not args.no_cpu_baseline:
