@@ -251,6 +251,10 @@ __device__ __forceinline__ void ah_unrope_store(const uint16_t* tile, int lane, 
   (void)scale;
 }
 
+#ifndef AH_FWD_PIPE
+#define AH_FWD_PIPE 1            // 0: the plain in-order key loop of rounds 2-4; 1: software pipeline, the compiler's schedule; 2: pinned with
+                                 // sched_group_barrier (timing A/B: `python -m pointcept_amd.build --variant d_AH_FWD_PIPE_2`)
+#endif
 // ------------------------------------------------------------------------------------------------ forward
 // LDS: K slabs DK x [lp_max][16] | V^T [D + 1][pitch] | AT_WAVES floats
 template <int DK, int MB, bool F16, bool ROPE = false>
@@ -328,6 +332,69 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
     if (!F16 && __builtin_amdgcn_ballot_w64(bnd > AT_FIXED_REF_MAX) == 0) {
       ref2 = bnd;
       const f32x16 negb = splat16(-bnd);
+      if constexpr (AH_FWD_PIPE != 0 && DK == 2 && MB == 1) {      // head_dim 17 .. 31 (the reference's 18); wider heads: measured slower, below
+      // Three-stage software pipeline over the key tiles (round 5; the head_dim-16 forward's principle, attention.hip): the S' products of
+      // tile kt + 1 sit in the matrix pipe while the vector pipe exponentiates tile kt, and P V of tile kt - 1 follows -- no MFMA of a
+      // trip depends on the trip's own vector work.  A wave is in-order and this kernel runs two waves per SIMD: in the plain loop
+      // (S' -> exp -> pack -> P V, each waiting for the one before) the 2 DK + 2 MB MFMAs and the 16 transcendentals of a tile never
+      // overlapped.  Same products, same accumulation order per accumulator: bit-identical to the plain loop (AH_FWD_PIPE 0).
+      // S' of one tile past the end is computed and never used (its K reads land in the next slab / the V^T image: in-bounds LDS).
+      auto s_tile = [&](int kt) {
+        f32x16 sv = negb;
+#pragma unroll
+        for (int j = 0; j < DK; ++j) {
+          const s16x8 kf = *reinterpret_cast<const s16x8*>(kbase + j * slab + kt * 1024);
+          sv = AE<F16>::mfma(kf, qhi[j], sv);
+          sv = AE<F16>::mfma(kf, qlo[j], sv);
+        }
+        return sv;
+      };
+      auto expo = [&](const f32x16& sv, uint32_t (&pk)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pk[i] = AE<F16>::pack2(__builtin_amdgcn_exp2f(sv[2 * i]), __builtin_amdgcn_exp2f(sv[2 * i + 1]));
+      };
+      auto pv = [&](int kt, const uint32_t (&pk)[8]) {
+        const s16x8 p0 = make_frag(pk[0], pk[1], pk[2], pk[3]), p1 = make_frag(pk[4], pk[5], pk[6], pk[7]);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          acc[m] = AE<F16>::mfma(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64), p0, acc[m]);
+          acc[m] = AE<F16>::mfma(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64 + 32), p1, acc[m]);
+        }
+      };
+      // pin the interleave of a half trip (6 MFMAs, 16 v_exp_f32, 8 packs; the compiler's own schedule keeps the stages in source order):
+      // the four LDS reads first, then behind every MFMA three transcendentals and one or two plain vector instructions
+      auto interleave = [&]() {
+#if AH_FWD_PIPE >= 2
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#define AH_GRP(T, V) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x400, T, 0); \
+                     __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+        AH_GRP(3, 2) AH_GRP(3, 2) AH_GRP(3, 1) AH_GRP(3, 1) AH_GRP(2, 1) AH_GRP(2, 1)
+#undef AH_GRP
+#endif
+      };
+      const int kt_last = n_tiles - 1;
+      f32x16 s0 = s_tile(0), s1 = s_tile(kt_last > 0 ? 1 : 0);
+      uint32_t pa[8], pb[8];
+      expo(s0, pa);
+      int kt = 1;
+      for (; kt + 1 < n_tiles; kt += 2) {               // at the top: s1 = S'(kt), pa = P(kt - 1), P V done for tiles < kt - 1
+        s0 = s_tile(kt + 1);
+        expo(s1, pb);
+        pv(kt - 1, pa);
+        interleave();
+        s1 = s_tile(kt + 2 <= kt_last ? kt + 2 : kt_last);
+        expo(s0, pa);
+        pv(kt, pb);
+        interleave();
+      }
+      if (kt < n_tiles) {                               // one tile left in s1, P(kt - 1) in pa
+        expo(s1, pb);
+        pv(kt - 1, pa);
+        pv(kt, pb);
+      } else {
+        pv(kt - 1, pa);
+      }
+      } else {
       for (int kt = 0; kt < n_tiles; ++kt) {
         f32x16 s = negb;
 #pragma unroll
@@ -345,6 +412,7 @@ attn_hd_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__
           acc[m] = AE<F16>::mfma(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64), p0, acc[m]);
           acc[m] = AE<F16>::mfma(*reinterpret_cast<const s16x8*>(vbase[m] + kt * 64 + 32), p1, acc[m]);
         }
+      }
       }
     } else {
       float mrun = -INFINITY;
