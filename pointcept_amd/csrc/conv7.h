@@ -46,6 +46,14 @@
 #define C7_DMA_SADDR 0                      // 1: DMA source = SGPR base + 32-bit lane offset (wgrad7's form) instead of 64-bit lane pointers: measured
                                             // SLOWER here, 148.0 vs 141.4 us at 64 -> 64 (profiles/r04_c_conv7_time.txt)
 #endif
+#ifndef C7_DMA_IN_TAPS
+#define C7_DMA_IN_TAPS 0                    // 1 (round 5, measured and left off): the DMA pieces of the NEXT block's halo and the id loads of the block
+                                            // after it issued between the statically unrolled taps of THIS block's loop (piece q in front of tap q)
+                                            // instead of in front of the loop, where nothing overlaps them (1020 of a block's 8900 cycles at
+                                            // 64 -> 64).  SLOWER: 160.1 vs 145.0 us at 64 -> 64, 68.8 vs 58.0 us at 32 -> 32 (N = 819200,
+                                            // profiles/r05_i_conv7_dma_in_taps.txt) -- each piece is an M0 save / set / restore around the DMA plus
+                                            // its address arithmetic in front of a tap's first MFMA, and the wave has nothing else to issue
+#endif
 #ifndef C7_LAG
 #define C7_LAG 2                            // MFMAs between a fragment's use and its reload (C = 64; 3 and 4 measured: see conv7_time)
 #endif
@@ -226,6 +234,37 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       }
     }
   };
+  // piece q of a block's halo (this wave's DMA instruction q) and of its id list, for the in-loop form (C7_DMA_IN_TAPS)
+  auto issue_dma_piece = [&](auto qc, int cnt, int bsel) {
+    constexpr int q = decltype(qc)::value;
+    const int i = 4 * q + wave;
+    if (i * RPI < cnt) {                                     // wave-uniform
+      const int slot = i * RPI + drow;
+      const int piece = dpos ^ G::swz(slot);
+      const uint32_t base = lds0 + (uint32_t)(bsel * G::BUF);
+      if constexpr (C7_DMA_SADDR) c7_dma16s(in, (uint32_t)ids[q] * (uint32_t)ROWB + (uint32_t)(piece * 16), base + (uint32_t)(i * 1024));
+      else c7_dma16(reinterpret_cast<const unsigned char*>(in) + (int64_t)ids[q] * ROWB + piece * 16, base + (uint32_t)(i * 1024));
+    }
+  };
+  auto load_id_piece = [&](auto qc, int blk) {
+    constexpr int q = decltype(qc)::value;
+    const int slot = (4 * q + wave) * RPI + drow;
+    ids[q] = hid[(int64_t)blk * C7_HCAP + (slot < C7_HCAP ? slot : C7_HCAP - 1)];
+  };
+  auto issue_table_dma = [&](int blk, int cnt, int bsel) {
+    if (cnt > 0) {
+      const uint32_t base = lds0 + (uint32_t)(bsel * G::BUF);
+      const unsigned char* tsrc = reinterpret_cast<const unsigned char*>(tab) + ((int64_t)(C == 64 ? 0 : n_blocks) + blk) * C7_TABB;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = 4 * q + wave;
+        if (i < C7_TABB / 1024) {
+          if constexpr (C7_DMA_SADDR) c7_dma16s(tsrc, (uint32_t)(i * 1024 + lane * 16), base + (uint32_t)(G::ROWS_BYTES + i * 1024));
+          else c7_dma16(tsrc + i * 1024 + lane * 16, base + (uint32_t)(G::ROWS_BYTES + i * 1024));
+        }
+      }
+    }
+  };
   // (Tried: plain 16-byte loads into 60 staging registers at the top of a block, ds_write_b128 behind its tap loop.  The loads issue
   //  faster -- 940 vs 1450 cycles per block -- but the stores into LDS cost 780, 270 more than they save: profiles/r03_o_conv7_phases.txt.
   //  Also tried: the halo ids as two lane-linear vectors per wave + a cross-lane read per piece instead of 13 small loads: the
@@ -260,9 +299,18 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 #pragma unroll 1
   for (int blk = b_begin; blk < b_end; blk += step) {
     // this workgroup's next block -> the other buffer (its ids arrived before the barrier that ended the previous iteration)
-    if (blk + step < b_end && !(C7_ABLATE & 1)) issue_dma(blk + step, cnt_nxt, cur ^ 1);
+    const bool dma_next = blk + step < b_end && !(C7_ABLATE & 1);
+    const bool ids_nn = blk + 2 * step < b_end;
+    // in-loop form: only the block's table goes out here; halo piece q is issued in front of tap q of the loop below (a piece's id
+    // register is free as soon as its DMA has issued: the id of the block after next is loaded into it at once).  A block whose own
+    // halo overflowed has no tap loop: everything is issued here, as before.
+    const bool in_taps = C7_DMA_IN_TAPS != 0 && cnt_cur > 0 && !(C7_ABLATE & 2);
+    if (dma_next) {
+      if (in_taps) issue_table_dma(blk + step, cnt_nxt, cur ^ 1);
+      else issue_dma(blk + step, cnt_nxt, cur ^ 1);
+    }
     int cnt_nn = count_of(blk + 2 * step);
-    if (blk + 2 * step < b_end) load_ids(blk + 2 * step);
+    if (ids_nn && !in_taps) load_ids(blk + 2 * step);
 
     tick(0);                                            // DMA issue + id loads
     const unsigned char* rowsL = smem + cur * G::BUF;
@@ -340,6 +388,10 @@ conv7_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
       tick(1);                                          // accumulator reset, mask, first gathers
       ptc_static_for<27>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
+        if constexpr (C7_DMA_IN_TAPS != 0 && k < G::NIW) {  // halo piece k of the next block, then the id of the block after next into its register
+          if (dma_next) issue_dma_piece(ptc_int<k>{}, cnt_nxt, cur ^ 1);
+          if (ids_nn) load_id_piece(ptc_int<k>{}, blk + 2 * step);
+        }
         if (m & (1u << k)) {                               // wave-uniform
           __builtin_amdgcn_sched_barrier(0);               // the pinned interleave below starts here
           entries(pop_tap(), teNN);                        // the active tap after the next one
