@@ -129,7 +129,14 @@ struct W2Plan {
 static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out, bool want_bias = false) {
   // workgroups aimed at per launch and 32-row steps a workgroup must at least own (swept for the small weight gradients of the deep
   // stages in round 2: 1024 / 16 kept)
-  constexpr int cot_max = 8, cit_max = 4, target_wgs = 1024, min_steps = 16;
+  // (round 5: 1024 -> 512.  Every workgroup along the row axis leaves one fp32 partial of its weight tile: at 1024 the Linear weight
+  //  gradients of a PT-v3m1 step wrote 1.15 GB of partials and read them back twice over (3.4 GB of the step's 98); 512 halves that
+  //  and the stage-0 / 1 launches still put two workgroups on every CU.  Step 46.9 / 46.8 -> 46.4 / 46.1 ms, SpUNet 26.9 / 26.7 ->
+  //  26.4 / 26.5 ms, outdoor neutral; 256 / 384 / 768 / 2048 measured beside it: profiles/r05_j_wgrad2_split_ab.txt)
+#ifndef W2_TARGET_WGS
+#define W2_TARGET_WGS 512
+#endif
+  constexpr int cot_max = 8, cit_max = 4, target_wgs = W2_TARGET_WGS, min_steps = 16;
   W2Plan p;
   // channel tiles: 64x64 accumulators by default; channel counts that are multiples of 32 but not of 64
   // (SpUNet's 96-channel decoder) take 32-wide input tiles / a 96-wide output tile so that no MFMA runs on padding
