@@ -276,6 +276,9 @@ static inline int at_split_host(int n_units, int lp_max) { return at_split(n_uni
 #ifndef AT_STAGE_FRAC
 #define AT_STAGE_FRAC 0.10
 #endif
+#ifndef AT_ALONE
+#define AT_ALONE 0.6             // duration of a workgroup that has its CU to itself, relative to one that shares it
+#endif
 struct AtPlan { int whole, qs; };     // per XCD chunk: unit index < whole -> one workgroup; else qs workgroups per unit
 __host__ __device__ __forceinline__ int at_plan_blocks_per_xcd(int n_units, AtPlan p) {
   const int per_xcd = (n_units + 7) >> 3, w = p.whole < per_xcd ? p.whole : per_xcd;
@@ -295,27 +298,30 @@ __device__ __forceinline__ bool at_plan_unit(int n_units, int whole, int qs, int
   return unit < n_units;
 }
 static double at_plan_makespan(int per_xcd, int slots, AtPlan p) {
-  // in-order list scheduling of the chunk's workgroups on `slots` slots: a min-heap of slot-free times in a flat array
+  // in-order dispatch of the chunk's workgroups onto the XCD's CUs, two slots per CU: the next workgroup takes the slot that frees first
+  // (an idle CU before the second slot of a busy one).  A workgroup that starts ALONE on its CU runs AT_ALONE x as long as one that
+  // shares it (the loop is issue-bound: 3200 units on 512 slots cost 459 us, 3584 units 489-528 us, r05_a_attn_tail_probe.txt; the
+  // deep-stage launches, 96 .. 384 units, are decided by this term: quarter units on every CU beat half units on three CUs in four).
   if (slots > 512) slots = 512;
-  double heap[512];
-  for (int i = 0; i < slots; ++i) heap[i] = 0.0;
+  if (slots < 2) slots = 2;
+  const int cus = slots / 2;
+  double fr[512];
+  for (int i = 0; i < 2 * cus; ++i) fr[i] = 0.0;
   const int w = p.whole < per_xcd ? p.whole : per_xcd;
   const long nblk = w + (long)(per_xcd - w) * p.qs;
   const double t_part = AT_STAGE_FRAC + (1.0 - AT_STAGE_FRAC) / p.qs;
   double end = 0.0;
   for (long b = 0; b < nblk; ++b) {
-    const double t = heap[0] + (b < w ? 1.0 : t_part);      // earliest free slot takes the next workgroup
-    if (t > end) end = t;
-    int i = 0;                                               // replace the root, sift down
-    for (;;) {
-      int c = 2 * i + 1;
-      if (c >= slots) break;
-      if (c + 1 < slots && heap[c + 1] < heap[c]) ++c;
-      if (heap[c] >= t) break;
-      heap[i] = heap[c];
-      i = c;
+    int best = 0;
+    double bt = 1e300, bsib = 1e300;
+    for (int i = 0; i < 2 * cus; ++i) {                      // (<= 64 slots per XCD, <= a few hundred workgroups, a handful of plans: cached)
+      const double sib = fr[i ^ 1];
+      if (fr[i] < bt || (fr[i] == bt && sib < bsib)) { bt = fr[i]; bsib = sib; best = i; }
     }
-    heap[i] = t;
+    const bool alone = fr[best ^ 1] <= bt;
+    const double t = bt + (b < w ? 1.0 : t_part) * (alone ? AT_ALONE : 1.0);
+    fr[best] = t;
+    if (t > end) end = t;
   }
   return end;
 }

@@ -374,8 +374,11 @@ static int launch_fwd2(const void* in, int64_t n_in, const void* w, const float*
       if (nblk % cand == 0 && (size_t)cand * NT * (c_in + 8) * 2 + (size_t)cand * NT * 4 + 16 + slices <= 64 * 1024) { nh = cand; break; }
     const size_t lds = (((size_t)nh * NT * (c_in + 8) * 2 + 15) & ~(size_t)15) + (size_t)nh * NT * 4 + slices;
     const int64_t tiles = ptc_cdiv(n_out, F2_ROWS);
-    int64_t per_cu = lds > 40 * 1024 ? 2 : 4;
-    if (lds_store) { per_cu = (160 * 1024) / (int64_t)lds; per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu); }
+#ifndef F2_PER_CU
+#define F2_PER_CU 4
+#endif
+    int64_t per_cu = lds > 40 * 1024 ? (F2_PER_CU > 2 ? 2 : F2_PER_CU) : F2_PER_CU;
+    if (lds_store) { per_cu = (160 * 1024) / (int64_t)lds; per_cu = per_cu > F2_PER_CU ? F2_PER_CU : (per_cu < 1 ? 1 : per_cu); }
     int64_t gx = 256 * per_cu / (nblk / nh);
     if (gx > tiles) gx = tiles;
     if (gx < 1) gx = 1;

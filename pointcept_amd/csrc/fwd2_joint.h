@@ -200,7 +200,10 @@ static int launch_linear_joint(const void* in, int64_t n_in, const void* w, cons
   const size_t lds = (((size_t)NT * (c_in + 8) * 2 + 15) & ~(size_t)15) + (size_t)NT * 4 + 4 * f2_out_slice_bytes(NT);
   const int64_t tiles = ptc_cdiv(n_out, F2_ROWS);
   int64_t per_cu = (160 * 1024) / (int64_t)lds;
-  per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+#ifndef F2_PER_CU
+#define F2_PER_CU 4
+#endif
+  per_cu = per_cu > F2_PER_CU ? F2_PER_CU : (per_cu < 1 ? 1 : per_cu);
   int64_t gx = 256 * per_cu;
   if (gx > tiles) gx = tiles;
   if (gx < 1) gx = 1;
