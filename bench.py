@@ -66,7 +66,7 @@ def parse(argv=None):
     ap.add_argument("--lovasz", action="store_true", help="(kept for old command lines; CE + Lovasz is the default)")
     ap.add_argument("--amp", default="bf16", choices=["bf16", "fp16"],
                     help="autocast dtype; fp16 adds torch.amp.GradScaler exactly as engines/train.py:203-231")
-    ap.add_argument("--model", default="ptv3", choices=["ptv3", "spunet", "ptv3-outdoor"],
+    ap.add_argument("--model", default="ptv3", choices=["ptv3", "spunet", "ptv3-outdoor", "ptv3m2-sonata"],
                     help="ptv3 = BASELINE.json metric (configs[2]); spunet = configs[1] (SpUNet-v1m1, 100000 voxels/scene); ptv3-outdoor = "
                          "configs[4] (LiDAR sweeps, depth-12 grid) as the main model (profiling); each reported with its own metric name")
     ap.add_argument("--cpu-sample-points", type=int, default=10240)
@@ -460,6 +460,11 @@ def main():
         points = int(batch["offset"][-1]) // args.batch
         metric = "scenes/sec (fwd+bwd+optimizer) PT-v3m1 outdoor LiDAR semseg @ ~200k voxels (BASELINE configs[4])"
         workload = f"PT-v3m1 base, in_channels 4, 16 classes, CE + Lovasz, fwd+bwd+AdamW, {args.batch} scenes x ~{points} voxels per GPU"
+        amp = args.amp
+    elif args.model == "ptv3m2-sonata":
+        model, opt, batch, loss_of = build_ptv3m2_sonata(args, device, rank)
+        metric = "scenes/sec (fwd+bwd+optimizer) PT-v3m2 (Sonata widths 48..512) semseg @ ~100k pts"
+        workload = f"PT-v3m2 enc (48, 96, 192, 384, 512) / dec (48, 96, 192, 384), CE + Lovasz, fwd+bwd+AdamW, {args.batch} scenes x {points} voxels per GPU"
         amp = args.amp
     else:
         model, opt, batch, loss_of = build_ptv3(args, device, rank)

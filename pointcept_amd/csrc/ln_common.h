@@ -87,3 +87,24 @@ __device__ __forceinline__ void ln_normalize(float (&v)[LN_VEC], float eps, cons
 #pragma unroll
   for (int i = 0; i < LN_VEC; ++i) v[i] = fmaf((v[i] - mean) * rstd, g[i], b[i]);
 }
+
+// the same with the row width as a run-time value (norm.hip, round 5: widths that are no power of two run on the next larger instance with
+// the lanes past the row idle): `act` = this lane holds channels of the row (an idle lane's v is zero and stays out of the second moment).
+// For inv_c = 1 / (LPR * 8) and act = true everywhere this is ln_normalize statement for statement -- the joints in the GEMM epilogues
+// (fwd2_joint.h, compile-time widths) and add_norm_fwd_kernel keep producing the same bits.
+template <int LPR>
+__device__ __forceinline__ void ln_normalize_rt(float (&v)[LN_VEC], float eps, const float (&g)[LN_VEC], const float (&b)[LN_VEC], float& mean,
+                                                float& rstd, float inv_c, bool act) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_VEC; ++i) s += v[i];
+  mean = group_sum<LPR>(s) * inv_c;
+  float q = 0.f;
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < LN_VEC; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  }
+  rstd = rsqrtf(fmaf(group_sum<LPR>(q), inv_c, eps));
+#pragma unroll
+  for (int i = 0; i < LN_VEC; ++i) v[i] = fmaf((v[i] - mean) * rstd, g[i], b[i]);
+}

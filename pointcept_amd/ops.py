@@ -711,8 +711,13 @@ _DT = {torch.float32: _lib.PTC_F32, torch.float16: _lib.PTC_F16, torch.bfloat16:
 
 
 def layer_norm_supported(c: int) -> bool:
-    """the power-of-two instances (C = 32 .. 512): LayerNorm AND the fused residual joints (add_norm_*)"""
+    """the power-of-two instances (C = 32 .. 512): the widths the GEMM-epilogue joints and the Block executor are built for"""
     return lib().ptc_layer_norm_supported(int(c)) == 1
+
+
+def layer_norm_joint_available(c: int) -> bool:
+    """the fused residual joints (add_norm_fwd / _bwd) take this width: every width LayerNorm takes (round 5: generic even widths too)"""
+    return lib().ptc_layer_norm_supported(int(c)) != 0
 
 
 def layer_norm_available(c: int) -> bool:

@@ -804,7 +804,7 @@ def test_layer_norm_fwd_bwd(cuda, c, xdt, ydt):
     _close("ln_dbeta", db, br.grad, 1e-4, 1e-4 * float(br.grad.abs().max()) + 1e-3)
 
 
-@pytest.mark.parametrize("c", [32, 128, 512])
+@pytest.mark.parametrize("c", [32, 128, 512, 48, 96, 192, 384, 432, 1024])       # round 5: the generic (wave-per-row) joint for the m2 / m3 / LitePT widths
 @pytest.mark.parametrize("mode", ["ln_add_ln", "add_ln_scaled", "add_cast", "fp32", "f16_ln_add_ln", "f16_add_ln_scaled", "f16_add_cast"])
 def test_add_norm_fused_joint(cuda, c, mode):
     """PF.add_norm == a + s * LN_A(u) followed by LN_B / cast, forward and every gradient; bf16, f16 (the reference's fp16 + GradScaler

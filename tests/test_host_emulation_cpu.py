@@ -187,6 +187,8 @@ EMULATED_GPU_TESTS = [
     ("test_layer_norm_fwd_bwd", dict(c=36, xdt=torch.float32, ydt=torch.bfloat16)), ("test_layer_norm_fwd_bwd", dict(c=432, xdt=torch.bfloat16, ydt=torch.float32)),
     ("test_layer_norm_fwd_bwd", dict(c=1024, xdt=torch.bfloat16, ydt=torch.bfloat16)), ("test_layer_norm_empty_and_unsupported", dict()),
     ("test_add_norm_fused_joint", dict(c=32, mode="ln_add_ln")), ("test_add_norm_fused_joint", dict(c=128, mode="add_ln_scaled")),
+    ("test_add_norm_fused_joint", dict(c=48, mode="ln_add_ln")), ("test_add_norm_fused_joint", dict(c=432, mode="add_ln_scaled")),
+    ("test_add_norm_fused_joint", dict(c=96, mode="f16_add_cast")), ("test_add_norm_fused_joint", dict(c=192, mode="fp32")),
     ("test_batch_norm_act_train", dict(dtype=torch.float32, n=3000, c=64, act="gelu")),
     ("test_batch_norm_add_act_is_the_residual_block_tail", dict(dtype=torch.bfloat16, n=5003, c=96)),
     ("test_pointops_knn_query", dict(nsample=3)), ("test_seg_eval_hist_matches_the_reference_formula", dict(dtype=torch.float32)),
@@ -333,7 +335,7 @@ def test_whole_ptv3_step_with_every_kernel_on_the_emulation():
 
     if not emu_backend.available():
         pytest.skip("no host clang++ under /opt/rocm")
-    names = [n for n in mock_backend._STANDINS if n not in ("layer_norm_supported", "layer_norm_available", "batch_norm_supported", "linear_supported_ex")]
+    names = [n for n in mock_backend._STANDINS if n not in ("layer_norm_supported", "layer_norm_available", "layer_norm_joint_available", "batch_norm_supported", "linear_supported_ex")]
     with emu_backend.hybrid(names):
         T.test_ptv3_two_scenes_forward_backward_vs_oracle(torch.device("cpu"))
 

@@ -39,6 +39,8 @@ for sec in "$@"; do
     trace) timeout 600 python tools/trace_step.py > $O/${TAG}_trace_step.txt 2>$O/${TAG}_trace_step.err; echo "trace rc=$?" >> $O/${TAG}_env.log; head -5 $O/${TAG}_trace_step.txt;;
     copies) timeout 600 python tools/trace_copies.py > $O/${TAG}_trace_copies.txt 2>$O/${TAG}_trace_copies.err; echo "copies rc=$?" >> $O/${TAG}_env.log; head -30 $O/${TAG}_trace_copies.txt;;
     spunet) timeout 900 python bench.py --model spunet --steps 6 --warmup 2 > $O/${TAG}_spunet.log 2>&1; echo "spunet rc=$?" >> $O/${TAG}_env.log; tail -1 $O/${TAG}_spunet.log | cut -c1-400;;
+    profm2) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profm2 -- python $R/bench.py --model ptv3m2-sonata --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-fp16-recipe > $O/${TAG}_profm2.log 2>&1
+          cd $R; TOP=40 python tools/prof_top.py $O/${TAG}_profm2 5 $O/${TAG}_m2_kernel_stats.csv > $O/${TAG}_profm2_top.log 2>&1; rm -rf $O/${TAG}_profm2; head -40 $O/${TAG}_m2_kernel_stats.csv | cut -c1-150; tail -1 $O/${TAG}_m2_kernel_stats.csv;;
     profspunet) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profsp -- python $R/bench.py --model spunet --steps 3 --warmup 2 > $O/${TAG}_profsp.log 2>&1
           cd $R; TOP=30 python tools/prof_top.py $O/${TAG}_profsp 5 $O/${TAG}_spunet_kernel_stats.csv > $O/${TAG}_profsp_top.log 2>&1; rm -rf $O/${TAG}_profsp;;
     ab:*) envs=$(echo "${sec#ab:}" | tr ',' ' '); name=$(echo "${sec#ab:}" | tr -c 'A-Za-z0-9=\n' '_');
