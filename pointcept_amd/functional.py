@@ -372,9 +372,16 @@ class _SparseConv(Function):
         # channels are padded to 16; a stem (c_in <= 8: 6 colour + normal channels, k = 5) only to 8: its gathered rows are then 16
         # bytes and conv3 packs four table rows into one MFMA step (csrc/conv3.h, KPC = 16)
         cpad = 8 if (c_in <= 8 and kv > 1 and dt != torch.float32) else 16
+        opad = 16
+        if (blocks is not None and kv == 27 and c_in == c_out and 16 < c_in < 64 and c_in != 32 and dt != torch.float32
+                and ops.block_plan(64, 64, 27, dt, feat.shape[0]) is not None):
+            # round 5: a square submanifold 3^3 convolution of 17 .. 63 channels (PT-v3m2's 48, LitePT's 36 at stage 0) on the block-staged,
+            # register-weight kernels of the next width they exist for (conv7 / wgrad7: 32 | 64 channels), zero-padded: the 48-channel
+            # stage-0 convolutions ran 403 us on conv2 against 145 us for conv7 at 64 (profiles/r05_m_m2_kernel_stats.csv)
+            cpad = opad = 32 if c_in < 32 else 64
         f = _pad_to(feat.to(dt), 1, cpad).contiguous()
-        w = _pad_to(_pad_to(_cast_cache.get(weight, dt), 2, cpad), 0, 16).contiguous()
-        b = None if bias is None else _pad_to(bias.float(), 0, 16)
+        w = _pad_to(_pad_to(_cast_cache.get(weight, dt), 2, cpad), 0, opad).contiguous()
+        b = None if bias is None else _pad_to(bias.float(), 0, opad)
         # (padding the 6 -> 16 channel stem further to 32 so that conv3 takes it was measured SLOWER than conv2:
         #  1.20 ms vs 0.74 ms for the 125-offset table, r01_u)
         # blocks = ops.BlockProvider of the (submanifold) table: the LDS-staged kernel where the shape allows it
@@ -393,7 +400,7 @@ class _SparseConv(Function):
     def backward(ctx, grad):
         f, w, nbr, nbr_t, dup_out, dup_in = ctx.saved_tensors
         c_out, kv, c_in = ctx.shape
-        g = _pad_to(grad.to(f.dtype), 1, 16).contiguous()
+        g = _pad_to(grad.to(f.dtype), 1, w.shape[0] if w.shape[0] == f.shape[1] and w.shape[0] in (32, 64) else 16).contiguous()
         dfeat = dw = dbias = None
         if ctx.needs_input_grad[1]:
             # submanifold 3^3, 32 | 64 channels: the block-staged weight gradient over the tables the forward built (csrc/wgrad7.h)

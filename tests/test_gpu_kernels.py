@@ -1758,6 +1758,40 @@ def test_segmentor_ce_plus_lovasz(cuda):
     assert seg.seg_head.weight.grad is not None and torch.isfinite(seg.seg_head.weight.grad).all()
 
 
+@pytest.mark.parametrize("c", [48, 36, 24])
+def test_square_subm_conv_of_an_odd_width_on_the_block_staged_kernels(cuda, c, n_pts=9000):
+    """round 5: SubMConv3d(c, c, 3) with 16 < c < 64, c != 32 (PT-v3m2's 48 at the Sonata widths, LitePT's 36) under 16-bit autocast is
+    zero-padded to 32 / 64 channels and runs on conv7 / wgrad7 (square 32 | 64-channel kernels) where it ran on conv2: forward, input,
+    weight and bias gradients against the oracle's gather convolution in fp32 on the bf16-rounded operands."""
+    from pointcept_amd import spconv_api as sp
+
+    ind = _scene_indices(n_pts)
+    n = ind.shape[0]
+    assert n >= 4096                      # the block-staged kernels' minimum
+    nbr = oops.subm_rulebook(ind, 3)
+    g = torch.Generator().manual_seed(c)
+    conv = sp.SubMConv3d(c, c, 3, bias=True, indice_key="k").to(cuda)
+    feat = (torch.randn(n, c, generator=g) * 0.5)
+    probe = torch.randn(n, c, generator=g)
+    fe = feat.to(cuda).requires_grad_(True)
+    x = sp.SparseConvTensor(fe, torch.from_numpy(ind).int().to(cuda), [int(ind[:, 1:].max()) + 97] * 3, int(ind[:, 0].max()) + 1)
+    with torch.autocast("cuda" if torch.device(cuda).type == "cuda" else "cpu", dtype=torch.bfloat16, enabled=torch.device(cuda).type == "cuda"):
+        y = conv(x).features
+    assert y.shape == (n, c)
+    (y.float() * probe.to(cuda)).sum().backward()
+    rnd = (lambda t: t.to(torch.bfloat16).float()) if torch.device(cuda).type == "cuda" else (lambda t: t)
+    fr = rnd(feat).requires_grad_(True)
+    wr = rnd(conv.weight.detach().cpu().reshape(c, 27, c)).requires_grad_(True)
+    br = conv.bias.detach().cpu().clone().requires_grad_(True)
+    ref = oops.gather_conv(fr, wr, br, nbr)
+    (ref * rnd(probe)).sum().backward()
+    rtol, atol = _tols(torch.bfloat16)
+    _close("odd_conv_fwd", y, ref, rtol, atol * 4)
+    _close("odd_conv_dx", fe.grad, fr.grad, rtol, 4 * atol * float(fr.grad.abs().max()))
+    _close("odd_conv_dw", conv.weight.grad.reshape(c, 27, c), wr.grad, 2e-2, 1e-2 * float(wr.grad.abs().max()))
+    _close("odd_conv_db", conv.bias.grad, br.grad, 2e-2, 1e-2 * float(br.grad.abs().max()))
+
+
 def test_spconv_autograd_with_duplicate_voxels(cuda):
     """Mix3D batches list some voxels twice (or more).  Forward: the lowest row wins every lookup; the backward must be
     the exact adjoint of THAT map (copies that nothing reads get zero gradient, the gradients of identical output rows
