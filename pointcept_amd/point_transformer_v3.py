@@ -465,7 +465,7 @@ class Block(PointModule):
         """the whole block as one C call per direction (csrc/block_exec.hip): the bench configuration class -- bf16 or fp16 autocast,
         pre-norm, LayerNorm joints, the window-attention kernel with the gather tables folded into qkv / proj, fused MLP, <= 256 channels"""
         a = self.attn
-        return (config.EXEC_BLOCK and type(self) is Block and type(a) is SerializedAttention and torch.is_autocast_enabled("cuda")
+        return (config.EXEC_BLOCK and type(self) in _EXEC_BLOCK_TYPES and type(a) is SerializedAttention and torch.is_autocast_enabled("cuda")
                 and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16) and self.channels % 32 == 0 and self.channels <= 256
                 and a.enable_flash and not a.enable_rpe and a.num_heads * 16 == self.channels and config.FUSE_GATHER and config.FUSE_MLP
                 and (a.attn_drop == 0.0 or not self.training)
@@ -532,6 +532,10 @@ class Block(PointModule):
             point = self.norm2(point)
         point.sparse_conv_feat = point.sparse_conv_feat.replace_feature(point.feat)
         return point
+
+
+# block classes whose forward is the sequence csrc/block_exec.hip enqueues (PT-v3m2's Block without LayerScale registers itself)
+_EXEC_BLOCK_TYPES = {Block}
 
 
 class SerializedPooling(PointModule):

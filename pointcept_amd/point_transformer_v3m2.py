@@ -25,6 +25,7 @@ import torch.nn as nn
 from . import functional as PF
 from . import nn as PNN
 from . import ops
+from . import point_transformer_v3 as _m1_module
 from .point_transformer_v3 import Block as _BlockM1
 from .point_transformer_v3 import DropPath, PointModule, PointSequential, norm_then_act
 from .structure import AttrDict, Point
@@ -67,8 +68,10 @@ class Block(_BlockM1):
         return not self.has_layer_scale and super()._fusable(point)   # the fused joints carry a per-row scale only
 
     def forward(self, point: Point):
-        if self._fusable(point):
-            out = self._forward_fused(point)
+        if self._fusable(point):                  # (no LayerScale: the block IS m1's -- one C call per direction where the executor's shapes allow)
+            out = self._forward_exec(point) if self._exec_ok(point) else None
+            if out is None:
+                out = self._forward_fused(point)
             if out is not None:
                 return out
         shortcut = point.feat
@@ -90,6 +93,9 @@ class Block(_BlockM1):
             point = self.norm2(point)
         point.sparse_conv_feat = point.sparse_conv_feat.replace_feature(point.feat)
         return point
+
+
+_m1_module._EXEC_BLOCK_TYPES.add(Block)
 
 
 def grid_cluster_maps(grid_coord: torch.Tensor, batch: torch.Tensor, stride: int, coord_max, n_batch: int):

@@ -483,5 +483,6 @@ def test_block_executor_is_bit_identical_to_the_composed_path_on_the_emulation(m
     try:
         run(700, 32, 2, 128, torch.float32, True, False)
         run(2300, 64, 4, 128, torch.bfloat16, False, True)
+        run(500, 96, 6, 128, torch.float32, True, False)      # round 5: a width that is no power of two (PT-v3m2's 96 / 192): separate joints, run-time-width LayerNorm
     finally:
         PF.invalidate_weight_casts()
