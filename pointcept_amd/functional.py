@@ -379,6 +379,7 @@ class _SparseConv(Function):
             # register-weight kernels of the next width they exist for (conv7 / wgrad7: 32 | 64 channels), zero-padded: the 48-channel
             # stage-0 convolutions ran 403 us on conv2 against 145 us for conv7 at 64 (profiles/r05_m_m2_kernel_stats.csv)
             cpad = opad = 32 if c_in < 32 else 64
+        # (measured and dropped, round 5: SpUNet's 96-channel level-0 convolutions zero-padded onto the 128-channel instances -- step 26.7 -> 31.2 ms)
         f = _pad_to(feat.to(dt), 1, cpad).contiguous()
         w = _pad_to(_pad_to(_cast_cache.get(weight, dt), 2, cpad), 0, opad).contiguous()
         b = None if bias is None else _pad_to(bias.float(), 0, opad)
