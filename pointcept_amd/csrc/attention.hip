@@ -333,8 +333,8 @@ static AtPlan at_plan_host(int n_units, int lp_max) {
     const int qs = at_split_host(n_units, lp_max);
     return {0, qs};
   }
-  static struct { int n_units, lp_max; AtPlan p; } cache[16];
-  static int n_cache = 0;
+  static thread_local struct { int n_units, lp_max; AtPlan p; } cache[16];     // per thread: launches may come from several host threads
+  static thread_local int n_cache = 0;
   for (int i = 0; i < n_cache; ++i)
     if (cache[i].n_units == n_units && cache[i].lp_max == lp_max) return cache[i].p;
   const int per_xcd = (n_units + 7) >> 3, n_tiles = lp_max >> 5, S = slots_per_xcd;

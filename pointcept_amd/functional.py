@@ -519,6 +519,7 @@ class _LayerNorm(Function):
         y, mean, rstd = ops.layer_norm_fwd(x, weight, bias, eps, out_dtype)
         ctx.save_for_backward(x, mean, rstd, weight)
         ctx.has_affine = weight is not None
+        ctx.has_bias = bias is not None          # nn.LayerNorm(bias=False): no gradient may be returned for the absent input
         return y
 
     @staticmethod
@@ -527,7 +528,7 @@ class _LayerNorm(Function):
         x, mean, rstd, weight = ctx.saved_tensors
         dx, dg, db = ops.layer_norm_bwd(dy, x, mean, rstd, weight, want_affine=ctx.has_affine)
         if ctx.has_affine:
-            dg, db = dg.to(weight.dtype), db.to(weight.dtype)
+            dg, db = dg.to(weight.dtype), (db.to(weight.dtype) if ctx.has_bias else None)
         return dx, dg, db, None, None
 
 

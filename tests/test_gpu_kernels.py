@@ -908,6 +908,28 @@ def test_layer_norm_empty_and_unsupported(cuda):
     assert y.shape == (0, 64)
 
 
+@pytest.mark.parametrize("kw", [dict(bias=False), dict(elementwise_affine=False), dict()], ids=["no_bias", "no_affine", "affine"])
+@pytest.mark.parametrize("c", [64, 48, 18])
+def test_layer_norm_affine_variants(cuda, c, kw):
+    """nn.LayerNorm's three parameter layouts (weight + bias, weight only, none) through the autograd function the module mirror calls:
+    the backward returns no gradient for an absent input (autograd raises on one), and the present ones match torch's."""
+    from pointcept_amd import functional as PF
+
+    torch.manual_seed(c)
+    ref = torch.nn.LayerNorm(c, **kw)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.add_(torch.randn_like(p) * 0.3)
+    par = {n: p.detach().to(cuda).requires_grad_(True) for n, p in ref.named_parameters()}
+    x, dy = torch.randn(777, c), torch.randn(777, c)
+    xe, xr = x.clone().to(cuda).requires_grad_(True), x.clone().requires_grad_(True)
+    (PF.layer_norm(xe, par.get("weight"), par.get("bias"), ref.eps) * dy.to(cuda)).sum().backward()
+    (ref(xr) * dy).sum().backward()
+    _close("ln_var_dx", xe.grad, xr.grad, 1e-4, 1e-4 * float(xr.grad.abs().max()))
+    for n, pr in ref.named_parameters():
+        _close("ln_var_" + n, par[n].grad, pr.grad, 1e-4, 1e-4 * float(pr.grad.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------------
 # H. attention
 # ------------------------------------------------------------------------------------------------
