@@ -555,6 +555,7 @@ class _AddNorm(Function):
                               None if norm_b is None else norm_b[0])
         ctx.has_a, ctx.has_b = has_a, has_b
         ctx.aff = (ga is not None, gb is not None)
+        ctx.has_bias = (ba is not None, bb is not None)     # a weight-only LayerNorm gets no bias gradient back (autograd raises on one)
         ctx.a_dtype = a.dtype
         # an unused output (the cast copy of a stage's last block, which the pooling does not read) must not be
         # materialised as a zero gradient: that was 8 zero fills + 8 extra reads of [N, C] per step
@@ -576,7 +577,7 @@ class _AddNorm(Function):
         da, du, dga, dba, dgb, dbb = ops.add_norm_bwd(dz, dy, z, u, row_scale, ga, st_a, gb, st_b,
                                                       ctx.has_a and ctx.aff[0], ctx.has_b and ctx.aff[1] and dy is not None,
                                                       da_dtype=ctx.a_dtype)
-        return du, da, None, dga, dba, None, dgb, dbb, None, None, None, None
+        return du, da, None, dga, (dba if ctx.has_bias[0] else None), None, dgb, (dbb if ctx.has_bias[1] else None), None, None, None, None
 
 
 def add_norm(u: torch.Tensor, a: torch.Tensor, row_scale: Optional[torch.Tensor] = None, norm_a=None, norm_b=None,

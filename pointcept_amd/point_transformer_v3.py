@@ -431,6 +431,7 @@ class Block(PointModule):
         return (config.FUSE_BLOCK and self.pre_norm and point.feat.is_cuda and point.feat.dim() == 2
                 and isinstance(self.cpe[2], PNN.LayerNorm) and isinstance(self.norm1[0], PNN.LayerNorm)
                 and isinstance(self.norm2[0], PNN.LayerNorm) and ops.layer_norm_joint_available(self.channels)
+                and all(ln.weight is not None and ln.bias is not None for ln in (self.cpe[2], self.norm1[0], self.norm2[0]))
                 and point.feat.shape[0] > 0 and point.feat.dtype in (torch.float32, torch.bfloat16, torch.float16))
 
     def _forward_fused(self, point: Point):
