@@ -1248,6 +1248,29 @@ def test_flash_attn_api_head_dim_18_autograd(cuda):
     _close("fa18_bwd", xq.grad, x32.grad, 1.0 / 32, 1e-2 * float(x32.grad.abs().max()))
 
 
+@pytest.mark.parametrize("D,dtype", [(8, torch.bfloat16), (12, torch.float16), (3, torch.bfloat16)])
+def test_flash_attn_api_small_heads(cuda, D, dtype):
+    """head_dim below one MFMA k-step through the flash_attn mirror: zero-padded to 16 on the way in, cut on the way out; the default
+    softmax scale is that of the caller's head_dim."""
+    from pointcept_amd.flash_attn_api import flash_attn_varlen_qkvpacked_func
+
+    g = torch.Generator().manual_seed(80 + D)
+    lens, H = [700, 1, 64, 333], 5
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    x = (torch.randn(T, 3, H, D, generator=g) * 1.5).to(dtype)
+    xq = x.to(cuda).requires_grad_(True)
+    o = flash_attn_varlen_qkvpacked_func(xq, cu.to(cuda), max_seqlen=700)
+    assert o.shape == (T, H, D) and o.dtype == dtype
+    w = torch.randn(T, H, D, generator=g)
+    (o.float() * w.to(cuda)).sum().backward()
+    x32 = x.float().requires_grad_(True)
+    r = oops.attention_varlen(x32, cu, D ** -0.5)
+    (r * w).sum().backward()
+    _close("fa_small_fwd", o, r, 1.0 / 64, 2.0 ** -8 * float(x[:, 2].float().abs().max()))
+    _close("fa_small_bwd", xq.grad, x32.grad, 1.0 / 32, 1.5e-2 * float(x32.grad.abs().max()))
+
+
 def _rpe_reference(qkv, cu, scale, gc, table, bnd):
     """ptv3m1:29-48,190-206 on the CPU in fp32, window by window (the oracle of the RPE kernels)."""
     T, _, H, D = qkv.shape

@@ -879,6 +879,27 @@ def test_flash_attn_mirror_accepts_fp16_like_liteptS_call_site():
     assert _rel(out.detach().float(), want) < 1e-3 and float(qkv.grad.float().abs().max()) > 0
 
 
+def test_flash_attn_mirror_pads_small_heads_to_one_mfma_step():
+    """head_dim 1..15 (flash-attn serves them; no reference model uses them): zero channels up to 16, the caller's head_dim in the default
+    softmax scale, the result cut back -- values and gradients are those of the unpadded attention."""
+    from oracle import ops as oops
+    from pointcept_amd import flash_attn_api
+
+    g = torch.Generator().manual_seed(12)
+    cu = torch.tensor([0, 100, 130, 131], dtype=torch.int32)
+    for d in (8, 12, 1):
+        qkv = torch.randn(131, 3, 3, d, generator=g).bfloat16().requires_grad_(True)
+        w = torch.randn(131, 3, d, generator=g)
+        with mock_backend.cpu_ops():
+            out = flash_attn_api.flash_attn_varlen_qkvpacked_func(qkv, cu, max_seqlen=100)
+            (out.float() * w).sum().backward()
+        assert out.shape == (131, 3, d) and out.dtype == torch.bfloat16 and qkv.grad.shape == qkv.shape
+        q32 = qkv.detach().float().requires_grad_(True)
+        want = oops.attention_varlen(q32, cu.tolist(), d ** -0.5)
+        (want * w).sum().backward()
+        assert _rel(out.detach().float(), want.detach()) < 1e-2 and _rel(qkv.grad.float(), q32.grad) < 2e-2, d
+
+
 @pytest.mark.needs_reference
 def test_register_models_in_the_reference_registry():
     """B1 in one call: compat.register_models puts the engine's six module-level ports into the reference's MODELS registry
