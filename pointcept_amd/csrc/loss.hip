@@ -10,6 +10,7 @@
 //     (deterministic, no float atomics); backward writes softmax - onehot scaled by a DEVICE scalar
 //     (grad / count), so the mean never needs a host sync.  ATen: 0.95 ms + 0.61 ms per step.
 #include "ptc_common.h"
+#include "loss_rows.h"
 
 template <typename CoordT>
 __global__ void __launch_bounds__(256)
@@ -120,6 +121,72 @@ ce_bwd_kernel(const T* __restrict__ logits, int64_t row_stride, const int64_t* _
   }
 }
 
+// C <= LR_CP: the row in registers, one vector load pass; the gradient rows leave through LDS (loss_rows.h).  Same arithmetic, same bits.
+template <typename T, int VB>
+__global__ void __launch_bounds__(LR_THREADS)
+ce_fwd_rows_kernel(const T* __restrict__ logits, int64_t row_stride, const int64_t* __restrict__ target, int64_t n, int c,
+                   int64_t ignore_index, float* __restrict__ lse, float* __restrict__ partial) {
+  __shared__ float red[2][4];
+  const int64_t i = (int64_t)blockIdx.x * LR_THREADS + threadIdx.x;
+  float loss = 0.f, cnt = 0.f;
+  if (i < n) {
+    float v[LR_CP];
+    lr_load_row<T, VB>(logits + i * row_stride, c, v);
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < LR_CP; ++j) if (j < c) m = fmaxf(m, v[j]);
+    float ssum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LR_CP; ++j) if (j < c) ssum += __expf(v[j] - m);
+    const float l = m + __logf(ssum);
+    lse[i] = l;
+    const int64_t t = target[i];
+    if (t != ignore_index && t >= 0 && t < c) {
+      loss = l - lr_pick(v, (int)t);
+      cnt = 1.f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    loss += __shfl_xor(loss, o, 64);
+    cnt += __shfl_xor(cnt, o, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if (ptc_lane() == 0) { red[0][wave] = loss; red[1][wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * (int64_t)blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partial[2 * (int64_t)blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+template <typename T, int VB>
+__global__ void __launch_bounds__(LR_THREADS)
+ce_bwd_rows_kernel(const T* __restrict__ logits, int64_t row_stride, const int64_t* __restrict__ target, const float* __restrict__ lse,
+                   const float* __restrict__ scale, int64_t n, int c, int64_t ignore_index, T* __restrict__ dlogits, int a16) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [256][c] T: this workgroup's chunk of dlogits (dense rows)
+  const int64_t row0 = (int64_t)blockIdx.x * LR_THREADS, i = row0 + threadIdx.x;
+  if (i < n) {
+    float v[LR_CP];
+    lr_load_row<T, VB>(logits + i * row_stride, c, v);
+    const int64_t t = target[i];
+    const bool valid = t != ignore_index && t >= 0 && t < c;
+    const float sc = valid ? scale[0] : 0.f;
+    const float l = lse[i];
+    T* drow = reinterpret_cast<T*>(smem) + (int)threadIdx.x * c;
+#pragma unroll
+    for (int j = 0; j < LR_CP; ++j) {
+      if (j < c) {
+        const float p = __expf(v[j] - l);
+        drow[j] = ptc_from_float<T>(sc * (p - (j == t ? 1.f : 0.f)));
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t rows = (n - row0) < LR_THREADS ? (n - row0) : LR_THREADS;
+  lr_copy_out<T>(smem, dlogits + row0 * c, (int)rows * c, a16 != 0);
+}
+
 extern "C" int64_t ptc_cross_entropy_partials(int64_t n) { return n > 0 ? ptc_cdiv(n, 256) : 1; }
 
 extern "C" int ptc_cross_entropy_fwd(const void* logits, int64_t row_stride, const int64_t* target, int64_t n, int c, int dtype,
@@ -133,6 +200,13 @@ extern "C" int ptc_cross_entropy_fwd(const void* logits, int64_t row_stride, con
   }
   PTC_REQUIRE(logits && target && lse, PTC_EINVAL, "ptc_cross_entropy_fwd: null buffer");
   const unsigned grid = (unsigned)ptc_cdiv(n, 256);
+  if (c <= LR_CP) {
+    const int vb = lr_vec_bytes(logits, row_stride, c, ptc_dtype_size(dtype));
+    PTC_DISPATCH_DTYPE(dtype, T, LR_DISPATCH_VB(vb, VB, hipLaunchKernelGGL((ce_fwd_rows_kernel<T, VB>), dim3(grid), dim3(LR_THREADS), 0, s,
+                                                                         (const T*)logits, row_stride, target, n, c, ignore_index, lse, partial)));
+    PTC_CHECK_LAUNCH("ce_fwd_rows_kernel");
+    return PTC_OK;
+  }
   PTC_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(ce_fwd_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)logits, row_stride, target,
                                                    n, c, ignore_index, lse, partial));
   PTC_CHECK_LAUNCH("ce_fwd_kernel");
@@ -147,6 +221,16 @@ extern "C" int ptc_cross_entropy_bwd(const void* logits, int64_t row_stride, con
   PTC_REQUIRE(logits && target && lse && scale && dlogits, PTC_EINVAL, "ptc_cross_entropy_bwd: null buffer");
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)ptc_cdiv(n, 256);
+  if (c <= LR_CP && drow_stride == c) {       // dense gradient rows: the workgroup's chunk is contiguous
+    const int vb = lr_vec_bytes(logits, row_stride, c, ptc_dtype_size(dtype));
+    const int a16 = ((uintptr_t)dlogits & 15) == 0;
+    const size_t lds = (size_t)LR_THREADS * c * ptc_dtype_size(dtype);
+    PTC_DISPATCH_DTYPE(dtype, T, LR_DISPATCH_VB(vb, VB, hipLaunchKernelGGL((ce_bwd_rows_kernel<T, VB>), dim3(grid), dim3(LR_THREADS), lds, s,
+                                                                         (const T*)logits, row_stride, target, lse, scale, n, c, ignore_index,
+                                                                         (T*)dlogits, a16)));
+    PTC_CHECK_LAUNCH("ce_bwd_rows_kernel");
+    return PTC_OK;
+  }
   PTC_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(ce_bwd_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)logits, row_stride, target,
                                                    lse, scale, n, c, ignore_index, (T*)dlogits, drow_stride));
   PTC_CHECK_LAUNCH("ce_bwd_kernel");

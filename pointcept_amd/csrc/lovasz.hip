@@ -8,11 +8,14 @@
 // radix sort of the [C, N] error matrix (the row-batched sort of scan_sort.hip that also orders the serialization
 // curves):
 //   1. lovasz_keys      : per point softmax in fp32 straight from the (strided, 16-bit) head output; key[c][i] =
-//                         0x3f800000 - bits(|fg - p_c|): errors lie in [0, 1], so the 30-bit integer ascends as the
+//                         (0x3f800000 - bits(|fg - p_c|)) << 1 | fg: errors lie in [0, 1], so the 30-bit integer ascends as the
 //                         error descends.  Ignored points get error 0 (they sort to the tail and multiply their
 //                         Jaccard step by 0).  Class populations are counted with integer atomics (exact, order free).
-//   2. ptc_sort_keys    : C rows of N keys, bits [0, 30): 4 passes.
-//   3. lovasz_fg        : foreground flag of every sorted slot; ptc_exclusive_scan_i32 over the flat [C*N] flags.
+//   2. ptc_sort_keys_ex : C rows of N keys, bits [1, 31): 4 passes; the foreground flag in bit 0 is a payload the sort carries along,
+//                         and the sorted key words come back with the order (round 5: the first form gathered target[order[t]] for the
+//                         flag and keys[order[t]] for the error -- two random 8-byte gathers per slot, 143 + 452 us at 819200 x 20,
+//                         1.8 GB of sector traffic in lovasz_step for 0.5 GB of operands, profiles/r04_zy_step_traffic.txt).
+//   3. lovasz_fg        : foreground flag of every sorted slot (bit 0 of its key); ptc_exclusive_scan_i32 over the flat [C*N] flags.
 //   4. lovasz_step      : Jaccard step of slot i, computed EXACTLY from the integer counts instead of as the difference
 //                         of two nearly equal quotients (lovasz.py:31-32): with I = fg still to come, U = union so far,
 //                         step = 1/U for a foreground slot and I/(U (U-1)) for a background slot.  Accumulates
@@ -23,10 +26,16 @@
 // All of it is HBM-bound streaming work (~190 B per (point, class) slot); bit-reproducible.
 #include "ptc_common.h"
 #include "voxel_keys.h"
+#include "loss_rows.h"
 
 #define LV_THREADS 256
 #define LV_MAX_C 64
 #define LV_ONE 0x3f800000u
+
+// key word of one (class, point) slot: bits [1, 31) ascend as the error descends, bit 0 = the slot is foreground (its point carries this
+// class) -- below the sorted bit range, carried along by the sort
+__device__ __forceinline__ int64_t lv_key(float e, bool fg) { return (int64_t)(((uint64_t)(LV_ONE - __float_as_uint(e)) << 1) | (fg ? 1u : 0u)); }
+__device__ __forceinline__ float lv_key_error(int64_t key) { return __uint_as_float(LV_ONE - (uint32_t)((uint64_t)key >> 1)); }
 
 template <typename T>
 __global__ void __launch_bounds__(LV_THREADS)
@@ -49,7 +58,44 @@ lovasz_keys_kernel(const T* __restrict__ logits, int64_t row_stride, const int64
       const float p = __expf(ptc_to_float(row[j]) - m) * inv;
       float e = valid ? (j == t ? 1.f - p : p) : 0.f;
       e = fminf(fmaxf(e, 0.f), 1.f);
-      keys[(int64_t)j * n + i] = (int64_t)(LV_ONE - __float_as_uint(e));
+      keys[(int64_t)j * n + i] = lv_key(e, valid && j == t);
+    }
+    if (valid) atomicAdd(&cnt[(int)t], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < c && cnt[threadIdx.x] != 0) atomicAdd(&class_count[threadIdx.x], cnt[threadIdx.x]);
+}
+
+// C <= LR_CP: the row in registers (loss_rows.h); exp(x - m) is evaluated once per class instead of twice (the same call on the same
+// operands: the same value)
+template <typename T, int VB>
+__global__ void __launch_bounds__(LV_THREADS)
+lovasz_keys_rows_kernel(const T* __restrict__ logits, int64_t row_stride, const int64_t* __restrict__ target, int64_t n, int c,
+                        int64_t ignore_index, int64_t* __restrict__ keys, int32_t* __restrict__ class_count) {
+  __shared__ int32_t cnt[LV_MAX_C];
+  if (threadIdx.x < LV_MAX_C) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x;
+  if (i < n) {
+    float v[LR_CP];
+    lr_load_row<T, VB>(logits + i * row_stride, c, v);
+    const int64_t t = target[i];
+    const bool valid = t != ignore_index && t >= 0 && t < c;
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < LR_CP; ++j) if (j < c) m = fmaxf(m, v[j]);
+    float ssum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LR_CP; ++j) if (j < c) { v[j] = __expf(v[j] - m); ssum += v[j]; }
+    const float inv = 1.f / ssum;
+#pragma unroll
+    for (int j = 0; j < LR_CP; ++j) {
+      if (j < c) {
+        const float p = v[j] * inv;
+        float e = valid ? (j == t ? 1.f - p : p) : 0.f;
+        e = fminf(fmaxf(e, 0.f), 1.f);
+        keys[(int64_t)j * n + i] = lv_key(e, valid && j == t);
+      }
     }
     if (valid) atomicAdd(&cnt[(int)t], 1);
   }
@@ -58,17 +104,13 @@ lovasz_keys_kernel(const T* __restrict__ logits, int64_t row_stride, const int64
 }
 
 __global__ void __launch_bounds__(LV_THREADS)
-lovasz_fg_kernel(const int64_t* __restrict__ order, const int64_t* __restrict__ target, int64_t n, int c,
-                 int32_t* __restrict__ fg) {
-  const int64_t total = n * (int64_t)c;
+lovasz_fg_kernel(const int64_t* __restrict__ sorted_keys, int64_t total, int32_t* __restrict__ fg) {
   const int64_t t = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x;
-  if (t >= total) return;
-  const int row = (int)(t / n);
-  fg[t] = target[order[t]] == (int64_t)row ? 1 : 0;   // ignored / out-of-range labels never equal a class index
+  if (t < total) fg[t] = (int32_t)(sorted_keys[t] & 1);
 }
 
 __global__ void __launch_bounds__(LV_THREADS)
-lovasz_step_kernel(const int64_t* __restrict__ keys, const int64_t* __restrict__ order, const int32_t* __restrict__ fg,
+lovasz_step_kernel(const int64_t* __restrict__ sorted_keys, const int64_t* __restrict__ order,
                    const int64_t* __restrict__ fg_scan, const int32_t* __restrict__ class_count, int64_t n, int c,
                    float* __restrict__ gprob, double* __restrict__ partial) {
   __shared__ double red[LV_THREADS / 64];
@@ -89,11 +131,12 @@ lovasz_step_kernel(const int64_t* __restrict__ keys, const int64_t* __restrict__
     const int64_t gts = class_count[row];
     float g = 0.f;
     if (gts > 0) {
-      const int f = fg[t];
+      const int64_t key = sorted_keys[t];
+      const int f = (int)(key & 1);
       const int64_t cum_fg = fg_scan[t] - fg_scan[(int64_t)row * n] + f;   // inclusive
       const int64_t cum_bg = (i + 1) - cum_fg;
       const double step = ptc_lovasz_step(gts, cum_fg, cum_bg, f);   // exact Jaccard difference (voxel_keys.h)
-      const float e = __uint_as_float(LV_ONE - (uint32_t)keys[(int64_t)row * n + src]);
+      const float e = lv_key_error(key);
       contrib = (double)e * step;
       g = (float)(step / (double)n_present_s);
       g = f ? -g : g;                                    // d|fg - p| / dp
@@ -153,6 +196,49 @@ lovasz_dlogits_kernel(const T* __restrict__ logits, int64_t row_stride, const in
   }
 }
 
+// C <= LR_CP: row in registers, the gradient rows out through LDS (loss_rows.h); the arithmetic is lovasz_dlogits_kernel's
+template <typename T, int VB>
+__global__ void __launch_bounds__(LV_THREADS)
+lovasz_dlogits_rows_kernel(const T* __restrict__ logits, int64_t row_stride, const int64_t* __restrict__ target,
+                           const float* __restrict__ gprob, int64_t n, int c, int64_t ignore_index, float* __restrict__ dlogits, int a16) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [256][c] fp32: this workgroup's chunk of dlogits
+  const int64_t row0 = (int64_t)blockIdx.x * LV_THREADS, i = row0 + threadIdx.x;
+  if (i < n) {
+    float* drow = reinterpret_cast<float*>(smem) + (int)threadIdx.x * c;
+    const int64_t t = target[i];
+    const bool valid = t != ignore_index && t >= 0 && t < c;
+    if (!valid) {
+#pragma unroll
+      for (int j = 0; j < LR_CP; ++j) if (j < c) drow[j] = 0.f;
+    } else {
+      float v[LR_CP], gp[LR_CP];
+      lr_load_row<T, VB>(logits + i * row_stride, c, v);
+#pragma unroll
+      for (int j = 0; j < LR_CP; ++j) gp[j] = j < c ? gprob[(int64_t)j * n + i] : 0.f;
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < LR_CP; ++j) if (j < c) m = fmaxf(m, v[j]);
+      float ssum = 0.f;
+#pragma unroll
+      for (int j = 0; j < LR_CP; ++j) if (j < c) { v[j] = __expf(v[j] - m); ssum += v[j]; }
+      const float inv = 1.f / ssum;
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < LR_CP; ++j) if (j < c) dot += gp[j] * (v[j] * inv);
+#pragma unroll
+      for (int j = 0; j < LR_CP; ++j) {
+        if (j < c) {
+          const float p = v[j] * inv;
+          drow[j] = p * (gp[j] - dot);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t rows = (n - row0) < LV_THREADS ? (n - row0) : LV_THREADS;
+  lr_copy_out<float>(smem, dlogits + row0 * c, (int)rows * c, a16 != 0);
+}
+
 struct LvLayout {
   size_t keys, order, fg, scan, gprob, partial, count, sort_ws, scan_ws, total;
   int64_t n_partial;
@@ -206,22 +292,38 @@ extern "C" int ptc_lovasz_softmax(const void* logits, int64_t row_stride, const 
   const int64_t nc = n * (int64_t)c;
   const unsigned grid_n = (unsigned)ptc_cdiv(n, LV_THREADS), grid_nc = (unsigned)ptc_cdiv(nc, LV_THREADS);
 
+  const bool rows = c <= LR_CP;                      // the row-in-registers kernels (loss_rows.h)
+  const int vb = lr_vec_bytes(logits, row_stride, c, ptc_dtype_size(dtype));
   PTC_HIP(hipMemsetAsync(count, 0, 256, s));
-  PTC_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(lovasz_keys_kernel<T>, dim3(grid_n), dim3(LV_THREADS), 0, s, (const T*)logits,
-                                                   row_stride, target, n, c, ignore_index, keys, count));
+  if (rows) {
+    PTC_DISPATCH_DTYPE(dtype, T, LR_DISPATCH_VB(vb, VB, hipLaunchKernelGGL((lovasz_keys_rows_kernel<T, VB>), dim3(grid_n), dim3(LV_THREADS), 0, s,
+                                                                         (const T*)logits, row_stride, target, n, c, ignore_index, keys, count)))
+  } else {
+    PTC_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(lovasz_keys_kernel<T>, dim3(grid_n), dim3(LV_THREADS), 0, s, (const T*)logits,
+                                                     row_stride, target, n, c, ignore_index, keys, count))
+  }
   PTC_CHECK_LAUNCH("lovasz_keys_kernel");
-  int rc = ptc_sort_keys(keys, n, c, 0, 30, order, nullptr, ws + L.sort_ws, L.scan_ws - L.sort_ws, stream);
+  // the sorted key words replace the unsorted ones in place (the sort reads `keys` in its first pass only)
+  int rc = ptc_sort_keys_ex(keys, n, c, 1, 31, order, nullptr, keys, ws + L.sort_ws, L.scan_ws - L.sort_ws, stream);
   if (rc != PTC_OK) return rc;
-  hipLaunchKernelGGL(lovasz_fg_kernel, dim3(grid_nc), dim3(LV_THREADS), 0, s, order, target, n, c, fg);
+  hipLaunchKernelGGL(lovasz_fg_kernel, dim3(grid_nc), dim3(LV_THREADS), 0, s, keys, nc, fg);
   PTC_CHECK_LAUNCH("lovasz_fg_kernel");
   rc = ptc_exclusive_scan_i32(fg, nc, scan, ws + L.scan_ws, L.total - L.scan_ws, stream);
   if (rc != PTC_OK) return rc;
-  hipLaunchKernelGGL(lovasz_step_kernel, dim3(grid_nc), dim3(LV_THREADS), 0, s, keys, order, fg, scan, count, n, c, gprob, partial);
+  hipLaunchKernelGGL(lovasz_step_kernel, dim3(grid_nc), dim3(LV_THREADS), 0, s, keys, order, scan, count, n, c, gprob, partial);
   PTC_CHECK_LAUNCH("lovasz_step_kernel");
   hipLaunchKernelGGL(lovasz_finish_kernel, dim3(1), dim3(LV_THREADS), 0, s, partial, L.n_partial, count, c, loss);
   PTC_CHECK_LAUNCH("lovasz_finish_kernel");
-  PTC_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(lovasz_dlogits_kernel<T>, dim3(grid_n), dim3(LV_THREADS), 0, s, (const T*)logits,
-                                                   row_stride, target, gprob, n, c, ignore_index, dlogits));
+  if (rows) {
+    const int a16 = ((uintptr_t)dlogits & 15) == 0;
+    const size_t lds = (size_t)LV_THREADS * c * sizeof(float);
+    PTC_DISPATCH_DTYPE(dtype, T, LR_DISPATCH_VB(vb, VB, hipLaunchKernelGGL((lovasz_dlogits_rows_kernel<T, VB>), dim3(grid_n), dim3(LV_THREADS), lds, s,
+                                                                         (const T*)logits, row_stride, target, gprob, n, c, ignore_index, dlogits,
+                                                                         a16)))
+  } else {
+    PTC_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(lovasz_dlogits_kernel<T>, dim3(grid_n), dim3(LV_THREADS), 0, s, (const T*)logits,
+                                                     row_stride, target, gprob, n, c, ignore_index, dlogits))
+  }
   PTC_CHECK_LAUNCH("lovasz_dlogits_kernel");
   return PTC_OK;
 }

@@ -105,3 +105,7 @@ __host__ __device__ __forceinline__ void ptc_rope_pair(float u, float v, float c
   rv = fmaf(v, cs, u * sn);
 }
 
+// ---- library-internal entry points shared by translation units (C++ linkage: not part of include/ptcore.h) ----------------------------
+// ptc_sort_keys (scan_sort.hip) that also returns the key words in sorted order; see there.
+int ptc_sort_keys_ex(const int64_t* keys, int64_t n, int k, int begin_bit, int end_bit, int64_t* order, int64_t* inverse,
+                     int64_t* sorted_keys, void* workspace, size_t workspace_bytes, ptc_stream_t stream);

@@ -304,16 +304,22 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
   }
 }
 
+// `sorted_keys` (optional): the key words in sorted order -- bits [0, end_bit) of the caller's keys, i.e. INCLUDING whatever the caller
+// keeps below begin_bit (a payload the sort carries along: the Lovasz loss rides its foreground flag there, lovasz.hip).  `plain` = the
+// sorted key words of the unpacked path (or the input itself when the bit range is empty).
 __global__ void __launch_bounds__(256)
-rs_finalize_kernel(const uint32_t* __restrict__ idx, const uint64_t* __restrict__ packed, uint64_t idx_mask, int64_t n, int k,
-                   int64_t* __restrict__ order, int64_t* __restrict__ inverse) {
+rs_finalize_kernel(const uint32_t* __restrict__ idx, const uint64_t* __restrict__ packed, uint64_t idx_mask, int idx_bits, int64_t n, int k,
+                   int64_t* __restrict__ order, int64_t* __restrict__ inverse, const uint64_t* plain,
+                   int64_t* sorted_keys) {            // (`plain` and `sorted_keys` may be the same array: empty bit range, in-place caller)
   const int64_t total = n * k;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const int64_t row = t / n, i = t - row * n;
-    const int64_t src = packed ? (int64_t)(packed[t] & idx_mask) : (idx ? (int64_t)idx[t] : i);
+    const uint64_t word = packed ? packed[t] : 0ull;
+    const int64_t src = packed ? (int64_t)(word & idx_mask) : (idx ? (int64_t)idx[t] : i);
     order[t] = src;
     if (inverse) inverse[row * n + src] = i;
+    if (sorted_keys) sorted_keys[t] = (int64_t)(packed ? (word >> idx_bits) : plain[t]);
   }
 }
 
@@ -343,6 +349,13 @@ extern "C" size_t ptc_sort_keys_workspace_bytes(int64_t n, int k) { return rs_la
 extern "C" int ptc_sort_keys(const int64_t* keys, int64_t n, int k, int begin_bit, int end_bit,
                              int64_t* order, int64_t* inverse, void* workspace, size_t workspace_bytes,
                              ptc_stream_t stream) {
+  return ptc_sort_keys_ex(keys, n, k, begin_bit, end_bit, order, inverse, nullptr, workspace, workspace_bytes, stream);
+}
+
+// ptc_sort_keys + the sorted key words themselves (library-internal: lovasz.hip; `sorted_keys` may alias `keys`, which is read by the
+// first pass only -- and by the last kernel at the same index it writes when the bit range is empty)
+int ptc_sort_keys_ex(const int64_t* keys, int64_t n, int k, int begin_bit, int end_bit, int64_t* order, int64_t* inverse,
+                     int64_t* sorted_keys, void* workspace, size_t workspace_bytes, ptc_stream_t stream) {
   PTC_REQUIRE(n >= 0 && k >= 1, PTC_EINVAL, "ptc_sort_keys: bad n=%lld k=%d", (long long)n, k);
   PTC_REQUIRE(begin_bit >= 0 && end_bit <= 64 && begin_bit <= end_bit, PTC_EINVAL,
               "ptc_sort_keys: bad bit range [%d,%d)", begin_bit, end_bit);
@@ -396,7 +409,7 @@ extern "C" int ptc_sort_keys(const int64_t* keys, int64_t n, int k, int begin_bi
     if (grid > 4096) grid = 4096;
     const bool packed_out = pack && !first;
     hipLaunchKernelGGL(rs_finalize_kernel, dim3((unsigned)grid), dim3(256), 0, s, packed_out ? nullptr : cur_i, packed_out ? cur_k : nullptr,
-                       (((uint64_t)1 << idx_bits) - 1), n, k, order, inverse);
+                       (((uint64_t)1 << idx_bits) - 1), idx_bits, n, k, order, inverse, cur_k, sorted_keys);
     PTC_CHECK_LAUNCH("rs_finalize_kernel");
   }
   return PTC_OK;

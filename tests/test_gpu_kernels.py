@@ -1345,19 +1345,22 @@ def test_coord_max(cuda, n, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("n,c,strided", [(1, 20, False), (1000, 20, True), (70001, 16, False), (513, 13, True)])
+@pytest.mark.parametrize("n,c,strided", [(1, 20, False), (1000, 20, True), (70001, 16, False), (513, 13, True), (700, 13, False),
+                                         (300, 40, True)])
 def test_cross_entropy_fwd_bwd(cuda, dtype, n, c, strided):
     """CrossEntropyLoss(ignore_index=-1, mean) of pointcept/models/losses/misc.py: loss and gradient vs
-    torch on the same (rounded) logits in fp32; strided = a [:, :c] view of a wider head output."""
+    torch on the same (rounded) logits in fp32; strided = a [:, :c] view of a wider head output.  The cases cover the row loads of
+    csrc/loss_rows.h: 16-byte (64- / 128-byte rows), 8-byte (dense 20 x bf16), element-wise (dense 13 columns), and the kernels for
+    more than 32 classes."""
     from pointcept_amd import functional as PF
 
     g = torch.Generator().manual_seed(n * 31 + c)
-    wide = (torch.randn(n, 32, generator=g) * 3).to(dtype)
+    wide = (torch.randn(n, 32 if c <= 32 else 64, generator=g) * 3).to(dtype)
     tgt = torch.randint(0, c, (n,), generator=g)
     tgt[torch.rand(n, generator=g) < 0.1] = -1
     if n == 1:
         tgt[0] = 3
-    base = wide.to(cuda).requires_grad_(True)
+    base = wide.clone().to(cuda).requires_grad_(True)      # (clone: on the CPU test tiers .to() would alias `wide`)
     logits = base[:, :c] if strided else base[:, :c].contiguous()
     loss = PF.cross_entropy(logits, tgt.to(cuda), -1)
     loss.backward()
@@ -1715,7 +1718,7 @@ def test_lovasz_softmax_matches_reference_golden_and_oracle(cuda):
     from test_golden_cpu import lovasz_cases
 
     for ci, x, y, loss_ref, grad_ref in lovasz_cases():
-        xe = x.to(cuda).requires_grad_(True)
+        xe = x.clone().to(cuda).requires_grad_(True)
         loss = PF.lovasz_softmax(xe, y.to(cuda), -1)
         (loss * 2.5).backward()
         lo, do = losses.lovasz_softmax(x.numpy(), y.numpy(), -1)
@@ -1737,7 +1740,7 @@ def test_lovasz_softmax_16bit_strided_and_edge_cases(cuda, dtype):
     wide = (torch.randn(n, 32, generator=g) * 2).to(dtype)
     y = torch.randint(0, 17, (n,), generator=g)        # classes 17..19 absent
     y[torch.rand(n, generator=g) < 0.1] = -1
-    xe = wide.to(cuda).requires_grad_(True)
+    xe = wide.clone().to(cuda).requires_grad_(True)
     loss = PF.lovasz_softmax(xe[:, :c], y.to(cuda), -1)   # strided view of a wider head output
     loss.backward()
     lo, do = losses.lovasz_softmax(wide[:, :c].float().numpy(), y.numpy(), -1)
