@@ -31,6 +31,7 @@
 #define LV_THREADS 256
 #define LV_MAX_C 64
 #define LV_ONE 0x3f800000u
+#define LV_STEP_BLOCKS 4096
 
 // key word of one (class, point) slot: bits [1, 31) ascend as the error descends, bit 0 = the slot is foreground (its point carries this
 // class) -- below the sorted bit range, carried along by the sort
@@ -122,9 +123,10 @@ lovasz_step_kernel(const int64_t* __restrict__ sorted_keys, const int64_t* __res
   }
   __syncthreads();
   const int64_t total = n * (int64_t)c;
-  const int64_t t = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x;
   double contrib = 0.0;
-  if (t < total) {
+  // grid-stride over the slots: at most LV_STEP_BLOCKS workgroups, hence as many partial sums for lovasz_finish (one partial per 256
+  // slots -- 64000 at 819200 x 20 -- kept its single workgroup busy for 88 us; the order of the sum is fixed either way)
+  for (int64_t t = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; t < total; t += (int64_t)gridDim.x * LV_THREADS) {
     const int row = (int)(t / n);
     const int64_t i = t - (int64_t)row * n;
     const int64_t src = order[t];
@@ -137,7 +139,7 @@ lovasz_step_kernel(const int64_t* __restrict__ sorted_keys, const int64_t* __res
       const int64_t cum_bg = (i + 1) - cum_fg;
       const double step = ptc_lovasz_step(gts, cum_fg, cum_bg, f);   // exact Jaccard difference (voxel_keys.h)
       const float e = lv_key_error(key);
-      contrib = (double)e * step;
+      contrib += (double)e * step;
       g = (float)(step / (double)n_present_s);
       g = f ? -g : g;                                    // d|fg - p| / dp
     }
@@ -247,6 +249,7 @@ static LvLayout lv_layout(int64_t n, int c) {
   LvLayout L;
   const size_t nc = (size_t)(n > 0 ? n : 1) * (size_t)c;
   L.n_partial = ptc_cdiv((int64_t)nc, LV_THREADS);
+  if (L.n_partial > LV_STEP_BLOCKS) L.n_partial = LV_STEP_BLOCKS;
   size_t o = 0;
   L.keys = o; o += ptc_align_up(nc * 8, 256);
   L.order = o; o += ptc_align_up(nc * 8, 256);
@@ -310,7 +313,7 @@ extern "C" int ptc_lovasz_softmax(const void* logits, int64_t row_stride, const 
   PTC_CHECK_LAUNCH("lovasz_fg_kernel");
   rc = ptc_exclusive_scan_i32(fg, nc, scan, ws + L.scan_ws, L.total - L.scan_ws, stream);
   if (rc != PTC_OK) return rc;
-  hipLaunchKernelGGL(lovasz_step_kernel, dim3(grid_nc), dim3(LV_THREADS), 0, s, keys, order, scan, count, n, c, gprob, partial);
+  hipLaunchKernelGGL(lovasz_step_kernel, dim3((unsigned)L.n_partial), dim3(LV_THREADS), 0, s, keys, order, scan, count, n, c, gprob, partial);
   PTC_CHECK_LAUNCH("lovasz_step_kernel");
   hipLaunchKernelGGL(lovasz_finish_kernel, dim3(1), dim3(LV_THREADS), 0, s, partial, L.n_partial, count, c, loss);
   PTC_CHECK_LAUNCH("lovasz_finish_kernel");

@@ -1730,13 +1730,14 @@ def test_lovasz_softmax_matches_reference_golden_and_oracle(cuda):
         assert np.abs(g - grad_ref).max() <= 1e-3 * gmax, ci
 
 
+@pytest.mark.parametrize("n", [5000, 56000])        # 56000 x 20 slots: more than LV_STEP_BLOCKS workgroups of 256 (the grid-stride loop of lovasz_step)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_lovasz_softmax_16bit_strided_and_edge_cases(cuda, dtype):
+def test_lovasz_softmax_16bit_strided_and_edge_cases(cuda, dtype, n):
     from oracle import losses
     from pointcept_amd import functional as PF
 
     g = torch.Generator().manual_seed(11)
-    n, c = 5000, 20
+    c = 20
     wide = (torch.randn(n, 32, generator=g) * 2).to(dtype)
     y = torch.randint(0, 17, (n,), generator=g)        # classes 17..19 absent
     y[torch.rand(n, generator=g) < 0.1] = -1

@@ -188,8 +188,8 @@ EMULATED_GPU_TESTS = [
     ("test_layer_norm_fwd_bwd", dict(c=1024, xdt=torch.bfloat16, ydt=torch.bfloat16)), ("test_layer_norm_empty_and_unsupported", dict()),
     ("test_cross_entropy_fwd_bwd", dict(dtype=torch.bfloat16, n=1000, c=20, strided=True)), ("test_cross_entropy_fwd_bwd", dict(dtype=torch.bfloat16, n=1, c=20, strided=False)),
     ("test_cross_entropy_fwd_bwd", dict(dtype=torch.float32, n=700, c=13, strided=False)), ("test_cross_entropy_fwd_bwd", dict(dtype=torch.float32, n=300, c=40, strided=True)),
-    ("test_lovasz_softmax_matches_reference_golden_and_oracle", dict()), ("test_lovasz_softmax_16bit_strided_and_edge_cases", dict(dtype=torch.bfloat16)),
-    ("test_lovasz_softmax_16bit_strided_and_edge_cases", dict(dtype=torch.float16)),
+    ("test_lovasz_softmax_matches_reference_golden_and_oracle", dict()), ("test_lovasz_softmax_16bit_strided_and_edge_cases", dict(dtype=torch.bfloat16, n=5000)),
+    ("test_lovasz_softmax_16bit_strided_and_edge_cases", dict(dtype=torch.float16, n=56000)),
     ("test_layer_norm_affine_variants", dict(c=48, kw=dict(bias=False))), ("test_layer_norm_affine_variants", dict(c=18, kw=dict(elementwise_affine=False))),
     ("test_add_norm_fused_joint", dict(c=32, mode="ln_add_ln")), ("test_add_norm_fused_joint", dict(c=128, mode="add_ln_scaled")),
     ("test_add_norm_fused_joint", dict(c=48, mode="ln_add_ln")), ("test_add_norm_fused_joint", dict(c=432, mode="add_ln_scaled")),
