@@ -120,7 +120,7 @@ class SpUNetBase(nn.Module):
 
     def _forward(self, input_dict):
         grid_coord, feat, offset = input_dict["grid_coord"], input_dict["feat"], input_dict["offset"]
-        batch = offset2batch(offset)
+        batch = offset2batch(offset, int(feat.shape[0]))
         from . import config, ops
         from . import functional as PF
 

@@ -70,7 +70,13 @@ def offset2bincount(offset):
 
 
 @torch.no_grad()
-def offset2batch(offset):
+def offset2batch(offset, n=None):
+    """pointcept/models/utils/misc.py offset2batch.  `n` = the number of points (offset[-1]) when the caller already knows it on the host
+    (the row count of coord / feat): repeat_interleave has to fetch its output size from the device -- a host sync at the very top of the
+    step plus an 88 us kernel at 819 200 points (profiles/r05_r_bench_kernel_stats.csv, compute_cuda_kernel) -- whereas "how many scene
+    ends are <= i" is a search of B boundaries per point with nothing to wait for."""
+    if n is not None:
+        return torch.bucketize(torch.arange(int(n), device=offset.device), offset, right=True)
     bincount = offset2bincount(offset)
     return torch.arange(len(bincount), device=offset.device, dtype=torch.long).repeat_interleave(bincount)
 
@@ -88,7 +94,8 @@ class Point(_RefPoint if _RefPoint is not None else AttrDict):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         if "batch" not in self.keys() and "offset" in self.keys():
-            self["batch"] = offset2batch(self.offset)
+            rows = next((int(self[k].shape[0]) for k in ("coord", "grid_coord", "feat") if k in self.keys() and isinstance(self[k], torch.Tensor)), None)
+            self["batch"] = offset2batch(self.offset, rows)
         elif "offset" not in self.keys() and "batch" in self.keys():
             self["offset"] = batch2offset(self.batch)
 
