@@ -32,6 +32,12 @@
 #define LV_MAX_C 64
 #define LV_ONE 0x3f800000u
 #define LV_STEP_BLOCKS 4096
+#ifndef LV_XCD
+#define LV_XCD 0                            // 1: launches of LV_STEP_BLOCKS workgroups run lovasz_step one class row per XCD (timing A/B: d_LV_XCD_1).
+                                            // Measured SLOWER, 1310 vs 1220 us for the whole loss at 819200 x 20 (profiles/r05_s_lovasz_xcd_rows.txt):
+                                            // 20 rows over 8 XCDs is 3 / 2 rows per XCD, and the partial-sector write-backs it was meant to merge
+                                            // are not what bounds the kernel
+#endif
 
 // key word of one (class, point) slot: bits [1, 31) ascend as the error descends, bit 0 = the slot is foreground (its point carries this
 // class) -- below the sorted bit range, carried along by the sort
@@ -110,10 +116,32 @@ lovasz_fg_kernel(const int64_t* __restrict__ sorted_keys, int64_t total, int32_t
   if (t < total) fg[t] = (int32_t)(sorted_keys[t] & 1);
 }
 
+// one slot of lovasz_step: Jaccard step, the slot's share of the loss, the gradient w.r.t. the probability scattered back to the point
+__device__ __forceinline__ double lv_step_slot(int64_t key, int64_t src, int64_t scan_t, int64_t scan_row0, int64_t i, int64_t gts, int n_present,
+                                               float* __restrict__ gprob_row) {
+  double contrib = 0.0;
+  float g = 0.f;
+  if (gts > 0) {
+    const int f = (int)(key & 1);
+    const int64_t cum_fg = scan_t - scan_row0 + f;   // inclusive
+    const int64_t cum_bg = (i + 1) - cum_fg;
+    const double step = ptc_lovasz_step(gts, cum_fg, cum_bg, f);   // exact Jaccard difference (voxel_keys.h)
+    const float e = lv_key_error(key);
+    contrib = (double)e * step;
+    g = (float)(step / (double)n_present);
+    g = f ? -g : g;                                    // d|fg - p| / dp
+  }
+  gprob_row[src] = g;
+  return contrib;
+}
+
+// `by_xcd` (launches of 8 x G workgroups): class row r is handled by the workgroups of ONE XCD (workgroup b runs on XCD b % 8) and its three
+// input streams are loaded non-temporally -- the row's 4 N bytes of gprob, written at random positions 4 bytes at a time, then live in that
+// XCD's L2 until their 64-byte sectors are complete instead of being written back in parts from eight L2s (LV_XCD, see the host code).
 __global__ void __launch_bounds__(LV_THREADS)
 lovasz_step_kernel(const int64_t* __restrict__ sorted_keys, const int64_t* __restrict__ order,
                    const int64_t* __restrict__ fg_scan, const int32_t* __restrict__ class_count, int64_t n, int c,
-                   float* __restrict__ gprob, double* __restrict__ partial) {
+                   float* __restrict__ gprob, double* __restrict__ partial, int by_xcd) {
   __shared__ double red[LV_THREADS / 64];
   __shared__ int n_present_s;
   if (threadIdx.x == 0) {
@@ -122,28 +150,27 @@ lovasz_step_kernel(const int64_t* __restrict__ sorted_keys, const int64_t* __res
     n_present_s = np;
   }
   __syncthreads();
-  const int64_t total = n * (int64_t)c;
+  const int n_present = n_present_s;
   double contrib = 0.0;
-  // grid-stride over the slots: at most LV_STEP_BLOCKS workgroups, hence as many partial sums for lovasz_finish (one partial per 256
-  // slots -- 64000 at 819200 x 20 -- kept its single workgroup busy for 88 us; the order of the sum is fixed either way)
-  for (int64_t t = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; t < total; t += (int64_t)gridDim.x * LV_THREADS) {
-    const int row = (int)(t / n);
-    const int64_t i = t - (int64_t)row * n;
-    const int64_t src = order[t];
-    const int64_t gts = class_count[row];
-    float g = 0.f;
-    if (gts > 0) {
-      const int64_t key = sorted_keys[t];
-      const int f = (int)(key & 1);
-      const int64_t cum_fg = fg_scan[t] - fg_scan[(int64_t)row * n] + f;   // inclusive
-      const int64_t cum_bg = (i + 1) - cum_fg;
-      const double step = ptc_lovasz_step(gts, cum_fg, cum_bg, f);   // exact Jaccard difference (voxel_keys.h)
-      const float e = lv_key_error(key);
-      contrib += (double)e * step;
-      g = (float)(step / (double)n_present_s);
-      g = f ? -g : g;                                    // d|fg - p| / dp
+  if (by_xcd) {
+    const int xcd = (int)(blockIdx.x & 7), lb = (int)(blockIdx.x >> 3), per_xcd = (int)(gridDim.x >> 3);
+    for (int row = xcd; row < c; row += 8) {
+      const int64_t base = (int64_t)row * n, gts = class_count[row], scan0 = fg_scan[base];
+      for (int64_t i = (int64_t)lb * LV_THREADS + threadIdx.x; i < n; i += (int64_t)per_xcd * LV_THREADS) {
+        const int64_t t = base + i;
+        contrib += lv_step_slot(__builtin_nontemporal_load(sorted_keys + t), __builtin_nontemporal_load(order + t),
+                                __builtin_nontemporal_load(fg_scan + t), scan0, i, gts, n_present, gprob + base);
+      }
     }
-    gprob[(int64_t)row * n + src] = g;
+  } else {
+    // grid-stride over the slots: at most LV_STEP_BLOCKS workgroups, hence as many partial sums for lovasz_finish (one partial per 256
+    // slots -- 64000 at 819200 x 20 -- kept its single workgroup busy for 88 us; the order of the sum is fixed either way)
+    const int64_t total = n * (int64_t)c;
+    for (int64_t t = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; t < total; t += (int64_t)gridDim.x * LV_THREADS) {
+      const int row = (int)(t / n);
+      const int64_t base = (int64_t)row * n;
+      contrib += lv_step_slot(sorted_keys[t], order[t], fg_scan[t], fg_scan[base], t - base, class_count[row], n_present, gprob + base);
+    }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
@@ -313,7 +340,8 @@ extern "C" int ptc_lovasz_softmax(const void* logits, int64_t row_stride, const 
   PTC_CHECK_LAUNCH("lovasz_fg_kernel");
   rc = ptc_exclusive_scan_i32(fg, nc, scan, ws + L.scan_ws, L.total - L.scan_ws, stream);
   if (rc != PTC_OK) return rc;
-  hipLaunchKernelGGL(lovasz_step_kernel, dim3((unsigned)L.n_partial), dim3(LV_THREADS), 0, s, keys, order, scan, count, n, c, gprob, partial);
+  hipLaunchKernelGGL(lovasz_step_kernel, dim3((unsigned)L.n_partial), dim3(LV_THREADS), 0, s, keys, order, scan, count, n, c, gprob, partial,
+                     (LV_XCD && L.n_partial == LV_STEP_BLOCKS) ? 1 : 0);
   PTC_CHECK_LAUNCH("lovasz_step_kernel");
   hipLaunchKernelGGL(lovasz_finish_kernel, dim3(1), dim3(LV_THREADS), 0, s, partial, L.n_partial, count, c, loss);
   PTC_CHECK_LAUNCH("lovasz_finish_kernel");

@@ -65,6 +65,8 @@ def build(verbose: bool = False):
         # PTC_EMU_ASAN=1: AddressSanitizer on the kernels' GLOBAL and HEAP accesses (not their stacks: lanes run on switched stacks), to
         # be used with  LD_PRELOAD=<clang's libclang_rt.asan-x86_64.so> ASAN_OPTIONS=detect_leaks=0  (tools/emu_asan.sh)
         extra = ["-fsanitize=address", "-mllvm", "-asan-stack=0", "-g"] if os.environ.get("PTC_EMU_ASAN") == "1" else []
+        # PTC_EMU_DEFINES="LV_XCD=1,...": the emulation of a build variant (python -m pointcept_amd.build --variant d_<MACRO>_<VALUE>)
+        extra += ["-D" + m for m in os.environ.get("PTC_EMU_DEFINES", "").split(",") if m]
         procs.append((u, subprocess.Popen([CLANG, "-x", "c++", "-std=c++17", opt, "-fPIC", "-w", "-I", shim] + extra + ["-c", u, "-o", o],
                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
     errs = []
