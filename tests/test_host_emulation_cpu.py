@@ -345,6 +345,32 @@ def test_whole_ptv3_step_with_every_kernel_on_the_emulation():
         T.test_ptv3_two_scenes_forward_backward_vs_oracle(torch.device("cpu"))
 
 
+@pytest.mark.parametrize("ignore_index", [0, 5, 255])
+def test_lovasz_kernels_with_an_ignore_index_inside_and_outside_the_class_range(ignore_index):
+    """lovasz.py:149-166 drops the points labelled ignore_index whatever its value: the ScanNet configs use -1, SemanticKITTI-style label maps
+    0 or 255.  The kernels' loss and gradient against the fp64 oracle for an ignore_index that IS a class index (its points must not count
+    as foreground of that class) and for one above the range."""
+    import emu_backend
+    from oracle import losses
+    from pointcept_amd import functional as PF
+
+    if not emu_backend.available():
+        pytest.skip("no host clang++ under /opt/rocm")
+    g = torch.Generator().manual_seed(3)
+    n, c = 3000, 13
+    x = torch.randn(n, c, generator=g) * 2
+    y = torch.randint(0, c, (n,), generator=g)
+    with emu_backend.emulated_ops():
+        xe = x.clone().requires_grad_(True)
+        loss = PF.lovasz_softmax(xe, y, ignore_index)
+        loss.backward()
+    lo, do = losses.lovasz_softmax(x.numpy(), y.numpy(), ignore_index)
+    assert abs(float(loss.detach()) - lo) <= 2e-6 * abs(lo)
+    assert np.abs(xe.grad.numpy() - do).max() <= 1e-4 * np.abs(do).max()
+    if ignore_index < c:
+        assert float(xe.grad[y == ignore_index].abs().max()) == 0.0
+
+
 def test_cast_many_kernel_on_the_emulation_and_in_the_cast_cache(monkeypatch):
     """ptc_cast_many (one launch for the per-step fp32 -> 16-bit refresh of all weight shadows; the default refresh of functional._CastCache): on the
     emulation, for bf16 and f16, tensors whose sizes are not multiples of the 8-element unit and whose storage is not 16-byte
