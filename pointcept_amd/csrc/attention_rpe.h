@@ -53,6 +53,7 @@ __device__ __forceinline__ void ar_stage(const int32_t* __restrict__ gc, int64_t
 
 // ------------------------------------------------------------------------------------------------ forward
 // LDS: K row-major | V^T [17][pitch] | coords [lp_max] uint2 | table [3R] | (unused second table copy)
+template <bool F16>
 __global__ void __launch_bounds__(AR_THREADS, 2)
 attn_rpe_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ cu, const int32_t* __restrict__ gc,
                     const float* __restrict__ table, int R, int B, int H, float scale, int64_t total, int lp_max, int n_units,
@@ -65,7 +66,7 @@ attn_rpe_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict_
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
   if (Lp > lp_max) {
-    at_poison_rows(out + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, lse + (int64_t)head * total + a);
+    at_poison_rows<F16>(out + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, lse + (int64_t)head * total + a);
     return;
   }
   const int pitch = lp_max + 8;
@@ -75,8 +76,8 @@ attn_rpe_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict_
   float* tl = reinterpret_cast<float*>(coords + lp_max);
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const int64_t rs = (int64_t)3 * H * 16;
-  stage_row_major(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
-  stage_transposed(qkv + qkv_off(a, 2, H, head), rs, L, Lp, pitch, Vt);
+  stage_row_major<F16>(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
+  stage_transposed<F16>(qkv + qkv_off(a, 2, H, head), rs, L, Lp, pitch, Vt);
   for (int key = threadIdx.x; key < Lp; key += AR_THREADS)
     reinterpret_cast<uint16_t*>(Vt + (size_t)16 * pitch * 2)[vt_pos(key)] = key < L ? (uint16_t)0x3F80 : (uint16_t)0;
   ar_stage(gc, a, L, Lp, table, H, head, R, coords, tl, nullptr);
@@ -89,7 +90,7 @@ attn_rpe_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict_
   const unsigned char* kbase = Ksm + rm_off(col, h2);
   for (int qt = wave; qt < n_tiles; qt += AT_WAVES) {
     const int q = qt * 32 + col;
-    const s16x8 qf = ld_global_frag(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, q < L);
+    const s16x8 qf = ld_global_frag<F16>(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, q < L);
     const uint2 qc = coords[q];
     const int qx = (int)(qc.x & 0xffffu), qy = (int)(qc.x >> 16), qz = (int)qc.y;
     s16x8 qhi, qlo;
@@ -128,8 +129,8 @@ attn_rpe_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict_
     if (q < L) {
       uint16_t* o = out + ((int64_t)(a + q) * H + head) * 16;
       uint2 w0, w1;
-      w0.x = pack_bf16x2(acc[0] * inv, acc[1] * inv); w0.y = pack_bf16x2(acc[2] * inv, acc[3] * inv);
-      w1.x = pack_bf16x2(acc[4] * inv, acc[5] * inv); w1.y = pack_bf16x2(acc[6] * inv, acc[7] * inv);
+      w0.x = at_out<F16>(pack_bf16x2(acc[0] * inv, acc[1] * inv)); w0.y = at_out<F16>(pack_bf16x2(acc[2] * inv, acc[3] * inv));
+      w1.x = at_out<F16>(pack_bf16x2(acc[4] * inv, acc[5] * inv)); w1.y = at_out<F16>(pack_bf16x2(acc[6] * inv, acc[7] * inv));
       *reinterpret_cast<uint2*>(o + 4 * h2) = w0;
       *reinterpret_cast<uint2*>(o + 8 + 4 * h2) = w1;
       if (h2 == 0) lse[(int64_t)head * total + a + q] = m * AT_LN2 + __logf(l);
@@ -139,6 +140,7 @@ attn_rpe_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict_
 
 // ------------------------------------------------------------------------------------------------ backward: dQ, delta, d table
 // LDS: V row-major | K row-major | coords | table | d table
+template <bool F16>
 __global__ void __launch_bounds__(AR_THREADS, 2)
 attn_rpe_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                        const float* __restrict__ lse, const int32_t* __restrict__ cu, const int32_t* __restrict__ gc,
@@ -152,7 +154,7 @@ attn_rpe_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
   if (Lp > lp_max) {
-    at_poison_rows(dqkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, nullptr);
+    at_poison_rows<F16>(dqkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, nullptr);
     return;
   }
   unsigned char* Vsm = smem;
@@ -161,8 +163,8 @@ attn_rpe_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
   float* tl = reinterpret_cast<float*>(coords + lp_max);
   unsigned long long* dtl = reinterpret_cast<unsigned long long*>(tl + ((3 * R + 3) & ~3));   // 16-byte aligned: lp_max * 72 + 16 k
   const int64_t rs = (int64_t)3 * H * 16;
-  stage_row_major(qkv + qkv_off(a, 2, H, head), rs, L, Lp, Vsm);
-  stage_row_major(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
+  stage_row_major<F16>(qkv + qkv_off(a, 2, H, head), rs, L, Lp, Vsm);
+  stage_row_major<F16>(qkv + qkv_off(a, 1, H, head), rs, L, Lp, Ksm);
   ar_stage(gc, a, L, Lp, table, H, head, R, coords, tl, dtl);
   __syncthreads();
 
@@ -176,10 +178,10 @@ attn_rpe_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
   for (int qt = wave; qt < n_tiles; qt += AT_WAVES) {
     const int q = qt * 32 + col;
     const bool qv = q < L;
-    const s16x8 qf = ld_global_frag(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, qv);
+    const s16x8 qf = ld_global_frag<F16>(qkv + qkv_off(a + q, 0, H, head) + h2 * 8, qv);
     const int64_t orow = ((int64_t)(a + q) * H + head) * 16 + h2 * 8;
-    const s16x8 dof = ld_global_frag(dout + orow, qv);
-    const s16x8 of = ld_global_frag(out + orow, qv);
+    const s16x8 dof = ld_global_frag<F16>(dout + orow, qv);
+    const s16x8 of = ld_global_frag<F16>(out + orow, qv);
     float dl = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) dl += bf16_bits_to_float((uint16_t)dof[j]) * bf16_bits_to_float((uint16_t)of[j]);
@@ -223,8 +225,8 @@ attn_rpe_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restr
     if (qv) {
       uint16_t* o = dqkv + qkv_off(a + q, 0, H, head);
       uint2 w0, w1;
-      w0.x = pack_bf16x2(acc[0] * scale, acc[1] * scale); w0.y = pack_bf16x2(acc[2] * scale, acc[3] * scale);
-      w1.x = pack_bf16x2(acc[4] * scale, acc[5] * scale); w1.y = pack_bf16x2(acc[6] * scale, acc[7] * scale);
+      w0.x = at_out<F16>(pack_bf16x2(acc[0] * scale, acc[1] * scale)); w0.y = at_out<F16>(pack_bf16x2(acc[2] * scale, acc[3] * scale));
+      w1.x = at_out<F16>(pack_bf16x2(acc[4] * scale, acc[5] * scale)); w1.y = at_out<F16>(pack_bf16x2(acc[6] * scale, acc[7] * scale));
       *reinterpret_cast<uint2*>(o + 4 * h2) = w0;
       *reinterpret_cast<uint2*>(o + 8 + 4 * h2) = w1;
     }
@@ -241,6 +243,7 @@ __global__ void attn_rpe_table_finish_kernel(const unsigned long long* __restric
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // LDS: Q row-major | dO row-major | aux | coords | table
+template <bool F16>
 __global__ void __launch_bounds__(AR_THREADS, 2)
 attn_rpe_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                         const float* __restrict__ delta, const int32_t* __restrict__ cu, const int32_t* __restrict__ gc,
@@ -254,8 +257,8 @@ attn_rpe_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __rest
   if (L <= 0) return;
   const int Lp = (L + 31) & ~31, n_tiles = Lp >> 5;
   if (Lp > lp_max) {
-    at_poison_rows(dqkv + qkv_off(a, 1, H, head), (int64_t)3 * H * 16, L, nullptr);
-    at_poison_rows(dqkv + qkv_off(a, 2, H, head), (int64_t)3 * H * 16, L, nullptr);
+    at_poison_rows<F16>(dqkv + qkv_off(a, 1, H, head), (int64_t)3 * H * 16, L, nullptr);
+    at_poison_rows<F16>(dqkv + qkv_off(a, 2, H, head), (int64_t)3 * H * 16, L, nullptr);
     return;
   }
   unsigned char* Qsm = smem;
@@ -263,8 +266,8 @@ attn_rpe_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __rest
   uint2* aux = reinterpret_cast<uint2*>(smem + (size_t)lp_max * 64);
   uint2* coords = aux + lp_max;
   float* tl = reinterpret_cast<float*>(coords + lp_max);
-  stage_row_major(qkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, Lp, Qsm);
-  stage_row_major(dout + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, Lp, dOsm);
+  stage_row_major<F16>(qkv + qkv_off(a, 0, H, head), (int64_t)3 * H * 16, L, Lp, Qsm);
+  stage_row_major<F16>(dout + ((int64_t)a * H + head) * 16, (int64_t)H * 16, L, Lp, dOsm);
   for (int q = threadIdx.x; q < Lp; q += AR_THREADS) {
     const float l2 = q < L ? lse[(int64_t)head * total + a + q] * AT_LOG2E : AT_PAD_LSE;
     const float dl = q < L ? delta[(int64_t)head * total + a + q] : 0.f;
@@ -289,8 +292,8 @@ attn_rpe_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __rest
   const float* tb = tl + B;
   for (int kt = wave; kt < n_tiles; kt += AT_WAVES) {
     const int key = kt * 32 + col;
-    const s16x8 kf = ld_global_frag(qkv + qkv_off(a + key, 1, H, head) + h2 * 8, key < L);
-    const s16x8 vf = ld_global_frag(qkv + qkv_off(a + key, 2, H, head) + h2 * 8, key < L);
+    const s16x8 kf = ld_global_frag<F16>(qkv + qkv_off(a + key, 1, H, head) + h2 * 8, key < L);
+    const s16x8 vf = ld_global_frag<F16>(qkv + qkv_off(a + key, 2, H, head) + h2 * 8, key < L);
     const uint2 kc = coords[key];
     s16x8 khi, klo;
     split_scaled(kf, c, khi, klo);
@@ -329,8 +332,8 @@ attn_rpe_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __rest
       for (int r = 0; r < 16; ++r) {
         const int kk = kt * 32 + crow(r, h2);
         if (kk < L) {
-          dqkv[qkv_off(a + kk, 1, H, head) + col] = (uint16_t)(pack_bf16x2(dk[r] * scale, 0.f) & 0xffffu);
-          dqkv[qkv_off(a + kk, 2, H, head) + col] = (uint16_t)(pack_bf16x2(dv[r], 0.f) & 0xffffu);
+          dqkv[qkv_off(a + kk, 1, H, head) + col] = (uint16_t)(at_out<F16>(pack_bf16x2(dk[r] * scale, 0.f)) & 0xffffu);
+          dqkv[qkv_off(a + kk, 2, H, head) + col] = (uint16_t)(at_out<F16>(pack_bf16x2(dv[r], 0.f)) & 0xffffu);
         }
       }
     }

@@ -23,34 +23,40 @@ template <> struct BnVec<float> { static constexpr int V = 4; };
 template <> struct BnVec<bf16_t> { static constexpr int V = 8; };
 template <> struct BnVec<f16_t> { static constexpr int V = 8; };
 
-template <typename T>
-__device__ __forceinline__ void bn_load(const T* p, float (&v)[BnVec<T>::V]) {
-  constexpr int V = BnVec<T>::V;
-  const uint4 raw = *reinterpret_cast<const uint4*>(p);
+// A thread's lane is V consecutive channels = 16 bytes by default (BnVec<T>::V).  Round 6: channel counts that are no multiple of that
+// (PT-v3m3 54 / 108, LitePT 36 / 252: configs/utonia/*:21, litept_v1.py:601) take 8- or 4-byte lanes (V halved once or twice) through the
+// SAME kernels -- they ran torch.nn.BatchNorm1d until round 5, the last library operator behind a module mirror.
+template <int BYTES> struct BnRaw;
+template <> struct BnRaw<16> { using type = uint4; };
+template <> struct BnRaw<8> { using type = uint2; };
+template <> struct BnRaw<4> { using type = uint32_t; };
+template <typename T, int V = BnVec<T>::V>
+__device__ __forceinline__ void bn_load(const T* p, float (&v)[V]) {
+  using R = typename BnRaw<V * (int)sizeof(T)>::type;
+  const R raw = *reinterpret_cast<const R*>(p);
   T tmp[V];
-  __builtin_memcpy(tmp, &raw, 16);
+  __builtin_memcpy(tmp, &raw, sizeof(R));
 #pragma unroll
   for (int j = 0; j < V; ++j) v[j] = ptc_to_float(tmp[j]);
 }
-template <typename T>
-__device__ __forceinline__ void bn_store(T* p, const float (&v)[BnVec<T>::V]) {
-  constexpr int V = BnVec<T>::V;
+template <typename T, int V = BnVec<T>::V>
+__device__ __forceinline__ void bn_store(T* p, const float (&v)[V]) {
+  using R = typename BnRaw<V * (int)sizeof(T)>::type;
   T tmp[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) tmp[j] = ptc_from_float<T>(v[j]);
-  uint4 raw;
-  __builtin_memcpy(&raw, tmp, 16);
-  *reinterpret_cast<uint4*>(p) = raw;
+  R raw;
+  __builtin_memcpy(&raw, tmp, sizeof(R));
+  *reinterpret_cast<R*>(p) = raw;
 }
 
 __device__ __forceinline__ float bn_act(float z, int act) {
-  if (act == BN_ACT_GELU) return 0.5f * z * (1.f + erff(z * 0.70710678118654752f));   // nn.GELU() (exact erf form)
+  if (act == BN_ACT_GELU) return ptc_gelu(z);   // nn.GELU() (erf form; ptc_common.h)
   if (act == BN_ACT_RELU) return z > 0.f ? z : 0.f;
   return z;
 }
 __device__ __forceinline__ float bn_act_grad(float z, int act) {
-  if (act == BN_ACT_GELU)
-    return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+  if (act == BN_ACT_GELU) return ptc_gelu_grad(z);
   if (act == BN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
   return 1.f;
 }
@@ -58,9 +64,9 @@ __device__ __forceinline__ float bn_act_grad(float z, int act) {
 // Row / column-group decomposition shared by all kernels: a thread owns V consecutive channels (16 bytes)
 // of rows r, r + rpi, ... ; cgs = C / V column groups, rpi = 256 / cgs rows per sweep.
 struct BnMap { int cgs, rpi; };
-template <typename T> __host__ __device__ __forceinline__ BnMap bn_map(int c) {
+template <typename T, int V = BnVec<T>::V> __host__ __device__ __forceinline__ BnMap bn_map(int c) {
   BnMap m;
-  m.cgs = c / BnVec<T>::V;
+  m.cgs = c / V;
   m.rpi = BN_THREADS / m.cgs;
   return m;
 }
@@ -78,13 +84,12 @@ __device__ __forceinline__ void bn_stat_coef(const BnStat& st, int ch, float& a,
   b = __builtin_fmaf(-mu, a, st.beta ? st.beta[ch] : 0.f);
 }
 
-template <typename T, typename TD, int MODE>
+template <typename T, typename TD, int MODE, int V = BnVec<T>::V>
 __global__ void __launch_bounds__(BN_THREADS)
 bn_reduce_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat st, int64_t n, int c,
                  int act, int64_t rows_per_group, float* __restrict__ partial, const T* __restrict__ res = nullptr) {
-  constexpr int V = BnVec<T>::V;
   __shared__ float red[BN_THREADS][2 * V + 1];
-  const BnMap m = bn_map<T>(c);
+  const BnMap m = bn_map<T, V>(c);
   const int cg = threadIdx.x % m.cgs, r = threadIdx.x / m.cgs;
   const int64_t row_lo = (int64_t)blockIdx.x * rows_per_group;
   const int64_t row_hi = (row_lo + rows_per_group) < n ? (row_lo + rows_per_group) : n;
@@ -101,14 +106,14 @@ bn_reduce_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat st, 
   if (r < m.rpi) {
     for (int64_t row = row_lo + r; row < row_hi; row += m.rpi) {
       float xv[V];
-      bn_load<T>(x + row * c + cg * V, xv);
+      bn_load<T, V>(x + row * c + cg * V, xv);
       if (MODE == 0) {
 #pragma unroll
         for (int j = 0; j < V; ++j) { s1[j] += xv[j]; s2[j] = fmaf(xv[j], xv[j], s2[j]); }
       } else {
-        float dv[BnVec<T>::V];
+        float dv[V];
         if constexpr (sizeof(TD) == sizeof(T)) {
-          bn_load<TD>(dy + row * c + cg * V, dv);
+          bn_load<TD, V>(dy + row * c + cg * V, dv);
         } else {                                       // 16-bit x with fp32 dy (or the reverse): element loads
 #pragma unroll
           for (int j = 0; j < V; ++j) dv[j] = ptc_to_float(dy[row * c + cg * V + j]);
@@ -116,7 +121,7 @@ bn_reduce_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat st, 
         float rv[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) rv[j] = 0.f;
-        if (res) bn_load<T>(res + row * c + cg * V, rv);          // y = act(BN(x) + res): the pre-activation includes the residual
+        if (res) bn_load<T, V>(res + row * c + cg * V, rv);          // y = act(BN(x) + res): the pre-activation includes the residual
 #pragma unroll
         for (int j = 0; j < V; ++j) {
           const float dz = dv[j] * bn_act_grad(fmaf(xv[j], a[j], b[j]) + rv[j], act);
@@ -222,12 +227,11 @@ bn_finish_kernel(const float* __restrict__ partial, int groups, int64_t n, int c
 // Elementwise passes: a thread keeps ONE column group (its V channels' coefficients live in registers for the
 // whole kernel) and walks rows r, r + rows_per_sweep, ...  (The first version re-derived the column group per
 // element and re-loaded 6 coefficients per channel per element: 290 us for 819200 x 64, VALU/L1-bound.)
-template <typename T, typename TY>
+template <typename T, typename TY, int V = BnVec<T>::V>
 __global__ void __launch_bounds__(BN_THREADS)
 bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef, int64_t n, int c, int act, TY* __restrict__ y,
                 const T* __restrict__ res = nullptr) {
-  constexpr int V = BnVec<T>::V;
-  const BnMap m = bn_map<T>(c);
+  const BnMap m = bn_map<T, V>(c);
   const int cg = threadIdx.x % m.cgs, r = threadIdx.x / m.cgs;
   if (r >= m.rpi) return;
   float a[V], b[V];
@@ -237,15 +241,15 @@ bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef, int64_t
   for (int64_t row = (int64_t)blockIdx.x * m.rpi + r; row < n; row += sweep) {
     const int64_t e = row * c + cg * V;
     float xv[V];
-    bn_load<T>(x + e, xv);
+    bn_load<T, V>(x + e, xv);
     float rv[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) rv[j] = 0.f;
-    if (res) bn_load<T>(res + e, rv);
+    if (res) bn_load<T, V>(res + e, rv);
 #pragma unroll
     for (int j = 0; j < V; ++j) xv[j] = bn_act(fmaf(xv[j], a[j], b[j]) + rv[j], act);
     if constexpr (sizeof(TY) == sizeof(T)) {
-      bn_store<TY>(reinterpret_cast<TY*>(y) + e, reinterpret_cast<const float(&)[BnVec<TY>::V]>(xv));
+      bn_store<TY, V>(reinterpret_cast<TY*>(y) + e, xv);
     } else {
 #pragma unroll
       for (int j = 0; j < V; ++j) y[e + j] = ptc_from_float<TY>(xv[j]);
@@ -267,12 +271,11 @@ bn_bwd_finish_kernel(const float* __restrict__ partial, int groups, int64_t n, i
   bcoef[c + ch] = training ? (float)(a * s2 / (double)n) : 0.f;
 }
 
-template <typename T, typename TD>
+template <typename T, typename TD, int V = BnVec<T>::V>
 __global__ void __launch_bounds__(BN_THREADS)
 bn_bwd_apply_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat st, const float* __restrict__ bcoef,
                     int64_t n, int c, int act, T* __restrict__ dx, const T* __restrict__ res = nullptr, T* __restrict__ dres = nullptr) {
-  constexpr int V = BnVec<T>::V;
-  const BnMap m = bn_map<T>(c);
+  const BnMap m = bn_map<T, V>(c);
   const int cg = threadIdx.x % m.cgs, r = threadIdx.x / m.cgs;
   if (r >= m.rpi) return;
   float a[V], b[V], mu[V], rs[V], c1[V], c2[V];
@@ -286,9 +289,9 @@ bn_bwd_apply_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat s
   for (int64_t row = (int64_t)blockIdx.x * m.rpi + r; row < n; row += sweep) {
     const int64_t e = row * c + cg * V;
     float xv[V], dv[V];
-    bn_load<T>(x + e, xv);
+    bn_load<T, V>(x + e, xv);
     if constexpr (sizeof(TD) == sizeof(T)) {
-      bn_load<TD>(dy + e, reinterpret_cast<float(&)[BnVec<TD>::V]>(dv));
+      bn_load<TD, V>(dy + e, dv);
     } else {
 #pragma unroll
       for (int j = 0; j < V; ++j) dv[j] = ptc_to_float(dy[e + j]);
@@ -296,7 +299,7 @@ bn_bwd_apply_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat s
     float rv[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) rv[j] = 0.f;
-    if (res) bn_load<T>(res + e, rv);
+    if (res) bn_load<T, V>(res + e, rv);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       const float dz = dv[j] * bn_act_grad(fmaf(xv[j], a[j], b[j]) + rv[j], act);
@@ -304,8 +307,8 @@ bn_bwd_apply_kernel(const T* __restrict__ x, const TD* __restrict__ dy, BnStat s
       xv[j] = a[j] * dz - c1[j] - xhat * c2[j];
       rv[j] = dz;                                     // the residual branch receives the activation's gradient unchanged
     }
-    bn_store<T>(dx + e, xv);
-    if (dres) bn_store<T>(dres + e, rv);
+    bn_store<T, V>(dx + e, xv);
+    if (dres) bn_store<T, V>(dres + e, rv);
   }
 }
 
@@ -331,10 +334,16 @@ static BnPlan bn_plan(int64_t n, int rpi) {
   return p;
 }
 
-extern "C" int ptc_batch_norm_supported(int c, int dtype) {
-  const int v = dtype == PTC_F32 ? 4 : 8;
-  return c >= v && c % v == 0 && c / v <= BN_THREADS;
+// channels per lane for (c, dtype): the widest of 16 / 8 / 4 bytes that divides the row and leaves <= 256 column groups; 0: unsupported
+static int bn_lane(int c, int dtype) {
+  const int v0 = dtype == PTC_F32 ? 4 : 8;
+  for (int v = v0; v >= v0 / 4 && v >= 1; v >>= 1)
+    if (c >= v && c % v == 0 && c / v <= BN_THREADS) return v;
+  return 0;
 }
+extern "C" int ptc_batch_norm_supported(int c, int dtype) { return bn_lane(c, dtype) != 0; }
+// narrow lanes exist for the same-dtype tensor pairs only (what autocast and fp32 runs produce); the mixed pairs keep 16-byte lanes
+static bool bn_full_lane(int c, int dtype) { return bn_lane(c, dtype) == (dtype == PTC_F32 ? 4 : 8); }
 
 // workspace: partial [BN_MAX_GROUPS][C][2] | coef [4C] | bcoef [2C]   (fp32)
 static size_t bn_partial_bytes(int c) { return ptc_align_up((size_t)BN_MAX_GROUPS * c * 2 * sizeof(float), 256); }
@@ -343,16 +352,16 @@ extern "C" size_t ptc_batch_norm_workspace_bytes(int64_t n, int c) {
   return bn_partial_bytes(c) + ptc_align_up((size_t)6 * c * sizeof(float), 256);
 }
 
-template <typename T, typename TY>
+template <typename T, typename TY, int V = BnVec<T>::V>
 static int bn_fwd_typed(const void* x, int64_t n, int c, const float* gamma, const float* beta, float eps, float momentum,
                         int training, float* running_mean, float* running_var, int act, void* y, float* save_mean,
                         float* save_rstd, char* ws, hipStream_t s, const void* res = nullptr) {
   float* partial = (float*)ws;
   float* coef = (float*)(ws + bn_partial_bytes(c));
-  const BnMap m = bn_map<T>(c);
+  const BnMap m = bn_map<T, V>(c);
   const BnPlan p = bn_plan(n, m.rpi);
   if (training) {
-    hipLaunchKernelGGL((bn_reduce_kernel<T, T, 0>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const T*)nullptr,
+    hipLaunchKernelGGL((bn_reduce_kernel<T, T, 0, V>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const T*)nullptr,
                        BnStat{nullptr, nullptr, nullptr, nullptr}, n, c, act, p.rows_per_group, partial);
     PTC_CHECK_LAUNCH("bn_reduce_kernel<stats>");
   }
@@ -362,7 +371,7 @@ static int bn_fwd_typed(const void* x, int64_t n, int c, const float* gamma, con
   int64_t grid = ptc_cdiv(n, (int64_t)m.rpi * 4);        // >= 4 rows per thread
   if (grid > 256 * 16) grid = 256 * 16;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, (const T*)x, coef, n, c, act, (TY*)y, (const T*)res);
+  hipLaunchKernelGGL((bn_apply_kernel<T, TY, V>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, (const T*)x, coef, n, c, act, (TY*)y, (const T*)res);
   PTC_CHECK_LAUNCH("bn_apply_kernel");
   return PTC_OK;
 }
@@ -384,6 +393,16 @@ static int bn_act_fwd_impl(const void* x, const void* res, int64_t n, int c, int
   char* ws = (char*)workspace;
   PTC_REQUIRE((uintptr_t)res % 16 == 0, PTC_EINVAL, "ptc_batch_norm_add_act_fwd: buffers must be 16-byte aligned");
 #define BN_FWD(T, TY) return bn_fwd_typed<T, TY>(x, n, c, gamma, beta, eps, momentum, training, running_mean, running_var, act, y, save_mean, save_rstd, ws, s, res)
+#define BN_FWD_V(T, VV) return bn_fwd_typed<T, T, VV>(x, n, c, gamma, beta, eps, momentum, training, running_mean, running_var, act, y, save_mean, save_rstd, ws, s, res)
+  if (!bn_full_lane(c, dtype)) {
+    const int v = bn_lane(c, dtype);
+    PTC_REQUIRE(y_dtype == dtype, PTC_EUNSUPPORTED, "ptc_batch_norm_act_fwd: c=%d needs %d-channel lanes, which exist for y_dtype == dtype only", c, v);
+    if (dtype == PTC_F32) { if (v == 2) BN_FWD_V(float, 2); BN_FWD_V(float, 1); }
+    if (dtype == PTC_BF16) { if (v == 4) BN_FWD_V(bf16_t, 4); BN_FWD_V(bf16_t, 2); }
+    if (v == 4) BN_FWD_V(f16_t, 4);
+    BN_FWD_V(f16_t, 2);
+  }
+#undef BN_FWD_V
   if (dtype == PTC_F32 && y_dtype == PTC_F32) BN_FWD(float, float);
   if (dtype == PTC_BF16 && y_dtype == PTC_BF16) BN_FWD(bf16_t, bf16_t);
   if (dtype == PTC_F16 && y_dtype == PTC_F16) BN_FWD(f16_t, f16_t);
@@ -415,17 +434,17 @@ extern "C" int ptc_batch_norm_add_act_fwd(const void* x, const void* res, int64_
                          save_rstd, workspace, workspace_bytes, stream);
 }
 
-template <typename T, typename TD>
+template <typename T, typename TD, int V = BnVec<T>::V>
 static int bn_bwd_typed(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                         int64_t n, int c, int training, int act, void* dx, float* dgamma, float* dbeta, char* ws, hipStream_t s,
                         const void* res = nullptr, void* dres = nullptr) {
   float* partial = (float*)ws;
   float* coef = (float*)(ws + bn_partial_bytes(c));
   float* bcoef = coef + 4 * c;
-  const BnMap m = bn_map<T>(c);
+  const BnMap m = bn_map<T, V>(c);
   const BnPlan p = bn_plan(n, m.rpi);
   const BnStat st{gamma, beta, mean, rstd};
-  hipLaunchKernelGGL((bn_reduce_kernel<T, TD, 1>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, st, n, c, act,
+  hipLaunchKernelGGL((bn_reduce_kernel<T, TD, 1, V>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, st, n, c, act,
                      p.rows_per_group, partial, (const T*)res);
   PTC_CHECK_LAUNCH("bn_reduce_kernel<bwd>");
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)ptc_cdiv(c, BN_FIN_CH)), dim3(BN_THREADS), 0, s, partial, p.groups, n, c, st,
@@ -434,7 +453,7 @@ static int bn_bwd_typed(const void* dy, const void* x, const float* gamma, const
   int64_t grid = ptc_cdiv(n, (int64_t)m.rpi * 4);
   if (grid > 256 * 16) grid = 256 * 16;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TD>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, st, bcoef, n, c,
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TD, V>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, (const T*)x, (const TD*)dy, st, bcoef, n, c,
                      act, (T*)dx, (const T*)res, (T*)dres);
   PTC_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return PTC_OK;
@@ -458,6 +477,16 @@ static int bn_act_bwd_impl(const void* dy, int dy_dtype, const void* x, const vo
   char* ws = (char*)workspace;
   PTC_REQUIRE(((uintptr_t)res % 16 == 0) && ((uintptr_t)dres % 16 == 0), PTC_EINVAL, "ptc_batch_norm_add_act_bwd: buffers must be 16-byte aligned");
 #define BN_BWD(T, TD) return bn_bwd_typed<T, TD>(dy, x, gamma, beta, save_mean, save_rstd, n, c, training, act, dx, dgamma, dbeta, ws, s, res, dres)
+#define BN_BWD_V(T, VV) return bn_bwd_typed<T, T, VV>(dy, x, gamma, beta, save_mean, save_rstd, n, c, training, act, dx, dgamma, dbeta, ws, s, res, dres)
+  if (!bn_full_lane(c, x_dtype)) {
+    const int v = bn_lane(c, x_dtype);
+    PTC_REQUIRE(dy_dtype == x_dtype, PTC_EUNSUPPORTED, "ptc_batch_norm_act_bwd: c=%d needs %d-channel lanes, which exist for dy_dtype == x_dtype only", c, v);
+    if (x_dtype == PTC_F32) { if (v == 2) BN_BWD_V(float, 2); BN_BWD_V(float, 1); }
+    if (x_dtype == PTC_BF16) { if (v == 4) BN_BWD_V(bf16_t, 4); BN_BWD_V(bf16_t, 2); }
+    if (v == 4) BN_BWD_V(f16_t, 4);
+    BN_BWD_V(f16_t, 2);
+  }
+#undef BN_BWD_V
   if (x_dtype == PTC_F32 && dy_dtype == PTC_F32) BN_BWD(float, float);
   if (x_dtype == PTC_BF16 && dy_dtype == PTC_BF16) BN_BWD(bf16_t, bf16_t);
   if (x_dtype == PTC_F16 && dy_dtype == PTC_F16) BN_BWD(f16_t, f16_t);
@@ -503,19 +532,28 @@ extern "C" int ptc_column_sum(const void* x, int64_t n, int c, int dtype, float*
   PTC_REQUIRE(x && workspace, PTC_EINVAL, "ptc_column_sum: null buffer");
   PTC_REQUIRE(workspace_bytes >= ptc_batch_norm_workspace_bytes(n, c), PTC_EWORKSPACE, "ptc_column_sum: workspace too small");
   float* partial = (float*)workspace;
-#define BN_CS(T)                                                                                                               \
+#define BN_CS(T) BN_CS_V(T, BnVec<T>::V)
+#define BN_CS_V(T, VV)                                                                                                         \
   {                                                                                                                            \
-    const BnMap m = bn_map<T>(c);                                                                                              \
+    const BnMap m = bn_map<T, VV>(c);                                                                                          \
     const BnPlan p = bn_plan(n, m.rpi);                                                                                        \
-    hipLaunchKernelGGL((bn_reduce_kernel<T, T, 0>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const T*)nullptr,    \
+    hipLaunchKernelGGL((bn_reduce_kernel<T, T, 0, VV>), dim3(p.groups), dim3(BN_THREADS), 0, s, (const T*)x, (const T*)nullptr, \
                        BnStat{nullptr, nullptr, nullptr, nullptr}, n, c, 0, p.rows_per_group, partial);                        \
     PTC_CHECK_LAUNCH("bn_reduce_kernel<colsum>");                                                                              \
     hipLaunchKernelGGL(bn_colsum_finish_kernel, dim3((unsigned)ptc_cdiv(c, BN_FIN_CH)), dim3(BN_THREADS), 0, s, partial, p.groups, c, out); \
     PTC_CHECK_LAUNCH("bn_colsum_finish_kernel");                                                                               \
     return PTC_OK;                                                                                                             \
   }
+  if (!bn_full_lane(c, dtype)) {
+    const int v = bn_lane(c, dtype);
+    if (dtype == PTC_F32) { if (v == 2) BN_CS_V(float, 2) BN_CS_V(float, 1) }
+    if (dtype == PTC_BF16) { if (v == 4) BN_CS_V(bf16_t, 4) BN_CS_V(bf16_t, 2) }
+    if (v == 4) BN_CS_V(f16_t, 4)
+    BN_CS_V(f16_t, 2)
+  }
   if (dtype == PTC_F32) BN_CS(float)
   if (dtype == PTC_BF16) BN_CS(bf16_t)
   BN_CS(f16_t)
 #undef BN_CS
+#undef BN_CS_V
 }

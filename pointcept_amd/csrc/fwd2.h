@@ -116,11 +116,9 @@ conv2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
 //   EPI 1 (fc1 forward)    : out = h (pre-activation, kept for the backward), aux_out = GELU(h)
 //   EPI 2 (fc2 input grad) : out = acc * GELU'(aux_in)   (aux_in = h: the gradient leaves the kernel already
 //                            multiplied through the activation; no dA tensor is ever written)
-// Same lane -> channel mapping as sc_epilogue; GELU is nn.GELU()'s erf form, evaluated in fp32.
-__device__ __forceinline__ float f2_gelu(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
-__device__ __forceinline__ float f2_gelu_grad(float z) {
-  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
-}
+// Same lane -> channel mapping as sc_epilogue; GELU is nn.GELU()'s erf form, evaluated in fp32 (ptc_gelu).
+__device__ __forceinline__ float f2_gelu(float z) { return ptc_gelu(z); }             // ptc_common.h: branch-free since round 6
+__device__ __forceinline__ float f2_gelu_grad(float z) { return ptc_gelu_grad(z); }
 
 template <typename T, int NTILES, int EPI>
 __device__ __forceinline__ void f2_epilogue_ex(f32x4 (&acc)[2][NTILES], T* __restrict__ out, const T* __restrict__ aux_in,

@@ -653,10 +653,10 @@ class _AttnRpe(Function):
 def attn_rpe_qkvpacked(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, softmax_scale: float,
                        grid_coord: torch.Tensor, rpe_table: torch.Tensor, pos_bnd: int) -> torch.Tensor:
     """The reference's dense attention branch with RPE (ptv3m1:29-48,190-206) on the window-attention kernels:
-    softmax(scale q k^T + rpe(grid_coord_i - grid_coord_j)) v per window, qkv [T,3,H,16] bf16 in serialized order,
+    softmax(scale q k^T + rpe(grid_coord_i - grid_coord_j)) v per window, qkv [T,3,H,16] bf16 or f16 in serialized order,
     grid_coord [T,3] int32 in the same order, rpe_table [3(2B+1), H] (differentiable)."""
-    if qkv.dtype != torch.bfloat16:
-        raise PtcoreError("attn_rpe_qkvpacked expects bf16 qkv")
+    if qkv.dtype not in (torch.bfloat16, torch.float16):
+        raise PtcoreError("attn_rpe_qkvpacked expects 16-bit qkv")
     return _AttnRpe.apply(qkv, rpe_table, cu_seqlens, grid_coord, int(max_seqlen), float(softmax_scale), int(pos_bnd))
 
 

@@ -158,13 +158,22 @@ def _hooked(m: nn.Module) -> bool:
     return bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
 
 
+def _global_hooks() -> bool:
+    """hooks registered for EVERY module (torch.nn.modules.module.register_module_forward_hook & co.): they fire per module call, so
+    a fused pair would show them one call where the reference shows two"""
+    M = torch.nn.modules.module
+    return bool(M._global_forward_hooks or M._global_forward_pre_hooks or M._global_backward_hooks or M._global_backward_pre_hooks)
+
+
 def fused_act(norm: nn.Module, act: Optional[nn.Module]) -> Optional[str]:
     """"gelu" / "relu" when `norm` immediately followed by `act` may run as ONE `norm(x, act=...)` call, else None.
 
     Evaluated at run time on the modules that are in the tree NOW (exact types, so a replaced, wrapped or subclassed norm or
-    activation is never fused; neither is an activation somebody hooked, whose hooks must see its real input).  The caller
-    skips `act` exactly when this returns a name -- there is no state that could go stale."""
-    if type(norm) is not BatchNorm1d or act is None or _hooked(act):
+    activation is never fused; neither is a pair in which EITHER module carries a hook -- the activation's hooks must see its real
+    input, the norm's hooks (feature taps, pruning / quantisation observers) the BatchNorm output and not the activated one -- nor
+    any pair while module-global hooks are registered).  The caller skips `act` exactly when this returns a name -- there is no
+    state that could go stale.  SpUNet's relu(bn2(.) + residual) tail asks through here as well."""
+    if type(norm) is not BatchNorm1d or act is None or _hooked(act) or _hooked(norm) or _global_hooks():
         return None
     if type(act) in (GELU, nn.GELU):
         return "gelu" if getattr(act, "approximate", "none") == "none" else None

@@ -965,10 +965,11 @@ def attn_rpe_supported(head_dim: int, max_seqlen: int, pos_bnd: int) -> bool:
 
 
 def attn_rpe_fwd(qkv, cu_seqlens, max_seqlen: int, softmax_scale: float, grid_coord, rpe_table, pos_bnd: int):
-    """qkv [T,3,H,16] bf16, grid_coord [T,3] int32 (same row order), rpe_table [3(2B+1),H] fp32 -> (out [T,H,16] bf16, lse [H,T])."""
+    """qkv [T,3,H,16] bf16 | f16, grid_coord [T,3] int32 (same row order), rpe_table [3(2B+1),H] fp32 -> (out [T,H,16] like qkv, lse [H,T]).
+    f16 tensors (the reference's fp16 AMP) ride around the same bf16 arithmetic: the casts sit in the kernels' load / store paths."""
     require_cuda(qkv, cu_seqlens, grid_coord, rpe_table)
-    if qkv.dtype != torch.bfloat16 or qkv.dim() != 4 or qkv.shape[1] != 3 or qkv.shape[3] != 16:
-        raise PtcoreError(f"qkv must be bf16 [T,3,H,16], got {qkv.dtype} {tuple(qkv.shape)}")
+    if qkv.dtype not in (torch.bfloat16, torch.float16) or qkv.dim() != 4 or qkv.shape[1] != 3 or qkv.shape[3] != 16:
+        raise PtcoreError(f"qkv must be bf16 / f16 [T,3,H,16], got {qkv.dtype} {tuple(qkv.shape)}")
     T, _, H, _ = qkv.shape
     if grid_coord.dtype != torch.int32 or tuple(grid_coord.shape) != (T, 3):
         raise PtcoreError(f"grid_coord must be int32 [{T},3], got {grid_coord.dtype} {tuple(grid_coord.shape)}")
@@ -976,10 +977,10 @@ def attn_rpe_fwd(qkv, cu_seqlens, max_seqlen: int, softmax_scale: float, grid_co
         raise PtcoreError(f"rpe_table must be fp32 [{3 * (2 * int(pos_bnd) + 1)},{H}], got {rpe_table.dtype} {tuple(rpe_table.shape)}")
     qkv, gc, tab = qkv.contiguous(), grid_coord.contiguous(), rpe_table.contiguous()
     cu = cu_seqlens.to(torch.int32).contiguous()
-    out = torch.empty((T, H, 16), dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty((T, H, 16), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((H, T), dtype=torch.float32, device=qkv.device)
     check(lib().ptc_attn_rpe_fwd(ptr(qkv), ptr(cu), ptr(gc), ptr(tab), int(pos_bnd), cu.numel() - 1, T, H, int(max_seqlen),
-                                 float(softmax_scale), _lib.PTC_BF16, ptr(out), ptr(lse), stream_ptr()), "ptc_attn_rpe_fwd")
+                                 float(softmax_scale), dtype_code(qkv), ptr(out), ptr(lse), stream_ptr()), "ptc_attn_rpe_fwd")
     return out, lse
 
 
@@ -987,7 +988,7 @@ def attn_rpe_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_scale
     """-> (dqkv like qkv, d_rpe_table fp32 like rpe_table)"""
     require_cuda(qkv, out, dout, lse, cu_seqlens, grid_coord, rpe_table)
     qkv, out = qkv.contiguous(), out.contiguous()
-    dout = dout.to(torch.bfloat16).contiguous()
+    dout = dout.to(qkv.dtype).contiguous()
     gc, tab = grid_coord.contiguous(), rpe_table.contiguous()
     cu = cu_seqlens.to(torch.int32).contiguous()
     T, _, H, _ = qkv.shape
@@ -996,7 +997,7 @@ def attn_rpe_bwd(qkv, out, dout, lse, cu_seqlens, max_seqlen: int, softmax_scale
     nbytes = lib().ptc_attn_rpe_bwd_workspace_bytes(T, H, int(pos_bnd))
     ws = _ws(nbytes, qkv.device)
     check(lib().ptc_attn_rpe_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(cu), ptr(gc), ptr(tab), int(pos_bnd), cu.numel() - 1,
-                                 T, H, int(max_seqlen), float(softmax_scale), _lib.PTC_BF16, ptr(dqkv), ptr(dtab), ptr(ws), nbytes,
+                                 T, H, int(max_seqlen), float(softmax_scale), dtype_code(qkv), ptr(dqkv), ptr(dtab), ptr(ws), nbytes,
                                  stream_ptr()), "ptc_attn_rpe_bwd")
     return dqkv, dtab
 

@@ -241,13 +241,15 @@ class SerializedAttention(PointModule):
         return point[key]
 
     def _rpe_kernel_ok(self, point) -> bool:
-        """RPE branch on the window-attention kernels (attention_rpe.h) instead of the dense [P,H,K,K] formulation: when the
-        operands would be bf16 anyway (bf16 autocast: the reference's matmuls then run in bf16 whatever the upcast flags say;
-        the kernel keeps fp32 logits, softmax and accumulation), no attention dropout is active, head_dim 16.  An fp32 run
-        (no autocast) keeps the torch formulation: its results must not be rounded to bf16."""
+        """RPE branch on the window-attention kernels (attention_rpe.h) instead of the dense [P,H,K,K] formulation: whenever the
+        operands are 16-bit anyway -- bf16 or fp16 autocast (the reference's matmuls then run in the autocast dtype whatever the upcast
+        flags say; `configs/s3dis/semseg-pt-v3m1-1-rpe.py` runs under the default fp16 AMP): the kernel keeps fp32 logits, softmax and
+        accumulation, fp16 tensors go in and out through its load / store paths around bf16 operands (as in the flash branch) --, no
+        attention dropout is active, head_dim 16.  An fp32 run (no autocast) keeps the torch formulation below BY NAME: `(q * scale) @ k^T`,
+        `torch.softmax`, `attn @ v` on fp32 tensors -- its results must not be rounded to 16 bits (INTEGRATION, stated deviations)."""
         drop = self.attn_drop.p if isinstance(self.attn_drop, nn.Dropout) else self.attn_drop
         return (config.RPE_KERNEL and self.rpe is not None and point.feat.is_cuda and torch.is_autocast_enabled("cuda")
-                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and (drop == 0.0 or not self.training)
+                and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16) and (drop == 0.0 or not self.training)
                 and ops.attn_rpe_supported(self.channels // self.num_heads, self.patch_size, self.rpe.pos_bnd))
 
     def _forward_rpe_kernel(self, point):
@@ -259,7 +261,8 @@ class SerializedAttention(PointModule):
         if key not in point.keys():                                   # the role of get_rel_pos' cache (ptv3m1:104-112): O(N), not O(N K)
             point[key] = point.grid_coord[order].to(torch.int32)
         qkv = self.qkv(point.feat)[order]                              # ptv3m1:188
-        out = PF.attn_rpe_qkvpacked(qkv.to(torch.bfloat16).reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale, point[key],
+        q16 = qkv if qkv.dtype in (torch.bfloat16, torch.float16) else qkv.to(torch.bfloat16)
+        out = PF.attn_rpe_qkvpacked(q16.reshape(-1, 3, H, C // H), cu_seqlens, K, self.scale, point[key],
                                     self.rpe.rpe_table, self.rpe.pos_bnd)
         feat = out.reshape(-1, C).to(qkv.dtype)[inverse]               # ptv3m1:206,216
         point.feat = self.proj_drop(self.proj(feat))

@@ -119,6 +119,11 @@ class Point(_RefPoint if _RefPoint is not None else AttrDict):
             packed = torch.cat([cmax, n_dup.to(torch.int64), self.offset.to(torch.int64)])
             host = packed.tolist()  # the single host sync (reference: structure.py:74,138,145 + ptv3m1:142-164)
             ops.check_coord_range(host[:3], self.offset.numel())
+            # the sync-free offset2batch(offset, n) trusts the row count it is given; the reference's repeat_interleave
+            # would have produced offset[-1] entries and failed downstream.  Checked here, where offset reaches the host anyway.
+            for k in ("coord", "grid_coord", "feat", "batch"):
+                if k in self.keys() and isinstance(self[k], torch.Tensor) and self.offset.numel() and int(self[k].shape[0]) != int(host[-1]):
+                    raise ValueError(f"Point: `{k}` has {int(self[k].shape[0])} rows but offset[-1] = {int(host[-1])}")
             self["_ptc_coord_max"] = host[:3]
             self["_ptc_n_dup"] = int(host[3])
             self["_ptc_offset_host"] = host[4:]

@@ -443,7 +443,13 @@ def test_spunet_base_two_full_scenes_train_step_vs_oracle(cuda):
     network by tens of per cent at the deep stages whoever does the rounding (measured 28-53 % for bf16 at enc / down, on the MI355X
     kernels and on plain torch CPU autocast alike, profiles/r05_b_fullsize_spunet_step.txt).  The 16-bit gradients are therefore
     judged against an envelope: the SAME engine in fp32 with each module output / gradient rounded to the autocast dtype
-    (_autocast_rounding_twin) deviates from the fp32 oracle by e(stage); the 16-bit kernels must stay inside 1.5 e(stage) + 2e-2."""
+    (_autocast_rounding_twin) deviates from the fp32 oracle by e(stage); the 16-bit kernels must stay inside 1.1 e(stage) + 5e-3 (round 6,
+    VERDICT r5 weak 2: the two columns agreed to 2-3 % of themselves in every session of round 5; the old 1.5 e + 2e-2 would have let an
+    80 % gradient error pass at the deep stages).  Is the 28-53 % the DATA (labels U{0..19}: every class gradient a sum of cancelling
+    terms)?  No: with structured labels -- segment = f(0.5 m cell of the voxel), PTC_TEST_STRUCTURED_LABELS=1 -- the same run gives
+    23-57 % for bf16 and 9-20 % for fp16 at the same stages, kernels and envelope again within a few per cent of each other
+    (profiles/r06_b_fullsize_spunet_step_structured_labels.txt; the fp32 leg there sits at 1.2e-2 instead of 5e-3).  It is the network:
+    44 convolutions with batch-statistics BatchNorm amplify every rounding of an intermediate tensor, whoever rounds."""
     from oracle import ptv3_model as om
     from oracle import spunet_model as osp
     from pointcept_amd import functional as PF
@@ -453,6 +459,9 @@ def test_spunet_base_two_full_scenes_train_step_vs_oracle(cuda):
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     on_gpu = torch.device(cuda).type == "cuda"
     batch = synthetic.collate([synthetic.indoor_scene(61, _n(100000)), synthetic.indoor_scene(62, _n(100000))])
+    if os.environ.get("PTC_TEST_STRUCTURED_LABELS") == "1":             # the one-off run VERDICT r5 weak 2 asked for (see the docstring)
+        cell = batch["grid_coord"] // 25                               # 0.5 m cells at the 0.02 m grid
+        batch["segment"] = np.where(batch["segment"] >= 0, (cell[:, 0] + 3 * cell[:, 1] + 7 * cell[:, 2]) % 20, -1).astype(np.int64)
     kw = dict(channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2))
     torch.manual_seed(0)
     orc, eng = osp.SpUNetBase(6, 20, **kw), SpUNetBase(6, 20, **kw)
@@ -501,7 +510,7 @@ def test_spunet_base_two_full_scenes_train_step_vs_oracle(cuda):
             lines.append("   stage        16-bit kernels vs fp32 oracle   fp32 kernels + autocast roundings vs fp32 oracle")
             lines += [f"   {k:12s} {v:.3e}                       {env[k]:.3e}" for k, v in stages.items()]
             ok = (l_rel < 2e-3 and _rel_max(logits, logits_o) < 8e-2 and _rel_fro(logits, logits_o) < 3e-2 and agree > 0.97
-                  and all(stages[k] <= 1.5 * env[k] + 2e-2 for k in stages))
+                  and all(stages[k] <= 1.1 * env[k] + 5e-3 for k in stages))
         lines += [f"   worst {r:.3e} (|g| {n_:.3e}) {name}" for r, n_, name in worst[:3]]
         if not ok:
             failures.append(lines[-(len(stages) + 5):])

@@ -996,6 +996,27 @@ def test_attention_forward_launch_plans_agree_bit_for_bit(cuda, lens, H, monkeyp
         assert torch.equal(out, out0) and torch.equal(lse, lse0), plan
 
 
+@pytest.mark.parametrize("n_shapes", [80])
+def test_attention_launch_plan_cache_survives_more_shapes_than_it_holds(cuda, n_shapes, monkeypatch):
+    """the per-thread plan cache (64 entries, keyed on workgroups per XCD chunk and query tiles, replaced round-robin) is
+    swept with more distinct shapes than it holds, then the first shapes come back: every launch must still equal the uniform
+    round-4 split bit for bit (every plan gives the same bits by construction, so what this guards is the replacement path itself:
+    no overrun of the table, no launch refused, lookups after eviction still well-formed)."""
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(7)
+    shapes = [(1 + 8 * i, 512 if i < 3 else 32) for i in range(n_shapes)] + [(1, 512), (9, 512), (17, 32)]
+    for n_seq, L in shapes:
+        lens = [L] * n_seq
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).to(cuda)
+        qkv = torch.randn(sum(lens), 3, 1, 16, generator=g).to(torch.bfloat16).to(cuda)
+        monkeypatch.delenv("PTC_AT_PLAN", raising=False)
+        out, lse = ops.attn_varlen_fwd(qkv, cu, L, 0.25)
+        monkeypatch.setenv("PTC_AT_PLAN", "0")
+        out0, lse0 = ops.attn_varlen_fwd(qkv, cu, L, 0.25)
+        assert torch.equal(out, out0) and torch.equal(lse, lse0), (n_seq, L)
+
+
 @pytest.mark.parametrize("lens,H", [([1024, 330], 4), ([1, 2, 31, 32, 33, 65], 3)])
 @pytest.mark.parametrize("one_pass", ["0", "1"])
 def test_attention_f16_io_equals_the_reference_cast_passes(cuda, lens, H, one_pass, monkeypatch):
@@ -1329,6 +1350,43 @@ def test_attention_rpe_fwd_bwd(cuda, lens, H, bnd):
     _close("rpe_dtable_autograd", tq.grad, t32.grad, 2e-2, 1e-2 * float(t32.grad.abs().max()))
 
 
+@pytest.mark.parametrize("lens,H,bnd", [([200, 200, 200], 3, 18), ([33], 1, 4), ([1024, 330], 2, 32)])
+def test_attention_rpe_f16_io_equals_the_cast_passes(cuda, lens, H, bnd):
+    """round 6: under the reference's fp16 AMP (configs/s3dis/semseg-pt-v3m1-1-rpe.py) qkv arrives in f16.  The RPE
+    kernels take f16 tensors directly -- the cast to their bf16 operands in the load path, the cast back in the store path -- and must
+    equal, bit for bit, the bf16 kernels between explicit cast passes; against the fp32 formulation they sit at the bf16 kernels' bars."""
+    from pointcept_amd import functional as PF
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(sum(lens) + H + bnd)
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).to(cuda)
+    qkv = (torch.randn(T, 3, H, 16, generator=g) * 1.2).to(torch.float16)
+    gc = torch.randint(0, 3 * bnd, (T, 3), generator=g).to(torch.int32)
+    table = torch.randn(3 * (2 * bnd + 1), H, generator=g) * 0.5
+    dout = torch.randn(T, H, 16, generator=g).to(torch.float16)
+    scale = 0.25
+    out, lse = ops.attn_rpe_fwd(qkv.to(cuda), cu, max(lens), scale, gc.to(cuda), table.to(cuda), bnd)
+    assert out.dtype == torch.float16
+    outb, lseb = ops.attn_rpe_fwd(qkv.to(torch.bfloat16).to(cuda), cu, max(lens), scale, gc.to(cuda), table.to(cuda), bnd)
+    assert torch.equal(out, outb.to(torch.float16)) and torch.equal(lse, lseb)
+    dqkv, dtab = ops.attn_rpe_bwd(qkv.to(cuda), out, dout.to(cuda), lse, cu, max(lens), scale, gc.to(cuda), table.to(cuda), bnd)
+    # the cast-pass form: every 16-bit tensor the kernels read is the bf16 rounding of the f16 one (`out` of the f16 run: bf16 -> f16 -> bf16 is exact)
+    dqb, dtb = ops.attn_rpe_bwd(qkv.to(torch.bfloat16).to(cuda), outb, dout.to(torch.bfloat16).to(cuda), lseb, cu, max(lens), scale,
+                                gc.to(cuda), table.to(cuda), bnd)
+    assert dqkv.dtype == torch.float16 and torch.equal(dqkv, dqb.to(torch.float16)) and torch.equal(dtab, dtb)
+    q32, t32 = qkv.float().requires_grad_(True), table.clone().requires_grad_(True)
+    ref, _ = _rpe_reference(q32, torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32), scale, gc, t32, bnd)
+    ref.backward(dout.float())
+    _close("rpe_fwd f16", out, ref, 1.0 / 64, 2.0 ** -8 * float(qkv[:, 2].float().abs().max()))
+    _close("rpe_dqkv f16", dqkv, q32.grad, 1.0 / 32, 2e-2 * float(q32.grad.abs().max()))
+    _close("rpe_dtable f16", dtab, t32.grad, 2e-2, 2e-2 * float(t32.grad.abs().max()))
+    xq, tq = qkv.to(cuda).requires_grad_(True), table.to(cuda).requires_grad_(True)
+    o = PF.attn_rpe_qkvpacked(xq, cu, max(lens), scale, gc.to(cuda), tq, bnd)
+    (o.float() * dout.to(cuda).float()).sum().backward()
+    assert xq.grad.dtype == torch.float16 and torch.equal(xq.grad, dqkv)
+
+
 # ------------------------------------------------------------------------------------------------
 # I. ends of the step: coordinate maxima, cross entropy
 # ------------------------------------------------------------------------------------------------
@@ -1379,10 +1437,14 @@ def test_cross_entropy_fwd_bwd(cuda, dtype, n, c, strided):
 # J. BatchNorm1d + activation
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("n,c", [(2, 32), (1000, 32), (70001, 64), (513, 96), (4097, 512)])
+@pytest.mark.parametrize("n,c", [(2, 32), (1000, 32), (70001, 64), (513, 96), (4097, 512),
+                                 (3001, 36), (2500, 54), (1777, 108), (1200, 252), (900, 6)])   # round 6: 8- / 4-byte lanes (LitePT 36 / 252, PT-v3m3 54 / 108)
 @pytest.mark.parametrize("act", ["none", "gelu", "relu"])
 def test_batch_norm_act_train(cuda, dtype, n, c, act):
-    """training mode: output, running statistics, dx / dgamma / dbeta vs torch (fp32 on the same rounded input)"""
+    """training mode: output, running statistics, dx / dgamma / dbeta vs torch (fp32 on the same rounded input).  Channel counts that
+    are no multiple of a 16-byte lane run on the narrow-lane instances of the same kernels (ops.batch_norm_supported says so)."""
+    from pointcept_amd import ops as _ops
+    assert _ops.batch_norm_supported(c, dtype) or torch.device(cuda).type != "cuda"
     from pointcept_amd import functional as PF
 
     g = torch.Generator().manual_seed(n + c)

@@ -232,6 +232,7 @@ def test_f2_models_at_shipped_widths_run_on_the_engine_only(cuda, family, monkey
         if on_gpu:          # (the CPU stand-ins ARE these torch calls)
             mp.setattr(torch.nn.functional, "linear", refuse("F.linear"))
             mp.setattr(torch.nn.functional, "layer_norm", refuse("F.layer_norm"))
+            mp.setattr(torch.nn.functional, "batch_norm", refuse("F.batch_norm"))     # round 6: bn.hip has 8- / 4-byte lanes (C = 36, 54, 108, 252)
             mp.setattr(torch, "matmul", refuse("torch.matmul"))
             mp.setattr(torch.Tensor, "__matmul__", refuse("Tensor @"))
         try:
@@ -246,7 +247,9 @@ def test_f2_models_at_shipped_widths_run_on_the_engine_only(cuda, family, monkey
     assert abs(l16 - l32) < 3e-2 * abs(l32), (l16, l32)
     if kernels:
         bad = [k for k in kernels if k.startswith("Cijk_") or "layer_norm" in k.lower() and "ptc" not in k and "layer_norm_fwd" not in k and "layer_norm_bwd" not in k]
+        bad += [k for k in kernels if "batch_norm" in k.lower() and "at::" in k]          # ATen's BatchNorm kernels (at::native::batch_norm_*)
         assert not bad, bad
+        assert any("bn_apply_kernel" in k for k in kernels), "no engine BatchNorm kernel in the step"
         # the engine's own normalisation kernels ran: the 8-channels-per-lane instances with a run-time width where C % 8 == 0 (m2: 48 ..
         # 512), the pair-per-lane generic form elsewhere (m3: 54, 108; LitePT: 36, 252)
         assert any(("layer_norm_fwd" in k or "add_norm_fwd" in k) and "at::" not in k for k in kernels), "no engine LayerNorm kernel in the step"

@@ -416,8 +416,10 @@ def test_ptv3_pdnorm_ppt_configuration_matches_reference_golden(cuda):
                 assert abs(float(p.grad.double().norm()) - ref) <= 3e-2 * ref, (name, float(p.grad.norm()), ref)
 
 
-def test_ptv3_rpe_branch_on_the_kernels_under_bf16_autocast(cuda, monkeypatch):
-    """A13 under bf16 autocast: the RPE branch runs on the window-attention kernels (attention_rpe.h).  Same model, same
+@pytest.mark.parametrize("amp", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_ptv3_rpe_branch_on_the_kernels_under_autocast(cuda, monkeypatch, amp):
+    """A13 under bf16 AND fp16 autocast (the latter is what configs/s3dis/semseg-pt-v3m1-1-rpe.py runs: `_base_/default_runtime.py`
+    amp_dtype float16): the RPE branch runs on the window-attention kernels (attention_rpe.h).  Same model, same
     batch, same seeds with the kernels and with the dense torch formulation (PTC_RPE_KERNEL=0 semantics via config): features,
     loss and every gradient (the RPE tables included) agree to bf16 accuracy; both against the fp32 oracle."""
     from pointcept_amd import config, synthetic
@@ -440,11 +442,11 @@ def test_ptv3_rpe_branch_on_the_kernels_under_bf16_autocast(cuda, monkeypatch):
         monkeypatch.setattr(config, "RPE_KERNEL", on)
         eng.zero_grad(set_to_none=True)
         torch.manual_seed(6)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=amp):
             feat = eng(synthetic.to_torch(batch, cuda)).feat
         loss = feat.float().pow(2).mean()
-        loss.backward()
-        res[tag] = (feat.detach().float().cpu(), float(loss), {k: p.grad.detach().float().cpu().clone() for k, p in eng.named_parameters()})
+        (loss * 256.0).backward()              # a GradScaler-like factor: fp16 gradients of this tiny model underflow without one
+        res[tag] = (feat.detach().float().cpu(), float(loss), {k: p.grad.detach().float().cpu().clone() / 256.0 for k, p in eng.named_parameters()})
     n_rpe_blocks = sum(1 for mod in eng.modules() if isinstance(mod, m.SerializedAttention))
     assert calls["n"] == n_rpe_blocks, (calls, n_rpe_blocks)           # every attention of the kernel run went through the kernels
     fk, fd = res["kernel"][0], res["dense"][0]
@@ -461,7 +463,9 @@ def test_ptv3_rpe_branch_on_the_kernels_under_bf16_autocast(cuda, monkeypatch):
         if float(r.norm()) > 1e-6:
             ek = float((res["kernel"][2][name] - r).norm() / r.norm())
             ed = float((res["dense"][2][name] - r).norm() / r.norm())
-            assert ek <= max(2.0 * ed, 0.0) + 3e-2, (name, ek, ed)      # no worse than the bf16 torch formulation (+3 %)
+            # bf16: no worse than the bf16 torch formulation (+3 %).  fp16: the kernels keep bf16 OPERANDS between their f16 load / store
+            # paths (8 mantissa bits against the 11 of torch's fp16 matmuls: rounding noise up to 8 x), as the flash branch does
+            assert ek <= (2.0 if amp == torch.bfloat16 else 8.0) * ed + 3e-2, (name, ek, ed)
     assert float(res["kernel"][2]["dec.dec0.block0.attn.rpe.rpe_table"].abs().max()) > 0
 
 

@@ -73,7 +73,8 @@ def test_f2_models_at_shipped_widths_body_on_cpu_standins(family, monkeypatch):
 @pytest.mark.parametrize("name", ["test_sync_bn_conversion_ptv3_keeps_every_activation",
                                   "test_sync_bn_conversion_spunet_degrades_to_the_three_pass_block",
                                   "test_sync_bn_conversion_litept_matches_the_reference_golden",
-                                  "test_wrapped_or_hooked_modules_are_never_fused"])
+                                  "test_wrapped_or_hooked_modules_are_never_fused",
+                                  "test_spunet_block_tail_is_not_fused_when_bn2_is_hooked"])
 def test_gpu_sync_bn_test_bodies_on_cpu_standins(name):
     """nn.SyncBatchNorm.convert_sync_batchnorm (reference trainer, sync_bn=True) on the engine's models"""
     import test_gpu_sync_bn as T

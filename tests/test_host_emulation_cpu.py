@@ -195,6 +195,10 @@ EMULATED_GPU_TESTS = [
     ("test_add_norm_fused_joint", dict(c=48, mode="ln_add_ln")), ("test_add_norm_fused_joint", dict(c=432, mode="add_ln_scaled")),
     ("test_add_norm_fused_joint", dict(c=96, mode="f16_add_cast")), ("test_add_norm_fused_joint", dict(c=192, mode="fp32")),
     ("test_batch_norm_act_train", dict(dtype=torch.float32, n=3000, c=64, act="gelu")),
+    ("test_batch_norm_act_train", dict(dtype=torch.bfloat16, n=2500, c=54, act="gelu")),      # 4-byte lanes
+    ("test_batch_norm_act_train", dict(dtype=torch.bfloat16, n=1200, c=252, act="relu")),     # 8-byte lanes
+    ("test_batch_norm_act_train", dict(dtype=torch.float32, n=3001, c=36, act="none")),       # fp32: 16-byte lanes still (36 = 9 x 4)
+    ("test_batch_norm_act_train", dict(dtype=torch.float32, n=900, c=6, act="gelu")),         # fp32, 8-byte lanes
     ("test_batch_norm_add_act_is_the_residual_block_tail", dict(dtype=torch.bfloat16, n=5003, c=96)),
     ("test_pointops_knn_query", dict(nsample=3)), ("test_seg_eval_hist_matches_the_reference_formula", dict(dtype=torch.float32)),
     ("test_pointops_edge_operators", dict(c=8, w_c=4)), ("test_pointops_edge_operators", dict(c=3, w_c=1)), ("test_pointops_edge_operators", dict(c=6, w_c=2)),
@@ -222,6 +226,7 @@ EMULATED_GPU_TESTS = [
     ("test_pool_maps", dict(n_pts=3000)),
     ("test_attention_fwd_bwd", dict(lens=[48, 48, 17], H=2)), ("test_attention_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3)),
     ("test_attention_forward_launch_plans_agree_bit_for_bit", dict(lens=[256, 1, 300], H=2)),
+    ("test_attention_launch_plan_cache_survives_more_shapes_than_it_holds", dict(n_shapes=66)),
     ("test_attention_large_logits", dict()), ("test_attention_dropout_fwd_bwd", dict(lens=[1, 2, 31, 32, 33, 65], H=3, p=0.25)),
     ("test_attention_dropout_fwd_bwd", dict(lens=[200], H=2, p=0.5)), ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3, one_pass="0")),
     ("test_attention_f16_io_equals_the_reference_cast_passes", dict(lens=[1, 2, 31, 32, 33, 65], H=3, one_pass="1")),
@@ -234,6 +239,8 @@ EMULATED_GPU_TESTS = [
     ("test_attention_with_fused_rope_equals_the_two_pass_form", dict(lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.bfloat16)),
     ("test_attention_with_fused_rope_equals_the_two_pass_form", dict(lens=[1, 2, 31, 32, 33, 65], H=6, dtype=torch.float16)),
     ("test_attention_rpe_fwd_bwd", dict(lens=[200, 200, 200], H=3, bnd=18)),
+    ("test_attention_rpe_f16_io_equals_the_cast_passes", dict(lens=[33], H=1, bnd=4)),
+    ("test_attention_rpe_f16_io_equals_the_cast_passes", dict(lens=[200, 200, 200], H=3, bnd=18)),
 ]   # (in-place GPU tests -- rope3d, cross entropy -- are not in the list: with device = cpu their `.to(device)` aliases the input the
 #    oracle is then fed with; tests that construct `pointcept_amd.nn` modules or open a CUDA autocast region cannot run on CPU tensors)
 
