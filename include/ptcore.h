@@ -296,6 +296,23 @@ int ptc_linear_joint_fwd(const void* in, int64_t n_in, const void* weight, const
                          int c_out, int dtype, const float* a, const float* row_scale, const float* gB, const float* bB, float epsB,
                          int normB, float* z, void* y, float* statB, ptc_stream_t stream);
 
+/* The whole MLP of a PT-v3m1 Block in ONE kernel per direction (round 6, csrc/mlp.hip), C = 32 | 64, hidden = 4 C, 16-bit features:
+ *   ptc_mlp_fwd : m = GELU(x W1^T + b1) W2^T + b2 (pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:225-248, drop = 0), and --
+ *                 with a != NULL -- the residual joint behind it (:334-337): z = a + row_scale * m (fp32), y = cast(z) (feature dtype, may
+ *                 be NULL); with a == NULL: y = m.  The hidden tensor never reaches memory (per 64-channel chunk it goes from fc1's
+ *                 accumulators through GELU into fc2's operand registers).  Bit-identical to ptc_linear_fwd_ex(epilogue 1) followed by
+ *                 ptc_linear_joint_fwd / ptc_spconv_fwd.  w1 [4C][C], w2 [C][4C] in `dtype`; b1 / b2 fp32 or NULL; x [n][C].
+ *   ptc_mlp_bwd : from dm = d loss / d m [n][C] (feature dtype) and the forward's x: dx = ((dm W2) * GELU'(h)) W1 [n][C], dw1 [4C][C], db1 [4C],
+ *                 dw2 [C][4C], db2 [C] (fp32; db1 / db2 may be NULL), h = x W1^T + b1 RECOMPUTED per tile (the forward's bits).  w2t = W2^T
+ *                 [4C][C] in `dtype`.  Deterministic: per-workgroup partial sums in `workspace` (ptc_mlp_bwd_workspace_bytes), summed in a fixed
+ *                 order.  dx equals the split kernels' bits; the weight gradients differ from theirs in summation order only. */
+int ptc_mlp_supported(int c, int dtype);
+int ptc_mlp_fwd(const void* x, int64_t n, int c, int dtype, const void* w1, const float* b1, const void* w2, const float* b2,
+                const float* a, const float* row_scale, float* z, void* y, ptc_stream_t stream);
+size_t ptc_mlp_bwd_workspace_bytes(int64_t n, int c);
+int ptc_mlp_bwd(const void* dm, const void* x, int64_t n, int c, int dtype, const void* w1, const float* b1, const void* w2t, void* dx,
+                float* dw1, float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, ptc_stream_t stream);
+
 size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_in, int c_out);
 int ptc_spconv_wgrad(const void* in, int64_t n_in, const void* dout, const int32_t* nbr,
                      int64_t n_out, int kv, int c_in, int c_out, int dtype, float* dw, float* dbias,
@@ -692,6 +709,9 @@ enum { PTC_BLK_G_X0, PTC_BLK_G_XC, PTC_BLK_G_W_CONV, PTC_BLK_G_B_CONV, PTC_BLK_G
        PTC_BLK_S_DX2, PTC_BLK_S_DM, PTC_BLK_S_DH, PTC_BLK_S_DY2, PTC_BLK_S_DX1, PTC_BLK_S_DA, PTC_BLK_S_DATT, PTC_BLK_S_DQKV,
        PTC_BLK_S_DY1, PTC_BLK_S_DLIN, PTC_BLK_S_DCONV, PTC_BLK_GS_COUNT };
 int ptc_ptv3_block_abi(void);
+/* 1: the executor runs the Block's MLP on ptc_mlp_fwd / ptc_mlp_bwd for this (c, dtype) -- then O_H, O_ACT, O_M and S_DH are never
+ * touched and need not be allocated (round 6; PTC_BLK_MLP_FUSED=0 in the environment keeps the split kernels) */
+int ptc_ptv3_block_mlp_fused(int c, int dtype);
 size_t ptc_ptv3_block_workspace_bytes(int64_t n, int64_t n_pad, int c, int heads);
 int ptc_ptv3_block_fwd(const int64_t* iv, const float* fv, const void* const* in, void* const* out, ptc_stream_t stream);
 int ptc_ptv3_block_bwd(const int64_t* iv, const float* fv, const void* const* in, const void* const* sv, void* const* g,

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "ptc_rulebook_down_fill": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_spconv_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "ptc_ptv3_block_abi": (c_int, []),
+    "ptc_ptv3_block_mlp_fused": (c_int, [c_int, c_int]),
     "ptc_ptv3_block_workspace_bytes": (c_size, [c_i64, c_i64, c_int, c_int]),
     "ptc_ptv3_block_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_ptv3_block_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
@@ -63,6 +64,10 @@ _SIGNATURES = {
     "ptc_linear_joint_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_int,
                                      c_ptr, c_ptr, c_ptr, c_ptr]),
     "ptc_linear_fwd_ex": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "ptc_mlp_supported": (c_int, [c_int, c_int]),
+    "ptc_mlp_fwd": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "ptc_mlp_bwd_workspace_bytes": (c_size, [c_i64, c_int]),
+    "ptc_mlp_bwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "ptc_spconv_wgrad_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "ptc_spconv_wgrad": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size,
                                  c_ptr]),

@@ -47,6 +47,7 @@ HIP_SOURCES = [
     "rope.hip",
     "evalhist.hip",
     "block_exec.hip",
+    "mlp.hip",
 ]
 CXX_SOURCES = ["core.cpp"]
 PROBE_SOURCES = ["host_probe.cpp"]

@@ -28,6 +28,14 @@ template <typename T> static inline T* M(void* const* p, int i) { return (T*)p[i
 
 extern "C" int ptc_ptv3_block_abi(void) { return PTC_BLK_ABI; }
 
+// Round 6: the MLP of a Block (steps 8 + 9 / 9' + 8') on csrc/mlp.hip's one kernel per direction where it exists (C = 32 | 64: the
+// 819200- and ~200000-row stages).  Then H / ACT / M of the forward's slab and DH of the backward's are never touched (the caller need not
+// allocate them: functional._blk_plan asks this function), the backward recomputes h.  PTC_BLK_MLP_FUSED=0: the split kernels (A/B).
+extern "C" int ptc_ptv3_block_mlp_fused(int c, int dtype) {
+  static const int off = [] { const char* e = getenv("PTC_BLK_MLP_FUSED"); return e && e[0] == '0'; }();
+  return !off && ptc_mlp_supported(c, dtype);
+}
+
 // workspace of the backward: [scratch shared by the calls that finish inside themselves | one region per weight gradient: their
 // partial sums wait there for the ONE reduction launch at the end of the Block's backward]
 struct BlkWs { size_t common; size_t wg[6]; size_t off[6]; size_t total; };
@@ -40,7 +48,8 @@ static BlkWs blk_ws(int64_t n, int64_t n_pad, int c, int heads) {
   up(ptc_attn_varlen_bwd_workspace_bytes(n_pad, heads));
   up(ptc_batch_norm_workspace_bytes(n, c));
   w.common = ptc_align_up(w.common, 256);
-  w.wg[0] = ptc_spconv_wgrad_workspace_bytes(n, 1, hid, c);        // fc2
+  w.wg[0] = ptc_spconv_wgrad_workspace_bytes(n, 1, hid, c);        // fc2 (fused MLP: the partials of fc1 AND fc2, below)
+  if (ptc_mlp_supported(c, PTC_BF16) && ptc_mlp_bwd_workspace_bytes(n, c) > w.wg[0]) w.wg[0] = ptc_mlp_bwd_workspace_bytes(n, c);
   w.wg[1] = ptc_spconv_wgrad_workspace_bytes(n, 1, c, hid);        // fc1
   w.wg[2] = ptc_spconv_wgrad_workspace_bytes(n, 1, c, c);          // proj
   w.wg[3] = ptc_spconv_wgrad_workspace_bytes(n_pad, 1, c, 3 * c);  // qkv
@@ -109,6 +118,11 @@ extern "C" int ptc_ptv3_block_fwd(const int64_t* iv, const float* fv, const void
                          (const float*)P(in, PTC_BLK_P_G_N2), (const float*)P(in, PTC_BLK_P_BE_N2), fv[PTC_BLK_F_EPS_N2], 1, M<float>(out, PTC_BLK_O_X2),
                          out[PTC_BLK_O_Y2], dt, nullptr, M<float>(out, PTC_BLK_O_ST_N2), s));
   }
+  // 8 + 9 in ONE launch (mlp.hip): fc1 -> GELU -> fc2 -> x3 = x2 + droppath(m), xb3 = cast(x3); the hidden tensor stays on the CU
+  if (ptc_ptv3_block_mlp_fused(c, dt))
+    return ptc_mlp_fwd(out[PTC_BLK_O_Y2], n, c, dt, P(in, PTC_BLK_P_W_FC1), (const float*)P(in, PTC_BLK_P_B_FC1), P(in, PTC_BLK_P_W_FC2),
+                       (const float*)P(in, PTC_BLK_P_B_FC2), M<float>(out, PTC_BLK_O_X2), (const float*)P(in, PTC_BLK_P_RS2), M<float>(out, PTC_BLK_O_X3),
+                       out[PTC_BLK_O_XB3], s);
   // 8. MLP: (h, act) = fc1 + GELU in one kernel, then fc2 (ptv3m1:225-248)
   RUN(ptc_linear_fwd_ex(out[PTC_BLK_O_Y2], n, P(in, PTC_BLK_P_W_FC1), (const float*)P(in, PTC_BLK_P_B_FC1), c, hid, dt, 1, nullptr, out[PTC_BLK_O_H],
                         out[PTC_BLK_O_ACT], s));
@@ -150,10 +164,17 @@ extern "C" int ptc_ptv3_block_bwd(const int64_t* iv, const float* fv, const void
   RUN(ptc_add_norm_bwd((const float*)P(in, PTC_BLK_P_DZ3), P(in, PTC_BLK_P_DYB3), dt, (const float*)P(sv, PTC_BLK_O_X3), P(sv, PTC_BLK_O_M), dt, rs2, n, c,
                        nullptr, nullptr, 0, nullptr, nullptr, 0, g[PTC_BLK_S_DX2], PTC_F32, g[PTC_BLK_S_DM], nullptr, nullptr, nullptr, nullptr, ws, wb, s));
   // 8'. MLP: fc2 weight / bias gradients, dh = (dm W2) * GELU'(h), fc1 weight / bias gradients, dy2 = dh W1
+  const bool mlp_fused = ptc_ptv3_block_mlp_fused(c, dt) != 0;
+  if (mlp_fused) {    // ONE launch (mlp.hip: h recomputed, dh never written); its partial sums wait in the fc2 region for the reduction below
+    RUN(ptc_mlp_bwd_deferred(g[PTC_BLK_S_DM], P(sv, PTC_BLK_O_Y2), n, c, dt, P(in, PTC_BLK_P_W_FC1), (const float*)P(in, PTC_BLK_P_B_FC1),
+                             P(in, PTC_BLK_P_WT_FC2), g[PTC_BLK_S_DY2], M<float>(g, PTC_BLK_G_W_FC1), M<float>(g, PTC_BLK_G_B_FC1),
+                             M<float>(g, PTC_BLK_G_W_FC2), M<float>(g, PTC_BLK_G_B_FC2), wgws(0), W.wg[0], s, &jobs[1], &jobs[0]));
+  } else {
   calls[0] = PtcWgradCall{P(sv, PTC_BLK_O_ACT), n, g[PTC_BLK_S_DM], nullptr, n, 1, hid, c, dt, M<float>(g, PTC_BLK_G_W_FC2), M<float>(g, PTC_BLK_G_B_FC2), wgws(0), W.wg[0]};
   RUN(ptc_linear_fwd_ex(g[PTC_BLK_S_DM], n, P(in, PTC_BLK_P_WT_FC2), nullptr, c, hid, dt, 2, P(sv, PTC_BLK_O_H), g[PTC_BLK_S_DH], nullptr, s));
   calls[1] = PtcWgradCall{P(sv, PTC_BLK_O_Y2), n, g[PTC_BLK_S_DH], nullptr, n, 1, c, hid, dt, M<float>(g, PTC_BLK_G_W_FC1), M<float>(g, PTC_BLK_G_B_FC1), wgws(1), W.wg[1]};
   RUN(ptc_spconv_fwd(g[PTC_BLK_S_DH], n, P(in, PTC_BLK_P_WT_FC1), nullptr, nullptr, n, 1, hid, c, dt, g[PTC_BLK_S_DY2], s));
+  }
   // 7'. x2 = x1 + rs1 * a, y2 = norm2(x2):  dx1 = dx2 + LN'(dy2);  da = rs1 * dx1
   RUN(ptc_add_norm_bwd(M<float>(g, PTC_BLK_S_DX2), g[PTC_BLK_S_DY2], dt, (const float*)P(sv, PTC_BLK_O_X2), P(sv, PTC_BLK_O_A), dt, rs1, n, c, nullptr, nullptr, 0,
                        (const float*)P(in, PTC_BLK_P_G_N2), (const float*)P(sv, PTC_BLK_O_ST_N2), 1, g[PTC_BLK_S_DX1], PTC_F32, g[PTC_BLK_S_DA], nullptr, nullptr,
@@ -186,7 +207,8 @@ extern "C" int ptc_ptv3_block_bwd(const int64_t* iv, const float* fv, const void
                          (const int32_t*)P(in, PTC_BLK_P_BLK_HCNT), (int)iv[PTC_BLK_I_BLK_BM], (int)iv[PTC_BLK_I_BLK_HCAP], n, 27, c, c, dt, g[PTC_BLK_G_XC], s));
   // the five Linear weight gradients in one grouped launch (their operands -- saved activations and the scratch gradients above -- are
   // all still in place), then the split-K reductions of all six weight gradients in one launch
-  RUN(ptc_spconv_wgrad_group(calls, 5, jobs, s));
+  if (mlp_fused) RUN(ptc_spconv_wgrad_group(calls + 2, 3, jobs + 2, s));     // (jobs[0], jobs[1]: the MLP kernel's own partials)
+  else RUN(ptc_spconv_wgrad_group(calls, 5, jobs, s));
   RUN(ptc_wgrad_reduce_jobs(jobs, 6, s));
   return PTC_OK;
 }

@@ -38,3 +38,8 @@ int ptc_spconv_wgrad_group(const PtcWgradCall* calls, int n, PtcWgradJob* jobs, 
 // ONE launch for up to PTC_WGRAD_JOBS_MAX reductions (bit-identical to the separate launches: same per-output summation order)
 #define PTC_WGRAD_JOBS_MAX 8
 int ptc_wgrad_reduce_jobs(const PtcWgradJob* jobs, int n, ptc_stream_t stream);
+
+// ptc_mlp_bwd (mlp.hip) with the reduction of its per-workgroup partials left to the caller: jobs for (dw1, db1) and (dw2, db2)
+int ptc_mlp_bwd_deferred(const void* dm, const void* x, int64_t n, int c, int dtype, const void* w1, const float* b1, const void* w2t, void* dx,
+                         float* dw1, float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, ptc_stream_t stream,
+                         PtcWgradJob* job_fc1, PtcWgradJob* job_fc2);

@@ -840,17 +840,20 @@ def _blk_layout(items, elem_bytes):
 _blk_plans = {}
 
 
-def _blk_plan(n, npad, c, heads, x0_f32):
+def _blk_plan(n, npad, c, heads, x0_f32, dt=torch.bfloat16):
     """pointer-table layout of one Block call, cached per shape: byte offsets of every saved activation / scratch gradient inside
     the slabs, as (table index, offset) lists -- the per-call work is then two allocations and ~45 integer stores per direction"""
-    key = (n, npad, c, heads, x0_f32)
+    # round 6: where the executor runs the MLP on csrc/mlp.hip (C = 32 | 64) the hidden-width tensors do not exist: no H / ACT / M in the
+    # saved slab (2 x N x 4C x 2 bytes per Block: 0.84 GB at N = 819200, C = 64), no DH in the backward's scratch
+    fused = bool(ops.lib().ptc_ptv3_block_mlp_fused(int(c), _lib.PTC_F16 if dt == torch.float16 else _lib.PTC_BF16))
+    key = (n, npad, c, heads, x0_f32, fused)
     p = _blk_plans.get(key)
     if p is not None:
         return p
     E = _lib.block_enums()
     hid = 4 * c
-    l16, t16 = _blk_layout([("CONV", n, c), ("LIN", n, c), ("Y1", n, c), ("QKV", npad, 3 * c), ("ATT", npad, c), ("A", n, c), ("Y2", n, c), ("H", n, hid),
-                            ("ACT", n, hid), ("M", n, c)], 2)
+    l16, t16 = _blk_layout([("CONV", n, c), ("LIN", n, c), ("Y1", n, c), ("QKV", npad, 3 * c), ("ATT", npad, c), ("A", n, c), ("Y2", n, c)] +
+                           ([] if fused else [("H", n, hid), ("ACT", n, hid), ("M", n, c)]), 2)
     l32, t32 = _blk_layout([("X1", n, c), ("X2", n, c), ("ST_CPE", 2, n), ("ST_N1", 2, n), ("ST_N2", 2, n), ("LSE", heads, npad)], 4)
     shapes = {"W_CONV": (c, 27, c), "B_CONV": (c,), "W_LIN": (c, c), "B_LIN": (c,), "G_CPE": (c,), "BE_CPE": (c,), "G_N1": (c,), "BE_N1": (c,),
               "W_QKV": (3 * c, c), "B_QKV": (3 * c,), "W_PROJ": (c, c), "B_PROJ": (c,), "G_N2": (c,), "BE_N2": (c,), "W_FC1": (hid, c), "B_FC1": (hid,),
@@ -863,7 +866,7 @@ def _blk_plan(n, npad, c, heads, x0_f32):
     if x0_f32:
         gs_items.append(("G_X0", n, c))
     lgs, tgs = _blk_layout(gs_items, 4)
-    s_items = [("S_DM", n, c), ("S_DH", n, hid), ("S_DY2", n, c), ("S_DA", n, c), ("S_DATT", npad, c), ("S_DQKV", npad, 3 * c), ("S_DY1", n, c),
+    s_items = [("S_DM", n, c)] + ([] if fused else [("S_DH", n, hid)]) + [("S_DY2", n, c), ("S_DA", n, c), ("S_DATT", npad, c), ("S_DQKV", npad, 3 * c), ("S_DY1", n, c),
                ("S_DLIN", n, c), ("S_DCONV", n, c), ("G_XC", n, c)]
     if not x0_f32:
         s_items.append(("G_X0", n, c))
@@ -917,7 +920,7 @@ class _BlockFn(Function):
         dev = x0.device
         x0 = x0.contiguous()
         xc = xc.contiguous()
-        plan = _blk_plan(n, npad, c, heads, x0.dtype == torch.float32)
+        plan = _blk_plan(n, npad, c, heads, x0.dtype == torch.float32, dt)
         E = plan["E"]
         iv, fv, pin = _blk_tables(E, x0, meta)
         keep = []                                            # tensors the pointer table names (alive until saved / returned)
@@ -1066,17 +1069,28 @@ class _MLP(Function):
         dt = torch.get_autocast_dtype("cuda") if _autocast_on() else x.dtype
         xp = x.to(dt).contiguous()
         w1c, w2c = _cast_cache.get(w1, dt).contiguous(), _cast_cache.get(w2, dt).contiguous()
+        ctx.dtypes = (x.dtype, w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
+        ctx.one_kernel = config.MLP_ONE_KERNEL and w1.shape[0] == 4 * w1.shape[1] and w2.shape[0] == w1.shape[1] and ops.mlp_supported(w1.shape[1], dt)
+        if ctx.one_kernel:      # round 6 (csrc/mlp.hip): the hidden tensor never reaches memory, the backward recomputes it; same bits as below
+            ctx.save_for_backward(xp, w1c, w2c, b1)
+            return ops.mlp_fwd(xp, w1c, b1, w2c, b2)
         h, a = ops.linear_gelu_fwd(xp, w1c, b1)
         out = ops.spconv_fwd(a, w2c[:, None, :], None if b2 is None else b2.float(), None)      # shapes: mlp_gelu_supported
         ctx.save_for_backward(xp, h, a, w1c, w2c)
-        ctx.dtypes = (x.dtype, w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        xp, h, a, w1c, w2c = ctx.saved_tensors
         x_dt, w1_dt, b1_dt, w2_dt, b2_dt = ctx.dtypes
+        if ctx.one_kernel:
+            xp, w1c, w2c, b1 = ctx.saved_tensors
+            w2t = _cast_cache.layout(w2c, "mirror")
+            dx, dw1, db1, dw2, db2 = ops.mlp_bwd(dout.to(xp.dtype).contiguous(), xp, w1c, b1, w2c.t().contiguous() if w2t is None else w2t[:, 0, :],
+                                                 want_b1=b1_dt is not None, want_b2=b2_dt is not None)
+            return (dx.to(x_dt) if ctx.needs_input_grad[0] else None, dw1.to(w1_dt), None if db1 is None else db1.to(b1_dt), dw2.to(w2_dt),
+                    None if db2 is None else db2.to(b2_dt))
+        xp, h, a, w1c, w2c = ctx.saved_tensors
         g = dout.to(xp.dtype).contiguous()
         n = g.shape[0]
         # fc2: weight / bias gradients, then the input gradient THROUGH the activation

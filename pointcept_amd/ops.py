@@ -1194,6 +1194,58 @@ def linear_gelu_bwd_input(g: torch.Tensor, weight_t: torch.Tensor, h: torch.Tens
     return out
 
 
+def mlp_supported(c: int, dtype: torch.dtype) -> bool:
+    """the one-kernel MLP (csrc/mlp.hip): C = 32 | 64 (hidden 4 C), bf16 / f16"""
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    return bool(lib().ptc_mlp_supported(int(c), _lib.PTC_F16 if dtype == torch.float16 else _lib.PTC_BF16))
+
+
+def mlp_fwd(x, w1, b1, w2, b2, a=None, row_scale=None, want_y=True):
+    """m = GELU(x W1^T + b1) W2^T + b2 in one kernel.  a is None: -> m [N, C] (x's dtype).  a [N, C] fp32 (the residual stream):
+    -> (z = a + row_scale * m fp32, y = cast(z) or None)."""
+    require_cuda(x, w1, b1, w2, b2, a, row_scale)
+    x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
+    n, c = x.shape
+    if tuple(w1.shape) != (4 * c, c) or tuple(w2.shape) != (c, 4 * c) or w1.dtype != x.dtype or w2.dtype != x.dtype:
+        raise PtcoreError(f"mlp_fwd: x {tuple(x.shape)} {x.dtype}, w1 {tuple(w1.shape)} {w1.dtype}, w2 {tuple(w2.shape)} {w2.dtype}")
+    b1 = None if b1 is None else b1.to(torch.float32).contiguous()
+    b2 = None if b2 is None else b2.to(torch.float32).contiguous()
+    if a is None:
+        y = torch.empty((n, c), dtype=x.dtype, device=x.device)
+        check(lib().ptc_mlp_fwd(ptr(x), n, c, dtype_code(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), 0, 0, 0, ptr(y), stream_ptr()), "ptc_mlp_fwd")
+        return y
+    if a.dtype != torch.float32 or tuple(a.shape) != (n, c):
+        raise PtcoreError("mlp_fwd: the residual stream must be fp32 [N, C]")
+    a = a.contiguous()
+    rs = None if row_scale is None else row_scale.to(torch.float32).contiguous()
+    z = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    y = torch.empty((n, c), dtype=x.dtype, device=x.device) if want_y else None
+    check(lib().ptc_mlp_fwd(ptr(x), n, c, dtype_code(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(a), ptr(rs), ptr(z), ptr(y), stream_ptr()), "ptc_mlp_fwd")
+    return z, y
+
+
+def mlp_bwd(dm, x, w1, b1, w2t, want_b1=True, want_b2=True):
+    """-> (dx [N, C] like x, dw1 [4C, C], db1 [4C] | None, dw2 [C, 4C], db2 [C] | None), fp32 parameter gradients; w2t = W2^T [4C, C]."""
+    require_cuda(dm, x, w1, b1, w2t)
+    dm, x, w1, w2t = dm.contiguous(), x.contiguous(), w1.contiguous(), w2t.contiguous()
+    n, c = x.shape
+    hid = 4 * c
+    if dm.shape != x.shape or dm.dtype != x.dtype or tuple(w1.shape) != (hid, c) or tuple(w2t.shape) != (hid, c) or w1.dtype != x.dtype or w2t.dtype != x.dtype:
+        raise PtcoreError(f"mlp_bwd: dm {tuple(dm.shape)} {dm.dtype}, x {tuple(x.shape)} {x.dtype}, w1 {tuple(w1.shape)}, w2t {tuple(w2t.shape)}")
+    b1 = None if b1 is None else b1.to(torch.float32).contiguous()
+    dx = torch.empty_like(x)
+    dw1 = torch.empty((hid, c), dtype=torch.float32, device=x.device)
+    dw2 = torch.empty((c, hid), dtype=torch.float32, device=x.device)
+    db1 = torch.empty((hid,), dtype=torch.float32, device=x.device) if want_b1 else None
+    db2 = torch.empty((c,), dtype=torch.float32, device=x.device) if want_b2 else None
+    nbytes = lib().ptc_mlp_bwd_workspace_bytes(n, c)
+    ws = _ws(nbytes, x.device)
+    check(lib().ptc_mlp_bwd(ptr(dm), ptr(x), n, c, dtype_code(x), ptr(w1), ptr(b1), ptr(w2t), ptr(dx), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(ws), nbytes,
+                            stream_ptr()), "ptc_mlp_bwd")
+    return dx, dw1, db1, dw2, db2
+
+
 def weight_layouts(desc: torch.Tensor, prefix: torch.Tensor, n: int, total: int) -> None:
     """functional._CastCache: rewrite every backward-pass weight layout described by desc [n,6] / prefix [n+1] (device int64)."""
     require_cuda(desc, prefix)

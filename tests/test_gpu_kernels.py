@@ -730,6 +730,71 @@ def test_linear_with_the_residual_joint_in_its_epilogue(cuda, dtype, cin, cout):
             assert (sb is None) == (sb2 is None) and (sb is None or torch.equal(sb, sb2))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("c,n", [(64, 3001), (32, 3001), (64, 100), (32, 129)])
+def test_mlp_one_kernel_per_direction(cuda, dtype, c, n, monkeypatch):
+    """round 6 (csrc/mlp.hip): the MLP of a PT-v3m1 Block, fc1 -> GELU -> fc2 (+ the residual joint), as ONE kernel per direction with the
+    hidden tensor kept on the CU (forward: fc1 accumulators -> GELU -> fc2 operand registers; backward: h recomputed, GELU(h) / dh through LDS
+    into the weight gradients).  Against the split kernels it replaces:
+      forward   z, y (with the joint) and m (without) BIT-IDENTICAL to ptc_linear_fwd_ex(epilogue 1) + ptc_linear_joint_fwd / ptc_spconv_fwd;
+      backward  dx BIT-IDENTICAL to ptc_linear_fwd_ex(epilogue 2) + ptc_spconv_fwd(W1^T); weight / bias gradients equal to the split-K kernels'
+                up to summation order (1e-5 of the largest entry), and reproducible run to run;
+    and against the fp32 formulation of ptv3m1:225-248 at 16-bit operand accuracy.  Ragged row counts, several tiles per workgroup."""
+    from pointcept_amd import ops
+
+    on_gpu = torch.device(cuda).type == "cuda"
+    if not on_gpu:
+        monkeypatch.setenv("PTC_MLP_BWD_WGS", "3")          # emulation: three persistent workgroups = several tiles each at 3001 rows
+        monkeypatch.setenv("PTC_MLP_FWD_WGS", "5")
+    assert ops.mlp_supported(c, dtype) and not ops.mlp_supported(128, dtype) and not ops.mlp_supported(c, torch.float32)
+    g = torch.Generator().manual_seed(c + n)
+    hid = 4 * c
+    x = torch.randn(n, c, generator=g).to(dtype).to(cuda)
+    w1 = (torch.randn(hid, c, generator=g) / c ** 0.5).to(dtype).to(cuda)
+    b1 = (torch.randn(hid, generator=g) * 0.5).to(cuda)
+    w2 = (torch.randn(c, hid, generator=g) / hid ** 0.5).to(dtype).to(cuda)
+    b2 = torch.randn(c, generator=g).to(cuda)
+    a = torch.randn(n, c, generator=g).to(cuda)
+    rs = (torch.rand(n, generator=g) > 0.3).float().to(cuda) / 0.7
+    dm = (torch.randn(n, c, generator=g) * (1.0 if dtype == torch.bfloat16 else 0.25)).to(dtype).to(cuda)
+    # ---- forward
+    h, act = ops.linear_gelu_fwd(x, w1, b1)
+    m_split = ops.spconv_fwd(act, w2[:, None, :].contiguous(), b2, None)
+    m = ops.mlp_fwd(x, w1, b1, w2, b2)
+    assert m.dtype == dtype and torch.equal(m, m_split)
+    for scale in (rs, None):
+        z_split, y_split, _ = ops.linear_joint_fwd(act, w2, b2, None, a, scale, None, dtype)
+        z, y = ops.mlp_fwd(x, w1, b1, w2, b2, a, scale)
+        assert torch.equal(z, z_split) and torch.equal(y, y_split), scale is not None
+    z_only, none = ops.mlp_fwd(x, w1, b1, w2, b2, a, rs, want_y=False)
+    assert none is None and torch.equal(z_only, ops.mlp_fwd(x, w1, b1, w2, b2, a, rs)[0])
+    assert torch.equal(ops.mlp_fwd(x, w1, None, w2, None), ops.spconv_fwd(ops.linear_gelu_fwd(x, w1, None)[1], w2[:, None, :].contiguous(), None, None))
+    xr, w1r, b1r = x.double().cpu().requires_grad_(True), w1.double().cpu().requires_grad_(True), b1.double().cpu().requires_grad_(True)
+    w2r, b2r = w2.double().cpu().requires_grad_(True), b2.double().cpu().requires_grad_(True)
+    ref = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(xr, w1r, b1r)), w2r, b2r)
+    lo = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -9
+    assert float((m.double().cpu() - ref.detach()).norm() / ref.detach().norm()) < lo
+    # ---- backward
+    w2t, w1t = w2.t().contiguous(), w1.t().contiguous()
+    dh = ops.linear_gelu_bwd_input(dm, w2t, h)
+    dx_split = ops.spconv_fwd(dh, w1t[:, None, :].contiguous(), None, None)
+    dw2_s, db2_s = ops.spconv_wgrad(act, dm, None, want_bias=True)
+    dw1_s, db1_s = ops.spconv_wgrad(x, dh, None, want_bias=True)
+    dx, dw1, db1, dw2, db2 = ops.mlp_bwd(dm, x, w1, b1, w2t)
+    assert torch.equal(dx, dx_split)
+    for name, got, want in (("dw1", dw1, dw1_s[:, 0, :]), ("db1", db1, db1_s), ("dw2", dw2, dw2_s[:, 0, :]), ("db2", db2, db2_s)):
+        assert got.dtype == torch.float32 and got.shape == want.shape, name
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-6, (name, float((got - want).abs().max()), float(want.abs().max()))
+    again = ops.mlp_bwd(dm, x, w1, b1, w2t)
+    assert all(torch.equal(u, v) for u, v in zip(again, (dx, dw1, db1, dw2, db2))), "not reproducible"
+    dx2, dw1_2, none1, dw2_2, none2 = ops.mlp_bwd(dm, x, w1, None, w2t, want_b1=False, want_b2=False)
+    assert none1 is None and none2 is None and dx2.shape == dx.shape
+    ref.backward(dm.double().cpu())
+    for name, got, want in (("dx", dx, xr.grad), ("dw1", dw1, w1r.grad), ("db1", db1, b1r.grad), ("dw2", dw2, w2r.grad), ("db2", db2, b2r.grad)):
+        err = float((got.double().cpu() - want).norm() / want.norm())
+        assert err < 4 * lo, (name, err)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_linear_gather_tables(cuda, dtype):
     """out = F.linear(x)[gidx] with a padded permutation (duplicated tail rows), gather-form backward."""

@@ -208,6 +208,8 @@ EMULATED_GPU_TESTS = [
     ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.bfloat16, cin=64, cout=64)),
     ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.float16, cin=128, cout=32)),
     ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.bfloat16, cin=128, cout=128)),
+    ("test_mlp_one_kernel_per_direction", dict(dtype=torch.bfloat16, c=64, n=1100)), ("test_mlp_one_kernel_per_direction", dict(dtype=torch.float16, c=32, n=1100)),
+    ("test_mlp_one_kernel_per_direction", dict(dtype=torch.bfloat16, c=32, n=129)), ("test_mlp_one_kernel_per_direction", dict(dtype=torch.float16, c=64, n=100)),
     ("test_linear_identity_table", dict(dtype=torch.float32, n=1000, cin=32, cout=64)),
     ("test_linear_identity_table", dict(dtype=torch.bfloat16, n=300, cin=72, cout=288)), ("test_linear_identity_table", dict(dtype=torch.bfloat16, n=300, cin=288, cout=72)),
     ("test_linear_identity_table", dict(dtype=torch.float16, n=200, cin=432, cout=108)), ("test_linear_identity_table", dict(dtype=torch.bfloat16, n=150, cin=1008, cout=252)),

@@ -68,6 +68,41 @@ def bench_linear(rows, n, cin, cout, results):
                 f"wgrad own {r['own_wgrad']['us']:8.1f} lib {r['lib_wgrad']['us']:8.1f} | own fwd roof {r['own_fwd']['roof_frac']}")
 
 
+def bench_mlp(rows, n, c, results, dt=torch.bfloat16):
+    """csrc/mlp.hip against the split kernels it replaces (fc1 + GELU, fc2 + joint; GELU' dgrad, fc1 dgrad, two weight gradients)"""
+    hid = 4 * c
+    x = torch.randn(n, c, device=DEV).to(dt)
+    w1 = (torch.randn(hid, c, device=DEV) / c ** 0.5).to(dt)
+    w2 = (torch.randn(c, hid, device=DEV) / hid ** 0.5).to(dt)
+    b1, b2 = torch.randn(hid, device=DEV) * 0.3, torch.randn(c, device=DEV)
+    a = torch.randn(n, c, device=DEV)
+    dm = torch.randn(n, c, device=DEV).to(dt)
+    w2t, w1t = w2.t().contiguous(), w1.t().contiguous()[:, None, :].contiguous()
+    h, act = ops.linear_gelu_fwd(x, w1, b1)
+    dh = ops.linear_gelu_bwd_input(dm, w2t, h)
+
+    def split_fwd():
+        _, a_ = ops.linear_gelu_fwd(x, w1, b1)
+        return ops.linear_joint_fwd(a_, w2, b2, None, a, None, None, dt)
+
+    def split_bwd():
+        d = ops.linear_gelu_bwd_input(dm, w2t, h)
+        ops.spconv_fwd(d, w1t, None, None)
+        ops.spconv_wgrad(act, dm, None, want_bias=True)
+        ops.spconv_wgrad(x, d, None, want_bias=True)
+
+    r = {"shape": [n, c]}
+    fl_f, fl_b = 4.0 * n * c * hid, 10.0 * n * c * hid
+    r["fused_fwd"] = roof(n * c * 12, fl_f, timeit(lambda: ops.mlp_fwd(x, w1, b1, w2, b2, a, None)))
+    r["split_fwd"] = roof(n * c * 12, fl_f, timeit(split_fwd))
+    r["fused_bwd"] = roof(n * c * 6, fl_b, timeit(lambda: ops.mlp_bwd(dm, x, w1, b1, w2t)))
+    r["split_bwd"] = roof(n * c * 6, fl_b, timeit(split_bwd))
+    results.append(r)
+    rows.append(f"mlp n={n:7d} c={c:3d} {str(dt)[6:]:8s} | fwd fused {r['fused_fwd']['us']:7.1f} us ({r['fused_fwd']['GBps']:.0f} GB/s alg, {fl_f / r['fused_fwd']['us'] / 1e6:.0f} TF/s) "
+                f"split {r['split_fwd']['us']:7.1f} | bwd fused {r['fused_bwd']['us']:7.1f} us ({r['fused_bwd']['GBps']:.0f} GB/s alg, {fl_b / r['fused_bwd']['us'] / 1e6:.0f} TF/s) "
+                f"split {r['split_bwd']['us']:7.1f}")
+
+
 def bench_ln(rows, n, c, results):
     x = torch.randn(n, c, device=DEV)
     gm, bt = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV)
@@ -361,6 +396,11 @@ def main():
         bench_linear(rows, 819200, 64, 256, res["linear"])
         bench_linear(rows, 819200, 256, 64, res["linear"])
         bench_linear(rows, 819200, 64, 32, res["linear"])   # seg head (20 padded to 32)
+    if want("mlp"):
+        res["mlp"] = []
+        for n, c in ((819200, 64), (819200, 32), (202560, 64), (202560, 32)):
+            bench_mlp(rows, n, c, res["mlp"])
+        bench_mlp(rows, 819200, 64, res["mlp"], torch.float16)
     if "linprobe" in only:   # shape sweep at the stage-0 row count: which of (c_in, c_out) costs the bandwidth?
         res["linprobe"] = []
         for cin, cout in ((32, 32), (32, 64), (32, 128), (32, 256), (64, 32), (64, 64), (64, 128), (64, 192), (64, 256), (128, 64),
