@@ -128,6 +128,24 @@ def _latest_profile(pattern):
     return sorted(fs, key=lambda q: (os.path.basename(q)[:3], len(os.path.basename(q)), os.path.basename(q)))[-1] if fs else None
 
 
+def step_traffic():
+    """HBM bytes of ONE steady-state step of this workload, from the round's committed PMC table: the TOTAL line of the
+    latest profiles/*_step_traffic.txt -- FETCH_SIZE x 2 (the guide's gfx950 correction) + WRITE_SIZE over separate --pmc passes of
+    `bench.py --steps 2 | 5` (tools/gpu_session.sh traffic, tools/step_traffic.py).  Not re-measured inside the timed run (counters need
+    rocprofv3 around the process); the source file is named beside the number."""
+    import re
+
+    f = _latest_profile("*_step_traffic.txt")
+    if not f:
+        return None
+    for line in open(f):
+        m = re.match(r"TOTAL\s+read\s+([0-9.]+) GB\s+written\s+([0-9.]+) GB\s+sum\s+([0-9.]+) GB", line)
+        if m:
+            return {"step_traffic_gb": float(m.group(3)), "read_gb": float(m.group(1)), "written_gb": float(m.group(2)),
+                    "compulsory_gb": 24.0, "source": os.path.relpath(f, ROOT)}
+    return None
+
+
 def attention_roofline(device, scenes: int, points: int):
     """Time attn_fwd_kernel alone at the shape of the largest attention of the model (dec0:
     C=64 -> H=4, N' = scenes*points padded to patches of 1024) with HIP events on the launch
@@ -524,6 +542,11 @@ def main():
         if not args.stub and args.model == "ptv3":
             out["config"]["points_per_gpu"] = int(batch["offset"][-1])
             out["config"]["loss"] = "CrossEntropy(ignore_index=-1)" + ("" if args.ce_only else " + LovaszSoftmax")
+            if args.batch == 8 and args.points == 102400:      # the table was measured on the default workload
+                st = step_traffic()
+                if st:
+                    out["step_traffic_gb"] = st["step_traffic_gb"]
+                    out["step_traffic"] = st
             try:
                 out["roofline"] = attention_roofline(device, args.batch, args.points)
             except Exception as e:  # never lose the headline number to a diagnostics failure
