@@ -169,6 +169,10 @@ int ptc_pool_level_counts(const int64_t* code0, const int64_t* order0, int64_t n
  * ------------------------------------------------------------------------------------------ */
 int ptc_gather_rows(const void* src, int64_t n_src, const int64_t* idx, const int64_t* idx2,
                     int64_t n_out, int c, int dtype, void* out, ptc_stream_t stream);
+/* out[i] = addend[i] + src[idx[i]] (idx[i] < 0: addend[i]) in one pass, one rounding in the feature dtype -- SerializedUnpooling's
+ * `parent.feat + point.feat[inverse]` (pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:478).  c a multiple of a 16-byte lane. */
+int ptc_gather_rows_add(const void* src, int64_t n_src, const int64_t* idx, const void* addend, int64_t n_out, int c, int dtype,
+                        void* out, ptc_stream_t stream);
 int ptc_segment_csr_fwd(const void* src, const int64_t* perm, const int64_t* indptr, int64_t n_seg,
                         int c, int dtype, int reduce, void* out, int32_t* arg_out,
                         ptc_stream_t stream);

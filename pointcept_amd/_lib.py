@@ -35,6 +35,7 @@ _SIGNATURES = {
     "ptc_pool_child_codes": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "ptc_pool_level_counts": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr]),
     "ptc_gather_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    "ptc_gather_rows_add": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "ptc_segment_csr_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "ptc_segment_csr_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
     "ptc_hash_table_size": (c_i64, [c_i64]),

@@ -420,8 +420,12 @@ static int launch_fwd2(const void* in, int64_t n_in, const void* w, const float*
 template <typename T>
 static int dispatch_fwd2(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
                          int c_in, int c_out, void* out, hipStream_t s, int epi = 0, const void* aux_in = nullptr, void* aux_out = nullptr) {
-  if (c_out % 128 == 0) return launch_fwd2<T, 8>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
-  if (c_out % 96 == 0) return launch_fwd2<T, 6>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  // Linear layers of the deep stages (c_in >= 128, fewer 128-row x 128-column workgroups than CUs): 64-column workgroups -- twice as many,
+  // each staging half as much of W before its ONE row tile (round 6; PTC_L2_NARROW=0: the 128-column form, timing A/B)
+  static const bool narrow_on = [] { const char* e = getenv("PTC_L2_NARROW"); return !(e && e[0] == '0'); }();
+  const bool narrow = narrow_on && kv == 1 && epi == 0 && c_in >= 128 && ptc_cdiv(n_out, F2_ROWS) * (c_out / 128) < 256;
+  if (c_out % 128 == 0 && !narrow) return launch_fwd2<T, 8>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
+  if (c_out % 96 == 0 && !narrow) return launch_fwd2<T, 6>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
   if (c_out % 64 == 0) return launch_fwd2<T, 4>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
   if (c_out % 48 == 0) return launch_fwd2<T, 3>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);
   if (c_out % 32 == 0) return launch_fwd2<T, 2>(in, n_in, w, bias, nbr, n_out, kv, c_in, c_out, out, s, epi, aux_in, aux_out);

@@ -516,13 +516,13 @@ extern "C" int ptc_mlp_fwd(const void* x, int64_t n, int c, int dtype, const voi
   PTC_REQUIRE(x && w1 && w2 && (a ? z != nullptr : y != nullptr), PTC_EINVAL, "ptc_mlp_fwd: null buffer");
   PTC_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w1 % 16 == 0) && ((uintptr_t)w2 % 16 == 0) && ((uintptr_t)a % 16 == 0) && ((uintptr_t)z % 16 == 0) &&
               ((uintptr_t)y % 16 == 0), PTC_EINVAL, "ptc_mlp_fwd: buffers must be 16-byte aligned");
-  // 16 waves per workgroup, one workgroup per CU from ~2 steps per workgroup up; small inputs (deep stages never come here, but tests and
-  // other callers do) take 4-wave workgroups so that more CUs get work
-  int waves = n >= (int64_t)256 * 512 ? 16 : 4;
+  int waves = 4;            // (16-wave workgroups -- four waves per SIMD -- measured equal to 2 x 4 at C = 64, profiles/r06_d_mlp_sweeps.txt: kept as an instance)
   if (const char* e = getenv("PTC_MLP_FWD_WAVES")) { const int v = atoi(e); if (v == 4 || v == 16) waves = v; }
   const size_t lds = mlp_fwd_lds(c, waves);
   const int64_t tiles = ptc_cdiv(n, (int64_t)waves * 32);
-  int64_t gx = waves == 16 ? 256 : 512;
+  int64_t per_cu = (160 * 1024) / (int64_t)lds;          // workgroups a CU holds by LDS: 1 (16 waves) | 2 (C = 64) | 4+ (C = 32: 81 -> 72 us at N = 819200)
+  per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+  int64_t gx = 256 * per_cu;
   if (const char* e = getenv("PTC_MLP_FWD_WGS")) { const int v = atoi(e); if (v > 0) gx = v; }
   if (gx > tiles) gx = tiles;
   const MlpOut J{a, row_scale, z, y};

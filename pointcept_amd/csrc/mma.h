@@ -66,6 +66,9 @@ __device__ __forceinline__ uint4 ptc_buf_load16(__amdgpu_buffer_rsrc_t r, uint32
   const ptc_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
   return make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
 }
+__device__ __forceinline__ int32_t ptc_buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
+}
 template <typename T>
 __device__ __forceinline__ typename Mma<T>::frag ld_frag_buf(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
   const uint4 v = ptc_buf_load16(r, byte_off);

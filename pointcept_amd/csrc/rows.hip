@@ -58,6 +58,46 @@ gather_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ idx, c
   }
 }
 
+// out[i] = addend[i] + src[idx[i]] (one rounding, as the reference's `parent.feat + point.feat[inverse]`, ptv3m1:478): SerializedUnpooling's
+// gather and add in one pass instead of a gather kernel and an ATen add over [N, C] (round 6)
+template <typename T>
+__global__ void __launch_bounds__(256)
+gather_rows_add_kernel(const T* __restrict__ src, const int64_t* __restrict__ idx, const T* __restrict__ addend, int64_t n_out, int c,
+                       T* __restrict__ out) {
+  constexpr int W = Vec16<T>::N;
+  const int cpr = c / W;
+  const int64_t total = n_out * cpr;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t row = t / cpr;
+    const int ch = (int)(t - row * cpr) * W;
+    const int64_t s1 = idx[row];
+    Vec16<T> a = load16(addend + row * c + ch);
+    if (s1 >= 0) {
+      const Vec16<T> b = load16(src + s1 * c + ch);
+#pragma unroll
+      for (int j = 0; j < W; ++j) a.v[j] = ptc_from_float<T>(ptc_to_float(a.v[j]) + ptc_to_float(b.v[j]));
+    }
+    store16(out + row * c + ch, a);
+  }
+}
+
+extern "C" int ptc_gather_rows_add(const void* src, int64_t n_src, const int64_t* idx, const void* addend, int64_t n_out, int c, int dtype,
+                                   void* out, ptc_stream_t stream) {
+  PTC_REQUIRE(n_src >= 0 && n_out >= 0 && c >= 1, PTC_EINVAL, "ptc_gather_rows_add: bad sizes");
+  if (n_out == 0) return PTC_OK;
+  PTC_REQUIRE(src && idx && addend && out, PTC_EINVAL, "ptc_gather_rows_add: null buffer");
+  const int w = dtype == PTC_F32 ? 4 : 8;
+  PTC_REQUIRE(c % w == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)addend % 16 == 0 && (uintptr_t)out % 16 == 0, PTC_EUNSUPPORTED,
+              "ptc_gather_rows_add: rows of whole 16-byte lanes only (c=%d)", c);
+  int64_t grid = ptc_cdiv(n_out * (c / w), 256);
+  if (grid > 256 * 32) grid = 256 * 32;
+  PTC_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_rows_add_kernel<T>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, idx,
+                                                  (const T*)addend, n_out, c, (T*)out));
+  PTC_CHECK_LAUNCH("gather_rows_add_kernel");
+  return PTC_OK;
+}
+
 template <typename T>
 static int launch_gather_rows(const void* src, const int64_t* idx, const int64_t* idx2, int64_t n_out, int c,
                               void* out, hipStream_t s) {

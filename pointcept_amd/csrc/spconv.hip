@@ -218,6 +218,7 @@ static int dispatch_fwd(const void* in, const void* w, const float* bias, const 
 #include "conv3.h"
 #include "conv5.h"
 #include "conv7.h"
+#include "conv8.h"
 #include "wgrad7.h"
 
 extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, const float* bias, const int32_t* nbr,
@@ -253,6 +254,20 @@ extern "C" int ptc_spconv_fwd_blk(const void* in, int64_t n_in, const void* weig
                                   const void* tab, const int32_t* hid, const int32_t* hcnt, int bm, int hcap, int64_t n_out, int kv,
                                   int c_in, int c_out, int dtype, void* out, ptc_stream_t stream) {
   const bool buf_ok = (uint64_t)n_in * (uint64_t)c_in * ptc_dtype_size(dtype) <= PTC_BUF_MAX_BYTES;
+  // round 6: the wide shapes (c_in >= 96) on the block-staged kernel with streamed weights (conv8.h) -- OPT-IN (PTC_CONV8=1): correct
+  // (tests/test_gpu_kernels.py::test_spconv_fwd_block_staged_wide) but measured slower than conv3's global gathers at every shape of the two
+  // backbones (128 -> 96 at N = 819200: 820 vs 561 us; 256 -> 256 at N = 12115: 123 vs 100 us; profiles/r06_j_conv8_stages.txt, the ablation
+  // in r06_k_conv8_ablation.txt and DESIGN 4.2 say why)
+  const char* c8e = getenv("PTC_CONV8");
+  const bool conv8_on = c8e && c8e[0] == '1';
+  if (conv8_on && buf_ok && tab && hid && hcnt && nbr && n_in == n_out && conv8_supported(dtype, kv, c_in, c_out, bm, hcap, n_out)) {
+    PTC_REQUIRE(weight && out && in, PTC_EINVAL, "ptc_spconv_fwd_blk: null buffer");
+    PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)tab % 16 == 0), PTC_EINVAL,
+                "ptc_spconv_fwd_blk: buffers must be 16-byte aligned");
+    if (dtype == PTC_BF16)
+      return launch_conv8<bf16_t>(in, n_in, weight, bias, nbr, (const uint16_t*)tab, hid, hcnt, hcap, n_out, c_in, c_out, out, (hipStream_t)stream);
+    return launch_conv8<f16_t>(in, n_in, weight, bias, nbr, (const uint16_t*)tab, hid, hcnt, hcap, n_out, c_in, c_out, out, (hipStream_t)stream);
+  }
   if (!buf_ok || !tab || !hid || !hcnt || !nbr || n_in != n_out || !conv7_supported(dtype, kv, c_in, c_out, bm, hcap, n_out))
     return ptc_spconv_fwd(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, dtype, out, stream);
   PTC_REQUIRE(weight && out && in, PTC_EINVAL, "ptc_spconv_fwd_blk: null buffer");
@@ -670,7 +685,7 @@ static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const i
     rc = launch_wgrad2_inst<T, COT, CIT, KG>(p, in, n_in, dout, nbr, n_out, kv, c_in, c_out, partial, bias_partial, s, gate);
   W2_CASE(2, 1, 1) W2_CASE(2, 2, 1) W2_CASE(2, 4, 1) W2_CASE(4, 1, 1) W2_CASE(4, 2, 1) W2_CASE(4, 4, 1)
   W2_CASE(6, 1, 1) W2_CASE(6, 2, 1) W2_CASE(6, 4, 1) W2_CASE(8, 1, 1) W2_CASE(8, 2, 1)   // (8, 4, 1): never planned (w2_plan caps 64-wide input tiles at 64 outputs), spilled
-  W2_CASE(2, 1, 16) W2_CASE(2, 2, 4) W2_CASE(4, 2, 4) W2_CASE(2, 4, 4) W2_CASE(4, 4, 2) W2_CASE(6, 2, 2)
+  W2_CASE(2, 1, 8) W2_CASE(2, 2, 4) W2_CASE(4, 2, 4) W2_CASE(2, 4, 4) W2_CASE(4, 4, 2) W2_CASE(6, 2, 2)
 #undef W2_CASE
   if (rc != PTC_OK) {
     if (rc == PTC_EUNSUPPORTED) ptc_set_error("ptc_spconv_wgrad: no wgrad2 instance for tiles (%d,%d,%d)", p.cot, p.cit, p.kg);

@@ -67,6 +67,10 @@ __device__ __forceinline__ void w2_wave_sync() {
 template <int COT, int CIT, int KG>
 struct W2Pipe { static constexpr bool value = KG * COT * CIT * 4 + 4 * (COT + KG * CIT) + 4 * (COT + CIT) <= 208; };
 
+// the (.., 1, 8) instances are the PAIR form of wgrad2_body.inc (c_in = 8: two table rows per 16-column tile); planned for c_in == 8 only
+template <int CIT, int KG>
+struct W2Pair { static constexpr bool value = CIT == 1 && KG == 8; };
+
 template <typename T, int COT, int CIT, int KG>
 __global__ void __launch_bounds__(256, 2)   // two waves per SIMD: <= 256 registers
 wgrad2_kernel(const T* __restrict__ in, const T* __restrict__ dout, const int32_t* __restrict__ nbr, int64_t n_out, int kv,
@@ -149,7 +153,7 @@ static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out, bool wa
   if (p.cit > cit_max) p.cit = cit_max;
   p.kg = 1;
   if (kv > 1 && !want_bias) {  // instantiated groups (register budget: KG*COT*CIT*4 accumulators)
-    if (p.cot == 2 && p.cit == 1) p.kg = 16;
+    if (p.cot == 2 && p.cit == 1 && c_in == 8) p.kg = 8;    // PAIR: 8 tiles of two table rows each = 16 table rows per group, step-ahead prefetch fits (W2Pipe)
     else if (p.cot == 2 && p.cit == 2) p.kg = 4;   // (2,2,9) cannot hold the step-ahead prefetch in registers
     else if (p.cot == 4 && p.cit == 2) p.kg = 4;
     else if (p.cot == 2 && p.cit == 4) p.kg = 4;
@@ -158,7 +162,7 @@ static inline W2Plan w2_plan(int64_t n_out, int kv, int c_in, int c_out, bool wa
   }
   p.co_blocks = (int)ptc_cdiv(c_out, p.cot * 16);
   p.ci_blocks = (int)ptc_cdiv(c_in, p.cit * 16);
-  p.groups = (int)ptc_cdiv(kv, p.kg);
+  p.groups = (int)ptc_cdiv(kv, (p.cit == 1 && p.kg == 8) ? 16 : p.kg);
   const int64_t steps = ptc_cdiv(n_out, W2_ROWS);
   int64_t gx = (int64_t)target_wgs / ((int64_t)p.groups * p.co_blocks * p.ci_blocks);
   const int64_t max_gx = ptc_cdiv(steps, min_steps > 0 ? min_steps : 16);  // at least ~4 steps per wave

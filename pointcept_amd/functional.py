@@ -234,6 +234,31 @@ class _GatherByCluster(Function):
         return gsrc, None, None, None
 
 
+class _GatherByClusterAdd(Function):
+    """addend + src[cluster] in one kernel; the gradient of the addend is the incoming gradient itself"""
+
+    @staticmethod
+    def forward(ctx, src, cluster, perm, indptr, addend):
+        ctx.save_for_backward(perm, indptr)
+        return ops.gather_rows_add(src, cluster, addend)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        perm, indptr = ctx.saved_tensors
+        grad = grad.contiguous()
+        gsrc, _ = ops.segment_csr_fwd(grad, perm, indptr, "sum")
+        return gsrc, None, None, None, grad
+
+
+def gather_by_cluster_add(addend: torch.Tensor, src: torch.Tensor, cluster: torch.Tensor, perm: torch.Tensor, indptr: torch.Tensor):
+    """addend + src[cluster] (SerializedUnpooling, ptv3m1:478: `parent.feat + point.feat[inverse]`) -- one pass where the kernel serves the
+    shape (same 16-bit / fp32 dtype on both sides, rows of whole 16-byte lanes), the gather followed by torch's add otherwise."""
+    if ops.gather_rows_add_supported(src, addend) and addend.shape[0] == cluster.numel():
+        return _GatherByClusterAdd.apply(src, cluster, perm, indptr, addend)
+    return addend + gather_by_cluster(src, cluster, perm, indptr)
+
+
 def gather_by_cluster(src: torch.Tensor, cluster: torch.Tensor, perm: torch.Tensor, indptr: torch.Tensor):
     """out[p] = src[cluster[p]] (SerializedUnpooling, ptv3m1:478).  Backward = segmented sum over
     the cluster CSR (perm = points sorted by cluster, indptr = idx_ptr)."""

@@ -397,6 +397,24 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, idx2: Optional[torch.Tenso
     return out
 
 
+def gather_rows_add_supported(src: torch.Tensor, addend: torch.Tensor) -> bool:
+    return (src.dim() == 2 and addend.dim() == 2 and src.dtype == addend.dtype and src.shape[1] == addend.shape[1]
+            and src.dtype in (torch.float32, torch.bfloat16, torch.float16) and src.shape[1] % (4 if src.dtype == torch.float32 else 8) == 0)
+
+
+def gather_rows_add(src: torch.Tensor, idx: torch.Tensor, addend: torch.Tensor) -> torch.Tensor:
+    """out[i] = addend[i] + src[idx[i]] in one pass (SerializedUnpooling, ptv3m1:478)."""
+    require_cuda(src, idx, addend)
+    if not gather_rows_add_supported(src, addend) or addend.shape[0] != idx.numel():
+        raise PtcoreError(f"gather_rows_add: src {tuple(src.shape)} {src.dtype}, addend {tuple(addend.shape)} {addend.dtype}, idx {tuple(idx.shape)}")
+    src, addend = src.contiguous(), addend.contiguous()
+    idx = idx.to(torch.int64).contiguous()
+    out = torch.empty_like(addend)
+    check(lib().ptc_gather_rows_add(ptr(src), src.shape[0], ptr(idx), ptr(addend), idx.numel(), src.shape[1], dtype_code(src), ptr(out), stream_ptr()),
+          "ptc_gather_rows_add")
+    return out
+
+
 def segment_csr_fwd(src: torch.Tensor, perm: Optional[torch.Tensor], indptr: torch.Tensor, reduce: str):
     """out[s] = reduce_{r in [indptr[s], indptr[s+1])} src[perm[r]]; returns (out, arg|None)."""
     require_cuda(src, perm, indptr)
@@ -529,7 +547,10 @@ class BlockProvider:
         tables there; the sliced weight gradient of the wider shapes asks with conv=False from the backward, so inference, eval and
         PTC_WGRAD_BLK=0 never pay the table build (one launch + ~112 B per row) for a kernel that cannot use it."""
         plan = block_plan(c_in, c_out, self.nbr.shape[0], dtype, self.nbr.shape[1])
-        if plan is None or not self.nbr.is_cuda or (conv and not (c_in == c_out and c_in in (32, 64))):
+        from . import config
+
+        conv_kernel = (c_in == c_out and c_in in (32, 64)) or (config.CONV8 and c_in >= 96)      # conv7 | conv8 (round 6: c_in % 32 == 0 from 96 up)
+        if plan is None or not self.nbr.is_cuda or (conv and not conv_kernel):
             return None
         t = self.tables.get(plan)
         if t is None:

@@ -573,10 +573,10 @@ class SerializedPooling(PointModule):
             cluster, idx_ptr, head = ops.pool_maps(code[0], order0, shift, None if known is None else known[-1])
             child_code = ops.pool_child_codes(code, head, shift)                    # ptv3m1:398
             depth = point.serialized_depth - pooling_depth
+            if self.shuffle_orders:       # ptv3m1:408-412; the rows are sorted independently: permuting the codes FIRST gives the permuted
+                perm = torch.randperm(child_code.shape[0])                          # order / inverse rows without gathering them (CPU RNG, ptv3m1:409)
+                child_code = child_code[perm]
             order, inverse = ops.sort_keys(child_code, 0, depth * 3 + len(offset_host).bit_length())  # :399-406
-            if self.shuffle_orders:
-                perm = torch.randperm(child_code.shape[0])                          # ptv3m1:409 (CPU RNG)
-                child_code, order, inverse = child_code[perm], order[perm], inverse[perm]
             grid_coord = point.grid_coord[head] >> pooling_depth
             batch = point.batch[head]
         point_dict = AttrDict(
@@ -629,7 +629,7 @@ class SerializedUnpooling(PointModule):
         point = self.proj(point)
         parent = self.proj_skip(parent)
         # ptv3m1:478 -- note: parent.sparse_conv_feat is NOT refreshed here (Appendix D.1)
-        parent.feat = parent.feat + PF.gather_by_cluster(point.feat, inverse, perm, idx_ptr)
+        parent.feat = PF.gather_by_cluster_add(parent.feat, point.feat, inverse, perm, idx_ptr)
         if self.traceable:
             parent["unpooling_parent"] = point
         return parent

@@ -141,11 +141,15 @@ class Point(_RefPoint if _RefPoint is not None else AttrDict):
         nb = len(offset_host).bit_length()
         assert depth * 3 + nb <= 63  # structure.py:77
         assert depth <= 16            # structure.py:82
-        code = ops.serialize_encode(self.grid_coord, self.batch, depth, order)
-        sorted_order, inverse = ops.sort_keys(code, 0, depth * 3 + nb)
+        # shuffle_orders (structure.py:102-106: code / order / inverse rows permuted by a CPU randperm) without its three row gathers of
+        # [k, N] int64 tensors: every row is a function of its own order name alone, so encoding and sorting the names in permuted order
+        # IS the permuted result (same generator, same draw)
+        enc_order = order
         if shuffle_orders:
-            perm = torch.randperm(code.shape[0])  # CPU default generator, as structure.py:103
-            code, sorted_order, inverse = code[perm], sorted_order[perm], inverse[perm]
+            perm = torch.randperm(len(order))  # CPU default generator, as structure.py:103
+            enc_order = [order[int(p)] for p in perm]
+        code = ops.serialize_encode(self.grid_coord, self.batch, depth, enc_order)
+        sorted_order, inverse = ops.sort_keys(code, 0, depth * 3 + nb)
         self["serialized_code"] = code
         self["serialized_order"] = sorted_order
         self["serialized_inverse"] = inverse

@@ -463,5 +463,14 @@ static inline emu_i32x4 emu_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int v
   }
   return v;
 }
+static inline int emu_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  const uint64_t o = (uint64_t)((uint32_t)voff + (uint32_t)soff);
+  int w = 0;
+  ++emu::S().n_buf;
+  if (o + 4 <= r.num_records) memcpy(&w, r.base + o, 4);
+  else ++emu::S().n_buf_oob;
+  return w;
+}
+#define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, a) emu_raw_buffer_load_b32((r), (v), (s), (a))
 #define __builtin_amdgcn_make_buffer_rsrc(p, s, n, f) emu_make_rsrc((p), (s), (n), (f))
 #define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, a) emu_raw_buffer_load_b128((r), (v), (s), (a))

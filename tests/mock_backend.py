@@ -417,7 +417,7 @@ _STANDINS = dict(
     edge_rows=edge_rows, edge_reduce=edge_reduce, EdgeCSR=EdgeCSR, edge_scatter_bwd=edge_scatter_bwd, aggregation_edge_bwd=aggregation_edge_bwd,
     pair_dot_weighted=pair_dot_weighted, pair_segment_sum=pair_segment_sum,
     cross_entropy_bwd=cross_entropy_bwd, lovasz_softmax=lovasz_softmax, column_sum=column_sum, voxel_keys=voxel_keys,
-    layer_norm_supported=lambda c: False, layer_norm_joint_available=lambda c: False, layer_norm_available=lambda c: c % 2 == 0 and c <= 1024, layer_norm_fwd=layer_norm_fwd, layer_norm_bwd=layer_norm_bwd, batch_norm_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)
+    layer_norm_supported=lambda c: False, layer_norm_joint_available=lambda c: False, layer_norm_available=lambda c: c % 2 == 0 and c <= 1024, layer_norm_fwd=layer_norm_fwd, layer_norm_bwd=layer_norm_bwd, batch_norm_supported=lambda c, dt: False, gather_rows_add_supported=lambda s_, a_: False, mlp_supported=lambda c, dt: False, linear_supported_ex=lambda a, b, dt: False)
 
 
 @contextlib.contextmanager

@@ -542,10 +542,19 @@ def test_ptv3_base_b8_equals_the_sum_of_its_scenes(cuda):
     scenes = [sc for sc, d in zip(cand, depths) if d == common][:8]
     assert len(scenes) == 8, depths
     del cand
-    orc_b, eng_b = _pair(BASE, seed=7)
+    _batch_equals_the_sum_of_its_scenes(cuda, scenes, BASE, 20, f"PT-v3m1 base, 8 x {_n(102400)} voxels", "fullsize_ptv3_b8_linearity.txt")
+
+
+def _batch_equals_the_sum_of_its_scenes(cuda, scenes, cfg, n_cls, title, report):
+    from oracle import ptv3_model as om
+    from pointcept_amd import synthetic
+    from pointcept_amd.segmentor import DefaultSegmentorV2
+
+    on_gpu = torch.device(cuda).type == "cuda"
+    orc_b, eng_b = _pair(cfg, seed=7)
     torch.manual_seed(1)
-    orc = om.SegmentorV2(20, 64, orc_b).eval()
-    eng = DefaultSegmentorV2(20, 64, eng_b)
+    orc = om.SegmentorV2(n_cls, 64, orc_b).eval()
+    eng = DefaultSegmentorV2(n_cls, 64, eng_b)
     eng.seg_head.load_state_dict(orc.seg_head.state_dict())
     eng = eng.to(cuda).eval()
 
@@ -574,7 +583,7 @@ def test_ptv3_base_b8_equals_the_sum_of_its_scenes(cuda):
     stages, worst = _stage_distances(g8, sum_g, _stage_of)
     same_rows = float((logits8 == logits1).all(1).float().mean())
     l_rel = abs(l8 - acc_l / nv8) / abs(l8)
-    lines = [f"PT-v3m1 base, 8 x {_n(102400)} voxels, eval-mode BatchNorm, CE, bf16 autocast: B = 8 vs the n_valid-weighted sum of eight B = 1 runs",
+    lines = [f"{title}, eval-mode BatchNorm, CE, bf16 autocast: B = {len(scenes)} vs the n_valid-weighted sum of its B = 1 runs",
              f"loss B8 {l8:.7f}  sum {acc_l / nv8:.7f}  rel {l_rel:.2e}; logits rel_max {_rel_max(logits8, logits1):.3e}, rows bit-identical {same_rows:.4f}"]
     lines += [f"   {k:10s} {v:.3e}" for k, v in stages.items()]
     lines += [f"   worst {r:.3e} (|g| {n_:.3e}) {name}" for r, n_, name in worst[:3]]
@@ -590,10 +599,33 @@ def test_ptv3_base_b8_equals_the_sum_of_its_scenes(cuda):
     lines += [f"scene 0 (B = 1) vs fp32 CPU oracle: loss {first[0]:.6f} / {lo:.6f} rel {abs(first[0] - lo) / abs(lo):.2e}; logits rel_max "
               f"{_rel_max(first[1], out_o['seg_logits']):.3e} rel_fro {_rel_fro(first[1], out_o['seg_logits']):.3e} argmax {agree:.4f}"]
     lines += [f"   {k:10s} {v:.3e}" for k, v in o_stages.items()]
-    _report("fullsize_ptv3_b8_linearity.txt", lines)
+    _report(report, lines)
     assert l_rel < 1e-5, lines[1]
     assert _rel_max(logits8, logits1) < 1e-2, lines[1]          # measured: see profiles/r05_*_fullsize_ptv3_b8_linearity.txt
     assert max(stages.values()) < 1e-2, stages
     assert abs(first[0] - lo) < 5e-3 * abs(lo)
     assert _rel_fro(first[1], out_o["seg_logits"]) < 3e-2 and agree > 0.97
     assert max(o_stages.values()) < (6e-2 if on_gpu else 5e-3), o_stages
+
+
+def test_ptv3_outdoor_batch_equals_the_sum_of_its_scenes(cuda):
+    """BASELINE configs[4] (outdoor LiDAR, ~180 k voxels per scene, depth-12 grid: nuscenes/semseg-pt-v3m1-0-base.py:16,122
+    -- in_channels 4, 16 classes) forward AND backward in the driver-run suite, by the linearity identity of the indoor test above: in eval
+    mode with CE a batch of outdoor sweeps equals the n_valid-weighted sum of its scenes run alone (logits row by row, loss, every stage's
+    gradient), and scene 0 alone is pinned to the fp32 CPU oracle -- loss, logits, per-stage gradients.  The scenes are the bench's own
+    generator (`synthetic.outdoor_scene(seed, azimuth_steps=3300)`), picked to share one serialization depth."""
+    from pointcept_amd import synthetic
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    full = SCALE >= 1.0
+    cand = [synthetic.outdoor_scene(5000 + i, azimuth_steps=3300) if full else synthetic.outdoor_scene(5000 + i, _n(180000)) for i in range(5)]
+    depths = [int(sc["grid_coord"].max()).bit_length() for sc in cand]
+    common = max(set(depths), key=depths.count)
+    scenes = [sc for sc, d in zip(cand, depths) if d == common][:2]
+    assert len(scenes) == 2, depths
+    n0 = scenes[0]["grid_coord"].shape[0]
+    assert not full or (n0 >= 150000 and common >= 12), (n0, common)
+    del cand
+    _batch_equals_the_sum_of_its_scenes(cuda, scenes, dict(BASE, in_channels=4), 16, f"PT-v3m1 base outdoor (in_channels 4, 16 classes), 2 x ~{n0} voxels, depth {common}",
+                                        "fullsize_ptv3_outdoor_linearity.txt")
+

@@ -469,6 +469,51 @@ def test_spconv_fwd_block_staged(cuda, c, ordered, n_rows=35000):
         _close(f"conv7_nobias_{dtype}", nb, ref - bias, rtol, atol)
 
 
+@pytest.mark.parametrize("c", [(96, 96), (128, 96), (128, 128), (256, 256), (224, 96), (192, 64), (512, 512), (96, 32)])
+@pytest.mark.parametrize("ordered", [True, False])
+def test_spconv_fwd_block_staged_wide(cuda, c, ordered, monkeypatch, n_rows=9000):
+    """round 6, conv8 (csrc/conv8.h): the block-staged convolution for rows of 96 channels and more -- halo rows of a 128-row block staged
+    once per 128-channel chunk in LDS, weights streamed per tap through LDS -- at SpUNet's decoder widths (96 / 128 / 224 / 192), PT-v3's
+    deep stages (128 / 256 / 512) and mixed in / out widths: within the 16-bit bar of the fp32 oracle and within fp32 summation-order noise
+    of the global-gather kernel (conv3) on the same table.  The un-ordered case mixes staged blocks with blocks whose halo does not fit
+    (blocks.hip's overflow mark, or more than the image's 288 rows): those take the kernel's global-gather form.  Ragged row count, bf16
+    and f16, with / without bias, bit-reproducible."""
+    from pointcept_amd import ops
+
+    monkeypatch.setenv("PTC_CONV8", "1")       # opt-in kernel (slower than conv3 at the shapes measured: profiles/r06_j_conv8_stages.txt)
+    c_in, c_out = c
+    if c_in >= 512:
+        n_rows = min(n_rows, 3000)
+    ind = _curve_sorted_indices(n_rows)
+    if not ordered:
+        rng = np.random.default_rng(c_in + c_out)
+        h = ind.shape[0] // 2
+        ind = np.concatenate([ind[:h], ind[h:][rng.permutation(ind.shape[0] - h)]])
+    nbr = oops.subm_rulebook(ind, 3)
+    n = nbr.shape[1]
+    assert ops.block_plan(c_in, c_out, 27, torch.bfloat16, n) is not None
+    nbr_d = _t(nbr, cuda)
+    bt = ops.BlockTables(nbr_d)
+    assert (int(bt.n_overflow.item()) == 0) == ordered
+    g = torch.Generator().manual_seed(c_in * 131 + c_out)
+    for dtype in (torch.bfloat16, torch.float16):
+        feat = (torch.randn(n, c_in, generator=g) * 0.5).to(dtype)
+        w = (torch.randn(c_out, 27, c_in, generator=g) / (27 * c_in) ** 0.5 * 2).to(dtype)
+        bias = torch.randn(c_out, generator=g)
+        base = ops.spconv_fwd(feat.to(cuda), w.to(cuda), bias.to(cuda), nbr_d)
+        got = ops.spconv_fwd(feat.to(cuda), w.to(cuda), bias.to(cuda), nbr_d, bt)
+        assert torch.isfinite(got.float()).all()
+        ref = oops.gather_conv(feat.float(), w.float(), bias, nbr)
+        rtol, atol = _tols(dtype)
+        _close(f"conv8_{dtype}", got, ref, rtol, atol)
+        ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+        assert float((got.float() - base.float()).abs().max()) <= 2 * ulp * float(ref.abs().max())
+        assert torch.equal(got, ops.spconv_fwd(feat.to(cuda), w.to(cuda), bias.to(cuda), nbr_d, bt)), "conv8 must be bit-reproducible"
+        if dtype == torch.bfloat16:
+            nb = ops.spconv_fwd(feat.to(cuda), w.to(cuda), None, nbr_d, bt)
+            _close(f"conv8_nobias_{dtype}", nb, ref - bias, rtol, atol)
+
+
 @pytest.mark.parametrize("c", [32, 64, 128, (128, 96), 256, (192, 64), 96, (32, 64), (96, 32)])
 @pytest.mark.parametrize("ordered", [True, False])
 def test_spconv_wgrad_block_staged(cuda, c, ordered, n_rows=35000):
@@ -728,6 +773,36 @@ def test_linear_with_the_residual_joint_in_its_epilogue(cuda, dtype, cin, cout):
             z2, y2, sa2, sb2 = ops.add_norm_fwd(u2, res, None, (ga2, be2, 1e-6), norm, dtype)
             assert torch.equal(u, u2) and torch.equal(z, z2) and torch.equal(y, y2) and torch.equal(sa, sa2), (res.dtype, norm is not None)
             assert (sb is None) == (sb2 is None) and (sb is None or torch.equal(sb, sb2))
+
+
+@pytest.mark.parametrize("dtype,c", [(torch.bfloat16, 64), (torch.float16, 32), (torch.float32, 20), (torch.bfloat16, 36)])
+def test_unpooling_gather_with_addend(cuda, dtype, c):
+    """round 6: SerializedUnpooling's `parent.feat + point.feat[inverse]` (ptv3m1:478) as ONE pass (ptc_gather_rows_add) -- bit-identical to
+    the gather kernel followed by torch's add (one rounding of the fp32 sum either way); gradients: the addend's is the incoming gradient,
+    the source's the segmented sum over the cluster CSR.  Widths that are no multiple of a 16-byte lane keep the two-pass form."""
+    from pointcept_amd import functional as PF
+    from pointcept_amd import ops
+
+    g = torch.Generator().manual_seed(c)
+    n_par, n_child = 5003, 1201
+    cluster = torch.randint(0, n_child, (n_par,), generator=g)
+    perm = torch.argsort(cluster, stable=True)
+    indptr = torch.zeros(n_child + 1, dtype=torch.int64)
+    indptr[1:] = torch.cumsum(torch.bincount(cluster, minlength=n_child), 0)
+    src = torch.randn(n_child, c, generator=g).to(dtype)
+    add = torch.randn(n_par, c, generator=g).to(dtype)
+    dy = torch.randn(n_par, c, generator=g).to(dtype)
+    s1, a1 = src.to(cuda).requires_grad_(True), add.to(cuda).requires_grad_(True)
+    y = PF.gather_by_cluster_add(a1, s1, cluster.to(cuda), perm.to(cuda), indptr.to(cuda))
+    y.backward(dy.to(cuda))
+    s2, a2 = src.to(cuda).requires_grad_(True), add.to(cuda).requires_grad_(True)
+    y2 = a2 + PF.gather_by_cluster(s2, cluster.to(cuda), perm.to(cuda), indptr.to(cuda))
+    y2.backward(dy.to(cuda))
+    assert torch.equal(y, y2) and torch.equal(a1.grad, a2.grad) and torch.equal(s1.grad, s2.grad)
+    ref = add.float() + src.float()[cluster]
+    assert torch.equal(y.detach().cpu(), ref.to(dtype))
+    if torch.device(cuda).type == "cuda" or dtype != torch.float32 or c % 4 == 0:
+        assert ops.gather_rows_add_supported(s1, a1) == (c % (4 if dtype == torch.float32 else 8) == 0)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

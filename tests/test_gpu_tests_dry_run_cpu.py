@@ -36,7 +36,8 @@ def test_gpu_spunet_test_bodies_on_cpu_standins(name):
 FULLSIZE_TESTS = ["test_ptv3_base_one_full_scene_maps_and_logits", "test_ptv3_base_two_ragged_full_scenes_padding_borrow",
                   "test_ptv3_base_train_step_gradients_vs_oracle",
                   "test_spunet_base_one_full_scene_forward", "test_ptv3_outdoor_full_scene_forward",
-                  "test_spunet_base_two_full_scenes_train_step_vs_oracle", "test_ptv3_base_b8_equals_the_sum_of_its_scenes"]
+                  "test_spunet_base_two_full_scenes_train_step_vs_oracle", "test_ptv3_base_b8_equals_the_sum_of_its_scenes",
+                  "test_ptv3_outdoor_batch_equals_the_sum_of_its_scenes"]
 
 
 @pytest.mark.parametrize("name", FULLSIZE_TESTS)

@@ -210,6 +210,7 @@ EMULATED_GPU_TESTS = [
     ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.bfloat16, cin=128, cout=128)),
     ("test_mlp_one_kernel_per_direction", dict(dtype=torch.bfloat16, c=64, n=1100)), ("test_mlp_one_kernel_per_direction", dict(dtype=torch.float16, c=32, n=1100)),
     ("test_mlp_one_kernel_per_direction", dict(dtype=torch.bfloat16, c=32, n=129)), ("test_mlp_one_kernel_per_direction", dict(dtype=torch.float16, c=64, n=100)),
+    ("test_unpooling_gather_with_addend", dict(dtype=torch.bfloat16, c=64)), ("test_unpooling_gather_with_addend", dict(dtype=torch.float32, c=20)),
     ("test_linear_identity_table", dict(dtype=torch.float32, n=1000, cin=32, cout=64)),
     ("test_linear_identity_table", dict(dtype=torch.bfloat16, n=300, cin=72, cout=288)), ("test_linear_identity_table", dict(dtype=torch.bfloat16, n=300, cin=288, cout=72)),
     ("test_linear_identity_table", dict(dtype=torch.float16, n=200, cin=432, cout=108)), ("test_linear_identity_table", dict(dtype=torch.bfloat16, n=150, cin=1008, cout=252)),
@@ -221,6 +222,7 @@ EMULATED_GPU_TESTS = [
     ("test_sort_keys_at_the_packing_boundary", dict(n=8193)),
     ("test_rulebook_blocks", dict(ordered=True)), ("test_spconv_fwd_block_staged", dict(c=64, ordered=True, n_rows=2100)),
     ("test_spconv_fwd_block_staged", dict(c=32, ordered=False, n_rows=2100)),
+    ("test_spconv_fwd_block_staged_wide", dict(c=(224, 96), ordered=False, n_rows=700)),      # conv8 (opt-in): two chunks, staged + overflow blocks
     ("test_spconv_wgrad_block_staged", dict(c=64, ordered=True, n_rows=1600)), ("test_spconv_wgrad_block_staged", dict(c=32, ordered=True, n_rows=1600)),
     ("test_spconv_wgrad_block_staged", dict(c=64, ordered=False, n_rows=1600)),
     ("test_spconv_wgrad_block_staged", dict(c=(128, 96), ordered=True, n_rows=1150)),     # channel slices on both sides (c = 96 alone: GPU suite)
