@@ -199,7 +199,9 @@ int ptc_rulebook_subm(const int32_t* indices, int64_t n, int ksize, const void* 
                       int32_t* nbr, ptc_stream_t stream);
 /* Strided k=2,s=2 (SparseConv3d at spconv_unet_v1m1_base.py:137-144).
  * Phase 1: out_of_in[n_in] int32 = coarse row of each fine row, numbering = ascending
- *          (batch, x>>1, y>>1, z>>1) linear key; *n_out_dev (device int64) = number of coarse rows.
+ *          (batch, Morton code of (x>>1, y>>1, z>>1): bit i of x at 3i+2, y at 3i+1, z at 3i) -- consecutive coarse
+ *          rows are spatial neighbours (round 6; spconv's own numbering is hash-insertion order);
+ *          *n_out_dev (device int64) = number of coarse rows.
  *          coord_bits: every (coord>>1) < 2^coord_bits; batch_bits: every batch < 2^batch_bits
  *          (host derives both from spatial_shape / batch_size; they only bound the sort passes).
  * Phase 2: out_indices[n_out,4] int32, nbr_down[8][n_out] int32 (gather table of the down conv,

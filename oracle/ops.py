@@ -46,14 +46,25 @@ def subm_rulebook(indices: np.ndarray, ksize: int) -> np.ndarray:
     return nbr
 
 
+def _spread3(v: np.ndarray) -> np.ndarray:
+    """bit i of v (21 bits) -> bit 3 i"""
+    out = np.zeros_like(v, dtype=np.int64)
+    for i in range(21):
+        out |= ((v >> i) & 1) << (3 * i)
+    return out
+
+
 def down_rulebook(indices: np.ndarray):
-    """k=2 s=2: coarse sites = unique (b, x>>1, y>>1, z>>1) in ascending lexicographic order.
+    """k=2 s=2: coarse sites = unique (b, x>>1, y>>1, z>>1), numbered by ascending (b, Morton code of the coarse coordinate: bit i of
+    x at 3 i + 2, of y at 3 i + 1, of z at 3 i).  spconv numbers its output sites in hash-insertion order (SparseConv3d behind
+    spconv_unet_v1m1_base.py:137-144): nothing downstream may depend on the numbering, so the restatement picks the one whose
+    consecutive rows are spatial neighbours (round 6; before: the lexicographic key).
     Returns out_indices [n_out,4], out_of_in [n_in], nbr_down [8][n_out], nbr_up [8][n_in]."""
     ind = np.asarray(indices, dtype=np.int64)
     n = ind.shape[0]
     c = np.stack([ind[:, 0], ind[:, 1] >> 1, ind[:, 2] >> 1, ind[:, 3] >> 1], axis=1)
-    S = int(c[:, 1:].max()) + 1
-    key = _linear_key(c[:, 0], c[:, 1], c[:, 2], c[:, 3], S)
+    assert n == 0 or (int(c[:, 1:].max()) < (1 << 16) and int(c[:, 0].max()) < (1 << 15))
+    key = (c[:, 0].astype(np.int64) << 48) | (_spread3(c[:, 1]) << 2) | (_spread3(c[:, 2]) << 1) | _spread3(c[:, 3])
     ukeys, first, out_of_in = np.unique(key, return_index=True, return_inverse=True)
     n_out = len(ukeys)
     out_indices = c[first].astype(np.int32)

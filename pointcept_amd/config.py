@@ -23,8 +23,8 @@ settings), and so a regression can be bisected without a rebuild.
   PTC_FUSE_BN_TAIL=0 SpUNet's residual block runs bn2, the residual add and the ReLU as three passes (the reference's form) instead of in
                      the BatchNorm's apply pass (ptc_batch_norm_add_act_*), and every BatchNorm site increments its step counter itself
                      instead of one multi-tensor launch per forward
-  PTC_CONV8=1        3^3 convolutions of 96 channels and more on the block-staged conv8 (round 6; forward and input gradient) instead of
-                     the global-gather kernel conv3.  Off by default: parity-green, but slower than conv3 at every shape measured
+  PTC_CONV8=0        3^3 convolutions of 96 channels and more on the global-gather kernel conv3 instead of the block-staged conv8
+                     (round 6; forward and input gradient; profiles/r06_t_conv8_himg.txt)
   PTC_BLK_MLP_FUSED=0  the MLP of a 32- / 64-channel Block runs on the split kernels (fc1 + GELU, fc2 + joint; GELU' input gradient,
                      fc1 input gradient, two weight gradients) instead of csrc/mlp.hip's one kernel per direction (round 6)
   PTC_FUSE_BLOCK=0   the three residual joints of a PTv3 Block run as separate LayerNorm / add / cast
@@ -47,7 +47,7 @@ SORT_POINTS = _flag("PTC_SORT_POINTS", True)
 FUSE_BLOCK = _flag("PTC_FUSE_BLOCK", True)
 EXEC_BLOCK = _flag("PTC_EXEC_BLOCK", True)
 FUSE_MLP = _flag("PTC_FUSE_MLP", True)
-CONV8 = _flag("PTC_CONV8", False)                     # also read by the C side (ptc_spconv_fwd_blk); opt-in: measured slower than conv3
+CONV8 = _flag("PTC_CONV8", True)                      # also read by the C side (ptc_spconv_fwd_blk)
 MLP_ONE_KERNEL = _flag("PTC_BLK_MLP_FUSED", True)     # the same variable switches the block executor's C side (block_exec.hip)
 PREFETCH_LEVELS = _flag("PTC_PREFETCH_LEVELS", True)
 RPE_KERNEL = _flag("PTC_RPE_KERNEL", True)

@@ -62,7 +62,7 @@ template <typename T, int RT, int KPC, int NTILES, bool GEN, bool IDENT = false,
 __global__ void __launch_bounds__(256, 2)
 conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
              const int32_t* __restrict__ nbr, int64_t n_out, int kv, int c_in, int c_out, int n_rowblk, T* __restrict__ out,
-             uint32_t in_bytes) {
+             uint32_t in_bytes, const int32_t* __restrict__ skip_hcnt, int skip_max) {
   using M = Mma<T>;
   using frag = typename M::frag;
   const __amdgpu_buffer_rsrc_t in_buf = ptc_buf(in, in_bytes);
@@ -74,6 +74,19 @@ conv3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   const int lb = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (lb >= nblk) return;
   const int rb = lb / ny, n0 = (lb - rb * ny) * NT;
+  if (skip_hcnt) {   // follow-up of conv8 (round 6): 128-row blocks whose halo count is in [0, skip_max] were served there
+    const int nb128 = (int)((n_out + 127) >> 7);
+    bool mine = false;
+#pragma unroll
+    for (int q = 0; q < BM / 128; ++q) {
+      const int b = rb * (BM / 128) + q;
+      if (b < nb128) {
+        const int c = skip_hcnt[b];
+        mine |= !(c >= 0 && c <= skip_max);
+      }
+    }
+    if (!mine) return;
+  }
   const int lane = ptc_lane(), wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int64_t row0 = (int64_t)rb * BM + wave * (RT * 16);
@@ -307,6 +320,10 @@ static inline bool conv3_supported(int dtype, int kv, int c_in, int c_out, const
   return !(c_in == 32 && c_out % 64 != 0 && c_out % 96 != 0);
 }
 
+// set around a launch_conv3 call by conv8's launcher (conv8.h): the 128-row blocks with a halo count in [0, c3_skip_max] are skipped
+static thread_local const int32_t* c3_skip_hcnt = nullptr;
+static thread_local int c3_skip_max = 0;
+
 template <typename T, int RT, int KPC, int NTILES, bool GEN, bool IDENT = false, bool DEEP = false>
 static int launch_conv3_i(const void* in, int64_t n_in, const void* w, const float* bias, const int32_t* nbr, int64_t n_out, int kv,
                           int c_in, int c_out, void* out, hipStream_t s) {
@@ -320,7 +337,7 @@ static int launch_conv3_i(const void* in, int64_t n_in, const void* w, const flo
     allowed = lds;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(256), lds, s, (const T*)in, (const T*)w, bias, nbr, n_out, kv,
-                     c_in, c_out, n_rowblk, (T*)out, (uint32_t)((uint64_t)n_in * c_in * sizeof(T)));
+                     c_in, c_out, n_rowblk, (T*)out, (uint32_t)((uint64_t)n_in * c_in * sizeof(T)), c3_skip_hcnt, c3_skip_max);
   PTC_CHECK_LAUNCH("conv3_kernel");
   return PTC_OK;
 }

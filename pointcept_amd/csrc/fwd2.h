@@ -306,18 +306,29 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
         acc[0][t] = *reinterpret_cast<const f32x4*>(bl + h * NT + 16 * gs + 4 * G * g + 4 * (t - gs));
         acc[1][t] = acc[0][t];
       }
+      // FULL (c_in a multiple of 32: every width of PT-v3m1) reads the W fragments unconditionally.  With the per-lane guard `col < c_in`
+      // every ds_read_b128 sat under its own exec mask with s_waitcnt lgkmcnt(0) behind it: one LDS round trip per two MFMAs, nothing
+      // in flight (251 v_mov of zero-initialisation beside 128 MFMAs in the 128-column instance; round 6)
+      auto products = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const int col = s * 32 + g * 8;
-        const T* wrow = wl + (h * NT + r) * pitch + col;
+        for (int s = 0; s < S; ++s) {
+          const int col = s * 32 + g * 8;
+          const T* wrow = wl + (h * NT + r) * pitch + col;
 #pragma unroll
-        for (int t = 0; t < NTILES; ++t) {
-          typename M::frag fw = M::zero();
-          if (col < c_in) fw = ld_frag<T>(wrow + t * 16 * pitch);
-          acc[0][t] = M::mma(fw, ca[s], acc[0][t]);
-          acc[1][t] = M::mma(fw, cb[s], acc[1][t]);
+          for (int t = 0; t < NTILES; ++t) {
+            typename M::frag fw;
+            if constexpr (FULL) fw = ld_frag<T>(wrow + t * 16 * pitch);
+            else {
+              fw = M::zero();
+              if (col < c_in) fw = ld_frag<T>(wrow + t * 16 * pitch);
+            }
+            acc[0][t] = M::mma(fw, ca[s], acc[0][t]);
+            acc[1][t] = M::mma(fw, cb[s], acc[1][t]);
+          }
         }
-      }
+      };
+      if ((c_in & 31) == 0) products(std::true_type{}); else products(std::false_type{});
       if constexpr (LDSS) f2_store_rows_lds<T, NTILES>(acc, oslice, out, tile * F2_ROWS + wave * 32, n_out, c_out, n0 + h * NT, r, g, lane);
       else if constexpr (EPI == 0) sc_epilogue<T, NTILES>(acc, nullptr, out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);
       else f2_epilogue_ex<T, NTILES, EPI>(acc, out, aux_in, aux_out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);

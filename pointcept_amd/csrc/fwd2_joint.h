@@ -104,18 +104,26 @@ linear2_joint_kernel(const T* __restrict__ in, const T* __restrict__ w, const fl
       acc[0][t] = *reinterpret_cast<const f32x4*>(bl + 16 * gs + 4 * G * g + 4 * (t - gs));
       acc[1][t] = acc[0][t];
     }
+    auto products = [&](auto full_c) {                  // (see linear2_kernel: unconditional W reads when c_in is a multiple of 32)
+      constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const int col = s * 32 + g * 8;
-      const T* wrow = wl + r * pitch + col;
+      for (int s = 0; s < S; ++s) {
+        const int col = s * 32 + g * 8;
+        const T* wrow = wl + r * pitch + col;
 #pragma unroll
-      for (int t = 0; t < NTILES; ++t) {
-        typename M::frag fw = M::zero();
-        if (col < c_in) fw = ld_frag<T>(wrow + t * 16 * pitch);
-        acc[0][t] = M::mma(fw, ca[s], acc[0][t]);
-        acc[1][t] = M::mma(fw, cb[s], acc[1][t]);
+        for (int t = 0; t < NTILES; ++t) {
+          typename M::frag fw;
+          if constexpr (FULL) fw = ld_frag<T>(wrow + t * 16 * pitch);
+          else {
+            fw = M::zero();
+            if (col < c_in) fw = ld_frag<T>(wrow + t * 16 * pitch);
+          }
+          acc[0][t] = M::mma(fw, ca[s], acc[0][t]);
+          acc[1][t] = M::mma(fw, cb[s], acc[1][t]);
+        }
       }
-    }
+    };
+    if ((c_in & 31) == 0) products(std::true_type{}); else products(std::false_type{});
     // ---- epilogue: the 16-row halves of this wave's 32 rows through its LDS slice, then the joint in add_norm_fwd_kernel's mapping
     const int64_t row0 = tile * F2_ROWS + wave * 32;
 #pragma unroll

@@ -175,16 +175,29 @@ extern "C" int ptc_rulebook_subm(const int32_t* indices, int64_t n, int ksize, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// strided k=2 s=2 conv: coarse sites = unique (b, x>>1, y>>1, z>>1), ascending packed key
+// strided k=2 s=2 conv: coarse sites = unique (b, x>>1, y>>1, z>>1), numbered by ascending (batch, Morton code of the coarse
+// coordinate).  Round 6: the numbering was the lexicographic (b, x, y, z) key -- rows that follow each other were then neighbours along z
+// only, and a block of 128 consecutive coarse rows named ~600 distinct input rows in its 3^3 neighbourhood (the block-staged kernels'
+// LDS image holds 352 / 416) where a curve order names ~230 (tools/halo_stats.py --stride 2).  spconv's own numbering of the output
+// sites is its hash table's insertion order -- no caller may rely on it; the oracle (oracle/ops.py down_rulebook) numbers the same way.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t down_spread3(uint32_t v) {          // bit i of a 21-bit value -> bit 3 i
+  uint64_t x = v & 0x1fffffu;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
 __global__ void __launch_bounds__(256)
 down_keys_kernel(const int32_t* __restrict__ indices, int64_t n, int cb, int64_t* __restrict__ keys) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int4 c = reinterpret_cast<const int4*>(indices)[i];
-    // lexicographic (b, x>>1, y>>1, z>>1) with cb bits per axis
-    keys[i] = (int64_t)(((((uint64_t)(uint32_t)c.x << cb | (uint64_t)(uint32_t)(c.y >> 1)) << cb) |
-                         (uint64_t)(uint32_t)(c.z >> 1)) << cb | (uint64_t)(uint32_t)(c.w >> 1));
+    // (b, Morton(x>>1, y>>1, z>>1)): bit i of x at 3 i + 2, of y at 3 i + 1, of z at 3 i; cb bits per axis
+    keys[i] = (int64_t)((uint64_t)(uint32_t)c.x << (3 * cb) | down_spread3((uint32_t)(c.y >> 1)) << 2 | down_spread3((uint32_t)(c.z >> 1)) << 1 |
+                        down_spread3((uint32_t)(c.w >> 1)));
   }
 }
 

@@ -259,7 +259,7 @@ extern "C" int ptc_spconv_fwd_blk(const void* in, int64_t n_in, const void* weig
   // backbones (128 -> 96 at N = 819200: 820 vs 561 us; 256 -> 256 at N = 12115: 123 vs 100 us; profiles/r06_j_conv8_stages.txt, the ablation
   // in r06_k_conv8_ablation.txt and DESIGN 4.2 say why)
   const char* c8e = getenv("PTC_CONV8");
-  const bool conv8_on = c8e && c8e[0] == '1';
+  const bool conv8_on = !(c8e && c8e[0] == '0');
   if (conv8_on && buf_ok && tab && hid && hcnt && nbr && n_in == n_out && conv8_supported(dtype, kv, c_in, c_out, bm, hcap, n_out)) {
     PTC_REQUIRE(weight && out && in, PTC_EINVAL, "ptc_spconv_fwd_blk: null buffer");
     PTC_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)weight % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)tab % 16 == 0), PTC_EINVAL,

@@ -208,7 +208,11 @@ def test_oracle_spunet_tiny_matches_reference_golden():
     assert abs(float(out["loss"]) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     out["loss"].backward()
     norms = np.asarray([float(p.grad.double().norm()) for _, p in net.named_parameters()])
-    assert np.allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-7)
+    # 5e-3: the golden is the reference's fp32 run, whose BatchNorm gradient norms sit up to 3.4e-3 from the float64 value of the same
+    # network (cancellation in fp32 sums).  Since round 6 the oracle numbers the coarse sites in Morton order (oracle/ops.py
+    # down_rulebook): in float64 the two numberings agree to 7e-15, in fp32 the summation order differs -- this fp32 run is within 2e-6
+    # of the float64 value, the golden is not.
+    assert np.allclose(norms, g["grad_norms"], rtol=5e-3, atol=1e-7)
     assert np.allclose(net.final.weight.grad.numpy(), g["grad_final"], rtol=1e-3, atol=1e-6)
 
 

@@ -53,8 +53,10 @@ def test_down_and_inverse_conv_match_dense():
     ref = F.conv3d(dense, w.permute(0, 4, 1, 2, 3), None, stride=2)
     lo = torch.from_numpy(out_ind.astype(np.int64))
     assert torch.allclose(out, ref[lo[:, 0], :, lo[:, 1], lo[:, 2], lo[:, 3]], atol=1e-10)
-    # coarse sites: ascending lexicographic, unique, exactly the occupied parents
-    key = ((lo[:, 0] * 100 + lo[:, 1]) * 100 + lo[:, 2]) * 100 + lo[:, 3]
+    # coarse sites: ascending (batch, Morton code), unique, exactly the occupied parents
+    def spread(v):
+        return sum(((v >> i) & 1) << (3 * i) for i in range(8))
+    key = (lo[:, 0] << 30) | (spread(lo[:, 1]) << 2) | (spread(lo[:, 2]) << 1) | spread(lo[:, 3])
     assert bool((key[1:] > key[:-1]).all())
     occ = F.max_pool3d(_dense(torch.ones(len(ind), 1, dtype=torch.float64), li, (10, 10, 10), 2), 2)
     assert int(occ.sum()) == len(out_ind)

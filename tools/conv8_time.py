@@ -53,9 +53,9 @@ def main():
             y = ops.spconv_fwd(x, w, None, nbr, blk)
             nb = (n + 127) // 128
             ph = y.view(-1)[: nb * 128 * c_out].view(nb, 128 * c_out)[:, :32].contiguous().view(torch.int64).double().cpu()     # [block][phase]
-            names = ("prologue", "chunk barrier", "halo store", "W wait+store", "tap barrier", "products", "epilogue")
+            names = ("prologue", "chunk entry", "halo image", "last tap tiles", "epilogue", "tiles + fetch issue", "entry wait", "W wait")
             line += "\n    phases of wave 0, cycles per block (mean over blocks): " + ", ".join(f"{nm} {ph[:, i].mean():.0f}" for i, nm in enumerate(names)) \
-                    + f"; sum {ph[:, :7].sum(1).mean():.0f}"
+                    + f"; sum {ph[:, :8].sum(1).mean():.0f}"
     print(line)
 
 
