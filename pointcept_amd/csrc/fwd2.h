@@ -13,6 +13,9 @@
 //                  workgroups keep W in LDS for their whole life and walk 128-row tiles; the rows of
 //                  tile i+1 (and the table entries of tile i+2) are loaded before tile i is multiplied.
 #pragma once
+#ifndef F2_FULL_PATH
+#define F2_FULL_PATH 1       // 0: timing A/B only (`python -m pointcept_amd.build --variant d_F2_FULL_PATH_0`): the guarded W reads for every width
+#endif
 
 #define F2_ROWS 128
 #define F2_MAX_W_BYTES (40 * 1024)
@@ -328,7 +331,7 @@ linear2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* _
           }
         }
       };
-      if ((c_in & 31) == 0) products(std::true_type{}); else products(std::false_type{});
+      if (F2_FULL_PATH && (c_in & 31) == 0) products(std::true_type{}); else products(std::false_type{});
       if constexpr (LDSS) f2_store_rows_lds<T, NTILES>(acc, oslice, out, tile * F2_ROWS + wave * 32, n_out, c_out, n0 + h * NT, r, g, lane);
       else if constexpr (EPI == 0) sc_epilogue<T, NTILES>(acc, nullptr, out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);
       else f2_epilogue_ex<T, NTILES, EPI>(acc, out, aux_in, aux_out, rowA, rowA + 16, n_out, c_out, n0 + h * NT, g);

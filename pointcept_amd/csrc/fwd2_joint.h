@@ -123,7 +123,7 @@ linear2_joint_kernel(const T* __restrict__ in, const T* __restrict__ w, const fl
         }
       }
     };
-    if ((c_in & 31) == 0) products(std::true_type{}); else products(std::false_type{});
+    if (F2_FULL_PATH && (c_in & 31) == 0) products(std::true_type{}); else products(std::false_type{});
     // ---- epilogue: the 16-row halves of this wave's 32 rows through its LDS slice, then the joint in add_norm_fwd_kernel's mapping
     const int64_t row0 = tile * F2_ROWS + wave * 32;
 #pragma unroll
