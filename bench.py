@@ -204,8 +204,9 @@ def attention_roofline(device, scenes: int, points: int):
 def gather_roofline(device, batch):
     """The gather-table convolution at its largest shape in the model: the CPE convolution of dec0 (SubM k=3,
     64 -> 64 channels, N = all voxels of the batch, rows in curve order as the model keeps them).  HBM-bound by
-    SURVEY 8(d): algorithmic bytes = N C e (in) + N C e (out) + 4 kv N (dense gather table, the format this engine
-    reads) + kv C C e (weights); achieved = those bytes / launch time."""
+    SURVEY 8(d): algorithmic bytes = N C e (in) + N C e (out) + 8 B per (in, out) pair of the rulebook + kv C C e (weights) -- the
+    pair-list formula; achieved = those bytes / launch time (the bytes of the block-local tables the kernel really reads are
+    reported beside it).  `wide` (round 6): the same rulebook at 128 -> 96 channels on conv8, priced against the MFMA peak."""
     from pointcept_amd import ops
 
     gc, off = batch["grid_coord"], batch["offset"]
@@ -241,6 +242,24 @@ def gather_roofline(device, batch):
            "frac_with_block_tables": round(nbytes_blk / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
            "global_gather_kernel_launch_ms": round(ms_global, 4),
            "useful_tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+    # round 6: the same rulebook at SpUNet's widest level-0 shape (decoder block: 128 -> 96) on conv8, the block-staged kernel for rows of
+    # 96 channels and more -- MFMA-bound by SURVEY 8(d) (2 x pairs x c_in x c_out useful flops); conv3's global gathers beside it
+    try:
+        ci, co = 128, 96
+        xw = torch.randn(n, ci, generator=g).to(torch.bfloat16).to(device)
+        ww = (torch.randn(co, kv, ci, generator=g) * 0.03).to(torch.bfloat16).to(device)
+        bw = torch.zeros(co, device=device)
+        ms_w = _time_launches(lambda: ops.spconv_fwd(xw, ww, bw, nbr, blk), iters=10, warm=3)
+        ms_w3 = _time_launches(lambda: ops.spconv_fwd(xw, ww, bw, nbr), iters=5, warm=2)
+        fl = 2.0 * pairs * ci * co
+        out["wide"] = {"kernel": "conv8_kernel (SubM k=3, 128->96, SpUNet decoder level 0) + its conv3 follow-up for blocks whose halo does not fit",
+                       "bound": "mfma", "achieved": round(fl / (ms_w * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(fl / (ms_w * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "launch_ms": round(ms_w, 4),
+                       "algorithmic_flops_per_launch": fl, "global_gather_kernel_launch_ms": round(ms_w3, 4),
+                       "blocks_beyond_the_lds_image": int(((blk.hcnt < 0) | (blk.hcnt > 352)).sum().item()), "blocks": int(blk.hcnt.numel())}
+        del xw, ww
+    except Exception as e:       # (never takes the headline down)
+        out["wide"] = {"error": repr(e)[:200]}
     try:
         pm = _latest_profile("*conv_pmc_s0.json")
         ks = json.load(open(pm))["kernels"]

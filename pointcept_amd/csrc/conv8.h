@@ -30,6 +30,10 @@
 // image, two 4-wave workgroups per CU: 790 us, 682 with every prefetch a raw buffer load (as plain loads behind a select the compiler
 // serialised them: s_waitcnt vmcnt(0) after each); phase timers: 55 % products at ~20 % matrix-pipe occupancy, 23 % waiting at the
 // per-tap barrier for the row half with more neighbours, 12 % waiting for W.
+// Measured and dropped (profiles/r06_ab_*, r06_ac_*): three workgroups per CU (168 registers + 72 bytes of scratch: 1-5 %); 64- / 32-column
+// workgroups at c_out = 128 / 96 (3-20 % slower: more weight traffic per row); weights three taps ahead (no change); the B fragments of tap
+// k + 1 read tile by tile behind the products of the same tile of tap k (a software pipeline over the taps: 2-7 % SLOWER -- the entries of
+// the next tap then sit behind those reads in the LDS queue and the wait for them drains it).
 // Output-stationary, fixed summation order (chunk-major, taps ascending, 32-channel steps ascending): bit-reproducible.  The order differs
 // from conv3's (tap-major): results agree to fp32 summation order, not bit for bit.
 #pragma once

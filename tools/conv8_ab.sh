@@ -1,8 +1,9 @@
-# conv8 A/B session: kernel timings per library variant, then the SpUNet / PT-v3 steps with PTC_CONV8=0 | 1, then the tests that touch it
+# conv8 A/B session: bash tools/conv8_ab.sh  (C8_VARIANTS="d_X_1 ..." adds library variants; C8_NO_STEP=1 skips the step-level part)
 for v in $C8_VARIANTS ""; do export PTC_LIB_VARIANT=$v; echo "variant=$v"
 C8_ABL=0,16 timeout 300 python tools/conv8_time.py 128 96 2>&1 | tail -1
 C8_ABL=0 timeout 300 python tools/conv8_time.py 128 128 2>&1 | tail -1
 C8_ABL=0 timeout 300 python tools/conv8_time.py 96 96 2>&1 | tail -1
+C8_ABL=0 timeout 300 python tools/conv8_time.py 96 128 2>&1 | tail -1
 C8_ABL=0 timeout 300 python tools/conv8_time.py 128 128 2 102400 | tail -1
 C8_ABL=0 timeout 300 python tools/conv8_time.py 256 256 1 12115 | tail -1
 done
