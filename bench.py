@@ -256,7 +256,7 @@ def gather_roofline(device, batch):
                        "bound": "mfma", "achieved": round(fl / (ms_w * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(fl / (ms_w * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "launch_ms": round(ms_w, 4),
                        "algorithmic_flops_per_launch": fl, "global_gather_kernel_launch_ms": round(ms_w3, 4),
-                       "blocks_beyond_the_lds_image": int(((blk.hcnt < 0) | (blk.hcnt > 352)).sum().item()), "blocks": int(blk.hcnt.numel())}
+                       "blocks_beyond_the_lds_image": int(((blk.hcnt < 0) | (blk.hcnt > 416)).sum().item()), "blocks": int(blk.hcnt.numel())}
         del xw, ww
     except Exception as e:       # (never takes the headline down)
         out["wide"] = {"error": repr(e)[:200]}

@@ -40,14 +40,17 @@
 #include <mutex>
 
 #ifndef C8_HIMG
-#define C8_HIMG 352          // halo rows the LDS image holds (indoor scenes: mean 212, p99 283 -- tools/halo_stats.py).  At 288 the ~1 % of blocks
-                             // beyond it cost 150 us of a 650-us launch (the follow-up launch is a serial latency chain per block); 352 = 52.5 KB of LDS, the
-                             // kernel's registers allow two workgroups per CU either way (profiles/r06_t_conv8_himg.txt)
+#define C8_HIMG 352          // halo rows the LDS image of the 64- / 32-row forms holds (three workgroups per CU; the 128-row form: C8_HIMG_WIDE, below).
+                             // At 288 the ~1 % of blocks beyond it cost 150 us of a 650-us launch (profiles/r06_t_conv8_himg.txt); 352 = 52.5 KB of LDS
 #endif
 #define C8_KC 64             // input channels per chunk
 #define C8_PITCH (C8_KC * 2) // image rows are 128 bytes, their 16-byte pieces XOR-swizzled by the slot (PTC_SWZ64: blocks.hip's table entries carry it)
 #define C8_THREADS 256
-#define C8_PASSES ((C8_HIMG + 31) / 32)       // DMA instructions per wave and chunk: 8 rows x 128 bytes each, 32 rows per workgroup pass
+#ifndef C8_HIMG_WIDE
+#define C8_HIMG_WIDE 416     // the four-tiles-per-wave form (RT = 4) is held at two workgroups per CU by its registers: its image can be 62 KB.  At 352 ONE
+#endif                       // block of SpUNet's level 1 (354 rows, 8 x 100000 voxels) sent nine launches per step into a 52-us follow-up (r06_ah / r06_ai)
+__host__ __device__ constexpr int c8_himg(int rt) { return rt == 4 ? C8_HIMG_WIDE : C8_HIMG; }
+__host__ __device__ constexpr int c8_passes(int rt) { return (c8_himg(rt) + 31) / 32; }   // DMA instructions per wave and chunk: 8 rows x 128 bytes each, 32 rows per workgroup pass
 #define C8_TAB_BYTES (28 * 128 * 2)           // 27 table rows + the row of masks: seven whole 1-KB DMA pieces
 #ifndef C8_READ_ALL
 #define C8_READ_ALL 0        // 1: the B fragments of four row tiles in flight in front of their MFMAs, the zero row for tiles without a neighbour (timing A/B)
@@ -78,7 +81,7 @@ __device__ __forceinline__ void c8_dma16s(const void* sbase, uint32_t voff, uint
 __device__ __forceinline__ uint32_t c8_lds_addr(const void* p) { return (uint32_t)((const unsigned char*)p - smem); }
 #endif
 
-static inline size_t conv8_lds() { return (size_t)C8_TAB_BYTES + (size_t)(C8_HIMG + 1) * C8_PITCH + (size_t)C8_PASSES * 32 * 4; }   // table | image | halo list
+static inline size_t conv8_lds(int rt) { return (size_t)C8_TAB_BYTES + (size_t)(c8_himg(rt) + 1) * C8_PITCH + (size_t)c8_passes(rt) * 32 * 4; }   // table | image | halo list
 static inline bool conv8_supported(int dtype, int kv, int c_in, int c_out, int bm, int hcap, int64_t n_out) {
   return dtype != PTC_F32 && kv == 27 && c_in % 32 == 0 && c_in >= 96 && c_in <= 1024 && c_out % 32 == 0 && c_out <= 1024 && bm == 128 && hcap >= 16 &&
          hcap <= 511 && n_out >= 256;
@@ -151,6 +154,7 @@ conv8_kernel(const T* __restrict__ in, const T* __restrict__ wf, const float* __
              const uint16_t* __restrict__ tab, const int32_t* __restrict__ hid, const int32_t* __restrict__ hcnt, int64_t n, int c_in, int c_out,
              int hcap, int n_blocks, int cgw, T* __restrict__ out, int abl) {
   using frag = typename Mma<T>::frag;
+  constexpr int HIMG = c8_himg(RT), PASSES = c8_passes(RT);
   const int NT = 32 * cgw;                              // columns per workgroup
   const __amdgpu_buffer_rsrc_t wf_buf = ptc_buf(wf, (uint32_t)c_out * 27u * (uint32_t)c_in * 2u);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -182,14 +186,14 @@ conv8_kernel(const T* __restrict__ in, const T* __restrict__ wf, const float* __
   };
   if (timing) tlast = clock64();
   const int cnt = hcnt[b];
-  if (!(cnt >= 0 && cnt <= C8_HIMG)) return;            // conv3's block (wave-uniform: before any barrier)
+  if (!(cnt >= 0 && cnt <= HIMG)) return;            // conv3's block (wave-uniform: before any barrier)
 
   // ---- the block's table (LDS-DMA), tap masks of this wave's 32-row tiles, halo list.  Every load of this kernel that feeds a prefetch is
   // a RAW BUFFER LOAD (out-of-range offset = zeros): written as `v = *p; if (!ok) v = 0` the compiler turned each one into a branch around
   // the load with s_waitcnt vmcnt(0) behind it
   uint32_t tmk[RT], tm = 0u;                            // taps at which tile t / any tile of this wave has a neighbour
   const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c8_lds_addr(smem));
-  int32_t* hl = reinterpret_cast<int32_t*>(img + (size_t)(C8_HIMG + 1) * C8_PITCH);   // [32 PASSES] halo rows by slot (0 beyond the list: never named by the table)
+  int32_t* hl = reinterpret_cast<int32_t*>(img + (size_t)(HIMG + 1) * C8_PITCH);   // [32 PASSES] halo rows by slot (0 beyond the list: never named by the table)
   {
     const uint16_t* tb = tab + (int64_t)b * (28 * 128);
     const __amdgpu_buffer_rsrc_t hid_buf = ptc_buf(hid + (int64_t)b * hcap, (uint32_t)hcap * 4u);
@@ -200,9 +204,9 @@ conv8_kernel(const T* __restrict__ in, const T* __restrict__ wf, const float* __
     const uint32_t* mw = reinterpret_cast<const uint32_t*>(tb + 27 * 128);
 #pragma unroll
     for (int t = 0; t < RT; ++t) { tmk[t] = mw[t0 + t]; tm |= tmk[t]; }
-    for (int q = threadIdx.x; q < C8_PITCH / 4; q += C8_THREADS) reinterpret_cast<uint32_t*>(img + (size_t)C8_HIMG * C8_PITCH)[q] = 0u;
+    for (int q = threadIdx.x; q < C8_PITCH / 4; q += C8_THREADS) reinterpret_cast<uint32_t*>(img + (size_t)HIMG * C8_PITCH)[q] = 0u;
     hl[threadIdx.x] = (int)threadIdx.x < cnt ? h0 : 0;
-    if (threadIdx.x + C8_THREADS < C8_PASSES * 32) hl[threadIdx.x + C8_THREADS] = (int)threadIdx.x + C8_THREADS < cnt ? h1 : 0;
+    if (threadIdx.x + C8_THREADS < PASSES * 32) hl[threadIdx.x + C8_THREADS] = (int)threadIdx.x + C8_THREADS < cnt ? h1 : 0;
     __syncthreads();                                    // the halo list is in LDS (the table's DMA is waited for with the first chunk's rows)
   }
   if (!works || (abl & 1)) tm = 0u;
@@ -255,7 +259,7 @@ conv8_kernel(const T* __restrict__ in, const T* __restrict__ wf, const float* __
   auto hdma = [&](int c0, int kc) {
     const int np = kc >> 3;                             // pieces per row: 8 | 4
 #pragma unroll
-    for (int p = 0; p < C8_PASSES; ++p) {
+    for (int p = 0; p < PASSES; ++p) {
       const int slot0 = p * 32 + 8 * wave;
       if (slot0 < cnt) {                                // wave-uniform
         const int slot = slot0 + (lane >> 3);
@@ -288,7 +292,7 @@ conv8_kernel(const T* __restrict__ in, const T* __restrict__ wf, const float* __
     uint32_t po[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
-      po[t] = (uint32_t)C8_TAB_BYTES + ((en[t] < (uint32_t)hcap * 128u ? en[t] : (uint32_t)(C8_HIMG * C8_PITCH)) ^ (uint32_t)(h << 4));
+      po[t] = (uint32_t)C8_TAB_BYTES + ((en[t] < (uint32_t)hcap * 128u ? en[t] : (uint32_t)(HIMG * C8_PITCH)) ^ (uint32_t)(h << 4));
     // piece 2 ks + h of the row sits at position (2 ks + h) ^ swizzle; a full chunk has four 16-channel steps, the 32-channel tail two
     frag fb[RT][NK];
 #pragma unroll
@@ -391,7 +395,7 @@ static int launch_conv8_i(const void* in, int64_t n_in, const void* wf, const fl
                           int hcap, int64_t n, int c_in, int c_out, int nt, void* out, hipStream_t s) {
   const int n_blocks = (int)ptc_cdiv(n, 128);
   const int nblk = n_blocks * (c_out / nt);
-  const size_t lds = conv8_lds();
+  const size_t lds = conv8_lds(RT);
   auto kern = conv8_kernel<T, RT>;
   static bool attr = false;                   // per instantiation
   if (!attr) { PTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
@@ -418,7 +422,7 @@ static int launch_conv8(const void* in, int64_t n_in, const void* w, const float
   if (rc != PTC_OK || (c8_ablate() & 16)) return rc;      // (bit 16, timing probe: the first launch alone)
   // the blocks whose halo did not fit: conv3 over exactly those (their counts are on the device)
   c3_skip_hcnt = hcnt;
-  c3_skip_max = C8_HIMG;
+  c3_skip_max = c8_himg(nt >= 96 ? 4 : 1);
   rc = launch_conv3<T>(in, n_in, w, bias, nbr, n, 27, c_in, c_out, out, s);
   c3_skip_hcnt = nullptr;
   return rc;

@@ -82,6 +82,21 @@ def main():
             ops.spconv_fwd(x, w, bias, nbr, blk)       # conv7: register weights + DMA-staged halo
             ops.spconv_wgrad(x, go, nbr)
             ops.spconv_wgrad(x, go, nbr, blk=blk)      # wgrad7: accumulator-stationary, operands from the staged block images
+        if s == 0 and c == 64:
+            # round 6: SpUNet's widest level-0 shape on conv8 (block-staged, weights as register fragments) and on conv3 (global gathers)
+            ci, co = 128, 96
+            xw = torch.randn(n, ci, generator=g).to(torch.bfloat16).to(DEV)
+            ww = (torch.randn(co, 27, ci, generator=g) * 0.03).to(torch.bfloat16).to(DEV)
+            bw = torch.randn(co, generator=g).to(DEV)
+            info["conv_wide_128_96"] = {"alg_flops": 2.0 * pairs * ci * co, "alg_bytes_pair_list": n * (ci + co) * 2 + 8 * pairs + 27 * ci * co * 2,
+                                        "blocks": int(blk.hcnt.numel()), "blocks_beyond_416_rows": int(((blk.hcnt < 0) | (blk.hcnt > 416)).sum())}
+            for _ in range(ITERS):
+                ops.spconv_fwd(xw, ww, bw, nbr, blk)   # conv8 (+ its conv3 follow-up for the blocks beyond the image)
+            os.environ["PTC_CONV8"] = "0"
+            for _ in range(ITERS):
+                ops.spconv_fwd(xw, ww, bw, nbr, blk)   # conv3
+            os.environ["PTC_CONV8"] = "1"
+            del xw, ww
         if s == 0:
             # the gather-fused qkv GEMM: kv = 1 table = a permutation (serialization order)
             perm = torch.randperm(n, generator=g).int().to(DEV)[None].contiguous()

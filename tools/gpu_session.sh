@@ -88,7 +88,7 @@ for sec in "$@"; do
             timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE -d $O/${TAG}_ck_${cs}_sq -- python $R/tools/conv_kernels.py > $O/${TAG}_ck_${cs}_sq.log 2>&1
             timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU -d $O/${TAG}_ck_${cs}_sq2 -- python $R/tools/conv_kernels.py > $O/${TAG}_ck_${cs}_sq2.log 2>&1
             cd $R; python tools/pmc_summary.py --stats $O/${TAG}_ck_${cs}_stats --pmc $O/${TAG}_ck_${cs}_fetch $O/${TAG}_ck_${cs}_write $O/${TAG}_ck_${cs}_tcc $O/${TAG}_ck_${cs}_tcp $O/${TAG}_ck_${cs}_sq $O/${TAG}_ck_${cs}_sq2 \
-              --kernels conv7_kernel,wgrad7_kernel,rulebook_blocks_kernel,conv5_kernel,conv3_kernel,conv2_kernel,wgrad2_kernel,wgrad_reduce,linear2_kernel,rulebook_subm_kernel,hash_insert --out $O/${TAG}_conv_pmc_${cs}.json > $O/${TAG}_conv_pmc_${cs}.log 2>&1
+              --kernels conv8_kernel,conv7_kernel,wgrad7_kernel,rulebook_blocks_kernel,conv5_kernel,conv3_kernel,conv2_kernel,wgrad2_kernel,wgrad_reduce,linear2_kernel,rulebook_subm_kernel,hash_insert --out $O/${TAG}_conv_pmc_${cs}.json > $O/${TAG}_conv_pmc_${cs}.log 2>&1
             grep CONVKERNELS $O/${TAG}_ck_${cs}_stats.log > $O/${TAG}_conv_info_${cs}.txt
             rm -rf $O/${TAG}_ck_${cs}_stats $O/${TAG}_ck_${cs}_fetch $O/${TAG}_ck_${cs}_write $O/${TAG}_ck_${cs}_tcc $O/${TAG}_ck_${cs}_tcp $O/${TAG}_ck_${cs}_sq $O/${TAG}_ck_${cs}_sq2
             cd /tmp
