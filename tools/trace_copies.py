@@ -23,9 +23,24 @@ from pointcept_amd.segmentor import DefaultSegmentorV2  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.manual_seed(1234)
-model = DefaultSegmentorV2(20, 64, PointTransformerV3(**bench.PTV3_BASE), criteria=("ce", "lovasz")).to(dev).train()
-opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
-batch = synthetic.to_torch(synthetic.indoor_batch(8, 102400, rank=0), dev)
+SPUNET = "--model" in sys.argv and sys.argv[sys.argv.index("--model") + 1] == "spunet"
+if SPUNET:       # BASELINE configs[1]: SpUNet-v1m1 + CE + SGD, 8 x 100000 voxels (bench.build_spunet)
+    from pointcept_amd import functional as PF
+    from pointcept_amd.sparse_unet import SpUNetBase
+
+    net = SpUNetBase(6, 20, **bench.SPUNET_BASE).to(dev).train()
+    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    batch = synthetic.to_torch(synthetic.indoor_batch(8, 100000, rank=0), dev)
+
+    class _M(torch.nn.Module):
+        def forward(self, d):
+            return {"loss": PF.cross_entropy(net(d), d["segment"], -1)}
+
+    model = _M()
+else:
+    model = DefaultSegmentorV2(20, 64, PointTransformerV3(**bench.PTV3_BASE), criteria=("ce", "lovasz")).to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    batch = synthetic.to_torch(synthetic.indoor_batch(8, 102400, rank=0), dev)
 SKIP = ("aten::view", "aten::_unsafe_view", "aten::reshape", "aten::t", "aten::transpose", "aten::permute", "aten::slice", "aten::select",
         "aten::detach", "aten::alias", "aten::expand", "aten::as_strided", "aten::unsqueeze", "aten::squeeze", "aten::empty", "aten::size",
         "aten::stride", "aten::is_", "aten::sym_", "aten::_local_scalar_dense", "aten::lift_fresh", "aten::unbind", "aten::split",
