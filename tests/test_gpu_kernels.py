@@ -473,14 +473,16 @@ def test_spconv_fwd_block_staged(cuda, c, ordered, n_rows=35000):
 @pytest.mark.parametrize("ordered", [True, False])
 def test_spconv_fwd_block_staged_wide(cuda, c, ordered, monkeypatch, n_rows=9000):
     """round 6, conv8 (csrc/conv8.h): the block-staged convolution for rows of 96 channels and more -- halo rows of a 128-row block staged
-    once per 128-channel chunk in LDS, weights streamed per tap through LDS -- at SpUNet's decoder widths (96 / 128 / 224 / 192), PT-v3's
-    deep stages (128 / 256 / 512) and mixed in / out widths: within the 16-bit bar of the fp32 oracle and within fp32 summation-order noise
-    of the global-gather kernel (conv3) on the same table.  The un-ordered case mixes staged blocks with blocks whose halo does not fit
-    (blocks.hip's overflow mark, or more than the image's 288 rows): those take the kernel's global-gather form.  Ragged row count, bf16
-    and f16, with / without bias, bit-reproducible."""
+    once per 64-channel chunk in LDS, weights fetched in MFMA fragment order straight into registers -- at SpUNet's decoder widths (96 /
+    128 / 224 / 192), PT-v3's deep stages (128 / 256 / 512) and mixed in / out widths (the 128-row form at c_out = 96, the 64-row form at
+    c_out = 64, the 32-row form elsewhere at this row count; the full-size model tests run the 128-row form at c_out = 128): within the
+    16-bit bar of the fp32 oracle and within fp32 summation-order noise of the global-gather kernel (conv3) on the same table.  The
+    un-ordered case mixes staged blocks with blocks whose halo does not fit (blocks.hip's overflow mark, or more rows than the LDS
+    image holds): those are served by the conv3 follow-up launch, which skips the staged blocks.  Ragged row count, bf16 and f16, with /
+    without bias, bit-reproducible."""
     from pointcept_amd import ops
 
-    monkeypatch.setenv("PTC_CONV8", "1")       # opt-in kernel (slower than conv3 at the shapes measured: profiles/r06_j_conv8_stages.txt)
+    monkeypatch.setenv("PTC_CONV8", "1")       # (the default since profiles/r06_y_conv8_no_copies.txt)
     c_in, c_out = c
     if c_in >= 512:
         n_rows = min(n_rows, 3000)

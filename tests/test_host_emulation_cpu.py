@@ -222,7 +222,7 @@ EMULATED_GPU_TESTS = [
     ("test_sort_keys_at_the_packing_boundary", dict(n=8193)),
     ("test_rulebook_blocks", dict(ordered=True)), ("test_spconv_fwd_block_staged", dict(c=64, ordered=True, n_rows=2100)),
     ("test_spconv_fwd_block_staged", dict(c=32, ordered=False, n_rows=2100)),
-    ("test_spconv_fwd_block_staged_wide", dict(c=(224, 96), ordered=False, n_rows=700)),      # conv8 (opt-in): two chunks, staged + overflow blocks
+    ("test_spconv_fwd_block_staged_wide", dict(c=(224, 96), ordered=False, n_rows=700)),      # conv8: three 64-channel chunks + the 32-channel tail; staged blocks + blocks served by the conv3 follow-up
     ("test_spconv_wgrad_block_staged", dict(c=64, ordered=True, n_rows=1600)), ("test_spconv_wgrad_block_staged", dict(c=32, ordered=True, n_rows=1600)),
     ("test_spconv_wgrad_block_staged", dict(c=64, ordered=False, n_rows=1600)),
     ("test_spconv_wgrad_block_staged", dict(c=(128, 96), ordered=True, n_rows=1150)),     # channel slices on both sides (c = 96 alone: GPU suite)
