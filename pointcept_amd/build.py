@@ -34,6 +34,7 @@ HIP_SOURCES = [
     "blocks.hip",
     "spconv.hip",
     "conv7.hip",
+    "gemm3.hip",
     "wgrad7.hip",
     "norm.hip",
     "attention.hip",

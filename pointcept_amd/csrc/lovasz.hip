@@ -32,12 +32,6 @@
 #define LV_MAX_C 64
 #define LV_ONE 0x3f800000u
 #define LV_STEP_BLOCKS 4096
-#ifndef LV_XCD
-#define LV_XCD 0                            // 1: launches of LV_STEP_BLOCKS workgroups run lovasz_step one class row per XCD (timing A/B: d_LV_XCD_1).
-                                            // Measured SLOWER, 1310 vs 1220 us for the whole loss at 819200 x 20 (profiles/r05_s_lovasz_xcd_rows.txt):
-                                            // 20 rows over 8 XCDs is 3 / 2 rows per XCD, and the partial-sector write-backs it was meant to merge
-                                            // are not what bounds the kernel
-#endif
 
 // key word of one (class, point) slot: bits [1, 31) ascend as the error descends, bit 0 = the slot is foreground (its point carries this
 // class) -- below the sorted bit range, carried along by the sort
@@ -116,32 +110,32 @@ lovasz_fg_kernel(const int64_t* __restrict__ sorted_keys, int64_t total, int32_t
   if (t < total) fg[t] = (int32_t)(sorted_keys[t] & 1);
 }
 
-// one slot of lovasz_step: Jaccard step, the slot's share of the loss, the gradient w.r.t. the probability scattered back to the point
-__device__ __forceinline__ double lv_step_slot(int64_t key, int64_t src, int64_t scan_t, int64_t scan_row0, int64_t i, int64_t gts, int n_present,
+// one slot of lovasz_step: Jaccard step, the slot's share of the loss, the gradient w.r.t. the probability scattered back to the point.
+// ONE fp64 division per slot: the two branches of ptc_lovasz_step (voxel_keys.h) share it through selects of numerator and denominator
+// (same operands, same quotient), and the 1 / n_present of the gradient is a multiplication by the reciprocal the workgroup computed once.
+__device__ __forceinline__ double lv_step_slot(int64_t key, int32_t src, int32_t cum_fg_excl, int32_t i, int32_t gts, double inv_present,
                                                float* __restrict__ gprob_row) {
-  double contrib = 0.0;
-  float g = 0.f;
-  if (gts > 0) {
-    const int f = (int)(key & 1);
-    const int64_t cum_fg = scan_t - scan_row0 + f;   // inclusive
-    const int64_t cum_bg = (i + 1) - cum_fg;
-    const double step = ptc_lovasz_step(gts, cum_fg, cum_bg, f);   // exact Jaccard difference (voxel_keys.h)
-    const float e = lv_key_error(key);
-    contrib = (double)e * step;
-    g = (float)(step / (double)n_present);
-    g = f ? -g : g;                                    // d|fg - p| / dp
-  }
+  const int f = (int)(key & 1);
+  const int32_t cum_fg = cum_fg_excl + f;              // inclusive
+  const int32_t cum_bg = (i + 1) - cum_fg;
+  const double U = (double)gts + (double)cum_bg, I = (double)(gts - cum_fg);
+  const double step = (f ? 1.0 : I) / (f ? U : U * (U - 1.0));   // exact Jaccard difference, ptc_lovasz_step's two quotients
+  const float e = lv_key_error(key);
+  float g = (float)(step * inv_present);
+  g = f ? -g : g;                                      // d|fg - p| / dp
   gprob_row[src] = g;
-  return contrib;
+  return (double)e * step;
 }
 
-// `by_xcd` (launches of 8 x G workgroups): class row r is handled by the workgroups of ONE XCD (workgroup b runs on XCD b % 8) and its three
-// input streams are loaded non-temporally -- the row's 4 N bytes of gprob, written at random positions 4 bytes at a time, then live in that
-// XCD's L2 until their 64-byte sectors are complete instead of being written back in parts from eight L2s (LV_XCD, see the host code).
+// grid (G, c): class row blockIdx.y, G workgroups stride over its n sorted slots.  The first form of this kernel was ONE flat grid over the
+// c n slots: `row = t / n` is a 64-bit integer division per slot (a ~100-instruction software sequence) and the step took three fp64 divisions
+// (both Jaccard branches + step / n_present): 338 us at 819200 x 20 for 460 MB of streams -- compute, not the 4-byte scatter, bound it
+// (profiles/r05_s_lovasz_xcd_rows.txt had already shown that the write-backs do not).  Rows with no foreground (gts == 0: class absent) give
+// zero gradient and contribute nothing.
 __global__ void __launch_bounds__(LV_THREADS)
 lovasz_step_kernel(const int64_t* __restrict__ sorted_keys, const int64_t* __restrict__ order,
                    const int64_t* __restrict__ fg_scan, const int32_t* __restrict__ class_count, int64_t n, int c,
-                   float* __restrict__ gprob, double* __restrict__ partial, int by_xcd) {
+                   float* __restrict__ gprob, double* __restrict__ partial) {
   __shared__ double red[LV_THREADS / 64];
   __shared__ int n_present_s;
   if (threadIdx.x == 0) {
@@ -150,33 +144,27 @@ lovasz_step_kernel(const int64_t* __restrict__ sorted_keys, const int64_t* __res
     n_present_s = np;
   }
   __syncthreads();
-  const int n_present = n_present_s;
+  const double inv_present = 1.0 / (double)n_present_s;
+  const int row = (int)blockIdx.y;
+  const int64_t base = (int64_t)row * n;
+  const int32_t gts = class_count[row], nn = (int32_t)n;
+  const int64_t* __restrict__ kr = sorted_keys + base;
+  const int64_t* __restrict__ orr = order + base;
+  const int64_t* __restrict__ sr = fg_scan + base;
+  float* __restrict__ gr = gprob + base;
   double contrib = 0.0;
-  if (by_xcd) {
-    const int xcd = (int)(blockIdx.x & 7), lb = (int)(blockIdx.x >> 3), per_xcd = (int)(gridDim.x >> 3);
-    for (int row = xcd; row < c; row += 8) {
-      const int64_t base = (int64_t)row * n, gts = class_count[row], scan0 = fg_scan[base];
-      for (int64_t i = (int64_t)lb * LV_THREADS + threadIdx.x; i < n; i += (int64_t)per_xcd * LV_THREADS) {
-        const int64_t t = base + i;
-        contrib += lv_step_slot(__builtin_nontemporal_load(sorted_keys + t), __builtin_nontemporal_load(order + t),
-                                __builtin_nontemporal_load(fg_scan + t), scan0, i, gts, n_present, gprob + base);
-      }
-    }
+  if (gts > 0) {
+    const int64_t scan0 = sr[0];
+    for (int32_t i = (int32_t)(blockIdx.x * LV_THREADS + threadIdx.x); i < nn; i += (int32_t)(gridDim.x * LV_THREADS))
+      contrib += lv_step_slot(kr[i], (int32_t)orr[i], (int32_t)(sr[i] - scan0), i, gts, inv_present, gr);
   } else {
-    // grid-stride over the slots: at most LV_STEP_BLOCKS workgroups, hence as many partial sums for lovasz_finish (one partial per 256
-    // slots -- 64000 at 819200 x 20 -- kept its single workgroup busy for 88 us; the order of the sum is fixed either way)
-    const int64_t total = n * (int64_t)c;
-    for (int64_t t = (int64_t)blockIdx.x * LV_THREADS + threadIdx.x; t < total; t += (int64_t)gridDim.x * LV_THREADS) {
-      const int row = (int)(t / n);
-      const int64_t base = (int64_t)row * n;
-      contrib += lv_step_slot(sorted_keys[t], order[t], fg_scan[t], fg_scan[base], t - base, class_count[row], n_present, gprob + base);
-    }
+    for (int32_t i = (int32_t)(blockIdx.x * LV_THREADS + threadIdx.x); i < nn; i += (int32_t)(gridDim.x * LV_THREADS)) gr[i] = 0.f;
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
   if (ptc_lane() == 0) red[threadIdx.x >> 6] = contrib;
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ void __launch_bounds__(LV_THREADS)
@@ -275,8 +263,9 @@ struct LvLayout {
 static LvLayout lv_layout(int64_t n, int c) {
   LvLayout L;
   const size_t nc = (size_t)(n > 0 ? n : 1) * (size_t)c;
-  L.n_partial = ptc_cdiv((int64_t)nc, LV_THREADS);
-  if (L.n_partial > LV_STEP_BLOCKS) L.n_partial = LV_STEP_BLOCKS;
+  int64_t g = ptc_cdiv(n > 0 ? n : 1, LV_THREADS);           // lovasz_step: G workgroups per class row, one partial each
+  if (g > LV_STEP_BLOCKS / c) g = LV_STEP_BLOCKS / c;
+  L.n_partial = (g > 0 ? g : 1) * c;
   size_t o = 0;
   L.keys = o; o += ptc_align_up(nc * 8, 256);
   L.order = o; o += ptc_align_up(nc * 8, 256);
@@ -340,8 +329,8 @@ extern "C" int ptc_lovasz_softmax(const void* logits, int64_t row_stride, const 
   PTC_CHECK_LAUNCH("lovasz_fg_kernel");
   rc = ptc_exclusive_scan_i32(fg, nc, scan, ws + L.scan_ws, L.total - L.scan_ws, stream);
   if (rc != PTC_OK) return rc;
-  hipLaunchKernelGGL(lovasz_step_kernel, dim3((unsigned)L.n_partial), dim3(LV_THREADS), 0, s, keys, order, scan, count, n, c, gprob, partial,
-                     (LV_XCD && L.n_partial == LV_STEP_BLOCKS) ? 1 : 0);
+  hipLaunchKernelGGL(lovasz_step_kernel, dim3((unsigned)(L.n_partial / c), (unsigned)c), dim3(LV_THREADS), 0, s, keys, order, scan, count, n, c, gprob,
+                     partial);
   PTC_CHECK_LAUNCH("lovasz_step_kernel");
   hipLaunchKernelGGL(lovasz_finish_kernel, dim3(1), dim3(LV_THREADS), 0, s, partial, L.n_partial, count, c, loss);
   PTC_CHECK_LAUNCH("lovasz_finish_kernel");

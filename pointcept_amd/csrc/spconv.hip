@@ -215,6 +215,7 @@ static int dispatch_fwd(const void* in, const void* w, const float* bias, const 
 
 #include "fwd2.h"
 #include "fwd2_joint.h"
+#include "gemm3.h"
 #include "conv3.h"
 #include "conv5.h"
 #include "conv7.h"
@@ -234,6 +235,9 @@ extern "C" int ptc_spconv_fwd(const void* in, int64_t n_in, const void* weight, 
   hipStream_t s = (hipStream_t)stream;
   // the second- and third-generation kernels gather through raw buffer loads (32-bit offsets, < 2 GiB tensors)
   const bool buf_ok = (uint64_t)n_in * (uint64_t)c_in * ptc_dtype_size(dtype) <= PTC_BUF_MAX_BYTES;
+  if (buf_ok && kv <= 2 && (nbr || kv == 1) && ptc_gemm3_supported(dtype, kv, c_in, c_out)) {     // the Linear layers of the deep stages (gemm3.h)
+    return ptc_gemm3_launch(dtype, in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s, 0, nullptr, nullptr);
+  }
   if (buf_ok && conv5_supported(dtype, kv, c_in, c_out, nbr, n_in)) {
     if (dtype == PTC_BF16) return launch_conv5<bf16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
     return launch_conv5<f16_t>(in, n_in, weight, bias, nbr, n_out, kv, c_in, c_out, out, s);
@@ -288,6 +292,7 @@ extern "C" int ptc_spconv_fwd_blk(const void* in, int64_t n_in, const void* weig
 // epilogue 2 = out: acc * GELU'(aux_in).  16-bit features, c_in <= 256 (the persistent linear2 kernel).
 extern "C" int ptc_linear_supported_ex(int c_in, int c_out, int dtype) {
   // (the GELU epilogues are instantiated for 128-wide output tiles only: hidden widths 4 C with C a multiple of 32)
+  if (ptc_gemm3_supported(dtype, 1, c_in, c_out)) return 1;                          // gemm3.h: any c_in % 64 == 0 from 128 up
   return dtype != PTC_F32 && c_in % 8 == 0 && c_in <= 256 && c_out % 128 == 0;   // and n * c_in * 2 < 2 GiB (checked per call)
 }
 extern "C" int ptc_linear_fwd_ex(const void* in, int64_t n, const void* weight, const float* bias, int c_in, int c_out, int dtype,
@@ -299,6 +304,9 @@ extern "C" int ptc_linear_fwd_ex(const void* in, int64_t n, const void* weight, 
   if (n == 0) return PTC_OK;
   PTC_REQUIRE(in && weight && out && (epilogue == 1 ? aux_out != nullptr : aux_in != nullptr), PTC_EINVAL, "ptc_linear_fwd_ex: null buffer");
   hipStream_t s = (hipStream_t)stream;
+  if (ptc_gemm3_supported(dtype, 1, c_in, c_out)) {
+    return ptc_gemm3_launch(dtype, in, n, weight, bias, nullptr, n, 1, c_in, c_out, out, s, epilogue, aux_in, aux_out);
+  }
   if (dtype == PTC_BF16) return dispatch_fwd2<bf16_t>(in, n, weight, bias, nullptr, n, 1, c_in, c_out, out, s, epilogue, aux_in, aux_out);
   return dispatch_fwd2<f16_t>(in, n, weight, bias, nullptr, n, 1, c_in, c_out, out, s, epilogue, aux_in, aux_out);
 }

@@ -873,11 +873,12 @@ def test_mlp_one_kernel_per_direction(cuda, dtype, c, n, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_linear_gather_tables(cuda, dtype):
+@pytest.mark.parametrize("cin,cout", [(32, 96), (128, 384), (256, 768)])   # the wide pairs: gemm3.h (gathered rows, kv = 2 input gradient)
+def test_linear_gather_tables(cuda, dtype, cin, cout):
     """out = F.linear(x)[gidx] with a padded permutation (duplicated tail rows), gather-form backward."""
     from pointcept_amd import functional as PF
 
-    n, n_pad, cin, cout = 3000, 3072, 32, 96
+    n, n_pad = 3000, 3072
     g = torch.Generator().manual_seed(17)
     perm = torch.randperm(n, generator=g)
     gidx = torch.cat([perm, perm[n - 72 - 100:n - 100]])            # 72 padded slots repeat earlier points

@@ -53,6 +53,8 @@ for sec in "$@"; do
           timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof7 -- python $R/bench.py --steps 7 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_prof7.log 2>&1
           cd $R; TOP=30 python tools/steady_state_stats.py $O/${TAG}_prof 3 $O/${TAG}_prof7 7 $O/${TAG}_kernel_stats.csv > $O/${TAG}_prof_top.log 2>&1
           python tools/kernel_neighbours.py $O/${TAG}_prof > $O/${TAG}_fill_copy_neighbours.txt 2>&1; rm -rf $O/${TAG}_prof $O/${TAG}_prof7; tail -1 $O/${TAG}_kernel_stats.csv;;
+    timeline) cd /tmp; timeout 900 rocprofv3 --kernel-trace -d $O/${TAG}_tl -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-fp16-recipe > $O/${TAG}_tl.log 2>&1
+          cd $R; PTC_TIMELINE_SEQ=$O/${TAG}_step_sequence.txt python tools/step_timeline.py $O/${TAG}_tl > $O/${TAG}_step_timeline.txt 2>&1; rm -rf $O/${TAG}_tl; head -12 $O/${TAG}_step_timeline.txt;;
     profoutdoor) cd /tmp; BA="--model ptv3-outdoor --no-cpu-baseline --no-secondary --no-fp16-recipe --warmup 1"
           timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profo2 -- python $R/bench.py --steps 2 $BA > $O/${TAG}_profo2.log 2>&1
           timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profo5 -- python $R/bench.py --steps 5 $BA > $O/${TAG}_profo5.log 2>&1
