@@ -280,7 +280,7 @@ int ptc_spconv_wgrad_blk(const void* in, int64_t n_in, const void* dout, const i
 /* Dense row-wise GEMM out = in W^T + b with an MLP epilogue fused (PTv3 MLP, ptv3m1:225-248: fc1 -> GELU -> fc2):
  *   epilogue 1 : out = h (the pre-activation, saved for the backward), aux_out = GELU(h)         [fc1 forward]
  *   epilogue 2 : out = (in W^T) * GELU'(aux_in), aux_in = h [n, c_out]                          [fc2 input gradient]
- * weight [c_out][c_in] in `dtype` (bf16 / f16), c_in <= 256 (ptc_linear_supported_ex); GELU = erf form, fp32. */
+ * weight [c_out][c_in] in `dtype` (bf16 / f16), c_in <= 256 or a multiple of 64 from 128 up (ptc_linear_supported_ex); GELU = erf form, fp32. */
 int ptc_linear_supported_ex(int c_in, int c_out, int dtype);
 int ptc_linear_fwd_ex(const void* in, int64_t n, const void* weight, const float* bias, int c_in, int c_out, int dtype,
                       int epilogue, const void* aux_in, void* out, void* aux_out, ptc_stream_t stream);

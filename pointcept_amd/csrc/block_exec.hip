@@ -73,7 +73,10 @@ extern "C" int ptc_ptv3_block_fwd(const int64_t* iv, const float* fv, const void
   // f16 (round 4): the reference's fp16-autocast recipe -- every GEMM, joint and convolution on f16 operands; the window attention
   // keeps its bf16 arithmetic and does the call site's casts (ptv3m1:209,215) in its load / store paths (attention.hip, F16 I/O)
   PTC_REQUIRE(dt == PTC_BF16 || dt == PTC_F16, PTC_EUNSUPPORTED, "ptc_ptv3_block_fwd: 16-bit GEMM operands only");
-  PTC_REQUIRE(c % 16 == 0 && c <= 256 && H * 16 == c, PTC_EUNSUPPORTED, "ptc_ptv3_block_fwd: c=%d heads=%d (head_dim 16, c <= 256)", c, H);
+  // (c <= 256: linear2's range; wider Blocks -- stage 4 of PT-v3m1, 512 channels -- when the MLP GEMMs with their GELU epilogues exist at that
+  //  width: gemm3.h)
+  PTC_REQUIRE(c % 16 == 0 && H * 16 == c && (c <= 256 || (c <= 512 && ptc_linear_supported_ex(c, hid, dt))), PTC_EUNSUPPORTED,
+              "ptc_ptv3_block_fwd: c=%d heads=%d (head_dim 16, c <= 256, or <= 512 with the wide GEMM kernels)", c, H);
   if (n == 0) return PTC_OK;
   const int32_t* nbr = (const int32_t*)P(in, PTC_BLK_P_NBR);
   // 1. positional encoding: 3^3 submanifold convolution (ptv3m1:278-284) ...

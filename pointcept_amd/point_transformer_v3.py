@@ -470,7 +470,8 @@ class Block(PointModule):
         pre-norm, LayerNorm joints, the window-attention kernel with the gather tables folded into qkv / proj, fused MLP, <= 256 channels"""
         a = self.attn
         return (config.EXEC_BLOCK and type(self) in _EXEC_BLOCK_TYPES and type(a) is SerializedAttention and torch.is_autocast_enabled("cuda")
-                and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16) and self.channels % 32 == 0 and self.channels <= 256
+                and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16) and self.channels % 32 == 0
+                and (self.channels <= 256 or (self.channels <= 512 and ops.linear_supported_ex(self.channels, 4 * self.channels, torch.get_autocast_dtype("cuda"))))
                 and a.enable_flash and not a.enable_rpe and a.num_heads * 16 == self.channels and config.FUSE_GATHER and config.FUSE_MLP
                 and (a.attn_drop == 0.0 or not self.training)
                 and type(self.cpe[0]) is spconv.SubMConv3d and self.cpe[0].kernel_size[0] == 3 and self.cpe[0].bias is not None

@@ -107,7 +107,7 @@ def test_block_executor_step_is_bit_identical_to_the_composed_step(cuda, monkeyp
         (loss * (1024.0 if amp == torch.float16 else 1.0)).backward()       # a fixed loss scale stands in for GradScaler
         res[on] = (float(loss.detach()), {k: p.grad.clone() for k, p in eng.named_parameters()}, calls["n"])
     n_blocks = sum(1 for m_ in eng.modules() if type(m_).__name__ == "Block")
-    n_wide = sum(1 for m_ in eng.modules() if type(m_).__name__ == "Block" and m_.channels > 256)
+    n_wide = sum(1 for m_ in eng.modules() if type(m_).__name__ == "Block" and m_.channels > 512)   # (round 6: the 512-channel stage too, on gemm3.h)
     assert res[True][2] == n_blocks - n_wide and res[False][2] == 0, (res[True][2], res[False][2], n_blocks, n_wide)
     assert res[True][0] == res[False][0], (res[True][0], res[False][0])
     for k in res[True][1]:
