@@ -35,6 +35,7 @@ HIP_SOURCES = [
     "spconv.hip",
     "conv7.hip",
     "gemm3.hip",
+    "wgrad3.hip",
     "wgrad7.hip",
     "norm.hip",
     "attention.hip",

@@ -249,11 +249,15 @@ gemm3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
     if (it + 1 < total) store_chunk((it + 1) & 1, raS, rwS);
     __syncthreads();
   };
+  // both halves unconditional inside the loop (a skipped second half on the back edge made the compiler assume the worst about the loads in
+  // flight and drain them at the top of every first half); an odd last chunk runs behind it
+  int it = 0;
 #pragma unroll 1
-  for (int it = 0; it < total; it += 2) {
-    half(it, ra0, rw0, ra1, rw1);                         // chunk it + 2 -> set 0, chunk it + 1 (set 1) -> LDS
-    if (it + 1 < total) half(it + 1, ra1, rw1, ra0, rw0);
+  for (; it + 1 < total; it += 2) {
+    half(it, ra0, rw0, ra1, rw1);
+    half(it + 1, ra1, rw1, ra0, rw0);
   }
+  if (it < total) half(it, ra0, rw0, ra1, rw1);
 }
 
 static inline bool gemm3_enabled() {

@@ -216,6 +216,7 @@ static int dispatch_fwd(const void* in, const void* w, const float* bias, const 
 #include "fwd2.h"
 #include "fwd2_joint.h"
 #include "gemm3.h"
+#include "wgrad3.h"
 #include "conv3.h"
 #include "conv5.h"
 #include "conv7.h"
@@ -491,9 +492,33 @@ spconv_wgrad_kernel(const T* __restrict__ in, const T* __restrict__ dout, const 
 // owns 64 consecutive outputs (16 lanes x float4); 16 thread groups split the partial index, each keeps four
 // independent 16-byte loads in flight (the first version walked the partials with one dependent 4-byte load
 // at a time: 9.5 us per call, latency-bound), partial sums meet in LDS in a fixed order.
+// FEW partials (<= WG_REDUCE_FEW; `few`, decided on the host, sizes the first segment in blocks of 1024 outputs): one float4 per thread, the
+// partials walked in order.  The 16-group form above spends a 256-thread block on 64 outputs and keeps 15 of its 16 groups idle when there is
+// ONE partial -- the block-staged convolution gradient of the deep stages (one or eight sequences, wgrad7_splits): 28 MB of partial "reduced"
+// in 125 us at 512 channels, 43 us per stage-3 Block (profiles/r06_aw_step_sequence.txt).
+#define WG_REDUCE_FEW 8
 __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, int splits, int64_t count, float* __restrict__ dw, int nb1,
-                                                  const float* __restrict__ partial2, int64_t count2, float* __restrict__ out2, int bid) {
+                                                  const float* __restrict__ partial2, int64_t count2, float* __restrict__ out2, int bid, bool few) {
   __shared__ float4 red[16][16];
+  if (few && bid < nb1) {
+    const int64_t i = (int64_t)bid * 1024 + (int64_t)threadIdx.x * 4;
+    if (i >= count) return;
+    if ((i + 3 < count) && ((count & 3) == 0)) {
+      float4 a = *reinterpret_cast<const float4*>(partial + i);
+      for (int p = 1; p < splits; ++p) {
+        const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)p * count + i);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      *reinterpret_cast<float4*>(dw + i) = a;
+    } else {
+      for (int64_t j = i; j < count && j < i + 4; ++j) {
+        float a = partial[j];
+        for (int p = 1; p < splits; ++p) a += partial[(int64_t)p * count + j];
+        dw[j] = a;
+      }
+    }
+    return;
+  }
   if (bid >= nb1) {
     partial = partial2; count = count2; dw = out2;
   }
@@ -557,8 +582,8 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
 
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int64_t count, float* __restrict__ dw, int nb1,
-                    const float* __restrict__ partial2, int64_t count2, float* __restrict__ out2) {
-  wgrad_reduce_body(partial, splits, count, dw, nb1, partial2, count2, out2, (int)blockIdx.x);
+                    const float* __restrict__ partial2, int64_t count2, float* __restrict__ out2, int few) {
+  wgrad_reduce_body(partial, splits, count, dw, nb1, partial2, count2, out2, (int)blockIdx.x, few != 0);
 }
 
 // the reductions of several weight gradients in one launch (the Block executor: six per Block backward): workgroup b belongs to the job
@@ -567,6 +592,7 @@ struct WgradReduceMulti {
   int n;
   int start[PTC_WGRAD_JOBS_MAX + 1];   // first workgroup of job j; start[n] = grid
   int nb1[PTC_WGRAD_JOBS_MAX];
+  int few[PTC_WGRAD_JOBS_MAX];
   PtcWgradJob job[PTC_WGRAD_JOBS_MAX];
 };
 __global__ void __launch_bounds__(256)
@@ -578,7 +604,7 @@ wgrad_reduce_multi_kernel(WgradReduceMulti m) {
   const PtcWgradJob& J = m.job[j];
   const bool alt = J.gate != nullptr && *J.gate != 0;      // (uniform) which producer ran: see PtcWgradJob
   wgrad_reduce_body(alt ? J.alt_partial : J.partial, alt ? J.alt_splits : J.splits, J.count, J.dw, m.nb1[j], J.bias_partial, J.c_out, J.dbias,
-                    (int)blockIdx.x - m.start[j]);
+                    (int)blockIdx.x - m.start[j], m.few[j] != 0);
 }
 
 int ptc_wgrad_reduce_jobs(const PtcWgradJob* jobs, int n, ptc_stream_t stream) {
@@ -588,9 +614,11 @@ int ptc_wgrad_reduce_jobs(const PtcWgradJob* jobs, int n, ptc_stream_t stream) {
   int grid = 0;
   for (int q = 0; q < n; ++q) {
     if (jobs[q].splits <= 0) continue;
-    const int nb1 = (int)ptc_cdiv(jobs[q].count, 64), nb2 = jobs[q].dbias ? (int)ptc_cdiv(jobs[q].c_out, 64) : 0;
+    const bool few = jobs[q].splits <= WG_REDUCE_FEW && (jobs[q].gate == nullptr || jobs[q].alt_splits <= WG_REDUCE_FEW);
+    const int nb1 = (int)ptc_cdiv(jobs[q].count, few ? 1024 : 64), nb2 = jobs[q].dbias ? (int)ptc_cdiv(jobs[q].c_out, 64) : 0;
     m.start[m.n] = grid;
     m.nb1[m.n] = nb1;
+    m.few[m.n] = few ? 1 : 0;
     m.job[m.n] = jobs[q];
     grid += nb1 + nb2;
     ++m.n;
@@ -604,10 +632,11 @@ int ptc_wgrad_reduce_jobs(const PtcWgradJob* jobs, int n, ptc_stream_t stream) {
 
 static int launch_wgrad_reduce(const float* partial, int splits, int64_t count, float* dw, const float* bias_partial, int64_t c_out,
                                float* dbias, hipStream_t s) {
-  const int nb1 = (int)ptc_cdiv(count, 64);
+  const bool few = splits <= WG_REDUCE_FEW;
+  const int nb1 = (int)ptc_cdiv(count, few ? 1024 : 64);
   const int nb2 = dbias ? (int)ptc_cdiv(c_out, 64) : 0;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, s, partial, splits, count, dw, nb1, bias_partial,
-                     c_out, dbias);
+                     c_out, dbias, few ? 1 : 0);
   PTC_CHECK_LAUNCH("wgrad_reduce_kernel");
   return PTC_OK;
 }
@@ -629,6 +658,11 @@ extern "C" size_t ptc_spconv_wgrad_workspace_bytes(int64_t n_out, int kv, int c_
   const size_t gxb = (size_t)w2_plan(n_out, kv, c_in, c_out, true).gx;
   if (gxb > gx) gx = gxb;
   if (gx > splits) splits = gx;
+  if (ptc_wgrad3_supported(PTC_BF16, kv, c_in, c_out, n_out)) {      // wgrad3.h (the deep stages' Linear layers): its own split count
+    int s3, cps;
+    ptc_wgrad3_plan(n_out, c_in, c_out, &s3, &cps);
+    if ((size_t)s3 > splits) splits = (size_t)s3;
+  }
   return ptc_align_up(splits * (size_t)c_out * kv * c_in * sizeof(float), 256) + ptc_align_up(splits * (size_t)c_out * sizeof(float), 256);
 }
 
@@ -657,7 +691,7 @@ static int launch_wgrad(const void* in, const void* dout, const int32_t* nbr, in
   if (splits > 1) return launch_wgrad_reduce((const float*)ws, splits, count, dw, bias_partial, c_out, dbias, s);
   if (dbias) {  // single split: the weight partial went straight to dw, the bias partial still needs its copy-out
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ptc_cdiv(c_out, 64)), dim3(256), 0, s, (const float*)bias_partial, splits,
-                       (int64_t)c_out, dbias, 1 << 30, (const float*)nullptr, (int64_t)0, (float*)nullptr);
+                       (int64_t)c_out, dbias, 1 << 30, (const float*)nullptr, (int64_t)0, (float*)nullptr, 0);
     PTC_CHECK_LAUNCH("wgrad_reduce_kernel(bias)");
   }
   return PTC_OK;
@@ -710,6 +744,30 @@ static int launch_wgrad2(const void* in, int64_t n_in, const void* dout, const i
 static int spconv_wgrad_impl(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out,
                              int dtype, float* dw, float* dbias, void* workspace, size_t workspace_bytes, ptc_stream_t stream, PtcWgradJob* defer);
 
+// ---- wgrad3.h: the Linear layers of the deep stages (c_in, c_out multiples of 128), several weights per launch -------------------------
+static bool wgrad3_eligible(const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int kv, int c_in, int c_out, int dtype,
+                            const float* dw, const void* workspace, size_t workspace_bytes) {
+  return n_out > 0 && in && dout && dw && workspace && (dtype == PTC_BF16 || dtype == PTC_F16) && ptc_wgrad3_supported(dtype, kv, c_in, c_out, n_out) &&
+         (nbr || n_in >= n_out) && (uint64_t)n_in * c_in * 2 <= PTC_BUF_MAX_BYTES && (uint64_t)n_out * c_out * 2 <= PTC_BUF_MAX_BYTES &&
+         ((uintptr_t)in % 16 == 0) && ((uintptr_t)dout % 16 == 0) && workspace_bytes >= ptc_spconv_wgrad_workspace_bytes(n_out, kv, c_in, c_out);
+}
+// appends one weight to the group: its partials live in `workspace`; *job = the reduction still owed
+static void wgrad3_add(W3Group& g, const void* in, int64_t n_in, const void* dout, const int32_t* nbr, int64_t n_out, int c_in, int c_out, float* dw,
+                       float* dbias, void* workspace, PtcWgradJob* job) {
+  int splits, cps;
+  ptc_wgrad3_plan(n_out, c_in, c_out, &splits, &cps);
+  const int64_t count = (int64_t)c_out * c_in;
+  float* partial = (float*)workspace;
+  float* bias_partial = dbias ? (float*)((char*)workspace + ptc_align_up((size_t)splits * (size_t)count * sizeof(float), 256)) : nullptr;
+  const int tiles_i = c_in / 128, tiles = tiles_i * (c_out / 128);
+  const int q = g.n++;
+  g.p[q] = W3Problem{in, dout, nbr, n_out, c_in, c_out, partial, bias_partial, splits, cps, tiles, tiles_i, (uint32_t)((uint64_t)n_in * c_in * 2),
+                     (uint32_t)((uint64_t)n_out * c_out * 2)};
+  g.start[q + 1] = g.start[q] + splits * tiles;
+  for (int k = q + 2; k <= W3_MAX; ++k) g.start[k] = g.start[q + 1];
+  *job = PtcWgradJob{partial, splits, count, dw, bias_partial, (int64_t)c_out, dbias};
+}
+
 // the grouped launch: calls[i] that are wgrad2-eligible and planned on the (4, 4, 1) instance share one launch of wgrad2_group_kernel
 template <typename T>
 static int launch_wgrad2_group(const PtcWgradCall* const* cs, int m, PtcWgradJob* const* jobs, hipStream_t s) {
@@ -746,10 +804,20 @@ int ptc_spconv_wgrad_group(const PtcWgradCall* calls, int n, PtcWgradJob* jobs, 
   const PtcWgradCall* grp[W2_GROUP_MAX];
   PtcWgradJob* gj[W2_GROUP_MAX];
   int m = 0, gdtype = -1;
+  W3Group g3;
+  g3.n = 0;
+  for (int k = 0; k <= W3_MAX; ++k) g3.start[k] = 0;
+  int g3dtype = -1;
   for (int i = 0; i < n; ++i) {
     const PtcWgradCall& c = calls[i];
     jobs[i] = PtcWgradJob{nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
     bool grouped = false;
+    if (g3.n < W3_MAX && (g3dtype < 0 || g3dtype == c.dtype) &&
+        wgrad3_eligible(c.in, c.n_in, c.dout, c.nbr, c.n_out, c.kv, c.c_in, c.c_out, c.dtype, c.dw, c.workspace, c.workspace_bytes)) {
+      wgrad3_add(g3, c.in, c.n_in, c.dout, c.nbr, c.n_out, c.c_in, c.c_out, c.dw, c.dbias, c.workspace, &jobs[i]);
+      g3dtype = c.dtype;
+      continue;
+    }
     if (c.n_out > 0 && c.in && c.dout && c.dw && c.workspace && (c.dtype == PTC_BF16 || c.dtype == PTC_F16) && (c.nbr || (c.kv == 1 && c.n_in >= c.n_out)) &&
         c.c_in % 8 == 0 && c.c_out % 8 == 0 && (uint64_t)c.n_in * c.c_in * 2 <= PTC_BUF_MAX_BYTES && (uint64_t)c.n_out * c.c_out * 2 <= PTC_BUF_MAX_BYTES &&
         c.workspace_bytes >= ptc_spconv_wgrad_workspace_bytes(c.n_out, c.kv, c.c_in, c.c_out)) {
@@ -764,6 +832,10 @@ int ptc_spconv_wgrad_group(const PtcWgradCall* calls, int n, PtcWgradJob* jobs, 
                                        stream, &jobs[i]);
       if (rc != PTC_OK) return rc;
     }
+  }
+  if (g3.n > 0) {
+    const int rc = ptc_wgrad3_launch(g3dtype, g3, (hipStream_t)stream);
+    if (rc != PTC_OK) return rc;
   }
   if (m == 1) {
     const PtcWgradCall& c = *grp[0];
@@ -843,6 +915,17 @@ static int spconv_wgrad_impl(const void* in, int64_t n_in, const void* dout, con
   PTC_REQUIRE(nbr || (kv == 1 && n_in >= n_out), PTC_EINVAL, "ptc_spconv_wgrad: nbr may be NULL only for kv == 1 (identity table)");
   // wgrad2 gathers through raw buffer loads (< 2 GiB operands); larger ones take the v1 kernel
   const bool buf_ok = (uint64_t)n_in * c_in * 2 <= PTC_BUF_MAX_BYTES && (uint64_t)n_out * c_out * 2 <= PTC_BUF_MAX_BYTES;
+  if (wgrad3_eligible(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dtype, dw, workspace, workspace_bytes)) {
+    W3Group g3;
+    g3.n = 0;
+    for (int k = 0; k <= W3_MAX; ++k) g3.start[k] = 0;
+    PtcWgradJob job;
+    wgrad3_add(g3, in, n_in, dout, nbr, n_out, c_in, c_out, dw, dbias, workspace, &job);
+    const int rc = ptc_wgrad3_launch(dtype, g3, s);
+    if (rc != PTC_OK) return rc;
+    if (defer) { *defer = job; return PTC_OK; }
+    return launch_wgrad_reduce(job.partial, job.splits, job.count, dw, job.bias_partial, c_out, dbias, s);
+  }
   if (dtype == PTC_BF16 && buf_ok) return launch_wgrad2<bf16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s, defer);
   if (dtype == PTC_F16 && buf_ok) return launch_wgrad2<f16_t>(in, n_in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s, defer);
   PTC_DISPATCH_DTYPE(dtype, T, return launch_wgrad<T>(in, dout, nbr, n_out, kv, c_in, c_out, dw, dbias, workspace, s));
