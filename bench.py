@@ -21,6 +21,8 @@ Prints ONE JSON line on rank 0 (contract of the driver) carrying
   roofline        : the dominant kernel (serialized attention forward at the dec0/enc0 shapes),
                     timed live with HIP events on the launch stream
   roofline_gather : the gather-table convolution (CPE conv 64->64 at stage 0), HBM-bound by SURVEY 8(d)
+  roofline_gemm   : the Linear layers of a stage-3 Block (256 channels, ~20000 rows: qkv, fc1 + GELU, fc2 and the five weight gradients),
+                    MFMA-bound by SURVEY 8(d): gemm3.h / wgrad3.h against the bf16 matrix peak
   secondary       : BASELINE configs[1] (SpUNet-v1m1, 8 x 100000 voxels) measured in the same process
   cpu_baseline    : the CPU oracle (oracle/ptv3_model.py, port of the reference model) timed on this
                     box's host cores on a bounded sample (rank 0, N=1 only)
@@ -269,6 +271,38 @@ def gather_roofline(device, batch):
         out["traffic_source"] = os.path.relpath(pm, ROOT)
     except Exception:
         pass
+    return out
+
+
+def gemm_roofline(device, rows: int = 20000, c: int = 256):
+    """The dense GEMMs of a deep-stage Block (ptv3m1:173-248 at 256 channels; N = the ~20000 voxels stage 3 holds at the bench shape): forward
+    qkv (c -> 3c), fc1 with its GELU epilogue (c -> 4c), fc2 (4c -> c) on gemm3.h and the weight gradient of fc1 on wgrad3.h.  MFMA-bound by
+    SURVEY 8(d): useful flops = 2 N c_in c_out; achieved = flops / launch time (HIP events on the launch stream)."""
+    from pointcept_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(rows, c, generator=g).to(torch.bfloat16).to(device)
+    h = torch.randn(rows, 4 * c, generator=g).to(torch.bfloat16).to(device)
+    out = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "rows": rows, "kernels": {}}
+
+    def line(name, fn, cin, cout):
+        ms = _time_launches(fn, iters=20, warm=5)
+        fl = 2.0 * rows * cin * cout
+        out["kernels"][name] = {"launch_ms": round(ms, 4), "achieved": round(fl / (ms * 1e-3) / 1e12, 1),
+                                "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": fl}
+
+    w_qkv = (torch.randn(3 * c, 1, c, generator=g) * 0.05).to(torch.bfloat16).to(device)
+    b_qkv = torch.zeros(3 * c, device=device)
+    line("gemm3 qkv %d->%d" % (c, 3 * c), lambda: ops.spconv_fwd(x, w_qkv, b_qkv, None), c, 3 * c)
+    w1 = (torch.randn(4 * c, c, generator=g) * 0.05).to(torch.bfloat16).to(device)
+    b1 = torch.zeros(4 * c, device=device)
+    line("gemm3 fc1+GELU %d->%d" % (c, 4 * c), lambda: ops.linear_gelu_fwd(x, w1, b1), c, 4 * c)
+    w2 = (torch.randn(c, 1, 4 * c, generator=g) * 0.03).to(torch.bfloat16).to(device)
+    b2 = torch.zeros(c, device=device)
+    line("gemm3 fc2 %d->%d" % (4 * c, c), lambda: ops.spconv_fwd(h, w2, b2, None), 4 * c, c)
+    line("wgrad3 fc1 %d->%d (+ the reduction of its partials)" % (c, 4 * c), lambda: ops.spconv_wgrad(x, h, None, want_bias=True), c, 4 * c)
+    k = out["kernels"]["gemm3 qkv %d->%d" % (c, 3 * c)]
+    out.update(kernel="gemm3_kernel (qkv of a 256-channel Block)", achieved=k["achieved"], frac=k["frac"], launch_ms=k["launch_ms"], traffic=None)
     return out
 
 
@@ -575,6 +609,10 @@ def main():
                     out["roofline_gather"] = gather_roofline(device, batch)
                 except Exception as e:
                     out["roofline_gather"] = {"error": repr(e)}
+                try:
+                    out["roofline_gemm"] = gemm_roofline(device)
+                except Exception as e:
+                    out["roofline_gemm"] = {"error": repr(e)}
         if not args.stub and args.model == "ptv3" and world == 1 and not args.no_secondary:
             try:
                 del step, step_model, model, opt, batch

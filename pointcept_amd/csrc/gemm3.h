@@ -62,7 +62,7 @@ __device__ __forceinline__ int g3_off(int row, int p) { return row * (G3_BK * 2)
 // = 0.48 PF/s).  Now a workgroup walks ITS tiles as one flat chunk sequence: the loads of the next tile's first chunk, its table entries
 // (one segment ahead) and its bias go out while the current tile is still being multiplied and stored.
 template <typename T, int EPI, int RS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(256) PTC_WAVES_PER_EU(2, 2)
 gemm3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias, const int32_t* __restrict__ nbr, int64_t n_out,
              int kv, int c_in, int c_out, T* __restrict__ out, const T* __restrict__ aux_in, T* __restrict__ aux_out, uint32_t in_bytes,
              int n_col_tiles, int n_tiles) {

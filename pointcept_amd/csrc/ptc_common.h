@@ -149,6 +149,14 @@ __device__ __forceinline__ float ptc_gelu_grad(float z) {       // Phi(z) + z ph
 #endif
 }
 
+// exactly N waves per SIMD as the register budget of a kernel (launch_bounds' second argument is only a lower bound: the compiler then
+// aimed at three waves for gemm3.h / wgrad3.h and spilled their prefetch registers); nothing on the host emulation
+#ifdef __HIPCC__
+#define PTC_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#else
+#define PTC_WAVES_PER_EU(lo, hi)
+#endif
+
 // ---- library-internal entry points shared by translation units (C++ linkage: not part of include/ptcore.h) ----------------------------
 // ptc_sort_keys (scan_sort.hip) that also returns the key words in sorted order; see there.
 int ptc_sort_keys_ex(const int64_t* keys, int64_t n, int k, int begin_bit, int end_bit, int64_t* order, int64_t* inverse,

@@ -40,7 +40,7 @@ int ptc_wgrad3_launch(int dtype, const W3Group& g, hipStream_t s);
 #define W3_LDS_BYTES (2 * W3_STAGE)
 
 template <typename T>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(256) PTC_WAVES_PER_EU(2, 2)
 wgrad3_kernel(W3Group g) {
   using M = Mma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

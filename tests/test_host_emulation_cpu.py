@@ -204,7 +204,9 @@ EMULATED_GPU_TESTS = [
     ("test_pointops_edge_operators", dict(c=8, w_c=4)), ("test_pointops_edge_operators", dict(c=3, w_c=1)), ("test_pointops_edge_operators", dict(c=6, w_c=2)),
     ("test_pair_list_attention_steps_and_their_gradients", dict(c=12)), ("test_pair_list_attention_steps_and_their_gradients", dict(c=5)),
     # MFMA kernels: implicit-GEMM convolution / Linear (16x16x32 bf16 / f16, 16x16x4 f32) and window attention (32x32x16 bf16)
-    ("test_linear_gather_tables", dict(dtype=torch.bfloat16)),
+    ("test_linear_gather_tables", dict(dtype=torch.bfloat16, cin=32, cout=96)),
+    ("test_linear_gather_tables", dict(dtype=torch.bfloat16, cin=128, cout=384)),      # gemm3.h (gathered rows, kv = 2) and wgrad3.h on the emulation
+    ("test_linear_identity_table", dict(dtype=torch.bfloat16, n=333, cin=256, cout=128)),
     ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.bfloat16, cin=64, cout=64)),
     ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.float16, cin=128, cout=32)),
     ("test_linear_with_the_residual_joint_in_its_epilogue", dict(dtype=torch.bfloat16, cin=128, cout=128)),

@@ -78,6 +78,18 @@ for sec in "$@"; do
           cd $R; python tools/pmc_summary.py --stats $O/${TAG}_roof_stats --pmc $O/${TAG}_roof_fetch $O/${TAG}_roof_write $O/${TAG}_roof_sq $O/${TAG}_roof_sq2 \
             --kernels attn_fwd_kernel,attn_bwd_dq_kernel,attn_bwd_dkv_kernel,attn_bwd1_kernel --out $O/${TAG}_roof_pmc.json > $O/${TAG}_roof_pmc.log 2>&1
           rm -rf $O/${TAG}_roof_stats $O/${TAG}_roof_fetch $O/${TAG}_roof_write $O/${TAG}_roof_sq $O/${TAG}_roof_sq2; tail -3 $O/${TAG}_roof_sq2.log;;
+    gemmpmc) cd /tmp
+          for cs in qkv fc2 wgrad; do
+            export PTC_GK_CASE=$cs
+            timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_gk_${cs}_stats -- python $R/tools/gemm_kernels.py > $O/${TAG}_gk_${cs}_stats.log 2>&1
+            timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_gk_${cs}_fetch -- python $R/tools/gemm_kernels.py > $O/${TAG}_gk_${cs}_fetch.log 2>&1
+            timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_gk_${cs}_write -- python $R/tools/gemm_kernels.py > $O/${TAG}_gk_${cs}_write.log 2>&1
+            timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $O/${TAG}_gk_${cs}_sq -- python $R/tools/gemm_kernels.py > $O/${TAG}_gk_${cs}_sq.log 2>&1
+            timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS -d $O/${TAG}_gk_${cs}_sq2 -- python $R/tools/gemm_kernels.py > $O/${TAG}_gk_${cs}_sq2.log 2>&1
+            cd $R; python tools/pmc_summary.py --stats $O/${TAG}_gk_${cs}_stats --pmc $O/${TAG}_gk_${cs}_fetch $O/${TAG}_gk_${cs}_write $O/${TAG}_gk_${cs}_sq $O/${TAG}_gk_${cs}_sq2 \
+              --kernels gemm3_kernel,wgrad3_kernel,wgrad_reduce_kernel --out $O/${TAG}_gemm_pmc_${cs}.json > $O/${TAG}_gemm_pmc_${cs}.log 2>&1
+            cd /tmp; rm -rf $O/${TAG}_gk_${cs}_stats $O/${TAG}_gk_${cs}_fetch $O/${TAG}_gk_${cs}_write $O/${TAG}_gk_${cs}_sq $O/${TAG}_gk_${cs}_sq2
+          done; cd $R; cat $O/${TAG}_gemm_pmc_qkv.json | head -60;;
     convpmc) cd /tmp
           rocprofv3 -L > $O/${TAG}_counters_list.txt 2>&1
           for cs in s0 s1; do
