@@ -90,6 +90,8 @@ for sec in "$@"; do
               --kernels gemm3_kernel,wgrad3_kernel,wgrad_reduce_kernel --out $O/${TAG}_gemm_pmc_${cs}.json > $O/${TAG}_gemm_pmc_${cs}.log 2>&1
             cd /tmp; rm -rf $O/${TAG}_gk_${cs}_stats $O/${TAG}_gk_${cs}_fetch $O/${TAG}_gk_${cs}_write $O/${TAG}_gk_${cs}_sq $O/${TAG}_gk_${cs}_sq2
           done; cd $R; cat $O/${TAG}_gemm_pmc_qkv.json | head -60;;
+    gemmt:*) for v in $(echo "${sec#gemmt:}" | tr ',' ' '); do [ "$v" = default ] && export PTC_LIB_VARIANT= || export PTC_LIB_VARIANT=$v
+            timeout 300 python tools/gemm_time.py 2>&1 | grep -v amdgpu.ids; done > $O/${TAG}_gemm_time.txt; export PTC_LIB_VARIANT=; cat $O/${TAG}_gemm_time.txt;;
     convpmc) cd /tmp
           rocprofv3 -L > $O/${TAG}_counters_list.txt 2>&1
           for cs in s0 s1; do
