@@ -34,6 +34,9 @@ bool ptc_gemm3_supported(int dtype, int kv, int c_in, int c_out);
 
 #define G3_BN 128
 #define G3_BK 64
+#ifndef G3_STAGGER
+#define G3_STAGGER 0     // > 0 (library variant d_G3_STAGGER_n, timing A/B): the second half of an XCD's workgroups -- the second workgroup of every CU --
+#endif                   // sleeps n x 64 cycles before its first chunk, so that the two workgroups of a CU do not run their phases in lockstep
 
 // weight row permutation of a 64-column wave block (the 4-tile group of spconv.hip's TileGroups): MFMA tile tt, A-row 4 gq + e holds channel
 // 16 gq + 4 tt + e, so that lane (row r, group g) ends up with the 16 CONSECUTIVE channels 16 g .. 16 g + 15 of its row
@@ -80,6 +83,7 @@ gemm3_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __r
   const int PX = (int)gridDim.x >> 3, px = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
   const int tx0 = (int)((int64_t)n_tiles * xcd / 8), tx1 = (int)((int64_t)n_tiles * (xcd + 1) / 8);
   if (tx0 + px >= tx1) return;
+  if (G3_STAGGER > 0 && px >= PX / 2) __builtin_amdgcn_s_sleep(G3_STAGGER);
   const int n_my = (tx1 - tx0 - px + PX - 1) / PX;
   const int cpk = c_in / G3_BK, cpt = kv * cpk, total = n_my * cpt;
 

@@ -707,6 +707,9 @@ def test_spconv_down_up_tables(cuda):
                                         (900, 2048, 512), (2500, 64, 20), (4100, 6, 32), (2821, 512, 1536), (12115, 1024, 256),
                                         (50360, 512, 128), (2821, 512, 512), (70000, 256, 1024),
                                         (16500, 512, 512),     # 65 x 4 wide (128-column) workgroups: conv3's NTILES = 8 instance, forward and dgrad
+                                        # round 6: gemm3.h / wgrad3.h at their edges -- one row, less than a chunk, one row beyond a tile, a ragged last
+                                        # 64-row chunk with several splits, the tall-tile form (>= 512 tiles of 128 rows)
+                                        (1, 256, 128), (63, 128, 128), (129, 512, 256), (4133, 128, 384), (33000, 256, 2048),
                                         # round 5: contractions that are no multiple of 128 (general chunking of the identity-table kernel, operands
                                         # padded to 32): the MLP / qkv shapes of LitePT (36 .. 504), PT-v3m3 (54 .. 576) and PT-v3m2 (48 .. 384)
                                         (3000, 72, 288), (3000, 288, 72), (2000, 144, 576), (2000, 576, 144), (1500, 252, 1008), (1500, 1008, 252),
@@ -1696,7 +1699,7 @@ def test_column_sum(cuda, dtype, n, c):
     assert got.dtype == torch.float32
 
 
-@pytest.mark.parametrize("n,c", [(5000, 32), (4097, 64), (1000, 128), (333, 256)])
+@pytest.mark.parametrize("n,c", [(5000, 32), (4097, 64), (1000, 128), (333, 256), (2111, 512)])    # (512: gemm3.h's GELU epilogues, round 6)
 def test_mlp_gelu_fused(cuda, n, c):
     """fc1 -> GELU -> fc2 with GELU / GELU' fused into the GEMM epilogues vs torch fp32 on the same rounded
     operands (bf16 autocast): output, input gradient, all four parameter gradients."""

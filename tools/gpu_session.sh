@@ -55,6 +55,9 @@ for sec in "$@"; do
           python tools/kernel_neighbours.py $O/${TAG}_prof > $O/${TAG}_fill_copy_neighbours.txt 2>&1; rm -rf $O/${TAG}_prof $O/${TAG}_prof7; tail -1 $O/${TAG}_kernel_stats.csv;;
     timeline) cd /tmp; timeout 900 rocprofv3 --kernel-trace -d $O/${TAG}_tl -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-fp16-recipe > $O/${TAG}_tl.log 2>&1
           cd $R; PTC_TIMELINE_SEQ=$O/${TAG}_step_sequence.txt python tools/step_timeline.py $O/${TAG}_tl > $O/${TAG}_step_timeline.txt 2>&1; rm -rf $O/${TAG}_tl; head -12 $O/${TAG}_step_timeline.txt;;
+    timelinev:*) v=${sec#timelinev:}; cd /tmp; PTC_LIB_VARIANT=$v timeout 900 rocprofv3 --kernel-trace -d $O/${TAG}_tl_$v -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-fp16-recipe > $O/${TAG}_tl_$v.log 2>&1
+          cd $R; PTC_TIMELINE_SEQ=$O/${TAG}_step_sequence_$v.txt python tools/step_timeline.py $O/${TAG}_tl_$v > $O/${TAG}_step_timeline_$v.txt 2>&1; rm -rf $O/${TAG}_tl_$v; head -2 $O/${TAG}_step_timeline_$v.txt
+          awk '/gemm3/{n++; t+=$4} END{print "gemm3 launches", n, "us per step", t}' $O/${TAG}_step_sequence_$v.txt;;
     profoutdoor) cd /tmp; BA="--model ptv3-outdoor --no-cpu-baseline --no-secondary --no-fp16-recipe --warmup 1"
           timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profo2 -- python $R/bench.py --steps 2 $BA > $O/${TAG}_profo2.log 2>&1
           timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profo5 -- python $R/bench.py --steps 5 $BA > $O/${TAG}_profo5.log 2>&1

@@ -40,7 +40,7 @@ def load(d, counter):
     return acc
 
 
-FAMILIES = [("attention", ("attn_",)), ("linear (fwd / dgrad GEMMs, incl. the GEMMs with a residual joint in their epilogue)", ("linear2_kernel", "linear2_joint_kernel", "conv3_kernel", "conv2_kernel", "mlp_fwd_kernel", "mlp_bwd_kernel")),
+FAMILIES = [("attention", ("attn_",)), ("linear (fwd / dgrad GEMMs, incl. the GEMMs with a residual joint in their epilogue)", ("linear2_kernel", "linear2_joint_kernel", "conv3_kernel", "conv2_kernel", "mlp_fwd_kernel", "mlp_bwd_kernel", "gemm3_kernel")),
             ("gather convolution fwd / dgrad", ("conv7_kernel", "conv5_kernel")),
             ("weight gradients + reductions", ("wgrad", )), ("residual joints + LayerNorm", ("add_norm", "layer_norm")),
             ("BatchNorm", ("batch_norm", "bn_")), ("keys / sorts / maps / rulebooks", ("serialize", "rs_", "radix", "rulebook", "hash_", "pad_maps", "pool_", "scan", "coord_max", "maps")),
