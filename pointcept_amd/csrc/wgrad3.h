@@ -19,6 +19,11 @@
 #include "ptc_common.h"
 
 #define W3_MAX 8
+// workgroups per weight the split-K plan aims at (library variants d_W3_TARGET_n).  96 | 192 | 384: wgrad3 903 | 903 | 912 us per step, the
+// reduction of its partials 406 | 499 | 540 us (profiles/r06_bd_wgrad3_split_target.txt): the kernel does not care, the reduction does
+#ifndef W3_TARGET
+#define W3_TARGET 96
+#endif
 struct W3Problem {
   const void* in; const void* dout; const int32_t* nbr; int64_t n_out; int c_in, c_out;
   float* partial; float* bias_partial;       // [splits][c_out][c_in], [splits][c_out] (bias_partial may be null)
@@ -199,7 +204,7 @@ bool ptc_wgrad3_supported(int dtype, int kv, int c_in, int c_out, int64_t n_out)
 void ptc_wgrad3_plan(int64_t n_out, int c_in, int c_out, int* splits, int* cps) {
   const int64_t n_chunks = (n_out + 63) >> 6;
   const int tiles = (c_in / 128) * (c_out / 128);
-  int64_t s = (192 + tiles - 1) / tiles;           // ~192 workgroups per weight
+  int64_t s = (W3_TARGET + tiles - 1) / tiles;     // ~W3_TARGET workgroups per weight
   if (s > 64) s = 64;
   const int64_t max_s = (n_chunks + 3) / 4;        // at least 4 chunks per split
   if (s > max_s) s = max_s;

@@ -57,7 +57,7 @@ for sec in "$@"; do
           cd $R; PTC_TIMELINE_SEQ=$O/${TAG}_step_sequence.txt python tools/step_timeline.py $O/${TAG}_tl > $O/${TAG}_step_timeline.txt 2>&1; rm -rf $O/${TAG}_tl; head -12 $O/${TAG}_step_timeline.txt;;
     timelinev:*) v=${sec#timelinev:}; cd /tmp; PTC_LIB_VARIANT=$v timeout 900 rocprofv3 --kernel-trace -d $O/${TAG}_tl_$v -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-fp16-recipe > $O/${TAG}_tl_$v.log 2>&1
           cd $R; PTC_TIMELINE_SEQ=$O/${TAG}_step_sequence_$v.txt python tools/step_timeline.py $O/${TAG}_tl_$v > $O/${TAG}_step_timeline_$v.txt 2>&1; rm -rf $O/${TAG}_tl_$v; head -2 $O/${TAG}_step_timeline_$v.txt
-          awk '/gemm3/{n++; t+=$4} END{print "gemm3 launches", n, "us per step", t}' $O/${TAG}_step_sequence_$v.txt;;
+          awk '/gemm3/{n++; t+=$4} /wgrad3/{m++; u+=$4} /wgrad_reduce_multi/{k++; w+=$4} END{print "gemm3 launches", n, "us per step", t, "| wgrad3", m, u, "| wgrad_reduce_multi", k, w}' $O/${TAG}_step_sequence_$v.txt;;
     profoutdoor) cd /tmp; BA="--model ptv3-outdoor --no-cpu-baseline --no-secondary --no-fp16-recipe --warmup 1"
           timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profo2 -- python $R/bench.py --steps 2 $BA > $O/${TAG}_profo2.log 2>&1
           timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_profo5 -- python $R/bench.py --steps 5 $BA > $O/${TAG}_profo5.log 2>&1
