@@ -205,6 +205,8 @@ void ptc_wgrad3_plan(int64_t n_out, int c_in, int c_out, int* splits, int* cps) 
   const int64_t n_chunks = (n_out + 63) >> 6;
   const int tiles = (c_in / 128) * (c_out / 128);
   int64_t s = (W3_TARGET + tiles - 1) / tiles;     // ~W3_TARGET workgroups per weight
+  const int64_t min_s = (n_chunks + 127) / 128;    // ... and no workgroup walks more than 128 chunks (8192 rows): at 200 000+ rows (the outdoor
+  if (s < min_s) s = min_s;                        // configuration's deep stages) the target alone left 96 workgroups on 512 slots
   if (s > 64) s = 64;
   const int64_t max_s = (n_chunks + 3) / 4;        // at least 4 chunks per split
   if (s > max_s) s = max_s;

@@ -14,7 +14,8 @@ from pointcept_amd import ops  # noqa: E402
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(0)
 print("variant", os.environ.get("PTC_LIB_VARIANT", "") or "default", "PTC_GEMM3", os.environ.get("PTC_GEMM3", "1"))
-for rows, c in ((68000, 128), (20000, 256), (5500, 512)):
+shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ.get("PTC_GT_SHAPES", "68000x128,20000x256,5500x512").split(",")]
+for rows, c in shapes:
     x = torch.randn(rows, c, generator=g).to(torch.bfloat16).to(dev)
     h = torch.randn(rows, 4 * c, generator=g).to(torch.bfloat16).to(dev)
     for name, cin, cout, inp in (("proj", c, c, x), ("qkv", c, 3 * c, x), ("fc2", 4 * c, c, h)):
